@@ -1,0 +1,63 @@
+# Top-level build.  Everything is built in-tree (build/ and *.so are git-ignored but travel with gpurun).
+#
+#   make            product: libpagraph_hip.so (HIP kernels + C ABI, gfx950) and the `pagraph` executable
+#   make harness    test-only programs under tests/harness/ (these link the ORACLE; never shipped)
+#   make oracle     oracle/libpag_oracle.so (+ oracle/_ref/* when /root/reference is present)
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+CC       ?= gcc
+ARCH     ?= gfx950
+CXXFLAGS := -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude -Ialigngraph2_amd/csrc/host
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall
+
+HOST_DIR := aligngraph2_amd/csrc/host
+HIP_DIR  := aligngraph2_amd/csrc/hip
+B        := build
+
+HOST_SRCS := $(wildcard $(HOST_DIR)/*.cpp)
+HOST_LIB_SRCS := $(filter-out $(HOST_DIR)/pagraph_main.cpp,$(HOST_SRCS))
+HOST_OBJS := $(patsubst $(HOST_DIR)/%.cpp,$(B)/host/%.o,$(HOST_LIB_SRCS))
+HIP_SRCS  := $(wildcard $(HIP_DIR)/*.hip)
+HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pagraph_hip.h
+
+.PHONY: all product harness oracle clean
+all: product harness oracle
+
+product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph
+
+$(B)/host/%.o: $(HOST_DIR)/%.cpp $(wildcard $(HOST_DIR)/*.hpp) include/pagraph_hip.h
+	@mkdir -p $(B)/host
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(B)/libpagh_host.a: $(HOST_OBJS)
+	ar rcs $@ $^
+
+aligngraph2_amd/libpagraph_hip.so: $(HIP_SRCS) $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+
+aligngraph2_amd/bin/pagraph: $(HOST_DIR)/pagraph_main.cpp $(B)/libpagh_host.a aligngraph2_amd/libpagraph_hip.so
+	@mkdir -p aligngraph2_amd/bin
+	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/libpagh_host.a -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/..' -pthread
+
+# ---- test-only -------------------------------------------------------------------------------
+oracle:
+	$(MAKE) -C oracle all
+
+$(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
+	@mkdir -p $(B)
+	$(CC) -O2 -std=c99 -Wall -Wextra -fPIC -Iinclude -c $< -o $@
+
+HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/pagraph_oracle
+harness: $(HARNESS)
+
+tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(B)/libpagh_host.a $(B)/pag_oracle.o
+	@mkdir -p tests/harness/bin
+	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(B)/libpagh_host.a $(B)/pag_oracle.o -lm
+
+tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(B)/libpagh_host.a $(B)/pag_oracle.o
+	@mkdir -p tests/harness/bin
+	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(B)/libpagh_host.a $(B)/pag_oracle.o -lm -pthread
+
+clean:
+	rm -rf $(B) aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin tests/harness/bin
+	$(MAKE) -C oracle clean

@@ -1,0 +1,184 @@
+/* include/pagraph_hip.h — C ABI of the MI355X-native PAGraph hot path (libpagraph_hip.so).
+ *
+ * The reference (Godotcoffee/AlignGraph2, PAGraph/) has no library/FFI boundary for this path: the
+ * boundary its caller sees is the `pagraph` process (AlignGraph2.py:414-427).  This header is the thin
+ * C ABI *inside* our drop-in `pagraph` executable, between the host C++ (file parsing, alignment
+ * bookkeeping, traversal control, FASTA writers) and the hand-written HIP kernels.  Its entry points
+ * mirror the public surface of the reference's graph class that PositionProcessor / PAlgorithm call
+ * (PAGraph/src/tools/graph/PABruijnGraph.hpp:90-131); each one cites what it replaces.
+ *
+ * Conventions: opaque handle owned by the caller; int return (0 = ok, negative = PAG_E*); plain
+ * pointers and sizes only; no exceptions cross the ABI; one HIP stream per handle; a handle is not
+ * thread-safe.  Every input array may live in host memory or already in device memory (HBM) —
+ * `pag_build_input.on_device` says which; device-resident inputs are used in place, never copied.
+ * There is NO CPU fallback: every entry point fails with PAG_ENODEV when no gfx950 device is usable.
+ */
+#ifndef PAGRAPH_HIP_H
+#define PAGRAPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAG_OK 0
+#define PAG_EINVAL (-22)  /* bad argument / unsupported parameter (k > 16, outer_sample > 7, ...) */
+#define PAG_ENOMEM (-12)  /* device or host allocation failed */
+#define PAG_ENODEV (-19)  /* no usable HIP device */
+#define PAG_ERANGE (-34)  /* caller buffer too small; required sizes are reported */
+#define PAG_EFAULT (-14)  /* a HIP runtime call or kernel failed; see pag_last_error() */
+
+#define PAG_NONE 0xFFFFFFFFu
+
+/* ---- sequences -------------------------------------------------------------------------------
+ * 2-bit packed exactly like the reference's CompressedSeq (PAGraph/src/tools/seq/CompressedSeq.cpp
+ * :8-38): A/other = 0, C = 1, G = 2, T = 3; base i of a sequence sits at bits 2*(i&3) of byte i>>2.
+ * Every sequence starts on a 4-byte boundary of `packed`, and `packed` is padded with >= 16 readable
+ * bytes after the last sequence. */
+typedef struct pag_seqs {
+    uint64_t n_seqs;
+    const uint64_t *byte_off; /* [n_seqs] byte offset of each sequence in packed (multiple of 4) */
+    const uint32_t *len;      /* [n_seqs] length in bases */
+    const uint8_t *packed;
+    uint64_t packed_bytes;
+} pag_seqs;
+
+/* ---- alignments ------------------------------------------------------------------------------
+ * One record of a 3-line ALN file (reference AlignmentHelper.cpp:11-48) after the bookkeeping the
+ * reference does per alignment at the top of its two hot loops (Aligner.tcc:40-71 / :121-152):
+ * static eligibility, strand choice, coordinate flips.  The alignment columns are kept as the two
+ * "diff" bit-vectors of ParseAlignTools::parseDiff (ParseAlignTools.cpp:8-26), 2 bits per column,
+ * 16 columns per 32-bit word, column c at bits 2*(c&15): bit0 = queryDiff, bit1 = refDiff.
+ *   00 / 11  both advance, query base is emitted        (exactAlign, ParseAlignTools.tcc:58-61)
+ *   01       (queryDiff only) target advances            (:63-64)
+ *   10       (refDiff only)  query base emitted, query advances (:65-67) */
+typedef struct pag_aln {
+    uint32_t query;    /* index of the read in `reads`, PAG_NONE if the name is unknown */
+    uint32_t target;   /* contig index (pass 1) / reference index (pass 2), PAG_NONE if unknown */
+    uint32_t t_begin;  /* header target interval (used by the coverage filter, Aligner.tcc:140-147) */
+    uint32_t t_end;
+    uint32_t q_start;  /* read-strand coordinate of the first emitted base (after flipPosition);
+                          PAG_NONE when it lies outside the read (then n_valid == 0) */
+    uint32_t t_start;  /* target-strand coordinate the walk starts from (after flipPosition) */
+    uint32_t n_cols;   /* alignment columns */
+    uint32_t n_valid;  /* leading emitted columns (walk order) whose per-base list is non-empty */
+    uint64_t diff_off; /* index of the first 32-bit diff word of this alignment in pag_aln_db.diff */
+    uint32_t flags;    /* PAG_ALN_* */
+    uint32_t reserved;
+} pag_aln;
+
+#define PAG_ALN_REV_STRAND 1u /* positions go to the read's reverse-complement strand */
+#define PAG_ALN_WALK_BACK 2u  /* exactAlign(forward = false): columns are walked last -> first */
+#define PAG_ALN_ELIGIBLE 4u   /* passed the static filters (selected target, ratio, range) */
+
+typedef struct pag_aln_db {
+    uint64_t n_aln;
+    const pag_aln *aln;        /* grouped by query, inside a group in the reference's list order
+                                  (score-descending std::sort order, Aligner.cpp:53-55); records with
+                                  query == PAG_NONE come last */
+    const uint64_t *query_off; /* [n_reads + 1] range of each read's records in aln */
+    const uint32_t *diff;
+    uint64_t n_diff_words;
+} pag_aln_db;
+
+/* contig table for pass 1.  single_base already contains the strand offset of the selected
+ * orientation: ctgSingle = single_base + ctgPos (PositionMapper::dualToSingle, PositionMapper.cpp
+ * :37-42, truncated to u32 as in PositionProcessor.cpp:48-51). */
+typedef struct pag_ctg {
+    uint32_t len;
+    uint32_t selected; /* Aligner::_ctgFilterFlag */
+    uint32_t single_base;
+    uint32_t reserved;
+    uint64_t map_off; /* index of base 0 of this contig in ctg_ent_off (selected contigs only) */
+} pag_ctg;
+
+typedef struct pag_ref {
+    uint32_t len;
+    uint32_t accepted;    /* Aligner::_refFilterFlag */
+    uint32_t single_base; /* refSingle = single_base + refPos */
+    uint32_t reserved;
+} pag_ref;
+
+typedef struct pag_build_input {
+    uint32_t on_device; /* 0: every pointer below is host memory; 1: every pointer is device memory */
+    uint32_t n_threads; /* the reference's -t (only recorded; emission order comes from emit_order) */
+    pag_seqs reads;
+    const uint32_t *emit_order; /* [n_reads] read indices in canonical emission order */
+    pag_aln_db read_to_ctg;     /* pass 1 */
+    pag_aln_db read_to_ref;     /* pass 2 */
+    uint64_t n_ctgs;
+    const pag_ctg *ctgs;
+    /* per selected-contig base: list of refSingle coordinates = AlignReference::_fPositions /
+     * _rPositions after addExtraPosition (AlignReference.cpp:41-57, 69-79), already run through
+     * PositionMapper.  Entries of base b of contig c: ctg_ent[ctg_ent_off[m + b] .. ctg_ent_off[m + b + 1])
+     * with m = ctgs[c].map_off; each selected contig owns len + 1 consecutive offsets. */
+    const uint32_t *ctg_ent_off;
+    uint64_t n_ctg_ent_off;
+    const uint32_t *ctg_ent;
+    uint64_t n_ctg_ent;
+    uint64_t n_refs;
+    const pag_ref *refs;
+    uint32_t eps;          /* --epsilon: cluster radius (PositionProcessor.cpp:128) */
+    uint32_t cov_filter;   /* -v (Aligner.tcc:149) */
+    uint32_t outer_sample; /* 3 (pagraph.cpp:113); 1..7 supported */
+    int32_t topk_ctg;      /* -1 = all (pagraph.cpp:110) */
+    int32_t topk_ref;      /* -1 = all (pagraph.cpp:112) */
+    uint32_t reserved;
+} pag_build_input;
+
+/* the six numbers PositionProcessor::process prints (PositionProcessor.cpp:126-142) + sizes */
+typedef struct pag_build_stats {
+    uint64_t merge_edge[2];
+    uint64_t total_pos[2];
+    uint64_t merge_pos[2];
+    uint64_t n_tuples[2]; /* position tuples emitted by pass 1 / pass 2 */
+    uint64_t n_edges[2];  /* edge tuples emitted by pass 1 / pass 2 */
+    uint64_t n_nodes;     /* k-mer nodes with >= 1 position */
+    uint64_t n_pos;       /* vertices = clustered positions */
+    uint64_t n_uniq_edges;
+    double ms_extract, ms_sort, ms_cluster, ms_edges, ms_total; /* device time, HIP events */
+    double ms_sort_kernel; /* average duration of one launch of the dominant sort kernel */
+    uint64_t sort_records; /* records one such launch moves */
+} pag_build_stats;
+
+/* the finished graph, compact CSR, ascending k-mer code (types KMerAdjNode.hpp:19-23) */
+typedef struct pag_csr {
+    uint64_t n_nodes, n_pos, n_edges; /* in: capacities; out: sizes */
+    uint32_t *node_code;              /* [n_nodes] */
+    uint64_t *pos_off;                /* [n_nodes + 1] */
+    uint32_t *pos_ctg;                /* [n_pos] DualPos.first  */
+    uint32_t *pos_ref;                /* [n_pos] DualPos.second */
+    uint16_t *pos_cnt;                /* [n_pos] u16 abundance (wraps, PABruijnGraph.hpp:28) */
+    uint64_t *edge_off;               /* [n_nodes + 1] */
+    uint32_t *edge_to;                /* [n_edges] child k-mer code */
+    int32_t *edge_step;               /* [n_edges] */
+} pag_csr;
+
+typedef struct pag_graph pag_graph;
+
+/* PABruijnGraph::PABruijnGraph (PABruijnGraph.cpp:10-45): `codes` are ALL 64-bit words of the
+ * solid-set file after the first one, PLUS the first one (the header word k is ingested as a code,
+ * SURVEY quirk Q1) — the caller passes the file's words verbatim; sort+unique happens here.
+ * k <= 16.  Builds the 4^k-bit solid bitmap in HBM. */
+pag_graph *pag_create(const uint64_t *codes, uint64_t n_codes, uint32_t k, int device_ordinal, int *err);
+void pag_destroy(pag_graph *g);
+/* PABruijnGraph::availableKmerNumber (:371-373) */
+uint64_t pag_solid_count(const pag_graph *g);
+/* PABruijnGraph::resetAllNodes (:310-318) */
+int pag_reset(pag_graph *g);
+/* PositionProcessor::process (PositionProcessor.cpp:79-151): both extraction passes, mergeEdge,
+ * mergeKmerPosition, sortKmerPosition — as one device pipeline. */
+int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats);
+/* sizes of the finished graph, then the graph itself into caller buffers */
+int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);
+int pag_export_csr(const pag_graph *g, pag_csr *out);
+const char *pag_last_error(void);
+/* 1 if a gfx950 device is present and the code object loads */
+int pag_device_available(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGRAPH_HIP_H */

@@ -1,0 +1,48 @@
+/* oracle/pag_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the reference's graph build for the PAGraph hot path, taking the same
+ * flat input and producing the same flat output as the HIP library (include/pagraph_hip.h), so parity
+ * tests can hand both the same bytes and compare results bit for bit.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into this file.  It is
+ * never linked into the product (`pagraph`, libpagraph_hip.so).
+ *
+ * Pinning: oracle/pag_oracle.c is checked against the compiled reference itself — the complete graph
+ * dumped by oracle/_ref/graph_dump (the reference's own PositionProcessor / PABruijnGraph classes) on
+ * every fixture under tests/golden/, see tests/test_oracle_golden.py.
+ */
+#ifndef PAG_ORACLE_H
+#define PAG_ORACLE_H
+
+#include "pagraph_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pago_graph pago_graph;
+
+pago_graph *pago_create(const uint64_t *codes, uint64_t n_codes, uint32_t k);
+void pago_destroy(pago_graph *g);
+uint64_t pago_solid_count(const pago_graph *g);
+int pago_reset(pago_graph *g);
+int pago_process(pago_graph *g, const pag_build_input *in, pag_build_stats *stats);
+int pago_csr_sizes(const pago_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);
+int pago_export_csr(const pago_graph *g, pag_csr *out);
+
+/* function-level seams, exposed for known-answer tests */
+/* KmerHelper::kmer2Code (KmerHelper.cpp:7-25): writes len-k+1 codes, returns the count */
+uint64_t pago_kmer_codes(const char *seq, uint64_t len, uint32_t k, uint64_t *out);
+/* PABruijnGraph::isPosSimilar + the zero rule of mergeKmerPosition (PABruijnGraph.cpp:259-274, 379-383) */
+int pago_cluster_similar(uint32_t a_ctg, uint32_t a_ref, uint32_t b_ctg, uint32_t b_ref, uint64_t eps);
+/* PABruijnGraph::checkPosition (PABruijnGraph.cpp:143-165): 0 Oops 1 Skip 2 Good 3 Excellent 4 Amazing */
+int pago_check_position(uint32_t a_ctg, uint32_t a_ref, uint32_t b_ctg, uint32_t b_ref, uint32_t dist,
+                        uint32_t deviation, double error_rate);
+/* PABruijnGraph::isEdgeSimilar (:385-400): bit0 = contig side, bit1 = reference side */
+int pago_edge_similar(uint32_t a_ctg, uint32_t a_ref, uint32_t b_ctg, uint32_t b_ref, int dist, uint64_t deviation,
+                      double error_rate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
