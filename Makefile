@@ -8,7 +8,7 @@ CXX      ?= g++
 CC       ?= gcc
 ARCH     ?= gfx950
 CXXFLAGS := -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude -Ialigngraph2_amd/csrc/host
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall -Wno-unused-value
 
 HOST_DIR := aligngraph2_amd/csrc/host
 HIP_DIR  := aligngraph2_amd/csrc/hip
@@ -47,16 +47,16 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 	@mkdir -p $(B)
 	$(CC) -O2 -std=c99 -Wall -Wextra -fPIC -Iinclude -c $< -o $@
 
-HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/pagraph_oracle
+HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so
 harness: $(HARNESS)
 
 tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(B)/libpagh_host.a $(B)/pag_oracle.o
 	@mkdir -p tests/harness/bin
 	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(B)/libpagh_host.a $(B)/pag_oracle.o -lm
 
-tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(B)/libpagh_host.a $(B)/pag_oracle.o
+tests/harness/bin/libpagh_test.so: tests/harness/pagh_test.cpp $(B)/libpagh_host.a
 	@mkdir -p tests/harness/bin
-	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(B)/libpagh_host.a $(B)/pag_oracle.o -lm -pthread
+	$(CXX) $(CXXFLAGS) -shared -o $@ $< $(B)/libpagh_host.a
 
 clean:
 	rm -rf $(B) aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin tests/harness/bin

@@ -1,0 +1,462 @@
+// k1_extract.hip — K0/K1: alignment-column walk, k-mer extraction from 2-bit packed read strands,
+// solid-set test, greedy >= outer_sample sampling, and emission of position / edge tuples in the
+// canonical order.  One wavefront (= one 64-thread workgroup) owns one (read, strand) job; all
+// cross-lane work is wave shuffles/ballots, per-job scratch lives in 12.5 KB of LDS.
+//
+// Reference semantics reproduced here (paths under PAGraph/src/tools/):
+//   align/ParseAlignTools.tcc:44-70   exactAlign: column classes -> (read pos, target pos) pairs
+//   align/Aligner.tcc:73-96, 152-166  which read strand receives positions; per-base position lists
+//   align/Aligner.cpp:222-233         queryContig: one list entry per contig->ref entry of the base
+//   position/PositionProcessor.cpp:37-55  DualPos = (ctgSingle, refSingle), u32
+//   kmer/KmerHelper.cpp:7-25          rolling 2-bit code, first base most significant
+//   seq/CompressedSeq.cpp:56-74       reverse strand = complement read back to front
+//   graph/PABruijnGraph.tcc:5-26      sampleSequence: candidate = has position AND solid; keep the
+//                                     first, then every candidate >= outer_sample after the last kept
+//   graph/PABruijnGraph.cpp:238-257   addPositionAndEdge: all DualPos of a kept base, then one edge
+//                                     (prev kept k-mer -> this k-mer, step = index difference)
+//
+// Canonical order of the emitted streams: pass 1 then pass 2; inside a pass the reads
+// in emit_order; forward strand then reverse strand; samples ascending; per sample the list order
+// (alignment order x contig->ref entry order).  Offsets come from an exclusive scan over per-job counts
+// (count launch -> scan -> emit launch), so the streams are dense and need no atomics.
+#include "pag_device.hpp"
+
+namespace pagdev {
+
+constexpr int TILE = 1024;  // read positions per tile: 64 lanes x 16
+constexpr int CHUNK = 1024; // alignment columns per colidx chunk: 64 lanes x 16
+
+struct WaveLds {
+    uint32_t kept[64];   // per lane-slot: 16-bit mask of kept positions
+    uint32_t rank[64];   // per lane-slot: tile-local rank of its first kept sample
+    uint32_t scode[TILE]; // per tile-local sample: k-mer code
+    uint32_t scnt[TILE];  // per sample: tuple count, then exclusive offset inside the tile
+    uint32_t srun[TILE];  // per sample: tuples written so far
+};
+
+// ---------------------------------------------------------------------------------------------
+// column index: for every alignment, per 1024-column chunk in WALK order, the number of emitting
+// columns and of target-advancing columns before the chunk.  One wave per alignment.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_cols16(const uint32_t *__restrict__ diff, uint64_t diff_off, uint32_t n_cols,
+                                                bool back, uint32_t j0, uint32_t *n_lane) {
+    // returns the column classes of walk-order columns j0 .. j0+15 (2 bits each, jj at bits 2jj)
+    if (j0 >= n_cols) {
+        *n_lane = 0;
+        return 0;
+    }
+    uint32_t n = n_cols - j0;
+    if (n > 16) n = 16;
+    *n_lane = n;
+    if (!back) return diff[diff_off + (j0 >> 4)];  // j0 is a multiple of 16
+    int64_t s_lo = (int64_t)n_cols - 16 - (int64_t)j0;  // storage column of walk column j0 + 15
+    uint32_t w32;
+    if (s_lo >= 0) {
+        uint64_t w = diff_off + ((uint64_t)s_lo >> 4);
+        uint32_t sh = ((uint32_t)s_lo & 15u) * 2u;
+        uint32_t lo = diff[w];
+        w32 = lo >> sh;
+        if (sh) w32 |= diff[w + 1] << (32 - sh);
+    } else {
+        uint32_t m = (uint32_t)(-s_lo);  // 1..15 missing low columns
+        w32 = diff[diff_off] << (2 * m);
+    }
+    return rev2(w32);
+}
+
+__device__ __forceinline__ void col_masks(uint32_t bits, uint32_t n_lane, uint32_t *emitb, uint32_t *radvb) {
+    uint32_t valid = n_lane >= 16 ? 0x55555555u : (((1u << (2 * n_lane)) - 1u) & 0x55555555u);
+    uint32_t qd = bits & 0x55555555u, rd = (bits >> 1) & 0x55555555u;
+    *emitb = ~(qd & ~rd) & valid;  // class != 01: the query base is emitted
+    *radvb = ~(rd & ~qd) & valid;  // class != 10: the target advances
+}
+
+__global__ __launch_bounds__(64) void colidx_kernel(const pag_aln *__restrict__ aln, uint64_t n_aln,
+                                                    const uint32_t *__restrict__ diff,
+                                                    const uint64_t *__restrict__ colidx_off, uint2 *__restrict__ colidx) {
+    uint64_t ai = blockIdx.x;
+    if (ai >= n_aln) return;
+    pag_aln al = aln[ai];
+    if (!(al.flags & PAG_ALN_ELIGIBLE) || al.query == PAG_NONE) return;
+    bool back = (al.flags & PAG_ALN_WALK_BACK) != 0;
+    uint32_t n_chunks = (al.n_cols + CHUNK - 1) / CHUNK;
+    uint32_t e = 0, r = 0;
+    uint64_t base = colidx_off[ai];
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        if (lane_id() == 0) colidx[base + c] = make_uint2(e, r);
+        uint32_t n_lane, eb, rb;
+        uint32_t bits = load_cols16(diff, al.diff_off, al.n_cols, back, c * CHUNK + lane_id() * 16, &n_lane);
+        col_masks(bits, n_lane, &eb, &rb);
+        e += wave_sum(__popc(eb));
+        r += wave_sum(__popc(rb));
+    }
+}
+
+int launch_colidx(const pag_aln *aln, uint64_t n_aln, const uint32_t *diff, const uint64_t *colidx_off, uint2 *colidx,
+                  hipStream_t s) {
+    if (n_aln == 0) return PAG_OK;
+    colidx_kernel<<<dim3((unsigned)n_aln), dim3(64), 0, s>>>(aln, n_aln, diff, colidx_off, colidx);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-cooperative walk of the columns of one alignment that emit read positions in [lo, hi).
+// f(q, t) is called by the lane that owns the column: q = read-strand position, t = target position.
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void walk_alignment(const pag_aln &al, const uint32_t *__restrict__ diff,
+                                               const uint2 *__restrict__ cidx, uint32_t lo, uint32_t hi, F f) {
+    uint32_t q_end = al.q_start + al.n_valid;
+    uint32_t a = lo > al.q_start ? lo : al.q_start;
+    uint32_t b = hi < q_end ? hi : q_end;
+    if (a >= b) return;
+    uint32_t e0 = a - al.q_start, e1 = b - al.q_start;  // emit ordinals wanted: [e0, e1)
+    bool back = (al.flags & PAG_ALN_WALK_BACK) != 0;
+    uint32_t n_chunks = (al.n_cols + CHUNK - 1) / CHUNK;
+    // last chunk whose emit prefix is <= e0 (uniform binary search)
+    uint32_t c_lo = 0, c_hi = n_chunks;
+    while (c_hi - c_lo > 1) {
+        uint32_t mid = (c_lo + c_hi) >> 1;
+        if (cidx[mid].x <= e0) c_lo = mid;
+        else c_hi = mid;
+    }
+    for (uint32_t c = c_lo; c < n_chunks; ++c) {
+        uint2 pre = cidx[c];
+        if (pre.x >= e1) break;
+        uint32_t n_lane, eb, rb;
+        uint32_t bits = load_cols16(diff, al.diff_off, al.n_cols, back, c * CHUNK + lane_id() * 16, &n_lane);
+        col_masks(bits, n_lane, &eb, &rb);
+        uint32_t tot;
+        uint32_t eex = wave_excl_sum(__popc(eb), &tot) + pre.x;
+        uint32_t rex = wave_excl_sum(__popc(rb), &tot) + pre.y;
+        uint32_t m = eb;
+        while (m) {
+            uint32_t bit = __ffs(m) - 1;  // even bit index 2*jj
+            m &= m - 1;
+            uint32_t below = (1u << bit) - 1u;
+            uint32_t ord = eex + __popc(eb & below);
+            if (ord >= e0 && ord < e1) f(al.q_start + ord, al.t_start + rex + __popc(rb & below));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler automaton: state = min(S, positions since the last kept sample), S = "free".
+// A function state -> state is a packed table of 4-bit entries.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tab_get(uint32_t tab, uint32_t s) { return (tab >> (4 * s)) & 15u; }
+__device__ __forceinline__ uint32_t tab_compose(uint32_t first, uint32_t then, uint32_t S) {
+    uint32_t out = 0;
+    for (uint32_t s = 0; s <= S; ++s) out |= tab_get(then, tab_get(first, s)) << (4 * s);
+    return out;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
+    __shared__ WaveLds L;
+    const uint32_t job = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t r = A.emit_order[job >> 1];
+    const uint32_t strand = job & 1u;
+    const uint32_t len = A.read_len[r];
+    const uint32_t k = A.k;
+    const uint32_t S = A.outer;
+    const uint64_t a_lo = A.query_off[r], a_hi = A.query_off[r + 1];
+    const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    const uint32_t *__restrict__ words = (const uint32_t *)(A.packed + A.read_off[r]);
+
+    // every lane runs the same loop over the read's alignment list (uniform); `body(al, ai)` is called
+    // for the alignments that put positions on THIS strand
+    auto for_active = [&](auto body) {
+        int done = 0;
+        for (uint64_t ai = a_lo; ai < a_hi; ++ai) {
+            if (A.topk >= 0 && done >= A.topk) break;
+            pag_aln al = A.aln[ai];
+            if (!(al.flags & PAG_ALN_ELIGIBLE)) continue;
+            if (A.cov_ok && !A.cov_ok[ai]) continue;
+            ++done;
+            if (((al.flags & PAG_ALN_REV_STRAND) ? 1u : 0u) != strand) continue;
+            if (al.q_start == PAG_NONE || al.n_valid == 0) continue;
+            body(al, ai);
+        }
+    };
+
+    uint32_t job_samples = 0;
+    uint64_t job_tuples = 0;
+    bool any = false;
+    if (len >= k) for_active([&](const pag_aln &, uint64_t) { any = true; });
+    if (!any) {
+        if (!EMIT && lane == 0) {
+            A.job_samples[A.job_base + job] = 0;
+            A.job_tuples[A.job_base + job] = 0;
+        }
+        return;
+    }
+    const uint32_t n_pos = len - k + 1;
+    const uint64_t tuple_base = EMIT ? A.tuple_off[A.job_base + job] : 0;
+    const uint64_t edge_base = EMIT ? A.edge_off[A.job_base + job] : 0;
+
+    uint32_t state = S;  // free
+    bool carry_valid = false;
+    uint32_t carry_pos = 0, carry_code = 0;
+
+    for (uint32_t t0 = 0; t0 < n_pos; t0 += TILE) {
+        const uint32_t p0 = t0 + lane * 16;
+        const uint32_t t_hi = t0 + TILE < n_pos ? t0 + TILE : n_pos;
+
+        // ---- A. which of my 16 positions have a non-empty position list
+        uint32_t ne = 0;
+        for_active([&](const pag_aln &al, uint64_t) {
+            uint32_t lo = al.q_start > p0 ? al.q_start : p0;
+            uint32_t hi = al.q_start + al.n_valid;
+            if (hi > p0 + 16) hi = p0 + 16;
+            if (hi > n_pos) hi = n_pos;
+            if (lo < hi) ne |= ((1u << (hi - p0)) - 1u) & ~((1u << (lo - p0)) - 1u);
+        });
+        if (__ballot(ne != 0) == 0ull) {
+            state = S;  // >= S positions without a candidate (or the end of the strand)
+            continue;
+        }
+
+        // ---- B. k-mer codes of my positions + solid test
+        uint32_t code[16];
+        uint32_t cand = 0;
+        const uint32_t n_mine = p0 >= n_pos ? 0u : (n_pos - p0 > 16 ? 16u : n_pos - p0);
+        {
+            uint64_t W = 0;
+            uint32_t sh0 = 0;  // reverse strand: window bit offset of position j is 2*(15 - j) + sh0
+            if (n_mine) {      // lanes past the end of the strand must not touch memory
+                if (strand == 0) {
+                    uint32_t w0 = p0 >> 4;
+                    W = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
+                } else {
+                    int64_t a0 = (int64_t)len - (int64_t)k - (int64_t)p0 - 15;
+                    uint32_t a1 = a0 > 0 ? (uint32_t)a0 : 0u;
+                    uint32_t w = a1 >> 4, sh = (a1 & 15u) * 2u;
+                    uint64_t lo64 = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
+                    W = lo64 >> sh;
+                    if (sh) W |= (uint64_t)words[w + 2] << (64 - sh);
+                    sh0 = (uint32_t)((a0 - (int64_t)a1) * 2);  // <= 0 as a signed value; fine for valid j
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                uint32_t x;
+                if (strand == 0) {
+                    x = (uint32_t)(W >> (2 * j)) & kmask;
+                    code[j] = rev2(x) >> (32 - 2 * k);
+                } else {
+                    uint32_t shj = (uint32_t)(2 * (15 - j)) + sh0;  // wraps harmlessly for invalid j
+                    x = (uint32_t)(W >> (shj & 63u)) & kmask;
+                    code[j] = (~x) & kmask;
+                }
+                if ((ne >> j) & 1u) {
+                    uint32_t solid = 1;
+                    if (!A.all_solid) solid = (A.solid_bits[code[j] >> 5] >> (code[j] & 31u)) & 1u;
+                    cand |= solid << j;
+                }
+            }
+        }
+
+        // ---- C. greedy sampling as an associative scan of state-transition tables
+        uint32_t tab = 0;
+        for (uint32_t s = 0; s <= S; ++s) tab |= s << (4 * s);
+        for (uint32_t j = 0; j < n_mine; ++j) {
+            uint32_t c = (cand >> j) & 1u, nt = 0;
+            for (uint32_t s = 0; s <= S; ++s) {
+                uint32_t v = tab_get(tab, s);
+                v = (c && v + 1 >= S) ? 0u : (v + 1 > S ? S : v + 1);
+                nt |= v << (4 * s);
+            }
+            tab = nt;
+        }
+        uint32_t incl = tab;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t prev = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl = tab_compose(prev, incl, S);
+        }
+        uint32_t excl = __shfl_up(incl, 1, 64);
+        uint32_t v = lane == 0 ? state : tab_get(excl, state);
+        state = tab_get(__shfl(incl, 63, 64), state);
+        uint32_t kept = 0;
+        for (uint32_t j = 0; j < n_mine; ++j) {
+            uint32_t c = (cand >> j) & 1u;
+            if (c && v + 1 >= S) {
+                kept |= 1u << j;
+                v = 0;
+            } else {
+                v = v + 1 > S ? S : v + 1;
+            }
+        }
+
+        // ---- D. sample ranks
+        uint32_t tile_samples;
+        const uint32_t rank0 = wave_excl_sum(__popc(kept), &tile_samples);
+        if (tile_samples == 0) continue;
+
+        if (EMIT) {
+            __syncthreads();  // previous tile's readers are done with L
+            L.kept[lane] = kept;
+            L.rank[lane] = rank0;
+            // ---- E. edges between consecutive kept samples (prev -> this)
+            uint32_t last_pos = 0, last_code = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if ((kept >> j) & 1u) {
+                    last_pos = p0 + j;
+                    last_code = code[j];
+                }
+            }
+            uint64_t has = __ballot(kept != 0);
+            uint64_t before = has & lanemask_lt();
+            int src = before ? 63 - __clzll((long long)before) : 0;
+            uint32_t pp = __shfl(last_pos, src, 64), pc = __shfl(last_code, src, 64);
+            bool pvalid = before != 0;
+            if (!pvalid) {
+                pp = carry_pos;
+                pc = carry_code;
+                pvalid = carry_valid;
+            }
+            uint32_t i = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if ((kept >> j) & 1u) {
+                    uint32_t s_local = rank0 + i;
+                    L.scode[s_local] = code[j];
+                    L.scnt[s_local] = 0;
+                    L.srun[s_local] = 0;
+                    if (pvalid) {
+                        uint64_t slot = edge_base + (uint64_t)job_samples + s_local - 1;
+                        A.ekey[slot] = pc;
+                        A.eval[slot] = ((uint64_t)code[j] << 32) | ((uint64_t)(p0 + j - pp) << 1) | (uint64_t)A.pass;
+                    }
+                    pp = p0 + j;
+                    pc = code[j];
+                    pvalid = true;
+                    ++i;
+                }
+            }
+            int top = 63 - __clzll((long long)has);
+            carry_pos = __shfl(last_pos, top, 64);
+            carry_code = __shfl(last_code, top, 64);
+            carry_valid = true;
+            __syncthreads();
+        }
+
+        // ---- F. tuples of the kept samples
+        uint32_t tile_tuples = 0;
+        if (!EMIT) {
+            for_active([&](const pag_aln &al, uint64_t ai) {
+                bool multi = A.pass == 0 && A.ctgs[al.target].multi != 0;
+                if (!multi) {
+                    uint32_t lo = al.q_start > p0 ? al.q_start : p0;
+                    uint32_t hi = al.q_start + al.n_valid;
+                    if (hi > p0 + 16) hi = p0 + 16;
+                    if (lo < hi) tile_tuples += __popc(kept & ((1u << (hi - p0)) - 1u) & ~((1u << (lo - p0)) - 1u));
+                } else {
+                    // entry counts differ per base: walk.  kept masks must be visible to other lanes
+                    __syncthreads();
+                    L.kept[lane] = kept;
+                    __syncthreads();
+                    const pag_ctg cg = A.ctgs[al.target];
+                    walk_alignment(al, A.diff, A.colidx + A.colidx_off[ai], t0, t_hi, [&](uint32_t q, uint32_t t) {
+                        uint32_t d = q - t0;
+                        if ((L.kept[d >> 4] >> (d & 15u)) & 1u)
+                            tile_tuples += A.ctg_ent_off[cg.map_off + t + 1] - A.ctg_ent_off[cg.map_off + t];
+                    });
+                }
+            });
+            job_tuples += wave_sum(tile_tuples);
+        } else {
+            // F1: tuples per sample
+            for_active([&](const pag_aln &al, uint64_t ai) {
+                const bool ctg_pass = A.pass == 0;
+                pag_ctg cg{};
+                if (ctg_pass) cg = A.ctgs[al.target];
+                walk_alignment(al, A.diff, A.colidx + A.colidx_off[ai], t0, t_hi, [&](uint32_t q, uint32_t t) {
+                    uint32_t d = q - t0;
+                    uint32_t km = L.kept[d >> 4];
+                    if ((km >> (d & 15u)) & 1u) {
+                        uint32_t s_local = L.rank[d >> 4] + __popc(km & ((1u << (d & 15u)) - 1u));
+                        uint32_t c = ctg_pass ? A.ctg_ent_off[cg.map_off + t + 1] - A.ctg_ent_off[cg.map_off + t] : 1u;
+                        L.scnt[s_local] += c;
+                    }
+                });
+                __syncthreads();
+            });
+            // exclusive scan of scnt over the tile's samples (16 per lane)
+            {
+                uint32_t loc[16], sum = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    uint32_t idx = lane * 16 + i;
+                    loc[i] = idx < tile_samples ? L.scnt[idx] : 0u;
+                    sum += loc[i];
+                }
+                uint32_t ex = wave_excl_sum(sum, &tile_tuples);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    uint32_t idx = lane * 16 + i;
+                    if (idx < tile_samples) L.scnt[idx] = ex;
+                    ex += loc[i];
+                }
+                __syncthreads();
+            }
+            // F2: write
+            const uint64_t out0 = tuple_base + job_tuples;
+            for_active([&](const pag_aln &al, uint64_t ai) {
+                const bool ctg_pass = A.pass == 0;
+                pag_ctg cg{};
+                uint32_t ref_base = 0;
+                if (ctg_pass) cg = A.ctgs[al.target];
+                else ref_base = A.refs[al.target].single_base;
+                walk_alignment(al, A.diff, A.colidx + A.colidx_off[ai], t0, t_hi, [&](uint32_t q, uint32_t t) {
+                    uint32_t d = q - t0;
+                    uint32_t km = L.kept[d >> 4];
+                    if ((km >> (d & 15u)) & 1u) {
+                        uint32_t s_local = L.rank[d >> 4] + __popc(km & ((1u << (d & 15u)) - 1u));
+                        uint32_t run = L.srun[s_local];
+                        uint64_t dst = out0 + L.scnt[s_local] + run;
+                        uint32_t kc = L.scode[s_local];
+                        if (ctg_pass) {
+                            uint32_t e0 = A.ctg_ent_off[cg.map_off + t], e1 = A.ctg_ent_off[cg.map_off + t + 1];
+                            uint64_t hi = (uint64_t)(cg.single_base + t) << 32;
+                            for (uint32_t e = e0; e < e1; ++e) {
+                                A.tkey[dst] = kc;
+                                A.tval[dst] = hi | A.ctg_ent[e];
+                                ++dst;
+                            }
+                            L.srun[s_local] = run + (e1 - e0);
+                        } else {
+                            A.tkey[dst] = kc;
+                            A.tval[dst] = (uint64_t)(uint32_t)(ref_base + t);
+                            L.srun[s_local] = run + 1;
+                        }
+                    }
+                });
+                __syncthreads();
+            });
+            job_tuples += tile_tuples;
+        }
+        job_samples += tile_samples;
+    }
+
+    if (!EMIT && lane == 0) {
+        A.job_samples[A.job_base + job] = job_samples;
+        A.job_tuples[A.job_base + job] = (uint32_t)job_tuples;
+    }
+}
+
+int launch_extract(const ExtractArgs &a, bool emit, hipStream_t s) {
+    if (a.n_reads == 0) return PAG_OK;
+    dim3 grid(2u * a.n_reads), block(64);
+    if (emit) extract_kernel<true><<<grid, block, 0, s>>>(a);
+    else extract_kernel<false><<<grid, block, 0, s>>>(a);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+
+}  // namespace pagdev

@@ -1,0 +1,294 @@
+// k34_segments.hip — K3 (epsilon-windowed vertex merge) and K4 (edge de-duplication), both run over
+// the k-mer-sorted tuple streams, one k-mer segment at a time, in place.
+//
+// K3 = PABruijnGraph::mergeKmerPosition + KMerAdjNode::cluster + sortKmerPosition
+//      (reference graph/PABruijnGraph.cpp:259-283, node/KMerAdjNode.tcc:73-137):
+//      greedy leader clustering IN INSERTION ORDER — an item joins the FIRST existing leader it is
+//      similar to (both coordinates within eps, or both zero), adding to its u16 count (wraps);
+//      otherwise it becomes a leader.  Leaders keep the coordinates of their first member and are
+//      finally sorted by (ctg, ref).  The reference clusters after pass 1 and again after pass 2 on
+//      [pass-1 leaders] ++ [pass-2 items]; one greedy scan over [pass-1 items] ++ [pass-2 items] gives
+//      the identical result (leaders are pairwise dissimilar, so re-scanning them reproduces them),
+//      which is what the stable sort hands us.  Pass-1 items always have ctg != 0, pass-2 items ctg == 0,
+//      so "leaders created by pass 1" = leaders with ctg != 0 (needed for the reference's count lines).
+// K4 = PABruijnGraph::mergeEdge + KMerAdjNode::removeDuplicate (graph/PABruijnGraph.cpp:285-297,
+//      node/KMerAdjNode.tcc:45-71): per k-mer sort children by (to, step), drop exact duplicates.
+//      Payload = to << 32 | step << 1 | pass, so one numeric sort orders by (to, step, pass) and the
+//      head of every (to, step) group tells whether pass 1 already had that edge.
+//
+// Short segments (<= SHORT_MAX records): one thread per segment, sequential.  Long segments (repeats,
+// low-complexity k-mers) are queued and handled by one wavefront each: 64 leaders compared per step,
+// ballot -> first hit; rank sort through the idle sort ping-pong buffers.
+#include "pag_device.hpp"
+
+namespace pagdev {
+
+constexpr uint32_t SHORT_MAX = 32;
+
+__device__ __forceinline__ bool coord_sim(uint32_t a, uint32_t b, uint32_t eps) {
+    if (a == 0 || b == 0) return a == 0 && b == 0;
+    uint32_t d = a > b ? a - b : b - a;
+    return d <= eps;
+}
+__device__ __forceinline__ bool pos_sim(uint64_t x, uint64_t y, uint32_t eps) {
+    return coord_sim((uint32_t)(x >> 32), (uint32_t)(y >> 32), eps) && coord_sim((uint32_t)x, (uint32_t)y, eps);
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+__global__ __launch_bounds__(256) void cluster_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
+                                                    uint64_t n, uint32_t eps, ClusterOut out,
+                                                    uint64_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_ctg = 0, n_all = 0, n_seg = 0;
+    if (i < n) {
+        uint32_t kx = key[i];
+        bool head = i == 0 || key[i - 1] != kx;
+        uint32_t seglen = 0;
+        if (head) {
+            uint64_t j = i + 1;
+            while (j < n && j - i <= SHORT_MAX && key[j] == kx) ++j;
+            uint64_t len = j - i;
+            n_seg = 1;
+            if (len > SHORT_MAX) {
+                uint32_t slot = atomicAdd(long_count, 1u);
+                long_list[slot] = i;
+                seglen = 0xFFFFFFFFu;  // filled in by cluster_long
+            } else {
+                uint32_t p = 0;
+                for (uint64_t it = i; it < j; ++it) {
+                    uint64_t item = val[it];
+                    bool hit = false;
+                    for (uint32_t l = 0; l < p; ++l) {
+                        if (pos_sim(item, val[i + l], eps)) {
+                            out.cnt[i + l] = (uint16_t)(out.cnt[i + l] + 1);
+                            hit = true;
+                            break;
+                        }
+                    }
+                    if (!hit) {
+                        val[i + p] = item;
+                        out.cnt[i + p] = 1;
+                        ++p;
+                    }
+                }
+                // sortWithCount: insertion sort by position (distinct keys)
+                for (uint32_t a = 1; a < p; ++a) {
+                    uint64_t v = val[i + a];
+                    uint16_t c = out.cnt[i + a];
+                    uint32_t b = a;
+                    while (b > 0 && val[i + b - 1] > v) {
+                        val[i + b] = val[i + b - 1];
+                        out.cnt[i + b] = out.cnt[i + b - 1];
+                        --b;
+                    }
+                    val[i + b] = v;
+                    out.cnt[i + b] = c;
+                }
+                seglen = p;
+                n_all = p;
+                for (uint32_t l = 0; l < p; ++l) n_ctg += (val[i + l] >> 32) != 0;
+            }
+        }
+        out.seg_len[i] = seglen;
+    }
+    n_ctg = wave_sum(n_ctg);
+    n_all = wave_sum(n_all);
+    n_seg = wave_sum(n_seg);
+    if (lane_id() == 0) {
+        if (n_ctg) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_ctg);
+        if (n_all) atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)n_all);
+        if (n_seg) atomicAdd((unsigned long long *)&out.counters[2], (unsigned long long)n_seg);
+    }
+}
+
+// wave-cooperative: length of the run of `kx` starting at i
+__device__ __forceinline__ uint64_t run_end(const uint32_t *__restrict__ key, uint64_t i, uint64_t n, uint32_t kx) {
+    uint64_t j = i;
+    for (;;) {
+        uint64_t x = j + lane_id();
+        bool same = x < n && key[x] == kx;
+        uint64_t m = __ballot(same);
+        if (m != ~0ull) {
+            j += (uint64_t)__ffsll((long long)~m) - 1;
+            return j;
+        }
+        j += 64;
+    }
+}
+
+// rank sort of m records val[0..m) (with companion u16 cnt) by (val, index) through scratch buffers
+__device__ __forceinline__ void wave_rank_sort(uint64_t *__restrict__ val, uint16_t *__restrict__ cnt, uint32_t m,
+                                               uint64_t *__restrict__ s64, uint32_t *__restrict__ s32) {
+    __syncthreads();
+    for (uint32_t t = lane_id(); t < m; t += 64) {
+        uint64_t v = val[t];
+        uint32_t rank = 0;
+        for (uint32_t x = 0; x < m; ++x) {
+            uint64_t u = val[x];
+            rank += (u < v) || (u == v && x < t);
+        }
+        s64[rank] = v;
+        if (cnt) s32[rank] = cnt[t];
+    }
+    __syncthreads();
+    for (uint32_t t = lane_id(); t < m; t += 64) {
+        val[t] = s64[t];
+        if (cnt) cnt[t] = (uint16_t)s32[t];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void cluster_long(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
+                                                  uint64_t *__restrict__ s64, uint32_t *__restrict__ s32, uint64_t n,
+                                                  uint32_t eps, ClusterOut out, const uint64_t *__restrict__ long_list,
+                                                  const uint32_t *__restrict__ long_count) {
+    const uint32_t lane = lane_id();
+    for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
+        const uint64_t i = long_list[li];
+        const uint64_t j = run_end(key, i, n, key[i]);
+        uint32_t p = 0;
+        for (uint64_t it = i; it < j; ++it) {
+            uint64_t item = val[it];
+            int hit = -1;
+            for (uint32_t c0 = 0; c0 < p && hit < 0; c0 += 64) {
+                uint32_t l = c0 + lane;
+                bool sim = l < p && pos_sim(item, val[i + l], eps);
+                uint64_t m = __ballot(sim);
+                if (m) hit = (int)(c0 + __ffsll((long long)m) - 1);
+            }
+            if (lane == 0) {
+                if (hit >= 0) {
+                    out.cnt[i + hit] = (uint16_t)(out.cnt[i + hit] + 1);
+                } else {
+                    val[i + p] = item;
+                    out.cnt[i + p] = 1;
+                }
+            }
+            if (hit < 0) ++p;
+            __syncthreads();  // the new leader must be visible to every lane before the next item
+        }
+        wave_rank_sort(val + i, out.cnt + i, p, s64 + i, s32 + i);
+        uint32_t n_ctg = 0;
+        for (uint32_t l = lane; l < p; l += 64) n_ctg += (val[i + l] >> 32) != 0;
+        n_ctg = wave_sum(n_ctg);
+        if (lane == 0) {
+            out.seg_len[i] = p;
+            if (n_ctg) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_ctg);
+            atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)p);
+        }
+    }
+}
+
+int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, uint32_t eps, ClusterOut out,
+                   uint64_t *long_list, uint32_t *long_count, hipStream_t s) {
+    PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
+    PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
+    if (n == 0) return PAG_OK;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    cluster_short<<<dim3(grid), dim3(256), 0, s>>>(key, val, n, eps, out, long_list, long_count);
+    // scratch: u64[n] followed by u32[n] (the idle sort ping-pong buffers)
+    cluster_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, (uint32_t *)(scratch + n), n, eps, out,
+                                                 long_list, long_count);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ K4
+__global__ __launch_bounds__(256) void edges_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
+                                                  uint64_t n, EdgeOut out, uint64_t *__restrict__ long_list,
+                                                  uint32_t *__restrict__ long_count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_grp = 0, n_grp1 = 0;
+    if (i < n) {
+        uint32_t kx = key[i];
+        bool head = i == 0 || key[i - 1] != kx;
+        uint32_t seglen = 0;
+        if (head) {
+            uint64_t j = i + 1;
+            while (j < n && j - i <= SHORT_MAX && key[j] == kx) ++j;
+            uint64_t len = j - i;
+            if (len > SHORT_MAX) {
+                uint32_t slot = atomicAdd(long_count, 1u);
+                long_list[slot] = i;
+                seglen = 0xFFFFFFFFu;
+            } else {
+                for (uint32_t a = 1; a < len; ++a) {
+                    uint64_t v = val[i + a];
+                    uint32_t b = a;
+                    while (b > 0 && val[i + b - 1] > v) {
+                        val[i + b] = val[i + b - 1];
+                        --b;
+                    }
+                    val[i + b] = v;
+                }
+                uint32_t p = 0;
+                for (uint32_t a = 0; a < len; ++a) {
+                    uint64_t v = val[i + a];
+                    if (p == 0 || (val[i + p - 1] >> 1) != (v >> 1)) {
+                        val[i + p] = v;
+                        ++p;
+                        n_grp1 += (v & 1ull) == 0;
+                    }
+                }
+                seglen = p;
+                n_grp = p;
+            }
+        }
+        out.seg_len[i] = seglen;
+    }
+    n_grp = wave_sum(n_grp);
+    n_grp1 = wave_sum(n_grp1);
+    if (lane_id() == 0) {
+        if (n_grp) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_grp);
+        if (n_grp1) atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)n_grp1);
+    }
+}
+
+__global__ __launch_bounds__(64) void edges_long(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
+                                                uint64_t *__restrict__ s64, uint64_t n, EdgeOut out,
+                                                const uint64_t *__restrict__ long_list,
+                                                const uint32_t *__restrict__ long_count) {
+    const uint32_t lane = lane_id();
+    for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
+        const uint64_t i = long_list[li];
+        const uint64_t j = run_end(key, i, n, key[i]);
+        const uint32_t m = (uint32_t)(j - i);
+        wave_rank_sort(val + i, nullptr, m, s64 + i, nullptr);
+        // unique by (to, step): compact group heads through the scratch buffer
+        uint32_t p = 0, g1 = 0;
+        for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+            uint32_t x = c0 + lane;
+            uint64_t v = x < m ? val[i + x] : 0;
+            bool headg = x < m && (x == 0 || (val[i + x - 1] >> 1) != (v >> 1));
+            uint64_t hm = __ballot(headg);
+            if (headg) {
+                s64[i + p + __popcll(hm & lanemask_lt())] = v;
+                g1 += (v & 1ull) == 0;
+            }
+            p += (uint32_t)__popcll(hm);
+        }
+        __syncthreads();
+        for (uint32_t x = lane; x < p; x += 64) val[i + x] = s64[i + x];
+        g1 = wave_sum(g1);
+        if (lane == 0) {
+            out.seg_len[i] = p;
+            atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)p);
+            if (g1) atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)g1);
+        }
+        __syncthreads();
+    }
+}
+
+int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, EdgeOut out, uint64_t *long_list,
+                 uint32_t *long_count, hipStream_t s) {
+    PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
+    PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
+    if (n == 0) return PAG_OK;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    edges_short<<<dim3(grid), dim3(256), 0, s>>>(key, val, n, out, long_list, long_count);
+    edges_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, n, out, long_list, long_count);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+
+}  // namespace pagdev

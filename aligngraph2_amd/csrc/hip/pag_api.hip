@@ -1,0 +1,601 @@
+// pag_api.hip — the C ABI of libpagraph_hip.so (include/pagraph_hip.h) and the device pipeline of
+// PositionProcessor::process (reference PAGraph/src/tools/position/PositionProcessor.cpp:79-151):
+//
+//   coverage filter -> column index -> K1 count (pass 1, pass 2) -> scans -> K1 emit (pass 1, pass 2)
+//   -> K2 stable sort of position tuples by k-mer, K2 sort of edge tuples by `from`
+//   -> K3 cluster + sort positions per k-mer, K4 sort + unique edges per k-mer.
+//
+// The reference runs {extract, mergeEdge, cluster} twice (pass 1, then pass 2 on top of pass 1's
+// leaders).  Both greedy procedures are prefix-closed, so ONE sort + ONE cluster over the
+// concatenation [pass-1 stream] ++ [pass-2 stream] yields the identical graph (k34_segments.hip), and
+// the reference's six count lines are recovered from the stream lengths and two counters.
+//
+// No CPU fallback: without a usable gfx950 device every entry point returns PAG_ENODEV.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pag_device.hpp"
+
+using namespace pagdev;
+
+struct pag_graph {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t k = 0;
+    uint64_t n_solid = 0;
+    int all_solid = 0;
+    uint32_t *solid_bits = nullptr;  // 4^k bits
+    // finished graph (device): k-mer-sorted streams with in-place segment results
+    uint64_t n_t = 0, n_e = 0;
+    uint32_t *tkey = nullptr;
+    uint64_t *tval = nullptr;
+    uint32_t *tseg = nullptr;
+    uint16_t *tcnt = nullptr;
+    uint32_t *ekey = nullptr;
+    uint64_t *eval = nullptr;
+    uint32_t *eseg = nullptr;
+    pag_build_stats stats{};
+    // debug: raw emitted streams (host copies), kept when PAG_DEBUG_KEEP_STREAMS=1
+    std::vector<uint32_t> dbg_tkey, dbg_ekey;
+    std::vector<uint64_t> dbg_tval, dbg_eval;
+};
+
+namespace {
+
+struct DevBuf {  // RAII device allocation
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (p) {
+            hipFree(p);
+            p = nullptr;
+        }
+        if (bytes == 0) bytes = 16;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return PAG_ENOMEM;
+        }
+        return PAG_OK;
+    }
+    template <typename T>
+    T *as() const {
+        return (T *)p;
+    }
+    void *release() {
+        void *q = p;
+        p = nullptr;
+        return q;
+    }
+};
+
+// device view of an input array: uploads when the caller's array is in host memory
+template <typename T>
+int stage(const T *src, uint64_t n, bool on_device, DevBuf &own, const T **out, hipStream_t s) {
+    if (on_device) {
+        *out = src;
+        return PAG_OK;
+    }
+    int rc = own.alloc((size_t)n * sizeof(T) + 64);
+    if (rc != PAG_OK) return rc;
+    if (n) PAG_HIP_TRY(hipMemcpyAsync(own.p, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, s));
+    *out = own.as<T>();
+    return PAG_OK;
+}
+
+int pick_device(int ordinal) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device (hipGetDeviceCount)");
+        return PAG_ENODEV;
+    }
+    if (ordinal < 0 || ordinal >= n) {
+        set_error("device ordinal %d out of range (%d devices)", ordinal, n);
+        return PAG_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return PAG_ENODEV;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 only", ordinal, prop.gcnArchName);
+        return PAG_ENODEV;
+    }
+    if (hipSetDevice(ordinal) != hipSuccess) return PAG_ENODEV;
+    return PAG_OK;
+}
+
+void free_graph_results(pag_graph *g) {
+    void *ptrs[] = {g->tkey, g->tval, g->tseg, g->tcnt, g->ekey, g->eval, g->eseg};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    g->tkey = nullptr;
+    g->tval = nullptr;
+    g->tseg = nullptr;
+    g->tcnt = nullptr;
+    g->ekey = nullptr;
+    g->eval = nullptr;
+    g->eseg = nullptr;
+    g->n_t = g->n_e = 0;
+}
+
+__global__ void chunk_counts(const pag_aln *__restrict__ aln, uint64_t n, uint32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pag_aln a = aln[i];
+    bool used = (a.flags & PAG_ALN_ELIGIBLE) && a.query != PAG_NONE;
+    out[i] = used ? (a.n_cols + 1023u) / 1024u : 0u;
+}
+
+__global__ void edge_counts(const uint32_t *__restrict__ samples, uint64_t n, uint32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = samples[i] ? samples[i] - 1u : 0u;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pag_last_error(void) { return last_error(); }
+
+int pag_device_available(void) { return pick_device(0) == PAG_OK ? 1 : 0; }
+
+pag_graph *pag_create(const uint64_t *codes, uint64_t n_codes, uint32_t k, int device_ordinal, int *err) {
+    int rc = PAG_OK;
+    pag_graph *g = nullptr;
+    if (k == 0 || k > 16 || (!codes && n_codes)) {
+        set_error("pag_create: k must be in 1..16 (got %u)", k);
+        rc = PAG_EINVAL;
+    }
+    if (rc == PAG_OK) rc = pick_device(device_ordinal);
+    if (rc == PAG_OK) {
+        g = new (std::nothrow) pag_graph();
+        if (!g) rc = PAG_ENOMEM;
+    }
+    if (rc == PAG_OK) {
+        g->device = device_ordinal;
+        g->k = k;
+        // PABruijnGraph::PABruijnGraph: sort + unique of every word (PABruijnGraph.cpp:32-34)
+        std::vector<uint64_t> sorted(codes, codes + n_codes);
+        std::sort(sorted.begin(), sorted.end());
+        sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+        g->n_solid = sorted.size();
+        const uint64_t space = 1ull << (2 * k);
+        const uint64_t words = (space + 31) / 32;
+        std::vector<uint32_t> bits((size_t)words, 0u);
+        uint64_t in_space = 0;
+        for (uint64_t c : sorted) {
+            if (c < space) {  // read k-mers are masked to 2k bits; larger words can never match
+                bits[(size_t)(c >> 5)] |= 1u << (c & 31);
+                ++in_space;
+            }
+        }
+        g->all_solid = in_space == space;
+        hipError_t e = hipStreamCreate(&g->stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->solid_bits, (size_t)words * 4 + 64);
+        if (e == hipSuccess) e = hipMemcpy(g->solid_bits, bits.data(), (size_t)words * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("pag_create: %s", hipGetErrorString(e));
+            rc = PAG_EFAULT;
+        }
+    }
+    if (rc != PAG_OK && g) {
+        pag_destroy(g);
+        g = nullptr;
+    }
+    if (err) *err = rc;
+    return g;
+}
+
+void pag_destroy(pag_graph *g) {
+    if (!g) return;
+    hipSetDevice(g->device);
+    free_graph_results(g);
+    if (g->solid_bits) hipFree(g->solid_bits);
+    if (g->stream) hipStreamDestroy(g->stream);
+    delete g;
+}
+
+uint64_t pag_solid_count(const pag_graph *g) { return g ? g->n_solid : 0; }
+
+int pag_reset(pag_graph *g) {
+    if (!g) return PAG_EINVAL;
+    hipSetDevice(g->device);
+    free_graph_results(g);
+    g->stats = pag_build_stats{};
+    return PAG_OK;
+}
+
+int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats) {
+    if (!g || !in) return PAG_EINVAL;
+    if (in->outer_sample < 1 || in->outer_sample > 7) {
+        set_error("outer_sample must be 1..7");
+        return PAG_EINVAL;
+    }
+    if (in->reads.n_seqs >= 0x3FFFFFFFull) {
+        set_error("too many reads for one launch");
+        return PAG_EINVAL;
+    }
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    free_graph_results(g);
+    hipStream_t s = g->stream;
+    const bool dev = in->on_device != 0;
+    const uint32_t n_reads = (uint32_t)in->reads.n_seqs;
+    const uint64_t n_jobs = 4ull * n_reads;  // 2 passes x 2 strands
+    int rc;
+
+    hipEvent_t ev[8];
+    for (auto &e : ev) PAG_HIP_TRY(hipEventCreate(&e));
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard() {
+            for (int i = 0; i < 8; ++i) hipEventDestroy(e[i]);
+        }
+    } ev_guard{ev};
+    PAG_HIP_TRY(hipEventRecord(ev[0], s));
+
+    // ---- inputs -> device
+    DevBuf b_roff, b_rlen, b_packed, b_order, b_aln1, b_q1, b_d1, b_aln2, b_q2, b_d2, b_ctg, b_eoff, b_ent, b_ref;
+    const uint64_t *d_roff;
+    const uint32_t *d_rlen, *d_order, *d_d1, *d_d2, *d_eoff, *d_ent;
+    const uint8_t *d_packed;
+    const pag_aln *d_aln1, *d_aln2;
+    const uint64_t *d_q1, *d_q2;
+    const pag_ctg *d_ctg;
+    const pag_ref *d_ref;
+    if ((rc = stage(in->reads.byte_off, n_reads, dev, b_roff, &d_roff, s))) return rc;
+    if ((rc = stage(in->reads.len, n_reads, dev, b_rlen, &d_rlen, s))) return rc;
+    if ((rc = stage(in->reads.packed, in->reads.packed_bytes, dev, b_packed, &d_packed, s))) return rc;
+    if ((rc = stage(in->emit_order, n_reads, dev, b_order, &d_order, s))) return rc;
+    if ((rc = stage(in->read_to_ctg.aln, in->read_to_ctg.n_aln, dev, b_aln1, &d_aln1, s))) return rc;
+    if ((rc = stage(in->read_to_ctg.query_off, (uint64_t)n_reads + 1, dev, b_q1, &d_q1, s))) return rc;
+    if ((rc = stage(in->read_to_ctg.diff, in->read_to_ctg.n_diff_words, dev, b_d1, &d_d1, s))) return rc;
+    if ((rc = stage(in->read_to_ref.aln, in->read_to_ref.n_aln, dev, b_aln2, &d_aln2, s))) return rc;
+    if ((rc = stage(in->read_to_ref.query_off, (uint64_t)n_reads + 1, dev, b_q2, &d_q2, s))) return rc;
+    if ((rc = stage(in->read_to_ref.diff, in->read_to_ref.n_diff_words, dev, b_d2, &d_d2, s))) return rc;
+    if ((rc = stage(in->ctgs, in->n_ctgs, dev, b_ctg, &d_ctg, s))) return rc;
+    if ((rc = stage(in->ctg_ent_off, in->n_ctg_ent_off, dev, b_eoff, &d_eoff, s))) return rc;
+    if ((rc = stage(in->ctg_ent, in->n_ctg_ent, dev, b_ent, &d_ent, s))) return rc;
+    if ((rc = stage(in->refs, in->n_refs, dev, b_ref, &d_ref, s))) return rc;
+
+    // the reference table is tiny and needed on the host for scratch sizing
+    std::vector<pag_ref> refs_host((size_t)in->n_refs);
+    if (in->n_refs) {
+        if (dev) PAG_HIP_TRY(hipMemcpy(refs_host.data(), in->refs, in->n_refs * sizeof(pag_ref), hipMemcpyDeviceToHost));
+        else std::memcpy(refs_host.data(), in->refs, in->n_refs * sizeof(pag_ref));
+    }
+
+    // ---- coverage filter of pass 2
+    const uint64_t n_aln1 = in->read_to_ctg.n_aln, n_aln2 = in->read_to_ref.n_aln;
+    DevBuf b_covok, b_covtmp;
+    if ((rc = b_covok.alloc(n_aln2 + 16))) return rc;
+    size_t cov_bytes = cov_tmp_bytes(refs_host.data(), in->n_refs);
+    if ((rc = b_covtmp.alloc(cov_bytes))) return rc;
+    if ((rc = launch_cov_filter(d_aln2, n_aln2, d_ref, refs_host.data(), in->n_refs, in->cov_filter,
+                                b_covok.as<uint8_t>(), b_covtmp.p, cov_bytes, s)))
+        return rc;
+
+    // ---- column index of both alignment databases
+    DevBuf b_cc, b_cio1, b_cio2, b_ci1, b_ci2, b_scan, b_tot;
+    uint64_t n_alnmax = std::max(n_aln1, n_aln2);
+    if ((rc = b_cc.alloc((n_alnmax + 1) * 4))) return rc;
+    if ((rc = b_cio1.alloc((n_aln1 + 1) * 8))) return rc;
+    if ((rc = b_cio2.alloc((n_aln2 + 1) * 8))) return rc;
+    if ((rc = b_scan.alloc(scan_tmp_bytes(std::max<uint64_t>(n_alnmax, n_jobs) + 1)))) return rc;
+    if ((rc = b_tot.alloc(64))) return rc;
+    uint64_t *d_tot = b_tot.as<uint64_t>();
+    uint64_t n_ci[2] = {0, 0};
+    for (int pass = 0; pass < 2; ++pass) {
+        const pag_aln *al = pass == 0 ? d_aln1 : d_aln2;
+        uint64_t na = pass == 0 ? n_aln1 : n_aln2;
+        DevBuf &off = pass == 0 ? b_cio1 : b_cio2;
+        DevBuf &ci = pass == 0 ? b_ci1 : b_ci2;
+        if (na) {
+            chunk_counts<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s>>>(al, na, b_cc.as<uint32_t>());
+            if ((rc = scan_u32_to_u64(b_cc.as<uint32_t>(), off.as<uint64_t>(), na, d_tot + pass, b_scan.p, s))) return rc;
+            PAG_HIP_TRY(hipMemcpyAsync(&n_ci[pass], d_tot + pass, 8, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
+        if ((rc = ci.alloc((n_ci[pass] + 1) * sizeof(uint2)))) return rc;
+        if ((rc = launch_colidx(al, na, pass == 0 ? d_d1 : d_d2, off.as<uint64_t>(), ci.as<uint2>(), s))) return rc;
+    }
+
+    // ---- K1 count
+    DevBuf b_js, b_jt, b_je, b_toff, b_eoff2;
+    if ((rc = b_js.alloc((n_jobs + 1) * 4))) return rc;
+    if ((rc = b_jt.alloc((n_jobs + 1) * 4))) return rc;
+    if ((rc = b_je.alloc((n_jobs + 1) * 4))) return rc;
+    if ((rc = b_toff.alloc((n_jobs + 1) * 8))) return rc;
+    if ((rc = b_eoff2.alloc((n_jobs + 1) * 8))) return rc;
+    ExtractArgs xa[2];
+    for (int pass = 0; pass < 2; ++pass) {
+        ExtractArgs &a = xa[pass];
+        a = ExtractArgs{};
+        a.read_off = d_roff;
+        a.read_len = d_rlen;
+        a.packed = d_packed;
+        a.emit_order = d_order;
+        a.n_reads = n_reads;
+        a.aln = pass == 0 ? d_aln1 : d_aln2;
+        a.query_off = pass == 0 ? d_q1 : d_q2;
+        a.diff = pass == 0 ? d_d1 : d_d2;
+        a.colidx_off = (pass == 0 ? b_cio1 : b_cio2).as<uint64_t>();
+        a.colidx = (pass == 0 ? b_ci1 : b_ci2).as<uint2>();
+        a.cov_ok = pass == 0 ? nullptr : b_covok.as<uint8_t>();
+        a.pass = pass;
+        a.topk = pass == 0 ? in->topk_ctg : in->topk_ref;
+        a.ctgs = d_ctg;
+        a.ctg_ent_off = d_eoff;
+        a.ctg_ent = d_ent;
+        a.refs = d_ref;
+        a.solid_bits = g->solid_bits;
+        a.all_solid = g->all_solid;
+        a.k = g->k;
+        a.outer = in->outer_sample;
+        a.job_samples = b_js.as<uint32_t>();
+        a.job_tuples = b_jt.as<uint32_t>();
+        a.job_base = (uint32_t)(pass * 2ull * n_reads);
+        if ((rc = launch_extract(a, false, s))) return rc;
+    }
+    uint64_t T = 0, E = 0, T1 = 0, E1 = 0;
+    if (n_jobs) {
+        edge_counts<<<dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s>>>(b_js.as<uint32_t>(), n_jobs,
+                                                                                 b_je.as<uint32_t>());
+        if ((rc = scan_u32_to_u64(b_jt.as<uint32_t>(), b_toff.as<uint64_t>(), n_jobs, d_tot + 2, b_scan.p, s))) return rc;
+        if ((rc = scan_u32_to_u64(b_je.as<uint32_t>(), b_eoff2.as<uint64_t>(), n_jobs, d_tot + 3, b_scan.p, s))) return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(&T, d_tot + 2, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipMemcpyAsync(&E, d_tot + 3, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipMemcpyAsync(&T1, b_toff.as<uint64_t>() + 2ull * n_reads, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipMemcpyAsync(&E1, b_eoff2.as<uint64_t>() + 2ull * n_reads, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+    }
+
+    // ---- K1 emit
+    DevBuf b_tk0, b_tv0, b_tk1, b_tv1, b_ek0, b_ev0, b_ek1, b_ev1;
+    // the second value buffer of each stream doubles as u64[n] + u32[n] scratch for long segments
+    if ((rc = b_tk0.alloc((T + 1) * 4))) return rc;
+    if ((rc = b_tv0.alloc((T + 1) * 8))) return rc;
+    if ((rc = b_tk1.alloc((T + 1) * 4))) return rc;
+    if ((rc = b_tv1.alloc((T + 1) * 12))) return rc;
+    if ((rc = b_ek0.alloc((E + 1) * 4))) return rc;
+    if ((rc = b_ev0.alloc((E + 1) * 8))) return rc;
+    if ((rc = b_ek1.alloc((E + 1) * 4))) return rc;
+    if ((rc = b_ev1.alloc((E + 1) * 12))) return rc;
+    for (int pass = 0; pass < 2; ++pass) {
+        ExtractArgs &a = xa[pass];
+        a.tuple_off = b_toff.as<uint64_t>();
+        a.edge_off = b_eoff2.as<uint64_t>();
+        a.tkey = b_tk0.as<uint32_t>();
+        a.tval = b_tv0.as<uint64_t>();
+        a.ekey = b_ek0.as<uint32_t>();
+        a.eval = b_ev0.as<uint64_t>();
+        if ((rc = launch_extract(a, true, s))) return rc;
+    }
+    PAG_HIP_TRY(hipEventRecord(ev[1], s));
+
+    const char *keep = std::getenv("PAG_DEBUG_KEEP_STREAMS");
+    g->dbg_tkey.clear();
+    g->dbg_tval.clear();
+    g->dbg_ekey.clear();
+    g->dbg_eval.clear();
+    if (keep && keep[0] == '1') {
+        g->dbg_tkey.resize((size_t)T);
+        g->dbg_tval.resize((size_t)T);
+        g->dbg_ekey.resize((size_t)E);
+        g->dbg_eval.resize((size_t)E);
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (T) PAG_HIP_TRY(hipMemcpy(g->dbg_tkey.data(), b_tk0.p, T * 4, hipMemcpyDeviceToHost));
+        if (T) PAG_HIP_TRY(hipMemcpy(g->dbg_tval.data(), b_tv0.p, T * 8, hipMemcpyDeviceToHost));
+        if (E) PAG_HIP_TRY(hipMemcpy(g->dbg_ekey.data(), b_ek0.p, E * 4, hipMemcpyDeviceToHost));
+        if (E) PAG_HIP_TRY(hipMemcpy(g->dbg_eval.data(), b_ev0.p, E * 8, hipMemcpyDeviceToHost));
+    }
+
+    // ---- K2 sorts
+    DevBuf b_sorttmp;
+    if ((rc = b_sorttmp.alloc(sort_tmp_bytes(std::max(T, E))))) return rc;
+    int t_in0 = 1, e_in0 = 1, passes = 0;
+    float ms_scatter_t = 0.f, ms_scatter_e = 0.f;
+    if ((rc = sort_pairs(b_tk0.as<uint32_t>(), b_tv0.as<uint64_t>(), b_tk1.as<uint32_t>(), b_tv1.as<uint64_t>(), T,
+                         2 * (int)g->k, b_sorttmp.p, &t_in0, s, &ms_scatter_t, &passes)))
+        return rc;
+    if ((rc = sort_pairs(b_ek0.as<uint32_t>(), b_ev0.as<uint64_t>(), b_ek1.as<uint32_t>(), b_ev1.as<uint64_t>(), E,
+                         2 * (int)g->k, b_sorttmp.p, &e_in0, s, &ms_scatter_e, nullptr)))
+        return rc;
+    PAG_HIP_TRY(hipEventRecord(ev[2], s));
+    // make the sorted data live in the (k0, v0)-sized buffers, the spare (v1: 12 B/record) is scratch
+    DevBuf *tk = t_in0 ? &b_tk0 : &b_tk1, *tv = t_in0 ? &b_tv0 : &b_tv1;
+    DevBuf *ek = e_in0 ? &b_ek0 : &b_ek1, *evb = e_in0 ? &b_ev0 : &b_ev1;
+    DevBuf b_tscr, b_escr;
+    uint64_t *t_scratch, *e_scratch;
+    if (t_in0) {
+        t_scratch = b_tv1.as<uint64_t>();
+    } else {  // sorted values sit in the big buffer: give the segment kernels a fresh scratch
+        if ((rc = b_tscr.alloc((T + 1) * 12))) return rc;
+        t_scratch = b_tscr.as<uint64_t>();
+    }
+    if (e_in0) {
+        e_scratch = b_ev1.as<uint64_t>();
+    } else {
+        if ((rc = b_escr.alloc((E + 1) * 12))) return rc;
+        e_scratch = b_escr.as<uint64_t>();
+    }
+
+    // ---- K3 / K4
+    DevBuf b_tseg, b_tcnt, b_eseg, b_long, b_lcnt, b_ctr;
+    if ((rc = b_tseg.alloc((T + 1) * 4))) return rc;
+    if ((rc = b_tcnt.alloc((T + 1) * 2))) return rc;
+    if ((rc = b_eseg.alloc((E + 1) * 4))) return rc;
+    if ((rc = b_long.alloc((std::max(T, E) / 32 + 2) * 8))) return rc;
+    if ((rc = b_lcnt.alloc(64))) return rc;
+    if ((rc = b_ctr.alloc(64))) return rc;
+    ClusterOut co{b_tseg.as<uint32_t>(), b_tcnt.as<uint16_t>(), b_ctr.as<uint64_t>()};
+    if ((rc = launch_cluster(tk->as<uint32_t>(), tv->as<uint64_t>(), t_scratch, T, in->eps, co, b_long.as<uint64_t>(),
+                             b_lcnt.as<uint32_t>(), s)))
+        return rc;
+    uint64_t ctr_t[4] = {0, 0, 0, 0}, ctr_e[4] = {0, 0, 0, 0};
+    PAG_HIP_TRY(hipMemcpyAsync(ctr_t, b_ctr.p, 32, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipEventRecord(ev[3], s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    EdgeOut eo{b_eseg.as<uint32_t>(), b_ctr.as<uint64_t>()};
+    if ((rc = launch_edges(ek->as<uint32_t>(), evb->as<uint64_t>(), e_scratch, E, eo, b_long.as<uint64_t>(),
+                           b_lcnt.as<uint32_t>(), s)))
+        return rc;
+    PAG_HIP_TRY(hipMemcpyAsync(ctr_e, b_ctr.p, 32, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipEventRecord(ev[4], s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+
+    // ---- the reference's count lines (PositionProcessor.cpp:126-142)
+    pag_build_stats st{};
+    const uint64_t T2 = T - T1, E2 = E - E1;
+    const uint64_t L_ctg = ctr_t[0], L_all = ctr_t[1], U_all = ctr_e[0], U_1 = ctr_e[1];
+    st.n_tuples[0] = T1;
+    st.n_tuples[1] = T2;
+    st.n_edges[0] = E1;
+    st.n_edges[1] = E2;
+    st.merge_edge[0] = E1 - U_1;
+    st.total_pos[0] = T1;
+    st.merge_pos[0] = T1 - L_ctg;
+    st.merge_edge[1] = U_1 + E2 - U_all;
+    st.total_pos[1] = L_ctg + T2;
+    st.merge_pos[1] = L_ctg + T2 - L_all;
+    st.n_nodes = ctr_t[2];
+    st.n_pos = L_all;
+    st.n_uniq_edges = U_all;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev[0], ev[1]);
+    st.ms_extract = ms;
+    hipEventElapsedTime(&ms, ev[1], ev[2]);
+    st.ms_sort = ms;
+    hipEventElapsedTime(&ms, ev[2], ev[3]);
+    st.ms_cluster = ms;
+    hipEventElapsedTime(&ms, ev[3], ev[4]);
+    st.ms_edges = ms;
+    hipEventElapsedTime(&ms, ev[0], ev[4]);
+    st.ms_total = ms;
+    st.ms_sort_kernel = ms_scatter_t;
+    st.sort_records = T;
+    (void)passes;
+    (void)ms_scatter_e;
+
+    // ---- keep the finished graph
+    g->n_t = T;
+    g->n_e = E;
+    g->tkey = (uint32_t *)tk->release();
+    g->tval = (uint64_t *)tv->release();
+    g->tseg = (uint32_t *)b_tseg.release();
+    g->tcnt = (uint16_t *)b_tcnt.release();
+    g->ekey = (uint32_t *)ek->release();
+    g->eval = (uint64_t *)evb->release();
+    g->eseg = (uint32_t *)b_eseg.release();
+    g->stats = st;
+    if (stats) *stats = st;
+    return PAG_OK;
+}
+
+int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges) {
+    if (!g) return PAG_EINVAL;
+    if (n_nodes) *n_nodes = g->stats.n_nodes;
+    if (n_pos) *n_pos = g->stats.n_pos;
+    if (n_edges) *n_edges = g->stats.n_uniq_edges;
+    return PAG_OK;
+}
+
+// Compaction of the in-place segment results into a CSR.  Test/host-traversal path, not timed: the
+// streams are copied back and compacted on the host.
+int pag_export_csr(const pag_graph *g, pag_csr *out) {
+    if (!g || !out) return PAG_EINVAL;
+    const uint64_t nn = g->stats.n_nodes, np = g->stats.n_pos, ne = g->stats.n_uniq_edges;
+    if (out->n_nodes < nn || out->n_pos < np || out->n_edges < ne) {
+        out->n_nodes = nn;
+        out->n_pos = np;
+        out->n_edges = ne;
+        return PAG_ERANGE;
+    }
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    const uint64_t T = g->n_t, E = g->n_e;
+    std::vector<uint32_t> tkey((size_t)T), tseg((size_t)T), ekey((size_t)E), eseg((size_t)E);
+    std::vector<uint64_t> tval((size_t)T), eval((size_t)E);
+    std::vector<uint16_t> tcnt((size_t)T);
+    if (T) {
+        PAG_HIP_TRY(hipMemcpy(tkey.data(), g->tkey, T * 4, hipMemcpyDeviceToHost));
+        PAG_HIP_TRY(hipMemcpy(tseg.data(), g->tseg, T * 4, hipMemcpyDeviceToHost));
+        PAG_HIP_TRY(hipMemcpy(tval.data(), g->tval, T * 8, hipMemcpyDeviceToHost));
+        PAG_HIP_TRY(hipMemcpy(tcnt.data(), g->tcnt, T * 2, hipMemcpyDeviceToHost));
+    }
+    if (E) {
+        PAG_HIP_TRY(hipMemcpy(ekey.data(), g->ekey, E * 4, hipMemcpyDeviceToHost));
+        PAG_HIP_TRY(hipMemcpy(eseg.data(), g->eseg, E * 4, hipMemcpyDeviceToHost));
+        PAG_HIP_TRY(hipMemcpy(eval.data(), g->eval, E * 8, hipMemcpyDeviceToHost));
+    }
+    uint64_t in = 0, ip = 0, ie = 0, ecur = 0;
+    for (uint64_t i = 0; i < T; ++i) {
+        if (i != 0 && tkey[i] == tkey[i - 1]) continue;  // not a segment head
+        uint32_t code = tkey[i];
+        if (in >= nn) {
+            set_error("export: more nodes than counted");
+            return PAG_EFAULT;
+        }
+        out->node_code[in] = code;
+        out->pos_off[in] = ip;
+        out->edge_off[in] = ie;
+        for (uint32_t l = 0; l < tseg[i]; ++l) {
+            if (ip >= np) {
+                set_error("export: more positions than counted");
+                return PAG_EFAULT;
+            }
+            out->pos_ctg[ip] = (uint32_t)(tval[i + l] >> 32);
+            out->pos_ref[ip] = (uint32_t)tval[i + l];
+            out->pos_cnt[ip] = tcnt[i + l];
+            ++ip;
+        }
+        // edge segment of the same k-mer, if any (every `from` k-mer also owns positions)
+        while (ecur < E && ekey[ecur] < code) ++ecur;
+        if (ecur < E && ekey[ecur] == code) {
+            for (uint32_t l = 0; l < eseg[ecur]; ++l) {
+                if (ie >= ne) {
+                    set_error("export: more edges than counted");
+                    return PAG_EFAULT;
+                }
+                out->edge_to[ie] = (uint32_t)(eval[ecur + l] >> 32);
+                out->edge_step[ie] = (int32_t)(((uint32_t)eval[ecur + l]) >> 1);
+                ++ie;
+            }
+            while (ecur < E && ekey[ecur] == code) ++ecur;
+        }
+        ++in;
+    }
+    out->pos_off[in] = ip;
+    out->edge_off[in] = ie;
+    out->n_nodes = in;
+    out->n_pos = ip;
+    out->n_edges = ie;
+    if (in != nn || ip != np || ie != ne) {
+        set_error("export: size mismatch nodes %llu/%llu pos %llu/%llu edges %llu/%llu", (unsigned long long)in,
+                  (unsigned long long)nn, (unsigned long long)ip, (unsigned long long)np, (unsigned long long)ie,
+                  (unsigned long long)ne);
+        return PAG_EFAULT;
+    }
+    return PAG_OK;
+}
+
+// test hook: raw emitted streams of the last pag_process (needs PAG_DEBUG_KEEP_STREAMS=1)
+int pag_debug_stream_sizes(const pag_graph *g, uint64_t *n_tuples, uint64_t *n_edges) {
+    if (!g) return PAG_EINVAL;
+    *n_tuples = g->dbg_tkey.size();
+    *n_edges = g->dbg_ekey.size();
+    return PAG_OK;
+}
+int pag_debug_streams(const pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval) {
+    if (!g) return PAG_EINVAL;
+    std::memcpy(tkey, g->dbg_tkey.data(), g->dbg_tkey.size() * 4);
+    std::memcpy(tval, g->dbg_tval.data(), g->dbg_tval.size() * 8);
+    std::memcpy(ekey, g->dbg_ekey.data(), g->dbg_ekey.size() * 4);
+    std::memcpy(eval, g->dbg_eval.data(), g->dbg_eval.size() * 8);
+    return PAG_OK;
+}
+
+}  // extern "C"

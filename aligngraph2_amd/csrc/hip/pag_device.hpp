@@ -1,0 +1,143 @@
+// Internal header of libpagraph_hip.so: device helpers shared by the kernels + launcher prototypes.
+// gfx950 only: wavefront = 64 lanes everywhere (no 32-wide paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pagraph_hip.h"
+
+#define PAG_WAVE 64
+
+namespace pagdev {
+
+// ---------------------------------------------------------------- error plumbing (host side)
+void set_error(const char *fmt, ...);
+const char *last_error();
+#define PAG_HIP_TRY(expr)                                                                 \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            pagdev::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PAG_EFAULT;                                                            \
+        }                                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------- wave-level primitives (device)
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// exclusive prefix sum across the 64 lanes of a wave; *total receives the wave sum
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t *total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane_id() >= d) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+__device__ __forceinline__ uint64_t wave_excl_sum64(uint64_t v, uint64_t *total) {
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t y = __shfl_up(x, d, 64);
+        if ((int)lane_id() >= d) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// reverse the order of the sixteen 2-bit groups of a 32-bit word
+__device__ __forceinline__ uint32_t rev2(uint32_t x) {
+    x = __brev(x);
+    return ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+}
+#endif
+
+// ---------------------------------------------------------------- launchers (host side, defined in *.hip)
+
+// exclusive prefix sum of n u32 values into u64 (out[i] = sum of in[0..i)); *total_dev (device u64) gets the sum.
+// tmp must hold scan_tmp_bytes(n) bytes.
+size_t scan_tmp_bytes(uint64_t n);
+int scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *total_dev, void *tmp, hipStream_t s);
+
+// stable LSD radix sort of (u32 key, u64 value) pairs on key bits [0, key_bits).  Ping-pongs between
+// (k0, v0) and (k1, v1); returns in *result_in_0 which pair holds the result.  tmp: sort_tmp_bytes(n).
+size_t sort_tmp_bytes(uint64_t n);
+int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t n, int key_bits, void *tmp,
+               int *result_in_0, hipStream_t s, float *ms_dominant_kernel, int *n_passes);
+
+struct ExtractArgs {
+    // reads
+    const uint64_t *read_off;
+    const uint32_t *read_len;
+    const uint8_t *packed;
+    const uint32_t *emit_order;
+    uint32_t n_reads;
+    // alignment database of this pass
+    const pag_aln *aln;
+    const uint64_t *query_off;
+    const uint32_t *diff;
+    const uint64_t *colidx_off;  // [n_aln] first entry of each alignment in colidx
+    const uint2 *colidx;         // per 1024-column chunk (walk order): (emits before, target advances before)
+    const uint8_t *cov_ok;       // pass 2 only: 1 = alignment passes the coverage filter; nullptr = all pass
+    int pass;                    // 0 = read->contig, 1 = read->reference
+    int topk;
+    const pag_ctg *ctgs;
+    const uint32_t *ctg_ent_off;
+    const uint32_t *ctg_ent;
+    const pag_ref *refs;
+    // solid set
+    const uint32_t *solid_bits;
+    int all_solid;
+    uint32_t k;
+    uint32_t outer;
+    // outputs
+    uint32_t *job_samples;  // count mode: per job (2 per read: forward, reverse strand)
+    uint32_t *job_tuples;
+    const uint64_t *tuple_off;  // emit mode: exclusive prefix over jobs (global, both passes)
+    const uint64_t *edge_off;
+    uint32_t *tkey;
+    uint64_t *tval;
+    uint32_t *ekey;
+    uint64_t *eval;
+    uint32_t job_base;  // index of this pass's first job in the per-job arrays
+};
+int launch_colidx(const pag_aln *aln, uint64_t n_aln, const uint32_t *diff, const uint64_t *colidx_off, uint2 *colidx,
+                  hipStream_t s);
+int launch_extract(const ExtractArgs &a, bool emit, hipStream_t s);
+
+// coverage filter (pass 2): cov_ok[i] for every alignment
+int launch_cov_filter(const pag_aln *aln, uint64_t n_aln, const pag_ref *refs_dev, const pag_ref *refs_host,
+                      uint64_t n_refs, uint32_t cov_filter, uint8_t *cov_ok, void *tmp, size_t tmp_bytes,
+                      hipStream_t s);
+size_t cov_tmp_bytes(const pag_ref *refs_host, uint64_t n_refs);
+
+// cluster + sort positions inside each k-mer segment of the sorted tuple stream (in place in `val`)
+struct ClusterOut {
+    uint32_t *seg_len;  // [n] leaders of the segment starting at i (0 when i is not a segment head)
+    uint16_t *cnt;      // [n] abundance of the leader stored at i
+    uint64_t *counters; // device: [0] leaders with ctg != 0, [1] all leaders, [2] segments
+};
+int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, uint32_t eps, ClusterOut out,
+                   uint64_t *long_list, uint32_t *long_count, hipStream_t s);
+
+// sort + unique the (to, step, pass-tag) payloads inside each `from` segment of the sorted edge stream
+struct EdgeOut {
+    uint32_t *seg_len;  // [n] unique edges of the segment starting at i (0 when i is not a head)
+    uint64_t *counters; // device: [0] unique (to,step) groups, [1] groups whose first member is pass 1
+};
+int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, EdgeOut out, uint64_t *long_list,
+                 uint32_t *long_count, hipStream_t s);
+
+}  // namespace pagdev

@@ -112,6 +112,7 @@ AlnDb::AlnDb(const std::string &path, Flavor flavor) {
         }
     }
     sortByScore();
+    diff_.resize(diff_.size() + 4, 0);  // kernels may read one word past an alignment
 }
 
 }  // namespace pagh

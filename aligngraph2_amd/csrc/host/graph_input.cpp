@@ -90,6 +90,7 @@ void GraphInput::buildCtgMap(const SeqDb &ctgs, const SeqDb &refs, const AlnDb &
             ctgEntOff_.push_back(fitU32(run, "contig map offset"));
             cursor[b] = static_cast<std::uint32_t>(run);
             run += cnt[b] ? cnt[b] : 1;
+            if (cnt[b] > 1) t.multi = 1;
         }
         ctgEntOff_.push_back(fitU32(run, "contig map offset"));
         ctgEnt_.resize(run, 0);

@@ -90,7 +90,7 @@ typedef struct pag_ctg {
     uint32_t len;
     uint32_t selected; /* Aligner::_ctgFilterFlag */
     uint32_t single_base;
-    uint32_t reserved;
+    uint32_t multi;   /* 1 if some base of the selected orientation has more than one entry */
     uint64_t map_off; /* index of base 0 of this contig in ctg_ent_off (selected contigs only) */
 } pag_ctg;
 

@@ -39,6 +39,11 @@ struct pago_graph {
     uint64_t n_solid;
     uint64_t *codes; /* sorted unique = _kmerIndexArr (graph/PABruijnGraph.cpp:32-37) */
     node *nodes;     /* dense table */
+    /* optional record of the emitted streams, same encoding as the HIP library's debug hook */
+    int dbg;
+    uint32_t *dbg_tkey, *dbg_ekey;
+    uint64_t *dbg_tval, *dbg_eval;
+    size_t dbg_nt, dbg_ct, dbg_ne, dbg_ce;
 };
 
 #define GROW(ptr, n, cap, type)                                  \
@@ -117,6 +122,21 @@ static void node_free(node *nd) {
 /* graph/PABruijnGraph.cpp:310-318 resetAllNodes */
 int pago_reset(pago_graph *g) {
     for (uint64_t i = 0; i < g->n_solid; ++i) node_free(&g->nodes[i]);
+    g->dbg_nt = g->dbg_ne = 0;
+    return PAG_OK;
+}
+
+void pago_debug_enable(pago_graph *g, int on) { g->dbg = on; }
+int pago_debug_stream_sizes(const pago_graph *g, uint64_t *n_tuples, uint64_t *n_edges) {
+    *n_tuples = g->dbg_nt;
+    *n_edges = g->dbg_ne;
+    return PAG_OK;
+}
+int pago_debug_streams(const pago_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval) {
+    memcpy(tkey, g->dbg_tkey, g->dbg_nt * 4);
+    memcpy(tval, g->dbg_tval, g->dbg_nt * 8);
+    memcpy(ekey, g->dbg_ekey, g->dbg_ne * 4);
+    memcpy(eval, g->dbg_eval, g->dbg_ne * 8);
     return PAG_OK;
 }
 
@@ -125,6 +145,10 @@ void pago_destroy(pago_graph *g) {
     pago_reset(g);
     free(g->nodes);
     free(g->codes);
+    free(g->dbg_tkey);
+    free(g->dbg_tval);
+    free(g->dbg_ekey);
+    free(g->dbg_eval);
     free(g);
 }
 
@@ -302,7 +326,7 @@ static void qv_push(qpos_vec *v, uint32_t q, uint32_t ctg, uint32_t ref) {
  * `items` holds (read position, DualPos) in append order; per-base lists are recovered with a stable
  * counting sort on the read position. */
 static void add_position_and_edge(pago_graph *g, const char *seq, uint64_t len, const qpos_vec *items,
-                                  uint32_t outer_sample, uint64_t *n_tuples, uint64_t *n_edges) {
+                                  uint32_t outer_sample, uint64_t *n_tuples, uint64_t *n_edges, int pass) {
     uint32_t k = g->k;
     if (len < k) return;
     uint64_t n_codes = len - k + 1;
@@ -332,9 +356,31 @@ static void add_position_and_edge(pago_graph *g, const char *seq, uint64_t len, 
         last = (int64_t)i;
         node_add_positions(&g->nodes[idx], lists + off[i], (size_t)(off[i + 1] - off[i]));
         *n_tuples += off[i + 1] - off[i];
+        if (g->dbg) {
+            for (uint64_t x = off[i]; x < off[i + 1]; ++x) {
+                if (g->dbg_nt == g->dbg_ct) {
+                    g->dbg_ct = g->dbg_ct ? g->dbg_ct * 2 : 1024;
+                    g->dbg_tkey = (uint32_t *)realloc(g->dbg_tkey, g->dbg_ct * 4);
+                    g->dbg_tval = (uint64_t *)realloc(g->dbg_tval, g->dbg_ct * 8);
+                }
+                g->dbg_tkey[g->dbg_nt] = (uint32_t)codes[i];
+                g->dbg_tval[g->dbg_nt] = ((uint64_t)lists[x].ctg << 32) | lists[x].ref;
+                g->dbg_nt++;
+            }
+        }
         if (prev_idx >= 0) {
             node_add_child(&g->nodes[prev_idx], (uint64_t)idx, (int)(i - prev_pos));
             *n_edges += 1;
+            if (g->dbg) {
+                if (g->dbg_ne == g->dbg_ce) {
+                    g->dbg_ce = g->dbg_ce ? g->dbg_ce * 2 : 1024;
+                    g->dbg_ekey = (uint32_t *)realloc(g->dbg_ekey, g->dbg_ce * 4);
+                    g->dbg_eval = (uint64_t *)realloc(g->dbg_eval, g->dbg_ce * 8);
+                }
+                g->dbg_ekey[g->dbg_ne] = (uint32_t)g->codes[prev_idx];
+                g->dbg_eval[g->dbg_ne] = ((uint64_t)codes[i] << 32) | ((uint64_t)(i - prev_pos) << 1) | (uint64_t)pass;
+                g->dbg_ne++;
+            }
         }
         prev_idx = idx;
         prev_pos = i;
@@ -440,7 +486,7 @@ int pago_process(pago_graph *g, const pag_build_input *in, pag_build_stats *st) 
             for (int s = 0; s < 2; ++s) {
                 if (!useful[s]) continue;
                 read_to_string(reads, r, s == 0, seq);
-                add_position_and_edge(g, seq, len, &items[s], in->outer_sample, &st->n_tuples[pass], &st->n_edges[pass]);
+                add_position_and_edge(g, seq, len, &items[s], in->outer_sample, &st->n_tuples[pass], &st->n_edges[pass], pass);
             }
         }
         /* mergeEdge / totalPosition / mergeKmerPosition (graph/PABruijnGraph.cpp:285-297, 320-331, 259-274) */

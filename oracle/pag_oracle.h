@@ -30,6 +30,12 @@ int pago_process(pago_graph *g, const pag_build_input *in, pag_build_stats *stat
 int pago_csr_sizes(const pago_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);
 int pago_export_csr(const pago_graph *g, pag_csr *out);
 
+/* emitted streams in canonical order (for stage-by-stage comparison with the HIP library's
+ * pag_debug_streams): tval = ctgSingle << 32 | refSingle; eval = toCode << 32 | step << 1 | pass */
+void pago_debug_enable(pago_graph *g, int on);
+int pago_debug_stream_sizes(const pago_graph *g, uint64_t *n_tuples, uint64_t *n_edges);
+int pago_debug_streams(const pago_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval);
+
 /* function-level seams, exposed for known-answer tests */
 /* KmerHelper::kmer2Code (KmerHelper.cpp:7-25): writes len-k+1 codes, returns the count */
 uint64_t pago_kmer_codes(const char *seq, uint64_t len, uint32_t k, uint64_t *out);

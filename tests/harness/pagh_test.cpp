@@ -1,0 +1,65 @@
+// tests/harness/pagh_test.cpp — TEST SUPPORT (never part of the product).
+// Thin C wrapper over the product's host input pipeline so that Python tests (ctypes) can load a
+// pagraph input directory and hand the SAME flat pag_build_input to both the HIP library and the oracle.
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <memory>
+#include <string>
+
+#include "config.hpp"
+#include "graph_input.hpp"
+#include "kmer_file.hpp"
+
+namespace {
+struct Loaded {
+    std::unique_ptr<pagh::KmerFile> kmers;
+    std::unique_ptr<pagh::SeqDb> reads, ctgs, refs;
+    std::unique_ptr<pagh::AlnDb> readToCtg, readToRef, ctgToRef;
+    std::unique_ptr<pagh::GraphInput> input;
+};
+}  // namespace
+
+extern "C" {
+
+void *pagh_load(const char *dir, unsigned block, unsigned threads, uint64_t eps, uint64_t cov) {
+    try {
+        std::string d(dir);
+        auto L = std::make_unique<Loaded>();
+        auto blocks = pagh::loadConfig(d + "/config.txt");
+        if (block >= blocks.size()) return nullptr;
+        const auto &b = blocks[block];
+        L->kmers = std::make_unique<pagh::KmerFile>(d + "/kmer.bin");
+        L->ctgs = std::make_unique<pagh::SeqDb>(d + "/ctg.fasta");
+        L->refs = std::make_unique<pagh::SeqDb>(d + "/ref.fasta");
+        L->ctgToRef = std::make_unique<pagh::AlnDb>(d + "/aln", pagh::AlnDb::Flavor::MummerV2);
+        L->reads = std::make_unique<pagh::SeqDb>(d + "/" + b.readPath);
+        L->readToCtg = std::make_unique<pagh::AlnDb>(d + "/" + b.ctgAlnPath, pagh::AlnDb::Flavor::Mecat);
+        L->readToRef = std::make_unique<pagh::AlnDb>(d + "/" + b.refAlnPath, pagh::AlnDb::Flavor::Mecat);
+        pagh::BuildParams p;
+        p.threads = threads;
+        p.epsilon = eps;
+        p.covFilter = cov;
+        L->input = std::make_unique<pagh::GraphInput>(*L->reads, *L->ctgs, *L->refs, *L->readToCtg, *L->readToRef,
+                                                      *L->ctgToRef, b, p);
+        return L.release();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "pagh_load: %s\n", e.what());
+        return nullptr;
+    }
+}
+
+const pag_build_input *pagh_view(void *h) { return &static_cast<Loaded *>(h)->input->view(); }
+
+const uint64_t *pagh_kmer_words(void *h, uint64_t *n, uint64_t *k) {
+    auto *L = static_cast<Loaded *>(h);
+    *n = L->kmers->words().size();
+    *k = L->kmers->k();
+    return L->kmers->words().data();
+}
+
+uint64_t pagh_total_read_bases(void *h) { return static_cast<Loaded *>(h)->reads->totalBases(); }
+
+void pagh_free(void *h) { delete static_cast<Loaded *>(h); }
+
+}  // extern "C"
