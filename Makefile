@@ -47,7 +47,7 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 	@mkdir -p $(B)
 	$(CC) -O2 -std=c99 -Wall -Wextra -fPIC -Iinclude -c $< -o $@
 
-HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so
+HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle
 harness: $(HARNESS)
 
 tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(B)/libpagh_host.a $(B)/pag_oracle.o
@@ -57,6 +57,11 @@ tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(B)/li
 tests/harness/bin/libpagh_test.so: tests/harness/pagh_test.cpp $(B)/libpagh_host.a
 	@mkdir -p tests/harness/bin
 	$(CXX) $(CXXFLAGS) -shared -o $@ $< $(B)/libpagh_host.a
+
+HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o,$(HOST_OBJS))
+tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
+	@mkdir -p tests/harness/bin
+	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o -lm -pthread
 
 clean:
 	rm -rf $(B) aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin tests/harness/bin

@@ -1,0 +1,224 @@
+#include "assembly.hpp"
+
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <vector>
+
+#include "traversal.hpp"
+
+namespace pagh {
+
+namespace {
+
+// UnionSet (UnionSet.cpp:7-20)
+struct UnionSet {
+    std::vector<std::size_t> parent;
+    explicit UnionSet(std::size_t n) : parent(n) {
+        for (std::size_t i = 0; i < n; ++i) parent[i] = i;
+    }
+    std::size_t find(std::size_t p) { return p == parent[p] ? p : (parent[p] = find(parent[p])); }
+    void unionTwo(std::size_t left, std::size_t right) { parent[find(right)] = find(left); }
+};
+
+// PAssembly::combatSeq (PAssembly.tcc:2-31): follow the chain of leaps from contig to contig
+template <typename F>
+void combatSeq(const std::vector<TravelSequence> &seqs, const HostGraph &g, const PositionMapper &mapper, std::size_t start,
+               bool forward, F functor) {
+    std::size_t nextIdx = start * 2 + (forward ? 0 : 1);
+    std::size_t nextPos = 0;
+    std::set<std::size_t> seen;
+    seen.insert(nextIdx);
+    while (true) {
+        if (!functor(nextIdx / 2, nextIdx % 2 == 0, nextPos)) break;
+        if (seqs[nextIdx].empty() || g.position(seqs[nextIdx].back().first).first == 0) break;
+        auto last = mapper.singleToDual(g.position(seqs[nextIdx].back().first).first);
+        nextPos = static_cast<std::size_t>(last.second);
+        nextIdx = static_cast<std::size_t>(std::llabs(last.first) - 1) * 2 + (last.first > 0 ? 0 : 1);
+        if (seen.count(nextIdx) > 0) break;
+        seen.insert(nextIdx);
+    }
+}
+
+}  // namespace
+
+std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const std::string &prefix, const HostGraph &graph,
+                                                const SeqDb &contigs, const SeqDb &refs, const PositionMapper &ctgMapper,
+                                                const PositionMapper &refMapper,
+                                                const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
+                                                double errorRate, double startSplit, std::size_t minLen, unsigned threadNum) {
+    std::set<std::pair<std::string, bool>> success;
+    std::vector<TravelSequence> results(contigs.size() * 2);
+    std::vector<std::size_t> inDegrees(contigs.size() * 2);
+
+    // per selected contig: traverse, dump the path, drop short paths, count leap targets
+    // (PAssembly.cpp:30-79; the reference spreads this loop over max(1, t/8) threads, output-neutral)
+    for (auto &ctgName : ctgSet) {
+        std::size_t ctgIdx = contigs.id(ctgName.first);
+        std::size_t ctgOffset = ctgName.second ? 0 : 1;
+        std::string log;
+        Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum, &log);
+        std::cout << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << std::endl;
+        std::cout << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << std::endl;
+        auto &res = results[2 * ctgIdx + ctgOffset];
+        res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
+        std::cout << log;
+
+        std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
+        of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
+        for (auto &s : res) {
+            DualPos p = graph.position(s.first);
+            auto d1 = ctgMapper.singleToDual(p.first);
+            auto d2 = refMapper.singleToDual(p.second);
+            of << algo.vertexString(s.first) << "\t" << s.second << "\t" << d1.first << "," << d1.second << "\t" << d2.first
+               << "," << d2.second << "\n";
+        }
+        if (Traversal::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
+        if (!res.empty()) {
+            std::uint32_t lastCtgPos = graph.position(res.back().first).first;
+            if (lastCtgPos != 0) {
+                auto dual = ctgMapper.singleToDual(lastCtgPos);
+                std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
+                std::size_t fwd = dual.first > 0 ? 0 : 1;
+                if (idx != ctgIdx || fwd != ctgOffset) ++inDegrees[2 * idx + fwd];
+            }
+        }
+        std::cout << "[Travel] End" << std::endl;
+    }
+
+    // leaps into contigs whose own path was dropped are cut off again (PAssembly.cpp:129-150)
+    for (auto &ctgName : ctgSet) {
+        std::size_t ctgIdx = contigs.id(ctgName.first);
+        std::size_t ctgOffset = ctgName.second ? 0 : 1;
+        auto &res = results[2 * ctgIdx + ctgOffset];
+        if (res.empty()) continue;
+        std::uint32_t lastCtgPos = graph.position(res.back().first).first;
+        if (lastCtgPos == 0) continue;
+        auto dual = ctgMapper.singleToDual(lastCtgPos);
+        std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
+        std::size_t fwd = dual.first > 0 ? 0 : 1;
+        if ((idx != ctgIdx || fwd != ctgOffset) && results[2 * idx + fwd].empty()) {
+            res.pop_back();
+            --inDegrees[2 * idx + fwd];
+        }
+    }
+    for (std::size_t i = 0; i < inDegrees.size(); ++i)
+        if (inDegrees[i] > 0)
+            std::cout << "\t" << (i / 2) << " " << (i % 2 == 0 ? "forward" : "reverse") << " " << inDegrees[i] << std::endl;
+
+    // union-find over chained contigs (PAssembly.cpp:160-198)
+    std::cout << "[Union] Start" << std::endl;
+    std::map<std::pair<std::string, bool>, std::size_t> helper;
+    std::vector<std::pair<std::string, bool>> table;
+    for (auto &c : ctgSet) {
+        helper[c] = table.size();
+        table.push_back(c);
+    }
+    std::vector<bool> touched(helper.size(), false);
+    UnionSet us(helper.size());
+    for (auto &ctgName : ctgSet) {
+        std::size_t ctgIdx = contigs.id(ctgName.first);
+        std::size_t i = ctgIdx * 2 + (ctgName.second ? 0 : 1);
+        if (inDegrees[i] > 0 || results[i].empty()) continue;
+        std::size_t mainIdx = helper[ctgName];
+        touched[mainIdx] = true;
+        combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
+            if (ctgId != ctgIdx || forward != ctgName.second) {
+                std::size_t h = helper[{contigs.name(ctgId), forward}];  // operator[]: inserts 0 for unknown pairs, as the reference
+                us.unionTwo(h, mainIdx);
+                if (touched[h]) return false;
+                touched[h] = true;
+                return true;
+            }
+            return true;
+        });
+    }
+    std::vector<std::vector<std::size_t>> merged(helper.size());
+    for (std::size_t i = 0; i < table.size(); ++i) merged[us.find(i)].push_back(i);
+
+    // per group keep the start with the longest chain (PAssembly.cpp:207-232)
+    std::set<std::pair<std::string, bool>> starts;
+    for (auto &group : merged) {
+        if (group.empty()) continue;
+        std::size_t maxSize = 0, chosen = group.front();
+        for (auto idx : group) {
+            auto &ctgName = table[idx];
+            std::size_t ctgIdx = contigs.id(ctgName.first);
+            std::size_t i = ctgIdx * 2 + (ctgName.second ? 0 : 1);
+            if (inDegrees[i] > 0 || results[i].empty()) continue;
+            std::size_t len = 0;
+            combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool, std::size_t) -> bool {
+                len += contigs.length(ctgId);
+                return true;
+            });
+            if (len > maxSize) {
+                maxSize = len;
+                chosen = idx;
+            }
+        }
+        starts.insert(table[chosen]);
+    }
+    std::cout << "[Union] End" << std::endl;
+    std::cout << "Start From:" << std::endl;
+    for (auto &c : starts) std::cout << "\t" << c.first << " " << c.second << std::endl;
+
+    // emit chains (PAssembly.cpp:242-333)
+    std::cout << "[Assembly] Start" << std::endl;
+    std::size_t nameCnt = 0;
+    Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum);
+    for (auto &ctgName : starts) {
+        std::size_t ctgIdx = contigs.id(ctgName.first);
+        std::size_t i = ctgIdx * 2 + (ctgName.second ? 0 : 1);
+        if (inDegrees[i] > 0 || results[i].empty()) continue;
+        std::string name = prefix + std::to_string(nameCnt++);
+
+        std::set<std::pair<std::size_t, bool>> connected;
+        std::size_t maxLen = 0, totalLen = 0;
+        combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
+            connected.emplace(ctgId, forward);
+            maxLen = std::max<std::size_t>(maxLen, contigs.length(ctgId));
+            totalLen += Traversal::seqSize(results[ctgId * 2 + (forward ? 0 : 1)]);
+            return true;
+        });
+        bool isConnected = connected.size() > 1 && totalLen > maxLen * 1.05;
+        bool isExtended = connected.size() == 1 && Traversal::seqSize(results[i]) > contigs.length(ctgIdx) * 1.2;
+        if (!(isConnected || isExtended)) {
+            std::cout << "Ignore output" << std::endl;
+            continue;
+        }
+        const std::size_t lineSize = 70;
+        std::string base = outDir + "/" + prefix + std::to_string(i / 2) + "_" + std::to_string(i % 2);
+        {
+            std::ofstream help(base + ".help");
+            help << totalLen << "\n" << maxLen << "\n";
+        }
+        std::ofstream fasta(base + ".fasta");
+        std::ofstream con(base + ".con");
+        fasta << ">" << name << "\n";
+        std::size_t cnt = 0, cmbLen = 0;
+        std::vector<std::pair<std::pair<std::string, bool>, std::size_t>> conInf;
+        combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
+            std::cout << i << "=" << ctgId << std::endl;
+            conInf.push_back({{contigs.name(ctgId), forward}, contigs.length(ctgId)});
+            for (char ch : algo.seqToString(results[ctgId * 2 + (forward ? 0 : 1)], deviation, errorRate)) {
+                fasta << ch;
+                ++cmbLen;
+                if (++cnt % lineSize == 0) {
+                    fasta << "\n";
+                    cnt = 0;
+                }
+            }
+            return true;
+        });
+        if (cnt > 0) fasta << "\n";
+        con << name << "\t" << cmbLen << "\n";
+        for (auto &c : conInf) con << c.first.first << "\t" << (c.first.second ? "FORWARD" : "REV") << "\t" << c.second << "\n";
+        std::cout << "Out file: " << base << ".fasta" << std::endl;
+        for (auto &s : connected) success.emplace(contigs.name(s.first), s.second);
+    }
+    return success;
+}
+
+}  // namespace pagh

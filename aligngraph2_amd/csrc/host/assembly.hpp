@@ -1,0 +1,22 @@
+// Per-contig traversal driver, chain selection and output writers.
+// Restates PAssembly::testTravel5 + combatSeq + UnionSet (reference PAGraph/src/tools/graph/
+// PAssembly.cpp:11-336, PAssembly.tcc:2-31, UnionSet.cpp:7-20).
+#pragma once
+#include <set>
+#include <string>
+#include <utility>
+
+#include "host_graph.hpp"
+#include "position_mapper.hpp"
+#include "seq_db.hpp"
+
+namespace pagh {
+
+// returns the (contig name, forward) pairs consumed by emitted chains
+std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const std::string &prefix, const HostGraph &graph,
+                                                const SeqDb &contigs, const SeqDb &refs, const PositionMapper &ctgMapper,
+                                                const PositionMapper &refMapper,
+                                                const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
+                                                double errorRate, double startSplit, std::size_t minLen, unsigned threadNum);
+
+}  // namespace pagh

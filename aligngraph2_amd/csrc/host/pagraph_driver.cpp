@@ -1,0 +1,207 @@
+#include "pagraph_driver.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <unordered_set>
+
+#include "aln_db.hpp"
+#include "assembly.hpp"
+#include "config.hpp"
+#include "graph_input.hpp"
+#include "kmer_file.hpp"
+#include "seq_db.hpp"
+
+namespace pagh {
+
+namespace {
+
+struct Options {
+    unsigned threads = 16;
+    std::string kmer, read, contig, ref, pre, aln, out;
+    std::size_t minLen = 50, epsilon = 10, cov = 1;
+};
+
+void usage(std::ostream &os) {
+    os << "  pagraph {OPTIONS}\n\n  OPTIONS:\n\n"
+          "      -h, --help                        display this help menu\n"
+          "      -t[thread_num], --thread=[thread_num]   number of thread\n"
+          "      -k[path], --kmer=[path]           solid kmer set path\n"
+          "      -r[path], --read=[path]           read path\n"
+          "      -c[path], --contig=[path]         contig path\n"
+          "      -R[path], --ref=[path]            reference path\n"
+          "      -p[path], --pre_process=[path]    pre process directory\n"
+          "      -a[path], --aln=[path]            alignment path of contig to reference\n"
+          "      -o[path], --output=[path]         output directory\n"
+          "      -l[len], --length=[len]           minimum path length\n"
+          "      --epsilon=[dist]                  distance to join vertices\n"
+          "      -v[cov]                           coverage to filter\n";
+}
+
+struct ParseError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct HelpRequested {};
+
+template <typename T>
+T parseNumber(const std::string &flag, const std::string &v) {
+    // args.hxx reads values with an istream extraction and rejects leftovers
+    std::istringstream ss(v);
+    T x{};
+    ss >> x;
+    if (ss.fail() || ss.rdbuf()->in_avail() != 0)
+        throw ParseError("Argument '" + flag + "' received invalid value type '" + v + "'");
+    return x;
+}
+
+// Same surface as the args.hxx parser the reference uses (pagraph.cpp:71-99): "-t 16", "-t16",
+// "--thread 16", "--thread=16"; repeated flags are allowed and the last one wins (AlignGraph2.py passes
+// -r twice); unknown flags and stray positionals are errors; -h / --help prints the usage.
+Options parseCli(int argc, char **argv) {
+    Options o;
+    auto assign = [&](const std::string &name, const std::string &value) {
+        if (name == "t" || name == "thread") o.threads = parseNumber<unsigned>(name, value);
+        else if (name == "k" || name == "kmer") o.kmer = value;
+        else if (name == "r" || name == "read") o.read = value;
+        else if (name == "c" || name == "contig") o.contig = value;
+        else if (name == "R" || name == "ref") o.ref = value;
+        else if (name == "p" || name == "pre_process") o.pre = value;
+        else if (name == "a" || name == "aln") o.aln = value;
+        else if (name == "o" || name == "output") o.out = value;
+        else if (name == "l" || name == "length") o.minLen = parseNumber<std::size_t>(name, value);
+        else if (name == "epsilon") o.epsilon = parseNumber<std::size_t>(name, value);
+        else if (name == "v") o.cov = parseNumber<std::size_t>(name, value);
+        else throw ParseError("Flag could not be matched: " + name);
+    };
+    auto isLong = [](const std::string &n) {
+        static const char *names[] = {"thread", "kmer", "read", "contig", "ref", "pre_process", "aln", "output", "length", "epsilon"};
+        for (auto *x : names) if (n == x) return true;
+        return false;
+    };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-h" || a == "--help") throw HelpRequested{};
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            std::string body = a.substr(2), value;
+            auto eq = body.find('=');
+            if (eq != std::string::npos) {
+                value = body.substr(eq + 1);
+                body = body.substr(0, eq);
+                if (!isLong(body)) throw ParseError("Flag could not be matched: " + body);
+            } else {
+                if (!isLong(body)) throw ParseError("Flag could not be matched: " + body);
+                if (i + 1 >= argc) throw ParseError("Flag '" + body + "' requires an argument but received none");
+                value = argv[++i];
+            }
+            assign(body, value);
+        } else if (a.size() >= 2 && a[0] == '-') {
+            std::string name(1, a[1]);
+            if (std::strchr("tkrcRpaolv", a[1]) == nullptr) throw ParseError("Flag could not be matched: '" + name + "'");
+            std::string value;
+            if (a.size() > 2) {
+                value = a.substr(2);
+            } else {
+                if (i + 1 >= argc) throw ParseError("Flag '" + name + "' requires an argument but received none");
+                value = argv[++i];
+            }
+            assign(name, value);
+        } else {
+            throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + a);
+        }
+    }
+    return o;
+}
+
+}  // namespace
+
+int runPagraph(int argc, char **argv, GraphBackend &backend) {
+    if (argc <= 1) {
+        usage(std::cerr);
+        return 0;
+    }
+    Options opt;
+    try {
+        opt = parseCli(argc, argv);
+    } catch (const HelpRequested &) {
+        usage(std::cerr);
+        return 0;
+    } catch (const ParseError &e) {
+        std::cerr << e.what() << std::endl;
+        usage(std::cerr);
+        return 1;
+    }
+
+    try {
+        BuildParams params;
+        params.threads = opt.threads;
+        params.epsilon = opt.epsilon;
+        params.covFilter = opt.cov;
+        const double errorRate = 0.15, startSplit = 0.90;
+
+        std::cout << "Loading config.txt" << std::endl;
+        auto configs = loadConfig(opt.pre + "/config.txt");
+        std::cout << "Loading KMer" << std::endl;
+        KmerFile kmers(opt.kmer);
+        std::cout << "Done! k=" << kmers.k() << std::endl;
+        std::cout << "Loading Contigs" << std::endl;
+        SeqDb contigs(opt.contig);
+        std::cout << "Done! contigs number=" << contigs.size() << std::endl;
+        std::cout << "Loading References" << std::endl;
+        SeqDb refs(opt.ref);
+        std::cout << "Done! reference number=" << refs.size() << std::endl;
+        std::cout << "Loading ContigToRef" << std::endl;
+        AlnDb ctgToRef(opt.aln, AlnDb::Flavor::MummerV2);
+        std::cout << "Done! number=" << ctgToRef.size() << std::endl;
+        std::cout << "Building original pa Graph [" << backend.name() << "]" << std::endl;
+        backend.create(kmers.words(), static_cast<unsigned>(kmers.k()));
+        std::cout << "Done! kmer number=" << backend.solidCount() << std::endl;
+
+        std::unordered_set<std::string> okCtg;  // same container as the reference: contig.txt order (quirk Q11)
+        std::size_t blockNo = 0;
+        for (auto &cfg : configs) {
+            backend.reset();
+            std::cout << "Use Ref: " << cfg.ref << std::endl;
+            SeqDb reads(opt.pre + "/" + cfg.readPath);
+            std::cout << "Done! reads number=" << reads.size() << std::endl;
+            AlnDb readToCtg(opt.pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat);
+            std::cout << "Done! aln number=" << readToCtg.size() << std::endl;
+            AlnDb readToRef(opt.pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat);
+            std::cout << "Done! aln number=" << readToRef.size() << std::endl;
+
+            std::cout << "Pre Process" << std::endl;
+            GraphInput input(reads, contigs, refs, readToCtg, readToRef, ctgToRef, cfg, params);
+            std::set<std::pair<std::string, bool>> usedCtg;
+            for (auto &c : cfg.contigs) usedCtg.emplace(c);
+
+            std::cout << "[PositionProcessor] Running read to contig..." << std::endl;
+            pag_build_stats st{};
+            backend.process(input.view(), st);
+            std::cout << "\n\tmerge edge = " << st.merge_edge[0] << "\n\ttotal pos = " << st.total_pos[0]
+                      << "\n\tmerge pos = " << st.merge_pos[0] << "\n\n\n\tmerge edge = " << st.merge_edge[1]
+                      << "\n\ttotal pos = " << st.total_pos[1] << "\n\tmerge pos = " << st.merge_pos[1] << std::endl;
+            std::cout << "[PositionProcessor] Done!" << std::endl;
+
+            HostGraph graph;
+            backend.exportCsr(graph);
+            graph.k = static_cast<std::uint32_t>(kmers.k());
+
+            auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, input.ctgMapper(),
+                                       input.refMapper(), usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
+                                       opt.threads);
+            ++blockNo;
+            for (auto &s : successCtg) okCtg.emplace(s.first);
+        }
+        std::ofstream ctgList(opt.out + "/contig.txt");
+        for (auto &c : okCtg) ctgList << c << "\n";
+        return EXIT_SUCCESS;
+    } catch (const std::exception &e) {
+        std::cerr << "pagraph: " << e.what() << std::endl;
+        return 1;
+    }
+}
+
+}  // namespace pagh

@@ -1,0 +1,37 @@
+// tests/harness/pagraph_oracle.cpp — TEST HARNESS (never part of the product).
+// The product's `pagraph` driver (parsers, GraphInput, traversal, writers) with the graph build routed
+// through the C ORACLE instead of the HIP library, so the host half of the program can be checked
+// against the reference's golden outputs on a machine without a GPU.
+#include <stdexcept>
+
+#include "pag_oracle.h"
+#include "pagraph_driver.hpp"
+
+namespace {
+class OracleBackend final : public pagh::GraphBackend {
+public:
+    ~OracleBackend() override { pago_destroy(g_); }
+    const char *name() const override { return "C oracle (test harness)"; }
+    void create(const std::vector<std::uint64_t> &words, unsigned k) override { g_ = pago_create(words.data(), words.size(), k); }
+    std::uint64_t solidCount() override { return pago_solid_count(g_); }
+    void reset() override { pago_reset(g_); }
+    void process(const pag_build_input &in, pag_build_stats &stats) override {
+        if (pago_process(g_, &in, &stats) != PAG_OK) throw std::runtime_error("pago_process failed");
+    }
+    void exportCsr(pagh::HostGraph &out) override {
+        std::uint64_t nn, np, ne;
+        pago_csr_sizes(g_, &nn, &np, &ne);
+        out.resize(nn, np, ne);
+        pag_csr csr = out.view();
+        if (pago_export_csr(g_, &csr) != PAG_OK) throw std::runtime_error("pago_export_csr failed");
+    }
+
+private:
+    pago_graph *g_ = nullptr;
+};
+}  // namespace
+
+int main(int argc, char **argv) {
+    OracleBackend backend;
+    return pagh::runPagraph(argc, argv, backend);
+}

@@ -1,0 +1,51 @@
+"""GPU: the drop-in `pagraph` executable (HIP backend) against the reference's golden outputs and,
+on fresh seeded inputs, against the compiled reference binary itself (oracle/_ref/pagraph travels to
+the GPU box prebuilt).  Byte-exact on every output file."""
+import os
+import subprocess
+
+import pytest
+
+import goldens
+import pagctl
+import synth
+
+EXE = os.path.join(pagctl.ROOT, "aligngraph2_amd", "bin", "pagraph")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", goldens.case_names())
+def test_pagraph_matches_golden(name, workdir):
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / name / "in"))
+    out = str(workdir / name / "out")
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    r = subprocess.run(argv, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    assert "HIP gfx950" in r.stdout
+    goldens.compare_out_dir(name, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,threads", [(501, 1), (502, 16)])
+def test_pagraph_matches_reference_binary_on_fresh_input(seed, threads, workdir):
+    ref_bin = os.path.join(pagctl.REF_DIR, "pagraph")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/pagraph was not built (needs /root/reference at build time)")
+    d = str(workdir / f"fresh{seed}")
+    synth.generate(synth.Spec(seed=seed, ref_len=20000, n_reads=500, read_len=1200, read_len_jitter=0.3, k=10,
+                              contigs=[(300, 9500, False), (9900, 19700, seed % 2 == 0)], repeats=2), d + "/in")
+    r = pagctl.run_reference(d + "/in", d + "/ref", threads=threads, eps=10, cov=2)
+    assert r.returncode == 0
+    os.makedirs(d + "/ours", exist_ok=True)
+    o = subprocess.run(synth.pagraph_argv(EXE, d + "/in", d + "/ours", threads=threads, epsilon=10, cov=2),
+                       capture_output=True, text=True)
+    assert o.returncode == 0, o.stderr[-2000:]
+    fr, fo = sorted(os.listdir(d + "/ref")), sorted(os.listdir(d + "/ours"))
+    assert fr == fo
+    for f in fr:
+        a, b = open(f"{d}/ref/{f}", "rb").read(), open(f"{d}/ours/{f}", "rb").read()
+        if f == "contig.txt":
+            a, b = sorted(a.split()), sorted(b.split())
+        assert a == b, f"{f} differs from the reference binary's output"
