@@ -23,7 +23,7 @@ HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pag
 .PHONY: all product harness oracle clean
 all: product harness oracle
 
-product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph
+product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph aligngraph2_amd/libpagraph_host.so
 
 $(B)/host/%.o: $(HOST_DIR)/%.cpp $(wildcard $(HOST_DIR)/*.hpp) include/pagraph_hip.h
 	@mkdir -p $(B)/host
@@ -39,6 +39,9 @@ aligngraph2_amd/bin/pagraph: $(HOST_DIR)/pagraph_main.cpp $(B)/libpagh_host.a al
 	@mkdir -p aligngraph2_amd/bin
 	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/libpagh_host.a -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/..' -pthread
 
+aligngraph2_amd/libpagraph_host.so: $(B)/libpagh_host.a aligngraph2_amd/libpagraph_hip.so
+	$(CXX) -shared -o $@ -Wl,--whole-archive $(B)/libpagh_host.a -Wl,--no-whole-archive -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN' -pthread
+
 # ---- test-only -------------------------------------------------------------------------------
 oracle:
 	$(MAKE) -C oracle all
@@ -47,18 +50,19 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 	@mkdir -p $(B)
 	$(CC) -O2 -std=c99 -Wall -Wextra -fPIC -Iinclude -c $< -o $@
 
+HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
 HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle
 harness: $(HARNESS)
 
-tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(B)/libpagh_host.a $(B)/pag_oracle.o
+tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
 	@mkdir -p tests/harness/bin
-	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(B)/libpagh_host.a $(B)/pag_oracle.o -lm
+	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o -lm -pthread
 
-tests/harness/bin/libpagh_test.so: tests/harness/pagh_test.cpp $(B)/libpagh_host.a
+tests/harness/bin/libpagh_test.so: tests/harness/pagh_test.cpp $(HOST_NOHIP_OBJS)
 	@mkdir -p tests/harness/bin
-	$(CXX) $(CXXFLAGS) -shared -o $@ $< $(B)/libpagh_host.a
+	$(CXX) $(CXXFLAGS) -shared -o $@ $< $(HOST_NOHIP_OBJS) -pthread
 
-HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o,$(HOST_OBJS))
+HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
 tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
 	@mkdir -p tests/harness/bin
 	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o -lm -pthread

@@ -191,6 +191,43 @@ pag_graph *pag_create(const uint64_t *codes, uint64_t n_codes, uint32_t k, int d
     return g;
 }
 
+pag_graph *pag_create_from_bitmap(const uint32_t *bits, uint64_t n_solid, uint32_t k, int bits_on_device,
+                                  int device_ordinal, int *err) {
+    int rc = PAG_OK;
+    pag_graph *g = nullptr;
+    if (k == 0 || k > 16 || !bits) {
+        set_error("pag_create_from_bitmap: k must be in 1..16 and bits non-null");
+        rc = PAG_EINVAL;
+    }
+    if (rc == PAG_OK) rc = pick_device(device_ordinal);
+    if (rc == PAG_OK) {
+        g = new (std::nothrow) pag_graph();
+        if (!g) rc = PAG_ENOMEM;
+    }
+    if (rc == PAG_OK) {
+        g->device = device_ordinal;
+        g->k = k;
+        g->n_solid = n_solid;
+        const uint64_t space = 1ull << (2 * k);
+        const uint64_t words = (space + 31) / 32;
+        g->all_solid = n_solid == space;
+        hipError_t e = hipStreamCreate(&g->stream);
+        if (e == hipSuccess) e = hipMalloc((void **)&g->solid_bits, (size_t)words * 4 + 64);
+        if (e == hipSuccess)
+            e = hipMemcpy(g->solid_bits, bits, (size_t)words * 4, bits_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("pag_create_from_bitmap: %s", hipGetErrorString(e));
+            rc = PAG_EFAULT;
+        }
+    }
+    if (rc != PAG_OK && g) {
+        pag_destroy(g);
+        g = nullptr;
+    }
+    if (err) *err = rc;
+    return g;
+}
+
 void pag_destroy(pag_graph *g) {
     if (!g) return;
     hipSetDevice(g->device);

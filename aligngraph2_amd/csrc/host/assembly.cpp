@@ -1,10 +1,12 @@
 #include "assembly.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <map>
 #include <sstream>
+#include <thread>
 #include <vector>
 
 #include "traversal.hpp"
@@ -48,44 +50,71 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const SeqDb &contigs, const SeqDb &refs, const PositionMapper &ctgMapper,
                                                 const PositionMapper &refMapper,
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
-                                                double errorRate, double startSplit, std::size_t minLen, unsigned threadNum) {
+                                                double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
+                                                unsigned hostThreads, AssembleStats *stats, bool quiet) {
+    std::ostream nullOut(nullptr);
+    std::ostream &out = quiet ? nullOut : std::cout;
     std::set<std::pair<std::string, bool>> success;
     std::vector<TravelSequence> results(contigs.size() * 2);
     std::vector<std::size_t> inDegrees(contigs.size() * 2);
 
     // per selected contig: traverse, dump the path, drop short paths, count leap targets
-    // (PAssembly.cpp:30-79; the reference spreads this loop over max(1, t/8) threads, output-neutral)
-    for (auto &ctgName : ctgSet) {
-        std::size_t ctgIdx = contigs.id(ctgName.first);
-        std::size_t ctgOffset = ctgName.second ? 0 : 1;
-        std::string log;
-        Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum, &log);
-        std::cout << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << std::endl;
-        std::cout << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << std::endl;
-        auto &res = results[2 * ctgIdx + ctgOffset];
-        res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
-        std::cout << log;
+    // (PAssembly.cpp:30-79).  Contigs are independent, so the loop runs on a pool of host threads; the
+    // in-degree bookkeeping and the log are replayed in set order afterwards.
+    std::vector<std::pair<std::string, bool>> ctgList(ctgSet.begin(), ctgSet.end());
+    std::vector<std::string> logs(ctgList.size());
+    std::vector<std::int64_t> leapTarget(ctgList.size(), -1);
+    std::atomic<std::size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            std::size_t li = next.fetch_add(1);
+            if (li >= ctgList.size()) break;
+            auto &ctgName = ctgList[li];
+            std::size_t ctgIdx = contigs.id(ctgName.first);
+            std::size_t ctgOffset = ctgName.second ? 0 : 1;
+            std::stringstream log;
+            std::string tlog;
+            Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum, quiet ? nullptr : &tlog);
+            log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
+            log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
+            auto &res = results[2 * ctgIdx + ctgOffset];
+            res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
+            log << tlog;
 
-        std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
-        of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
-        for (auto &s : res) {
-            DualPos p = graph.position(s.first);
-            auto d1 = ctgMapper.singleToDual(p.first);
-            auto d2 = refMapper.singleToDual(p.second);
-            of << algo.vertexString(s.first) << "\t" << s.second << "\t" << d1.first << "," << d1.second << "\t" << d2.first
-               << "," << d2.second << "\n";
-        }
-        if (Traversal::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
-        if (!res.empty()) {
-            std::uint32_t lastCtgPos = graph.position(res.back().first).first;
-            if (lastCtgPos != 0) {
-                auto dual = ctgMapper.singleToDual(lastCtgPos);
-                std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
-                std::size_t fwd = dual.first > 0 ? 0 : 1;
-                if (idx != ctgIdx || fwd != ctgOffset) ++inDegrees[2 * idx + fwd];
+            std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
+            of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
+            for (auto &s : res) {
+                DualPos p = graph.position(s.first);
+                auto d1 = ctgMapper.singleToDual(p.first);
+                auto d2 = refMapper.singleToDual(p.second);
+                of << algo.vertexString(s.first) << "\t" << s.second << "\t" << d1.first << "," << d1.second << "\t"
+                   << d2.first << "," << d2.second << "\n";
             }
+            if (Traversal::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
+            if (!res.empty()) {
+                std::uint32_t lastCtgPos = graph.position(res.back().first).first;
+                if (lastCtgPos != 0) {
+                    auto dual = ctgMapper.singleToDual(lastCtgPos);
+                    std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
+                    std::size_t fwd = dual.first > 0 ? 0 : 1;
+                    if (idx != ctgIdx || fwd != ctgOffset) leapTarget[li] = static_cast<std::int64_t>(2 * idx + fwd);
+                }
+            }
+            log << "[Travel] End\n";
+            logs[li] = log.str();
         }
-        std::cout << "[Travel] End" << std::endl;
+    };
+    {
+        unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
+        nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, ctgList.size())));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
+    for (std::size_t li = 0; li < ctgList.size(); ++li) {
+        out << logs[li];
+        if (leapTarget[li] >= 0) ++inDegrees[static_cast<std::size_t>(leapTarget[li])];
     }
 
     // leaps into contigs whose own path was dropped are cut off again (PAssembly.cpp:129-150)
@@ -106,10 +135,10 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     }
     for (std::size_t i = 0; i < inDegrees.size(); ++i)
         if (inDegrees[i] > 0)
-            std::cout << "\t" << (i / 2) << " " << (i % 2 == 0 ? "forward" : "reverse") << " " << inDegrees[i] << std::endl;
+            out << "\t" << (i / 2) << " " << (i % 2 == 0 ? "forward" : "reverse") << " " << inDegrees[i] << std::endl;
 
     // union-find over chained contigs (PAssembly.cpp:160-198)
-    std::cout << "[Union] Start" << std::endl;
+    out << "[Union] Start" << std::endl;
     std::map<std::pair<std::string, bool>, std::size_t> helper;
     std::vector<std::pair<std::string, bool>> table;
     for (auto &c : ctgSet) {
@@ -160,12 +189,12 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         }
         starts.insert(table[chosen]);
     }
-    std::cout << "[Union] End" << std::endl;
-    std::cout << "Start From:" << std::endl;
-    for (auto &c : starts) std::cout << "\t" << c.first << " " << c.second << std::endl;
+    out << "[Union] End" << std::endl;
+    out << "Start From:" << std::endl;
+    for (auto &c : starts) out << "\t" << c.first << " " << c.second << std::endl;
 
     // emit chains (PAssembly.cpp:242-333)
-    std::cout << "[Assembly] Start" << std::endl;
+    out << "[Assembly] Start" << std::endl;
     std::size_t nameCnt = 0;
     Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum);
     for (auto &ctgName : starts) {
@@ -185,7 +214,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         bool isConnected = connected.size() > 1 && totalLen > maxLen * 1.05;
         bool isExtended = connected.size() == 1 && Traversal::seqSize(results[i]) > contigs.length(ctgIdx) * 1.2;
         if (!(isConnected || isExtended)) {
-            std::cout << "Ignore output" << std::endl;
+            out << "Ignore output" << std::endl;
             continue;
         }
         const std::size_t lineSize = 70;
@@ -200,7 +229,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         std::size_t cnt = 0, cmbLen = 0;
         std::vector<std::pair<std::pair<std::string, bool>, std::size_t>> conInf;
         combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
-            std::cout << i << "=" << ctgId << std::endl;
+            out << i << "=" << ctgId << std::endl;
             conInf.push_back({{contigs.name(ctgId), forward}, contigs.length(ctgId)});
             for (char ch : algo.seqToString(results[ctgId * 2 + (forward ? 0 : 1)], deviation, errorRate)) {
                 fasta << ch;
@@ -215,8 +244,25 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         if (cnt > 0) fasta << "\n";
         con << name << "\t" << cmbLen << "\n";
         for (auto &c : conInf) con << c.first.first << "\t" << (c.first.second ? "FORWARD" : "REV") << "\t" << c.second << "\n";
-        std::cout << "Out file: " << base << ".fasta" << std::endl;
+        out << "Out file: " << base << ".fasta" << std::endl;
         for (auto &s : connected) success.emplace(contigs.name(s.first), s.second);
+        if (stats) {
+            stats->nChains++;
+            stats->nFastaBases += cmbLen;
+        }
+    }
+    if (stats) {
+        stats->nContigs = ctgSet.size();
+        for (std::size_t i = 0; i < results.size(); ++i) {
+            std::uint64_t h = 1469598103934665603ull ^ i;
+            for (auto &n : results[i]) {
+                h = (h ^ graph.slot(n.first)) * 1099511628211ull;
+                h = (h ^ static_cast<std::uint64_t>(n.second)) * 1099511628211ull;
+            }
+            if (!results[i].empty()) stats->pathChecksum += h;
+            stats->nPathNodes += results[i].size();
+            stats->nPathBases += Traversal::seqSize(results[i]);
+        }
     }
     return success;
 }

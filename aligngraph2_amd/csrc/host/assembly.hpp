@@ -12,11 +12,18 @@
 
 namespace pagh {
 
-// returns the (contig name, forward) pairs consumed by emitted chains
+struct AssembleStats {
+    std::uint64_t nContigs = 0, nPathNodes = 0, nPathBases = 0, nChains = 0, nFastaBases = 0, pathChecksum = 0;
+};
+
+// returns the (contig name, forward) pairs consumed by emitted chains.
+// hostThreads: workers for the per-contig traversal loop (the reference uses max(1, t/8) threads there,
+// PAssembly.cpp:30; results are independent of the worker count).
 std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const std::string &prefix, const HostGraph &graph,
                                                 const SeqDb &contigs, const SeqDb &refs, const PositionMapper &ctgMapper,
                                                 const PositionMapper &refMapper,
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
-                                                double errorRate, double startSplit, std::size_t minLen, unsigned threadNum);
+                                                double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
+                                                unsigned hostThreads = 1, AssembleStats *stats = nullptr, bool quiet = false);
 
 }  // namespace pagh

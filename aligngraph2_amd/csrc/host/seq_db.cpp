@@ -40,6 +40,19 @@ void SeqDb::add(const std::string &comment, const std::string &seq) {
     }
 }
 
+void SeqDb::addPacked(const std::string &name, const std::uint8_t *packed, std::uint32_t len) {
+    nameToId_[name] = names_.size();
+    names_.push_back(name);
+    len_.push_back(len);
+    byteOff_.push_back(packed_.size());
+    totalBases_ += len;
+    std::size_t nBytes = (static_cast<std::size_t>(len) + 3) / 4;
+    std::size_t base = packed_.size();
+    packed_.resize(base + ((nBytes + 3) & ~std::size_t(3)), 0);
+    for (std::size_t i = 0; i < nBytes; ++i) packed_[base + i] = packed[i];
+    if (len & 3u) packed_[base + nBytes - 1] &= static_cast<std::uint8_t>((1u << ((len & 3u) * 2)) - 1u);
+}
+
 void SeqDb::finish() { packed_.resize(packed_.size() + 32, 0); }
 
 SeqDb::SeqDb(const std::string &path) {

@@ -39,6 +39,8 @@ public:
     const std::vector<std::uint8_t> &packed() const { return packed_; }
 
     void add(const std::string &comment, const std::string &seq);
+    // adopt an already 2-bit packed sequence (pag_seqs layout)
+    void addPacked(const std::string &name, const std::uint8_t *packed, std::uint32_t len);
     void finish();  // pads the packed buffer
 
 private:

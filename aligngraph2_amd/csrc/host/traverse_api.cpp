@@ -1,0 +1,91 @@
+// C ABI of the host half (include/pagraph_host.h): export the device graph, traverse, write outputs.
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <exception>
+#include <set>
+#include <string>
+
+#include "assembly.hpp"
+#include "host_graph.hpp"
+#include "pagraph_host.h"
+#include "position_mapper.hpp"
+#include "seq_db.hpp"
+
+namespace {
+thread_local char g_err[512] = "";
+void setErr(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+double nowMs() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+pagh::SeqDb fromPacked(const pag_seqs *s, const char *const *names, const char *stem, unsigned firstNo) {
+    pagh::SeqDb db;
+    for (std::uint64_t i = 0; i < s->n_seqs; ++i) {
+        std::string name = names ? names[i] : stem + std::to_string(i + firstNo);
+        db.addPacked(name, s->packed + s->byte_off[i], s->len[i]);
+    }
+    db.finish();
+    return db;
+}
+}  // namespace
+
+extern "C" {
+
+const char *pagh_last_error(void) { return g_err; }
+
+int pagh_traverse(const pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
+                  const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads,
+                  uint64_t epsilon, uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
+                  pagh_traverse_stats *stats) {
+    if (!g || !ctgs || !refs || !ctg_orient || !out_dir) return PAG_EINVAL;
+    try {
+        const double t0 = nowMs();
+        pagh::HostGraph graph;
+        std::uint64_t nn = 0, np = 0, ne = 0;
+        int rc = pag_csr_sizes(g, &nn, &np, &ne);
+        if (rc != PAG_OK) return rc;
+        graph.resize(nn, np, ne);
+        pag_csr csr = graph.view();
+        rc = pag_export_csr(g, &csr);
+        if (rc != PAG_OK) {
+            setErr("pag_export_csr: %s", pag_last_error());
+            return rc;
+        }
+        graph.k = k;
+        const double t1 = nowMs();
+
+        pagh::SeqDb contigDb = fromPacked(ctgs, ctg_names, "ctg", 0);
+        pagh::SeqDb refDb = fromPacked(refs, ref_names, "ref", 1);
+        pagh::PositionMapper ctgMapper(contigDb), refMapper(refDb);
+        std::set<std::pair<std::string, bool>> ctgSet;
+        for (std::uint64_t i = 0; i < ctgs->n_seqs; ++i)
+            if (ctg_orient[i] >= 0) ctgSet.emplace(contigDb.name(i), ctg_orient[i] != 0);
+
+        pagh::AssembleStats as;
+        pagh::assemble(out_dir, prefix ? prefix : "0_", graph, contigDb, refDb, ctgMapper, refMapper, ctgSet, epsilon * 2, 0.15,
+                       0.90, min_len, ref_threads, host_threads, &as, true);
+        const double t2 = nowMs();
+        if (stats) {
+            stats->n_contigs = as.nContigs;
+            stats->n_path_nodes = as.nPathNodes;
+            stats->n_path_bases = as.nPathBases;
+            stats->n_chains_emitted = as.nChains;
+            stats->n_fasta_bases = as.nFastaBases;
+            stats->path_checksum = as.pathChecksum;
+            stats->ms_export = t1 - t0;
+            stats->ms_traverse = t2 - t1;
+            stats->ms_total = t2 - t0;
+        }
+        return PAG_OK;
+    } catch (const std::exception &e) {
+        setErr("pagh_traverse: %s", e.what());
+        return PAG_EFAULT;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — aligned-read-bases/s through the PAGraph hot path (graph build + traversal) on MI355X.
+
+One step = one pass of the hot path over one config block (one reference sequence) of synthetic
+aligned reads that are already resident in HBM: pag_process (coverage filter, column walk, k-mer
+extraction + sampling, tuple emission, stable k-mer sort, epsilon cluster, edge de-duplication) followed
+by pagh_traverse (graph export, per-contig epsilon-join traversal, FASTA/.con/.help/.txt writers).
+
+N = 1 workload = BASELINE.json configs[1]: 100k x 10 kb reads vs a 50 Mb yeast-like reference, k = 14,
+epsilon = 10.  N > 1: the path shards by reference sequence (SURVEY.md §8e level 1): every rank owns
+one independent config block of the same size (different seed) — weak scaling, no data-path collective;
+torch.distributed (RCCL) is only used for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
+kernel (the radix scatter of the k-mer sort) and `cpu_baseline` (the compiled reference pagraph, or the
+C oracle when oracle/_ref is absent, on a bounded sample of the same kind of workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+SORT_BYTES_PER_RECORD = 24.0  # one read + one write of every 12-byte record
+
+
+class TraverseStats(C.Structure):
+    _fields_ = [("n_contigs", C.c_uint64), ("n_path_nodes", C.c_uint64), ("n_path_bases", C.c_uint64),
+                ("n_chains_emitted", C.c_uint64), ("n_fasta_bases", C.c_uint64), ("path_checksum", C.c_uint64),
+                ("ms_export", C.c_double), ("ms_traverse", C.c_double), ("ms_total", C.c_double)]
+
+
+def load_libs():
+    import pagctl
+    hip = pagctl.hip_lib()  # raises if the HIP library is missing: there is no CPU fallback
+    host_path = os.path.join(ROOT, "aligngraph2_amd", "libpagraph_host.so")
+    if not os.path.exists(host_path):
+        raise RuntimeError(f"{host_path} missing: run __graft_entry__.build()")
+    host = C.CDLL(host_path)
+    hip.pag_create_from_bitmap.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    hip.pag_create_from_bitmap.restype = C.c_void_p
+    host.pagh_traverse.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32,
+                                   C.POINTER(TraverseStats)]
+    host.pagh_traverse.restype = C.c_int
+    host.pagh_last_error.restype = C.c_char_p
+    return hip, host
+
+
+def host_seqs(codes_list):
+    """2-bit pack a list of uint8 code arrays into a host pag_seqs (keeps the numpy buffers alive)."""
+    import biggen
+    offs, lens, chunks, cur = [], [], [], 0
+    for c in codes_list:
+        n = len(c)
+        pad = (-n) % 16
+        cc = np.concatenate([c, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+        b = (cc[:, 0] | (cc[:, 1] << 2) | (cc[:, 2] << 4) | (cc[:, 3] << 6)).astype(np.uint8)
+        offs.append(cur)
+        lens.append(n)
+        chunks.append(b)
+        cur += len(b)
+    packed = np.concatenate(chunks + [np.zeros(64, np.uint8)])
+    off_a = np.array(offs, dtype=np.uint64)
+    len_a = np.array(lens, dtype=np.uint32)
+    s = biggen.PagSeqs(len(codes_list), off_a.ctypes.data, len_a.ctypes.data, packed.ctypes.data, len(packed))
+    return s, (packed, off_a, len_a)
+
+
+def cpu_baseline(k, eps, cov, threads_flag):
+    """Time the CPU reference on a bounded sample of the same kind of workload (rank 0, N = 1 only)."""
+    import biggen
+    import pagctl
+    import synth
+    ncores = os.cpu_count() or 1
+    sp = biggen.BigSpec(seed=99, ref_len=2_000_000, n_reads=2000, read_span=10_000, k=k, ctg_len=500_000, eps=eps, cov=cov,
+                        threads=threads_flag, solid_min_abundance=2, chunk_reads=1000)
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    w = biggen.BigWorkload(sp, device=dev)
+    tmp = tempfile.mkdtemp(prefix="pagcpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        w.write_text(tmp)
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "pagraph")
+        sample = f"{sp.n_reads} x {sp.read_span // 1000} kb reads vs {sp.ref_len // 1_000_000} Mb reference, k={k}, text inputs from /dev/shm"
+        if os.path.exists(ref_bin):
+            t_use = min(ncores, 64)
+            out = os.path.join(tmp, "out")
+            os.makedirs(out)
+            argv = synth.pagraph_argv(ref_bin, tmp, out, threads=t_use, epsilon=eps, cov=cov)
+            t0 = time.time()
+            r = subprocess.run(argv, capture_output=True, text=True)
+            dt = time.time() - t0
+            if r.returncode != 0:
+                raise RuntimeError("reference pagraph failed: " + r.stderr[-500:])
+            return {"value": w.n_bases / dt, "unit": "aligned-read-bases/s", "cores": t_use, "kind": "reference",
+                    "sample": sample + f"; compiled reference pagraph -t {t_use} (-O3), wall {dt:.1f} s incl. its file parsing"}
+        inp = pagctl.LoadedInput(tmp, threads=threads_flag, eps=eps, cov=cov)
+        t0 = time.time()
+        pagctl.run_oracle(inp)
+        dt = time.time() - t0
+        inp.close()
+        return {"value": w.n_bases / dt, "unit": "aligned-read-bases/s", "cores": 1, "kind": "port",
+                "sample": sample + f"; C oracle (graph build only, 1 thread), {dt:.1f} s"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000)
+    ap.add_argument("--read-span", type=int, default=10_000)
+    ap.add_argument("--ref-len", type=int, default=50_000_000)
+    ap.add_argument("--k", type=int, default=14)
+    ap.add_argument("--epsilon", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--build-only", action="store_true", help="diagnostic: skip traversal (NOT a valid bench line)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+
+    import biggen
+    hip, host = load_libs()
+    spec = biggen.BigSpec(seed=2 + rank, ref_len=args.ref_len, n_reads=args.reads, read_span=args.read_span, k=args.k,
+                          eps=args.epsilon, cov=2, threads=16)
+    w = biggen.BigWorkload(spec, device=f"cuda:{local}")
+    torch.cuda.synchronize()
+    inp = w.build_input()
+    err = C.c_int()
+    g = hip.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, spec.k, 1, local, C.byref(err))
+    if not g:
+        raise SystemExit(f"pag_create_from_bitmap failed ({err.value}): {hip.pag_last_error().decode()}")
+
+    # host copies of the contigs / reference for the traversal epilogue (sequence gap filling)
+    ref_np = w.ref.cpu().numpy()
+    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_seqs, keep1 = host_seqs(ctg_codes)
+    ref_seqs, keep2 = host_seqs([ref_np])
+    orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
+    out_dir = tempfile.mkdtemp(prefix=f"pagbench{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+    import pagctl
+    st = pagctl.BuildStats()
+    ts = TraverseStats()
+
+    def step():
+        rc = hip.pag_process(g, C.byref(inp), C.byref(st))
+        if rc != 0:
+            raise SystemExit(f"pag_process failed ({rc}): {hip.pag_last_error().decode()}")
+        if not args.build_only:
+            rc = host.pagh_traverse(g, spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, spec.threads,
+                                    spec.eps, 50, out_dir.encode(), b"0_", 0, C.byref(ts))
+            if rc != 0:
+                raise SystemExit(f"pagh_traverse failed ({rc}): {host.pagh_last_error().decode()}")
+
+    def sync():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    sort_ms, build_ms, trav_ms = [], [], []
+    for _ in range(args.steps):
+        step()
+        sort_ms.append(st.ms_sort_kernel)
+        build_ms.append(st.ms_total)
+        trav_ms.append(ts.ms_total)
+    sync()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+    bases = torch.tensor([float(w.n_bases)], dtype=torch.float64, device=f"cuda:{local}")
+    if dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(bases, op=dist.ReduceOp.SUM)
+    dt_max = float(tt.item())
+    total_bases = float(bases.item())
+
+    if rank == 0:
+        ms_sort = float(np.mean(sort_ms))
+        achieved = SORT_BYTES_PER_RECORD * st.sort_records / (ms_sort * 1e-3) / 1e9 if ms_sort > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "sort_scatter_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "aligned-read-bases/sec through PAGraph build+traverse",
+            "value": total_bases * args.steps / dt_max,
+            "unit": "aligned-read-bases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.reads} x {args.read_span // 1000} kb reads vs {args.ref_len / 1e6:g} Mb reference per GPU, "
+                            f"k={args.k}, epsilon={args.epsilon}, -t 16 semantics (BASELINE configs[1])"
+                            + (" [BUILD ONLY, diagnostic]" if args.build_only else ""),
+                "read_bases_per_gpu": w.n_bases,
+                "contigs": len(w.ctgs),
+                "solid_kmers": w.n_solid,
+                "position_tuples": int(st.n_tuples[0] + st.n_tuples[1]),
+                "edge_tuples": int(st.n_edges[0] + st.n_edges[1]),
+                "vertices": int(st.n_pos),
+                "sharding": "one reference-sequence block per GPU, no data-path collective",
+                "ms_build_device": float(np.mean(build_ms)),
+                "ms_extract": st.ms_extract, "ms_sort": st.ms_sort, "ms_cluster": st.ms_cluster, "ms_edges": st.ms_edges,
+                "ms_traverse_host": float(np.mean(trav_ms)), "ms_export": ts.ms_export,
+                "build_only_bases_per_s": w.n_bases / (float(np.mean(build_ms)) * 1e-3),
+                "path_bases": int(ts.n_path_bases), "chains": int(ts.n_chains_emitted),
+            },
+            "roofline": {"bound": "hbm", "kernel": "pagdev::sort_scatter (k-mer sort, one radix pass)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "records_per_launch": int(st.sort_records), "ms_per_launch": ms_sort},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.k, args.epsilon, 2, 16)
+            except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+                line["cpu_baseline"] = {"value": None, "unit": "aligned-read-bases/s", "cores": 0, "kind": "reference",
+                                        "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    shutil.rmtree(out_dir, ignore_errors=True)
+    hip.pag_destroy(g)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,6 +163,11 @@ typedef struct pag_graph pag_graph;
  * SURVEY quirk Q1) — the caller passes the file's words verbatim; sort+unique happens here.
  * k <= 16.  Builds the 4^k-bit solid bitmap in HBM. */
 pag_graph *pag_create(const uint64_t *codes, uint64_t n_codes, uint32_t k, int device_ordinal, int *err);
+/* Same graph object from the solid set given as its 4^k-bit membership bitmap (bit c of word c >> 5),
+ * host or device resident; n_solid = number of set bits (only reported).  Used when the set is produced
+ * on the device (k-mer counting), so that it never makes a round trip through a sorted host array. */
+pag_graph *pag_create_from_bitmap(const uint32_t *bits, uint64_t n_solid, uint32_t k, int bits_on_device,
+                                  int device_ordinal, int *err);
 void pag_destroy(pag_graph *g);
 /* PABruijnGraph::availableKmerNumber (:371-373) */
 uint64_t pag_solid_count(const pag_graph *g);

@@ -1,0 +1,40 @@
+/* include/pagraph_host.h — C ABI of the host half of the PAGraph hot path (libpagraph_host.so):
+ * traversal control, chain selection and the output writers, on top of a graph built by
+ * libpagraph_hip.so.  Mirrors PAssembly::testTravel5 (reference PAGraph/src/tools/graph/PAssembly.cpp
+ * :11-336), which the reference main calls right after PositionProcessor::process (pagraph.cpp:241-256).
+ * The `pagraph` executable links the same code statically; this library exists so that non-C++ callers
+ * (bench.py, tests) can drive the identical path. */
+#ifndef PAGRAPH_HOST_H
+#define PAGRAPH_HOST_H
+
+#include "pagraph_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pagh_traverse_stats {
+    uint64_t n_contigs;        /* contig orientations traversed */
+    uint64_t n_path_nodes;     /* vertices on all kept paths */
+    uint64_t n_path_bases;     /* sum of steps over all kept paths (PAlgorithm::seqSize) */
+    uint64_t n_chains_emitted; /* FASTA records written */
+    uint64_t n_fasta_bases;
+    uint64_t path_checksum;    /* order-independent hash of (contig, path vertices): cheap cross-checks */
+    double ms_export, ms_traverse, ms_total; /* host wall clock */
+} pagh_traverse_stats;
+
+/* ctgs / refs: HOST memory, 2-bit packed (pag_seqs).  names may be NULL ("ctg<i>" / "ref<i+1>").
+ * ctg_orient[i]: 1 = traverse forward, 0 = traverse reverse, -1 = contig not selected (config.txt).
+ * Writes <prefix><C>_<O>.txt/.fasta/.con/.help into out_dir exactly like the reference.
+ * host_threads: worker threads for the per-contig loop (0 = hardware concurrency); results do not
+ * depend on it.  ref_threads = the reference's -t (seed top-K = min(t, 8), quirk Q10). */
+int pagh_traverse(const pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
+                  const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads,
+                  uint64_t epsilon, uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
+                  pagh_traverse_stats *stats);
+const char *pagh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

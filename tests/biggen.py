@@ -1,0 +1,499 @@
+"""Large synthetic PAGraph workloads generated directly as the flat C-ABI input (bench + scale tests).
+
+Everything is built with torch on the chosen device, so that at bench scale (BASELINE.json config 2:
+100k x 10 kb reads vs a 50 Mb reference) the inputs are resident in HBM before the timed region starts.
+Model (simplified where it does not change the work): reference = i.i.d. ACGT with
+planted repeats; contigs = exact reference segments (mean `ctg_len`, gaps 1-20 kb, ~10 % stored
+reverse-complemented); reads = fixed reference span, uniform start, strand 50/50, PacBio-CLR-like
+errors 3 % sub / 4 % del / 5 % ins; read->ref and read->contig alignments from the simulation truth;
+solid k-mer set by the reference kmer_counter's rule (kmer_counter.cpp:68-77).
+
+The same generator writes the TEXT form of a workload (FASTQ / 3-line ALN / FASTA / config / kmer.bin),
+which is what the compiled reference needs for the cpu_baseline leg and for parity checks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+PAG_NONE = 0xFFFFFFFF
+ALN_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("t_begin", "<u4"), ("t_end", "<u4"), ("q_start", "<u4"),
+                      ("t_start", "<u4"), ("n_cols", "<u4"), ("n_valid", "<u4"), ("diff_off", "<u8"), ("flags", "<u4"),
+                      ("reserved", "<u4")])
+CTG_DTYPE = np.dtype([("len", "<u4"), ("selected", "<u4"), ("single_base", "<u4"), ("multi", "<u4"), ("map_off", "<u8")])
+REF_DTYPE = np.dtype([("len", "<u4"), ("accepted", "<u4"), ("single_base", "<u4"), ("reserved", "<u4")])
+FLAG_REV, FLAG_BACK, FLAG_ELIG = 1, 2, 4
+
+
+class PagSeqs(C.Structure):
+    _fields_ = [("n_seqs", C.c_uint64), ("byte_off", C.c_void_p), ("len", C.c_void_p), ("packed", C.c_void_p),
+                ("packed_bytes", C.c_uint64)]
+
+
+class PagAlnDb(C.Structure):
+    _fields_ = [("n_aln", C.c_uint64), ("aln", C.c_void_p), ("query_off", C.c_void_p), ("diff", C.c_void_p),
+                ("n_diff_words", C.c_uint64)]
+
+
+class PagBuildInput(C.Structure):
+    _fields_ = [("on_device", C.c_uint32), ("n_threads", C.c_uint32), ("reads", PagSeqs), ("emit_order", C.c_void_p),
+                ("read_to_ctg", PagAlnDb), ("read_to_ref", PagAlnDb), ("n_ctgs", C.c_uint64), ("ctgs", C.c_void_p),
+                ("ctg_ent_off", C.c_void_p), ("n_ctg_ent_off", C.c_uint64), ("ctg_ent", C.c_void_p),
+                ("n_ctg_ent", C.c_uint64), ("n_refs", C.c_uint64), ("refs", C.c_void_p), ("eps", C.c_uint32),
+                ("cov_filter", C.c_uint32), ("outer_sample", C.c_uint32), ("topk_ctg", C.c_int32), ("topk_ref", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
+@dataclass
+class BigSpec:
+    seed: int = 2
+    ref_len: int = 50_000_000
+    n_reads: int = 100_000
+    read_span: int = 10_000  # reference bases under each read (read length ~ span * 1.01)
+    k: int = 14
+    ctg_len: int = 1_000_000
+    gap_lo: int = 1_000
+    gap_hi: int = 20_000
+    rev_ctg_frac: float = 0.1
+    sub: float = 0.03
+    dele: float = 0.04
+    ins: float = 0.05
+    repeat_frac: float = 0.05
+    threads: int = 16  # the reference's -t: emission order + seed top-K
+    eps: int = 10
+    cov: int = 2
+    solid_threshold: float = 0.2  # kmer_counter -m
+    solid_min_abundance: int = -1  # >= 0: use this abundance cut instead of the kmer_counter rule
+    chunk_reads: int = 8192
+
+
+def _mapper_starts(lens):
+    """PositionMapper::generateStartPosHelper (position/PositionMapper.cpp:16-31)."""
+    start = [lens[0]]
+    for i in range(1, len(lens)):
+        start.append(start[-1] + 3 * lens[i - 1] + max(lens[i - 1], lens[i]))
+    return start
+
+
+class BigWorkload:
+    """Holds every tensor of one config block + the ctypes view of it."""
+
+    def __init__(self, spec: BigSpec, device: str = "cuda"):
+        self.spec = spec
+        self.dev = torch.device(device)
+        self._keep = []
+        self._generate()
+
+    # ------------------------------------------------------------------ generation
+    def _generate(self):
+        sp, dev = self.spec, self.dev
+        g = torch.Generator(device=dev)
+        g.manual_seed(sp.seed)
+        rs = np.random.default_rng(sp.seed)
+        G, S, n = sp.ref_len, sp.read_span, sp.n_reads
+
+        ref = torch.randint(0, 4, (G,), dtype=torch.uint8, device=dev, generator=g)
+        # planted 2-10 kb repeats over ~repeat_frac of the reference
+        n_rep = int(G * sp.repeat_frac / 6000)
+        for _ in range(n_rep):
+            L = int(rs.integers(2000, 10000))
+            if G <= 2 * L:
+                break
+            a, b = int(rs.integers(0, G - L)), int(rs.integers(0, G - L))
+            ref[b:b + L] = ref[a:a + L].clone()
+        self.ref = ref
+
+        # contigs: exact reference segments
+        ctgs = []
+        pos = int(rs.integers(0, max(1, min(sp.gap_hi, G // 50))))
+        while pos < G - 2000:
+            L = int(min(G - pos, max(2000, rs.normal(sp.ctg_len, sp.ctg_len * 0.2))))
+            ctgs.append((pos, pos + L, bool(rs.random() < sp.rev_ctg_frac)))
+            pos += L + int(rs.integers(sp.gap_lo, sp.gap_hi + 1))
+        self.ctgs = ctgs
+        nc = len(ctgs)
+        ctg_lens = [e - s for s, e, _ in ctgs]
+        ctg_start = _mapper_starts(ctg_lens)
+        ref_start = _mapper_starts([G])
+        if ctg_start[-1] + 4 * ctg_lens[-1] >= 2**32 - 1 or ref_start[-1] + 4 * G >= 2**32 - 1:
+            raise ValueError("coordinate space exceeds 32 bits; split the reference (SURVEY §5)")
+        self.ctg_mapper_start, self.ref_mapper_start = ctg_start, ref_start
+
+        cs_t = torch.tensor([c[0] for c in ctgs], dtype=torch.int64, device=dev)
+        ce_t = torch.tensor([c[1] for c in ctgs], dtype=torch.int64, device=dev)
+        crev_t = torch.tensor([c[2] for c in ctgs], dtype=torch.bool, device=dev)
+
+        starts = torch.randint(0, G - S, (n,), device=dev, generator=g)
+        rev = torch.rand(n, device=dev, generator=g) < 0.5
+
+        read_len = torch.zeros(n, dtype=torch.int64, device=dev)
+        packed_chunks, diff1_chunks, diff2_chunks = [], [], []
+        rec1, rec2 = [], []  # per-chunk dicts of alignment fields
+        byte_cursor = 0
+        w1_cursor = 0
+        w2_cursor = 0
+        read_byte_off = torch.zeros(n, dtype=torch.int64, device=dev)
+        kmer_hist = torch.zeros(4 ** sp.k, dtype=torch.int32, device=dev) if sp.k <= 14 else None
+        self.solid_codes_host = None
+        k = sp.k
+
+        for lo in range(0, n, sp.chunk_reads):
+            hi = min(n, lo + sp.chunk_reads)
+            m = hi - lo
+            st = starts[lo:hi]
+            idx = st[:, None] + torch.arange(S, device=dev)[None, :]
+            rb = ref[idx]  # [m, S] reference bases under the read
+            u = torch.rand(m, S, device=dev, generator=g)
+            is_del = u < sp.dele
+            is_sub = (~is_del) & (u < sp.dele + sp.sub)
+            is_ins = torch.rand(m, S, device=dev, generator=g) < sp.ins
+            is_del[:, 0] = False
+            is_del[:, -1] = False
+            is_ins[:, -1] = False
+            shift = torch.randint(1, 4, (m, S), dtype=torch.uint8, device=dev, generator=g)
+            qb = torch.where(is_sub, (rb + shift) & 3, rb)
+            ins_base = torch.randint(0, 4, (m, S), dtype=torch.uint8, device=dev, generator=g)
+
+            ncol_per = 1 + is_ins.to(torch.int32)
+            col_end = torch.cumsum(ncol_per, dim=1)  # exclusive end column of each ref base (incl. its insertion)
+            col0 = col_end - ncol_per  # column of the ref base itself
+            n_cols = col_end[:, -1]  # [m]
+            Cmax = int(n_cols.max().item())
+            Cpad = (Cmax + 15) // 16 * 16
+            # column classes: 0 match, 3 mismatch, 1 deletion (queryDiff only), 2 insertion (refDiff only)
+            # scatter targets that do not exist go to a spare last column, sliced off afterwards
+            W = Cpad + 16
+            cls = torch.zeros(m, W, dtype=torch.uint8, device=dev)
+            base_cls = torch.where(is_del, torch.ones_like(rb), torch.where(is_sub, torch.full_like(rb, 3), torch.zeros_like(rb)))
+            cls.scatter_(1, col0.long(), base_cls)
+            ins_col = torch.where(is_ins, (col0 + 1).long(), torch.full_like(col0.long(), W - 1))
+            cls.scatter_(1, ins_col, torch.full_like(rb, 2))
+            cls = cls[:, :Cpad].contiguous()
+            # query base per column (undefined for deletions)
+            qcol = torch.zeros(m, W, dtype=torch.uint8, device=dev)
+            qcol.scatter_(1, col0.long(), qb)
+            qcol.scatter_(1, ins_col, ins_base)
+            qcol = qcol[:, :Cpad].contiguous()
+            colmask = torch.arange(Cpad, device=dev)[None, :] < n_cols[:, None]
+            emit = colmask & (cls != 1)
+            # fragment = emitted bases in column order
+            epos = torch.cumsum(emit.to(torch.int32), dim=1) - 1
+            flen = (epos[:, -1] + 1).long()  # read length
+            Lmax = int(flen.max().item())
+            Lpad = (Lmax + 15) // 16 * 16
+            frag = torch.zeros(m, Lpad + 16, dtype=torch.uint8, device=dev)
+            tgt = torch.where(emit, epos.long(), torch.full_like(epos.long(), Lpad + 15))
+            frag.scatter_(1, tgt, qcol)
+            frag = frag[:, :Lpad].contiguous()
+            # stored read = fragment or its reverse complement
+            ar = torch.arange(Lpad, device=dev)[None, :]
+            ridx = (flen[:, None] - 1 - ar).clamp(min=0)
+            rc = 3 - frag.gather(1, ridx)
+            rv = rev[lo:hi]
+            stored = torch.where(rv[:, None], rc, frag)
+            stored = torch.where(ar < flen[:, None], stored, torch.zeros_like(stored))
+            read_len[lo:hi] = flen
+
+            # k-mer histogram of the stored reads (forward strand only, like kmer_counter)
+            if kmer_hist is not None:
+                code = torch.zeros(m, Lpad - k + 1, dtype=torch.int64, device=dev)
+                for j in range(k):
+                    code = (code << 2) | stored[:, j:j + Lpad - k + 1].long()
+                valid = torch.arange(Lpad - k + 1, device=dev)[None, :] < (flen[:, None] - k + 1)
+                kmer_hist += torch.bincount(code[valid], minlength=4 ** k).to(torch.int32)
+                del code, valid
+
+            # pack reads: 4 bases / byte LSB first, each read padded to 16 bases (4 bytes)
+            pb = (stored.view(m, Lpad // 4, 4).to(torch.int32) * torch.tensor([1, 4, 16, 64], device=dev)).sum(-1).to(torch.uint8)
+            nbytes = ((flen + 15) // 16) * 4
+            bmask = torch.arange(Lpad // 4, device=dev)[None, :] < nbytes[:, None]
+            packed_chunks.append(pb[bmask])
+            off = torch.cumsum(nbytes, 0) - nbytes + byte_cursor
+            read_byte_off[lo:hi] = off
+            byte_cursor += int(nbytes.sum().item())
+
+            # ---- read -> ref alignment (whole read), columns in reference order
+            def pack_cols(c, ncol):  # c: [m, Cpad] classes, rows valid for ncol columns
+                cm = torch.arange(c.shape[1], device=dev)[None, :] < ncol[:, None]
+                c = torch.where(cm, c, torch.zeros_like(c))
+                w = (c.view(c.shape[0], -1, 16).to(torch.int64) << (2 * torch.arange(16, device=dev))).sum(-1)
+                nw = (ncol + 15) // 16
+                wm = torch.arange(w.shape[1], device=dev)[None, :] < nw[:, None]
+                return w[wm].to(torch.int32), nw
+
+            w2, nw2 = pack_cols(cls, n_cols.long())
+            diff2_chunks.append(w2)
+            off2 = torch.cumsum(nw2, 0) - nw2 + w2_cursor
+            w2_cursor += int(nw2.sum().item())
+            rec2.append(dict(query=torch.arange(lo, hi, device=dev), target=torch.zeros(m, dtype=torch.int64, device=dev),
+                             t_begin=st, t_end=st + S, q_start=torch.zeros(m, dtype=torch.int64, device=dev), t_start=st,
+                             n_cols=n_cols.long(), n_valid=flen, diff_off=off2,
+                             flags=FLAG_ELIG + rv.long() * FLAG_REV, score=(cls == 0).sum(1) - (Cpad - n_cols.long())))
+
+            # ---- read -> contig alignments: up to two contigs per read
+            j0 = torch.searchsorted(cs_t, st, right=True) - 1  # last contig starting at or before the read
+            for cand in (0, 1):
+                cj = j0 + cand
+                ok = (cj >= 0) & (cj < nc)
+                cjc = cj.clamp(0, nc - 1)
+                c_s, c_e, c_r = cs_t[cjc], ce_t[cjc], crev_t[cjc]
+                # the alignment must not end on the contig's last base IN CONTIG-FORWARD coordinates
+                # (Aligner.tcc:62 drops `ctgEnd >= ctgLen`, quirk Q14): forward contigs lose their last
+                # base, reverse-complemented contigs lose the base that sits first in reference order
+                a = torch.maximum(st, c_s + c_r.long()) - st  # first ref base index inside the contig
+                b = torch.minimum(st + S, c_e - 1 + c_r.long()) - st  # exclusive
+                ok &= b - a >= 16
+                a = a.clamp(0, S - 1)
+                b = b.clamp(1, S)
+                c0 = col0.gather(1, a[:, None]).squeeze(1).long()
+                c1 = col0.gather(1, (b - 1)[:, None]).squeeze(1).long() + 1
+                ncol = (c1 - c0).clamp(min=0)
+                eb = torch.cat([torch.zeros(m, 1, dtype=torch.int32, device=dev), torch.cumsum(emit.to(torch.int32), 1)], 1)
+                fa = eb.gather(1, c0[:, None]).squeeze(1).long()
+                fb = eb.gather(1, c1[:, None]).squeeze(1).long()
+                nq = fb - fa
+                ok &= nq.double() / flen.double() >= 0.35  # readToCtgRatio (Aligner.tcc:52)
+                if not bool(ok.any()):
+                    continue
+                sel = torch.nonzero(ok).squeeze(1)
+                ms = sel.numel()
+                cc = cls[sel]
+                ncs, c0s, revs = ncol[sel], c0[sel], c_r[sel]
+                Cs = int(ncs.max().item())
+                Csp = (Cs + 15) // 16 * 16
+                jj = torch.arange(Csp, device=dev)[None, :]
+                src = torch.where(revs[:, None], c0s[:, None] + ncs[:, None] - 1 - jj, c0s[:, None] + jj).clamp(0, Cpad - 1)
+                sub = cc.gather(1, src)  # reversed contigs store the columns in contig-forward (file) order
+                w1, nw1 = pack_cols(sub, ncs)
+                diff1_chunks.append(w1)
+                off1 = torch.cumsum(nw1, 0) - nw1 + w1_cursor
+                w1_cursor += int(nw1.sum().item())
+                match = ((sub == 0) & (jj < ncs[:, None])).sum(1)
+                tb_ref, te_ref = (a + st - c_s)[sel], (b + st - c_s)[sel]
+                clen_s = (c_e - c_s)[sel]
+                rec1.append(dict(query=sel + lo, target=cjc[sel], t_begin=torch.where(revs, clen_s - te_ref, tb_ref),
+                                 t_end=torch.where(revs, clen_s - tb_ref, te_ref),
+                                 q_start=fa[sel], t_start=(a + st - c_s)[sel], n_cols=ncs, n_valid=nq[sel], diff_off=off1,
+                                 flags=FLAG_ELIG + rv[sel].long() * FLAG_REV + revs.long() * FLAG_BACK, score=match))
+            del idx, rb, u, is_del, is_sub, is_ins, shift, qb, ins_base, cls, qcol, frag, stored, rc, pb
+
+        self.n_bases = int(read_len.sum().item())
+        self.read_len = read_len.to(torch.int32)
+        self.read_byte_off = read_byte_off
+        pad = torch.zeros(64, dtype=torch.uint8, device=dev)
+        self.packed = torch.cat(packed_chunks + [pad])
+
+        def finish_db(recs, diff_chunks):
+            if recs:
+                f = {kk: torch.cat([r[kk] for r in recs]) for kk in recs[0]}
+            else:
+                f = {kk: torch.zeros(0, dtype=torch.int64, device=dev) for kk in
+                     ("query", "target", "t_begin", "t_end", "q_start", "t_start", "n_cols", "n_valid", "diff_off", "flags", "score")}
+            # group by read; inside a read by score descending (stable on ties)
+            order = torch.argsort(-f["score"], stable=True)
+            order = order[torch.argsort(f["query"][order], stable=True)]
+            f = {kk: v[order] for kk, v in f.items()}
+            na = f["query"].numel()
+            arr = np.zeros(na, dtype=ALN_DTYPE)
+            for kk in ("query", "target", "t_begin", "t_end", "q_start", "t_start", "n_cols", "n_valid", "diff_off", "flags"):
+                arr[kk] = f[kk].cpu().numpy()
+            qoff = torch.searchsorted(f["query"].contiguous(), torch.arange(n + 1, device=dev)).to(torch.int64)
+            diff = torch.cat(diff_chunks + [torch.zeros(8, dtype=torch.int32, device=dev)]) if diff_chunks else torch.zeros(8, dtype=torch.int32, device=dev)
+            return arr, qoff, diff
+
+        self.aln1, self.qoff1, self.diff1 = finish_db(rec1, diff1_chunks)
+        self.aln2, self.qoff2, self.diff2 = finish_db(rec2, diff2_chunks)
+
+        # contig table + identity contig->ref map (one entry per base, both orientations alike)
+        ctab = np.zeros(nc, dtype=CTG_DTYPE)
+        ent_off, ents = [], []
+        cursor = 0
+        for c, (s, e, r) in enumerate(ctgs):
+            L = e - s
+            ctab[c] = (L, 1, (ctg_start[c] + (2 * L if r else 0)) & 0xFFFFFFFF, 0, cursor + c)
+            ent_off.append(torch.arange(cursor, cursor + L + 1, dtype=torch.int64, device=dev))
+            ents.append(torch.arange(s, e, dtype=torch.int64, device=dev) + ref_start[0])
+            cursor += L
+        self.ctab = ctab
+        self.ctg_ent_off = torch.cat(ent_off).to(torch.int32)
+        self.ctg_ent = torch.cat(ents + [torch.zeros(1, dtype=torch.int64, device=dev)]).to(torch.int32)
+        self.rtab = np.array([(G, 1, ref_start[0], 0)], dtype=REF_DTYPE)
+
+        T = max(1, sp.threads)
+        self.emit_order = torch.cat([torch.arange(t, n, T, device=dev) for t in range(T)]).to(torch.int32)
+
+        # solid set, kmer_counter's rule (kmer_counter.cpp:60-77): smallest abundance a such that the
+        # fraction of codes with abundance > a is <= threshold; solid = abundance >= a
+        if kmer_hist is not None:
+            if sp.solid_min_abundance >= 0:
+                min_ab = sp.solid_min_abundance
+            else:
+                mx = int(kmer_hist.max().item())
+                cnt = torch.bincount(kmer_hist.long().clamp(max=mx), minlength=mx + 1)
+                cum = torch.cumsum(cnt, 0).double()
+                okk = (1.0 - cum / float(4 ** k)) <= sp.solid_threshold
+                min_ab = int(torch.nonzero(okk)[0].item())
+            solid = kmer_hist >= min_ab
+            solid[k] = True  # the file's header word (value k) is ingested as a code (quirk Q1)
+            self.min_abundance = min_ab
+            self.n_solid = int(solid.sum().item())
+            bits = (solid.view(-1, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
+            self.solid_bits = bits.to(torch.int32)
+            self.solid_mask = solid
+        self._to_device_tables()
+
+    def _to_device_tables(self):
+        dev = self.dev
+        self.aln1_t = torch.from_numpy(self.aln1.view(np.uint8).copy()).to(dev)
+        self.aln2_t = torch.from_numpy(self.aln2.view(np.uint8).copy()).to(dev)
+        self.ctab_t = torch.from_numpy(self.ctab.view(np.uint8).copy()).to(dev)
+        self.rtab_t = torch.from_numpy(self.rtab.view(np.uint8).copy()).to(dev)
+
+    def clone_to(self, device: str) -> "BigWorkload":
+        """the same workload with every tensor on another device (e.g. 'cpu' for the oracle)"""
+        import copy
+        o = copy.copy(self)
+        o.dev = torch.device(device)
+        for name, v in list(vars(self).items()):
+            if isinstance(v, torch.Tensor):
+                setattr(o, name, v.to(device))
+        return o
+
+    # ------------------------------------------------------------------ C-ABI view
+    def build_input(self) -> PagBuildInput:
+        sp = self.spec
+        on_dev = 1 if self.dev.type == "cuda" else 0
+        p = lambda t: t.data_ptr()  # noqa: E731
+        inp = PagBuildInput()
+        inp.on_device = on_dev
+        inp.n_threads = sp.threads
+        inp.reads = PagSeqs(sp.n_reads, p(self.read_byte_off), p(self.read_len), p(self.packed), self.packed.numel())
+        inp.emit_order = p(self.emit_order)
+        inp.read_to_ctg = PagAlnDb(len(self.aln1), p(self.aln1_t), p(self.qoff1), p(self.diff1), self.diff1.numel())
+        inp.read_to_ref = PagAlnDb(len(self.aln2), p(self.aln2_t), p(self.qoff2), p(self.diff2), self.diff2.numel())
+        inp.n_ctgs = len(self.ctab)
+        inp.ctgs = p(self.ctab_t)
+        inp.ctg_ent_off = p(self.ctg_ent_off)
+        inp.n_ctg_ent_off = self.ctg_ent_off.numel()
+        inp.ctg_ent = p(self.ctg_ent)
+        inp.n_ctg_ent = self.ctg_ent.numel()
+        inp.n_refs = 1
+        inp.refs = p(self.rtab_t)
+        inp.eps = sp.eps
+        inp.cov_filter = sp.cov
+        inp.outer_sample = 3
+        inp.topk_ctg = -1
+        inp.topk_ref = -1
+        return inp
+
+    def solid_words(self) -> np.ndarray:
+        """every u64 word of the equivalent solid-set file (header word first)"""
+        codes = torch.nonzero(self.solid_mask).squeeze(1).cpu().numpy().astype(np.uint64)
+        return np.concatenate([np.array([self.spec.k], dtype=np.uint64), codes])
+
+    # ------------------------------------------------------------------ text form (for the reference binary)
+    def write_text(self, out_dir: str):
+        os.makedirs(out_dir, exist_ok=True)
+        sp = self.spec
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        comp = np.frombuffer(b"TGCA", dtype=np.uint8)
+        ref = self.ref.cpu().numpy()
+        G = len(ref)
+
+        def fasta(path, recs):
+            with open(path, "w") as f:
+                for name, codes in recs:
+                    f.write(f">{name}\n")
+                    s = acgt[codes].tobytes().decode()
+                    f.write("\n".join(s[i:i + 100] for i in range(0, len(s), 100)) + "\n")
+
+        fasta(os.path.join(out_dir, "ref.fasta"), [("ref1", ref)])
+        ctg_recs = []
+        with open(os.path.join(out_dir, "aln"), "w") as f:
+            for c, (s, e, r) in enumerate(self.ctgs):
+                seg = ref[s:e]
+                seq = (3 - seg[::-1]) if r else seg
+                ctg_recs.append((f"ctg{c}", seq))
+                row = acgt[seg].tobytes().decode()
+                f.write(f"ctg{c} ref1 {'R' if r else 'F'} NULL 0 {e - s} {e - s} {s} {e} {G}\n{row}\n{row}\n")
+        fasta(os.path.join(out_dir, "ctg.fasta"), ctg_recs)
+
+        packed = self.packed.cpu().numpy()
+        boff = self.read_byte_off.cpu().numpy()
+        rlen = self.read_len.cpu().numpy()
+
+        def read_codes(i):
+            b = packed[boff[i]:boff[i] + (rlen[i] + 3) // 4]
+            return np.stack([(b >> s) & 3 for s in (0, 2, 4, 6)], 1).reshape(-1)[:rlen[i]]
+
+        with open(os.path.join(out_dir, "0.new.fastq"), "w") as f:
+            for i in range(sp.n_reads):
+                s = acgt[read_codes(i)].tobytes().decode()
+                f.write(f"@{i + 1}\n{s}\n+\n{'~' * len(s)}\n")
+
+        def write_aln(path, arr, diff, target_name, target_len, target_seq):
+            diff = diff.cpu().numpy().view(np.uint32)
+            with open(path, "w") as f:
+                for a in arr:
+                    i = int(a["query"])
+                    nc_ = int(a["n_cols"])
+                    w = diff[int(a["diff_off"]):int(a["diff_off"]) + (nc_ + 15) // 16]
+                    cls = np.stack([(w >> (2 * j)) & 3 for j in range(16)], 1).reshape(-1)[:nc_]  # file order
+                    rev_read = bool(a["flags"] & FLAG_REV)
+                    back = bool(a["flags"] & FLAG_BACK)
+                    tname, tlen, tseq = target_name(a), target_len(a), target_seq(a)
+                    rc = read_codes(i)
+                    n = len(rc)
+                    walk = cls[::-1] if back else cls
+                    n_emit = int((walk != 1).sum())
+                    n_radv = int((walk != 2).sum())
+                    qs, ts = int(a["q_start"]), int(a["t_start"])
+                    # strand string the positions refer to
+                    strand = (3 - rc[::-1]) if rev_read else rc
+                    GAPC = 4
+                    fwd_tab = np.frombuffer(b"ACGT-", dtype=np.uint8)
+                    cmp_tab = np.frombuffer(b"TGCA-", dtype=np.uint8)
+                    q_walk = np.full(nc_, GAPC, dtype=np.uint8)
+                    t_walk = np.full(nc_, GAPC, dtype=np.uint8)
+                    q_walk[walk != 1] = strand[qs:qs + n_emit]
+                    t_walk[walk != 2] = tseq[ts:ts + n_radv]
+                    if back:
+                        # file rows are in contig-forward orientation = reverse complement of the walk rows;
+                        # relative strand flips; contig coordinates go back to the contig's forward strand
+                        q_row, t_row = cmp_tab[q_walk[::-1]], cmp_tab[t_walk[::-1]]
+                        f_is_forward = rev_read
+                        tb, te = tlen - (ts + n_radv), tlen - ts
+                    else:
+                        q_row, t_row = fwd_tab[q_walk], fwd_tab[t_walk]
+                        f_is_forward = not rev_read
+                        tb, te = ts, ts + n_radv
+                    # header query coordinates are on the read's forward strand
+                    qb, qe = (n - (qs + n_emit), n - qs) if rev_read else (qs, qs + n_emit)
+                    score = int((cls == 0).sum())
+                    f.write(f"{i + 1} {tname} {'F' if f_is_forward else 'R'} {score} {qb} {qe} {n} {tb} {te} {tlen}\n"
+                            f"{q_row.tobytes().decode()}\n{t_row.tobytes().decode()}\n")
+
+        ctg_seqs = {}
+
+        def ctg_strand_seq(a):  # the contig strand the walk's coordinates refer to = reference orientation
+            c = int(a["target"])
+            if c not in ctg_seqs:
+                s, e, r = self.ctgs[c]
+                ctg_seqs[c] = ref[s:e]
+            return ctg_seqs[c]
+
+        write_aln(os.path.join(out_dir, "0.ctg.ref"), self.aln1, self.diff1, lambda a: f"ctg{int(a['target'])}",
+                  lambda a: self.ctgs[int(a["target"])][1] - self.ctgs[int(a["target"])][0], ctg_strand_seq)
+        write_aln(os.path.join(out_dir, "0.ref.ref"), self.aln2, self.diff2, lambda a: "ref1", lambda a: G, lambda a: ref)
+        with open(os.path.join(out_dir, "config.txt"), "w") as f:
+            f.write("ref1\n0.new.fastq\n0.ctg.ref\n0.ref.ref\n")
+            for c, (s, e, r) in enumerate(self.ctgs):
+                f.write(f"ctg{c}\n{0 if r else 1}\n")
+            f.write("\n")
+        with open(os.path.join(out_dir, "kmer.bin"), "wb") as f:
+            f.write(self.solid_words().tobytes())
+        return out_dir

@@ -1,0 +1,74 @@
+"""GPU: the bench-scale generator (tests/biggen.py, inputs resident in HBM, on_device = 1) at a size the
+oracle still finishes in seconds: HIP build vs oracle bit for bit, and the complete product path
+(pag_process + pagh_traverse) against the compiled reference binary run on the text form of the same
+workload."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import pagctl
+
+
+def _oracle_on(w_host):
+    lib = pagctl.oracle_lib()
+    words = w_host.solid_words()
+    g = lib.pago_create(words.ctypes.data, len(words), w_host.spec.k)
+    inp = w_host.build_input()
+    st = pagctl.BuildStats()
+    assert lib.pago_process(g, C.byref(inp), C.byref(st)) == 0
+    nn, npos, ne = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    lib.pago_csr_sizes(g, C.byref(nn), C.byref(npos), C.byref(ne))
+    lib.pago_destroy(g)
+    return st, (nn.value, npos.value, ne.value)
+
+
+@pytest.mark.gpu
+def test_device_resident_input_matches_oracle_and_reference(workdir):
+    import torch
+    import bench
+    import biggen
+    hip, host = bench.load_libs()
+    sp = biggen.BigSpec(seed=5, ref_len=1_500_000, n_reads=1500, read_span=4000, k=12, ctg_len=300_000, gap_lo=300, gap_hi=3000,
+                        rev_ctg_frac=0.3, threads=16, cov=2, solid_min_abundance=2, chunk_reads=512)
+    w = biggen.BigWorkload(sp, device="cuda")
+    torch.cuda.synchronize()
+    inp = w.build_input()
+    err = C.c_int()
+    g = hip.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, sp.k, 1, 0, C.byref(err))
+    assert g, hip.pag_last_error()
+    st = pagctl.BuildStats()
+    assert hip.pag_process(g, C.byref(inp), C.byref(st)) == 0, hip.pag_last_error()
+
+    # (1) oracle on a host copy of the very same tensors
+    ost, osizes = _oracle_on(w.clone_to("cpu"))
+    assert st.counts() == ost.counts()
+    assert (st.n_nodes, st.n_pos, st.n_uniq_edges) == osizes
+    assert tuple(st.n_tuples) == tuple(ost.n_tuples) and tuple(st.n_edges) == tuple(ost.n_edges)
+
+    # (2) whole product path vs the compiled reference on the text form
+    ref_np = w.ref.cpu().numpy()
+    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_seqs, k1 = bench.host_seqs(ctg_codes)
+    ref_seqs, k2 = bench.host_seqs([ref_np])
+    orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
+    ours = str(workdir / "big_ours")
+    os.makedirs(ours, exist_ok=True)
+    ts = bench.TraverseStats()
+    rc = host.pagh_traverse(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads, sp.eps, 50,
+                            ours.encode(), b"0_", 0, C.byref(ts))
+    assert rc == 0, host.pagh_last_error()
+    hip.pag_destroy(g)
+    assert ts.n_path_bases > 0
+
+    if not os.path.exists(os.path.join(pagctl.REF_DIR, "pagraph")):
+        pytest.skip("oracle/_ref/pagraph not built")
+    txt = str(workdir / "big_txt")
+    w.write_text(txt)
+    r = pagctl.run_reference(txt, str(workdir / "big_ref"), threads=sp.threads, eps=sp.eps, cov=sp.cov)
+    assert r.returncode == 0
+    ref_files = sorted(f for f in os.listdir(workdir / "big_ref") if f != "contig.txt")
+    assert ref_files == sorted(os.listdir(ours))
+    for f in ref_files:
+        assert open(workdir / "big_ref" / f, "rb").read() == open(os.path.join(ours, f), "rb").read(), f
