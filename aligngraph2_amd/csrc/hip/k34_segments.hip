@@ -19,6 +19,8 @@
 // Short segments (<= SHORT_MAX records): one thread per segment, sequential.  Long segments (repeats,
 // low-complexity k-mers) are queued and handled by one wavefront each: 64 leaders compared per step,
 // ballot -> first hit; rank sort through the idle sort ping-pong buffers.
+#include <algorithm>
+
 #include "pag_device.hpp"
 
 namespace pagdev {
@@ -34,13 +36,35 @@ __device__ __forceinline__ bool pos_sim(uint64_t x, uint64_t y, uint32_t eps) {
     return coord_sim((uint32_t)(x >> 32), (uint32_t)(y >> 32), eps) && coord_sim((uint32_t)x, (uint32_t)y, eps);
 }
 
+// sum three per-thread counters over the block and add them to counters[0..2] with one atomic each
+__device__ __forceinline__ void block_flush3(uint64_t a, uint64_t b, uint64_t c, uint64_t *counters) {
+    __shared__ unsigned long long red[3];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t t;
+    wave_excl_sum64(a, &t);
+    a = t;
+    wave_excl_sum64(b, &t);
+    b = t;
+    wave_excl_sum64(c, &t);
+    c = t;
+    if (lane_id() == 0) {
+        if (a) atomicAdd(&red[0], (unsigned long long)a);
+        if (b) atomicAdd(&red[1], (unsigned long long)b);
+        if (c) atomicAdd(&red[2], (unsigned long long)c);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && red[threadIdx.x]) atomicAdd((unsigned long long *)&counters[threadIdx.x], red[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------------ K3
 __global__ __launch_bounds__(256) void cluster_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                     uint64_t n, uint32_t eps, ClusterOut out,
                                                     uint64_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_ctg = 0, n_all = 0, n_seg = 0;
-    if (i < n) {
+    // grid-stride over the stream; counters are accumulated per thread and flushed once per block
+    // (one same-address atomic costs ~12 ns: a per-wave flush would serialise into tens of ms)
+    uint64_t n_ctg = 0, n_all = 0, n_seg = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t kx = key[i];
         bool head = i == 0 || key[i - 1] != kx;
         uint32_t seglen = 0;
@@ -48,7 +72,7 @@ __global__ __launch_bounds__(256) void cluster_short(const uint32_t *__restrict_
             uint64_t j = i + 1;
             while (j < n && j - i <= SHORT_MAX && key[j] == kx) ++j;
             uint64_t len = j - i;
-            n_seg = 1;
+            n_seg += 1;
             if (len > SHORT_MAX) {
                 uint32_t slot = atomicAdd(long_count, 1u);
                 long_list[slot] = i;
@@ -85,20 +109,13 @@ __global__ __launch_bounds__(256) void cluster_short(const uint32_t *__restrict_
                     out.cnt[i + b] = c;
                 }
                 seglen = p;
-                n_all = p;
+                n_all += p;
                 for (uint32_t l = 0; l < p; ++l) n_ctg += (val[i + l] >> 32) != 0;
             }
         }
         out.seg_len[i] = seglen;
     }
-    n_ctg = wave_sum(n_ctg);
-    n_all = wave_sum(n_all);
-    n_seg = wave_sum(n_seg);
-    if (lane_id() == 0) {
-        if (n_ctg) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_ctg);
-        if (n_all) atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)n_all);
-        if (n_seg) atomicAdd((unsigned long long *)&out.counters[2], (unsigned long long)n_seg);
-    }
+    block_flush3(n_ctg, n_all, n_seg, out.counters);
 }
 
 // wave-cooperative: length of the run of `kx` starting at i
@@ -184,7 +201,7 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)((n + 255) / 256);
+    unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
     cluster_short<<<dim3(grid), dim3(256), 0, s>>>(key, val, n, eps, out, long_list, long_count);
     // scratch: u64[n] followed by u32[n] (the idle sort ping-pong buffers)
     cluster_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, (uint32_t *)(scratch + n), n, eps, out,
@@ -197,9 +214,8 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
 __global__ __launch_bounds__(256) void edges_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                   uint64_t n, EdgeOut out, uint64_t *__restrict__ long_list,
                                                   uint32_t *__restrict__ long_count) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_grp = 0, n_grp1 = 0;
-    if (i < n) {
+    uint64_t n_grp = 0, n_grp1 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t kx = key[i];
         bool head = i == 0 || key[i - 1] != kx;
         uint32_t seglen = 0;
@@ -231,17 +247,12 @@ __global__ __launch_bounds__(256) void edges_short(const uint32_t *__restrict__ 
                     }
                 }
                 seglen = p;
-                n_grp = p;
+                n_grp += p;
             }
         }
         out.seg_len[i] = seglen;
     }
-    n_grp = wave_sum(n_grp);
-    n_grp1 = wave_sum(n_grp1);
-    if (lane_id() == 0) {
-        if (n_grp) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_grp);
-        if (n_grp1) atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)n_grp1);
-    }
+    block_flush3(n_grp, n_grp1, 0, out.counters);
 }
 
 __global__ __launch_bounds__(64) void edges_long(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
@@ -284,7 +295,7 @@ int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)((n + 255) / 256);
+    unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
     edges_short<<<dim3(grid), dim3(256), 0, s>>>(key, val, n, out, long_list, long_count);
     edges_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, n, out, long_list, long_count);
     PAG_HIP_TRY(hipGetLastError());

@@ -38,6 +38,13 @@ struct pag_graph {
     uint64_t *eval = nullptr;
     uint32_t *eseg = nullptr;
     pag_build_stats stats{};
+    // device memory pool: every buffer of the pipeline lives in a named slot that is reused (and only
+    // ever grown) across pag_process calls, so steady-state calls do no hipMalloc/hipFree at all
+    struct Slot {
+        void *p = nullptr;
+        size_t cap = 0;
+    };
+    Slot pool[64];
     // debug: raw emitted streams (host copies), kept when PAG_DEBUG_KEEP_STREAMS=1
     std::vector<uint32_t> dbg_tkey, dbg_ekey;
     std::vector<uint64_t> dbg_tval, dbg_eval;
@@ -45,33 +52,33 @@ struct pag_graph {
 
 namespace {
 
-struct DevBuf {  // RAII device allocation
+struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_destroy does)
+    pag_graph *g = nullptr;
+    int slot = -1;
     void *p = nullptr;
-    ~DevBuf() {
-        if (p) hipFree(p);
-    }
+    DevBuf(pag_graph *gg, int s) : g(gg), slot(s) {}
     int alloc(size_t bytes) {
-        if (p) {
-            hipFree(p);
-            p = nullptr;
-        }
         if (bytes == 0) bytes = 16;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-            return PAG_ENOMEM;
+        pag_graph::Slot &sl = g->pool[slot];
+        if (sl.cap < bytes) {
+            if (sl.p) hipFree(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+            size_t want = bytes + bytes / 8 + 256;
+            hipError_t e = hipMalloc(&sl.p, want);
+            if (e != hipSuccess) {
+                sl.p = nullptr;
+                set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+                return PAG_ENOMEM;
+            }
+            sl.cap = want;
         }
+        p = sl.p;
         return PAG_OK;
     }
     template <typename T>
     T *as() const {
         return (T *)p;
-    }
-    void *release() {
-        void *q = p;
-        p = nullptr;
-        return q;
     }
 };
 
@@ -109,10 +116,7 @@ int pick_device(int ordinal) {
     return PAG_OK;
 }
 
-void free_graph_results(pag_graph *g) {
-    void *ptrs[] = {g->tkey, g->tval, g->tseg, g->tcnt, g->ekey, g->eval, g->eseg};
-    for (void *p : ptrs)
-        if (p) hipFree(p);
+void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->tkey = nullptr;
     g->tval = nullptr;
     g->tseg = nullptr;
@@ -232,6 +236,8 @@ void pag_destroy(pag_graph *g) {
     if (!g) return;
     hipSetDevice(g->device);
     free_graph_results(g);
+    for (auto &sl : g->pool)
+        if (sl.p) hipFree(sl.p);
     if (g->solid_bits) hipFree(g->solid_bits);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;
@@ -276,7 +282,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     PAG_HIP_TRY(hipEventRecord(ev[0], s));
 
     // ---- inputs -> device
-    DevBuf b_roff, b_rlen, b_packed, b_order, b_aln1, b_q1, b_d1, b_aln2, b_q2, b_d2, b_ctg, b_eoff, b_ent, b_ref;
+    DevBuf b_roff(g, 0), b_rlen(g, 1), b_packed(g, 2), b_order(g, 3), b_aln1(g, 4), b_q1(g, 5), b_d1(g, 6), b_aln2(g, 7), b_q2(g, 8), b_d2(g, 9), b_ctg(g, 10), b_eoff(g, 11), b_ent(g, 12), b_ref(g, 13);
     const uint64_t *d_roff;
     const uint32_t *d_rlen, *d_order, *d_d1, *d_d2, *d_eoff, *d_ent;
     const uint8_t *d_packed;
@@ -308,7 +314,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
 
     // ---- coverage filter of pass 2
     const uint64_t n_aln1 = in->read_to_ctg.n_aln, n_aln2 = in->read_to_ref.n_aln;
-    DevBuf b_covok, b_covtmp;
+    DevBuf b_covok(g, 14), b_covtmp(g, 15);
     if ((rc = b_covok.alloc(n_aln2 + 16))) return rc;
     size_t cov_bytes = cov_tmp_bytes(refs_host.data(), in->n_refs);
     if ((rc = b_covtmp.alloc(cov_bytes))) return rc;
@@ -317,7 +323,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         return rc;
 
     // ---- column index of both alignment databases
-    DevBuf b_cc, b_cio1, b_cio2, b_ci1, b_ci2, b_scan, b_tot;
+    DevBuf b_cc(g, 16), b_cio1(g, 17), b_cio2(g, 18), b_ci1(g, 19), b_ci2(g, 20), b_scan(g, 21), b_tot(g, 22);
     uint64_t n_alnmax = std::max(n_aln1, n_aln2);
     if ((rc = b_cc.alloc((n_alnmax + 1) * 4))) return rc;
     if ((rc = b_cio1.alloc((n_aln1 + 1) * 8))) return rc;
@@ -342,7 +348,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     }
 
     // ---- K1 count
-    DevBuf b_js, b_jt, b_je, b_toff, b_eoff2;
+    DevBuf b_js(g, 25), b_jt(g, 26), b_je(g, 27), b_toff(g, 28), b_eoff2(g, 29);
     if ((rc = b_js.alloc((n_jobs + 1) * 4))) return rc;
     if ((rc = b_jt.alloc((n_jobs + 1) * 4))) return rc;
     if ((rc = b_je.alloc((n_jobs + 1) * 4))) return rc;
@@ -392,7 +398,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     }
 
     // ---- K1 emit
-    DevBuf b_tk0, b_tv0, b_tk1, b_tv1, b_ek0, b_ev0, b_ek1, b_ev1;
+    DevBuf b_tk0(g, 30), b_tv0(g, 31), b_tk1(g, 32), b_tv1(g, 33), b_ek0(g, 34), b_ev0(g, 35), b_ek1(g, 36), b_ev1(g, 37);
     // the second value buffer of each stream doubles as u64[n] + u32[n] scratch for long segments
     if ((rc = b_tk0.alloc((T + 1) * 4))) return rc;
     if ((rc = b_tv0.alloc((T + 1) * 8))) return rc;
@@ -432,7 +438,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     }
 
     // ---- K2 sorts
-    DevBuf b_sorttmp;
+    DevBuf b_sorttmp(g, 38);
     if ((rc = b_sorttmp.alloc(sort_tmp_bytes(std::max(T, E))))) return rc;
     int t_in0 = 1, e_in0 = 1, passes = 0;
     float ms_scatter_t = 0.f, ms_scatter_e = 0.f;
@@ -446,7 +452,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     // make the sorted data live in the (k0, v0)-sized buffers, the spare (v1: 12 B/record) is scratch
     DevBuf *tk = t_in0 ? &b_tk0 : &b_tk1, *tv = t_in0 ? &b_tv0 : &b_tv1;
     DevBuf *ek = e_in0 ? &b_ek0 : &b_ek1, *evb = e_in0 ? &b_ev0 : &b_ev1;
-    DevBuf b_tscr, b_escr;
+    DevBuf b_tscr(g, 43), b_escr(g, 44);
     uint64_t *t_scratch, *e_scratch;
     if (t_in0) {
         t_scratch = b_tv1.as<uint64_t>();
@@ -462,7 +468,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     }
 
     // ---- K3 / K4
-    DevBuf b_tseg, b_tcnt, b_eseg, b_long, b_lcnt, b_ctr;
+    DevBuf b_tseg(g, 45), b_tcnt(g, 46), b_eseg(g, 47), b_long(g, 48), b_lcnt(g, 49), b_ctr(g, 50);
     if ((rc = b_tseg.alloc((T + 1) * 4))) return rc;
     if ((rc = b_tcnt.alloc((T + 1) * 2))) return rc;
     if ((rc = b_eseg.alloc((E + 1) * 4))) return rc;
@@ -521,13 +527,13 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     // ---- keep the finished graph
     g->n_t = T;
     g->n_e = E;
-    g->tkey = (uint32_t *)tk->release();
-    g->tval = (uint64_t *)tv->release();
-    g->tseg = (uint32_t *)b_tseg.release();
-    g->tcnt = (uint16_t *)b_tcnt.release();
-    g->ekey = (uint32_t *)ek->release();
-    g->eval = (uint64_t *)evb->release();
-    g->eseg = (uint32_t *)b_eseg.release();
+    g->tkey = tk->as<uint32_t>();
+    g->tval = tv->as<uint64_t>();
+    g->tseg = b_tseg.as<uint32_t>();
+    g->tcnt = b_tcnt.as<uint16_t>();
+    g->ekey = ek->as<uint32_t>();
+    g->eval = evb->as<uint64_t>();
+    g->eseg = b_eseg.as<uint32_t>();
     g->stats = st;
     if (stats) *stats = st;
     return PAG_OK;

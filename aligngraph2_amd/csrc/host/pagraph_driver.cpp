@@ -1,5 +1,6 @@
 #include "pagraph_driver.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -118,7 +119,18 @@ Options parseCli(int argc, char **argv) {
 
 }  // namespace
 
+namespace {
+double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 int runPagraph(int argc, char **argv, GraphBackend &backend) {
+    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    double tPrev = nowSec();
+    auto lap = [&](const char *what) {
+        double t = nowSec();
+        if (timing) std::cerr << "[timing] " << what << " " << (t - tPrev) << " s" << std::endl;
+        tPrev = t;
+    };
     if (argc <= 1) {
         usage(std::cerr);
         return 0;
@@ -159,6 +171,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         std::cout << "Building original pa Graph [" << backend.name() << "]" << std::endl;
         backend.create(kmers.words(), static_cast<unsigned>(kmers.k()));
         std::cout << "Done! kmer number=" << backend.solidCount() << std::endl;
+        lap("load global inputs + create");
 
         std::unordered_set<std::string> okCtg;  // same container as the reference: contig.txt order (quirk Q11)
         std::size_t blockNo = 0;
@@ -172,11 +185,13 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             AlnDb readToRef(opt.pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat);
             std::cout << "Done! aln number=" << readToRef.size() << std::endl;
 
+            lap("load block inputs");
             std::cout << "Pre Process" << std::endl;
             GraphInput input(reads, contigs, refs, readToCtg, readToRef, ctgToRef, cfg, params);
             std::set<std::pair<std::string, bool>> usedCtg;
             for (auto &c : cfg.contigs) usedCtg.emplace(c);
 
+            lap("GraphInput (preProcess)");
             std::cout << "[PositionProcessor] Running read to contig..." << std::endl;
             pag_build_stats st{};
             backend.process(input.view(), st);
@@ -185,13 +200,16 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                       << "\n\ttotal pos = " << st.total_pos[1] << "\n\tmerge pos = " << st.merge_pos[1] << std::endl;
             std::cout << "[PositionProcessor] Done!" << std::endl;
 
+            lap("graph build (process)");
             HostGraph graph;
             backend.exportCsr(graph);
+            lap("graph export");
             graph.k = static_cast<std::uint32_t>(kmers.k());
 
             auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, input.ctgMapper(),
                                        input.refMapper(), usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
                                        opt.threads);
+            lap("traverse + write");
             ++blockNo;
             for (auto &s : successCtg) okCtg.emplace(s.first);
         }
