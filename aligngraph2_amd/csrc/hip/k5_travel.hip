@@ -1,0 +1,791 @@
+// k5_travel.hip — K5: epsilon-join traversal on the device.
+//
+// What runs where (reference PAGraph/src/tools/graph/):
+//   device  PABruijnGraph::searchSuccessors + checkPosition + isEdgeSimilar   PABruijnGraph.cpp:143-197, 385-400
+//           PAlgorithm::classifySuccessors / walkStraight / graphTravel        PAlgorithm.tcc:35-298
+//           PAlgorithm::searchPANode / searchPANode2 (seed scans)             PAlgorithm.tcc:300-365
+//           PABruijnGraph::findAll (contig k-mers -> graph nodes)              PABruijnGraph.cpp:339-353
+//   host    the outer loop of PAlgorithm::travelSequence (PAlgorithm.cpp:144-426): per round pick the
+//           longest / leaping seed walk, appendSeq, repeat detection, re-seeding incl. the unstable
+//           std::sort by edit distance (same libstdc++ => same tie order), filterSequence, "Pump it".
+//
+// One wavefront (= one 64-thread workgroup) owns one (contig, seed) graphTravel.  A walk is a chain of
+// dependent steps, so the kernel is latency-bound by design; the lanes share the work inside a step:
+// expanding children x positions, the f64 match predicates, the three visited-set probes, and ordered
+// compaction by ballot.  Visited sets are open-addressing hash tables in HBM; the per-probe set of
+// walkStraight uses generation tags so it never needs clearing.
+//
+// Before traversal the k-mer-sorted streams are compacted into a CSR with dense node / vertex ids and a
+// 4^k-bit node bitmap + rank directory (code -> node id in two loads).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "pag_device.hpp"
+#include "pag_travel.hpp"
+
+namespace pagdev {
+
+// =================================================================================================
+// graph compaction
+// =================================================================================================
+__global__ void k_head_flags(const uint32_t *__restrict__ key, uint64_t n, uint32_t *__restrict__ flag) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        flag[i] = (i == 0 || key[i - 1] != key[i]) ? 1u : 0u;
+}
+
+__global__ void k_compact_nodes(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval,
+                                const uint32_t *__restrict__ tseg, const uint16_t *__restrict__ tcnt, uint64_t T,
+                                const uint64_t *__restrict__ node_idx, const uint64_t *__restrict__ pos_off, TravGraph G) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t kx = tkey[i];
+        if (i != 0 && tkey[i - 1] == kx) continue;
+        uint64_t n = node_idx[i], p = pos_off[i];
+        G.ncode[n] = kx;
+        G.npos_off[n] = (uint32_t)p;
+        atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
+        uint32_t len = tseg[i];
+        for (uint32_t l = 0; l < len; ++l) {
+            G.vpos[p + l] = tval[i + l];
+            G.vcnt[p + l] = tcnt[i + l];
+            G.vnode[p + l] = (uint32_t)n;
+        }
+    }
+}
+
+__global__ void k_popc_words(const uint64_t *__restrict__ bitmap, uint64_t n_words, uint32_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (uint32_t)__popcll(bitmap[i]);
+}
+
+__global__ void k_narrow(const uint64_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (uint32_t)in[i];
+}
+
+__device__ __forceinline__ uint32_t node_of_code(const TravGraph &G, uint32_t code) {
+    uint64_t w = G.bitmap[code >> 6];
+    uint32_t b = code & 63u;
+    if (!((w >> b) & 1ull)) return PAG_NONE;
+    return G.rank[code >> 6] + (uint32_t)__popcll(w & ((1ull << b) - 1ull));
+}
+
+__global__ void k_edge_counts(const uint32_t *__restrict__ ekey, const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G,
+                              uint32_t *__restrict__ necnt) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t kx = ekey[j];
+        if (j != 0 && ekey[j - 1] == kx) continue;
+        uint32_t n = node_of_code(G, kx);
+        if (n != PAG_NONE) necnt[n] = eseg[j];
+    }
+}
+
+__global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_t *__restrict__ eval,
+                                const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t kx = ekey[j];
+        if (j != 0 && ekey[j - 1] == kx) continue;
+        uint32_t n = node_of_code(G, kx);
+        if (n == PAG_NONE) continue;
+        uint32_t dst = G.nedge_off[n], len = eseg[j];
+        for (uint32_t l = 0; l < len; ++l) {
+            uint64_t v = eval[j + l];
+            G.eto[dst + l] = node_of_code(G, (uint32_t)(v >> 32));
+            G.estep[dst + l] = ((uint32_t)v) >> 1;
+        }
+    }
+}
+
+// contig strand k-mers -> node ids (PABruijnGraph::findAll).  One thread per k-mer start.
+__global__ void k_ctg_nodes(const uint8_t *__restrict__ packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k,
+                            TravGraph G, uint32_t *__restrict__ out) {
+    const uint32_t n_pos = len >= k ? len - k + 1 : 0;
+    const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    const uint32_t *words = (const uint32_t *)(packed + byte_off);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += gridDim.x * blockDim.x) {
+        uint32_t a = forward ? i : len - k - i;  // first contig base (forward numbering) covered by the k-mer
+        uint32_t w = a >> 4, sh = (a & 15u) * 2u;
+        uint64_t W = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
+        uint32_t x = (uint32_t)(W >> sh) & kmask;
+        uint32_t code = forward ? (rev2(x) >> (32 - 2 * k)) : ((~x) & kmask);
+        out[i] = node_of_code(G, code);
+    }
+}
+
+// =================================================================================================
+// match predicates (f64 exactly as the reference; compiled with -ffp-contract=off, no fast-math)
+// =================================================================================================
+__device__ __forceinline__ bool d_coord_sim(uint32_t a, uint32_t b, uint64_t dev) {
+    return a != 0 && b != 0 && (uint64_t)((a > b ? a : b) - (a > b ? b : a)) <= dev;
+}
+// isEdgeSimilar (PABruijnGraph.cpp:385-400): bit0 contig side, bit1 reference side
+__device__ __forceinline__ uint32_t d_edge_similar(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, int dist, uint64_t dev,
+                                                  double err) {
+    uint32_t tc = ac != 0 ? ac + (uint32_t)dist : 0, tr = ar != 0 ? ar + (uint32_t)dist : 0;
+    bool s1 = d_coord_sim(tc, bc, dev), s2 = d_coord_sim(tr, br, dev);
+    s1 = s1 || (ac != 0 && bc != 0 && fabs(1.0 - ((double)(uint32_t)(bc - ac) * 1.0 / (double)dist)) <= err);
+    s2 = s2 || (ar != 0 && br != 0 && fabs(1.0 - ((double)(uint32_t)(br - ar) * 1.0 / (double)dist)) <= err);
+    return (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
+}
+enum { G_OOPS = 0, G_SKIP = 1, G_GOOD = 2, G_EXCELLENT = 3, G_AMAZING = 4 };
+// checkPosition (PABruijnGraph.cpp:143-165) incl. the un-guarded second ratio test (quirk Q6)
+__device__ __forceinline__ int d_check_position(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev,
+                                                double err, uint32_t *edge_sim) {
+    uint32_t st = d_edge_similar(ac, ar, bc, br, (int)dist, dev, err);
+    *edge_sim = st;
+    bool s1 = st & 1u, s2 = (st >> 1) & 1u;
+    s1 = s1 || fabs(1.0 - ((double)(uint32_t)(bc - ac) * 1.0 / (double)dist)) <= err;
+    s2 = s2 || fabs(1.0 - ((double)(uint32_t)(br - ar) * 1.0 / (double)dist)) <= err;
+    if (ac == 0 || bc == 0) return s2 ? (bc != 0 ? G_EXCELLENT : (ac != 0 ? G_SKIP : G_GOOD)) : G_OOPS;
+    if (ar == 0 || br == 0) return s1 ? (br != 0 ? G_EXCELLENT : G_GOOD) : G_OOPS;
+    return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
+}
+
+// =================================================================================================
+// visited sets
+// =================================================================================================
+#define HS_EMPTY 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t hs_hash(uint32_t key, uint32_t mask) { return (key * 2654435761u) & mask; }
+// lookups use agent-scope (sc1) loads: inserts are L2 atomics, which a CU's L1 does not observe
+__device__ __forceinline__ bool hs_has(const uint32_t *tab, uint32_t mask, uint32_t key) {
+    if (!tab) return false;
+    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
+        uint32_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x == key) return true;
+        if (x == HS_EMPTY) return false;
+    }
+}
+// concurrent insert (distinct or equal keys, any lanes)
+__device__ __forceinline__ void hs_insert(uint32_t *tab, uint32_t mask, uint32_t key) {
+    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
+        uint32_t old = atomicCAS(&tab[s], HS_EMPTY, key);
+        if (old == HS_EMPTY || old == key) return;
+    }
+}
+// generation-tagged set: entry = key | gen << 32; an entry of another generation counts as free
+__device__ __forceinline__ bool gs_has(const uint64_t *tab, uint32_t mask, uint32_t key, uint32_t gen) {
+    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
+        uint64_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(x >> 32) != gen) return false;
+        if ((uint32_t)x == key) return true;
+    }
+}
+__device__ __forceinline__ void gs_insert_single(uint64_t *tab, uint32_t mask, uint32_t key, uint32_t gen) {  // one lane only
+    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
+        uint64_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(x >> 32) != gen) {
+            __hip_atomic_store(&tab[s], (uint64_t)key | ((uint64_t)gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if ((uint32_t)x == key) return;
+    }
+}
+
+// =================================================================================================
+// the walker
+// =================================================================================================
+constexpr int LIST_CAP = 256;  // successors of one vertex kept per class
+constexpr int BR_CAP = 256;    // branch fan-out kept per graphTravel round
+
+struct WalkLds {
+    uint32_t e_to[64], e_step[64], e_p0[64], e_pre[65];
+    uint32_t lst_v[4][LIST_CAP], lst_s[4][LIST_CAP];
+    uint32_t lst_n[4];
+    uint32_t br_v[BR_CAP], br_s[BR_CAP];
+    uint32_t out_n;
+};
+
+struct WalkCtx {
+    TravGraph G;
+    TravContig C;
+    // job state
+    uint32_t *tset;
+    uint32_t tmask;
+    uint64_t *pset;
+    uint32_t pmask;
+    uint32_t gen;
+    uint32_t win_g0, win_g1;  // ctgGlobalPosTable
+    uint32_t win_t0, win_t1;  // ctgTravelPosTable
+    uint32_t win_p0, win_p1;  // walkStraight's ctgPosTable
+    uint32_t dev;
+    double err;
+    int overflow;
+};
+
+__device__ __forceinline__ bool in_win(uint32_t lo, uint32_t hi, uint32_t p) { return p >= lo && p <= hi; }
+__device__ __forceinline__ void win_add(uint32_t &lo, uint32_t &hi, uint32_t p) {
+    if (p == 0) return;
+    lo = p < lo ? p : lo;
+    hi = p > hi ? p : hi;
+}
+
+// classifySuccessors (PAlgorithm.tcc:35-90) on top of searchSuccessors (PABruijnGraph.cpp:167-197).
+// level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
+// Result: L.lst_v/lst_s[0] hold the chosen class in reference order, return = its size.
+__device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap, int level) {
+    const uint32_t lane = lane_id();
+    const uint64_t rootp = X.G.vpos[cur];
+    const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
+    const uint32_t node = X.G.vnode[cur];
+    const uint32_t e0 = X.G.nedge_off[node], e1 = X.G.nedge_off[node + 1];
+    __syncthreads();
+    if (lane < 4) L.lst_n[lane] = 0;
+    __syncthreads();
+    for (uint32_t eb = e0; eb < e1; eb += 64) {
+        // this group's edges and the vertex ranges of their targets
+        uint32_t cnt = 0;
+        if (eb + lane < e1) {
+            uint32_t to = X.G.eto[eb + lane];
+            L.e_to[lane] = to;
+            L.e_step[lane] = X.G.estep[eb + lane];
+            uint32_t p0 = 0, p1 = 0;
+            if (to != PAG_NONE) {
+                p0 = X.G.npos_off[to];
+                p1 = X.G.npos_off[to + 1];
+            }
+            L.e_p0[lane] = p0;
+            cnt = p1 - p0;
+        }
+        uint32_t total;
+        uint32_t ex = wave_excl_sum(cnt, &total);
+        L.e_pre[lane] = ex;
+        if (lane == 63) L.e_pre[64] = total;
+        __syncthreads();
+        for (uint32_t cb = 0; cb < total; cb += 64) {
+            uint32_t ci = cb + lane;
+            int cls = -1;
+            uint32_t v = 0, step = 0;
+            if (ci < total) {
+                // edge slot of candidate ci: last slot with prefix <= ci
+                uint32_t lo = 0, hi = 64;
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (L.e_pre[mid] <= ci) lo = mid;
+                    else hi = mid;
+                }
+                v = L.e_p0[lo] + (ci - L.e_pre[lo]);
+                step = L.e_step[lo];
+                const uint64_t pp = X.G.vpos[v];
+                const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
+                uint32_t esim;
+                int grade = d_check_position(rc, rr, pc, pr, step, X.dev, X.err, &esim);
+                bool ok = grade != G_OOPS;
+                const bool ectg = esim & 1u;
+                // filters, innermost level first is irrelevant: all must hold
+                if (ok) ok = !hs_has(X.C.gset, X.C.gmask, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
+                             (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
+                if (ok) ok = !hs_has(X.tset, X.tmask, v) && (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
+                if (ok && level == 2) ok = !gs_has(X.pset, X.pmask, v, X.gen) && (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
+                if (ok) {
+                    bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
+                    if (leap) {
+                        // landing rule: only the first leapMin fraction of the target contig strand
+                        // singleToDual (PositionMapper.cpp:44-64) via the start table
+                        uint32_t lo2 = 0, hi2 = X.C.n_ctgs + 1;  // starts has n_ctgs + 1 entries
+                        // upper_bound(starts, pc) then step back
+                        while (lo2 < hi2) {
+                            uint32_t mid = (lo2 + hi2) >> 1;
+                            if (X.C.starts[mid] <= (uint64_t)pc) lo2 = mid + 1;
+                            else hi2 = mid;
+                        }
+                        uint32_t idx = lo2 ? lo2 - 1 : 0;
+                        uint64_t off = (uint64_t)pc - X.C.starts[idx];
+                        uint64_t sz = idx < X.C.n_ctgs ? X.C.sizes[idx] : 0;
+                        if (off >= 2 * sz) off -= 2 * sz;
+                        if ((double)(int64_t)off > (double)sz * X.C.leap_min) ok = false;
+                        if (!can_leap) ok = false;
+                    }
+                    if (ok) {
+                        if (grade == G_AMAZING || leap) cls = 0;
+                        else if (grade == G_EXCELLENT) cls = 1;
+                        else if (grade == G_GOOD) cls = 2;
+                        else if (can_leap && grade == G_SKIP) cls = 3;
+                    }
+                }
+            }
+            // ordered append to the four class lists
+            for (int c = 0; c < 4; ++c) {
+                uint64_t m = __ballot(cls == c);
+                if (m == 0) continue;
+                uint32_t base = L.lst_n[c];
+                if (cls == c) {
+                    uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt());
+                    if (at < LIST_CAP) {
+                        L.lst_v[c][at] = v;
+                        L.lst_s[c][at] = step;
+                    }
+                }
+                __syncthreads();
+                if (lane == 0) L.lst_n[c] = base + (uint32_t)__popcll(m);
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    int chosen = L.lst_n[0] ? 0 : (L.lst_n[1] ? 1 : (L.lst_n[2] ? 2 : 3));
+    uint32_t n = L.lst_n[chosen];
+    if (n > LIST_CAP) {
+        X.overflow = 1;
+        n = LIST_CAP;
+    }
+    if (chosen != 0) {
+        for (uint32_t i = lane; i < n; i += 64) {
+            L.lst_v[0][i] = L.lst_v[chosen][i];
+            L.lst_s[0][i] = L.lst_s[chosen][i];
+        }
+    }
+    __syncthreads();
+    return n;
+}
+
+enum { WS_END = 0, WS_BRANCH = 1, WS_LIMIT = 2, WS_LEAP = 3 };
+
+// walkStraight (PAlgorithm.tcc:93-170): writes the path to pv/ps (capacity cap), returns status
+__device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, uint64_t has_size, uint32_t *pv, uint32_t *ps,
+                             uint64_t cap, uint64_t *out_len) {
+    const uint32_t lane = lane_id();
+    X.gen += 1;
+    X.win_p0 = 0xFFFFFFFFu;
+    X.win_p1 = 0;
+    uint64_t now_size = s0, len = 0;
+    if (cap == 0) {
+        X.overflow = 1;
+        *out_len = 0;
+        return WS_END;
+    }
+    if (lane == 0) {
+        pv[0] = v0;
+        ps[0] = s0;
+    }
+    len = 1;
+    uint32_t c = (uint32_t)(X.G.vpos[v0] >> 32);
+    if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
+        *out_len = len;
+        return WS_LEAP;
+    }
+    win_add(X.win_p0, X.win_p1, c);
+    if (lane == 0) gs_insert_single(X.pset, X.pmask, v0, X.gen);
+    __syncthreads();
+    uint32_t cur = v0;
+    int status;
+    for (;;) {
+        uint32_t m = classify(L, X, cur, (has_size + now_size) >= X.C.split_size, 2);
+        if (m == 0) {
+            status = WS_END;
+            break;
+        }
+        if (m > 1) {
+            status = WS_BRANCH;
+            break;
+        }
+        uint32_t v = L.lst_v[0][0], s = L.lst_s[0][0];
+        __syncthreads();
+        if (len >= cap || (len + 1) * 2 > (uint64_t)X.pmask) {
+            X.overflow = 1;
+            status = WS_END;
+            break;
+        }
+        uint32_t vc = (uint32_t)(X.G.vpos[v] >> 32);
+        if (lane == 0) {
+            gs_insert_single(X.pset, X.pmask, v, X.gen);
+            pv[len] = v;
+            ps[len] = s;
+        }
+        win_add(X.win_p0, X.win_p1, vc);
+        len += 1;
+        now_size += s;
+        __syncthreads();
+        if (vc != 0 && (vc < X.C.ctg_left || vc >= X.C.ctg_right)) {
+            status = WS_LEAP;
+            break;
+        }
+        cur = v;
+    }
+    *out_len = len;
+    return status;
+}
+
+// graphTravel (PAlgorithm.tcc:172-298), one wave per job
+__global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__restrict__ ctgs, const TravJob *__restrict__ jobs,
+                                             TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k, uint32_t dev, double err) {
+    __shared__ WalkLds L;
+    const uint32_t jid = blockIdx.x;
+    if (jid >= n_jobs) return;
+    const uint32_t lane = lane_id();
+    const TravJob J = jobs[jid];
+    WalkCtx X;
+    X.G = G;
+    X.C = ctgs[J.ctg];
+    X.tset = J.tset;
+    X.tmask = J.tmask;
+    X.pset = J.pset;
+    X.pmask = J.pmask;
+    X.gen = 0;
+    X.win_g0 = X.C.gwin_lo;
+    X.win_g1 = X.C.gwin_hi;
+    X.win_t0 = 0xFFFFFFFFu;
+    X.win_t1 = 0;
+    X.dev = dev;
+    X.err = err;
+    X.overflow = 0;
+
+    uint64_t seq_len = 0, now_size = k, seq_size = 0;
+    const uint64_t has_size = J.has_size;
+    win_add(X.win_t0, X.win_t1, (uint32_t)(G.vpos[J.start] >> 32));
+
+    // first walk from the seed
+    uint64_t plen = 0;
+    walk_straight(L, X, J.start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
+    uint64_t ch_off = 0, ch_len = plen;  // chosen path inside the arena
+
+    for (;;) {
+        // append the chosen path to the sequence, mark visited, widen the travel window
+        if (seq_len + ch_len > J.seq_cap || (seq_len + ch_len) * 2 > (uint64_t)J.tmask) {
+            X.overflow = 1;
+            break;
+        }
+        uint64_t add = 0;
+        for (uint64_t i = lane; i < ch_len; i += 64) {
+            uint32_t v = J.arena_v[ch_off + i], s = J.arena_s[ch_off + i];
+            J.seq_v[seq_len + i] = v;
+            J.seq_s[seq_len + i] = s;
+            hs_insert(J.tset, J.tmask, v);
+            add += s;
+        }
+        // wave reductions: sum of steps, min/max of non-zero contig coordinates
+        {
+            uint64_t tot;
+            wave_excl_sum64(add, &tot);
+            now_size += tot;
+            seq_size += tot;
+            uint32_t lo = 0xFFFFFFFFu, hi = 0;
+            for (uint64_t i = lane; i < ch_len; i += 64) {
+                uint32_t c = (uint32_t)(G.vpos[J.arena_v[ch_off + i]] >> 32);
+                if (c != 0) {
+                    lo = c < lo ? c : lo;
+                    hi = c > hi ? c : hi;
+                }
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                uint32_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
+                lo = ol < lo ? ol : lo;
+                hi = oh > hi ? oh : hi;
+            }
+            if (hi != 0) {
+                X.win_t0 = lo < X.win_t0 ? lo : X.win_t0;
+                X.win_t1 = hi > X.win_t1 ? hi : X.win_t1;
+            }
+        }
+        seq_len += ch_len;
+        __threadfence_block();
+        __syncthreads();
+
+        const uint32_t last = J.seq_v[seq_len - 1];
+        const uint32_t lc = (uint32_t)(G.vpos[last] >> 32);
+        if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
+
+        uint32_t m = classify(L, X, last, (has_size + now_size) >= X.C.split_size, 1);
+        if (m == 0) break;
+        if (m > BR_CAP) {
+            X.overflow = 1;
+            m = BR_CAP;
+        }
+        for (uint32_t i = lane; i < m; i += 64) {
+            L.br_v[i] = L.lst_v[0][i];
+            L.br_s[i] = L.lst_s[0][i];
+        }
+        __syncthreads();
+
+        // probe every alternative (PAlgorithm.tcc:251-266), paths laid out back to back in the arena
+        uint64_t used = 0;
+        int first_leap = -1, best_branch = -1, best_tip = -1;
+        uint32_t best_ab = 0;
+        uint64_t best_tip_len = 0, leap_off = 0, leap_len = 0, br_off = 0, br_len = 0, tip_off = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+            uint32_t sv = L.br_v[i], ss = L.br_s[i];
+            uint64_t l2 = 0;
+            int stt = walk_straight(L, X, sv, ss, has_size + now_size, J.arena_v + used, J.arena_s + used, J.arena_cap - used, &l2);
+            if (stt == WS_LEAP) {
+                if (first_leap < 0) {
+                    first_leap = (int)i;
+                    leap_off = used;
+                    leap_len = l2;
+                }
+            } else if (stt == WS_END) {
+                if (best_tip < 0 || l2 > best_tip_len) {
+                    best_tip = (int)i;
+                    best_tip_len = l2;
+                    tip_off = used;
+                }
+            } else {
+                uint32_t ab = G.vcnt[sv];
+                if (best_branch < 0 || ab > best_ab) {
+                    best_branch = (int)i;
+                    best_ab = ab;
+                    br_off = used;
+                    br_len = l2;
+                }
+            }
+            used += l2;
+            if (X.overflow) break;
+        }
+        if (X.overflow) break;
+        if (first_leap >= 0) {
+            ch_off = leap_off;
+            ch_len = leap_len;
+        } else if (best_branch >= 0) {
+            ch_off = br_off;
+            ch_len = br_len;
+        } else {
+            ch_off = tip_off;
+            ch_len = best_tip_len;
+        }
+    }
+    if (lane == 0) {
+        TravJobOut o;
+        o.seq_len = seq_len;
+        o.seq_size = seq_size;
+        o.overflow = X.overflow;
+        o.last_ctg = seq_len ? (uint32_t)(G.vpos[J.seq_v[seq_len - 1]] >> 32) : 0;
+        outs[jid] = o;
+    }
+}
+
+// =================================================================================================
+// seeds
+// =================================================================================================
+// searchPANode(onlyFirst = true) (PAlgorithm.tcc:300-327): the first contig k-mer one of whose positions
+// lies on this contig strand within `dev` of the k-mer's own offset; all such positions of that k-mer.
+// One wave per contig.  out[0] = count, then (vertex, node) pairs.
+__global__ __launch_bounds__(64) void k_seed_first(TravGraph G, const TravContig *__restrict__ ctgs, uint32_t n_ctgs_sel,
+                                                   uint64_t dev, uint32_t *__restrict__ out, uint32_t out_stride) {
+    const uint32_t c = blockIdx.x;
+    if (c >= n_ctgs_sel) return;
+    const TravContig C = ctgs[c];
+    const uint32_t lane = lane_id();
+    uint32_t *o = out + (uint64_t)c * out_stride;
+    uint32_t found = 0;
+    for (uint32_t base = 0; base < C.n_kmers && !found; base += 64) {
+        uint32_t i = base + lane;
+        bool hit = false;
+        uint32_t node = PAG_NONE;
+        if (i < C.n_kmers) {
+            node = C.nodes[i];
+            if (node != PAG_NONE) {
+                for (uint32_t p = G.npos_off[node]; p < G.npos_off[node + 1] && !hit; ++p) {
+                    uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
+                    if (pc >= C.ctg_left && pc < C.ctg_right) {
+                        uint64_t off = pc - C.ctg_left;
+                        uint64_t d = off > i ? off - i : (uint64_t)i - off;
+                        hit = d <= dev;
+                    }
+                }
+            }
+        }
+        uint64_t m = __ballot(hit);
+        if (m) {
+            int src = __ffsll((long long)m) - 1;
+            if ((int)lane == src) {
+                uint32_t n = 0;
+                for (uint32_t p = G.npos_off[node]; p < G.npos_off[node + 1]; ++p) {
+                    uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
+                    if (pc >= C.ctg_left && pc < C.ctg_right) {
+                        uint64_t off = pc - C.ctg_left;
+                        uint64_t d = off > i ? off - i : (uint64_t)i - off;
+                        if (d <= dev && 1 + 2 * n + 1 < out_stride) {
+                            o[1 + 2 * n] = p;
+                            o[2 + 2 * n] = i;
+                            ++n;
+                        }
+                    }
+                }
+                o[0] = n;
+            }
+            found = 1;
+        }
+    }
+    if (!found && lane == 0) o[0] = 0;
+}
+
+// searchPANode2 (PAlgorithm.tcc:329-365): every (contig offset in [left, right], position) pair whose
+// position lies on this strand within `dev` of `pos`, in order.  Duplicates of a vertex are removed on
+// the host (first occurrence wins).  One wave per request.  out[0] = count, then vertex ids.
+__global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravContig *__restrict__ ctgs,
+                                                    const TravSeedReq *__restrict__ reqs, uint32_t n_req, uint64_t dev,
+                                                    uint32_t *__restrict__ out, uint32_t out_stride) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n_req) return;
+    const TravSeedReq R = reqs[r];
+    const TravContig C = ctgs[R.ctg];
+    const uint32_t lane = lane_id();
+    uint32_t *o = out + (uint64_t)r * out_stride;
+    uint32_t n_out = 0;
+    uint64_t right = R.right < (uint64_t)C.n_kmers ? R.right + 1 : C.n_kmers;  // exclusive
+    for (uint64_t base = R.left; base < right; base += 64) {
+        uint64_t i = base + lane;
+        uint32_t node = i < right ? C.nodes[i] : PAG_NONE;
+        uint32_t p0 = 0, p1 = 0;
+        if (node != PAG_NONE) {
+            p0 = G.npos_off[node];
+            p1 = G.npos_off[node + 1];
+        }
+        // lanes emit in lane order, positions in order: serialise over the lanes that have matches
+        uint32_t cnt = 0;
+        for (uint32_t p = p0; p < p1; ++p) {
+            uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
+            if (pc >= C.ctg_left && pc < C.ctg_right) {
+                uint64_t off = pc - C.ctg_left;
+                uint64_t d = off > R.pos ? off - R.pos : R.pos - off;
+                cnt += d <= dev;
+            }
+        }
+        uint32_t tot;
+        uint32_t ex = wave_excl_sum(cnt, &tot);
+        uint32_t w = n_out + ex;
+        for (uint32_t p = p0; p < p1 && cnt; ++p) {
+            uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
+            if (pc >= C.ctg_left && pc < C.ctg_right) {
+                uint64_t off = pc - C.ctg_left;
+                uint64_t d = off > R.pos ? off - R.pos : R.pos - off;
+                if (d <= dev) {
+                    if (1 + w < out_stride) o[1 + w] = p;
+                    ++w;
+                }
+            }
+        }
+        n_out += tot;
+    }
+    if (lane == 0) o[0] = n_out;
+}
+
+// insert a finished walk into the contig's global visited set
+__global__ void k_commit(const uint32_t *__restrict__ seq_v, uint64_t len, uint32_t *gset, uint32_t gmask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
+        hs_insert(gset, gmask, seq_v[i]);
+}
+
+// vertex attributes of a path for the host
+__global__ void k_gather_path(TravGraph G, const uint32_t *__restrict__ seq_v, const uint32_t *__restrict__ seq_s, uint64_t len,
+                              pag_path_node *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = seq_v[i];
+        uint64_t p = G.vpos[v];
+        pag_path_node o;
+        o.code = G.ncode[G.vnode[v]];
+        o.ctg = (uint32_t)(p >> 32);
+        o.ref = (uint32_t)p;
+        o.cnt = G.vcnt[v];
+        o.reserved = 0;
+        o.step = (int32_t)seq_s[i];
+        o.vid = v;
+        out[i] = o;
+    }
+}
+
+__global__ void k_gather_vertices(TravGraph G, const uint32_t *__restrict__ vids, uint32_t n, pag_path_node *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = vids[i];
+    uint64_t p = G.vpos[v];
+    pag_path_node o;
+    o.code = G.ncode[G.vnode[v]];
+    o.ctg = (uint32_t)(p >> 32);
+    o.ref = (uint32_t)p;
+    o.cnt = G.vcnt[v];
+    o.reserved = 0;
+    o.step = 0;
+    o.vid = v;
+    out[i] = o;
+}
+
+// -------------------------------------------------------------------------------------------------
+// launch wrappers used by pag_travel.cpp-side orchestration in pag_api.hip
+// -------------------------------------------------------------------------------------------------
+static unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16) + (n == 0); }
+
+int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
+                 const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
+                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s) {
+    // tmp: flags u32[max(T, E, words, nodes + 1)] | scan out u64[same] | scan out 2 u64[T] | scan tmp
+    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
+    uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
+    char *p = (char *)tmp;
+    auto take = [&](size_t bytes) {
+        char *q = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return (void *)q;
+    };
+    uint32_t *flags = (uint32_t *)take(m * 4);
+    uint64_t *sc1 = (uint64_t *)take(m * 8);
+    uint64_t *sc2 = (uint64_t *)take(m * 8);
+    void *scan_tmp = take(scan_tmp_bytes(m));
+    if ((size_t)(p - (char *)tmp) > tmp_bytes) {
+        set_error("trav_compact: scratch too small");
+        return PAG_EINVAL;
+    }
+    PAG_HIP_TRY(hipMemsetAsync(G.bitmap, 0, n_words * 8, s));
+    int rc;
+    if (T) {
+        k_head_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, T, flags);
+        if ((rc = scan_u32_to_u64(flags, sc1, T, nullptr, scan_tmp, s))) return rc;
+        if ((rc = scan_u32_to_u64(tseg, sc2, T, nullptr, scan_tmp, s))) return rc;
+        k_compact_nodes<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, tcnt, T, sc1, sc2, G);
+    }
+    uint32_t np32 = (uint32_t)n_pos, ne32 = (uint32_t)n_edges;
+    PAG_HIP_TRY(hipMemcpyAsync(G.npos_off + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
+    // rank directory
+    k_popc_words<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(G.bitmap, n_words, flags);
+    if ((rc = scan_u32_to_u64(flags, sc1, n_words, nullptr, scan_tmp, s))) return rc;
+    k_narrow<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(sc1, n_words, G.rank);
+    // edges
+    PAG_HIP_TRY(hipMemsetAsync(flags, 0, (n_nodes + 1) * 4, s));
+    if (E) k_edge_counts<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eseg, E, G, flags);
+    if ((rc = scan_u32_to_u64(flags, sc1, n_nodes + 1, nullptr, scan_tmp, s))) return rc;
+    k_narrow<<<dim3(grid_for(n_nodes + 1)), dim3(256), 0, s>>>(sc1, n_nodes + 1, G.nedge_off);
+    if (E) k_compact_edges<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eval, eseg, E, G);
+    (void)ne32;
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+
+size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes) {
+    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
+    uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
+    return ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024;
+}
+
+void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
+                           uint32_t *out, hipStream_t s) {
+    uint32_t n = len >= k ? len - k + 1 : 0;
+    if (!n) return;
+    k_ctg_nodes<<<dim3(grid_for(n)), dim3(256), 0, s>>>(packed, byte_off, len, forward, k, G, out);
+}
+void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uint64_t dev, uint32_t *out, uint32_t stride,
+                            hipStream_t s) {
+    if (n) k_seed_first<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, n, dev, out, stride);
+}
+void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
+                             uint32_t *out, uint32_t stride, hipStream_t s) {
+    if (n) k_seed_window<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out, stride);
+}
+void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
+                      uint32_t dev, double err, hipStream_t s) {
+    if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k, dev, err);
+}
+void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t *gset, uint32_t gmask, hipStream_t s) {
+    if (len) k_commit<<<dim3(grid_for(len)), dim3(256), 0, s>>>(seq_v, len, gset, gmask);
+}
+void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
+                             hipStream_t s) {
+    if (len) k_gather_path<<<dim3(grid_for(len)), dim3(256), 0, s>>>(G, seq_v, seq_s, len, out);
+}
+void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s) {
+    if (n) k_gather_vertices<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(G, vids, n, out);
+}
+
+}  // namespace pagdev

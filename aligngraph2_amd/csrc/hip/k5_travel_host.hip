@@ -1,0 +1,595 @@
+// k5_travel_host.hip — pag_travel: the per-round control of PAlgorithm::travelSequence
+// (reference PAGraph/src/tools/graph/PAlgorithm.cpp:144-426) around the device kernels of k5_travel.hip.
+//
+// All selected contigs advance in lock step: round r launches one walker wave per (contig, seed), the
+// host then applies the reference's choice rule per contig (first leaping walk, else the longest; seeds
+// after the first must reach minLen), splices the walk into the running path (appendSeq), records it in
+// the contig's global visited set (device hash set + host mirror), checks the repeat / leap stop rules
+// and prepares the next seeds (window scan on the device; ordering by edit distance with the same
+// unstable std::sort as the reference on the host).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "pag_graph_impl.hpp"
+
+using namespace pagdev;
+
+namespace {
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// PositionMapper (position/PositionMapper.cpp:16-64) over contig lengths
+struct Mapper {
+    std::vector<uint64_t> starts, sizes;
+    Mapper(const uint32_t *len, uint64_t n) {
+        for (uint64_t i = 0; i < n; ++i) sizes.push_back(len[i]);
+        if (sizes.empty()) return;
+        starts.push_back(sizes[0]);
+        for (size_t i = 1; i < sizes.size(); ++i) starts.push_back(starts.back() + 3 * sizes[i - 1] + std::max(sizes[i - 1], sizes[i]));
+        starts.push_back(starts.back() + 4 * sizes.back());
+    }
+    uint64_t dualToSingle(int64_t idx, int64_t pos) const {
+        if (idx == 0) return 0;
+        size_t i = (size_t)(idx > 0 ? idx - 1 : -idx - 1);
+        return starts[i] + (idx > 0 ? 0 : 2 * sizes[i]) + (uint64_t)pos;
+    }
+    std::pair<int64_t, int64_t> singleToDual(uint64_t single) const {
+        if (single == 0) return {0, 0};
+        auto it = std::upper_bound(starts.begin(), starts.end(), single);
+        if (it != starts.begin()) it = std::prev(it);
+        int64_t idx = it - starts.begin();
+        uint64_t off = single - *it;
+        uint64_t sz = (size_t)idx < sizes.size() ? sizes[(size_t)idx] : 0;
+        if (off >= 2 * sz) {
+            off -= 2 * sz;
+            idx = -(idx + 1);
+        } else {
+            ++idx;
+        }
+        return {idx, (int64_t)off};
+    }
+};
+
+std::string code2kmer(uint32_t code, uint32_t k) {
+    std::string s(k, 'A');
+    for (uint32_t i = 0; i < k; ++i) {
+        s[k - 1 - i] = "ACGT"[code & 3u];
+        code >>= 2;
+    }
+    return s;
+}
+
+// PAlgorithm::editDistance (PAlgorithm.cpp:46-69)
+size_t edit_distance(const std::string &a, const std::string &b) {
+    std::vector<std::vector<size_t>> dp(2, std::vector<size_t>(b.size() + 1, 0));
+    size_t flag = 0;
+    for (size_t j = 0; j <= b.size(); ++j) dp[flag][j] = j;
+    flag ^= 1;
+    for (size_t i = 1; i <= a.size(); ++i) {
+        for (size_t j = 0; j <= b.size(); ++j) {
+            if (j == 0) {
+                dp[flag][j] = i;
+            } else {
+                dp[flag][j] = std::min(dp[flag ^ 1][j] + 1, dp[flag][j - 1] + 1);
+                dp[flag][j] = std::min(dp[flag][j], dp[flag ^ 1][j - 1] + (a[i - 1] == b[j - 1] ? 0 : 1));
+            }
+        }
+        flag ^= 1;
+    }
+    return dp[flag ^ 1][b.size()];
+}
+
+struct CtgState {
+    uint32_t ci = 0;  // contig index
+    bool forward = true;
+    int64_t chosenOne = 0;
+    uint32_t len = 0;
+    uint32_t ctgLeft = 0, ctgRight = 0, revLeft = 0, revRight = 0;
+    uint64_t nodesOff = 0;  // offset of this contig's node table
+    std::vector<pag_path_node> travel;
+    std::vector<pag_path_node> seeds;
+    int64_t varLen = 0;
+    std::deque<uint32_t> ctgQ, refQ;
+    bool finalLeap = false, done = false;
+    std::unordered_set<uint32_t> globalUnique;
+    uint32_t gwinLo = 0xFFFFFFFFu, gwinHi = 0;
+    uint32_t *gset = nullptr;  // device
+    uint32_t gcap = 0;
+    uint64_t seqCap = 0;
+    uint32_t parentCode = 0;  // k-mer of the last contig-consistent path vertex (seed ordering key)
+    bool haveParent = false;
+};
+
+uint64_t pow2_at_least(uint64_t x) {
+    uint64_t p = 1024;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// PAlgorithm::appendSeq (PAlgorithm.cpp:110-142) on path records
+int64_t append_seq(std::vector<pag_path_node> &base, const std::vector<pag_path_node> &tail, uint32_t k) {
+    if (tail.empty()) return 0;
+    int64_t dLen = 0;
+    const pag_path_node &head = tail.front();
+    int32_t dist = (int32_t)k;
+    while (!base.empty() && (base.back().ctg == 0 || head.ctg <= base.back().ctg)) {
+        dLen -= base.back().step;
+        base.pop_back();
+    }
+    if (!base.empty()) dist = (int32_t)(head.ctg - base.back().ctg);
+    for (auto &n : tail) {
+        dLen += n.step;
+        base.push_back(n);
+    }
+    pag_path_node &first = base[base.size() - tail.size()];
+    dLen -= first.step - dist;
+    first.step = dist;
+    return dLen;
+}
+
+}  // namespace
+
+extern "C" {
+
+const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
+    if (!g || ctg_index >= g->paths.size()) {
+        if (len) *len = 0;
+        return nullptr;
+    }
+    if (len) *len = g->paths[ctg_index].size();
+    return g->paths[ctg_index].data();
+}
+
+int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+               const pag_travel_params *prm, pag_travel_stats *stats) {
+    if (!g || !ctgs || !orient || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const double t_begin = now_ms();
+    const uint32_t k = g->k;
+    const uint64_t deviation = prm->deviation;
+    const double errorRate = prm->error_rate, startSplit = prm->start_split;
+    const size_t topK = std::min<uint32_t>(prm->ref_threads, 8u);
+    int rc;
+    int slot = TRAV_SLOT0;
+    auto buf = [&](void) { return DevBuf(g, slot++); };
+
+    // ---- compact CSR (once per built graph)
+    DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
+           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf();
+    const uint64_t nn = g->stats.n_nodes, np = g->stats.n_pos, ne = g->stats.n_uniq_edges;
+    if (np >= 0xFFFFFFF0ull || ne >= 0xFFFFFFF0ull) {
+        set_error("pag_travel: more than 2^32 vertices/edges");
+        return PAG_EINVAL;
+    }
+    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
+    if ((rc = b_ncode.alloc((nn + 1) * 4)) || (rc = b_npos.alloc((nn + 2) * 4)) || (rc = b_nedge.alloc((nn + 2) * 4)) ||
+        (rc = b_vpos.alloc((np + 1) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
+        (rc = b_eto.alloc((ne + 1) * 4)) || (rc = b_estep.alloc((ne + 1) * 4)) || (rc = b_bitmap.alloc(n_words * 8)) ||
+        (rc = b_rank.alloc(n_words * 4)))
+        return rc;
+    TravGraph G{};
+    G.n_nodes = nn;
+    G.n_pos = np;
+    G.n_edges = ne;
+    G.ncode = b_ncode.as<uint32_t>();
+    G.npos_off = b_npos.as<uint32_t>();
+    G.nedge_off = b_nedge.as<uint32_t>();
+    G.vpos = b_vpos.as<uint64_t>();
+    G.vcnt = b_vcnt.as<uint16_t>();
+    G.vnode = b_vnode.as<uint32_t>();
+    G.eto = b_eto.as<uint32_t>();
+    G.estep = b_estep.as<uint32_t>();
+    G.bitmap = b_bitmap.as<uint64_t>();
+    G.rank = b_rank.as<uint32_t>();
+    double t_compact = 0;
+    if (!g->tg_ready) {
+        const double t0 = now_ms();
+        size_t tb = trav_compact_tmp_bytes(g->n_t, g->n_e, k, nn);
+        if ((rc = b_ctmp.alloc(tb))) return rc;
+        if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
+                               b_ctmp.p, tb, s)))
+            return rc;
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        g->tg = G;
+        g->tg_ready = true;
+        t_compact = now_ms() - t0;
+    }
+
+    // ---- contigs: packed bases, mapper tables, per-strand node tables
+    Mapper mapper(ctgs->len, ctgs->n_seqs);
+    Mapper refMapper(ref_len, n_refs);
+    const uint32_t n_ctgs = (uint32_t)ctgs->n_seqs;
+    g->paths.assign(n_ctgs, {});
+    std::vector<CtgState> st;
+    uint64_t nodes_total = 0;
+    for (uint32_t c = 0; c < n_ctgs; ++c) {
+        if (orient[c] < 0) continue;
+        CtgState cs;
+        cs.ci = c;
+        cs.forward = orient[c] != 0;
+        cs.chosenOne = cs.forward ? (int64_t)c + 1 : -(int64_t)c - 1;
+        cs.len = ctgs->len[c];
+        cs.ctgLeft = (uint32_t)mapper.dualToSingle(cs.chosenOne, 0);
+        cs.ctgRight = (uint32_t)mapper.dualToSingle(cs.chosenOne, cs.len);
+        cs.revLeft = (uint32_t)mapper.dualToSingle(-cs.chosenOne, 0);
+        cs.revRight = (uint32_t)mapper.dualToSingle(-cs.chosenOne, cs.len);
+        cs.nodesOff = nodes_total;
+        cs.seqCap = (uint64_t)cs.len / 2 + 8192;
+        nodes_total += cs.len >= k ? cs.len - k + 1 : 0;
+        st.push_back(std::move(cs));
+    }
+    const uint32_t n_sel = (uint32_t)st.size();
+    if (n_sel == 0) return PAG_OK;
+
+    DevBuf b_packed = buf(), b_nodes = buf(), b_starts = buf(), b_sizes = buf(), b_tc = buf(), b_seedout = buf(), b_req = buf(),
+           b_jobs = buf(), b_outs = buf(), b_seqv = buf(), b_seqs = buf(), b_arv = buf(), b_ars = buf(), b_tset = buf(),
+           b_pset = buf(), b_gset = buf(), b_gather = buf(), b_vids = buf();
+    if ((rc = b_packed.alloc(ctgs->packed_bytes + 64)) || (rc = b_nodes.alloc((nodes_total + 1) * 4)) ||
+        (rc = b_starts.alloc(mapper.starts.size() * 8 + 8)) || (rc = b_sizes.alloc(mapper.sizes.size() * 8 + 8)) ||
+        (rc = b_tc.alloc(n_sel * sizeof(TravContig))))
+        return rc;
+    PAG_HIP_TRY(hipMemcpyAsync(b_packed.p, ctgs->packed, ctgs->packed_bytes, hipMemcpyHostToDevice, s));
+    PAG_HIP_TRY(hipMemcpyAsync(b_starts.p, mapper.starts.data(), mapper.starts.size() * 8, hipMemcpyHostToDevice, s));
+    PAG_HIP_TRY(hipMemcpyAsync(b_sizes.p, mapper.sizes.data(), mapper.sizes.size() * 8, hipMemcpyHostToDevice, s));
+    for (auto &cs : st)
+        trav_launch_ctg_nodes(b_packed.as<uint8_t>(), ctgs->byte_off[cs.ci], cs.len, cs.forward ? 1 : 0, k, G,
+                              b_nodes.as<uint32_t>() + cs.nodesOff, s);
+
+    // global visited sets, one per contig
+    {
+        uint64_t tot = 0;
+        for (auto &cs : st) {
+            cs.gcap = (uint32_t)pow2_at_least(cs.seqCap * 4);
+            tot += cs.gcap;
+        }
+        if ((rc = b_gset.alloc(tot * 4))) return rc;
+        PAG_HIP_TRY(hipMemsetAsync(b_gset.p, 0xFF, tot * 4, s));
+        uint64_t off = 0;
+        for (auto &cs : st) {
+            cs.gset = b_gset.as<uint32_t>() + off;
+            off += cs.gcap;
+        }
+    }
+
+    std::vector<TravContig> tc(n_sel);
+    auto upload_contigs = [&]() -> int {
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            CtgState &cs = st[i];
+            TravContig &t = tc[i];
+            t.nodes = b_nodes.as<uint32_t>() + cs.nodesOff;
+            t.n_kmers = cs.len >= k ? cs.len - k + 1 : 0;
+            t.ctg_left = cs.ctgLeft;
+            t.ctg_right = cs.ctgRight;
+            t.rev_left = cs.revLeft;
+            t.rev_right = cs.revRight;
+            t.split_size = (uint64_t)(cs.len * startSplit);
+            t.leap_min = 1 - startSplit;
+            t.starts = b_starts.as<uint64_t>();
+            t.sizes = b_sizes.as<uint64_t>();
+            t.n_ctgs = n_ctgs;
+            t.gset = cs.globalUnique.empty() ? nullptr : cs.gset;
+            t.gmask = cs.gcap - 1;
+            t.gwin_lo = cs.gwinLo;
+            t.gwin_hi = cs.gwinHi;
+        }
+        PAG_HIP_TRY(hipMemcpyAsync(b_tc.p, tc.data(), n_sel * sizeof(TravContig), hipMemcpyHostToDevice, s));
+        return PAG_OK;
+    };
+
+    // vertex attributes for a list of vertex ids
+    auto fetch_vertices = [&](const std::vector<uint32_t> &vids, std::vector<pag_path_node> &out) -> int {
+        out.resize(vids.size());
+        if (vids.empty()) return PAG_OK;
+        int r;
+        if ((r = b_vids.alloc(vids.size() * 4)) || (r = b_gather.alloc(vids.size() * sizeof(pag_path_node)))) return r;
+        PAG_HIP_TRY(hipMemcpyAsync(b_vids.p, vids.data(), vids.size() * 4, hipMemcpyHostToDevice, s));
+        trav_launch_gather_vertices(G, b_vids.as<uint32_t>(), (uint32_t)vids.size(), b_gather.as<pag_path_node>(), s);
+        PAG_HIP_TRY(hipMemcpyAsync(out.data(), b_gather.p, vids.size() * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        return PAG_OK;
+    };
+
+    // ---- round 0 seeds: searchPANode(onlyFirst) then top-K
+    const uint32_t SEED_STRIDE = 4096;
+    if ((rc = b_seedout.alloc((uint64_t)n_sel * SEED_STRIDE * 4))) return rc;
+    if ((rc = upload_contigs())) return rc;
+    trav_launch_seed_first(G, b_tc.as<TravContig>(), n_sel, deviation, b_seedout.as<uint32_t>(), SEED_STRIDE, s);
+    std::vector<uint32_t> seedbuf((size_t)n_sel * SEED_STRIDE);
+    PAG_HIP_TRY(hipMemcpyAsync(seedbuf.data(), b_seedout.p, seedbuf.size() * 4, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    {
+        std::vector<uint32_t> vids;
+        std::vector<size_t> cnt(n_sel);
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            const uint32_t *o = &seedbuf[(size_t)i * SEED_STRIDE];
+            size_t n = std::min<size_t>(std::min<size_t>(o[0], (SEED_STRIDE - 2) / 2), topK);
+            cnt[i] = n;
+            for (size_t j = 0; j < n; ++j) vids.push_back(o[1 + 2 * j]);
+        }
+        std::vector<pag_path_node> attrs;
+        if ((rc = fetch_vertices(vids, attrs))) return rc;
+        size_t at = 0;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            st[i].seeds.assign(attrs.begin() + at, attrs.begin() + at + cnt[i]);
+            at += cnt[i];
+            if (st[i].seeds.empty()) st[i].done = true;
+        }
+    }
+
+    uint64_t rounds = 0, jobs_total = 0, steps_total = 0;
+    double t_walk = 0;
+    uint32_t grow = 1;
+    for (;;) {
+        // ---- jobs of this round
+        struct JobRef {
+            uint32_t cs, seed;
+        };
+        std::vector<JobRef> jr;
+        for (uint32_t i = 0; i < n_sel; ++i)
+            if (!st[i].done)
+                for (uint32_t sd = 0; sd < st[i].seeds.size(); ++sd) jr.push_back({i, sd});
+        if (jr.empty()) break;
+        ++rounds;
+        jobs_total += jr.size();
+        std::vector<TravJob> jobs(jr.size());
+        uint64_t tot_seq = 0, tot_arena = 0, tot_t = 0, tot_p = 0;
+        std::vector<uint64_t> o_seq(jr.size()), o_ar(jr.size()), o_t(jr.size()), o_p(jr.size());
+        for (size_t j = 0; j < jr.size(); ++j) {
+            uint64_t cap = st[jr[j].cs].seqCap * grow;
+            o_seq[j] = tot_seq;
+            o_ar[j] = tot_arena;
+            o_t[j] = tot_t;
+            o_p[j] = tot_p;
+            tot_seq += cap;
+            tot_arena += 2 * cap;
+            tot_t += pow2_at_least(2 * cap + 2);
+            tot_p += pow2_at_least(4 * cap + 2);
+        }
+        if ((rc = b_seqv.alloc(tot_seq * 4)) || (rc = b_seqs.alloc(tot_seq * 4)) || (rc = b_arv.alloc(tot_arena * 4)) ||
+            (rc = b_ars.alloc(tot_arena * 4)) || (rc = b_tset.alloc(tot_t * 4)) || (rc = b_pset.alloc(tot_p * 8)) ||
+            (rc = b_jobs.alloc(jobs.size() * sizeof(TravJob))) || (rc = b_outs.alloc(jobs.size() * sizeof(TravJobOut))))
+            return rc;
+        PAG_HIP_TRY(hipMemsetAsync(b_tset.p, 0xFF, tot_t * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_pset.p, 0, tot_p * 8, s));
+        for (size_t j = 0; j < jr.size(); ++j) {
+            CtgState &cs = st[jr[j].cs];
+            uint64_t cap = cs.seqCap * grow;
+            TravJob &J = jobs[j];
+            J.ctg = jr[j].cs;
+            J.start = cs.seeds[jr[j].seed].vid;
+            J.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
+            J.seq_v = b_seqv.as<uint32_t>() + o_seq[j];
+            J.seq_s = b_seqs.as<uint32_t>() + o_seq[j];
+            J.seq_cap = cap;
+            J.arena_v = b_arv.as<uint32_t>() + o_ar[j];
+            J.arena_s = b_ars.as<uint32_t>() + o_ar[j];
+            J.arena_cap = 2 * cap;
+            J.tset = b_tset.as<uint32_t>() + o_t[j];
+            J.tmask = (uint32_t)pow2_at_least(2 * cap + 2) - 1;
+            J.pset = b_pset.as<uint64_t>() + o_p[j];
+            J.pmask = (uint32_t)pow2_at_least(4 * cap + 2) - 1;
+        }
+        if ((rc = upload_contigs())) return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(b_jobs.p, jobs.data(), jobs.size() * sizeof(TravJob), hipMemcpyHostToDevice, s));
+        const double tw0 = now_ms();
+        trav_launch_walk(G, b_tc.as<TravContig>(), b_jobs.as<TravJob>(), b_outs.as<TravJobOut>(), (uint32_t)jobs.size(), k,
+                         (uint32_t)deviation, errorRate, s);
+        std::vector<TravJobOut> outs(jobs.size());
+        PAG_HIP_TRY(hipMemcpyAsync(outs.data(), b_outs.p, outs.size() * sizeof(TravJobOut), hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        PAG_HIP_TRY(hipGetLastError());
+        t_walk += now_ms() - tw0;
+        bool overflow = false;
+        for (auto &o : outs) overflow |= o.overflow != 0;
+        if (overflow) {
+            if (grow >= 64) {
+                set_error("pag_travel: walker buffers overflow even at 64x capacity");
+                return PAG_ENOMEM;
+            }
+            grow *= 2;
+            --rounds;
+            jobs_total -= jr.size();
+            continue;  // redo the round with larger buffers
+        }
+        for (auto &o : outs) steps_total += o.seq_len;
+
+        // ---- per contig: choose, splice, stop rules (PAlgorithm.cpp:238-330)
+        std::vector<TravSeedReq> reqs;
+        std::vector<uint32_t> req_cs;
+        size_t j0 = 0;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            CtgState &cs = st[i];
+            if (cs.done) continue;
+            const size_t ns = cs.seeds.size();
+            size_t maxLen = 0, chooseCtgPos = 0, chooseRefPos = 0;
+            bool leap = false;
+            int chosen = -1;
+            for (size_t sd = 0; sd < ns; ++sd) {
+                const TravJobOut &o = outs[j0 + sd];
+                size_t len = o.seq_size;
+                leap = o.last_ctg != 0 && mapper.singleToDual(o.last_ctg).first != cs.chosenOne;
+                if (!leap && sd > 0 && prm->min_len > 0 && len < prm->min_len) continue;
+                if (len > maxLen || leap) {
+                    maxLen = len;
+                    chosen = (int)sd;
+                    chooseCtgPos = (size_t)mapper.singleToDual(cs.seeds[sd].ctg).second;
+                    chooseRefPos = (size_t)refMapper.singleToDual(cs.seeds[sd].ref).second;
+                    if (leap) break;
+                }
+            }
+            std::vector<pag_path_node> longest;
+            if (chosen >= 0) {
+                const TravJobOut &o = outs[j0 + chosen];
+                longest.resize(o.seq_len);
+                if ((rc = b_gather.alloc(o.seq_len * sizeof(pag_path_node) + 64))) return rc;
+                trav_launch_gather_path(G, jobs[j0 + chosen].seq_v, jobs[j0 + chosen].seq_s, o.seq_len,
+                                        b_gather.as<pag_path_node>(), s);
+                PAG_HIP_TRY(hipMemcpyAsync(longest.data(), b_gather.p, o.seq_len * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
+                // record the walk in the device-side global visited set of this contig
+                trav_launch_commit(jobs[j0 + chosen].seq_v, o.seq_len, cs.gset, cs.gcap - 1, s);
+                PAG_HIP_TRY(hipStreamSynchronize(s));
+            }
+            j0 += ns;
+
+            cs.varLen += append_seq(cs.travel, longest, k);
+            if (chooseCtgPos != 0) {
+                cs.ctgQ.push_back((uint32_t)chooseCtgPos);
+                while (cs.ctgQ.size() > 4) cs.ctgQ.pop_front();
+            }
+            if (chooseRefPos != 0) {
+                cs.refQ.push_back((uint32_t)chooseRefPos);
+                while (cs.refQ.size() > 4) cs.refQ.pop_front();
+            }
+            for (auto &n : longest) {
+                cs.globalUnique.insert(n.vid);
+                if (n.ctg != 0) {
+                    cs.gwinLo = std::min(cs.gwinLo, n.ctg);
+                    cs.gwinHi = std::max(cs.gwinHi, n.ctg);
+                }
+            }
+            bool ctgRepeat = false, refRepeat = false;
+            if (cs.ctgQ.size() >= 4) {
+                auto mm = std::minmax_element(cs.ctgQ.begin(), cs.ctgQ.end());
+                ctgRepeat = (uint64_t)(*mm.second - *mm.first) <= 2 * deviation;
+            }
+            if (cs.refQ.size() >= 4) {
+                auto mm = std::minmax_element(cs.refQ.begin(), cs.refQ.end());
+                refRepeat = (uint64_t)(*mm.second - *mm.first) <= 2 * deviation;
+            }
+            if (ctgRepeat || refRepeat || leap) {
+                if (leap) cs.finalLeap = true;
+                cs.done = true;
+                continue;
+            }
+            // last contig-consistent vertex of the running path (PAlgorithm.cpp:332-360)
+            uint64_t lastCtgPos = 0;
+            uint32_t lastCode = 0;
+            bool haveKmer = false;
+            for (auto it = cs.travel.rbegin(); it != cs.travel.rend(); ++it) {
+                if (it->ctg != 0) {
+                    auto d = mapper.singleToDual(it->ctg);
+                    if (d.first == cs.chosenOne && d.second >= 0) {
+                        lastCtgPos = (uint64_t)d.second;
+                        lastCode = it->code;
+                        haveKmer = true;
+                        break;
+                    }
+                }
+            }
+            if ((uint64_t)cs.globalUnique.size() * 2 > cs.gcap) {
+                set_error("pag_travel: global visited set of contig %u is full", cs.ci);
+                return PAG_ENOMEM;
+            }
+            TravSeedReq r{};
+            r.ctg = i;
+            r.pos = lastCtgPos;
+            r.left = lastCtgPos - std::min<uint64_t>(lastCtgPos, 1000 * deviation);
+            r.right = lastCtgPos + 1000 * deviation;
+            reqs.push_back(r);
+            req_cs.push_back(i);
+            cs.seeds.clear();
+            cs.parentCode = lastCode;
+            cs.haveParent = haveKmer;
+        }
+
+        // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
+        if (!reqs.empty()) {
+            const uint32_t WSTRIDE = 16384;
+            if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc((uint64_t)reqs.size() * WSTRIDE * 4)))
+                return rc;
+            PAG_HIP_TRY(hipMemcpyAsync(b_req.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s));
+            trav_launch_seed_window(G, b_tc.as<TravContig>(), b_req.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation,
+                                    b_seedout.as<uint32_t>(), WSTRIDE, s);
+            std::vector<uint32_t> wb((size_t)reqs.size() * WSTRIDE);
+            PAG_HIP_TRY(hipMemcpyAsync(wb.data(), b_seedout.p, wb.size() * 4, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            std::vector<uint32_t> vids;
+            std::vector<size_t> cnt(reqs.size());
+            for (size_t q = 0; q < reqs.size(); ++q) {
+                CtgState &cs = st[req_cs[q]];
+                const uint32_t *o = &wb[q * WSTRIDE];
+                if (o[0] > WSTRIDE - 1) {
+                    set_error("pag_travel: seed window overflow (%u candidates)", o[0]);
+                    return PAG_ENOMEM;
+                }
+                std::unordered_set<uint32_t> seen;
+                size_t n = 0;
+                for (uint32_t x = 0; x < o[0]; ++x) {
+                    uint32_t v = o[1 + x];
+                    if (!seen.insert(v).second) continue;         // std::set `unique` in searchPANode2
+                    if (cs.globalUnique.count(v)) continue;        // filterPANodes
+                    vids.push_back(v);
+                    ++n;
+                }
+                cnt[q] = n;
+            }
+            std::vector<pag_path_node> attrs;
+            if ((rc = fetch_vertices(vids, attrs))) return rc;
+            size_t at = 0;
+            for (size_t q = 0; q < reqs.size(); ++q) {
+                CtgState &cs = st[req_cs[q]];
+                const std::string parent = cs.haveParent ? code2kmer(cs.parentCode, k) : std::string();
+                std::vector<pag_path_node> cand(attrs.begin() + at, attrs.begin() + at + cnt[q]);
+                at += cnt[q];
+                // std::sort with the reference's comparator (edit distance to the parent k-mer), unstable:
+                // precomputed keys give the same comparison outcomes, hence the same permutation
+                struct Keyed {
+                    size_t d;
+                    pag_path_node n;
+                };
+                std::vector<Keyed> keyed;
+                keyed.reserve(cand.size());
+                for (auto &c : cand) keyed.push_back({edit_distance(parent, code2kmer(c.code, k)), c});
+                std::sort(keyed.begin(), keyed.end(), [](const Keyed &a, const Keyed &b) { return a.d < b.d; });
+                cs.seeds.clear();
+                for (size_t x = 0; x < keyed.size() && x < topK; ++x) cs.seeds.push_back(keyed[x].n);
+                if (cs.seeds.empty()) cs.done = true;
+            }
+        }
+    }
+
+    // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)
+    for (auto &cs : st) {
+        auto &seq = cs.travel;
+        if (!cs.finalLeap) {
+            const size_t windowSize = 10;
+            if (seq.size() >= windowSize) {
+                size_t startIdx = seq.size() - seq.size() / 90;
+                for (size_t i = startIdx; i < seq.size() - windowSize + 1; ++i) {
+                    uint32_t firstPos = seq[i].ctg;
+                    uint32_t secondPos = seq[std::min(seq.size(), i + windowSize) - 1].ctg;
+                    if (secondPos != 0 && firstPos != 0 && secondPos < firstPos) {
+                        seq.resize(i + 1);
+                        break;
+                    }
+                }
+            }
+        } else if (!seq.empty()) {
+            auto d = mapper.singleToDual(seq.back().ctg);
+            uint64_t a = (uint64_t)std::llabs(d.first);
+            if (a == (uint64_t)cs.ci + 1 || (a >= 1 && a <= mapper.sizes.size() &&
+                                             (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit)))
+                seq.pop_back();
+        }
+        g->paths[cs.ci] = std::move(seq);
+    }
+    if (stats) {
+        stats->ms_compact = t_compact;
+        stats->ms_walk = t_walk;
+        stats->ms_total = now_ms() - t_begin;
+        stats->rounds = rounds;
+        stats->jobs = jobs_total;
+        stats->walk_steps = steps_total;
+    }
+    return PAG_OK;
+}
+
+}  // extern "C"

@@ -21,66 +21,9 @@
 
 using namespace pagdev;
 
-struct pag_graph {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    uint32_t k = 0;
-    uint64_t n_solid = 0;
-    int all_solid = 0;
-    uint32_t *solid_bits = nullptr;  // 4^k bits
-    // finished graph (device): k-mer-sorted streams with in-place segment results
-    uint64_t n_t = 0, n_e = 0;
-    uint32_t *tkey = nullptr;
-    uint64_t *tval = nullptr;
-    uint32_t *tseg = nullptr;
-    uint16_t *tcnt = nullptr;
-    uint32_t *ekey = nullptr;
-    uint64_t *eval = nullptr;
-    uint32_t *eseg = nullptr;
-    pag_build_stats stats{};
-    // device memory pool: every buffer of the pipeline lives in a named slot that is reused (and only
-    // ever grown) across pag_process calls, so steady-state calls do no hipMalloc/hipFree at all
-    struct Slot {
-        void *p = nullptr;
-        size_t cap = 0;
-    };
-    Slot pool[64];
-    // debug: raw emitted streams (host copies), kept when PAG_DEBUG_KEEP_STREAMS=1
-    std::vector<uint32_t> dbg_tkey, dbg_ekey;
-    std::vector<uint64_t> dbg_tval, dbg_eval;
-};
+#include "pag_graph_impl.hpp"
 
 namespace {
-
-struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_destroy does)
-    pag_graph *g = nullptr;
-    int slot = -1;
-    void *p = nullptr;
-    DevBuf(pag_graph *gg, int s) : g(gg), slot(s) {}
-    int alloc(size_t bytes) {
-        if (bytes == 0) bytes = 16;
-        pag_graph::Slot &sl = g->pool[slot];
-        if (sl.cap < bytes) {
-            if (sl.p) hipFree(sl.p);
-            sl.p = nullptr;
-            sl.cap = 0;
-            size_t want = bytes + bytes / 8 + 256;
-            hipError_t e = hipMalloc(&sl.p, want);
-            if (e != hipSuccess) {
-                sl.p = nullptr;
-                set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-                return PAG_ENOMEM;
-            }
-            sl.cap = want;
-        }
-        p = sl.p;
-        return PAG_OK;
-    }
-    template <typename T>
-    T *as() const {
-        return (T *)p;
-    }
-};
 
 // device view of an input array: uploads when the caller's array is in host memory
 template <typename T>
@@ -125,6 +68,8 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->eval = nullptr;
     g->eseg = nullptr;
     g->n_t = g->n_e = 0;
+    g->tg_ready = false;
+    g->paths.clear();
 }
 
 __global__ void chunk_counts(const pag_aln *__restrict__ aln, uint64_t n, uint32_t *__restrict__ out) {

@@ -1,0 +1,84 @@
+// Internal types of the device traversal (k5_travel.hip kernels <-> k5_travel_host.hip orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pagraph_hip.h"
+
+namespace pagdev {
+
+// compact CSR of the finished graph, dense ids: node = k-mer with >= 1 vertex (ascending code),
+// vertex = clustered position (node-major, inside a node ascending (ctg, ref))
+struct TravGraph {
+    uint64_t n_nodes, n_pos, n_edges;
+    uint32_t *ncode;      // [n_nodes]
+    uint32_t *npos_off;   // [n_nodes + 1] first vertex of each node
+    uint32_t *nedge_off;  // [n_nodes + 1]
+    uint64_t *vpos;       // [n_pos] ctg << 32 | ref
+    uint16_t *vcnt;       // [n_pos]
+    uint32_t *vnode;      // [n_pos]
+    uint32_t *eto;        // [n_edges] child node id
+    uint32_t *estep;      // [n_edges]
+    uint64_t *bitmap;     // 4^k bits: k-mer code owns a node
+    uint32_t *rank;       // per 64-bit bitmap word: nodes before it
+};
+
+struct TravContig {
+    const uint32_t *nodes;  // [n_kmers] node id of every k-mer of the traversed contig strand, PAG_NONE if absent
+    uint32_t n_kmers;
+    uint32_t ctg_left, ctg_right;  // single-coordinate range of the traversed strand
+    uint32_t rev_left, rev_right;  // ... of the opposite strand (excluded, PAlgorithm.cpp:176-178)
+    uint64_t split_size;           // ctgLen * startSplit
+    double leap_min;               // 1 - startSplit
+    const uint64_t *starts;        // contig PositionMapper start table [n_ctgs + 1]
+    const uint64_t *sizes;         // [n_ctgs]
+    uint32_t n_ctgs;
+    uint32_t *gset;  // globalUniqueTable (may be null before the first commit)
+    uint32_t gmask;
+    uint32_t gwin_lo, gwin_hi;  // ctgGlobalPosTable
+};
+
+struct TravJob {
+    uint32_t ctg;    // index into the TravContig array
+    uint32_t start;  // seed vertex
+    uint64_t has_size;
+    uint32_t *seq_v, *seq_s;
+    uint64_t seq_cap;
+    uint32_t *arena_v, *arena_s;
+    uint64_t arena_cap;
+    uint32_t *tset;
+    uint32_t tmask;
+    uint64_t *pset;
+    uint32_t pmask;
+};
+
+struct TravJobOut {
+    uint64_t seq_len, seq_size;
+    uint32_t last_ctg;
+    int overflow;
+};
+
+struct TravSeedReq {
+    uint32_t ctg;
+    uint32_t pad;
+    uint64_t left, right, pos;
+};
+
+int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
+                 const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
+                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s);
+size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes);
+void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
+                           uint32_t *out, hipStream_t s);
+void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uint64_t dev, uint32_t *out, uint32_t stride,
+                            hipStream_t s);
+void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
+                             uint32_t *out, uint32_t stride, hipStream_t s);
+void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
+                      uint32_t dev, double err, hipStream_t s);
+void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t *gset, uint32_t gmask, hipStream_t s);
+void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
+                             hipStream_t s);
+void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s);
+
+}  // namespace pagdev

@@ -51,7 +51,8 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const PositionMapper &refMapper,
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
-                                                unsigned hostThreads, AssembleStats *stats, bool quiet) {
+                                                unsigned hostThreads, AssembleStats *stats, bool quiet,
+                                                const std::vector<TravelSequence> *precomputed) {
     std::ostream nullOut(nullptr);
     std::ostream &out = quiet ? nullOut : std::cout;
     std::set<std::pair<std::string, bool>> success;
@@ -78,7 +79,8 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
             log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
             auto &res = results[2 * ctgIdx + ctgOffset];
-            res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
+            if (precomputed) res = (*precomputed)[2 * ctgIdx + ctgOffset];
+            else res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
             log << tlog;
 
             std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
@@ -256,7 +258,9 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         for (std::size_t i = 0; i < results.size(); ++i) {
             std::uint64_t h = 1469598103934665603ull ^ i;
             for (auto &n : results[i]) {
-                h = (h ^ graph.slot(n.first)) * 1099511628211ull;
+                DualPos pp = graph.position(n.first);
+                h = (h ^ ((static_cast<std::uint64_t>(pp.first) << 32) | pp.second)) * 1099511628211ull;
+                h = (h ^ graph.nodeCode[n.first.node]) * 1099511628211ull;
                 h = (h ^ static_cast<std::uint64_t>(n.second)) * 1099511628211ull;
             }
             if (!results[i].empty()) stats->pathChecksum += h;

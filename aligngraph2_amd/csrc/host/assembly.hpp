@@ -6,7 +6,10 @@
 #include <string>
 #include <utility>
 
+#include <vector>
+
 #include "host_graph.hpp"
+#include "traversal.hpp"
 #include "position_mapper.hpp"
 #include "seq_db.hpp"
 
@@ -17,6 +20,8 @@ struct AssembleStats {
 };
 
 // returns the (contig name, forward) pairs consumed by emitted chains.
+// precomputed: travel sequences produced elsewhere (the device traversal), indexed 2 * contig + (reverse ? 1 : 0);
+// when given, `graph` only has to contain the vertices on those sequences.
 // hostThreads: workers for the per-contig traversal loop (the reference uses max(1, t/8) threads there,
 // PAssembly.cpp:30; results are independent of the worker count).
 std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const std::string &prefix, const HostGraph &graph,
@@ -24,6 +29,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const PositionMapper &refMapper,
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
-                                                unsigned hostThreads = 1, AssembleStats *stats = nullptr, bool quiet = false);
+                                                unsigned hostThreads = 1, AssembleStats *stats = nullptr, bool quiet = false,
+                                                const std::vector<TravelSequence> *precomputed = nullptr);
 
 }  // namespace pagh

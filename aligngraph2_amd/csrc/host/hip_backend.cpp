@@ -28,6 +28,19 @@ public:
         check(pag_export_csr(g_, &csr), "pag_export_csr");
     }
 
+    bool travel(const pag_seqs &ctgs, const std::vector<int> &orient, const std::vector<std::uint32_t> &refLen,
+                const pag_travel_params &params, std::vector<std::vector<pag_path_node>> &paths) override {
+        std::vector<std::int32_t> o(orient.begin(), orient.end());
+        check(pag_travel(g_, &ctgs, o.data(), refLen.data(), refLen.size(), &params, nullptr), "pag_travel");
+        paths.assign(ctgs.n_seqs, {});
+        for (std::uint64_t c = 0; c < ctgs.n_seqs; ++c) {
+            std::uint64_t len = 0;
+            const pag_path_node *p = pag_travel_path(g_, c, &len);
+            if (p && len) paths[c].assign(p, p + len);
+        }
+        return true;
+    }
+
 private:
     void check(int rc, const char *what) {
         if (rc != PAG_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + pag_last_error());

@@ -15,6 +15,7 @@
 #include "config.hpp"
 #include "graph_input.hpp"
 #include "kmer_file.hpp"
+#include "path_graph.hpp"
 #include "seq_db.hpp"
 
 namespace pagh {
@@ -202,13 +203,44 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
 
             lap("graph build (process)");
             HostGraph graph;
-            backend.exportCsr(graph);
-            lap("graph export");
-            graph.k = static_cast<std::uint32_t>(kmers.k());
-
+            std::vector<TravelSequence> precomputed;
+            bool onDevice = false;
+            {
+                // orientation per contig exactly as assemble() will look it up (std::set order, last wins)
+                std::vector<int> orient(contigs.size(), -1);
+                for (auto &c : usedCtg)
+                    if (contigs.contains(c.first)) orient[contigs.id(c.first)] = c.second ? 1 : 0;
+                std::vector<std::uint32_t> refLen;
+                for (std::size_t i = 0; i < refs.size(); ++i) refLen.push_back(refs.length(i));
+                pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(),
+                            contigs.packed().size()};
+                pag_travel_params tp{};
+                tp.ref_threads = opt.threads;
+                tp.deviation = opt.epsilon * 2;
+                tp.error_rate = errorRate;
+                tp.start_split = startSplit;
+                tp.min_len = opt.minLen;
+                std::vector<std::vector<pag_path_node>> paths;
+                bool hostWalk = std::getenv("PAGRAPH_HOST_WALK") != nullptr;  // verification aid only
+                {  // a contig listed with both orientations is traversed twice by the reference: host walk
+                    std::set<std::string> names;
+                    for (auto &c : usedCtg)
+                        if (!names.insert(c.first).second) hostWalk = true;
+                }
+                if (!hostWalk && backend.travel(cs, orient, refLen, tp, paths)) {
+                    buildPathGraph(paths, orient, static_cast<unsigned>(kmers.k()), graph, precomputed);
+                    onDevice = true;
+                    lap("device traversal");
+                }
+            }
+            if (!onDevice) {
+                backend.exportCsr(graph);
+                lap("graph export");
+                graph.k = static_cast<std::uint32_t>(kmers.k());
+            }
             auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, input.ctgMapper(),
                                        input.refMapper(), usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
-                                       opt.threads);
+                                       opt.threads, 0, nullptr, false, onDevice ? &precomputed : nullptr);
             lap("traverse + write");
             ++blockNo;
             for (auto &s : successCtg) okCtg.emplace(s.first);

@@ -22,6 +22,12 @@ public:
     virtual void reset() = 0;
     virtual void process(const pag_build_input &in, pag_build_stats &stats) = 0;
     virtual void exportCsr(HostGraph &out) = 0;
+    // device traversal (PAlgorithm::travelSequence for every selected contig); backends without one
+    // return false and the driver walks the exported graph on the host instead
+    virtual bool travel(const pag_seqs & /*ctgs*/, const std::vector<int> & /*orient*/, const std::vector<std::uint32_t> & /*refLen*/,
+                        const pag_travel_params & /*params*/, std::vector<std::vector<pag_path_node>> & /*paths*/) {
+        return false;
+    }
 };
 
 int runPagraph(int argc, char **argv, GraphBackend &backend);

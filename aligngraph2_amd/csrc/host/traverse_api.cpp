@@ -9,6 +9,7 @@
 #include "assembly.hpp"
 #include "host_graph.hpp"
 #include "pagraph_host.h"
+#include "path_graph.hpp"
 #include "position_mapper.hpp"
 #include "seq_db.hpp"
 
@@ -38,37 +39,65 @@ extern "C" {
 
 const char *pagh_last_error(void) { return g_err; }
 
-int pagh_traverse(const pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
-                  const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads,
-                  uint64_t epsilon, uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
-                  pagh_traverse_stats *stats) {
+static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                        const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                        uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
+                        pagh_traverse_stats *stats, bool deviceWalk) {
     if (!g || !ctgs || !refs || !ctg_orient || !out_dir) return PAG_EINVAL;
     try {
         const double t0 = nowMs();
-        pagh::HostGraph graph;
-        std::uint64_t nn = 0, np = 0, ne = 0;
-        int rc = pag_csr_sizes(g, &nn, &np, &ne);
-        if (rc != PAG_OK) return rc;
-        graph.resize(nn, np, ne);
-        pag_csr csr = graph.view();
-        rc = pag_export_csr(g, &csr);
-        if (rc != PAG_OK) {
-            setErr("pag_export_csr: %s", pag_last_error());
-            return rc;
-        }
-        graph.k = k;
-        const double t1 = nowMs();
-
         pagh::SeqDb contigDb = fromPacked(ctgs, ctg_names, "ctg", 0);
         pagh::SeqDb refDb = fromPacked(refs, ref_names, "ref", 1);
         pagh::PositionMapper ctgMapper(contigDb), refMapper(refDb);
         std::set<std::pair<std::string, bool>> ctgSet;
+        std::vector<int> orient(ctgs->n_seqs, -1);
         for (std::uint64_t i = 0; i < ctgs->n_seqs; ++i)
-            if (ctg_orient[i] >= 0) ctgSet.emplace(contigDb.name(i), ctg_orient[i] != 0);
+            if (ctg_orient[i] >= 0) {
+                ctgSet.emplace(contigDb.name(i), ctg_orient[i] != 0);
+                orient[i] = ctg_orient[i] != 0 ? 1 : 0;
+            }
+
+        pagh::HostGraph graph;
+        std::vector<pagh::TravelSequence> precomputed;
+        double t1;
+        if (deviceWalk) {
+            pag_travel_params tp{};
+            tp.ref_threads = ref_threads;
+            tp.deviation = epsilon * 2;
+            tp.error_rate = 0.15;
+            tp.start_split = 0.90;
+            tp.min_len = min_len;
+            int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, nullptr);
+            if (rc != PAG_OK) {
+                setErr("pag_travel: %s", pag_last_error());
+                return rc;
+            }
+            std::vector<std::vector<pag_path_node>> paths(ctgs->n_seqs);
+            for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c) {
+                std::uint64_t len = 0;
+                const pag_path_node *p = pag_travel_path(g, c, &len);
+                if (p && len) paths[c].assign(p, p + len);
+            }
+            pagh::buildPathGraph(paths, orient, k, graph, precomputed);
+            t1 = nowMs();
+        } else {
+            std::uint64_t nn = 0, np = 0, ne = 0;
+            int rc = pag_csr_sizes(g, &nn, &np, &ne);
+            if (rc != PAG_OK) return rc;
+            graph.resize(nn, np, ne);
+            pag_csr csr = graph.view();
+            rc = pag_export_csr(g, &csr);
+            if (rc != PAG_OK) {
+                setErr("pag_export_csr: %s", pag_last_error());
+                return rc;
+            }
+            graph.k = k;
+            t1 = nowMs();
+        }
 
         pagh::AssembleStats as;
         pagh::assemble(out_dir, prefix ? prefix : "0_", graph, contigDb, refDb, ctgMapper, refMapper, ctgSet, epsilon * 2, 0.15,
-                       0.90, min_len, ref_threads, host_threads, &as, true);
+                       0.90, min_len, ref_threads, host_threads, &as, true, deviceWalk ? &precomputed : nullptr);
         const double t2 = nowMs();
         if (stats) {
             stats->n_contigs = as.nContigs;
@@ -86,6 +115,21 @@ int pagh_traverse(const pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
         setErr("pagh_traverse: %s", e.what());
         return PAG_EFAULT;
     }
+}
+
+int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
+    return traverseImpl(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, ref_threads, epsilon, min_len, out_dir, prefix,
+                        host_threads, stats, true);
+}
+
+int pagh_traverse_hostwalk(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                           const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                           uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
+                           pagh_traverse_stats *stats) {
+    return traverseImpl(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, ref_threads, epsilon, min_len, out_dir, prefix,
+                        host_threads, stats, false);
 }
 
 }  // extern "C"

@@ -179,6 +179,43 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
 /* sizes of the finished graph, then the graph itself into caller buffers */
 int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);
 int pag_export_csr(const pag_graph *g, pag_csr *out);
+/* ---- traversal ----------------------------------------------------------------------------------
+ * PAlgorithm::travelSequence (PAGraph/src/tools/graph/PAlgorithm.cpp:144-426) for every selected contig of
+ * the block at once: seed search, graphTravel / walkStraight / classifySuccessors with the epsilon-join
+ * predicates run on the device (one wavefront per (contig, seed) walk); the outer per-round bookkeeping
+ * (longest / leaping pick, appendSeq, repeat detection, re-seeding order, filterSequence) is host code
+ * inside the library.  The graph never leaves HBM; only the chosen paths come back. */
+typedef struct pag_path_node {
+    uint32_t code;  /* k-mer code of the vertex' node */
+    uint32_t ctg;   /* DualPos.first  */
+    uint32_t ref;   /* DualPos.second */
+    uint16_t cnt;   /* abundance */
+    uint16_t reserved;
+    int32_t step;   /* distance from the previous path vertex (k for the first) */
+    uint32_t vid;   /* dense vertex id (stable for the lifetime of the built graph) */
+} pag_path_node;
+
+typedef struct pag_travel_params {
+    uint32_t ref_threads; /* the reference's -t: seed top-K = min(t, 8) (PAlgorithm.cpp:146) */
+    uint32_t reserved;
+    uint64_t deviation;   /* 2 * epsilon (pagraph.cpp:251) */
+    double error_rate;    /* 0.15 */
+    double start_split;   /* 0.90 */
+    uint64_t min_len;     /* -l */
+} pag_travel_params;
+
+typedef struct pag_travel_stats {
+    double ms_compact, ms_walk, ms_total; /* device + host wall, ms */
+    uint64_t rounds, jobs, walk_steps;
+} pag_travel_stats;
+
+/* ctgs: HOST memory (2-bit packed); orient[i]: 1 traverse forward, 0 reverse, -1 not selected.
+ * ref_len[n_refs]: lengths of the reference sequences (their PositionMapper is needed for the repeat check).
+ * After success, pag_travel_path(g, i, &len) returns contig i's path (library-owned, valid until the next
+ * pag_travel / pag_process / pag_destroy on the handle). */
+int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+               const pag_travel_params *params, pag_travel_stats *stats);
+const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);
 const char *pag_last_error(void);
 /* 1 if a gfx950 device is present and the code object loads */
 int pag_device_available(void);

@@ -28,10 +28,17 @@ typedef struct pagh_traverse_stats {
  * Writes <prefix><C>_<O>.txt/.fasta/.con/.help into out_dir exactly like the reference.
  * host_threads: worker threads for the per-contig loop (0 = hardware concurrency); results do not
  * depend on it.  ref_threads = the reference's -t (seed top-K = min(t, 8), quirk Q10). */
-int pagh_traverse(const pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
+int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
                   const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads,
                   uint64_t epsilon, uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
                   pagh_traverse_stats *stats);
+/* Verification aid: the same outputs with the walk done on the HOST over an exported copy of the graph
+ * (pag_export_csr + the host restatement of PAlgorithm).  Slow; used by tests to cross-check the device
+ * walkers.  The product path is pagh_traverse. */
+int pagh_traverse_hostwalk(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
+                           const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient,
+                           uint32_t ref_threads, uint64_t epsilon, uint64_t min_len, const char *out_dir,
+                           const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats);
 const char *pagh_last_error(void);
 
 #ifdef __cplusplus

@@ -59,8 +59,20 @@ def test_device_resident_input_matches_oracle_and_reference(workdir):
     rc = host.pagh_traverse(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads, sp.eps, 50,
                             ours.encode(), b"0_", 0, C.byref(ts))
     assert rc == 0, host.pagh_last_error()
-    hip.pag_destroy(g)
     assert ts.n_path_bases > 0
+    # (2b) device walkers vs the host walk over the exported graph: identical files and checksum
+    hostw = str(workdir / "big_hostwalk")
+    os.makedirs(hostw, exist_ok=True)
+    ts2 = bench.TraverseStats()
+    host.pagh_traverse_hostwalk.argtypes = host.pagh_traverse.argtypes
+    rc = host.pagh_traverse_hostwalk(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads,
+                                     sp.eps, 50, hostw.encode(), b"0_", 0, C.byref(ts2))
+    assert rc == 0, host.pagh_last_error()
+    hip.pag_destroy(g)
+    assert (ts.n_path_nodes, ts.n_path_bases, ts.path_checksum) == (ts2.n_path_nodes, ts2.n_path_bases, ts2.path_checksum)
+    assert sorted(os.listdir(hostw)) == sorted(os.listdir(ours))
+    for f in sorted(os.listdir(ours)):
+        assert open(os.path.join(hostw, f), "rb").read() == open(os.path.join(ours, f), "rb").read(), f
 
     if not os.path.exists(os.path.join(pagctl.REF_DIR, "pagraph")):
         pytest.skip("oracle/_ref/pagraph not built")
