@@ -1,10 +1,9 @@
 // Turns the paths returned by the device traversal (pag_travel) into the (graph view, travel sequences)
 // pair that the chain selection / seqToString / writers of assembly.cpp work on: a HostGraph that
-// contains exactly the vertices that lie on some path.
+// contains exactly the vertices that lie on some path.  Sort-based (paths hold millions of vertices).
 #pragma once
 #include <algorithm>
-#include <map>
-#include <unordered_map>
+#include <cstdint>
 #include <vector>
 
 #include "host_graph.hpp"
@@ -14,37 +13,53 @@ namespace pagh {
 
 inline void buildPathGraph(const std::vector<std::vector<pag_path_node>> &paths, const std::vector<int> &orient, unsigned k,
                            HostGraph &graph, std::vector<TravelSequence> &results) {
-    // distinct vertices, grouped by k-mer code
-    std::map<std::uint32_t, std::vector<const pag_path_node *>> byCode;
-    std::unordered_map<std::uint32_t, bool> seen;
+    struct Ref {
+        std::uint32_t code, vid;
+        const pag_path_node *n;
+    };
+    std::vector<Ref> all;
+    std::size_t total = 0;
+    for (auto &p : paths) total += p.size();
+    all.reserve(total);
     for (auto &p : paths)
-        for (auto &n : p)
-            if (seen.emplace(n.vid, true).second) byCode[n.code].push_back(&n);
-    std::size_t nPos = seen.size();
-    graph.resize(byCode.size(), nPos, 0);
+        for (auto &n : p) all.push_back({n.code, n.vid, &n});
+    std::sort(all.begin(), all.end(), [](const Ref &a, const Ref &b) { return a.code != b.code ? a.code < b.code : a.vid < b.vid; });
+    all.erase(std::unique(all.begin(), all.end(), [](const Ref &a, const Ref &b) { return a.vid == b.vid && a.code == b.code; }),
+              all.end());
+
+    std::size_t nNodes = 0;
+    for (std::size_t i = 0; i < all.size(); ++i)
+        if (i == 0 || all[i].code != all[i - 1].code) ++nNodes;
+    graph.resize(nNodes, all.size(), 0);
     graph.k = k;
-    std::unordered_map<std::uint32_t, Vertex> where;
-    std::size_t ni = 0, pi = 0;
-    for (auto &kv : byCode) {
-        graph.nodeCode[ni] = kv.first;
-        graph.posOff[ni] = pi;
-        std::uint32_t j = 0;
-        for (auto *n : kv.second) {
-            graph.posCtg[pi] = n->ctg;
-            graph.posRef[pi] = n->ref;
-            graph.posCnt[pi] = n->cnt;
-            where[n->vid] = Vertex{static_cast<std::uint32_t>(ni), j++};
-            ++pi;
+    // (vid -> vertex) lookup table, sorted by vid
+    std::vector<std::pair<std::uint32_t, Vertex>> where(all.size());
+    std::size_t ni = 0;
+    std::uint32_t pi = 0;
+    for (std::size_t i = 0; i < all.size(); ++i) {
+        if (i == 0 || all[i].code != all[i - 1].code) {
+            if (i != 0) ++ni;
+            graph.nodeCode[ni] = all[i].code;
+            graph.posOff[ni] = i;
+            pi = 0;
         }
-        ++ni;
+        graph.posCtg[i] = all[i].n->ctg;
+        graph.posRef[i] = all[i].n->ref;
+        graph.posCnt[i] = all[i].n->cnt;
+        where[i] = {all[i].vid, Vertex{static_cast<std::uint32_t>(ni), pi++}};
     }
-    graph.posOff[ni] = pi;
+    if (nNodes) graph.posOff[nNodes] = all.size();
+    std::sort(where.begin(), where.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    auto find = [&](std::uint32_t vid) {
+        auto it = std::lower_bound(where.begin(), where.end(), vid, [](const auto &a, std::uint32_t v) { return a.first < v; });
+        return it->second;
+    };
     results.assign(paths.size() * 2, {});
     for (std::size_t c = 0; c < paths.size(); ++c) {
         if (c >= orient.size() || orient[c] < 0) continue;
         auto &res = results[2 * c + (orient[c] ? 0 : 1)];
         res.reserve(paths[c].size());
-        for (auto &n : paths[c]) res.emplace_back(where[n.vid], n.step);
+        for (auto &n : paths[c]) res.emplace_back(find(n.vid), n.step);
     }
 }
 

@@ -2,6 +2,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <exception>
 #include <set>
 #include <string>
@@ -67,7 +68,12 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
             tp.error_rate = 0.15;
             tp.start_split = 0.90;
             tp.min_len = min_len;
-            int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, nullptr);
+            pag_travel_stats tst{};
+            int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
+            if (std::getenv("PAGRAPH_TIMING"))
+                std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu\n", tst.ms_total,
+                             tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
+                             (unsigned long long)tst.walk_steps);
             if (rc != PAG_OK) {
                 setErr("pag_travel: %s", pag_last_error());
                 return rc;
@@ -78,8 +84,10 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
                 const pag_path_node *p = pag_travel_path(g, c, &len);
                 if (p && len) paths[c].assign(p, p + len);
             }
+            const double tg0 = nowMs();
             pagh::buildPathGraph(paths, orient, k, graph, precomputed);
             t1 = nowMs();
+            if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
         } else {
             std::uint64_t nn = 0, np = 0, ne = 0;
             int rc = pag_csr_sizes(g, &nn, &np, &ne);
