@@ -186,33 +186,108 @@ __device__ __forceinline__ void gs_insert_single(uint64_t *tab, uint32_t mask, u
 }
 
 // =================================================================================================
+// coordinate order + precomputed successor lists
+// =================================================================================================
+// A walk advances along the contig coordinate, but vertex ids are k-mer major, i.e. random with respect
+// to the coordinate: every step of a walk on the k-mer-major CSR is a chain of ~8 dependent random HBM
+// accesses (TLB misses included, ~3 us each).  So the vertices are renumbered by contig coordinate
+// (stable radix sort on DualPos.first: [ctg == 0 vertices] ++ [ctg != 0 ascending]) and the static part of
+// the epsilon-join — searchSuccessors + checkPosition + isEdgeSimilar for EVERY vertex — is evaluated
+// once, in parallel, into per-vertex successor records stored in that order.  A walk then streams
+// through nearly consecutive memory: records, visit stamps and offsets of consecutive path vertices are
+// neighbours.
+__global__ void k_order_keys(const uint64_t *__restrict__ vpos, uint64_t n, uint32_t *__restrict__ key, uint64_t *__restrict__ val) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        key[i] = (uint32_t)(vpos[i] >> 32);
+        val[i] = i;
+    }
+}
+
+__global__ void k_order_apply(const uint64_t *__restrict__ sorted_old, uint64_t n, TravGraph G) {
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = (uint32_t)sorted_old[u];
+        G.uold[u] = v;
+        G.newid[v] = (uint32_t)u;
+        G.upos[u] = G.vpos[v];
+    }
+}
+
+template <bool FILL>
+__global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt) {
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < G.n_pos; u += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = G.uold[u];
+        const uint64_t rootp = G.upos[u];
+        const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
+        const uint32_t node = G.vnode[v];
+        uint32_t n = 0;
+        uint32_t out = FILL ? G.succ_off[u] : 0;
+        for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
+            const uint32_t to = G.eto[e], step = G.estep[e];
+            if (to == PAG_NONE) continue;
+            for (uint32_t p = G.npos_off[to]; p < G.npos_off[to + 1]; ++p) {
+                const uint64_t pp = G.vpos[p];
+                const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
+                uint32_t esim;
+                int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
+                if (grade == G_OOPS) continue;
+                if (FILL) {
+                    SuccRec r;
+                    r.tgt = G.newid[p];
+                    r.pc = pc;
+                    r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+                    G.succ[out + n] = r;
+                }
+                ++n;
+            }
+        }
+        if (!FILL) cnt[u] = n;
+    }
+}
+
+// [first, last) new-id range of the vertices whose contig coordinate lies in [lo, hi)
+__global__ void k_ranges(TravGraph G, TravContig *ctgs, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto lower = [&](uint32_t x) {
+        uint64_t lo = 0, hi = G.n_pos;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if ((uint32_t)(G.upos[mid] >> 32) < x) lo = mid + 1;
+            else hi = mid;
+        }
+        return (uint32_t)lo;
+    };
+    ctgs[i].in_lo = lower(ctgs[i].ctg_left);
+    ctgs[i].in_hi = lower(ctgs[i].ctg_right);
+}
+
+// =================================================================================================
 // the walker
 // =================================================================================================
 constexpr int LIST_CAP = 256;  // successors of one vertex kept per class
 constexpr int BR_CAP = 256;    // branch fan-out kept per graphTravel round
+#define STAMP_TRAVEL 0xFFFFFFFFu
 
 struct WalkLds {
-    uint32_t e_to[64], e_step[64], e_p0[64], e_pre[65];
     uint32_t lst_v[4][LIST_CAP], lst_s[4][LIST_CAP];
     uint32_t lst_n[4];
     uint32_t br_v[BR_CAP], br_s[BR_CAP];
-    uint32_t out_n;
 };
 
 struct WalkCtx {
     TravGraph G;
     TravContig C;
-    // job state
-    uint32_t *tset;
-    uint32_t tmask;
-    uint64_t *pset;
-    uint32_t pmask;
+    // visited state of this job: stamps for vertices on the contig strand, small hash sets for the rest
+    uint32_t *stamp;   // [in_hi - in_lo]: 0 unvisited, STAMP_TRAVEL = travelUniqueTable, else walkStraight generation
+    uint32_t *tset_o;  // travelUniqueTable, vertices outside the strand's id range
+    uint32_t tmask_o;
+    uint64_t *pset_o;  // walkStraight uniqueTable, outside the range
+    uint32_t pmask_o;
+    uint32_t n_out;    // entries in the outside sets (load-factor guard)
     uint32_t gen;
     uint32_t win_g0, win_g1;  // ctgGlobalPosTable
     uint32_t win_t0, win_t1;  // ctgTravelPosTable
     uint32_t win_p0, win_p1;  // walkStraight's ctgPosTable
-    uint32_t dev;
-    double err;
     int overflow;
 };
 
@@ -222,109 +297,88 @@ __device__ __forceinline__ void win_add(uint32_t &lo, uint32_t &hi, uint32_t p) 
     lo = p < lo ? p : lo;
     hi = p > hi ? p : hi;
 }
+__device__ __forceinline__ bool in_range(const WalkCtx &X, uint32_t u) { return u >= X.C.in_lo && u < X.C.in_hi; }
+__device__ __forceinline__ uint32_t stamp_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stamp_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// classifySuccessors (PAlgorithm.tcc:35-90) on top of searchSuccessors (PABruijnGraph.cpp:167-197).
+__device__ __forceinline__ bool visited_global(const WalkCtx &X, uint32_t u) {
+    if (in_range(X, u)) {
+        if (!X.C.gbits) return false;
+        uint32_t d = u - X.C.in_lo;
+        return (X.C.gbits[d >> 5] >> (d & 31u)) & 1u;
+    }
+    return hs_has(X.C.gset, X.C.gmask, u);
+}
+
+// classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
 // level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
 // Result: L.lst_v/lst_s[0] hold the chosen class in reference order, return = its size.
 __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap, int level) {
     const uint32_t lane = lane_id();
-    const uint64_t rootp = X.G.vpos[cur];
-    const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
-    const uint32_t node = X.G.vnode[cur];
-    const uint32_t e0 = X.G.nedge_off[node], e1 = X.G.nedge_off[node + 1];
+    const uint32_t r0 = X.G.succ_off[cur], r1 = X.G.succ_off[cur + 1];
     __syncthreads();
     if (lane < 4) L.lst_n[lane] = 0;
     __syncthreads();
-    for (uint32_t eb = e0; eb < e1; eb += 64) {
-        // this group's edges and the vertex ranges of their targets
-        uint32_t cnt = 0;
-        if (eb + lane < e1) {
-            uint32_t to = X.G.eto[eb + lane];
-            L.e_to[lane] = to;
-            L.e_step[lane] = X.G.estep[eb + lane];
-            uint32_t p0 = 0, p1 = 0;
-            if (to != PAG_NONE) {
-                p0 = X.G.npos_off[to];
-                p1 = X.G.npos_off[to + 1];
-            }
-            L.e_p0[lane] = p0;
-            cnt = p1 - p0;
-        }
-        uint32_t total;
-        uint32_t ex = wave_excl_sum(cnt, &total);
-        L.e_pre[lane] = ex;
-        if (lane == 63) L.e_pre[64] = total;
-        __syncthreads();
-        for (uint32_t cb = 0; cb < total; cb += 64) {
-            uint32_t ci = cb + lane;
-            int cls = -1;
-            uint32_t v = 0, step = 0;
-            if (ci < total) {
-                // edge slot of candidate ci: last slot with prefix <= ci
-                uint32_t lo = 0, hi = 64;
-                while (hi - lo > 1) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (L.e_pre[mid] <= ci) lo = mid;
-                    else hi = mid;
+    for (uint32_t rb = r0; rb < r1; rb += 64) {
+        int cls = -1;
+        uint32_t v = 0, step = 0;
+        if (rb + lane < r1) {
+            const SuccRec rec = X.G.succ[rb + lane];
+            v = rec.tgt;
+            step = rec.meta & 0xFFFFFFu;
+            const int grade = (int)((rec.meta >> 24) & 7u);
+            const bool ectg = (rec.meta >> 27) & 1u;
+            const uint32_t pc = rec.pc;
+            const bool inr = in_range(X, v);
+            uint32_t stp = 0;
+            if (inr) stp = stamp_load(&X.stamp[v - X.C.in_lo]);
+            bool ok = !visited_global(X, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
+                      (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
+            if (ok) ok = !(inr ? stp == STAMP_TRAVEL : hs_has(X.tset_o, X.tmask_o, v)) &&
+                         (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
+            if (ok && level == 2)
+                ok = !(inr ? stp == X.gen : gs_has(X.pset_o, X.pmask_o, v, X.gen)) &&
+                     (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
+            if (ok) {
+                bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
+                if (leap) {
+                    // landing rule (PAlgorithm.tcc:60-67): singleToDual (PositionMapper.cpp:44-64) on the start table
+                    uint32_t lo2 = 0, hi2 = X.C.n_ctgs + 1;
+                    while (lo2 < hi2) {  // upper_bound(starts, pc)
+                        uint32_t mid = (lo2 + hi2) >> 1;
+                        if (X.C.starts[mid] <= (uint64_t)pc) lo2 = mid + 1;
+                        else hi2 = mid;
+                    }
+                    uint32_t idx = lo2 ? lo2 - 1 : 0;
+                    uint64_t off = (uint64_t)pc - X.C.starts[idx];
+                    uint64_t sz = idx < X.C.n_ctgs ? X.C.sizes[idx] : 0;
+                    if (off >= 2 * sz) off -= 2 * sz;
+                    if ((double)(int64_t)off > (double)sz * X.C.leap_min) ok = false;
+                    if (!can_leap) ok = false;
                 }
-                v = L.e_p0[lo] + (ci - L.e_pre[lo]);
-                step = L.e_step[lo];
-                const uint64_t pp = X.G.vpos[v];
-                const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
-                uint32_t esim;
-                int grade = d_check_position(rc, rr, pc, pr, step, X.dev, X.err, &esim);
-                bool ok = grade != G_OOPS;
-                const bool ectg = esim & 1u;
-                // filters, innermost level first is irrelevant: all must hold
-                if (ok) ok = !hs_has(X.C.gset, X.C.gmask, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
-                             (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
-                if (ok) ok = !hs_has(X.tset, X.tmask, v) && (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
-                if (ok && level == 2) ok = !gs_has(X.pset, X.pmask, v, X.gen) && (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
                 if (ok) {
-                    bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
-                    if (leap) {
-                        // landing rule: only the first leapMin fraction of the target contig strand
-                        // singleToDual (PositionMapper.cpp:44-64) via the start table
-                        uint32_t lo2 = 0, hi2 = X.C.n_ctgs + 1;  // starts has n_ctgs + 1 entries
-                        // upper_bound(starts, pc) then step back
-                        while (lo2 < hi2) {
-                            uint32_t mid = (lo2 + hi2) >> 1;
-                            if (X.C.starts[mid] <= (uint64_t)pc) lo2 = mid + 1;
-                            else hi2 = mid;
-                        }
-                        uint32_t idx = lo2 ? lo2 - 1 : 0;
-                        uint64_t off = (uint64_t)pc - X.C.starts[idx];
-                        uint64_t sz = idx < X.C.n_ctgs ? X.C.sizes[idx] : 0;
-                        if (off >= 2 * sz) off -= 2 * sz;
-                        if ((double)(int64_t)off > (double)sz * X.C.leap_min) ok = false;
-                        if (!can_leap) ok = false;
-                    }
-                    if (ok) {
-                        if (grade == G_AMAZING || leap) cls = 0;
-                        else if (grade == G_EXCELLENT) cls = 1;
-                        else if (grade == G_GOOD) cls = 2;
-                        else if (can_leap && grade == G_SKIP) cls = 3;
-                    }
+                    if (grade == G_AMAZING || leap) cls = 0;
+                    else if (grade == G_EXCELLENT) cls = 1;
+                    else if (grade == G_GOOD) cls = 2;
+                    else if (can_leap && grade == G_SKIP) cls = 3;
                 }
-            }
-            // ordered append to the four class lists
-            for (int c = 0; c < 4; ++c) {
-                uint64_t m = __ballot(cls == c);
-                if (m == 0) continue;
-                uint32_t base = L.lst_n[c];
-                if (cls == c) {
-                    uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt());
-                    if (at < LIST_CAP) {
-                        L.lst_v[c][at] = v;
-                        L.lst_s[c][at] = step;
-                    }
-                }
-                __syncthreads();
-                if (lane == 0) L.lst_n[c] = base + (uint32_t)__popcll(m);
-                __syncthreads();
             }
         }
-        __syncthreads();
+        for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
+            uint64_t m = __ballot(cls == c);
+            if (m == 0) continue;
+            uint32_t base = L.lst_n[c];
+            if (cls == c) {
+                uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt());
+                if (at < LIST_CAP) {
+                    L.lst_v[c][at] = v;
+                    L.lst_s[c][at] = step;
+                }
+            }
+            __syncthreads();
+            if (lane == 0) L.lst_n[c] = base + (uint32_t)__popcll(m);
+            __syncthreads();
+        }
     }
     __syncthreads();
     int chosen = L.lst_n[0] ? 0 : (L.lst_n[1] ? 1 : (L.lst_n[2] ? 2 : 3));
@@ -341,6 +395,15 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap
     }
     __syncthreads();
     return n;
+}
+
+// mark a vertex in walkStraight's uniqueTable (one lane)
+__device__ __forceinline__ void probe_mark(WalkCtx &X, uint32_t u) {
+    if (in_range(X, u)) {
+        stamp_store(&X.stamp[u - X.C.in_lo], X.gen);
+    } else {
+        gs_insert_single(X.pset_o, X.pmask_o, u, X.gen);
+    }
 }
 
 enum { WS_END = 0, WS_BRANCH = 1, WS_LIMIT = 2, WS_LEAP = 3 };
@@ -363,13 +426,15 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
         ps[0] = s0;
     }
     len = 1;
-    uint32_t c = (uint32_t)(X.G.vpos[v0] >> 32);
+    uint32_t c = (uint32_t)(X.G.upos[v0] >> 32);
     if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
         *out_len = len;
         return WS_LEAP;
     }
     win_add(X.win_p0, X.win_p1, c);
-    if (lane == 0) gs_insert_single(X.pset, X.pmask, v0, X.gen);
+    uint32_t out_used = 0;
+    if (lane == 0) probe_mark(X, v0);
+    if (!in_range(X, v0)) ++out_used;
     __syncthreads();
     uint32_t cur = v0;
     int status;
@@ -385,17 +450,18 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
         }
         uint32_t v = L.lst_v[0][0], s = L.lst_s[0][0];
         __syncthreads();
-        if (len >= cap || (len + 1) * 2 > (uint64_t)X.pmask) {
+        if (len >= cap || (uint64_t)(out_used + 1) * 2 > (uint64_t)X.pmask_o) {
             X.overflow = 1;
             status = WS_END;
             break;
         }
-        uint32_t vc = (uint32_t)(X.G.vpos[v] >> 32);
+        uint32_t vc = (uint32_t)(X.G.upos[v] >> 32);
         if (lane == 0) {
-            gs_insert_single(X.pset, X.pmask, v, X.gen);
+            probe_mark(X, v);
             pv[len] = v;
             ps[len] = s;
         }
+        if (!in_range(X, v)) ++out_used;
         win_add(X.win_p0, X.win_p1, vc);
         len += 1;
         now_size += s;
@@ -412,7 +478,7 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
 
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
 __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__restrict__ ctgs, const TravJob *__restrict__ jobs,
-                                             TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k, uint32_t dev, double err) {
+                                             TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k) {
     __shared__ WalkLds L;
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
@@ -421,56 +487,59 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     WalkCtx X;
     X.G = G;
     X.C = ctgs[J.ctg];
-    X.tset = J.tset;
-    X.tmask = J.tmask;
-    X.pset = J.pset;
-    X.pmask = J.pmask;
+    X.stamp = J.stamp;
+    X.tset_o = J.tset;
+    X.tmask_o = J.tmask;
+    X.pset_o = J.pset;
+    X.pmask_o = J.pmask;
+    X.n_out = 0;
     X.gen = 0;
     X.win_g0 = X.C.gwin_lo;
     X.win_g1 = X.C.gwin_hi;
     X.win_t0 = 0xFFFFFFFFu;
     X.win_t1 = 0;
-    X.dev = dev;
-    X.err = err;
     X.overflow = 0;
 
     uint64_t seq_len = 0, now_size = k, seq_size = 0;
     const uint64_t has_size = J.has_size;
-    win_add(X.win_t0, X.win_t1, (uint32_t)(G.vpos[J.start] >> 32));
+    const uint32_t start = G.newid[J.start];
+    win_add(X.win_t0, X.win_t1, (uint32_t)(G.upos[start] >> 32));
 
-    // first walk from the seed
     uint64_t plen = 0;
-    walk_straight(L, X, J.start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
+    walk_straight(L, X, start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
     uint64_t ch_off = 0, ch_len = plen;  // chosen path inside the arena
 
     for (;;) {
-        // append the chosen path to the sequence, mark visited, widen the travel window
-        if (seq_len + ch_len > J.seq_cap || (seq_len + ch_len) * 2 > (uint64_t)J.tmask) {
+        // append the chosen path to the sequence, mark it visited, widen the travel window
+        if (seq_len + ch_len > J.seq_cap) {
             X.overflow = 1;
             break;
         }
         uint64_t add = 0;
+        uint32_t lo = 0xFFFFFFFFu, hi = 0, n_outside = 0;
         for (uint64_t i = lane; i < ch_len; i += 64) {
             uint32_t v = J.arena_v[ch_off + i], s = J.arena_s[ch_off + i];
             J.seq_v[seq_len + i] = v;
             J.seq_s[seq_len + i] = s;
-            hs_insert(J.tset, J.tmask, v);
+            if (in_range(X, v)) {
+                stamp_store(&X.stamp[v - X.C.in_lo], STAMP_TRAVEL);
+            } else {
+                hs_insert(X.tset_o, X.tmask_o, v);
+                ++n_outside;
+            }
             add += s;
+            uint32_t c = (uint32_t)(G.upos[v] >> 32);
+            if (c != 0) {
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
+            }
         }
-        // wave reductions: sum of steps, min/max of non-zero contig coordinates
         {
             uint64_t tot;
             wave_excl_sum64(add, &tot);
             now_size += tot;
             seq_size += tot;
-            uint32_t lo = 0xFFFFFFFFu, hi = 0;
-            for (uint64_t i = lane; i < ch_len; i += 64) {
-                uint32_t c = (uint32_t)(G.vpos[J.arena_v[ch_off + i]] >> 32);
-                if (c != 0) {
-                    lo = c < lo ? c : lo;
-                    hi = c > hi ? c : hi;
-                }
-            }
+            X.n_out += wave_sum(n_outside);
             for (int d = 32; d >= 1; d >>= 1) {
                 uint32_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
                 lo = ol < lo ? ol : lo;
@@ -482,11 +551,15 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
             }
         }
         seq_len += ch_len;
+        if ((uint64_t)X.n_out * 2 > (uint64_t)X.tmask_o) {
+            X.overflow = 1;
+            break;
+        }
         __threadfence_block();
         __syncthreads();
 
         const uint32_t last = J.seq_v[seq_len - 1];
-        const uint32_t lc = (uint32_t)(G.vpos[last] >> 32);
+        const uint32_t lc = (uint32_t)(G.upos[last] >> 32);
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
 
         uint32_t m = classify(L, X, last, (has_size + now_size) >= X.C.split_size, 1);
@@ -523,7 +596,7 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
                     tip_off = used;
                 }
             } else {
-                uint32_t ab = G.vcnt[sv];
+                uint32_t ab = G.vcnt[G.uold[sv]];
                 if (best_branch < 0 || ab > best_ab) {
                     best_branch = (int)i;
                     best_ab = ab;
@@ -551,7 +624,7 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         o.seq_len = seq_len;
         o.seq_size = seq_size;
         o.overflow = X.overflow;
-        o.last_ctg = seq_len ? (uint32_t)(G.vpos[J.seq_v[seq_len - 1]] >> 32) : 0;
+        o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;
         outs[jid] = o;
     }
 }
@@ -663,17 +736,21 @@ __global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravConti
     if (lane == 0) o[0] = n_out;
 }
 
-// insert a finished walk into the contig's global visited set
-__global__ void k_commit(const uint32_t *__restrict__ seq_v, uint64_t len, uint32_t *gset, uint32_t gmask) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
-        hs_insert(gset, gmask, seq_v[i]);
+// record a finished walk (new ids) in the contig's global visited structures
+__global__ void k_commit(const uint32_t *__restrict__ seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits,
+                         uint32_t *gset, uint32_t gmask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t u = seq_v[i];
+        if (u >= in_lo && u < in_hi) atomicOr(&gbits[(u - in_lo) >> 5], 1u << ((u - in_lo) & 31u));
+        else hs_insert(gset, gmask, u);
+    }
 }
 
-// vertex attributes of a path for the host
+// vertex attributes of a path (new ids) for the host
 __global__ void k_gather_path(TravGraph G, const uint32_t *__restrict__ seq_v, const uint32_t *__restrict__ seq_s, uint64_t len,
                               pag_path_node *__restrict__ out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t v = seq_v[i];
+        uint32_t v = G.uold[seq_v[i]];
         uint64_t p = G.vpos[v];
         pag_path_node o;
         o.code = G.ncode[G.vnode[v]];
@@ -774,11 +851,47 @@ void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeed
     if (n) k_seed_window<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out, stride);
 }
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
-                      uint32_t dev, double err, hipStream_t s) {
-    if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k, dev, err);
+                      hipStream_t s) {
+    if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k);
 }
-void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t *gset, uint32_t gmask, hipStream_t s) {
-    if (len) k_commit<<<dim3(grid_for(len)), dim3(256), 0, s>>>(seq_v, len, gset, gmask);
+void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
+                        uint32_t gmask, hipStream_t s) {
+    if (len) k_commit<<<dim3(grid_for(len)), dim3(256), 0, s>>>(seq_v, len, in_lo, in_hi, gbits, gset, gmask);
+}
+void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s) {
+    if (n) k_ranges<<<dim3((n + 63) / 64), dim3(64), 0, s>>>(G, ctgs, n);
+}
+
+// coordinate order + successor records.  key/val/key2/val2: u32/u64 [n_pos] scratch pairs for the sort;
+// cnt: u32 [n_pos + 1]; *n_succ_out receives the number of successor records (call twice: first with
+// G.succ == nullptr to size it, then with the allocation)
+int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, hipStream_t s) {
+    const uint64_t n = G.n_pos;
+    if (!n) return PAG_OK;
+    k_order_keys<<<dim3(grid_for(n)), dim3(256), 0, s>>>(G.vpos, n, key, val);
+    int in0 = 1, rc;
+    if ((rc = sort_pairs(key, val, key2, val2, n, 32, sort_tmp, &in0, s, nullptr, nullptr))) return rc;
+    k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(in0 ? val : val2, n, G);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
+                    hipStream_t s) {
+    const uint64_t n = G.n_pos;
+    if (!n) return PAG_OK;
+    k_succ<false><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt);
+    PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
+    int rc;
+    if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
+    k_narrow<<<dim3(grid_for(n + 1)), dim3(256), 0, s>>>(scan_out, n + 1, G.succ_off);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+int trav_succ_fill(TravGraph G, uint32_t dev, double err, hipStream_t s) {
+    if (!G.n_pos) return PAG_OK;
+    k_succ<true><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
 }
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
                              hipStream_t s) {

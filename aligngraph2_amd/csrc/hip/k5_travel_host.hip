@@ -100,8 +100,11 @@ struct CtgState {
     bool finalLeap = false, done = false;
     std::unordered_set<uint32_t> globalUnique;
     uint32_t gwinLo = 0xFFFFFFFFu, gwinHi = 0;
-    uint32_t *gset = nullptr;  // device
+    uint32_t *gset = nullptr;   // device: global visited, vertices outside the strand's id range
     uint32_t gcap = 0;
+    uint32_t *gbits = nullptr;  // device: global visited bitmap over [inLo, inHi)
+    uint32_t inLo = 0, inHi = 0;
+    uint64_t nOutside = 0;      // entries in gset
     uint64_t seqCap = 0;
     uint32_t parentCode = 0;  // k-mer of the last contig-consistent path vertex (seed ordering key)
     bool haveParent = false;
@@ -163,7 +166,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
-           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf();
+           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(),
+           b_soff = buf(), b_succ = buf(), b_ok0 = buf(), b_ov0 = buf(), b_ok1 = buf(), b_ov1 = buf(), b_otmp = buf();
     const uint64_t nn = g->stats.n_nodes, np = g->stats.n_pos, ne = g->stats.n_uniq_edges;
     if (np >= 0xFFFFFFF0ull || ne >= 0xFFFFFFF0ull) {
         set_error("pag_travel: more than 2^32 vertices/edges");
@@ -173,7 +177,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     if ((rc = b_ncode.alloc((nn + 1) * 4)) || (rc = b_npos.alloc((nn + 2) * 4)) || (rc = b_nedge.alloc((nn + 2) * 4)) ||
         (rc = b_vpos.alloc((np + 1) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
         (rc = b_eto.alloc((ne + 1) * 4)) || (rc = b_estep.alloc((ne + 1) * 4)) || (rc = b_bitmap.alloc(n_words * 8)) ||
-        (rc = b_rank.alloc(n_words * 4)))
+        (rc = b_rank.alloc(n_words * 4)) || (rc = b_uold.alloc((np + 1) * 4)) || (rc = b_newid.alloc((np + 1) * 4)) ||
+        (rc = b_upos.alloc((np + 1) * 8)) || (rc = b_soff.alloc((np + 2) * 4)))
         return rc;
     TravGraph G{};
     G.n_nodes = nn;
@@ -189,7 +194,16 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     G.estep = b_estep.as<uint32_t>();
     G.bitmap = b_bitmap.as<uint64_t>();
     G.rank = b_rank.as<uint32_t>();
+    G.uold = b_uold.as<uint32_t>();
+    G.newid = b_newid.as<uint32_t>();
+    G.upos = b_upos.as<uint64_t>();
+    G.succ_off = b_soff.as<uint32_t>();
     double t_compact = 0;
+    if (g->tg_ready && (g->tg_dev != deviation || g->tg_err != errorRate)) g->tg_ready = false;
+    if (g->tg_ready) {
+        G.succ = g->tg.succ;
+        G.n_succ = g->tg.n_succ;
+    }
     if (!g->tg_ready) {
         const double t0 = now_ms();
         size_t tb = trav_compact_tmp_bytes(g->n_t, g->n_e, k, nn);
@@ -197,8 +211,31 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
                                b_ctmp.p, tb, s)))
             return rc;
+        // coordinate order, then the static half of the epsilon-join for every vertex
+        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 1) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
+            (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
+            return rc;
+        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, s)))
+            return rc;
+        uint64_t n_succ = 0;
+        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov1[0] as the total
+        if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
+                                  b_ov1.as<uint64_t>(), s)))
+            return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov1.p, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (n_succ >= 0xFFFFFFF0ull) {
+            set_error("pag_travel: more than 2^32 successor records");
+            return PAG_EINVAL;
+        }
+        if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
+        G.succ = b_succ.as<SuccRec>();
+        G.n_succ = n_succ;
+        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         g->tg = G;
+        g->tg_dev = deviation;
+        g->tg_err = errorRate;
         g->tg_ready = true;
         t_compact = now_ms() - t0;
     }
@@ -231,7 +268,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     DevBuf b_packed = buf(), b_nodes = buf(), b_starts = buf(), b_sizes = buf(), b_tc = buf(), b_seedout = buf(), b_req = buf(),
            b_jobs = buf(), b_outs = buf(), b_seqv = buf(), b_seqs = buf(), b_arv = buf(), b_ars = buf(), b_tset = buf(),
-           b_pset = buf(), b_gset = buf(), b_gather = buf(), b_vids = buf();
+           b_pset = buf(), b_gset = buf(), b_gather = buf(), b_vids = buf(), b_stamp = buf(), b_gbits = buf();
     if ((rc = b_packed.alloc(ctgs->packed_bytes + 64)) || (rc = b_nodes.alloc((nodes_total + 1) * 4)) ||
         (rc = b_starts.alloc(mapper.starts.size() * 8 + 8)) || (rc = b_sizes.alloc(mapper.sizes.size() * 8 + 8)) ||
         (rc = b_tc.alloc(n_sel * sizeof(TravContig))))
@@ -243,24 +280,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         trav_launch_ctg_nodes(b_packed.as<uint8_t>(), ctgs->byte_off[cs.ci], cs.len, cs.forward ? 1 : 0, k, G,
                               b_nodes.as<uint32_t>() + cs.nodesOff, s);
 
-    // global visited sets, one per contig
-    {
-        uint64_t tot = 0;
-        for (auto &cs : st) {
-            cs.gcap = (uint32_t)pow2_at_least(cs.seqCap * 4);
-            tot += cs.gcap;
-        }
-        if ((rc = b_gset.alloc(tot * 4))) return rc;
-        PAG_HIP_TRY(hipMemsetAsync(b_gset.p, 0xFF, tot * 4, s));
-        uint64_t off = 0;
-        for (auto &cs : st) {
-            cs.gset = b_gset.as<uint32_t>() + off;
-            off += cs.gcap;
-        }
-    }
-
     std::vector<TravContig> tc(n_sel);
-    auto upload_contigs = [&]() -> int {
+    auto fill_contigs = [&]() {
         for (uint32_t i = 0; i < n_sel; ++i) {
             CtgState &cs = st[i];
             TravContig &t = tc[i];
@@ -275,14 +296,47 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             t.starts = b_starts.as<uint64_t>();
             t.sizes = b_sizes.as<uint64_t>();
             t.n_ctgs = n_ctgs;
+            t.in_lo = cs.inLo;
+            t.in_hi = cs.inHi;
+            t.gbits = cs.globalUnique.empty() ? nullptr : cs.gbits;
             t.gset = cs.globalUnique.empty() ? nullptr : cs.gset;
             t.gmask = cs.gcap - 1;
             t.gwin_lo = cs.gwinLo;
             t.gwin_hi = cs.gwinHi;
         }
+    };
+    auto upload_contigs = [&]() -> int {
+        fill_contigs();
         PAG_HIP_TRY(hipMemcpyAsync(b_tc.p, tc.data(), n_sel * sizeof(TravContig), hipMemcpyHostToDevice, s));
         return PAG_OK;
     };
+    // id ranges of the strands, then the per-contig global visited structures
+    {
+        for (auto &cs : st) cs.gcap = 1024;  // placeholder so that gmask is well formed
+        if ((rc = upload_contigs())) return rc;
+        trav_launch_ranges(G, b_tc.as<TravContig>(), n_sel, s);
+        PAG_HIP_TRY(hipMemcpyAsync(tc.data(), b_tc.p, n_sel * sizeof(TravContig), hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        uint64_t tot_set = 0, tot_bits = 0;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            CtgState &cs = st[i];
+            cs.inLo = tc[i].in_lo;
+            cs.inHi = tc[i].in_hi;
+            cs.gcap = (uint32_t)pow2_at_least(cs.seqCap / 2 + 8192);
+            tot_set += cs.gcap;
+            tot_bits += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+        }
+        if ((rc = b_gset.alloc(tot_set * 4)) || (rc = b_gbits.alloc(tot_bits * 4))) return rc;
+        PAG_HIP_TRY(hipMemsetAsync(b_gset.p, 0xFF, tot_set * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_gbits.p, 0, tot_bits * 4, s));
+        uint64_t o1 = 0, o2 = 0;
+        for (auto &cs : st) {
+            cs.gset = b_gset.as<uint32_t>() + o1;
+            o1 += cs.gcap;
+            cs.gbits = b_gbits.as<uint32_t>() + o2;
+            o2 += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+        }
+    }
 
     // vertex attributes for a list of vertex ids
     auto fetch_vertices = [&](const std::vector<uint32_t> &vids, std::vector<pag_path_node> &out) -> int {
@@ -340,25 +394,31 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         ++rounds;
         jobs_total += jr.size();
         std::vector<TravJob> jobs(jr.size());
-        uint64_t tot_seq = 0, tot_arena = 0, tot_t = 0, tot_p = 0;
-        std::vector<uint64_t> o_seq(jr.size()), o_ar(jr.size()), o_t(jr.size()), o_p(jr.size());
+        uint64_t tot_seq = 0, tot_arena = 0, tot_t = 0, tot_p = 0, tot_stamp = 0;
+        std::vector<uint64_t> o_seq(jr.size()), o_ar(jr.size()), o_t(jr.size()), o_p(jr.size()), o_st(jr.size());
+        auto out_cap = [&](const CtgState &cs) { return pow2_at_least((cs.seqCap / 4 + 4096) * grow); };
         for (size_t j = 0; j < jr.size(); ++j) {
-            uint64_t cap = st[jr[j].cs].seqCap * grow;
+            const CtgState &cs = st[jr[j].cs];
+            uint64_t cap = cs.seqCap * grow;
             o_seq[j] = tot_seq;
             o_ar[j] = tot_arena;
             o_t[j] = tot_t;
             o_p[j] = tot_p;
+            o_st[j] = tot_stamp;
             tot_seq += cap;
             tot_arena += 2 * cap;
-            tot_t += pow2_at_least(2 * cap + 2);
-            tot_p += pow2_at_least(4 * cap + 2);
+            tot_t += out_cap(cs);
+            tot_p += out_cap(cs);
+            tot_stamp += (uint64_t)(cs.inHi - cs.inLo) + 1;
         }
         if ((rc = b_seqv.alloc(tot_seq * 4)) || (rc = b_seqs.alloc(tot_seq * 4)) || (rc = b_arv.alloc(tot_arena * 4)) ||
             (rc = b_ars.alloc(tot_arena * 4)) || (rc = b_tset.alloc(tot_t * 4)) || (rc = b_pset.alloc(tot_p * 8)) ||
-            (rc = b_jobs.alloc(jobs.size() * sizeof(TravJob))) || (rc = b_outs.alloc(jobs.size() * sizeof(TravJobOut))))
+            (rc = b_stamp.alloc(tot_stamp * 4)) || (rc = b_jobs.alloc(jobs.size() * sizeof(TravJob))) ||
+            (rc = b_outs.alloc(jobs.size() * sizeof(TravJobOut))))
             return rc;
         PAG_HIP_TRY(hipMemsetAsync(b_tset.p, 0xFF, tot_t * 4, s));
         PAG_HIP_TRY(hipMemsetAsync(b_pset.p, 0, tot_p * 8, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_stamp.p, 0, tot_stamp * 4, s));
         for (size_t j = 0; j < jr.size(); ++j) {
             CtgState &cs = st[jr[j].cs];
             uint64_t cap = cs.seqCap * grow;
@@ -372,16 +432,16 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.arena_v = b_arv.as<uint32_t>() + o_ar[j];
             J.arena_s = b_ars.as<uint32_t>() + o_ar[j];
             J.arena_cap = 2 * cap;
+            J.stamp = b_stamp.as<uint32_t>() + o_st[j];
             J.tset = b_tset.as<uint32_t>() + o_t[j];
-            J.tmask = (uint32_t)pow2_at_least(2 * cap + 2) - 1;
+            J.tmask = (uint32_t)out_cap(cs) - 1;
             J.pset = b_pset.as<uint64_t>() + o_p[j];
-            J.pmask = (uint32_t)pow2_at_least(4 * cap + 2) - 1;
+            J.pmask = (uint32_t)out_cap(cs) - 1;
         }
         if ((rc = upload_contigs())) return rc;
         PAG_HIP_TRY(hipMemcpyAsync(b_jobs.p, jobs.data(), jobs.size() * sizeof(TravJob), hipMemcpyHostToDevice, s));
         const double tw0 = now_ms();
-        trav_launch_walk(G, b_tc.as<TravContig>(), b_jobs.as<TravJob>(), b_outs.as<TravJobOut>(), (uint32_t)jobs.size(), k,
-                         (uint32_t)deviation, errorRate, s);
+        trav_launch_walk(G, b_tc.as<TravContig>(), b_jobs.as<TravJob>(), b_outs.as<TravJobOut>(), (uint32_t)jobs.size(), k, s);
         std::vector<TravJobOut> outs(jobs.size());
         PAG_HIP_TRY(hipMemcpyAsync(outs.data(), b_outs.p, outs.size() * sizeof(TravJobOut), hipMemcpyDeviceToHost, s));
         PAG_HIP_TRY(hipStreamSynchronize(s));
@@ -434,7 +494,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                                         b_gather.as<pag_path_node>(), s);
                 PAG_HIP_TRY(hipMemcpyAsync(longest.data(), b_gather.p, o.seq_len * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
                 // record the walk in the device-side global visited set of this contig
-                trav_launch_commit(jobs[j0 + chosen].seq_v, o.seq_len, cs.gset, cs.gcap - 1, s);
+                trav_launch_commit(jobs[j0 + chosen].seq_v, o.seq_len, cs.inLo, cs.inHi, cs.gbits, cs.gset, cs.gcap - 1, s);
                 PAG_HIP_TRY(hipStreamSynchronize(s));
             }
             j0 += ns;
@@ -449,7 +509,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 while (cs.refQ.size() > 4) cs.refQ.pop_front();
             }
             for (auto &n : longest) {
-                cs.globalUnique.insert(n.vid);
+                if (cs.globalUnique.insert(n.vid).second && (n.ctg < cs.ctgLeft || n.ctg >= cs.ctgRight)) ++cs.nOutside;
                 if (n.ctg != 0) {
                     cs.gwinLo = std::min(cs.gwinLo, n.ctg);
                     cs.gwinHi = std::max(cs.gwinHi, n.ctg);
@@ -484,7 +544,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                     }
                 }
             }
-            if ((uint64_t)cs.globalUnique.size() * 2 > cs.gcap) {
+            if (cs.nOutside * 2 > cs.gcap) {
                 set_error("pag_travel: global visited set of contig %u is full", cs.ci);
                 return PAG_ENOMEM;
             }

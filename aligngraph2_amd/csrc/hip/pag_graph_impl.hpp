@@ -32,6 +32,8 @@ struct pag_graph {
     // traversal state (k5_travel_host.hip)
     pagdev::TravGraph tg{};
     bool tg_ready = false;
+    uint64_t tg_dev = 0;   // parameters the successor records were built with
+    double tg_err = 0;
     std::vector<std::vector<pag_path_node>> paths;
     // debug: raw emitted streams (host copies), kept when PAG_DEBUG_KEEP_STREAMS=1
     std::vector<uint32_t> dbg_tkey, dbg_ekey;

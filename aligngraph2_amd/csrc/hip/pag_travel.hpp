@@ -21,6 +21,20 @@ struct TravGraph {
     uint32_t *estep;      // [n_edges]
     uint64_t *bitmap;     // 4^k bits: k-mer code owns a node
     uint32_t *rank;       // per 64-bit bitmap word: nodes before it
+    // coordinate order ("new ids" u): [ctg == 0 vertices] ++ [ctg != 0 ascending]
+    uint32_t *uold;       // [n_pos] new id -> vertex id
+    uint32_t *newid;      // [n_pos] vertex id -> new id
+    uint64_t *upos;       // [n_pos] positions in new order
+    uint32_t *succ_off;   // [n_pos + 1] successor records of new id u
+    struct SuccRec *succ; // [n_succ]
+    uint64_t n_succ;
+};
+
+// one graded successor of a vertex (searchSuccessors + checkPosition != Oops), in reference order
+struct SuccRec {
+    uint32_t tgt;   // new id
+    uint32_t pc;    // contig coordinate of the target
+    uint32_t meta;  // step (24 bits) | grade << 24 | isEdgeSimilar().first << 27
 };
 
 struct TravContig {
@@ -33,7 +47,9 @@ struct TravContig {
     const uint64_t *starts;        // contig PositionMapper start table [n_ctgs + 1]
     const uint64_t *sizes;         // [n_ctgs]
     uint32_t n_ctgs;
-    uint32_t *gset;  // globalUniqueTable (may be null before the first commit)
+    uint32_t in_lo, in_hi;  // new-id range of the vertices on the traversed strand (filled by k_ranges)
+    uint32_t *gbits;        // globalUniqueTable: bitmap over [in_lo, in_hi) (null before the first commit)
+    uint32_t *gset;         // ... hash set for vertices outside that range (null before the first commit)
     uint32_t gmask;
     uint32_t gwin_lo, gwin_hi;  // ctgGlobalPosTable
 };
@@ -46,7 +62,8 @@ struct TravJob {
     uint64_t seq_cap;
     uint32_t *arena_v, *arena_s;
     uint64_t arena_cap;
-    uint32_t *tset;
+    uint32_t *stamp;  // [in_hi - in_lo] zeroed: visit stamps of the strand's vertices
+    uint32_t *tset;   // hash sets for vertices outside the strand's id range
     uint32_t tmask;
     uint64_t *pset;
     uint32_t pmask;
@@ -75,8 +92,14 @@ void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uin
 void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
                              uint32_t *out, uint32_t stride, hipStream_t s);
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
-                      uint32_t dev, double err, hipStream_t s);
-void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t *gset, uint32_t gmask, hipStream_t s);
+                      hipStream_t s);
+void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
+                        uint32_t gmask, hipStream_t s);
+void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);
+int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, hipStream_t s);
+int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
+                    hipStream_t s);
+int trav_succ_fill(TravGraph G, uint32_t dev, double err, hipStream_t s);
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
                              hipStream_t s);
 void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s);
