@@ -288,6 +288,9 @@ struct WalkCtx {
     uint32_t win_g0, win_g1;  // ctgGlobalPosTable
     uint32_t win_t0, win_t1;  // ctgTravelPosTable
     uint32_t win_p0, win_p1;  // walkStraight's ctgPosTable
+    uint32_t pf_hi;   // ids below this have been pulled towards the L2 (lookahead)
+    uint32_t pf_acc;  // keeps the lookahead loads alive
+    uint64_t n_classify, n_probe, n_records;  // work counters
     int overflow;
 };
 
@@ -313,56 +316,94 @@ __device__ __forceinline__ bool visited_global(const WalkCtx &X, uint32_t u) {
 // classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
 // level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
 // Result: L.lst_v/lst_s[0] hold the chosen class in reference order, return = its size.
-__device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap, int level) {
+// per-lane evaluation of one successor record: class 0 Amazing/leap, 1 Excellent, 2 Good, 3 Skip, -1 rejected
+__device__ __forceinline__ int eval_record(const WalkCtx &X, const SuccRec &rec, bool can_leap, int level) {
+    const uint32_t v = rec.tgt;
+    const int grade = (int)((rec.meta >> 24) & 7u);
+    const bool ectg = (rec.meta >> 27) & 1u;
+    const uint32_t pc = rec.pc;
+    const bool inr = in_range(X, v);
+    uint32_t stp = 0;
+    if (inr) stp = stamp_load(&X.stamp[v - X.C.in_lo]);
+    bool ok = !visited_global(X, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
+              (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
+    if (ok) ok = !(inr ? stp == STAMP_TRAVEL : hs_has(X.tset_o, X.tmask_o, v)) && (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
+    if (ok && level == 2)
+        ok = !(inr ? stp == X.gen : gs_has(X.pset_o, X.pmask_o, v, X.gen)) && (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
+    if (!ok) return -1;
+    const bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
+    if (leap) {
+        // landing rule (PAlgorithm.tcc:60-67): singleToDual (PositionMapper.cpp:44-64) on the start table
+        uint32_t lo2 = 0, hi2 = X.C.n_ctgs + 1;
+        while (lo2 < hi2) {  // upper_bound(starts, pc)
+            uint32_t mid = (lo2 + hi2) >> 1;
+            if (X.C.starts[mid] <= (uint64_t)pc) lo2 = mid + 1;
+            else hi2 = mid;
+        }
+        uint32_t idx = lo2 ? lo2 - 1 : 0;
+        uint64_t off = (uint64_t)pc - X.C.starts[idx];
+        uint64_t sz = idx < X.C.n_ctgs ? X.C.sizes[idx] : 0;
+        if (off >= 2 * sz) off -= 2 * sz;
+        if ((double)(int64_t)off > (double)sz * X.C.leap_min) return -1;
+        if (!can_leap) return -1;
+    }
+    if (grade == G_AMAZING || leap) return 0;
+    if (grade == G_EXCELLENT) return 1;
+    if (grade == G_GOOD) return 2;
+    if (can_leap && grade == G_SKIP) return 3;
+    return -1;
+}
+
+// classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
+// level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
+// Returns the size n of the chosen class.  n == 1: the successor is returned in *one_v/*one_s/*one_pc and
+// nothing touches LDS (the common case of a straight walk).  n > 1: the chosen class is in
+// L.lst_v/lst_s[0] in reference order.
+__device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap, int level, uint32_t *one_v, uint32_t *one_s,
+                             uint32_t *one_pc) {
     const uint32_t lane = lane_id();
     const uint32_t r0 = X.G.succ_off[cur], r1 = X.G.succ_off[cur + 1];
+    X.n_classify += 1;
+    X.n_records += r1 - r0;
+    if (r1 - r0 <= 64) {
+        int cls = -1;
+        SuccRec rec{0, 0, 0};
+        if (r0 + lane < r1) {
+            rec = X.G.succ[r0 + lane];
+            cls = eval_record(X, rec, can_leap, level);
+        }
+        uint64_t m = __ballot(cls == 0);
+        if (!m) m = __ballot(cls == 1);
+        if (!m) m = __ballot(cls == 2);
+        if (!m) m = __ballot(cls == 3);
+        uint32_t n = (uint32_t)__popcll(m);
+        if (n == 0) return 0;
+        if (n == 1) {
+            int src = __ffsll((long long)m) - 1;
+            *one_v = __shfl(rec.tgt, src, 64);
+            *one_s = __shfl(rec.meta & 0xFFFFFFu, src, 64);
+            *one_pc = __shfl(rec.pc, src, 64);
+            return 1;
+        }
+        __syncthreads();
+        if ((m >> lane) & 1ull) {
+            uint32_t at = (uint32_t)__popcll(m & lanemask_lt());
+            L.lst_v[0][at] = rec.tgt;
+            L.lst_s[0][at] = rec.meta & 0xFFFFFFu;
+        }
+        __syncthreads();
+        return n;
+    }
+    // more than 64 successor records (repeats): chunked, all four class lists kept in LDS
     __syncthreads();
     if (lane < 4) L.lst_n[lane] = 0;
     __syncthreads();
     for (uint32_t rb = r0; rb < r1; rb += 64) {
         int cls = -1;
-        uint32_t v = 0, step = 0;
+        SuccRec rec{0, 0, 0};
         if (rb + lane < r1) {
-            const SuccRec rec = X.G.succ[rb + lane];
-            v = rec.tgt;
-            step = rec.meta & 0xFFFFFFu;
-            const int grade = (int)((rec.meta >> 24) & 7u);
-            const bool ectg = (rec.meta >> 27) & 1u;
-            const uint32_t pc = rec.pc;
-            const bool inr = in_range(X, v);
-            uint32_t stp = 0;
-            if (inr) stp = stamp_load(&X.stamp[v - X.C.in_lo]);
-            bool ok = !visited_global(X, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
-                      (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
-            if (ok) ok = !(inr ? stp == STAMP_TRAVEL : hs_has(X.tset_o, X.tmask_o, v)) &&
-                         (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
-            if (ok && level == 2)
-                ok = !(inr ? stp == X.gen : gs_has(X.pset_o, X.pmask_o, v, X.gen)) &&
-                     (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
-            if (ok) {
-                bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
-                if (leap) {
-                    // landing rule (PAlgorithm.tcc:60-67): singleToDual (PositionMapper.cpp:44-64) on the start table
-                    uint32_t lo2 = 0, hi2 = X.C.n_ctgs + 1;
-                    while (lo2 < hi2) {  // upper_bound(starts, pc)
-                        uint32_t mid = (lo2 + hi2) >> 1;
-                        if (X.C.starts[mid] <= (uint64_t)pc) lo2 = mid + 1;
-                        else hi2 = mid;
-                    }
-                    uint32_t idx = lo2 ? lo2 - 1 : 0;
-                    uint64_t off = (uint64_t)pc - X.C.starts[idx];
-                    uint64_t sz = idx < X.C.n_ctgs ? X.C.sizes[idx] : 0;
-                    if (off >= 2 * sz) off -= 2 * sz;
-                    if ((double)(int64_t)off > (double)sz * X.C.leap_min) ok = false;
-                    if (!can_leap) ok = false;
-                }
-                if (ok) {
-                    if (grade == G_AMAZING || leap) cls = 0;
-                    else if (grade == G_EXCELLENT) cls = 1;
-                    else if (grade == G_GOOD) cls = 2;
-                    else if (can_leap && grade == G_SKIP) cls = 3;
-                }
-            }
+            rec = X.G.succ[rb + lane];
+            cls = eval_record(X, rec, can_leap, level);
         }
         for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
             uint64_t m = __ballot(cls == c);
@@ -371,8 +412,8 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap
             if (cls == c) {
                 uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt());
                 if (at < LIST_CAP) {
-                    L.lst_v[c][at] = v;
-                    L.lst_s[c][at] = step;
+                    L.lst_v[c][at] = rec.tgt;
+                    L.lst_s[c][at] = rec.meta & 0xFFFFFFu;
                 }
             }
             __syncthreads();
@@ -394,7 +435,32 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap
         }
     }
     __syncthreads();
+    if (n == 1) {
+        *one_v = L.lst_v[0][0];
+        *one_s = L.lst_s[0][0];
+        *one_pc = (uint32_t)(X.G.upos[*one_v] >> 32);
+    }
     return n;
+}
+
+// Lanes are mostly idle while a walk advances one vertex at a time, so they pull the next stretch of the
+// coordinate-ordered arrays (offsets, records, stamps) towards the L2 ahead of the walk: ids
+// [X.pf_hi, X.pf_hi + 1024), 16 per lane.  The loaded values only feed a dummy accumulator.
+__device__ __forceinline__ void lookahead(WalkCtx &X, uint32_t cur) {
+    if (cur + 256u <= X.pf_hi || cur < X.C.in_lo || cur >= X.C.in_hi) return;
+    uint32_t base = cur > X.pf_hi ? cur : X.pf_hi;
+    uint32_t id = base + lane_id() * 16u;
+    uint32_t acc = 0;
+    if (id < X.C.in_hi) {
+        uint32_t o = X.G.succ_off[id];
+        uint32_t id2 = id + 16u < (uint32_t)X.G.n_pos ? id + 16u : (uint32_t)X.G.n_pos;
+        uint32_t o2 = X.G.succ_off[id2];
+        acc ^= stamp_load(&X.stamp[id - X.C.in_lo]);
+        if (o2 - o > 512u) o2 = o + 512u;  // a repeat region: do not chase it
+        for (uint32_t r = o; r < o2; r += 5u) acc ^= X.G.succ[r].tgt;  // one touch per 60 bytes
+    }
+    X.pf_acc ^= acc;
+    X.pf_hi = base + 1024u;
 }
 
 // mark a vertex in walkStraight's uniqueTable (one lane)
@@ -413,6 +479,7 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
                              uint64_t cap, uint64_t *out_len) {
     const uint32_t lane = lane_id();
     X.gen += 1;
+    X.n_probe += 1;
     X.win_p0 = 0xFFFFFFFFu;
     X.win_p1 = 0;
     uint64_t now_size = s0, len = 0;
@@ -439,7 +506,9 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
     uint32_t cur = v0;
     int status;
     for (;;) {
-        uint32_t m = classify(L, X, cur, (has_size + now_size) >= X.C.split_size, 2);
+        lookahead(X, cur);
+        uint32_t v = 0, s = 0, vc = 0;
+        uint32_t m = classify(L, X, cur, (has_size + now_size) >= X.C.split_size, 2, &v, &s, &vc);
         if (m == 0) {
             status = WS_END;
             break;
@@ -448,14 +517,13 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
             status = WS_BRANCH;
             break;
         }
-        uint32_t v = L.lst_v[0][0], s = L.lst_s[0][0];
-        __syncthreads();
         if (len >= cap || (uint64_t)(out_used + 1) * 2 > (uint64_t)X.pmask_o) {
             X.overflow = 1;
             status = WS_END;
             break;
         }
-        uint32_t vc = (uint32_t)(X.G.upos[v] >> 32);
+        // same-wave stores and later loads of one address stay ordered in the memory pipeline, so the
+        // mark needs no wait before the next step's stamp loads
         if (lane == 0) {
             probe_mark(X, v);
             pv[len] = v;
@@ -465,13 +533,13 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
         win_add(X.win_p0, X.win_p1, vc);
         len += 1;
         now_size += s;
-        __syncthreads();
         if (vc != 0 && (vc < X.C.ctg_left || vc >= X.C.ctg_right)) {
             status = WS_LEAP;
             break;
         }
         cur = v;
     }
+    __syncthreads();  // the path written by lane 0 is read by all lanes afterwards
     *out_len = len;
     return status;
 }
@@ -499,6 +567,9 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     X.win_t0 = 0xFFFFFFFFu;
     X.win_t1 = 0;
     X.overflow = 0;
+    X.pf_hi = 0;
+    X.pf_acc = 0;
+    X.n_classify = X.n_probe = X.n_records = 0;
 
     uint64_t seq_len = 0, now_size = k, seq_size = 0;
     const uint64_t has_size = J.has_size;
@@ -562,8 +633,17 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         const uint32_t lc = (uint32_t)(G.upos[last] >> 32);
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
 
-        uint32_t m = classify(L, X, last, (has_size + now_size) >= X.C.split_size, 1);
+        uint32_t one_v = 0, one_s = 0, one_pc = 0;
+        uint32_t m = classify(L, X, last, (has_size + now_size) >= X.C.split_size, 1, &one_v, &one_s, &one_pc);
         if (m == 0) break;
+        if (m == 1) {  // the single-successor fast path bypasses the LDS list
+            __syncthreads();
+            if (lane == 0) {
+                L.lst_v[0][0] = one_v;
+                L.lst_s[0][0] = one_s;
+            }
+            __syncthreads();
+        }
         if (m > BR_CAP) {
             X.overflow = 1;
             m = BR_CAP;
@@ -623,7 +703,10 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         TravJobOut o;
         o.seq_len = seq_len;
         o.seq_size = seq_size;
-        o.overflow = X.overflow;
+        o.overflow = X.overflow | (X.pf_acc == 0x9E3779B9u && seq_len == 0xFFFFFFFFFFull ? 2 : 0);
+        o.n_classify = X.n_classify;
+        o.n_probe = X.n_probe;
+        o.n_records = X.n_records;
         o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;
         outs[jid] = o;
     }

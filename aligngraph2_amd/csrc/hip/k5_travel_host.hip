@@ -378,7 +378,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
     }
 
-    uint64_t rounds = 0, jobs_total = 0, steps_total = 0;
+    uint64_t rounds = 0, jobs_total = 0, steps_total = 0, classify_total = 0, probe_total = 0, record_total = 0;
     double t_walk = 0;
     uint32_t grow = 1;
     for (;;) {
@@ -459,7 +459,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             jobs_total -= jr.size();
             continue;  // redo the round with larger buffers
         }
-        for (auto &o : outs) steps_total += o.seq_len;
+        for (auto &o : outs) {
+            steps_total += o.seq_len;
+            classify_total += o.n_classify;
+            probe_total += o.n_probe;
+            record_total += o.n_records;
+        }
 
         // ---- per contig: choose, splice, stop rules (PAlgorithm.cpp:238-330)
         std::vector<TravSeedReq> reqs;
@@ -648,6 +653,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         stats->rounds = rounds;
         stats->jobs = jobs_total;
         stats->walk_steps = steps_total;
+        stats->classify_calls = classify_total;
+        stats->probes = probe_total;
+        stats->records = record_total;
     }
     return PAG_OK;
 }

@@ -71,6 +71,7 @@ struct TravJob {
 
 struct TravJobOut {
     uint64_t seq_len, seq_size;
+    uint64_t n_classify, n_probe, n_records;
     uint32_t last_ctg;
     int overflow;
 };

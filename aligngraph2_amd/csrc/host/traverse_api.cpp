@@ -71,9 +71,10 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
             pag_travel_stats tst{};
             int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
             if (std::getenv("PAGRAPH_TIMING"))
-                std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu\n", tst.ms_total,
+                std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
                              tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
-                             (unsigned long long)tst.walk_steps);
+                             (unsigned long long)tst.walk_steps, (unsigned long long)tst.classify_calls, (unsigned long long)tst.probes,
+                             (unsigned long long)tst.records);
             if (rc != PAG_OK) {
                 setErr("pag_travel: %s", pag_last_error());
                 return rc;

@@ -207,6 +207,7 @@ typedef struct pag_travel_params {
 typedef struct pag_travel_stats {
     double ms_compact, ms_walk, ms_total; /* device + host wall, ms */
     uint64_t rounds, jobs, walk_steps;
+    uint64_t classify_calls, probes, records; /* successor evaluations, walkStraight calls, records read */
 } pag_travel_stats;
 
 /* ctgs: HOST memory (2-bit packed); orient[i]: 1 traverse forward, 0 reverse, -1 not selected.
