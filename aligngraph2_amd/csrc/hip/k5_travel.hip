@@ -234,7 +234,10 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                     SuccRec r;
                     r.tgt = G.newid[p];
                     r.pc = pc;
-                    r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+                    const uint32_t t0 = G.succ_off[r.tgt], t1 = G.succ_off[r.tgt + 1];
+                    const uint32_t tc = t1 - t0 < 15u ? t1 - t0 : 15u;  // 15 = "15 or more: look the range up"
+                    r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27) | (tc << 28);
+                    r.toff = t0;
                     G.succ[out + n] = r;
                 }
                 ++n;
@@ -359,17 +362,27 @@ __device__ __forceinline__ int eval_record(const WalkCtx &X, const SuccRec &rec,
 // Returns the size n of the chosen class.  n == 1: the successor is returned in *one_v/*one_s/*one_pc and
 // nothing touches LDS (the common case of a straight walk).  n > 1: the chosen class is in
 // L.lst_v/lst_s[0] in reference order.
-__device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap, int level, uint32_t *one_v, uint32_t *one_s,
-                             uint32_t *one_pc) {
+// The single survivor of a classification and, speculatively, its own only successor record
+struct Step {
+    uint32_t v, s, pc;   // vertex (new id), step, contig coordinate
+    uint32_t off, cnt;   // its successor records [off, off + cnt); cnt == 15 means "15 or more"
+    bool have_next;      // cnt == 1 and `next` already holds that record (loaded while the stamps were in flight)
+    SuccRec next;
+};
+
+__device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
+                             int level, Step *one) {
     const uint32_t lane = lane_id();
-    const uint32_t r0 = X.G.succ_off[cur], r1 = X.G.succ_off[cur + 1];
+    const uint32_t r1 = r0 + cnt;
     X.n_classify += 1;
-    X.n_records += r1 - r0;
-    if (r1 - r0 <= 64) {
+    X.n_records += cnt;
+    if (cnt <= 64) {
         int cls = -1;
-        SuccRec rec{0, 0, 0};
-        if (r0 + lane < r1) {
-            rec = X.G.succ[r0 + lane];
+        SuccRec rec{0, 0, 0, 0}, nx{0, 0, 0, 0};
+        if (lane < cnt) {
+            rec = have_pre ? pre : X.G.succ[r0 + lane];
+            // speculative: the target's only successor record, requested together with the stamp
+            if ((rec.meta >> 28) == 1u) nx = X.G.succ[rec.toff];
             cls = eval_record(X, rec, can_leap, level);
         }
         uint64_t m = __ballot(cls == 0);
@@ -380,9 +393,17 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap
         if (n == 0) return 0;
         if (n == 1) {
             int src = __ffsll((long long)m) - 1;
-            *one_v = __shfl(rec.tgt, src, 64);
-            *one_s = __shfl(rec.meta & 0xFFFFFFu, src, 64);
-            *one_pc = __shfl(rec.pc, src, 64);
+            uint32_t meta = __shfl(rec.meta, src, 64);
+            one->v = __shfl(rec.tgt, src, 64);
+            one->s = meta & 0xFFFFFFu;
+            one->pc = __shfl(rec.pc, src, 64);
+            one->off = __shfl(rec.toff, src, 64);
+            one->cnt = meta >> 28;
+            one->have_next = one->cnt == 1u;
+            one->next.tgt = __shfl(nx.tgt, src, 64);
+            one->next.pc = __shfl(nx.pc, src, 64);
+            one->next.meta = __shfl(nx.meta, src, 64);
+            one->next.toff = __shfl(nx.toff, src, 64);
             return 1;
         }
         __syncthreads();
@@ -400,7 +421,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap
     __syncthreads();
     for (uint32_t rb = r0; rb < r1; rb += 64) {
         int cls = -1;
-        SuccRec rec{0, 0, 0};
+        SuccRec rec{0, 0, 0, 0};
         if (rb + lane < r1) {
             rec = X.G.succ[rb + lane];
             cls = eval_record(X, rec, can_leap, level);
@@ -436,9 +457,13 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t cur, bool can_leap
     }
     __syncthreads();
     if (n == 1) {
-        *one_v = L.lst_v[0][0];
-        *one_s = L.lst_s[0][0];
-        *one_pc = (uint32_t)(X.G.upos[*one_v] >> 32);
+        one->v = L.lst_v[0][0];
+        one->s = L.lst_s[0][0];
+        one->pc = (uint32_t)(X.G.upos[one->v] >> 32);
+        one->off = X.G.succ_off[one->v];
+        uint32_t c2 = X.G.succ_off[one->v + 1] - one->off;
+        one->cnt = c2 < 15u ? c2 : 15u;
+        one->have_next = false;
     }
     return n;
 }
@@ -504,11 +529,14 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
     if (!in_range(X, v0)) ++out_used;
     __syncthreads();
     uint32_t cur = v0;
+    uint32_t off = X.G.succ_off[v0], cnt = X.G.succ_off[v0 + 1] - off;
+    bool have_pre = false;
+    SuccRec pre{0, 0, 0, 0};
     int status;
     for (;;) {
         lookahead(X, cur);
-        uint32_t v = 0, s = 0, vc = 0;
-        uint32_t m = classify(L, X, cur, (has_size + now_size) >= X.C.split_size, 2, &v, &s, &vc);
+        Step st;
+        uint32_t m = classify(L, X, off, cnt, have_pre, pre, (has_size + now_size) >= X.C.split_size, 2, &st);
         if (m == 0) {
             status = WS_END;
             break;
@@ -525,19 +553,28 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
         // same-wave stores and later loads of one address stay ordered in the memory pipeline, so the
         // mark needs no wait before the next step's stamp loads
         if (lane == 0) {
-            probe_mark(X, v);
-            pv[len] = v;
-            ps[len] = s;
+            probe_mark(X, st.v);
+            pv[len] = st.v;
+            ps[len] = st.s;
         }
-        if (!in_range(X, v)) ++out_used;
-        win_add(X.win_p0, X.win_p1, vc);
+        if (!in_range(X, st.v)) ++out_used;
+        win_add(X.win_p0, X.win_p1, st.pc);
         len += 1;
-        now_size += s;
-        if (vc != 0 && (vc < X.C.ctg_left || vc >= X.C.ctg_right)) {
+        now_size += st.s;
+        if (st.pc != 0 && (st.pc < X.C.ctg_left || st.pc >= X.C.ctg_right)) {
             status = WS_LEAP;
             break;
         }
-        cur = v;
+        cur = st.v;
+        off = st.off;
+        cnt = st.cnt;
+        have_pre = st.have_next;
+        pre = st.next;
+        if (cnt == 15u) {  // "15 or more": take the exact range from the offset table
+            off = X.G.succ_off[cur];
+            cnt = X.G.succ_off[cur + 1] - off;
+            have_pre = false;
+        }
     }
     __syncthreads();  // the path written by lane 0 is read by all lanes afterwards
     *out_len = len;
@@ -633,14 +670,16 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         const uint32_t lc = (uint32_t)(G.upos[last] >> 32);
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
 
-        uint32_t one_v = 0, one_s = 0, one_pc = 0;
-        uint32_t m = classify(L, X, last, (has_size + now_size) >= X.C.split_size, 1, &one_v, &one_s, &one_pc);
+        Step one;
+        const uint32_t l_off = G.succ_off[last];
+        const SuccRec none{0, 0, 0, 0};
+        uint32_t m = classify(L, X, l_off, G.succ_off[last + 1] - l_off, false, none, (has_size + now_size) >= X.C.split_size, 1, &one);
         if (m == 0) break;
         if (m == 1) {  // the single-successor fast path bypasses the LDS list
             __syncthreads();
             if (lane == 0) {
-                L.lst_v[0][0] = one_v;
-                L.lst_s[0][0] = one_s;
+                L.lst_v[0][0] = one.v;
+                L.lst_s[0][0] = one.s;
             }
             __syncthreads();
         }

@@ -34,7 +34,8 @@ struct TravGraph {
 struct SuccRec {
     uint32_t tgt;   // new id
     uint32_t pc;    // contig coordinate of the target
-    uint32_t meta;  // step (24 bits) | grade << 24 | isEdgeSimilar().first << 27
+    uint32_t meta;  // step (24 bits) | grade << 24 | isEdgeSimilar().first << 27 | min(#successors of tgt, 15) << 28
+    uint32_t toff;  // first successor record of the target (so a walk never has to read the offset table)
 };
 
 struct TravContig {
