@@ -137,12 +137,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        dist = dist_mod
+    from aligngraph2_amd import parallel
+    dist = parallel.init("nccl")  # RCCL; only the barrier and two 8-byte all-reduces use it
 
     import biggen
     hip, host = load_libs()
@@ -195,13 +191,7 @@ def main():
         trav_ms.append(ts.ms_total)
     sync()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
-    bases = torch.tensor([float(w.n_bases)], dtype=torch.float64, device=f"cuda:{local}")
-    if dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(bases, op=dist.ReduceOp.SUM)
-    dt_max = float(tt.item())
-    total_bases = float(bases.item())
+    dt_max, total_bases = parallel.aggregate(dist, dt, float(w.n_bases), device=f"cuda:{local}")
 
     if rank == 0:
         ms_sort = float(np.mean(sort_ms))
@@ -239,7 +229,8 @@ def main():
                 "sharding": "one reference-sequence block per GPU, no data-path collective",
                 "ms_build_device": float(np.mean(build_ms)),
                 "ms_extract": st.ms_extract, "ms_sort": st.ms_sort, "ms_cluster": st.ms_cluster, "ms_edges": st.ms_edges,
-                "ms_traverse_host": float(np.mean(trav_ms)), "ms_export": ts.ms_export,
+                "ms_traverse_total": float(np.mean(trav_ms)), "ms_traverse_device_walk": ts.ms_export,
+                "ms_traverse_host_epilogue": ts.ms_traverse,
                 "build_only_bases_per_s": w.n_bases / (float(np.mean(build_ms)) * 1e-3),
                 "path_bases": int(ts.n_path_bases), "chains": int(ts.n_chains_emitted),
             },
