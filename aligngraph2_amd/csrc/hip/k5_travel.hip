@@ -269,6 +269,7 @@ __global__ void k_ranges(TravGraph G, TravContig *ctgs, uint32_t n) {
 // =================================================================================================
 constexpr int LIST_CAP = 256;  // successors of one vertex kept per class
 constexpr int BR_CAP = 256;    // branch fan-out kept per graphTravel round
+constexpr int PROBE_GROUPS = 4;  // alternatives of a branch probed side by side, 16 lanes each
 #define STAMP_TRAVEL 0xFFFFFFFFu
 
 struct WalkLds {
@@ -281,10 +282,12 @@ struct WalkCtx {
     TravGraph G;
     TravContig C;
     // visited state of this job: stamps for vertices on the contig strand, small hash sets for the rest
-    uint32_t *stamp;   // [in_hi - in_lo]: 0 unvisited, STAMP_TRAVEL = travelUniqueTable, else walkStraight generation
+    uint32_t *stamp;   // walkStraight uniqueTable marks: PROBE_GROUPS arrays of [in_hi - in_lo] generation stamps
+    uint32_t stamp_stride;
+    uint32_t *tbits;   // travelUniqueTable over [in_lo, in_hi): one bit per vertex
     uint32_t *tset_o;  // travelUniqueTable, vertices outside the strand's id range
     uint32_t tmask_o;
-    uint64_t *pset_o;  // walkStraight uniqueTable, outside the range
+    uint64_t *pset_o;  // walkStraight uniqueTable, outside the range: PROBE_GROUPS tables of pmask_o + 1 entries
     uint32_t pmask_o;
     uint32_t n_out;    // entries in the outside sets (load-factor guard)
     uint32_t gen;
@@ -293,7 +296,7 @@ struct WalkCtx {
     uint32_t win_p0, win_p1;  // walkStraight's ctgPosTable
     uint32_t pf_hi;   // ids below this have been pulled towards the L2 (lookahead)
     uint32_t pf_acc;  // keeps the lookahead loads alive
-    uint64_t n_classify, n_probe, n_records;  // work counters
+    uint32_t n_classify, n_probe, n_records;  // work counters
     int overflow;
 };
 
@@ -320,19 +323,24 @@ __device__ __forceinline__ bool visited_global(const WalkCtx &X, uint32_t u) {
 // level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
 // Result: L.lst_v/lst_s[0] hold the chosen class in reference order, return = its size.
 // per-lane evaluation of one successor record: class 0 Amazing/leap, 1 Excellent, 2 Good, 3 Skip, -1 rejected
-__device__ __forceinline__ int eval_record(const WalkCtx &X, const SuccRec &rec, bool can_leap, int level) {
+__device__ __forceinline__ int eval_record(const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
+                                           const uint32_t *pstamp, const uint64_t *pset) {
     const uint32_t v = rec.tgt;
     const int grade = (int)((rec.meta >> 24) & 7u);
     const bool ectg = (rec.meta >> 27) & 1u;
     const uint32_t pc = rec.pc;
     const bool inr = in_range(X, v);
-    uint32_t stp = 0;
-    if (inr) stp = stamp_load(&X.stamp[v - X.C.in_lo]);
+    uint32_t stp = 0, tw = 0;
+    if (inr) {
+        const uint32_t d = v - X.C.in_lo;
+        tw = stamp_load(&X.tbits[d >> 5]) >> (d & 31u);
+        if (level == 2) stp = stamp_load(&pstamp[d]);
+    }
     bool ok = !visited_global(X, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
               (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
-    if (ok) ok = !(inr ? stp == STAMP_TRAVEL : hs_has(X.tset_o, X.tmask_o, v)) && (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
+    if (ok) ok = !(inr ? (tw & 1u) != 0 : hs_has(X.tset_o, X.tmask_o, v)) && (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
     if (ok && level == 2)
-        ok = !(inr ? stp == X.gen : gs_has(X.pset_o, X.pmask_o, v, X.gen)) && (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
+        ok = !(inr ? stp == X.gen : gs_has(pset, X.pmask_o, v, X.gen)) && (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
     if (!ok) return -1;
     const bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
     if (leap) {
@@ -383,7 +391,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
             rec = have_pre ? pre : X.G.succ[r0 + lane];
             // speculative: the target's only successor record, requested together with the stamp
             if ((rec.meta >> 28) == 1u) nx = X.G.succ[rec.toff];
-            cls = eval_record(X, rec, can_leap, level);
+            cls = eval_record(X, rec, can_leap, level, X.stamp, X.pset_o);
         }
         uint64_t m = __ballot(cls == 0);
         if (!m) m = __ballot(cls == 1);
@@ -424,7 +432,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
         SuccRec rec{0, 0, 0, 0};
         if (rb + lane < r1) {
             rec = X.G.succ[rb + lane];
-            cls = eval_record(X, rec, can_leap, level);
+            cls = eval_record(X, rec, can_leap, level, X.stamp, X.pset_o);
         }
         for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
             uint64_t m = __ballot(cls == c);
@@ -480,9 +488,13 @@ __device__ __forceinline__ void lookahead(WalkCtx &X, uint32_t cur) {
         uint32_t o = X.G.succ_off[id];
         uint32_t id2 = id + 16u < (uint32_t)X.G.n_pos ? id + 16u : (uint32_t)X.G.n_pos;
         uint32_t o2 = X.G.succ_off[id2];
-        acc ^= stamp_load(&X.stamp[id - X.C.in_lo]);
+        const uint32_t d = id - X.C.in_lo;
+#pragma unroll
+        for (int g = 0; g < PROBE_GROUPS; ++g) acc ^= stamp_load(&X.stamp[(uint64_t)g * X.stamp_stride + d]);
+        acc ^= stamp_load(&X.tbits[d >> 5]);
+        if (X.C.gbits) acc ^= X.C.gbits[d >> 5];
         if (o2 - o > 512u) o2 = o + 512u;  // a repeat region: do not chase it
-        for (uint32_t r = o; r < o2; r += 5u) acc ^= X.G.succ[r].tgt;  // one touch per 60 bytes
+        for (uint32_t r = o; r < o2; r += 4u) acc ^= X.G.succ[r].tgt;  // one touch per 64 bytes
     }
     X.pf_acc ^= acc;
     X.pf_hi = base + 1024u;
@@ -491,7 +503,7 @@ __device__ __forceinline__ void lookahead(WalkCtx &X, uint32_t cur) {
 // mark a vertex in walkStraight's uniqueTable (one lane)
 __device__ __forceinline__ void probe_mark(WalkCtx &X, uint32_t u) {
     if (in_range(X, u)) {
-        stamp_store(&X.stamp[u - X.C.in_lo], X.gen);
+        stamp_store(&X.stamp[u - X.C.in_lo], X.gen);  // group 0 arrays serve the sequential mode
     } else {
         gs_insert_single(X.pset_o, X.pmask_o, u, X.gen);
     }
@@ -581,6 +593,132 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
     return status;
 }
 
+// Up to PROBE_GROUPS alternatives of one branch probed SIDE BY SIDE: lanes 16g .. 16g+15 run the
+// walkStraight of alternative g (its own generation stamps, window, arena region); the instruction stream
+// of a step is shared, so the serial cost of a branch is the LONGEST probe instead of the sum of all
+// probes (three quarters of all successor evaluations are probes that end up not being chosen).
+// Returns false if some vertex has more than 16 successor records (caller falls back to sequential probing).
+__device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, const uint32_t *alt_s, uint64_t has_size,
+                            uint32_t *arena_v, uint32_t *arena_s, uint64_t cap_each, int *status_out, uint32_t *len_out) {
+    const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
+    const bool active = g < n_alt;
+    X.gen += 1;
+    X.n_probe += n_alt;
+    uint32_t *pstamp = X.stamp + (uint64_t)g * X.stamp_stride;
+    uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
+    uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
+    uint32_t wp0 = 0xFFFFFFFFu, wp1 = 0;
+    uint32_t len = 0, out_used = 0, off = 0, cnt = 0, cur_v = 0;
+    uint64_t now_size = 0;
+    int status = -1;  // running
+    if (cap_each == 0) {
+        X.overflow = 1;
+        *status_out = WS_END;
+        *len_out = 0;
+        return true;
+    }
+    if (active) {
+        const uint32_t v0 = alt_v[g], s0 = alt_s[g];
+        cur_v = v0;
+        now_size = s0;
+        len = 1;
+        if (sub == 0) {
+            pv[0] = v0;
+            ps[0] = s0;
+        }
+        const uint32_t c = (uint32_t)(X.G.upos[v0] >> 32);
+        if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
+            status = WS_LEAP;
+        } else {
+            win_add(wp0, wp1, c);
+            if (sub == 0) {
+                if (in_range(X, v0)) stamp_store(&pstamp[v0 - X.C.in_lo], X.gen);
+                else gs_insert_single(pset, X.pmask_o, v0, X.gen);
+            }
+            if (!in_range(X, v0)) ++out_used;
+            off = X.G.succ_off[v0];
+            cnt = X.G.succ_off[v0 + 1] - off;
+        }
+    } else {
+        status = WS_END;
+    }
+    bool wide = false;
+    for (;;) {
+        const bool running = status < 0;
+        if (__ballot(running && cnt > 16u)) {
+            wide = true;
+            break;
+        }
+        if (!__ballot(running)) break;
+        lookahead(X, __shfl(cur_v, 0, 64));
+        X.n_classify += 1;
+        int cls = -1;
+        SuccRec rec{0, 0, 0, 0};
+        const bool can_leap = (has_size + now_size) >= X.C.split_size;
+        if (running && sub < cnt) {
+            rec = X.G.succ[off + sub];
+            // the probe-level tests use this group's window and stamps
+            const uint32_t sg0 = X.win_p0, sg1 = X.win_p1;
+            X.win_p0 = wp0;
+            X.win_p1 = wp1;
+            cls = eval_record(X, rec, can_leap, 2, pstamp, pset);
+            X.win_p0 = sg0;
+            X.win_p1 = sg1;
+        }
+        uint32_t cm = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint64_t bm = __ballot(cls == c);
+            uint32_t gm = (uint32_t)(bm >> (16u * g)) & 0xFFFFu;
+            if (cm == 0) cm = gm;
+        }
+        const uint32_t n = (uint32_t)__popc(cm);
+        const int src = (int)(16u * g) + (cm ? __ffs(cm) - 1 : 0);
+        const uint32_t meta = __shfl(rec.meta, src, 64);
+        const uint32_t nv = __shfl(rec.tgt, src, 64);
+        const uint32_t npc = __shfl(rec.pc, src, 64);
+        const uint32_t noff = __shfl(rec.toff, src, 64);
+        if (running) {
+            if (n == 0) {
+                status = WS_END;
+            } else if (n > 1) {
+                status = WS_BRANCH;
+            } else if (len >= cap_each || (uint64_t)(out_used + 1) * 2 > (uint64_t)X.pmask_o) {
+                X.overflow = 1;
+                status = WS_END;
+            } else {
+                const uint32_t ns = meta & 0xFFFFFFu;
+                if (sub == 0) {
+                    if (in_range(X, nv)) stamp_store(&pstamp[nv - X.C.in_lo], X.gen);
+                    else gs_insert_single(pset, X.pmask_o, nv, X.gen);
+                    pv[len] = nv;
+                    ps[len] = ns;
+                }
+                if (!in_range(X, nv)) ++out_used;
+                win_add(wp0, wp1, npc);
+                len += 1;
+                now_size += ns;
+                if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
+                    status = WS_LEAP;
+                } else {
+                    cur_v = nv;
+                    off = noff;
+                    cnt = meta >> 28;
+                    if (cnt == 15u) {
+                        off = X.G.succ_off[nv];
+                        cnt = X.G.succ_off[nv + 1] - off;
+                    }
+                }
+            }
+        }
+    }
+    X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
+    __syncthreads();  // paths written by the group leaders are read by all lanes afterwards
+    *status_out = status;
+    *len_out = len;
+    return !wide;
+}
+
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
 __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__restrict__ ctgs, const TravJob *__restrict__ jobs,
                                              TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k) {
@@ -593,6 +731,8 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     X.G = G;
     X.C = ctgs[J.ctg];
     X.stamp = J.stamp;
+    X.stamp_stride = J.stamp_stride;
+    X.tbits = J.tbits;
     X.tset_o = J.tset;
     X.tmask_o = J.tmask;
     X.pset_o = J.pset;
@@ -630,7 +770,7 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
             J.seq_v[seq_len + i] = v;
             J.seq_s[seq_len + i] = s;
             if (in_range(X, v)) {
-                stamp_store(&X.stamp[v - X.C.in_lo], STAMP_TRAVEL);
+                atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
             } else {
                 hs_insert(X.tset_o, X.tmask_o, v);
                 ++n_outside;
@@ -693,38 +833,55 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         }
         __syncthreads();
 
-        // probe every alternative (PAlgorithm.tcc:251-266), paths laid out back to back in the arena
-        uint64_t used = 0;
+        // probe every alternative (PAlgorithm.tcc:251-266): PROBE_GROUPS at a time side by side, each in
+        // its own quarter of the arena; sequential full-wave probing only when a vertex is too wide
         int first_leap = -1, best_branch = -1, best_tip = -1;
         uint32_t best_ab = 0;
         uint64_t best_tip_len = 0, leap_off = 0, leap_len = 0, br_off = 0, br_len = 0, tip_off = 0;
-        for (uint32_t i = 0; i < m; ++i) {
-            uint32_t sv = L.br_v[i], ss = L.br_s[i];
-            uint64_t l2 = 0;
-            int stt = walk_straight(L, X, sv, ss, has_size + now_size, J.arena_v + used, J.arena_s + used, J.arena_cap - used, &l2);
+        auto account = [&](uint32_t i, int stt, uint64_t l2, uint64_t at) {
             if (stt == WS_LEAP) {
                 if (first_leap < 0) {
                     first_leap = (int)i;
-                    leap_off = used;
+                    leap_off = at;
                     leap_len = l2;
                 }
             } else if (stt == WS_END) {
                 if (best_tip < 0 || l2 > best_tip_len) {
                     best_tip = (int)i;
                     best_tip_len = l2;
-                    tip_off = used;
+                    tip_off = at;
                 }
             } else {
-                uint32_t ab = G.vcnt[G.uold[sv]];
+                uint32_t ab = G.vcnt[G.uold[L.br_v[i]]];
                 if (best_branch < 0 || ab > best_ab) {
                     best_branch = (int)i;
                     best_ab = ab;
-                    br_off = used;
+                    br_off = at;
                     br_len = l2;
                 }
             }
-            used += l2;
-            if (X.overflow) break;
+        };
+        bool multi_ok = m <= PROBE_GROUPS;  // larger fan-outs would need several arena generations: sequential
+        if (multi_ok) {
+            const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
+            int stt;
+            uint32_t l2;
+            multi_ok = probe_multi(X, m, L.br_v, L.br_s, has_size + now_size, J.arena_v, J.arena_s, cap_each, &stt, &l2);
+            if (multi_ok) {
+                for (uint32_t i = 0; i < m; ++i)
+                    account(i, __shfl(stt, (int)(16u * i), 64), (uint64_t)__shfl(l2, (int)(16u * i), 64), (uint64_t)i * cap_each);
+            }
+        }
+        if (!multi_ok) {
+            uint64_t used = 0;
+            for (uint32_t i = 0; i < m; ++i) {
+                uint64_t l2 = 0;
+                int stt = walk_straight(L, X, L.br_v[i], L.br_s[i], has_size + now_size, J.arena_v + used, J.arena_s + used,
+                                        J.arena_cap - used, &l2);
+                account(i, stt, l2, used);
+                used += l2;
+                if (X.overflow) break;
+            }
         }
         if (X.overflow) break;
         if (first_leap >= 0) {
@@ -743,7 +900,7 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         o.seq_len = seq_len;
         o.seq_size = seq_size;
         o.overflow = X.overflow | (X.pf_acc == 0x9E3779B9u && seq_len == 0xFFFFFFFFFFull ? 2 : 0);
-        o.n_classify = X.n_classify;
+        o.n_classify = __shfl(X.n_classify, 0, 64);
         o.n_probe = X.n_probe;
         o.n_records = X.n_records;
         o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;

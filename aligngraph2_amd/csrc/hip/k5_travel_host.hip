@@ -268,7 +268,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     DevBuf b_packed = buf(), b_nodes = buf(), b_starts = buf(), b_sizes = buf(), b_tc = buf(), b_seedout = buf(), b_req = buf(),
            b_jobs = buf(), b_outs = buf(), b_seqv = buf(), b_seqs = buf(), b_arv = buf(), b_ars = buf(), b_tset = buf(),
-           b_pset = buf(), b_gset = buf(), b_gather = buf(), b_vids = buf(), b_stamp = buf(), b_gbits = buf();
+           b_pset = buf(), b_gset = buf(), b_gather = buf(), b_vids = buf(), b_stamp = buf(), b_gbits = buf(), b_tbits = buf();
     if ((rc = b_packed.alloc(ctgs->packed_bytes + 64)) || (rc = b_nodes.alloc((nodes_total + 1) * 4)) ||
         (rc = b_starts.alloc(mapper.starts.size() * 8 + 8)) || (rc = b_sizes.alloc(mapper.sizes.size() * 8 + 8)) ||
         (rc = b_tc.alloc(n_sel * sizeof(TravContig))))
@@ -394,8 +394,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         ++rounds;
         jobs_total += jr.size();
         std::vector<TravJob> jobs(jr.size());
-        uint64_t tot_seq = 0, tot_arena = 0, tot_t = 0, tot_p = 0, tot_stamp = 0;
-        std::vector<uint64_t> o_seq(jr.size()), o_ar(jr.size()), o_t(jr.size()), o_p(jr.size()), o_st(jr.size());
+        uint64_t tot_seq = 0, tot_arena = 0, tot_t = 0, tot_p = 0, tot_stamp = 0, tot_tb = 0;
+        std::vector<uint64_t> o_seq(jr.size()), o_ar(jr.size()), o_t(jr.size()), o_p(jr.size()), o_st(jr.size()), o_tb(jr.size());
         auto out_cap = [&](const CtgState &cs) { return pow2_at_least((cs.seqCap / 4 + 4096) * grow); };
         for (size_t j = 0; j < jr.size(); ++j) {
             const CtgState &cs = st[jr[j].cs];
@@ -405,20 +405,23 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             o_t[j] = tot_t;
             o_p[j] = tot_p;
             o_st[j] = tot_stamp;
+            o_tb[j] = tot_tb;
             tot_seq += cap;
-            tot_arena += 2 * cap;
+            tot_arena += 4 * cap;
             tot_t += out_cap(cs);
-            tot_p += out_cap(cs);
-            tot_stamp += (uint64_t)(cs.inHi - cs.inLo) + 1;
+            tot_p += 4 * out_cap(cs);
+            tot_stamp += 4 * ((uint64_t)(cs.inHi - cs.inLo) + 1);
+            tot_tb += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
         }
         if ((rc = b_seqv.alloc(tot_seq * 4)) || (rc = b_seqs.alloc(tot_seq * 4)) || (rc = b_arv.alloc(tot_arena * 4)) ||
             (rc = b_ars.alloc(tot_arena * 4)) || (rc = b_tset.alloc(tot_t * 4)) || (rc = b_pset.alloc(tot_p * 8)) ||
-            (rc = b_stamp.alloc(tot_stamp * 4)) || (rc = b_jobs.alloc(jobs.size() * sizeof(TravJob))) ||
+            (rc = b_stamp.alloc(tot_stamp * 4)) || (rc = b_tbits.alloc(tot_tb * 4)) || (rc = b_jobs.alloc(jobs.size() * sizeof(TravJob))) ||
             (rc = b_outs.alloc(jobs.size() * sizeof(TravJobOut))))
             return rc;
         PAG_HIP_TRY(hipMemsetAsync(b_tset.p, 0xFF, tot_t * 4, s));
         PAG_HIP_TRY(hipMemsetAsync(b_pset.p, 0, tot_p * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_stamp.p, 0, tot_stamp * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_tbits.p, 0, tot_tb * 4, s));
         for (size_t j = 0; j < jr.size(); ++j) {
             CtgState &cs = st[jr[j].cs];
             uint64_t cap = cs.seqCap * grow;
@@ -431,8 +434,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.seq_cap = cap;
             J.arena_v = b_arv.as<uint32_t>() + o_ar[j];
             J.arena_s = b_ars.as<uint32_t>() + o_ar[j];
-            J.arena_cap = 2 * cap;
+            J.arena_cap = 4 * cap;
             J.stamp = b_stamp.as<uint32_t>() + o_st[j];
+            J.stamp_stride = (uint32_t)(cs.inHi - cs.inLo) + 1;
+            J.tbits = b_tbits.as<uint32_t>() + o_tb[j];
             J.tset = b_tset.as<uint32_t>() + o_t[j];
             J.tmask = (uint32_t)out_cap(cs) - 1;
             J.pset = b_pset.as<uint64_t>() + o_p[j];

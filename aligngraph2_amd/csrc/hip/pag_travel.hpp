@@ -63,7 +63,9 @@ struct TravJob {
     uint64_t seq_cap;
     uint32_t *arena_v, *arena_s;
     uint64_t arena_cap;
-    uint32_t *stamp;  // [in_hi - in_lo] zeroed: visit stamps of the strand's vertices
+    uint32_t *stamp;  // zeroed: 4 arrays of [stamp_stride] generation stamps (walkStraight marks, one array per probe group)
+    uint32_t stamp_stride;
+    uint32_t *tbits;  // zeroed: travel-visited bitmap over the strand's vertices
     uint32_t *tset;   // hash sets for vertices outside the strand's id range
     uint32_t tmask;
     uint64_t *pset;
