@@ -16,16 +16,16 @@
 
 namespace pagdev {
 
-constexpr int ST = 256;           // threads per block
+constexpr int ST = 512;           // threads per block
 constexpr int SW = ST / 64;       // waves per block
-constexpr int SROUNDS = 16;       // records per thread
+constexpr int SROUNDS = 8;        // records per thread
 constexpr int STILE = ST * SROUNDS;
 constexpr int SMAXR = 256;        // max radix (8 bits)
 
 __global__ __launch_bounds__(ST) void sort_hist(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t rmask,
                                                uint32_t *__restrict__ hist, uint32_t n_tiles) {
     __shared__ uint32_t h[SMAXR];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < SMAXR) h[threadIdx.x] = 0;
     __syncthreads();
     uint64_t base = (uint64_t)blockIdx.x * STILE;
 #pragma unroll
@@ -38,8 +38,7 @@ __global__ __launch_bounds__(ST) void sort_hist(const uint32_t *__restrict__ key
 }
 
 struct ScatterLds {
-    uint32_t wcnt[SW][SMAXR];   // per-wave running digit counters
-    uint32_t woff[SW][SMAXR];   // exclusive prefix of the wave counters over waves
+    uint32_t wcnt[SW][SMAXR];   // per-wave running digit counters, then their exclusive prefix over waves
     uint32_t dstart[SMAXR];     // exclusive prefix of the tile's digit totals over digits
     uint64_t gbase[SMAXR];      // output base of (digit, this tile)
     uint32_t skey[STILE];
@@ -74,37 +73,38 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
             peers &= ((d >> b) & 1u) ? vote : ~vote;
         }
         uint32_t before = __popcll(peers & lanemask_lt());
+        // per-wave counters: the read (all lanes) and the leader's write are LDS operations of ONE wave,
+        // which the LDS executes in program order — no barrier needed between rounds
         uint32_t base = valid ? L.wcnt[w][d] : 0u;
-        __syncthreads();  // all lanes have read the counter before the group leader bumps it
         if (valid && before == 0) L.wcnt[w][d] = base + (uint32_t)__popcll(peers);
-        __syncthreads();
         rk[r] = base + before;
     }
 
+    __syncthreads();
     // per digit: prefix over waves, tile totals, prefix over digits, global base
-    {
-        uint32_t d = threadIdx.x;  // ST == SMAXR
+    if (threadIdx.x < SMAXR) {
+        uint32_t d = threadIdx.x;
         uint32_t run = 0;
 #pragma unroll
         for (int ww = 0; ww < SW; ++ww) {
-            L.woff[ww][d] = run;
-            run += L.wcnt[ww][d];
+            uint32_t c = L.wcnt[ww][d];
+            L.wcnt[ww][d] = run;
+            run += c;
         }
         uint64_t tot;
         // block exclusive scan of `run` over the 256 digits
         uint64_t wtot;
         uint64_t ex = wave_excl_sum64(run, &wtot);
         if (lane == 63) L.red[w] = wtot;
-        __syncthreads();
-        uint64_t pre = 0;
-        tot = 0;
-        for (int i = 0; i < SW; ++i) {
-            if (i < (int)w) pre += L.red[i];
-            tot += L.red[i];
-        }
-        L.dstart[d] = (uint32_t)(ex + pre);
+        L.dstart[d] = (uint32_t)ex;  // completed with the preceding waves' totals below
         L.gbase[d] = d <= rmask ? hist_scan[(uint64_t)d * n_tiles + blockIdx.x] : 0;
         (void)tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < SMAXR) {
+        uint32_t pre = 0;
+        for (int i = 0; i < (int)w; ++i) pre += (uint32_t)L.red[i];  // waves 0..3 hold the 256 digits
+        L.dstart[threadIdx.x] += pre;
     }
     __syncthreads();
 
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
         uint64_t i = wave_base + (uint64_t)r * 64 + lane;
         if (i < n) {
             uint32_t d = (key[r] >> shift) & rmask;
-            uint32_t p = L.dstart[d] + L.woff[w][d] + rk[r];
+            uint32_t p = L.dstart[d] + L.wcnt[w][d] + rk[r];
             L.skey[p] = key[r];
             L.sval[p] = vals[i];
         }

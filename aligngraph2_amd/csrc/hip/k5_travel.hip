@@ -308,7 +308,10 @@ __device__ __forceinline__ void win_add(uint32_t &lo, uint32_t &hi, uint32_t p) 
 }
 __device__ __forceinline__ bool in_range(const WalkCtx &X, uint32_t u) { return u >= X.C.in_lo && u < X.C.in_hi; }
 __device__ __forceinline__ uint32_t stamp_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stamp_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Stamps are private to one wavefront.  The store is a plain (workgroup-scope) write-through store, which
+// KEEPS the line in the XCD's L2 — an agent-scope (sc1) store would drop it and send the next stamp load
+// of the neighbouring vertex to memory; the loads stay L2-served (sc1) so they never read a stale L1 line.
+__device__ __forceinline__ void stamp_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 __device__ __forceinline__ bool visited_global(const WalkCtx &X, uint32_t u) {
     if (in_range(X, u)) {

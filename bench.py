@@ -179,13 +179,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    first = None
+
+    def check_repeatable():
+        # idempotence: every step must reproduce the same graph (counts, sizes, path checksum)
+        nonlocal first
+        sig = (st.counts(), st.n_nodes, st.n_pos, st.n_uniq_edges, ts.n_path_nodes, ts.path_checksum)
+        if first is None:
+            first = sig
+        elif sig != first:
+            raise SystemExit(f"non-repeatable result: {sig} vs {first}")
+
     for _ in range(args.warmup):
         step()
+        check_repeatable()
     sync()
     t0 = time.perf_counter()
     sort_ms, build_ms, trav_ms = [], [], []
     for _ in range(args.steps):
         step()
+        check_repeatable()
         sort_ms.append(st.ms_sort_kernel)
         build_ms.append(st.ms_total)
         trav_ms.append(ts.ms_total)
