@@ -58,62 +58,89 @@ __device__ __forceinline__ void block_flush3(uint64_t a, uint64_t b, uint64_t c,
 }
 
 // ------------------------------------------------------------------------------------------------ K3
-__global__ __launch_bounds__(256) void cluster_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
-                                                    uint64_t n, uint32_t eps, ClusterOut out,
-                                                    uint64_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
-    // grid-stride over the stream; counters are accumulated per thread and flushed once per block
-    // (one same-address atomic costs ~12 ns: a per-wave flush would serialise into tens of ms)
+// Tiles of 256 consecutive records (+ a look-ahead halo of SHORT_MAX) are staged through LDS with coalesced
+// loads; the per-segment greedy scans then run on LDS copies (a head thread's chain of dependent reads costs
+// ~64 cycles each instead of an HBM/L2 round trip each), and only the leaders go back to HBM.
+constexpr int SEG_TILE = 256;
+struct SegLds {
+    uint32_t key[SEG_TILE + SHORT_MAX + 1];  // key[0] = record before the tile
+    uint64_t val[SEG_TILE + SHORT_MAX];
+    uint16_t cnt[SEG_TILE + SHORT_MAX];
+};
+
+__global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
+                                                         uint64_t n, uint32_t eps, ClusterOut out,
+                                                         uint64_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
+    __shared__ SegLds S;
     uint64_t n_ctg = 0, n_all = 0, n_seg = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t kx = key[i];
-        bool head = i == 0 || key[i - 1] != kx;
-        uint32_t seglen = 0;
-        if (head) {
-            uint64_t j = i + 1;
-            while (j < n && j - i <= SHORT_MAX && key[j] == kx) ++j;
-            uint64_t len = j - i;
-            n_seg += 1;
-            if (len > SHORT_MAX) {
-                uint32_t slot = atomicAdd(long_count, 1u);
-                long_list[slot] = i;
-                seglen = 0xFFFFFFFFu;  // filled in by cluster_long
-            } else {
-                uint32_t p = 0;
-                for (uint64_t it = i; it < j; ++it) {
-                    uint64_t item = val[it];
-                    bool hit = false;
-                    for (uint32_t l = 0; l < p; ++l) {
-                        if (pos_sim(item, val[i + l], eps)) {
-                            out.cnt[i + l] = (uint16_t)(out.cnt[i + l] + 1);
-                            hit = true;
-                            break;
+    const uint32_t t = threadIdx.x;
+    const uint64_t n_tiles = (n + SEG_TILE - 1) / SEG_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t base = tile * SEG_TILE;
+        __syncthreads();
+        for (uint32_t x = t; x < SEG_TILE + SHORT_MAX; x += SEG_TILE) {
+            uint64_t gi = base + x;
+            S.key[x + 1] = gi < n ? key[gi] : 0xFFFFFFFFu;
+            S.val[x] = gi < n ? val[gi] : 0;
+        }
+        if (t == 0) S.key[0] = base ? key[base - 1] : 0xFFFFFFFFu;
+        __syncthreads();
+        const uint64_t i = base + t;
+        if (i < n) {
+            const uint32_t kx = S.key[t + 1];
+            const bool head = i == 0 || S.key[t] != kx;
+            uint32_t seglen = 0;
+            if (head) {
+                uint32_t len = 1;
+                while (len <= SHORT_MAX && i + len < n && S.key[t + 1 + len] == kx) ++len;
+                n_seg += 1;
+                if (len > SHORT_MAX) {
+                    uint32_t slot = atomicAdd(long_count, 1u);
+                    long_list[slot] = i;
+                    seglen = 0xFFFFFFFFu;  // filled in by cluster_long
+                } else {
+                    uint32_t p = 0;
+                    for (uint32_t it = 0; it < len; ++it) {
+                        const uint64_t item = S.val[t + it];
+                        bool hit = false;
+                        for (uint32_t l = 0; l < p; ++l) {
+                            if (pos_sim(item, S.val[t + l], eps)) {
+                                S.cnt[t + l] = (uint16_t)(S.cnt[t + l] + 1);
+                                hit = true;
+                                break;
+                            }
+                        }
+                        if (!hit) {
+                            S.val[t + p] = item;
+                            S.cnt[t + p] = 1;
+                            ++p;
                         }
                     }
-                    if (!hit) {
-                        val[i + p] = item;
-                        out.cnt[i + p] = 1;
-                        ++p;
+                    // sortWithCount: insertion sort by position (distinct keys)
+                    for (uint32_t a = 1; a < p; ++a) {
+                        const uint64_t v = S.val[t + a];
+                        const uint16_t c = S.cnt[t + a];
+                        uint32_t b2 = a;
+                        while (b2 > 0 && S.val[t + b2 - 1] > v) {
+                            S.val[t + b2] = S.val[t + b2 - 1];
+                            S.cnt[t + b2] = S.cnt[t + b2 - 1];
+                            --b2;
+                        }
+                        S.val[t + b2] = v;
+                        S.cnt[t + b2] = c;
                     }
-                }
-                // sortWithCount: insertion sort by position (distinct keys)
-                for (uint32_t a = 1; a < p; ++a) {
-                    uint64_t v = val[i + a];
-                    uint16_t c = out.cnt[i + a];
-                    uint32_t b = a;
-                    while (b > 0 && val[i + b - 1] > v) {
-                        val[i + b] = val[i + b - 1];
-                        out.cnt[i + b] = out.cnt[i + b - 1];
-                        --b;
+                    for (uint32_t l = 0; l < p; ++l) {
+                        const uint64_t v = S.val[t + l];
+                        val[i + l] = v;
+                        out.cnt[i + l] = S.cnt[t + l];
+                        n_ctg += (v >> 32) != 0;
                     }
-                    val[i + b] = v;
-                    out.cnt[i + b] = c;
+                    seglen = p;
+                    n_all += p;
                 }
-                seglen = p;
-                n_all += p;
-                for (uint32_t l = 0; l < p; ++l) n_ctg += (val[i + l] >> 32) != 0;
             }
+            out.seg_len[i] = seglen;
         }
-        out.seg_len[i] = seglen;
     }
     block_flush3(n_ctg, n_all, n_seg, out.counters);
 }
@@ -201,8 +228,8 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-    cluster_short<<<dim3(grid), dim3(256), 0, s>>>(key, val, n, eps, out, long_list, long_count);
+    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_TILE - 1) / SEG_TILE, 256 * 32);
+    cluster_short<<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, eps, out, long_list, long_count);
     // scratch: u64[n] followed by u32[n] (the idle sort ping-pong buffers)
     cluster_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, (uint32_t *)(scratch + n), n, eps, out,
                                                  long_list, long_count);
@@ -211,46 +238,62 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
 }
 
 // ------------------------------------------------------------------------------------------------ K4
-__global__ __launch_bounds__(256) void edges_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
-                                                  uint64_t n, EdgeOut out, uint64_t *__restrict__ long_list,
-                                                  uint32_t *__restrict__ long_count) {
+__global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
+                                                       uint64_t n, EdgeOut out, uint64_t *__restrict__ long_list,
+                                                       uint32_t *__restrict__ long_count) {
+    __shared__ SegLds S;
     uint64_t n_grp = 0, n_grp1 = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t kx = key[i];
-        bool head = i == 0 || key[i - 1] != kx;
-        uint32_t seglen = 0;
-        if (head) {
-            uint64_t j = i + 1;
-            while (j < n && j - i <= SHORT_MAX && key[j] == kx) ++j;
-            uint64_t len = j - i;
-            if (len > SHORT_MAX) {
-                uint32_t slot = atomicAdd(long_count, 1u);
-                long_list[slot] = i;
-                seglen = 0xFFFFFFFFu;
-            } else {
-                for (uint32_t a = 1; a < len; ++a) {
-                    uint64_t v = val[i + a];
-                    uint32_t b = a;
-                    while (b > 0 && val[i + b - 1] > v) {
-                        val[i + b] = val[i + b - 1];
-                        --b;
-                    }
-                    val[i + b] = v;
-                }
-                uint32_t p = 0;
-                for (uint32_t a = 0; a < len; ++a) {
-                    uint64_t v = val[i + a];
-                    if (p == 0 || (val[i + p - 1] >> 1) != (v >> 1)) {
-                        val[i + p] = v;
-                        ++p;
-                        n_grp1 += (v & 1ull) == 0;
-                    }
-                }
-                seglen = p;
-                n_grp += p;
-            }
+    const uint32_t t = threadIdx.x;
+    const uint64_t n_tiles = (n + SEG_TILE - 1) / SEG_TILE;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t base = tile * SEG_TILE;
+        __syncthreads();
+        for (uint32_t x = t; x < SEG_TILE + SHORT_MAX; x += SEG_TILE) {
+            uint64_t gi = base + x;
+            S.key[x + 1] = gi < n ? key[gi] : 0xFFFFFFFFu;
+            S.val[x] = gi < n ? val[gi] : 0;
         }
-        out.seg_len[i] = seglen;
+        if (t == 0) S.key[0] = base ? key[base - 1] : 0xFFFFFFFFu;
+        __syncthreads();
+        const uint64_t i = base + t;
+        if (i < n) {
+            const uint32_t kx = S.key[t + 1];
+            const bool head = i == 0 || S.key[t] != kx;
+            uint32_t seglen = 0;
+            if (head) {
+                uint32_t len = 1;
+                while (len <= SHORT_MAX && i + len < n && S.key[t + 1 + len] == kx) ++len;
+                if (len > SHORT_MAX) {
+                    uint32_t slot = atomicAdd(long_count, 1u);
+                    long_list[slot] = i;
+                    seglen = 0xFFFFFFFFu;
+                } else {
+                    for (uint32_t a = 1; a < len; ++a) {
+                        const uint64_t v = S.val[t + a];
+                        uint32_t b2 = a;
+                        while (b2 > 0 && S.val[t + b2 - 1] > v) {
+                            S.val[t + b2] = S.val[t + b2 - 1];
+                            --b2;
+                        }
+                        S.val[t + b2] = v;
+                    }
+                    uint32_t p = 0;
+                    uint64_t prev = 0;
+                    for (uint32_t a = 0; a < len; ++a) {
+                        const uint64_t v = S.val[t + a];
+                        if (p == 0 || (prev >> 1) != (v >> 1)) {
+                            val[i + p] = v;
+                            prev = v;
+                            ++p;
+                            n_grp1 += (v & 1ull) == 0;
+                        }
+                    }
+                    seglen = p;
+                    n_grp += p;
+                }
+            }
+            out.seg_len[i] = seglen;
+        }
     }
     block_flush3(n_grp, n_grp1, 0, out.counters);
 }
@@ -295,8 +338,8 @@ int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-    edges_short<<<dim3(grid), dim3(256), 0, s>>>(key, val, n, out, long_list, long_count);
+    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_TILE - 1) / SEG_TILE, 256 * 32);
+    edges_short<<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, out, long_list, long_count);
     edges_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, n, out, long_list, long_count);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;

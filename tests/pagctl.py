@@ -65,6 +65,11 @@ def hip_lib():
     if "hip" not in _libs:
         if not os.path.exists(HIP_LIB):
             raise RuntimeError(f"{HIP_LIB} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If
+        # our library were loaded first it would pull in the system runtime and a later `import torch` would
+        # mix it with torch's HSA ("no ROCm-capable device").  Loading torch first makes both share torch's.
+        import torch
+        torch.cuda.is_available()
         lib = C.CDLL(HIP_LIB)
         _bind(lib, "pag")
         lib.pag_create.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
