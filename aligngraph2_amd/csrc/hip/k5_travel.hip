@@ -611,7 +611,7 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
     uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
     uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
     uint32_t wp0 = 0xFFFFFFFFu, wp1 = 0;
-    uint32_t len = 0, out_used = 0, off = 0, cnt = 0, cur_v = 0;
+    uint32_t len = 0, out_used = 0, off = 0, cnt = 0, cur_v = 0, pb_v = 0, pb_s = 0;
     uint64_t now_size = 0;
     int status = -1;  // running
     if (cap_each == 0) {
@@ -625,9 +625,9 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
         cur_v = v0;
         now_size = s0;
         len = 1;
-        if (sub == 0) {
-            pv[0] = v0;
-            ps[0] = s0;
+        if (sub == 0) {  // path entries wait in registers, 16 per group, and leave in one coalesced store
+            pb_v = v0;
+            pb_s = s0;
         }
         const uint32_t c = (uint32_t)(X.G.upos[v0] >> 32);
         if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
@@ -694,13 +694,19 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
                 if (sub == 0) {
                     if (in_range(X, nv)) stamp_store(&pstamp[nv - X.C.in_lo], X.gen);
                     else gs_insert_single(pset, X.pmask_o, nv, X.gen);
-                    pv[len] = nv;
-                    ps[len] = ns;
+                }
+                if (sub == (len & 15u)) {
+                    pb_v = nv;
+                    pb_s = ns;
                 }
                 if (!in_range(X, nv)) ++out_used;
                 win_add(wp0, wp1, npc);
                 len += 1;
                 now_size += ns;
+                if ((len & 15u) == 0) {  // 16 entries pending: one 64-byte store per array
+                    pv[len - 16u + sub] = pb_v;
+                    ps[len - 16u + sub] = pb_s;
+                }
                 if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
                     status = WS_LEAP;
                 } else {
@@ -715,8 +721,12 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
             }
         }
     }
+    if (active && sub < (len & 15u)) {  // the entries still waiting in registers
+        pv[len - (len & 15u) + sub] = pb_v;
+        ps[len - (len & 15u) + sub] = pb_s;
+    }
     X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
-    __syncthreads();  // paths written by the group leaders are read by all lanes afterwards
+    __syncthreads();  // paths written by the groups are read by all lanes afterwards
     *status_out = status;
     *len_out = len;
     return !wide;
