@@ -141,6 +141,94 @@ __device__ __forceinline__ void walk_alignment(const pag_aln &al, const uint32_t
     }
 }
 
+// k-mer codes of the 16 positions p0 .. p0+15 of one read strand (kmer2Code / reverse strand of
+// CompressedSeq): a 64-bit window of the 2-bit packed read, 2-bit-group reversal for the forward strand
+// (first base most significant), complement for the reverse strand.
+__device__ __forceinline__ void lane_codes(const uint32_t *__restrict__ words, uint32_t strand, uint32_t len, uint32_t k,
+                                           uint32_t kmask, uint32_t p0, uint32_t n_mine, uint32_t (&code)[16]) {
+    uint64_t W = 0;
+    uint32_t sh0 = 0;  // reverse strand: window bit offset of position j is 2*(15 - j) + sh0
+    if (n_mine) {      // lanes past the end of the strand must not touch memory
+        if (strand == 0) {
+            uint32_t w0 = p0 >> 4;
+            W = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
+        } else {
+            int64_t a0 = (int64_t)len - (int64_t)k - (int64_t)p0 - 15;
+            uint32_t a1 = a0 > 0 ? (uint32_t)a0 : 0u;
+            uint32_t w = a1 >> 4, sh = (a1 & 15u) * 2u;
+            uint64_t lo64 = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
+            W = lo64 >> sh;
+            if (sh) W |= (uint64_t)words[w + 2] << (64 - sh);
+            sh0 = (uint32_t)((a0 - (int64_t)a1) * 2);  // <= 0 as a signed value; fine for valid j
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        uint32_t x;
+        if (strand == 0) {
+            x = (uint32_t)(W >> (2 * j)) & kmask;
+            code[j] = rev2(x) >> (32 - 2 * k);
+        } else {
+            uint32_t shj = (uint32_t)(2 * (15 - j)) + sh0;  // wraps harmlessly for invalid j
+            x = (uint32_t)(W >> (shj & 63u)) & kmask;
+            code[j] = (~x) & kmask;
+        }
+    }
+}
+
+// Solid-set membership of every k-mer start of every read strand that some alignment (of either pass)
+// touches: ONE random bitmap gather per read position for the whole build.  The four extraction launches
+// (count / emit x pass 1 / pass 2) then read a 16-bit mask per 16 positions instead of gathering again —
+// the gathers (a 64-byte line each from a 4^k-bit table that no L2 holds) were 98 % of their HBM traffic.
+__global__ __launch_bounds__(64) void solid_mask_kernel(ExtractArgs A, const pag_aln *__restrict__ aln2,
+                                                        const uint64_t *__restrict__ qoff2, uint16_t *__restrict__ mask) {
+    const uint32_t job = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const uint32_t r = A.emit_order[job >> 1];
+    const uint32_t strand = job & 1u;
+    const uint32_t len = A.read_len[r];
+    const uint32_t k = A.k;
+    if (len < k) return;
+    const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    const uint32_t *__restrict__ words = (const uint32_t *)(A.packed + A.read_off[r]);
+    const uint32_t n_pos = len - k + 1;
+    // union of the intervals any eligible alignment of this strand covers (both databases)
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    for (int db = 0; db < 2; ++db) {
+        const pag_aln *al = db == 0 ? A.aln : aln2;
+        const uint64_t *qo = db == 0 ? A.query_off : qoff2;
+        for (uint64_t ai = qo[r]; ai < qo[r + 1]; ++ai) {
+            pag_aln a = al[ai];
+            if (!(a.flags & PAG_ALN_ELIGIBLE) || a.q_start == PAG_NONE || a.n_valid == 0) continue;
+            if (((a.flags & PAG_ALN_REV_STRAND) ? 1u : 0u) != strand) continue;
+            lo = a.q_start < lo ? a.q_start : lo;
+            hi = a.q_start + a.n_valid > hi ? a.q_start + a.n_valid : hi;
+        }
+    }
+    if (hi > n_pos) hi = n_pos;
+    if (lo >= hi) return;
+    uint16_t *m = mask + 2ull * (A.read_off[r] >> 2) + strand;
+    for (uint32_t t0 = lo & ~(uint32_t)(TILE - 1); t0 < hi; t0 += TILE) {
+        const uint32_t p0 = t0 + lane * 16;
+        const uint32_t n_mine = p0 >= n_pos ? 0u : (n_pos - p0 > 16 ? 16u : n_pos - p0);
+        if (p0 + 16 <= lo || p0 >= hi || n_mine == 0) continue;
+        uint32_t code[16];
+        lane_codes(words, strand, len, k, kmask, p0, n_mine, code);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if ((uint32_t)j < n_mine) bits |= ((A.solid_bits[code[j] >> 5] >> (code[j] & 31u)) & 1u) << j;
+        m[2ull * (p0 >> 4)] = (uint16_t)bits;
+    }
+}
+
+int launch_solid_mask(const ExtractArgs &a, const pag_aln *aln2, const uint64_t *qoff2, uint16_t *mask, hipStream_t s) {
+    if (a.n_reads == 0) return PAG_OK;
+    solid_mask_kernel<<<dim3(2u * a.n_reads), dim3(64), 0, s>>>(a, aln2, qoff2, mask);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sampler automaton: state = min(S, positions since the last kept sample), S = "free".
 // A function state -> state is a packed table of 4-bit entries.
@@ -223,40 +311,12 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
         uint32_t code[16];
         uint32_t cand = 0;
         const uint32_t n_mine = p0 >= n_pos ? 0u : (n_pos - p0 > 16 ? 16u : n_pos - p0);
-        {
-            uint64_t W = 0;
-            uint32_t sh0 = 0;  // reverse strand: window bit offset of position j is 2*(15 - j) + sh0
-            if (n_mine) {      // lanes past the end of the strand must not touch memory
-                if (strand == 0) {
-                    uint32_t w0 = p0 >> 4;
-                    W = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
-                } else {
-                    int64_t a0 = (int64_t)len - (int64_t)k - (int64_t)p0 - 15;
-                    uint32_t a1 = a0 > 0 ? (uint32_t)a0 : 0u;
-                    uint32_t w = a1 >> 4, sh = (a1 & 15u) * 2u;
-                    uint64_t lo64 = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
-                    W = lo64 >> sh;
-                    if (sh) W |= (uint64_t)words[w + 2] << (64 - sh);
-                    sh0 = (uint32_t)((a0 - (int64_t)a1) * 2);  // <= 0 as a signed value; fine for valid j
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t x;
-                if (strand == 0) {
-                    x = (uint32_t)(W >> (2 * j)) & kmask;
-                    code[j] = rev2(x) >> (32 - 2 * k);
-                } else {
-                    uint32_t shj = (uint32_t)(2 * (15 - j)) + sh0;  // wraps harmlessly for invalid j
-                    x = (uint32_t)(W >> (shj & 63u)) & kmask;
-                    code[j] = (~x) & kmask;
-                }
-                if ((ne >> j) & 1u) {
-                    uint32_t solid = 1;
-                    if (!A.all_solid) solid = (A.solid_bits[code[j] >> 5] >> (code[j] & 31u)) & 1u;
-                    cand |= solid << j;
-                }
-            }
+        lane_codes(words, strand, len, k, kmask, p0, n_mine, code);
+        if (A.all_solid) {
+            cand = ne;
+        } else if (ne) {
+            // the solid bits of this strand were gathered once by solid_mask_kernel
+            cand = ne & (uint32_t)A.solid_mask[2ull * ((A.read_off[r] >> 2) + (p0 >> 4)) + strand];
         }
 
         // ---- C. greedy sampling as an associative scan of state-transition tables

@@ -299,6 +299,11 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     if ((rc = b_je.alloc((n_jobs + 1) * 4))) return rc;
     if ((rc = b_toff.alloc((n_jobs + 1) * 8))) return rc;
     if ((rc = b_eoff2.alloc((n_jobs + 1) * 8))) return rc;
+    DevBuf b_smask(g, 51);
+    if (!g->all_solid) {
+        // mask entries: 2 strands x one u16 per 16 bases (= per packed 32-bit word of the reads)
+        if ((rc = b_smask.alloc((in->reads.packed_bytes / 4 + 16) * 2 * sizeof(uint16_t)))) return rc;
+    }
     ExtractArgs xa[2];
     for (int pass = 0; pass < 2; ++pass) {
         ExtractArgs &a = xa[pass];
@@ -321,14 +326,17 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         a.ctg_ent = d_ent;
         a.refs = d_ref;
         a.solid_bits = g->solid_bits;
+        a.solid_mask = g->all_solid ? nullptr : b_smask.as<uint16_t>();
         a.all_solid = g->all_solid;
         a.k = g->k;
         a.outer = in->outer_sample;
         a.job_samples = b_js.as<uint32_t>();
         a.job_tuples = b_jt.as<uint32_t>();
         a.job_base = (uint32_t)(pass * 2ull * n_reads);
-        if ((rc = launch_extract(a, false, s))) return rc;
     }
+    if (!g->all_solid && (rc = launch_solid_mask(xa[0], d_aln2, d_q2, b_smask.as<uint16_t>(), s))) return rc;
+    for (int pass = 0; pass < 2; ++pass)
+        if ((rc = launch_extract(xa[pass], false, s))) return rc;
     uint64_t T = 0, E = 0, T1 = 0, E1 = 0;
     if (n_jobs) {
         edge_counts<<<dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, s>>>(b_js.as<uint32_t>(), n_jobs,
