@@ -51,8 +51,14 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 	$(CC) -O2 -std=c99 -Wall -Wextra -fPIC -Iinclude -c $< -o $@
 
 HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
-HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle
+HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle \
+           tests/harness/bin/seg_kernels_test
 harness: $(HARNESS)
+
+# kernel-level check of K3/K4 against a sequential restatement (needs a GPU to run)
+tests/harness/bin/seg_kernels_test: tests/harness/seg_kernels_test.hip $(HIP_DIR)/k34_segments.hip $(HIP_HDRS)
+	@mkdir -p tests/harness/bin
+	$(HIPCC) $(HIPFLAGS) -fno-PIC -o $@ $<
 
 tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
 	@mkdir -p tests/harness/bin

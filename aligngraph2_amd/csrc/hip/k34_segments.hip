@@ -16,9 +16,9 @@
 //      Payload = to << 32 | step << 1 | pass, so one numeric sort orders by (to, step, pass) and the
 //      head of every (to, step) group tells whether pass 1 already had that edge.
 //
-// Short segments (<= SHORT_MAX records): one thread per segment, sequential.  Long segments (repeats,
-// low-complexity k-mers) are queued and handled by one wavefront each: 64 leaders compared per step,
-// ballot -> first hit; rank sort through the idle sort ping-pong buffers.
+// Short segments (<= SHORT_MAX records): one thread per record, bit-mask formulation (see K3 below).  Long
+// segments (repeats, low-complexity k-mers) are queued and handled by one wavefront each: 64 leaders
+// compared per step, ballot -> first hit; rank sort through the idle sort ping-pong buffers.
 #include <algorithm>
 
 #include "pag_device.hpp"
@@ -58,15 +58,87 @@ __device__ __forceinline__ void block_flush3(uint64_t a, uint64_t b, uint64_t c,
 }
 
 // ------------------------------------------------------------------------------------------------ K3
-// Tiles of 256 consecutive records (+ a look-ahead halo of SHORT_MAX) are staged through LDS with coalesced
-// loads; the per-segment greedy scans then run on LDS copies (a head thread's chain of dependent reads costs
-// ~64 cycles each instead of an HBM/L2 round trip each), and only the leaders go back to HBM.
-constexpr int SEG_TILE = 256;
+// One thread per RECORD, not per segment.  A block stages SEG_OWN consecutive records plus a look-ahead
+// halo of SHORT_MAX through LDS with coalesced loads and owns the segments whose head lies in the first
+// SEG_OWN records.  Every record finds its offset `o` in its segment and the segment length by scanning
+// the staged keys, then the greedy scan is evaluated without any serial per-segment thread:
+//   M[x]  = bit j set iff record x is similar to the EARLIER record j of its segment     (o compares)
+//   L     = leader mask: record j is a leader iff M[j] & L == 0, folded for j = 0..len-1   (len steps)
+//   a non-leader adds 1 to leader ctz(M & L) — the first leader it is similar to, exactly the reference's
+//   scan order; a leader's output slot is its rank by (ctg, ref) among the leaders.
+// All lanes of a wave are busy and the trip counts are the segment length, instead of one lane in ~5
+// running length^2/2 dependent compares (the earlier layout was VALU-issue bound at 45 ms for the C2 set).
+constexpr int SEG_OWN = 480;
+constexpr int SEG_TILE = SEG_OWN + (int)SHORT_MAX;  // threads per block = staged records
 struct SegLds {
-    uint32_t key[SEG_TILE + SHORT_MAX + 1];  // key[0] = record before the tile
-    uint64_t val[SEG_TILE + SHORT_MAX];
-    uint16_t cnt[SEG_TILE + SHORT_MAX];
+    uint64_t flag[SEG_TILE / 64 + 1];  // bit x = record x starts a k-mer segment; word 8 covers record SEG_TILE
+    uint64_t val[SEG_TILE];
+    uint32_t m[SEG_TILE];
+    uint32_t cnt[SEG_TILE];
 };
+
+struct SegPos {
+    uint32_t o, s, len;
+    bool head;    // record is the head of a segment (any length) that starts inside the owned range
+    bool active;  // record belongs to a short segment owned by this tile
+    bool is_long; // head of a long segment
+};
+
+// Stage one tile: values into LDS, segment-start flags as one ballot word per wave.  A record that continues
+// the segment of the record before the tile gets no flag, so the leading part of a segment headed in the
+// previous tile has no start inside this tile and is left to that tile.
+__device__ __forceinline__ void seg_stage(SegLds &S, const uint32_t *__restrict__ key, const uint64_t *__restrict__ val,
+                                          uint64_t base, uint64_t n) {
+    const uint32_t t = threadIdx.x;
+    const uint64_t gi = base + t;
+    bool f = true;  // records past the end close the last segment
+    if (gi < n) {
+        f = gi == 0 || key[gi - 1] != key[gi];
+        S.val[t] = val[gi];
+    }
+    const uint64_t w = __ballot(f);
+    if ((t & 63u) == 0) S.flag[t >> 6] = w;
+    if (t == 0) {
+        const uint64_t ge = base + SEG_TILE;
+        const bool fe = ge >= n || key[ge - 1] != key[ge];
+        S.flag[SEG_TILE / 64] = ~1ull | (fe ? 1ull : 0ull);
+    }
+}
+
+// locate record x of the staged tile inside its k-mer segment: nearest start flag at or before x and the
+// next one after it, each at most two flag words away for a short segment
+__device__ __forceinline__ SegPos seg_locate(const SegLds &S, uint32_t x, uint64_t base, uint64_t n) {
+    SegPos r;
+    r.o = 0;
+    r.s = x;
+    r.len = 0;
+    r.head = r.active = r.is_long = false;
+    const uint32_t w = x >> 6, b = x & 63u;
+    const uint64_t cur = S.flag[w];
+    const uint64_t prev = w ? S.flag[w - 1] : 0ull;
+    const uint64_t next = S.flag[w + 1];
+    const uint64_t le = cur & (~0ull >> (63u - b));
+    uint32_t s = 0xFFFFFFFFu;
+    if (le)
+        s = w * 64u + 63u - (uint32_t)__builtin_clzll(le);
+    else if (prev)
+        s = (w - 1u) * 64u + 63u - (uint32_t)__builtin_clzll(prev);
+    const uint64_t gt = cur & (~1ull << b);
+    uint32_t e = 0xFFFFFFFFu;  // no start flag within reach: the segment is long
+    if (gt)
+        e = w * 64u + (uint32_t)__builtin_ctzll(gt);
+    else if (next)
+        e = (w + 1u) * 64u + (uint32_t)__builtin_ctzll(next);
+    if (base + x >= n || s == 0xFFFFFFFFu || s >= (uint32_t)SEG_OWN || x - s > SHORT_MAX) return r;
+    r.o = x - s;
+    r.s = s;
+    r.len = e == 0xFFFFFFFFu ? SHORT_MAX + 1 : e - s;
+    if (r.len > SHORT_MAX) r.len = SHORT_MAX + 1;
+    r.head = r.o == 0;
+    r.is_long = r.len > SHORT_MAX;
+    r.active = !r.is_long;
+    return r;
+}
 
 __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                          uint64_t n, uint32_t eps, ClusterOut out,
@@ -74,72 +146,55 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
     __shared__ SegLds S;
     uint64_t n_ctg = 0, n_all = 0, n_seg = 0;
     const uint32_t t = threadIdx.x;
-    const uint64_t n_tiles = (n + SEG_TILE - 1) / SEG_TILE;
+    const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t base = tile * SEG_TILE;
+        const uint64_t base = tile * SEG_OWN;
         __syncthreads();
-        for (uint32_t x = t; x < SEG_TILE + SHORT_MAX; x += SEG_TILE) {
-            uint64_t gi = base + x;
-            S.key[x + 1] = gi < n ? key[gi] : 0xFFFFFFFFu;
-            S.val[x] = gi < n ? val[gi] : 0;
+        seg_stage(S, key, val, base, n);
+        __syncthreads();
+        const SegPos P = seg_locate(S, t, base, n);
+        const uint64_t v = S.val[t];
+        uint32_t M = 0;
+        if (P.active) {
+            for (uint32_t j = 0; j < P.o; ++j) M |= (uint32_t)pos_sim(v, S.val[P.s + j], eps) << j;
         }
-        if (t == 0) S.key[0] = base ? key[base - 1] : 0xFFFFFFFFu;
+        S.m[t] = M;
+        S.cnt[t] = 1;
         __syncthreads();
-        const uint64_t i = base + t;
-        if (i < n) {
-            const uint32_t kx = S.key[t + 1];
-            const bool head = i == 0 || S.key[t] != kx;
+        uint32_t L = 0;
+        bool leader = false;
+        uint32_t rank = 0;
+        if (P.active) {
+            for (uint32_t j = 0; j < P.len; ++j) L |= (uint32_t)((S.m[P.s + j] & L) == 0) << j;
+            leader = (L >> P.o) & 1u;
+            if (!leader) {
+                atomicAdd(&S.cnt[P.s + (uint32_t)__builtin_ctz(M & L)], 1u);
+            } else {
+                // sortWithCount: slot = rank by (ctg, ref) among the leaders (distinct keys)
+                for (uint32_t j = 0; j < P.len; ++j) rank += ((L >> j) & 1u) && S.val[P.s + j] < v;
+            }
+        }
+        __syncthreads();
+        if (leader) {
+            const uint64_t dst = base + P.s + rank;
+            val[dst] = v;
+            out.cnt[dst] = (uint16_t)S.cnt[t];
+            n_ctg += (v >> 32) != 0;
+        }
+        if (t < (uint32_t)SEG_OWN && base + t < n) {
             uint32_t seglen = 0;
-            if (head) {
-                uint32_t len = 1;
-                while (len <= SHORT_MAX && i + len < n && S.key[t + 1 + len] == kx) ++len;
+            if (P.head) {
                 n_seg += 1;
-                if (len > SHORT_MAX) {
+                if (P.is_long) {
                     uint32_t slot = atomicAdd(long_count, 1u);
-                    long_list[slot] = i;
+                    long_list[slot] = base + t;
                     seglen = 0xFFFFFFFFu;  // filled in by cluster_long
                 } else {
-                    uint32_t p = 0;
-                    for (uint32_t it = 0; it < len; ++it) {
-                        const uint64_t item = S.val[t + it];
-                        bool hit = false;
-                        for (uint32_t l = 0; l < p; ++l) {
-                            if (pos_sim(item, S.val[t + l], eps)) {
-                                S.cnt[t + l] = (uint16_t)(S.cnt[t + l] + 1);
-                                hit = true;
-                                break;
-                            }
-                        }
-                        if (!hit) {
-                            S.val[t + p] = item;
-                            S.cnt[t + p] = 1;
-                            ++p;
-                        }
-                    }
-                    // sortWithCount: insertion sort by position (distinct keys)
-                    for (uint32_t a = 1; a < p; ++a) {
-                        const uint64_t v = S.val[t + a];
-                        const uint16_t c = S.cnt[t + a];
-                        uint32_t b2 = a;
-                        while (b2 > 0 && S.val[t + b2 - 1] > v) {
-                            S.val[t + b2] = S.val[t + b2 - 1];
-                            S.cnt[t + b2] = S.cnt[t + b2 - 1];
-                            --b2;
-                        }
-                        S.val[t + b2] = v;
-                        S.cnt[t + b2] = c;
-                    }
-                    for (uint32_t l = 0; l < p; ++l) {
-                        const uint64_t v = S.val[t + l];
-                        val[i + l] = v;
-                        out.cnt[i + l] = S.cnt[t + l];
-                        n_ctg += (v >> 32) != 0;
-                    }
-                    seglen = p;
-                    n_all += p;
+                    seglen = (uint32_t)__popc(L);
+                    n_all += seglen;
                 }
             }
-            out.seg_len[i] = seglen;
+            out.seg_len[base + t] = seglen;
         }
     }
     block_flush3(n_ctg, n_all, n_seg, out.counters);
@@ -228,7 +283,7 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_TILE - 1) / SEG_TILE, 256 * 32);
+    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_OWN - 1) / SEG_OWN, 256 * 16);
     cluster_short<<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, eps, out, long_list, long_count);
     // scratch: u64[n] followed by u32[n] (the idle sort ping-pong buffers)
     cluster_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, (uint32_t *)(scratch + n), n, eps, out,
@@ -238,61 +293,58 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
 }
 
 // ------------------------------------------------------------------------------------------------ K4
+// Same record-per-thread layout as cluster_short: a record survives iff it is the smallest (value, index) of its
+// (to, step) group, and its output slot is the number of surviving records with a smaller value.
 __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                        uint64_t n, EdgeOut out, uint64_t *__restrict__ long_list,
                                                        uint32_t *__restrict__ long_count) {
     __shared__ SegLds S;
     uint64_t n_grp = 0, n_grp1 = 0;
     const uint32_t t = threadIdx.x;
-    const uint64_t n_tiles = (n + SEG_TILE - 1) / SEG_TILE;
+    const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t base = tile * SEG_TILE;
+        const uint64_t base = tile * SEG_OWN;
         __syncthreads();
-        for (uint32_t x = t; x < SEG_TILE + SHORT_MAX; x += SEG_TILE) {
-            uint64_t gi = base + x;
-            S.key[x + 1] = gi < n ? key[gi] : 0xFFFFFFFFu;
-            S.val[x] = gi < n ? val[gi] : 0;
+        seg_stage(S, key, val, base, n);
+        __syncthreads();
+        const SegPos P = seg_locate(S, t, base, n);
+        const uint64_t v = S.val[t];
+        bool kept = false;
+        if (P.active) {
+            kept = true;
+            for (uint32_t j = 0; j < P.len; ++j) {
+                const uint64_t u = S.val[P.s + j];
+                kept = kept && !((u >> 1) == (v >> 1) && (u < v || (u == v && j < P.o)));
+            }
         }
-        if (t == 0) S.key[0] = base ? key[base - 1] : 0xFFFFFFFFu;
+        S.m[t] = kept;
         __syncthreads();
-        const uint64_t i = base + t;
-        if (i < n) {
-            const uint32_t kx = S.key[t + 1];
-            const bool head = i == 0 || S.key[t] != kx;
+        uint32_t p = 0;
+        if (P.active && (kept || P.head)) {
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < P.len; ++j) {
+                const bool kj = S.m[P.s + j] != 0;
+                p += kj;
+                rank += kj && S.val[P.s + j] < v;
+            }
+            if (kept) {
+                val[base + P.s + rank] = v;
+                n_grp1 += (v & 1ull) == 0;
+            }
+            if (P.head) n_grp += p;
+        }
+        if (t < (uint32_t)SEG_OWN && base + t < n) {
             uint32_t seglen = 0;
-            if (head) {
-                uint32_t len = 1;
-                while (len <= SHORT_MAX && i + len < n && S.key[t + 1 + len] == kx) ++len;
-                if (len > SHORT_MAX) {
+            if (P.head) {
+                if (P.is_long) {
                     uint32_t slot = atomicAdd(long_count, 1u);
-                    long_list[slot] = i;
+                    long_list[slot] = base + t;
                     seglen = 0xFFFFFFFFu;
                 } else {
-                    for (uint32_t a = 1; a < len; ++a) {
-                        const uint64_t v = S.val[t + a];
-                        uint32_t b2 = a;
-                        while (b2 > 0 && S.val[t + b2 - 1] > v) {
-                            S.val[t + b2] = S.val[t + b2 - 1];
-                            --b2;
-                        }
-                        S.val[t + b2] = v;
-                    }
-                    uint32_t p = 0;
-                    uint64_t prev = 0;
-                    for (uint32_t a = 0; a < len; ++a) {
-                        const uint64_t v = S.val[t + a];
-                        if (p == 0 || (prev >> 1) != (v >> 1)) {
-                            val[i + p] = v;
-                            prev = v;
-                            ++p;
-                            n_grp1 += (v & 1ull) == 0;
-                        }
-                    }
                     seglen = p;
-                    n_grp += p;
                 }
             }
-            out.seg_len[i] = seglen;
+            out.seg_len[base + t] = seglen;
         }
     }
     block_flush3(n_grp, n_grp1, 0, out.counters);
@@ -338,7 +390,7 @@ int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_TILE - 1) / SEG_TILE, 256 * 32);
+    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_OWN - 1) / SEG_OWN, 256 * 16);
     edges_short<<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, out, long_list, long_count);
     edges_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, n, out, long_list, long_count);
     PAG_HIP_TRY(hipGetLastError());

@@ -2,6 +2,8 @@
 
 Bit-exact (integer work): emitted tuple/edge streams in canonical order, the reference's six count
 lines, and the finished CSR (k-mer codes, clustered positions, u16 counts, unique edges)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -38,3 +40,14 @@ def test_build_matches_oracle(name, workdir):
         assert hip["stats"].n_pos > 0
     finally:
         inp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("segments,seed", [(2000, 1), (20000, 2), (300000, 3)])
+def test_segment_kernels_match_sequential_restatement(segments, seed):
+    """K3/K4 alone (short and long segments, tile halos) against a sequential greedy scan / sort-unique."""
+    import subprocess
+    exe = os.path.join(pagctl.ROOT, "tests", "harness", "bin", "seg_kernels_test")
+    assert os.path.exists(exe), "run `make harness`"
+    r = subprocess.run([exe, str(segments), str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
