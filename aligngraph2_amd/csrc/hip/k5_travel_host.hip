@@ -8,12 +8,15 @@
 // and prepares the next seeds (window scan on the device; ordering by edit distance with the same
 // unstable std::sort as the reference on the host).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -86,6 +89,45 @@ size_t edit_distance(const std::string &a, const std::string &b) {
     return dp[flag ^ 1][b.size()];
 }
 
+// open-addressing set of vertex ids (PAlgorithm's globalUniqueTable on the host side)
+struct VidSet {
+    std::vector<uint32_t> slot;
+    size_t n = 0;
+    static uint32_t mix(uint32_t x) {
+        x *= 0x9E3779B1u;
+        return x ^ (x >> 15);
+    }
+    bool empty() const { return n == 0; }
+    void grow() {
+        std::vector<uint32_t> old;
+        old.swap(slot);
+        slot.assign(old.empty() ? 1024 : old.size() * 4, 0xFFFFFFFFu);
+        n = 0;
+        for (uint32_t v : old)
+            if (v != 0xFFFFFFFFu) insert(v);
+    }
+    bool insert(uint32_t v) {  // true if newly inserted
+        if ((n + 1) * 2 > slot.size()) grow();
+        const size_t mask = slot.size() - 1;
+        for (size_t h = mix(v) & mask;; h = (h + 1) & mask) {
+            if (slot[h] == v) return false;
+            if (slot[h] == 0xFFFFFFFFu) {
+                slot[h] = v;
+                ++n;
+                return true;
+            }
+        }
+    }
+    bool contains(uint32_t v) const {
+        if (slot.empty()) return false;
+        const size_t mask = slot.size() - 1;
+        for (size_t h = mix(v) & mask;; h = (h + 1) & mask) {
+            if (slot[h] == v) return true;
+            if (slot[h] == 0xFFFFFFFFu) return false;
+        }
+    }
+};
+
 struct CtgState {
     uint32_t ci = 0;  // contig index
     bool forward = true;
@@ -98,7 +140,7 @@ struct CtgState {
     int64_t varLen = 0;
     std::deque<uint32_t> ctgQ, refQ;
     bool finalLeap = false, done = false;
-    std::unordered_set<uint32_t> globalUnique;
+    VidSet globalUnique;
     uint32_t gwinLo = 0xFFFFFFFFu, gwinHi = 0;
     uint32_t *gset = nullptr;   // device: global visited, vertices outside the strand's id range
     uint32_t gcap = 0;
@@ -156,6 +198,21 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     PAG_HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = g->stream;
     const double t_begin = now_ms();
+    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    double lap_t = t_begin;
+    std::vector<std::pair<const char *, double>> laps;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = now_ms();
+        for (auto &l : laps)
+            if (l.first == what) {
+                l.second += t - lap_t;
+                lap_t = t;
+                return;
+            }
+        laps.emplace_back(what, t - lap_t);
+        lap_t = t;
+    };
     const uint32_t k = g->k;
     const uint64_t deviation = prm->deviation;
     const double errorRate = prm->error_rate, startSplit = prm->start_split;
@@ -240,6 +297,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         t_compact = now_ms() - t0;
     }
 
+    lap("compact");
     // ---- contigs: packed bases, mapper tables, per-strand node tables
     Mapper mapper(ctgs->len, ctgs->n_seqs);
     Mapper refMapper(ref_len, n_refs);
@@ -338,6 +396,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
     }
 
+    lap("contig tables");
     // vertex attributes for a list of vertex ids
     auto fetch_vertices = [&](const std::vector<uint32_t> &vids, std::vector<pag_path_node> &out) -> int {
         out.resize(vids.size());
@@ -378,6 +437,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
     }
 
+    lap("first seeds");
     uint64_t rounds = 0, jobs_total = 0, steps_total = 0, classify_total = 0, probe_total = 0, record_total = 0;
     double t_walk = 0;
     uint32_t grow = 1;
@@ -445,6 +505,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         if ((rc = upload_contigs())) return rc;
         PAG_HIP_TRY(hipMemcpyAsync(b_jobs.p, jobs.data(), jobs.size() * sizeof(TravJob), hipMemcpyHostToDevice, s));
+        lap("round prep");
         const double tw0 = now_ms();
         trav_launch_walk(G, b_tc.as<TravContig>(), b_jobs.as<TravJob>(), b_outs.as<TravJobOut>(), (uint32_t)jobs.size(), k, s);
         std::vector<TravJobOut> outs(jobs.size());
@@ -452,6 +513,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         PAG_HIP_TRY(hipStreamSynchronize(s));
         PAG_HIP_TRY(hipGetLastError());
         t_walk += now_ms() - tw0;
+        lap("walk");
         bool overflow = false;
         for (auto &o : outs) overflow |= o.overflow != 0;
         if (overflow) {
@@ -471,60 +533,90 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             record_total += o.n_records;
         }
 
-        // ---- per contig: choose, splice, stop rules (PAlgorithm.cpp:238-330)
-        std::vector<TravSeedReq> reqs;
-        std::vector<uint32_t> req_cs;
-        size_t j0 = 0;
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            CtgState &cs = st[i];
-            if (cs.done) continue;
-            const size_t ns = cs.seeds.size();
-            size_t maxLen = 0, chooseCtgPos = 0, chooseRefPos = 0;
-            bool leap = false;
+        // ---- per contig: choose (PAlgorithm.cpp:238-262); the chosen walks are gathered and committed on the
+        //      device back to back, copied out, and spliced by a pool of host threads (contigs are independent)
+        struct Pick {
             int chosen = -1;
-            for (size_t sd = 0; sd < ns; ++sd) {
-                const TravJobOut &o = outs[j0 + sd];
-                size_t len = o.seq_size;
-                leap = o.last_ctg != 0 && mapper.singleToDual(o.last_ctg).first != cs.chosenOne;
-                if (!leap && sd > 0 && prm->min_len > 0 && len < prm->min_len) continue;
-                if (len > maxLen || leap) {
-                    maxLen = len;
-                    chosen = (int)sd;
-                    chooseCtgPos = (size_t)mapper.singleToDual(cs.seeds[sd].ctg).second;
-                    chooseRefPos = (size_t)refMapper.singleToDual(cs.seeds[sd].ref).second;
-                    if (leap) break;
+            bool leap = false, active = false;
+            size_t j = 0, chooseCtgPos = 0, chooseRefPos = 0;
+            uint64_t off = 0, len = 0;
+        };
+        std::vector<Pick> picks(n_sel);
+        {
+            size_t j0 = 0;
+            uint64_t tot = 0;
+            for (uint32_t i = 0; i < n_sel; ++i) {
+                CtgState &cs = st[i];
+                if (cs.done) continue;
+                Pick &P = picks[i];
+                P.active = true;
+                const size_t ns = cs.seeds.size();
+                size_t maxLen = 0;
+                for (size_t sd = 0; sd < ns; ++sd) {
+                    const TravJobOut &o = outs[j0 + sd];
+                    size_t len = o.seq_size;
+                    P.leap = o.last_ctg != 0 && mapper.singleToDual(o.last_ctg).first != cs.chosenOne;
+                    if (!P.leap && sd > 0 && prm->min_len > 0 && len < prm->min_len) continue;
+                    if (len > maxLen || P.leap) {
+                        maxLen = len;
+                        P.chosen = (int)sd;
+                        P.chooseCtgPos = (size_t)mapper.singleToDual(cs.seeds[sd].ctg).second;
+                        P.chooseRefPos = (size_t)refMapper.singleToDual(cs.seeds[sd].ref).second;
+                        if (P.leap) break;
+                    }
                 }
+                if (P.chosen >= 0) {
+                    P.j = j0 + (size_t)P.chosen;
+                    P.off = tot;
+                    P.len = outs[P.j].seq_len;
+                    tot += P.len;
+                }
+                j0 += ns;
             }
-            std::vector<pag_path_node> longest;
-            if (chosen >= 0) {
-                const TravJobOut &o = outs[j0 + chosen];
-                longest.resize(o.seq_len);
-                if ((rc = b_gather.alloc(o.seq_len * sizeof(pag_path_node) + 64))) return rc;
-                trav_launch_gather_path(G, jobs[j0 + chosen].seq_v, jobs[j0 + chosen].seq_s, o.seq_len,
-                                        b_gather.as<pag_path_node>(), s);
-                PAG_HIP_TRY(hipMemcpyAsync(longest.data(), b_gather.p, o.seq_len * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
+            if ((rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return rc;
+            for (uint32_t i = 0; i < n_sel; ++i) {
+                const Pick &P = picks[i];
+                if (P.chosen < 0 || P.len == 0) continue;
+                trav_launch_gather_path(G, jobs[P.j].seq_v, jobs[P.j].seq_s, P.len, b_gather.as<pag_path_node>() + P.off, s);
                 // record the walk in the device-side global visited set of this contig
-                trav_launch_commit(jobs[j0 + chosen].seq_v, o.seq_len, cs.inLo, cs.inHi, cs.gbits, cs.gset, cs.gcap - 1, s);
-                PAG_HIP_TRY(hipStreamSynchronize(s));
+                trav_launch_commit(jobs[P.j].seq_v, P.len, st[i].inLo, st[i].inHi, st[i].gbits, st[i].gset, st[i].gcap - 1, s);
             }
-            j0 += ns;
+        }
+        std::vector<std::vector<pag_path_node>> longest(n_sel);
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            const Pick &P = picks[i];
+            if (P.chosen < 0 || P.len == 0) continue;
+            longest[i].resize(P.len);
+            PAG_HIP_TRY(hipMemcpyAsync(longest[i].data(), b_gather.as<pag_path_node>() + P.off, P.len * sizeof(pag_path_node),
+                                       hipMemcpyDeviceToHost, s));
+        }
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        lap("choose+gather");
 
-            cs.varLen += append_seq(cs.travel, longest, k);
-            if (chooseCtgPos != 0) {
-                cs.ctgQ.push_back((uint32_t)chooseCtgPos);
+        // splice + stop rules (PAlgorithm.cpp:264-360)
+        std::vector<TravSeedReq> slot_req(n_sel);
+        std::vector<uint8_t> slot_has(n_sel, 0), slot_full(n_sel, 0);
+        auto splice = [&](uint32_t i) {
+            CtgState &cs = st[i];
+            const Pick &P = picks[i];
+            const bool leap = P.leap;
+            cs.varLen += append_seq(cs.travel, longest[i], k);
+            if (P.chooseCtgPos != 0) {
+                cs.ctgQ.push_back((uint32_t)P.chooseCtgPos);
                 while (cs.ctgQ.size() > 4) cs.ctgQ.pop_front();
             }
-            if (chooseRefPos != 0) {
-                cs.refQ.push_back((uint32_t)chooseRefPos);
+            if (P.chooseRefPos != 0) {
+                cs.refQ.push_back((uint32_t)P.chooseRefPos);
                 while (cs.refQ.size() > 4) cs.refQ.pop_front();
             }
-            for (auto &n : longest) {
-                if (cs.globalUnique.insert(n.vid).second && (n.ctg < cs.ctgLeft || n.ctg >= cs.ctgRight)) ++cs.nOutside;
+            for (auto &n : longest[i]) {
+                if (cs.globalUnique.insert(n.vid) && (n.ctg < cs.ctgLeft || n.ctg >= cs.ctgRight)) ++cs.nOutside;
                 if (n.ctg != 0) {
                     cs.gwinLo = std::min(cs.gwinLo, n.ctg);
                     cs.gwinHi = std::max(cs.gwinHi, n.ctg);
                 }
             }
+            std::vector<pag_path_node>().swap(longest[i]);
             bool ctgRepeat = false, refRepeat = false;
             if (cs.ctgQ.size() >= 4) {
                 auto mm = std::minmax_element(cs.ctgQ.begin(), cs.ctgQ.end());
@@ -537,7 +629,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             if (ctgRepeat || refRepeat || leap) {
                 if (leap) cs.finalLeap = true;
                 cs.done = true;
-                continue;
+                return;
             }
             // last contig-consistent vertex of the running path (PAlgorithm.cpp:332-360)
             uint64_t lastCtgPos = 0;
@@ -555,21 +647,48 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 }
             }
             if (cs.nOutside * 2 > cs.gcap) {
-                set_error("pag_travel: global visited set of contig %u is full", cs.ci);
-                return PAG_ENOMEM;
+                slot_full[i] = 1;
+                return;
             }
             TravSeedReq r{};
             r.ctg = i;
             r.pos = lastCtgPos;
             r.left = lastCtgPos - std::min<uint64_t>(lastCtgPos, 1000 * deviation);
             r.right = lastCtgPos + 1000 * deviation;
-            reqs.push_back(r);
-            req_cs.push_back(i);
+            slot_req[i] = r;
+            slot_has[i] = 1;
             cs.seeds.clear();
             cs.parentCode = lastCode;
             cs.haveParent = haveKmer;
+        };
+        {
+            std::vector<uint32_t> todo;
+            for (uint32_t i = 0; i < n_sel; ++i)
+                if (picks[i].active) todo.push_back(i);
+            unsigned nthr = std::min<unsigned>((unsigned)todo.size(), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t x; (x = next.fetch_add(1)) < todo.size();) splice(todo[x]);
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+            worker();
+            for (auto &t : pool) t.join();
+        }
+        std::vector<TravSeedReq> reqs;
+        std::vector<uint32_t> req_cs;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            if (slot_full[i]) {
+                set_error("pag_travel: global visited set of contig %u is full", st[i].ci);
+                return PAG_ENOMEM;
+            }
+            if (slot_has[i]) {
+                reqs.push_back(slot_req[i]);
+                req_cs.push_back(i);
+            }
         }
 
+        lap("splice");
         // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
         if (!reqs.empty()) {
             const uint32_t WSTRIDE = 16384;
@@ -595,7 +714,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 for (uint32_t x = 0; x < o[0]; ++x) {
                     uint32_t v = o[1 + x];
                     if (!seen.insert(v).second) continue;         // std::set `unique` in searchPANode2
-                    if (cs.globalUnique.count(v)) continue;        // filterPANodes
+                    if (cs.globalUnique.contains(v)) continue;     // filterPANodes
                     vids.push_back(v);
                     ++n;
                 }
@@ -624,6 +743,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 if (cs.seeds.empty()) cs.done = true;
             }
         }
+        lap("reseed");
     }
 
     // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)
@@ -650,6 +770,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 seq.pop_back();
         }
         g->paths[cs.ci] = std::move(seq);
+    }
+    lap("epilogue");
+    if (timing) {
+        std::fprintf(stderr, "[timing] pag_travel laps:");
+        for (auto &l : laps) std::fprintf(stderr, " %s %.1f ms;", l.first, l.second);
+        std::fprintf(stderr, "\n");
     }
     if (stats) {
         stats->ms_compact = t_compact;
