@@ -1,6 +1,8 @@
 #include "assembly.hpp"
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -53,6 +55,15 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads, AssembleStats *stats, bool quiet,
                                                 const std::vector<TravelSequence> *precomputed) {
+    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    auto nowMs = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tLap = nowMs();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        double t = nowMs();
+        std::fprintf(stderr, "[timing] assemble %s %.1f ms\n", what, t - tLap);
+        tLap = t;
+    };
     std::ostream nullOut(nullptr);
     std::ostream &out = quiet ? nullOut : std::cout;
     std::set<std::pair<std::string, bool>> success;
@@ -114,6 +125,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         worker();
         for (auto &t : pool) t.join();
     }
+    lap("per-contig paths + dumps");
     for (std::size_t li = 0; li < ctgList.size(); ++li) {
         out << logs[li];
         if (leapTarget[li] >= 0) ++inDegrees[static_cast<std::size_t>(leapTarget[li])];
@@ -195,6 +207,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     out << "Start From:" << std::endl;
     for (auto &c : starts) out << "\t" << c.first << " " << c.second << std::endl;
 
+    lap("union/starts");
     // emit chains (PAssembly.cpp:242-333)
     out << "[Assembly] Start" << std::endl;
     std::size_t nameCnt = 0;
@@ -228,22 +241,61 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         std::ofstream fasta(base + ".fasta");
         std::ofstream con(base + ".con");
         fasta << ">" << name << "\n";
-        std::size_t cnt = 0, cmbLen = 0;
+        std::size_t cmbLen = 0;
         std::vector<std::pair<std::pair<std::string, bool>, std::size_t>> conInf;
+        // the chain's consensus pieces are independent: rendered by a pool of host threads, then written
+        // out in chain order as 70-column lines
+        std::vector<std::size_t> order;
         combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
             out << i << "=" << ctgId << std::endl;
             conInf.push_back({{contigs.name(ctgId), forward}, contigs.length(ctgId)});
-            for (char ch : algo.seqToString(results[ctgId * 2 + (forward ? 0 : 1)], deviation, errorRate)) {
-                fasta << ch;
-                ++cmbLen;
-                if (++cnt % lineSize == 0) {
-                    fasta << "\n";
-                    cnt = 0;
-                }
-            }
+            order.push_back(ctgId * 2 + (forward ? 0 : 1));
             return true;
         });
-        if (cnt > 0) fasta << "\n";
+        std::vector<std::string> pieces(order.size());
+        {
+            std::atomic<std::size_t> nextPiece{0};
+            auto render = [&]() {
+                for (std::size_t x; (x = nextPiece.fetch_add(1)) < order.size();)
+                    pieces[x] = algo.seqToString(results[order[x]], deviation, errorRate);
+            };
+            unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
+            nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, order.size())));
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(render);
+            render();
+            for (auto &t : pool) t.join();
+        }
+        {
+            std::string line;
+            line.reserve(lineSize + 1);
+            std::string buf;
+            buf.reserve(1 << 20);
+            for (auto &piece : pieces) {
+                cmbLen += piece.size();
+                std::size_t at = 0;
+                while (at < piece.size()) {
+                    std::size_t take = std::min(lineSize - line.size(), piece.size() - at);
+                    line.append(piece, at, take);
+                    at += take;
+                    if (line.size() == lineSize) {
+                        buf.append(line);
+                        buf.push_back('\n');
+                        line.clear();
+                        if (buf.size() >= (1 << 20) - lineSize - 1) {
+                            fasta.write(buf.data(), static_cast<std::streamsize>(buf.size()));
+                            buf.clear();
+                        }
+                    }
+                }
+                std::string().swap(piece);
+            }
+            if (!line.empty()) {
+                buf.append(line);
+                buf.push_back('\n');
+            }
+            fasta.write(buf.data(), static_cast<std::streamsize>(buf.size()));
+        }
         con << name << "\t" << cmbLen << "\n";
         for (auto &c : conInf) con << c.first.first << "\t" << (c.first.second ? "FORWARD" : "REV") << "\t" << c.second << "\n";
         out << "Out file: " << base << ".fasta" << std::endl;
@@ -253,6 +305,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             stats->nFastaBases += cmbLen;
         }
     }
+    lap("emit chains");
     if (stats) {
         stats->nContigs = ctgSet.size();
         for (std::size_t i = 0; i < results.size(); ++i) {
@@ -268,6 +321,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             stats->nPathBases += Traversal::seqSize(results[i]);
         }
     }
+    lap("stats");
     return success;
 }
 
