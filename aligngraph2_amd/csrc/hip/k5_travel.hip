@@ -272,11 +272,55 @@ constexpr int BR_CAP = 256;    // branch fan-out kept per graphTravel round
 constexpr int PROBE_GROUPS = 4;  // alternatives of a branch probed side by side, 16 lanes each
 #define STAMP_TRAVEL 0xFFFFFFFFu
 
+// A walk moves through the coordinate-ordered arrays almost monotonically, a few ids per step, and every
+// step is a chain of two dependent reads (successor records, then the visited marks of their targets).
+// Served from HBM/L2 that chain costs ~2.3 us per step; the walker therefore keeps a WINDOW of the arrays
+// in LDS — the records, the four probe-stamp arrays and the two visited bitmaps of WIN_IDS consecutive
+// vertices of the strand — refilled with wave-wide coalesced loads every couple of hundred steps.  The
+// window is a pure read cache: every mark is written through to the global arrays, and any access that
+// falls outside the window uses them directly.
+constexpr uint32_t WIN_IDS = 2048;
+constexpr uint32_t WIN_REC = 4096;
+constexpr uint32_t FILT_WORDS = 1024;  // 64 Ki-bit membership filters in front of the outside-range hash sets
+constexpr uint32_t WIN_BACK = 128;   // ids kept behind the anchor at a refill
+constexpr uint32_t WIN_AHEAD = 160;  // refill when the anchor gets this close to the upper end
+
 struct WalkLds {
     uint32_t lst_v[4][LIST_CAP], lst_s[4][LIST_CAP];
     uint32_t lst_n[4];
     uint32_t br_v[BR_CAP], br_s[BR_CAP];
+    SuccRec wrec[WIN_REC];
+    uint32_t wst[PROBE_GROUPS][WIN_IDS];
+    uint32_t wtb[WIN_IDS / 32], wgb[WIN_IDS / 32];
+    // blocked Bloom filters (two bits inside one 64-bit word) over the vertices OUTSIDE the strand's id range
+    // that are in the travel-visited set (ft, maintained on insert) and in the contig's global visited set
+    // (fg, built once per job): a clear bit proves absence, so the random probe into the global hash table
+    // is only made when both bits are set
+    uint64_t ft[FILT_WORDS], fg[FILT_WORDS];
 };
+// the first outside-range vertices marked by the running probe, so that the usual case (none, one or two)
+// never reads the probe's global hash set
+struct ProbeOut {
+    uint32_t n, v0, v1;
+};
+__device__ __forceinline__ void probe_out_add(ProbeOut &P, uint32_t v) {
+    if (P.n == 0) P.v0 = v;
+    else if (P.n == 1) P.v1 = v;
+    P.n += 1;
+}
+struct FiltKey {
+    uint32_t word;
+    uint64_t mask;
+};
+__device__ __forceinline__ FiltKey filt_key(uint32_t v) {
+    v *= 0x85EBCA6Bu;
+    v ^= v >> 15;
+    return FiltKey{v & (FILT_WORDS - 1u), (1ull << ((v >> 10) & 63u)) | (1ull << ((v >> 16) & 63u))};
+}
+__device__ __forceinline__ void filt_set(uint64_t *f, uint32_t v) {
+    const FiltKey k = filt_key(v);
+    atomicOr((unsigned long long *)&f[k.word], (unsigned long long)k.mask);
+}
 
 struct WalkCtx {
     TravGraph G;
@@ -294,8 +338,10 @@ struct WalkCtx {
     uint32_t win_g0, win_g1;  // ctgGlobalPosTable
     uint32_t win_t0, win_t1;  // ctgTravelPosTable
     uint32_t win_p0, win_p1;  // walkStraight's ctgPosTable
-    uint32_t pf_hi;   // ids below this have been pulled towards the L2 (lookahead)
-    uint32_t pf_acc;  // keeps the lookahead loads alive
+    // LDS window: vertices in_lo + [w_d0, w_d0 + w_nid), records [w_r0, w_r0 + w_nrec)
+    uint32_t w_d0, w_nid, w_r0, w_nrec;
+    uint32_t w_anchor;  // offset the window was last filled for
+    uint32_t n_fill;
     uint32_t n_classify, n_probe, n_records;  // work counters
     int overflow;
 };
@@ -313,40 +359,135 @@ __device__ __forceinline__ uint32_t stamp_load(const uint32_t *p) { return __hip
 // of the neighbouring vertex to memory; the loads stay L2-served (sc1) so they never read a stale L1 line.
 __device__ __forceinline__ void stamp_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__device__ __forceinline__ bool visited_global(const WalkCtx &X, uint32_t u) {
-    if (in_range(X, u)) {
-        if (!X.C.gbits) return false;
-        uint32_t d = u - X.C.in_lo;
-        return (X.C.gbits[d >> 5] >> (d & 31u)) & 1u;
+__device__ __forceinline__ SuccRec rec_load(const WalkLds &L, const WalkCtx &X, uint32_t idx) {
+    const uint32_t e = idx - X.w_r0;
+    return e < X.w_nrec ? L.wrec[e] : X.G.succ[idx];
+}
+
+// mark vertex u (on the strand) in probe group grp's generation stamps: global array + window copy
+__device__ __forceinline__ void stamp_put(WalkLds &L, const WalkCtx &X, uint32_t grp, uint32_t u) {
+    const uint32_t d = u - X.C.in_lo;
+    stamp_store(&X.stamp[(uint64_t)grp * X.stamp_stride + d], X.gen);
+    const uint32_t e = d - X.w_d0;
+    if (e < X.w_nid) L.wst[grp][e] = X.gen;
+}
+
+// (Re)load the window around strand offset d = anchor - in_lo.  All lanes.  Kept out of line (and fed with
+// plain values) so that its batches of in-flight loads do not inflate the register budget of the walk loops.
+struct WinState {
+    uint32_t d0, nid, r0, nrec;
+};
+__device__ __attribute__((noinline)) WinState win_fill_impl(WalkLds *L, const uint32_t *succ_off, const SuccRec *succ,
+                                                            const uint32_t *stamp, uint32_t stride, const uint32_t *tbits,
+                                                            const uint32_t *gbits, uint32_t in_lo, uint32_t in_hi, uint32_t anchor) {
+    const uint32_t lane = lane_id();
+    const uint32_t d = anchor - in_lo, span = in_hi - in_lo;
+    const uint32_t d0 = (d > WIN_BACK ? d - WIN_BACK : 0u) & ~31u;
+    const uint32_t nid = span - d0 < WIN_IDS ? span - d0 : WIN_IDS;
+    const uint32_t r0 = succ_off[in_lo + d0], r1 = succ_off[in_lo + d0 + nid];
+    const uint32_t nrec = r1 - r0 < WIN_REC ? r1 - r0 : WIN_REC;
+    __syncthreads();
+    // batches of eight independent loads per lane, so that a refill costs a few memory round trips
+    for (uint32_t b = 0; b < nrec; b += 512u) {
+        SuccRec t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t i = b + (uint32_t)q * 64u + lane;
+            t[q] = i < nrec ? succ[r0 + i] : SuccRec{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t i = b + (uint32_t)q * 64u + lane;
+            if (i < nrec) L->wrec[i] = t[q];
+        }
     }
-    return hs_has(X.C.gset, X.C.gmask, u);
+#pragma unroll 1
+    for (int g = 0; g < PROBE_GROUPS; ++g) {
+        const uint32_t *src = stamp + (uint64_t)g * stride + d0;
+        uint32_t t[WIN_IDS / 64];
+#pragma unroll
+        for (uint32_t q = 0; q < WIN_IDS / 64; ++q) {
+            const uint32_t i = q * 64u + lane;
+            t[q] = i < nid ? stamp_load(&src[i]) : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < WIN_IDS / 64; ++q) L->wst[g][q * 64u + lane] = t[q];
+    }
+    if (lane < (nid + 31u) / 32u) {
+        L->wtb[lane] = stamp_load(&tbits[(d0 >> 5) + lane]);
+        L->wgb[lane] = gbits ? gbits[(d0 >> 5) + lane] : 0u;
+    }
+    __syncthreads();
+    return WinState{d0, nid, r0, nrec};
+}
+__device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor) {
+    const WinState w = win_fill_impl(&L, X.G.succ_off, X.G.succ, X.stamp, X.stamp_stride, X.tbits, X.C.gbits, X.C.in_lo, X.C.in_hi, anchor);
+    X.w_d0 = w.d0;
+    X.w_nid = w.nid;
+    X.w_r0 = w.r0;
+    X.w_nrec = w.nrec;
+    X.w_anchor = anchor - X.C.in_lo;
+    X.n_fill += 1;
+}
+
+// Keep the window around vertex `cur` whose records [off, off + cnt) are about to be read (uniform call).
+__device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur, uint32_t off, uint32_t cnt) {
+    if (!in_range(X, cur)) return;
+    const uint32_t d = cur - X.C.in_lo, span = X.C.in_hi - X.C.in_lo;
+    const uint32_t e = d - X.w_d0;
+    bool need = e >= X.w_nid;                                                        // outside
+    need = need || (e + WIN_AHEAD > X.w_nid && X.w_d0 + X.w_nid < span);               // close to the upper end
+    need = need || (e < 32u && X.w_d0 > 0u);                                          // close to the lower end
+    need = need || (off - X.w_r0 + cnt > X.w_nrec && X.w_nrec == WIN_REC);            // records cut short
+    if (!need) return;
+    const uint32_t moved = d > X.w_anchor ? d - X.w_anchor : X.w_anchor - d;
+    if (X.w_nid != 0 && moved < 64u) return;  // dense repeat region: do not thrash, the global arrays serve it
+    win_fill(L, X, cur);
 }
 
 // classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
 // level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
 // Result: L.lst_v/lst_s[0] hold the chosen class in reference order, return = its size.
 // per-lane evaluation of one successor record: class 0 Amazing/leap, 1 Excellent, 2 Good, 3 Skip, -1 rejected
-__device__ __forceinline__ int eval_record(const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
-                                           const uint32_t *pstamp, const uint64_t *pset) {
-    const uint32_t v = rec.tgt;
-    const int grade = (int)((rec.meta >> 24) & 7u);
+// Written without short-circuit logic: every lane issues the same five LDS reads (window marks for a target
+// on the strand, filter words for a target off it) and combines plain bit operations; the rare cases — a
+// strand vertex outside the window, a filter hit, a probe with more than two outside vertices, a leap —
+// are resolved afterwards under one branch each.
+__device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
+                                           uint32_t grp, const ProbeOut &po) {
+    const uint32_t v = rec.tgt, pc = rec.pc;
+    const uint32_t grade = (rec.meta >> 24) & 7u;
     const bool ectg = (rec.meta >> 27) & 1u;
-    const uint32_t pc = rec.pc;
-    const bool inr = in_range(X, v);
-    uint32_t stp = 0, tw = 0;
-    if (inr) {
-        const uint32_t d = v - X.C.in_lo;
-        tw = stamp_load(&X.tbits[d >> 5]) >> (d & 31u);
-        if (level == 2) stp = stamp_load(&pstamp[d]);
+    const uint32_t d = v - X.C.in_lo, e = d - X.w_d0;
+    const bool inr = d < X.C.in_hi - X.C.in_lo;
+    const bool inw = inr & (e < X.w_nid);
+    const uint32_t ei = inw ? e : 0u;
+    const uint32_t bit = 1u << (ei & 31u);
+    const uint32_t tww = L.wtb[ei >> 5], gww = L.wgb[ei >> 5], stw = L.wst[grp][ei];
+    const FiltKey fk = filt_key(v);
+    const uint64_t ftw = L.ft[fk.word], fgw = L.fg[fk.word];
+    bool tvis = inw & ((tww & bit) != 0u);
+    bool gvis = inw & ((gww & bit) != 0u);
+    bool pvis = (inw & (stw == X.gen)) | (!inr & (((po.n >= 1u) & (v == po.v0)) | ((po.n >= 2u) & (v == po.v1))));
+    const bool fth = !inr & ((ftw & fk.mask) == fk.mask), fgh = !inr & ((fgw & fk.mask) == fk.mask);
+    if ((inr & !inw) | fth | fgh | (!inr & (po.n > 2u))) {
+        if (inr) {
+            tvis = (stamp_load(&X.tbits[d >> 5]) >> (d & 31u)) & 1u;
+            gvis = X.C.gbits ? (X.C.gbits[d >> 5] >> (d & 31u)) & 1u : false;
+            if (level == 2) pvis = stamp_load(&X.stamp[(uint64_t)grp * X.stamp_stride + d]) == X.gen;
+        } else {
+            if (fgh) gvis = hs_has(X.C.gset, X.C.gmask, v);
+            if (fth) tvis = hs_has(X.tset_o, X.tmask_o, v);
+            if (level == 2 && po.n > 2u) pvis = gs_has(X.pset_o + (uint64_t)grp * ((uint64_t)X.pmask_o + 1), X.pmask_o, v, X.gen);
+        }
     }
-    bool ok = !visited_global(X, v) && (pc == 0 || ectg || !in_win(X.win_g0, X.win_g1, pc)) &&
-              (pc == 0 || pc < X.C.rev_left || pc >= X.C.rev_right);
-    if (ok) ok = !(inr ? (tw & 1u) != 0 : hs_has(X.tset_o, X.tmask_o, v)) && (pc == 0 || ectg || !in_win(X.win_t0, X.win_t1, pc));
-    if (ok && level == 2)
-        ok = !(inr ? stp == X.gen : gs_has(pset, X.pmask_o, v, X.gen)) && (pc == 0 || ectg || !in_win(X.win_p0, X.win_p1, pc));
-    if (!ok) return -1;
-    const bool leap = pc != 0 && (pc < X.C.ctg_left || pc >= X.C.ctg_right);
-    if (leap) {
+    const bool free_pc = (pc == 0u) | ectg;  // no coordinate, or the edge follows the contig: the window tests do not apply
+    const bool hit_g = !free_pc & in_win(X.win_g0, X.win_g1, pc), hit_t = !free_pc & in_win(X.win_t0, X.win_t1, pc);
+    const bool rev = (pc != 0u) & (pc >= X.C.rev_left) & (pc < X.C.rev_right);
+    bool ok = !(gvis | hit_g | rev | tvis | hit_t);
+    if (level == 2) ok = ok & !(pvis | (!free_pc & in_win(X.win_p0, X.win_p1, pc)));
+    const bool leap = (pc != 0u) & ((pc < X.C.ctg_left) | (pc >= X.C.ctg_right));
+    if (ok & leap) {
         // landing rule (PAlgorithm.tcc:60-67): singleToDual (PositionMapper.cpp:44-64) on the start table
         uint32_t lo2 = 0, hi2 = X.C.n_ctgs + 1;
         while (lo2 < hi2) {  // upper_bound(starts, pc)
@@ -358,14 +499,10 @@ __device__ __forceinline__ int eval_record(const WalkCtx &X, const SuccRec &rec,
         uint64_t off = (uint64_t)pc - X.C.starts[idx];
         uint64_t sz = idx < X.C.n_ctgs ? X.C.sizes[idx] : 0;
         if (off >= 2 * sz) off -= 2 * sz;
-        if ((double)(int64_t)off > (double)sz * X.C.leap_min) return -1;
-        if (!can_leap) return -1;
+        ok = !((double)(int64_t)off > (double)sz * X.C.leap_min) & can_leap;
     }
-    if (grade == G_AMAZING || leap) return 0;
-    if (grade == G_EXCELLENT) return 1;
-    if (grade == G_GOOD) return 2;
-    if (can_leap && grade == G_SKIP) return 3;
-    return -1;
+    int cls = ((grade == G_AMAZING) | leap) ? 0 : grade == G_EXCELLENT ? 1 : grade == G_GOOD ? 2 : (can_leap & (grade == G_SKIP)) ? 3 : -1;
+    return ok ? cls : -1;
 }
 
 // classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
@@ -382,7 +519,7 @@ struct Step {
 };
 
 __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
-                             int level, Step *one) {
+                             int level, const ProbeOut &po, Step *one) {
     const uint32_t lane = lane_id();
     const uint32_t r1 = r0 + cnt;
     X.n_classify += 1;
@@ -391,10 +528,10 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
         int cls = -1;
         SuccRec rec{0, 0, 0, 0}, nx{0, 0, 0, 0};
         if (lane < cnt) {
-            rec = have_pre ? pre : X.G.succ[r0 + lane];
+            rec = have_pre ? pre : rec_load(L, X, r0 + lane);
             // speculative: the target's only successor record, requested together with the stamp
-            if ((rec.meta >> 28) == 1u) nx = X.G.succ[rec.toff];
-            cls = eval_record(X, rec, can_leap, level, X.stamp, X.pset_o);
+            if ((rec.meta >> 28) == 1u) nx = rec_load(L, X, rec.toff);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po);
         }
         uint64_t m = __ballot(cls == 0);
         if (!m) m = __ballot(cls == 1);
@@ -434,8 +571,8 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
         int cls = -1;
         SuccRec rec{0, 0, 0, 0};
         if (rb + lane < r1) {
-            rec = X.G.succ[rb + lane];
-            cls = eval_record(X, rec, can_leap, level, X.stamp, X.pset_o);
+            rec = rec_load(L, X, rb + lane);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po);
         }
         for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
             uint64_t m = __ballot(cls == c);
@@ -479,34 +616,10 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
     return n;
 }
 
-// Lanes are mostly idle while a walk advances one vertex at a time, so they pull the next stretch of the
-// coordinate-ordered arrays (offsets, records, stamps) towards the L2 ahead of the walk: ids
-// [X.pf_hi, X.pf_hi + 1024), 16 per lane.  The loaded values only feed a dummy accumulator.
-__device__ __forceinline__ void lookahead(WalkCtx &X, uint32_t cur) {
-    if (cur + 256u <= X.pf_hi || cur < X.C.in_lo || cur >= X.C.in_hi) return;
-    uint32_t base = cur > X.pf_hi ? cur : X.pf_hi;
-    uint32_t id = base + lane_id() * 16u;
-    uint32_t acc = 0;
-    if (id < X.C.in_hi) {
-        uint32_t o = X.G.succ_off[id];
-        uint32_t id2 = id + 16u < (uint32_t)X.G.n_pos ? id + 16u : (uint32_t)X.G.n_pos;
-        uint32_t o2 = X.G.succ_off[id2];
-        const uint32_t d = id - X.C.in_lo;
-#pragma unroll
-        for (int g = 0; g < PROBE_GROUPS; ++g) acc ^= stamp_load(&X.stamp[(uint64_t)g * X.stamp_stride + d]);
-        acc ^= stamp_load(&X.tbits[d >> 5]);
-        if (X.C.gbits) acc ^= X.C.gbits[d >> 5];
-        if (o2 - o > 512u) o2 = o + 512u;  // a repeat region: do not chase it
-        for (uint32_t r = o; r < o2; r += 4u) acc ^= X.G.succ[r].tgt;  // one touch per 64 bytes
-    }
-    X.pf_acc ^= acc;
-    X.pf_hi = base + 1024u;
-}
-
 // mark a vertex in walkStraight's uniqueTable (one lane)
-__device__ __forceinline__ void probe_mark(WalkCtx &X, uint32_t u) {
+__device__ __forceinline__ void probe_mark(WalkLds &L, WalkCtx &X, uint32_t u) {
     if (in_range(X, u)) {
-        stamp_store(&X.stamp[u - X.C.in_lo], X.gen);  // group 0 arrays serve the sequential mode
+        stamp_put(L, X, 0u, u);  // group 0 arrays serve the sequential mode
     } else {
         gs_insert_single(X.pset_o, X.pmask_o, u, X.gen);
     }
@@ -539,9 +652,9 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
         return WS_LEAP;
     }
     win_add(X.win_p0, X.win_p1, c);
-    uint32_t out_used = 0;
-    if (lane == 0) probe_mark(X, v0);
-    if (!in_range(X, v0)) ++out_used;
+    ProbeOut po{0, 0, 0};
+    if (lane == 0) probe_mark(L, X, v0);
+    if (!in_range(X, v0)) probe_out_add(po, v0);
     __syncthreads();
     uint32_t cur = v0;
     uint32_t off = X.G.succ_off[v0], cnt = X.G.succ_off[v0 + 1] - off;
@@ -549,9 +662,9 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
     SuccRec pre{0, 0, 0, 0};
     int status;
     for (;;) {
-        lookahead(X, cur);
+        win_follow(L, X, cur, off, cnt);
         Step st;
-        uint32_t m = classify(L, X, off, cnt, have_pre, pre, (has_size + now_size) >= X.C.split_size, 2, &st);
+        uint32_t m = classify(L, X, off, cnt, have_pre, pre, (has_size + now_size) >= X.C.split_size, 2, po, &st);
         if (m == 0) {
             status = WS_END;
             break;
@@ -560,7 +673,7 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
             status = WS_BRANCH;
             break;
         }
-        if (len >= cap || (uint64_t)(out_used + 1) * 2 > (uint64_t)X.pmask_o) {
+        if (len >= cap || (uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
             X.overflow = 1;
             status = WS_END;
             break;
@@ -568,11 +681,11 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
         // same-wave stores and later loads of one address stay ordered in the memory pipeline, so the
         // mark needs no wait before the next step's stamp loads
         if (lane == 0) {
-            probe_mark(X, st.v);
+            probe_mark(L, X, st.v);
             pv[len] = st.v;
             ps[len] = st.s;
         }
-        if (!in_range(X, st.v)) ++out_used;
+        if (!in_range(X, st.v)) probe_out_add(po, st.v);
         win_add(X.win_p0, X.win_p1, st.pc);
         len += 1;
         now_size += st.s;
@@ -601,17 +714,17 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
 // of a step is shared, so the serial cost of a branch is the LONGEST probe instead of the sum of all
 // probes (three quarters of all successor evaluations are probes that end up not being chosen).
 // Returns false if some vertex has more than 16 successor records (caller falls back to sequential probing).
-__device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, const uint32_t *alt_s, uint64_t has_size,
+__device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, const uint32_t *alt_s, uint64_t has_size,
                             uint32_t *arena_v, uint32_t *arena_s, uint64_t cap_each, int *status_out, uint32_t *len_out) {
     const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
     const bool active = g < n_alt;
     X.gen += 1;
     X.n_probe += n_alt;
-    uint32_t *pstamp = X.stamp + (uint64_t)g * X.stamp_stride;
     uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
     uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
     uint32_t wp0 = 0xFFFFFFFFu, wp1 = 0;
-    uint32_t len = 0, out_used = 0, off = 0, cnt = 0, cur_v = 0, pb_v = 0, pb_s = 0;
+    uint32_t len = 0, off = 0, cnt = 0, cur_v = 0, pb_v = 0, pb_s = 0;
+    ProbeOut po{0, 0, 0};
     uint64_t now_size = 0;
     int status = -1;  // running
     if (cap_each == 0) {
@@ -635,10 +748,10 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
         } else {
             win_add(wp0, wp1, c);
             if (sub == 0) {
-                if (in_range(X, v0)) stamp_store(&pstamp[v0 - X.C.in_lo], X.gen);
+                if (in_range(X, v0)) stamp_put(L, X, g, v0);
                 else gs_insert_single(pset, X.pmask_o, v0, X.gen);
             }
-            if (!in_range(X, v0)) ++out_used;
+            if (!in_range(X, v0)) probe_out_add(po, v0);
             off = X.G.succ_off[v0];
             cnt = X.G.succ_off[v0 + 1] - off;
         }
@@ -653,18 +766,35 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
             break;
         }
         if (!__ballot(running)) break;
-        lookahead(X, __shfl(cur_v, 0, 64));
+        {   // the window follows the lowest running alternative; the others use it while they are inside
+            const uint32_t av = running ? cur_v : 0xFFFFFFFFu;
+            uint32_t a = __builtin_amdgcn_readlane(av, 0), ao = __builtin_amdgcn_readlane(off, 0), ac = __builtin_amdgcn_readlane(cnt, 0);
+#define PAG_ANCHOR(LN)                                                   \
+    {                                                                    \
+        const uint32_t b = __builtin_amdgcn_readlane(av, LN);            \
+        if (b < a) {                                                     \
+            a = b;                                                       \
+            ao = __builtin_amdgcn_readlane(off, LN);                     \
+            ac = __builtin_amdgcn_readlane(cnt, LN);                     \
+        }                                                                \
+    }
+            PAG_ANCHOR(16)
+            PAG_ANCHOR(32)
+            PAG_ANCHOR(48)
+#undef PAG_ANCHOR
+            if (a != 0xFFFFFFFFu) win_follow(L, X, a, ao, ac);
+        }
         X.n_classify += 1;
         int cls = -1;
         SuccRec rec{0, 0, 0, 0};
         const bool can_leap = (has_size + now_size) >= X.C.split_size;
         if (running && sub < cnt) {
-            rec = X.G.succ[off + sub];
+            rec = rec_load(L, X, off + sub);
             // the probe-level tests use this group's window and stamps
             const uint32_t sg0 = X.win_p0, sg1 = X.win_p1;
             X.win_p0 = wp0;
             X.win_p1 = wp1;
-            cls = eval_record(X, rec, can_leap, 2, pstamp, pset);
+            cls = eval_record(L, X, rec, can_leap, 2, g, po);
             X.win_p0 = sg0;
             X.win_p1 = sg1;
         }
@@ -686,20 +816,20 @@ __device__ bool probe_multi(WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, c
                 status = WS_END;
             } else if (n > 1) {
                 status = WS_BRANCH;
-            } else if (len >= cap_each || (uint64_t)(out_used + 1) * 2 > (uint64_t)X.pmask_o) {
+            } else if (len >= cap_each || (uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
                 X.overflow = 1;
                 status = WS_END;
             } else {
                 const uint32_t ns = meta & 0xFFFFFFu;
                 if (sub == 0) {
-                    if (in_range(X, nv)) stamp_store(&pstamp[nv - X.C.in_lo], X.gen);
+                    if (in_range(X, nv)) stamp_put(L, X, g, nv);
                     else gs_insert_single(pset, X.pmask_o, nv, X.gen);
                 }
                 if (sub == (len & 15u)) {
                     pb_v = nv;
                     pb_s = ns;
                 }
-                if (!in_range(X, nv)) ++out_used;
+                if (!in_range(X, nv)) probe_out_add(po, nv);
                 win_add(wp0, wp1, npc);
                 len += 1;
                 now_size += ns;
@@ -757,9 +887,29 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     X.win_t0 = 0xFFFFFFFFu;
     X.win_t1 = 0;
     X.overflow = 0;
-    X.pf_hi = 0;
-    X.pf_acc = 0;
+    X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.n_fill = 0;
     X.n_classify = X.n_probe = X.n_records = 0;
+
+    for (uint32_t i = lane; i < FILT_WORDS; i += 64) {
+        L.ft[i] = 0;
+        L.fg[i] = 0;
+    }
+    __syncthreads();
+    if (X.C.gset) {  // members of the contig's global visited set (outside-range part), 16 probes in flight per lane
+        const uint32_t cap = X.C.gmask + 1u;
+        for (uint32_t b = 0; b < cap; b += 1024u) {
+            uint32_t t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t i = b + (uint32_t)q * 64u + lane;
+                t[q] = i < cap ? X.C.gset[i] : HS_EMPTY;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (t[q] != HS_EMPTY) filt_set(L.fg, t[q]);
+        }
+    }
+    __syncthreads();
 
     uint64_t seq_len = 0, now_size = k, seq_size = 0;
     const uint64_t has_size = J.has_size;
@@ -770,7 +920,9 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     walk_straight(L, X, start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
     uint64_t ch_off = 0, ch_len = plen;  // chosen path inside the arena
 
+    uint64_t n_main = 0;
     for (;;) {
+        ++n_main;
         // append the chosen path to the sequence, mark it visited, widen the travel window
         if (seq_len + ch_len > J.seq_cap) {
             X.overflow = 1;
@@ -784,8 +936,11 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
             J.seq_s[seq_len + i] = s;
             if (in_range(X, v)) {
                 atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
+                const uint32_t e = v - X.C.in_lo - X.w_d0;
+                if (e < X.w_nid) atomicOr(&L.wtb[e >> 5], 1u << (e & 31u));
             } else {
                 hs_insert(X.tset_o, X.tmask_o, v);
+                filt_set(L.ft, v);
                 ++n_outside;
             }
             add += s;
@@ -826,7 +981,8 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         Step one;
         const uint32_t l_off = G.succ_off[last];
         const SuccRec none{0, 0, 0, 0};
-        uint32_t m = classify(L, X, l_off, G.succ_off[last + 1] - l_off, false, none, (has_size + now_size) >= X.C.split_size, 1, &one);
+        win_follow(L, X, last, l_off, G.succ_off[last + 1] - l_off);
+        uint32_t m = classify(L, X, l_off, G.succ_off[last + 1] - l_off, false, none, (has_size + now_size) >= X.C.split_size, 1, ProbeOut{0, 0, 0}, &one);
         if (m == 0) break;
         if (m == 1) {  // the single-successor fast path bypasses the LDS list
             __syncthreads();
@@ -879,7 +1035,7 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
             const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
             int stt;
             uint32_t l2;
-            multi_ok = probe_multi(X, m, L.br_v, L.br_s, has_size + now_size, J.arena_v, J.arena_s, cap_each, &stt, &l2);
+            multi_ok = probe_multi(L, X, m, L.br_v, L.br_s, has_size + now_size, J.arena_v, J.arena_s, cap_each, &stt, &l2);
             if (multi_ok) {
                 for (uint32_t i = 0; i < m; ++i)
                     account(i, __shfl(stt, (int)(16u * i), 64), (uint64_t)__shfl(l2, (int)(16u * i), 64), (uint64_t)i * cap_each);
@@ -912,10 +1068,13 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         TravJobOut o;
         o.seq_len = seq_len;
         o.seq_size = seq_size;
-        o.overflow = X.overflow | (X.pf_acc == 0x9E3779B9u && seq_len == 0xFFFFFFFFFFull ? 2 : 0);
+        o.overflow = X.overflow;
         o.n_classify = __shfl(X.n_classify, 0, 64);
         o.n_probe = X.n_probe;
         o.n_records = X.n_records;
+        o.n_fill = X.n_fill;
+        o.n_out = X.n_out;
+        o.n_main = n_main;
         o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;
         outs[jid] = o;
     }

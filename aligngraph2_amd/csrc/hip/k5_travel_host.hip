@@ -294,6 +294,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         g->tg_dev = deviation;
         g->tg_err = errorRate;
         g->tg_ready = true;
+        if (std::getenv("PAGRAPH_TIMING"))
+            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices\n", (unsigned long long)n_succ, (unsigned long long)np);
         t_compact = now_ms() - t0;
     }
 
@@ -513,6 +515,19 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         PAG_HIP_TRY(hipStreamSynchronize(s));
         PAG_HIP_TRY(hipGetLastError());
         t_walk += now_ms() - tw0;
+        if (timing) {
+            uint64_t mx = 0, sum = 0, mxlen = 0, fills = 0, mxout = 0, mains = 0;
+            for (auto &o : outs) {
+                fills += o.n_fill;
+                mxout = std::max<uint64_t>(mxout, o.n_out);
+                mains += o.n_main;
+                mx = std::max<uint64_t>(mx, o.n_classify);
+                sum += o.n_classify;
+                mxlen = std::max<uint64_t>(mxlen, o.seq_len);
+            }
+            std::fprintf(stderr, "[timing] walk round: %zu jobs %.1f ms, classify max %llu sum %llu, longest path %llu, window fills %llu, max outside-visited %llu, main iterations %llu\n", jobs.size(),
+                         now_ms() - tw0, (unsigned long long)mx, (unsigned long long)sum, (unsigned long long)mxlen, (unsigned long long)fills, (unsigned long long)mxout, (unsigned long long)mains);
+        }
         lap("walk");
         bool overflow = false;
         for (auto &o : outs) overflow |= o.overflow != 0;

@@ -77,6 +77,7 @@ struct TravJobOut {
     uint64_t n_classify, n_probe, n_records;
     uint32_t last_ctg;
     int overflow;
+    uint64_t n_fill, n_out, n_main;
 };
 
 struct TravSeedReq {

@@ -1,6 +1,7 @@
 #include "assembly.hpp"
 
 #include <atomic>
+#include <charconv>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -96,12 +97,36 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
 
             std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
             of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
-            for (auto &s : res) {
-                DualPos p = graph.position(s.first);
-                auto d1 = ctgMapper.singleToDual(p.first);
-                auto d2 = refMapper.singleToDual(p.second);
-                of << algo.vertexString(s.first) << "\t" << s.second << "\t" << d1.first << "," << d1.second << "\t"
-                   << d2.first << "," << d2.second << "\n";
+            {
+                std::string buf;
+                buf.reserve(1 << 20);
+                char num[24];
+                auto putInt = [&](long long v) {
+                    auto r = std::to_chars(num, num + sizeof num, v);
+                    buf.append(num, static_cast<std::size_t>(r.ptr - num));
+                };
+                for (auto &s : res) {
+                    DualPos p = graph.position(s.first);
+                    auto d1 = ctgMapper.singleToDual(p.first);
+                    auto d2 = refMapper.singleToDual(p.second);
+                    buf.append(algo.vertexString(s.first));
+                    buf.push_back('\t');
+                    putInt(s.second);
+                    buf.push_back('\t');
+                    putInt(d1.first);
+                    buf.push_back(',');
+                    putInt(d1.second);
+                    buf.push_back('\t');
+                    putInt(d2.first);
+                    buf.push_back(',');
+                    putInt(d2.second);
+                    buf.push_back('\n');
+                    if (buf.size() >= (1 << 20) - 256) {
+                        of.write(buf.data(), static_cast<std::streamsize>(buf.size()));
+                        buf.clear();
+                    }
+                }
+                of.write(buf.data(), static_cast<std::streamsize>(buf.size()));
             }
             if (Traversal::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
             if (!res.empty()) {

@@ -1,5 +1,6 @@
 #include "traversal.hpp"
 
+#include <charconv>
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -11,9 +12,15 @@ namespace pagh {
 
 std::string Traversal::vertexString(const Vertex &v) const {
     DualPos p = g_.position(v);
-    std::stringstream ss;
-    ss << g_.kmerString(v.node) << "," << p.first << "," << p.second << "," << g_.abundance(v);
-    return ss.str();
+    std::string out = g_.kmerString(v.node);
+    char num[24];
+    for (unsigned long long x : {static_cast<unsigned long long>(p.first), static_cast<unsigned long long>(p.second),
+                                 static_cast<unsigned long long>(g_.abundance(v))}) {
+        out.push_back(',');
+        auto r = std::to_chars(num, num + sizeof num, x);
+        out.append(num, static_cast<std::size_t>(r.ptr - num));
+    }
+    return out;
 }
 
 std::size_t Traversal::seqSize(const TravelSequence &seq) {
