@@ -304,8 +304,8 @@ struct ProbeOut {
     uint32_t n, v0, v1;
 };
 __device__ __forceinline__ void probe_out_add(ProbeOut &P, uint32_t v) {
-    if (P.n == 0) P.v0 = v;
-    else if (P.n == 1) P.v1 = v;
+    P.v0 = P.n == 0u ? v : P.v0;  // selects, not an indexed store: the struct has to stay in registers
+    P.v1 = P.n == 1u ? v : P.v1;
     P.n += 1;
 }
 struct FiltKey {
@@ -361,7 +361,10 @@ __device__ __forceinline__ void stamp_store(uint32_t *p, uint32_t v) { __hip_ato
 
 __device__ __forceinline__ SuccRec rec_load(const WalkLds &L, const WalkCtx &X, uint32_t idx) {
     const uint32_t e = idx - X.w_r0;
-    return e < X.w_nrec ? L.wrec[e] : X.G.succ[idx];
+    const bool in = e < X.w_nrec;
+    SuccRec r = L.wrec[in ? e : 0u];  // always an LDS read; the global read only under its own (rare) branch
+    if (!in) r = X.G.succ[idx];
+    return r;
 }
 
 // mark vertex u (on the strand) in probe group grp's generation stamps: global array + window copy
@@ -454,7 +457,7 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
 // strand vertex outside the window, a filter hit, a probe with more than two outside vertices, a leap —
 // are resolved afterwards under one branch each.
 __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
-                                           uint32_t grp, const ProbeOut &po) {
+                                           uint32_t grp, const ProbeOut po) {
     const uint32_t v = rec.tgt, pc = rec.pc;
     const uint32_t grade = (rec.meta >> 24) & 7u;
     const bool ectg = (rec.meta >> 27) & 1u;
@@ -501,8 +504,10 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, c
         if (off >= 2 * sz) off -= 2 * sz;
         ok = !((double)(int64_t)off > (double)sz * X.C.leap_min) & can_leap;
     }
-    int cls = ((grade == G_AMAZING) | leap) ? 0 : grade == G_EXCELLENT ? 1 : grade == G_GOOD ? 2 : (can_leap & (grade == G_SKIP)) ? 3 : -1;
-    return ok ? cls : -1;
+    // class by grade through a nibble table: Amazing 0, Excellent 1, Good 2, Skip 3 (only once leaping is allowed)
+    const uint32_t table = can_leap ? 0x0123Fu : 0x012FFu;
+    const uint32_t c4 = leap ? 0u : (table >> (grade * 4u)) & 0xFu;
+    return (ok & (c4 != 0xFu)) ? (int)c4 : -1;
 }
 
 // classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
@@ -519,7 +524,7 @@ struct Step {
 };
 
 __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
-                             int level, const ProbeOut &po, Step *one) {
+                             int level, const ProbeOut po, Step *one) {
     const uint32_t lane = lane_id();
     const uint32_t r1 = r0 + cnt;
     X.n_classify += 1;
