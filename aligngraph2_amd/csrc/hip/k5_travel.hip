@@ -375,62 +375,59 @@ __device__ __forceinline__ void stamp_put(WalkLds &L, const WalkCtx &X, uint32_t
     if (e < X.w_nid) L.wst[grp][e] = X.gen;
 }
 
-// (Re)load the window around strand offset d = anchor - in_lo.  All lanes.  Kept out of line (and fed with
-// plain values) so that its batches of in-flight loads do not inflate the register budget of the walk loops.
-struct WinState {
-    uint32_t d0, nid, r0, nrec;
-};
-__device__ __attribute__((noinline)) WinState win_fill_impl(WalkLds *L, const uint32_t *succ_off, const SuccRec *succ,
-                                                            const uint32_t *stamp, uint32_t stride, const uint32_t *tbits,
-                                                            const uint32_t *gbits, uint32_t in_lo, uint32_t in_hi, uint32_t anchor) {
+// (Re)load the window around strand offset d = anchor - in_lo.  All lanes.  The copies are LDS-direct
+// loads (global_load_lds: memory -> LDS without passing through registers), so the ~190 loads per lane of a
+// refill are all in flight together and a refill costs a few memory round trips instead of one per batch.
+// Lanes past the end of a range re-load its last element (the slots they fill are never read).
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+__device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor) {
     const uint32_t lane = lane_id();
-    const uint32_t d = anchor - in_lo, span = in_hi - in_lo;
+    const uint32_t d = anchor - X.C.in_lo, span = X.C.in_hi - X.C.in_lo;
     const uint32_t d0 = (d > WIN_BACK ? d - WIN_BACK : 0u) & ~31u;
     const uint32_t nid = span - d0 < WIN_IDS ? span - d0 : WIN_IDS;
-    const uint32_t r0 = succ_off[in_lo + d0], r1 = succ_off[in_lo + d0 + nid];
+    const uint32_t r0 = X.G.succ_off[X.C.in_lo + d0], r1 = X.G.succ_off[X.C.in_lo + d0 + nid];
     const uint32_t nrec = r1 - r0 < WIN_REC ? r1 - r0 : WIN_REC;
     __syncthreads();
-    // batches of eight independent loads per lane, so that a refill costs a few memory round trips
-    for (uint32_t b = 0; b < nrec; b += 512u) {
-        SuccRec t[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t i = b + (uint32_t)q * 64u + lane;
-            t[q] = i < nrec ? succ[r0 + i] : SuccRec{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t i = b + (uint32_t)q * 64u + lane;
-            if (i < nrec) L->wrec[i] = t[q];
+    if (nrec) {
+        const SuccRec *src = X.G.succ + r0;
+        for (uint32_t b = 0; b < nrec; b += 64u) {
+            const uint32_t i = b + lane < nrec ? b + lane : nrec - 1u;
+            __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wrec[b], 16, 0, 0);
         }
     }
-#pragma unroll 1
-    for (int g = 0; g < PROBE_GROUPS; ++g) {
-        const uint32_t *src = stamp + (uint64_t)g * stride + d0;
-        uint32_t t[WIN_IDS / 64];
+    if (nid) {
 #pragma unroll
-        for (uint32_t q = 0; q < WIN_IDS / 64; ++q) {
-            const uint32_t i = q * 64u + lane;
-            t[q] = i < nid ? stamp_load(&src[i]) : 0u;
+        for (int g = 0; g < PROBE_GROUPS; ++g) {
+            const uint32_t *src = X.stamp + (uint64_t)g * X.stamp_stride + d0;
+            for (uint32_t b = 0; b < nid; b += 64u) {
+                const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
+                // sc1: the stamps were written through to the L2 by this wave, an L1 line may be older
+                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wst[g][b], 4, 0, 16);
+            }
         }
-#pragma unroll
-        for (uint32_t q = 0; q < WIN_IDS / 64; ++q) L->wst[g][q * 64u + lane] = t[q];
+        const uint32_t nw = (nid + 31u) / 32u;  // <= 64
+        const uint32_t w = lane < nw ? lane : nw - 1u;
+        __builtin_amdgcn_global_load_lds((const void *)(X.tbits + (d0 >> 5) + w), (lds_ptr_t)&L.wtb[0], 4, 0, 16);
+        if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + (d0 >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
+        else L.wgb[lane] = 0u;
     }
-    if (lane < (nid + 31u) / 32u) {
-        L->wtb[lane] = stamp_load(&tbits[(d0 >> 5) + lane]);
-        L->wgb[lane] = gbits ? gbits[(d0 >> 5) + lane] : 0u;
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    return WinState{d0, nid, r0, nrec};
-}
-__device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor) {
-    const WinState w = win_fill_impl(&L, X.G.succ_off, X.G.succ, X.stamp, X.stamp_stride, X.tbits, X.C.gbits, X.C.in_lo, X.C.in_hi, anchor);
-    X.w_d0 = w.d0;
-    X.w_nid = w.nid;
-    X.w_r0 = w.r0;
-    X.w_nrec = w.nrec;
-    X.w_anchor = anchor - X.C.in_lo;
+    X.w_d0 = d0;
+    X.w_nid = nid;
+    X.w_r0 = r0;
+    X.w_nrec = nrec;
+    X.w_anchor = d;
     X.n_fill += 1;
+}
+
+// true if vertex `cur` with records [off, off + cnt) is served by the window with room to spare (per lane)
+__device__ __forceinline__ bool win_comfortable(const WalkCtx &X, uint32_t cur, uint32_t off, uint32_t cnt) {
+    const uint32_t d = cur - X.C.in_lo, span = X.C.in_hi - X.C.in_lo;
+    const uint32_t e = d - X.w_d0;
+    const bool ok = (e < X.w_nid) & ((e + WIN_AHEAD <= X.w_nid) | (X.w_d0 + X.w_nid >= span)) & ((e >= 32u) | (X.w_d0 == 0u)) &
+                    ((off - X.w_r0 + cnt <= X.w_nrec) | (X.w_nrec != WIN_REC));
+    return ok | (d >= span);  // a vertex off the strand has nothing to follow
 }
 
 // Keep the window around vertex `cur` whose records [off, off + cnt) are about to be read (uniform call).
@@ -771,7 +768,8 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32
             break;
         }
         if (!__ballot(running)) break;
-        {   // the window follows the lowest running alternative; the others use it while they are inside
+        if (__ballot(running && !win_comfortable(X, cur_v, off, cnt))) {
+            // the window follows the lowest running alternative; the others use it while they are inside
             const uint32_t av = running ? cur_v : 0xFFFFFFFFu;
             uint32_t a = __builtin_amdgcn_readlane(av, 0), ao = __builtin_amdgcn_readlane(off, 0), ac = __builtin_amdgcn_readlane(cnt, 0);
 #define PAG_ANCHOR(LN)                                                   \
