@@ -289,6 +289,10 @@ struct WalkLds {
     uint32_t lst_v[4][LIST_CAP], lst_s[4][LIST_CAP];
     uint32_t lst_n[4];
     uint32_t br_v[BR_CAP], br_s[BR_CAP];
+    // per list entry of class 0 / per alternative: contig coordinate, first successor record, record count
+    // (15 = look it up) of the vertex, taken from the record that led to it; valid when *_meta is set
+    uint32_t lst_pc[LIST_CAP], lst_off[LIST_CAP], lst_cnt[LIST_CAP];
+    uint32_t br_pc[BR_CAP], br_off[BR_CAP], br_cnt[BR_CAP];
     SuccRec wrec[WIN_REC];
     uint32_t wst[PROBE_GROUPS][WIN_IDS];
     uint32_t wtb[WIN_IDS / 32], wgb[WIN_IDS / 32];
@@ -521,7 +525,7 @@ struct Step {
 };
 
 __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
-                             int level, const ProbeOut po, Step *one) {
+                             int level, const ProbeOut po, Step *one, bool *list_meta = nullptr) {
     const uint32_t lane = lane_id();
     const uint32_t r1 = r0 + cnt;
     X.n_classify += 1;
@@ -561,10 +565,15 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
             uint32_t at = (uint32_t)__popcll(m & lanemask_lt());
             L.lst_v[0][at] = rec.tgt;
             L.lst_s[0][at] = rec.meta & 0xFFFFFFu;
+            L.lst_pc[at] = rec.pc;
+            L.lst_off[at] = rec.toff;
+            L.lst_cnt[at] = rec.meta >> 28;
         }
+        if (list_meta) *list_meta = true;
         __syncthreads();
         return n;
     }
+    if (list_meta) *list_meta = false;
     // more than 64 successor records (repeats): chunked, all four class lists kept in LDS
     __syncthreads();
     if (lane < 4) L.lst_n[lane] = 0;
@@ -716,27 +725,39 @@ __device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, u
 // of a step is shared, so the serial cost of a branch is the LONGEST probe instead of the sum of all
 // probes (three quarters of all successor evaluations are probes that end up not being chosen).
 // Returns false if some vertex has more than 16 successor records (caller falls back to sequential probing).
-__device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32_t *alt_v, const uint32_t *alt_s, uint64_t has_size,
-                            uint32_t *arena_v, uint32_t *arena_s, uint64_t cap_each, int *status_out, uint32_t *len_out) {
+// what a probe group knows when it stops (uniform inside the group)
+struct ProbeRes {
+    int status;
+    uint32_t len;
+    uint32_t last_v, last_pc;  // last path vertex and its contig coordinate
+    uint32_t off, cnt;         // successor records of last_v (exact) — meaningful for END / BRANCH
+    uint32_t w0, w1;           // min / max contig coordinate over the path (0 = none)
+    uint32_t n_out;            // path vertices outside the strand's id range
+    uint32_t ab;               // abundance of the first path vertex
+    uint64_t size;             // sum of the steps
+};
+
+__device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_meta, uint64_t has_size, uint32_t *arena_v,
+                            uint32_t *arena_s, uint64_t cap_each, ProbeRes *res) {
     const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
     const bool active = g < n_alt;
     X.gen += 1;
     X.n_probe += n_alt;
     uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
     uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
-    uint32_t wp0 = 0xFFFFFFFFu, wp1 = 0;
-    uint32_t len = 0, off = 0, cnt = 0, cur_v = 0, pb_v = 0, pb_s = 0;
+    uint32_t wp0 = 0xFFFFFFFFu, wp1 = 0, aw0 = 0xFFFFFFFFu, aw1 = 0;
+    uint32_t len = 0, off = 0, cnt = 0, cur_v = 0, pb_v = 0, pb_s = 0, last_pc = 0, ab = 0;
     ProbeOut po{0, 0, 0};
     uint64_t now_size = 0;
     int status = -1;  // running
     if (cap_each == 0) {
         X.overflow = 1;
-        *status_out = WS_END;
-        *len_out = 0;
+        res->status = WS_END;
+        res->len = 0;
         return true;
     }
     if (active) {
-        const uint32_t v0 = alt_v[g], s0 = alt_s[g];
+        const uint32_t v0 = L.br_v[g], s0 = L.br_s[g];
         cur_v = v0;
         now_size = s0;
         len = 1;
@@ -744,7 +765,11 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32
             pb_v = v0;
             pb_s = s0;
         }
-        const uint32_t c = (uint32_t)(X.G.upos[v0] >> 32);
+        // abundance of the alternative (needed if it ends in a branch): requested now, consumed after the walk
+        ab = X.G.vcnt[X.G.uold[v0]];
+        const uint32_t c = have_meta ? L.br_pc[g] : (uint32_t)(X.G.upos[v0] >> 32);
+        last_pc = c;
+        win_add(aw0, aw1, c);
         if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
             status = WS_LEAP;
         } else {
@@ -754,8 +779,16 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32
                 else gs_insert_single(pset, X.pmask_o, v0, X.gen);
             }
             if (!in_range(X, v0)) probe_out_add(po, v0);
-            off = X.G.succ_off[v0];
-            cnt = X.G.succ_off[v0 + 1] - off;
+            if (have_meta) {
+                off = L.br_off[g];
+                cnt = L.br_cnt[g];
+            } else {
+                cnt = 15u;
+            }
+            if (cnt == 15u) {
+                off = X.G.succ_off[v0];
+                cnt = X.G.succ_off[v0 + 1] - off;
+            }
         }
     } else {
         status = WS_END;
@@ -834,16 +867,18 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32
                 }
                 if (!in_range(X, nv)) probe_out_add(po, nv);
                 win_add(wp0, wp1, npc);
+                win_add(aw0, aw1, npc);
+                last_pc = npc;
                 len += 1;
                 now_size += ns;
                 if ((len & 15u) == 0) {  // 16 entries pending: one 64-byte store per array
                     pv[len - 16u + sub] = pb_v;
                     ps[len - 16u + sub] = pb_s;
                 }
+                cur_v = nv;
                 if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
                     status = WS_LEAP;
                 } else {
-                    cur_v = nv;
                     off = noff;
                     cnt = meta >> 28;
                     if (cnt == 15u) {
@@ -860,8 +895,17 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, const uint32
     }
     X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
     __syncthreads();  // paths written by the groups are read by all lanes afterwards
-    *status_out = status;
-    *len_out = len;
+    res->status = status;
+    res->len = len;
+    res->last_v = cur_v;
+    res->last_pc = last_pc;
+    res->off = off;
+    res->cnt = cnt;
+    res->w0 = aw0;
+    res->w1 = aw1;
+    res->n_out = po.n;
+    res->ab = ab;
+    res->size = now_size;
     return !wide;
 }
 
@@ -922,6 +966,11 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     uint64_t plen = 0;
     walk_straight(L, X, start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
     uint64_t ch_off = 0, ch_len = plen;  // chosen path inside the arena
+    // what the probe that produced the chosen path already knows about it (fast == true): no need to read
+    // the positions / offsets of its vertices back from memory
+    bool fast = false;
+    uint32_t f_w0 = 0, f_w1 = 0, f_nout = 0, f_last = 0, f_lpc = 0, f_off = 0, f_cnt = 0;
+    uint64_t f_size = 0;
 
     uint64_t n_main = 0;
     for (;;) {
@@ -931,140 +980,222 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
             X.overflow = 1;
             break;
         }
-        uint64_t add = 0;
-        uint32_t lo = 0xFFFFFFFFu, hi = 0, n_outside = 0;
-        for (uint64_t i = lane; i < ch_len; i += 64) {
-            uint32_t v = J.arena_v[ch_off + i], s = J.arena_s[ch_off + i];
-            J.seq_v[seq_len + i] = v;
-            J.seq_s[seq_len + i] = s;
-            if (in_range(X, v)) {
-                atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
-                const uint32_t e = v - X.C.in_lo - X.w_d0;
-                if (e < X.w_nid) atomicOr(&L.wtb[e >> 5], 1u << (e & 31u));
-            } else {
-                hs_insert(X.tset_o, X.tmask_o, v);
-                filt_set(L.ft, v);
-                ++n_outside;
+        uint32_t last, lc, l_off, l_cnt;
+        if (fast) {
+            uint32_t n_outside_chk = 0;
+            for (uint64_t i = lane; i < ch_len; i += 64) {
+                const uint32_t v = J.arena_v[ch_off + i], st = J.arena_s[ch_off + i];
+                J.seq_v[seq_len + i] = v;
+                J.seq_s[seq_len + i] = st;
+                if (in_range(X, v)) {
+                    atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
+                    const uint32_t e = v - X.C.in_lo - X.w_d0;
+                    if (e < X.w_nid) atomicOr(&L.wtb[e >> 5], 1u << (e & 31u));
+                } else {
+                    hs_insert(X.tset_o, X.tmask_o, v);
+                    filt_set(L.ft, v);
+                    ++n_outside_chk;
+                }
             }
-            add += s;
-            uint32_t c = (uint32_t)(G.upos[v] >> 32);
-            if (c != 0) {
-                lo = c < lo ? c : lo;
-                hi = c > hi ? c : hi;
+            (void)n_outside_chk;
+            now_size += f_size;
+            seq_size += f_size;
+            X.n_out += f_nout;
+            if (f_w1 != 0) {
+                X.win_t0 = f_w0 < X.win_t0 ? f_w0 : X.win_t0;
+                X.win_t1 = f_w1 > X.win_t1 ? f_w1 : X.win_t1;
             }
+            seq_len += ch_len;
+            if ((uint64_t)X.n_out * 2 > (uint64_t)X.tmask_o) {
+                X.overflow = 1;
+                break;
+            }
+            __syncthreads();
+            last = f_last;
+            lc = f_lpc;
+            l_off = f_off;
+            l_cnt = f_cnt;
+        } else {
+            uint64_t add = 0;
+            uint32_t lo = 0xFFFFFFFFu, hi = 0, n_outside = 0;
+            for (uint64_t i = lane; i < ch_len; i += 64) {
+                uint32_t v = J.arena_v[ch_off + i], st = J.arena_s[ch_off + i];
+                J.seq_v[seq_len + i] = v;
+                J.seq_s[seq_len + i] = st;
+                if (in_range(X, v)) {
+                    atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
+                    const uint32_t e = v - X.C.in_lo - X.w_d0;
+                    if (e < X.w_nid) atomicOr(&L.wtb[e >> 5], 1u << (e & 31u));
+                } else {
+                    hs_insert(X.tset_o, X.tmask_o, v);
+                    filt_set(L.ft, v);
+                    ++n_outside;
+                }
+                add += st;
+                uint32_t c = (uint32_t)(G.upos[v] >> 32);
+                if (c != 0) {
+                    lo = c < lo ? c : lo;
+                    hi = c > hi ? c : hi;
+                }
+            }
+            {
+                uint64_t tot;
+                wave_excl_sum64(add, &tot);
+                now_size += tot;
+                seq_size += tot;
+                X.n_out += wave_sum(n_outside);
+                for (int d = 32; d >= 1; d >>= 1) {
+                    uint32_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
+                    lo = ol < lo ? ol : lo;
+                    hi = oh > hi ? oh : hi;
+                }
+                if (hi != 0) {
+                    X.win_t0 = lo < X.win_t0 ? lo : X.win_t0;
+                    X.win_t1 = hi > X.win_t1 ? hi : X.win_t1;
+                }
+            }
+            seq_len += ch_len;
+            if ((uint64_t)X.n_out * 2 > (uint64_t)X.tmask_o) {
+                X.overflow = 1;
+                break;
+            }
+            __threadfence_block();
+            __syncthreads();
+            last = J.seq_v[seq_len - 1];
+            lc = (uint32_t)(G.upos[last] >> 32);
+            l_off = G.succ_off[last];
+            l_cnt = G.succ_off[last + 1] - l_off;
         }
-        {
-            uint64_t tot;
-            wave_excl_sum64(add, &tot);
-            now_size += tot;
-            seq_size += tot;
-            X.n_out += wave_sum(n_outside);
-            for (int d = 32; d >= 1; d >>= 1) {
-                uint32_t ol = __shfl_xor(lo, d, 64), oh = __shfl_xor(hi, d, 64);
-                lo = ol < lo ? ol : lo;
-                hi = oh > hi ? oh : hi;
-            }
-            if (hi != 0) {
-                X.win_t0 = lo < X.win_t0 ? lo : X.win_t0;
-                X.win_t1 = hi > X.win_t1 ? hi : X.win_t1;
-            }
-        }
-        seq_len += ch_len;
-        if ((uint64_t)X.n_out * 2 > (uint64_t)X.tmask_o) {
-            X.overflow = 1;
-            break;
-        }
-        __threadfence_block();
-        __syncthreads();
-
-        const uint32_t last = J.seq_v[seq_len - 1];
-        const uint32_t lc = (uint32_t)(G.upos[last] >> 32);
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
 
         Step one;
-        const uint32_t l_off = G.succ_off[last];
+        bool list_meta = false;
         const SuccRec none{0, 0, 0, 0};
-        win_follow(L, X, last, l_off, G.succ_off[last + 1] - l_off);
-        uint32_t m = classify(L, X, l_off, G.succ_off[last + 1] - l_off, false, none, (has_size + now_size) >= X.C.split_size, 1, ProbeOut{0, 0, 0}, &one);
+        win_follow(L, X, last, l_off, l_cnt);
+        uint32_t m = classify(L, X, l_off, l_cnt, false, none, (has_size + now_size) >= X.C.split_size, 1, ProbeOut{0, 0, 0}, &one,
+                              &list_meta);
         if (m == 0) break;
-        if (m == 1) {  // the single-successor fast path bypasses the LDS list
-            __syncthreads();
-            if (lane == 0) {
-                L.lst_v[0][0] = one.v;
-                L.lst_s[0][0] = one.s;
-            }
-            __syncthreads();
-        }
         if (m > BR_CAP) {
             X.overflow = 1;
             m = BR_CAP;
         }
-        for (uint32_t i = lane; i < m; i += 64) {
-            L.br_v[i] = L.lst_v[0][i];
-            L.br_s[i] = L.lst_s[0][i];
+        __syncthreads();
+        if (m == 1) {  // the single-successor fast path of classify bypasses the LDS list
+            if (lane == 0) {
+                L.br_v[0] = one.v;
+                L.br_s[0] = one.s;
+                L.br_pc[0] = one.pc;
+                L.br_off[0] = one.off;
+                L.br_cnt[0] = one.cnt;
+            }
+            list_meta = true;
+        } else {
+            for (uint32_t i = lane; i < m; i += 64) {
+                L.br_v[i] = L.lst_v[0][i];
+                L.br_s[i] = L.lst_s[0][i];
+                if (list_meta) {
+                    L.br_pc[i] = L.lst_pc[i];
+                    L.br_off[i] = L.lst_off[i];
+                    L.br_cnt[i] = L.lst_cnt[i];
+                }
+            }
         }
         __syncthreads();
 
         // probe every alternative (PAlgorithm.tcc:251-266): PROBE_GROUPS at a time side by side, each in
         // its own quarter of the arena; sequential full-wave probing only when a vertex is too wide
-        int first_leap = -1, best_branch = -1, best_tip = -1;
-        uint32_t best_ab = 0;
-        uint64_t best_tip_len = 0, leap_off = 0, leap_len = 0, br_off = 0, br_len = 0, tip_off = 0;
-        auto account = [&](uint32_t i, int stt, uint64_t l2, uint64_t at) {
-            if (stt == WS_LEAP) {
-                if (first_leap < 0) {
-                    first_leap = (int)i;
-                    leap_off = at;
-                    leap_len = l2;
-                }
-            } else if (stt == WS_END) {
-                if (best_tip < 0 || l2 > best_tip_len) {
-                    best_tip = (int)i;
-                    best_tip_len = l2;
-                    tip_off = at;
-                }
-            } else {
-                uint32_t ab = G.vcnt[G.uold[L.br_v[i]]];
-                if (best_branch < 0 || ab > best_ab) {
-                    best_branch = (int)i;
-                    best_ab = ab;
-                    br_off = at;
-                    br_len = l2;
-                }
-            }
-        };
+        fast = false;
         bool multi_ok = m <= PROBE_GROUPS;  // larger fan-outs would need several arena generations: sequential
         if (multi_ok) {
             const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
-            int stt;
-            uint32_t l2;
-            multi_ok = probe_multi(L, X, m, L.br_v, L.br_s, has_size + now_size, J.arena_v, J.arena_s, cap_each, &stt, &l2);
+            ProbeRes R;
+            multi_ok = probe_multi(L, X, m, list_meta, has_size + now_size, J.arena_v, J.arena_s, cap_each, &R);
             if (multi_ok) {
-                for (uint32_t i = 0; i < m; ++i)
-                    account(i, __shfl(stt, (int)(16u * i), 64), (uint64_t)__shfl(l2, (int)(16u * i), 64), (uint64_t)i * cap_each);
+                if (X.overflow) break;
+                // choice (PAlgorithm.tcc:268-296): the first alternative that leaps; else the branching one
+                // with the most abundant first vertex (first wins ties); else the longest dead end (first wins)
+                int pick = -1;
+                for (uint32_t i = 0; i < m && pick < 0; ++i)
+                    if (__shfl(R.status, (int)(16u * i), 64) == WS_LEAP) pick = (int)i;
+                if (pick < 0) {
+                    uint32_t best_ab = 0;
+                    for (uint32_t i = 0; i < m; ++i) {
+                        if (__shfl(R.status, (int)(16u * i), 64) != WS_BRANCH) continue;
+                        const uint32_t ab = __shfl(R.ab, (int)(16u * i), 64);
+                        if (pick < 0 || ab > best_ab) {
+                            pick = (int)i;
+                            best_ab = ab;
+                        }
+                    }
+                }
+                if (pick < 0) {
+                    uint32_t best_len = 0;
+                    for (uint32_t i = 0; i < m; ++i) {
+                        const uint32_t l2 = __shfl(R.len, (int)(16u * i), 64);
+                        if (pick < 0 || l2 > best_len) {
+                            pick = (int)i;
+                            best_len = l2;
+                        }
+                    }
+                }
+                const int src = 16 * pick;
+                ch_off = (uint64_t)pick * cap_each;
+                ch_len = __shfl(R.len, src, 64);
+                fast = true;
+                f_w0 = __shfl(R.w0, src, 64);
+                f_w1 = __shfl(R.w1, src, 64);
+                f_nout = __shfl(R.n_out, src, 64);
+                f_last = __shfl(R.last_v, src, 64);
+                f_lpc = __shfl(R.last_pc, src, 64);
+                f_off = __shfl(R.off, src, 64);
+                f_cnt = __shfl(R.cnt, src, 64);
+                f_size = __shfl(R.size, src, 64);
             }
         }
         if (!multi_ok) {
+            int first_leap = -1, best_branch = -1, best_tip = -1;
+            uint32_t best_ab = 0;
+            uint64_t best_tip_len = 0, leap_off = 0, leap_len = 0, br_off = 0, br_len = 0, tip_off = 0;
             uint64_t used = 0;
             for (uint32_t i = 0; i < m; ++i) {
                 uint64_t l2 = 0;
                 int stt = walk_straight(L, X, L.br_v[i], L.br_s[i], has_size + now_size, J.arena_v + used, J.arena_s + used,
                                         J.arena_cap - used, &l2);
-                account(i, stt, l2, used);
+                if (stt == WS_LEAP) {
+                    if (first_leap < 0) {
+                        first_leap = (int)i;
+                        leap_off = used;
+                        leap_len = l2;
+                    }
+                } else if (stt == WS_END) {
+                    if (best_tip < 0 || l2 > best_tip_len) {
+                        best_tip = (int)i;
+                        best_tip_len = l2;
+                        tip_off = used;
+                    }
+                } else {
+                    uint32_t ab = G.vcnt[G.uold[L.br_v[i]]];
+                    if (best_branch < 0 || ab > best_ab) {
+                        best_branch = (int)i;
+                        best_ab = ab;
+                        br_off = used;
+                        br_len = l2;
+                    }
+                }
                 used += l2;
                 if (X.overflow) break;
             }
-        }
-        if (X.overflow) break;
-        if (first_leap >= 0) {
-            ch_off = leap_off;
-            ch_len = leap_len;
-        } else if (best_branch >= 0) {
-            ch_off = br_off;
-            ch_len = br_len;
-        } else {
-            ch_off = tip_off;
-            ch_len = best_tip_len;
+            if (X.overflow) break;
+            if (first_leap >= 0) {
+                ch_off = leap_off;
+                ch_len = leap_len;
+            } else if (best_branch >= 0) {
+                ch_off = br_off;
+                ch_len = br_len;
+            } else {
+                ch_off = tip_off;
+                ch_len = best_tip_len;
+            }
         }
     }
     if (lane == 0) {
