@@ -909,6 +909,138 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
     return !wide;
 }
 
+// walkStraight for ONE alternative by a whole wave: every piece of walk state (current vertex, record range,
+// length, windows, status) is wave-uniform, so it lives in scalar registers and is updated by the scalar
+// unit; only the evaluation of the <= 64 successor records of a vertex is per-lane work.  `grp` selects the
+// stamp array / outside set of this probe, `alt` the alternative (start vertex in L.br_*), the path goes to
+// pv/ps.  Returns false if a vertex with more than 64 records was met (caller falls back to walk_straight).
+__device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, bool have_meta, uint64_t has_size, uint32_t *pv,
+                           uint32_t *ps, uint64_t cap, bool follow, ProbeRes *res) {
+    const uint32_t lane = lane_id();
+    uint64_t *pset = X.pset_o + (uint64_t)grp * ((uint64_t)X.pmask_o + 1);
+    uint32_t aw0 = 0xFFFFFFFFu, aw1 = 0;
+    const uint32_t sg0 = X.win_p0, sg1 = X.win_p1;
+    X.win_p0 = 0xFFFFFFFFu;
+    X.win_p1 = 0;
+    ProbeOut po{0, 0, 0};
+    X.n_probe += 1;
+    const uint32_t v0 = L.br_v[alt], s0 = L.br_s[alt];
+    uint32_t cur = v0, len = 1, off = 0, cnt = 0;
+    uint64_t now_size = s0;
+    int status = -1;
+    bool wide = false;
+    if (cap == 0) {
+        X.overflow = 1;
+        res->status = WS_END;
+        res->len = 0;
+        return true;
+    }
+    if (lane == 0) {
+        pv[0] = v0;
+        ps[0] = s0;
+    }
+    const uint32_t ab = X.G.vcnt[X.G.uold[v0]];
+    const uint32_t c0 = have_meta ? L.br_pc[alt] : (uint32_t)(X.G.upos[v0] >> 32);
+    uint32_t last_pc = c0;
+    win_add(aw0, aw1, c0);
+    if (c0 != 0 && (c0 < X.C.ctg_left || c0 >= X.C.ctg_right)) {
+        status = WS_LEAP;
+    } else {
+        win_add(X.win_p0, X.win_p1, c0);
+        if (lane == 0) {
+            if (in_range(X, v0)) stamp_put(L, X, grp, v0);
+            else gs_insert_single(pset, X.pmask_o, v0, X.gen);
+        }
+        if (!in_range(X, v0)) probe_out_add(po, v0);
+        if (have_meta) {
+            off = L.br_off[alt];
+            cnt = L.br_cnt[alt];
+        } else {
+            cnt = 15u;
+        }
+        if (cnt == 15u) {
+            off = X.G.succ_off[v0];
+            cnt = X.G.succ_off[v0 + 1] - off;
+        }
+    }
+    while (status < 0) {
+        if (cnt > 64u) {
+            wide = true;
+            break;
+        }
+        if (follow) win_follow(L, X, cur, off, cnt);
+        X.n_classify += 1;
+        const bool can_leap = (has_size + now_size) >= X.C.split_size;
+        int cls = -1;
+        SuccRec rec{0, 0, 0, 0};
+        if (lane < cnt) {
+            rec = rec_load(L, X, off + lane);
+            cls = eval_record(L, X, rec, can_leap, 2, grp, po);
+        }
+        uint64_t m = __ballot(cls == 0);
+        if (!m) m = __ballot(cls == 1);
+        if (!m) m = __ballot(cls == 2);
+        if (!m) m = __ballot(cls == 3);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n == 0) {
+            status = WS_END;
+            break;
+        }
+        if (n > 1) {
+            status = WS_BRANCH;
+            break;
+        }
+        if (len >= cap || (uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
+            X.overflow = 1;
+            status = WS_END;
+            break;
+        }
+        const int src = __ffsll((long long)m) - 1;
+        const uint32_t meta = __shfl(rec.meta, src, 64);
+        const uint32_t nv = __shfl(rec.tgt, src, 64);
+        const uint32_t npc = __shfl(rec.pc, src, 64);
+        const uint32_t noff = __shfl(rec.toff, src, 64);
+        const uint32_t ns = meta & 0xFFFFFFu;
+        if (lane == 0) {
+            if (in_range(X, nv)) stamp_put(L, X, grp, nv);
+            else gs_insert_single(pset, X.pmask_o, nv, X.gen);
+            pv[len] = nv;
+            ps[len] = ns;
+        }
+        if (!in_range(X, nv)) probe_out_add(po, nv);
+        win_add(X.win_p0, X.win_p1, npc);
+        win_add(aw0, aw1, npc);
+        last_pc = npc;
+        len += 1;
+        now_size += ns;
+        cur = nv;
+        if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
+            status = WS_LEAP;
+            break;
+        }
+        off = noff;
+        cnt = meta >> 28;
+        if (cnt == 15u) {
+            off = X.G.succ_off[nv];
+            cnt = X.G.succ_off[nv + 1] - off;
+        }
+    }
+    X.win_p0 = sg0;
+    X.win_p1 = sg1;
+    res->status = status;
+    res->len = len;
+    res->last_v = cur;
+    res->last_pc = last_pc;
+    res->off = off;
+    res->cnt = cnt;
+    res->w0 = aw0;
+    res->w1 = aw1;
+    res->n_out = po.n;
+    res->ab = ab;
+    res->size = now_size;
+    return !wide;
+}
+
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
 __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__restrict__ ctgs, const TravJob *__restrict__ jobs,
                                              TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k) {
@@ -1106,6 +1238,56 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         // its own quarter of the arena; sequential full-wave probing only when a vertex is too wide
         fast = false;
         bool multi_ok = m <= PROBE_GROUPS;  // larger fan-outs would need several arena generations: sequential
+        if (m == 1) {  // a single alternative: the whole wave walks it (scalar walk state, see probe_wave)
+            const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
+            ProbeRes R[PROBE_GROUPS];
+            bool ok_all = true;
+            X.gen += 1;
+            for (uint32_t i = 0; i < m && ok_all; ++i)
+                ok_all = probe_wave(L, X, i, i, list_meta, has_size + now_size, J.arena_v + i * cap_each, J.arena_s + i * cap_each, cap_each,
+                                    true, &R[i]);
+            if (ok_all) {
+                __syncthreads();
+                if (X.overflow) break;
+                int pick = -1;
+                for (uint32_t i = 0; i < m && pick < 0; ++i)
+                    if (R[i].status == WS_LEAP) pick = (int)i;
+                if (pick < 0) {
+                    uint32_t best_ab = 0;
+                    for (uint32_t i = 0; i < m; ++i) {
+                        if (R[i].status != WS_BRANCH) continue;
+                        if (pick < 0 || R[i].ab > best_ab) {
+                            pick = (int)i;
+                            best_ab = R[i].ab;
+                        }
+                    }
+                }
+                if (pick < 0) {
+                    uint32_t best_len = 0;
+                    for (uint32_t i = 0; i < m; ++i)
+                        if (pick < 0 || R[i].len > best_len) {
+                            pick = (int)i;
+                            best_len = R[i].len;
+                        }
+                }
+                ProbeRes Q = R[0];
+                for (uint32_t i = 1; i < m; ++i)
+                    if ((int)i == pick) Q = R[i];
+                ch_off = (uint64_t)pick * cap_each;
+                ch_len = Q.len;
+                fast = true;
+                f_w0 = Q.w0;
+                f_w1 = Q.w1;
+                f_nout = Q.n_out;
+                f_last = Q.last_v;
+                f_lpc = Q.last_pc;
+                f_off = Q.off;
+                f_cnt = Q.cnt;
+                f_size = Q.size;
+                continue;
+            }
+            X.gen += 1;
+        }
         if (multi_ok) {
             const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
             ProbeRes R;
