@@ -1042,16 +1042,12 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
 }
 
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
-__global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__restrict__ ctgs, const TravJob *__restrict__ jobs,
-                                             TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k) {
-    __shared__ WalkLds L;
-    const uint32_t jid = blockIdx.x;
-    if (jid >= n_jobs) return;
+__device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &G, const TravContig &C, const TravJob &Jsrc, TravJobOut *out, uint32_t k) {
     const uint32_t lane = lane_id();
-    const TravJob J = jobs[jid];
+    const TravJob J = Jsrc;  // by value: the record may live in host memory
     WalkCtx X;
     X.G = G;
-    X.C = ctgs[J.ctg];
+    X.C = C;
     X.stamp = J.stamp;
     X.stamp_stride = J.stamp_stride;
     X.tbits = J.tbits;
@@ -1089,7 +1085,6 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         }
     }
     __syncthreads();
-
     uint64_t seq_len = 0, now_size = k, seq_size = 0;
     const uint64_t has_size = J.has_size;
     const uint32_t start = G.newid[J.start];
@@ -1103,7 +1098,6 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
     bool fast = false;
     uint32_t f_w0 = 0, f_w1 = 0, f_nout = 0, f_last = 0, f_lpc = 0, f_off = 0, f_cnt = 0;
     uint64_t f_size = 0;
-
     uint64_t n_main = 0;
     for (;;) {
         ++n_main;
@@ -1392,7 +1386,59 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
         o.n_out = X.n_out;
         o.n_main = n_main;
         o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;
-        outs[jid] = o;
+        *out = o;
+    }
+}
+
+// one launch = one batch of jobs, one wave each
+__global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__restrict__ ctgs, const TravJob *__restrict__ jobs,
+                                             TravJobOut *__restrict__ outs, uint32_t n_jobs, uint32_t k) {
+    __shared__ WalkLds L;
+    const uint32_t jid = blockIdx.x;
+    if (jid >= n_jobs) return;
+    walk_job(L, G, ctgs[jobs[jid].ctg], jobs[jid], &outs[jid], k);
+}
+
+// Persistent form: the grid stays resident and takes jobs from a queue that the host keeps feeding, so that the
+// contigs advance through their traversal rounds independently of each other (a round of one contig starts as
+// soon as ITS previous round is done, instead of when the slowest contig of the batch is done).
+// The queue lives in fine-grained host memory: q->posted (host, release) = number of valid entries of `jobs`;
+// a wave claims the next index from a device counter, waits until that entry is posted, runs it, writes the
+// result record, makes its device-memory writes visible (system release) and raises done[index].
+// A job starts with a system-scope acquire: buffers of the job were prepared by other kernels / copies.
+__global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done,
+                                                        const TravQueue *q, uint32_t *next, uint32_t cap, uint32_t k,
+                                                        uint64_t idle_timeout) {
+    __shared__ WalkLds L;
+    const uint32_t lane = lane_id();
+    // Single-exit scalar loop: every value that steers it is wave-uniform by construction (readfirstlane).
+    bool alive = true;
+    while (alive) {
+        const uint32_t idx = __builtin_amdgcn_readfirstlane(atomicAdd(next, lane == 0 ? 1u : 0u));
+        int go = idx >= cap ? 2 : 0;  // 0 wait, 1 run, 2 leave
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        uint32_t naps = 1;
+        while (go == 0) {
+            // One relaxed 8-byte read of host memory per poll (posted | exit << 32), and polls spaced out up to
+            // ~100 us: hundreds of idle waves hammering the host link would slow the working waves down.  (An
+            // acquire here would also invalidate the L2 on every poll; the acquire that matters follows below.)
+            const uint64_t w = __hip_atomic_load((const uint64_t *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t posted = __builtin_amdgcn_readfirstlane((uint32_t)w), bye = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
+            if (posted > idx) go = 1;
+            else if (bye != 0u || __builtin_amdgcn_s_memtime() - t0 > idle_timeout) go = 2;  // host done, or host gone
+            else {
+                for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
+                naps = naps < 32u ? naps * 2u : 32u;
+            }
+        }
+        if (go == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            walk_job(L, G, jobs[idx].C, jobs[idx].J, &outs[idx], k);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(&done[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // same value from every lane
+        } else {
+            alive = false;
+        }
     }
 }
 
@@ -1620,6 +1666,10 @@ void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeed
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s) {
     if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k);
+}
+void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,
+                                 uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_timeout, hipStream_t s) {
+    k_walk_persistent<<<dim3(n_waves), dim3(64), 0, s>>>(G, jobs, outs, done, q, next, cap, k, idle_timeout);
 }
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s) {

@@ -327,8 +327,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     if (n_sel == 0) return PAG_OK;
 
     DevBuf b_packed = buf(), b_nodes = buf(), b_starts = buf(), b_sizes = buf(), b_tc = buf(), b_seedout = buf(), b_req = buf(),
-           b_jobs = buf(), b_outs = buf(), b_seqv = buf(), b_seqs = buf(), b_arv = buf(), b_ars = buf(), b_tset = buf(),
-           b_pset = buf(), b_gset = buf(), b_gather = buf(), b_vids = buf(), b_stamp = buf(), b_gbits = buf(), b_tbits = buf();
+           b_gset = buf(), b_gather = buf(), b_vids = buf(), b_gbits = buf();
     if ((rc = b_packed.alloc(ctgs->packed_bytes + 64)) || (rc = b_nodes.alloc((nodes_total + 1) * 4)) ||
         (rc = b_starts.alloc(mapper.starts.size() * 8 + 8)) || (rc = b_sizes.alloc(mapper.sizes.size() * 8 + 8)) ||
         (rc = b_tc.alloc(n_sel * sizeof(TravContig))))
@@ -442,133 +441,239 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     lap("first seeds");
     uint64_t rounds = 0, jobs_total = 0, steps_total = 0, classify_total = 0, probe_total = 0, record_total = 0;
     double t_walk = 0;
-    uint32_t grow = 1;
-    for (;;) {
-        // ---- jobs of this round
-        struct JobRef {
-            uint32_t cs, seed;
-        };
-        std::vector<JobRef> jr;
-        for (uint32_t i = 0; i < n_sel; ++i)
-            if (!st[i].done)
-                for (uint32_t sd = 0; sd < st[i].seeds.size(); ++sd) jr.push_back({i, sd});
-        if (jr.empty()) break;
-        ++rounds;
-        jobs_total += jr.size();
-        std::vector<TravJob> jobs(jr.size());
-        uint64_t tot_seq = 0, tot_arena = 0, tot_t = 0, tot_p = 0, tot_stamp = 0, tot_tb = 0;
-        std::vector<uint64_t> o_seq(jr.size()), o_ar(jr.size()), o_t(jr.size()), o_p(jr.size()), o_st(jr.size()), o_tb(jr.size());
-        auto out_cap = [&](const CtgState &cs) { return pow2_at_least((cs.seqCap / 4 + 4096) * grow); };
-        for (size_t j = 0; j < jr.size(); ++j) {
-            const CtgState &cs = st[jr[j].cs];
-            uint64_t cap = cs.seqCap * grow;
-            o_seq[j] = tot_seq;
-            o_ar[j] = tot_arena;
-            o_t[j] = tot_t;
-            o_p[j] = tot_p;
-            o_st[j] = tot_stamp;
-            o_tb[j] = tot_tb;
-            tot_seq += cap;
-            tot_arena += 4 * cap;
-            tot_t += out_cap(cs);
-            tot_p += 4 * out_cap(cs);
-            tot_stamp += 4 * ((uint64_t)(cs.inHi - cs.inLo) + 1);
-            tot_tb += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+
+    // ---- the walks.  The contigs are independent state machines (walk the seeds of the round, choose, splice,
+    //      stop or re-seed); a persistent walker grid executes whatever jobs are posted, and this loop posts the
+    //      next round of a contig as soon as that contig's previous round is done.
+    enum { CB_SEQV = 0, CB_SEQS, CB_ARV, CB_ARS, CB_TSET, CB_PSET, CB_STAMP, CB_TBITS, CB_N };
+    if (g->cpool.size() < (size_t)n_sel * CB_N) g->cpool.resize((size_t)n_sel * CB_N);
+    auto cbuf = [&](uint32_t i, int b) { return DevBuf(g, &g->cpool[(size_t)i * CB_N + b]); };
+    const uint32_t QCAP = 8192;
+    const size_t q_need = 256 + (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
+    if (g->wq_bytes < q_need) {
+        if (g->wq_host) hipHostFree(g->wq_host);
+        g->wq_host = nullptr;
+        g->wq_bytes = 0;
+        PAG_HIP_TRY(hipHostMalloc(&g->wq_host, q_need, hipHostMallocCoherent | hipHostMallocMapped));
+        g->wq_bytes = q_need;
+    }
+    if (!g->wq_next) PAG_HIP_TRY(hipMalloc((void **)&g->wq_next, 256));
+    if (!g->walk_stream) PAG_HIP_TRY(hipStreamCreateWithFlags(&g->walk_stream, hipStreamNonBlocking));
+    TravQueue *hq = (TravQueue *)g->wq_host;
+    TravPosted *hjobs = (TravPosted *)((char *)g->wq_host + 256);
+    TravJobOut *houts = (TravJobOut *)(hjobs + QCAP);
+    uint32_t *hdone = (uint32_t *)(houts + QCAP);
+    std::memset(g->wq_host, 0, q_need);
+    PAG_HIP_TRY(hipMemsetAsync(g->wq_next, 0, 256, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+
+    struct CRun {
+        uint32_t first = 0, n = 0, grow = 1, round = 0;
+        bool outstanding = false;
+    };
+    std::vector<CRun> run(n_sel);
+    uint32_t n_posted = 0, n_outstanding = 0;
+    bool walker_up = false;
+    auto shutdown_walker = [&]() {
+        if (!walker_up) return;
+        __atomic_store_n(&hq->exit, 1u, __ATOMIC_RELEASE);
+        hipStreamSynchronize(g->walk_stream);
+        walker_up = false;
+        g->defer_free = false;
+        for (void *q : g->deferred) hipFree(q);
+        g->deferred.clear();
+    };
+    auto out_cap = [&](const CtgState &cs, uint32_t grow) { return pow2_at_least((cs.seqCap / 4 + 4096) * grow); };
+    // buffers + job records of the next round of contig i (memsets go to stream s; the records become visible
+    // to the walker only by publish())
+    auto prepare = [&](uint32_t i) -> int {
+        CtgState &cs = st[i];
+        CRun &R = run[i];
+        const size_t ns = cs.seeds.size();
+        if (n_posted + ns > QCAP) {
+            set_error("pag_travel: more than %u walk jobs", QCAP);
+            return PAG_ENOMEM;
         }
-        if ((rc = b_seqv.alloc(tot_seq * 4)) || (rc = b_seqs.alloc(tot_seq * 4)) || (rc = b_arv.alloc(tot_arena * 4)) ||
-            (rc = b_ars.alloc(tot_arena * 4)) || (rc = b_tset.alloc(tot_t * 4)) || (rc = b_pset.alloc(tot_p * 8)) ||
-            (rc = b_stamp.alloc(tot_stamp * 4)) || (rc = b_tbits.alloc(tot_tb * 4)) || (rc = b_jobs.alloc(jobs.size() * sizeof(TravJob))) ||
-            (rc = b_outs.alloc(jobs.size() * sizeof(TravJobOut))))
-            return rc;
-        PAG_HIP_TRY(hipMemsetAsync(b_tset.p, 0xFF, tot_t * 4, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_pset.p, 0, tot_p * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_stamp.p, 0, tot_stamp * 4, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_tbits.p, 0, tot_tb * 4, s));
-        for (size_t j = 0; j < jr.size(); ++j) {
-            CtgState &cs = st[jr[j].cs];
-            uint64_t cap = cs.seqCap * grow;
-            TravJob &J = jobs[j];
-            J.ctg = jr[j].cs;
-            J.start = cs.seeds[jr[j].seed].vid;
+        const uint64_t cap = cs.seqCap * R.grow, oc = out_cap(cs, R.grow);
+        const uint64_t span = (uint64_t)(cs.inHi - cs.inLo) + 1, tbw = ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+        DevBuf b_sv = cbuf(i, CB_SEQV), b_ss = cbuf(i, CB_SEQS), b_av = cbuf(i, CB_ARV), b_as = cbuf(i, CB_ARS), b_ts = cbuf(i, CB_TSET),
+               b_ps = cbuf(i, CB_PSET), b_st = cbuf(i, CB_STAMP), b_tb = cbuf(i, CB_TBITS);
+        int r;
+        if ((r = b_sv.alloc(ns * cap * 4)) || (r = b_ss.alloc(ns * cap * 4)) || (r = b_av.alloc(ns * 4 * cap * 4)) ||
+            (r = b_as.alloc(ns * 4 * cap * 4)) || (r = b_ts.alloc(ns * oc * 4)) || (r = b_ps.alloc(ns * 4 * oc * 8)) ||
+            (r = b_st.alloc(ns * 4 * span * 4)) || (r = b_tb.alloc(ns * tbw * 4)))
+            return r;
+        PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, ns * oc * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, ns * 4 * oc * 8, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, ns * 4 * span * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, ns * tbw * 4, s));
+        fill_contigs();
+        R.first = n_posted;
+        R.n = (uint32_t)ns;
+        R.outstanding = true;
+        R.round += 1;
+        for (size_t sd = 0; sd < ns; ++sd) {
+            TravPosted &P = hjobs[n_posted + sd];
+            TravJob &J = P.J;
+            J.ctg = i;
+            J.start = cs.seeds[sd].vid;
             J.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
-            J.seq_v = b_seqv.as<uint32_t>() + o_seq[j];
-            J.seq_s = b_seqs.as<uint32_t>() + o_seq[j];
+            J.seq_v = b_sv.as<uint32_t>() + sd * cap;
+            J.seq_s = b_ss.as<uint32_t>() + sd * cap;
             J.seq_cap = cap;
-            J.arena_v = b_arv.as<uint32_t>() + o_ar[j];
-            J.arena_s = b_ars.as<uint32_t>() + o_ar[j];
+            J.arena_v = b_av.as<uint32_t>() + sd * 4 * cap;
+            J.arena_s = b_as.as<uint32_t>() + sd * 4 * cap;
             J.arena_cap = 4 * cap;
-            J.stamp = b_stamp.as<uint32_t>() + o_st[j];
-            J.stamp_stride = (uint32_t)(cs.inHi - cs.inLo) + 1;
-            J.tbits = b_tbits.as<uint32_t>() + o_tb[j];
-            J.tset = b_tset.as<uint32_t>() + o_t[j];
-            J.tmask = (uint32_t)out_cap(cs) - 1;
-            J.pset = b_pset.as<uint64_t>() + o_p[j];
-            J.pmask = (uint32_t)out_cap(cs) - 1;
+            J.stamp = b_st.as<uint32_t>() + sd * 4 * span;
+            J.stamp_stride = (uint32_t)span;
+            J.tbits = b_tb.as<uint32_t>() + sd * tbw;
+            J.tset = b_ts.as<uint32_t>() + sd * oc;
+            J.tmask = (uint32_t)oc - 1;
+            J.pset = b_ps.as<uint64_t>() + sd * 4 * oc;
+            J.pmask = (uint32_t)oc - 1;
+            P.C = tc[i];
+            hdone[n_posted + sd] = 0;
         }
-        if ((rc = upload_contigs())) return rc;
-        PAG_HIP_TRY(hipMemcpyAsync(b_jobs.p, jobs.data(), jobs.size() * sizeof(TravJob), hipMemcpyHostToDevice, s));
-        lap("round prep");
-        const double tw0 = now_ms();
-        trav_launch_walk(G, b_tc.as<TravContig>(), b_jobs.as<TravJob>(), b_outs.as<TravJobOut>(), (uint32_t)jobs.size(), k, s);
-        std::vector<TravJobOut> outs(jobs.size());
-        PAG_HIP_TRY(hipMemcpyAsync(outs.data(), b_outs.p, outs.size() * sizeof(TravJobOut), hipMemcpyDeviceToHost, s));
+        n_posted += (uint32_t)ns;
+        n_outstanding += 1;
+        rounds = std::max<uint64_t>(rounds, R.round);
+        jobs_total += ns;
+        return PAG_OK;
+    };
+    auto publish = [&]() -> int {  // after the prepared buffers are ready on the device
+        if (std::getenv("PAG_WALK_DEBUG")) std::fprintf(stderr, "[walk] publish: waiting for stream\n");
         PAG_HIP_TRY(hipStreamSynchronize(s));
-        PAG_HIP_TRY(hipGetLastError());
-        t_walk += now_ms() - tw0;
-        if (timing) {
-            uint64_t mx = 0, sum = 0, mxlen = 0, fills = 0, mxout = 0, mains = 0;
-            for (auto &o : outs) {
-                fills += o.n_fill;
-                mxout = std::max<uint64_t>(mxout, o.n_out);
-                mains += o.n_main;
-                mx = std::max<uint64_t>(mx, o.n_classify);
-                sum += o.n_classify;
-                mxlen = std::max<uint64_t>(mxlen, o.seq_len);
-            }
-            std::fprintf(stderr, "[timing] walk round: %zu jobs %.1f ms, classify max %llu sum %llu, longest path %llu, window fills %llu, max outside-visited %llu, main iterations %llu\n", jobs.size(),
-                         now_ms() - tw0, (unsigned long long)mx, (unsigned long long)sum, (unsigned long long)mxlen, (unsigned long long)fills, (unsigned long long)mxout, (unsigned long long)mains);
+        if (std::getenv("PAG_WALK_DEBUG")) std::fprintf(stderr, "[walk] publish: posting %u\n", n_posted);
+        __atomic_store_n(&hq->posted, n_posted, __ATOMIC_RELEASE);
+        return PAG_OK;
+    };
+
+    const bool wdebug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+    const double tw0 = now_ms();
+    g->defer_free = true;
+    for (uint32_t i = 0; i < n_sel; ++i)
+        if (!st[i].done && (rc = prepare(i))) {
+            g->defer_free = false;
+            return rc;
         }
+    if (n_outstanding) {
+        int n_cu = 256;
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
+        trav_launch_walk_persistent(G, hjobs, houts, hdone, hq, g->wq_next, QCAP, k, (uint32_t)std::max(64, n_cu),
+                                    (uint64_t)(std::getenv("PAG_WALK_IDLE_S") ? std::atoi(std::getenv("PAG_WALK_IDLE_S")) : 120) * 2400000000ull, g->walk_stream);
+        if (hipGetLastError() != hipSuccess) {
+            g->defer_free = false;
+            set_error("pag_travel: walker launch failed");
+            return PAG_EFAULT;
+        }
+        if (wdebug) std::fprintf(stderr, "[walk] walker launched, %u jobs prepared\n", n_posted);
+        walker_up = true;
+        if ((rc = publish())) {
+            shutdown_walker();
+            return rc;
+        }
+    } else {
+        g->defer_free = false;
+    }
+    lap("round prep");
+
+    double t_progress = now_ms();
+    while (n_outstanding) {
+        // contigs whose jobs of the running round are all done
+        std::vector<uint32_t> batch;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            if (!run[i].outstanding) continue;
+            bool all = true;
+            for (uint32_t j = 0; j < run[i].n && all; ++j) all = __atomic_load_n(&hdone[run[i].first + j], __ATOMIC_ACQUIRE) != 0;
+            if (all) batch.push_back(i);
+        }
+        if (batch.empty()) {
+            if (hipStreamQuery(g->walk_stream) == hipSuccess) {  // the grid is gone although jobs are outstanding
+                walker_up = false;
+                shutdown_walker();
+                g->defer_free = false;
+                set_error("pag_travel: the walker stopped with jobs outstanding");
+                return PAG_EFAULT;
+            }
+            if (wdebug && now_ms() - t_progress > 3000.0) {
+                static double last = 0;
+                if (now_ms() - last > 2000.0) {
+                    last = now_ms();
+                    uint32_t ticket = 0;
+                    hipMemcpyAsync(&ticket, g->wq_next, 4, hipMemcpyDeviceToHost, s);
+                    hipStreamSynchronize(s);
+                    std::fprintf(stderr, "[walk] waiting: posted %u tickets %u done0 %u done1 %u query %d stage0 %llu stage1 %llu\n", n_posted, ticket, hdone[0], hdone[1],
+                                 (int)hipStreamQuery(g->walk_stream), (unsigned long long)houts[0].n_main, (unsigned long long)houts[1].n_main);
+                }
+            }
+            if (now_ms() - t_progress > 60000.0) {  // no job finished for a minute: give up instead of hanging
+                uint32_t ticket = 0;
+                hipMemcpyAsync(&ticket, g->wq_next, 4, hipMemcpyDeviceToHost, s);
+                hipStreamSynchronize(s);
+                shutdown_walker();
+                set_error("pag_travel: no walk job finished within 60 s (posted %u, tickets taken %u, contigs waiting %u)", n_posted, ticket,
+                          n_outstanding);
+                return PAG_EFAULT;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            continue;
+        }
+        t_progress = now_ms();
+        if (wdebug)
+            for (uint32_t i : batch) {
+                uint64_t mx = 0;
+                for (uint32_t j = 0; j < run[i].n; ++j) mx = std::max<uint64_t>(mx, houts[run[i].first + j].n_classify);
+                std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u done (%u jobs, max classify %llu), %u still walking\n", now_ms() - tw0, i, run[i].round, run[i].n,
+                             (unsigned long long)mx, n_outstanding - (uint32_t)batch.size());
+            }
         lap("walk");
-        bool overflow = false;
-        for (auto &o : outs) overflow |= o.overflow != 0;
-        if (overflow) {
-            if (grow >= 64) {
-                set_error("pag_travel: walker buffers overflow even at 64x capacity");
-                return PAG_ENOMEM;
+        std::vector<uint32_t> redo, next_round;
+        for (uint32_t i : batch) {
+            run[i].outstanding = false;
+            n_outstanding -= 1;
+            bool overflow = false;
+            for (uint32_t j = 0; j < run[i].n; ++j) overflow |= houts[run[i].first + j].overflow != 0;
+            if (overflow) {
+                if (run[i].grow >= 64) {
+                    shutdown_walker();
+                    set_error("pag_travel: walker buffers overflow even at 64x capacity");
+                    return PAG_ENOMEM;
+                }
+                run[i].grow *= 2;
+                run[i].round -= 1;
+                jobs_total -= run[i].n;
+                redo.push_back(i);
             }
-            grow *= 2;
-            --rounds;
-            jobs_total -= jr.size();
-            continue;  // redo the round with larger buffers
         }
-        for (auto &o : outs) {
-            steps_total += o.seq_len;
-            classify_total += o.n_classify;
-            probe_total += o.n_probe;
-            record_total += o.n_records;
-        }
+        batch.erase(std::remove_if(batch.begin(), batch.end(), [&](uint32_t i) { return std::find(redo.begin(), redo.end(), i) != redo.end(); }),
+                    batch.end());
+        for (uint32_t i : batch)
+            for (uint32_t j = 0; j < run[i].n; ++j) {
+                const TravJobOut &o = houts[run[i].first + j];
+                steps_total += o.seq_len;
+                classify_total += o.n_classify;
+                probe_total += o.n_probe;
+                record_total += o.n_records;
+            }
 
         // ---- per contig: choose (PAlgorithm.cpp:238-262); the chosen walks are gathered and committed on the
         //      device back to back, copied out, and spliced by a pool of host threads (contigs are independent)
         struct Pick {
             int chosen = -1;
-            bool leap = false, active = false;
+            bool leap = false;
             size_t j = 0, chooseCtgPos = 0, chooseRefPos = 0;
             uint64_t off = 0, len = 0;
         };
         std::vector<Pick> picks(n_sel);
         {
-            size_t j0 = 0;
             uint64_t tot = 0;
-            for (uint32_t i = 0; i < n_sel; ++i) {
+            for (uint32_t i : batch) {
                 CtgState &cs = st[i];
-                if (cs.done) continue;
                 Pick &P = picks[i];
-                P.active = true;
-                const size_t ns = cs.seeds.size();
+                const size_t ns = cs.seeds.size(), j0 = run[i].first;
                 size_t maxLen = 0;
                 for (size_t sd = 0; sd < ns; ++sd) {
-                    const TravJobOut &o = outs[j0 + sd];
+                    const TravJobOut &o = houts[j0 + sd];
                     size_t len = o.seq_size;
                     P.leap = o.last_ctg != 0 && mapper.singleToDual(o.last_ctg).first != cs.chosenOne;
                     if (!P.leap && sd > 0 && prm->min_len > 0 && len < prm->min_len) continue;
@@ -583,29 +688,39 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 if (P.chosen >= 0) {
                     P.j = j0 + (size_t)P.chosen;
                     P.off = tot;
-                    P.len = outs[P.j].seq_len;
+                    P.len = houts[P.j].seq_len;
                     tot += P.len;
                 }
-                j0 += ns;
             }
-            if ((rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return rc;
-            for (uint32_t i = 0; i < n_sel; ++i) {
+            if ((rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) {
+                shutdown_walker();
+                return rc;
+            }
+            for (uint32_t i : batch) {
                 const Pick &P = picks[i];
                 if (P.chosen < 0 || P.len == 0) continue;
-                trav_launch_gather_path(G, jobs[P.j].seq_v, jobs[P.j].seq_s, P.len, b_gather.as<pag_path_node>() + P.off, s);
+                trav_launch_gather_path(G, hjobs[P.j].J.seq_v, hjobs[P.j].J.seq_s, P.len, b_gather.as<pag_path_node>() + P.off, s);
                 // record the walk in the device-side global visited set of this contig
-                trav_launch_commit(jobs[P.j].seq_v, P.len, st[i].inLo, st[i].inHi, st[i].gbits, st[i].gset, st[i].gcap - 1, s);
+                trav_launch_commit(hjobs[P.j].J.seq_v, P.len, st[i].inLo, st[i].inHi, st[i].gbits, st[i].gset, st[i].gcap - 1, s);
             }
         }
         std::vector<std::vector<pag_path_node>> longest(n_sel);
-        for (uint32_t i = 0; i < n_sel; ++i) {
+        for (uint32_t i : batch) {
             const Pick &P = picks[i];
             if (P.chosen < 0 || P.len == 0) continue;
             longest[i].resize(P.len);
-            PAG_HIP_TRY(hipMemcpyAsync(longest[i].data(), b_gather.as<pag_path_node>() + P.off, P.len * sizeof(pag_path_node),
-                                       hipMemcpyDeviceToHost, s));
+            if (hipMemcpyAsync(longest[i].data(), b_gather.as<pag_path_node>() + P.off, P.len * sizeof(pag_path_node), hipMemcpyDeviceToHost,
+                               s) != hipSuccess) {
+                shutdown_walker();
+                set_error("pag_travel: path copy failed");
+                return PAG_EFAULT;
+            }
         }
-        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            shutdown_walker();
+            set_error("pag_travel: stream failure while gathering paths");
+            return PAG_EFAULT;
+        }
         lap("choose+gather");
 
         // splice + stop rules (PAlgorithm.cpp:264-360)
@@ -677,13 +792,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             cs.haveParent = haveKmer;
         };
         {
-            std::vector<uint32_t> todo;
-            for (uint32_t i = 0; i < n_sel; ++i)
-                if (picks[i].active) todo.push_back(i);
-            unsigned nthr = std::min<unsigned>((unsigned)todo.size(), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+            unsigned nthr = std::min<unsigned>((unsigned)batch.size(), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
             std::atomic<size_t> next{0};
             auto worker = [&]() {
-                for (size_t x; (x = next.fetch_add(1)) < todo.size();) splice(todo[x]);
+                for (size_t x; (x = next.fetch_add(1)) < batch.size();) splice(batch[x]);
             };
             std::vector<std::thread> pool;
             for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
@@ -692,8 +804,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         std::vector<TravSeedReq> reqs;
         std::vector<uint32_t> req_cs;
-        for (uint32_t i = 0; i < n_sel; ++i) {
+        for (uint32_t i : batch) {
             if (slot_full[i]) {
+                shutdown_walker();
                 set_error("pag_travel: global visited set of contig %u is full", st[i].ci);
                 return PAG_ENOMEM;
             }
@@ -702,25 +815,33 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 req_cs.push_back(i);
             }
         }
-
         lap("splice");
+
         // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
         if (!reqs.empty()) {
             const uint32_t WSTRIDE = 16384;
-            if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc((uint64_t)reqs.size() * WSTRIDE * 4)))
+            if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc((uint64_t)reqs.size() * WSTRIDE * 4))) {
+                shutdown_walker();
                 return rc;
-            PAG_HIP_TRY(hipMemcpyAsync(b_req.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s));
+            }
+            std::vector<uint32_t> wb((size_t)reqs.size() * WSTRIDE);
+            hipError_t he = hipMemcpyAsync(b_req.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s);
             trav_launch_seed_window(G, b_tc.as<TravContig>(), b_req.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation,
                                     b_seedout.as<uint32_t>(), WSTRIDE, s);
-            std::vector<uint32_t> wb((size_t)reqs.size() * WSTRIDE);
-            PAG_HIP_TRY(hipMemcpyAsync(wb.data(), b_seedout.p, wb.size() * 4, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
+            if (he == hipSuccess) he = hipMemcpyAsync(wb.data(), b_seedout.p, wb.size() * 4, hipMemcpyDeviceToHost, s);
+            if (he == hipSuccess) he = hipStreamSynchronize(s);
+            if (he != hipSuccess) {
+                shutdown_walker();
+                set_error("pag_travel: seed search failed: %s", hipGetErrorString(he));
+                return PAG_EFAULT;
+            }
             std::vector<uint32_t> vids;
             std::vector<size_t> cnt(reqs.size());
             for (size_t q = 0; q < reqs.size(); ++q) {
                 CtgState &cs = st[req_cs[q]];
                 const uint32_t *o = &wb[q * WSTRIDE];
                 if (o[0] > WSTRIDE - 1) {
+                    shutdown_walker();
                     set_error("pag_travel: seed window overflow (%u candidates)", o[0]);
                     return PAG_ENOMEM;
                 }
@@ -736,7 +857,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 cnt[q] = n;
             }
             std::vector<pag_path_node> attrs;
-            if ((rc = fetch_vertices(vids, attrs))) return rc;
+            if ((rc = fetch_vertices(vids, attrs))) {
+                shutdown_walker();
+                return rc;
+            }
             size_t at = 0;
             for (size_t q = 0; q < reqs.size(); ++q) {
                 CtgState &cs = st[req_cs[q]];
@@ -756,10 +880,26 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 cs.seeds.clear();
                 for (size_t x = 0; x < keyed.size() && x < topK; ++x) cs.seeds.push_back(keyed[x].n);
                 if (cs.seeds.empty()) cs.done = true;
+                else next_round.push_back(req_cs[q]);
             }
         }
         lap("reseed");
+        // ---- post the follow-up rounds (and the repeats with larger buffers)
+        for (uint32_t i : redo) next_round.push_back(i);
+        for (uint32_t i : next_round)
+            if ((rc = prepare(i))) {
+                shutdown_walker();
+                return rc;
+            }
+        if (!next_round.empty() && (rc = publish())) {
+            shutdown_walker();
+            return rc;
+        }
+        lap("round prep");
     }
+    shutdown_walker();
+    t_walk = now_ms() - tw0;
+    lap("walk");
 
     // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)
     for (auto &cs : st) {

@@ -183,6 +183,12 @@ void pag_destroy(pag_graph *g) {
     free_graph_results(g);
     for (auto &sl : g->pool)
         if (sl.p) hipFree(sl.p);
+    for (auto &sl : g->cpool)
+        if (sl.p) hipFree(sl.p);
+    for (void *q : g->deferred) hipFree(q);
+    if (g->wq_host) hipHostFree(g->wq_host);
+    if (g->wq_next) hipFree(g->wq_next);
+    if (g->walk_stream) hipStreamDestroy(g->walk_stream);
     if (g->solid_bits) hipFree(g->solid_bits);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;

@@ -29,6 +29,17 @@ struct pag_graph {
         size_t cap = 0;
     };
     Slot pool[128];
+    // per-contig walker buffers (k5_travel_host.hip), grown on demand like the slots above
+    std::vector<Slot> cpool;
+    // while the persistent walker is resident nothing may be hipFree'd (it synchronises the device): replaced
+    // buffers are parked here and released afterwards
+    bool defer_free = false;
+    std::vector<void *> deferred;
+    // job queue of the persistent walker (fine-grained host memory) and its device-side ticket counter
+    void *wq_host = nullptr;
+    size_t wq_bytes = 0;
+    uint32_t *wq_next = nullptr;
+    hipStream_t walk_stream = nullptr;
     // traversal state (k5_travel_host.hip)
     pagdev::TravGraph tg{};
     bool tg_ready = false;
@@ -45,26 +56,29 @@ namespace pagdev {
 
 struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_destroy does)
     pag_graph *g = nullptr;
-    int slot = -1;
+    pag_graph::Slot *sl = nullptr;
     void *p = nullptr;
-    DevBuf(pag_graph *gg, int s) : g(gg), slot(s) {}
+    DevBuf(pag_graph *gg, int s) : g(gg), sl(&gg->pool[s]) {}
+    DevBuf(pag_graph *gg, pag_graph::Slot *slot) : g(gg), sl(slot) {}
     int alloc(size_t bytes) {
         if (bytes == 0) bytes = 16;
-        pag_graph::Slot &sl = g->pool[slot];
-        if (sl.cap < bytes) {
-            if (sl.p) hipFree(sl.p);
-            sl.p = nullptr;
-            sl.cap = 0;
+        if (sl->cap < bytes) {
+            if (sl->p) {
+                if (g->defer_free) g->deferred.push_back(sl->p);
+                else hipFree(sl->p);
+            }
+            sl->p = nullptr;
+            sl->cap = 0;
             size_t want = bytes + bytes / 8 + 256;
-            hipError_t e = hipMalloc(&sl.p, want);
+            hipError_t e = hipMalloc(&sl->p, want);
             if (e != hipSuccess) {
-                sl.p = nullptr;
+                sl->p = nullptr;
                 pagdev::set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
                 return PAG_ENOMEM;
             }
-            sl.cap = want;
+            sl->cap = want;
         }
-        p = sl.p;
+        p = sl->p;
         return PAG_OK;
     }
     template <typename T>

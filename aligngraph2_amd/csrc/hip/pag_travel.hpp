@@ -80,6 +80,16 @@ struct TravJobOut {
     uint64_t n_fill, n_out, n_main;
 };
 
+// queue of the persistent walker (fine-grained host memory)
+struct TravPosted {
+    TravJob J;
+    TravContig C;  // snapshot of the contig record this job runs with
+};
+struct TravQueue {
+    uint32_t posted;  // entries of the job array that are valid (host writes, release)
+    uint32_t exit;    // host: no further jobs will be posted
+};
+
 struct TravSeedReq {
     uint32_t ctg;
     uint32_t pad;
@@ -98,6 +108,8 @@ void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeed
                              uint32_t *out, uint32_t stride, hipStream_t s);
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s);
+void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,
+                                 uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_timeout, hipStream_t s);
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s);
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);
