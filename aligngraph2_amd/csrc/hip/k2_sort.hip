@@ -16,9 +16,9 @@
 
 namespace pagdev {
 
-constexpr int ST = 512;           // threads per block
+constexpr int ST = 1024;          // threads per block
 constexpr int SW = ST / 64;       // waves per block
-constexpr int SROUNDS = 8;        // records per thread
+constexpr int SROUNDS = 5;       // records per thread
 constexpr int STILE = ST * SROUNDS;
 constexpr int SMAXR = 256;        // max radix (8 bits)
 
