@@ -209,6 +209,7 @@ __global__ void k_order_apply(const uint64_t *__restrict__ sorted_old, uint64_t 
         G.uold[u] = v;
         G.newid[v] = (uint32_t)u;
         G.upos[u] = G.vpos[v];
+        G.ucnt[u] = G.vcnt[v];
     }
 }
 
@@ -296,6 +297,7 @@ struct WalkLds {
     SuccRec wrec[WIN_REC];
     uint32_t wst[PROBE_GROUPS][WIN_IDS];
     uint32_t wtb[WIN_IDS / 32], wgb[WIN_IDS / 32];
+    uint32_t wab[WIN_IDS];  // abundance of the window's vertices (choice among branching alternatives)
     // blocked Bloom filters (two bits inside one 64-bit word) over the vertices OUTSIDE the strand's id range
     // that are in the travel-visited set (ft, maintained on insert) and in the contig's global visited set
     // (fg, built once per job): a clear bit proves absence, so the random probe into the global hash table
@@ -407,6 +409,13 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
                 const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
                 // sc1: the stamps were written through to the L2 by this wave, an L1 line may be older
                 __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wst[g][b], 4, 0, 16);
+            }
+        }
+        {
+            const uint32_t *src = X.G.ucnt + X.C.in_lo + d0;
+            for (uint32_t b = 0; b < nid; b += 64u) {
+                const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
+                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wab[b], 4, 0, 0);
             }
         }
         const uint32_t nw = (nid + 31u) / 32u;  // <= 64
@@ -765,8 +774,11 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
             pb_v = v0;
             pb_s = s0;
         }
-        // abundance of the alternative (needed if it ends in a branch): requested now, consumed after the walk
-        ab = X.G.vcnt[X.G.uold[v0]];
+        {   // abundance of the alternative (needed if it ends in a branch)
+            const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
+            ab = L.wab[e0 < X.w_nid ? e0 : 0u];
+            if (!(e0 < X.w_nid)) ab = X.G.ucnt[v0];
+        }
         const uint32_t c = have_meta ? L.br_pc[g] : (uint32_t)(X.G.upos[v0] >> 32);
         last_pc = c;
         win_add(aw0, aw1, c);
@@ -939,7 +951,12 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
         pv[0] = v0;
         ps[0] = s0;
     }
-    const uint32_t ab = X.G.vcnt[X.G.uold[v0]];
+    uint32_t ab;
+    {
+        const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
+        ab = L.wab[e0 < X.w_nid ? e0 : 0u];
+        if (!(e0 < X.w_nid)) ab = X.G.ucnt[v0];
+    }
     const uint32_t c0 = have_meta ? L.br_pc[alt] : (uint32_t)(X.G.upos[v0] >> 32);
     uint32_t last_pc = c0;
     win_add(aw0, aw1, c0);
@@ -1350,7 +1367,7 @@ __device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &
                         tip_off = used;
                     }
                 } else {
-                    uint32_t ab = G.vcnt[G.uold[L.br_v[i]]];
+                    uint32_t ab = G.ucnt[L.br_v[i]];
                     if (best_branch < 0 || ab > best_ab) {
                         best_branch = (int)i;
                         best_ab = ab;

@@ -223,7 +223,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
-           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(),
+           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(), b_ucnt = buf(),
            b_soff = buf(), b_succ = buf(), b_ok0 = buf(), b_ov0 = buf(), b_ok1 = buf(), b_ov1 = buf(), b_otmp = buf();
     const uint64_t nn = g->stats.n_nodes, np = g->stats.n_pos, ne = g->stats.n_uniq_edges;
     if (np >= 0xFFFFFFF0ull || ne >= 0xFFFFFFF0ull) {
@@ -235,7 +235,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         (rc = b_vpos.alloc((np + 1) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
         (rc = b_eto.alloc((ne + 1) * 4)) || (rc = b_estep.alloc((ne + 1) * 4)) || (rc = b_bitmap.alloc(n_words * 8)) ||
         (rc = b_rank.alloc(n_words * 4)) || (rc = b_uold.alloc((np + 1) * 4)) || (rc = b_newid.alloc((np + 1) * 4)) ||
-        (rc = b_upos.alloc((np + 1) * 8)) || (rc = b_soff.alloc((np + 2) * 4)))
+        (rc = b_upos.alloc((np + 1) * 8)) || (rc = b_ucnt.alloc((np + 1) * 4)) || (rc = b_soff.alloc((np + 2) * 4)))
         return rc;
     TravGraph G{};
     G.n_nodes = nn;
@@ -254,6 +254,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     G.uold = b_uold.as<uint32_t>();
     G.newid = b_newid.as<uint32_t>();
     G.upos = b_upos.as<uint64_t>();
+    G.ucnt = b_ucnt.as<uint32_t>();
     G.succ_off = b_soff.as<uint32_t>();
     double t_compact = 0;
     if (g->tg_ready && (g->tg_dev != deviation || g->tg_err != errorRate)) g->tg_ready = false;

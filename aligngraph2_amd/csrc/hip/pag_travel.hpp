@@ -25,6 +25,7 @@ struct TravGraph {
     uint32_t *uold;       // [n_pos] new id -> vertex id
     uint32_t *newid;      // [n_pos] vertex id -> new id
     uint64_t *upos;       // [n_pos] positions in new order
+    uint32_t *ucnt;       // [n_pos] abundance in new order
     uint32_t *succ_off;   // [n_pos + 1] successor records of new id u
     struct SuccRec *succ; // [n_succ]
     uint64_t n_succ;
