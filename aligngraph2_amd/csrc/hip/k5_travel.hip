@@ -298,6 +298,11 @@ struct WalkLds {
     uint32_t wst[PROBE_GROUPS][WIN_IDS];
     uint32_t wtb[WIN_IDS / 32], wgb[WIN_IDS / 32];
     uint32_t wab[WIN_IDS];  // abundance of the window's vertices (choice among branching alternatives)
+    // the classification a probe stopped at (END / BRANCH): every accepted record with its class, in record order.
+    // After the chosen path is appended, graphTravel's own classification of its last vertex is this list minus
+    // the records whose coordinate now falls into the (hull of the) travel window — see k_walk's main loop.
+    uint32_t pb_cnt[PROBE_GROUPS];
+    uint32_t pb_v[PROBE_GROUPS][64], pb_meta[PROBE_GROUPS][64], pb_pc[PROBE_GROUPS][64], pb_off[PROBE_GROUPS][64], pb_cls[PROBE_GROUPS][64];
     // blocked Bloom filters (two bits inside one 64-bit word) over the vertices OUTSIDE the strand's id range
     // that are in the travel-visited set (ft, maintained on insert) and in the contig's global visited set
     // (fg, built once per job): a clear bit proves absence, so the random probe into the global hash table
@@ -854,6 +859,20 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
             if (cm == 0) cm = gm;
         }
         const uint32_t n = (uint32_t)__popc(cm);
+        {   // a group that stops here by classification leaves its accepted records behind
+            const uint32_t ga = (uint32_t)(__ballot(cls >= 0) >> (16u * g)) & 0xFFFFu;
+            if (running && n != 1u) {
+                if (cls >= 0) {
+                    const uint32_t kk = (uint32_t)__popc(ga & ((1u << sub) - 1u));
+                    L.pb_v[g][kk] = rec.tgt;
+                    L.pb_meta[g][kk] = rec.meta;
+                    L.pb_pc[g][kk] = rec.pc;
+                    L.pb_off[g][kk] = rec.toff;
+                    L.pb_cls[g][kk] = (uint32_t)cls;
+                }
+                if (sub == 0) L.pb_cnt[g] = (uint32_t)__popc(ga);
+            }
+        }
         const int src = (int)(16u * g) + (cm ? __ffs(cm) - 1 : 0);
         const uint32_t meta = __shfl(rec.meta, src, 64);
         const uint32_t nv = __shfl(rec.tgt, src, 64);
@@ -999,12 +1018,18 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
         if (!m) m = __ballot(cls == 2);
         if (!m) m = __ballot(cls == 3);
         const uint32_t n = (uint32_t)__popcll(m);
-        if (n == 0) {
-            status = WS_END;
-            break;
-        }
-        if (n > 1) {
-            status = WS_BRANCH;
+        if (n != 1u) {  // the walk stops at this classification: leave the accepted records behind (see WalkLds)
+            const uint64_t am = __ballot(cls >= 0);
+            if (cls >= 0) {
+                const uint32_t kk = (uint32_t)__popcll(am & lanemask_lt());
+                L.pb_v[grp][kk] = rec.tgt;
+                L.pb_meta[grp][kk] = rec.meta;
+                L.pb_pc[grp][kk] = rec.pc;
+                L.pb_off[grp][kk] = rec.toff;
+                L.pb_cls[grp][kk] = (uint32_t)cls;
+            }
+            if (lane == 0) L.pb_cnt[grp] = (uint32_t)__popcll(am);
+            status = n == 0 ? WS_END : WS_BRANCH;
             break;
         }
         if (len >= cap || (uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
@@ -1113,7 +1138,8 @@ __device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &
     // what the probe that produced the chosen path already knows about it (fast == true): no need to read
     // the positions / offsets of its vertices back from memory
     bool fast = false;
-    uint32_t f_w0 = 0, f_w1 = 0, f_nout = 0, f_last = 0, f_lpc = 0, f_off = 0, f_cnt = 0;
+    uint32_t f_w0 = 0, f_w1 = 0, f_nout = 0, f_last = 0, f_lpc = 0, f_off = 0, f_cnt = 0, f_grp = 0;
+    bool f_list = false;  // L.pb_*[f_grp] holds the classification the chosen probe stopped at
     uint64_t f_size = 0;
     uint64_t n_main = 0;
     for (;;) {
@@ -1213,9 +1239,46 @@ __device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &
 
         Step one;
         bool list_meta = false;
+        uint32_t m;
+        if (fast && f_list) {
+            // graphTravel's classification of `last` (level 1) = the classification the chosen probe stopped at
+            // (level 2): the probe's marks are exactly the vertices just appended and its coordinate window has just
+            // been merged into the travel window.  The one difference: the merged window is the HULL of the two, so
+            // an accepted record whose coordinate lies in the gap between them is rejected now.
+            __syncthreads();
+            const uint32_t nc = L.pb_cnt[f_grp];
+            int c = -1;
+            uint32_t cv = 0, cmeta = 0, cpc = 0, coff = 0;
+            if (lane < nc) {
+                cv = L.pb_v[f_grp][lane];
+                cmeta = L.pb_meta[f_grp][lane];
+                cpc = L.pb_pc[f_grp][lane];
+                coff = L.pb_off[f_grp][lane];
+                const bool free_pc = (cpc == 0u) | (((cmeta >> 27) & 1u) != 0u);
+                c = (free_pc || !in_win(X.win_t0, X.win_t1, cpc)) ? (int)L.pb_cls[f_grp][lane] : -1;
+            }
+            uint64_t mm = __ballot(c == 0);
+            if (!mm) mm = __ballot(c == 1);
+            if (!mm) mm = __ballot(c == 2);
+            if (!mm) mm = __ballot(c == 3);
+            m = (uint32_t)__popcll(mm);
+            X.n_classify += 1;
+            if (m == 0) break;
+            __syncthreads();
+            if ((mm >> lane) & 1ull) {
+                const uint32_t at = (uint32_t)__popcll(mm & lanemask_lt());
+                L.br_v[at] = cv;
+                L.br_s[at] = cmeta & 0xFFFFFFu;
+                L.br_pc[at] = cpc;
+                L.br_off[at] = coff;
+                L.br_cnt[at] = cmeta >> 28;
+            }
+            list_meta = true;
+            __syncthreads();
+        } else {
         const SuccRec none{0, 0, 0, 0};
         win_follow(L, X, last, l_off, l_cnt);
-        uint32_t m = classify(L, X, l_off, l_cnt, false, none, (has_size + now_size) >= X.C.split_size, 1, ProbeOut{0, 0, 0}, &one,
+        m = classify(L, X, l_off, l_cnt, false, none, (has_size + now_size) >= X.C.split_size, 1, ProbeOut{0, 0, 0}, &one,
                               &list_meta);
         if (m == 0) break;
         if (m > BR_CAP) {
@@ -1244,6 +1307,7 @@ __device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &
             }
         }
         __syncthreads();
+        }
 
         // probe every alternative (PAlgorithm.tcc:251-266): PROBE_GROUPS at a time side by side, each in
         // its own quarter of the arena; sequential full-wave probing only when a vertex is too wide
@@ -1287,6 +1351,8 @@ __device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &
                 ch_off = (uint64_t)pick * cap_each;
                 ch_len = Q.len;
                 fast = true;
+                f_grp = (uint32_t)pick;
+                f_list = Q.status == WS_END || Q.status == WS_BRANCH;
                 f_w0 = Q.w0;
                 f_w1 = Q.w1;
                 f_nout = Q.n_out;
@@ -1335,6 +1401,11 @@ __device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &
                 ch_off = (uint64_t)pick * cap_each;
                 ch_len = __shfl(R.len, src, 64);
                 fast = true;
+                f_grp = (uint32_t)pick;
+                {
+                    const int stt = __shfl(R.status, src, 64);
+                    f_list = stt == WS_END || stt == WS_BRANCH;
+                }
                 f_w0 = __shfl(R.w0, src, 64);
                 f_w1 = __shfl(R.w1, src, 64);
                 f_nout = __shfl(R.n_out, src, 64);
