@@ -333,17 +333,33 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     lap("emit chains");
     if (stats) {
         stats->nContigs = ctgSet.size();
-        for (std::size_t i = 0; i < results.size(); ++i) {
-            std::uint64_t h = 1469598103934665603ull ^ i;
-            for (auto &n : results[i]) {
-                DualPos pp = graph.position(n.first);
-                h = (h ^ ((static_cast<std::uint64_t>(pp.first) << 32) | pp.second)) * 1099511628211ull;
-                h = (h ^ graph.nodeCode[n.first.node]) * 1099511628211ull;
-                h = (h ^ static_cast<std::uint64_t>(n.second)) * 1099511628211ull;
+        std::vector<std::uint64_t> hs(results.size(), 0), nb(results.size(), 0);
+        std::atomic<std::size_t> nextRes{0};
+        auto sumWorker = [&]() {
+            for (std::size_t i; (i = nextRes.fetch_add(1)) < results.size();) {
+                std::uint64_t h = 1469598103934665603ull ^ i;
+                for (auto &n : results[i]) {
+                    DualPos pp = graph.position(n.first);
+                    h = (h ^ ((static_cast<std::uint64_t>(pp.first) << 32) | pp.second)) * 1099511628211ull;
+                    h = (h ^ graph.nodeCode[n.first.node]) * 1099511628211ull;
+                    h = (h ^ static_cast<std::uint64_t>(n.second)) * 1099511628211ull;
+                }
+                hs[i] = h;
+                nb[i] = Traversal::seqSize(results[i]);
             }
-            if (!results[i].empty()) stats->pathChecksum += h;
+        };
+        {
+            unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
+            nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, results.size())));
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(sumWorker);
+            sumWorker();
+            for (auto &t : pool) t.join();
+        }
+        for (std::size_t i = 0; i < results.size(); ++i) {
+            if (!results[i].empty()) stats->pathChecksum += hs[i];
             stats->nPathNodes += results[i].size();
-            stats->nPathBases += Traversal::seqSize(results[i]);
+            stats->nPathBases += nb[i];
         }
     }
     lap("stats");

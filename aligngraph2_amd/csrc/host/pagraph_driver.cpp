@@ -228,7 +228,9 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                         if (!names.insert(c.first).second) hostWalk = true;
                 }
                 if (!hostWalk && backend.travel(cs, orient, refLen, tp, paths)) {
-                    buildPathGraph(paths, orient, static_cast<unsigned>(kmers.k()), graph, precomputed);
+                    std::vector<std::pair<const pag_path_node *, std::uint64_t>> views;
+                    for (auto &pth : paths) views.emplace_back(pth.data(), pth.size());
+                    buildPathGraph(views, orient, static_cast<unsigned>(kmers.k()), graph, precomputed);
                     onDevice = true;
                     lap("device traversal");
                 }

@@ -1,9 +1,14 @@
 // Turns the paths returned by the device traversal (pag_travel) into the (graph view, travel sequences)
 // pair that the chain selection / seqToString / writers of assembly.cpp work on: a HostGraph that
-// contains exactly the vertices that lie on some path.  Sort-based (paths hold millions of vertices).
+// contains exactly the vertices that lie on some path, one single-position node per path element (the
+// post-processing only ever asks for the k-mer, position and abundance of a path vertex, so no
+// de-duplication or ordering is needed).  Contigs fill disjoint slices, so they are filled by a pool of threads.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "host_graph.hpp"
@@ -11,30 +16,40 @@
 
 namespace pagh {
 
-inline void buildPathGraph(const std::vector<std::vector<pag_path_node>> &paths, const std::vector<int> &orient, unsigned k,
-                           HostGraph &graph, std::vector<TravelSequence> &results) {
-    // every path element becomes its own single-position node: the post-processing only ever asks for the
-    // k-mer, position and abundance of a path vertex, so no de-duplication or ordering is needed
-    std::size_t total = 0;
-    for (auto &p : paths) total += p.size();
+// paths[c] = (pointer, length) of contig c's path
+inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, std::uint64_t>> &paths, const std::vector<int> &orient,
+                           unsigned k, HostGraph &graph, std::vector<TravelSequence> &results, unsigned threads = 0) {
+    std::vector<std::size_t> base(paths.size() + 1, 0);
+    for (std::size_t c = 0; c < paths.size(); ++c) base[c + 1] = base[c] + paths[c].second;
+    const std::size_t total = base.back();
     graph.resize(total, total, 0);
     graph.k = k;
     results.assign(paths.size() * 2, {});
-    std::size_t i = 0;
-    for (std::size_t c = 0; c < paths.size(); ++c) {
-        const bool used = c < orient.size() && orient[c] >= 0;
-        TravelSequence *res = used ? &results[2 * c + (orient[c] ? 0 : 1)] : nullptr;
-        if (res) res->reserve(paths[c].size());
-        for (auto &n : paths[c]) {
-            graph.nodeCode[i] = n.code;
-            graph.posOff[i] = i;
-            graph.posCtg[i] = n.ctg;
-            graph.posRef[i] = n.ref;
-            graph.posCnt[i] = n.cnt;
-            if (res) res->emplace_back(Vertex{static_cast<std::uint32_t>(i), 0u}, n.step);
-            ++i;
+    std::atomic<std::size_t> next{0};
+    auto worker = [&]() {
+        for (std::size_t c; (c = next.fetch_add(1)) < paths.size();) {
+            const bool used = c < orient.size() && orient[c] >= 0;
+            TravelSequence *res = used ? &results[2 * c + (orient[c] ? 0 : 1)] : nullptr;
+            const pag_path_node *p = paths[c].first;
+            const std::size_t n = paths[c].second;
+            if (res) res->resize(n);
+            std::size_t i = base[c];
+            for (std::size_t x = 0; x < n; ++x, ++i) {
+                graph.nodeCode[i] = p[x].code;
+                graph.posOff[i] = i;
+                graph.posCtg[i] = p[x].ctg;
+                graph.posRef[i] = p[x].ref;
+                graph.posCnt[i] = p[x].cnt;
+                if (res) (*res)[x] = {Vertex{static_cast<std::uint32_t>(i), 0u}, p[x].step};
+            }
         }
-    }
+    };
+    unsigned nThreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, paths.size())));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
     if (total) graph.posOff[total] = total;
 }
 

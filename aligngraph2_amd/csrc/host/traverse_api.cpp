@@ -79,14 +79,14 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
                 setErr("pag_travel: %s", pag_last_error());
                 return rc;
             }
-            std::vector<std::vector<pag_path_node>> paths(ctgs->n_seqs);
+            std::vector<std::pair<const pag_path_node *, std::uint64_t>> paths(ctgs->n_seqs);
             for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c) {
                 std::uint64_t len = 0;
                 const pag_path_node *p = pag_travel_path(g, c, &len);
-                if (p && len) paths[c].assign(p, p + len);
+                paths[c] = {p, p ? len : 0};
             }
             const double tg0 = nowMs();
-            pagh::buildPathGraph(paths, orient, k, graph, precomputed);
+            pagh::buildPathGraph(paths, orient, k, graph, precomputed, host_threads);
             t1 = nowMs();
             if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
         } else {
