@@ -321,6 +321,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         cs.revRight = (uint32_t)mapper.dualToSingle(-cs.chosenOne, cs.len);
         cs.nodesOff = nodes_total;
         cs.seqCap = (uint64_t)cs.len / 2 + 8192;
+        if (const char *e = std::getenv("PAG_DEBUG_SEQCAP")) cs.seqCap = std::max(16, std::atoi(e));  // tests: force the overflow / regrow path
         nodes_total += cs.len >= k ? cs.len - k + 1 : 0;
         st.push_back(std::move(cs));
     }

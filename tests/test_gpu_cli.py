@@ -49,3 +49,18 @@ def test_pagraph_matches_reference_binary_on_fresh_input(seed, threads, workdir)
         if f == "contig.txt":
             a, b = sorted(a.split()), sorted(b.split())
         assert a == b, f"{f} differs from the reference binary's output"
+
+
+@pytest.mark.gpu
+def test_walker_regrows_its_buffers_and_stays_exact(workdir, monkeypatch):
+    """Tiny initial walk buffers: every contig overflows and is re-posted with doubled capacity until the walk fits."""
+    name = goldens.case_names()[0]
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / "regrow" / "in"))
+    out = str(workdir / "regrow" / "out")
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    env = dict(os.environ, PAG_DEBUG_SEQCAP="48")
+    r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    goldens.compare_out_dir(name, out)
