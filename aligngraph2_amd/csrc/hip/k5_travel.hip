@@ -374,6 +374,9 @@ __device__ __forceinline__ SuccRec rec_load(const WalkLds &L, const WalkCtx &X, 
     const uint32_t e = idx - X.w_r0;
     const bool in = e < X.w_nrec;
     SuccRec r = L.wrec[in ? e : 0u];  // always an LDS read; the global read only under its own (rare) branch
+    // pinning the LDS result in registers keeps the compiler from sinking the two reads into one FLAT load
+    // through a selected pointer (a flat load of LDS data is slower and waits on both memory counters)
+    asm volatile("" : "+v"(r.tgt), "+v"(r.pc), "+v"(r.meta), "+v"(r.toff));
     if (!in) r = X.G.succ[idx];
     return r;
 }
@@ -1084,7 +1087,7 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
 }
 
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
-__device__ __attribute__((noinline)) void walk_job(WalkLds &L, const TravGraph &G, const TravContig &C, const TravJob &Jsrc, TravJobOut *out, uint32_t k) {
+__device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const TravContig &C, const TravJob &Jsrc, TravJobOut *out, uint32_t k) {
     const uint32_t lane = lane_id();
     const TravJob J = Jsrc;  // by value: the record may live in host memory
     WalkCtx X;

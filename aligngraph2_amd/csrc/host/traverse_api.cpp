@@ -61,6 +61,7 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
         pagh::HostGraph graph;
         std::vector<pagh::TravelSequence> precomputed;
         double t1;
+        pag_travel_stats tstAll{};
         if (deviceWalk) {
             pag_travel_params tp{};
             tp.ref_threads = ref_threads;
@@ -79,6 +80,7 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
                 setErr("pag_travel: %s", pag_last_error());
                 return rc;
             }
+            tstAll = tst;
             std::vector<std::pair<const pag_path_node *, std::uint64_t>> paths(ctgs->n_seqs);
             for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c) {
                 std::uint64_t len = 0;
@@ -118,6 +120,12 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
             stats->ms_export = t1 - t0;
             stats->ms_traverse = t2 - t1;
             stats->ms_total = t2 - t0;
+            stats->ms_successors = tstAll.ms_compact;
+            stats->ms_walk = tstAll.ms_walk;
+            stats->walk_rounds = tstAll.rounds;
+            stats->walk_jobs = tstAll.jobs;
+            stats->walk_steps = tstAll.walk_steps;
+            stats->walk_classifications = tstAll.classify_calls;
         }
         return PAG_OK;
     } catch (const std::exception &e) {

@@ -39,7 +39,9 @@ SORT_BYTES_PER_RECORD = 24.0  # one read + one write of every 12
 class TraverseStats(C.Structure):
     _fields_ = [("n_contigs", C.c_uint64), ("n_path_nodes", C.c_uint64), ("n_path_bases", C.c_uint64),
                 ("n_chains_emitted", C.c_uint64), ("n_fasta_bases", C.c_uint64), ("path_checksum", C.c_uint64),
-                ("ms_export", C.c_double), ("ms_traverse", C.c_double), ("ms_total", C.c_double)]
+                ("ms_export", C.c_double), ("ms_traverse", C.c_double), ("ms_total", C.c_double),
+                ("ms_successors", C.c_double), ("ms_walk", C.c_double), ("walk_rounds", C.c_uint64), ("walk_jobs", C.c_uint64),
+                ("walk_steps", C.c_uint64), ("walk_classifications", C.c_uint64)]
 
 
 def load_libs():
@@ -246,6 +248,13 @@ def main():
                 "ms_traverse_host_epilogue": ts.ms_traverse,
                 "build_only_bases_per_s": w.n_bases / (float(np.mean(build_ms)) * 1e-3),
                 "path_bases": int(ts.n_path_bases), "chains": int(ts.n_chains_emitted),
+                # the traversal is a latency-bound serial chain (no HBM roofline): what bounds it is the longest
+                # chain of dependent walk steps and the time per step, reported here instead
+                "ms_successor_records": ts.ms_successors, "ms_walk": ts.ms_walk,
+                "walk_jobs": int(ts.walk_jobs), "walk_rounds_longest_chain": int(ts.walk_rounds),
+                "walk_path_vertices": int(ts.walk_steps), "walk_classifications": int(ts.walk_classifications),
+                "time_share": "walks (latency-bound, k_walk_persistent) dominate the step; the roofline object grades the "
+                              "dominant BANDWIDTH-bound kernel of the build",
             },
             "roofline": {"bound": "hbm", "kernel": "pagdev::sort_scatter (k-mer sort, one radix pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -21,6 +21,10 @@ typedef struct pagh_traverse_stats {
     uint64_t n_fasta_bases;
     uint64_t path_checksum;    /* order-independent hash of (contig, path vertices): cheap cross-checks */
     double ms_export, ms_traverse, ms_total; /* host wall clock */
+    /* device traversal (copied from pag_travel_stats; zero for the host walk) */
+    double ms_successors, ms_walk;           /* successor records; walk event loop */
+    uint64_t walk_rounds, walk_jobs;         /* longest chain of rounds over the contigs; (contig, seed) walks */
+    uint64_t walk_steps, walk_classifications; /* path vertices produced; successor classifications evaluated */
 } pagh_traverse_stats;
 
 /* ctgs / refs: HOST memory, 2-bit packed (pag_seqs).  names may be NULL ("ctg<i>" / "ref<i+1>").
