@@ -215,9 +215,12 @@ __global__ void k_order_apply(const uint64_t *__restrict__ sorted_old, uint64_t 
 
 template <bool FILL>
 __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt) {
-    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < G.n_pos; u += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t v = G.uold[u];
-        const uint64_t rootp = G.upos[u];
+    // Threads run over the vertices in k-mer-major order (the order of the CSR): neighbouring threads belong to the
+    // same k-mer node, so the node's edge list and the position lists of its target nodes are shared through the
+    // caches; only the per-vertex results go to coordinate-ordered (random) places.
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t u = G.newid[v];
+        const uint64_t rootp = G.vpos[v];
         const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
         const uint32_t node = G.vnode[v];
         uint32_t n = 0;
