@@ -154,6 +154,30 @@ def main():
     if not g:
         raise SystemExit(f"pag_create_from_bitmap failed ({err.value}): {hip.pag_last_error().decode()}")
 
+    # the solid set, the way the pipeline gets it: kmer_counter on the device over the resident reads.
+    # Not part of `value` (the reference runs it as a separate program before pagraph); its result must equal the set
+    # the generator computed with torch, bit for bit (code k aside: the file header quirk Q1 puts it into the set).
+    kc = None
+    if rank == 0 and world == 1 and spec.k <= 14:
+        class KmerCountResult(C.Structure):
+            _fields_ = [("min_abundance", C.c_uint64), ("n_solid", C.c_uint64), ("n_kmers_counted", C.c_uint64),
+                        ("ms_count", C.c_double), ("ms_select", C.c_double)]
+        hip.pag_kmer_count.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        hip.pag_kmer_count.restype = C.c_int
+        kres = KmerCountResult()
+        bm = torch.zeros(4 ** spec.k // 32 + 8, dtype=torch.int32, device=f"cuda:{local}")
+        rc = hip.pag_kmer_count(C.byref(inp.reads), 1, spec.k, spec.solid_threshold, local, bm.data_ptr(), 1, C.byref(kres))
+        if rc != 0:
+            raise SystemExit(f"pag_kmer_count failed ({rc}): {hip.pag_last_error().decode()}")
+        torch.cuda.synchronize()
+        diff = torch.nonzero(bm[:4 ** spec.k // 32] != w.solid_bits[:4 ** spec.k // 32]).squeeze(1).tolist()
+        if kres.min_abundance != w.min_abundance or diff not in ([], [spec.k >> 5]):
+            raise SystemExit(f"device k-mer counter disagrees with the generator: min {kres.min_abundance} vs {w.min_abundance}, "
+                             f"{len(diff)} differing words")
+        kc = {"ms_count": kres.ms_count, "ms_select": kres.ms_select, "min_abundance": int(kres.min_abundance),
+              "bases_per_s": w.n_bases / ((kres.ms_count + kres.ms_select) * 1e-3)}
+        del bm
+
     # host copies of the contigs / reference for the traversal epilogue (sequence gap filling)
     ref_np = w.ref.cpu().numpy()
     ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
@@ -261,6 +285,7 @@ def main():
                 "ms_successor_records": ts.ms_successors, "ms_walk": ts.ms_walk,
                 "walk_jobs": int(ts.walk_jobs), "walk_rounds_longest_chain": int(ts.walk_rounds),
                 "walk_path_vertices": int(ts.walk_steps), "walk_classifications": int(ts.walk_classifications),
+                "kmer_counter_on_device": kc,
                 "time_share": "walks (latency-bound, k_walk_persistent) dominate the step; the roofline object grades the "
                               "dominant BANDWIDTH-bound kernel of the build",
             },

@@ -217,6 +217,24 @@ typedef struct pag_travel_stats {
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *params, pag_travel_stats *stats);
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);
+/* ---- kmer_counter on the device (replaces PAGraph/src/main/kmer_counter.cpp:19-96) ----------------
+ * Counts every k-mer of the forward strand of every read (KmerHelper::kmer2Code, KmerHelper.cpp:7-25) in a dense 4^k
+ * table, derives the minimum abundance by the reference's rule (the first occurring abundance a, ascending, with
+ * 1 - #{codes with abundance <= a} / 4^k <= threshold; 0 if none) and returns the solid set {abundance >= minimum}
+ * as a 4^k-bit bitmap (bit c of word c >> 5) — the form pag_create_from_bitmap() takes, and what the kmer_counter
+ * executable of this package writes out as the reference's `-k` file.
+ * reads: pag_seqs in host memory (reads_on_device = 0) or device memory (1; every read 4-byte aligned and followed by
+ * at least 8 readable bytes).  bitmap: 4^k / 8 bytes (at least 4), host or device (bitmap_on_device).  k = 1..16
+ * (the reference's own table size overflows at k = 16, quirk Q13; here k = 16 means 2^32 codes). */
+typedef struct pag_kmer_count_result {
+    uint64_t min_abundance;
+    uint64_t n_solid;
+    uint64_t n_kmers_counted; /* k-mer occurrences (0 if some abundance exceeded the histogram range) */
+    double ms_count, ms_select; /* device time: count + histogram; bitmap */
+} pag_kmer_count_result;
+int pag_kmer_count(const pag_seqs *reads, int reads_on_device, uint32_t k, double threshold, int device, uint32_t *bitmap,
+                   int bitmap_on_device, pag_kmer_count_result *res);
+
 const char *pag_last_error(void);
 /* 1 if a gfx950 device is present and the code object loads */
 int pag_device_available(void);

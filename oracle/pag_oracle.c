@@ -563,3 +563,68 @@ int pago_export_csr(const pago_graph *g, pag_csr *out) {
     out->n_edges = ne;
     return PAG_OK;
 }
+
+/* ================================================================ kmer_counter
+ * kmer_counter.cpp:19-96.  One dense size_t table like the reference's (the four partial tables are summed there
+ * before use, :59-66); abundances visited through a sorted list of the occurring values like its std::map. */
+
+int pago_kmer_count(const pag_seqs *reads, uint32_t k, double threshold, uint64_t *min_abundance, uint32_t *bitmap) {
+    if (!reads || !bitmap || k < 1 || k > 15) return PAG_EINVAL;
+    const uint64_t n_codes = 1ull << (2 * k);
+    const uint64_t mask = n_codes - 1;
+    uint64_t *table = (uint64_t *)calloc(n_codes, sizeof(uint64_t));
+    if (!table) return PAG_ENOMEM;
+    for (uint64_t r = 0; r < reads->n_seqs; ++r) {
+        const uint8_t *p = reads->packed + reads->byte_off[r];
+        const uint64_t len = reads->len[r];
+        /* KmerHelper::kmer2Code (KmerHelper.cpp:7-25) on the unpacked bases */
+        uint64_t code = 0;
+        for (uint64_t i = 0; i < len; ++i) {
+            const uint64_t b = (p[i >> 2] >> (2 * (i & 3))) & 3u;
+            code = ((code << 2) | b) & mask;
+            if (i + 1 >= k) ++table[code];
+        }
+    }
+    /* mergeMap (:57-66): occurring abundances with their multiplicities, ascending */
+    uint64_t *sorted = (uint64_t *)malloc(n_codes * sizeof(uint64_t));
+    if (!sorted) {
+        free(table);
+        return PAG_ENOMEM;
+    }
+    memcpy(sorted, table, n_codes * sizeof(uint64_t));
+    qsort(sorted, n_codes, sizeof(uint64_t), cmp_u64);
+    uint64_t sum = 0, min_ab = 0;
+    for (uint64_t i = 0; i < n_codes;) {
+        uint64_t j = i;
+        while (j < n_codes && sorted[j] == sorted[i]) ++j;
+        sum += j - i;
+        if (1 - sum * 1.0 / (double)n_codes <= threshold) { /* :71-76 */
+            min_ab = sorted[i];
+            break;
+        }
+        i = j;
+    }
+    free(sorted);
+    const uint64_t n_words = (n_codes + 31) / 32;
+    memset(bitmap, 0, n_words * 4);
+    for (uint64_t c = 0; c < n_codes; ++c)
+        if (table[c] >= min_ab) bitmap[c >> 5] |= 1u << (c & 31);
+    free(table);
+    if (min_abundance) *min_abundance = min_ab;
+    return PAG_OK;
+}
+
+uint64_t pago_kmer_file_words(const uint32_t *bitmap, uint32_t k, uint32_t threads, uint64_t *out, uint64_t cap) {
+    const uint64_t n_codes = 1ull << (2 * k);
+    uint64_t n = 0;
+    if (out && n < cap) out[n] = k;
+    ++n;
+    if (threads == 0) threads = 1;
+    for (uint32_t t = 0; t < threads; ++t) /* MultiThreadTools::traversalHelper: i = t, t + T, ... */
+        for (uint64_t c = t; c < n_codes; c += threads)
+            if ((bitmap[c >> 5] >> (c & 31)) & 1u) {
+                if (out && n < cap) out[n] = c;
+                ++n;
+            }
+    return n;
+}

@@ -48,6 +48,15 @@ int pago_check_position(uint32_t a_ctg, uint32_t a_ref, uint32_t b_ctg, uint32_t
 int pago_edge_similar(uint32_t a_ctg, uint32_t a_ref, uint32_t b_ctg, uint32_t b_ref, int dist, uint64_t deviation,
                       double error_rate);
 
+/* ---- kmer_counter (PAGraph/src/main/kmer_counter.cpp:19-96), for the device k-mer counter ----
+ * reads: host pag_seqs (2-bit packed).  Counts every forward-strand k-mer (kmer2Code), applies the abundance rule
+ * (:59-77) and fills the solid bitmap (4^k bits, bit c of word c >> 5).  Pinned against oracle/_ref/kmer_counter. */
+int pago_kmer_count(const pag_seqs *reads, uint32_t k, double threshold, uint64_t *min_abundance, uint32_t *bitmap);
+/* the file the reference writes (:79-95): k as u64, then the solid codes as u64, thread t of `threads` contributing
+ * the codes c with c % threads == t in ascending order, t = 0 .. threads-1.  Returns the number of u64 words; writes
+ * them to out when out != NULL (capacity cap words). */
+uint64_t pago_kmer_file_words(const uint32_t *bitmap, uint32_t k, uint32_t threads, uint64_t *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif
