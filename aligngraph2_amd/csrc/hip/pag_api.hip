@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "pag_device.hpp"
@@ -108,21 +109,36 @@ pag_graph *pag_create(const uint64_t *codes, uint64_t n_codes, uint32_t k, int d
     if (rc == PAG_OK) {
         g->device = device_ordinal;
         g->k = k;
-        // PABruijnGraph::PABruijnGraph: sort + unique of every word (PABruijnGraph.cpp:32-34)
-        std::vector<uint64_t> sorted(codes, codes + n_codes);
-        std::sort(sorted.begin(), sorted.end());
-        sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
-        g->n_solid = sorted.size();
+        // PABruijnGraph::PABruijnGraph: sort + unique of every word (PABruijnGraph.cpp:32-34).  The set itself is all
+        // that is needed: a bitmap over the 4^k code space (read k-mers are masked to 2k bits, larger words can never
+        // match) and the number of distinct words; the bits are set by a pool of threads, no copy and no sort.
         const uint64_t space = 1ull << (2 * k);
         const uint64_t words = (space + 31) / 32;
         std::vector<uint32_t> bits((size_t)words, 0u);
-        uint64_t in_space = 0;
-        for (uint64_t c : sorted) {
-            if (c < space) {  // read k-mers are masked to 2k bits; larger words can never match
-                bits[(size_t)(c >> 5)] |= 1u << (c & 31);
-                ++in_space;
-            }
+        std::vector<uint64_t> outside;
+        {
+            unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            if (n_codes < (1u << 20)) T = 1;
+            std::vector<std::vector<uint64_t>> out_t(T);
+            auto work = [&](unsigned t) {
+                const uint64_t lo = n_codes * t / T, hi = n_codes * (t + 1) / T;
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const uint64_t c = codes[i];
+                    if (c < space) __atomic_fetch_or(&bits[(size_t)(c >> 5)], 1u << (c & 31), __ATOMIC_RELAXED);
+                    else out_t[t].push_back(c);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto &th : pool) th.join();
+            for (auto &v : out_t) outside.insert(outside.end(), v.begin(), v.end());
         }
+        std::sort(outside.begin(), outside.end());
+        outside.erase(std::unique(outside.begin(), outside.end()), outside.end());
+        uint64_t in_space = 0;
+        for (uint32_t wbits : bits) in_space += (uint64_t)__builtin_popcount(wbits);
+        g->n_solid = in_space + outside.size();
         g->all_solid = in_space == space;
         hipError_t e = hipStreamCreate(&g->stream);
         if (e == hipSuccess) e = hipMalloc((void **)&g->solid_bits, (size_t)words * 4 + 64);

@@ -60,6 +60,7 @@ public:
     void sortByScore();
 
 private:
+    bool loadMecatParallel(const std::string &path);
     std::vector<AlnRecord> recs_;
     std::vector<std::uint32_t> diff_;
 };

@@ -1,8 +1,11 @@
 #include "seq_db.hpp"
 
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+
+#include "line_index.hpp"
 
 namespace pagh {
 
@@ -81,7 +84,7 @@ SeqDb::SeqDb(const std::string &path) {
             }
         }
         if (!header.empty()) add(header, buffer);
-    } else {
+    } else if (!loadFastqParallel(path)) {
         // 4-line FASTQ records; a trailing partial record is dropped (SeqHelper.cpp:13-26)
         std::string l1, l2, l3, l4;
         while (std::getline(in, l1) && std::getline(in, l2) && std::getline(in, l3) && std::getline(in, l4)) {
@@ -89,6 +92,58 @@ SeqDb::SeqDb(const std::string &path) {
         }
     }
     finish();
+}
+
+// The same records as the sequential loop above, with the lines found and the reads packed by a pool of threads.
+// Returns false (nothing loaded) when a header line has no token: the reference then re-uses the previous
+// record's name (AutoSeqDatabase.cpp:12), a cross-record dependency that is left to the sequential path.
+bool SeqDb::loadFastqParallel(const std::string &path) {
+    FileLines fl;
+    if (!fl.load(path)) return false;
+    const std::size_t nRec = fl.size() / 4;
+    if (nRec == 0) return true;
+    // token of every header line
+    std::vector<std::pair<std::uint32_t, std::uint32_t>> tok(nRec);  // (offset in line, length)
+    std::atomic<bool> plain{true};
+    parallelFor(nRec, 4096, [&](std::size_t r) {
+        const char *p = fl.data(4 * r);
+        const std::size_t n = fl.length(4 * r);
+        std::size_t a = 0;
+        while (a < n && isSpaceC(p[a])) ++a;
+        std::size_t b = a;
+        while (b < n && !isSpaceC(p[b])) ++b;
+        if (a == b) plain = false;
+        tok[r] = {static_cast<std::uint32_t>(a), static_cast<std::uint32_t>(b - a)};
+        if (fl.length(4 * r + 1) > 0xFFFFFFFFull) plain = false;
+    });
+    if (!plain) return false;
+    const std::size_t first = names_.size();
+    names_.resize(first + nRec);
+    len_.resize(first + nRec);
+    byteOff_.resize(first + nRec);
+    std::size_t cursor = packed_.size();
+    for (std::size_t r = 0; r < nRec; ++r) {
+        const std::size_t n = fl.length(4 * r + 1);
+        len_[first + r] = static_cast<std::uint32_t>(n);
+        byteOff_[first + r] = cursor;
+        cursor += (((n + 3) / 4) + 3) & ~std::size_t(3);
+        totalBases_ += n;
+    }
+    packed_.resize(cursor, 0);
+    parallelFor(nRec, 256, [&](std::size_t r) {
+        names_[first + r].assign(fl.data(4 * r) + tok[r].first + 1, tok[r].second - 1);
+        const char *sq = fl.data(4 * r + 1);
+        const std::size_t n = len_[first + r];
+        std::uint8_t *out = packed_.data() + byteOff_[first + r];
+        std::size_t i = 0;
+        for (; i + 4 <= n; i += 4)
+            out[i >> 2] = static_cast<std::uint8_t>(encodeBase(sq[i]) | (encodeBase(sq[i + 1]) << 2) | (encodeBase(sq[i + 2]) << 4) |
+                                                    (encodeBase(sq[i + 3]) << 6));
+        for (; i < n; ++i) out[i >> 2] |= static_cast<std::uint8_t>(encodeBase(sq[i]) << ((i & 3) * 2));
+    });
+    for (std::size_t r = 0; r < nRec; ++r) nameToId_[names_[first + r]] = first + r;  // later duplicates win
+    lastName_.assign(fl.data(4 * (nRec - 1)) + tok[nRec - 1].first, tok[nRec - 1].second);
+    return true;
 }
 
 std::string SeqDb::toString(std::size_t id, bool forward) const {

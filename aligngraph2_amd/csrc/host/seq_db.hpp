@@ -44,6 +44,7 @@ public:
     void finish();  // pads the packed buffer
 
 private:
+    bool loadFastqParallel(const std::string &path);
     std::vector<std::string> names_;
     std::vector<std::uint32_t> len_;
     std::vector<std::uint64_t> byteOff_;
