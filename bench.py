@@ -138,9 +138,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # test hook: several ranks on ONE device (RCCL refuses duplicate devices, so the group is gloo then); lets a
+    # single-GPU box exercise the N > 1 control path.  Never set for a real measurement.
+    one_device = os.environ.get("PAG_BENCH_SINGLE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     from aligngraph2_amd import parallel
-    dist = parallel.init("nccl")  # RCCL; only the barrier and two 8-byte all-reduces use it
+    dist = parallel.init("gloo" if one_device else "nccl")  # RCCL; only the barrier and two 8-byte all-reduces use it
 
     import biggen
     hip, host = load_libs()
@@ -237,7 +242,7 @@ def main():
         trav_ms.append(ts.ms_total)
     sync()
     dt = time.perf_counter() - t0
-    dt_max, total_bases = parallel.aggregate(dist, dt, float(w.n_bases), device=f"cuda:{local}")
+    dt_max, total_bases = parallel.aggregate(dist, dt, float(w.n_bases), device="cpu" if one_device else f"cuda:{local}")
 
     if rank == 0:
         ms_sort = float(np.mean(sort_ms))
