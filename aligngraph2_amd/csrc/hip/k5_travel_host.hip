@@ -460,7 +460,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         g->wq_bytes = q_need;
     }
     if (!g->wq_next) PAG_HIP_TRY(hipMalloc((void **)&g->wq_next, 256));
-    if (!g->walk_stream) PAG_HIP_TRY(hipStreamCreateWithFlags(&g->walk_stream, hipStreamNonBlocking));
+    if (!g->walk_stream) {
+        // the resident grid gets a stream of its own priority class: the runtime multiplexes streams onto a few
+        // hardware queues, and work of this call's side stream must never be queued behind the walker
+        int lo = 0, hi = 0;
+        PAG_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PAG_HIP_TRY(hipStreamCreateWithPriority(&g->walk_stream, hipStreamNonBlocking, hi));
+    }
     TravQueue *hq = (TravQueue *)g->wq_host;
     TravPosted *hjobs = (TravPosted *)((char *)g->wq_host + 256);
     TravJobOut *houts = (TravJobOut *)(hjobs + QCAP);
