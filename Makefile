@@ -15,7 +15,7 @@ HIP_DIR  := aligngraph2_amd/csrc/hip
 B        := build
 
 HOST_SRCS := $(wildcard $(HOST_DIR)/*.cpp)
-HOST_LIB_SRCS := $(filter-out $(HOST_DIR)/pagraph_main.cpp $(HOST_DIR)/kmer_counter_main.cpp,$(HOST_SRCS))
+HOST_LIB_SRCS := $(filter-out $(HOST_DIR)/pagraph_main.cpp $(HOST_DIR)/kmer_counter_main.cpp $(HOST_DIR)/pre_process_main.cpp,$(HOST_SRCS))
 HOST_OBJS := $(patsubst $(HOST_DIR)/%.cpp,$(B)/host/%.o,$(HOST_LIB_SRCS))
 HIP_SRCS  := $(wildcard $(HIP_DIR)/*.hip)
 HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pagraph_hip.h
@@ -23,7 +23,7 @@ HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pag
 .PHONY: all product harness oracle clean
 all: product harness oracle
 
-product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph aligngraph2_amd/bin/kmer_counter aligngraph2_amd/libpagraph_host.so
+product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph aligngraph2_amd/bin/kmer_counter aligngraph2_amd/bin/pre_process aligngraph2_amd/libpagraph_host.so
 
 $(B)/host/%.o: $(HOST_DIR)/%.cpp $(wildcard $(HOST_DIR)/*.hpp) include/pagraph_hip.h
 	@mkdir -p $(B)/host
@@ -42,6 +42,11 @@ aligngraph2_amd/bin/pagraph: $(HOST_DIR)/pagraph_main.cpp $(B)/libpagh_host.a al
 aligngraph2_amd/bin/kmer_counter: $(HOST_DIR)/kmer_counter_main.cpp $(B)/libpagh_host.a aligngraph2_amd/libpagraph_hip.so
 	@mkdir -p aligngraph2_amd/bin
 	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/libpagh_host.a -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/..' -pthread
+
+# host-only tool (no device work in the reference either)
+aligngraph2_amd/bin/pre_process: $(HOST_DIR)/pre_process_main.cpp $(HOST_DIR)/line_index.hpp
+	@mkdir -p aligngraph2_amd/bin
+	$(CXX) $(CXXFLAGS) -o $@ $< -pthread
 
 aligngraph2_amd/libpagraph_host.so: $(B)/libpagh_host.a aligngraph2_amd/libpagraph_hip.so
 	$(CXX) -shared -o $@ -Wl,--whole-archive $(B)/libpagh_host.a -Wl,--no-whole-archive -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN' -pthread
