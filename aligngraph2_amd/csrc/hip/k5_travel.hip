@@ -166,6 +166,23 @@ __device__ __forceinline__ void hs_insert(uint32_t *tab, uint32_t mask, uint32_t
         if (old == HS_EMPTY || old == key) return;
     }
 }
+// epoch-tagged travel set: entry = key | epoch << 32, empty = all ones; lookup returns the epoch (0 = absent)
+#define HS64_EMPTY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ uint32_t hs64_epoch(const uint64_t *tab, uint32_t mask, uint32_t key) {
+    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
+        const uint64_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x == HS64_EMPTY) return 0u;
+        if ((uint32_t)x == key) return (uint32_t)(x >> 32);
+    }
+}
+// concurrent insert of distinct keys (a key is inserted once per job: a vertex is appended once)
+__device__ __forceinline__ void hs64_insert(uint64_t *tab, uint32_t mask, uint32_t key, uint32_t epoch) {
+    const unsigned long long want = (unsigned long long)key | ((unsigned long long)epoch << 32);
+    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
+        const unsigned long long old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)HS64_EMPTY, want);
+        if (old == (unsigned long long)HS64_EMPTY || (uint32_t)old == key) return;
+    }
+}
 // generation-tagged set: entry = key | gen << 32; an entry of another generation counts as free
 __device__ __forceinline__ bool gs_has(const uint64_t *tab, uint32_t mask, uint32_t key, uint32_t gen) {
     for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
@@ -299,7 +316,8 @@ struct WalkLds {
     uint32_t br_pc[BR_CAP], br_off[BR_CAP], br_cnt[BR_CAP];
     SuccRec wrec[WIN_REC];
     uint32_t wst[PROBE_GROUPS][WIN_IDS];
-    uint32_t wtb[WIN_IDS / 32], wgb[WIN_IDS / 32];
+    uint32_t wts[WIN_IDS];       // travel-visited epoch of the window's vertices
+    uint32_t wgb[WIN_IDS / 32];  // global-visited bits
     uint32_t wab[WIN_IDS];  // abundance of the window's vertices (choice among branching alternatives)
     // the classification a probe stopped at (END / BRANCH): every accepted record with its class, in record order.
     // After the chosen path is appended, graphTravel's own classification of its last vertex is this list minus
@@ -342,8 +360,9 @@ struct WalkCtx {
     // visited state of this job: stamps for vertices on the contig strand, small hash sets for the rest
     uint32_t *stamp;   // walkStraight uniqueTable marks: PROBE_GROUPS arrays of [in_hi - in_lo] generation stamps
     uint32_t stamp_stride;
-    uint32_t *tbits;   // travelUniqueTable over [in_lo, in_hi): one bit per vertex
-    uint32_t *tset_o;  // travelUniqueTable, vertices outside the strand's id range
+    uint32_t *tbits;   // travelUniqueTable over [in_lo, in_hi): epoch of the append per vertex, 0 = not visited
+    uint64_t *tset_o;  // travelUniqueTable, vertices outside the strand's id range: (vertex | epoch << 32)
+    uint32_t epoch;    // graphTravel iteration: marks with a later epoch do not exist yet for a probe of this one
     uint32_t tmask_o;
     uint64_t *pset_o;  // walkStraight uniqueTable, outside the range: PROBE_GROUPS tables of pmask_o + 1 entries
     uint32_t pmask_o;
@@ -429,9 +448,15 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
                 __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wab[b], 4, 0, 0);
             }
         }
+        {
+            const uint32_t *src = X.tbits + d0;
+            for (uint32_t b = 0; b < nid; b += 64u) {
+                const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
+                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wts[b], 4, 0, 16);
+            }
+        }
         const uint32_t nw = (nid + 31u) / 32u;  // <= 64
         const uint32_t w = lane < nw ? lane : nw - 1u;
-        __builtin_amdgcn_global_load_lds((const void *)(X.tbits + (d0 >> 5) + w), (lds_ptr_t)&L.wtb[0], 4, 0, 16);
         if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + (d0 >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
         else L.wgb[lane] = 0u;
     }
@@ -478,7 +503,7 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
 // strand vertex outside the window, a filter hit, a probe with more than two outside vertices, a leap —
 // are resolved afterwards under one branch each.
 __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
-                                           uint32_t grp, const ProbeOut po) {
+                                           uint32_t grp, const ProbeOut po, uint32_t epoch) {
     const uint32_t v = rec.tgt, pc = rec.pc;
     const uint32_t grade = (rec.meta >> 24) & 7u;
     const bool ectg = (rec.meta >> 27) & 1u;
@@ -487,21 +512,27 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, c
     const bool inw = inr & (e < X.w_nid);
     const uint32_t ei = inw ? e : 0u;
     const uint32_t bit = 1u << (ei & 31u);
-    const uint32_t tww = L.wtb[ei >> 5], gww = L.wgb[ei >> 5], stw = L.wst[grp][ei];
+    const uint32_t tsw = L.wts[ei], gww = L.wgb[ei >> 5], stw = L.wst[grp][ei];
     const FiltKey fk = filt_key(v);
     const uint64_t ftw = L.ft[fk.word], fgw = L.fg[fk.word];
-    bool tvis = inw & ((tww & bit) != 0u);
+    bool tvis = inw & (tsw != 0u) & (tsw <= epoch);
     bool gvis = inw & ((gww & bit) != 0u);
     bool pvis = (inw & (stw == X.gen)) | (!inr & (((po.n >= 1u) & (v == po.v0)) | ((po.n >= 2u) & (v == po.v1))));
     const bool fth = !inr & ((ftw & fk.mask) == fk.mask), fgh = !inr & ((fgw & fk.mask) == fk.mask);
     if ((inr & !inw) | fth | fgh | (!inr & (po.n > 2u))) {
         if (inr) {
-            tvis = (stamp_load(&X.tbits[d >> 5]) >> (d & 31u)) & 1u;
+            {
+                const uint32_t ts = stamp_load(&X.tbits[d]);
+                tvis = (ts != 0u) & (ts <= epoch);
+            }
             gvis = X.C.gbits ? (X.C.gbits[d >> 5] >> (d & 31u)) & 1u : false;
             if (level == 2) pvis = stamp_load(&X.stamp[(uint64_t)grp * X.stamp_stride + d]) == X.gen;
         } else {
             if (fgh) gvis = hs_has(X.C.gset, X.C.gmask, v);
-            if (fth) tvis = hs_has(X.tset_o, X.tmask_o, v);
+            if (fth) {
+                const uint32_t ts = hs64_epoch(X.tset_o, X.tmask_o, v);
+                tvis = (ts != 0u) & (ts <= epoch);
+            }
             if (level == 2 && po.n > 2u) pvis = gs_has(X.pset_o + (uint64_t)grp * ((uint64_t)X.pmask_o + 1), X.pmask_o, v, X.gen);
         }
     }
@@ -557,7 +588,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
             rec = have_pre ? pre : rec_load(L, X, r0 + lane);
             // speculative: the target's only successor record, requested together with the stamp
             if ((rec.meta >> 28) == 1u) nx = rec_load(L, X, rec.toff);
-            cls = eval_record(L, X, rec, can_leap, level, 0u, po);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch);
         }
         uint64_t m = __ballot(cls == 0);
         if (!m) m = __ballot(cls == 1);
@@ -603,7 +634,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
         SuccRec rec{0, 0, 0, 0};
         if (rb + lane < r1) {
             rec = rec_load(L, X, rb + lane);
-            cls = eval_record(L, X, rec, can_leap, level, 0u, po);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch);
         }
         for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
             uint64_t m = __ballot(cls == c);
@@ -853,7 +884,7 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
             const uint32_t sg0 = X.win_p0, sg1 = X.win_p1;
             X.win_p0 = wp0;
             X.win_p1 = wp1;
-            cls = eval_record(L, X, rec, can_leap, 2, g, po);
+            cls = eval_record(L, X, rec, can_leap, 2, g, po, X.epoch);
             X.win_p0 = sg0;
             X.win_p1 = sg1;
         }
@@ -1017,7 +1048,7 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
         SuccRec rec{0, 0, 0, 0};
         if (lane < cnt) {
             rec = rec_load(L, X, off + lane);
-            cls = eval_record(L, X, rec, can_leap, 2, grp, po);
+            cls = eval_record(L, X, rec, can_leap, 2, grp, po, X.epoch);
         }
         uint64_t m = __ballot(cls == 0);
         if (!m) m = __ballot(cls == 1);
@@ -1105,6 +1136,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.pmask_o = J.pmask;
     X.n_out = 0;
     X.gen = 0;
+    X.epoch = 0;
     X.win_g0 = X.C.gwin_lo;
     X.win_g1 = X.C.gwin_hi;
     X.win_t0 = 0xFFFFFFFFu;
@@ -1150,6 +1182,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     uint64_t n_main = 0;
     for (;;) {
         ++n_main;
+        X.epoch = (uint32_t)n_main;  // marks appended in this iteration carry it; the probes launched after see all of them
         // append the chosen path to the sequence, mark it visited, widen the travel window
         if (seq_len + ch_len > J.seq_cap) {
             X.overflow = 1;
@@ -1163,11 +1196,11 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 J.seq_v[seq_len + i] = v;
                 J.seq_s[seq_len + i] = st;
                 if (in_range(X, v)) {
-                    atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
+                    stamp_store(&X.tbits[v - X.C.in_lo], X.epoch);
                     const uint32_t e = v - X.C.in_lo - X.w_d0;
-                    if (e < X.w_nid) atomicOr(&L.wtb[e >> 5], 1u << (e & 31u));
+                    if (e < X.w_nid) L.wts[e] = X.epoch;
                 } else {
-                    hs_insert(X.tset_o, X.tmask_o, v);
+                    hs64_insert(X.tset_o, X.tmask_o, v, X.epoch);
                     filt_set(L.ft, v);
                     ++n_outside_chk;
                 }
@@ -1198,11 +1231,11 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 J.seq_v[seq_len + i] = v;
                 J.seq_s[seq_len + i] = st;
                 if (in_range(X, v)) {
-                    atomicOr(&X.tbits[(v - X.C.in_lo) >> 5], 1u << ((v - X.C.in_lo) & 31u));
+                    stamp_store(&X.tbits[v - X.C.in_lo], X.epoch);
                     const uint32_t e = v - X.C.in_lo - X.w_d0;
-                    if (e < X.w_nid) atomicOr(&L.wtb[e >> 5], 1u << (e & 31u));
+                    if (e < X.w_nid) L.wts[e] = X.epoch;
                 } else {
-                    hs_insert(X.tset_o, X.tmask_o, v);
+                    hs64_insert(X.tset_o, X.tmask_o, v, X.epoch);
                     filt_set(L.ft, v);
                     ++n_outside;
                 }

@@ -503,15 +503,15 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             return PAG_ENOMEM;
         }
         const uint64_t cap = cs.seqCap * R.grow, oc = out_cap(cs, R.grow);
-        const uint64_t span = (uint64_t)(cs.inHi - cs.inLo) + 1, tbw = ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+        const uint64_t span = (uint64_t)(cs.inHi - cs.inLo) + 1, tbw = span + 1;  // one travel epoch per strand vertex
         DevBuf b_sv = cbuf(i, CB_SEQV), b_ss = cbuf(i, CB_SEQS), b_av = cbuf(i, CB_ARV), b_as = cbuf(i, CB_ARS), b_ts = cbuf(i, CB_TSET),
                b_ps = cbuf(i, CB_PSET), b_st = cbuf(i, CB_STAMP), b_tb = cbuf(i, CB_TBITS);
         int r;
         if ((r = b_sv.alloc(ns * cap * 4)) || (r = b_ss.alloc(ns * cap * 4)) || (r = b_av.alloc(ns * 4 * cap * 4)) ||
-            (r = b_as.alloc(ns * 4 * cap * 4)) || (r = b_ts.alloc(ns * oc * 4)) || (r = b_ps.alloc(ns * 4 * oc * 8)) ||
+            (r = b_as.alloc(ns * 4 * cap * 4)) || (r = b_ts.alloc(ns * oc * 8)) || (r = b_ps.alloc(ns * 4 * oc * 8)) ||
             (r = b_st.alloc(ns * 4 * span * 4)) || (r = b_tb.alloc(ns * tbw * 4)))
             return r;
-        PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, ns * oc * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, ns * oc * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, ns * 4 * oc * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, ns * 4 * span * 4, s));
         PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, ns * tbw * 4, s));
@@ -535,7 +535,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.stamp = b_st.as<uint32_t>() + sd * 4 * span;
             J.stamp_stride = (uint32_t)span;
             J.tbits = b_tb.as<uint32_t>() + sd * tbw;
-            J.tset = b_ts.as<uint32_t>() + sd * oc;
+            J.tset = b_ts.as<uint64_t>() + sd * oc;
             J.tmask = (uint32_t)oc - 1;
             J.pset = b_ps.as<uint64_t>() + sd * 4 * oc;
             J.pmask = (uint32_t)oc - 1;

@@ -66,8 +66,8 @@ struct TravJob {
     uint64_t arena_cap;
     uint32_t *stamp;  // zeroed: 4 arrays of [stamp_stride] generation stamps (walkStraight marks, one array per probe group)
     uint32_t stamp_stride;
-    uint32_t *tbits;  // zeroed: travel-visited bitmap over the strand's vertices
-    uint32_t *tset;   // hash sets for vertices outside the strand's id range
+    uint32_t *tbits;  // zeroed: travel-visited EPOCH per strand vertex (0 = not visited; epoch = graphTravel iteration of the append)
+    uint64_t *tset;   // all-ones: (vertex | epoch << 32) hash set for vertices outside the strand's id range
     uint32_t tmask;
     uint64_t *pset;
     uint32_t pmask;
