@@ -304,7 +304,8 @@ constexpr uint32_t WIN_IDS = 2048;
 constexpr uint32_t WIN_REC = 4096;
 constexpr uint32_t FILT_WORDS = 1024;  // 64 Ki-bit membership filters in front of the outside-range hash sets
 constexpr uint32_t WIN_BACK = 128;   // ids kept behind the anchor at a refill
-constexpr uint32_t WIN_AHEAD = 160;  // refill when the anchor gets this close to the upper end
+constexpr uint32_t WIN_AHEAD = 160;
+constexpr uint64_t SPEC_MARGIN = 50000;  // bases: no zombie within this distance of the can-leap threshold  // refill when the anchor gets this close to the upper end
 
 struct WalkLds {
     uint32_t lst_v[4][LIST_CAP], lst_s[4][LIST_CAP];
@@ -377,6 +378,7 @@ struct WalkCtx {
     uint32_t n_fill;
     uint32_t n_classify, n_probe, n_records;  // work counters
     int overflow;
+    int spec_fail;  // a zombie probe ended in a leap (or could not be continued): the job has to be redone without speculation
 };
 
 __device__ __forceinline__ bool in_win(uint32_t lo, uint32_t hi, uint32_t p) { return p >= lo && p <= hi; }
@@ -404,11 +406,11 @@ __device__ __forceinline__ SuccRec rec_load(const WalkLds &L, const WalkCtx &X, 
 }
 
 // mark vertex u (on the strand) in probe group grp's generation stamps: global array + window copy
-__device__ __forceinline__ void stamp_put(WalkLds &L, const WalkCtx &X, uint32_t grp, uint32_t u) {
+__device__ __forceinline__ void stamp_put(WalkLds &L, const WalkCtx &X, uint32_t grp, uint32_t u, uint32_t gen) {
     const uint32_t d = u - X.C.in_lo;
-    stamp_store(&X.stamp[(uint64_t)grp * X.stamp_stride + d], X.gen);
+    stamp_store(&X.stamp[(uint64_t)grp * X.stamp_stride + d], gen);
     const uint32_t e = d - X.w_d0;
-    if (e < X.w_nid) L.wst[grp][e] = X.gen;
+    if (e < X.w_nid) L.wst[grp][e] = gen;
 }
 
 // (Re)load the window around strand offset d = anchor - in_lo.  All lanes.  The copies are LDS-direct
@@ -479,6 +481,13 @@ __device__ __forceinline__ bool win_comfortable(const WalkCtx &X, uint32_t cur, 
     return ok | (d >= span);  // a vertex off the strand has nothing to follow
 }
 
+// true if vertex `cur` and its records are inside the window (per lane); vertices off the strand count as served
+__device__ __forceinline__ bool win_serves(const WalkCtx &X, uint32_t cur, uint32_t off, uint32_t cnt) {
+    const uint32_t d = cur - X.C.in_lo, span = X.C.in_hi - X.C.in_lo;
+    const uint32_t e = d - X.w_d0;
+    return ((e < X.w_nid) & (off - X.w_r0 + cnt <= X.w_nrec)) | (d >= span);
+}
+
 // Keep the window around vertex `cur` whose records [off, off + cnt) are about to be read (uniform call).
 __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur, uint32_t off, uint32_t cnt) {
     if (!in_range(X, cur)) return;
@@ -503,7 +512,7 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
 // strand vertex outside the window, a filter hit, a probe with more than two outside vertices, a leap —
 // are resolved afterwards under one branch each.
 __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
-                                           uint32_t grp, const ProbeOut po, uint32_t epoch) {
+                                           uint32_t grp, const ProbeOut po, uint32_t epoch, uint32_t gen) {
     const uint32_t v = rec.tgt, pc = rec.pc;
     const uint32_t grade = (rec.meta >> 24) & 7u;
     const bool ectg = (rec.meta >> 27) & 1u;
@@ -517,7 +526,7 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, c
     const uint64_t ftw = L.ft[fk.word], fgw = L.fg[fk.word];
     bool tvis = inw & (tsw != 0u) & (tsw <= epoch);
     bool gvis = inw & ((gww & bit) != 0u);
-    bool pvis = (inw & (stw == X.gen)) | (!inr & (((po.n >= 1u) & (v == po.v0)) | ((po.n >= 2u) & (v == po.v1))));
+    bool pvis = (inw & (stw == gen)) | (!inr & (((po.n >= 1u) & (v == po.v0)) | ((po.n >= 2u) & (v == po.v1))));
     const bool fth = !inr & ((ftw & fk.mask) == fk.mask), fgh = !inr & ((fgw & fk.mask) == fk.mask);
     if ((inr & !inw) | fth | fgh | (!inr & (po.n > 2u))) {
         if (inr) {
@@ -526,14 +535,14 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, c
                 tvis = (ts != 0u) & (ts <= epoch);
             }
             gvis = X.C.gbits ? (X.C.gbits[d >> 5] >> (d & 31u)) & 1u : false;
-            if (level == 2) pvis = stamp_load(&X.stamp[(uint64_t)grp * X.stamp_stride + d]) == X.gen;
+            if (level == 2) pvis = stamp_load(&X.stamp[(uint64_t)grp * X.stamp_stride + d]) == gen;
         } else {
             if (fgh) gvis = hs_has(X.C.gset, X.C.gmask, v);
             if (fth) {
                 const uint32_t ts = hs64_epoch(X.tset_o, X.tmask_o, v);
                 tvis = (ts != 0u) & (ts <= epoch);
             }
-            if (level == 2 && po.n > 2u) pvis = gs_has(X.pset_o + (uint64_t)grp * ((uint64_t)X.pmask_o + 1), X.pmask_o, v, X.gen);
+            if (level == 2 && po.n > 2u) pvis = gs_has(X.pset_o + (uint64_t)grp * ((uint64_t)X.pmask_o + 1), X.pmask_o, v, gen);
         }
     }
     const bool free_pc = (pc == 0u) | ectg;  // no coordinate, or the edge follows the contig: the window tests do not apply
@@ -575,7 +584,7 @@ struct Step {
     SuccRec next;
 };
 
-__device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
+__device__ __forceinline__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
                              int level, const ProbeOut po, Step *one, bool *list_meta = nullptr) {
     const uint32_t lane = lane_id();
     const uint32_t r1 = r0 + cnt;
@@ -588,7 +597,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
             rec = have_pre ? pre : rec_load(L, X, r0 + lane);
             // speculative: the target's only successor record, requested together with the stamp
             if ((rec.meta >> 28) == 1u) nx = rec_load(L, X, rec.toff);
-            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch, X.gen);
         }
         uint64_t m = __ballot(cls == 0);
         if (!m) m = __ballot(cls == 1);
@@ -634,7 +643,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
         SuccRec rec{0, 0, 0, 0};
         if (rb + lane < r1) {
             rec = rec_load(L, X, rb + lane);
-            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch, X.gen);
         }
         for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
             uint64_t m = __ballot(cls == c);
@@ -681,7 +690,7 @@ __device__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, 
 // mark a vertex in walkStraight's uniqueTable (one lane)
 __device__ __forceinline__ void probe_mark(WalkLds &L, WalkCtx &X, uint32_t u) {
     if (in_range(X, u)) {
-        stamp_put(L, X, 0u, u);  // group 0 arrays serve the sequential mode
+        stamp_put(L, X, 0u, u, X.gen);  // group 0 arrays serve the sequential mode
     } else {
         gs_insert_single(X.pset_o, X.pmask_o, u, X.gen);
     }
@@ -690,7 +699,7 @@ __device__ __forceinline__ void probe_mark(WalkLds &L, WalkCtx &X, uint32_t u) {
 enum { WS_END = 0, WS_BRANCH = 1, WS_LIMIT = 2, WS_LEAP = 3 };
 
 // walkStraight (PAlgorithm.tcc:93-170): writes the path to pv/ps (capacity cap), returns status
-__device__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, uint64_t has_size, uint32_t *pv, uint32_t *ps,
+__device__ __forceinline__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0, uint32_t s0, uint64_t has_size, uint32_t *pv, uint32_t *ps,
                              uint64_t cap, uint64_t *out_len) {
     const uint32_t lane = lane_id();
     X.gen += 1;
@@ -829,7 +838,7 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
         } else {
             win_add(wp0, wp1, c);
             if (sub == 0) {
-                if (in_range(X, v0)) stamp_put(L, X, g, v0);
+                if (in_range(X, v0)) stamp_put(L, X, g, v0, X.gen);
                 else gs_insert_single(pset, X.pmask_o, v0, X.gen);
             }
             if (!in_range(X, v0)) probe_out_add(po, v0);
@@ -884,7 +893,7 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
             const uint32_t sg0 = X.win_p0, sg1 = X.win_p1;
             X.win_p0 = wp0;
             X.win_p1 = wp1;
-            cls = eval_record(L, X, rec, can_leap, 2, g, po, X.epoch);
+            cls = eval_record(L, X, rec, can_leap, 2, g, po, X.epoch, X.gen);
             X.win_p0 = sg0;
             X.win_p1 = sg1;
         }
@@ -926,7 +935,7 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
             } else {
                 const uint32_t ns = meta & 0xFFFFFFu;
                 if (sub == 0) {
-                    if (in_range(X, nv)) stamp_put(L, X, g, nv);
+                    if (in_range(X, nv)) stamp_put(L, X, g, nv, X.gen);
                     else gs_insert_single(pset, X.pmask_o, nv, X.gen);
                 }
                 if (sub == (len & 15u)) {
@@ -977,12 +986,388 @@ __device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_me
     return !wide;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Probe SLOTS.  The four lane groups are slots that outlive a graphTravel iteration.  Of the alternatives of a branch
+// almost all stop at the next branching vertex, and graphTravel then takes the one with the most abundant first
+// vertex (the first one to leap would win over all of them, PAlgorithm.tcc:268-296).  So once an alternative A has
+// stopped at a branch, a still-running alternative j with a lower claim (smaller abundance, or equal and later in
+// order) can change the choice in ONE way only: by ending in a leap.  Waiting for that costs the longest probe of
+// every branch (10.7 steps at C2) where the choice is known after 3.  Instead j becomes a ZOMBIE: the main walk goes
+// on with A, j keeps walking in its slot — against the state of ITS iteration: travel marks are epochs and it only
+// sees those up to its own, it keeps its own copy of the travel window and of the accumulated size — and if it ever
+// ends in a leap the job is reported as mis-speculated and the host runs it again with speculation off.  A job ends
+// only after its zombies have.  An alternative that started after a finished leap of its iteration can never be
+// chosen and is simply dropped.
+struct Slot {
+    int status;       // < 0: walking; otherwise WS_* of the last probe
+    uint32_t fresh;   // the result belongs to the running iteration and has not been consumed
+    uint32_t zombie;  // walking, but only a leap would still matter
+    uint32_t epoch, gen, alt;
+    uint32_t cur_v, off, cnt, len, last_pc, ab;
+    uint32_t wp0, wp1, aw0, aw1, wt0, wt1;
+    ProbeOut po;
+    uint64_t now_size, H;
+    uint32_t pb_v, pb_s;
+};
+
+// A zombie that reaches a vertex with more than 16 records cannot go on inside its 16 lanes: the whole wave walks it
+// to its end (scalar walk state, the other slots wait); only its final status matters.
+__device__ __forceinline__ void slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S, uint32_t g) {
+    const uint32_t lane = lane_id();
+    const int src = (int)(16u * g);
+    uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
+    int status = __shfl(S.status, src, 64);
+    const uint32_t epoch = __shfl(S.epoch, src, 64), gen = __shfl(S.gen, src, 64);
+    uint32_t cur = __shfl(S.cur_v, src, 64), off = __shfl(S.off, src, 64), cnt = __shfl(S.cnt, src, 64);
+    uint32_t wp0 = __shfl(S.wp0, src, 64), wp1 = __shfl(S.wp1, src, 64);
+    const uint32_t wt0 = __shfl(S.wt0, src, 64), wt1 = __shfl(S.wt1, src, 64);
+    ProbeOut po{__shfl(S.po.n, src, 64), __shfl(S.po.v0, src, 64), __shfl(S.po.v1, src, 64)};
+    uint64_t now_size = __shfl(S.now_size, src, 64);
+    const uint64_t H = __shfl(S.H, src, 64);
+    int fail = 0;
+    while (status < 0) {
+        if (cnt > 64u) {
+            fail |= 2;
+            status = WS_END;
+            break;
+        }
+        win_follow(L, X, cur, off, cnt);
+        X.n_classify += 1;
+        const bool can_leap = (H + now_size) >= X.C.split_size;
+        int cls = -1;
+        SuccRec rec{0, 0, 0, 0};
+        if (lane < cnt) {
+            rec = rec_load(L, X, off + lane);
+            const uint32_t sp0 = X.win_p0, sp1 = X.win_p1, st0 = X.win_t0, st1 = X.win_t1;
+            X.win_p0 = wp0;
+            X.win_p1 = wp1;
+            X.win_t0 = wt0;
+            X.win_t1 = wt1;
+            cls = eval_record(L, X, rec, can_leap, 2, g, po, epoch, gen);
+            X.win_p0 = sp0;
+            X.win_p1 = sp1;
+            X.win_t0 = st0;
+            X.win_t1 = st1;
+        }
+        uint64_t m = __ballot(cls == 0);
+        if (!m) m = __ballot(cls == 1);
+        if (!m) m = __ballot(cls == 2);
+        if (!m) m = __ballot(cls == 3);
+        const uint32_t n = (uint32_t)__popcll(m);
+        if (n != 1u) {
+            status = n == 0 ? WS_END : WS_BRANCH;
+            break;
+        }
+        if ((uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
+            fail |= 4;
+            status = WS_END;
+            break;
+        }
+        const int sl = __ffsll((long long)m) - 1;
+        const uint32_t meta = __shfl(rec.meta, sl, 64), nv = __shfl(rec.tgt, sl, 64), npc = __shfl(rec.pc, sl, 64), noff = __shfl(rec.toff, sl, 64);
+        if (lane == 0) {
+            if (in_range(X, nv)) stamp_put(L, X, g, nv, gen);
+            else gs_insert_single(pset, X.pmask_o, nv, gen);
+        }
+        if (!in_range(X, nv)) probe_out_add(po, nv);
+        win_add(wp0, wp1, npc);
+        now_size += meta & 0xFFFFFFu;
+        cur = nv;
+        if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
+            status = WS_LEAP;
+            break;
+        }
+        off = noff;
+        cnt = meta >> 28;
+        if (cnt == 15u) {
+            off = X.G.succ_off[nv];
+            cnt = X.G.succ_off[nv + 1] - off;
+        }
+    }
+    if (status == WS_LEAP) fail |= 1;
+    X.spec_fail |= fail;
+    if ((lane >> 4) == g) {
+        S.status = status;
+        S.zombie = 0;
+        S.fresh = 0;
+    }
+}
+
+// one step of every walking slot.  *wide: a slot of the running iteration met a vertex with more than 16 records.
+__device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint32_t *arena_v, uint32_t *arena_s, uint64_t cap_each,
+                                           bool *wide, bool drain) {
+    const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
+    uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
+    uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
+    if (__ballot(S.status < 0 && S.cnt > 16u)) {
+        for (;;) {  // wide zombies, one at a time (one copy of the wide walk in the code)
+            const uint64_t wz = __ballot(S.status < 0 && S.cnt > 16u && S.zombie != 0u);
+            if (!wz) break;
+            slot_finish_wide(L, X, S, (uint32_t)(__ffsll((long long)wz) - 1) >> 4);
+        }
+        if (__ballot(S.status < 0 && S.cnt > 16u)) {
+            *wide = true;
+            return;
+        }
+    }
+    // The window belongs to the probes of the running iteration.  A zombie steps along while the window serves it;
+    // once it has wandered off it is SUSPENDED (its slow global reads would be paid by every slot of the wave) and
+    // is only walked on when the wave has nothing better to do: waiting for a free slot, or at the end of the job.
+    const bool walking = S.status < 0;
+    const bool lead = drain ? walking : (walking && !S.zombie);  // who may move the window
+    const bool running = walking && (lead || win_serves(X, S.cur_v, S.off, S.cnt));
+    if (__ballot(lead && !win_comfortable(X, S.cur_v, S.off, S.cnt))) {
+        // the window follows the lowest leading slot; the others use it while they are inside
+        const uint32_t av = lead ? S.cur_v : 0xFFFFFFFFu;
+        uint32_t a = __builtin_amdgcn_readlane(av, 0), ao = __builtin_amdgcn_readlane(S.off, 0), ac = __builtin_amdgcn_readlane(S.cnt, 0);
+#define PAG_ANCHOR(LN)                                                   \
+    {                                                                    \
+        const uint32_t b = __builtin_amdgcn_readlane(av, LN);            \
+        if (b < a) {                                                     \
+            a = b;                                                       \
+            ao = __builtin_amdgcn_readlane(S.off, LN);                   \
+            ac = __builtin_amdgcn_readlane(S.cnt, LN);                   \
+        }                                                                \
+    }
+        PAG_ANCHOR(16)
+        PAG_ANCHOR(32)
+        PAG_ANCHOR(48)
+#undef PAG_ANCHOR
+        if (a != 0xFFFFFFFFu) win_follow(L, X, a, ao, ac);
+    }
+    X.n_classify += 1;
+    int cls = -1;
+    SuccRec rec{0, 0, 0, 0};
+    const bool can_leap = (S.H + S.now_size) >= X.C.split_size;
+    if (running && sub < S.cnt) {
+        rec = rec_load(L, X, S.off + sub);
+        // the tests of a probe use ITS windows: the probe's own, and the travel window of its iteration
+        const uint32_t sp0 = X.win_p0, sp1 = X.win_p1, st0 = X.win_t0, st1 = X.win_t1;
+        X.win_p0 = S.wp0;
+        X.win_p1 = S.wp1;
+        X.win_t0 = S.wt0;
+        X.win_t1 = S.wt1;
+        cls = eval_record(L, X, rec, can_leap, 2, g, S.po, S.epoch, S.gen);
+        X.win_p0 = sp0;
+        X.win_p1 = sp1;
+        X.win_t0 = st0;
+        X.win_t1 = st1;
+    }
+    uint32_t cm = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint64_t bm = __ballot(cls == c);
+        uint32_t gm = (uint32_t)(bm >> (16u * g)) & 0xFFFFu;
+        if (cm == 0) cm = gm;
+    }
+    const uint32_t n = (uint32_t)__popc(cm);
+    {   // a probe of the running iteration that stops here by classification leaves its accepted records behind
+        const uint32_t ga = (uint32_t)(__ballot(cls >= 0) >> (16u * g)) & 0xFFFFu;
+        if (running && !S.zombie && n != 1u) {
+            if (cls >= 0) {
+                const uint32_t kk = (uint32_t)__popc(ga & ((1u << sub) - 1u));
+                L.pb_v[g][kk] = rec.tgt;
+                L.pb_meta[g][kk] = rec.meta;
+                L.pb_pc[g][kk] = rec.pc;
+                L.pb_off[g][kk] = rec.toff;
+                L.pb_cls[g][kk] = (uint32_t)cls;
+            }
+            if (sub == 0) L.pb_cnt[g] = (uint32_t)__popc(ga);
+        }
+    }
+    const int src = (int)(16u * g) + (cm ? __ffs(cm) - 1 : 0);
+    const uint32_t meta = __shfl(rec.meta, src, 64);
+    const uint32_t nv = __shfl(rec.tgt, src, 64);
+    const uint32_t npc = __shfl(rec.pc, src, 64);
+    const uint32_t noff = __shfl(rec.toff, src, 64);
+    if (running) {
+        if (n == 0) {
+            S.status = WS_END;
+        } else if (n > 1) {
+            S.status = WS_BRANCH;
+        } else if ((!S.zombie && S.len >= cap_each) || (uint64_t)(S.po.n + 1) * 2 > (uint64_t)X.pmask_o) {
+            if (S.zombie) X.spec_fail |= 4;  // out of room for a walk whose only purpose is the check
+            else X.overflow = 1;
+            S.status = WS_END;
+        } else {
+            const uint32_t ns = meta & 0xFFFFFFu;
+            if (sub == 0) {
+                if (in_range(X, nv)) stamp_put(L, X, g, nv, S.gen);
+                else gs_insert_single(pset, X.pmask_o, nv, S.gen);
+            }
+            if (!S.zombie && sub == (S.len & 15u)) {
+                S.pb_v = nv;
+                S.pb_s = ns;
+            }
+            if (!in_range(X, nv)) probe_out_add(S.po, nv);
+            win_add(S.wp0, S.wp1, npc);
+            win_add(S.aw0, S.aw1, npc);
+            S.last_pc = npc;
+            S.len += 1;
+            S.now_size += ns;
+            if (!S.zombie && (S.len & 15u) == 0) {  // 16 entries pending: one 64-byte store per array
+                pv[S.len - 16u + sub] = S.pb_v;
+                ps[S.len - 16u + sub] = S.pb_s;
+            }
+            S.cur_v = nv;
+            if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
+                S.status = WS_LEAP;
+            } else {
+                S.off = noff;
+                S.cnt = meta >> 28;
+                if (S.cnt == 15u) {
+                    S.off = X.G.succ_off[nv];
+                    S.cnt = X.G.succ_off[nv + 1] - S.off;
+                }
+            }
+        }
+        if (S.status >= 0) {  // stopped in this step
+            if (S.zombie) {
+                if (S.status == WS_LEAP) X.spec_fail |= 1;
+                S.zombie = 0;
+            } else {
+                if (sub < (S.len & 15u)) {  // the entries still waiting in registers
+                    pv[S.len - (S.len & 15u) + sub] = S.pb_v;
+                    ps[S.len - (S.len & 15u) + sub] = S.pb_s;
+                }
+                S.fresh = 1;
+            }
+        }
+    }
+}
+
+// After a step: what the finished alternatives of the running iteration mean for the ones still walking.
+__device__ __forceinline__ void slots_dominate(const WalkCtx &X, Slot &S, bool speculate) {
+    const bool mine = S.status < 0 && S.epoch == X.epoch;
+#pragma unroll
+    for (int a = 0; a < PROBE_GROUPS; ++a) {
+        const int sa = __builtin_amdgcn_readlane(S.status, 16 * a);
+        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a);
+        const uint32_t aba = __builtin_amdgcn_readlane(S.ab, 16 * a), alta = __builtin_amdgcn_readlane(S.alt, 16 * a);
+        if (!(fa != 0u && ea == X.epoch)) continue;
+        if (mine) {
+            if (sa == WS_LEAP && alta < S.alt) {  // an earlier alternative leaps: this one can never be chosen
+                S.status = WS_END;
+                S.zombie = 0;
+                S.fresh = 0;
+            } else if (speculate && !S.zombie && sa == WS_BRANCH && (aba > S.ab || (aba == S.ab && alta < S.alt)) &&
+                       S.H + S.now_size + SPEC_MARGIN < X.C.split_size) {
+                // (only while the walk is far from the size at which leaping becomes possible at all: close to it,
+                // leaps of side paths are common and every one would void the whole job)
+                S.zombie = 1;
+            }
+        }
+    }
+}
+
+// Start the m alternatives L.br_* in free slots and walk until the choice among them is determined.
+// Returns false if an alternative met a vertex with more than 16 records (the caller probes sequentially).
+__device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uint32_t m, bool have_meta, uint64_t has_size, uint32_t *arena_v,
+                            uint32_t *arena_s, uint64_t cap_each, bool speculate) {
+    const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
+    bool wide = false;
+    if (cap_each == 0) {
+        X.overflow = 1;
+        return true;
+    }
+    // wait for m free slots (zombies occupy theirs until they stop)
+    uint32_t free_mask;
+    for (;;) {
+        const uint64_t fb = __ballot(sub == 0 && S.status >= 0);
+        free_mask = (uint32_t)((fb & 1ull) | ((fb >> 15) & 2ull) | ((fb >> 30) & 4ull) | ((fb >> 45) & 8ull));
+        if ((uint32_t)__popc(free_mask) >= m) break;
+        slots_step(L, X, S, arena_v, arena_s, cap_each, &wide, true);
+        wide = false;  // a zombie that gets too wide is finished by the whole wave inside the step
+    }
+    X.gen += 1;
+    X.n_probe += m;
+    const uint32_t rank = (uint32_t)__popc(free_mask & ((1u << g) - 1u));
+    if (((free_mask >> g) & 1u) && rank < m) {
+        uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
+        const uint32_t v0 = L.br_v[rank], s0 = L.br_s[rank];
+        S.status = -1;
+        S.fresh = 0;
+        S.zombie = 0;
+        S.epoch = X.epoch;
+        S.gen = X.gen;
+        S.alt = rank;
+        S.cur_v = v0;
+        S.now_size = s0;
+        S.H = has_size;
+        S.len = 1;
+        S.off = 0;
+        S.cnt = 0;
+        S.wp0 = 0xFFFFFFFFu;
+        S.wp1 = 0;
+        S.aw0 = 0xFFFFFFFFu;
+        S.aw1 = 0;
+        S.wt0 = X.win_t0;
+        S.wt1 = X.win_t1;
+        S.po = ProbeOut{0, 0, 0};
+        S.pb_v = v0;  // entry 0 of the path waits in lane 0 of the group (sub == len & 15 == 0 holds it)
+        S.pb_s = s0;
+        {   // abundance of the alternative (needed if it ends in a branch)
+            const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
+            S.ab = L.wab[e0 < X.w_nid ? e0 : 0u];
+            if (!(e0 < X.w_nid)) S.ab = X.G.ucnt[v0];
+        }
+        const uint32_t c = have_meta ? L.br_pc[rank] : (uint32_t)(X.G.upos[v0] >> 32);
+        S.last_pc = c;
+        win_add(S.aw0, S.aw1, c);
+        if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
+            S.status = WS_LEAP;
+            S.fresh = 1;
+            if (sub == 0) {
+                arena_v[(uint64_t)g * cap_each] = v0;
+                arena_s[(uint64_t)g * cap_each] = s0;
+            }
+        } else {
+            win_add(S.wp0, S.wp1, c);
+            if (sub == 0) {
+                if (in_range(X, v0)) stamp_put(L, X, g, v0, S.gen);
+                else gs_insert_single(pset, X.pmask_o, v0, S.gen);
+            }
+            if (!in_range(X, v0)) probe_out_add(S.po, v0);
+            if (have_meta) {
+                S.off = L.br_off[rank];
+                S.cnt = L.br_cnt[rank];
+            } else {
+                S.cnt = 15u;
+            }
+            if (S.cnt == 15u) {
+                S.off = X.G.succ_off[v0];
+                S.cnt = X.G.succ_off[v0 + 1] - S.off;
+            }
+        }
+    }
+    slots_dominate(X, S, speculate);  // an alternative may have leapt right at its first vertex
+    uint64_t seen = __ballot(S.fresh != 0u && S.epoch == X.epoch);
+    for (;;) {
+        if (!__ballot(S.status < 0 && !S.zombie && S.epoch == X.epoch)) break;
+        slots_step(L, X, S, arena_v, arena_s, cap_each, &wide, false);
+        if (wide) return false;
+        const uint64_t now = __ballot(S.fresh != 0u && S.epoch == X.epoch);
+        if (now != seen) {  // an alternative of this iteration has stopped: what does it mean for the others?
+            slots_dominate(X, S, speculate);
+            seen = now;
+        }
+    }
+    X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
+    {
+        int sf = X.spec_fail;
+        for (int d2 = 32; d2 >= 1; d2 >>= 1) sf |= __shfl_xor(sf, d2, 64);
+        X.spec_fail = sf;
+    }
+    __syncthreads();  // paths written by the groups are read by all lanes afterwards
+    return true;
+}
+
 // walkStraight for ONE alternative by a whole wave: every piece of walk state (current vertex, record range,
 // length, windows, status) is wave-uniform, so it lives in scalar registers and is updated by the scalar
 // unit; only the evaluation of the <= 64 successor records of a vertex is per-lane work.  `grp` selects the
 // stamp array / outside set of this probe, `alt` the alternative (start vertex in L.br_*), the path goes to
 // pv/ps.  Returns false if a vertex with more than 64 records was met (caller falls back to walk_straight).
-__device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, bool have_meta, uint64_t has_size, uint32_t *pv,
+__device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, bool have_meta, uint64_t has_size, uint32_t *pv,
                            uint32_t *ps, uint64_t cap, bool follow, ProbeRes *res) {
     const uint32_t lane = lane_id();
     uint64_t *pset = X.pset_o + (uint64_t)grp * ((uint64_t)X.pmask_o + 1);
@@ -1021,7 +1406,7 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
     } else {
         win_add(X.win_p0, X.win_p1, c0);
         if (lane == 0) {
-            if (in_range(X, v0)) stamp_put(L, X, grp, v0);
+            if (in_range(X, v0)) stamp_put(L, X, grp, v0, X.gen);
             else gs_insert_single(pset, X.pmask_o, v0, X.gen);
         }
         if (!in_range(X, v0)) probe_out_add(po, v0);
@@ -1048,7 +1433,7 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
         SuccRec rec{0, 0, 0, 0};
         if (lane < cnt) {
             rec = rec_load(L, X, off + lane);
-            cls = eval_record(L, X, rec, can_leap, 2, grp, po, X.epoch);
+            cls = eval_record(L, X, rec, can_leap, 2, grp, po, X.epoch, X.gen);
         }
         uint64_t m = __ballot(cls == 0);
         if (!m) m = __ballot(cls == 1);
@@ -1081,7 +1466,7 @@ __device__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp, uint32_t alt, b
         const uint32_t noff = __shfl(rec.toff, src, 64);
         const uint32_t ns = meta & 0xFFFFFFu;
         if (lane == 0) {
-            if (in_range(X, nv)) stamp_put(L, X, grp, nv);
+            if (in_range(X, nv)) stamp_put(L, X, grp, nv, X.gen);
             else gs_insert_single(pset, X.pmask_o, nv, X.gen);
             pv[len] = nv;
             ps[len] = ns;
@@ -1142,6 +1527,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.win_t0 = 0xFFFFFFFFu;
     X.win_t1 = 0;
     X.overflow = 0;
+    X.spec_fail = 0;
     X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.n_fill = 0;
     X.n_classify = X.n_probe = X.n_records = 0;
 
@@ -1179,6 +1565,17 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     uint32_t f_w0 = 0, f_w1 = 0, f_nout = 0, f_last = 0, f_lpc = 0, f_off = 0, f_cnt = 0, f_grp = 0;
     bool f_list = false;  // L.pb_*[f_grp] holds the classification the chosen probe stopped at
     uint64_t f_size = 0;
+    Slot S;
+    S.status = WS_END;
+    S.fresh = S.zombie = S.epoch = S.gen = S.alt = 0;
+    S.cur_v = S.off = S.cnt = S.len = S.last_pc = S.ab = 0;
+    S.wp0 = S.wp1 = S.aw0 = S.aw1 = S.wt0 = S.wt1 = 0;
+    S.po = ProbeOut{0, 0, 0};
+    S.now_size = S.H = 0;
+    S.pb_v = S.pb_s = 0;
+    const bool speculate = J.exact == 0;
+    const uint64_t slot_cap = J.arena_cap / PROBE_GROUPS;
+
     uint64_t n_main = 0;
     for (;;) {
         ++n_main;
@@ -1352,7 +1749,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         // its own quarter of the arena; sequential full-wave probing only when a vertex is too wide
         fast = false;
         bool multi_ok = m <= PROBE_GROUPS;  // larger fan-outs would need several arena generations: sequential
-        if (m == 1) {  // a single alternative: the whole wave walks it (scalar walk state, see probe_wave)
+        const bool zombies = __ballot(S.status < 0) != 0ull;  // between iterations only zombies are walking
+        if (m == 1 && !zombies) {  // a single alternative and no slot in use: the whole wave walks it (scalar walk state)
             const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
             ProbeRes R[PROBE_GROUPS];
             bool ok_all = true;
@@ -1405,54 +1803,80 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             X.gen += 1;
         }
         if (multi_ok) {
-            const uint64_t cap_each = J.arena_cap / PROBE_GROUPS;
-            ProbeRes R;
-            multi_ok = probe_multi(L, X, m, list_meta, has_size + now_size, J.arena_v, J.arena_s, cap_each, &R);
+            multi_ok = probe_slots(L, X, S, m, list_meta, has_size + now_size, J.arena_v, J.arena_s, slot_cap, speculate);
             if (multi_ok) {
                 if (X.overflow) break;
-                // choice (PAlgorithm.tcc:268-296): the first alternative that leaps; else the branching one
-                // with the most abundant first vertex (first wins ties); else the longest dead end (first wins)
+                // choice (PAlgorithm.tcc:268-296) among the alternatives of this iteration that have stopped (the
+                // zombies are taken not to leap): the first one that leaps; else the branching one with the most
+                // abundant first vertex (first wins ties); else the longest dead end (first wins ties)
                 int pick = -1;
-                for (uint32_t i = 0; i < m && pick < 0; ++i)
-                    if (__shfl(R.status, (int)(16u * i), 64) == WS_LEAP) pick = (int)i;
+                uint32_t best_alt = 0xFFFFFFFFu, best_ab = 0, best_len = 0;
+#pragma unroll
+                for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
+                    const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a2), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a2);
+                    if (!(fa != 0u && ea == X.epoch)) continue;
+                    const int sa = __builtin_amdgcn_readlane(S.status, 16 * a2);
+                    const uint32_t alta = __builtin_amdgcn_readlane(S.alt, 16 * a2);
+                    if (sa == WS_LEAP && alta < best_alt) {
+                        pick = a2;
+                        best_alt = alta;
+                    }
+                }
                 if (pick < 0) {
-                    uint32_t best_ab = 0;
-                    for (uint32_t i = 0; i < m; ++i) {
-                        if (__shfl(R.status, (int)(16u * i), 64) != WS_BRANCH) continue;
-                        const uint32_t ab = __shfl(R.ab, (int)(16u * i), 64);
-                        if (pick < 0 || ab > best_ab) {
-                            pick = (int)i;
-                            best_ab = ab;
+#pragma unroll
+                    for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
+                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a2), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a2);
+                        if (!(fa != 0u && ea == X.epoch)) continue;
+                        const int sa = __builtin_amdgcn_readlane(S.status, 16 * a2);
+                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, 16 * a2), aba = __builtin_amdgcn_readlane(S.ab, 16 * a2);
+                        if (sa == WS_BRANCH && (pick < 0 || aba > best_ab || (aba == best_ab && alta < best_alt))) {
+                            pick = a2;
+                            best_ab = aba;
+                            best_alt = alta;
                         }
                     }
                 }
                 if (pick < 0) {
-                    uint32_t best_len = 0;
-                    for (uint32_t i = 0; i < m; ++i) {
-                        const uint32_t l2 = __shfl(R.len, (int)(16u * i), 64);
-                        if (pick < 0 || l2 > best_len) {
-                            pick = (int)i;
-                            best_len = l2;
+#pragma unroll
+                    for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
+                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a2), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a2);
+                        if (!(fa != 0u && ea == X.epoch)) continue;
+                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, 16 * a2), la = __builtin_amdgcn_readlane(S.len, 16 * a2);
+                        if (pick < 0 || la > best_len || (la == best_len && alta < best_alt)) {
+                            pick = a2;
+                            best_len = la;
+                            best_alt = alta;
                         }
                     }
                 }
                 const int src = 16 * pick;
-                ch_off = (uint64_t)pick * cap_each;
-                ch_len = __shfl(R.len, src, 64);
+                ch_off = (uint64_t)pick * slot_cap;
+                ch_len = __shfl(S.len, src, 64);
                 fast = true;
                 f_grp = (uint32_t)pick;
                 {
-                    const int stt = __shfl(R.status, src, 64);
+                    const int stt = __shfl(S.status, src, 64);
                     f_list = stt == WS_END || stt == WS_BRANCH;
                 }
-                f_w0 = __shfl(R.w0, src, 64);
-                f_w1 = __shfl(R.w1, src, 64);
-                f_nout = __shfl(R.n_out, src, 64);
-                f_last = __shfl(R.last_v, src, 64);
-                f_lpc = __shfl(R.last_pc, src, 64);
-                f_off = __shfl(R.off, src, 64);
-                f_cnt = __shfl(R.cnt, src, 64);
-                f_size = __shfl(R.size, src, 64);
+                f_w0 = __shfl(S.aw0, src, 64);
+                f_w1 = __shfl(S.aw1, src, 64);
+                f_nout = __shfl(S.po.n, src, 64);
+                f_last = __shfl(S.cur_v, src, 64);
+                f_lpc = __shfl(S.last_pc, src, 64);
+                f_off = __shfl(S.off, src, 64);
+                f_cnt = __shfl(S.cnt, src, 64);
+                f_size = __shfl(S.now_size, src, 64);
+                S.fresh = 0;  // consumed
+            } else if (S.epoch == X.epoch && (S.status < 0 || S.fresh != 0u)) {  // too wide: this iteration is probed sequentially
+                S.status = WS_END;
+                S.fresh = 0;
+                S.zombie = 0;
+            }
+        }
+        if (!multi_ok) {  // the sequential probes use the arrays of slot 0 and the whole arena: let the zombies finish first
+            while (__ballot(S.status < 0)) {
+                bool w = false;
+                slots_step(L, X, S, J.arena_v, J.arena_s, slot_cap, &w, true);
             }
         }
         if (!multi_ok) {
@@ -1501,15 +1925,24 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             }
         }
     }
+    while (__ballot(S.status < 0)) {  // the speculation is only valid once every zombie has stopped without a leap
+        bool w = false;
+        slots_step(L, X, S, J.arena_v, J.arena_s, slot_cap, &w, true);
+    }
+    {
+        int sf = X.spec_fail;
+        for (int d2 = 32; d2 >= 1; d2 >>= 1) sf |= __shfl_xor(sf, d2, 64);
+        X.spec_fail = sf;
+    }
     if (lane == 0) {
         TravJobOut o;
         o.seq_len = seq_len;
         o.seq_size = seq_size;
-        o.overflow = X.overflow;
+        o.overflow = X.overflow | (X.spec_fail ? 4 : 0);
         o.n_classify = __shfl(X.n_classify, 0, 64);
         o.n_probe = X.n_probe;
         o.n_records = X.n_records;
-        o.n_fill = X.n_fill;
+        o.n_fill = X.n_fill | ((uint64_t)X.spec_fail << 32);
         o.n_out = X.n_out;
         o.n_main = n_main;
         o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;

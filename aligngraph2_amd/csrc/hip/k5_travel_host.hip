@@ -478,9 +478,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     struct CRun {
         uint32_t first = 0, n = 0, grow = 1, round = 0;
         bool outstanding = false;
+        bool exact = false;  // a speculation of this contig's walk failed once: walk without from now on
     };
     std::vector<CRun> run(n_sel);
-    uint32_t n_posted = 0, n_outstanding = 0;
+    uint32_t n_posted = 0, n_outstanding = 0, respeculated = 0;
     bool walker_up = false;
     auto shutdown_walker = [&]() {
         if (!walker_up) return;
@@ -539,6 +540,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.tmask = (uint32_t)oc - 1;
             J.pset = b_ps.as<uint64_t>() + sd * 4 * oc;
             J.pmask = (uint32_t)oc - 1;
+            J.exact = (R.exact || std::getenv("PAG_WALK_EXACT")) ? 1u : 0u;
             P.C = tc[i];
             hdone[n_posted + sd] = 0;
         }
@@ -639,9 +641,24 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (uint32_t i : batch) {
             run[i].outstanding = false;
             n_outstanding -= 1;
-            bool overflow = false;
-            for (uint32_t j = 0; j < run[i].n; ++j) overflow |= houts[run[i].first + j].overflow != 0;
+            bool overflow = false, misspec = false;
+            for (uint32_t j = 0; j < run[i].n; ++j) {
+                overflow |= (houts[run[i].first + j].overflow & 3) != 0;
+                misspec |= (houts[run[i].first + j].overflow & 4) != 0;
+            }
+            if (misspec && !overflow) {  // a zombie probe leapt: the round is walked again, every probe to its end
+                if (wdebug)
+                    std::fprintf(stderr, "[walk] contig %u: speculation failed (cause bits %llu), exact walk\n", i,
+                                 (unsigned long long)(houts[run[i].first].n_fill >> 32));
+                run[i].exact = true;
+                run[i].round -= 1;
+                jobs_total -= run[i].n;
+                ++respeculated;
+                redo.push_back(i);
+                continue;
+            }
             if (overflow) {
+                if (misspec) run[i].exact = true;
                 if (run[i].grow >= 64) {
                     shutdown_walker();
                     set_error("pag_travel: walker buffers overflow even at 64x capacity");
@@ -936,6 +953,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     }
     lap("epilogue");
     if (timing) {
+        std::fprintf(stderr, "[timing] walks redone without speculation: %u\n", respeculated);
         std::fprintf(stderr, "[timing] pag_travel laps:");
         for (auto &l : laps) std::fprintf(stderr, " %s %.1f ms;", l.first, l.second);
         std::fprintf(stderr, "\n");

@@ -71,6 +71,7 @@ struct TravJob {
     uint32_t tmask;
     uint64_t *pset;
     uint32_t pmask;
+    uint32_t exact;  // 1: no speculation (probes of a branch all run to their end before the choice), see Slot
 };
 
 struct TravJobOut {
