@@ -290,7 +290,11 @@ __global__ void k_ranges(TravGraph G, TravContig *ctgs, uint32_t n) {
 // =================================================================================================
 constexpr int LIST_CAP = 256;  // successors of one vertex kept per class
 constexpr int BR_CAP = 256;    // branch fan-out kept per graphTravel round
-constexpr int PROBE_GROUPS = 4;  // alternatives of a branch probed side by side, 16 lanes each
+constexpr int PROBE_GROUPS = TRAV_PROBE_GROUPS;  // probe slots = lane groups of a wave
+constexpr uint32_t GL = 64u / PROBE_GROUPS;       // lanes per slot: successor records of one vertex evaluated side by side
+constexpr uint32_t GL_SHIFT = GL == 8u ? 3u : 4u;
+constexpr uint32_t GL_MASK = (1u << GL) - 1u;
+static_assert(GL == 8u || GL == 16u, "slot geometry");
 #define STAMP_TRAVEL 0xFFFFFFFFu
 
 // A walk moves through the coordinate-ordered arrays almost monotonically, a few ids per step, and every
@@ -300,8 +304,9 @@ constexpr int PROBE_GROUPS = 4;  // alternatives of a branch probed side by side
 // vertices of the strand — refilled with wave-wide coalesced loads every couple of hundred steps.  The
 // window is a pure read cache: every mark is written through to the global arrays, and any access that
 // falls outside the window uses them directly.
-constexpr uint32_t WIN_IDS = 2048;
+constexpr uint32_t WIN_IDS = 1024;
 constexpr uint32_t WIN_REC = 4096;
+static_assert(WIN_IDS / 32u <= 64u, "one lane per word of the global-visited window");
 constexpr uint32_t FILT_WORDS = 1024;  // 64 Ki-bit membership filters in front of the outside-range hash sets
 constexpr uint32_t WIN_BACK = 128;   // ids kept behind the anchor at a refill
 constexpr uint32_t WIN_AHEAD = 160;
@@ -457,10 +462,10 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
                 __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wts[b], 4, 0, 16);
             }
         }
-        const uint32_t nw = (nid + 31u) / 32u;  // <= 64
+        const uint32_t nw = (nid + 31u) / 32u;  // <= WIN_IDS / 32 <= 64
         const uint32_t w = lane < nw ? lane : nw - 1u;
         if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + (d0 >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
-        else L.wgb[lane] = 0u;
+        else if (lane < WIN_IDS / 32u) L.wgb[lane] = 0u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -780,11 +785,6 @@ __device__ __forceinline__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0
     return status;
 }
 
-// Up to PROBE_GROUPS alternatives of one branch probed SIDE BY SIDE: lanes 16g .. 16g+15 run the
-// walkStraight of alternative g (its own generation stamps, window, arena region); the instruction stream
-// of a step is shared, so the serial cost of a branch is the LONGEST probe instead of the sum of all
-// probes (three quarters of all successor evaluations are probes that end up not being chosen).
-// Returns false if some vertex has more than 16 successor records (caller falls back to sequential probing).
 // what a probe group knows when it stops (uniform inside the group)
 struct ProbeRes {
     int status;
@@ -796,195 +796,6 @@ struct ProbeRes {
     uint32_t ab;               // abundance of the first path vertex
     uint64_t size;             // sum of the steps
 };
-
-__device__ bool probe_multi(WalkLds &L, WalkCtx &X, uint32_t n_alt, bool have_meta, uint64_t has_size, uint32_t *arena_v,
-                            uint32_t *arena_s, uint64_t cap_each, ProbeRes *res) {
-    const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
-    const bool active = g < n_alt;
-    X.gen += 1;
-    X.n_probe += n_alt;
-    uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
-    uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
-    uint32_t wp0 = 0xFFFFFFFFu, wp1 = 0, aw0 = 0xFFFFFFFFu, aw1 = 0;
-    uint32_t len = 0, off = 0, cnt = 0, cur_v = 0, pb_v = 0, pb_s = 0, last_pc = 0, ab = 0;
-    ProbeOut po{0, 0, 0};
-    uint64_t now_size = 0;
-    int status = -1;  // running
-    if (cap_each == 0) {
-        X.overflow = 1;
-        res->status = WS_END;
-        res->len = 0;
-        return true;
-    }
-    if (active) {
-        const uint32_t v0 = L.br_v[g], s0 = L.br_s[g];
-        cur_v = v0;
-        now_size = s0;
-        len = 1;
-        if (sub == 0) {  // path entries wait in registers, 16 per group, and leave in one coalesced store
-            pb_v = v0;
-            pb_s = s0;
-        }
-        {   // abundance of the alternative (needed if it ends in a branch)
-            const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
-            ab = L.wab[e0 < X.w_nid ? e0 : 0u];
-            if (!(e0 < X.w_nid)) ab = X.G.ucnt[v0];
-        }
-        const uint32_t c = have_meta ? L.br_pc[g] : (uint32_t)(X.G.upos[v0] >> 32);
-        last_pc = c;
-        win_add(aw0, aw1, c);
-        if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
-            status = WS_LEAP;
-        } else {
-            win_add(wp0, wp1, c);
-            if (sub == 0) {
-                if (in_range(X, v0)) stamp_put(L, X, g, v0, X.gen);
-                else gs_insert_single(pset, X.pmask_o, v0, X.gen);
-            }
-            if (!in_range(X, v0)) probe_out_add(po, v0);
-            if (have_meta) {
-                off = L.br_off[g];
-                cnt = L.br_cnt[g];
-            } else {
-                cnt = 15u;
-            }
-            if (cnt == 15u) {
-                off = X.G.succ_off[v0];
-                cnt = X.G.succ_off[v0 + 1] - off;
-            }
-        }
-    } else {
-        status = WS_END;
-    }
-    bool wide = false;
-    for (;;) {
-        const bool running = status < 0;
-        if (__ballot(running && cnt > 16u)) {
-            wide = true;
-            break;
-        }
-        if (!__ballot(running)) break;
-        if (__ballot(running && !win_comfortable(X, cur_v, off, cnt))) {
-            // the window follows the lowest running alternative; the others use it while they are inside
-            const uint32_t av = running ? cur_v : 0xFFFFFFFFu;
-            uint32_t a = __builtin_amdgcn_readlane(av, 0), ao = __builtin_amdgcn_readlane(off, 0), ac = __builtin_amdgcn_readlane(cnt, 0);
-#define PAG_ANCHOR(LN)                                                   \
-    {                                                                    \
-        const uint32_t b = __builtin_amdgcn_readlane(av, LN);            \
-        if (b < a) {                                                     \
-            a = b;                                                       \
-            ao = __builtin_amdgcn_readlane(off, LN);                     \
-            ac = __builtin_amdgcn_readlane(cnt, LN);                     \
-        }                                                                \
-    }
-            PAG_ANCHOR(16)
-            PAG_ANCHOR(32)
-            PAG_ANCHOR(48)
-#undef PAG_ANCHOR
-            if (a != 0xFFFFFFFFu) win_follow(L, X, a, ao, ac);
-        }
-        X.n_classify += 1;
-        int cls = -1;
-        SuccRec rec{0, 0, 0, 0};
-        const bool can_leap = (has_size + now_size) >= X.C.split_size;
-        if (running && sub < cnt) {
-            rec = rec_load(L, X, off + sub);
-            // the probe-level tests use this group's window and stamps
-            const uint32_t sg0 = X.win_p0, sg1 = X.win_p1;
-            X.win_p0 = wp0;
-            X.win_p1 = wp1;
-            cls = eval_record(L, X, rec, can_leap, 2, g, po, X.epoch, X.gen);
-            X.win_p0 = sg0;
-            X.win_p1 = sg1;
-        }
-        uint32_t cm = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint64_t bm = __ballot(cls == c);
-            uint32_t gm = (uint32_t)(bm >> (16u * g)) & 0xFFFFu;
-            if (cm == 0) cm = gm;
-        }
-        const uint32_t n = (uint32_t)__popc(cm);
-        {   // a group that stops here by classification leaves its accepted records behind
-            const uint32_t ga = (uint32_t)(__ballot(cls >= 0) >> (16u * g)) & 0xFFFFu;
-            if (running && n != 1u) {
-                if (cls >= 0) {
-                    const uint32_t kk = (uint32_t)__popc(ga & ((1u << sub) - 1u));
-                    L.pb_v[g][kk] = rec.tgt;
-                    L.pb_meta[g][kk] = rec.meta;
-                    L.pb_pc[g][kk] = rec.pc;
-                    L.pb_off[g][kk] = rec.toff;
-                    L.pb_cls[g][kk] = (uint32_t)cls;
-                }
-                if (sub == 0) L.pb_cnt[g] = (uint32_t)__popc(ga);
-            }
-        }
-        const int src = (int)(16u * g) + (cm ? __ffs(cm) - 1 : 0);
-        const uint32_t meta = __shfl(rec.meta, src, 64);
-        const uint32_t nv = __shfl(rec.tgt, src, 64);
-        const uint32_t npc = __shfl(rec.pc, src, 64);
-        const uint32_t noff = __shfl(rec.toff, src, 64);
-        if (running) {
-            if (n == 0) {
-                status = WS_END;
-            } else if (n > 1) {
-                status = WS_BRANCH;
-            } else if (len >= cap_each || (uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
-                X.overflow = 1;
-                status = WS_END;
-            } else {
-                const uint32_t ns = meta & 0xFFFFFFu;
-                if (sub == 0) {
-                    if (in_range(X, nv)) stamp_put(L, X, g, nv, X.gen);
-                    else gs_insert_single(pset, X.pmask_o, nv, X.gen);
-                }
-                if (sub == (len & 15u)) {
-                    pb_v = nv;
-                    pb_s = ns;
-                }
-                if (!in_range(X, nv)) probe_out_add(po, nv);
-                win_add(wp0, wp1, npc);
-                win_add(aw0, aw1, npc);
-                last_pc = npc;
-                len += 1;
-                now_size += ns;
-                if ((len & 15u) == 0) {  // 16 entries pending: one 64-byte store per array
-                    pv[len - 16u + sub] = pb_v;
-                    ps[len - 16u + sub] = pb_s;
-                }
-                cur_v = nv;
-                if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
-                    status = WS_LEAP;
-                } else {
-                    off = noff;
-                    cnt = meta >> 28;
-                    if (cnt == 15u) {
-                        off = X.G.succ_off[nv];
-                        cnt = X.G.succ_off[nv + 1] - off;
-                    }
-                }
-            }
-        }
-    }
-    if (active && sub < (len & 15u)) {  // the entries still waiting in registers
-        pv[len - (len & 15u) + sub] = pb_v;
-        ps[len - (len & 15u) + sub] = pb_s;
-    }
-    X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
-    __syncthreads();  // paths written by the groups are read by all lanes afterwards
-    res->status = status;
-    res->len = len;
-    res->last_v = cur_v;
-    res->last_pc = last_pc;
-    res->off = off;
-    res->cnt = cnt;
-    res->w0 = aw0;
-    res->w1 = aw1;
-    res->n_out = po.n;
-    res->ab = ab;
-    res->size = now_size;
-    return !wide;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Probe SLOTS.  The four lane groups are slots that outlive a graphTravel iteration.  Of the alternatives of a branch
@@ -1010,23 +821,34 @@ struct Slot {
     uint32_t pb_v, pb_s;
 };
 
-// A zombie that reaches a vertex with more than 16 records cannot go on inside its 16 lanes: the whole wave walks it
-// to its end (scalar walk state, the other slots wait); only its final status matters.
-__device__ __forceinline__ void slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S, uint32_t g) {
+// A slot that reaches a vertex with more records than it has lanes cannot go on inside its lane group: the whole wave
+// walks it to its end (scalar walk state, the other slots wait).  Of a zombie only the final status matters; a probe
+// of the running iteration also leaves its path, its windows and the accepted records of its last vertex behind.
+__device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S, uint32_t g, uint32_t *arena_v, uint32_t *arena_s,
+                                                 uint64_t cap_each) {
     const uint32_t lane = lane_id();
-    const int src = (int)(16u * g);
+    const int src = (int)(GL * g);
     uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
+    uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
     int status = __shfl(S.status, src, 64);
+    const bool zombie = __shfl(S.zombie, src, 64) != 0u;
     const uint32_t epoch = __shfl(S.epoch, src, 64), gen = __shfl(S.gen, src, 64);
     uint32_t cur = __shfl(S.cur_v, src, 64), off = __shfl(S.off, src, 64), cnt = __shfl(S.cnt, src, 64);
     uint32_t wp0 = __shfl(S.wp0, src, 64), wp1 = __shfl(S.wp1, src, 64);
+    uint32_t aw0 = __shfl(S.aw0, src, 64), aw1 = __shfl(S.aw1, src, 64), last_pc = __shfl(S.last_pc, src, 64);
     const uint32_t wt0 = __shfl(S.wt0, src, 64), wt1 = __shfl(S.wt1, src, 64);
     ProbeOut po{__shfl(S.po.n, src, 64), __shfl(S.po.v0, src, 64), __shfl(S.po.v1, src, 64)};
     uint64_t now_size = __shfl(S.now_size, src, 64);
+    uint32_t len = __shfl(S.len, src, 64);
     const uint64_t H = __shfl(S.H, src, 64);
+    if (!zombie && (lane >> GL_SHIFT) == g && (lane & (GL - 1u)) < (len & (GL - 1u))) {  // path entries waiting in registers
+        pv[len - (len & (GL - 1u)) + (lane & (GL - 1u))] = S.pb_v;
+        ps[len - (len & (GL - 1u)) + (lane & (GL - 1u))] = S.pb_s;
+    }
     int fail = 0;
     while (status < 0) {
         if (cnt > 64u) {
+            if (!zombie) return false;  // more successor records than lanes: the caller probes this iteration sequentially
             fail |= 2;
             status = WS_END;
             break;
@@ -1056,10 +878,23 @@ __device__ __forceinline__ void slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         const uint32_t n = (uint32_t)__popcll(m);
         if (n != 1u) {
             status = n == 0 ? WS_END : WS_BRANCH;
+            if (!zombie) {  // the accepted records, for the classification of the chosen path's last vertex
+                const uint64_t ga = __ballot(cls >= 0);
+                if (cls >= 0) {
+                    const uint32_t kk = (uint32_t)__popcll(ga & lanemask_lt());
+                    L.pb_v[g][kk] = rec.tgt;
+                    L.pb_meta[g][kk] = rec.meta;
+                    L.pb_pc[g][kk] = rec.pc;
+                    L.pb_off[g][kk] = rec.toff;
+                    L.pb_cls[g][kk] = (uint32_t)cls;
+                }
+                if (lane == 0) L.pb_cnt[g] = (uint32_t)__popcll(ga);
+            }
             break;
         }
-        if ((uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
-            fail |= 4;
+        if ((!zombie && len >= cap_each) || (uint64_t)(po.n + 1) * 2 > (uint64_t)X.pmask_o) {
+            if (zombie) fail |= 4;
+            else X.overflow = 1;
             status = WS_END;
             break;
         }
@@ -1068,9 +903,16 @@ __device__ __forceinline__ void slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         if (lane == 0) {
             if (in_range(X, nv)) stamp_put(L, X, g, nv, gen);
             else gs_insert_single(pset, X.pmask_o, nv, gen);
+            if (!zombie) {
+                pv[len] = nv;
+                ps[len] = meta & 0xFFFFFFu;
+            }
         }
         if (!in_range(X, nv)) probe_out_add(po, nv);
         win_add(wp0, wp1, npc);
+        win_add(aw0, aw1, npc);
+        last_pc = npc;
+        len += 1;
         now_size += meta & 0xFFFFFFu;
         cur = nv;
         if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
@@ -1084,28 +926,37 @@ __device__ __forceinline__ void slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
             cnt = X.G.succ_off[nv + 1] - off;
         }
     }
-    if (status == WS_LEAP) fail |= 1;
+    if (zombie && status == WS_LEAP) fail |= 1;
     X.spec_fail |= fail;
-    if ((lane >> 4) == g) {
+    if ((lane >> GL_SHIFT) == g) {
         S.status = status;
         S.zombie = 0;
-        S.fresh = 0;
+        S.fresh = zombie ? 0u : 1u;
+        S.cur_v = cur;
+        S.off = off;
+        S.cnt = cnt;
+        S.len = len;
+        S.now_size = now_size;
+        S.last_pc = last_pc;
+        S.aw0 = aw0;
+        S.aw1 = aw1;
+        S.wp0 = wp0;
+        S.wp1 = wp1;
+        S.po = po;
     }
+    return true;
 }
 
-// one step of every walking slot.  *wide: a slot of the running iteration met a vertex with more than 16 records.
+// one step of every walking slot
 __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint32_t *arena_v, uint32_t *arena_s, uint64_t cap_each,
                                            bool *wide, bool drain) {
-    const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
+    const uint32_t lane = lane_id(), g = lane >> GL_SHIFT, sub = lane & (GL - 1u);
     uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
     uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
-    if (__ballot(S.status < 0 && S.cnt > 16u)) {
-        for (;;) {  // wide zombies, one at a time (one copy of the wide walk in the code)
-            const uint64_t wz = __ballot(S.status < 0 && S.cnt > 16u && S.zombie != 0u);
-            if (!wz) break;
-            slot_finish_wide(L, X, S, (uint32_t)(__ffsll((long long)wz) - 1) >> 4);
-        }
-        if (__ballot(S.status < 0 && S.cnt > 16u)) {
+    for (;;) {  // slots too wide for their lanes, one at a time (one copy of the wide walk in the code)
+        const uint64_t wz = __ballot(S.status < 0 && S.cnt > GL);
+        if (!wz) break;
+        if (!slot_finish_wide(L, X, S, (uint32_t)(__ffsll((long long)wz) - 1) >> GL_SHIFT, arena_v, arena_s, cap_each)) {
             *wide = true;
             return;
         }
@@ -1120,19 +971,15 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
         // the window follows the lowest leading slot; the others use it while they are inside
         const uint32_t av = lead ? S.cur_v : 0xFFFFFFFFu;
         uint32_t a = __builtin_amdgcn_readlane(av, 0), ao = __builtin_amdgcn_readlane(S.off, 0), ac = __builtin_amdgcn_readlane(S.cnt, 0);
-#define PAG_ANCHOR(LN)                                                   \
-    {                                                                    \
-        const uint32_t b = __builtin_amdgcn_readlane(av, LN);            \
-        if (b < a) {                                                     \
-            a = b;                                                       \
-            ao = __builtin_amdgcn_readlane(S.off, LN);                   \
-            ac = __builtin_amdgcn_readlane(S.cnt, LN);                   \
-        }                                                                \
-    }
-        PAG_ANCHOR(16)
-        PAG_ANCHOR(32)
-        PAG_ANCHOR(48)
-#undef PAG_ANCHOR
+#pragma unroll
+        for (int q = 1; q < PROBE_GROUPS; ++q) {
+            const uint32_t b = __builtin_amdgcn_readlane(av, q * (int)GL);
+            if (b < a) {
+                a = b;
+                ao = __builtin_amdgcn_readlane(S.off, q * (int)GL);
+                ac = __builtin_amdgcn_readlane(S.cnt, q * (int)GL);
+            }
+        }
         if (a != 0xFFFFFFFFu) win_follow(L, X, a, ao, ac);
     }
     X.n_classify += 1;
@@ -1157,12 +1004,12 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         uint64_t bm = __ballot(cls == c);
-        uint32_t gm = (uint32_t)(bm >> (16u * g)) & 0xFFFFu;
+        uint32_t gm = (uint32_t)(bm >> (GL * g)) & GL_MASK;
         if (cm == 0) cm = gm;
     }
     const uint32_t n = (uint32_t)__popc(cm);
     {   // a probe of the running iteration that stops here by classification leaves its accepted records behind
-        const uint32_t ga = (uint32_t)(__ballot(cls >= 0) >> (16u * g)) & 0xFFFFu;
+        const uint32_t ga = (uint32_t)(__ballot(cls >= 0) >> (GL * g)) & GL_MASK;
         if (running && !S.zombie && n != 1u) {
             if (cls >= 0) {
                 const uint32_t kk = (uint32_t)__popc(ga & ((1u << sub) - 1u));
@@ -1175,7 +1022,7 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
             if (sub == 0) L.pb_cnt[g] = (uint32_t)__popc(ga);
         }
     }
-    const int src = (int)(16u * g) + (cm ? __ffs(cm) - 1 : 0);
+    const int src = (int)(GL * g) + (cm ? __ffs(cm) - 1 : 0);
     const uint32_t meta = __shfl(rec.meta, src, 64);
     const uint32_t nv = __shfl(rec.tgt, src, 64);
     const uint32_t npc = __shfl(rec.pc, src, 64);
@@ -1195,7 +1042,7 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
                 if (in_range(X, nv)) stamp_put(L, X, g, nv, S.gen);
                 else gs_insert_single(pset, X.pmask_o, nv, S.gen);
             }
-            if (!S.zombie && sub == (S.len & 15u)) {
+            if (!S.zombie && sub == (S.len & (GL - 1u))) {
                 S.pb_v = nv;
                 S.pb_s = ns;
             }
@@ -1205,9 +1052,9 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
             S.last_pc = npc;
             S.len += 1;
             S.now_size += ns;
-            if (!S.zombie && (S.len & 15u) == 0) {  // 16 entries pending: one 64-byte store per array
-                pv[S.len - 16u + sub] = S.pb_v;
-                ps[S.len - 16u + sub] = S.pb_s;
+            if (!S.zombie && (S.len & (GL - 1u)) == 0) {  // GL entries pending: one coalesced store per array
+                pv[S.len - GL + sub] = S.pb_v;
+                ps[S.len - GL + sub] = S.pb_s;
             }
             S.cur_v = nv;
             if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
@@ -1226,9 +1073,9 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
                 if (S.status == WS_LEAP) X.spec_fail |= 1;
                 S.zombie = 0;
             } else {
-                if (sub < (S.len & 15u)) {  // the entries still waiting in registers
-                    pv[S.len - (S.len & 15u) + sub] = S.pb_v;
-                    ps[S.len - (S.len & 15u) + sub] = S.pb_s;
+                if (sub < (S.len & (GL - 1u))) {  // the entries still waiting in registers
+                    pv[S.len - (S.len & (GL - 1u)) + sub] = S.pb_v;
+                    ps[S.len - (S.len & (GL - 1u)) + sub] = S.pb_s;
                 }
                 S.fresh = 1;
             }
@@ -1241,9 +1088,9 @@ __device__ __forceinline__ void slots_dominate(const WalkCtx &X, Slot &S, bool s
     const bool mine = S.status < 0 && S.epoch == X.epoch;
 #pragma unroll
     for (int a = 0; a < PROBE_GROUPS; ++a) {
-        const int sa = __builtin_amdgcn_readlane(S.status, 16 * a);
-        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a);
-        const uint32_t aba = __builtin_amdgcn_readlane(S.ab, 16 * a), alta = __builtin_amdgcn_readlane(S.alt, 16 * a);
+        const int sa = __builtin_amdgcn_readlane(S.status, (int)GL * a);
+        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a);
+        const uint32_t aba = __builtin_amdgcn_readlane(S.ab, (int)GL * a), alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a);
         if (!(fa != 0u && ea == X.epoch)) continue;
         if (mine) {
             if (sa == WS_LEAP && alta < S.alt) {  // an earlier alternative leaps: this one can never be chosen
@@ -1261,10 +1108,10 @@ __device__ __forceinline__ void slots_dominate(const WalkCtx &X, Slot &S, bool s
 }
 
 // Start the m alternatives L.br_* in free slots and walk until the choice among them is determined.
-// Returns false if an alternative met a vertex with more than 16 records (the caller probes sequentially).
+// Returns false if an alternative met a vertex with more than 64 records (the caller probes sequentially).
 __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uint32_t m, bool have_meta, uint64_t has_size, uint32_t *arena_v,
                             uint32_t *arena_s, uint64_t cap_each, bool speculate) {
-    const uint32_t lane = lane_id(), g = lane >> 4, sub = lane & 15u;
+    const uint32_t lane = lane_id(), g = lane >> GL_SHIFT, sub = lane & (GL - 1u);
     bool wide = false;
     if (cap_each == 0) {
         X.overflow = 1;
@@ -1274,10 +1121,12 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
     uint32_t free_mask;
     for (;;) {
         const uint64_t fb = __ballot(sub == 0 && S.status >= 0);
-        free_mask = (uint32_t)((fb & 1ull) | ((fb >> 15) & 2ull) | ((fb >> 30) & 4ull) | ((fb >> 45) & 8ull));
+        free_mask = 0;
+#pragma unroll
+        for (int q = 0; q < PROBE_GROUPS; ++q) free_mask |= (uint32_t)((fb >> (q * (int)GL)) & 1ull) << q;
         if ((uint32_t)__popc(free_mask) >= m) break;
         slots_step(L, X, S, arena_v, arena_s, cap_each, &wide, true);
-        wide = false;  // a zombie that gets too wide is finished by the whole wave inside the step
+        wide = false;  // only zombies walk here, and a zombie that gets too wide is finished inside the step
     }
     X.gen += 1;
     X.n_probe += m;
@@ -1304,7 +1153,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         S.wt0 = X.win_t0;
         S.wt1 = X.win_t1;
         S.po = ProbeOut{0, 0, 0};
-        S.pb_v = v0;  // entry 0 of the path waits in lane 0 of the group (sub == len & 15 == 0 holds it)
+        S.pb_v = v0;  // entry 0 of the path waits in lane 0 of the group
         S.pb_s = s0;
         {   // abundance of the alternative (needed if it ends in a branch)
             const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
@@ -1746,7 +1595,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         }
 
         // probe every alternative (PAlgorithm.tcc:251-266): PROBE_GROUPS at a time side by side, each in
-        // its own quarter of the arena; sequential full-wave probing only when a vertex is too wide
+        // its own share of the arena; sequential full-wave probing only when a vertex has more than 64 records
         fast = false;
         bool multi_ok = m <= PROBE_GROUPS;  // larger fan-outs would need several arena generations: sequential
         const bool zombies = __ballot(S.status < 0) != 0ull;  // between iterations only zombies are walking
@@ -1813,10 +1662,10 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 uint32_t best_alt = 0xFFFFFFFFu, best_ab = 0, best_len = 0;
 #pragma unroll
                 for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
-                    const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a2), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a2);
+                    const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a2), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a2);
                     if (!(fa != 0u && ea == X.epoch)) continue;
-                    const int sa = __builtin_amdgcn_readlane(S.status, 16 * a2);
-                    const uint32_t alta = __builtin_amdgcn_readlane(S.alt, 16 * a2);
+                    const int sa = __builtin_amdgcn_readlane(S.status, (int)GL * a2);
+                    const uint32_t alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a2);
                     if (sa == WS_LEAP && alta < best_alt) {
                         pick = a2;
                         best_alt = alta;
@@ -1825,10 +1674,10 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 if (pick < 0) {
 #pragma unroll
                     for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
-                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a2), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a2);
+                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a2), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a2);
                         if (!(fa != 0u && ea == X.epoch)) continue;
-                        const int sa = __builtin_amdgcn_readlane(S.status, 16 * a2);
-                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, 16 * a2), aba = __builtin_amdgcn_readlane(S.ab, 16 * a2);
+                        const int sa = __builtin_amdgcn_readlane(S.status, (int)GL * a2);
+                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a2), aba = __builtin_amdgcn_readlane(S.ab, (int)GL * a2);
                         if (sa == WS_BRANCH && (pick < 0 || aba > best_ab || (aba == best_ab && alta < best_alt))) {
                             pick = a2;
                             best_ab = aba;
@@ -1839,9 +1688,9 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 if (pick < 0) {
 #pragma unroll
                     for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
-                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, 16 * a2), ea = __builtin_amdgcn_readlane(S.epoch, 16 * a2);
+                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a2), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a2);
                         if (!(fa != 0u && ea == X.epoch)) continue;
-                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, 16 * a2), la = __builtin_amdgcn_readlane(S.len, 16 * a2);
+                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a2), la = __builtin_amdgcn_readlane(S.len, (int)GL * a2);
                         if (pick < 0 || la > best_len || (la == best_len && alta < best_alt)) {
                             pick = a2;
                             best_len = la;
@@ -1849,7 +1698,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                         }
                     }
                 }
-                const int src = 16 * pick;
+                const int src = (int)GL * pick;
                 ch_off = (uint64_t)pick * slot_cap;
                 ch_len = __shfl(S.len, src, 64);
                 fast = true;

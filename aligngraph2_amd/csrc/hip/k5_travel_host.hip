@@ -503,18 +503,19 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             set_error("pag_travel: more than %u walk jobs", QCAP);
             return PAG_ENOMEM;
         }
+        const uint64_t PG = TRAV_PROBE_GROUPS;
         const uint64_t cap = cs.seqCap * R.grow, oc = out_cap(cs, R.grow);
         const uint64_t span = (uint64_t)(cs.inHi - cs.inLo) + 1, tbw = span + 1;  // one travel epoch per strand vertex
         DevBuf b_sv = cbuf(i, CB_SEQV), b_ss = cbuf(i, CB_SEQS), b_av = cbuf(i, CB_ARV), b_as = cbuf(i, CB_ARS), b_ts = cbuf(i, CB_TSET),
                b_ps = cbuf(i, CB_PSET), b_st = cbuf(i, CB_STAMP), b_tb = cbuf(i, CB_TBITS);
         int r;
-        if ((r = b_sv.alloc(ns * cap * 4)) || (r = b_ss.alloc(ns * cap * 4)) || (r = b_av.alloc(ns * 4 * cap * 4)) ||
-            (r = b_as.alloc(ns * 4 * cap * 4)) || (r = b_ts.alloc(ns * oc * 8)) || (r = b_ps.alloc(ns * 4 * oc * 8)) ||
-            (r = b_st.alloc(ns * 4 * span * 4)) || (r = b_tb.alloc(ns * tbw * 4)))
+        if ((r = b_sv.alloc(ns * cap * 4)) || (r = b_ss.alloc(ns * cap * 4)) || (r = b_av.alloc(ns * PG * cap * 4)) ||
+            (r = b_as.alloc(ns * PG * cap * 4)) || (r = b_ts.alloc(ns * oc * 8)) || (r = b_ps.alloc(ns * PG * oc * 8)) ||
+            (r = b_st.alloc(ns * PG * span * 4)) || (r = b_tb.alloc(ns * tbw * 4)))
             return r;
         PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, ns * oc * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, ns * 4 * oc * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, ns * 4 * span * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, ns * PG * oc * 8, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, ns * PG * span * 4, s));
         PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, ns * tbw * 4, s));
         fill_contigs();
         R.first = n_posted;
@@ -530,15 +531,15 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.seq_v = b_sv.as<uint32_t>() + sd * cap;
             J.seq_s = b_ss.as<uint32_t>() + sd * cap;
             J.seq_cap = cap;
-            J.arena_v = b_av.as<uint32_t>() + sd * 4 * cap;
-            J.arena_s = b_as.as<uint32_t>() + sd * 4 * cap;
-            J.arena_cap = 4 * cap;
-            J.stamp = b_st.as<uint32_t>() + sd * 4 * span;
+            J.arena_v = b_av.as<uint32_t>() + sd * PG * cap;
+            J.arena_s = b_as.as<uint32_t>() + sd * PG * cap;
+            J.arena_cap = PG * cap;
+            J.stamp = b_st.as<uint32_t>() + sd * PG * span;
             J.stamp_stride = (uint32_t)span;
             J.tbits = b_tb.as<uint32_t>() + sd * tbw;
             J.tset = b_ts.as<uint64_t>() + sd * oc;
             J.tmask = (uint32_t)oc - 1;
-            J.pset = b_ps.as<uint64_t>() + sd * 4 * oc;
+            J.pset = b_ps.as<uint64_t>() + sd * PG * oc;
             J.pmask = (uint32_t)oc - 1;
             J.exact = (R.exact || std::getenv("PAG_WALK_EXACT")) ? 1u : 0u;
             P.C = tc[i];

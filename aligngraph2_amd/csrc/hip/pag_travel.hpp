@@ -7,6 +7,9 @@
 
 namespace pagdev {
 
+// probe slots of a walker wave (lane groups); sizes the per-job stamp arrays, outside sets and arena shares
+constexpr int TRAV_PROBE_GROUPS = 8;
+
 // compact CSR of the finished graph, dense ids: node = k-mer with >= 1 vertex (ascending code),
 // vertex = clustered position (node-major, inside a node ascending (ctg, ref))
 struct TravGraph {
@@ -64,7 +67,7 @@ struct TravJob {
     uint64_t seq_cap;
     uint32_t *arena_v, *arena_s;
     uint64_t arena_cap;
-    uint32_t *stamp;  // zeroed: 4 arrays of [stamp_stride] generation stamps (walkStraight marks, one array per probe group)
+    uint32_t *stamp;  // zeroed: TRAV_PROBE_GROUPS arrays of [stamp_stride] generation stamps (walkStraight marks, one array per probe slot)
     uint32_t stamp_stride;
     uint32_t *tbits;  // zeroed: travel-visited EPOCH per strand vertex (0 = not visited; epoch = graphTravel iteration of the append)
     uint64_t *tset;   // all-ones: (vertex | epoch << 32) hash set for vertices outside the strand's id range
