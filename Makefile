@@ -8,7 +8,10 @@ CXX      ?= g++
 CC       ?= gcc
 ARCH     ?= gfx950
 CXXFLAGS := -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude -Ialigngraph2_amd/csrc/host
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall -Wno-unused-value
+ifdef WALK_PROF
+PROF_FLAGS := -DPAG_WALK_PROF
+endif
+HIPFLAGS := $(PROF_FLAGS) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall -Wno-unused-value
 
 HOST_DIR := aligngraph2_amd/csrc/host
 HIP_DIR  := aligngraph2_amd/csrc/hip

@@ -384,7 +384,24 @@ struct WalkCtx {
     uint32_t n_classify, n_probe, n_records;  // work counters
     int overflow;
     int spec_fail;  // a zombie probe ended in a leap (or could not be continued): the job has to be redone without speculation
+#ifdef PAG_WALK_PROF
+    uint64_t pt[12];
+    uint32_t pc[12];
+#endif
 };
+
+// development aid (make WALK_PROF=1): cycles (s_memtime) and counts per section of a walk, reported through TravJobOut
+#ifdef PAG_WALK_PROF
+#define PROF_BEGIN(name) const uint64_t name = __builtin_amdgcn_s_memtime()
+#define PROF_END(X, i, name)                                  \
+    do {                                                     \
+        (X).pt[i] += __builtin_amdgcn_s_memtime() - (name); \
+        (X).pc[i] += 1;                                      \
+    } while (0)
+#else
+#define PROF_BEGIN(name) do { } while (0)
+#define PROF_END(X, i, name) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool in_win(uint32_t lo, uint32_t hi, uint32_t p) { return p >= lo && p <= hi; }
 __device__ __forceinline__ void win_add(uint32_t &lo, uint32_t &hi, uint32_t p) {
@@ -424,6 +441,7 @@ __device__ __forceinline__ void stamp_put(WalkLds &L, const WalkCtx &X, uint32_t
 // Lanes past the end of a range re-load its last element (the slots they fill are never read).
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor) {
+    PROF_BEGIN(t_fill);
     const uint32_t lane = lane_id();
     const uint32_t d = anchor - X.C.in_lo, span = X.C.in_hi - X.C.in_lo;
     const uint32_t d0 = (d > WIN_BACK ? d - WIN_BACK : 0u) & ~31u;
@@ -475,6 +493,7 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
     X.w_nrec = nrec;
     X.w_anchor = d;
     X.n_fill += 1;
+    PROF_END(X, 6, t_fill);
 }
 
 // true if vertex `cur` with records [off, off + cnt) is served by the window with room to spare (per lane)
@@ -953,10 +972,14 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
     const uint32_t lane = lane_id(), g = lane >> GL_SHIFT, sub = lane & (GL - 1u);
     uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
     uint32_t *pv = arena_v + (uint64_t)g * cap_each, *ps = arena_s + (uint64_t)g * cap_each;
+    PROF_BEGIN(t_a);
     for (;;) {  // slots too wide for their lanes, one at a time (one copy of the wide walk in the code)
         const uint64_t wz = __ballot(S.status < 0 && S.cnt > GL);
         if (!wz) break;
-        if (!slot_finish_wide(L, X, S, (uint32_t)(__ffsll((long long)wz) - 1) >> GL_SHIFT, arena_v, arena_s, cap_each)) {
+        PROF_BEGIN(t_w);
+        const bool okw = slot_finish_wide(L, X, S, (uint32_t)(__ffsll((long long)wz) - 1) >> GL_SHIFT, arena_v, arena_s, cap_each);
+        PROF_END(X, 7, t_w);
+        if (!okw) {
             *wide = true;
             return;
         }
@@ -969,19 +992,20 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
     const bool running = walking && (lead || win_serves(X, S.cur_v, S.off, S.cnt));
     if (__ballot(lead && !win_comfortable(X, S.cur_v, S.off, S.cnt))) {
         // the window follows the lowest leading slot; the others use it while they are inside
-        const uint32_t av = lead ? S.cur_v : 0xFFFFFFFFu;
-        uint32_t a = __builtin_amdgcn_readlane(av, 0), ao = __builtin_amdgcn_readlane(S.off, 0), ac = __builtin_amdgcn_readlane(S.cnt, 0);
-#pragma unroll
-        for (int q = 1; q < PROBE_GROUPS; ++q) {
-            const uint32_t b = __builtin_amdgcn_readlane(av, q * (int)GL);
-            if (b < a) {
-                a = b;
-                ao = __builtin_amdgcn_readlane(S.off, q * (int)GL);
-                ac = __builtin_amdgcn_readlane(S.cnt, q * (int)GL);
-            }
+        uint32_t av = lead ? S.cur_v : 0xFFFFFFFFu;
+        if (GL == 8u) av = min(av, (uint32_t)__builtin_amdgcn_update_dpp((int)av, (int)av, 0x128, 0xF, 0xF, false));  // row_ror:8
+        const uint32_t a = min(min((uint32_t)__builtin_amdgcn_readlane((int)av, 0), (uint32_t)__builtin_amdgcn_readlane((int)av, 16)),
+                               min((uint32_t)__builtin_amdgcn_readlane((int)av, 32), (uint32_t)__builtin_amdgcn_readlane((int)av, 48)));
+        uint32_t ao = 0, ac = 0;
+        if (a != 0xFFFFFFFFu) {
+            const int al = __ffsll((long long)__ballot(lead && S.cur_v == a)) - 1;
+            ao = (uint32_t)__builtin_amdgcn_readlane((int)S.off, al);
+            ac = (uint32_t)__builtin_amdgcn_readlane((int)S.cnt, al);
         }
         if (a != 0xFFFFFFFFu) win_follow(L, X, a, ao, ac);
     }
+    PROF_END(X, 8, t_a);
+    PROF_BEGIN(t_b);
     X.n_classify += 1;
     int cls = -1;
     SuccRec rec{0, 0, 0, 0};
@@ -1000,13 +1024,15 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
         X.win_t0 = st0;
         X.win_t1 = st1;
     }
-    uint32_t cm = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        uint64_t bm = __ballot(cls == c);
-        uint32_t gm = (uint32_t)(bm >> (GL * g)) & GL_MASK;
-        if (cm == 0) cm = gm;
-    }
+    PROF_END(X, 9, t_b);
+    PROF_BEGIN(t_c);
+    // the best class present among the records of the slot (lane-group minimum by DPP), then its members
+    uint32_t key = cls < 0 ? 4u : (uint32_t)cls, mn = key;
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0x141, 0xF, 0xF, false));  // row_half_mirror
+    if (GL == 16u) mn = min(mn, (uint32_t)__builtin_amdgcn_update_dpp((int)mn, (int)mn, 0x140, 0xF, 0xF, false));  // row_mirror
+    const uint32_t cm = (uint32_t)(__ballot(key == mn && key < 4u) >> (GL * g)) & GL_MASK;
     const uint32_t n = (uint32_t)__popc(cm);
     {   // a probe of the running iteration that stops here by classification leaves its accepted records behind
         const uint32_t ga = (uint32_t)(__ballot(cls >= 0) >> (GL * g)) & GL_MASK;
@@ -1027,6 +1053,8 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
     const uint32_t nv = __shfl(rec.tgt, src, 64);
     const uint32_t npc = __shfl(rec.pc, src, 64);
     const uint32_t noff = __shfl(rec.toff, src, 64);
+    PROF_END(X, 10, t_c);
+    PROF_BEGIN(t_d);
     if (running) {
         if (n == 0) {
             S.status = WS_END;
@@ -1081,29 +1109,54 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
             }
         }
     }
+    PROF_END(X, 11, t_d);
+}
+
+// one bit per slot: its first lane
+constexpr uint64_t SLOT_LEADS = GL == 8u ? 0x0101010101010101ull : 0x0001000100010001ull;
+
+// the most abundant first vertex among the slots in `cand` (first lanes of slots; ties: the lowest slot, which within
+// one iteration is the earliest alternative).  Uniform.
+__device__ __forceinline__ int slots_best(uint64_t cand, uint32_t key, uint32_t *best_key) {
+    int pick = -1;
+    uint32_t best = 0;
+    while (cand) {
+        const int l = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        const uint32_t kq = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
+        if (pick < 0 || kq > best) {
+            pick = l;
+            best = kq;
+        }
+    }
+    *best_key = best;
+    return pick;
 }
 
 // After a step: what the finished alternatives of the running iteration mean for the ones still walking.
+// (The alternatives of one iteration sit in slots of increasing index, so "an earlier alternative" = "a lower slot".)
 __device__ __forceinline__ void slots_dominate(const WalkCtx &X, Slot &S, bool speculate) {
-    const bool mine = S.status < 0 && S.epoch == X.epoch;
-#pragma unroll
-    for (int a = 0; a < PROBE_GROUPS; ++a) {
-        const int sa = __builtin_amdgcn_readlane(S.status, (int)GL * a);
-        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a);
-        const uint32_t aba = __builtin_amdgcn_readlane(S.ab, (int)GL * a), alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a);
-        if (!(fa != 0u && ea == X.epoch)) continue;
-        if (mine) {
-            if (sa == WS_LEAP && alta < S.alt) {  // an earlier alternative leaps: this one can never be chosen
-                S.status = WS_END;
-                S.zombie = 0;
-                S.fresh = 0;
-            } else if (speculate && !S.zombie && sa == WS_BRANCH && (aba > S.ab || (aba == S.ab && alta < S.alt)) &&
-                       S.H + S.now_size + SPEC_MARGIN < X.C.split_size) {
-                // (only while the walk is far from the size at which leaping becomes possible at all: close to it,
-                // leaps of side paths are common and every one would void the whole job)
-                S.zombie = 1;
-            }
+    const bool fin = S.fresh != 0u && S.epoch == X.epoch;
+    const uint64_t lm = __ballot(fin && S.status == WS_LEAP) & SLOT_LEADS;
+    if (lm) {  // an earlier alternative leaps: the later ones can never be chosen
+        const uint32_t alt_l = (uint32_t)__builtin_amdgcn_readlane((int)S.alt, __ffsll((long long)lm) - 1);
+        if (S.status < 0 && S.epoch == X.epoch && alt_l < S.alt) {
+            S.status = WS_END;
+            S.zombie = 0;
+            S.fresh = 0;
         }
+    }
+    if (!speculate) return;
+    const uint64_t bm = __ballot(fin && S.status == WS_BRANCH) & SLOT_LEADS;
+    if (bm) {
+        uint32_t bab;
+        const int bl = slots_best(bm, S.ab, &bab);
+        const uint32_t balt = (uint32_t)__builtin_amdgcn_readlane((int)S.alt, bl);
+        // (only while the walk is far from the size at which leaping becomes possible at all: close to it,
+        // leaps of side paths are common and every one would void the whole job)
+        if (S.status < 0 && S.epoch == X.epoch && !S.zombie && (bab > S.ab || (bab == S.ab && balt < S.alt)) &&
+            S.H + S.now_size + SPEC_MARGIN < X.C.split_size)
+            S.zombie = 1;
     }
 }
 
@@ -1118,20 +1171,20 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         return true;
     }
     // wait for m free slots (zombies occupy theirs until they stop)
-    uint32_t free_mask;
+    uint64_t free_leads;
+    PROF_BEGIN(t_wait);
     for (;;) {
-        const uint64_t fb = __ballot(sub == 0 && S.status >= 0);
-        free_mask = 0;
-#pragma unroll
-        for (int q = 0; q < PROBE_GROUPS; ++q) free_mask |= (uint32_t)((fb >> (q * (int)GL)) & 1ull) << q;
-        if ((uint32_t)__popc(free_mask) >= m) break;
+        free_leads = __ballot(S.status >= 0) & SLOT_LEADS;
+        if ((uint32_t)__popcll(free_leads) >= m) break;
         slots_step(L, X, S, arena_v, arena_s, cap_each, &wide, true);
         wide = false;  // only zombies walk here, and a zombie that gets too wide is finished inside the step
     }
+    PROF_END(X, 2, t_wait);
+    PROF_BEGIN(t_setup);
     X.gen += 1;
     X.n_probe += m;
-    const uint32_t rank = (uint32_t)__popc(free_mask & ((1u << g) - 1u));
-    if (((free_mask >> g) & 1u) && rank < m) {
+    const uint32_t rank = (uint32_t)__popcll(free_leads & ((1ull << (GL * g)) - 1ull));
+    if (S.status >= 0 && rank < m) {
         uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
         const uint32_t v0 = L.br_v[rank], s0 = L.br_s[rank];
         S.status = -1;
@@ -1190,6 +1243,8 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         }
     }
     slots_dominate(X, S, speculate);  // an alternative may have leapt right at its first vertex
+    PROF_END(X, 3, t_setup);
+    PROF_BEGIN(t_steps);
     uint64_t seen = __ballot(S.fresh != 0u && S.epoch == X.epoch);
     for (;;) {
         if (!__ballot(S.status < 0 && !S.zombie && S.epoch == X.epoch)) break;
@@ -1201,6 +1256,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
             seen = now;
         }
     }
+    PROF_END(X, 4, t_steps);
     X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
     {
         int sf = X.spec_fail;
@@ -1378,6 +1434,12 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.overflow = 0;
     X.spec_fail = 0;
     X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.n_fill = 0;
+#ifdef PAG_WALK_PROF
+    for (int q = 0; q < 12; ++q) {
+        X.pt[q] = 0;
+        X.pc[q] = 0;
+    }
+#endif
     X.n_classify = X.n_probe = X.n_records = 0;
 
     for (uint32_t i = lane; i < FILT_WORDS; i += 64) {
@@ -1428,6 +1490,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     uint64_t n_main = 0;
     for (;;) {
         ++n_main;
+        PROF_BEGIN(t_app);
         X.epoch = (uint32_t)n_main;  // marks appended in this iteration carry it; the probes launched after see all of them
         // append the chosen path to the sequence, mark it visited, widen the travel window
         if (seq_len + ch_len > J.seq_cap) {
@@ -1521,6 +1584,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             l_cnt = G.succ_off[last + 1] - l_off;
         }
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
+        PROF_END(X, 0, t_app);
+        PROF_BEGIN(t_cls);
 
         Step one;
         bool list_meta = false;
@@ -1596,6 +1661,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
 
         // probe every alternative (PAlgorithm.tcc:251-266): PROBE_GROUPS at a time side by side, each in
         // its own share of the arena; sequential full-wave probing only when a vertex has more than 64 records
+        PROF_END(X, 1, t_cls);
         fast = false;
         bool multi_ok = m <= PROBE_GROUPS;  // larger fan-outs would need several arena generations: sequential
         const bool zombies = __ballot(S.status < 0) != 0ull;  // between iterations only zombies are walking
@@ -1604,9 +1670,11 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             ProbeRes R[PROBE_GROUPS];
             bool ok_all = true;
             X.gen += 1;
+            PROF_BEGIN(t_pw);
             for (uint32_t i = 0; i < m && ok_all; ++i)
                 ok_all = probe_wave(L, X, i, i, list_meta, has_size + now_size, J.arena_v + i * cap_each, J.arena_s + i * cap_each, cap_each,
                                     true, &R[i]);
+            PROF_END(X, 7, t_pw);
             if (ok_all) {
                 __syncthreads();
                 if (X.overflow) break;
@@ -1655,50 +1723,19 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             multi_ok = probe_slots(L, X, S, m, list_meta, has_size + now_size, J.arena_v, J.arena_s, slot_cap, speculate);
             if (multi_ok) {
                 if (X.overflow) break;
+                PROF_BEGIN(t_choice);
                 // choice (PAlgorithm.tcc:268-296) among the alternatives of this iteration that have stopped (the
                 // zombies are taken not to leap): the first one that leaps; else the branching one with the most
                 // abundant first vertex (first wins ties); else the longest dead end (first wins ties)
-                int pick = -1;
-                uint32_t best_alt = 0xFFFFFFFFu, best_ab = 0, best_len = 0;
-#pragma unroll
-                for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
-                    const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a2), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a2);
-                    if (!(fa != 0u && ea == X.epoch)) continue;
-                    const int sa = __builtin_amdgcn_readlane(S.status, (int)GL * a2);
-                    const uint32_t alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a2);
-                    if (sa == WS_LEAP && alta < best_alt) {
-                        pick = a2;
-                        best_alt = alta;
-                    }
-                }
-                if (pick < 0) {
-#pragma unroll
-                    for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
-                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a2), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a2);
-                        if (!(fa != 0u && ea == X.epoch)) continue;
-                        const int sa = __builtin_amdgcn_readlane(S.status, (int)GL * a2);
-                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a2), aba = __builtin_amdgcn_readlane(S.ab, (int)GL * a2);
-                        if (sa == WS_BRANCH && (pick < 0 || aba > best_ab || (aba == best_ab && alta < best_alt))) {
-                            pick = a2;
-                            best_ab = aba;
-                            best_alt = alta;
-                        }
-                    }
-                }
-                if (pick < 0) {
-#pragma unroll
-                    for (int a2 = 0; a2 < PROBE_GROUPS; ++a2) {
-                        const uint32_t fa = __builtin_amdgcn_readlane(S.fresh, (int)GL * a2), ea = __builtin_amdgcn_readlane(S.epoch, (int)GL * a2);
-                        if (!(fa != 0u && ea == X.epoch)) continue;
-                        const uint32_t alta = __builtin_amdgcn_readlane(S.alt, (int)GL * a2), la = __builtin_amdgcn_readlane(S.len, (int)GL * a2);
-                        if (pick < 0 || la > best_len || (la == best_len && alta < best_alt)) {
-                            pick = a2;
-                            best_len = la;
-                            best_alt = alta;
-                        }
-                    }
-                }
-                const int src = (int)GL * pick;
+                const bool fin = S.fresh != 0u && S.epoch == X.epoch;
+                const uint64_t lm = __ballot(fin && S.status == WS_LEAP) & SLOT_LEADS;
+                const uint64_t bm = __ballot(fin && S.status == WS_BRANCH) & SLOT_LEADS;
+                int src;
+                uint32_t kq;
+                if (lm) src = __ffsll((long long)lm) - 1;
+                else if (bm) src = slots_best(bm, S.ab, &kq);
+                else src = slots_best(__ballot(fin) & SLOT_LEADS, S.len, &kq);
+                const int pick = src >> GL_SHIFT;
                 ch_off = (uint64_t)pick * slot_cap;
                 ch_len = __shfl(S.len, src, 64);
                 fast = true;
@@ -1716,6 +1753,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 f_cnt = __shfl(S.cnt, src, 64);
                 f_size = __shfl(S.now_size, src, 64);
                 S.fresh = 0;  // consumed
+                PROF_END(X, 5, t_choice);
             } else if (S.epoch == X.epoch && (S.status < 0 || S.fresh != 0u)) {  // too wide: this iteration is probed sequentially
                 S.status = WS_END;
                 S.fresh = 0;
@@ -1794,6 +1832,12 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         o.n_fill = X.n_fill | ((uint64_t)X.spec_fail << 32);
         o.n_out = X.n_out;
         o.n_main = n_main;
+#ifdef PAG_WALK_PROF
+        for (int q = 0; q < 12; ++q) {
+            o.prof_t[q] = X.pt[q];
+            o.prof_c[q] = X.pc[q];
+        }
+#endif
         o.last_ctg = seq_len ? (uint32_t)(G.upos[J.seq_v[seq_len - 1]] >> 32) : 0;
         *out = o;
     }

@@ -636,6 +636,17 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 for (uint32_t j = 0; j < run[i].n; ++j) mx = std::max<uint64_t>(mx, houts[run[i].first + j].n_classify);
                 std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u done (%u jobs, max classify %llu), %u still walking\n", now_ms() - tw0, i, run[i].round, run[i].n,
                              (unsigned long long)mx, n_outstanding - (uint32_t)batch.size());
+#ifdef PAG_WALK_PROF
+                for (uint32_t j = 0; j < run[i].n; ++j) {
+                    const TravJobOut &o = houts[run[i].first + j];
+                    if (o.n_classify != mx) continue;
+                    static const char *nm[12] = {"append", "classify", "wait", "setup", "steps", "choice", "fill", "probe_wave", "st.window", "st.eval", "st.ballot", "st.update"};
+                    std::fprintf(stderr, "[prof] contig %u main %llu fills %llu:", i, (unsigned long long)o.n_main, (unsigned long long)(o.n_fill & 0xFFFFFFFFu));
+                    for (int q = 0; q < 12; ++q) std::fprintf(stderr, " %s %.1f Mcyc /%u", nm[q], o.prof_t[q] * 1e-6, o.prof_c[q]);
+                    std::fprintf(stderr, "\n");
+                    break;
+                }
+#endif
             }
         lap("walk");
         std::vector<uint32_t> redo, next_round;

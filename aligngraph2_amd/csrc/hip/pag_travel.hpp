@@ -83,6 +83,10 @@ struct TravJobOut {
     uint32_t last_ctg;
     int overflow;
     uint64_t n_fill, n_out, n_main;
+#ifdef PAG_WALK_PROF
+    uint64_t prof_t[12];  // cycles per section of the walk (development aid, make WALK_PROF=1)
+    uint32_t prof_c[12];
+#endif
 };
 
 // queue of the persistent walker (fine-grained host memory)
