@@ -64,11 +64,16 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 
 HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
 HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle \
-           tests/harness/bin/seg_kernels_test
+           tests/harness/bin/seg_kernels_test tests/harness/bin/sort_bench
 harness: $(HARNESS)
 
 # kernel-level check of K3/K4 against a sequential restatement (needs a GPU to run)
 tests/harness/bin/seg_kernels_test: tests/harness/seg_kernels_test.hip $(HIP_DIR)/k34_segments.hip $(HIP_HDRS)
+	@mkdir -p tests/harness/bin
+	$(HIPCC) $(HIPFLAGS) -fno-PIC -o $@ $<
+
+# timing + correctness aid for the radix sort (needs a GPU to run); -DSORT_X=1|2|4 builds the timing experiments
+tests/harness/bin/sort_bench: tests/harness/sort_bench.hip $(HIP_DIR)/k2_sort.hip $(HIP_DIR)/util.hip $(HIP_HDRS)
 	@mkdir -p tests/harness/bin
 	$(HIPCC) $(HIPFLAGS) -fno-PIC -o $@ $<
 

@@ -21,6 +21,9 @@ constexpr int SW = ST / 64;       // waves per block
 constexpr int SROUNDS = 5;       // records per thread
 constexpr int STILE = ST * SROUNDS;
 constexpr int SMAXR = 256;        // max radix (8 bits)
+#ifndef SORT_X
+#define SORT_X 0  // timing experiments of tests/harness/sort_bench.hip (results wrong when non-zero)
+#endif
 
 __global__ __launch_bounds__(ST) void sort_hist(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t rmask,
                                                uint32_t *__restrict__ hist, uint32_t n_tiles) {
@@ -38,106 +41,165 @@ __global__ __launch_bounds__(ST) void sort_hist(const uint32_t *__restrict__ key
 }
 
 struct ScatterLds {
-    uint32_t wcnt[SW][SMAXR];   // per-wave running digit counters, then their exclusive prefix over waves
-    uint32_t dstart[SMAXR];     // exclusive prefix of the tile's digit totals over digits
-    uint64_t gbase[SMAXR];      // output base of (digit, this tile)
+    uint32_t wcnt[SW][SMAXR + 1];  // per-wave running digit counters, then their exclusive prefix over waves (+1: bank spread)
+    uint32_t dtot[SMAXR];          // records of the tile per digit
+    uint32_t dstart[SMAXR];        // exclusive prefix of dtot over digits
+    uint64_t goff[SMAXR];          // output base of (digit, this tile) minus dstart: destination = goff[d] + staged position
     uint32_t skey[STILE];
     uint64_t sval[STILE];
-    uint64_t red[8];
 };
+static_assert(SW == 16, "the wave prefix below scans rows of 16 lanes");
+static_assert(sizeof(uint64_t) * STILE >= sizeof(uint64_t) * SW * SMAXR, "match words alias the payload staging buffer");
 
+// inclusive prefix sum inside each row of 16 lanes (DPP row shifts, zero fill)
+__device__ __forceinline__ uint32_t row16_incl_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    return v;
+}
+
+// Persistent blocks (two per CU), each looping over tiles: the keys and payloads of the NEXT tile (and its output
+// bases) are requested into registers before the current tile is ranked, staged and written, so that loads are in
+// flight during the phases of a tile that do not touch memory.  Tile order: the 64 blocks resident on one XCD (block
+// id mod 8 = XCD) work on 64 CONSECUTIVE tiles at a time, so the runs they append to a digit's output region are
+// adjacent and the partial cache lines at run boundaries are combined in that XCD's L2 instead of being written back
+// by two L2s.
+constexpr uint32_t SCHUNK = 64;  // consecutive tiles taken by the blocks of one XCD per iteration
+
+__device__ __forceinline__ uint64_t scatter_tile(uint32_t block, uint32_t n_blocks, uint32_t it) {
+    // blocks per XCD = n_blocks / 8 when the grid fills the chip; small grids fall back to a plain stride
+    if (n_blocks % (8u * SCHUNK) != 0u) return (uint64_t)it * n_blocks + block;
+    const uint32_t per_xcd = n_blocks / 8u, x = block & 7u, slot = block >> 3;
+    const uint32_t chunks_per_it = per_xcd / SCHUNK;  // chunks one XCD takes per iteration
+    const uint32_t c = slot / SCHUNK, t = slot % SCHUNK;
+    return ((uint64_t)((uint64_t)it * chunks_per_it + c) * 8u + x) * SCHUNK + t;
+}
+
+template <int BITS>
 __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
                                                   uint32_t *__restrict__ okeys, uint64_t *__restrict__ ovals, uint64_t n,
-                                                  int shift, int bits, const uint64_t *__restrict__ hist_scan,
-                                                  uint32_t n_tiles) {
+                                                  int shift, const uint64_t *__restrict__ hist_scan, uint32_t n_tiles) {
     __shared__ ScatterLds L;
-    const uint32_t rmask = (1u << bits) - 1u;
+    constexpr uint32_t rmask = (1u << BITS) - 1u;
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < SW * SMAXR; i += ST) (&L.wcnt[0][0])[i] = 0;
-    __syncthreads();
+    const uint32_t n_iter = (n_tiles + gridDim.x - 1) / gridDim.x;  // (both tile orders enumerate [it * grid, (it + 1) * grid) in iteration it)
 
-    const uint64_t tile_base = (uint64_t)blockIdx.x * STILE;
-    const uint64_t wave_base = tile_base + (uint64_t)w * (64 * SROUNDS);
-    uint32_t key[SROUNDS];
-    uint32_t rk[SROUNDS];  // rank of the record among same-digit records of this wave
+    uint32_t nkey[SROUNDS];
+    uint64_t nval[SROUNDS];
+    uint64_t ngbase = 0;  // threads 0 .. 2^BITS - 1: output base of (digit = thread, tile)
+    auto request = [&](uint64_t tile) {
+        const uint64_t wb = tile * STILE + (uint64_t)w * (64 * SROUNDS);
+        if (threadIdx.x <= rmask && tile < n_tiles) ngbase = hist_scan[(uint64_t)threadIdx.x * n_tiles + tile];
 #pragma unroll
-    for (int r = 0; r < SROUNDS; ++r) {
-        uint64_t i = wave_base + (uint64_t)r * 64 + lane;
-        bool valid = i < n;
-        key[r] = valid ? keys[i] : 0u;
-        uint32_t d = (key[r] >> shift) & rmask;
-        // peers = lanes of this wave holding the same digit in this round
-        uint64_t peers = __ballot(valid);
-        for (int b = 0; b < bits; ++b) {
-            uint64_t vote = __ballot(valid && ((d >> b) & 1u));
-            peers &= ((d >> b) & 1u) ? vote : ~vote;
+        for (int r = 0; r < SROUNDS; ++r) {
+            const uint64_t i = wb + (uint64_t)r * 64 + lane;
+            const bool valid = tile < n_tiles && i < n;
+            nkey[r] = valid ? keys[i] : 0u;
+            nval[r] = valid ? vals[i] : 0ull;
         }
-        uint32_t before = __popcll(peers & lanemask_lt());
-        // per-wave counters: the read (all lanes) and the leader's write are LDS operations of ONE wave,
-        // which the LDS executes in program order — no barrier needed between rounds
-        uint32_t base = valid ? L.wcnt[w][d] : 0u;
-        if (valid && before == 0) L.wcnt[w][d] = base + (uint32_t)__popcll(peers);
-        rk[r] = base + before;
-    }
+    };
+    request(scatter_tile(blockIdx.x, gridDim.x, 0));
 
-    __syncthreads();
-    // per digit: prefix over waves, tile totals, prefix over digits, global base
-    if (threadIdx.x < SMAXR) {
-        uint32_t d = threadIdx.x;
-        uint32_t run = 0;
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        const uint64_t tile = scatter_tile(blockIdx.x, gridDim.x, it);
+        uint32_t key[SROUNDS];
+        uint64_t val[SROUNDS];
 #pragma unroll
-        for (int ww = 0; ww < SW; ++ww) {
-            uint32_t c = L.wcnt[ww][d];
-            L.wcnt[ww][d] = run;
-            run += c;
+        for (int r = 0; r < SROUNDS; ++r) {
+            key[r] = nkey[r];
+            val[r] = nval[r];
         }
-        uint64_t tot;
-        // block exclusive scan of `run` over the 256 digits
-        uint64_t wtot;
-        uint64_t ex = wave_excl_sum64(run, &wtot);
-        if (lane == 63) L.red[w] = wtot;
-        L.dstart[d] = (uint32_t)ex;  // completed with the preceding waves' totals below
-        L.gbase[d] = d <= rmask ? hist_scan[(uint64_t)d * n_tiles + blockIdx.x] : 0;
-        (void)tot;
-    }
-    __syncthreads();
-    if (threadIdx.x < SMAXR) {
-        uint32_t pre = 0;
-        for (int i = 0; i < (int)w; ++i) pre += (uint32_t)L.red[i];  // waves 0..3 hold the 256 digits
-        L.dstart[threadIdx.x] += pre;
-    }
-    __syncthreads();
+        const uint64_t gbase = ngbase;
+        if (it + 1 < n_iter) request(scatter_tile(blockIdx.x, gridDim.x, it + 1));
+        if (tile >= n_tiles) continue;  // (uniform per block)
 
-    // stage the tile in digit order
+        const uint64_t tile_base = tile * STILE;
+        const uint64_t wave_base = tile_base + (uint64_t)w * (64 * SROUNDS);
+        // every wave clears its own counters and match words: LDS operations of one wave execute in program order, no
+        // barrier needed
+        unsigned long long *match = (unsigned long long *)&L.sval[0] + (size_t)w * (rmask + 1u);  // (the staging buffer is free now)
 #pragma unroll
-    for (int r = 0; r < SROUNDS; ++r) {
-        uint64_t i = wave_base + (uint64_t)r * 64 + lane;
-        if (i < n) {
-            uint32_t d = (key[r] >> shift) & rmask;
-            uint32_t p = L.dstart[d] + L.wcnt[w][d] + rk[r];
-            L.skey[p] = key[r];
-            L.sval[p] = vals[i];
+        for (int i = 0; i < SMAXR / 64; ++i) L.wcnt[w][i * 64 + lane] = 0;
+#pragma unroll
+        for (uint32_t i = lane; i <= rmask; i += 64) match[i] = 0ull;
+        uint32_t rk[SROUNDS];  // rank of the record among same-digit records of this wave
+#pragma unroll
+        for (int r = 0; r < SROUNDS; ++r) {
+            const uint64_t i = wave_base + (uint64_t)r * 64 + lane;
+            const bool valid = i < n;
+            const uint32_t d = (key[r] >> shift) & rmask;
+            // peers = lanes of this wave holding the same digit in this round: every lane ORs its bit into the digit's
+            // match word (one LDS atomic), reads the word back and clears it for the next round — three LDS
+            // instructions instead of BITS ballots with per-lane 64-bit selects
+            if (valid) atomicOr(&match[d], 1ull << lane);
+            const uint64_t peers = valid ? match[d] : 0ull;
+            if (valid) match[d] = 0ull;
+            const uint32_t before = __popcll(peers & lanemask_lt());
+            const uint32_t base = valid ? L.wcnt[w][d] : 0u;
+            if (valid && before == 0) L.wcnt[w][d] = base + (uint32_t)__popcll(peers);
+            rk[r] = base + before;
         }
-    }
-    __syncthreads();
-    const uint32_t count = (uint32_t)((n - tile_base) < (uint64_t)STILE ? (n - tile_base) : (uint64_t)STILE);
-    for (uint32_t p = threadIdx.x; p < count; p += ST) {
-        uint32_t kx = L.skey[p];
-        uint32_t d = (kx >> shift) & rmask;
-        uint64_t dst = L.gbase[d] + (p - L.dstart[d]);
-        okeys[dst] = kx;
-        ovals[dst] = L.sval[p];
+
+        __syncthreads();
+        // per digit: exclusive prefix over the 16 waves (a row of 16 lanes per digit), tile totals
+#pragma unroll
+        for (int j = 0; j < SMAXR * SW / ST; ++j) {
+            const uint32_t d = (uint32_t)j * (ST / SW) + (threadIdx.x >> 4), ww = threadIdx.x & 15u;
+            const uint32_t c = L.wcnt[ww][d];
+            const uint32_t incl = row16_incl_sum(c);
+            L.wcnt[ww][d] = incl - c;
+            if (ww == 15u) L.dtot[d] = incl;
+        }
+        __syncthreads();
+        // prefix over digits by one wave (four digits per lane); output bases
+        if (w == 0) {
+            const uint32_t t0 = L.dtot[4 * lane], t1 = L.dtot[4 * lane + 1], t2 = L.dtot[4 * lane + 2], t3 = L.dtot[4 * lane + 3];
+            uint32_t tot;
+            const uint32_t ex = wave_excl_sum(t0 + t1 + t2 + t3, &tot);
+            L.dstart[4 * lane] = ex;
+            L.dstart[4 * lane + 1] = ex + t0;
+            L.dstart[4 * lane + 2] = ex + t0 + t1;
+            L.dstart[4 * lane + 3] = ex + t0 + t1 + t2;
+        }
+        __syncthreads();
+        if (threadIdx.x <= rmask) L.goff[threadIdx.x] = gbase - L.dstart[threadIdx.x];
+
+        // stage the tile in digit order
+#pragma unroll
+        for (int r = 0; r < SROUNDS; ++r) {
+            const uint64_t i = wave_base + (uint64_t)r * 64 + lane;
+            if ((SORT_X & 2) && key[r] != 0x12345678u) continue;
+            if (i < n) {
+                const uint32_t d = (key[r] >> shift) & rmask;
+                const uint32_t p = L.dstart[d] + L.wcnt[w][d] + rk[r];
+                L.skey[p] = key[r];
+                L.sval[p] = val[r];
+            }
+        }
+        __syncthreads();
+        const uint32_t count = (uint32_t)((n - tile_base) < (uint64_t)STILE ? (n - tile_base) : (uint64_t)STILE);
+        for (uint32_t p = threadIdx.x; p < count; p += ST) {
+            const uint32_t kx = L.skey[p];
+            const uint32_t d = (kx >> shift) & rmask;
+            const uint64_t dst = L.goff[d] + p;
+            if ((SORT_X & 3) && kx != 0x12345678u) continue;
+            okeys[dst] = kx;
+            ovals[dst] = L.sval[p];
+        }
+        __syncthreads();  // the next iteration's match words live in the staging buffer
     }
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t sort_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // tmp layout: hist u32[R * n_tiles] | hist_scan u64[R * n_tiles] | scan tmp
 size_t sort_tmp_bytes(uint64_t n) {
     uint64_t n_tiles = (n + STILE - 1) / STILE;
     if (n_tiles == 0) n_tiles = 1;
     uint64_t cells = (uint64_t)SMAXR * n_tiles;
-    return align256(cells * 4) + align256(cells * 8) + align256(scan_tmp_bytes(cells)) + 256;
+    return sort_align256(cells * 4) + sort_align256(cells * 8) + sort_align256(scan_tmp_bytes(cells)) + 256;
 }
 
 int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t n, int key_bits, void *tmp,
@@ -157,11 +219,13 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
     char *p = (char *)tmp;
     uint32_t *hist = (uint32_t *)p;
     uint64_t cells = (uint64_t)SMAXR * n_tiles;
-    p += align256(cells * 4);
+    p += sort_align256(cells * 4);
     uint64_t *hist_scan = (uint64_t *)p;
-    p += align256(cells * 8);
+    p += sort_align256(cells * 8);
     void *scan_tmp = p;
 
+    // persistent scatter blocks: two 80 KB blocks fit a CU's LDS; 256 CUs
+    const uint32_t scatter_grid = n_tiles < 512u ? n_tiles : 512u;
     hipEvent_t ev[2 * 8];
     for (int i = 0; i < 2 * passes; ++i) PAG_HIP_TRY(hipEventCreate(&ev[i]));
     uint32_t *ka = k0, *kb = k1;
@@ -176,7 +240,14 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
         int rc = scan_u32_to_u64(hist, hist_scan, used, nullptr, scan_tmp, s);
         if (rc != PAG_OK) return rc;
         PAG_HIP_TRY(hipEventRecord(ev[2 * pass], s));
-        sort_scatter<<<dim3(n_tiles), dim3(ST), 0, s>>>(ka, va, kb, vb, n, shift, b, hist_scan, n_tiles);
+        switch (b) {
+#define PAG_SCATTER(B)                                                                                              \
+    case B:                                                                                                         \
+        sort_scatter<B><<<dim3(scatter_grid), dim3(ST), 0, s>>>(ka, va, kb, vb, n, shift, hist_scan, n_tiles);      \
+        break;
+            PAG_SCATTER(1) PAG_SCATTER(2) PAG_SCATTER(3) PAG_SCATTER(4) PAG_SCATTER(5) PAG_SCATTER(6) PAG_SCATTER(7) PAG_SCATTER(8)
+#undef PAG_SCATTER
+        }
         PAG_HIP_TRY(hipEventRecord(ev[2 * pass + 1], s));
         uint32_t *tk = ka;
         ka = kb;

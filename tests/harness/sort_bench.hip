@@ -1,0 +1,87 @@
+// Development aid (not a test, not shipped): times the radix-sort passes of k2_sort.hip on random records and checks
+// the result against std::stable_sort on a sample size.  make tests/harness/bin/sort_bench; run on a GPU box:
+//   sort_bench [n_records] [key_bits]
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../aligngraph2_amd/csrc/hip/util.hip"
+#include "../../aligngraph2_amd/csrc/hip/k2_sort.hip"
+
+using namespace pagdev;
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));            \
+            return 2;                                                              \
+        }                                                                          \
+    } while (0)
+
+__global__ void fill_random(uint32_t *k, uint64_t *v, uint64_t n, uint32_t mask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 32;
+        k[i] = (uint32_t)x & mask;
+        v[i] = i;
+    }
+}
+
+int main(int argc, char **argv) {
+    const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 448810094ull;
+    const int bits = argc > 2 ? std::atoi(argv[2]) : 28;
+    const bool check = n <= (1ull << 24);
+    uint32_t *k0, *k1;
+    uint64_t *v0, *v1;
+    void *tmp;
+    CK(hipMalloc(&k0, n * 4));
+    CK(hipMalloc(&k1, n * 4));
+    CK(hipMalloc(&v0, n * 8));
+    CK(hipMalloc(&v1, n * 8));
+    CK(hipMalloc(&tmp, sort_tmp_bytes(n)));
+    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+    for (int rep = 0; rep < 3; ++rep) {
+        fill_random<<<4096, 256>>>(k0, v0, n, mask);
+        CK(hipDeviceSynchronize());
+        int in0 = 0, passes = 0;
+        float ms = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        if (sort_pairs(k0, v0, k1, v1, n, bits, tmp, &in0, 0, &ms, &passes) != PAG_OK) {
+            std::fprintf(stderr, "sort failed: %s\n", last_error());
+            return 2;
+        }
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("n=%llu bits=%d passes=%d scatter %.3f ms/pass = %.0f GB/s (%.1f %% of 8 TB/s), whole sort %.2f ms\n",
+                    (unsigned long long)n, bits, passes, ms, 24.0 * n / ms * 1e-6, 24.0 * n / ms * 1e-6 / 80.0, wall);
+        if (check && rep == 0) {
+            std::vector<uint32_t> hk(n), rk(n);
+            std::vector<uint64_t> hv(n), rv(n);
+            fill_random<<<4096, 256>>>(k1, v1, n, mask);  // regenerate the input on the side that holds no result
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(rk.data(), in0 ? k0 : k1, n * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(rv.data(), in0 ? v0 : v1, n * 8, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n; ++i) {
+                uint64_t x = i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+                x ^= x >> 29;
+                x *= 0xBF58476D1CE4E5B9ull;
+                x ^= x >> 32;
+                hk[i] = (uint32_t)x & mask;
+                hv[i] = i;
+            }
+            std::vector<uint64_t> idx(n);
+            for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return hk[a] < hk[b]; });
+            uint64_t bad = 0;
+            for (uint64_t i = 0; i < n; ++i) bad += (rk[i] != hk[idx[i]]) | (rv[i] != hv[idx[i]]);
+            std::printf("check: %llu mismatches\n", (unsigned long long)bad);
+            if (bad) return 1;
+        }
+    }
+    return 0;
+}
