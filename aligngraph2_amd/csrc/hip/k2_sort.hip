@@ -12,13 +12,21 @@
 //                 LDS counters), records staged through LDS in digit order, then written out in runs
 //                 so that the HBM stores are coalesced.
 // HBM traffic per pass: keys 4 B (hist) + 12 B read + 12 B write per record.
+#include <stdlib.h>
+
 #include "pag_device.hpp"
 
 namespace pagdev {
 
-constexpr int ST = 1024;          // threads per block
+#ifndef SORT_ST
+#define SORT_ST 1024
+#endif
+#ifndef SORT_ROUNDS
+#define SORT_ROUNDS 5
+#endif
+constexpr int ST = SORT_ST;       // threads per block
 constexpr int SW = ST / 64;       // waves per block
-constexpr int SROUNDS = 5;       // records per thread
+constexpr int SROUNDS = SORT_ROUNDS;  // records per thread
 constexpr int STILE = ST * SROUNDS;
 constexpr int SMAXR = 256;        // max radix (8 bits)
 #ifndef SORT_X
@@ -40,45 +48,59 @@ __global__ __launch_bounds__(ST) void sort_hist(const uint32_t *__restrict__ key
     if (threadIdx.x <= rmask) hist[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
 }
 
-struct ScatterLds {
-    uint32_t wcnt[SW][SMAXR + 1];  // per-wave running digit counters, then their exclusive prefix over waves (+1: bank spread)
-    uint32_t dtot[SMAXR];          // records of the tile per digit
-    uint32_t dstart[SMAXR];        // exclusive prefix of dtot over digits
-    uint64_t goff[SMAXR];          // output base of (digit, this tile) minus dstart: destination = goff[d] + staged position
+struct ScatterStage {       // one tile staged in digit order, waiting to be written out
+    uint64_t goff[SMAXR];   // output base of (digit, tile) minus the digit's first staged position: destination =
+                            // goff[d] + staged position (its first half holds the tile's digit totals until the
+                            // digit prefix is done)
     uint32_t skey[STILE];
     uint64_t sval[STILE];
 };
-static_assert(SW == 16, "the wave prefix below scans rows of 16 lanes");
-static_assert(sizeof(uint64_t) * STILE >= sizeof(uint64_t) * SW * SMAXR, "match words alias the payload staging buffer");
+struct ScatterLds {
+    uint32_t wcnt[SW][SMAXR + 1];  // per-wave running digit counters, then their exclusive prefix over waves (+1: bank spread)
+    uint32_t dstart[SMAXR];        // exclusive prefix of the tile's digit totals over digits
+    ScatterStage stage[2];         // tile i is staged into stage[i & 1] while tile i - 1 is written out of the other
+};
+static_assert(SW == 16 || SW == 8, "the wave prefix below scans groups of SW lanes inside a DPP row");
+static_assert(sizeof(ScatterLds) <= 160 * 1024, "LDS");
+static_assert(STILE >= SW * SMAXR, "match words alias the payload staging buffer");
 
-// inclusive prefix sum inside each row of 16 lanes (DPP row shifts, zero fill)
-__device__ __forceinline__ uint32_t row16_incl_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+// inclusive prefix sum inside each group of SW (8 or 16) consecutive lanes (DPP row shifts, zero fill at the row start)
+__device__ __forceinline__ uint32_t group_incl_sum(uint32_t v, uint32_t pos) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (SW == 16 || pos >= 1u) ? t : 0u;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (SW == 16 || pos >= 2u) ? t : 0u;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (SW == 16 || pos >= 4u) ? t : 0u;
+    if (SW == 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
     return v;
 }
 
-// Persistent blocks (two per CU), each looping over tiles: the keys and payloads of the NEXT tile (and its output
-// bases) are requested into registers before the current tile is ranked, staged and written, so that loads are in
-// flight during the phases of a tile that do not touch memory.  Tile order: the 64 blocks resident on one XCD (block
-// id mod 8 = XCD) work on 64 CONSECUTIVE tiles at a time, so the runs they append to a digit's output region are
-// adjacent and the partial cache lines at run boundaries are combined in that XCD's L2 instead of being written back
-// by two L2s.
-constexpr uint32_t SCHUNK = 64;  // consecutive tiles taken by the blocks of one XCD per iteration
-
+// Persistent blocks (one per CU: 140 KB of LDS), each looping over tiles as a three-stage pipeline:
+//   iteration i:  request the keys / payloads / output bases of tile i + 1 into registers,
+//                 write tile i - 1 out of its LDS staging buffer (stores only),
+//                 rank tile i, prefix its digit counts, stage it into the other LDS buffer.
+// So the loads of the next tile and the stores of the previous one are in flight while a tile is ranked and staged,
+// and the wait for the requested data at the top of an iteration finds loads AND stores issued most of an iteration
+// ago (gfx950 has one counter for both: waiting for loads right after issuing stores would expose the store latency
+// once per tile).  Tile order: the blocks resident on one XCD (block id mod 8 = XCD) work on CONSECUTIVE tiles at a
+// time, so the runs they append to a digit's output region are adjacent and the partial cache lines at run
+// boundaries are combined in that XCD's L2 instead of being written back by two L2s.
 __device__ __forceinline__ uint64_t scatter_tile(uint32_t block, uint32_t n_blocks, uint32_t it) {
-    // blocks per XCD = n_blocks / 8 when the grid fills the chip; small grids fall back to a plain stride
-    if (n_blocks % (8u * SCHUNK) != 0u) return (uint64_t)it * n_blocks + block;
+    // a grid that does not fill the XCDs evenly falls back to a plain stride
+    if (n_blocks % 8u != 0u) return (uint64_t)it * n_blocks + block;
     const uint32_t per_xcd = n_blocks / 8u, x = block & 7u, slot = block >> 3;
-    const uint32_t chunks_per_it = per_xcd / SCHUNK;  // chunks one XCD takes per iteration
-    const uint32_t c = slot / SCHUNK, t = slot % SCHUNK;
-    return ((uint64_t)((uint64_t)it * chunks_per_it + c) * 8u + x) * SCHUNK + t;
+    return ((uint64_t)it * 8u + x) * per_xcd + slot;
 }
 
+#ifdef SORT_WAVES_PER_EU
+#define SORT_BOUNDS __launch_bounds__(ST, SORT_WAVES_PER_EU)
+#else
+#define SORT_BOUNDS __launch_bounds__(ST)
+#endif
 template <int BITS>
-__global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
+__global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
                                                   uint32_t *__restrict__ okeys, uint64_t *__restrict__ ovals, uint64_t n,
                                                   int shift, const uint64_t *__restrict__ hist_scan, uint32_t n_tiles) {
     __shared__ ScatterLds L;
@@ -102,6 +124,31 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
     };
     request(scatter_tile(blockIdx.x, gridDim.x, 0));
 
+    const uint32_t last_count = (uint32_t)(n - (uint64_t)(n_tiles - 1u) * STILE);  // records of the last tile (1 .. STILE)
+    auto write_out = [&](const ScatterStage &B, uint32_t count) {
+        if (count == (uint32_t)STILE && !(SORT_X & 8)) {
+#pragma unroll
+            for (int r = 0; r < SROUNDS; ++r) {
+                const uint32_t p = (uint32_t)r * ST + threadIdx.x;
+                const uint32_t kx = B.skey[p];
+                const uint64_t dst = B.goff[(kx >> shift) & rmask] + p;
+                if ((SORT_X & 3) && kx != 0x12345678u) continue;
+                okeys[dst] = kx;
+                ovals[dst] = B.sval[p];
+            }
+        } else {
+            for (uint32_t p = threadIdx.x; p < count; p += ST) {
+                const uint32_t kx = B.skey[p];
+                const uint64_t dst = B.goff[(kx >> shift) & rmask] + p;
+                okeys[dst] = kx;
+                ovals[dst] = B.sval[p];
+            }
+        }
+    };
+
+    bool pending = false;  // a staged tile waits to be written out
+    uint32_t pending_count = 0;
+    uint32_t buf = 0;
     for (uint32_t it = 0; it < n_iter; ++it) {
         const uint64_t tile = scatter_tile(blockIdx.x, gridDim.x, it);
         uint32_t key[SROUNDS];
@@ -113,13 +160,16 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
         }
         const uint64_t gbase = ngbase;
         if (it + 1 < n_iter) request(scatter_tile(blockIdx.x, gridDim.x, it + 1));
+        if (pending) write_out(L.stage[buf ^ 1u], pending_count);
+        pending = false;
         if (tile >= n_tiles) continue;  // (uniform per block)
 
+        ScatterStage &B = L.stage[buf];
         const uint64_t tile_base = tile * STILE;
         const uint64_t wave_base = tile_base + (uint64_t)w * (64 * SROUNDS);
         // every wave clears its own counters and match words: LDS operations of one wave execute in program order, no
         // barrier needed
-        unsigned long long *match = (unsigned long long *)&L.sval[0] + (size_t)w * (rmask + 1u);  // (the staging buffer is free now)
+        unsigned long long *match = (unsigned long long *)&B.sval[0] + (size_t)w * (rmask + 1u);  // (this staging buffer is free now)
 #pragma unroll
         for (int i = 0; i < SMAXR / 64; ++i) L.wcnt[w][i * 64 + lane] = 0;
 #pragma unroll
@@ -143,19 +193,20 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
         }
 
         __syncthreads();
-        // per digit: exclusive prefix over the 16 waves (a row of 16 lanes per digit), tile totals
+        // per digit: exclusive prefix over the waves (a group of SW lanes per digit), tile totals
+        uint32_t *dtot = (uint32_t *)&B.goff[0];
 #pragma unroll
         for (int j = 0; j < SMAXR * SW / ST; ++j) {
-            const uint32_t d = (uint32_t)j * (ST / SW) + (threadIdx.x >> 4), ww = threadIdx.x & 15u;
+            const uint32_t d = (uint32_t)j * (ST / SW) + threadIdx.x / SW, ww = threadIdx.x % SW;
             const uint32_t c = L.wcnt[ww][d];
-            const uint32_t incl = row16_incl_sum(c);
+            const uint32_t incl = group_incl_sum(c, ww);
             L.wcnt[ww][d] = incl - c;
-            if (ww == 15u) L.dtot[d] = incl;
+            if (ww == SW - 1u) dtot[d] = incl;
         }
         __syncthreads();
-        // prefix over digits by one wave (four digits per lane); output bases
+        // prefix over digits by one wave (four digits per lane)
         if (w == 0) {
-            const uint32_t t0 = L.dtot[4 * lane], t1 = L.dtot[4 * lane + 1], t2 = L.dtot[4 * lane + 2], t3 = L.dtot[4 * lane + 3];
+            const uint32_t t0 = dtot[4 * lane], t1 = dtot[4 * lane + 1], t2 = dtot[4 * lane + 2], t3 = dtot[4 * lane + 3];
             uint32_t tot;
             const uint32_t ex = wave_excl_sum(t0 + t1 + t2 + t3, &tot);
             L.dstart[4 * lane] = ex;
@@ -164,7 +215,7 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
             L.dstart[4 * lane + 3] = ex + t0 + t1 + t2;
         }
         __syncthreads();
-        if (threadIdx.x <= rmask) L.goff[threadIdx.x] = gbase - L.dstart[threadIdx.x];
+        if (threadIdx.x <= rmask) B.goff[threadIdx.x] = gbase - L.dstart[threadIdx.x];
 
         // stage the tile in digit order
 #pragma unroll
@@ -174,22 +225,16 @@ __global__ __launch_bounds__(ST) void sort_scatter(const uint32_t *__restrict__ 
             if (i < n) {
                 const uint32_t d = (key[r] >> shift) & rmask;
                 const uint32_t p = L.dstart[d] + L.wcnt[w][d] + rk[r];
-                L.skey[p] = key[r];
-                L.sval[p] = val[r];
+                B.skey[p] = key[r];
+                B.sval[p] = val[r];
             }
         }
-        __syncthreads();
-        const uint32_t count = (uint32_t)((n - tile_base) < (uint64_t)STILE ? (n - tile_base) : (uint64_t)STILE);
-        for (uint32_t p = threadIdx.x; p < count; p += ST) {
-            const uint32_t kx = L.skey[p];
-            const uint32_t d = (kx >> shift) & rmask;
-            const uint64_t dst = L.goff[d] + p;
-            if ((SORT_X & 3) && kx != 0x12345678u) continue;
-            okeys[dst] = kx;
-            ovals[dst] = L.sval[p];
-        }
-        __syncthreads();  // the next iteration's match words live in the staging buffer
+        __syncthreads();  // staged: the tile is written out in the next iteration (or after the loop)
+        pending = true;
+        pending_count = tile == (uint64_t)n_tiles - 1u ? last_count : (uint32_t)STILE;
+        buf ^= 1u;
     }
+    if (pending) write_out(L.stage[buf ^ 1u], pending_count);
 }
 
 static size_t sort_align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -224,8 +269,17 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
     p += sort_align256(cells * 8);
     void *scan_tmp = p;
 
-    // persistent scatter blocks: two 80 KB blocks fit a CU's LDS; 256 CUs
-    const uint32_t scatter_grid = n_tiles < 512u ? n_tiles : 512u;
+    // persistent scatter blocks: as many as are resident at once (LDS would allow two per CU, registers decide)
+    static int scatter_blocks = 0;
+    if (scatter_blocks == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        PAG_HIP_TRY(hipGetDevice(&dev));
+        PAG_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        PAG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sort_scatter<8>, ST, 0));
+        if (const char *e = getenv("PAG_SORT_BLOCKS_PER_CU")) per_cu = atoi(e);
+        scatter_blocks = cus * (per_cu > 0 ? per_cu : 1);
+    }
+    const uint32_t scatter_grid = n_tiles < (uint32_t)scatter_blocks ? n_tiles : (uint32_t)scatter_blocks;
     hipEvent_t ev[2 * 8];
     for (int i = 0; i < 2 * passes; ++i) PAG_HIP_TRY(hipEventCreate(&ev[i]));
     uint32_t *ka = k0, *kb = k1;

@@ -62,8 +62,6 @@ int main(int argc, char **argv) {
         if (check && rep == 0) {
             std::vector<uint32_t> hk(n), rk(n);
             std::vector<uint64_t> hv(n), rv(n);
-            fill_random<<<4096, 256>>>(k1, v1, n, mask);  // regenerate the input on the side that holds no result
-            CK(hipDeviceSynchronize());
             CK(hipMemcpy(rk.data(), in0 ? k0 : k1, n * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(rv.data(), in0 ? v0 : v1, n * 8, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < n; ++i) {
@@ -78,7 +76,13 @@ int main(int argc, char **argv) {
             for (uint64_t i = 0; i < n; ++i) idx[i] = i;
             std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return hk[a] < hk[b]; });
             uint64_t bad = 0;
-            for (uint64_t i = 0; i < n; ++i) bad += (rk[i] != hk[idx[i]]) | (rv[i] != hv[idx[i]]);
+            for (uint64_t i = 0; i < n; ++i) {
+                const bool b = rk[i] != hk[idx[i]] || rv[i] != hv[idx[i]];
+                if (b && bad < 8)
+                    std::printf("  [%llu] got key %u val %llu, expected key %u val %llu\n", (unsigned long long)i, rk[i],
+                                (unsigned long long)rv[i], hk[idx[i]], (unsigned long long)hv[idx[i]]);
+                bad += b ? 1 : 0;
+            }
             std::printf("check: %llu mismatches\n", (unsigned long long)bad);
             if (bad) return 1;
         }
