@@ -138,7 +138,7 @@ class BigWorkload:
         w2_cursor = 0
         read_byte_off = torch.zeros(n, dtype=torch.int64, device=dev)
         kmer_hist = torch.zeros(4 ** sp.k, dtype=torch.int32, device=dev) if sp.k <= 14 else None
-        self.solid_codes_host = None
+        code_chunks = []  # k > 14: the dense 4^k histogram is replaced by the list of k-mer codes seen
         k = sp.k
 
         for lo in range(0, n, sp.chunk_reads):
@@ -205,6 +205,13 @@ class BigWorkload:
                     code = (code << 2) | stored[:, j:j + Lpad - k + 1].long()
                 valid = torch.arange(Lpad - k + 1, device=dev)[None, :] < (flen[:, None] - k + 1)
                 kmer_hist += torch.bincount(code[valid], minlength=4 ** k).to(torch.int32)
+                del code, valid
+            else:
+                code = torch.zeros(m, Lpad - k + 1, dtype=torch.int64, device=dev)
+                for j in range(k):
+                    code = (code << 2) | stored[:, j:j + Lpad - k + 1].long()
+                valid = torch.arange(Lpad - k + 1, device=dev)[None, :] < (flen[:, None] - k + 1)
+                code_chunks.append(code[valid])
                 del code, valid
 
             # pack reads: 4 bases / byte LSB first, each read padded to 16 bases (4 bytes)
@@ -344,6 +351,29 @@ class BigWorkload:
             bits = (solid.view(-1, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)
             self.solid_bits = bits.to(torch.int32)
             self.solid_mask = solid
+            self.solid_codes = None
+        else:
+            # sparse form of the same rule (the zero-abundance codes are counted, not stored)
+            uniq, counts = torch.unique(torch.cat(code_chunks), return_counts=True)
+            if sp.solid_min_abundance >= 0:
+                min_ab = sp.solid_min_abundance
+            else:
+                mx = int(counts.max().item())
+                cnt = torch.bincount(counts, minlength=mx + 1)
+                cnt[0] = 4 ** k - uniq.numel()
+                cum = torch.cumsum(cnt, 0).double()
+                okk = ((1.0 - cum / float(4 ** k)) <= sp.solid_threshold) & (cnt > 0)
+                min_ab = int(torch.nonzero(okk)[0].item())
+            if min_ab <= 0:
+                raise ValueError("k > 14 with an all-solid set is not generated (4^k codes)")
+            codes = torch.unique(torch.cat([uniq[counts >= min_ab], torch.tensor([k], dtype=torch.int64, device=dev)]))  # + Q1
+            self.min_abundance = min_ab
+            self.n_solid = int(codes.numel())
+            words = torch.zeros(4 ** k // 32, dtype=torch.int64, device=dev)
+            words.index_add_(0, codes >> 5, torch.ones_like(codes) << (codes & 31))
+            self.solid_bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+            self.solid_mask = None
+            self.solid_codes = codes
         self._to_device_tables()
 
     def _to_device_tables(self):
@@ -392,7 +422,10 @@ class BigWorkload:
 
     def solid_words(self) -> np.ndarray:
         """every u64 word of the equivalent solid-set file (header word first)"""
-        codes = torch.nonzero(self.solid_mask).squeeze(1).cpu().numpy().astype(np.uint64)
+        if self.solid_codes is not None:
+            codes = self.solid_codes.cpu().numpy().astype(np.uint64)
+        else:
+            codes = torch.nonzero(self.solid_mask).squeeze(1).cpu().numpy().astype(np.uint64)
         return np.concatenate([np.array([self.spec.k], dtype=np.uint64), codes])
 
     # ------------------------------------------------------------------ text form (for the reference binary)
