@@ -72,8 +72,22 @@ def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_read
     rc = host.pagh_traverse_hostwalk(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads,
                                      sp.eps, 50, hostw.encode(), b"0_", 0, C.byref(ts2))
     assert rc == 0, host.pagh_last_error()
+    # (2c) the walkers without speculation (every probe to its end before the choice): identical again
+    exactd = str(workdir / "big_exact")
+    os.makedirs(exactd, exist_ok=True)
+    ts3 = bench.TraverseStats()
+    os.environ["PAG_WALK_EXACT"] = "1"
+    try:
+        rc = host.pagh_traverse(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads, sp.eps,
+                                50, exactd.encode(), b"0_", 0, C.byref(ts3))
+    finally:
+        os.environ.pop("PAG_WALK_EXACT", None)
+    assert rc == 0, host.pagh_last_error()
     hip.pag_destroy(g)
     assert (ts.n_path_nodes, ts.n_path_bases, ts.path_checksum) == (ts2.n_path_nodes, ts2.n_path_bases, ts2.path_checksum)
+    assert (ts.n_path_nodes, ts.n_path_bases, ts.path_checksum) == (ts3.n_path_nodes, ts3.n_path_bases, ts3.path_checksum)
+    for f in sorted(os.listdir(ours)):
+        assert open(os.path.join(exactd, f), "rb").read() == open(os.path.join(ours, f), "rb").read(), f
     assert sorted(os.listdir(hostw)) == sorted(os.listdir(ours))
     for f in sorted(os.listdir(ours)):
         assert open(os.path.join(hostw, f), "rb").read() == open(os.path.join(ours, f), "rb").read(), f

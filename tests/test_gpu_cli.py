@@ -13,15 +13,22 @@ import synth
 EXE = os.path.join(pagctl.ROOT, "aligngraph2_amd", "bin", "pagraph")
 
 
+# walker modes: speculative choice among probes (default; a failed speculation is redone exactly) and PAG_WALK_EXACT=1
+# (every probe runs to its end before the choice) — both must reproduce the reference byte for byte
 @pytest.mark.gpu
+@pytest.mark.parametrize("exact", [False, True], ids=["speculative", "exact"])
 @pytest.mark.parametrize("name", goldens.case_names())
-def test_pagraph_matches_golden(name, workdir):
+def test_pagraph_matches_golden(name, exact, workdir):
     spec = goldens.load_spec(name)
     ind = goldens.materialize_inputs(name, str(workdir / name / "in"))
-    out = str(workdir / name / "out")
+    out = str(workdir / name / ("out_exact" if exact else "out"))
     os.makedirs(out, exist_ok=True)
     argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
-    r = subprocess.run(argv, capture_output=True, text=True)
+    env = dict(os.environ)
+    env.pop("PAG_WALK_EXACT", None)
+    if exact:
+        env["PAG_WALK_EXACT"] = "1"
+    r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     assert "HIP gfx950" in r.stdout
     goldens.compare_out_dir(name, out)
