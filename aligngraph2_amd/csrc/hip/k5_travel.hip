@@ -255,16 +255,29 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                     SuccRec r;
                     r.tgt = G.newid[p];
                     r.pc = pc;
-                    const uint32_t t0 = G.succ_off[r.tgt], t1 = G.succ_off[r.tgt + 1];
-                    const uint32_t tc = t1 - t0 < 15u ? t1 - t0 : 15u;  // 15 = "15 or more: look the range up"
-                    r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27) | (tc << 28);
-                    r.toff = t0;
+                    r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+                    r.toff = 0;  // the target's own record range is linked in by k_succ_link
                     G.succ[out + n] = r;
                 }
                 ++n;
             }
         }
         if (!FILL) cnt[u] = n;
+    }
+}
+
+// Every record learns its target's record range (offset + count clamped to 15 = "15 or more: look the range up"), so
+// that a walk step never waits for succ_off.  A pass of its own over the records IN COORDINATE ORDER: the targets of
+// neighbouring records are neighbours on the strand, so the succ_off reads hit the caches — inside k_succ (k-mer-major
+// threads) the same reads were one random HBM access per record.
+__global__ void k_succ_link(TravGraph G, uint64_t n_rec) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t)gridDim.x * blockDim.x) {
+        SuccRec r = G.succ[i];  // one 16-byte load, one 16-byte store
+        const uint32_t t0 = G.succ_off[r.tgt], t1 = G.succ_off[r.tgt + 1];
+        const uint32_t tc = t1 - t0 < 15u ? t1 - t0 : 15u;
+        r.meta |= tc << 28;
+        r.toff = t0;
+        G.succ[i] = r;
     }
 }
 
@@ -2157,9 +2170,10 @@ int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
-int trav_succ_fill(TravGraph G, uint32_t dev, double err, hipStream_t s) {
+int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, hipStream_t s) {
     if (!G.n_pos) return PAG_OK;
     k_succ<true><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr);
+    if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }

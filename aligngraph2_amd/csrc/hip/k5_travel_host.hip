@@ -289,7 +289,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
         G.succ = b_succ.as<SuccRec>();
         G.n_succ = n_succ;
-        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, s))) return rc;
+        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         g->tg = G;
         g->tg_dev = deviation;

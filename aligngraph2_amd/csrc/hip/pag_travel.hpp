@@ -35,7 +35,7 @@ struct TravGraph {
 };
 
 // one graded successor of a vertex (searchSuccessors + checkPosition != Oops), in reference order
-struct SuccRec {
+struct alignas(16) SuccRec {
     uint32_t tgt;   // new id
     uint32_t pc;    // contig coordinate of the target
     uint32_t meta;  // step (24 bits) | grade << 24 | isEdgeSimilar().first << 27 | min(#successors of tgt, 15) << 28
@@ -125,7 +125,7 @@ void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s
 int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, hipStream_t s);
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
                     hipStream_t s);
-int trav_succ_fill(TravGraph G, uint32_t dev, double err, hipStream_t s);
+int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, hipStream_t s);
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
                              hipStream_t s);
 void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s);
