@@ -122,24 +122,29 @@ __global__ void k_ctg_nodes(const uint8_t *__restrict__ packed, uint64_t byte_of
 __device__ __forceinline__ bool d_coord_sim(uint32_t a, uint32_t b, uint64_t dev) {
     return a != 0 && b != 0 && (uint64_t)((a > b ? a : b) - (a > b ? b : a)) <= dev;
 }
-// isEdgeSimilar (PABruijnGraph.cpp:385-400): bit0 contig side, bit1 reference side
-__device__ __forceinline__ uint32_t d_edge_similar(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, int dist, uint64_t dev,
-                                                  double err) {
-    uint32_t tc = ac != 0 ? ac + (uint32_t)dist : 0, tr = ar != 0 ? ar + (uint32_t)dist : 0;
-    bool s1 = d_coord_sim(tc, bc, dev), s2 = d_coord_sim(tr, br, dev);
-    s1 = s1 || (ac != 0 && bc != 0 && fabs(1.0 - ((double)(uint32_t)(bc - ac) * 1.0 / (double)dist)) <= err);
-    s2 = s2 || (ar != 0 && br != 0 && fabs(1.0 - ((double)(uint32_t)(br - ar) * 1.0 / (double)dist)) <= err);
-    return (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
+// the ratio test of both predicates: fabs(1.0 - (double)D * 1.0 / (double)dist) <= err, D = u32 difference of the
+// coordinates.  The f64 division (a ~25-instruction sequence) is only executed when D is within one percent of the
+// accepted band: outside of [(1 - err - 0.01) dist, (1 + err + 0.01) dist] the quotient misses the band by 0.01, fifteen
+// orders of magnitude more than the rounding of the two multiplications, so the answer is "no" without dividing.  Nine
+// in ten candidate pairs (other copies of a repeated k-mer) leave here.
+__device__ __forceinline__ bool d_ratio_ok(uint32_t D, int dist, double err) {
+    const double dd = (double)D, ds = (double)dist;
+    if (dd < (1.0 - err - 0.01) * ds || dd > (1.0 + err + 0.01) * ds) return false;
+    return fabs(1.0 - (dd * 1.0 / ds)) <= err;
 }
 enum { G_OOPS = 0, G_SKIP = 1, G_GOOD = 2, G_EXCELLENT = 3, G_AMAZING = 4 };
-// checkPosition (PABruijnGraph.cpp:143-165) incl. the un-guarded second ratio test (quirk Q6)
+// checkPosition (PABruijnGraph.cpp:143-165) incl. the un-guarded second ratio test (quirk Q6), with isEdgeSimilar
+// (PABruijnGraph.cpp:385-400; *edge_sim: bit0 contig side, bit1 reference side) evaluated on the way: both use the
+// same two ratio tests, each computed once here
 __device__ __forceinline__ int d_check_position(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev,
                                                 double err, uint32_t *edge_sim) {
-    uint32_t st = d_edge_similar(ac, ar, bc, br, (int)dist, dev, err);
-    *edge_sim = st;
-    bool s1 = st & 1u, s2 = (st >> 1) & 1u;
-    s1 = s1 || fabs(1.0 - ((double)(uint32_t)(bc - ac) * 1.0 / (double)dist)) <= err;
-    s2 = s2 || fabs(1.0 - ((double)(uint32_t)(br - ar) * 1.0 / (double)dist)) <= err;
+    const bool q1 = d_ratio_ok(bc - ac, (int)dist, err), q2 = d_ratio_ok(br - ar, (int)dist, err);
+    const uint32_t tc = ac != 0 ? ac + dist : 0, tr = ar != 0 ? ar + dist : 0;
+    bool s1 = d_coord_sim(tc, bc, dev) || (ac != 0 && bc != 0 && q1);
+    bool s2 = d_coord_sim(tr, br, dev) || (ar != 0 && br != 0 && q2);
+    *edge_sim = (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
+    s1 = s1 || q1;
+    s2 = s2 || q2;
     if (ac == 0 || bc == 0) return s2 ? (bc != 0 ? G_EXCELLENT : (ac != 0 ? G_SKIP : G_GOOD)) : G_OOPS;
     if (ar == 0 || br == 0) return s1 ? (br != 0 ? G_EXCELLENT : G_GOOD) : G_OOPS;
     return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
@@ -230,8 +235,12 @@ __global__ void k_order_apply(const uint64_t *__restrict__ sorted_old, uint64_t 
     }
 }
 
-template <bool FILL>
-__global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt) {
+// MODE 0: count the records of every vertex (cnt[u]).  MODE 1: write them to their final place succ[succ_off[u] ..]
+// (needs MODE 0 + scan first: the two-pass path).  MODE 2: write them to a staging array at stage_off[v] — offsets from
+// the cheap upper bound of k_succ_bound, so no counting pass is needed — and count; k_succ_place moves them afterwards.
+template <int MODE>
+__global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
+                       SuccRec *__restrict__ stage) {
     // Threads run over the vertices in k-mer-major order (the order of the CSR): neighbouring threads belong to the
     // same k-mer node, so the node's edge list and the position lists of its target nodes are shared through the
     // caches; only the per-vertex results go to coordinate-ordered (random) places.
@@ -241,7 +250,7 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
         const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
         const uint32_t node = G.vnode[v];
         uint32_t n = 0;
-        uint32_t out = FILL ? G.succ_off[u] : 0;
+        SuccRec *out = MODE == 1 ? G.succ + G.succ_off[u] : MODE == 2 ? stage + stage_off[v] : nullptr;
         for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
             const uint32_t to = G.eto[e], step = G.estep[e];
             if (to == PAG_NONE) continue;
@@ -251,18 +260,48 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                 uint32_t esim;
                 int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
                 if (grade == G_OOPS) continue;
-                if (FILL) {
+                if (MODE != 0) {
                     SuccRec r;
                     r.tgt = G.newid[p];
                     r.pc = pc;
                     r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
-                    r.toff = 0;  // the target's own record range is linked in by k_succ_link
-                    G.succ[out + n] = r;
+                    r.toff = 0;  // the target's own record range is linked in afterwards
+                    out[n] = r;
                 }
                 ++n;
             }
         }
-        if (!FILL) cnt[u] = n;
+        if (MODE != 1) cnt[u] = n;
+    }
+}
+
+// upper bound of a vertex's records: the positions of all target nodes of its k-mer node (every candidate pair)
+__global__ void k_succ_bound(TravGraph G, uint32_t *__restrict__ ub) {
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t node = G.vnode[v];
+        uint32_t n = 0;
+        for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
+            const uint32_t to = G.eto[e];
+            if (to != PAG_NONE) n += G.npos_off[to + 1] - G.npos_off[to];
+        }
+        ub[v] = n;
+    }
+}
+
+// staged records -> coordinate order, target ranges linked in on the way (see k_succ_link)
+__global__ void k_succ_place(TravGraph G, const uint64_t *__restrict__ stage_off, const SuccRec *__restrict__ stage) {
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < G.n_pos; u += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t o0 = G.succ_off[u], o1 = G.succ_off[u + 1];
+        if (o0 == o1) continue;
+        const SuccRec *src = stage + stage_off[G.uold[u]];
+        for (uint32_t j = 0; j < o1 - o0; ++j) {
+            SuccRec r = src[j];
+            const uint32_t t0 = G.succ_off[r.tgt], t1 = G.succ_off[r.tgt + 1];
+            const uint32_t tc = t1 - t0 < 15u ? t1 - t0 : 15u;
+            r.meta |= tc << 28;
+            r.toff = t0;
+            G.succ[o0 + j] = r;
+        }
     }
 }
 
@@ -2159,10 +2198,11 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     return PAG_OK;
 }
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                    hipStream_t s) {
+                    const uint64_t *stage_off, SuccRec *stage, hipStream_t s) {
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
-    k_succ<false><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt);
+    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage);
+    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr);
     PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
     int rc;
     if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
@@ -2170,10 +2210,24 @@ int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
-int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, hipStream_t s) {
+int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s) {
+    const uint64_t n = G.n_pos;
+    if (!n) return PAG_OK;
+    k_succ_bound<<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, ub);
+    PAG_HIP_TRY(hipMemsetAsync(ub + n, 0, 4, s));
+    int rc;
+    if ((rc = scan_u32_to_u64(ub, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage, hipStream_t s) {
     if (!G.n_pos) return PAG_OK;
-    k_succ<true><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr);
-    if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
+    if (stage) {
+        k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
+    } else {
+        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr);
+        if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
+    }
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }

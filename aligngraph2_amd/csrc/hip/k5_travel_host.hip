@@ -270,17 +270,39 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                                b_ctmp.p, tb, s)))
             return rc;
         // coordinate order, then the static half of the epsilon-join for every vertex
-        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 1) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
+        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
             (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
             return rc;
         if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, s)))
             return rc;
-        uint64_t n_succ = 0;
-        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov1[0] as the total
+        uint64_t n_succ = 0, n_cand = 0;
+        // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
+        // staging array laid out by the candidate-pair bound (b_ok1 = bound per vertex, b_ov1 = its prefix,
+        // b_ov0[np + 1] = total), then moved to coordinate order.  Staging = 16 B per CANDIDATE (about twice the
+        // records); it reuses the compaction scratch slot.
+        const SuccRec *stage = nullptr;
+        const uint64_t *stage_off = nullptr;
+        if (!std::getenv("PAG_SUCC_TWO_PASS")) {
+            if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
+                return rc;
+            PAG_HIP_TRY(hipMemcpyAsync(&n_cand, b_ov0.as<uint64_t>() + np + 1, 8, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            size_t free_b = 0, total_b = 0;
+            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const size_t want = (n_cand + 1) * sizeof(SuccRec);
+            // the final array (<= the staging size) has to fit as well; keep a margin for the walk buffers
+            if (want <= b_ctmp.sl->cap || want < (free_b + b_ctmp.sl->cap) / 4) {
+                if (b_ctmp.alloc(want) == PAG_OK) {
+                    stage = b_ctmp.as<SuccRec>();
+                    stage_off = b_ov1.as<uint64_t>();
+                }
+            }
+        }
+        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
         if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                  b_ov1.as<uint64_t>(), s)))
+                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), s)))
             return rc;
-        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov1.p, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
         PAG_HIP_TRY(hipStreamSynchronize(s));
         if (n_succ >= 0xFFFFFFF0ull) {
             set_error("pag_travel: more than 2^32 successor records");
@@ -289,14 +311,15 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
         G.succ = b_succ.as<SuccRec>();
         G.n_succ = n_succ;
-        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, s))) return rc;
+        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         g->tg = G;
         g->tg_dev = deviation;
         g->tg_err = errorRate;
         g->tg_ready = true;
         if (std::getenv("PAGRAPH_TIMING"))
-            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices\n", (unsigned long long)n_succ, (unsigned long long)np);
+            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%s, %llu candidate pairs)\n", (unsigned long long)n_succ,
+                         (unsigned long long)np, stage ? "staged, one evaluation" : "two passes", (unsigned long long)n_cand);
         t_compact = now_ms() - t0;
     }
 
