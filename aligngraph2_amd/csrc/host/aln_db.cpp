@@ -1,10 +1,16 @@
 #include "aln_db.hpp"
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <unordered_map>
 
 #include "line_index.hpp"
 
@@ -150,9 +156,127 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ packed sidecar
+namespace {
+struct PackedHeader {
+    char magic[8];  // "PAGALN1\0"
+    std::uint32_t version, flavor;
+    std::uint64_t nRecs, nDiffWords, nameBytes;
+    std::uint64_t srcSize;
+    std::int64_t srcMtimeSec, srcMtimeNsec;
+};
+struct PackedRec {
+    std::uint64_t score, queryBegin, queryEnd, refBegin, refEnd, diffOff;
+    std::uint32_t nCols, nEmit, nRadv, queryName, refName;  // names: offsets of NUL-terminated strings in the blob
+    std::uint32_t forward;
+};
+const char kMagic[8] = {'P', 'A', 'G', 'A', 'L', 'N', '1', '\0'};
+
+bool statOf(const std::string &path, std::uint64_t *size, std::int64_t *sec, std::int64_t *nsec) {
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return false;
+    *size = static_cast<std::uint64_t>(st.st_size);
+    *sec = static_cast<std::int64_t>(st.st_mtim.tv_sec);
+    *nsec = static_cast<std::int64_t>(st.st_mtim.tv_nsec);
+    return true;
+}
+}  // namespace
+
+bool AlnDb::loadPacked(const std::string &alnPath, Flavor flavor) {
+    std::uint64_t size = 0;
+    std::int64_t sec = 0, nsec = 0;
+    if (!statOf(alnPath, &size, &sec, &nsec)) return false;
+    std::FILE *f = std::fopen(sidecarPath(alnPath).c_str(), "rb");
+    if (!f) return false;
+    PackedHeader h;
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, kMagic, 8) == 0 && h.version == 1 &&
+              h.flavor == static_cast<std::uint32_t>(flavor) && h.srcSize == size && h.srcMtimeSec == sec && h.srcMtimeNsec == nsec;
+    std::vector<PackedRec> pr;
+    std::vector<char> names;
+    std::vector<std::uint32_t> diff;
+    if (ok) {
+        pr.resize(h.nRecs);
+        names.resize(h.nameBytes);
+        diff.resize(h.nDiffWords);
+        ok = (h.nRecs == 0 || std::fread(pr.data(), sizeof(PackedRec), h.nRecs, f) == h.nRecs) &&
+             (h.nameBytes == 0 || std::fread(names.data(), 1, h.nameBytes, f) == h.nameBytes) &&
+             (h.nDiffWords == 0 || std::fread(diff.data(), 4, h.nDiffWords, f) == h.nDiffWords) &&
+             (names.empty() || names.back() == '\0');
+    }
+    std::fclose(f);
+    if (!ok) return false;
+    for (const PackedRec &r : pr)  // a damaged file must not send anyone out of bounds
+        if (r.queryName >= std::max<std::size_t>(names.size(), 1) || r.refName >= std::max<std::size_t>(names.size(), 1) ||
+            r.diffOff + (static_cast<std::uint64_t>(r.nCols) + 15) / 16 > diff.size())
+            return false;
+    recs_.assign(pr.size(), AlnRecord{});
+    parallelFor(pr.size(), 4096, [&](std::size_t i) {
+        const PackedRec &r = pr[i];
+        AlnRecord &o = recs_[i];
+        if (!names.empty()) {
+            o.queryName = names.data() + r.queryName;
+            o.refName = names.data() + r.refName;
+        }
+        o.score = r.score;
+        o.queryBegin = r.queryBegin;
+        o.queryEnd = r.queryEnd;
+        o.refBegin = r.refBegin;
+        o.refEnd = r.refEnd;
+        o.forward = r.forward != 0;
+        o.diffOff = r.diffOff;
+        o.nCols = r.nCols;
+        o.nEmit = r.nEmit;
+        o.nRadv = r.nRadv;
+    });
+    diff_.swap(diff);
+    fromSidecar_ = true;
+    return true;
+}
+
+bool AlnDb::savePacked(const std::string &alnPath, Flavor flavor) const {
+    PackedHeader h{};
+    std::memcpy(h.magic, kMagic, 8);
+    h.version = 1;
+    h.flavor = static_cast<std::uint32_t>(flavor);
+    if (!statOf(alnPath, &h.srcSize, &h.srcMtimeSec, &h.srcMtimeNsec)) return false;
+    std::vector<PackedRec> pr(recs_.size());
+    std::vector<char> names;
+    std::unordered_map<std::string, std::uint32_t> seen;
+    auto intern = [&](const std::string &s) -> std::uint32_t {
+        auto it = seen.find(s);
+        if (it != seen.end()) return it->second;
+        if (names.size() + s.size() + 1 > 0xFFFFFFFFull) throw std::runtime_error("sidecar: name blob over 4 GiB");
+        const std::uint32_t off = static_cast<std::uint32_t>(names.size());
+        names.insert(names.end(), s.begin(), s.end());
+        names.push_back('\0');
+        seen.emplace(s, off);
+        return off;
+    };
+    for (std::size_t i = 0; i < recs_.size(); ++i) {
+        const AlnRecord &r = recs_[i];
+        if (r.queryName.find('\0') != std::string::npos || r.refName.find('\0') != std::string::npos) return false;
+        pr[i] = PackedRec{r.score, r.queryBegin, r.queryEnd, r.refBegin, r.refEnd, r.diffOff, r.nCols, r.nEmit, r.nRadv,
+                          intern(r.queryName), intern(r.refName), r.forward ? 1u : 0u};
+    }
+    h.nRecs = pr.size();
+    h.nDiffWords = diff_.size();
+    h.nameBytes = names.size();
+    const std::string out = sidecarPath(alnPath), tmp = out + ".tmp." + std::to_string(static_cast<long>(::getpid()));
+    std::FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && (pr.empty() || std::fwrite(pr.data(), sizeof(PackedRec), pr.size(), f) == pr.size()) &&
+              (names.empty() || std::fwrite(names.data(), 1, names.size(), f) == names.size()) &&
+              (diff_.empty() || std::fwrite(diff_.data(), 4, diff_.size(), f) == diff_.size());
+    ok = (std::fclose(f) == 0) && ok;
+    if (ok) ok = std::rename(tmp.c_str(), out.c_str()) == 0;
+    if (!ok) std::remove(tmp.c_str());
+    return ok;
+}
+
 AlnDb::AlnDb(const std::string &path, Flavor flavor) {
     std::ifstream in(path);
     if (!in.is_open()) return;  // the reference silently yields an empty database
+    if (loadPacked(path, flavor)) return;
 
     std::stringstream ss;
     if (flavor == Flavor::Mecat && loadMecatParallel(path)) {
@@ -213,6 +337,8 @@ AlnDb::AlnDb(const std::string &path, Flavor flavor) {
     }
     sortByScore();
     diff_.resize(diff_.size() + 4, 0);  // kernels may read one word past an alignment
+    if (const char *e = std::getenv("PAGRAPH_ALN_SIDECAR"))
+        if (e[0] == '1') savePacked(path, flavor);
 }
 
 }  // namespace pagh
