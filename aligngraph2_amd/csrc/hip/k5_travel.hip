@@ -534,8 +534,12 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
         }
         const uint32_t nw = (nid + 31u) / 32u;  // <= WIN_IDS / 32 <= 64
         const uint32_t w = lane < nw ? lane : nw - 1u;
-        if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + (d0 >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
-        else if (lane < WIN_IDS / 32u) L.wgb[lane] = 0u;
+        // (an LDS-direct load writes one slot PER ACTIVE LANE: only the lanes that own a word of wgb may take part,
+        // the others would write past its end, into the abundances)
+        if (lane < WIN_IDS / 32u) {
+            if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + (d0 >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
+            else L.wgb[lane] = 0u;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

@@ -285,6 +285,7 @@ def main():
                 "ms_traverse_host_epilogue": ts.ms_traverse,
                 "build_only_bases_per_s": w.n_bases / (float(np.mean(build_ms)) * 1e-3),
                 "path_bases": int(ts.n_path_bases), "chains": int(ts.n_chains_emitted),
+                "path_nodes": int(ts.n_path_nodes), "path_checksum": f"{int(ts.path_checksum):016x}",
                 # the traversal is a latency-bound serial chain (no HBM roofline): what bounds it is the longest
                 # chain of dependent walk steps and the time per step, reported here instead
                 "ms_successor_records": ts.ms_successors, "ms_walk": ts.ms_walk,
