@@ -376,7 +376,7 @@ struct WalkLds {
     uint32_t wst[PROBE_GROUPS][WIN_IDS];
     uint32_t wts[WIN_IDS];       // travel-visited epoch of the window's vertices
     uint32_t wgb[WIN_IDS / 32];  // global-visited bits
-    uint32_t wab[WIN_IDS];  // abundance of the window's vertices (choice among branching alternatives)
+    uint32_t wab[WIN_IDS + 256];  // abundance of the window's vertices, from id w_d0 - w_ab (choice among branching alternatives)
     // the classification a probe stopped at (END / BRANCH): every accepted record with its class, in record order.
     // After the chosen path is appended, graphTravel's own classification of its last vertex is this list minus
     // the records whose coordinate now falls into the (hull of the) travel window — see k_walk's main loop.
@@ -432,6 +432,7 @@ struct WalkCtx {
     // LDS window: vertices in_lo + [w_d0, w_d0 + w_nid), records [w_r0, w_r0 + w_nrec)
     uint32_t w_d0, w_nid, w_r0, w_nrec;
     uint32_t w_anchor;  // offset the window was last filled for
+    uint32_t w_ab;      // the abundance copy L.wab starts this many ids before the window (16-byte aligned loads)
     uint32_t n_fill;
     uint32_t n_classify, n_probe, n_records;  // work counters
     int overflow;
@@ -500,6 +501,7 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
     const uint32_t nid = span - d0 < WIN_IDS ? span - d0 : WIN_IDS;
     const uint32_t r0 = X.G.succ_off[X.C.in_lo + d0], r1 = X.G.succ_off[X.C.in_lo + d0 + nid];
     const uint32_t nrec = r1 - r0 < WIN_REC ? r1 - r0 : WIN_REC;
+    uint32_t ab_shift = 0;
     __syncthreads();
     if (nrec) {
         const SuccRec *src = X.G.succ + r0;
@@ -509,28 +511,35 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
         }
     }
     if (nid) {
+        // 4-byte arrays: four ids per lane and instruction (b128).  The stamp / epoch arrays are padded by the host to a
+        // multiple of four ids and d0 is a multiple of 32, so the addresses are 16-byte aligned; a lane past the end
+        // re-loads the last quad of the array (the LDS slots it fills are never read).
+        const uint32_t last_quad = X.stamp_stride - 4u - d0;  // (stamp_stride >= span rounded up to 4, d0 < span)
 #pragma unroll
         for (int g = 0; g < PROBE_GROUPS; ++g) {
             const uint32_t *src = X.stamp + (uint64_t)g * X.stamp_stride + d0;
-            for (uint32_t b = 0; b < nid; b += 64u) {
-                const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
+            for (uint32_t b = 0; b < nid; b += 256u) {
+                const uint32_t i = b + 4u * lane < last_quad ? b + 4u * lane : last_quad;
                 // sc1: the stamps were written through to the L2 by this wave, an L1 line may be older
-                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wst[g][b], 4, 0, 16);
-            }
-        }
-        {
-            const uint32_t *src = X.G.ucnt + X.C.in_lo + d0;
-            for (uint32_t b = 0; b < nid; b += 64u) {
-                const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
-                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wab[b], 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wst[g][b], 16, 0, 16);
             }
         }
         {
             const uint32_t *src = X.tbits + d0;
-            for (uint32_t b = 0; b < nid; b += 64u) {
-                const uint32_t i = b + lane < nid ? b + lane : nid - 1u;
-                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wts[b], 4, 0, 16);
+            for (uint32_t b = 0; b < nid; b += 256u) {
+                const uint32_t i = b + 4u * lane < last_quad ? b + 4u * lane : last_quad;
+                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wts[b], 16, 0, 16);
             }
+        }
+        {   // the abundances are indexed by vertex id: aligned down, the window copy starts `shift` ids early
+            const uint32_t first = X.C.in_lo + d0, shift = first & 3u;
+            const uint32_t *src = X.G.ucnt + (first - shift);
+            const uint32_t n4 = (nid + shift + 3u) & ~3u, lastq = n4 - 4u;
+            for (uint32_t b = 0; b < n4; b += 256u) {
+                const uint32_t i = b + 4u * lane < lastq ? b + 4u * lane : lastq;
+                __builtin_amdgcn_global_load_lds((const void *)(src + i), (lds_ptr_t)&L.wab[b], 16, 0, 0);
+            }
+            ab_shift = shift;
         }
         const uint32_t nw = (nid + 31u) / 32u;  // <= WIN_IDS / 32 <= 64
         const uint32_t w = lane < nw ? lane : nw - 1u;
@@ -548,6 +557,7 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
     X.w_r0 = r0;
     X.w_nrec = nrec;
     X.w_anchor = d;
+    X.w_ab = ab_shift;
     X.n_fill += 1;
     PROF_END(X, 6, t_fill);
 }
@@ -1266,7 +1276,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         S.pb_s = s0;
         {   // abundance of the alternative (needed if it ends in a branch)
             const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
-            S.ab = L.wab[e0 < X.w_nid ? e0 : 0u];
+            S.ab = L.wab[e0 < X.w_nid ? e0 + X.w_ab : 0u];
             if (!(e0 < X.w_nid)) S.ab = X.G.ucnt[v0];
         }
         const uint32_t c = have_meta ? L.br_pc[rank] : (uint32_t)(X.G.upos[v0] >> 32);
@@ -1356,7 +1366,7 @@ __device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp,
     uint32_t ab;
     {
         const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
-        ab = L.wab[e0 < X.w_nid ? e0 : 0u];
+        ab = L.wab[e0 < X.w_nid ? e0 + X.w_ab : 0u];
         if (!(e0 < X.w_nid)) ab = X.G.ucnt[v0];
     }
     const uint32_t c0 = have_meta ? L.br_pc[alt] : (uint32_t)(X.G.upos[v0] >> 32);
@@ -1489,7 +1499,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.win_t1 = 0;
     X.overflow = 0;
     X.spec_fail = 0;
-    X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.n_fill = 0;
+    X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.w_ab = X.n_fill = 0;
 #ifdef PAG_WALK_PROF
     for (int q = 0; q < 12; ++q) {
         X.pt[q] = 0;

@@ -528,7 +528,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         const uint64_t PG = TRAV_PROBE_GROUPS;
         const uint64_t cap = cs.seqCap * R.grow, oc = out_cap(cs, R.grow);
-        const uint64_t span = (uint64_t)(cs.inHi - cs.inLo) + 1, tbw = span + 1;  // one travel epoch per strand vertex
+        // one travel epoch / probe stamp per strand vertex; padded to a multiple of four so that the walker's window
+        // refills can use 16-byte loads
+        const uint64_t span = ((uint64_t)(cs.inHi - cs.inLo) + 1 + 3) & ~3ull, tbw = span + 4;
         DevBuf b_sv = cbuf(i, CB_SEQV), b_ss = cbuf(i, CB_SEQS), b_av = cbuf(i, CB_ARV), b_as = cbuf(i, CB_ARS), b_ts = cbuf(i, CB_TSET),
                b_ps = cbuf(i, CB_PSET), b_st = cbuf(i, CB_STAMP), b_tb = cbuf(i, CB_TBITS);
         int r;

@@ -119,6 +119,10 @@ def cpu_baseline(k, eps, cov, threads_flag):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+# (reads, read_span, ref_len, k, epsilon, seed) -> (path nodes, path checksum) verified against the host walk
+KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2): (11927387, "a5be0e7e6768d02b")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,6 +231,15 @@ def main():
         elif sig != first:
             raise SystemExit(f"non-repeatable result: {sig} vs {first}")
 
+    def check_known_answer():
+        # the default workload's traversal was checked once against the host restatement of the reference's traversal
+        # (tests/walk_check.py, 58 s of host walking): any later change of the path is a parity bug, not a speed-up
+        key = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon, 2 + rank)
+        want = KNOWN_PATHS.get(key)
+        if want and not args.build_only and (int(ts.n_path_nodes), f"{int(ts.path_checksum):016x}") != want:
+            raise SystemExit(f"traversal differs from the verified result for this workload: "
+                             f"{(int(ts.n_path_nodes), f'{int(ts.path_checksum):016x}')} vs {want}")
+
     for _ in range(args.warmup):
         step()
         check_repeatable()
@@ -242,6 +255,7 @@ def main():
         trav_ms.append(ts.ms_total)
     sync()
     dt = time.perf_counter() - t0
+    check_known_answer()  # (outside the timed region)
     dt_max, total_bases = parallel.aggregate(dist, dt, float(w.n_bases), device="cpu" if one_device else f"cuda:{local}")
 
     if rank == 0:

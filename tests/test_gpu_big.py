@@ -102,3 +102,16 @@ def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_read
     assert ref_files == sorted(os.listdir(ours))
     for f in ref_files:
         assert open(workdir / "big_ref" / f, "rb").read() == open(os.path.join(ours, f), "rb").read(), f
+
+
+@pytest.mark.gpu
+def test_device_walks_equal_host_walk_on_multi_round_contigs(workdir):
+    """25 Mb / 50 k reads: two dozen 1 Mb contigs, several of which need re-seeded rounds (global-visit tables in play) —
+    the size at which a window-refill overflow once changed 1 contig in 24 while every smaller test passed.  Device
+    walkers (speculative and exact) against the host restatement of the reference's traversal: same fingerprint, same
+    files."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(pagctl.ROOT, "tests", "walk_check.py"), "--reads", "50000", "--ref-len", "25000000"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL EQUAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
