@@ -120,7 +120,9 @@ def cpu_baseline(k, eps, cov, threads_flag):
 
 
 # (reads, read_span, ref_len, k, epsilon, seed) -> (path nodes, path checksum) verified against the host walk
-KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2): (11927387, "a5be0e7e6768d02b")}
+KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2): (11927387, "a5be0e7e6768d02b"),   # rank 0
+               (100_000, 10_000, 50_000_000, 14, 10, 3): (11921623, "fb604061f9706aee"),   # rank 1
+               (100_000, 10_000, 50_000_000, 14, 10, 9): (11924729, "5a52149c2e26d0d2")}   # rank 7
 
 
 def main():
