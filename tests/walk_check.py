@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--epsilon", type=int, default=10)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-host", action="store_true")
+    ap.add_argument("--min-abundance", type=int, default=-1, help=">= 0: abundance cut of the solid set (needed for k > 14)")
     args = ap.parse_args()
     import torch
     import bench
@@ -31,7 +32,7 @@ def main():
     import pagctl
     hip, host = bench.load_libs()
     sp = biggen.BigSpec(seed=args.seed, ref_len=args.ref_len, n_reads=args.reads, read_span=args.read_span, k=args.k,
-                        eps=args.epsilon, cov=2, threads=16)
+                        eps=args.epsilon, cov=2, threads=16, solid_min_abundance=args.min_abundance)
     w = biggen.BigWorkload(sp, device="cuda:0")
     torch.cuda.synchronize()
     inp = w.build_input()
