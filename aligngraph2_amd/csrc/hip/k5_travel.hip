@@ -240,38 +240,63 @@ __global__ void k_order_apply(const uint64_t *__restrict__ sorted_old, uint64_t 
 // the cheap upper bound of k_succ_bound, so no counting pass is needed — and count; k_succ_place moves them afterwards.
 template <int MODE>
 __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
-                       SuccRec *__restrict__ stage) {
+                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask) {
     // Threads run over the vertices in k-mer-major order (the order of the CSR): neighbouring threads belong to the
     // same k-mer node, so the node's edge list and the position lists of its target nodes are shared through the
     // caches; only the per-vertex results go to coordinate-ordered (random) places.
+    // amask[v] (two-pass path): which of the vertex's first 64 candidate pairs the counting pass accepted, so that the
+    // filling pass only touches those (nine in ten candidates are rejects); candidates from the 65th on are evaluated
+    // again.
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t u = G.newid[v];
         const uint64_t rootp = G.vpos[v];
         const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
         const uint32_t node = G.vnode[v];
-        uint32_t n = 0;
+        uint32_t n = 0, base = 0;
+        uint64_t mask = MODE == 1 && amask ? amask[v] : 0ull;
         SuccRec *out = MODE == 1 ? G.succ + G.succ_off[u] : MODE == 2 ? stage + stage_off[v] : nullptr;
+        auto emit = [&](uint32_t p, uint32_t pc, uint32_t step, int grade, uint32_t esim) {
+            SuccRec r;
+            r.tgt = G.newid[p];
+            r.pc = pc;
+            r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+            r.toff = 0;  // the target's own record range is linked in afterwards
+            out[n] = r;
+        };
         for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
             const uint32_t to = G.eto[e], step = G.estep[e];
             if (to == PAG_NONE) continue;
-            for (uint32_t p = G.npos_off[to]; p < G.npos_off[to + 1]; ++p) {
+            const uint32_t p0 = G.npos_off[to], q = G.npos_off[to + 1] - p0;
+            uint32_t j0 = 0;
+            if (MODE == 1 && amask) {  // the candidates the mask covers: accepted ones only
+                const uint32_t lim = base < 64u ? (q < 64u - base ? q : 64u - base) : 0u;
+                uint64_t sub = lim ? (mask >> base) & (lim == 64u ? ~0ull : ((1ull << lim) - 1ull)) : 0ull;
+                while (sub) {
+                    const uint32_t p = p0 + (uint32_t)(__ffsll((long long)sub) - 1);
+                    sub &= sub - 1ull;
+                    const uint64_t pp = G.vpos[p];
+                    uint32_t esim;
+                    const int grade = d_check_position(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, &esim);
+                    emit(p, (uint32_t)(pp >> 32), step, grade, esim);
+                    ++n;
+                }
+                j0 = lim;
+            }
+            for (uint32_t j = j0; j < q; ++j) {
+                const uint32_t p = p0 + j;
                 const uint64_t pp = G.vpos[p];
                 const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
                 uint32_t esim;
                 int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
                 if (grade == G_OOPS) continue;
-                if (MODE != 0) {
-                    SuccRec r;
-                    r.tgt = G.newid[p];
-                    r.pc = pc;
-                    r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
-                    r.toff = 0;  // the target's own record range is linked in afterwards
-                    out[n] = r;
-                }
+                if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
+                if (MODE != 0) emit(p, pc, step, grade, esim);
                 ++n;
             }
+            base += q;
         }
         if (MODE != 1) cnt[u] = n;
+        if (MODE == 0 && amask) amask[v] = mask;
     }
 }
 
@@ -2212,11 +2237,11 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     return PAG_OK;
 }
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                    const uint64_t *stage_off, SuccRec *stage, hipStream_t s) {
+                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, hipStream_t s) {
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
-    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage);
-    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr);
+    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr);
+    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask);
     PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
     int rc;
     if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
@@ -2234,12 +2259,13 @@ int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tm
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
-int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage, hipStream_t s) {
+int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
+                   uint64_t *amask, hipStream_t s) {
     if (!G.n_pos) return PAG_OK;
     if (stage) {
         k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
     } else {
-        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr);
+        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask);
         if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
     }
     PAG_HIP_TRY(hipGetLastError());

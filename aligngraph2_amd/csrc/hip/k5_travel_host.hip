@@ -298,9 +298,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 }
             }
         }
+        // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
+        uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
         // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
         if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), s)))
+                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
             return rc;
         PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
         PAG_HIP_TRY(hipStreamSynchronize(s));
@@ -311,7 +313,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
         G.succ = b_succ.as<SuccRec>();
         G.n_succ = n_succ;
-        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, s))) return rc;
+        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         g->tg = G;
         g->tg_dev = deviation;
