@@ -335,13 +335,30 @@ __global__ void k_succ_place(TravGraph G, const uint64_t *__restrict__ stage_off
 // neighbouring records are neighbours on the strand, so the succ_off reads hit the caches — inside k_succ (k-mer-major
 // threads) the same reads were one random HBM access per record.
 __global__ void k_succ_link(TravGraph G, uint64_t n_rec) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += (uint64_t)gridDim.x * blockDim.x) {
-        SuccRec r = G.succ[i];  // one 16-byte load, one 16-byte store
-        const uint32_t t0 = G.succ_off[r.tgt], t1 = G.succ_off[r.tgt + 1];
-        const uint32_t tc = t1 - t0 < 15u ? t1 - t0 : 15u;
-        r.meta |= tc << 28;
-        r.toff = t0;
-        G.succ[i] = r;
+    // four records per thread and trip, their loads issued together (one dependent gather each: latency-bound otherwise)
+    const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += 4 * T) {
+        SuccRec r[4];
+        uint32_t t0[4], t1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t x = i + (uint64_t)q * T;
+            r[q] = G.succ[x < n_rec ? x : i];  // one 16-byte load
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t0[q] = G.succ_off[r[q].tgt];
+            t1[q] = G.succ_off[r[q].tgt + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint64_t x = i + (uint64_t)q * T;
+            if (x >= n_rec) continue;
+            const uint32_t tc = t1[q] - t0[q] < 15u ? t1[q] - t0[q] : 15u;
+            r[q].meta |= tc << 28;
+            r[q].toff = t0[q];
+            G.succ[x] = r[q];  // one 16-byte store
+        }
     }
 }
 

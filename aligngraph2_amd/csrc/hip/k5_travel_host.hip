@@ -282,7 +282,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // records); it reuses the compaction scratch slot.
         const SuccRec *stage = nullptr;
         const uint64_t *stage_off = nullptr;
-        if (!std::getenv("PAG_SUCC_TWO_PASS")) {
+        // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
+        // records, see DESIGN.md, and computing the bound is not free)
+        if (!std::getenv("PAG_SUCC_TWO_PASS") && np <= (64ull << 20)) {
             if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
                 return rc;
             PAG_HIP_TRY(hipMemcpyAsync(&n_cand, b_ov0.as<uint64_t>() + np + 1, 8, hipMemcpyDeviceToHost, s));
