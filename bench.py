@@ -120,9 +120,9 @@ def cpu_baseline(k, eps, cov, threads_flag):
 
 
 # (reads, read_span, ref_len, k, epsilon, seed) -> (path nodes, path checksum) verified against the host walk
-KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2): (11927387, "a5be0e7e6768d02b"),   # rank 0
-               (100_000, 10_000, 50_000_000, 14, 10, 3): (11921623, "fb604061f9706aee"),   # rank 1
-               (100_000, 10_000, 50_000_000, 14, 10, 9): (11924729, "5a52149c2e26d0d2")}   # rank 7
+KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2 + r): v for r, v in enumerate([
+    (11927387, "a5be0e7e6768d02b"), (11921623, "fb604061f9706aee"), (11923285, "075d8b1aaf068b17"), (11919358, "86e94438bddea6ba"),
+    (11925391, "1a01e8987336b9e4"), (11929002, "1a7605fbef93d1ee"), (11922551, "24414d165e923e69"), (11924729, "5a52149c2e26d0d2")])}  # ranks 0..7
 
 
 def main():
