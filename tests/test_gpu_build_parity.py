@@ -3,6 +3,7 @@
 Bit-exact (integer work): emitted tuple/edge streams in canonical order, the reference's six count
 lines, and the finished CSR (k-mer codes, clustered positions, u16 counts, unique edges)."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -51,3 +52,16 @@ def test_segment_kernels_match_sequential_restatement(segments, seed):
     assert os.path.exists(exe), "run `make harness`"
     r = subprocess.run([exe, str(segments), str(seed)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,bits", [(1, 5), (64, 6), (5000, 13), (5120, 14), (5121, 14), (7000, 32), (100000, 21), (1000003, 25),
+                                    (10000000, 28)])
+def test_radix_sort_is_a_stable_sort(n, bits):
+    """K2 alone (tests/harness/sort_bench.hip): random keys of `bits` bits, payload = input index; the result must equal
+    std::stable_sort's — full and partial tiles, one block and many, every digit width the pass splitter produces."""
+    exe = os.path.join(pagctl.ROOT, "tests", "harness", "bin", "sort_bench")
+    if not os.path.exists(exe):
+        pytest.skip("tests/harness/bin/sort_bench not built")
+    r = subprocess.run([exe, str(n), str(bits)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "check: 0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
