@@ -942,7 +942,7 @@ struct Slot {
     uint32_t zombie;  // walking, but only a leap would still matter
     uint32_t epoch, gen, alt;
     uint32_t cur_v, off, cnt, len, last_pc, ab;
-    uint32_t wp0, wp1, aw0, aw1, wt0, wt1;
+    uint32_t wp0, wp1, wt0, wt1;  // the probe's coordinate window (start vertex included), the travel window of its iteration
     ProbeOut po;
     uint64_t now_size, H;
     uint32_t pb_v, pb_s;
@@ -962,7 +962,7 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
     const uint32_t epoch = __shfl(S.epoch, src, 64), gen = __shfl(S.gen, src, 64);
     uint32_t cur = __shfl(S.cur_v, src, 64), off = __shfl(S.off, src, 64), cnt = __shfl(S.cnt, src, 64);
     uint32_t wp0 = __shfl(S.wp0, src, 64), wp1 = __shfl(S.wp1, src, 64);
-    uint32_t aw0 = __shfl(S.aw0, src, 64), aw1 = __shfl(S.aw1, src, 64), last_pc = __shfl(S.last_pc, src, 64);
+    uint32_t last_pc = __shfl(S.last_pc, src, 64);
     const uint32_t wt0 = __shfl(S.wt0, src, 64), wt1 = __shfl(S.wt1, src, 64);
     ProbeOut po{__shfl(S.po.n, src, 64), __shfl(S.po.v0, src, 64), __shfl(S.po.v1, src, 64)};
     uint64_t now_size = __shfl(S.now_size, src, 64);
@@ -1037,7 +1037,6 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         }
         if (!in_range(X, nv)) probe_out_add(po, nv);
         win_add(wp0, wp1, npc);
-        win_add(aw0, aw1, npc);
         last_pc = npc;
         len += 1;
         now_size += meta & 0xFFFFFFu;
@@ -1065,8 +1064,6 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         S.len = len;
         S.now_size = now_size;
         S.last_pc = last_pc;
-        S.aw0 = aw0;
-        S.aw1 = aw1;
         S.wp0 = wp0;
         S.wp1 = wp1;
         S.po = po;
@@ -1184,7 +1181,6 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
             }
             if (!in_range(X, nv)) probe_out_add(S.po, nv);
             win_add(S.wp0, S.wp1, npc);
-            win_add(S.aw0, S.aw1, npc);
             S.last_pc = npc;
             S.len += 1;
             S.now_size += ns;
@@ -1309,8 +1305,6 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         S.cnt = 0;
         S.wp0 = 0xFFFFFFFFu;
         S.wp1 = 0;
-        S.aw0 = 0xFFFFFFFFu;
-        S.aw1 = 0;
         S.wt0 = X.win_t0;
         S.wt1 = X.win_t1;
         S.po = ProbeOut{0, 0, 0};
@@ -1323,7 +1317,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         }
         const uint32_t c = have_meta ? L.br_pc[rank] : (uint32_t)(X.G.upos[v0] >> 32);
         S.last_pc = c;
-        win_add(S.aw0, S.aw1, c);
+        win_add(S.wp0, S.wp1, c);
         if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
             S.status = WS_LEAP;
             S.fresh = 1;
@@ -1332,7 +1326,6 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
                 arena_s[(uint64_t)g * cap_each] = s0;
             }
         } else {
-            win_add(S.wp0, S.wp1, c);
             if (sub == 0) {
                 if (in_range(X, v0)) stamp_put(L, X, g, v0, S.gen);
                 else gs_insert_single(pset, X.pmask_o, v0, S.gen);
@@ -1588,7 +1581,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     S.status = WS_END;
     S.fresh = S.zombie = S.epoch = S.gen = S.alt = 0;
     S.cur_v = S.off = S.cnt = S.len = S.last_pc = S.ab = 0;
-    S.wp0 = S.wp1 = S.aw0 = S.aw1 = S.wt0 = S.wt1 = 0;
+    S.wp0 = S.wp1 = S.wt0 = S.wt1 = 0;
     S.po = ProbeOut{0, 0, 0};
     S.now_size = S.H = 0;
     S.pb_v = S.pb_s = 0;
@@ -1852,8 +1845,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                     const int stt = __shfl(S.status, src, 64);
                     f_list = stt == WS_END || stt == WS_BRANCH;
                 }
-                f_w0 = __shfl(S.aw0, src, 64);
-                f_w1 = __shfl(S.aw1, src, 64);
+                f_w0 = __shfl(S.wp0, src, 64);
+                f_w1 = __shfl(S.wp1, src, 64);
                 f_nout = __shfl(S.po.n, src, 64);
                 f_last = __shfl(S.cur_v, src, 64);
                 f_lpc = __shfl(S.last_pc, src, 64);
