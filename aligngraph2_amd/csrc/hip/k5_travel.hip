@@ -1160,58 +1160,61 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
     const uint32_t noff = __shfl(rec.toff, src, 64);
     PROF_END(X, 10, t_c);
     PROF_BEGIN(t_d);
-    if (running) {
-        if (n == 0) {
-            S.status = WS_END;
-        } else if (n > 1) {
-            S.status = WS_BRANCH;
-        } else if ((!S.zombie && S.len >= cap_each) || (uint64_t)(S.po.n + 1) * 2 > (uint64_t)X.pmask_o) {
-            if (S.zombie) X.spec_fail |= 4;  // out of room for a walk whose only purpose is the check
-            else X.overflow = 1;
-            S.status = WS_END;
-        } else {
-            const uint32_t ns = meta & 0xFFFFFFu;
-            if (sub == 0) {
-                if (in_range(X, nv)) stamp_put(L, X, g, nv, S.gen);
-                else gs_insert_single(pset, X.pmask_o, nv, S.gen);
-            }
-            if (!S.zombie && sub == (S.len & (GL - 1u))) {
-                S.pb_v = nv;
-                S.pb_s = ns;
-            }
-            if (!in_range(X, nv)) probe_out_add(S.po, nv);
-            win_add(S.wp0, S.wp1, npc);
-            S.last_pc = npc;
-            S.len += 1;
-            S.now_size += ns;
-            if (!S.zombie && (S.len & (GL - 1u)) == 0) {  // GL entries pending: one coalesced store per array
-                pv[S.len - GL + sub] = S.pb_v;
-                ps[S.len - GL + sub] = S.pb_s;
-            }
-            S.cur_v = nv;
-            if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
-                S.status = WS_LEAP;
-            } else {
-                S.off = noff;
-                S.cnt = meta >> 28;
-                if (S.cnt == 15u) {
-                    S.off = X.G.succ_off[nv];
-                    S.cnt = X.G.succ_off[nv + 1] - S.off;
-                }
-            }
+    // State update in predicated form (selects, no nested divergent regions: every slot of the wave takes the same
+    // instruction path, and a branchy version costs ~40 register copies per step at the merge points).
+    const bool full = (!S.zombie && S.len >= cap_each) || (uint64_t)(S.po.n + 1) * 2 > (uint64_t)X.pmask_o;
+    const bool adv = running && n == 1u && !full;                     // the walk moves on to nv
+    const bool leap = adv && npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right);
+    const bool inr_nv = in_range(X, nv);
+    const uint32_t ns = meta & 0xFFFFFFu;
+    if (running && n == 1u && full) {  // (rare)
+        if (S.zombie) X.spec_fail |= 4;  // out of room for a walk whose only purpose is the check
+        else X.overflow = 1;
+    }
+    if (adv && sub == 0) {
+        if (inr_nv) stamp_put(L, X, g, nv, S.gen);
+        else gs_insert_single(pset, X.pmask_o, nv, S.gen);
+    }
+    if (adv && !inr_nv) probe_out_add(S.po, nv);
+    {
+        const bool hold = adv && !S.zombie && sub == (S.len & (GL - 1u));
+        S.pb_v = hold ? nv : S.pb_v;
+        S.pb_s = hold ? ns : S.pb_s;
+    }
+    {
+        const bool w = adv && npc != 0;
+        S.wp0 = w && npc < S.wp0 ? npc : S.wp0;
+        S.wp1 = w && npc > S.wp1 ? npc : S.wp1;
+    }
+    S.last_pc = adv ? npc : S.last_pc;
+    S.len += adv ? 1u : 0u;
+    S.now_size += adv ? ns : 0u;
+    if (adv && !S.zombie && (S.len & (GL - 1u)) == 0) {  // GL entries pending: one coalesced store per array
+        pv[S.len - GL + sub] = S.pb_v;
+        ps[S.len - GL + sub] = S.pb_s;
+    }
+    S.cur_v = adv ? nv : S.cur_v;
+    {
+        uint32_t noff2 = noff, ncnt = meta >> 28;
+        if (adv && !leap && ncnt == 15u) {  // "15 or more": the exact range (rare)
+            noff2 = X.G.succ_off[nv];
+            ncnt = X.G.succ_off[nv + 1] - noff2;
         }
-        if (S.status >= 0) {  // stopped in this step
-            if (S.zombie) {
-                if (S.status == WS_LEAP) X.spec_fail |= 1;
-                S.zombie = 0;
-            } else {
-                if (sub < (S.len & (GL - 1u))) {  // the entries still waiting in registers
-                    pv[S.len - (S.len & (GL - 1u)) + sub] = S.pb_v;
-                    ps[S.len - (S.len & (GL - 1u)) + sub] = S.pb_s;
-                }
-                S.fresh = 1;
-            }
+        const bool go = adv && !leap;
+        S.off = go ? noff2 : S.off;
+        S.cnt = go ? ncnt : S.cnt;
+    }
+    {
+        const int st = !running ? S.status : n == 0u ? (int)WS_END : n > 1u ? (int)WS_BRANCH : full ? (int)WS_END : leap ? (int)WS_LEAP : S.status;
+        const bool stopped = running && st >= 0;  // stopped in this step
+        if (stopped && S.zombie && st == WS_LEAP) X.spec_fail |= 1;
+        if (stopped && !S.zombie && sub < (S.len & (GL - 1u))) {  // the entries still waiting in registers
+            pv[S.len - (S.len & (GL - 1u)) + sub] = S.pb_v;
+            ps[S.len - (S.len & (GL - 1u)) + sub] = S.pb_s;
         }
+        S.fresh = stopped && !S.zombie ? 1u : S.fresh;
+        S.zombie = stopped ? 0u : S.zombie;
+        S.status = st;
     }
     PROF_END(X, 11, t_d);
 }
