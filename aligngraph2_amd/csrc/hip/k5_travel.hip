@@ -1291,60 +1291,60 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
     X.gen += 1;
     X.n_probe += m;
     const uint32_t rank = (uint32_t)__popcll(free_leads & ((1ull << (GL * g)) - 1ull));
-    if (S.status >= 0 && rank < m) {
+    {   // the free slots of rank < m take the alternatives (predicated form: one instruction path for the whole wave)
+        const bool take = S.status >= 0 && rank < m;
+        const uint32_t rk = take ? rank : 0u;
         uint64_t *pset = X.pset_o + (uint64_t)g * ((uint64_t)X.pmask_o + 1);
-        const uint32_t v0 = L.br_v[rank], s0 = L.br_s[rank];
-        S.status = -1;
-        S.fresh = 0;
-        S.zombie = 0;
-        S.epoch = X.epoch;
-        S.gen = X.gen;
-        S.alt = rank;
-        S.cur_v = v0;
-        S.now_size = s0;
-        S.H = has_size;
-        S.len = 1;
-        S.off = 0;
-        S.cnt = 0;
-        S.wp0 = 0xFFFFFFFFu;
-        S.wp1 = 0;
-        S.wt0 = X.win_t0;
-        S.wt1 = X.win_t1;
-        S.po = ProbeOut{0, 0, 0};
-        S.pb_v = v0;  // entry 0 of the path waits in lane 0 of the group
-        S.pb_s = s0;
+        const uint32_t v0 = L.br_v[rk], s0 = L.br_s[rk];
+        uint32_t c = L.br_pc[rk], off0 = L.br_off[rk], cnt0 = L.br_cnt[rk];
+        if (take && !have_meta) {  // (the list came without the vertices' own data: rare)
+            c = (uint32_t)(X.G.upos[v0] >> 32);
+            cnt0 = 15u;
+        }
+        const bool leap0 = take && c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right);
+        const bool go = take && !leap0;
+        if (go && cnt0 == 15u) {  // "15 or more": the exact range (rare)
+            off0 = X.G.succ_off[v0];
+            cnt0 = X.G.succ_off[v0 + 1] - off0;
+        }
+        uint32_t ab0;
         {   // abundance of the alternative (needed if it ends in a branch)
             const uint32_t e0 = v0 - X.C.in_lo - X.w_d0;
-            S.ab = L.wab[e0 < X.w_nid ? e0 + X.w_ab : 0u];
-            if (!(e0 < X.w_nid)) S.ab = X.G.ucnt[v0];
+            ab0 = L.wab[e0 < X.w_nid ? e0 + X.w_ab : 0u];
+            if (take && !(e0 < X.w_nid)) ab0 = X.G.ucnt[v0];
         }
-        const uint32_t c = have_meta ? L.br_pc[rank] : (uint32_t)(X.G.upos[v0] >> 32);
-        S.last_pc = c;
-        win_add(S.wp0, S.wp1, c);
-        if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
-            S.status = WS_LEAP;
-            S.fresh = 1;
-            if (sub == 0) {
-                arena_v[(uint64_t)g * cap_each] = v0;
-                arena_s[(uint64_t)g * cap_each] = s0;
-            }
-        } else {
-            if (sub == 0) {
-                if (in_range(X, v0)) stamp_put(L, X, g, v0, S.gen);
-                else gs_insert_single(pset, X.pmask_o, v0, S.gen);
-            }
-            if (!in_range(X, v0)) probe_out_add(S.po, v0);
-            if (have_meta) {
-                S.off = L.br_off[rank];
-                S.cnt = L.br_cnt[rank];
-            } else {
-                S.cnt = 15u;
-            }
-            if (S.cnt == 15u) {
-                S.off = X.G.succ_off[v0];
-                S.cnt = X.G.succ_off[v0 + 1] - S.off;
-            }
+        const bool inr0 = in_range(X, v0);
+        if (leap0 && sub == 0) {
+            arena_v[(uint64_t)g * cap_each] = v0;
+            arena_s[(uint64_t)g * cap_each] = s0;
         }
+        if (go && sub == 0) {
+            if (inr0) stamp_put(L, X, g, v0, X.gen);
+            else gs_insert_single(pset, X.pmask_o, v0, X.gen);
+        }
+        S.status = take ? (leap0 ? (int)WS_LEAP : -1) : S.status;
+        S.fresh = take ? (leap0 ? 1u : 0u) : S.fresh;
+        S.zombie = take ? 0u : S.zombie;
+        S.epoch = take ? X.epoch : S.epoch;
+        S.gen = take ? X.gen : S.gen;
+        S.alt = take ? rank : S.alt;
+        S.cur_v = take ? v0 : S.cur_v;
+        S.now_size = take ? (uint64_t)s0 : S.now_size;
+        S.H = take ? has_size : S.H;
+        S.len = take ? 1u : S.len;
+        S.off = take ? (go ? off0 : 0u) : S.off;
+        S.cnt = take ? (go ? cnt0 : 0u) : S.cnt;
+        S.wp0 = take ? (c != 0 ? c : 0xFFFFFFFFu) : S.wp0;
+        S.wp1 = take ? c : S.wp1;
+        S.wt0 = take ? X.win_t0 : S.wt0;
+        S.wt1 = take ? X.win_t1 : S.wt1;
+        S.po.n = take ? (go && !inr0 ? 1u : 0u) : S.po.n;
+        S.po.v0 = take ? (go && !inr0 ? v0 : 0u) : S.po.v0;
+        S.po.v1 = take ? 0u : S.po.v1;
+        S.pb_v = take ? v0 : S.pb_v;  // entry 0 of the path waits in lane 0 of the group
+        S.pb_s = take ? s0 : S.pb_s;
+        S.ab = take ? ab0 : S.ab;
+        S.last_pc = take ? c : S.last_pc;
     }
     slots_dominate(X, S, speculate);  // an alternative may have leapt right at its first vertex
     PROF_END(X, 3, t_setup);
