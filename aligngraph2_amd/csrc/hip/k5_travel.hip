@@ -973,10 +973,13 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         ps[len - (len & (GL - 1u)) + (lane & (GL - 1u))] = S.pb_s;
     }
     int fail = 0;
+    bool too_wide = false;
     while (status < 0) {
         if (cnt > 64u) {
-            if (!zombie) return false;  // more successor records than lanes: the caller probes this iteration sequentially
-            fail |= 2;
+            // more successor records than lanes: a zombie fails the speculation; for a probe of the running iteration
+            // the caller probes this iteration again sequentially (sticky flag, the slot is parked as a dead end)
+            if (zombie) fail |= 2;
+            else too_wide = true;
             status = WS_END;
             break;
         }
@@ -1068,7 +1071,7 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         S.wp1 = wp1;
         S.po = po;
     }
-    return true;
+    return !too_wide;
 }
 
 // one step of every walking slot
@@ -1084,10 +1087,7 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
         PROF_BEGIN(t_w);
         const bool okw = slot_finish_wide(L, X, S, (uint32_t)(__ffsll((long long)wz) - 1) >> GL_SHIFT, arena_v, arena_s, cap_each);
         PROF_END(X, 7, t_w);
-        if (!okw) {
-            *wide = true;
-            return;
-        }
+        if (!okw) *wide = true;  // (sticky; the step goes on, the iteration is redone by the caller)
     }
     // The window belongs to the probes of the running iteration.  A zombie steps along while the window serves it;
     // once it has wandered off it is SUSPENDED (its slow global reads would be paid by every slot of the wave) and
@@ -1353,7 +1353,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
     for (;;) {
         if (!__ballot(S.status < 0 && !S.zombie && S.epoch == X.epoch)) break;
         slots_step(L, X, S, arena_v, arena_s, cap_each, &wide, false);
-        if (wide) return false;
+        if (wide) break;
         const uint64_t now = __ballot(S.fresh != 0u && S.epoch == X.epoch);
         if (now != seen) {  // an alternative of this iteration has stopped: what does it mean for the others?
             slots_dominate(X, S, speculate);
@@ -1368,7 +1368,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         X.spec_fail = sf;
     }
     __syncthreads();  // paths written by the groups are read by all lanes afterwards
-    return true;
+    return !wide;
 }
 
 // walkStraight for ONE alternative by a whole wave: every piece of walk state (current vertex, record range,
