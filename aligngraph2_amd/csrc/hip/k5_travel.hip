@@ -944,7 +944,7 @@ struct Slot {
     uint32_t cur_v, off, cnt, len, last_pc, ab;
     uint32_t wp0, wp1, wt0, wt1;  // the probe's coordinate window (start vertex included), the travel window of its iteration
     ProbeOut po;
-    uint64_t now_size, H;
+    uint64_t tot;  // size walked so far INCLUDING the size of the sequence when the probe started (leaping needs the sum)
     uint32_t pb_v, pb_s;
 };
 
@@ -965,9 +965,8 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
     uint32_t last_pc = __shfl(S.last_pc, src, 64);
     const uint32_t wt0 = __shfl(S.wt0, src, 64), wt1 = __shfl(S.wt1, src, 64);
     ProbeOut po{__shfl(S.po.n, src, 64), __shfl(S.po.v0, src, 64), __shfl(S.po.v1, src, 64)};
-    uint64_t now_size = __shfl(S.now_size, src, 64);
+    uint64_t tot = __shfl(S.tot, src, 64);
     uint32_t len = __shfl(S.len, src, 64);
-    const uint64_t H = __shfl(S.H, src, 64);
     if (!zombie && (lane >> GL_SHIFT) == g && (lane & (GL - 1u)) < (len & (GL - 1u))) {  // path entries waiting in registers
         pv[len - (len & (GL - 1u)) + (lane & (GL - 1u))] = S.pb_v;
         ps[len - (len & (GL - 1u)) + (lane & (GL - 1u))] = S.pb_s;
@@ -985,7 +984,7 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         }
         win_follow(L, X, cur, off, cnt);
         X.n_classify += 1;
-        const bool can_leap = (H + now_size) >= X.C.split_size;
+        const bool can_leap = tot >= X.C.split_size;
         int cls = -1;
         SuccRec rec{0, 0, 0, 0};
         if (lane < cnt) {
@@ -1042,7 +1041,7 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         win_add(wp0, wp1, npc);
         last_pc = npc;
         len += 1;
-        now_size += meta & 0xFFFFFFu;
+        tot += meta & 0xFFFFFFu;
         cur = nv;
         if (npc != 0 && (npc < X.C.ctg_left || npc >= X.C.ctg_right)) {
             status = WS_LEAP;
@@ -1065,7 +1064,7 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
         S.off = off;
         S.cnt = cnt;
         S.len = len;
-        S.now_size = now_size;
+        S.tot = tot;
         S.last_pc = last_pc;
         S.wp0 = wp0;
         S.wp1 = wp1;
@@ -1114,7 +1113,7 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
     X.n_classify += 1;
     int cls = -1;
     SuccRec rec{0, 0, 0, 0};
-    const bool can_leap = (S.H + S.now_size) >= X.C.split_size;
+    const bool can_leap = S.tot >= X.C.split_size;
     if (running && sub < S.cnt) {
         rec = rec_load(L, X, S.off + sub);
         // the tests of a probe use ITS windows: the probe's own, and the travel window of its iteration
@@ -1188,7 +1187,7 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
     }
     S.last_pc = adv ? npc : S.last_pc;
     S.len += adv ? 1u : 0u;
-    S.now_size += adv ? ns : 0u;
+    S.tot += adv ? ns : 0u;
     if (adv && !S.zombie && (S.len & (GL - 1u)) == 0) {  // GL entries pending: one coalesced store per array
         pv[S.len - GL + sub] = S.pb_v;
         ps[S.len - GL + sub] = S.pb_s;
@@ -1262,7 +1261,7 @@ __device__ __forceinline__ void slots_dominate(const WalkCtx &X, Slot &S, bool s
         // (only while the walk is far from the size at which leaping becomes possible at all: close to it,
         // leaps of side paths are common and every one would void the whole job)
         if (S.status < 0 && S.epoch == X.epoch && !S.zombie && (bab > S.ab || (bab == S.ab && balt < S.alt)) &&
-            S.H + S.now_size + SPEC_MARGIN < X.C.split_size)
+            S.tot + SPEC_MARGIN < X.C.split_size)
             S.zombie = 1;
     }
 }
@@ -1329,8 +1328,7 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         S.gen = take ? X.gen : S.gen;
         S.alt = take ? rank : S.alt;
         S.cur_v = take ? v0 : S.cur_v;
-        S.now_size = take ? (uint64_t)s0 : S.now_size;
-        S.H = take ? has_size : S.H;
+        S.tot = take ? has_size + s0 : S.tot;
         S.len = take ? 1u : S.len;
         S.off = take ? (go ? off0 : 0u) : S.off;
         S.cnt = take ? (go ? cnt0 : 0u) : S.cnt;
@@ -1586,7 +1584,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     S.cur_v = S.off = S.cnt = S.len = S.last_pc = S.ab = 0;
     S.wp0 = S.wp1 = S.wt0 = S.wt1 = 0;
     S.po = ProbeOut{0, 0, 0};
-    S.now_size = S.H = 0;
+    S.tot = 0;
     S.pb_v = S.pb_s = 0;
     const bool speculate = J.exact == 0;
     const uint64_t slot_cap = J.arena_cap / PROBE_GROUPS;
@@ -1855,7 +1853,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 f_lpc = __shfl(S.last_pc, src, 64);
                 f_off = __shfl(S.off, src, 64);
                 f_cnt = __shfl(S.cnt, src, 64);
-                f_size = __shfl(S.now_size, src, 64);
+                f_size = __shfl(S.tot, src, 64) - (has_size + now_size);  // (the chosen slot was started in this iteration)
                 S.fresh = 0;  // consumed
                 PROF_END(X, 5, t_choice);
             } else if (S.epoch == X.epoch && (S.status < 0 || S.fresh != 0u)) {  // too wide: this iteration is probed sequentially
