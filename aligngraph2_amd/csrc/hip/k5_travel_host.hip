@@ -339,6 +339,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if (orient[c] < 0) continue;
         CtgState cs;
         cs.ci = c;
+        if (c < g->paths_pool.size()) {  // storage of the previous block's path for this slot
+            cs.travel.swap(g->paths_pool[c]);
+            cs.travel.clear();
+        }
         cs.forward = orient[c] != 0;
         cs.chosenOne = cs.forward ? (int64_t)c + 1 : -(int64_t)c - 1;
         cs.len = ctgs->len[c];

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 #include "pag_device.hpp"
@@ -70,6 +71,7 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->eseg = nullptr;
     g->n_t = g->n_e = 0;
     g->tg_ready = false;
+    if (!g->paths.empty()) g->paths_pool.swap(g->paths);  // keep the storage (see paths_pool)
     g->paths.clear();
 }
 
@@ -230,6 +232,9 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         set_error("too many reads for one launch");
         return PAG_EINVAL;
     }
+    const bool timing = getenv("PAGRAPH_TIMING") != nullptr;
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto wall_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(); };
     PAG_HIP_TRY(hipSetDevice(g->device));
     free_graph_results(g);
     hipStream_t s = g->stream;
@@ -247,6 +252,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         }
     } ev_guard{ev};
     PAG_HIP_TRY(hipEventRecord(ev[0], s));
+    const double w_ev0 = wall_ms();
 
     // ---- inputs -> device
     DevBuf b_roff(g, 0), b_rlen(g, 1), b_packed(g, 2), b_order(g, 3), b_aln1(g, 4), b_q1(g, 5), b_d1(g, 6), b_aln2(g, 7), b_q2(g, 8), b_d2(g, 9), b_ctg(g, 10), b_eoff(g, 11), b_ent(g, 12), b_ref(g, 13);
@@ -465,6 +471,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     PAG_HIP_TRY(hipMemcpyAsync(ctr_e, b_ctr.p, 32, hipMemcpyDeviceToHost, s));
     PAG_HIP_TRY(hipEventRecord(ev[4], s));
     PAG_HIP_TRY(hipStreamSynchronize(s));
+    const double w_ev4 = wall_ms();
 
     // ---- the reference's count lines (PositionProcessor.cpp:126-142)
     pag_build_stats st{};
@@ -494,6 +501,9 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     st.ms_edges = ms;
     hipEventElapsedTime(&ms, ev[0], ev[4]);
     st.ms_total = ms;
+    if (timing)
+        fprintf(stderr, "[timing] pag_process wall: %.1f ms before the first event, %.1f ms first..last event (device %.1f ms), now %.1f ms\n", w_ev0,
+                w_ev4 - w_ev0, (double)ms, wall_ms());
     st.ms_sort_kernel = ms_scatter_t;
     st.sort_records = T;
     (void)passes;
