@@ -38,7 +38,8 @@ inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, st
         t5.join();
     }
     graph.k = k;
-    results.assign(paths.size() * 2, {});
+    results.resize(paths.size() * 2);  // (inner vectors keep their storage from the previous block)
+    for (auto &r : results) r.clear();
     std::atomic<std::size_t> next{0};
     auto worker = [&]() {
         for (std::size_t c; (c = next.fetch_add(1)) < paths.size();) {

@@ -58,8 +58,10 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
                 orient[i] = ctg_orient[i] != 0 ? 1 : 0;
             }
 
-        pagh::HostGraph graph;
-        std::vector<pagh::TravelSequence> precomputed;
+        // kept between calls (one block after the other on a handle): releasing and re-faulting ~1 GB of host arrays
+        // per block costs tens of milliseconds
+        static thread_local pagh::HostGraph graph;
+        static thread_local std::vector<pagh::TravelSequence> precomputed;
         double t1;
         pag_travel_stats tstAll{};
         if (deviceWalk) {
