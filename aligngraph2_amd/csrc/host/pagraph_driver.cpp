@@ -176,6 +176,8 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
 
         std::unordered_set<std::string> okCtg;  // same container as the reference: contig.txt order (quirk Q11)
         std::size_t blockNo = 0;
+        HostGraph graph;  // (storage reused from block to block)
+        std::vector<TravelSequence> precomputed;
         for (auto &cfg : configs) {
             backend.reset();
             std::cout << "Use Ref: " << cfg.ref << std::endl;
@@ -202,8 +204,6 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             std::cout << "[PositionProcessor] Done!" << std::endl;
 
             lap("graph build (process)");
-            HostGraph graph;
-            std::vector<TravelSequence> precomputed;
             bool onDevice = false;
             {
                 // orientation per contig exactly as assemble() will look it up (std::set order, last wins)
