@@ -115,3 +115,27 @@ def test_device_walks_equal_host_walk_on_multi_round_contigs(workdir):
     r = subprocess.run([sys.executable, os.path.join(pagctl.ROOT, "tests", "walk_check.py"), "--reads", "50000", "--ref-len", "25000000"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL EQUAL" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_line_contract(workdir):
+    """bench.py on a small workload: one JSON line with the fields the driver reads, a roofline object for the sort kernel
+    and a cpu_baseline object from the compiled reference (or a stated failure where oracle/_ref is absent)."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(pagctl.ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--reads", "3000",
+                        "--ref-len", "3000000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["scaling"] == "weak" and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and "sample" in cb and "cores" in cb
