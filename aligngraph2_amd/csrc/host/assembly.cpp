@@ -55,7 +55,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads, AssembleStats *stats, bool quiet,
-                                                const std::vector<TravelSequence> *precomputed) {
+                                                std::vector<TravelSequence> *precomputed) {
     const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
     auto nowMs = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tLap = nowMs();
@@ -91,7 +91,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
             log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
             auto &res = results[2 * ctgIdx + ctgOffset];
-            if (precomputed) res = (*precomputed)[2 * ctgIdx + ctgOffset];
+            if (precomputed) res.swap((*precomputed)[2 * ctgIdx + ctgOffset]);  // (taken over, handed back at the end: no copy)
             else res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
             log << tlog;
 
@@ -363,6 +363,9 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         }
     }
     lap("stats");
+    if (precomputed)  // the storage goes back to the caller's cache (the contents are spent)
+        for (std::size_t i = 0; i < results.size() && i < precomputed->size(); ++i)
+            if (results[i].capacity() > (*precomputed)[i].capacity()) results[i].swap((*precomputed)[i]);
     return success;
 }
 

@@ -30,6 +30,6 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads = 1, AssembleStats *stats = nullptr, bool quiet = false,
-                                                const std::vector<TravelSequence> *precomputed = nullptr);
+                                                std::vector<TravelSequence> *precomputed = nullptr);
 
 }  // namespace pagh
