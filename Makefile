@@ -64,7 +64,7 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 
 HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
 HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle \
-           tests/harness/bin/seg_kernels_test tests/harness/bin/sort_bench
+           tests/harness/bin/seg_kernels_test tests/harness/bin/sort_bench tests/harness/bin/libpagh_walk_test.so
 harness: $(HARNESS)
 
 # kernel-level check of K3/K4 against a sequential restatement (needs a GPU to run)
@@ -85,10 +85,19 @@ tests/harness/bin/libpagh_test.so: tests/harness/pagh_test.cpp $(HOST_NOHIP_OBJS
 	@mkdir -p tests/harness/bin
 	$(CXX) $(CXXFLAGS) -shared -o $@ $< $(HOST_NOHIP_OBJS) -pthread
 
-HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
-tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
+# host restatement of the reference's traversal: test infrastructure, linked into harness programs only
+$(B)/host_walk.o: tests/harness/host_walk.cpp tests/harness/host_walk.hpp $(wildcard $(HOST_DIR)/*.hpp)
+	@mkdir -p $(B)
+	$(CXX) $(CXXFLAGS) -Itests/harness -c $< -o $@
+
+tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o $(B)/host_walk.o
 	@mkdir -p tests/harness/bin
-	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o -lm -pthread
+	$(CXX) $(CXXFLAGS) -Ioracle -Itests/harness -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o $(B)/host_walk.o -lm -pthread
+
+# device graph exported + host walk (needs the HIP library at run time): cross-check of the device walkers
+tests/harness/bin/libpagh_walk_test.so: tests/harness/pagh_walk_test.cpp $(HOST_NOHIP_OBJS) $(B)/host_walk.o aligngraph2_amd/libpagraph_hip.so
+	@mkdir -p tests/harness/bin
+	$(CXX) $(CXXFLAGS) -Itests/harness -shared -o $@ $< $(HOST_NOHIP_OBJS) $(B)/host_walk.o -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/../../../aligngraph2_amd' -pthread
 
 clean:
 	rm -rf $(B) aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin tests/harness/bin

@@ -2290,4 +2290,44 @@ void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, 
     if (n) k_gather_vertices<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(G, vids, n, out);
 }
 
+// test hook: the device match predicates on caller-supplied rows (tests/test_gpu_predicates.py feeds the reference's
+// truth table tests/golden/func_predicate.txt.gz and a dense sweep around the 0.15 ratio boundary)
+__global__ void k_debug_predicates(const uint32_t *__restrict__ rows, uint64_t n, double err, uint8_t *__restrict__ grade,
+                                   uint8_t *__restrict__ edge_sim) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *r = rows + 6 * i;  // a_ctg a_ref b_ctg b_ref dist dev
+    uint32_t es = 0;
+    grade[i] = (uint8_t)d_check_position(r[0], r[1], r[2], r[3], r[4], r[5], err, &es);
+    edge_sim[i] = (uint8_t)es;
+}
+
 }  // namespace pagdev
+
+extern "C" int pag_debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device) {
+    using namespace pagdev;
+    if (!rows || !grade || !edge_sim) return PAG_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return PAG_ENODEV;
+    uint32_t *d_rows = nullptr;
+    uint8_t *d_out = nullptr;
+    if (n == 0) return PAG_OK;
+    PAG_HIP_TRY(hipMalloc((void **)&d_rows, n * 24));
+    if (hipMalloc((void **)&d_out, 2 * n) != hipSuccess) {
+        hipFree(d_rows);
+        return PAG_ENOMEM;
+    }
+    hipError_t e = hipMemcpy(d_rows, rows, n * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_debug_predicates<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_rows, n, err, d_out, d_out + n);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(grade, d_out, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(edge_sim, d_out + n, n, hipMemcpyDeviceToHost);
+    hipFree(d_rows);
+    hipFree(d_out);
+    if (e != hipSuccess) {
+        set_error("pag_debug_predicates: %s", hipGetErrorString(e));
+        return PAG_EFAULT;
+    }
+    return PAG_OK;
+}

@@ -183,13 +183,31 @@ int64_t append_seq(std::vector<pag_path_node> &base, const std::vector<pag_path_
 
 extern "C" {
 
-const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
-    if (!g || ctg_index >= g->paths.size()) {
+// test hooks (host code only, no device needed): the library's own copies of PositionMapper and editDistance against the
+// reference's function-level golden tables (tests/test_function_goldens.py)
+uint64_t pag_debug_edit_distance(const char *a, const char *b) { return edit_distance(a, b); }
+uint64_t pag_debug_mapper_d2s(const uint32_t *len, uint64_t n, int64_t idx, int64_t pos) { return Mapper(len, n).dualToSingle(idx, pos); }
+void pag_debug_mapper_s2d(const uint32_t *len, uint64_t n, uint64_t single, int64_t *idx, int64_t *pos) {
+    auto d = Mapper(len, n).singleToDual(single);
+    *idx = d.first;
+    *pos = d.second;
+}
+uint64_t pag_debug_mapper_extra(const uint32_t *len, uint64_t n) { return Mapper(len, n).starts.back(); }
+
+// g->paths[2 * contig + (reverse ? 1 : 0)]
+const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len) {
+    const uint64_t slot = 2 * ctg_index + (forward ? 0 : 1);
+    if (!g || slot >= g->paths.size() || !g->path_valid[slot]) {
         if (len) *len = 0;
         return nullptr;
     }
-    if (len) *len = g->paths[ctg_index].size();
-    return g->paths[ctg_index].data();
+    if (len) *len = g->paths[slot].size();
+    return g->paths[slot].data();
+}
+
+const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
+    if (g && 2 * ctg_index + 1 < g->paths.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
+    return pag_travel_path_oriented(g, ctg_index, 1, len);
 }
 
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
@@ -332,18 +350,24 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     Mapper mapper(ctgs->len, ctgs->n_seqs);
     Mapper refMapper(ref_len, n_refs);
     const uint32_t n_ctgs = (uint32_t)ctgs->n_seqs;
-    g->paths.assign(n_ctgs, {});
+    g->paths.assign(2 * (size_t)n_ctgs, {});
+    g->path_valid.assign(2 * (size_t)n_ctgs, 0);
     std::vector<CtgState> st;
     uint64_t nodes_total = 0;
-    for (uint32_t c = 0; c < n_ctgs; ++c) {
-        if (orient[c] < 0) continue;
+    // one entry per (contig, orientation): a contig selected with both orientations is two independent traversals
+    // (PAssembly.cpp:28-36 walks every (name, forward) pair of its set)
+    for (uint32_t c2 = 0; c2 < 2 * n_ctgs; ++c2) {
+        const uint32_t c = c2 >> 1;
+        const bool fwd = (c2 & 1u) == 0;
+        const int32_t o = orient[c];
+        if (!(o == PAG_ORIENT_BOTH || (fwd && o == PAG_ORIENT_FORWARD) || (!fwd && o == PAG_ORIENT_REVERSE))) continue;
         CtgState cs;
         cs.ci = c;
-        if (c < g->paths_pool.size()) {  // storage of the previous block's path for this slot
-            cs.travel.swap(g->paths_pool[c]);
+        if (c2 < g->paths_pool.size()) {  // storage of the previous block's path for this slot
+            cs.travel.swap(g->paths_pool[c2]);
             cs.travel.clear();
         }
-        cs.forward = orient[c] != 0;
+        cs.forward = fwd;
         cs.chosenOne = cs.forward ? (int64_t)c + 1 : -(int64_t)c - 1;
         cs.len = ctgs->len[c];
         cs.ctgLeft = (uint32_t)mapper.dualToSingle(cs.chosenOne, 0);
@@ -994,7 +1018,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                                              (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit)))
                 seq.pop_back();
         }
-        g->paths[cs.ci] = std::move(seq);
+        g->paths[2 * (size_t)cs.ci + (cs.forward ? 0 : 1)] = std::move(seq);
+        g->path_valid[2 * (size_t)cs.ci + (cs.forward ? 0 : 1)] = 1;
     }
     lap("epilogue");
     if (timing) {

@@ -73,6 +73,7 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->tg_ready = false;
     if (!g->paths.empty()) g->paths_pool.swap(g->paths);  // keep the storage (see paths_pool)
     g->paths.clear();
+    g->path_valid.clear();
 }
 
 __global__ void chunk_counts(const pag_aln *__restrict__ aln, uint64_t n, uint32_t *__restrict__ out) {

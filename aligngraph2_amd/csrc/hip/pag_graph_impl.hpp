@@ -45,7 +45,8 @@ struct pag_graph {
     bool tg_ready = false;
     uint64_t tg_dev = 0;   // parameters the successor records were built with
     double tg_err = 0;
-    std::vector<std::vector<pag_path_node>> paths;
+    std::vector<std::vector<pag_path_node>> paths;  // [2 * contig + (reverse ? 1 : 0)]
+    std::vector<uint8_t> path_valid;                // that orientation was traversed by the last pag_travel
     std::vector<std::vector<pag_path_node>> paths_pool;  // storage of the previous result, taken over by the next traversal
                                                           // (releasing and re-faulting ~0.4 GB per block costs tens of ms)
     // debug: raw emitted streams (host copies), kept when PAG_DEBUG_KEEP_STREAMS=1

@@ -55,7 +55,9 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads, AssembleStats *stats, bool quiet,
-                                                std::vector<TravelSequence> *precomputed) {
+                                                std::vector<TravelSequence> &travelled) {
+    (void)minLen;     // (both only steer the walk itself, which has already happened: PAlgorithm::travelSequence on the device)
+    (void)threadNum;
     const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
     auto nowMs = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tLap = nowMs();
@@ -86,14 +88,13 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             std::size_t ctgIdx = contigs.id(ctgName.first);
             std::size_t ctgOffset = ctgName.second ? 0 : 1;
             std::stringstream log;
-            std::string tlog;
-            Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum, quiet ? nullptr : &tlog);
+            SeqTools algo(graph, contigs, refs, ctgMapper, refMapper);
             log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
             log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
             auto &res = results[2 * ctgIdx + ctgOffset];
-            if (precomputed) res.swap((*precomputed)[2 * ctgIdx + ctgOffset]);  // (taken over, handed back at the end: no copy)
-            else res = algo.travelSequence(ctgIdx, ctgOffset == 0, deviation, errorRate, startSplit, minLen);
-            log << tlog;
+            // PAlgorithm::travelSequence ran on the device (pag_travel); its result is taken over here and its storage
+            // handed back at the end: no copy
+            if (2 * ctgIdx + ctgOffset < travelled.size()) res.swap(travelled[2 * ctgIdx + ctgOffset]);
 
             std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
             of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
@@ -128,7 +129,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                 }
                 of.write(buf.data(), static_cast<std::streamsize>(buf.size()));
             }
-            if (Traversal::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
+            if (SeqTools::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
             if (!res.empty()) {
                 std::uint32_t lastCtgPos = graph.position(res.back().first).first;
                 if (lastCtgPos != 0) {
@@ -236,7 +237,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     // emit chains (PAssembly.cpp:242-333)
     out << "[Assembly] Start" << std::endl;
     std::size_t nameCnt = 0;
-    Traversal algo(graph, contigs, refs, ctgMapper, refMapper, threadNum);
+    SeqTools algo(graph, contigs, refs, ctgMapper, refMapper);
     for (auto &ctgName : starts) {
         std::size_t ctgIdx = contigs.id(ctgName.first);
         std::size_t i = ctgIdx * 2 + (ctgName.second ? 0 : 1);
@@ -248,11 +249,11 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
             connected.emplace(ctgId, forward);
             maxLen = std::max<std::size_t>(maxLen, contigs.length(ctgId));
-            totalLen += Traversal::seqSize(results[ctgId * 2 + (forward ? 0 : 1)]);
+            totalLen += SeqTools::seqSize(results[ctgId * 2 + (forward ? 0 : 1)]);
             return true;
         });
         bool isConnected = connected.size() > 1 && totalLen > maxLen * 1.05;
-        bool isExtended = connected.size() == 1 && Traversal::seqSize(results[i]) > contigs.length(ctgIdx) * 1.2;
+        bool isExtended = connected.size() == 1 && SeqTools::seqSize(results[i]) > contigs.length(ctgIdx) * 1.2;
         if (!(isConnected || isExtended)) {
             out << "Ignore output" << std::endl;
             continue;
@@ -345,7 +346,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                     h = (h ^ static_cast<std::uint64_t>(n.second)) * 1099511628211ull;
                 }
                 hs[i] = h;
-                nb[i] = Traversal::seqSize(results[i]);
+                nb[i] = SeqTools::seqSize(results[i]);
             }
         };
         {
@@ -363,9 +364,9 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         }
     }
     lap("stats");
-    if (precomputed)  // the storage goes back to the caller's cache (the contents are spent)
-        for (std::size_t i = 0; i < results.size() && i < precomputed->size(); ++i)
-            if (results[i].capacity() > (*precomputed)[i].capacity()) results[i].swap((*precomputed)[i]);
+    // the storage goes back to the caller's cache (the contents are spent)
+    for (std::size_t i = 0; i < results.size() && i < travelled.size(); ++i)
+        if (results[i].capacity() > travelled[i].capacity()) results[i].swap(travelled[i]);
     return success;
 }
 

@@ -20,8 +20,9 @@ struct AssembleStats {
 };
 
 // returns the (contig name, forward) pairs consumed by emitted chains.
-// precomputed: travel sequences produced elsewhere (the device traversal), indexed 2 * contig + (reverse ? 1 : 0);
-// when given, `graph` only has to contain the vertices on those sequences.
+// travelled: the travel sequences (PAlgorithm::travelSequence, produced by the device traversal), indexed
+// 2 * contig + (reverse ? 1 : 0); `graph` only has to contain the vertices on those sequences.  The sequences are
+// consumed (their storage is handed back for the next block).
 // hostThreads: workers for the per-contig traversal loop (the reference uses max(1, t/8) threads there,
 // PAssembly.cpp:30; results are independent of the worker count).
 std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const std::string &prefix, const HostGraph &graph,
@@ -29,7 +30,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const PositionMapper &refMapper,
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
-                                                unsigned hostThreads = 1, AssembleStats *stats = nullptr, bool quiet = false,
-                                                std::vector<TravelSequence> *precomputed = nullptr);
+                                                unsigned hostThreads, AssembleStats *stats, bool quiet,
+                                                std::vector<TravelSequence> &travelled);
 
 }  // namespace pagh

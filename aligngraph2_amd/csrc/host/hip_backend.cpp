@@ -1,5 +1,7 @@
 #include "hip_backend.hpp"
 
+#include "path_graph.hpp"
+
 #include <stdexcept>
 #include <string>
 
@@ -28,17 +30,30 @@ public:
         check(pag_export_csr(g_, &csr), "pag_export_csr");
     }
 
-    bool travel(const pag_seqs &ctgs, const std::vector<int> &orient, const std::vector<std::uint32_t> &refLen,
-                const pag_travel_params &params, std::vector<std::vector<pag_path_node>> &paths) override {
-        std::vector<std::int32_t> o(orient.begin(), orient.end());
-        check(pag_travel(g_, &ctgs, o.data(), refLen.data(), refLen.size(), &params, nullptr), "pag_travel");
-        paths.assign(ctgs.n_seqs, {});
-        for (std::uint64_t c = 0; c < ctgs.n_seqs; ++c) {
-            std::uint64_t len = 0;
-            const pag_path_node *p = pag_travel_path(g_, c, &len);
-            if (p && len) paths[c].assign(p, p + len);
+    void travel(const TravelContext &ctx, const pag_travel_params &params, HostGraph &graph,
+                std::vector<TravelSequence> &travelled) override {
+        const SeqDb &contigs = ctx.contigs;
+        // orientation(s) per contig as PAssembly::testTravel5 walks its ctgSet (PAssembly.cpp:28-36): a contig listed with
+        // both orientations is traversed twice, as two independent entries
+        std::vector<std::int32_t> orient(contigs.size(), PAG_ORIENT_NONE);
+        for (auto &c : ctx.ctgSet) {
+            if (!contigs.contains(c.first)) continue;
+            std::int32_t &o = orient[contigs.id(c.first)];
+            const std::int32_t mine = c.second ? PAG_ORIENT_FORWARD : PAG_ORIENT_REVERSE;
+            o = (o == PAG_ORIENT_NONE || o == mine) ? mine : PAG_ORIENT_BOTH;
         }
-        return true;
+        std::vector<std::uint32_t> refLen;
+        for (std::size_t i = 0; i < ctx.refs.size(); ++i) refLen.push_back(ctx.refs.length(i));
+        pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(), contigs.packed().size()};
+        check(pag_travel(g_, &cs, orient.data(), refLen.data(), refLen.size(), &params, nullptr), "pag_travel");
+        std::vector<std::pair<const pag_path_node *, std::uint64_t>> views(2 * contigs.size(), {nullptr, 0});
+        for (std::uint64_t c = 0; c < contigs.size(); ++c)
+            for (int rev = 0; rev < 2; ++rev) {
+                std::uint64_t len = 0;
+                const pag_path_node *p = pag_travel_path_oriented(g_, c, rev == 0, &len);
+                if (p && len) views[2 * c + rev] = {p, len};
+            }
+        buildPathGraph(views, ctx.k, graph, travelled);
     }
 
 private:

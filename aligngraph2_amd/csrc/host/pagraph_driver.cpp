@@ -204,45 +204,21 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             std::cout << "[PositionProcessor] Done!" << std::endl;
 
             lap("graph build (process)");
-            bool onDevice = false;
             {
-                // orientation per contig exactly as assemble() will look it up (std::set order, last wins)
-                std::vector<int> orient(contigs.size(), -1);
-                for (auto &c : usedCtg)
-                    if (contigs.contains(c.first)) orient[contigs.id(c.first)] = c.second ? 1 : 0;
-                std::vector<std::uint32_t> refLen;
-                for (std::size_t i = 0; i < refs.size(); ++i) refLen.push_back(refs.length(i));
-                pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(),
-                            contigs.packed().size()};
                 pag_travel_params tp{};
                 tp.ref_threads = opt.threads;
                 tp.deviation = opt.epsilon * 2;
                 tp.error_rate = errorRate;
                 tp.start_split = startSplit;
                 tp.min_len = opt.minLen;
-                std::vector<std::vector<pag_path_node>> paths;
-                bool hostWalk = std::getenv("PAGRAPH_HOST_WALK") != nullptr;  // verification aid only
-                {  // a contig listed with both orientations is traversed twice by the reference: host walk
-                    std::set<std::string> names;
-                    for (auto &c : usedCtg)
-                        if (!names.insert(c.first).second) hostWalk = true;
-                }
-                if (!hostWalk && backend.travel(cs, orient, refLen, tp, paths)) {
-                    std::vector<std::pair<const pag_path_node *, std::uint64_t>> views;
-                    for (auto &pth : paths) views.emplace_back(pth.data(), pth.size());
-                    buildPathGraph(views, orient, static_cast<unsigned>(kmers.k()), graph, precomputed);
-                    onDevice = true;
-                    lap("device traversal");
-                }
-            }
-            if (!onDevice) {
-                backend.exportCsr(graph);
-                lap("graph export");
-                graph.k = static_cast<std::uint32_t>(kmers.k());
+                GraphBackend::TravelContext ctx{contigs, refs, input.ctgMapper(), input.refMapper(), usedCtg,
+                                                static_cast<unsigned>(kmers.k())};
+                backend.travel(ctx, tp, graph, precomputed);
+                lap("traversal");
             }
             auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, input.ctgMapper(),
                                        input.refMapper(), usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
-                                       opt.threads, 0, nullptr, false, onDevice ? &precomputed : nullptr);
+                                       opt.threads, 0, nullptr, false, precomputed);
             lap("traverse + write");
             ++blockNo;
             for (auto &s : successCtg) okCtg.emplace(s.first);

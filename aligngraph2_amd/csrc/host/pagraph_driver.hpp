@@ -7,8 +7,15 @@
 #include <cstdint>
 #include <vector>
 
+#include <set>
+#include <string>
+#include <utility>
+
 #include "host_graph.hpp"
 #include "pagraph_hip.h"
+#include "position_mapper.hpp"
+#include "seq_db.hpp"
+#include "traversal.hpp"
 
 namespace pagh {
 
@@ -22,12 +29,19 @@ public:
     virtual void reset() = 0;
     virtual void process(const pag_build_input &in, pag_build_stats &stats) = 0;
     virtual void exportCsr(HostGraph &out) = 0;
-    // device traversal (PAlgorithm::travelSequence for every selected contig); backends without one
-    // return false and the driver walks the exported graph on the host instead
-    virtual bool travel(const pag_seqs & /*ctgs*/, const std::vector<int> & /*orient*/, const std::vector<std::uint32_t> & /*refLen*/,
-                        const pag_travel_params & /*params*/, std::vector<std::vector<pag_path_node>> & /*paths*/) {
-        return false;
-    }
+    // PAlgorithm::travelSequence for every (contig, orientation) of ctgSet (PAssembly.cpp:30-36): fills `graph` with (at
+    // least) the vertices on the travel sequences and travelled[2 * contig + (reverse ? 1 : 0)].  The product backend
+    // walks on the device (pag_travel); there is no host walk in the product.
+    struct TravelContext {
+        const SeqDb &contigs;
+        const SeqDb &refs;
+        const PositionMapper &ctgMapper;
+        const PositionMapper &refMapper;
+        const std::set<std::pair<std::string, bool>> &ctgSet;
+        unsigned k;
+    };
+    virtual void travel(const TravelContext &ctx, const pag_travel_params &params, HostGraph &graph,
+                        std::vector<TravelSequence> &travelled) = 0;
 };
 
 int runPagraph(int argc, char **argv, GraphBackend &backend);

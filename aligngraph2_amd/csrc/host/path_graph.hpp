@@ -16,9 +16,9 @@
 
 namespace pagh {
 
-// paths[c] = (pointer, length) of contig c's path
-inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, std::uint64_t>> &paths, const std::vector<int> &orient,
-                           unsigned k, HostGraph &graph, std::vector<TravelSequence> &results, unsigned threads = 0) {
+// paths[2 * c + (reverse ? 1 : 0)] = (pointer, length) of the path of contig c in that orientation (0 = not traversed)
+inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, std::uint64_t>> &paths, unsigned k, HostGraph &graph,
+                           std::vector<TravelSequence> &results, unsigned threads = 0) {
     std::vector<std::size_t> base(paths.size() + 1, 0);
     for (std::size_t c = 0; c < paths.size(); ++c) base[c + 1] = base[c] + paths[c].second;
     const std::size_t total = base.back();
@@ -38,16 +38,15 @@ inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, st
         t5.join();
     }
     graph.k = k;
-    results.resize(paths.size() * 2);  // (inner vectors keep their storage from the previous block)
+    results.resize(paths.size());  // (inner vectors keep their storage from the previous block)
     for (auto &r : results) r.clear();
     std::atomic<std::size_t> next{0};
     auto worker = [&]() {
         for (std::size_t c; (c = next.fetch_add(1)) < paths.size();) {
-            const bool used = c < orient.size() && orient[c] >= 0;
-            TravelSequence *res = used ? &results[2 * c + (orient[c] ? 0 : 1)] : nullptr;
+            TravelSequence *res = &results[c];
             const pag_path_node *p = paths[c].first;
             const std::size_t n = paths[c].second;
-            if (res) res->resize(n);
+            res->resize(n);
             std::size_t i = base[c];
             for (std::size_t x = 0; x < n; ++x, ++i) {
                 graph.nodeCode[i] = p[x].code;
@@ -55,7 +54,7 @@ inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, st
                 graph.posCtg[i] = p[x].ctg;
                 graph.posRef[i] = p[x].ref;
                 graph.posCnt[i] = p[x].cnt;
-                if (res) (*res)[x] = {Vertex{static_cast<std::uint32_t>(i), 0u}, p[x].step};
+                (*res)[x] = {Vertex{static_cast<std::uint32_t>(i), 0u}, p[x].step};
             }
         }
     };

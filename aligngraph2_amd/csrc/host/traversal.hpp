@@ -1,10 +1,9 @@
-// Epsilon-join traversal of the positional A-Bruijn graph: host-side control.
-// Restates PAlgorithm (reference PAGraph/src/tools/graph/PAlgorithm.{hpp,tcc,cpp}): successor
-// classification, walkStraight, graphTravel (branch probing), travelSequence (outer loop with seeds,
-// repeat detection, leap to the next contig), appendSeq, filterSequence and seqToString.
+// Host side of the traversal epilogue: what is done with a finished travel sequence.
+// Restates PAlgorithm::seqToString / seqSize (reference PAGraph/src/tools/graph/PAlgorithm.cpp:428-497) and
+// PABruijnGraph::toString(PANode) (PABruijnGraph.cpp:358-364).  The walk that produces the sequences runs on the
+// device (csrc/hip/k5_travel*.hip); no host walk is part of the product.
 #pragma once
 #include <cstdint>
-#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -17,66 +16,25 @@ namespace pagh {
 
 using TravelSequence = std::vector<std::pair<Vertex, int>>;
 
-class Traversal {
+class SeqTools {
 public:
-    Traversal(const HostGraph &g, const SeqDb &contigs, const SeqDb &refs, const PositionMapper &ctgMapper,
-              const PositionMapper &refMapper, unsigned threadNum, std::string *log = nullptr)
-        : g_(g), contigs_(contigs), refs_(refs), ctgMapper_(ctgMapper), refMapper_(refMapper), threadNum_(threadNum), log_(log) {}
+    SeqTools(const HostGraph &g, const SeqDb &contigs, const SeqDb &refs, const PositionMapper &ctgMapper,
+             const PositionMapper &refMapper)
+        : g_(g), contigs_(contigs), refs_(refs), ctgMapper_(ctgMapper), refMapper_(refMapper) {}
 
-    // PAlgorithm::travelSequence (PAlgorithm.cpp:144-426)
-    TravelSequence travelSequence(std::size_t ctgIdx, bool forward, std::size_t deviation, double errorRate,
-                                  double startSplit, std::size_t minLen);
     // PAlgorithm::seqToString (PAlgorithm.cpp:428-489)
     std::string seqToString(const TravelSequence &seq, std::size_t deviation, double errorRate) const;
     // PAlgorithm::seqSize (PAlgorithm.cpp:491-497)
     static std::size_t seqSize(const TravelSequence &seq);
-    // PAlgorithm::editDistance (PAlgorithm.cpp:46-69)
-    static std::size_t editDistance(const std::string &a, const std::string &b);
     // PABruijnGraph::toString(PANode) (PABruijnGraph.cpp:358-364)
     std::string vertexString(const Vertex &v) const;
 
 private:
-    enum NodeStatus { End, Branch, Limit, Leap };
-    using PosTable = std::pair<std::uint32_t, std::uint32_t>;
-    using UniqueTable = std::set<std::uint64_t>;  // vertex slots
-
-    template <typename Filter>
-    void classifySuccessors(std::vector<std::pair<Vertex, int>> &results, const Vertex &v, std::uint32_t deviation,
-                            double errorRate, std::pair<std::int64_t, std::int64_t> ctgRange, bool canLeap, double leapMin,
-                            Filter filter) const;
-    template <typename ParentFilter>
-    NodeStatus walkStraight(const std::pair<Vertex, int> &start, std::vector<std::pair<Vertex, int>> &path, int deviation,
-                            double errorRate, std::pair<std::int64_t, std::int64_t> ctgRange, std::size_t hasSize,
-                            std::size_t splitSize, double splitMin, ParentFilter parentFilter, std::size_t limitation = 0) const;
-    template <typename ParentFilter>
-    TravelSequence graphTravel(const Vertex &start, int deviation, double errorRate,
-                               std::pair<std::int64_t, std::int64_t> ctgRange, std::size_t hasSize, std::size_t splitSize,
-                               double splitMin, ParentFilter parentFilter) const;
-    void successors(std::vector<std::pair<Vertex, int>> &out, const Vertex &v, std::uint32_t deviation, double errorRate) const;
-    std::int64_t appendSeq(TravelSequence &base, const TravelSequence &tail) const;
-    void filterSequence(TravelSequence &seq) const;
-
-    static bool existCtgPos(const PosTable &t, std::uint32_t pos) { return pos >= t.first && pos <= t.second; }
-    static void resetCtgPosTable(PosTable &t) {
-        t.first = 0xFFFFFFFFu;
-        t.second = 0;
-    }
-    static void insertCtgPos(PosTable &t, std::uint32_t pos) {
-        if (pos == 0) return;
-        t.first = std::min(t.first, pos);
-        t.second = std::max(t.second, pos);
-    }
-    void say(const std::string &s) const {
-        if (log_) *log_ += s;
-    }
-
     const HostGraph &g_;
     const SeqDb &contigs_;
     const SeqDb &refs_;
     const PositionMapper &ctgMapper_;
     const PositionMapper &refMapper_;
-    unsigned threadNum_;
-    std::string *log_;
 };
 
 }  // namespace pagh

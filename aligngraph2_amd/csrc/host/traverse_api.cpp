@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 
@@ -40,10 +43,31 @@ extern "C" {
 
 const char *pagh_last_error(void) { return g_err; }
 
-static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
-                        const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
-                        uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
-                        pagh_traverse_stats *stats, bool deviceWalk) {
+// storage kept between calls on one graph handle (one block after the other: releasing and re-faulting ~1 GB of host
+// arrays per block costs tens of milliseconds); dropped by pagh_release()
+namespace {
+struct HandleCache {
+    pagh::HostGraph graph;
+    std::vector<pagh::TravelSequence> travelled;
+};
+std::mutex g_cacheLock;
+std::map<const pag_graph *, std::unique_ptr<HandleCache>> g_cache;
+HandleCache &cacheOf(const pag_graph *g) {
+    std::lock_guard<std::mutex> l(g_cacheLock);
+    auto &slot = g_cache[g];
+    if (!slot) slot.reset(new HandleCache());
+    return *slot;
+}
+}  // namespace
+
+void pagh_release(pag_graph *g) {
+    std::lock_guard<std::mutex> l(g_cacheLock);
+    g_cache.erase(g);
+}
+
+int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
     if (!g || !ctgs || !refs || !ctg_orient || !out_dir) return PAG_EINVAL;
     try {
         const double t0 = nowMs();
@@ -51,66 +75,44 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
         pagh::SeqDb refDb = fromPacked(refs, ref_names, "ref", 1);
         pagh::PositionMapper ctgMapper(contigDb), refMapper(refDb);
         std::set<std::pair<std::string, bool>> ctgSet;
-        std::vector<int> orient(ctgs->n_seqs, -1);
-        for (std::uint64_t i = 0; i < ctgs->n_seqs; ++i)
-            if (ctg_orient[i] >= 0) {
-                ctgSet.emplace(contigDb.name(i), ctg_orient[i] != 0);
-                orient[i] = ctg_orient[i] != 0 ? 1 : 0;
-            }
-
-        // kept between calls (one block after the other on a handle): releasing and re-faulting ~1 GB of host arrays
-        // per block costs tens of milliseconds
-        static thread_local pagh::HostGraph graph;
-        static thread_local std::vector<pagh::TravelSequence> precomputed;
-        double t1;
-        pag_travel_stats tstAll{};
-        if (deviceWalk) {
-            pag_travel_params tp{};
-            tp.ref_threads = ref_threads;
-            tp.deviation = epsilon * 2;
-            tp.error_rate = 0.15;
-            tp.start_split = 0.90;
-            tp.min_len = min_len;
-            pag_travel_stats tst{};
-            int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
-            if (std::getenv("PAGRAPH_TIMING"))
-                std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
-                             tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
-                             (unsigned long long)tst.walk_steps, (unsigned long long)tst.classify_calls, (unsigned long long)tst.probes,
-                             (unsigned long long)tst.records);
-            if (rc != PAG_OK) {
-                setErr("pag_travel: %s", pag_last_error());
-                return rc;
-            }
-            tstAll = tst;
-            std::vector<std::pair<const pag_path_node *, std::uint64_t>> paths(ctgs->n_seqs);
-            for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c) {
-                std::uint64_t len = 0;
-                const pag_path_node *p = pag_travel_path(g, c, &len);
-                paths[c] = {p, p ? len : 0};
-            }
-            const double tg0 = nowMs();
-            pagh::buildPathGraph(paths, orient, k, graph, precomputed, host_threads);
-            t1 = nowMs();
-            if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
-        } else {
-            std::uint64_t nn = 0, np = 0, ne = 0;
-            int rc = pag_csr_sizes(g, &nn, &np, &ne);
-            if (rc != PAG_OK) return rc;
-            graph.resize(nn, np, ne);
-            pag_csr csr = graph.view();
-            rc = pag_export_csr(g, &csr);
-            if (rc != PAG_OK) {
-                setErr("pag_export_csr: %s", pag_last_error());
-                return rc;
-            }
-            graph.k = k;
-            t1 = nowMs();
+        for (std::uint64_t i = 0; i < ctgs->n_seqs; ++i) {
+            const int32_t o = ctg_orient[i];
+            if (o == PAG_ORIENT_FORWARD || o == PAG_ORIENT_BOTH) ctgSet.emplace(contigDb.name(i), true);
+            if (o == PAG_ORIENT_REVERSE || o == PAG_ORIENT_BOTH) ctgSet.emplace(contigDb.name(i), false);
         }
+        HandleCache &hc = cacheOf(g);
+        pag_travel_params tp{};
+        tp.ref_threads = ref_threads;
+        tp.deviation = epsilon * 2;
+        tp.error_rate = 0.15;
+        tp.start_split = 0.90;
+        tp.min_len = min_len;
+        pag_travel_stats tst{};
+        int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
+        if (std::getenv("PAGRAPH_TIMING"))
+            std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
+                         tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
+                         (unsigned long long)tst.walk_steps, (unsigned long long)tst.classify_calls, (unsigned long long)tst.probes,
+                         (unsigned long long)tst.records);
+        if (rc != PAG_OK) {
+            setErr("pag_travel: %s", pag_last_error());
+            return rc;
+        }
+        std::vector<std::pair<const pag_path_node *, std::uint64_t>> paths(2 * ctgs->n_seqs, {nullptr, 0});
+        for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c)
+            for (int rev = 0; rev < 2; ++rev) {
+                std::uint64_t len = 0;
+                const pag_path_node *p = pag_travel_path_oriented(g, c, rev == 0, &len);
+                if (p && len) paths[2 * c + rev] = {p, len};
+            }
+        const double tg0 = nowMs();
+        pagh::buildPathGraph(paths, k, hc.graph, hc.travelled, host_threads);
+        const double t1 = nowMs();
+        if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
 
         pagh::AssembleStats as;
-        pagh::assemble(out_dir, prefix ? prefix : "0_", graph, contigDb, refDb, ctgMapper, refMapper, ctgSet, epsilon * 2, 0.15,
-                       0.90, min_len, ref_threads, host_threads, &as, true, deviceWalk ? &precomputed : nullptr);
+        pagh::assemble(out_dir, prefix ? prefix : "0_", hc.graph, contigDb, refDb, ctgMapper, refMapper, ctgSet, epsilon * 2, 0.15,
+                       0.90, min_len, ref_threads, host_threads, &as, true, hc.travelled);
         const double t2 = nowMs();
         if (stats) {
             stats->n_contigs = as.nContigs;
@@ -122,33 +124,18 @@ static int traverseImpl(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const ch
             stats->ms_export = t1 - t0;
             stats->ms_traverse = t2 - t1;
             stats->ms_total = t2 - t0;
-            stats->ms_successors = tstAll.ms_compact;
-            stats->ms_walk = tstAll.ms_walk;
-            stats->walk_rounds = tstAll.rounds;
-            stats->walk_jobs = tstAll.jobs;
-            stats->walk_steps = tstAll.walk_steps;
-            stats->walk_classifications = tstAll.classify_calls;
+            stats->ms_successors = tst.ms_compact;
+            stats->ms_walk = tst.ms_walk;
+            stats->walk_rounds = tst.rounds;
+            stats->walk_jobs = tst.jobs;
+            stats->walk_steps = tst.walk_steps;
+            stats->walk_classifications = tst.classify_calls;
         }
         return PAG_OK;
     } catch (const std::exception &e) {
         setErr("pagh_traverse: %s", e.what());
         return PAG_EFAULT;
     }
-}
-
-int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
-                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
-                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
-    return traverseImpl(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, ref_threads, epsilon, min_len, out_dir, prefix,
-                        host_threads, stats, true);
-}
-
-int pagh_traverse_hostwalk(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
-                           const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
-                           uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
-                           pagh_traverse_stats *stats) {
-    return traverseImpl(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, ref_threads, epsilon, min_len, out_dir, prefix,
-                        host_threads, stats, false);
 }
 
 }  // extern "C"

@@ -210,13 +210,22 @@ typedef struct pag_travel_stats {
     uint64_t classify_calls, probes, records; /* successor evaluations, walkStraight calls, records read */
 } pag_travel_stats;
 
-/* ctgs: HOST memory (2-bit packed); orient[i]: 1 traverse forward, 0 reverse, -1 not selected.
+/* orientations in which a contig is traversed (config.txt lists (name, 1|0) pairs; the reference walks every pair of
+ * its std::set, so a contig listed with both orientations is walked twice: PAssembly.cpp:28-36) */
+#define PAG_ORIENT_NONE (-1)
+#define PAG_ORIENT_REVERSE 0
+#define PAG_ORIENT_FORWARD 1
+#define PAG_ORIENT_BOTH 2
+
+/* ctgs: HOST memory (2-bit packed); orient[i]: PAG_ORIENT_*.
  * ref_len[n_refs]: lengths of the reference sequences (their PositionMapper is needed for the repeat check).
- * After success, pag_travel_path(g, i, &len) returns contig i's path (library-owned, valid until the next
- * pag_travel / pag_process / pag_destroy on the handle). */
+ * After success, pag_travel_path_oriented(g, i, forward, &len) returns the path of contig i in that orientation
+ * (library-owned, valid until the next pag_travel / pag_process / pag_destroy on the handle; NULL / 0 if that
+ * orientation was not traversed); pag_travel_path(g, i, &len) = the forward path if there is one, else the reverse. */
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *params, pag_travel_stats *stats);
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);
+const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len);
 /* ---- kmer_counter on the device (replaces PAGraph/src/main/kmer_counter.cpp:19-96) ----------------
  * Counts every k-mer of the forward strand of every read (KmerHelper::kmer2Code, KmerHelper.cpp:7-25) in a dense 4^k
  * table, derives the minimum abundance by the reference's rule (the first occurring abundance a, ascending, with

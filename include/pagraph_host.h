@@ -28,7 +28,8 @@ typedef struct pagh_traverse_stats {
 } pagh_traverse_stats;
 
 /* ctgs / refs: HOST memory, 2-bit packed (pag_seqs).  names may be NULL ("ctg<i>" / "ref<i+1>").
- * ctg_orient[i]: 1 = traverse forward, 0 = traverse reverse, -1 = contig not selected (config.txt).
+ * ctg_orient[i]: PAG_ORIENT_FORWARD / _REVERSE / _BOTH / _NONE (config.txt; a contig listed with both orientations is
+ * traversed twice, PAssembly.cpp:28-36).
  * Writes <prefix><C>_<O>.txt/.fasta/.con/.help into out_dir exactly like the reference.
  * host_threads: worker threads for the per-contig loop (0 = hardware concurrency); results do not
  * depend on it.  ref_threads = the reference's -t (seed top-K = min(t, 8), quirk Q10). */
@@ -36,13 +37,8 @@ int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *co
                   const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads,
                   uint64_t epsilon, uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
                   pagh_traverse_stats *stats);
-/* Verification aid: the same outputs with the walk done on the HOST over an exported copy of the graph
- * (pag_export_csr + the host restatement of PAlgorithm).  Slow; used by tests to cross-check the device
- * walkers.  The product path is pagh_traverse. */
-int pagh_traverse_hostwalk(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
-                           const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient,
-                           uint32_t ref_threads, uint64_t epsilon, uint64_t min_len, const char *out_dir,
-                           const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats);
+/* Drops the host storage kept for a graph handle between pagh_traverse calls (call before pag_destroy). */
+void pagh_release(pag_graph *g);
 const char *pagh_last_error(void);
 
 #ifdef __cplusplus

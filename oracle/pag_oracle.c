@@ -39,6 +39,8 @@ struct pago_graph {
     uint64_t n_solid;
     uint64_t *codes; /* sorted unique = _kmerIndexArr (graph/PABruijnGraph.cpp:32-37) */
     node *nodes;     /* dense table */
+    uint32_t *dense; /* k <= 14: code -> dense index (0xFFFFFFFF = not solid), the reference's unordered_map as a direct
+                        table; only a faster searchDenseIndex, the answers are those of the binary search */
     /* optional record of the emitted streams, same encoding as the HIP library's debug hook */
     int dbg;
     uint32_t *dbg_tkey, *dbg_ekey;
@@ -109,6 +111,15 @@ pago_graph *pago_create(const uint64_t *codes, uint64_t n_codes, uint32_t k) {
         if (m == 0 || g->codes[m - 1] != g->codes[i]) g->codes[m++] = g->codes[i];
     g->n_solid = m;
     g->nodes = (node *)calloc(m ? m : 1, sizeof(node));
+    if (k <= 14 && m < 0xFFFFFFFFull) {
+        const uint64_t space = 1ull << (2 * k);
+        g->dense = (uint32_t *)malloc(space * sizeof(uint32_t));
+        if (g->dense) {
+            memset(g->dense, 0xFF, space * sizeof(uint32_t));
+            for (uint64_t i = 0; i < m; ++i)
+                if (g->codes[i] < space) g->dense[g->codes[i]] = (uint32_t)i;
+        }
+    }
     return g;
 }
 
@@ -145,6 +156,7 @@ void pago_destroy(pago_graph *g) {
     pago_reset(g);
     free(g->nodes);
     free(g->codes);
+    free(g->dense);
     free(g->dbg_tkey);
     free(g->dbg_tval);
     free(g->dbg_ekey);
@@ -156,6 +168,7 @@ uint64_t pago_solid_count(const pago_graph *g) { return g->n_solid; }
 
 /* graph/PABruijnGraph.cpp:98-104 searchDenseIndex (hash map there, binary search here) */
 static int64_t dense_index(const pago_graph *g, uint64_t code) {
+    if (g->dense && code < (1ull << (2 * g->k))) return g->dense[code] == 0xFFFFFFFFu ? -1 : (int64_t)g->dense[code];
     uint64_t lo = 0, hi = g->n_solid;
     while (lo < hi) {
         uint64_t mid = (lo + hi) / 2;
@@ -287,6 +300,11 @@ static int cmp_poscnt(const void *a, const void *b) {
  * position, and rebuilds both vectors with equal length */
 static void node_sort_positions(node *nd) {
     size_t n = nd->n_pos < nd->n_cnt ? nd->n_pos : nd->n_cnt;
+    if (n <= 1) { /* nothing to order; both vectors end with the common length all the same */
+        nd->n_pos = n;
+        nd->n_cnt = n;
+        return;
+    }
     poscnt *tmp = (poscnt *)malloc((n ? n : 1) * sizeof(poscnt));
     for (size_t i = 0; i < n; ++i) {
         tmp[i].pos = nd->pos[i];

@@ -49,6 +49,17 @@ CASES = {
                                   contigs=[(200, 6700, False), (7000, 13800, False)]), 16, 20, 3, False),
 }
 
+# multi-block cases: name -> (list of Spec kwargs (one per config block), threads, epsilon, cov, keep_inputs).
+# Blocks with different contig counts / path lengths / orientations after one another (storage of the previous block is
+# reused by the product), and a contig listed with BOTH orientations in the second block.
+MULTI_CASES = {
+    "two_blocks_both_orient_t16": ([dict(seed=107, ref_len=9000, n_reads=260, read_len=900, k=8,
+                                         contigs=[(150, 4200, False), (4450, 8850, True)]),
+                                    dict(seed=108, ref_len=12000, n_reads=330, read_len=1000, k=8,
+                                         contigs=[(200, 3600, False), (3800, 7600, False), (7850, 11800, True)],
+                                         both_orient=(1,))], 16, 10, 2, True),
+}
+
 
 def sha_dir(d):
     out = {}
@@ -69,15 +80,22 @@ def run(argv, threads):
 
 
 def main():
-    for name, (kw, threads, eps, cov, keep) in CASES.items():
+    only = set(sys.argv[1:])
+    all_cases = [(n, c, False) for n, c in CASES.items()] + [(n, c, True) for n, c in MULTI_CASES.items()]
+    for name, (kw, threads, eps, cov, keep), multi in all_cases:
+        if only and name not in only:
+            continue
         case = os.path.join(HERE, name)
         shutil.rmtree(case, ignore_errors=True)
         os.makedirs(case)
         with tempfile.TemporaryDirectory() as tmp:
             ind = os.path.join(tmp, "in")
-            synth.generate(synth.Spec(**kw), ind)
-            json.dump({"spec": kw, "threads": threads, "epsilon": eps, "cov": cov}, open(os.path.join(case, "spec.json"), "w"),
-                      indent=1)
+            if multi:
+                synth.generate_multi([synth.Spec(**b) for b in kw], ind)
+            else:
+                synth.generate(synth.Spec(**kw), ind)
+            json.dump({("blocks" if multi else "spec"): kw, "threads": threads, "epsilon": eps, "cov": cov},
+                      open(os.path.join(case, "spec.json"), "w"), indent=1)
             json.dump(sha_dir(ind), open(os.path.join(case, "inputs.sha256"), "w"), indent=1)
             if keep:
                 with tarfile.open(os.path.join(case, "inputs.tar.gz"), "w:gz", compresslevel=9) as tf:
@@ -94,11 +112,12 @@ def main():
             run([os.path.join(REF, "graph_dump"), "-t", str(threads), "-k", ind + "/kmer.bin", "-c", ind + "/ctg.fasta",
                  "-R", ind + "/ref.fasta", "-p", ind, "-a", ind + "/aln", "-o", gd, "--epsilon", str(eps), "-v", str(cov)],
                 threads)
-            with open(os.path.join(gd, "0.graph.txt"), "rb") as src, gzip.GzipFile(os.path.join(case, "graph.txt.gz"), "wb",
-                                                                                 compresslevel=9, mtime=0) as dst:
-                dst.write(src.read())
+            dumps = sorted((f for f in os.listdir(gd) if f.endswith(".graph.txt")), key=lambda f: int(f.split(".")[0]))
+            with gzip.GzipFile(os.path.join(case, "graph.txt.gz"), "wb", compresslevel=9, mtime=0) as dst:
+                for f in dumps:  # (one dump per config block, in block order)
+                    dst.write(open(os.path.join(gd, f), "rb").read())
         print(name, sorted(os.listdir(os.path.join(case, "out"))))
-    for what in ("kmer", "mapper", "predicate", "edit"):
+    for what in ("kmer", "mapper", "predicate", "edit") if not only else ():
         r = subprocess.run([os.path.join(REF, "func_golden"), what], capture_output=True, check=True)
         path = os.path.join(HERE, f"func_{what}.txt")
         if len(r.stdout) > 200_000:

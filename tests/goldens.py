@@ -29,12 +29,26 @@ def materialize_inputs(name, dest):
         with tarfile.open(tar) as tf:
             tf.extractall(dest)
     else:
-        synth.generate(synth.Spec(**load_spec(name)["spec"]), dest)
+        generate_case(load_spec(name), dest)
     want = json.load(open(os.path.join(case, "inputs.sha256")))
     for f, h in want.items():
         got = hashlib.sha256(open(os.path.join(dest, f), "rb").read()).hexdigest()
         assert got == h, f"golden input drift in {name}/{f}"
     return dest
+
+
+def generate_case(spec, dest):
+    """spec["spec"]: Spec kwargs of a single-block case; spec["blocks"]: list of Spec kwargs of a multi-block case"""
+    if "blocks" in spec:
+        def fix(kw):
+            kw = dict(kw)
+            if "contigs" in kw:
+                kw["contigs"] = [tuple(c) for c in kw["contigs"]]
+            if "both_orient" in kw:
+                kw["both_orient"] = tuple(kw["both_orient"])
+            return kw
+        return synth.generate_multi([synth.Spec(**fix(kw)) for kw in spec["blocks"]], dest)
+    return synth.generate(synth.Spec(**spec["spec"]), dest)
 
 
 def golden_graph(name):

@@ -10,6 +10,8 @@
 #include "config.hpp"
 #include "graph_input.hpp"
 #include "kmer_file.hpp"
+#include "position_mapper.hpp"
+#include <vector>
 
 namespace {
 struct Loaded {
@@ -61,5 +63,23 @@ const uint64_t *pagh_kmer_words(void *h, uint64_t *n, uint64_t *k) {
 uint64_t pagh_total_read_bases(void *h) { return static_cast<Loaded *>(h)->reads->totalBases(); }
 
 void pagh_free(void *h) { delete static_cast<Loaded *>(h); }
+
+// function-level hooks: the product's PositionMapper (csrc/host/position_mapper.hpp) over sequences of given lengths
+static pagh::PositionMapper mapperOf(const uint32_t *len, uint64_t n) {
+    pagh::SeqDb db;
+    for (uint64_t i = 0; i < n; ++i) {
+        std::vector<uint8_t> packed((len[i] + 3) / 4 + 16, 0);
+        db.addPacked("s" + std::to_string(i), packed.data(), len[i]);
+    }
+    db.finish();
+    return pagh::PositionMapper(db);
+}
+uint64_t pagt_mapper_d2s(const uint32_t *len, uint64_t n, int64_t idx, int64_t pos) { return mapperOf(len, n).dualToSingle(idx, pos); }
+void pagt_mapper_s2d(const uint32_t *len, uint64_t n, uint64_t single, int64_t *idx, int64_t *pos) {
+    auto d = mapperOf(len, n).singleToDual(single);
+    *idx = d.first;
+    *pos = d.second;
+}
+uint64_t pagt_mapper_extra(const uint32_t *len, uint64_t n) { return mapperOf(len, n).extraStart(); }
 
 }  // extern "C"

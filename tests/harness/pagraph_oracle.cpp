@@ -4,6 +4,7 @@
 // against the reference's golden outputs on a machine without a GPU.
 #include <stdexcept>
 
+#include "host_walk.hpp"
 #include "pag_oracle.h"
 #include "pagraph_driver.hpp"
 
@@ -24,6 +25,15 @@ public:
         out.resize(nn, np, ne);
         pag_csr csr = out.view();
         if (pago_export_csr(g_, &csr) != PAG_OK) throw std::runtime_error("pago_export_csr failed");
+    }
+
+    // the walk of the harness: host restatement of PAlgorithm over the exported graph
+    void travel(const TravelContext &ctx, const pag_travel_params &p, pagh::HostGraph &graph,
+                std::vector<pagh::TravelSequence> &travelled) override {
+        exportCsr(graph);
+        graph.k = ctx.k;
+        travelled = pagh::hostWalkAll(graph, ctx.contigs, ctx.refs, ctx.ctgMapper, ctx.refMapper, ctx.ctgSet, p.deviation,
+                                      p.error_rate, p.start_split, p.min_len, p.ref_threads, 0);
     }
 
 private:

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIP_LIB = os.path.join(ROOT, "aligngraph2_amd", "libpagraph_hip.so")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "libpag_oracle.so")
 TEST_LIB = os.path.join(ROOT, "tests", "harness", "bin", "libpagh_test.so")
+WALK_TEST_LIB = os.path.join(ROOT, "tests", "harness", "bin", "libpagh_walk_test.so")
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 
@@ -113,6 +114,17 @@ def test_lib():
         lib.pagh_free.restype = None
         _libs["test"] = lib
     return _libs["test"]
+
+
+def walk_test_lib():
+    """pagt_traverse_hostwalk: device graph exported, walk by the host restatement of the reference's PAlgorithm (test
+    infrastructure, tests/harness/host_walk.cpp); same argument list as pagh_traverse."""
+    if "walk" not in _libs:
+        hip_lib()  # (the HIP runtime has to come from torch, see hip_lib)
+        if not os.path.exists(WALK_TEST_LIB):
+            subprocess.run(["make", "-C", ROOT, WALK_TEST_LIB[len(ROOT) + 1:]], check=True, capture_output=True)
+        _libs["walk"] = C.CDLL(WALK_TEST_LIB)
+    return _libs["walk"]
 
 
 class LoadedInput:

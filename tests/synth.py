@@ -156,6 +156,12 @@ class Spec:
     extra_ctg_aln: bool = False  # add a second, overlapping contig->ref alignment (multi-entry bases)
     dup_read_aln: bool = False  # add lower-scoring duplicate read->ref alignments for some reads
     min_ctg_overlap: float = 0.35
+    # multi-block inputs (generate_multi): names of this block's reference / contigs, its config block number (prefix
+    # of the read / alignment files), and contigs listed in config.txt with BOTH orientations (indices into `contigs`)
+    ref_name: str = "ref1"
+    ctg_prefix: str = "ctg"
+    block: int = 0
+    both_orient: tuple = ()
 
 
 def _aln_record(qname, rname, strand, score, qb, qe, qsize, rb, re_, rsize, qrow, rrow):
@@ -207,11 +213,11 @@ def generate(spec: Spec, out_dir: str) -> dict:
     contigs = []
     for i, (lo, hi, rev) in enumerate(ctg_specs):
         seg = target[lo:hi]
-        contigs.append(Contig(f"ctg{i}", lo, hi, rev, revcomp(seg) if rev else seg.copy()))
+        contigs.append(Contig(f"{spec.ctg_prefix}{i}", lo, hi, rev, revcomp(seg) if rev else seg.copy()))
 
-    refs = [("ref1", ref)]
+    refs = [(spec.ref_name, ref)]
     for j in range(1, spec.n_refs):
-        refs.append((f"ref{j + 1}", random_seq(rng, max(1000, G // 4))))
+        refs.append((f"{spec.ref_name}_decoy{j + 1}" if spec.ref_name != "ref1" else f"ref{j + 1}", random_seq(rng, max(1000, G // 4))))
 
     def fasta(path, records):
         with open(path, "w") as f:
@@ -239,7 +245,7 @@ def generate(spec: Spec, out_dir: str) -> dict:
             else:
                 qb, qe = tl, clen - th
                 strand = "F"
-            f.write(_aln_record(c.name, "ref1", strand, "NULL", qb, qe, clen, rb, re_, G, q_row, r_row))
+            f.write(_aln_record(c.name, spec.ref_name, strand, "NULL", qb, qe, clen, rb, re_, G, q_row, r_row))
             if spec.extra_ctg_aln and clen > 2000:
                 # a second alignment of the contig's first third (same truth) -> multi-entry bases
                 sub_hi = clen // 3
@@ -250,13 +256,14 @@ def generate(spec: Spec, out_dir: str) -> dict:
                     qb2, qe2 = clen - (sub_hi - th2), clen - tl2
                 else:
                     qb2, qe2 = tl2, sub_hi - th2
-                f.write(_aln_record(c.name, "ref1", strand, "NULL", qb2, qe2, clen, rb2, re2, G, q2, rr2))
+                f.write(_aln_record(c.name, spec.ref_name, strand, "NULL", qb2, qe2, clen, rb2, re2, G, q2, rr2))
     del ident_t
 
     # reads
-    fq = open(os.path.join(out_dir, "0.new.fastq"), "w")
-    f_ctg = open(os.path.join(out_dir, "0.ctg.ref"), "w")
-    f_ref = open(os.path.join(out_dir, "0.ref.ref"), "w")
+    B = spec.block
+    fq = open(os.path.join(out_dir, f"{B}.new.fastq"), "w")
+    f_ctg = open(os.path.join(out_dir, f"{B}.ctg.ref"), "w")
+    f_ref = open(os.path.join(out_dir, f"{B}.ref.ref"), "w")
     all_codes = []
     n_bases = 0
     for rid in range(1, spec.n_reads + 1):
@@ -298,7 +305,7 @@ def generate(spec: Spec, out_dir: str) -> dict:
             fa, fb = q_lo + tl, q_hi - th  # fragment coordinates
             qb, qe = (n - fb, n - fa) if read_rev else (fa, fb)
             score = int((q_row == r_row).sum())
-            f_ref.write(_aln_record(rid, "ref1", "R" if read_rev else "F", score, qb, qe, n, rb, re_, G,
+            f_ref.write(_aln_record(rid, spec.ref_name, "R" if read_rev else "F", score, qb, qe, n, rb, re_, G,
                                     q_row, r_row))
             if spec.dup_read_aln and rid % 7 == 0 and len(q_row) > 400:
                 # a lower-scoring partial duplicate (first half of the columns, trimmed)
@@ -309,7 +316,7 @@ def generate(spec: Spec, out_dir: str) -> dict:
                 fb2 = fa + int((q2 != GAP).sum())
                 re2 = rb + int((r2 != GAP).sum())
                 qb2, qe2 = (n - fb2, n - fa) if read_rev else (fa, fb2)
-                f_ref.write(_aln_record(rid, "ref1", "R" if read_rev else "F", int((q2 == r2).sum()),
+                f_ref.write(_aln_record(rid, spec.ref_name, "R" if read_rev else "F", int((q2 == r2).sum()),
                                         qb2, qe2, n, rb, re2, G, q2, r2))
 
         # read -> contigs
@@ -345,8 +352,10 @@ def generate(spec: Spec, out_dir: str) -> dict:
     f_ref.close()
 
     with open(os.path.join(out_dir, "config.txt"), "w") as f:
-        f.write("ref1\n0.new.fastq\n0.ctg.ref\n0.ref.ref\n")
-        for c in contigs:
+        f.write(f"{spec.ref_name}\n{B}.new.fastq\n{B}.ctg.ref\n{B}.ref.ref\n")
+        for i, c in enumerate(contigs):
+            if i in tuple(spec.both_orient):  # listed twice: the reference traverses both (PAssembly.cpp:28-36), the graph
+                f.write(f"{c.name}\n{1 if c.reverse else 0}\n")  # is built with the LAST listed one (Aligner.cpp:311-320)
             f.write(f"{c.name}\n{0 if c.reverse else 1}\n")
         f.write("\n")
 
@@ -356,6 +365,35 @@ def generate(spec: Spec, out_dir: str) -> dict:
     write_kmer_file(os.path.join(out_dir, "kmer.bin"), spec.k, solid)
     return {"dir": out_dir, "n_bases": n_bases, "n_solid": int(len(solid)), "k": spec.k,
             "contigs": [c.name for c in contigs]}
+
+
+def generate_multi(specs, out_dir: str) -> dict:
+    """Several config blocks in ONE pagraph input directory: every block is generated on its own (own reference sequence,
+    own contigs, own read / alignment files <block>.*), the global files (ref.fasta, ctg.fasta, aln, kmer.bin, config.txt)
+    are the concatenation / union over the blocks.  specs: list of Spec (names and block numbers are assigned here)."""
+    import shutil
+    import tempfile
+    os.makedirs(out_dir, exist_ok=True)
+    glob = {"ref.fasta": [], "ctg.fasta": [], "aln": [], "config.txt": []}
+    solid = []
+    info = []
+    k = specs[0].k
+    for b, sp in enumerate(specs):
+        assert sp.k == k, "one solid-set file per run: all blocks share k"
+        kw = dict(sp.__dict__)
+        kw.update(ref_name=f"ref{b + 1}", ctg_prefix=f"b{b}ctg", block=b)
+        with tempfile.TemporaryDirectory() as tmp:
+            info.append(generate(Spec(**kw), tmp))
+            for f in glob:
+                glob[f].append(open(os.path.join(tmp, f), "rb").read())
+            words = np.fromfile(os.path.join(tmp, "kmer.bin"), dtype=np.uint64)
+            solid.append(words[1:])
+            for f in (f"{b}.new.fastq", f"{b}.ctg.ref", f"{b}.ref.ref"):
+                shutil.copy(os.path.join(tmp, f), os.path.join(out_dir, f))
+    for f, parts in glob.items():
+        open(os.path.join(out_dir, f), "wb").write(b"".join(parts))
+    write_kmer_file(os.path.join(out_dir, "kmer.bin"), k, np.unique(np.concatenate(solid)))
+    return {"dir": out_dir, "blocks": info, "k": k}
 
 
 def pagraph_argv(binary: str, in_dir: str, out_dir: str, threads: int = 1, epsilon: int = 10, cov: int = 2,

@@ -27,7 +27,9 @@ def _oracle_on(w_host):
 # (k, epsilon) corners of BASELINE configs[4]'s sweep (k in {12, 14, 16} x epsilon in {5, 10, 20}); k = 16 is outside the
 # reference PIPELINE's range (its kmer_counter stops at 15, quirk Q13) but inside pagraph's, which is what is compared
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,eps,seed,n_reads", [(12, 10, 5, 1500), (14, 20, 5, 3000), (16, 5, 5, 3000), (12, 5, 5, 1500), (16, 20, 5, 3000)])
+# all nine (k, epsilon) points of the sweep
+@pytest.mark.parametrize("k,eps,seed,n_reads", [(12, 10, 5, 1500), (14, 20, 5, 3000), (16, 5, 5, 3000), (12, 5, 5, 1500), (16, 20, 5, 3000),
+                                                (12, 20, 5, 1500), (14, 5, 5, 3000), (14, 10, 5, 3000), (16, 10, 5, 3000)])
 def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_reads, workdir):
     import torch
     import bench
@@ -68,8 +70,9 @@ def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_read
     hostw = str(workdir / "big_hostwalk")
     os.makedirs(hostw, exist_ok=True)
     ts2 = bench.TraverseStats()
-    host.pagh_traverse_hostwalk.argtypes = host.pagh_traverse.argtypes
-    rc = host.pagh_traverse_hostwalk(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads,
+    hostwalk = pagctl.walk_test_lib().pagt_traverse_hostwalk
+    hostwalk.argtypes = host.pagh_traverse.argtypes
+    rc = hostwalk(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads,
                                      sp.eps, 50, hostw.encode(), b"0_", 0, C.byref(ts2))
     assert rc == 0, host.pagh_last_error()
     # (2c) the walkers without speculation (every probe to its end before the choice): identical again

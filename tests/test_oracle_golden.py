@@ -32,7 +32,8 @@ def test_oracle_graph_equals_reference_graph(name, workdir):
     os.makedirs(out, exist_ok=True)
     subprocess.run([os.path.join(BIN, "oracle_graph_dump"), "-k", ind + "/kmer.bin", "-c", ind + "/ctg.fasta", "-R",
                     ind + "/ref.fasta", "-p", ind, "-a", ind + "/aln", "-o", out] + _flags(spec), check=True)
-    got = open(os.path.join(out, "0.graph.txt"), "rb").read()
+    dumps = sorted((f for f in os.listdir(out) if f.endswith(".graph.txt")), key=lambda f: int(f.split(".")[0]))
+    got = b"".join(open(os.path.join(out, f), "rb").read() for f in dumps)  # (one dump per config block)
     assert got == goldens.golden_graph(name)
 
 

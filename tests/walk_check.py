@@ -46,7 +46,8 @@ def main():
     ctg_seqs, k1 = bench.host_seqs(ctg_codes)
     ref_seqs, k2 = bench.host_seqs([ref_np])
     orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
-    host.pagh_traverse_hostwalk.argtypes = host.pagh_traverse.argtypes
+    hostwalk = pagctl.walk_test_lib().pagt_traverse_hostwalk
+    hostwalk.argtypes = host.pagh_traverse.argtypes
     res = {}
     for mode in (["host walk"] if not args.no_host else []) + ["exact", "speculative"]:
         out = tempfile.mkdtemp(prefix="walkcheck_", dir="/dev/shm")
@@ -54,7 +55,7 @@ def main():
         os.environ.pop("PAG_WALK_EXACT", None)
         if mode == "exact":
             os.environ["PAG_WALK_EXACT"] = "1"
-        fn = host.pagh_traverse_hostwalk if mode == "host walk" else host.pagh_traverse
+        fn = hostwalk if mode == "host walk" else host.pagh_traverse
         t0 = time.time()
         rc = fn(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads, sp.eps, 50,
                 out.encode(), b"0_", 0, C.byref(ts))
