@@ -479,6 +479,7 @@ struct WalkCtx {
     uint32_t n_classify, n_probe, n_records;  // work counters
     int overflow;
     int spec_fail;  // a zombie probe ended in a leap (or could not be continued): the job has to be redone without speculation
+    uint64_t max_probe;  // per lane: largest probe size (sum of steps) seen, wave maximum taken at the end of the job
 #ifdef PAG_WALK_PROF
     uint64_t pt[12];
     uint32_t pc[12];
@@ -850,6 +851,7 @@ __device__ __forceinline__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0
     }
     len = 1;
     uint32_t c = (uint32_t)(X.G.upos[v0] >> 32);
+    X.max_probe = now_size > X.max_probe ? now_size : X.max_probe;
     if (c != 0 && (c < X.C.ctg_left || c >= X.C.ctg_right)) {
         *out_len = len;
         return WS_LEAP;
@@ -909,6 +911,7 @@ __device__ __forceinline__ int walk_straight(WalkLds &L, WalkCtx &X, uint32_t v0
     }
     __syncthreads();  // the path written by lane 0 is read by all lanes afterwards
     *out_len = len;
+    X.max_probe = now_size > X.max_probe ? now_size : X.max_probe;
     return status;
 }
 
@@ -945,6 +948,7 @@ struct Slot {
     uint32_t wp0, wp1, wt0, wt1;  // the probe's coordinate window (start vertex included), the travel window of its iteration
     ProbeOut po;
     uint64_t tot;  // size walked so far INCLUDING the size of the sequence when the probe started (leaping needs the sum)
+    uint64_t base; // ... that size of the sequence (tot - base = the probe's own size)
     uint32_t pb_v, pb_s;
 };
 
@@ -1056,6 +1060,10 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
     }
     if (zombie && status == WS_LEAP) fail |= 1;
     X.spec_fail |= fail;
+    {
+        const uint64_t psz = tot - __shfl(S.base, src, 64);
+        X.max_probe = psz > X.max_probe ? psz : X.max_probe;
+    }
     if ((lane >> GL_SHIFT) == g) {
         S.status = status;
         S.zombie = 0;
@@ -1207,6 +1215,7 @@ __device__ __forceinline__ void slots_step(WalkLds &L, WalkCtx &X, Slot &S, uint
         const int st = !running ? S.status : n == 0u ? (int)WS_END : n > 1u ? (int)WS_BRANCH : full ? (int)WS_END : leap ? (int)WS_LEAP : S.status;
         const bool stopped = running && st >= 0;  // stopped in this step
         if (stopped && S.zombie && st == WS_LEAP) X.spec_fail |= 1;
+        if (stopped && S.tot - S.base > X.max_probe) X.max_probe = S.tot - S.base;
         if (stopped && !S.zombie && sub < (S.len & (GL - 1u))) {  // the entries still waiting in registers
             pv[S.len - (S.len & (GL - 1u)) + sub] = S.pb_v;
             ps[S.len - (S.len & (GL - 1u)) + sub] = S.pb_s;
@@ -1329,6 +1338,8 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
         S.alt = take ? rank : S.alt;
         S.cur_v = take ? v0 : S.cur_v;
         S.tot = take ? has_size + s0 : S.tot;
+        S.base = take ? has_size : S.base;
+        if (take && (uint64_t)s0 > X.max_probe) X.max_probe = s0;
         S.len = take ? 1u : S.len;
         S.off = take ? (go ? off0 : 0u) : S.off;
         S.cnt = take ? (go ? cnt0 : 0u) : S.cnt;
@@ -1509,6 +1520,7 @@ __device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp,
     res->n_out = po.n;
     res->ab = ab;
     res->size = now_size;
+    X.max_probe = now_size > X.max_probe ? now_size : X.max_probe;
     return !wide;
 }
 
@@ -1535,6 +1547,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.win_t1 = 0;
     X.overflow = 0;
     X.spec_fail = 0;
+    X.max_probe = 0;
+    if (J.mode & TRAV_MODE_SPEC) X.C.split_size = ~0ull;  // a piece walked ahead of its graphTravel: leaping is off
     X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.w_ab = X.n_fill = 0;
 #ifdef PAG_WALK_PROF
     for (int q = 0; q < 12; ++q) {
@@ -1569,8 +1583,22 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     const uint32_t start = G.newid[J.start];
     win_add(X.win_t0, X.win_t1, (uint32_t)(G.upos[start] >> 32));
 
+    // stitch bookkeeping (see TravJobOut): the lowest coordinate the probes of the running iteration visited
+    uint32_t it_low = 0xFFFFFFFFu, max_back = 0, max_chosen = 0, stopped = 0;
+    const bool resume = (J.mode & TRAV_MODE_RESUME) != 0;
     uint64_t plen = 0;
-    walk_straight(L, X, start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
+    // the chosen path of an iteration lives in the arena; the path a RESUME job continues lives in the sequence itself
+    const uint32_t *ch_v = J.arena_v, *ch_s = J.arena_s;
+    if (!resume) {
+        walk_straight(L, X, start, k, has_size + now_size, J.arena_v, J.arena_s, J.arena_cap, &plen);
+        it_low = X.win_p0;
+        const uint32_t c0 = (uint32_t)(G.upos[start] >> 32);
+        if (it_low < c0 && c0 - it_low > max_back) max_back = c0 - it_low;
+    } else {
+        ch_v = J.seq_v;
+        ch_s = J.seq_s;
+        plen = J.init_len;
+    }
     uint64_t ch_off = 0, ch_len = plen;  // chosen path inside the arena
     // what the probe that produced the chosen path already knows about it (fast == true): no need to read
     // the positions / offsets of its vertices back from memory
@@ -1585,6 +1613,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     S.wp0 = S.wp1 = S.wt0 = S.wt1 = 0;
     S.po = ProbeOut{0, 0, 0};
     S.tot = 0;
+    S.base = 0;
     S.pb_v = S.pb_s = 0;
     const bool speculate = J.exact == 0;
     const uint64_t slot_cap = J.arena_cap / PROBE_GROUPS;
@@ -1600,6 +1629,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             break;
         }
         uint32_t last, lc, l_off, l_cnt;
+        max_chosen = ch_len > max_chosen ? (uint32_t)(ch_len < 0xFFFFFFFFull ? ch_len : 0xFFFFFFFFull) : max_chosen;
         if (fast) {
             uint32_t n_outside_chk = 0;
             for (uint64_t i = lane; i < ch_len; i += 64) {
@@ -1638,8 +1668,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             uint64_t add = 0;
             uint32_t lo = 0xFFFFFFFFu, hi = 0, n_outside = 0;
             for (uint64_t i = lane; i < ch_len; i += 64) {
-                uint32_t v = J.arena_v[ch_off + i], st = J.arena_s[ch_off + i];
-                J.seq_v[seq_len + i] = v;
+                uint32_t v = ch_v[ch_off + i], st = ch_s[ch_off + i];
+                J.seq_v[seq_len + i] = v;  // (a RESUME job's first "chosen path" is the sequence itself: stored onto itself)
                 J.seq_s[seq_len + i] = st;
                 if (in_range(X, v)) {
                     stamp_store(&X.tbits[v - X.C.in_lo], X.epoch);
@@ -1684,8 +1714,15 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             lc = (uint32_t)(G.upos[last] >> 32);
             l_off = G.succ_off[last];
             l_cnt = G.succ_off[last + 1] - l_off;
+            ch_v = J.arena_v;
+            ch_s = J.arena_s;
         }
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
+        if (J.stop_pc != 0u && lc >= J.stop_pc) {  // (lc is on the own strand here) the piece ends at this iteration boundary
+            stopped = 1;
+            break;
+        }
+        it_low = lc != 0u ? lc : 0xFFFFFFFFu;
         PROF_END(X, 0, t_app);
         PROF_BEGIN(t_cls);
 
@@ -1780,6 +1817,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             if (ok_all) {
                 __syncthreads();
                 if (X.overflow) break;
+                for (uint32_t i = 0; i < m; ++i) it_low = R[i].w0 < it_low ? R[i].w0 : it_low;
+                if (it_low < lc && lc - it_low > max_back) max_back = lc - it_low;
                 int pick = -1;
                 for (uint32_t i = 0; i < m && pick < 0; ++i)
                     if (R[i].status == WS_LEAP) pick = (int)i;
@@ -1825,6 +1864,16 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             multi_ok = probe_slots(L, X, S, m, list_meta, has_size + now_size, J.arena_v, J.arena_s, slot_cap, speculate);
             if (multi_ok) {
                 if (X.overflow) break;
+                {   // lowest coordinate visited by the alternatives of this iteration (zombies: up to now; what they do later
+                    // can only matter through a leap, which fails the job)
+                    uint32_t lw = S.epoch == X.epoch ? S.wp0 : 0xFFFFFFFFu;
+                    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+                        const uint32_t o2 = (uint32_t)__shfl_xor((int)lw, d2, 64);
+                        lw = o2 < lw ? o2 : lw;
+                    }
+                    it_low = lw < it_low ? lw : it_low;
+                    if (it_low < lc && lc - it_low > max_back) max_back = lc - it_low;
+                }
                 PROF_BEGIN(t_choice);
                 // choice (PAlgorithm.tcc:268-296) among the alternatives of this iteration that have stopped (the
                 // zombies are taken not to leap): the first one that leaps; else the branching one with the most
@@ -1877,6 +1926,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 uint64_t l2 = 0;
                 int stt = walk_straight(L, X, L.br_v[i], L.br_s[i], has_size + now_size, J.arena_v + used, J.arena_s + used,
                                         J.arena_cap - used, &l2);
+                it_low = X.win_p0 < it_low ? X.win_p0 : it_low;
+                if (it_low < lc && lc - it_low > max_back) max_back = lc - it_low;
                 if (stt == WS_LEAP) {
                     if (first_leap < 0) {
                         first_leap = (int)i;
@@ -1923,6 +1974,11 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         for (int d2 = 32; d2 >= 1; d2 >>= 1) sf |= __shfl_xor(sf, d2, 64);
         X.spec_fail = sf;
     }
+    uint64_t mp_all = X.max_probe;
+    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+        const uint64_t o2 = __shfl_xor(mp_all, d2, 64);
+        mp_all = o2 > mp_all ? o2 : mp_all;
+    }
     if (lane == 0) {
         TravJobOut o;
         o.seq_len = seq_len;
@@ -1934,6 +1990,11 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         o.n_fill = X.n_fill | ((uint64_t)X.spec_fail << 32);
         o.n_out = X.n_out;
         o.n_main = n_main;
+        o.stopped = stopped;
+        o.max_back = max_back;
+        o.max_chosen = max_chosen;
+        o.reserved2 = 0;
+        o.max_probe = mp_all;
 #ifdef PAG_WALK_PROF
         for (int q = 0; q < 12; ++q) {
             o.prof_t[q] = X.pt[q];

@@ -75,7 +75,17 @@ struct TravJob {
     uint64_t *pset;
     uint32_t pmask;
     uint32_t exact;  // 1: no speculation (probes of a branch all run to their end before the choice), see Slot
+    // ---- segment-parallel walking (k5_travel_host.hip, "pieces"): a graphTravel is cut into pieces along the contig
+    // coordinate; every piece is one job.  mode bit 0 (TRAV_MODE_SPEC): a piece started ahead of the walk at a
+    // checkpoint vertex, walked as if leaping were impossible (split size = infinity); bit 1 (TRAV_MODE_RESUME): the
+    // walk continues a path whose first init_len vertices are already in seq_v / seq_s (the job marks them visited, sums
+    // their steps, then classifies the last one as graphTravel would at that point).  stop_pc != 0: the job ends at the
+    // first graphTravel iteration boundary whose last vertex has a contig coordinate >= stop_pc (on the own strand).
+    uint32_t mode;
+    uint32_t stop_pc;
+    uint64_t init_len;
 };
+enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2 };
 
 struct TravJobOut {
     uint64_t seq_len, seq_size;
@@ -83,6 +93,13 @@ struct TravJobOut {
     uint32_t last_ctg;
     int overflow;
     uint64_t n_fill, n_out, n_main;
+    // what a later stitch needs to know about this piece (see k5_travel_host.hip):
+    uint32_t stopped;       // 1: ended by the stop_pc rule (the graphTravel is not finished), 0: ended by itself
+    uint32_t max_back;      // max over iterations of (coordinate of the branch vertex - lowest coordinate any probe of that
+                            // iteration visited); the initial walkStraight counts as an iteration
+    uint32_t max_chosen;    // longest chosen path appended in one iteration (vertices)
+    uint32_t reserved2;
+    uint64_t max_probe;     // largest size (sum of steps) of any probe, zombies included
 #ifdef PAG_WALK_PROF
     uint64_t prof_t[12];  // cycles per section of the walk (development aid, make WALK_PROF=1)
     uint32_t prof_c[12];
