@@ -2030,8 +2030,9 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
     // Single-exit scalar loop: every value that steers it is wave-uniform by construction (readfirstlane).
     bool alive = true;
     while (alive) {
-        const uint32_t idx = __builtin_amdgcn_readfirstlane(atomicAdd(next, lane == 0 ? 1u : 0u));
-        int go = idx >= cap ? 2 : 0;  // 0 wait, 1 run, 2 leave
+        const uint32_t idx = __builtin_amdgcn_readfirstlane(atomicAdd(next, lane == 0 ? 1u : 0u));  // job number
+        const uint32_t slot = idx % cap;  // the job records form a ring (the host reuses a slot after it has consumed the job)
+        int go = 0;  // 0 wait, 1 run, 2 leave
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
         uint32_t naps = 1;
         while (go == 0) {
@@ -2040,7 +2041,7 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
             // acquire here would also invalidate the L2 on every poll; the acquire that matters follows below.)
             const uint64_t w = __hip_atomic_load((const uint64_t *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const uint32_t posted = __builtin_amdgcn_readfirstlane((uint32_t)w), bye = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
-            if (posted > idx) go = 1;
+            if ((int32_t)(posted - idx) > 0) go = 1;
             else if (bye != 0u || __builtin_amdgcn_s_memtime() - t0 > idle_timeout) go = 2;  // host done, or host gone
             else {
                 for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
@@ -2049,9 +2050,9 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
         }
         if (go == 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-            walk_job(L, G, jobs[idx].C, jobs[idx].J, &outs[idx], k);
+            walk_job(L, G, jobs[slot].C, jobs[slot].J, &outs[slot], k);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            __hip_atomic_store(&done[idx], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // same value from every lane
+            __hip_atomic_store(&done[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // same value from every lane
         } else {
             alive = false;
         }
@@ -2163,6 +2164,66 @@ __global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravConti
         n_out += tot;
     }
     if (lane == 0) o[0] = n_out;
+}
+
+// Checkpoints of the segment-parallel walk (k5_travel_host.hip): for every request (contig, contig offset) the most
+// abundant vertex that lies ON the contig strand (its k-mer is the contig's k-mer at offset i and its contig coordinate
+// is within `dev` of i, like a seed of searchPANode) for i in [left, right], and that is not in the contig's global
+// visited set.  Ties: the lowest offset, then position order.  One wave per request; out = (old vertex id, contig
+// coordinate, abundance) or (PAG_NONE, 0, 0).  Which vertex is picked has no influence on the results of the
+// traversal, only on how soon the walk that arrives from behind meets the piece started here.
+__global__ __launch_bounds__(64) void k_checkpoints(TravGraph G, const TravContig *__restrict__ ctgs, const TravSeedReq *__restrict__ reqs,
+                                                    uint32_t n_req, uint64_t dev, uint32_t *__restrict__ out) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n_req) return;
+    const TravSeedReq R = reqs[r];
+    const TravContig C = ctgs[R.ctg];
+    const uint32_t lane = lane_id();
+    const uint64_t right = R.right < (uint64_t)C.n_kmers ? R.right + 1 : C.n_kmers;  // exclusive
+    uint64_t best = 0;  // abundance << 40 | (0xFFFFF - (offset - left)) << 20 | (0xFFFFF - position rank): larger is better
+    uint32_t best_v = PAG_NONE, best_pc = 0;
+    for (uint64_t base = R.left; base < right; base += 64) {
+        const uint64_t i = base + lane;
+        const uint32_t node = i < right ? C.nodes[i] : PAG_NONE;
+        if (node == PAG_NONE) continue;
+        const uint32_t p0 = G.npos_off[node], p1 = G.npos_off[node + 1];
+        for (uint32_t p = p0; p < p1; ++p) {
+            const uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
+            if (pc < C.ctg_left || pc >= C.ctg_right) continue;
+            const uint64_t off = pc - C.ctg_left;
+            const uint64_t d = off > i ? off - i : i - off;
+            if (d > dev) continue;
+            const uint32_t u = G.newid[p];
+            if (C.gbits && u >= C.in_lo && u < C.in_hi && ((C.gbits[(u - C.in_lo) >> 5] >> ((u - C.in_lo) & 31u)) & 1u)) continue;
+            const uint64_t key = ((uint64_t)G.vcnt[p] << 40) | ((uint64_t)(0xFFFFFu - (uint32_t)((i - R.left) & 0xFFFFFu)) << 20) |
+                                 (uint64_t)(0xFFFFFu - ((p - p0) & 0xFFFFFu));
+            if (key > best) {
+                best = key;
+                best_v = p;
+                best_pc = pc;
+            }
+        }
+    }
+    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+        const uint64_t ob = __shfl_xor(best, d2, 64);
+        const uint32_t ov = (uint32_t)__shfl_xor((int)best_v, d2, 64), op = (uint32_t)__shfl_xor((int)best_pc, d2, 64);
+        if (ob > best) {
+            best = ob;
+            best_v = ov;
+            best_pc = op;
+        }
+    }
+    if (lane == 0) {
+        out[3 * r] = best_v;
+        out[3 * r + 1] = best_pc;
+        out[3 * r + 2] = (uint32_t)(best >> 40);
+    }
+}
+
+// contig coordinates of a path (new ids) for the host-side stitch
+__global__ void k_gather_pc(TravGraph G, const uint32_t *__restrict__ seq_v, uint64_t len, uint32_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = (uint32_t)(G.upos[seq_v[i]] >> 32);
 }
 
 // record a finished walk (new ids) in the contig's global visited structures
@@ -2278,6 +2339,13 @@ void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uin
 void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
                              uint32_t *out, uint32_t stride, hipStream_t s) {
     if (n) k_seed_window<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out, stride);
+}
+void trav_launch_checkpoints(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev, uint32_t *out,
+                             hipStream_t s) {
+    if (n) k_checkpoints<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out);
+}
+void trav_launch_gather_pc(TravGraph G, const uint32_t *seq_v, uint64_t len, uint32_t *out, hipStream_t s) {
+    if (len) k_gather_pc<<<dim3(grid_for(len)), dim3(256), 0, s>>>(G, seq_v, len, out);
 }
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s) {

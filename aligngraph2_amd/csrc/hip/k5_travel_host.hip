@@ -146,7 +146,7 @@ struct CtgState {
     uint32_t gcap = 0;
     uint32_t *gbits = nullptr;  // device: global visited bitmap over [inLo, inHi)
     uint32_t inLo = 0, inHi = 0;
-    uint64_t nOutside = 0;      // entries in gset
+    std::vector<uint32_t> outsideU;  // the entries of gset (new ids)
     uint64_t seqCap = 0;
     uint32_t parentCode = 0;  // k-mer of the last contig-consistent path vertex (seed ordering key)
     bool haveParent = false;
@@ -499,13 +499,33 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     uint64_t rounds = 0, jobs_total = 0, steps_total = 0, classify_total = 0, probe_total = 0, record_total = 0;
     double t_walk = 0;
 
-    // ---- the walks.  The contigs are independent state machines (walk the seeds of the round, choose, splice,
-    //      stop or re-seed); a persistent walker grid executes whatever jobs are posted, and this loop posts the
-    //      next round of a contig as soon as that contig's previous round is done.
+    // ---- the walks.
+    // The contigs are independent state machines (walk the seeds of the round, choose, splice, stop or re-seed); a persistent
+    // walker grid executes whatever jobs are posted, and this loop posts the next piece of work of a contig as soon as what it
+    // depends on is done.
+    //
+    // PIECES.  A graphTravel (PAlgorithm.tcc:172-298) is one chain of dependent steps: a quarter of a million path vertices on
+    // a 1 Mb contig, walked by one wavefront at ~1.7 us per step, while the other 255 compute units idle.  The chain is cut
+    // along the contig coordinate:
+    //   * the walk of a seed (a CHAIN) runs as a job with a stop coordinate: it ends at the first iteration boundary of
+    //     graphTravel whose last vertex lies at or beyond it;
+    //   * ahead of it, SEGMENT jobs start at checkpoint vertices (the most abundant on-contig vertex near x0 + j * seg_len)
+    //     and walk as if they were graphTravels of their own that can never leap (TRAV_MODE_SPEC), each up to the next
+    //     checkpoint plus an overlap.  They only exist up to the coordinate at which the real walk could start leaping;
+    //   * when a chain has reached the start of a finished segment and its tail COINCIDES, vertex for vertex, with a stretch of
+    //     that segment's path, the rest of the segment's path is adopted (see `try_merge` for the condition under which that is
+    //     exactly what the real walk would have done) and the chain goes on to the next segment;
+    //   * where no segment can be adopted the chain continues as a RESUME job (the path so far is handed to the walker, which
+    //     marks it visited and goes on exactly as graphTravel would), with the next checkpoint as its stop coordinate, or
+    //     without one from the zone where leaping becomes possible to the end of the walk.
+    // The result is vertex-for-vertex the path of the un-cut walk (PAG_WALK_PIECES=0 runs that, tests compare both with the
+    // host restatement of the reference), and the critical path of a contig shrinks from the whole contig to one segment
+    // plus the leaping zone.
     enum { CB_SEQV = 0, CB_SEQS, CB_ARV, CB_ARS, CB_TSET, CB_PSET, CB_STAMP, CB_TBITS, CB_N };
-    if (g->cpool.size() < (size_t)n_sel * CB_N) g->cpool.resize((size_t)n_sel * CB_N);
-    auto cbuf = [&](uint32_t i, int b) { return DevBuf(g, &g->cpool[(size_t)i * CB_N + b]); };
-    const uint32_t QCAP = 8192;
+    enum { GRP_ROUND = 0, GRP_CHAIN0 = 1, GRP_FINAL = 9, GROUPS = 10 };  // buffer groups per contig (chains: top-K <= 8)
+    if (g->cpool.size() < (size_t)n_sel * GROUPS * CB_N) g->cpool.resize((size_t)n_sel * GROUPS * CB_N);
+    auto cbuf = [&](uint32_t i, int grp, int b) { return DevBuf(g, &g->cpool[((size_t)i * GROUPS + grp) * CB_N + b]); };
+    const uint32_t QCAP = 65536;  // ring of job records: slot = job number mod QCAP
     const size_t q_need = 256 + (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
     if (g->wq_bytes < q_need) {
         if (g->wq_host) hipHostFree(g->wq_host);
@@ -526,17 +546,66 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     TravPosted *hjobs = (TravPosted *)((char *)g->wq_host + 256);
     TravJobOut *houts = (TravJobOut *)(hjobs + QCAP);
     uint32_t *hdone = (uint32_t *)(houts + QCAP);
-    std::memset(g->wq_host, 0, q_need);
+    std::memset(g->wq_host, 0, 256);
+    std::memset(hdone, 0, (size_t)QCAP * sizeof(uint32_t));
     PAG_HIP_TRY(hipMemsetAsync(g->wq_next, 0, 256, s));
     PAG_HIP_TRY(hipStreamSynchronize(s));
 
-    struct CRun {
-        uint32_t first = 0, n = 0, grow = 1, round = 0;
-        bool outstanding = false;
-        bool exact = false;  // a speculation of this contig's walk failed once: walk without from now on
+    const bool wdebug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+    const bool use_pieces = !(std::getenv("PAG_WALK_PIECES") && std::atoi(std::getenv("PAG_WALK_PIECES")) == 0);
+    const uint64_t seg_len_env = std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 0;
+    const uint64_t seg_ov = std::getenv("PAG_SEG_OVERLAP") ? std::strtoull(std::getenv("PAG_SEG_OVERLAP"), nullptr, 10) : 3000;
+    const bool force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
+
+    struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
+        std::vector<uint32_t> v, s, pc;
     };
-    std::vector<CRun> run(n_sel);
-    uint32_t n_posted = 0, n_outstanding = 0, respeculated = 0;
+    struct Seg {  // one segment job of a round
+        uint32_t x = 0;      // checkpoint coordinate
+        uint32_t stop = 0;   // its stop coordinate
+        uint32_t vid = 0;    // start vertex (old id)
+        bool done = false, usable = false, stopped = false;
+        Piece P;
+        std::vector<uint64_t> cum;       // cum[i] = sum of the steps of P[0 .. i]
+        std::vector<uint32_t> prefmax;   // max coordinate over P[0 .. i]
+        std::vector<uint32_t> sufmin;    // min coordinate over P[i ..]
+        std::unordered_map<uint32_t, uint32_t> index;  // vertex -> position in P (built on first use)
+        uint32_t max_back = 0, max_chosen = 0;
+        uint64_t max_probe = 0;
+    };
+    struct Chain {  // one graphTravel: (contig, seed) of the running round
+        Piece T;    // the validated path so far
+        std::vector<uint32_t> prefmax;
+        uint64_t size = 0;  // sum of its steps
+        bool final = false;
+        int waiting_seg = -1;  // the segment whose job this chain waits for
+        int next_seg = 0;
+        uint32_t grow = 1;
+        bool exact = false;
+        int job = -1;          // outstanding job number, -1: none
+        // the job that is outstanding (to repeat it with larger buffers / without speculation)
+        uint32_t job_mode = 0, job_stop = 0;
+    };
+    struct RoundState {
+        uint32_t round = 0;
+        bool active = false;
+        std::vector<Seg> segs;
+        std::vector<Chain> chains;
+        uint32_t zone_end = 0;  // coordinate from which the walk is no longer cut (0: no segments this round)
+        uint32_t live_jobs = 0;
+        uint64_t has_size = 0;
+    };
+    std::vector<RoundState> RS(n_sel);
+    struct JobRef {
+        uint32_t ctg = 0;
+        int kind = 0;  // 0: chain job (seed or resume), 1: segment
+        int idx = 0;   // chain / segment number
+        uint64_t init_len = 0;
+        bool live = false;
+    };
+    std::vector<JobRef> jref(QCAP);
+    uint32_t n_posted = 0, n_live = 0, respeculated = 0;
+    uint64_t n_adopted = 0, n_merge_fail = 0, n_seg_jobs = 0, n_resume_jobs = 0;
     bool walker_up = false;
     auto shutdown_walker = [&]() {
         if (!walker_up) return;
@@ -547,84 +616,320 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (void *q : g->deferred) hipFree(q);
         g->deferred.clear();
     };
-    auto out_cap = [&](const CtgState &cs, uint32_t grow) { return pow2_at_least((cs.seqCap / 4 + 4096) * grow); };
-    // buffers + job records of the next round of contig i (memsets go to stream s; the records become visible
-    // to the walker only by publish())
-    auto prepare = [&](uint32_t i) -> int {
+    struct JobPlan {
+        int kind, idx;
+        uint64_t cap;       // sequence capacity (vertices)
+        uint32_t start_vid; // old id of the start vertex
+        uint32_t mode, stop_pc;
+        const Piece *init;  // RESUME: the path so far
+        bool exact;
+    };
+    bool need_publish = false;
+    // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
+    // the walker only by publish())
+    auto post_batch = [&](uint32_t i, int grp, const std::vector<JobPlan> &plans) -> int {
+        if (plans.empty()) return PAG_OK;
         CtgState &cs = st[i];
-        CRun &R = run[i];
-        const size_t ns = cs.seeds.size();
-        if (n_posted + ns > QCAP) {
-            set_error("pag_travel: more than %u walk jobs", QCAP);
-            return PAG_ENOMEM;
-        }
+        RoundState &R = RS[i];
         const uint64_t PG = TRAV_PROBE_GROUPS;
-        const uint64_t cap = cs.seqCap * R.grow, oc = out_cap(cs, R.grow);
         // one travel epoch / probe stamp per strand vertex; padded to a multiple of four so that the walker's window
         // refills can use 16-byte loads
         const uint64_t span = ((uint64_t)(cs.inHi - cs.inLo) + 1 + 3) & ~3ull, tbw = span + 4;
-        DevBuf b_sv = cbuf(i, CB_SEQV), b_ss = cbuf(i, CB_SEQS), b_av = cbuf(i, CB_ARV), b_as = cbuf(i, CB_ARS), b_ts = cbuf(i, CB_TSET),
-               b_ps = cbuf(i, CB_PSET), b_st = cbuf(i, CB_STAMP), b_tb = cbuf(i, CB_TBITS);
+        const size_t nj = plans.size();
+        std::vector<uint64_t> o_seq(nj + 1, 0), o_oc(nj + 1, 0);
+        for (size_t j = 0; j < nj; ++j) {
+            o_seq[j + 1] = o_seq[j] + plans[j].cap;
+            o_oc[j + 1] = o_oc[j] + pow2_at_least(plans[j].cap / 4 + 4096);
+        }
+        DevBuf b_sv = cbuf(i, grp, CB_SEQV), b_ss = cbuf(i, grp, CB_SEQS), b_av = cbuf(i, grp, CB_ARV), b_as = cbuf(i, grp, CB_ARS),
+               b_ts = cbuf(i, grp, CB_TSET), b_ps = cbuf(i, grp, CB_PSET), b_st = cbuf(i, grp, CB_STAMP), b_tb = cbuf(i, grp, CB_TBITS);
         int r;
-        if ((r = b_sv.alloc(ns * cap * 4)) || (r = b_ss.alloc(ns * cap * 4)) || (r = b_av.alloc(ns * PG * cap * 4)) ||
-            (r = b_as.alloc(ns * PG * cap * 4)) || (r = b_ts.alloc(ns * oc * 8)) || (r = b_ps.alloc(ns * PG * oc * 8)) ||
-            (r = b_st.alloc(ns * PG * span * 4)) || (r = b_tb.alloc(ns * tbw * 4)))
+        if ((r = b_sv.alloc(o_seq[nj] * 4)) || (r = b_ss.alloc(o_seq[nj] * 4)) || (r = b_av.alloc(o_seq[nj] * PG * 4)) ||
+            (r = b_as.alloc(o_seq[nj] * PG * 4)) || (r = b_ts.alloc(o_oc[nj] * 8)) || (r = b_ps.alloc(o_oc[nj] * PG * 8)) ||
+            (r = b_st.alloc(nj * PG * span * 4)) || (r = b_tb.alloc(nj * tbw * 4)))
             return r;
-        PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, ns * oc * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, ns * PG * oc * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, ns * PG * span * 4, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, ns * tbw * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, o_oc[nj] * 8, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, o_oc[nj] * PG * 8, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, nj * PG * span * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, nj * tbw * 4, s));
         fill_contigs();
-        R.first = n_posted;
-        R.n = (uint32_t)ns;
-        R.outstanding = true;
-        R.round += 1;
-        for (size_t sd = 0; sd < ns; ++sd) {
-            TravPosted &P = hjobs[n_posted + sd];
+        for (size_t j = 0; j < nj; ++j) {
+            const JobPlan &pl = plans[j];
+            const uint32_t jn = n_posted, slot = jn % QCAP;
+            if (jref[slot].live) {
+                set_error("pag_travel: the job ring is full (%u jobs in flight)", QCAP);
+                return PAG_ENOMEM;
+            }
+            const uint64_t cap = pl.cap, oc = o_oc[j + 1] - o_oc[j];
+            TravPosted &P = hjobs[slot];
             TravJob &J = P.J;
             J.ctg = i;
-            J.start = cs.seeds[sd].vid;
-            J.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
-            J.seq_v = b_sv.as<uint32_t>() + sd * cap;
-            J.seq_s = b_ss.as<uint32_t>() + sd * cap;
+            J.start = pl.start_vid;
+            J.has_size = R.has_size;
+            J.seq_v = b_sv.as<uint32_t>() + o_seq[j];
+            J.seq_s = b_ss.as<uint32_t>() + o_seq[j];
             J.seq_cap = cap;
-            J.arena_v = b_av.as<uint32_t>() + sd * PG * cap;
-            J.arena_s = b_as.as<uint32_t>() + sd * PG * cap;
+            J.arena_v = b_av.as<uint32_t>() + o_seq[j] * PG;
+            J.arena_s = b_as.as<uint32_t>() + o_seq[j] * PG;
             J.arena_cap = PG * cap;
-            J.stamp = b_st.as<uint32_t>() + sd * PG * span;
+            J.stamp = b_st.as<uint32_t>() + j * PG * span;
             J.stamp_stride = (uint32_t)span;
-            J.tbits = b_tb.as<uint32_t>() + sd * tbw;
-            J.tset = b_ts.as<uint64_t>() + sd * oc;
+            J.tbits = b_tb.as<uint32_t>() + j * tbw;
+            J.tset = b_ts.as<uint64_t>() + o_oc[j];
             J.tmask = (uint32_t)oc - 1;
-            J.pset = b_ps.as<uint64_t>() + sd * PG * oc;
+            J.pset = b_ps.as<uint64_t>() + o_oc[j] * PG;
             J.pmask = (uint32_t)oc - 1;
-            J.exact = (R.exact || std::getenv("PAG_WALK_EXACT")) ? 1u : 0u;
+            J.exact = (pl.exact || force_exact) ? 1u : 0u;
+            J.mode = pl.mode;
+            J.stop_pc = pl.stop_pc;
+            J.init_len = 0;
+            if (pl.mode & TRAV_MODE_RESUME) {
+                const uint64_t n0 = pl.init->v.size();
+                if (n0 == 0 || n0 > cap) {
+                    set_error("pag_travel: resume job with a %llu-vertex path in a %llu-vertex buffer", (unsigned long long)n0, (unsigned long long)cap);
+                    return PAG_EFAULT;
+                }
+                J.init_len = n0;
+                PAG_HIP_TRY(hipMemcpyAsync(J.seq_v, pl.init->v.data(), n0 * 4, hipMemcpyHostToDevice, s));
+                PAG_HIP_TRY(hipMemcpyAsync(J.seq_s, pl.init->s.data(), n0 * 4, hipMemcpyHostToDevice, s));
+            }
             P.C = tc[i];
-            hdone[n_posted + sd] = 0;
+            hdone[slot] = 0;
+            jref[slot].ctg = i;
+            jref[slot].kind = pl.kind;
+            jref[slot].idx = pl.idx;
+            jref[slot].init_len = J.init_len;
+            jref[slot].live = true;
+            if (pl.kind == 0) {
+                Chain &ch = R.chains[(size_t)pl.idx];
+                ch.job = (int)jn;
+                ch.job_mode = pl.mode;
+                ch.job_stop = pl.stop_pc;
+                if (pl.mode & TRAV_MODE_RESUME) ++n_resume_jobs;
+            } else {
+                ++n_seg_jobs;
+            }
+            n_posted += 1;
+            n_live += 1;
+            R.live_jobs += 1;
+            jobs_total += 1;
         }
-        n_posted += (uint32_t)ns;
-        n_outstanding += 1;
-        rounds = std::max<uint64_t>(rounds, R.round);
-        jobs_total += ns;
+        need_publish = true;
         return PAG_OK;
     };
     auto publish = [&]() -> int {  // after the prepared buffers are ready on the device
-        if (std::getenv("PAG_WALK_DEBUG")) std::fprintf(stderr, "[walk] publish: waiting for stream\n");
+        if (!need_publish) return PAG_OK;
         PAG_HIP_TRY(hipStreamSynchronize(s));
-        if (std::getenv("PAG_WALK_DEBUG")) std::fprintf(stderr, "[walk] publish: posting %u\n", n_posted);
         __atomic_store_n(&hq->posted, n_posted, __ATOMIC_RELEASE);
+        need_publish = false;
         return PAG_OK;
     };
 
-    const bool wdebug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+    // ---- start of a round of contig i: its seeds are in cs.seeds.  Decides where the walk can be cut, finds the checkpoint
+    //      vertices and posts the seed jobs and the segment jobs.
+    DevBuf b_ckreq = buf(), b_ckout = buf();
+    auto start_round = [&](uint32_t i) -> int {
+        CtgState &cs = st[i];
+        RoundState &R = RS[i];
+        R.round += 1;
+        R.active = true;
+        R.segs.clear();
+        R.chains.assign(cs.seeds.size(), Chain{});
+        R.zone_end = 0;
+        R.live_jobs = 0;
+        R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
+        rounds = std::max<uint64_t>(rounds, R.round);
+        const uint64_t split = (uint64_t)(cs.len * startSplit);
+        // where leaping becomes possible: hasSize + nowSize >= split, nowSize = k + the steps walked.  The steps follow the
+        // contig coordinate closely but not exactly, so the zone is left with a margin; WHERE the walk is cut only decides how
+        // much of it runs in parallel, every adoption is checked against the true sizes (try_merge).
+        uint32_t x0 = 0xFFFFFFFFu;
+        for (auto &sd : cs.seeds) x0 = std::min(x0, sd.ctg);
+        std::vector<uint32_t> ck_x;
+        if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
+            const uint64_t H = (uint64_t)cs.varLen + k;
+            const uint64_t seg_len = seg_len_env ? seg_len_env : std::max<uint64_t>(30000, cs.len / 24);
+            const uint64_t safety = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 25 + 500;
+            if (split > H + safety + seg_len) {
+                const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H - safety), (uint64_t)cs.ctgRight - 1);
+                for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
+                if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
+            }
+        }
+        if (!ck_x.empty()) {
+            std::vector<TravSeedReq> reqs(ck_x.size());
+            for (size_t q = 0; q < ck_x.size(); ++q) {
+                const uint64_t off = ck_x[q] - cs.ctgLeft;
+                reqs[q].ctg = i;
+                reqs[q].pad = 0;
+                reqs[q].pos = off;
+                reqs[q].left = off - std::min<uint64_t>(off, 64);
+                reqs[q].right = off + 64;
+            }
+            int r;
+            if ((r = b_ckreq.alloc(reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(reqs.size() * 12))) return r;
+            if ((r = upload_contigs())) return r;
+            std::vector<uint32_t> out(reqs.size() * 3);
+            PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s));
+            trav_launch_checkpoints(G, b_tc.as<TravContig>(), b_ckreq.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation, b_ckout.as<uint32_t>(), s);
+            PAG_HIP_TRY(hipMemcpyAsync(out.data(), b_ckout.p, out.size() * 4, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            for (size_t q = 0; q < ck_x.size(); ++q) {
+                if (out[3 * q] == PAG_NONE) continue;
+                Seg sg;
+                sg.x = out[3 * q + 1];
+                sg.vid = out[3 * q];
+                if (!R.segs.empty() && sg.x <= R.segs.back().x) continue;
+                R.segs.push_back(std::move(sg));
+            }
+            for (size_t q = 0; q < R.segs.size(); ++q)
+                R.segs[q].stop = q + 1 < R.segs.size() ? (uint32_t)std::min<uint64_t>((uint64_t)R.segs[q + 1].x + seg_ov, R.zone_end) : R.zone_end;
+            if (R.segs.empty()) R.zone_end = 0;
+        }
+        std::vector<JobPlan> plans;
+        const uint64_t cap_full = cs.seqCap;
+        for (size_t sd = 0; sd < cs.seeds.size(); ++sd) {
+            const uint32_t stop = R.segs.empty() ? 0u : (uint32_t)std::min<uint64_t>((uint64_t)R.segs[0].x + seg_ov, R.zone_end);
+            plans.push_back(JobPlan{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false});
+        }
+        for (size_t q = 0; q < R.segs.size(); ++q) {
+            const uint64_t spanc = (uint64_t)R.segs[q].stop - R.segs[q].x;
+            const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
+            plans.push_back(JobPlan{1, (int)q, cap, R.segs[q].vid, (uint32_t)TRAV_MODE_SPEC, R.segs[q].stop, nullptr, false});
+        }
+        if (wdebug)
+            std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_begin, i,
+                         R.round, cs.seeds.size(), R.segs.size(), R.zone_end, cs.ctgLeft, cs.ctgRight);
+        return post_batch(i, GRP_ROUND, plans);
+    };
+
+    // continue chain c of contig i exactly: the path so far goes to the walker as a RESUME job
+    auto post_resume = [&](uint32_t i, int c, uint32_t stop) -> int {
+        CtgState &cs = st[i];
+        Chain &ch = RS[i].chains[(size_t)c];
+        const uint64_t cap = std::max<uint64_t>(cs.seqCap * ch.grow, ch.T.v.size() + cs.seqCap / 4 + 4096);
+        std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)TRAV_MODE_RESUME, stop, &ch.T, ch.exact}};
+        return post_batch(i, GRP_CHAIN0 + c, plans);
+    };
+
+    // Adoption of a finished segment by a chain whose last vertex lies inside it.
+    //
+    // Let T be the chain's path (its walk stands at an iteration boundary of graphTravel behind T's last vertex) and P the
+    // segment's path.  Condition: the last vertex of T is P[be], and going backwards T and P agree on t + 1 vertices
+    // (T[e - j] == P[be - j], same steps from the second common vertex on).  While leaping is impossible every successor a
+    // classification can accept follows the contig (isEdgeSimilar on the contig coordinate: PABruijnGraph.cpp:385-400 and the
+    // grade table of checkPosition :158-164 leave nothing else once Skip and leaps are excluded, PAlgorithm.tcc:69-86), so
+    //   (a) the coordinate windows (existCtgPos) never decide anything, and
+    //   (b) an accepted successor of a vertex at coordinate c lies at >= c + step - deviation > c - deviation.
+    // Hence the ONLY state through which the past acts on the continuation are the visited sets, and the two walks differ in
+    // them by D = vertices of T before the common stretch (+) vertices of P before it.  P's job reports how far below the
+    // coordinate of an iteration's branch vertex any of its probes went (max_back) and how long its chosen paths were
+    // (max_chosen): every candidate vertex the segment's walk examined in an iteration that contributes a vertex behind P[be]
+    // has a coordinate > min(coord of P[q ..]) - max_back - deviation with q = be + 1 - max_chosen.  If that bound exceeds
+    // the largest coordinate in D, no vertex of D was ever a candidate: the real walk, continuing from T, takes exactly P's
+    // decisions, and P[be + 1 ..] is its path — as far as leaping stays impossible for it, which is checked with the true
+    // sizes: hasSize + k + (steps of T) + (steps adopted) + (largest probe of the segment's walk) < split size.
+    // Returns 0: not adoptable (now), 1: adopted up to the end of P, 2: adopted up to where leaping may begin.
+    auto try_merge = [&](uint32_t i, Chain &ch, Seg &sg) -> int {
+        CtgState &cs = st[i];
+        RoundState &R = RS[i];
+        Piece &T = ch.T;
+        const Piece &P = sg.P;
+        if (!sg.usable || T.v.empty() || P.v.empty()) return 0;
+        if (sg.index.empty())
+            for (uint32_t x = 0; x < (uint32_t)P.v.size(); ++x) sg.index.emplace(P.v[x], x);
+        const size_t e = T.v.size() - 1;
+        auto it = sg.index.find(T.v[e]);
+        if (it == sg.index.end()) return 0;
+        const size_t be = it->second;
+        size_t t = 0;
+        while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
+        const size_t a = e - t, b = be - t;
+        if (t < 4) return 0;
+        const uint64_t dmax = std::max<uint64_t>(a ? ch.prefmax[a - 1] : 0u, b ? sg.prefmax[b - 1] : 0u);
+        const size_t q = be + 1 > sg.max_chosen ? be + 1 - sg.max_chosen : 0;
+        const uint64_t low = sg.sufmin[q];
+        if (low <= dmax + sg.max_back + deviation) return 0;
+        const uint64_t split = (uint64_t)(cs.len * startSplit);
+        const uint64_t base = R.has_size + k + ch.size + sg.max_probe + 1;
+        if (base >= split) return 0;  // (no room: the caller resumes exactly)
+        const uint64_t room = split - base;  // steps that may still be adopted
+        // largest index whose cumulated steps behind P[be] stay below `room`
+        size_t lo = be, hi = P.v.size() - 1;
+        while (lo < hi) {
+            const size_t mid = (lo + hi + 1) / 2;
+            if (sg.cum[mid] - sg.cum[be] < room) lo = mid;
+            else hi = mid - 1;
+        }
+        const size_t last = lo;
+        if (last == be && last + 1 < P.v.size()) return 0;
+        for (size_t x = be + 1; x <= last; ++x) {
+            T.v.push_back(P.v[x]);
+            T.s.push_back(P.s[x]);
+            T.pc.push_back(P.pc[x]);
+            ch.prefmax.push_back(std::max(ch.prefmax.back(), P.pc[x]));
+            ch.size += P.s[x];
+        }
+        n_adopted += last - be;
+        return last + 1 == P.v.size() ? 1 : 2;
+    };
+
+    // what a chain does after its job has ended at a stop coordinate or after a segment it waits for has finished
+    auto advance = [&](uint32_t i, int c) -> int {
+        RoundState &R = RS[i];
+        Chain &ch = R.chains[(size_t)c];
+        for (;;) {
+            if (ch.final || ch.job >= 0) return PAG_OK;
+            const uint32_t cT = ch.T.pc.empty() ? 0u : ch.T.pc.back();
+            // the last segment that starts at or before the chain's end
+            int j = -1;
+            for (int q = (int)R.segs.size() - 1; q >= ch.next_seg; --q)
+                if (R.segs[(size_t)q].x <= cT) {
+                    j = q;
+                    break;
+                }
+            if (j < 0 || cT == 0 || cT >= R.zone_end) {  // nothing ahead to adopt: walk to the end
+                ch.waiting_seg = -1;
+                if (j < 0 && cT != 0 && cT < R.zone_end && ch.next_seg < (int)R.segs.size()) {
+                    // the chain has not reached the next checkpoint yet (its job stopped short): go on to it
+                    const Seg &nx = R.segs[(size_t)ch.next_seg];
+                    return post_resume(i, c, (uint32_t)std::min<uint64_t>((uint64_t)nx.x + seg_ov, R.zone_end));
+                }
+                return post_resume(i, c, 0u);
+            }
+            Seg &sg = R.segs[(size_t)j];
+            if (!sg.done) {
+                ch.waiting_seg = j;
+                return PAG_OK;
+            }
+            ch.waiting_seg = -1;
+            const int m = try_merge(i, ch, sg);
+            ch.next_seg = j + 1;
+            if (m == 1) {
+                if (!sg.stopped) {  // the segment's walk ended by itself, and so does the real one
+                    ch.final = true;
+                    return PAG_OK;
+                }
+                continue;  // on to the next segment
+            }
+            if (m == 2) return post_resume(i, c, 0u);  // the leaping zone begins
+            ++n_merge_fail;
+            if (wdebug) std::fprintf(stderr, "[walk] contig %u chain %d: segment %d not adoptable, walking on exactly\n", i, c, j);
+            // (the next turn of the loop finds no started segment any more and resumes up to the next checkpoint, or to the end)
+        }
+    };
+
+    auto fail = [&](int rc2) {
+        shutdown_walker();
+        g->defer_free = false;
+        return rc2;
+    };
+
     const double tw0 = now_ms();
     g->defer_free = true;
     for (uint32_t i = 0; i < n_sel; ++i)
-        if (!st[i].done && (rc = prepare(i))) {
-            g->defer_free = false;
-            return rc;
-        }
-    if (n_outstanding) {
+        if (!st[i].done && (rc = start_round(i))) return fail(rc);
+    if (n_live) {
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
         trav_launch_walk_persistent(G, hjobs, houts, hdone, hq, g->wq_next, QCAP, k, (uint32_t)std::max(64, n_cu),
@@ -636,140 +941,219 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         if (wdebug) std::fprintf(stderr, "[walk] walker launched, %u jobs prepared\n", n_posted);
         walker_up = true;
-        if ((rc = publish())) {
-            shutdown_walker();
-            return rc;
-        }
+        if ((rc = publish())) return fail(rc);
     } else {
         g->defer_free = false;
     }
     lap("round prep");
 
+    DevBuf b_fetch = buf();
+    uint32_t scan_from = 0;  // every job number below it has been handled
     double t_progress = now_ms();
-    while (n_outstanding) {
-        // contigs whose jobs of the running round are all done
-        std::vector<uint32_t> batch;
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            if (!run[i].outstanding) continue;
-            bool all = true;
-            for (uint32_t j = 0; j < run[i].n && all; ++j) all = __atomic_load_n(&hdone[run[i].first + j], __ATOMIC_ACQUIRE) != 0;
-            if (all) batch.push_back(i);
+    while (n_live) {
+        // ---- jobs that have finished since the last look
+        std::vector<uint32_t> fin;
+        while (scan_from < n_posted && !jref[scan_from % QCAP].live) ++scan_from;
+        for (uint32_t jn = scan_from; jn < n_posted; ++jn) {
+            const uint32_t slot = jn % QCAP;
+            if (jref[slot].live && __atomic_load_n(&hdone[slot], __ATOMIC_ACQUIRE) != 0) fin.push_back(jn);
         }
-        if (batch.empty()) {
+        if (fin.empty()) {
             if (hipStreamQuery(g->walk_stream) == hipSuccess) {  // the grid is gone although jobs are outstanding
                 walker_up = false;
-                shutdown_walker();
-                g->defer_free = false;
                 set_error("pag_travel: the walker stopped with jobs outstanding");
-                return PAG_EFAULT;
-            }
-            if (wdebug && now_ms() - t_progress > 3000.0) {
-                static double last = 0;
-                if (now_ms() - last > 2000.0) {
-                    last = now_ms();
-                    uint32_t ticket = 0;
-                    hipMemcpyAsync(&ticket, g->wq_next, 4, hipMemcpyDeviceToHost, s);
-                    hipStreamSynchronize(s);
-                    std::fprintf(stderr, "[walk] waiting: posted %u tickets %u done0 %u done1 %u query %d stage0 %llu stage1 %llu\n", n_posted, ticket, hdone[0], hdone[1],
-                                 (int)hipStreamQuery(g->walk_stream), (unsigned long long)houts[0].n_main, (unsigned long long)houts[1].n_main);
-                }
+                return fail(PAG_EFAULT);
             }
             if (now_ms() - t_progress > 60000.0) {  // no job finished for a minute: give up instead of hanging
                 uint32_t ticket = 0;
                 hipMemcpyAsync(&ticket, g->wq_next, 4, hipMemcpyDeviceToHost, s);
                 hipStreamSynchronize(s);
-                shutdown_walker();
-                set_error("pag_travel: no walk job finished within 60 s (posted %u, tickets taken %u, contigs waiting %u)", n_posted, ticket,
-                          n_outstanding);
-                return PAG_EFAULT;
+                set_error("pag_travel: no walk job finished within 60 s (posted %u, tickets taken %u, jobs outstanding %u)", n_posted, ticket, n_live);
+                return fail(PAG_EFAULT);
             }
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            std::this_thread::sleep_for(std::chrono::microseconds(30));
             continue;
         }
         t_progress = now_ms();
-        if (wdebug)
-            for (uint32_t i : batch) {
-                uint64_t mx = 0;
-                for (uint32_t j = 0; j < run[i].n; ++j) mx = std::max<uint64_t>(mx, houts[run[i].first + j].n_classify);
-                std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u done (%u jobs, max classify %llu), %u still walking\n", now_ms() - tw0, i, run[i].round, run[i].n,
-                             (unsigned long long)mx, n_outstanding - (uint32_t)batch.size());
-#ifdef PAG_WALK_PROF
-                for (uint32_t j = 0; j < run[i].n; ++j) {
-                    const TravJobOut &o = houts[run[i].first + j];
-                    if (o.n_classify != mx) continue;
-                    static const char *nm[12] = {"append", "classify", "wait", "setup", "steps", "choice", "fill", "probe_wave", "st.window", "st.eval", "st.ballot", "st.update"};
-                    std::fprintf(stderr, "[prof] contig %u main %llu fills %llu:", i, (unsigned long long)o.n_main, (unsigned long long)(o.n_fill & 0xFFFFFFFFu));
-                    for (int q = 0; q < 12; ++q) std::fprintf(stderr, " %s %.1f Mcyc /%u", nm[q], o.prof_t[q] * 1e-6, o.prof_c[q]);
-                    std::fprintf(stderr, "\n");
-                    break;
-                }
-#endif
-            }
         lap("walk");
-        std::vector<uint32_t> redo, next_round;
-        for (uint32_t i : batch) {
-            run[i].outstanding = false;
-            n_outstanding -= 1;
-            bool overflow = false, misspec = false;
-            for (uint32_t j = 0; j < run[i].n; ++j) {
-                overflow |= (houts[run[i].first + j].overflow & 3) != 0;
-                misspec |= (houts[run[i].first + j].overflow & 4) != 0;
+
+        // ---- their paths: vertices, steps and contig coordinates to the host (one round trip for the batch)
+        struct Got {
+            uint32_t jn;
+            uint64_t from, len, off;  // the part of the sequence that is new, its place in the fetch buffer
+            std::vector<uint32_t> v, s, pc;
+        };
+        std::vector<Got> got(fin.size());
+        {
+            uint64_t tot = 0;
+            for (size_t x = 0; x < fin.size(); ++x) {
+                const uint32_t slot = fin[x] % QCAP;
+                const TravJobOut &o = houts[slot];
+                Got &G2 = got[x];
+                G2.jn = fin[x];
+                G2.from = std::min<uint64_t>(jref[slot].init_len, o.seq_len);
+                G2.len = o.seq_len - G2.from;
+                G2.off = tot;
+                tot += G2.len;
             }
-            if (misspec && !overflow) {  // a zombie probe leapt: the round is walked again, every probe to its end
-                if (wdebug)
-                    std::fprintf(stderr, "[walk] contig %u: speculation failed (cause bits %llu), exact walk\n", i,
-                                 (unsigned long long)(houts[run[i].first].n_fill >> 32));
-                run[i].exact = true;
-                run[i].round -= 1;
-                jobs_total -= run[i].n;
-                ++respeculated;
-                redo.push_back(i);
-                continue;
+            if ((rc = b_fetch.alloc(tot * 4 + 64))) return fail(rc);
+            for (Got &G2 : got) {
+                if (!G2.len) continue;
+                const TravJob &J = hjobs[G2.jn % QCAP].J;
+                G2.v.resize(G2.len);
+                G2.s.resize(G2.len);
+                G2.pc.resize(G2.len);
+                trav_launch_gather_pc(G, J.seq_v + G2.from, G2.len, b_fetch.as<uint32_t>() + G2.off, s);
+                hipMemcpyAsync(G2.v.data(), J.seq_v + G2.from, G2.len * 4, hipMemcpyDeviceToHost, s);
+                hipMemcpyAsync(G2.s.data(), J.seq_s + G2.from, G2.len * 4, hipMemcpyDeviceToHost, s);
+                hipMemcpyAsync(G2.pc.data(), b_fetch.as<uint32_t>() + G2.off, G2.len * 4, hipMemcpyDeviceToHost, s);
             }
-            if (overflow) {
-                if (misspec) run[i].exact = true;
-                if (run[i].grow >= 64) {
-                    shutdown_walker();
-                    set_error("pag_travel: walker buffers overflow even at 64x capacity");
-                    return PAG_ENOMEM;
-                }
-                run[i].grow *= 2;
-                run[i].round -= 1;
-                jobs_total -= run[i].n;
-                redo.push_back(i);
+            if (hipStreamSynchronize(s) != hipSuccess) {
+                set_error("pag_travel: stream failure while fetching paths");
+                return fail(PAG_EFAULT);
             }
         }
-        batch.erase(std::remove_if(batch.begin(), batch.end(), [&](uint32_t i) { return std::find(redo.begin(), redo.end(), i) != redo.end(); }),
-                    batch.end());
-        for (uint32_t i : batch)
-            for (uint32_t j = 0; j < run[i].n; ++j) {
-                const TravJobOut &o = houts[run[i].first + j];
-                steps_total += o.seq_len;
-                classify_total += o.n_classify;
-                probe_total += o.n_probe;
-                record_total += o.n_records;
-            }
+        lap("fetch");
 
-        // ---- per contig: choose (PAlgorithm.cpp:238-262); the chosen walks are gathered and committed on the
+        std::vector<uint32_t> touched;  // contigs with news
+        for (Got &G2 : got) {
+            const uint32_t slot = G2.jn % QCAP;
+            JobRef &jr = jref[slot];
+            const TravJobOut o = houts[slot];
+            const uint32_t i = jr.ctg;
+            RoundState &R = RS[i];
+            jr.live = false;
+            n_live -= 1;
+            R.live_jobs -= 1;
+            steps_total += o.seq_len - G2.from;
+            classify_total += o.n_classify;
+            probe_total += o.n_probe;
+            record_total += o.n_records;
+            const bool overflow = (o.overflow & 3) != 0, misspec = (o.overflow & 4) != 0;
+            touched.push_back(i);
+            if (jr.kind == 1) {  // a segment
+                Seg &sg = R.segs[(size_t)jr.idx];
+                sg.done = true;
+                sg.usable = !overflow && !misspec && G2.len >= 8;
+                sg.stopped = o.stopped != 0;
+                if (sg.usable) {
+                    sg.P.v.swap(G2.v);
+                    sg.P.s.swap(G2.s);
+                    sg.P.pc.swap(G2.pc);
+                    const size_t n = sg.P.v.size();
+                    sg.cum.resize(n);
+                    sg.prefmax.resize(n);
+                    sg.sufmin.resize(n);
+                    uint64_t c2 = 0;
+                    uint32_t mx = 0;
+                    for (size_t x = 0; x < n; ++x) {
+                        c2 += sg.P.s[x];
+                        sg.cum[x] = c2;
+                        mx = std::max(mx, sg.P.pc[x]);
+                        sg.prefmax[x] = mx;
+                        if (sg.P.pc[x] == 0) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
+                    }
+                    uint32_t mn = 0xFFFFFFFFu;
+                    for (size_t x = n; x-- > 0;) {
+                        mn = std::min(mn, sg.P.pc[x]);
+                        sg.sufmin[x] = mn;
+                    }
+                    sg.max_back = o.max_back;
+                    sg.max_chosen = std::max<uint32_t>(o.max_chosen, 1u);
+                    sg.max_probe = o.max_probe;
+                }
+                if (wdebug)
+                    std::fprintf(stderr, "[walk] t=%.1f ms contig %u segment %d done: %llu vertices, %s, %s (classify %llu, back %u, chosen %u, probe %llu)\n", now_ms() - tw0, i, jr.idx,
+                                 (unsigned long long)o.seq_len, sg.stopped ? "stopped" : "ended", sg.usable ? "usable" : "NOT usable", (unsigned long long)o.n_classify,
+                                 o.max_back, o.max_chosen, (unsigned long long)o.max_probe);
+                continue;
+            }
+            Chain &ch = R.chains[(size_t)jr.idx];
+            ch.job = -1;
+            if (misspec && !overflow) {  // a zombie probe leapt: the job is walked again, every probe to its end
+                ch.exact = true;
+                ++respeculated;
+                if (wdebug) std::fprintf(stderr, "[walk] contig %u chain %d: speculation failed, exact walk\n", i, jr.idx);
+            } else if (overflow) {
+                if (misspec) ch.exact = true;
+                if (ch.grow >= 64) {
+                    set_error("pag_travel: walker buffers overflow even at 64x capacity");
+                    return fail(PAG_ENOMEM);
+                }
+                ch.grow *= 2;
+            }
+            if (misspec || overflow) {  // the same job again (its path so far, if any, is still on the host)
+                std::vector<JobPlan> plans;
+                const uint64_t cap = std::max<uint64_t>(st[i].seqCap * ch.grow, ch.T.v.size() + st[i].seqCap / 4 + 4096);
+                plans.push_back(JobPlan{0, jr.idx, cap, st[i].seeds[(size_t)jr.idx].vid, ch.job_mode, ch.job_stop, (ch.job_mode & TRAV_MODE_RESUME) ? &ch.T : nullptr, ch.exact});
+                if ((rc = post_batch(i, GRP_CHAIN0 + jr.idx, plans))) return fail(rc);
+                continue;
+            }
+            // the new part of the path
+            for (size_t x = 0; x < G2.len; ++x) {
+                ch.T.v.push_back(G2.v[x]);
+                ch.T.s.push_back(G2.s[x]);
+                ch.T.pc.push_back(G2.pc[x]);
+                ch.prefmax.push_back(ch.prefmax.empty() ? G2.pc[x] : std::max(ch.prefmax.back(), G2.pc[x]));
+                ch.size += G2.s[x];
+            }
+            if (!o.stopped) ch.final = true;
+            if (wdebug)
+                std::fprintf(stderr, "[walk] t=%.1f ms contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0, i, jr.idx, (unsigned long long)G2.len,
+                             ch.T.v.size(), o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
+        }
+        std::sort(touched.begin(), touched.end());
+        touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+        for (uint32_t i : touched) {
+            RoundState &R = RS[i];
+            for (size_t c = 0; c < R.chains.size(); ++c) {
+                Chain &ch = R.chains[c];
+                if (ch.final || ch.job >= 0) continue;
+                if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
+                if ((rc = advance(i, (int)c))) return fail(rc);
+            }
+        }
+        lap("stitch");
+
+        // ---- contigs whose chains are all final: the round is decided
+        std::vector<uint32_t> batch;
+        for (uint32_t i : touched) {
+            RoundState &R = RS[i];
+            if (!R.active) continue;
+            bool all = true;
+            for (auto &ch : R.chains) all = all && ch.final;
+            // (segment jobs that are still walking use buffers the next round takes over: the round waits for them)
+            if (all && R.live_jobs == 0) batch.push_back(i);
+        }
+        if (batch.empty()) {
+            if ((rc = publish())) return fail(rc);
+            lap("round prep");
+            continue;
+        }
+
+        // ---- per contig: choose (PAlgorithm.cpp:238-262); the chosen walks are uploaded, gathered and committed on the
         //      device back to back, copied out, and spliced by a pool of host threads (contigs are independent)
         struct Pick {
             int chosen = -1;
             bool leap = false;
-            size_t j = 0, chooseCtgPos = 0, chooseRefPos = 0;
+            size_t chooseCtgPos = 0, chooseRefPos = 0;
             uint64_t off = 0, len = 0;
         };
         std::vector<Pick> picks(n_sel);
+        std::vector<uint32_t> next_round;
         {
             uint64_t tot = 0;
             for (uint32_t i : batch) {
                 CtgState &cs = st[i];
+                RoundState &R = RS[i];
+                R.active = false;
                 Pick &P = picks[i];
-                const size_t ns = cs.seeds.size(), j0 = run[i].first;
                 size_t maxLen = 0;
-                for (size_t sd = 0; sd < ns; ++sd) {
-                    const TravJobOut &o = houts[j0 + sd];
-                    size_t len = o.seq_size;
-                    P.leap = o.last_ctg != 0 && mapper.singleToDual(o.last_ctg).first != cs.chosenOne;
+                for (size_t sd = 0; sd < R.chains.size(); ++sd) {
+                    const Chain &ch = R.chains[sd];
+                    const size_t len = ch.size;
+                    const uint32_t last_ctg = ch.T.pc.empty() ? 0u : ch.T.pc.back();
+                    P.leap = last_ctg != 0 && mapper.singleToDual(last_ctg).first != cs.chosenOne;
                     if (!P.leap && sd > 0 && prm->min_len > 0 && len < prm->min_len) continue;
                     if (len > maxLen || P.leap) {
                         maxLen = len;
@@ -780,22 +1164,40 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                     }
                 }
                 if (P.chosen >= 0) {
-                    P.j = j0 + (size_t)P.chosen;
                     P.off = tot;
-                    P.len = houts[P.j].seq_len;
+                    P.len = R.chains[(size_t)P.chosen].T.v.size();
                     tot += P.len;
                 }
             }
-            if ((rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) {
-                shutdown_walker();
-                return rc;
-            }
+            if ((rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return fail(rc);
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
                 if (P.chosen < 0 || P.len == 0) continue;
-                trav_launch_gather_path(G, hjobs[P.j].J.seq_v, hjobs[P.j].J.seq_s, P.len, b_gather.as<pag_path_node>() + P.off, s);
+                const Chain &ch = RS[i].chains[(size_t)P.chosen];
+                {   // globalUniqueTable on the device: its hash set (vertices outside the strand's id range) grows as needed
+                    CtgState &cs = st[i];
+                    for (uint32_t u : ch.T.v)
+                        if (u < cs.inLo || u >= cs.inHi) cs.outsideU.push_back(u);
+                    if ((uint64_t)cs.outsideU.size() * 2 > cs.gcap) {
+                        uint32_t ncap = cs.gcap;
+                        while ((uint64_t)cs.outsideU.size() * 4 > ncap) ncap *= 2;
+                        DevBuf b_ng = cbuf(i, GRP_FINAL, CB_TSET), b_ou = cbuf(i, GRP_FINAL, CB_PSET);
+                        if ((rc = b_ng.alloc((size_t)ncap * 4)) || (rc = b_ou.alloc(cs.outsideU.size() * 4))) return fail(rc);
+                        hipMemsetAsync(b_ng.p, 0xFF, (size_t)ncap * 4, s);
+                        // (the vertices of this round's path are inserted by the commit below; the earlier ones here)
+                        hipMemcpyAsync(b_ou.p, cs.outsideU.data(), cs.outsideU.size() * 4, hipMemcpyHostToDevice, s);
+                        trav_launch_commit(b_ou.as<uint32_t>(), cs.outsideU.size(), 0u, 0u, nullptr, b_ng.as<uint32_t>(), ncap - 1, s);
+                        cs.gset = b_ng.as<uint32_t>();
+                        cs.gcap = ncap;
+                    }
+                }
+                DevBuf b_fv = cbuf(i, GRP_FINAL, CB_SEQV), b_fs = cbuf(i, GRP_FINAL, CB_SEQS);
+                if ((rc = b_fv.alloc(P.len * 4)) || (rc = b_fs.alloc(P.len * 4))) return fail(rc);
+                hipMemcpyAsync(b_fv.p, ch.T.v.data(), P.len * 4, hipMemcpyHostToDevice, s);
+                hipMemcpyAsync(b_fs.p, ch.T.s.data(), P.len * 4, hipMemcpyHostToDevice, s);
+                trav_launch_gather_path(G, b_fv.as<uint32_t>(), b_fs.as<uint32_t>(), P.len, b_gather.as<pag_path_node>() + P.off, s);
                 // record the walk in the device-side global visited set of this contig
-                trav_launch_commit(hjobs[P.j].J.seq_v, P.len, st[i].inLo, st[i].inHi, st[i].gbits, st[i].gset, st[i].gcap - 1, s);
+                trav_launch_commit(b_fv.as<uint32_t>(), P.len, st[i].inLo, st[i].inHi, st[i].gbits, st[i].gset, st[i].gcap - 1, s);
             }
         }
         std::vector<std::vector<pag_path_node>> longest(n_sel);
@@ -805,21 +1207,23 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             longest[i].resize(P.len);
             if (hipMemcpyAsync(longest[i].data(), b_gather.as<pag_path_node>() + P.off, P.len * sizeof(pag_path_node), hipMemcpyDeviceToHost,
                                s) != hipSuccess) {
-                shutdown_walker();
                 set_error("pag_travel: path copy failed");
-                return PAG_EFAULT;
+                return fail(PAG_EFAULT);
             }
         }
         if (hipStreamSynchronize(s) != hipSuccess) {
-            shutdown_walker();
             set_error("pag_travel: stream failure while gathering paths");
-            return PAG_EFAULT;
+            return fail(PAG_EFAULT);
+        }
+        for (uint32_t i : batch) {  // the host copies of the round are spent
+            RS[i].chains.clear();
+            RS[i].segs.clear();
         }
         lap("choose+gather");
 
         // splice + stop rules (PAlgorithm.cpp:264-360)
         std::vector<TravSeedReq> slot_req(n_sel);
-        std::vector<uint8_t> slot_has(n_sel, 0), slot_full(n_sel, 0);
+        std::vector<uint8_t> slot_has(n_sel, 0);
         auto splice = [&](uint32_t i) {
             CtgState &cs = st[i];
             const Pick &P = picks[i];
@@ -834,7 +1238,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 while (cs.refQ.size() > 4) cs.refQ.pop_front();
             }
             for (auto &n : longest[i]) {
-                if (cs.globalUnique.insert(n.vid) && (n.ctg < cs.ctgLeft || n.ctg >= cs.ctgRight)) ++cs.nOutside;
+                cs.globalUnique.insert(n.vid);
                 if (n.ctg != 0) {
                     cs.gwinLo = std::min(cs.gwinLo, n.ctg);
                     cs.gwinHi = std::max(cs.gwinHi, n.ctg);
@@ -870,10 +1274,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                     }
                 }
             }
-            if (cs.nOutside * 2 > cs.gcap) {
-                slot_full[i] = 1;
-                return;
-            }
             TravSeedReq r{};
             r.ctg = i;
             r.pos = lastCtgPos;
@@ -898,47 +1298,44 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         std::vector<TravSeedReq> reqs;
         std::vector<uint32_t> req_cs;
-        for (uint32_t i : batch) {
-            if (slot_full[i]) {
-                shutdown_walker();
-                set_error("pag_travel: global visited set of contig %u is full", st[i].ci);
-                return PAG_ENOMEM;
-            }
+        for (uint32_t i : batch)
             if (slot_has[i]) {
                 reqs.push_back(slot_req[i]);
                 req_cs.push_back(i);
             }
-        }
         lap("splice");
 
         // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
         if (!reqs.empty()) {
-            const uint32_t WSTRIDE = 16384;
-            if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc((uint64_t)reqs.size() * WSTRIDE * 4))) {
-                shutdown_walker();
-                return rc;
-            }
-            std::vector<uint32_t> wb((size_t)reqs.size() * WSTRIDE);
-            hipError_t he = hipMemcpyAsync(b_req.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s);
-            trav_launch_seed_window(G, b_tc.as<TravContig>(), b_req.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation,
-                                    b_seedout.as<uint32_t>(), WSTRIDE, s);
-            if (he == hipSuccess) he = hipMemcpyAsync(wb.data(), b_seedout.p, wb.size() * 4, hipMemcpyDeviceToHost, s);
-            if (he == hipSuccess) he = hipStreamSynchronize(s);
-            if (he != hipSuccess) {
-                shutdown_walker();
-                set_error("pag_travel: seed search failed: %s", hipGetErrorString(he));
-                return PAG_EFAULT;
+            uint32_t WSTRIDE = 16384;
+            std::vector<uint32_t> wb;
+            for (;;) {  // (a window with more candidates than the stride is searched again with a larger one)
+                if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc((uint64_t)reqs.size() * WSTRIDE * 4))) return fail(rc);
+                wb.resize((size_t)reqs.size() * WSTRIDE);
+                hipError_t he = hipMemcpyAsync(b_req.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s);
+                if (upload_contigs() != PAG_OK) he = hipErrorUnknown;
+                trav_launch_seed_window(G, b_tc.as<TravContig>(), b_req.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation,
+                                        b_seedout.as<uint32_t>(), WSTRIDE, s);
+                if (he == hipSuccess) he = hipMemcpyAsync(wb.data(), b_seedout.p, wb.size() * 4, hipMemcpyDeviceToHost, s);
+                if (he == hipSuccess) he = hipStreamSynchronize(s);
+                if (he != hipSuccess) {
+                    set_error("pag_travel: seed search failed: %s", hipGetErrorString(he));
+                    return fail(PAG_EFAULT);
+                }
+                uint32_t most = 0;
+                for (size_t q = 0; q < reqs.size(); ++q) most = std::max(most, wb[q * WSTRIDE]);
+                if (most <= WSTRIDE - 1) break;
+                if (most > (1u << 28)) {
+                    set_error("pag_travel: seed window with %u candidates", most);
+                    return fail(PAG_ENOMEM);
+                }
+                WSTRIDE = (uint32_t)pow2_at_least((uint64_t)most + 2);
             }
             std::vector<uint32_t> vids;
             std::vector<size_t> cnt(reqs.size());
             for (size_t q = 0; q < reqs.size(); ++q) {
                 CtgState &cs = st[req_cs[q]];
                 const uint32_t *o = &wb[q * WSTRIDE];
-                if (o[0] > WSTRIDE - 1) {
-                    shutdown_walker();
-                    set_error("pag_travel: seed window overflow (%u candidates)", o[0]);
-                    return PAG_ENOMEM;
-                }
                 std::unordered_set<uint32_t> seen;
                 size_t n = 0;
                 for (uint32_t x = 0; x < o[0]; ++x) {
@@ -951,10 +1348,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 cnt[q] = n;
             }
             std::vector<pag_path_node> attrs;
-            if ((rc = fetch_vertices(vids, attrs))) {
-                shutdown_walker();
-                return rc;
-            }
+            if ((rc = fetch_vertices(vids, attrs))) return fail(rc);
             size_t at = 0;
             for (size_t q = 0; q < reqs.size(); ++q) {
                 CtgState &cs = st[req_cs[q]];
@@ -978,22 +1372,19 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
         }
         lap("reseed");
-        // ---- post the follow-up rounds (and the repeats with larger buffers)
-        for (uint32_t i : redo) next_round.push_back(i);
+        // ---- post the follow-up rounds
         for (uint32_t i : next_round)
-            if ((rc = prepare(i))) {
-                shutdown_walker();
-                return rc;
-            }
-        if (!next_round.empty() && (rc = publish())) {
-            shutdown_walker();
-            return rc;
-        }
+            if ((rc = start_round(i))) return fail(rc);
+        if ((rc = publish())) return fail(rc);
         lap("round prep");
     }
     shutdown_walker();
     t_walk = now_ms() - tw0;
     lap("walk");
+    if (timing || wdebug)
+        std::fprintf(stderr, "[timing] pieces: %llu segment jobs, %llu resume jobs, %llu vertices adopted, %llu segments not adoptable\n", (unsigned long long)n_seg_jobs,
+                     (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted, (unsigned long long)n_merge_fail);
+
 
     // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)
     for (auto &cs : st) {

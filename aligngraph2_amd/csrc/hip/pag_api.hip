@@ -223,37 +223,26 @@ int pag_reset(pag_graph *g) {
     return PAG_OK;
 }
 
-int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats) {
-    if (!g || !in) return PAG_EINVAL;
-    if (in->outer_sample < 1 || in->outer_sample > 7) {
-        set_error("outer_sample must be 1..7");
-        return PAG_EINVAL;
-    }
-    if (in->reads.n_seqs >= 0x3FFFFFFFull) {
-        set_error("too many reads for one launch");
-        return PAG_EINVAL;
-    }
-    const bool timing = getenv("PAGRAPH_TIMING") != nullptr;
-    const auto wall0 = std::chrono::steady_clock::now();
-    auto wall_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(); };
-    PAG_HIP_TRY(hipSetDevice(g->device));
-    free_graph_results(g);
+}  // extern "C"
+
+namespace {
+
+struct Extracted {  // what extract_stage leaves in the pool slots 30 / 31 / 34 / 35
+    uint64_t T = 0, E = 0, T1 = 0, E1 = 0;  // tuples / edges emitted, of which by pass 1 (they come first)
+};
+
+// Both extraction passes of PositionProcessor::process (PositionProcessor.cpp:86-124) for the reads at emission positions
+// [emit_lo, emit_hi) of in->emit_order: coverage filter, column index, K1 count, scans, K1 emit.  The streams
+// [pass-1 tuples] ++ [pass-2 tuples] (and edges likewise) are left in canonical order in slots 30/31 (tuples) and 34/35 (edges).
+int extract_stage(pag_graph *g, const pag_build_input *in, uint64_t emit_lo, uint64_t emit_hi, Extracted *out, hipEvent_t ev_begin,
+                  hipEvent_t ev_end) {
     hipStream_t s = g->stream;
     const bool dev = in->on_device != 0;
-    const uint32_t n_reads = (uint32_t)in->reads.n_seqs;
-    const uint64_t n_jobs = 4ull * n_reads;  // 2 passes x 2 strands
+    const uint32_t n_reads_all = (uint32_t)in->reads.n_seqs;
+    const uint32_t n_reads = (uint32_t)(emit_hi - emit_lo);  // reads of this call
+    const uint64_t n_jobs = 4ull * n_reads;                   // 2 passes x 2 strands
     int rc;
-
-    hipEvent_t ev[8];
-    for (auto &e : ev) PAG_HIP_TRY(hipEventCreate(&e));
-    struct EvGuard {
-        hipEvent_t *e;
-        ~EvGuard() {
-            for (int i = 0; i < 8; ++i) hipEventDestroy(e[i]);
-        }
-    } ev_guard{ev};
-    PAG_HIP_TRY(hipEventRecord(ev[0], s));
-    const double w_ev0 = wall_ms();
+    if (ev_begin) PAG_HIP_TRY(hipEventRecord(ev_begin, s));
 
     // ---- inputs -> device
     DevBuf b_roff(g, 0), b_rlen(g, 1), b_packed(g, 2), b_order(g, 3), b_aln1(g, 4), b_q1(g, 5), b_d1(g, 6), b_aln2(g, 7), b_q2(g, 8), b_d2(g, 9), b_ctg(g, 10), b_eoff(g, 11), b_ent(g, 12), b_ref(g, 13);
@@ -264,20 +253,21 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     const uint64_t *d_q1, *d_q2;
     const pag_ctg *d_ctg;
     const pag_ref *d_ref;
-    if ((rc = stage(in->reads.byte_off, n_reads, dev, b_roff, &d_roff, s))) return rc;
-    if ((rc = stage(in->reads.len, n_reads, dev, b_rlen, &d_rlen, s))) return rc;
+    if ((rc = stage(in->reads.byte_off, n_reads_all, dev, b_roff, &d_roff, s))) return rc;
+    if ((rc = stage(in->reads.len, n_reads_all, dev, b_rlen, &d_rlen, s))) return rc;
     if ((rc = stage(in->reads.packed, in->reads.packed_bytes, dev, b_packed, &d_packed, s))) return rc;
-    if ((rc = stage(in->emit_order, n_reads, dev, b_order, &d_order, s))) return rc;
+    if ((rc = stage(in->emit_order, n_reads_all, dev, b_order, &d_order, s))) return rc;
     if ((rc = stage(in->read_to_ctg.aln, in->read_to_ctg.n_aln, dev, b_aln1, &d_aln1, s))) return rc;
-    if ((rc = stage(in->read_to_ctg.query_off, (uint64_t)n_reads + 1, dev, b_q1, &d_q1, s))) return rc;
+    if ((rc = stage(in->read_to_ctg.query_off, (uint64_t)n_reads_all + 1, dev, b_q1, &d_q1, s))) return rc;
     if ((rc = stage(in->read_to_ctg.diff, in->read_to_ctg.n_diff_words, dev, b_d1, &d_d1, s))) return rc;
     if ((rc = stage(in->read_to_ref.aln, in->read_to_ref.n_aln, dev, b_aln2, &d_aln2, s))) return rc;
-    if ((rc = stage(in->read_to_ref.query_off, (uint64_t)n_reads + 1, dev, b_q2, &d_q2, s))) return rc;
+    if ((rc = stage(in->read_to_ref.query_off, (uint64_t)n_reads_all + 1, dev, b_q2, &d_q2, s))) return rc;
     if ((rc = stage(in->read_to_ref.diff, in->read_to_ref.n_diff_words, dev, b_d2, &d_d2, s))) return rc;
     if ((rc = stage(in->ctgs, in->n_ctgs, dev, b_ctg, &d_ctg, s))) return rc;
     if ((rc = stage(in->ctg_ent_off, in->n_ctg_ent_off, dev, b_eoff, &d_eoff, s))) return rc;
     if ((rc = stage(in->ctg_ent, in->n_ctg_ent, dev, b_ent, &d_ent, s))) return rc;
     if ((rc = stage(in->refs, in->n_refs, dev, b_ref, &d_ref, s))) return rc;
+    d_order += emit_lo;
 
     // the reference table is tiny and needed on the host for scratch sizing
     std::vector<pag_ref> refs_host((size_t)in->n_refs);
@@ -286,7 +276,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         else std::memcpy(refs_host.data(), in->refs, in->n_refs * sizeof(pag_ref));
     }
 
-    // ---- coverage filter of pass 2
+    // ---- coverage filter of pass 2 (over ALL read->reference alignments, whichever reads this call extracts)
     const uint64_t n_aln1 = in->read_to_ctg.n_aln, n_aln2 = in->read_to_ref.n_aln;
     DevBuf b_covok(g, 14), b_covtmp(g, 15);
     if ((rc = b_covok.alloc(n_aln2 + 16))) return rc;
@@ -310,13 +300,18 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         const pag_aln *al = pass == 0 ? d_aln1 : d_aln2;
         uint64_t na = pass == 0 ? n_aln1 : n_aln2;
         DevBuf &off = pass == 0 ? b_cio1 : b_cio2;
-        DevBuf &ci = pass == 0 ? b_ci1 : b_ci2;
         if (na) {
             chunk_counts<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s>>>(al, na, b_cc.as<uint32_t>());
             if ((rc = scan_u32_to_u64(b_cc.as<uint32_t>(), off.as<uint64_t>(), na, d_tot + pass, b_scan.p, s))) return rc;
             PAG_HIP_TRY(hipMemcpyAsync(&n_ci[pass], d_tot + pass, 8, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
         }
+    }
+    PAG_HIP_TRY(hipStreamSynchronize(s));  // (one round trip for both sizes)
+    for (int pass = 0; pass < 2; ++pass) {
+        const pag_aln *al = pass == 0 ? d_aln1 : d_aln2;
+        uint64_t na = pass == 0 ? n_aln1 : n_aln2;
+        DevBuf &off = pass == 0 ? b_cio1 : b_cio2;
+        DevBuf &ci = pass == 0 ? b_ci1 : b_ci2;
         if ((rc = ci.alloc((n_ci[pass] + 1) * sizeof(uint2)))) return rc;
         if ((rc = launch_colidx(al, na, pass == 0 ? d_d1 : d_d2, off.as<uint64_t>(), ci.as<uint2>(), s))) return rc;
     }
@@ -380,16 +375,11 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     }
 
     // ---- K1 emit
-    DevBuf b_tk0(g, 30), b_tv0(g, 31), b_tk1(g, 32), b_tv1(g, 33), b_ek0(g, 34), b_ev0(g, 35), b_ek1(g, 36), b_ev1(g, 37);
-    // the second value buffer of each stream doubles as u64[n] + u32[n] scratch for long segments
+    DevBuf b_tk0(g, 30), b_tv0(g, 31), b_ek0(g, 34), b_ev0(g, 35);
     if ((rc = b_tk0.alloc((T + 1) * 4))) return rc;
     if ((rc = b_tv0.alloc((T + 1) * 8))) return rc;
-    if ((rc = b_tk1.alloc((T + 1) * 4))) return rc;
-    if ((rc = b_tv1.alloc((T + 1) * 12))) return rc;
     if ((rc = b_ek0.alloc((E + 1) * 4))) return rc;
     if ((rc = b_ev0.alloc((E + 1) * 8))) return rc;
-    if ((rc = b_ek1.alloc((E + 1) * 4))) return rc;
-    if ((rc = b_ev1.alloc((E + 1) * 12))) return rc;
     for (int pass = 0; pass < 2; ++pass) {
         ExtractArgs &a = xa[pass];
         a.tuple_off = b_toff.as<uint64_t>();
@@ -400,24 +390,31 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
         a.eval = b_ev0.as<uint64_t>();
         if ((rc = launch_extract(a, true, s))) return rc;
     }
-    PAG_HIP_TRY(hipEventRecord(ev[1], s));
+    if (ev_end) PAG_HIP_TRY(hipEventRecord(ev_end, s));
+    out->T = T;
+    out->E = E;
+    out->T1 = T1;
+    out->E1 = E1;
+    return PAG_OK;
+}
 
-    const char *keep = std::getenv("PAG_DEBUG_KEEP_STREAMS");
-    g->dbg_tkey.clear();
-    g->dbg_tval.clear();
-    g->dbg_ekey.clear();
-    g->dbg_eval.clear();
-    if (keep && keep[0] == '1') {
-        g->dbg_tkey.resize((size_t)T);
-        g->dbg_tval.resize((size_t)T);
-        g->dbg_ekey.resize((size_t)E);
-        g->dbg_eval.resize((size_t)E);
-        PAG_HIP_TRY(hipStreamSynchronize(s));
-        if (T) PAG_HIP_TRY(hipMemcpy(g->dbg_tkey.data(), b_tk0.p, T * 4, hipMemcpyDeviceToHost));
-        if (T) PAG_HIP_TRY(hipMemcpy(g->dbg_tval.data(), b_tv0.p, T * 8, hipMemcpyDeviceToHost));
-        if (E) PAG_HIP_TRY(hipMemcpy(g->dbg_ekey.data(), b_ek0.p, E * 4, hipMemcpyDeviceToHost));
-        if (E) PAG_HIP_TRY(hipMemcpy(g->dbg_eval.data(), b_ev0.p, E * 8, hipMemcpyDeviceToHost));
-    }
+// mergeEdge / mergeKmerPosition / sortKmerPosition for both passes at once (see the head of this file) over the streams in
+// slots 30/31 (tuples: T records, the first T1 from pass 1) and 34/35 (edges): K2 sorts, K3, K4; leaves the finished graph
+// in the handle.  The reference's count lines are additive over k-mers, so a handle that owns only a k-mer range of the
+// graph reports its share of each line.
+int build_stage(pag_graph *g, uint32_t eps, const Extracted &x, pag_build_stats *st_out, hipEvent_t *ev /*[4]: sort begin, sort end, cluster end, edges end*/) {
+    hipStream_t s = g->stream;
+    const uint64_t T = x.T, E = x.E, T1 = x.T1, E1 = x.E1;
+    int rc;
+    DevBuf b_tk0(g, 30), b_tv0(g, 31), b_tk1(g, 32), b_tv1(g, 33), b_ek0(g, 34), b_ev0(g, 35), b_ek1(g, 36), b_ev1(g, 37);
+    // (the first buffers were filled by the caller; alloc() only hands their pointers back)
+    if ((rc = b_tk0.alloc((T + 1) * 4)) || (rc = b_tv0.alloc((T + 1) * 8)) || (rc = b_ek0.alloc((E + 1) * 4)) || (rc = b_ev0.alloc((E + 1) * 8))) return rc;
+    // the second value buffer of each stream doubles as u64[n] + u32[n] scratch for long segments
+    if ((rc = b_tk1.alloc((T + 1) * 4))) return rc;
+    if ((rc = b_tv1.alloc((T + 1) * 12))) return rc;
+    if ((rc = b_ek1.alloc((E + 1) * 4))) return rc;
+    if ((rc = b_ev1.alloc((E + 1) * 12))) return rc;
+    PAG_HIP_TRY(hipEventRecord(ev[0], s));
 
     // ---- K2 sorts
     DevBuf b_sorttmp(g, 38);
@@ -430,7 +427,7 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     if ((rc = sort_pairs(b_ek0.as<uint32_t>(), b_ev0.as<uint64_t>(), b_ek1.as<uint32_t>(), b_ev1.as<uint64_t>(), E,
                          2 * (int)g->k, b_sorttmp.p, &e_in0, s, &ms_scatter_e, nullptr)))
         return rc;
-    PAG_HIP_TRY(hipEventRecord(ev[2], s));
+    PAG_HIP_TRY(hipEventRecord(ev[1], s));
     // make the sorted data live in the (k0, v0)-sized buffers, the spare (v1: 12 B/record) is scratch
     DevBuf *tk = t_in0 ? &b_tk0 : &b_tk1, *tv = t_in0 ? &b_tv0 : &b_tv1;
     DevBuf *ek = e_in0 ? &b_ek0 : &b_ek1, *evb = e_in0 ? &b_ev0 : &b_ev1;
@@ -456,28 +453,26 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     if ((rc = b_eseg.alloc((E + 1) * 4))) return rc;
     if ((rc = b_long.alloc((std::max(T, E) / 32 + 2) * 8))) return rc;
     if ((rc = b_lcnt.alloc(64))) return rc;
-    if ((rc = b_ctr.alloc(64))) return rc;
-    ClusterOut co{b_tseg.as<uint32_t>(), b_tcnt.as<uint16_t>(), b_ctr.as<uint64_t>()};
-    if ((rc = launch_cluster(tk->as<uint32_t>(), tv->as<uint64_t>(), t_scratch, T, in->eps, co, b_long.as<uint64_t>(),
+    if ((rc = b_ctr.alloc(128))) return rc;
+    uint64_t *ctr_dev = b_ctr.as<uint64_t>();  // [0..3] cluster counters, [4..7] edge counters
+    ClusterOut co{b_tseg.as<uint32_t>(), b_tcnt.as<uint16_t>(), ctr_dev};
+    if ((rc = launch_cluster(tk->as<uint32_t>(), tv->as<uint64_t>(), t_scratch, T, eps, co, b_long.as<uint64_t>(),
                              b_lcnt.as<uint32_t>(), s)))
         return rc;
-    uint64_t ctr_t[4] = {0, 0, 0, 0}, ctr_e[4] = {0, 0, 0, 0};
-    PAG_HIP_TRY(hipMemcpyAsync(ctr_t, b_ctr.p, 32, hipMemcpyDeviceToHost, s));
-    PAG_HIP_TRY(hipEventRecord(ev[3], s));
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-    EdgeOut eo{b_eseg.as<uint32_t>(), b_ctr.as<uint64_t>()};
+    PAG_HIP_TRY(hipEventRecord(ev[2], s));
+    EdgeOut eo{b_eseg.as<uint32_t>(), ctr_dev + 4};
     if ((rc = launch_edges(ek->as<uint32_t>(), evb->as<uint64_t>(), e_scratch, E, eo, b_long.as<uint64_t>(),
                            b_lcnt.as<uint32_t>(), s)))
         return rc;
-    PAG_HIP_TRY(hipMemcpyAsync(ctr_e, b_ctr.p, 32, hipMemcpyDeviceToHost, s));
-    PAG_HIP_TRY(hipEventRecord(ev[4], s));
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-    const double w_ev4 = wall_ms();
+    uint64_t ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PAG_HIP_TRY(hipMemcpyAsync(ctr, b_ctr.p, 64, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipEventRecord(ev[3], s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));  // (the only host round trip of the stage)
 
     // ---- the reference's count lines (PositionProcessor.cpp:126-142)
     pag_build_stats st{};
     const uint64_t T2 = T - T1, E2 = E - E1;
-    const uint64_t L_ctg = ctr_t[0], L_all = ctr_t[1], U_all = ctr_e[0], U_1 = ctr_e[1];
+    const uint64_t L_ctg = ctr[0], L_all = ctr[1], U_all = ctr[4], U_1 = ctr[5];
     st.n_tuples[0] = T1;
     st.n_tuples[1] = T2;
     st.n_edges[0] = E1;
@@ -488,23 +483,16 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     st.merge_edge[1] = U_1 + E2 - U_all;
     st.total_pos[1] = L_ctg + T2;
     st.merge_pos[1] = L_ctg + T2 - L_all;
-    st.n_nodes = ctr_t[2];
+    st.n_nodes = ctr[2];
     st.n_pos = L_all;
     st.n_uniq_edges = U_all;
     float ms = 0.f;
     hipEventElapsedTime(&ms, ev[0], ev[1]);
-    st.ms_extract = ms;
-    hipEventElapsedTime(&ms, ev[1], ev[2]);
     st.ms_sort = ms;
-    hipEventElapsedTime(&ms, ev[2], ev[3]);
+    hipEventElapsedTime(&ms, ev[1], ev[2]);
     st.ms_cluster = ms;
-    hipEventElapsedTime(&ms, ev[3], ev[4]);
+    hipEventElapsedTime(&ms, ev[2], ev[3]);
     st.ms_edges = ms;
-    hipEventElapsedTime(&ms, ev[0], ev[4]);
-    st.ms_total = ms;
-    if (timing)
-        fprintf(stderr, "[timing] pag_process wall: %.1f ms before the first event, %.1f ms first..last event (device %.1f ms), now %.1f ms\n", w_ev0,
-                w_ev4 - w_ev0, (double)ms, wall_ms());
     st.ms_sort_kernel = ms_scatter_t;
     st.sort_records = T;
     (void)passes;
@@ -520,6 +508,79 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     g->ekey = ek->as<uint32_t>();
     g->eval = evb->as<uint64_t>();
     g->eseg = b_eseg.as<uint32_t>();
+    g->stats = st;
+    *st_out = st;
+    return PAG_OK;
+}
+
+struct EventSet {
+    hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int create() {
+        for (auto &x : e) PAG_HIP_TRY(hipEventCreate(&x));
+        return PAG_OK;
+    }
+    ~EventSet() {
+        for (auto x : e)
+            if (x) hipEventDestroy(x);
+    }
+};
+
+void keep_debug_streams(pag_graph *g, uint64_t T, uint64_t E) {
+    const char *keep = std::getenv("PAG_DEBUG_KEEP_STREAMS");
+    g->dbg_tkey.clear();
+    g->dbg_tval.clear();
+    g->dbg_ekey.clear();
+    g->dbg_eval.clear();
+    if (!(keep && keep[0] == '1')) return;
+    g->dbg_tkey.resize((size_t)T);
+    g->dbg_tval.resize((size_t)T);
+    g->dbg_ekey.resize((size_t)E);
+    g->dbg_eval.resize((size_t)E);
+    hipStreamSynchronize(g->stream);
+    if (T) hipMemcpy(g->dbg_tkey.data(), g->pool[30].p, T * 4, hipMemcpyDeviceToHost);
+    if (T) hipMemcpy(g->dbg_tval.data(), g->pool[31].p, T * 8, hipMemcpyDeviceToHost);
+    if (E) hipMemcpy(g->dbg_ekey.data(), g->pool[34].p, E * 4, hipMemcpyDeviceToHost);
+    if (E) hipMemcpy(g->dbg_eval.data(), g->pool[35].p, E * 8, hipMemcpyDeviceToHost);
+}
+
+int check_process_args(const pag_graph *g, const pag_build_input *in) {
+    if (!g || !in) return PAG_EINVAL;
+    if (in->outer_sample < 1 || in->outer_sample > 7) {
+        set_error("outer_sample must be 1..7");
+        return PAG_EINVAL;
+    }
+    if (in->reads.n_seqs >= 0x3FFFFFFFull) {
+        set_error("too many reads for one launch");
+        return PAG_EINVAL;
+    }
+    return PAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats) {
+    int rc = check_process_args(g, in);
+    if (rc != PAG_OK) return rc;
+    const bool timing = getenv("PAGRAPH_TIMING") != nullptr;
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto wall_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(); };
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    free_graph_results(g);
+    EventSet ev;
+    if ((rc = ev.create())) return rc;
+    Extracted x;
+    if ((rc = extract_stage(g, in, 0, in->reads.n_seqs, &x, ev.e[0], ev.e[1]))) return rc;
+    keep_debug_streams(g, x.T, x.E);
+    pag_build_stats st{};
+    if ((rc = build_stage(g, in->eps, x, &st, ev.e + 2))) return rc;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev.e[0], ev.e[1]);
+    st.ms_extract = ms;
+    hipEventElapsedTime(&ms, ev.e[0], ev.e[5]);
+    st.ms_total = ms;
+    if (timing) fprintf(stderr, "[timing] pag_process wall %.1f ms (device %.1f ms)\n", wall_ms(), (double)ms);
     g->stats = st;
     if (stats) *stats = st;
     return PAG_OK;

@@ -132,6 +132,9 @@ void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uin
                             hipStream_t s);
 void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
                              uint32_t *out, uint32_t stride, hipStream_t s);
+void trav_launch_checkpoints(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev, uint32_t *out,
+                             hipStream_t s);  // out: 3 x u32 per request (old vertex id | PAG_NONE, contig coordinate, abundance)
+void trav_launch_gather_pc(TravGraph G, const uint32_t *seq_v, uint64_t len, uint32_t *out, hipStream_t s);
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s);
 void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,

@@ -15,23 +15,31 @@ EXE = os.path.join(pagctl.ROOT, "aligngraph2_amd", "bin", "pagraph")
 
 # walker modes: speculative choice among probes (default; a failed speculation is redone exactly) and PAG_WALK_EXACT=1
 # (every probe runs to its end before the choice) — both must reproduce the reference byte for byte
+# and the segment-parallel walk: at the default segment length the few-kb golden contigs are walked in one piece ("uncut"
+# is what the other two modes run); "pieces" cuts them every 400 bases so that checkpoints, adoption of segments and
+# resumed walks all happen on inputs whose exact outputs the reference wrote
 @pytest.mark.gpu
-@pytest.mark.parametrize("exact", [False, True], ids=["speculative", "exact"])
+@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact"])
 @pytest.mark.parametrize("name", goldens.case_names())
-def test_pagraph_matches_golden(name, exact, workdir):
+def test_pagraph_matches_golden(name, mode, workdir):
     spec = goldens.load_spec(name)
     ind = goldens.materialize_inputs(name, str(workdir / name / "in"))
-    out = str(workdir / name / ("out_exact" if exact else "out"))
+    out = str(workdir / name / ("out_" + mode))
     os.makedirs(out, exist_ok=True)
     argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
     env = dict(os.environ)
-    env.pop("PAG_WALK_EXACT", None)
-    if exact:
+    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES"):
+        env.pop(v, None)
+    if mode.startswith("pieces"):
+        env.update(PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200", PAGRAPH_TIMING="1")
+    if mode.endswith("exact"):
         env["PAG_WALK_EXACT"] = "1"
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     assert "HIP gfx950" in r.stdout
     goldens.compare_out_dir(name, out)
+    if mode == "pieces":
+        print([ln for ln in r.stderr.splitlines() if "pieces:" in ln])
 
 
 @pytest.mark.gpu

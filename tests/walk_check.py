@@ -49,19 +49,22 @@ def main():
     hostwalk = pagctl.walk_test_lib().pagt_traverse_hostwalk
     hostwalk.argtypes = host.pagh_traverse.argtypes
     res = {}
-    for mode in (["host walk"] if not args.no_host else []) + ["exact", "speculative"]:
+    for mode in (["host walk"] if not args.no_host else []) + ["exact", "speculative", "uncut"]:
         out = tempfile.mkdtemp(prefix="walkcheck_", dir="/dev/shm")
         ts = bench.TraverseStats()
         os.environ.pop("PAG_WALK_EXACT", None)
+        os.environ.pop("PAG_WALK_PIECES", None)
         if mode == "exact":
             os.environ["PAG_WALK_EXACT"] = "1"
+        if mode == "uncut":  # one job per (contig, seed): the walk without the segment-parallel cut
+            os.environ["PAG_WALK_PIECES"] = "0"
         fn = hostwalk if mode == "host walk" else host.pagh_traverse
         t0 = time.time()
         rc = fn(g, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, sp.threads, sp.eps, 50,
                 out.encode(), b"0_", 0, C.byref(ts))
         assert rc == 0, host.pagh_last_error()
         res[mode] = (int(ts.n_path_nodes), int(ts.n_path_bases), f"{int(ts.path_checksum):016x}")
-        print(f"{mode:18s} {res[mode]}  {time.time() - t0:.1f} s", flush=True)
+        print(f"{mode:18s} {res[mode]}  {time.time() - t0:.1f} s (walk {ts.ms_walk:.0f} ms, {ts.walk_jobs} jobs, successor records {ts.ms_successors:.0f} ms)", flush=True)
         files = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
         if "files" in res:
             bad = [f for f in files if files[f] != res["files"].get(f)]
