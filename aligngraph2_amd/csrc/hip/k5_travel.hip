@@ -377,6 +377,22 @@ __global__ void k_ranges(TravGraph G, TravContig *ctgs, uint32_t n) {
     };
     ctgs[i].in_lo = lower(ctgs[i].ctg_left);
     ctgs[i].in_hi = lower(ctgs[i].ctg_right);
+    ctgs[i].g_lo = ctgs[i].in_lo;
+    ctgs[i].g_hi = ctgs[i].in_hi;
+}
+
+// first new id whose contig coordinate is >= coords[i] (the vertices with a coordinate are ordered by it)
+__global__ void k_id_bounds(TravGraph G, const uint32_t *__restrict__ coords, uint32_t n, uint32_t *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = coords[i];
+    uint64_t lo = 0, hi = G.n_pos;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if ((uint32_t)(G.upos[mid] >> 32) < x) lo = mid + 1;
+        else hi = mid;
+    }
+    out[i] = (uint32_t)lo;
 }
 
 // =================================================================================================
@@ -589,7 +605,7 @@ __device__ __forceinline__ void win_fill(WalkLds &L, WalkCtx &X, uint32_t anchor
         // (an LDS-direct load writes one slot PER ACTIVE LANE: only the lanes that own a word of wgb may take part,
         // the others would write past its end, into the abundances)
         if (lane < WIN_IDS / 32u) {
-            if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + (d0 >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
+            if (X.C.gbits) __builtin_amdgcn_global_load_lds((const void *)(X.C.gbits + ((X.C.in_lo - X.C.g_lo + d0) >> 5) + w), (lds_ptr_t)&L.wgb[0], 4, 0, 0);
             else L.wgb[lane] = 0u;
         }
     }
@@ -661,16 +677,20 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, c
     bool gvis = inw & ((gww & bit) != 0u);
     bool pvis = (inw & (stw == gen)) | (!inr & (((po.n >= 1u) & (v == po.v0)) | ((po.n >= 2u) & (v == po.v1))));
     const bool fth = !inr & ((ftw & fk.mask) == fk.mask), fgh = !inr & ((fgw & fk.mask) == fk.mask);
-    if ((inr & !inw) | fth | fgh | (!inr & (po.n > 2u))) {
+    // a strand vertex outside the range of the job's own arrays (segment jobs): its global mark is in the strand's bitmap
+    const uint32_t dg = v - X.C.g_lo;
+    const bool ing = !inr & (dg < X.C.g_hi - X.C.g_lo) & (X.C.gbits != nullptr);
+    if ((inr & !inw) | fth | fgh | ing | (!inr & (po.n > 2u))) {
         if (inr) {
             {
                 const uint32_t ts = stamp_load(&X.tbits[d]);
                 tvis = (ts != 0u) & (ts <= epoch);
             }
-            gvis = X.C.gbits ? (X.C.gbits[d >> 5] >> (d & 31u)) & 1u : false;
+            gvis = X.C.gbits ? (X.C.gbits[dg >> 5] >> (dg & 31u)) & 1u : false;
             if (level == 2) pvis = stamp_load(&X.stamp[(uint64_t)grp * X.stamp_stride + d]) == gen;
         } else {
-            if (fgh) gvis = hs_has(X.C.gset, X.C.gmask, v);
+            if (ing) gvis = (X.C.gbits[dg >> 5] >> (dg & 31u)) & 1u;
+            else if (fgh) gvis = hs_has(X.C.gset, X.C.gmask, v);
             if (fth) {
                 const uint32_t ts = hs64_epoch(X.tset_o, X.tmask_o, v);
                 tvis = (ts != 0u) & (ts <= epoch);
@@ -2138,13 +2158,21 @@ __global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravConti
             p1 = G.npos_off[node + 1];
         }
         // lanes emit in lane order, positions in order: serialise over the lanes that have matches
+        // filterPANodes (PAlgorithm.cpp:97-105): vertices of the contig's globalUniqueTable are dropped here, on the device
+        // (a per-vertex predicate: applying it before the host removes duplicates gives the same list)
+        auto visited = [&](uint32_t p) -> bool {
+            if (!C.gbits) return false;
+            const uint32_t u = G.newid[p];
+            if (u >= C.g_lo && u < C.g_hi) return ((C.gbits[(u - C.g_lo) >> 5] >> ((u - C.g_lo) & 31u)) & 1u) != 0u;
+            return C.gset ? hs_has(C.gset, C.gmask, u) : false;
+        };
         uint32_t cnt = 0;
         for (uint32_t p = p0; p < p1; ++p) {
             uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
             if (pc >= C.ctg_left && pc < C.ctg_right) {
                 uint64_t off = pc - C.ctg_left;
                 uint64_t d = off > R.pos ? off - R.pos : R.pos - off;
-                cnt += d <= dev;
+                cnt += (d <= dev && !visited(p)) ? 1u : 0u;
             }
         }
         uint32_t tot;
@@ -2155,7 +2183,7 @@ __global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravConti
             if (pc >= C.ctg_left && pc < C.ctg_right) {
                 uint64_t off = pc - C.ctg_left;
                 uint64_t d = off > R.pos ? off - R.pos : R.pos - off;
-                if (d <= dev) {
+                if (d <= dev && !visited(p)) {
                     if (1 + w < out_stride) o[1 + w] = p;
                     ++w;
                 }
@@ -2194,7 +2222,7 @@ __global__ __launch_bounds__(64) void k_checkpoints(TravGraph G, const TravConti
             const uint64_t d = off > i ? off - i : i - off;
             if (d > dev) continue;
             const uint32_t u = G.newid[p];
-            if (C.gbits && u >= C.in_lo && u < C.in_hi && ((C.gbits[(u - C.in_lo) >> 5] >> ((u - C.in_lo) & 31u)) & 1u)) continue;
+            if (C.gbits && u >= C.g_lo && u < C.g_hi && ((C.gbits[(u - C.g_lo) >> 5] >> ((u - C.g_lo) & 31u)) & 1u)) continue;
             const uint64_t key = ((uint64_t)G.vcnt[p] << 40) | ((uint64_t)(0xFFFFFu - (uint32_t)((i - R.left) & 0xFFFFFu)) << 20) |
                                  (uint64_t)(0xFFFFFu - ((p - p0) & 0xFFFFFu));
             if (key > best) {
@@ -2217,6 +2245,21 @@ __global__ __launch_bounds__(64) void k_checkpoints(TravGraph G, const TravConti
         out[3 * r] = best_v;
         out[3 * r + 1] = best_pc;
         out[3 * r + 2] = (uint32_t)(best >> 40);
+    }
+}
+
+// The new parts of the sequences of a batch of finished jobs, packed for ONE copy to the host: per job its vertices (new
+// ids), its steps and the contig coordinates of its vertices, each `len` words, at out + off.
+__global__ void k_pack_paths(TravGraph G, const TravPackDesc *__restrict__ descs, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t j = blockIdx.y;
+    if (j >= n) return;
+    const TravPackDesc D = descs[j];
+    uint32_t *o = out + D.off;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D.len; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = D.seq_v[i];
+        o[i] = v;
+        o[D.len + i] = D.seq_s[i];
+        o[2 * D.len + i] = (uint32_t)(G.upos[v] >> 32);
     }
 }
 
@@ -2343,6 +2386,14 @@ void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeed
 void trav_launch_checkpoints(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev, uint32_t *out,
                              hipStream_t s) {
     if (n) k_checkpoints<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out);
+}
+void trav_launch_id_bounds(TravGraph G, const uint32_t *coords, uint32_t n, uint32_t *out, hipStream_t s) {
+    if (n) k_id_bounds<<<dim3((n + 63) / 64), dim3(64), 0, s>>>(G, coords, n, out);
+}
+void trav_launch_pack_paths(TravGraph G, const TravPackDesc *descs, uint32_t n, uint64_t max_len, uint32_t *out, hipStream_t s) {
+    if (!n) return;
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((max_len + 255) / 256, 1), 64);
+    k_pack_paths<<<dim3(gx, n), dim3(256), 0, s>>>(G, descs, n, out);
 }
 void trav_launch_gather_pc(TravGraph G, const uint32_t *seq_v, uint64_t len, uint32_t *out, hipStream_t s) {
     if (len) k_gather_pc<<<dim3(grid_for(len)), dim3(256), 0, s>>>(G, seq_v, len, out);

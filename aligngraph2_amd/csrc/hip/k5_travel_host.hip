@@ -89,43 +89,12 @@ size_t edit_distance(const std::string &a, const std::string &b) {
     return dp[flag ^ 1][b.size()];
 }
 
-// open-addressing set of vertex ids (PAlgorithm's globalUniqueTable on the host side)
-struct VidSet {
-    std::vector<uint32_t> slot;
-    size_t n = 0;
-    static uint32_t mix(uint32_t x) {
-        x *= 0x9E3779B1u;
-        return x ^ (x >> 15);
-    }
-    bool empty() const { return n == 0; }
-    void grow() {
-        std::vector<uint32_t> old;
-        old.swap(slot);
-        slot.assign(old.empty() ? 1024 : old.size() * 4, 0xFFFFFFFFu);
-        n = 0;
-        for (uint32_t v : old)
-            if (v != 0xFFFFFFFFu) insert(v);
-    }
-    bool insert(uint32_t v) {  // true if newly inserted
-        if ((n + 1) * 2 > slot.size()) grow();
-        const size_t mask = slot.size() - 1;
-        for (size_t h = mix(v) & mask;; h = (h + 1) & mask) {
-            if (slot[h] == v) return false;
-            if (slot[h] == 0xFFFFFFFFu) {
-                slot[h] = v;
-                ++n;
-                return true;
-            }
-        }
-    }
-    bool contains(uint32_t v) const {
-        if (slot.empty()) return false;
-        const size_t mask = slot.size() - 1;
-        for (size_t h = mix(v) & mask;; h = (h + 1) & mask) {
-            if (slot[h] == v) return true;
-            if (slot[h] == 0xFFFFFFFFu) return false;
-        }
-    }
+// a vertex of a running travel sequence as the per-round control needs it: new id, step, contig coordinate.  The full
+// records (k-mer, reference coordinate, abundance) are gathered once, for the finished sequences.
+struct LNode {
+    uint32_t u;
+    int32_t step;
+    uint32_t ctg;
 };
 
 struct CtgState {
@@ -135,12 +104,12 @@ struct CtgState {
     uint32_t len = 0;
     uint32_t ctgLeft = 0, ctgRight = 0, revLeft = 0, revRight = 0;
     uint64_t nodesOff = 0;  // offset of this contig's node table
-    std::vector<pag_path_node> travel;
+    std::vector<LNode> travel;
     std::vector<pag_path_node> seeds;
     int64_t varLen = 0;
     std::deque<uint32_t> ctgQ, refQ;
     bool finalLeap = false, done = false;
-    VidSet globalUnique;
+    bool committed = false;  // a walk has been recorded in the global visited structures (device: gbits / gset)
     uint32_t gwinLo = 0xFFFFFFFFu, gwinHi = 0;
     uint32_t *gset = nullptr;   // device: global visited, vertices outside the strand's id range
     uint32_t gcap = 0;
@@ -149,6 +118,7 @@ struct CtgState {
     std::vector<uint32_t> outsideU;  // the entries of gset (new ids)
     uint64_t seqCap = 0;
     uint32_t parentCode = 0;  // k-mer of the last contig-consistent path vertex (seed ordering key)
+    uint32_t parentU = 0;     // ... that vertex (new id)
     bool haveParent = false;
 };
 
@@ -159,10 +129,10 @@ uint64_t pow2_at_least(uint64_t x) {
 }
 
 // PAlgorithm::appendSeq (PAlgorithm.cpp:110-142) on path records
-int64_t append_seq(std::vector<pag_path_node> &base, const std::vector<pag_path_node> &tail, uint32_t k) {
+int64_t append_seq(std::vector<LNode> &base, const std::vector<LNode> &tail, uint32_t k) {
     if (tail.empty()) return 0;
     int64_t dLen = 0;
-    const pag_path_node &head = tail.front();
+    const LNode &head = tail.front();
     int32_t dist = (int32_t)k;
     while (!base.empty() && (base.back().ctg == 0 || head.ctg <= base.back().ctg)) {
         dLen -= base.back().step;
@@ -173,7 +143,7 @@ int64_t append_seq(std::vector<pag_path_node> &base, const std::vector<pag_path_
         dLen += n.step;
         base.push_back(n);
     }
-    pag_path_node &first = base[base.size() - tail.size()];
+    LNode &first = base[base.size() - tail.size()];
     dLen -= first.step - dist;
     first.step = dist;
     return dLen;
@@ -197,16 +167,16 @@ uint64_t pag_debug_mapper_extra(const uint32_t *len, uint64_t n) { return Mapper
 // g->paths[2 * contig + (reverse ? 1 : 0)]
 const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len) {
     const uint64_t slot = 2 * ctg_index + (forward ? 0 : 1);
-    if (!g || slot >= g->paths.size() || !g->path_valid[slot]) {
+    if (!g || slot >= g->path_valid.size() || !g->path_valid[slot]) {
         if (len) *len = 0;
         return nullptr;
     }
-    if (len) *len = g->paths[slot].size();
-    return g->paths[slot].data();
+    if (len) *len = g->path_len[slot];
+    return g->path_store + g->path_off[slot];
 }
 
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
-    if (g && 2 * ctg_index + 1 < g->paths.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
+    if (g && 2 * ctg_index + 1 < g->path_valid.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
     return pag_travel_path_oriented(g, ctg_index, 1, len);
 }
 
@@ -238,6 +208,25 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     int rc;
     int slot = TRAV_SLOT0;
     auto buf = [&](void) { return DevBuf(g, slot++); };
+    // pinned host staging area (grown, kept in the handle): packed job results on their way in, uploads on their way out
+    std::vector<void *> pinned_parked;  // (freeing host memory synchronises the device: never while the walker grid is resident)
+    auto pinned = [&](size_t bytes) -> void * {
+        if (g->pin_bytes < bytes) {
+            if (g->pin_host) {
+                if (g->defer_free) pinned_parked.push_back(g->pin_host);
+                else hipHostFree(g->pin_host);
+            }
+            g->pin_host = nullptr;
+            g->pin_bytes = 0;
+            const size_t want = bytes + bytes / 4 + (1u << 20);
+            if (hipHostMalloc(&g->pin_host, want, hipHostMallocDefault) != hipSuccess) {
+                set_error("pag_travel: hipHostMalloc(%zu) failed", want);
+                return nullptr;
+            }
+            g->pin_bytes = want;
+        }
+        return g->pin_host;
+    };
 
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
@@ -350,7 +339,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     Mapper mapper(ctgs->len, ctgs->n_seqs);
     Mapper refMapper(ref_len, n_refs);
     const uint32_t n_ctgs = (uint32_t)ctgs->n_seqs;
-    g->paths.assign(2 * (size_t)n_ctgs, {});
+    g->path_off.assign(2 * (size_t)n_ctgs, 0);
+    g->path_len.assign(2 * (size_t)n_ctgs, 0);
     g->path_valid.assign(2 * (size_t)n_ctgs, 0);
     std::vector<CtgState> st;
     uint64_t nodes_total = 0;
@@ -363,10 +353,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if (!(o == PAG_ORIENT_BOTH || (fwd && o == PAG_ORIENT_FORWARD) || (!fwd && o == PAG_ORIENT_REVERSE))) continue;
         CtgState cs;
         cs.ci = c;
-        if (c2 < g->paths_pool.size()) {  // storage of the previous block's path for this slot
-            cs.travel.swap(g->paths_pool[c2]);
-            cs.travel.clear();
-        }
         cs.forward = fwd;
         cs.chosenOne = cs.forward ? (int64_t)c + 1 : -(int64_t)c - 1;
         cs.len = ctgs->len[c];
@@ -414,8 +400,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             t.n_ctgs = n_ctgs;
             t.in_lo = cs.inLo;
             t.in_hi = cs.inHi;
-            t.gbits = cs.globalUnique.empty() ? nullptr : cs.gbits;
-            t.gset = cs.globalUnique.empty() ? nullptr : cs.gset;
+            t.g_lo = cs.inLo;
+            t.g_hi = cs.inHi;
+            t.gbits = cs.committed ? cs.gbits : nullptr;
+            t.gset = cs.committed ? cs.gset : nullptr;
             t.gmask = cs.gcap - 1;
             t.gwin_lo = cs.gwinLo;
             t.gwin_hi = cs.gwinHi;
@@ -564,12 +552,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint32_t x = 0;      // checkpoint coordinate
         uint32_t stop = 0;   // its stop coordinate
         uint32_t vid = 0;    // start vertex (old id)
+        uint32_t win_lo = 0, win_hi = 0;  // new-id range its job keeps direct-mapped marks for (around the segment)
         bool done = false, usable = false, stopped = false;
         Piece P;
         std::vector<uint64_t> cum;       // cum[i] = sum of the steps of P[0 .. i]
         std::vector<uint32_t> prefmax;   // max coordinate over P[0 .. i]
         std::vector<uint32_t> sufmin;    // min coordinate over P[i ..]
-        std::unordered_map<uint32_t, uint32_t> index;  // vertex -> position in P (built on first use)
         uint32_t max_back = 0, max_chosen = 0;
         uint64_t max_probe = 0;
     };
@@ -615,6 +603,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         g->defer_free = false;
         for (void *q : g->deferred) hipFree(q);
         g->deferred.clear();
+        for (void *q : pinned_parked) hipHostFree(q);
+        pinned_parked.clear();
     };
     struct JobPlan {
         int kind, idx;
@@ -623,6 +613,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint32_t mode, stop_pc;
         const Piece *init;  // RESUME: the path so far
         bool exact;
+        uint32_t win_lo = 0, win_hi = 0;  // id range of the job's direct-mapped marks (0, 0: the whole strand)
     };
     bool need_publish = false;
     // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
@@ -632,26 +623,29 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         CtgState &cs = st[i];
         RoundState &R = RS[i];
         const uint64_t PG = TRAV_PROBE_GROUPS;
-        // one travel epoch / probe stamp per strand vertex; padded to a multiple of four so that the walker's window
-        // refills can use 16-byte loads
-        const uint64_t span = ((uint64_t)(cs.inHi - cs.inLo) + 1 + 3) & ~3ull, tbw = span + 4;
+        // one travel epoch / probe stamp per vertex of the job's id range (the whole strand, or the surroundings of a
+        // segment); padded to a multiple of four so that the walker's window refills can use 16-byte loads
         const size_t nj = plans.size();
-        std::vector<uint64_t> o_seq(nj + 1, 0), o_oc(nj + 1, 0);
+        std::vector<uint64_t> o_seq(nj + 1, 0), o_oc(nj + 1, 0), o_st(nj + 1, 0), o_tb(nj + 1, 0), spans(nj, 0);
         for (size_t j = 0; j < nj; ++j) {
+            const uint32_t lo = plans[j].win_hi ? plans[j].win_lo : cs.inLo, hi = plans[j].win_hi ? plans[j].win_hi : cs.inHi;
+            spans[j] = ((uint64_t)(hi - lo) + 1 + 3) & ~3ull;
             o_seq[j + 1] = o_seq[j] + plans[j].cap;
             o_oc[j + 1] = o_oc[j] + pow2_at_least(plans[j].cap / 4 + 4096);
+            o_st[j + 1] = o_st[j] + PG * spans[j];
+            o_tb[j + 1] = o_tb[j] + spans[j] + 4;
         }
         DevBuf b_sv = cbuf(i, grp, CB_SEQV), b_ss = cbuf(i, grp, CB_SEQS), b_av = cbuf(i, grp, CB_ARV), b_as = cbuf(i, grp, CB_ARS),
                b_ts = cbuf(i, grp, CB_TSET), b_ps = cbuf(i, grp, CB_PSET), b_st = cbuf(i, grp, CB_STAMP), b_tb = cbuf(i, grp, CB_TBITS);
         int r;
         if ((r = b_sv.alloc(o_seq[nj] * 4)) || (r = b_ss.alloc(o_seq[nj] * 4)) || (r = b_av.alloc(o_seq[nj] * PG * 4)) ||
             (r = b_as.alloc(o_seq[nj] * PG * 4)) || (r = b_ts.alloc(o_oc[nj] * 8)) || (r = b_ps.alloc(o_oc[nj] * PG * 8)) ||
-            (r = b_st.alloc(nj * PG * span * 4)) || (r = b_tb.alloc(nj * tbw * 4)))
+            (r = b_st.alloc(o_st[nj] * 4)) || (r = b_tb.alloc(o_tb[nj] * 4)))
             return r;
         PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, o_oc[nj] * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, o_oc[nj] * PG * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, nj * PG * span * 4, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, nj * tbw * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, o_st[nj] * 4, s));
+        PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, o_tb[nj] * 4, s));
         fill_contigs();
         for (size_t j = 0; j < nj; ++j) {
             const JobPlan &pl = plans[j];
@@ -672,9 +666,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.arena_v = b_av.as<uint32_t>() + o_seq[j] * PG;
             J.arena_s = b_as.as<uint32_t>() + o_seq[j] * PG;
             J.arena_cap = PG * cap;
-            J.stamp = b_st.as<uint32_t>() + j * PG * span;
-            J.stamp_stride = (uint32_t)span;
-            J.tbits = b_tb.as<uint32_t>() + j * tbw;
+            J.stamp = b_st.as<uint32_t>() + o_st[j];
+            J.stamp_stride = (uint32_t)spans[j];
+            J.tbits = b_tb.as<uint32_t>() + o_tb[j];
             J.tset = b_ts.as<uint64_t>() + o_oc[j];
             J.tmask = (uint32_t)oc - 1;
             J.pset = b_ps.as<uint64_t>() + o_oc[j] * PG;
@@ -694,6 +688,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 PAG_HIP_TRY(hipMemcpyAsync(J.seq_s, pl.init->s.data(), n0 * 4, hipMemcpyHostToDevice, s));
             }
             P.C = tc[i];
+            if (pl.win_hi) {  // a segment job: direct-mapped marks only around the segment
+                P.C.in_lo = pl.win_lo;
+                P.C.in_hi = pl.win_hi;
+            }
             hdone[slot] = 0;
             jref[slot].ctg = i;
             jref[slot].kind = pl.kind;
@@ -785,6 +783,25 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             for (size_t q = 0; q < R.segs.size(); ++q)
                 R.segs[q].stop = q + 1 < R.segs.size() ? (uint32_t)std::min<uint64_t>((uint64_t)R.segs[q + 1].x + seg_ov, R.zone_end) : R.zone_end;
             if (R.segs.empty()) R.zone_end = 0;
+            if (!R.segs.empty()) {  // id ranges around the segments: [checkpoint - 2000, stop + 3000] in contig coordinates
+                std::vector<uint32_t> co(2 * R.segs.size()), ids(2 * R.segs.size());
+                for (size_t q = 0; q < R.segs.size(); ++q) {
+                    co[2 * q] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)R.segs[q].x - std::min<uint64_t>(R.segs[q].x, 2000));
+                    co[2 * q + 1] = (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)R.segs[q].stop + 3000);
+                }
+                if ((r = b_ckreq.alloc(co.size() * 4 + reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(co.size() * 4 + reqs.size() * 12))) return r;
+                PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s));
+                trav_launch_id_bounds(G, b_ckreq.as<uint32_t>(), (uint32_t)co.size(), b_ckout.as<uint32_t>(), s);
+                PAG_HIP_TRY(hipMemcpyAsync(ids.data(), b_ckout.p, ids.size() * 4, hipMemcpyDeviceToHost, s));
+                PAG_HIP_TRY(hipStreamSynchronize(s));
+                for (size_t q = 0; q < R.segs.size(); ++q) {
+                    uint32_t lo = std::max(ids[2 * q], cs.inLo), hi = std::min(ids[2 * q + 1], cs.inHi);
+                    lo = cs.inLo + ((lo - cs.inLo) & ~31u);  // (the strand's global-visited bitmap is read word-wise from here)
+                    if (hi <= lo) hi = std::min<uint32_t>(cs.inHi, lo + 64);
+                    R.segs[q].win_lo = lo;
+                    R.segs[q].win_hi = hi;
+                }
+            }
         }
         std::vector<JobPlan> plans;
         const uint64_t cap_full = cs.seqCap;
@@ -795,7 +812,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (size_t q = 0; q < R.segs.size(); ++q) {
             const uint64_t spanc = (uint64_t)R.segs[q].stop - R.segs[q].x;
             const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
-            plans.push_back(JobPlan{1, (int)q, cap, R.segs[q].vid, (uint32_t)TRAV_MODE_SPEC, R.segs[q].stop, nullptr, false});
+            plans.push_back(JobPlan{1, (int)q, cap, R.segs[q].vid, (uint32_t)TRAV_MODE_SPEC, R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi});
         }
         if (wdebug)
             std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_begin, i,
@@ -836,12 +853,15 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         Piece &T = ch.T;
         const Piece &P = sg.P;
         if (!sg.usable || T.v.empty() || P.v.empty()) return 0;
-        if (sg.index.empty())
-            for (uint32_t x = 0; x < (uint32_t)P.v.size(); ++x) sg.index.emplace(P.v[x], x);
         const size_t e = T.v.size() - 1;
-        auto it = sg.index.find(T.v[e]);
-        if (it == sg.index.end()) return 0;
-        const size_t be = it->second;
+        // the last vertex of T in P: P's coordinates grow (not strictly), sufmin says where the search can stop
+        size_t be = P.v.size();
+        for (size_t x = 0; x < P.v.size() && sg.sufmin[x] <= T.pc[e]; ++x)
+            if (P.v[x] == T.v[e]) {
+                be = x;
+                break;
+            }
+        if (be == P.v.size()) return 0;
         size_t t = 0;
         while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
         const size_t a = e - t, b = be - t;
@@ -863,12 +883,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         const size_t last = lo;
         if (last == be && last + 1 < P.v.size()) return 0;
-        for (size_t x = be + 1; x <= last; ++x) {
-            T.v.push_back(P.v[x]);
-            T.s.push_back(P.s[x]);
-            T.pc.push_back(P.pc[x]);
-            ch.prefmax.push_back(std::max(ch.prefmax.back(), P.pc[x]));
-            ch.size += P.s[x];
+        {
+            T.v.insert(T.v.end(), P.v.begin() + (be + 1), P.v.begin() + (last + 1));
+            T.s.insert(T.s.end(), P.s.begin() + (be + 1), P.s.begin() + (last + 1));
+            T.pc.insert(T.pc.end(), P.pc.begin() + (be + 1), P.pc.begin() + (last + 1));
+            const size_t n0 = ch.prefmax.size();
+            ch.prefmax.resize(n0 + (last - be));
+            uint32_t mx = ch.prefmax[n0 - 1];
+            for (size_t x = be + 1; x <= last; ++x) {
+                mx = std::max(mx, P.pc[x]);
+                ch.prefmax[n0 + (x - be - 1)] = mx;
+            }
+            ch.size += sg.cum[last] - sg.cum[be];
         }
         n_adopted += last - be;
         return last + 1 == P.v.size() ? 1 : 2;
@@ -922,9 +948,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     auto fail = [&](int rc2) {
         shutdown_walker();
         g->defer_free = false;
+        for (void *q : pinned_parked) hipHostFree(q);
+        pinned_parked.clear();
         return rc2;
     };
 
+    if (!pinned(64u << 20)) return PAG_ENOMEM;  // (grown later if a batch needs more)
     const double tw0 = now_ms();
     g->defer_free = true;
     for (uint32_t i = 0; i < n_sel; ++i)
@@ -947,7 +976,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     }
     lap("round prep");
 
-    DevBuf b_fetch = buf();
+    DevBuf b_fetch = buf(), b_fdesc = buf();
     uint32_t scan_from = 0;  // every job number below it has been handled
     double t_progress = now_ms();
     while (n_live) {
@@ -980,37 +1009,42 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // ---- their paths: vertices, steps and contig coordinates to the host (one round trip for the batch)
         struct Got {
             uint32_t jn;
-            uint64_t from, len, off;  // the part of the sequence that is new, its place in the fetch buffer
-            std::vector<uint32_t> v, s, pc;
+            uint64_t from, len, off;       // the part of the sequence that is new; word offset of its 3 * len packed words
+            const uint32_t *v, *s, *pc;     // ... in the pinned staging area (valid until the next batch)
         };
         std::vector<Got> got(fin.size());
         {
-            uint64_t tot = 0;
+            uint64_t tot = 0, max_len = 0;
+            std::vector<TravPackDesc> descs(fin.size());
             for (size_t x = 0; x < fin.size(); ++x) {
                 const uint32_t slot = fin[x] % QCAP;
                 const TravJobOut &o = houts[slot];
+                const TravJob &J = hjobs[slot].J;
                 Got &G2 = got[x];
                 G2.jn = fin[x];
                 G2.from = std::min<uint64_t>(jref[slot].init_len, o.seq_len);
                 G2.len = o.seq_len - G2.from;
                 G2.off = tot;
-                tot += G2.len;
+                tot += 3 * G2.len;
+                max_len = std::max(max_len, G2.len);
+                descs[x] = TravPackDesc{J.seq_v + G2.from, J.seq_s + G2.from, G2.len, G2.off};
             }
-            if ((rc = b_fetch.alloc(tot * 4 + 64))) return fail(rc);
-            for (Got &G2 : got) {
-                if (!G2.len) continue;
-                const TravJob &J = hjobs[G2.jn % QCAP].J;
-                G2.v.resize(G2.len);
-                G2.s.resize(G2.len);
-                G2.pc.resize(G2.len);
-                trav_launch_gather_pc(G, J.seq_v + G2.from, G2.len, b_fetch.as<uint32_t>() + G2.off, s);
-                hipMemcpyAsync(G2.v.data(), J.seq_v + G2.from, G2.len * 4, hipMemcpyDeviceToHost, s);
-                hipMemcpyAsync(G2.s.data(), J.seq_s + G2.from, G2.len * 4, hipMemcpyDeviceToHost, s);
-                hipMemcpyAsync(G2.pc.data(), b_fetch.as<uint32_t>() + G2.off, G2.len * 4, hipMemcpyDeviceToHost, s);
-            }
+            uint32_t *hp = (uint32_t *)pinned(tot * 4 + fin.size() * sizeof(TravPackDesc) + 256);
+            if (!hp) return fail(PAG_ENOMEM);
+            TravPackDesc *hd = (TravPackDesc *)(hp + ((tot + 3) & ~3ull));
+            std::memcpy(hd, descs.data(), descs.size() * sizeof(TravPackDesc));
+            if ((rc = b_fetch.alloc(tot * 4 + 64)) || (rc = b_fdesc.alloc(descs.size() * sizeof(TravPackDesc)))) return fail(rc);
+            hipMemcpyAsync(b_fdesc.p, hd, descs.size() * sizeof(TravPackDesc), hipMemcpyHostToDevice, s);
+            trav_launch_pack_paths(G, b_fdesc.as<TravPackDesc>(), (uint32_t)descs.size(), max_len, b_fetch.as<uint32_t>(), s);
+            if (tot) hipMemcpyAsync(hp, b_fetch.p, tot * 4, hipMemcpyDeviceToHost, s);
             if (hipStreamSynchronize(s) != hipSuccess) {
                 set_error("pag_travel: stream failure while fetching paths");
                 return fail(PAG_EFAULT);
+            }
+            for (Got &G2 : got) {
+                G2.v = hp + G2.off;
+                G2.s = G2.v + G2.len;
+                G2.pc = G2.s + G2.len;
             }
         }
         lap("fetch");
@@ -1037,9 +1071,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 sg.usable = !overflow && !misspec && G2.len >= 8;
                 sg.stopped = o.stopped != 0;
                 if (sg.usable) {
-                    sg.P.v.swap(G2.v);
-                    sg.P.s.swap(G2.s);
-                    sg.P.pc.swap(G2.pc);
+                    sg.P.v.assign(G2.v, G2.v + G2.len);
+                    sg.P.s.assign(G2.s, G2.s + G2.len);
+                    sg.P.pc.assign(G2.pc, G2.pc + G2.len);
                     const size_t n = sg.P.v.size();
                     sg.cum.resize(n);
                     sg.prefmax.resize(n);
@@ -1090,12 +1124,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 continue;
             }
             // the new part of the path
-            for (size_t x = 0; x < G2.len; ++x) {
-                ch.T.v.push_back(G2.v[x]);
-                ch.T.s.push_back(G2.s[x]);
-                ch.T.pc.push_back(G2.pc[x]);
-                ch.prefmax.push_back(ch.prefmax.empty() ? G2.pc[x] : std::max(ch.prefmax.back(), G2.pc[x]));
-                ch.size += G2.s[x];
+            {
+                ch.T.v.insert(ch.T.v.end(), G2.v, G2.v + G2.len);
+                ch.T.s.insert(ch.T.s.end(), G2.s, G2.s + G2.len);
+                ch.T.pc.insert(ch.T.pc.end(), G2.pc, G2.pc + G2.len);
+                const size_t n0 = ch.prefmax.size();
+                ch.prefmax.resize(n0 + G2.len);
+                uint32_t mx = n0 ? ch.prefmax[n0 - 1] : 0u;
+                for (size_t x = 0; x < G2.len; ++x) {
+                    mx = std::max(mx, G2.pc[x]);
+                    ch.prefmax[n0 + x] = mx;
+                    ch.size += G2.s[x];
+                }
             }
             if (!o.stopped) ch.final = true;
             if (wdebug)
@@ -1169,13 +1209,23 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                     tot += P.len;
                 }
             }
-            if ((rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return fail(rc);
+            // the chosen walks go to the device through the pinned staging area (vertex ids only: the commit kernels need
+            // nothing else), one copy for the batch
+            uint32_t *hp = (uint32_t *)pinned(tot * 4 + 256);
+            if (!hp) return fail(PAG_ENOMEM);
+            if ((rc = b_gather.alloc(tot * 4 + 64))) return fail(rc);
+            for (uint32_t i : batch) {
+                const Pick &P = picks[i];
+                if (P.chosen < 0 || P.len == 0) continue;
+                std::memcpy(hp + P.off, RS[i].chains[(size_t)P.chosen].T.v.data(), P.len * 4);
+            }
+            if (tot) hipMemcpyAsync(b_gather.p, hp, tot * 4, hipMemcpyHostToDevice, s);
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
                 if (P.chosen < 0 || P.len == 0) continue;
                 const Chain &ch = RS[i].chains[(size_t)P.chosen];
+                CtgState &cs = st[i];
                 {   // globalUniqueTable on the device: its hash set (vertices outside the strand's id range) grows as needed
-                    CtgState &cs = st[i];
                     for (uint32_t u : ch.T.v)
                         if (u < cs.inLo || u >= cs.inHi) cs.outsideU.push_back(u);
                     if ((uint64_t)cs.outsideU.size() * 2 > cs.gcap) {
@@ -1191,29 +1241,19 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                         cs.gcap = ncap;
                     }
                 }
-                DevBuf b_fv = cbuf(i, GRP_FINAL, CB_SEQV), b_fs = cbuf(i, GRP_FINAL, CB_SEQS);
-                if ((rc = b_fv.alloc(P.len * 4)) || (rc = b_fs.alloc(P.len * 4))) return fail(rc);
-                hipMemcpyAsync(b_fv.p, ch.T.v.data(), P.len * 4, hipMemcpyHostToDevice, s);
-                hipMemcpyAsync(b_fs.p, ch.T.s.data(), P.len * 4, hipMemcpyHostToDevice, s);
-                trav_launch_gather_path(G, b_fv.as<uint32_t>(), b_fs.as<uint32_t>(), P.len, b_gather.as<pag_path_node>() + P.off, s);
                 // record the walk in the device-side global visited set of this contig
-                trav_launch_commit(b_fv.as<uint32_t>(), P.len, st[i].inLo, st[i].inHi, st[i].gbits, st[i].gset, st[i].gcap - 1, s);
+                trav_launch_commit(b_gather.as<uint32_t>() + P.off, P.len, cs.inLo, cs.inHi, cs.gbits, cs.gset, cs.gcap - 1, s);
+                cs.committed = true;
             }
         }
-        std::vector<std::vector<pag_path_node>> longest(n_sel);
+        // the chosen walks as the splice needs them (host data of the chains, no device round trip)
+        std::vector<std::vector<LNode>> longest(n_sel);
         for (uint32_t i : batch) {
             const Pick &P = picks[i];
             if (P.chosen < 0 || P.len == 0) continue;
+            const Chain &ch = RS[i].chains[(size_t)P.chosen];
             longest[i].resize(P.len);
-            if (hipMemcpyAsync(longest[i].data(), b_gather.as<pag_path_node>() + P.off, P.len * sizeof(pag_path_node), hipMemcpyDeviceToHost,
-                               s) != hipSuccess) {
-                set_error("pag_travel: path copy failed");
-                return fail(PAG_EFAULT);
-            }
-        }
-        if (hipStreamSynchronize(s) != hipSuccess) {
-            set_error("pag_travel: stream failure while gathering paths");
-            return fail(PAG_EFAULT);
+            for (size_t x = 0; x < P.len; ++x) longest[i][x] = LNode{ch.T.v[x], (int32_t)ch.T.s[x], ch.T.pc[x]};
         }
         for (uint32_t i : batch) {  // the host copies of the round are spent
             RS[i].chains.clear();
@@ -1238,13 +1278,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 while (cs.refQ.size() > 4) cs.refQ.pop_front();
             }
             for (auto &n : longest[i]) {
-                cs.globalUnique.insert(n.vid);
                 if (n.ctg != 0) {
                     cs.gwinLo = std::min(cs.gwinLo, n.ctg);
                     cs.gwinHi = std::max(cs.gwinHi, n.ctg);
                 }
             }
-            std::vector<pag_path_node>().swap(longest[i]);
+            std::vector<LNode>().swap(longest[i]);
             bool ctgRepeat = false, refRepeat = false;
             if (cs.ctgQ.size() >= 4) {
                 auto mm = std::minmax_element(cs.ctgQ.begin(), cs.ctgQ.end());
@@ -1261,14 +1300,14 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
             // last contig-consistent vertex of the running path (PAlgorithm.cpp:332-360)
             uint64_t lastCtgPos = 0;
-            uint32_t lastCode = 0;
+            uint32_t lastU = 0;  // (its k-mer is looked up on the device together with the next seeds)
             bool haveKmer = false;
             for (auto it = cs.travel.rbegin(); it != cs.travel.rend(); ++it) {
                 if (it->ctg != 0) {
                     auto d = mapper.singleToDual(it->ctg);
                     if (d.first == cs.chosenOne && d.second >= 0) {
                         lastCtgPos = (uint64_t)d.second;
-                        lastCode = it->code;
+                        lastU = it->u;
                         haveKmer = true;
                         break;
                     }
@@ -1282,7 +1321,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             slot_req[i] = r;
             slot_has[i] = 1;
             cs.seeds.clear();
-            cs.parentCode = lastCode;
+            cs.parentU = lastU;
             cs.haveParent = haveKmer;
         };
         {
@@ -1334,21 +1373,34 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             std::vector<uint32_t> vids;
             std::vector<size_t> cnt(reqs.size());
             for (size_t q = 0; q < reqs.size(); ++q) {
-                CtgState &cs = st[req_cs[q]];
                 const uint32_t *o = &wb[q * WSTRIDE];
                 std::unordered_set<uint32_t> seen;
                 size_t n = 0;
                 for (uint32_t x = 0; x < o[0]; ++x) {
                     uint32_t v = o[1 + x];
                     if (!seen.insert(v).second) continue;         // std::set `unique` in searchPANode2
-                    if (cs.globalUnique.contains(v)) continue;     // filterPANodes
-                    vids.push_back(v);
+                    vids.push_back(v);                            // (filterPANodes was applied by the kernel)
                     ++n;
                 }
                 cnt[q] = n;
             }
             std::vector<pag_path_node> attrs;
             if ((rc = fetch_vertices(vids, attrs))) return fail(rc);
+            {   // k-mers of the parents (last contig-consistent vertex of each running path)
+                std::vector<uint32_t> pu(reqs.size());
+                for (size_t q = 0; q < reqs.size(); ++q) pu[q] = st[req_cs[q]].parentU;
+                std::vector<pag_path_node> pa(reqs.size());
+                if ((rc = b_vids.alloc(pu.size() * 8)) || (rc = b_gather.alloc(pu.size() * sizeof(pag_path_node) + 64))) return fail(rc);
+                hipMemcpyAsync(b_vids.p, pu.data(), pu.size() * 4, hipMemcpyHostToDevice, s);
+                hipMemsetAsync(b_vids.as<uint32_t>() + pu.size(), 0, pu.size() * 4, s);
+                trav_launch_gather_path(G, b_vids.as<uint32_t>(), b_vids.as<uint32_t>() + pu.size(), pu.size(), b_gather.as<pag_path_node>(), s);
+                hipMemcpyAsync(pa.data(), b_gather.p, pa.size() * sizeof(pag_path_node), hipMemcpyDeviceToHost, s);
+                if (hipStreamSynchronize(s) != hipSuccess) {
+                    set_error("pag_travel: parent k-mer lookup failed");
+                    return fail(PAG_EFAULT);
+                }
+                for (size_t q = 0; q < reqs.size(); ++q) st[req_cs[q]].parentCode = pa[q].code;
+            }
             size_t at = 0;
             for (size_t q = 0; q < reqs.size(); ++q) {
                 CtgState &cs = st[req_cs[q]];
@@ -1379,6 +1431,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         lap("round prep");
     }
     shutdown_walker();
+    g->defer_free = false;
+    for (void *q : pinned_parked) hipHostFree(q);
+    pinned_parked.clear();
     t_walk = now_ms() - tw0;
     lap("walk");
     if (timing || wdebug)
@@ -1409,8 +1464,44 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                                              (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit)))
                 seq.pop_back();
         }
-        g->paths[2 * (size_t)cs.ci + (cs.forward ? 0 : 1)] = std::move(seq);
-        g->path_valid[2 * (size_t)cs.ci + (cs.forward ? 0 : 1)] = 1;
+    }
+    {   // the full records of the finished sequences: one gather for all contigs, results straight into the pinned array
+        // the handle keeps for pag_travel_path()
+        uint64_t tot = 0;
+        for (auto &cs : st) tot += cs.travel.size();
+        if (g->path_cap < tot + 1) {
+            if (g->path_store) hipHostFree(g->path_store);
+            g->path_store = nullptr;
+            g->path_cap = 0;
+            const size_t want = tot + tot / 8 + 1024;
+            if (hipHostMalloc((void **)&g->path_store, want * sizeof(pag_path_node), hipHostMallocDefault) != hipSuccess) {
+                set_error("pag_travel: hipHostMalloc for %zu path records failed", want);
+                return PAG_ENOMEM;
+            }
+            g->path_cap = want;
+        }
+        uint32_t *hp = (uint32_t *)pinned(tot * 8 + 256);
+        if (!hp) return PAG_ENOMEM;
+        uint64_t at = 0;
+        for (auto &cs : st) {
+            const size_t slot2 = 2 * (size_t)cs.ci + (cs.forward ? 0 : 1);
+            g->path_off[slot2] = at;
+            g->path_len[slot2] = cs.travel.size();
+            g->path_valid[slot2] = 1;
+            for (size_t x = 0; x < cs.travel.size(); ++x) {
+                hp[at + x] = cs.travel[x].u;
+                hp[tot + at + x] = (uint32_t)cs.travel[x].step;
+            }
+            at += cs.travel.size();
+        }
+        DevBuf b_fin = buf();
+        if ((rc = b_fin.alloc(tot * 8 + 64)) || (rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return rc;
+        if (tot) {
+            PAG_HIP_TRY(hipMemcpyAsync(b_fin.p, hp, tot * 8, hipMemcpyHostToDevice, s));
+            trav_launch_gather_path(G, b_fin.as<uint32_t>(), b_fin.as<uint32_t>() + tot, tot, b_gather.as<pag_path_node>(), s);
+            PAG_HIP_TRY(hipMemcpyAsync(g->path_store, b_gather.p, tot * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
     }
     lap("epilogue");
     if (timing) {

@@ -71,8 +71,8 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->eseg = nullptr;
     g->n_t = g->n_e = 0;
     g->tg_ready = false;
-    if (!g->paths.empty()) g->paths_pool.swap(g->paths);  // keep the storage (see paths_pool)
-    g->paths.clear();
+    g->path_off.clear();  // (the pinned storage stays)
+    g->path_len.clear();
     g->path_valid.clear();
 }
 
@@ -206,6 +206,8 @@ void pag_destroy(pag_graph *g) {
         if (sl.p) hipFree(sl.p);
     for (void *q : g->deferred) hipFree(q);
     if (g->wq_host) hipHostFree(g->wq_host);
+    if (g->path_store) hipHostFree(g->path_store);
+    if (g->pin_host) hipHostFree(g->pin_host);
     if (g->wq_next) hipFree(g->wq_next);
     if (g->walk_stream) hipStreamDestroy(g->walk_stream);
     if (g->solid_bits) hipFree(g->solid_bits);

@@ -45,10 +45,15 @@ struct pag_graph {
     bool tg_ready = false;
     uint64_t tg_dev = 0;   // parameters the successor records were built with
     double tg_err = 0;
-    std::vector<std::vector<pag_path_node>> paths;  // [2 * contig + (reverse ? 1 : 0)]
-    std::vector<uint8_t> path_valid;                // that orientation was traversed by the last pag_travel
-    std::vector<std::vector<pag_path_node>> paths_pool;  // storage of the previous result, taken over by the next traversal
-                                                          // (releasing and re-faulting ~0.4 GB per block costs tens of ms)
+    // result of the last pag_travel: one array in pinned host memory (grown, never released before pag_destroy), slot
+    // 2 * contig + (reverse ? 1 : 0) at path_off / path_len
+    pag_path_node *path_store = nullptr;
+    size_t path_cap = 0;
+    std::vector<uint64_t> path_off, path_len;
+    std::vector<uint8_t> path_valid;  // that orientation was traversed by the last pag_travel
+    // pinned host staging area of the traversal (packed job results, uploads)
+    void *pin_host = nullptr;
+    size_t pin_bytes = 0;
     // debug: raw emitted streams (host copies), kept when PAG_DEBUG_KEEP_STREAMS=1
     std::vector<uint32_t> dbg_tkey, dbg_ekey;
     std::vector<uint64_t> dbg_tval, dbg_eval;

@@ -52,8 +52,11 @@ struct TravContig {
     const uint64_t *starts;        // contig PositionMapper start table [n_ctgs + 1]
     const uint64_t *sizes;         // [n_ctgs]
     uint32_t n_ctgs;
-    uint32_t in_lo, in_hi;  // new-id range of the vertices on the traversed strand (filled by k_ranges)
-    uint32_t *gbits;        // globalUniqueTable: bitmap over [in_lo, in_hi) (null before the first commit)
+    uint32_t in_lo, in_hi;  // new-id range covered by the per-job arrays (stamps, travel epochs) and the LDS window: the whole
+                            // strand (filled by k_ranges) or, for a segment job, the part of it around the segment; a vertex
+                            // outside is kept in the job's hash sets, exactly like a vertex off the strand
+    uint32_t g_lo, g_hi;    // new-id range of the vertices on the traversed strand (in_lo - g_lo is a multiple of 32)
+    uint32_t *gbits;        // globalUniqueTable: bitmap over [g_lo, g_hi) (null before the first commit)
     uint32_t *gset;         // ... hash set for vertices outside that range (null before the first commit)
     uint32_t gmask;
     uint32_t gwin_lo, gwin_hi;  // ctgGlobalPosTable
@@ -116,6 +119,12 @@ struct TravQueue {
     uint32_t exit;    // host: no further jobs will be posted
 };
 
+struct TravPackDesc {  // one finished job of a fetch batch (k_pack_paths)
+    const uint32_t *seq_v, *seq_s;  // first new vertex / step of the job's sequence
+    uint64_t len;                   // how many
+    uint64_t off;                   // word offset of the job's 3 * len words in the packed buffer
+};
+
 struct TravSeedReq {
     uint32_t ctg;
     uint32_t pad;
@@ -134,6 +143,8 @@ void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeed
                              uint32_t *out, uint32_t stride, hipStream_t s);
 void trav_launch_checkpoints(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev, uint32_t *out,
                              hipStream_t s);  // out: 3 x u32 per request (old vertex id | PAG_NONE, contig coordinate, abundance)
+void trav_launch_id_bounds(TravGraph G, const uint32_t *coords, uint32_t n, uint32_t *out, hipStream_t s);
+void trav_launch_pack_paths(TravGraph G, const TravPackDesc *descs, uint32_t n, uint64_t max_len, uint32_t *out, hipStream_t s);
 void trav_launch_gather_pc(TravGraph G, const uint32_t *seq_v, uint64_t len, uint32_t *out, hipStream_t s);
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s);
