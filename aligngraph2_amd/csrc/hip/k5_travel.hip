@@ -2047,34 +2047,57 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
                                                         uint64_t idle_timeout) {
     __shared__ WalkLds L;
     const uint32_t lane = lane_id();
-    // Single-exit scalar loop: every value that steers it is wave-uniform by construction (readfirstlane).
+    // TRAV_RINGS rings of job records, served in order: the jobs a contig's progress waits for (the walk of a seed, a
+    // resumed walk) are taken before the segment jobs that only run ahead of it, and those of contigs in a later round
+    // before those of the first round (see k5_travel_host.hip).  A wave claims the next job number of a
+    // ring with a compare-and-swap on the ring's counter when the host has posted beyond it; slot = ring * cap + number
+    // mod cap.  Single-exit scalar loop: every value that steers it is wave-uniform by construction (readfirstlane).
     bool alive = true;
+    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint32_t naps = 1;
     while (alive) {
-        const uint32_t idx = __builtin_amdgcn_readfirstlane(atomicAdd(next, lane == 0 ? 1u : 0u));  // job number
-        const uint32_t slot = idx % cap;  // the job records form a ring (the host reuses a slot after it has consumed the job)
-        int go = 0;  // 0 wait, 1 run, 2 leave
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        uint32_t naps = 1;
-        while (go == 0) {
-            // One relaxed 8-byte read of host memory per poll (posted | exit << 32), and polls spaced out up to
-            // ~100 us: hundreds of idle waves hammering the host link would slow the working waves down.  (An
-            // acquire here would also invalidate the L2 on every poll; the acquire that matters follows below.)
-            const uint64_t w = __hip_atomic_load((const uint64_t *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const uint32_t posted = __builtin_amdgcn_readfirstlane((uint32_t)w), bye = __builtin_amdgcn_readfirstlane((uint32_t)(w >> 32));
-            if ((int32_t)(posted - idx) > 0) go = 1;
-            else if (bye != 0u || __builtin_amdgcn_s_memtime() - t0 > idle_timeout) go = 2;  // host done, or host gone
-            else {
-                for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
-                naps = naps < 32u ? naps * 2u : 32u;
+        // One relaxed 8-byte read of host memory per poll (posted[0] | posted[1] << 32), polls of an idle wave spaced out up
+        // to ~100 us: hundreds of idle waves hammering the host link would slow the working waves down.  (An acquire here
+        // would also invalidate the L2 on every poll; the acquire that matters follows below.)
+        const uint64_t w = __hip_atomic_load((const uint64_t *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t w2 = __hip_atomic_load((const uint64_t *)q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        static_assert(TRAV_RINGS == 3, "posted[] is read as two 8-byte words");
+        const uint32_t posted[TRAV_RINGS] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32)),
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w2)};
+        const uint32_t bye = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w2 >> 32));
+        int ring = -1;
+        uint32_t idx = 0;
+        for (int r = 0; r < TRAV_RINGS && ring < 0; ++r) {
+            for (;;) {
+                const uint32_t cur = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&next[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if ((int32_t)(posted[r] - cur) <= 0) break;  // nothing posted beyond the counter
+                uint32_t won = 0;
+                if (lane == 0) {
+                    uint32_t expect = cur;
+                    won = __hip_atomic_compare_exchange_strong(&next[r], &expect, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+                }
+                if (__builtin_amdgcn_readfirstlane(won)) {
+                    ring = r;
+                    idx = cur;
+                    break;
+                }
             }
         }
-        if (go == 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (ring >= 0) {
+            const uint32_t slot = (uint32_t)ring * cap + idx % cap;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // buffers of the job were prepared by other kernels / copies
             walk_job(L, G, jobs[slot].C, jobs[slot].J, &outs[slot], k);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(&done[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // same value from every lane
+            t0 = __builtin_amdgcn_s_memtime();
+            naps = 1;
         } else {
-            alive = false;
+            if (bye != 0u || __builtin_amdgcn_s_memtime() - t0 > idle_timeout) {  // host done, or host gone
+                alive = false;
+            } else {
+                for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
+                naps = naps < 32u ? naps * 2u : 32u;
+            }
         }
     }
 }

@@ -513,8 +513,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     enum { GRP_ROUND = 0, GRP_CHAIN0 = 1, GRP_FINAL = 9, GROUPS = 10 };  // buffer groups per contig (chains: top-K <= 8)
     if (g->cpool.size() < (size_t)n_sel * GROUPS * CB_N) g->cpool.resize((size_t)n_sel * GROUPS * CB_N);
     auto cbuf = [&](uint32_t i, int grp, int b) { return DevBuf(g, &g->cpool[((size_t)i * GROUPS + grp) * CB_N + b]); };
-    const uint32_t QCAP = 65536;  // ring of job records: slot = job number mod QCAP
-    const size_t q_need = 256 + (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
+    // rings of job records, served in order: 0 chain jobs (what a contig's progress waits for), 1 segment jobs of contigs
+    // in a later round (they are further along their critical path), 2 segment jobs of first rounds.  slot = ring * QCAP +
+    // number mod QCAP
+    const uint32_t QCAP = 32768, NR = TRAV_RINGS;
+    const size_t q_need = 256 + NR * (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
     if (g->wq_bytes < q_need) {
         if (g->wq_host) hipHostFree(g->wq_host);
         g->wq_host = nullptr;
@@ -532,17 +535,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     }
     TravQueue *hq = (TravQueue *)g->wq_host;
     TravPosted *hjobs = (TravPosted *)((char *)g->wq_host + 256);
-    TravJobOut *houts = (TravJobOut *)(hjobs + QCAP);
-    uint32_t *hdone = (uint32_t *)(houts + QCAP);
+    TravJobOut *houts = (TravJobOut *)(hjobs + NR * (size_t)QCAP);
+    uint32_t *hdone = (uint32_t *)(houts + NR * (size_t)QCAP);
     std::memset(g->wq_host, 0, 256);
-    std::memset(hdone, 0, (size_t)QCAP * sizeof(uint32_t));
+    std::memset(hdone, 0, NR * (size_t)QCAP * sizeof(uint32_t));
     PAG_HIP_TRY(hipMemsetAsync(g->wq_next, 0, 256, s));
     PAG_HIP_TRY(hipStreamSynchronize(s));
 
     const bool wdebug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+    double t_walk0 = now_ms();  // (debug time stamps count from the launch of the walker)
     const bool use_pieces = !(std::getenv("PAG_WALK_PIECES") && std::atoi(std::getenv("PAG_WALK_PIECES")) == 0);
     const uint64_t seg_len_env = std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 0;
-    const uint64_t seg_ov = std::getenv("PAG_SEG_OVERLAP") ? std::strtoull(std::getenv("PAG_SEG_OVERLAP"), nullptr, 10) : 3000;
+    const uint64_t seg_ov = std::getenv("PAG_SEG_OVERLAP") ? std::strtoull(std::getenv("PAG_SEG_OVERLAP"), nullptr, 10) : 1500;
     const bool force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
 
     struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
@@ -591,8 +595,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint64_t init_len = 0;
         bool live = false;
     };
-    std::vector<JobRef> jref(QCAP);
-    uint32_t n_posted = 0, n_live = 0, respeculated = 0;
+    std::vector<JobRef> jref(NR * (size_t)QCAP);
+    uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
     uint64_t n_adopted = 0, n_merge_fail = 0, n_seg_jobs = 0, n_resume_jobs = 0;
     bool walker_up = false;
     auto shutdown_walker = [&]() {
@@ -649,7 +653,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         fill_contigs();
         for (size_t j = 0; j < nj; ++j) {
             const JobPlan &pl = plans[j];
-            const uint32_t jn = n_posted, slot = jn % QCAP;
+            const uint32_t ring = pl.kind == 0 ? 0u : (R.round > 1 ? 1u : 2u);
+            const uint32_t jn = n_posted[ring], slot = ring * QCAP + jn % QCAP;
             if (jref[slot].live) {
                 set_error("pag_travel: the job ring is full (%u jobs in flight)", QCAP);
                 return PAG_ENOMEM;
@@ -700,14 +705,14 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             jref[slot].live = true;
             if (pl.kind == 0) {
                 Chain &ch = R.chains[(size_t)pl.idx];
-                ch.job = (int)jn;
+                ch.job = (int)slot;
                 ch.job_mode = pl.mode;
                 ch.job_stop = pl.stop_pc;
                 if (pl.mode & TRAV_MODE_RESUME) ++n_resume_jobs;
             } else {
                 ++n_seg_jobs;
             }
-            n_posted += 1;
+            n_posted[ring] += 1;
             n_live += 1;
             R.live_jobs += 1;
             jobs_total += 1;
@@ -718,7 +723,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     auto publish = [&]() -> int {  // after the prepared buffers are ready on the device
         if (!need_publish) return PAG_OK;
         PAG_HIP_TRY(hipStreamSynchronize(s));
-        __atomic_store_n(&hq->posted, n_posted, __ATOMIC_RELEASE);
+        for (uint32_t r = NR; r-- > 0;) __atomic_store_n(&hq->posted[r], n_posted[r], __ATOMIC_RELEASE);
         need_publish = false;
         return PAG_OK;
     };
@@ -746,8 +751,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         std::vector<uint32_t> ck_x;
         if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
             const uint64_t H = (uint64_t)cs.varLen + k;
-            const uint64_t seg_len = seg_len_env ? seg_len_env : std::max<uint64_t>(30000, cs.len / 24);
-            const uint64_t safety = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 25 + 500;
+            // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
+            // jobs; shorter ones pay more overlap and job start-up, longer ones lengthen the first piece of every chain)
+            const uint64_t seg_len = seg_len_env ? seg_len_env : 12000;
+            const uint64_t safety = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 100 + 2000;
             if (split > H + safety + seg_len) {
                 const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H - safety), (uint64_t)cs.ctgRight - 1);
                 for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
@@ -815,7 +822,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             plans.push_back(JobPlan{1, (int)q, cap, R.segs[q].vid, (uint32_t)TRAV_MODE_SPEC, R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi});
         }
         if (wdebug)
-            std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_begin, i,
+            std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_walk0, i,
                          R.round, cs.seeds.size(), R.segs.size(), R.zone_end, cs.ctgLeft, cs.ctgRight);
         return post_batch(i, GRP_ROUND, plans);
     };
@@ -955,9 +962,16 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     if (!pinned(64u << 20)) return PAG_ENOMEM;  // (grown later if a batch needs more)
     const double tw0 = now_ms();
+    t_walk0 = tw0;
     g->defer_free = true;
-    for (uint32_t i = 0; i < n_sel; ++i)
-        if (!st[i].done && (rc = start_round(i))) return fail(rc);
+    {   // longest contigs first: their exact tails (the leaping zone is a tenth of the contig) are the longest, so their
+        // segments should be through the queue first
+        std::vector<uint32_t> order(n_sel);
+        for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a2, uint32_t b2) { return st[a2].len > st[b2].len; });
+        for (uint32_t i : order)
+            if (!st[i].done && (rc = start_round(i))) return fail(rc);
+    }
     if (n_live) {
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
@@ -968,7 +982,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             set_error("pag_travel: walker launch failed");
             return PAG_EFAULT;
         }
-        if (wdebug) std::fprintf(stderr, "[walk] walker launched, %u jobs prepared\n", n_posted);
+        if (wdebug) std::fprintf(stderr, "[walk] walker launched, %u + %u + %u jobs prepared\n", n_posted[0], n_posted[1], n_posted[2]);
         walker_up = true;
         if ((rc = publish())) return fail(rc);
     } else {
@@ -977,15 +991,17 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     lap("round prep");
 
     DevBuf b_fetch = buf(), b_fdesc = buf();
-    uint32_t scan_from = 0;  // every job number below it has been handled
+    uint32_t scan_from[TRAV_RINGS] = {0, 0, 0};  // per ring: every job number below it has been handled
     double t_progress = now_ms();
     while (n_live) {
         // ---- jobs that have finished since the last look
         std::vector<uint32_t> fin;
-        while (scan_from < n_posted && !jref[scan_from % QCAP].live) ++scan_from;
-        for (uint32_t jn = scan_from; jn < n_posted; ++jn) {
-            const uint32_t slot = jn % QCAP;
-            if (jref[slot].live && __atomic_load_n(&hdone[slot], __ATOMIC_ACQUIRE) != 0) fin.push_back(jn);
+        for (uint32_t ring = 0; ring < NR; ++ring) {
+            while (scan_from[ring] < n_posted[ring] && !jref[ring * QCAP + scan_from[ring] % QCAP].live) ++scan_from[ring];
+            for (uint32_t jn = scan_from[ring]; jn < n_posted[ring]; ++jn) {
+                const uint32_t slot = ring * QCAP + jn % QCAP;
+                if (jref[slot].live && __atomic_load_n(&hdone[slot], __ATOMIC_ACQUIRE) != 0) fin.push_back(slot);
+            }
         }
         if (fin.empty()) {
             if (hipStreamQuery(g->walk_stream) == hipSuccess) {  // the grid is gone although jobs are outstanding
@@ -997,7 +1013,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 uint32_t ticket = 0;
                 hipMemcpyAsync(&ticket, g->wq_next, 4, hipMemcpyDeviceToHost, s);
                 hipStreamSynchronize(s);
-                set_error("pag_travel: no walk job finished within 60 s (posted %u, tickets taken %u, jobs outstanding %u)", n_posted, ticket, n_live);
+                set_error("pag_travel: no walk job finished within 60 s (posted %u + %u + %u, tickets taken %u, jobs outstanding %u)", n_posted[0], n_posted[1], n_posted[2], ticket, n_live);
                 return fail(PAG_EFAULT);
             }
             std::this_thread::sleep_for(std::chrono::microseconds(30));
@@ -1017,7 +1033,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             uint64_t tot = 0, max_len = 0;
             std::vector<TravPackDesc> descs(fin.size());
             for (size_t x = 0; x < fin.size(); ++x) {
-                const uint32_t slot = fin[x] % QCAP;
+                const uint32_t slot = fin[x];
                 const TravJobOut &o = houts[slot];
                 const TravJob &J = hjobs[slot].J;
                 Got &G2 = got[x];
@@ -1051,7 +1067,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
         std::vector<uint32_t> touched;  // contigs with news
         for (Got &G2 : got) {
-            const uint32_t slot = G2.jn % QCAP;
+            const uint32_t slot = G2.jn;
             JobRef &jr = jref[slot];
             const TravJobOut o = houts[slot];
             const uint32_t i = jr.ctg;

@@ -114,9 +114,10 @@ struct TravPosted {
     TravJob J;
     TravContig C;  // snapshot of the contig record this job runs with
 };
+constexpr int TRAV_RINGS = 3;
 struct TravQueue {
-    uint32_t posted;  // entries of the job array that are valid (host writes, release)
-    uint32_t exit;    // host: no further jobs will be posted
+    uint32_t posted[TRAV_RINGS];  // per ring: job numbers below it are valid (host writes, release); ring 0 is served first
+    uint32_t exit;                // host: no further jobs will be posted
 };
 
 struct TravPackDesc {  // one finished job of a fetch batch (k_pack_paths)
