@@ -248,7 +248,7 @@ size_t sort_tmp_bytes(uint64_t n) {
 }
 
 int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t n, int key_bits, void *tmp,
-               int *result_in_0, hipStream_t s, float *ms_dominant_kernel, int *n_passes) {
+               int *result_in_0, hipStream_t s, float *ms_dominant_kernel, int *n_passes, int first_bit) {
     *result_in_0 = 1;
     if (ms_dominant_kernel) *ms_dominant_kernel = 0.f;
     if (n_passes) *n_passes = 0;
@@ -269,11 +269,14 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
     p += sort_align256(cells * 8);
     void *scan_tmp = p;
 
-    // persistent scatter blocks: as many as are resident at once (LDS would allow two per CU, registers decide)
-    static int scatter_blocks = 0;
+    // persistent scatter blocks: as many as are resident at once (LDS would allow two per CU, registers decide); asked
+    // once per device of the process (handles on different devices must not share the answer)
+    static int scatter_blocks_of[64] = {0};
+    int dev = 0;
+    PAG_HIP_TRY(hipGetDevice(&dev));
+    int &scatter_blocks = scatter_blocks_of[dev & 63];
     if (scatter_blocks == 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        PAG_HIP_TRY(hipGetDevice(&dev));
+        int cus = 0, per_cu = 0;
         PAG_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         PAG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sort_scatter<8>, ST, 0));
         if (const char *e = getenv("PAG_SORT_BLOCKS_PER_CU")) per_cu = atoi(e);
@@ -286,8 +289,8 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
     uint64_t *va = v0, *vb = v1;
     int in0 = 1;
     for (int pass = 0; pass < passes; ++pass) {
-        int shift = pass * bits;
-        int b = key_bits - shift < bits ? key_bits - shift : bits;
+        int shift = first_bit + pass * bits;
+        int b = key_bits - pass * bits < bits ? key_bits - pass * bits : bits;
         uint32_t rmask = (1u << b) - 1u;
         uint64_t used = (uint64_t)(rmask + 1) * n_tiles;
         sort_hist<<<dim3(n_tiles), dim3(ST), 0, s>>>(ka, n, shift, rmask, hist, n_tiles);

@@ -84,6 +84,17 @@ __global__ void chunk_counts(const pag_aln *__restrict__ aln, uint64_t n, uint32
     out[i] = used ? (a.n_cols + 1023u) / 1024u : 0u;
 }
 
+// records per (owner, pass) of a stream in emission order: the first n1 records are pass-1 records
+__global__ void owner_counts(const uint32_t *__restrict__ key, uint64_t n, uint64_t n1, int shift, unsigned long long *__restrict__ out /*[8][2]*/) {
+    __shared__ unsigned int h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[((key[i] >> shift) & 7u) * 2u + (i < n1 ? 0u : 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 __global__ void edge_counts(const uint32_t *__restrict__ samples, uint64_t n, uint32_t *__restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = samples[i] ? samples[i] - 1u : 0u;
@@ -585,6 +596,203 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     if (timing) fprintf(stderr, "[timing] pag_process wall %.1f ms (device %.1f ms)\n", wall_ms(), (double)ms);
     g->stats = st;
     if (stats) *stats = st;
+    return PAG_OK;
+}
+
+// ---- one graph built by several GPUs (see include/pagraph_hip.h)
+static int log2_shards(uint32_t n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : -1; }
+
+int pag_shard_extract(pag_graph *g, const pag_build_input *in, uint32_t shard, uint32_t n_shards, uint64_t *counts) {
+    int rc = check_process_args(g, in);
+    if (rc != PAG_OK) return rc;
+    const int lg = log2_shards(n_shards);
+    if (lg < 0 || shard >= n_shards || !counts || 2 * (int)g->k < lg) {
+        set_error("pag_shard_extract: n_shards must be 1, 2, 4 or 8 (got %u) and shard below it", n_shards);
+        return PAG_EINVAL;
+    }
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    free_graph_results(g);
+    hipStream_t s = g->stream;
+    const uint64_t n = in->reads.n_seqs, lo = n * shard / n_shards, hi = n * (shard + 1ull) / n_shards;
+    Extracted x;
+    if ((rc = extract_stage(g, in, lo, hi, &x, nullptr, nullptr))) return rc;
+    keep_debug_streams(g, x.T, x.E);
+    g->shard_x[0] = x.T;
+    g->shard_x[1] = x.E;
+    g->shard_in0[0] = g->shard_in0[1] = 1;
+    for (uint32_t i = 0; i < 4 * n_shards; ++i) counts[i] = 0;
+    if (n_shards == 1) {
+        counts[0] = x.T1;
+        counts[1] = x.T - x.T1;
+        counts[2] = x.E1;
+        counts[3] = x.E - x.E1;
+        return PAG_OK;
+    }
+    // records per (owner, pass), then ONE stable radix pass on the owner bits of the k-mer code
+    const int shift = 2 * (int)g->k - lg;
+    DevBuf b_tk0(g, 30), b_tv0(g, 31), b_tk1(g, 32), b_tv1(g, 33), b_ek0(g, 34), b_ev0(g, 35), b_ek1(g, 36), b_ev1(g, 37), b_sorttmp(g, 38), b_ctr(g, 50);
+    if ((rc = b_tk0.alloc((x.T + 1) * 4)) || (rc = b_tv0.alloc((x.T + 1) * 8)) || (rc = b_ek0.alloc((x.E + 1) * 4)) || (rc = b_ev0.alloc((x.E + 1) * 8)) ||
+        (rc = b_tk1.alloc((x.T + 1) * 4)) || (rc = b_tv1.alloc((x.T + 1) * 12)) || (rc = b_ek1.alloc((x.E + 1) * 4)) || (rc = b_ev1.alloc((x.E + 1) * 12)) ||
+        (rc = b_sorttmp.alloc(sort_tmp_bytes(std::max(x.T, x.E)))) || (rc = b_ctr.alloc(512)))
+        return rc;
+    unsigned long long *ctr = b_ctr.as<unsigned long long>();
+    PAG_HIP_TRY(hipMemsetAsync(ctr, 0, 256, s));
+    if (x.T) owner_counts<<<dim3(1024), dim3(256), 0, s>>>(b_tk0.as<uint32_t>(), x.T, x.T1, shift, ctr);
+    if (x.E) owner_counts<<<dim3(1024), dim3(256), 0, s>>>(b_ek0.as<uint32_t>(), x.E, x.E1, shift, ctr + 16);
+    int t_in0 = 1, e_in0 = 1;
+    if ((rc = sort_pairs(b_tk0.as<uint32_t>(), b_tv0.as<uint64_t>(), b_tk1.as<uint32_t>(), b_tv1.as<uint64_t>(), x.T, lg, b_sorttmp.p, &t_in0, s, nullptr,
+                         nullptr, shift)))
+        return rc;
+    if ((rc = sort_pairs(b_ek0.as<uint32_t>(), b_ev0.as<uint64_t>(), b_ek1.as<uint32_t>(), b_ev1.as<uint64_t>(), x.E, lg, b_sorttmp.p, &e_in0, s, nullptr,
+                         nullptr, shift)))
+        return rc;
+    unsigned long long h[32];
+    PAG_HIP_TRY(hipMemcpyAsync(h, ctr, 256, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t o = 0; o < n_shards; ++o) {
+        counts[4 * o + 0] = h[2 * o];
+        counts[4 * o + 1] = h[2 * o + 1];
+        counts[4 * o + 2] = h[16 + 2 * o];
+        counts[4 * o + 3] = h[16 + 2 * o + 1];
+    }
+    g->shard_in0[0] = t_in0;
+    g->shard_in0[1] = e_in0;
+    return PAG_OK;
+}
+
+int pag_shard_take(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval) {
+    if (!g) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const uint64_t T = g->shard_x[0], E = g->shard_x[1];
+    const int ts = g->shard_in0[0] ? 30 : 32, es = g->shard_in0[1] ? 34 : 36;
+    if (T) PAG_HIP_TRY(hipMemcpyAsync(tkey, g->pool[ts].p, T * 4, hipMemcpyDeviceToDevice, s));
+    if (T) PAG_HIP_TRY(hipMemcpyAsync(tval, g->pool[ts + 1].p, T * 8, hipMemcpyDeviceToDevice, s));
+    if (E) PAG_HIP_TRY(hipMemcpyAsync(ekey, g->pool[es].p, E * 4, hipMemcpyDeviceToDevice, s));
+    if (E) PAG_HIP_TRY(hipMemcpyAsync(eval, g->pool[es + 1].p, E * 8, hipMemcpyDeviceToDevice, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    return PAG_OK;
+}
+
+int pag_shard_build(pag_graph *g, const uint32_t *tkey, const uint64_t *tval, uint64_t n_t, uint64_t t1, const uint32_t *ekey,
+                    const uint64_t *eval, uint64_t n_e, uint64_t e1, uint32_t eps, pag_build_stats *stats) {
+    if (!g || t1 > n_t || e1 > n_e || (n_t && (!tkey || !tval)) || (n_e && (!ekey || !eval))) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    free_graph_results(g);
+    hipStream_t s = g->stream;
+    int rc;
+    DevBuf b_tk0(g, 30), b_tv0(g, 31), b_ek0(g, 34), b_ev0(g, 35);
+    if ((rc = b_tk0.alloc((n_t + 1) * 4)) || (rc = b_tv0.alloc((n_t + 1) * 8)) || (rc = b_ek0.alloc((n_e + 1) * 4)) || (rc = b_ev0.alloc((n_e + 1) * 8))) return rc;
+    if (n_t) PAG_HIP_TRY(hipMemcpyAsync(b_tk0.p, tkey, n_t * 4, hipMemcpyDeviceToDevice, s));
+    if (n_t) PAG_HIP_TRY(hipMemcpyAsync(b_tv0.p, tval, n_t * 8, hipMemcpyDeviceToDevice, s));
+    if (n_e) PAG_HIP_TRY(hipMemcpyAsync(b_ek0.p, ekey, n_e * 4, hipMemcpyDeviceToDevice, s));
+    if (n_e) PAG_HIP_TRY(hipMemcpyAsync(b_ev0.p, eval, n_e * 8, hipMemcpyDeviceToDevice, s));
+    EventSet ev;
+    if ((rc = ev.create())) return rc;
+    Extracted x;
+    x.T = n_t;
+    x.E = n_e;
+    x.T1 = t1;
+    x.E1 = e1;
+    pag_build_stats st{};
+    if ((rc = build_stage(g, eps, x, &st, ev.e + 2))) return rc;
+    g->stats = st;
+    if (stats) *stats = st;
+    return PAG_OK;
+}
+
+int pag_shard_export(const pag_graph *g, pag_shard_slice *out) {
+    if (!g || !out) return PAG_EINVAL;
+    out->n_t = g->n_t;
+    out->n_e = g->n_e;
+    out->tkey = g->tkey;
+    out->tval = g->tval;
+    out->tseg = g->tseg;
+    out->tcnt = g->tcnt;
+    out->ekey = g->ekey;
+    out->eval = g->eval;
+    out->eseg = g->eseg;
+    out->stats = g->stats;
+    return PAG_OK;
+}
+
+int pag_shard_take_slice(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *tseg, uint16_t *tcnt, uint32_t *ekey, uint64_t *eval,
+                         uint32_t *eseg) {
+    if (!g) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const uint64_t T = g->n_t, E = g->n_e;
+    if (T) {
+        PAG_HIP_TRY(hipMemcpyAsync(tkey, g->tkey, T * 4, hipMemcpyDeviceToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(tval, g->tval, T * 8, hipMemcpyDeviceToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(tseg, g->tseg, T * 4, hipMemcpyDeviceToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(tcnt, g->tcnt, T * 2, hipMemcpyDeviceToDevice, s));
+    }
+    if (E) {
+        PAG_HIP_TRY(hipMemcpyAsync(ekey, g->ekey, E * 4, hipMemcpyDeviceToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(eval, g->eval, E * 8, hipMemcpyDeviceToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(eseg, g->eseg, E * 4, hipMemcpyDeviceToDevice, s));
+    }
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    return PAG_OK;
+}
+
+int pag_shard_import(pag_graph *g, const pag_shard_slice *parts, uint32_t n_parts, pag_build_stats *total) {
+    if (!g || (!parts && n_parts)) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    uint64_t T = 0, E = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        T += parts[p].n_t;
+        E += parts[p].n_e;
+    }
+    // the imported streams live in slots of their own: the parts may be the handle's own slice (slots 30..47)
+    int rc;
+    DevBuf b_tk(g, 52), b_tv(g, 53), b_ts(g, 54), b_tc(g, 55), b_ek(g, 56), b_ev(g, 57), b_es(g, 58);
+    if ((rc = b_tk.alloc((T + 1) * 4)) || (rc = b_tv.alloc((T + 1) * 8)) || (rc = b_ts.alloc((T + 1) * 4)) || (rc = b_tc.alloc((T + 1) * 2)) ||
+        (rc = b_ek.alloc((E + 1) * 4)) || (rc = b_ev.alloc((E + 1) * 8)) || (rc = b_es.alloc((E + 1) * 4)))
+        return rc;
+    pag_build_stats st{};
+    uint64_t at = 0, ae = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const pag_shard_slice &P = parts[p];
+        if (P.n_t) {
+            PAG_HIP_TRY(hipMemcpyAsync(b_tk.as<uint32_t>() + at, P.tkey, P.n_t * 4, hipMemcpyDeviceToDevice, s));
+            PAG_HIP_TRY(hipMemcpyAsync(b_tv.as<uint64_t>() + at, P.tval, P.n_t * 8, hipMemcpyDeviceToDevice, s));
+            PAG_HIP_TRY(hipMemcpyAsync(b_ts.as<uint32_t>() + at, P.tseg, P.n_t * 4, hipMemcpyDeviceToDevice, s));
+            PAG_HIP_TRY(hipMemcpyAsync(b_tc.as<uint16_t>() + at, P.tcnt, P.n_t * 2, hipMemcpyDeviceToDevice, s));
+        }
+        if (P.n_e) {
+            PAG_HIP_TRY(hipMemcpyAsync(b_ek.as<uint32_t>() + ae, P.ekey, P.n_e * 4, hipMemcpyDeviceToDevice, s));
+            PAG_HIP_TRY(hipMemcpyAsync(b_ev.as<uint64_t>() + ae, P.eval, P.n_e * 8, hipMemcpyDeviceToDevice, s));
+            PAG_HIP_TRY(hipMemcpyAsync(b_es.as<uint32_t>() + ae, P.eseg, P.n_e * 4, hipMemcpyDeviceToDevice, s));
+        }
+        at += P.n_t;
+        ae += P.n_e;
+        for (int q = 0; q < 2; ++q) {
+            st.merge_edge[q] += P.stats.merge_edge[q];
+            st.total_pos[q] += P.stats.total_pos[q];
+            st.merge_pos[q] += P.stats.merge_pos[q];
+            st.n_tuples[q] += P.stats.n_tuples[q];
+            st.n_edges[q] += P.stats.n_edges[q];
+        }
+        st.n_nodes += P.stats.n_nodes;
+        st.n_pos += P.stats.n_pos;
+        st.n_uniq_edges += P.stats.n_uniq_edges;
+    }
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    free_graph_results(g);
+    g->n_t = T;
+    g->n_e = E;
+    g->tkey = b_tk.as<uint32_t>();
+    g->tval = b_tv.as<uint64_t>();
+    g->tseg = b_ts.as<uint32_t>();
+    g->tcnt = b_tc.as<uint16_t>();
+    g->ekey = b_ek.as<uint32_t>();
+    g->eval = b_ev.as<uint64_t>();
+    g->eseg = b_es.as<uint32_t>();
+    g->stats = st;
+    if (total) *total = st;
     return PAG_OK;
 }
 

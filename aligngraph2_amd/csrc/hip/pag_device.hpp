@@ -71,11 +71,11 @@ __device__ __forceinline__ uint32_t rev2(uint32_t x) {
 size_t scan_tmp_bytes(uint64_t n);
 int scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *total_dev, void *tmp, hipStream_t s);
 
-// stable LSD radix sort of (u32 key, u64 value) pairs on key bits [0, key_bits).  Ping-pongs between
-// (k0, v0) and (k1, v1); returns in *result_in_0 which pair holds the result.  tmp: sort_tmp_bytes(n).
+// stable LSD radix sort of (u32 key, u64 value) pairs on key bits [first_bit, first_bit + key_bits).  Ping-pongs
+// between (k0, v0) and (k1, v1); returns in *result_in_0 which pair holds the result.  tmp: sort_tmp_bytes(n).
 size_t sort_tmp_bytes(uint64_t n);
 int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t n, int key_bits, void *tmp,
-               int *result_in_0, hipStream_t s, float *ms_dominant_kernel, int *n_passes);
+               int *result_in_0, hipStream_t s, float *ms_dominant_kernel, int *n_passes, int first_bit = 0);
 
 struct ExtractArgs {
     // reads

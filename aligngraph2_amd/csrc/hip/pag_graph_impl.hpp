@@ -22,6 +22,10 @@ struct pag_graph {
     uint64_t *eval = nullptr;
     uint32_t *eseg = nullptr;
     pag_build_stats stats{};
+    // pag_shard_extract -> pag_shard_take: sizes of the partitioned streams (tuples, edges) and which buffer of each
+    // ping-pong pair holds them
+    uint64_t shard_x[2] = {0, 0};
+    int shard_in0[2] = {1, 1};
     // device memory pool: every buffer of the pipeline lives in a named slot that is reused (and only
     // ever grown) across pag_process calls, so steady-state calls do no hipMalloc/hipFree at all
     struct Slot {

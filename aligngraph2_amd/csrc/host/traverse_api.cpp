@@ -65,10 +65,13 @@ void pagh_release(pag_graph *g) {
     g_cache.erase(g);
 }
 
-int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
-                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
-                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
-    if (!g || !ctgs || !refs || !ctg_orient || !out_dir) return PAG_EINVAL;
+// chain selection + writers over finished travel sequences (PAssembly::testTravel5 after its travelSequence loop,
+// PAssembly.cpp:81-336)
+int pagh_assemble_paths(pag_graph *cache_key, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                        const char *const *ref_names, const int32_t *ctg_orient, const pag_path_node *const *paths,
+                        const uint64_t *path_len, uint32_t ref_threads, uint64_t epsilon, uint64_t min_len, const char *out_dir,
+                        const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
+    if (!ctgs || !refs || !ctg_orient || !out_dir || !paths || !path_len) return PAG_EINVAL;
     try {
         const double t0 = nowMs();
         pagh::SeqDb contigDb = fromPacked(ctgs, ctg_names, "ctg", 0);
@@ -80,36 +83,14 @@ int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *co
             if (o == PAG_ORIENT_FORWARD || o == PAG_ORIENT_BOTH) ctgSet.emplace(contigDb.name(i), true);
             if (o == PAG_ORIENT_REVERSE || o == PAG_ORIENT_BOTH) ctgSet.emplace(contigDb.name(i), false);
         }
-        HandleCache &hc = cacheOf(g);
-        pag_travel_params tp{};
-        tp.ref_threads = ref_threads;
-        tp.deviation = epsilon * 2;
-        tp.error_rate = 0.15;
-        tp.start_split = 0.90;
-        tp.min_len = min_len;
-        pag_travel_stats tst{};
-        int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
-        if (std::getenv("PAGRAPH_TIMING"))
-            std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
-                         tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
-                         (unsigned long long)tst.walk_steps, (unsigned long long)tst.classify_calls, (unsigned long long)tst.probes,
-                         (unsigned long long)tst.records);
-        if (rc != PAG_OK) {
-            setErr("pag_travel: %s", pag_last_error());
-            return rc;
-        }
-        std::vector<std::pair<const pag_path_node *, std::uint64_t>> paths(2 * ctgs->n_seqs, {nullptr, 0});
-        for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c)
-            for (int rev = 0; rev < 2; ++rev) {
-                std::uint64_t len = 0;
-                const pag_path_node *p = pag_travel_path_oriented(g, c, rev == 0, &len);
-                if (p && len) paths[2 * c + rev] = {p, len};
-            }
+        HandleCache &hc = cacheOf(cache_key);
+        std::vector<std::pair<const pag_path_node *, std::uint64_t>> views(2 * ctgs->n_seqs, {nullptr, 0});
+        for (std::uint64_t c = 0; c < 2 * ctgs->n_seqs; ++c)
+            if (paths[c] && path_len[c]) views[c] = {paths[c], path_len[c]};
         const double tg0 = nowMs();
-        pagh::buildPathGraph(paths, k, hc.graph, hc.travelled, host_threads);
+        pagh::buildPathGraph(views, k, hc.graph, hc.travelled, host_threads);
         const double t1 = nowMs();
         if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
-
         pagh::AssembleStats as;
         pagh::assemble(out_dir, prefix ? prefix : "0_", hc.graph, contigDb, refDb, ctgMapper, refMapper, ctgSet, epsilon * 2, 0.15,
                        0.90, min_len, ref_threads, host_threads, &as, true, hc.travelled);
@@ -124,18 +105,61 @@ int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *co
             stats->ms_export = t1 - t0;
             stats->ms_traverse = t2 - t1;
             stats->ms_total = t2 - t0;
-            stats->ms_successors = tst.ms_compact;
-            stats->ms_walk = tst.ms_walk;
-            stats->walk_rounds = tst.rounds;
-            stats->walk_jobs = tst.jobs;
-            stats->walk_steps = tst.walk_steps;
-            stats->walk_classifications = tst.classify_calls;
         }
         return PAG_OK;
     } catch (const std::exception &e) {
-        setErr("pagh_traverse: %s", e.what());
+        setErr("pagh_assemble_paths: %s", e.what());
         return PAG_EFAULT;
     }
+}
+
+int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
+    if (!g || !ctgs || !refs || !ctg_orient || !out_dir) return PAG_EINVAL;
+    const double t0 = nowMs();
+    pag_travel_params tp{};
+    tp.ref_threads = ref_threads;
+    tp.deviation = epsilon * 2;
+    tp.error_rate = 0.15;
+    tp.start_split = 0.90;
+    tp.min_len = min_len;
+    pag_travel_stats tst{};
+    int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
+    if (std::getenv("PAGRAPH_TIMING"))
+        std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
+                     tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
+                     (unsigned long long)tst.walk_steps, (unsigned long long)tst.classify_calls, (unsigned long long)tst.probes,
+                     (unsigned long long)tst.records);
+    if (rc != PAG_OK) {
+        setErr("pag_travel: %s", pag_last_error());
+        return rc;
+    }
+    std::vector<const pag_path_node *> paths(2 * ctgs->n_seqs, nullptr);
+    std::vector<std::uint64_t> lens(2 * ctgs->n_seqs, 0);
+    for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c)
+        for (int rev = 0; rev < 2; ++rev) {
+            std::uint64_t len = 0;
+            const pag_path_node *p = pag_travel_path_oriented(g, c, rev == 0, &len);
+            if (p && len) {
+                paths[2 * c + rev] = p;
+                lens[2 * c + rev] = len;
+            }
+        }
+    const double t1 = nowMs();
+    rc = pagh_assemble_paths(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, paths.data(), lens.data(), ref_threads, epsilon, min_len,
+                             out_dir, prefix, host_threads, stats);
+    if (rc == PAG_OK && stats) {
+        stats->ms_export += t1 - t0;  // (device traversal included, as before)
+        stats->ms_total += t1 - t0;
+        stats->ms_successors = tst.ms_compact;
+        stats->ms_walk = tst.ms_walk;
+        stats->walk_rounds = tst.rounds;
+        stats->walk_jobs = tst.jobs;
+        stats->walk_steps = tst.walk_steps;
+        stats->walk_classifications = tst.classify_calls;
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -86,3 +86,196 @@ def pagraph_runner(argv_for_dir: Callable[[str], List[str]]):
         return subprocess.run([PAGRAPH, *argv_for_dir(sub_dir)], env=env).returncode
 
     return run_one
+
+
+# ======================================================================================================
+# ONE graph built by several GPUs (SURVEY.md §8e level 2; C side: include/pagraph_hip.h, pag_shard_*)
+# ======================================================================================================
+# Reads are split over the ranks for the extraction, k-mer ranges for everything after it; in between ONE all-to-all(v) of
+# 12-byte tuples over xGMI (RCCL all_to_all_single with split sizes), afterwards ONE all-gather of the owners' finished
+# slices.  Order argument (why this is bit-identical to one GPU): the canonical order of the tuples of a k-mer is [pass 1
+# in emission order] ++ [pass 2 in emission order]; rank r extracts the r-th contiguous range of the emission order, so
+# the owner of a k-mer restores that order by laying what it receives out as [pass 1 from rank 0] .. [pass 1 from rank
+# N-1] [pass 2 from rank 0] .. [pass 2 from rank N-1] and sorting STABLY by k-mer (pag_shard_build).  No sequence numbers
+# travel.  Wire volume per GPU: (N-1)/N of its own tuples out (12 B each, two streams) + (N-1)/N of the finished graph in
+# (18 B per tuple slot + 16 B per edge slot): for BASELINE configs[2] on 4 GPUs (1.08e10 tuples + as many edges) about
+# 49 GB out and 69 GB in per GPU, i.e. ~0.11 s + ~0.15 s at 3 peer links x 153 GB/s if all links are driven at once.
+
+import ctypes as _C
+
+
+class BuildStats(_C.Structure):
+    """pag_build_stats (include/pagraph_hip.h)"""
+    _fields_ = [("merge_edge", _C.c_uint64 * 2), ("total_pos", _C.c_uint64 * 2), ("merge_pos", _C.c_uint64 * 2),
+                ("n_tuples", _C.c_uint64 * 2), ("n_edges", _C.c_uint64 * 2), ("n_nodes", _C.c_uint64),
+                ("n_pos", _C.c_uint64), ("n_uniq_edges", _C.c_uint64), ("ms_extract", _C.c_double),
+                ("ms_sort", _C.c_double), ("ms_cluster", _C.c_double), ("ms_edges", _C.c_double),
+                ("ms_total", _C.c_double), ("ms_sort_kernel", _C.c_double), ("sort_records", _C.c_uint64)]
+
+    def counts(self):
+        return (self.merge_edge[0], self.total_pos[0], self.merge_pos[0], self.merge_edge[1], self.total_pos[1],
+                self.merge_pos[1])
+
+
+class ShardSlice(_C.Structure):
+    """pag_shard_slice (include/pagraph_hip.h)"""
+    _fields_ = [("n_t", _C.c_uint64), ("n_e", _C.c_uint64), ("tkey", _C.c_void_p), ("tval", _C.c_void_p), ("tseg", _C.c_void_p),
+                ("tcnt", _C.c_void_p), ("ekey", _C.c_void_p), ("eval", _C.c_void_p), ("eseg", _C.c_void_p), ("stats", BuildStats)]
+
+
+def layout_received(chunks, counts_to_me):
+    """The records an owner receives, in the order pag_shard_build expects.
+
+    chunks[r]: what rank r sent to this owner = [its pass-1 records][its pass-2 records] (a 1-D tensor / array);
+    counts_to_me[r] = (n pass 1, n pass 2).  Returns ([pass 1 from rank 0] .. [pass 1 from rank N-1] [pass 2 from rank 0] ..,
+    number of pass-1 records)."""
+    import torch
+    p1 = [chunks[r][:int(counts_to_me[r][0])] for r in range(len(chunks))]
+    p2 = [chunks[r][int(counts_to_me[r][0]):int(counts_to_me[r][0]) + int(counts_to_me[r][1])] for r in range(len(chunks))]
+    return torch.cat(p1 + p2), int(sum(int(c[0]) for c in counts_to_me))
+
+
+def exchange_stream(arrays, counts, rank, world, dist=None, peers=None):
+    """One tuple stream (a tuple of parallel 1-D tensors, e.g. (keys u32-as-i32, values u64-as-i64)), partitioned by owner
+    as pag_shard_extract leaves it, to its owners.
+
+    counts: [world(src)][world(dst)][2] records of this stream per (source, owner, pass), known to every rank.
+    dist: torch.distributed (all_to_all_single with split sizes: RCCL over xGMI on GPUs, gloo in the CPU test);
+    peers: instead of dist, the partitioned streams of ALL ranks (a list indexed by rank) — the single-process emulation the
+    shard tests use.  Returns (arrays for pag_shard_build, number of pass-1 records among them)."""
+    import torch
+    send_splits = [int(counts[rank][o][0] + counts[rank][o][1]) for o in range(world)]
+    recv_splits = [int(counts[r][rank][0] + counts[r][rank][1]) for r in range(world)]
+    out = []
+    n1 = 0
+    for ai, a in enumerate(arrays):
+        if peers is not None:
+            chunks = []
+            for r in range(world):
+                off = sum(int(counts[r][o][0] + counts[r][o][1]) for o in range(rank))
+                chunks.append(peers[r][ai][off:off + recv_splits[r]])
+        else:
+            recv = torch.empty(sum(recv_splits), dtype=a.dtype, device=a.device)
+            dist.all_to_all_single(recv, a.contiguous(), recv_splits, send_splits)
+            chunks = list(torch.split(recv, recv_splits))
+        laid, n1 = layout_received(chunks, [counts[r][rank] for r in range(world)])
+        out.append(laid.contiguous())
+    return tuple(out), n1
+
+
+class ShardedBuild:
+    """The phases of a sharded graph build for ONE rank; the driver (build_sharded below, or the single-process emulation
+    in tests/test_gpu_shards.py) runs them with the collectives in between."""
+
+    def __init__(self, hip, g, inp, rank, world, device):
+        import numpy as np
+        import torch
+        self.hip, self.g, self.inp, self.rank, self.world, self.device = hip, g, inp, rank, world, device
+        self.np, self.torch = np, torch
+        self.Slice = ShardSlice
+        self.BuildStats = BuildStats
+
+    def extract(self):
+        """K1 for this rank's reads + stable partition by owner.  -> counts[world][4], (tkey, tval), (ekey, eval)"""
+        np, torch = self.np, self.torch
+        c = (_C.c_uint64 * (4 * self.world))()
+        rc = self.hip.pag_shard_extract(_C.c_void_p(self.g), _C.byref(self.inp), self.rank, self.world, c)
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_extract failed ({rc}): {self.hip.pag_last_error().decode()}")
+        counts = np.array(list(c), dtype=np.int64).reshape(self.world, 4)
+        T, E = int(counts[:, 0:2].sum()), int(counts[:, 2:4].sum())
+        tk = torch.empty(T, dtype=torch.int32, device=self.device)
+        tv = torch.empty(T, dtype=torch.int64, device=self.device)
+        ek = torch.empty(E, dtype=torch.int32, device=self.device)
+        ev = torch.empty(E, dtype=torch.int64, device=self.device)
+        rc = self.hip.pag_shard_take(_C.c_void_p(self.g), _C.c_void_p(tk.data_ptr()), _C.c_void_p(tv.data_ptr()), _C.c_void_p(ek.data_ptr()),
+                                     _C.c_void_p(ev.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_take failed ({rc}): {self.hip.pag_last_error().decode()}")
+        return counts, (tk, tv), (ek, ev)
+
+    def build(self, tuples, t1, edges, e1, eps):
+        """K2-K4 over the records this owner received -> its slice (kept in the handle) and its share of the counts"""
+        st = self.BuildStats()
+        (tk, tv), (ek, ev) = tuples, edges
+        rc = self.hip.pag_shard_build(_C.c_void_p(self.g), _C.c_void_p(tk.data_ptr()), _C.c_void_p(tv.data_ptr()), tk.numel(), t1,
+                                      _C.c_void_p(ek.data_ptr()), _C.c_void_p(ev.data_ptr()), ek.numel(), e1, eps, _C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_build failed ({rc}): {self.hip.pag_last_error().decode()}")
+        return st
+
+    def export(self):
+        """the slice as torch tensors (copies: they outlive the handle's buffers through the all-gather)"""
+        torch = self.torch
+        sl = self.Slice()
+        rc = self.hip.pag_shard_export(_C.c_void_p(self.g), _C.byref(sl))
+        if rc != 0:
+            raise RuntimeError("pag_shard_export failed")
+        out = {}
+        for name, n, dt in (("tkey", sl.n_t, torch.int32), ("tval", sl.n_t, torch.int64), ("tseg", sl.n_t, torch.int32),
+                            ("tcnt", sl.n_t, torch.int16), ("ekey", sl.n_e, torch.int32), ("eval", sl.n_e, torch.int64),
+                            ("eseg", sl.n_e, torch.int32)):
+            out[name] = torch.empty(int(n), dtype=dt, device=self.device)
+        rc = self.hip.pag_shard_take_slice(_C.c_void_p(self.g), *[_C.c_void_p(out[n].data_ptr()) for n in
+                                                                  ("tkey", "tval", "tseg", "tcnt", "ekey", "eval", "eseg")])
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_take_slice failed ({rc}): {self.hip.pag_last_error().decode()}")
+        return out, BuildStats.from_buffer_copy(bytes(sl.stats))
+
+    def import_all(self, slices, stats_list):
+        """the whole graph from the slices of all owners (lists in owner order) -> total count lines"""
+        parts = (self.Slice * len(slices))()
+        for i, (sl, st) in enumerate(zip(slices, stats_list)):
+            parts[i].n_t = sl["tkey"].numel()
+            parts[i].n_e = sl["ekey"].numel()
+            for name in ("tkey", "tval", "tseg", "tcnt", "ekey", "eval", "eseg"):
+                setattr(parts[i], name, sl[name].data_ptr())
+            parts[i].stats = st
+        tot = self.BuildStats()
+        rc = self.hip.pag_shard_import(_C.c_void_p(self.g), parts, len(slices), _C.byref(tot))
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_import failed ({rc}): {self.hip.pag_last_error().decode()}")
+        return tot
+
+
+def build_sharded(hip, g, inp, eps, dist, device):
+    """One config block built by all ranks of `dist` (each rank passes the SAME input; it extracts its share of the reads).
+    Afterwards every rank's handle holds the whole graph.  Returns the total count lines (pag_build_stats)."""
+    import numpy as np
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sb = ShardedBuild(hip, g, inp, rank, world, device)
+    counts, tuples, edges = sb.extract()
+    allc = torch.zeros(world, world, 4, dtype=torch.int64, device=device)
+    mine = torch.from_numpy(counts).to(device)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    for r in range(world):
+        allc[r] = gathered[r]
+    allc = allc.cpu().numpy()
+    rt, t1 = exchange_stream(tuples, allc[:, :, 0:2], rank, world, dist=dist)
+    re, e1 = exchange_stream(edges, allc[:, :, 2:4], rank, world, dist=dist)
+    del tuples, edges
+    sb.build(rt, t1, re, e1, eps)
+    del rt, re
+    sl, st = sb.export()
+    # all-gather of the slices (padded to the largest; sizes first)
+    sizes = torch.tensor([sl["tkey"].numel(), sl["ekey"].numel()], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [x.cpu().tolist() for x in all_sizes]
+    slices = [dict() for _ in range(world)]
+    for name in ("tkey", "tval", "tseg", "tcnt", "ekey", "eval", "eseg"):
+        which = 0 if name[0] == "t" else 1
+        mx = max(s[which] for s in all_sizes)
+        pad = torch.zeros(mx, dtype=sl[name].dtype, device=device)
+        pad[:sl[name].numel()] = sl[name]
+        outs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad)
+        for r in range(world):
+            slices[r][name] = outs[r][:all_sizes[r][which]].contiguous()
+    st_bytes = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(device)
+    all_st = [torch.empty_like(st_bytes) for _ in range(world)]
+    dist.all_gather(all_st, st_bytes)
+    stats_list = [BuildStats.from_buffer_copy(bytes(x.cpu().numpy().tobytes())) for x in all_st]
+    return sb.import_all(slices, stats_list)

@@ -176,6 +176,50 @@ int pag_reset(pag_graph *g);
 /* PositionProcessor::process (PositionProcessor.cpp:79-151): both extraction passes, mergeEdge,
  * mergeKmerPosition, sortKmerPosition — as one device pipeline. */
 int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats);
+/* ---- one graph built by several GPUs (SURVEY §8e level 2) ------------------------------------------------------
+ * The reference keeps all graph state per k-mer (node/KMerAdjNode.hpp:19-23; PABruijnGraph::mergeKmerPosition /
+ * mergeEdge loop over the k-mers, PABruijnGraph.cpp:259-297) and extracts read by read (PositionProcessor.cpp:86-124),
+ * so one config block splits as: reads over the shards for the extraction, k-mer ranges over the shards for everything
+ * after it, ONE exchange of tuples in between.  With n_shards a power of two (<= 8):
+ *   shard s extracts the reads at emission positions [s * n / S, (s + 1) * n / S) of in->emit_order;
+ *   owner(code) = code >> (2k - log2 S): contiguous, ascending k-mer ranges;
+ *   the canonical order of a k-mer's tuples is [pass 1, emission order] ++ [pass 2, emission order]; the shards' read
+ *     ranges are contiguous in emission order, so the owner restores it by concatenating what it receives as
+ *     [pass 1 from shard 0] .. [pass 1 from shard S-1] [pass 2 from shard 0] .. and sorting stably by k-mer — no sequence
+ *     numbers travel;
+ *   the finished graph is the concatenation of the owners' slices in owner order (the count lines are sums over
+ *     k-mers, hence over owners).
+ * pag_shard_extract: both extraction passes for this shard's reads, then a stable partition by owner.  counts[o * 4 + ..]
+ *   = {tuples pass 1, tuples pass 2, edges pass 1, edges pass 2} destined for owner o; in the partitioned streams the
+ *   part of owner o is [its pass-1 records][its pass-2 records], owners ascending.
+ * pag_shard_take: copies the partitioned streams into caller (device) buffers of the sizes just reported.
+ * pag_shard_build: the received records (device pointers, already in the order described above; t1 / e1 = how many
+ *   of them are pass-1 records) -> K2 sort, K3, K4; the handle then holds the slice of this owner.
+ * pag_shard_export / pag_shard_take_slice / pag_shard_import: the slice as device arrays; a whole graph from the slices of all owners (device
+ *   pointers, in owner order): the handle then is indistinguishable from one that ran pag_process on the whole input
+ *   (pag_export_csr, pag_travel ...). */
+typedef struct pag_shard_slice {
+    uint64_t n_t, n_e;      /* records in the tuple / edge stream arrays */
+    const uint32_t *tkey;   /* [n_t] k-mer code, ascending */
+    const uint64_t *tval;   /* [n_t] in place: the clustered, sorted positions of the segment at its head */
+    const uint32_t *tseg;   /* [n_t] leaders of the segment starting here (0 off a segment head) */
+    const uint16_t *tcnt;   /* [n_t] abundance of the leader stored here */
+    const uint32_t *ekey;   /* [n_e] */
+    const uint64_t *eval;   /* [n_e] */
+    const uint32_t *eseg;   /* [n_e] */
+    pag_build_stats stats;  /* this owner's share of every count */
+} pag_shard_slice;
+int pag_shard_extract(pag_graph *g, const pag_build_input *in, uint32_t shard, uint32_t n_shards, uint64_t *counts);
+int pag_shard_take(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval);
+int pag_shard_build(pag_graph *g, const uint32_t *tkey, const uint64_t *tval, uint64_t n_t, uint64_t t1, const uint32_t *ekey,
+                    const uint64_t *eval, uint64_t n_e, uint64_t e1, uint32_t eps, pag_build_stats *stats);
+int pag_shard_export(const pag_graph *g, pag_shard_slice *out);
+/* ... copied into caller (device) buffers of the sizes pag_shard_export reports (they outlive the handle's own storage,
+ * e.g. through an all-gather) */
+int pag_shard_take_slice(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *tseg, uint16_t *tcnt, uint32_t *ekey, uint64_t *eval,
+                         uint32_t *eseg);
+int pag_shard_import(pag_graph *g, const pag_shard_slice *parts, uint32_t n_parts, pag_build_stats *total);
+
 /* sizes of the finished graph, then the graph itself into caller buffers */
 int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);
 int pag_export_csr(const pag_graph *g, pag_csr *out);

@@ -45,6 +45,8 @@ struct pago_graph {
     int dbg;
     uint32_t *dbg_tkey, *dbg_ekey;
     uint64_t *dbg_tval, *dbg_eval;
+    uint32_t *dbg_tread, *dbg_eread; /* emission position (index into emit_order) of the read that emitted the record */
+    uint32_t dbg_cur;
     size_t dbg_nt, dbg_ct, dbg_ne, dbg_ce;
 };
 
@@ -151,12 +153,21 @@ int pago_debug_streams(const pago_graph *g, uint32_t *tkey, uint64_t *tval, uint
     return PAG_OK;
 }
 
+/* test hook: for every record of the debug streams, the emission position of the read that emitted it */
+int pago_debug_stream_reads(const pago_graph *g, uint32_t *tread, uint32_t *eread) {
+    memcpy(tread, g->dbg_tread, g->dbg_nt * 4);
+    memcpy(eread, g->dbg_eread, g->dbg_ne * 4);
+    return PAG_OK;
+}
+
 void pago_destroy(pago_graph *g) {
     if (!g) return;
     pago_reset(g);
     free(g->nodes);
     free(g->codes);
     free(g->dense);
+    free(g->dbg_tread);
+    free(g->dbg_eread);
     free(g->dbg_tkey);
     free(g->dbg_tval);
     free(g->dbg_ekey);
@@ -380,7 +391,9 @@ static void add_position_and_edge(pago_graph *g, const char *seq, uint64_t len, 
                     g->dbg_ct = g->dbg_ct ? g->dbg_ct * 2 : 1024;
                     g->dbg_tkey = (uint32_t *)realloc(g->dbg_tkey, g->dbg_ct * 4);
                     g->dbg_tval = (uint64_t *)realloc(g->dbg_tval, g->dbg_ct * 8);
+                    g->dbg_tread = (uint32_t *)realloc(g->dbg_tread, g->dbg_ct * 4);
                 }
+                g->dbg_tread[g->dbg_nt] = g->dbg_cur;
                 g->dbg_tkey[g->dbg_nt] = (uint32_t)codes[i];
                 g->dbg_tval[g->dbg_nt] = ((uint64_t)lists[x].ctg << 32) | lists[x].ref;
                 g->dbg_nt++;
@@ -394,7 +407,9 @@ static void add_position_and_edge(pago_graph *g, const char *seq, uint64_t len, 
                     g->dbg_ce = g->dbg_ce ? g->dbg_ce * 2 : 1024;
                     g->dbg_ekey = (uint32_t *)realloc(g->dbg_ekey, g->dbg_ce * 4);
                     g->dbg_eval = (uint64_t *)realloc(g->dbg_eval, g->dbg_ce * 8);
+                    g->dbg_eread = (uint32_t *)realloc(g->dbg_eread, g->dbg_ce * 4);
                 }
+                g->dbg_eread[g->dbg_ne] = g->dbg_cur;
                 g->dbg_ekey[g->dbg_ne] = (uint32_t)g->codes[prev_idx];
                 g->dbg_eval[g->dbg_ne] = ((uint64_t)codes[i] << 32) | ((uint64_t)(i - prev_pos) << 1) | (uint64_t)pass;
                 g->dbg_ne++;
@@ -451,6 +466,7 @@ int pago_process(pago_graph *g, const pag_build_input *in, pag_build_stats *st) 
         for (uint64_t e = 0; e < reads->n_seqs; ++e) {
             uint32_t r = in->emit_order[e];
             uint64_t len = reads->len[r];
+            g->dbg_cur = (uint32_t)e;
             items[0].n = items[1].n = 0;
             int useful[2] = {0, 0};
             int done = 0;

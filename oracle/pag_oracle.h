@@ -35,6 +35,7 @@ int pago_export_csr(const pago_graph *g, pag_csr *out);
 void pago_debug_enable(pago_graph *g, int on);
 int pago_debug_stream_sizes(const pago_graph *g, uint64_t *n_tuples, uint64_t *n_edges);
 int pago_debug_streams(const pago_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval);
+int pago_debug_stream_reads(const pago_graph *g, uint32_t *tread, uint32_t *eread);
 
 /* function-level seams, exposed for known-answer tests */
 /* KmerHelper::kmer2Code (KmerHelper.cpp:7-25): writes len-k+1 codes, returns the count */

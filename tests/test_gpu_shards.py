@@ -1,0 +1,167 @@
+"""GPU: ONE graph built by N shards (SURVEY §8e level 2) — emulated in one process on one device: N handles play the N
+ranks, the collectives are replaced by slicing the other "ranks'" buffers (parallel.exchange_stream(peers=...)), every
+kernel and every piece of host logic is the one the multi-GPU run uses (pag_shard_extract / _build / _import through
+aligngraph2_amd.parallel.ShardedBuild).  N shards must reproduce the single pag_process BYTE FOR BYTE: count lines, every
+CSR array, and the traversal outputs — also when the contigs are walked by different "ranks" and the travel sequences are
+gathered for one pagh_assemble_paths."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import pagctl
+
+sys.path.insert(0, pagctl.ROOT)
+from aligngraph2_amd import parallel  # noqa: E402
+
+
+def _csr(hip, g):
+    nn, npos, ne = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    hip.pag_csr_sizes(C.c_void_p(g), C.byref(nn), C.byref(npos), C.byref(ne))
+    arrs = {"node_code": np.zeros(nn.value + 1, np.uint32), "pos_off": np.zeros(nn.value + 1, np.uint64),
+            "pos_ctg": np.zeros(npos.value + 1, np.uint32), "pos_ref": np.zeros(npos.value + 1, np.uint32),
+            "pos_cnt": np.zeros(npos.value + 1, np.uint16), "edge_off": np.zeros(nn.value + 1, np.uint64),
+            "edge_to": np.zeros(ne.value + 1, np.uint32), "edge_step": np.zeros(ne.value + 1, np.int32)}
+    csr = pagctl.Csr(nn.value, npos.value, ne.value, *[arrs[k].ctypes.data for k in ("node_code", "pos_off", "pos_ctg", "pos_ref", "pos_cnt",
+                                                                                    "edge_off", "edge_to", "edge_step")])
+    assert hip.pag_export_csr(C.c_void_p(g), C.byref(csr)) == 0, hip.pag_last_error()
+    return (nn.value, npos.value, ne.value), arrs
+
+
+def _bind(hip):
+    hip.pag_create_from_bitmap.restype = C.c_void_p
+    hip.pag_export_csr.argtypes = [C.c_void_p, C.POINTER(pagctl.Csr)]
+    hip.pag_csr_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
+    hip.pag_shard_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    hip.pag_shard_take.argtypes = [C.c_void_p] * 5
+    hip.pag_shard_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                    C.c_uint32, C.c_void_p]
+    hip.pag_shard_export.argtypes = [C.c_void_p, C.c_void_p]
+    hip.pag_shard_take_slice.argtypes = [C.c_void_p] * 8
+    hip.pag_shard_import.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+
+
+def _sharded(hip, w, n_shards):
+    """the emulated N-rank build; returns the N handles, each holding the WHOLE graph afterwards, and the total stats"""
+    import torch
+    sp = w.spec
+    inp = w.build_input()
+    gs, sbs = [], []
+    for r in range(n_shards):
+        err = C.c_int()
+        g = hip.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, sp.k, 1, 0, C.byref(err))
+        assert g, hip.pag_last_error()
+        gs.append(g)
+        sbs.append(parallel.ShardedBuild(hip, g, inp, r, n_shards, "cuda"))
+    ext = [sb.extract() for sb in sbs]  # (counts[world][4], (tk, tv), (ek, ev)) per rank
+    allc = np.stack([e[0] for e in ext])  # [src][dst][4]
+    slices, stats = [], []
+    for r, sb in enumerate(sbs):
+        rt, t1 = parallel.exchange_stream(ext[r][1], allc[:, :, 0:2], r, n_shards, peers=[e[1] for e in ext])
+        re_, e1 = parallel.exchange_stream(ext[r][2], allc[:, :, 2:4], r, n_shards, peers=[e[2] for e in ext])
+        sb.build(rt, t1, re_, e1, sp.eps)
+        sl, st = sb.export()
+        slices.append(sl)
+        stats.append(st)
+    totals = [sb.import_all(slices, stats) for sb in sbs]
+    torch.cuda.synchronize()
+    assert all(t.counts() == totals[0].counts() for t in totals)
+    return gs, totals[0]
+
+
+def _traverse(host, g, w, out, orient):
+    import bench
+    ref_np = w.ref.cpu().numpy()
+    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_seqs, k1 = bench.host_seqs(ctg_codes)
+    ref_seqs, k2 = bench.host_seqs([ref_np])
+    os.makedirs(out, exist_ok=True)
+    ts = bench.TraverseStats()
+    rc = host.pagh_traverse(g, w.spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, w.spec.threads, w.spec.eps, 50,
+                            out.encode(), b"0_", 0, C.byref(ts))
+    assert rc == 0, host.pagh_last_error()
+    return ts, (ctg_seqs, ref_seqs, k1, k2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards", [2, 4, 8])
+def test_n_shards_build_the_graph_of_one(n_shards, workdir):
+    import torch
+    import bench
+    import biggen
+    hip, host = bench.load_libs()
+    _bind(hip)
+    sp = biggen.BigSpec(seed=7, ref_len=1_500_000, n_reads=3000, read_span=4000, k=14, eps=10, ctg_len=300_000, gap_lo=300, gap_hi=3000,
+                        rev_ctg_frac=0.3, threads=16, cov=2, solid_min_abundance=2, chunk_reads=512)
+    w = biggen.BigWorkload(sp, device="cuda")
+    torch.cuda.synchronize()
+    inp = w.build_input()
+    err = C.c_int()
+    g1 = hip.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, sp.k, 1, 0, C.byref(err))
+    st1 = pagctl.BuildStats()
+    assert hip.pag_process(C.c_void_p(g1), C.byref(inp), C.byref(st1)) == 0, hip.pag_last_error()
+    sizes1, csr1 = _csr(hip, g1)
+
+    gs, tot = _sharded(hip, w, n_shards)
+    assert tot.counts() == st1.counts()
+    assert tuple(tot.n_tuples) == tuple(st1.n_tuples) and tuple(tot.n_edges) == tuple(st1.n_edges)
+    assert (tot.n_nodes, tot.n_pos, tot.n_uniq_edges) == (st1.n_nodes, st1.n_pos, st1.n_uniq_edges)
+    for g in (gs[0], gs[-1]):
+        sizes, csr = _csr(hip, g)
+        assert sizes == sizes1
+        for kk in csr1:
+            assert np.array_equal(csr[kk], csr1[kk]), f"{n_shards} shards: CSR array {kk} differs"
+
+    # traversal: one handle walks everything ...
+    orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
+    ts1, _ = _traverse(host, g1, w, str(workdir / f"sh{n_shards}_one"), orient)
+    tsN, seqs = _traverse(host, gs[0], w, str(workdir / f"sh{n_shards}_all"), orient)
+    assert (ts1.n_path_nodes, ts1.n_path_bases, ts1.path_checksum) == (tsN.n_path_nodes, tsN.n_path_bases, tsN.path_checksum)
+    # ... or the contigs are dealt out over the "ranks", each walks its own on its copy of the graph, and the travel
+    # sequences are gathered for one chain selection
+    n_ctg = len(w.ctgs)
+    hip.pag_travel_path_oriented.restype = C.c_void_p
+    hip.pag_travel_path_oriented.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    paths = (C.c_void_p * (2 * n_ctg))()
+    lens = (C.c_uint64 * (2 * n_ctg))()
+    keep = []
+    tp = (C.c_uint32 * 2 + C.c_uint64 * 1 + C.c_double * 2 + C.c_uint64 * 1)  # noqa: F841  (pag_travel_params layout, see below)
+
+    class TravelParams(C.Structure):
+        _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
+                    ("start_split", C.c_double), ("min_len", C.c_uint64)]
+    prm = TravelParams(sp.threads, 0, 2 * sp.eps, 0.15, 0.90, 50)
+    ctg_seqs, ref_seqs = seqs[0], seqs[1]
+    ref_len = np.array([len(w.ref)], dtype=np.uint32)
+    hip.pag_travel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    for r, g in enumerate(gs):
+        mine = np.array([orient[c] if c % n_shards == r else -1 for c in range(n_ctg)], dtype=np.int32)
+        assert hip.pag_travel(g, C.byref(ctg_seqs), mine.ctypes.data, ref_len.ctypes.data, 1, C.byref(prm), None) == 0, hip.pag_last_error()
+        for c in range(n_ctg):
+            if mine[c] < 0:
+                continue
+            n = C.c_uint64()
+            p = hip.pag_travel_path_oriented(g, c, int(mine[c] != 0), C.byref(n))
+            buf = C.create_string_buffer(C.string_at(p, n.value * 24), n.value * 24) if n.value else None  # (the "gather")
+            keep.append(buf)
+            slot = 2 * c + (0 if mine[c] else 1)
+            paths[slot] = C.cast(buf, C.c_void_p).value if buf is not None else None
+            lens[slot] = n.value
+    out = str(workdir / f"sh{n_shards}_gathered")
+    os.makedirs(out, exist_ok=True)
+    tsG = bench.TraverseStats()
+    host.pagh_assemble_paths.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p]
+    rc = host.pagh_assemble_paths(None, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, paths, lens, sp.threads, sp.eps, 50,
+                                  out.encode(), b"0_", 0, C.byref(tsG))
+    assert rc == 0, host.pagh_last_error()
+    one = str(workdir / f"sh{n_shards}_one")
+    for d in (str(workdir / f"sh{n_shards}_all"), out):
+        assert sorted(os.listdir(d)) == sorted(os.listdir(one))
+        for f in os.listdir(one):
+            assert open(os.path.join(d, f), "rb").read() == open(os.path.join(one, f), "rb").read(), f"{d}: {f}"
+    assert (tsG.n_path_nodes, tsG.n_path_bases, tsG.path_checksum) == (ts1.n_path_nodes, ts1.n_path_bases, ts1.path_checksum)
+    for g in gs + [g1]:
+        hip.pag_destroy(C.c_void_p(g))

@@ -47,3 +47,86 @@ def test_sharded_run_world2_gloo(tmp_path):
     assert done == [f"ref{i}" for i in range(5)]
     owners = {d: open(tmp_path / d / "DONE").read().split()[0] for d in done}
     assert set(owners.values()) == {"rank0", "rank1"}  # both ranks did work
+
+
+# ---- one graph over several ranks: the exchange of real tuples (SURVEY §8e level 2) -------------------------------------
+def _oracle_streams_with_reads(in_dir):
+    """The C oracle's emitted tuple / edge streams of a small synthetic block + the emission position of the read that
+    emitted every record (test hook pago_debug_stream_reads)."""
+    import ctypes as C
+    import numpy as np
+    import pagctl
+    inp = pagctl.LoadedInput(in_dir, threads=4, eps=10, cov=2)
+    lib = pagctl.oracle_lib()
+    g = lib.pago_create(inp.kmer_words, inp.n_kmer_words, inp.k)
+    lib.pago_debug_enable(g, 1)
+    st = pagctl.BuildStats()
+    assert lib.pago_process(g, inp.view, C.byref(st)) == 0
+    nt, ne = C.c_uint64(), C.c_uint64()
+    lib.pago_debug_stream_sizes(g, C.byref(nt), C.byref(ne))
+    s = {"tkey": np.zeros(nt.value, np.uint32), "tval": np.zeros(nt.value, np.uint64), "ekey": np.zeros(ne.value, np.uint32),
+         "eval": np.zeros(ne.value, np.uint64), "tread": np.zeros(nt.value, np.uint32), "eread": np.zeros(ne.value, np.uint32)}
+    lib.pago_debug_streams(g, *[s[k].ctypes.data for k in ("tkey", "tval", "ekey", "eval")])
+    lib.pago_debug_stream_reads.argtypes = [C.c_void_p] * 3
+    lib.pago_debug_stream_reads(g, s["tread"].ctypes.data, s["eread"].ctypes.data)
+    n_reads = C.cast(inp.view, C.POINTER(C.c_uint64))[1]  # pag_build_input: {u32 on_device, u32 n_threads, pag_seqs reads{u64 n_seqs ...}}
+    t1, e1 = int(st.n_tuples[0]), int(st.n_edges[0])
+    lib.pago_destroy(g)
+    inp.close()
+    return s, int(n_reads), int(inp.k), t1, e1
+
+
+def _shard_worker(rank, world, port, in_dir, out_dir):
+    import numpy as np
+    import torch
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = parallel.init("gloo")
+    s, n_reads, k, t1_all, e1_all = _oracle_streams_with_reads(in_dir)
+    lg = {1: 0, 2: 1, 4: 2, 8: 3}[world]
+    lo, hi = n_reads * rank // world, n_reads * (rank + 1) // world
+    res = {}
+    for name, n1_all in (("t", t1_all), ("e", e1_all)):
+        key, val, rd = s[name + "key"], s[name + "val"], s[name + "read"]
+        is_p1 = np.arange(len(key)) < n1_all
+        # what THIS rank would extract: the records of its reads, in canonical order (pass 1 then pass 2, emission order)
+        mine = (rd >= lo) & (rd < hi)
+        mk, mv, mp1 = key[mine], val[mine], is_p1[mine]
+        owner = (mk >> np.uint32(2 * k - lg)).astype(np.int64) if lg else np.zeros(len(mk), np.int64)
+        order = np.argsort(owner, kind="stable")  # = the stable partition of pag_shard_extract
+        mk, mv, mp1, owner = mk[order], mv[order], mp1[order], owner[order]
+        counts = np.zeros((world, 2), np.int64)
+        for o in range(world):
+            counts[o, 0] = int(((owner == o) & mp1).sum())
+            counts[o, 1] = int(((owner == o) & ~mp1).sum())
+        allc = [torch.zeros(world, 2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allc, torch.from_numpy(counts))
+        allc = torch.stack(allc).numpy()  # [src][dst][pass]
+        (rk, rv), n1 = parallel.exchange_stream((torch.from_numpy(mk.view(np.int32)), torch.from_numpy(mv.view(np.int64))), allc, rank, world, dist=dist)
+        rk, rv = rk.numpy().view(np.uint32), rv.numpy().view(np.uint64)
+        # the owner's merge: stable sort by k-mer of [pass 1 from rank 0 ..][pass 2 from rank 0 ..]
+        so = np.argsort(rk, kind="stable")
+        got_k, got_v = rk[so], rv[so]
+        # expectation from the un-sharded stream: the records of this owner's k-mer range, stably sorted by k-mer
+        gowner = (key >> np.uint32(2 * k - lg)).astype(np.int64) if lg else np.zeros(len(key), np.int64)
+        sel = gowner == rank
+        wk, wv = key[sel], val[sel]
+        wo = np.argsort(wk, kind="stable")
+        assert n1 == int((sel & is_p1).sum())
+        assert np.array_equal(got_k, wk[wo]) and np.array_equal(got_v, wv[wo]), f"rank {rank}: stream {name} differs after the exchange"
+        res[name] = int(len(got_k))
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(f"{res['t']} {res['e']} {int(sel.sum())}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tuple_exchange_world2_gloo_restores_the_canonical_order(tmp_path):
+    """Real tuples (the C oracle's emitted streams of a synthetic block, 4-thread emission order) through the exchange the
+    multi-GPU build uses — all_to_all_single with split sizes, here over gloo — and the owner-side layout + stable merge:
+    every owner ends up with exactly the records of its k-mer range in exactly the order a single process has them."""
+    import synth
+    d = str(tmp_path / "in")
+    synth.generate(synth.Spec(seed=11, ref_len=9000, n_reads=300, read_len=800, k=8, contigs=[(150, 4200, False), (4450, 8850, True)]), d)
+    port = 29500 + (os.getpid() + 17) % 1000
+    mp.spawn(_shard_worker, args=(2, port, d, str(tmp_path)), nprocs=2, join=True)
+    got = [open(tmp_path / f"rank{r}.txt").read().split() for r in range(2)]
+    assert all(int(g[0]) > 100 and int(g[1]) > 100 for g in got)  # both owners received records
