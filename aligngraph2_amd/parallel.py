@@ -135,6 +135,13 @@ def layout_received(chunks, counts_to_me):
     return torch.cat(p1 + p2), int(sum(int(c[0]) for c in counts_to_me))
 
 
+def _is_gloo(dist):
+    try:
+        return dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
 def exchange_stream(arrays, counts, rank, world, dist=None, peers=None):
     """One tuple stream (a tuple of parallel 1-D tensors, e.g. (keys u32-as-i32, values u64-as-i64)), partitioned by owner
     as pag_shard_extract leaves it, to its owners.
@@ -155,8 +162,14 @@ def exchange_stream(arrays, counts, rank, world, dist=None, peers=None):
                 off = sum(int(counts[r][o][0] + counts[r][o][1]) for o in range(rank))
                 chunks.append(peers[r][ai][off:off + recv_splits[r]])
         else:
-            recv = torch.empty(sum(recv_splits), dtype=a.dtype, device=a.device)
-            dist.all_to_all_single(recv, a.contiguous(), recv_splits, send_splits)
+            # (gloo moves host memory only: the single-device test hook of bench.py stages through the host; RCCL sends
+            # device memory over xGMI directly)
+            stage = a.device.type != "cpu" and _is_gloo(dist)
+            src = a.contiguous().cpu() if stage else a.contiguous()
+            recv = torch.empty(sum(recv_splits), dtype=a.dtype, device=src.device)
+            dist.all_to_all_single(recv, src, recv_splits, send_splits)
+            if stage:
+                recv = recv.to(a.device)
             chunks = list(torch.split(recv, recv_splits))
         laid, n1 = layout_received(chunks, [counts[r][rank] for r in range(world)])
         out.append(laid.contiguous())
@@ -244,15 +257,17 @@ def build_sharded(hip, g, inp, eps, dist, device):
     import numpy as np
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
+    cdev = "cpu" if _is_gloo(dist) else device  # where the collectives' buffers live
+
+    def all_gather(t):
+        src = t.to(cdev)
+        outs = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(outs, src)
+        return outs
+
     sb = ShardedBuild(hip, g, inp, rank, world, device)
     counts, tuples, edges = sb.extract()
-    allc = torch.zeros(world, world, 4, dtype=torch.int64, device=device)
-    mine = torch.from_numpy(counts).to(device)
-    gathered = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    for r in range(world):
-        allc[r] = gathered[r]
-    allc = allc.cpu().numpy()
+    allc = torch.stack(all_gather(torch.from_numpy(counts))).cpu().numpy()  # [src][dst][4]
     rt, t1 = exchange_stream(tuples, allc[:, :, 0:2], rank, world, dist=dist)
     re, e1 = exchange_stream(edges, allc[:, :, 2:4], rank, world, dist=dist)
     del tuples, edges
@@ -260,22 +275,69 @@ def build_sharded(hip, g, inp, eps, dist, device):
     del rt, re
     sl, st = sb.export()
     # all-gather of the slices (padded to the largest; sizes first)
-    sizes = torch.tensor([sl["tkey"].numel(), sl["ekey"].numel()], dtype=torch.int64, device=device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    all_sizes = [x.cpu().tolist() for x in all_sizes]
+    all_sizes = [x.cpu().tolist() for x in all_gather(torch.tensor([sl["tkey"].numel(), sl["ekey"].numel()], dtype=torch.int64))]
     slices = [dict() for _ in range(world)]
     for name in ("tkey", "tval", "tseg", "tcnt", "ekey", "eval", "eseg"):
         which = 0 if name[0] == "t" else 1
         mx = max(s[which] for s in all_sizes)
         pad = torch.zeros(mx, dtype=sl[name].dtype, device=device)
         pad[:sl[name].numel()] = sl[name]
-        outs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(outs, pad)
+        outs = all_gather(pad)
         for r in range(world):
-            slices[r][name] = outs[r][:all_sizes[r][which]].contiguous()
-    st_bytes = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(device)
-    all_st = [torch.empty_like(st_bytes) for _ in range(world)]
-    dist.all_gather(all_st, st_bytes)
+            slices[r][name] = outs[r][:all_sizes[r][which]].to(device).contiguous()
+    all_st = all_gather(torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8))
     stats_list = [BuildStats.from_buffer_copy(bytes(x.cpu().numpy().tobytes())) for x in all_st]
     return sb.import_all(slices, stats_list)
+
+
+def deal_contigs(lengths, world):
+    """contigs -> ranks for the traversal (longest first, as assign_blocks)"""
+    return assign_blocks(list(lengths), world)
+
+
+def gather_paths(hip, g, mine, n_ctgs, dist, device):
+    """Travel sequences of the contigs this rank walked (pag_travel with the others PAG_ORIENT_NONE) -> on every rank, the
+    arrays pagh_assemble_paths takes: (paths[2 * n_ctgs] of c_void_p, lens[2 * n_ctgs], keep-alive buffers).
+    mine: {slot = 2 * contig + (reverse ? 1 : 0)} this rank walked."""
+    import numpy as np
+    import torch
+    world = dist.get_world_size() if dist else 1
+    REC = 24  # sizeof(pag_path_node)
+    hip.pag_travel_path_oriented.restype = _C.c_void_p
+    hip.pag_travel_path_oriented.argtypes = [_C.c_void_p, _C.c_uint64, _C.c_int, _C.POINTER(_C.c_uint64)]
+    meta = np.zeros((2 * n_ctgs,), dtype=np.int64)
+    chunks = []
+    for slot in sorted(mine):
+        n = _C.c_uint64()
+        p = hip.pag_travel_path_oriented(_C.c_void_p(g), slot // 2, 1 if slot % 2 == 0 else 0, _C.byref(n))
+        meta[slot] = n.value
+        if n.value:
+            chunks.append(np.frombuffer(_C.string_at(p, n.value * REC), dtype=np.uint8))
+    blob = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    if dist is None or world == 1:
+        all_meta, all_blob = [meta], [blob]
+    else:
+        cdev = "cpu" if _is_gloo(dist) else device
+        m = torch.from_numpy(meta).to(cdev)
+        ms = [torch.empty_like(m) for _ in range(world)]
+        dist.all_gather(ms, m)
+        all_meta = [x.cpu().numpy() for x in ms]
+        mx = max(int(x.sum()) * REC for x in all_meta)
+        pad = torch.zeros(mx, dtype=torch.uint8, device=cdev)
+        pad[:len(blob)] = torch.from_numpy(blob.copy()).to(cdev)
+        bs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bs, pad)
+        all_blob = [b.cpu().numpy() for b in bs]
+    paths = (_C.c_void_p * (2 * n_ctgs))()
+    lens = (_C.c_uint64 * (2 * n_ctgs))()
+    keep = []
+    for mt, bl in zip(all_meta, all_blob):
+        at = 0
+        bl = np.ascontiguousarray(bl)
+        keep.append(bl)
+        for slot in range(2 * n_ctgs):
+            if mt[slot]:
+                paths[slot] = bl.ctypes.data + at
+                lens[slot] = int(mt[slot])
+                at += int(mt[slot]) * REC
+    return paths, lens, keep

@@ -7,9 +7,16 @@ extraction + sampling, tuple emission, stable k-mer sort, epsilon cluster, edge 
 by pagh_traverse (graph export, per-contig epsilon-join traversal, FASTA/.con/.help/.txt writers).
 
 N = 1 workload = BASELINE.json configs[1]: 100k x 10 kb reads vs a 50 Mb yeast-like reference, k = 14,
-epsilon = 10.  N > 1: the path shards by reference sequence (SURVEY.md §8e level 1): every rank owns
-one independent config block of the same size (different seed) — weak scaling, no data-path collective;
-torch.distributed (RCCL) is only used for the barrier and the max-over-ranks time.
+epsilon = 10.  N > 1, two ways:
+  --mode blocks (default)  the path shards by reference sequence (level 1): every rank owns one independent config
+                block of the same size (different seed) — weak scaling, no data-path collective; torch.distributed
+                (RCCL) is only used for the barrier and the max-over-ranks time.  This is how BASELINE configs[3] (a
+                genome of 24 reference sequences) spreads over a node.
+  --mode shard  ONE config block built by all ranks (level 2): reads split over the ranks for the extraction, k-mer
+                ranges for the sort / cluster / edge stages, one all-to-all(v) of tuples and one all-gather of the
+                finished slices over xGMI in between (aligngraph2_amd/parallel.py); the contigs are dealt out over the
+                ranks for the traversal and rank 0 selects the chains.  Strong scaling: the block is the same whatever N.
+                BASELINE configs[2] is `--gpus 4 --mode shard --reads 1000000 --ref-len 250000000`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
 kernel (the radix scatter of the k-mer sort) and `cpu_baseline` (the compiled reference pagraph, or the
@@ -135,6 +142,7 @@ def main():
     ap.add_argument("--ref-len", type=int, default=50_000_000)
     ap.add_argument("--k", type=int, default=14)
     ap.add_argument("--epsilon", type=int, default=10)
+    ap.add_argument("--mode", choices=["blocks", "shard"], default="blocks", help="N > 1: one block per rank, or ONE block over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--build-only", action="store_true", help="diagnostic: skip traversal (NOT a valid bench line)")
     args = ap.parse_args()
@@ -155,7 +163,8 @@ def main():
 
     import biggen
     hip, host = load_libs()
-    spec = biggen.BigSpec(seed=2 + rank, ref_len=args.ref_len, n_reads=args.reads, read_span=args.read_span, k=args.k,
+    shard = args.mode == "shard" and world > 1
+    spec = biggen.BigSpec(seed=2 + (0 if shard else rank), ref_len=args.ref_len, n_reads=args.reads, read_span=args.read_span, k=args.k,
                           eps=args.epsilon, cov=2, threads=16)
     w = biggen.BigWorkload(spec, device=f"cuda:{local}")
     torch.cuda.synchronize()
@@ -202,8 +211,49 @@ def main():
     ts = TraverseStats()
 
     wall = {"process": 0.0, "traverse": 0.0}
+    dev_name = f"cuda:{local}"
+    if shard:
+        import test_gpu_shards  # (ctypes signatures of the shard entry points)
+        test_gpu_shards._bind(hip)
+        hip.pag_travel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        host.pagh_assemble_paths.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p]
+        deal = parallel.deal_contigs([e - s for s, e, _ in w.ctgs], world)
+        my_orient = np.full(len(w.ctgs), -1, dtype=np.int32)
+        for c in deal[rank]:
+            my_orient[c] = orient[c]
+        my_slots = {2 * c + (0 if orient[c] else 1) for c in deal[rank]}
+        ref_len_arr = np.array([len(ref_np)], dtype=np.uint32)
+
+        class TravelParams(C.Structure):
+            _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
+                        ("start_split", C.c_double), ("min_len", C.c_uint64)]
+        tparams = TravelParams(spec.threads, 0, 2 * spec.eps, 0.15, 0.90, 50)
+
+    def step_shard():
+        # ONE block over all ranks: sharded build, every rank then holds the graph; the contigs are dealt out for the walks,
+        # the travel sequences gathered, rank 0 selects the chains and writes the outputs
+        nonlocal st
+        tp0 = time.perf_counter()
+        st = parallel.build_sharded(hip, g, inp, spec.eps, dist, dev_name)
+        wall["process"] += time.perf_counter() - tp0
+        if args.build_only:
+            return
+        tp1 = time.perf_counter()
+        rc = hip.pag_travel(g, C.byref(ctg_seqs), my_orient.ctypes.data, ref_len_arr.ctypes.data, 1, C.byref(tparams), None)
+        if rc != 0:
+            raise SystemExit(f"pag_travel failed ({rc}): {hip.pag_last_error().decode()}")
+        paths, lens, keep = parallel.gather_paths(hip, g, my_slots, len(w.ctgs), dist, dev_name)
+        if rank == 0:
+            rc = host.pagh_assemble_paths(None, spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, paths, lens,
+                                          spec.threads, spec.eps, 50, out_dir.encode(), b"0_", 0, C.byref(ts))
+            if rc != 0:
+                raise SystemExit(f"pagh_assemble_paths failed ({rc}): {host.pagh_last_error().decode()}")
+        wall["traverse"] += time.perf_counter() - tp1
 
     def step():
+        if shard:
+            return step_shard()
         tp0 = time.perf_counter()
         rc = hip.pag_process(g, C.byref(inp), C.byref(st))
         wall["process"] += time.perf_counter() - tp0
@@ -236,8 +286,10 @@ def main():
     def check_known_answer():
         # the default workload's traversal was checked once against the host restatement of the reference's traversal
         # (tests/walk_check.py, 58 s of host walking): any later change of the path is a parity bug, not a speed-up
-        key = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon, 2 + rank)
+        key = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon, 2 + (0 if shard else rank))
         want = KNOWN_PATHS.get(key)
+        if shard and rank != 0:
+            return  # (the chains are selected on rank 0)
         if want and not args.build_only and (int(ts.n_path_nodes), f"{int(ts.path_checksum):016x}") != want:
             raise SystemExit(f"traversal differs from the verified result for this workload: "
                              f"{(int(ts.n_path_nodes), f'{int(ts.path_checksum):016x}')} vs {want}")
@@ -259,6 +311,8 @@ def main():
     dt = time.perf_counter() - t0
     check_known_answer()  # (outside the timed region)
     dt_max, total_bases = parallel.aggregate(dist, dt, float(w.n_bases), device="cpu" if one_device else f"cuda:{local}")
+    if shard:
+        total_bases = float(w.n_bases)  # one block, whatever the number of ranks
 
     if rank == 0:
         ms_sort = float(np.mean(sort_ms))
@@ -279,12 +333,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.reads} x {args.read_span // 1000} kb reads vs {args.ref_len / 1e6:g} Mb reference per GPU, "
+                "workload": f"{args.reads} x {args.read_span // 1000} kb reads vs {args.ref_len / 1e6:g} Mb reference {'in ONE block' if shard else 'per GPU'}, "
                             f"k={args.k}, epsilon={args.epsilon}, -t 16 semantics (BASELINE configs[1])"
                             + (" [BUILD ONLY, diagnostic]" if args.build_only else ""),
                 "read_bases_per_gpu": w.n_bases,
@@ -293,7 +347,9 @@ def main():
                 "position_tuples": int(st.n_tuples[0] + st.n_tuples[1]),
                 "edge_tuples": int(st.n_edges[0] + st.n_edges[1]),
                 "vertices": int(st.n_pos),
-                "sharding": "one reference-sequence block per GPU, no data-path collective",
+                "sharding": ("ONE block over all GPUs: reads split for the extraction, k-mer ranges for sort/cluster/edges, all-to-all(v) of "
+                             "tuples + all-gather of the slices, contigs dealt out for the walks") if shard else
+                            "one reference-sequence block per GPU, no data-path collective",
                 "ms_build_device": float(np.mean(build_ms)),
                 "ms_pag_process_wall": wall["process"] / args.steps * 1e3, "ms_pagh_traverse_wall": wall["traverse"] / args.steps * 1e3,
                 "ms_extract": st.ms_extract, "ms_sort": st.ms_sort, "ms_cluster": st.ms_cluster, "ms_edges": st.ms_edges,

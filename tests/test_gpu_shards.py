@@ -127,7 +127,6 @@ def test_n_shards_build_the_graph_of_one(n_shards, workdir):
     paths = (C.c_void_p * (2 * n_ctg))()
     lens = (C.c_uint64 * (2 * n_ctg))()
     keep = []
-    tp = (C.c_uint32 * 2 + C.c_uint64 * 1 + C.c_double * 2 + C.c_uint64 * 1)  # noqa: F841  (pag_travel_params layout, see below)
 
     class TravelParams(C.Structure):
         _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
@@ -165,3 +164,26 @@ def test_n_shards_build_the_graph_of_one(n_shards, workdir):
     assert (tsG.n_path_nodes, tsG.n_path_bases, tsG.path_checksum) == (ts1.n_path_nodes, ts1.n_path_bases, ts1.path_checksum)
     for g in gs + [g1]:
         hip.pag_destroy(C.c_void_p(g))
+
+
+@pytest.mark.gpu
+def test_bench_shard_mode_two_processes_equal_one(workdir):
+    """bench.py --mode shard with TWO processes (one device, gloo staged through the host: the PAG_BENCH_SINGLE_DEVICE hook) —
+    the real multi-process control path: all_to_all_single of the tuples, all-gather of the slices, contigs dealt out,
+    paths gathered, chains selected on rank 0 — against the one-process run of the same block: same graph, same paths."""
+    import json
+    import subprocess
+    size = ["--reads", "3000", "--ref-len", "3000000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(pagctl.ROOT, "bench.py")] + size, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    env = dict(os.environ, PAG_BENCH_SINGLE_DEVICE="1")
+    port = 29600 + os.getpid() % 300
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(pagctl.ROOT, "bench.py"), "--gpus", "2", "--mode", "shard"] + size,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong"
+    for kk in ("position_tuples", "edge_tuples", "vertices", "path_nodes", "path_bases", "path_checksum", "chains"):
+        assert d1["config"][kk] == d2["config"][kk], kk
