@@ -260,10 +260,11 @@ def build_sharded(hip, g, inp, eps, dist, device):
     cdev = "cpu" if _is_gloo(dist) else device  # where the collectives' buffers live
 
     def all_gather(t):
-        src = t.to(cdev)
+        # as bytes: neither RCCL nor gloo carries every dtype (the u16 abundances are int16 tensors here)
+        src = t.to(cdev).contiguous().view(torch.uint8)
         outs = [torch.empty_like(src) for _ in range(world)]
         dist.all_gather(outs, src)
-        return outs
+        return [o.view(t.dtype) for o in outs]
 
     sb = ShardedBuild(hip, g, inp, rank, world, device)
     counts, tuples, edges = sb.extract()

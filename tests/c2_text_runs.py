@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""One-off measurement (GPU box): BASELINE configs[1] as TEXT files, through (a) the compiled reference `pagraph -t 64`
+(oracle/_ref, natural threads: a timing run, its outputs are not compared) and (b) the drop-in bin/pagraph — wall clock of
+both whole programs, file parsing included.  Writes a JSON record that bench.py quotes as the like-for-like CPU baseline
+(`cpu_baseline.full_workload`) and as `file_to_file_bases_per_s`; the record is committed under profiles/.
+
+usage: python tests/c2_text_runs.py OUT.json [--reads N --ref-len L]"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--reads", type=int, default=100_000)
+    ap.add_argument("--ref-len", type=int, default=50_000_000)
+    ap.add_argument("--ref-threads", type=int, default=64)
+    args = ap.parse_args()
+    import biggen
+    import synth
+    sp = biggen.BigSpec(seed=2, ref_len=args.ref_len, n_reads=args.reads, k=14, eps=10, cov=2, threads=16)
+    t0 = time.time()
+    w = biggen.BigWorkload(sp, device="cuda")
+    d = "/dev/shm/c2_text"
+    shutil.rmtree(d, ignore_errors=True)
+    w.write_text(d)
+    n_bases = w.n_bases
+    del w
+    rec = {"workload": f"{args.reads} x 10 kb reads vs {args.ref_len / 1e6:g} Mb reference, k=14, epsilon=10 (BASELINE configs[1], seed 2), text inputs in /dev/shm",
+           "read_bases": n_bases, "host_cores": os.cpu_count(), "generate_and_write_s": time.time() - t0,
+           "input_bytes": {f: os.path.getsize(os.path.join(d, f)) for f in sorted(os.listdir(d))}}
+    print(rec, flush=True)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "pagraph")
+    ours = os.path.join(ROOT, "aligngraph2_amd", "bin", "pagraph")
+    for name, exe, threads, env in (("reference", ref_bin, args.ref_threads, {}), ("ours", ours, 16, {"PAGRAPH_TIMING": "1"})):
+        out = f"/dev/shm/c2_out_{name}"
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        t0 = time.time()
+        r = subprocess.run(synth.pagraph_argv(exe, d, out, threads=threads, epsilon=10, cov=2), capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        dt = time.time() - t0
+        rec[name] = {"program": os.path.relpath(exe, ROOT), "threads_flag": threads, "returncode": r.returncode, "wall_s": dt,
+                     "bases_per_s": n_bases / dt, "output_files": len(os.listdir(out)),
+                     "count_lines": [ln.strip() for ln in r.stdout.splitlines() if ln.strip().startswith(("merge edge", "total pos", "merge pos"))],
+                     "stderr_tail": r.stderr[-3000:] if name == "ours" else r.stderr[-300:]}
+        print(name, rec[name]["wall_s"], rec[name]["bases_per_s"], flush=True)
+        shutil.rmtree(out, ignore_errors=True)
+    shutil.rmtree(d, ignore_errors=True)
+    json.dump(rec, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
