@@ -2160,19 +2160,25 @@ __global__ __launch_bounds__(64) void k_seed_first(TravGraph G, const TravContig
 
 // searchPANode2 (PAlgorithm.tcc:329-365): every (contig offset in [left, right], position) pair whose
 // position lies on this strand within `dev` of `pos`, in order.  Duplicates of a vertex are removed on
-// the host (first occurrence wins).  One wave per request.  out[0] = count, then vertex ids.
+// the host (first occurrence wins).  TRAV_SEED_PARTS waves per request, each scanning one part of the offset range
+// (the window spans 1000 x deviation offsets on either side); part p of request r writes out[(r * PARTS + p) * stride]:
+// [0] = count, then vertex ids; the host concatenates the parts in order.
 __global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravContig *__restrict__ ctgs,
                                                     const TravSeedReq *__restrict__ reqs, uint32_t n_req, uint64_t dev,
                                                     uint32_t *__restrict__ out, uint32_t out_stride) {
-    const uint32_t r = blockIdx.x;
+    const uint32_t r = blockIdx.x, part = blockIdx.y;
     if (r >= n_req) return;
     const TravSeedReq R = reqs[r];
     const TravContig C = ctgs[R.ctg];
     const uint32_t lane = lane_id();
-    uint32_t *o = out + (uint64_t)r * out_stride;
+    uint32_t *o = out + ((uint64_t)r * TRAV_SEED_PARTS + part) * out_stride;
     uint32_t n_out = 0;
-    uint64_t right = R.right < (uint64_t)C.n_kmers ? R.right + 1 : C.n_kmers;  // exclusive
-    for (uint64_t base = R.left; base < right; base += 64) {
+    const uint64_t right_all = R.right < (uint64_t)C.n_kmers ? R.right + 1 : C.n_kmers;  // exclusive
+    const uint64_t span = right_all > R.left ? right_all - R.left : 0;
+    const uint64_t per = ((span + TRAV_SEED_PARTS - 1) / TRAV_SEED_PARTS + 63) & ~63ull;  // offsets per part (whole wave rows)
+    const uint64_t left = R.left + (uint64_t)part * per;
+    const uint64_t right = left + per < right_all ? left + per : right_all;
+    for (uint64_t base = left; base < right; base += 64) {
         uint64_t i = base + lane;
         uint32_t node = i < right ? C.nodes[i] : PAG_NONE;
         uint32_t p0 = 0, p1 = 0;
@@ -2404,7 +2410,7 @@ void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uin
 }
 void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
                              uint32_t *out, uint32_t stride, hipStream_t s) {
-    if (n) k_seed_window<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out, stride);
+    if (n) k_seed_window<<<dim3(n, TRAV_SEED_PARTS), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out, stride);
 }
 void trav_launch_checkpoints(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev, uint32_t *out,
                              hipStream_t s) {

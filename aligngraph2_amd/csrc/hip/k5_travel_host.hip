@@ -71,7 +71,15 @@ std::string code2kmer(uint32_t code, uint32_t k) {
 
 // PAlgorithm::editDistance (PAlgorithm.cpp:46-69)
 size_t edit_distance(const std::string &a, const std::string &b) {
-    std::vector<std::vector<size_t>> dp(2, std::vector<size_t>(b.size() + 1, 0));
+    // (two rows of the table; on the stack for k-mer sized strings: this runs once per re-seed candidate)
+    size_t stack_rows[2][40];
+    std::vector<size_t> heap_rows;
+    size_t *dp[2] = {stack_rows[0], stack_rows[1]};
+    if (b.size() + 1 > 40) {
+        heap_rows.assign(2 * (b.size() + 1), 0);
+        dp[0] = heap_rows.data();
+        dp[1] = heap_rows.data() + b.size() + 1;
+    }
     size_t flag = 0;
     for (size_t j = 0; j <= b.size(); ++j) dp[flag][j] = j;
     flag ^= 1;
@@ -1362,24 +1370,30 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
         // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
         if (!reqs.empty()) {
-            uint32_t WSTRIDE = 16384;
+            const uint32_t PARTS = TRAV_SEED_PARTS;
+            uint32_t WSTRIDE = 2048;  // words per part of a request
             std::vector<uint32_t> wb;
-            for (;;) {  // (a window with more candidates than the stride is searched again with a larger one)
-                if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc((uint64_t)reqs.size() * WSTRIDE * 4))) return fail(rc);
-                wb.resize((size_t)reqs.size() * WSTRIDE);
+            for (;;) {  // (a part with more candidates than the stride is searched again with a larger one)
+                const size_t words = (size_t)reqs.size() * PARTS * WSTRIDE;
+                if ((rc = b_req.alloc(reqs.size() * sizeof(TravSeedReq))) || (rc = b_seedout.alloc(words * 4))) return fail(rc);
+                uint32_t *hp = (uint32_t *)pinned(words * 4 + 256);
+                if (!hp) return fail(PAG_ENOMEM);
                 hipError_t he = hipMemcpyAsync(b_req.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s);
                 if (upload_contigs() != PAG_OK) he = hipErrorUnknown;
                 trav_launch_seed_window(G, b_tc.as<TravContig>(), b_req.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation,
                                         b_seedout.as<uint32_t>(), WSTRIDE, s);
-                if (he == hipSuccess) he = hipMemcpyAsync(wb.data(), b_seedout.p, wb.size() * 4, hipMemcpyDeviceToHost, s);
+                if (he == hipSuccess) he = hipMemcpyAsync(hp, b_seedout.p, words * 4, hipMemcpyDeviceToHost, s);
                 if (he == hipSuccess) he = hipStreamSynchronize(s);
                 if (he != hipSuccess) {
                     set_error("pag_travel: seed search failed: %s", hipGetErrorString(he));
                     return fail(PAG_EFAULT);
                 }
                 uint32_t most = 0;
-                for (size_t q = 0; q < reqs.size(); ++q) most = std::max(most, wb[q * WSTRIDE]);
-                if (most <= WSTRIDE - 1) break;
+                for (size_t q = 0; q < reqs.size() * PARTS; ++q) most = std::max(most, hp[q * WSTRIDE]);
+                if (most <= WSTRIDE - 1) {
+                    wb.assign(hp, hp + words);
+                    break;
+                }
                 if (most > (1u << 28)) {
                     set_error("pag_travel: seed window with %u candidates", most);
                     return fail(PAG_ENOMEM);
@@ -1389,14 +1403,16 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             std::vector<uint32_t> vids;
             std::vector<size_t> cnt(reqs.size());
             for (size_t q = 0; q < reqs.size(); ++q) {
-                const uint32_t *o = &wb[q * WSTRIDE];
                 std::unordered_set<uint32_t> seen;
                 size_t n = 0;
-                for (uint32_t x = 0; x < o[0]; ++x) {
-                    uint32_t v = o[1 + x];
-                    if (!seen.insert(v).second) continue;         // std::set `unique` in searchPANode2
-                    vids.push_back(v);                            // (filterPANodes was applied by the kernel)
-                    ++n;
+                for (uint32_t part = 0; part < PARTS; ++part) {  // (the parts of the window, in offset order)
+                    const uint32_t *o = &wb[(q * PARTS + part) * WSTRIDE];
+                    for (uint32_t x = 0; x < o[0]; ++x) {
+                        uint32_t v = o[1 + x];
+                        if (!seen.insert(v).second) continue;         // std::set `unique` in searchPANode2
+                        vids.push_back(v);                            // (filterPANodes was applied by the kernel)
+                        ++n;
+                    }
                 }
                 cnt[q] = n;
             }

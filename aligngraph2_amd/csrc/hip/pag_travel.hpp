@@ -126,6 +126,8 @@ struct TravPackDesc {  // one finished job of a fetch batch (k_pack_paths)
     uint64_t off;                   // word offset of the job's 3 * len words in the packed buffer
 };
 
+constexpr uint32_t TRAV_SEED_PARTS = 16;  // waves per re-seed window request (k_seed_window)
+
 struct TravSeedReq {
     uint32_t ctg;
     uint32_t pad;

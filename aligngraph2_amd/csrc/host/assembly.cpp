@@ -1,5 +1,7 @@
 #include "assembly.hpp"
 
+#include <functional>
+
 #include <atomic>
 #include <charconv>
 #include <chrono>
@@ -79,78 +81,97 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     std::vector<std::pair<std::string, bool>> ctgList(ctgSet.begin(), ctgSet.end());
     std::vector<std::string> logs(ctgList.size());
     std::vector<std::int64_t> leapTarget(ctgList.size(), -1);
-    std::atomic<std::size_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            std::size_t li = next.fetch_add(1);
-            if (li >= ctgList.size()) break;
-            auto &ctgName = ctgList[li];
-            std::size_t ctgIdx = contigs.id(ctgName.first);
-            std::size_t ctgOffset = ctgName.second ? 0 : 1;
-            std::stringstream log;
-            SeqTools algo(graph, contigs, refs, ctgMapper, refMapper);
-            log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
-            log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
-            auto &res = results[2 * ctgIdx + ctgOffset];
-            // PAlgorithm::travelSequence ran on the device (pag_travel); its result is taken over here and its storage
-            // handed back at the end: no copy
-            if (2 * ctgIdx + ctgOffset < travelled.size()) res.swap(travelled[2 * ctgIdx + ctgOffset]);
-
-            std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
-            of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
-            {
-                std::string buf;
-                buf.reserve(1 << 20);
-                char num[24];
-                auto putInt = [&](long long v) {
-                    auto r = std::to_chars(num, num + sizeof num, v);
-                    buf.append(num, static_cast<std::size_t>(r.ptr - num));
-                };
-                for (auto &s : res) {
-                    DualPos p = graph.position(s.first);
-                    auto d1 = ctgMapper.singleToDual(p.first);
-                    auto d2 = refMapper.singleToDual(p.second);
-                    buf.append(algo.vertexString(s.first));
-                    buf.push_back('\t');
-                    putInt(s.second);
-                    buf.push_back('\t');
-                    putInt(d1.first);
-                    buf.push_back(',');
-                    putInt(d1.second);
-                    buf.push_back('\t');
-                    putInt(d2.first);
-                    buf.push_back(',');
-                    putInt(d2.second);
-                    buf.push_back('\n');
-                    if (buf.size() >= (1 << 20) - 256) {
-                        of.write(buf.data(), static_cast<std::streamsize>(buf.size()));
-                        buf.clear();
-                    }
-                }
-                of.write(buf.data(), static_cast<std::streamsize>(buf.size()));
-            }
-            if (SeqTools::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
-            if (!res.empty()) {
-                std::uint32_t lastCtgPos = graph.position(res.back().first).first;
-                if (lastCtgPos != 0) {
-                    auto dual = ctgMapper.singleToDual(lastCtgPos);
-                    std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
-                    std::size_t fwd = dual.first > 0 ? 0 : 1;
-                    if (idx != ctgIdx || fwd != ctgOffset) leapTarget[li] = static_cast<std::int64_t>(2 * idx + fwd);
-                }
-            }
-            log << "[Travel] End\n";
-            logs[li] = log.str();
-        }
+    // The path dumps are text, ~60 bytes per path vertex: the lines of every contig are rendered in chunks of 32 Ki
+    // vertices by a pool of host threads (a 1.5 Mb contig alone is 370 k lines), then written contig by contig.
+    const std::size_t CHUNK = 32768;
+    struct DumpChunk {
+        std::size_t li, from, to;
+        std::string text;
     };
-    {
+    std::vector<DumpChunk> chunks;
+    std::vector<std::size_t> firstChunk(ctgList.size() + 1, 0);
+    for (std::size_t li = 0; li < ctgList.size(); ++li) {
+        std::size_t ctgIdx = contigs.id(ctgList[li].first), ctgOffset = ctgList[li].second ? 0 : 1;
+        auto &res = results[2 * ctgIdx + ctgOffset];
+        // PAlgorithm::travelSequence ran on the device (pag_travel); its result is taken over here and its storage
+        // handed back at the end: no copy
+        if (2 * ctgIdx + ctgOffset < travelled.size()) res.swap(travelled[2 * ctgIdx + ctgOffset]);
+        firstChunk[li] = chunks.size();
+        for (std::size_t from = 0; from < res.size(); from += CHUNK) chunks.push_back({li, from, std::min(res.size(), from + CHUNK), std::string()});
+    }
+    firstChunk[ctgList.size()] = chunks.size();
+    auto runPool = [&](std::size_t nTasks, const std::function<void(std::size_t)> &task) {
+        std::atomic<std::size_t> next{0};
+        auto worker = [&]() {
+            for (std::size_t x; (x = next.fetch_add(1)) < nTasks;) task(x);
+        };
         unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
-        nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, ctgList.size())));
+        nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, nTasks)));
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
         worker();
         for (auto &t : pool) t.join();
-    }
+    };
+    runPool(chunks.size(), [&](std::size_t x) {
+        DumpChunk &c = chunks[x];
+        std::size_t ctgIdx = contigs.id(ctgList[c.li].first), ctgOffset = ctgList[c.li].second ? 0 : 1;
+        const auto &res = results[2 * ctgIdx + ctgOffset];
+        SeqTools algo(graph, contigs, refs, ctgMapper, refMapper);
+        std::string &buf = c.text;
+        buf.reserve((c.to - c.from) * 64);
+        char num[24];
+        auto putInt = [&](long long v) {
+            auto r = std::to_chars(num, num + sizeof num, v);
+            buf.append(num, static_cast<std::size_t>(r.ptr - num));
+        };
+        for (std::size_t q = c.from; q < c.to; ++q) {
+            const auto &s = res[q];
+            DualPos p = graph.position(s.first);
+            auto d1 = ctgMapper.singleToDual(p.first);
+            auto d2 = refMapper.singleToDual(p.second);
+            buf.append(algo.vertexString(s.first));
+            buf.push_back('\t');
+            putInt(s.second);
+            buf.push_back('\t');
+            putInt(d1.first);
+            buf.push_back(',');
+            putInt(d1.second);
+            buf.push_back('\t');
+            putInt(d2.first);
+            buf.push_back(',');
+            putInt(d2.second);
+            buf.push_back('\n');
+        }
+    });
+    runPool(ctgList.size(), [&](std::size_t li) {
+        auto &ctgName = ctgList[li];
+        std::size_t ctgIdx = contigs.id(ctgName.first);
+        std::size_t ctgOffset = ctgName.second ? 0 : 1;
+        std::stringstream log;
+        log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
+        log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
+        auto &res = results[2 * ctgIdx + ctgOffset];
+        {
+            std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
+            of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
+            for (std::size_t x = firstChunk[li]; x < firstChunk[li + 1]; ++x) {
+                of.write(chunks[x].text.data(), static_cast<std::streamsize>(chunks[x].text.size()));
+                std::string().swap(chunks[x].text);
+            }
+        }
+        if (SeqTools::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
+        if (!res.empty()) {
+            std::uint32_t lastCtgPos = graph.position(res.back().first).first;
+            if (lastCtgPos != 0) {
+                auto dual = ctgMapper.singleToDual(lastCtgPos);
+                std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
+                std::size_t fwd = dual.first > 0 ? 0 : 1;
+                if (idx != ctgIdx || fwd != ctgOffset) leapTarget[li] = static_cast<std::int64_t>(2 * idx + fwd);
+            }
+        }
+        log << "[Travel] End\n";
+        logs[li] = log.str();
+    });
     lap("per-contig paths + dumps");
     for (std::size_t li = 0; li < ctgList.size(); ++li) {
         out << logs[li];

@@ -157,7 +157,9 @@ int main(int argc, char **argv) {
         std::ofstream of(o.out, std::ios::binary);
         const std::uint64_t k64 = o.k;
         of.write(reinterpret_cast<const char *>(&k64), sizeof k64);
-        const unsigned T = o.threads ? o.threads : 1;  // the reference would not terminate with 0 threads
+        // -t 0: the reference's multiTraversal starts no worker, its availKmer(0) is empty, and the file is the 8-byte
+        // header alone (kmer_counter.cpp:79-95)
+        const unsigned T = o.threads;
         std::vector<std::uint64_t> buf;
         buf.reserve(1 << 16);
         for (unsigned t = 0; t < T; ++t) {

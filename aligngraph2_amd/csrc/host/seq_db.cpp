@@ -60,7 +60,10 @@ void SeqDb::finish() { packed_.resize(packed_.size() + 32, 0); }
 
 SeqDb::SeqDb(const std::string &path) {
     std::ifstream probe(path);
-    if (!probe) throw std::runtime_error("cannot open sequence file: " + path);
+    if (!probe) {  // the reference's AutoSeqDatabase yields an empty database for a file it cannot open (SeqHelper::
+        finish();  // autoLoadFromFile finds no record type, AutoSeqDatabase.cpp:9-22) and pagraph carries on
+        return;
+    }
     std::string first;
     bool fasta = false;
     if (std::getline(probe, first) && !first.empty()) fasta = first.front() == '>' || first.front() == ';';

@@ -64,7 +64,7 @@ def test_kmer_counter_executable_matches_golden(name, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,threads,fmt", [(10, 16, "fastq"), (12, 3, "fasta")])
+@pytest.mark.parametrize("k,threads,fmt", [(10, 16, "fastq"), (12, 3, "fasta"), (9, 0, "fastq")])  # (-t 0: header-only file)
 def test_kmer_counter_executable_matches_reference_binary(k, threads, fmt, tmp_path):
     ref = os.path.join(pagctl.REF_DIR, "kmer_counter")
     if not os.path.exists(ref):
