@@ -567,7 +567,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint32_t win_lo = 0, win_hi = 0;  // new-id range its job keeps direct-mapped marks for (around the segment)
         bool done = false, usable = false, stopped = false;
         Piece P;
-        std::vector<uint64_t> cum;       // cum[i] = sum of the steps of P[0 .. i]
+        std::vector<uint32_t> cum;       // cum[i] = sum of the steps of P[0 .. i] (a segment is a few thousand vertices)
         std::vector<uint32_t> prefmax;   // max coordinate over P[0 .. i]
         std::vector<uint32_t> sufmin;    // min coordinate over P[i ..]
         uint32_t max_back = 0, max_chosen = 0;
@@ -893,7 +893,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         size_t lo = be, hi = P.v.size() - 1;
         while (lo < hi) {
             const size_t mid = (lo + hi + 1) / 2;
-            if (sg.cum[mid] - sg.cum[be] < room) lo = mid;
+            if ((uint64_t)(sg.cum[mid] - sg.cum[be]) < room) lo = mid;
             else hi = mid - 1;
         }
         const size_t last = lo;
@@ -1000,7 +1000,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     DevBuf b_fetch = buf(), b_fdesc = buf();
     uint32_t scan_from[TRAV_RINGS] = {0, 0, 0};  // per ring: every job number below it has been handled
-    double t_progress = now_ms();
+    double t_progress = now_ms(), t_first_fin = 0;
     while (n_live) {
         // ---- jobs that have finished since the last look
         std::vector<uint32_t> fin;
@@ -1010,6 +1010,25 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 const uint32_t slot = ring * QCAP + jn % QCAP;
                 if (jref[slot].live && __atomic_load_n(&hdone[slot], __ATOMIC_ACQUIRE) != 0) fin.push_back(slot);
             }
+        }
+        // A batch costs a kernel launch, a copy and a stream synchronisation (~0.1 ms of this thread): finished SEGMENT jobs
+        // that no chain is waiting for are left to accumulate (up to 64 of them or 1 ms); a finished chain job, or a
+        // segment some chain of its contig waits for, is fetched at once.
+        if (!fin.empty()) {
+            bool urgent = fin.size() >= 64 || (t_first_fin > 0 && now_ms() - t_first_fin > 1.0);
+            for (size_t x = 0; x < fin.size() && !urgent; ++x) {
+                const JobRef &jr = jref[fin[x]];
+                if (jr.kind == 0) urgent = true;
+                else
+                    for (const Chain &ch : RS[jr.ctg].chains)
+                        if (ch.waiting_seg == jr.idx) urgent = true;
+            }
+            if (t_first_fin == 0) t_first_fin = now_ms();
+            if (!urgent) {
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                continue;
+            }
+            t_first_fin = 0;
         }
         if (fin.empty()) {
             if (hipStreamQuery(g->walk_stream) == hipSuccess) {  // the grid is gone although jobs are outstanding
@@ -1106,7 +1125,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                     uint32_t mx = 0;
                     for (size_t x = 0; x < n; ++x) {
                         c2 += sg.P.s[x];
-                        sg.cum[x] = c2;
+                        if (c2 > 0xFFFFFFF0ull) sg.usable = false;  // (never: steps are read offsets)
+                        sg.cum[x] = (uint32_t)c2;
                         mx = std::max(mx, sg.P.pc[x]);
                         sg.prefmax[x] = mx;
                         if (sg.P.pc[x] == 0) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)

@@ -81,50 +81,70 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     std::vector<std::pair<std::string, bool>> ctgList(ctgSet.begin(), ctgSet.end());
     std::vector<std::string> logs(ctgList.size());
     std::vector<std::int64_t> leapTarget(ctgList.size(), -1);
-    // The path dumps are text, ~60 bytes per path vertex: the lines of every contig are rendered in chunks of 32 Ki
-    // vertices by a pool of host threads (a 1.5 Mb contig alone is 370 k lines), then written contig by contig.
-    const std::size_t CHUNK = 32768;
-    struct DumpChunk {
-        std::size_t li, from, to;
-        std::string text;
+    // The path dumps are text, ~60 bytes per path vertex (a 1.5 Mb contig alone is 370 k lines): every contig's lines are
+    // rendered in chunks of 16 Ki vertices by a pool of host threads, each into its own reusable buffer, and appended to
+    // the contig's file in chunk order (a thread waits for its chunk's turn; the chunks are handed out in order, so the
+    // wait is at most one chunk's rendering).
+    const std::size_t CHUNK = 16384;
+    struct DumpFile {
+        std::size_t ctgIdx = 0, ctgOffset = 0, nChunks = 0;
+        std::FILE *f = nullptr;
+        std::atomic<std::size_t> turn{0};
     };
-    std::vector<DumpChunk> chunks;
-    std::vector<std::size_t> firstChunk(ctgList.size() + 1, 0);
+    std::vector<DumpFile> files(ctgList.size());
+    std::vector<std::pair<std::size_t, std::size_t>> chunkOf;  // (file, chunk in file)
     for (std::size_t li = 0; li < ctgList.size(); ++li) {
-        std::size_t ctgIdx = contigs.id(ctgList[li].first), ctgOffset = ctgList[li].second ? 0 : 1;
-        auto &res = results[2 * ctgIdx + ctgOffset];
+        DumpFile &F = files[li];
+        F.ctgIdx = contigs.id(ctgList[li].first);
+        F.ctgOffset = ctgList[li].second ? 0 : 1;
+        auto &res = results[2 * F.ctgIdx + F.ctgOffset];
         // PAlgorithm::travelSequence ran on the device (pag_travel); its result is taken over here and its storage
         // handed back at the end: no copy
-        if (2 * ctgIdx + ctgOffset < travelled.size()) res.swap(travelled[2 * ctgIdx + ctgOffset]);
-        firstChunk[li] = chunks.size();
-        for (std::size_t from = 0; from < res.size(); from += CHUNK) chunks.push_back({li, from, std::min(res.size(), from + CHUNK), std::string()});
+        if (2 * F.ctgIdx + F.ctgOffset < travelled.size()) res.swap(travelled[2 * F.ctgIdx + F.ctgOffset]);
+        F.nChunks = (res.size() + CHUNK - 1) / CHUNK;
+        const std::string path = outDir + "/" + prefix + std::to_string(F.ctgIdx) + "_" + std::to_string(F.ctgOffset) + ".txt";
+        F.f = std::fopen(path.c_str(), "wb");
+        if (!F.f) throw std::runtime_error("cannot write " + path);
+        std::fprintf(F.f, "%s\t%zu\n", ctgList[li].first.c_str(), static_cast<std::size_t>(contigs.length(F.ctgIdx)));
     }
-    firstChunk[ctgList.size()] = chunks.size();
+    // chunk c of every file before chunk c + 1 of any: the threads then append to as many different files as there are
+    // threads (writing new pages of a file is what the kernel serialises)
+    for (std::size_t c = 0;; ++c) {
+        bool any = false;
+        for (std::size_t li = 0; li < files.size(); ++li)
+            if (c < files[li].nChunks) {
+                chunkOf.emplace_back(li, c);
+                any = true;
+            }
+        if (!any) break;
+    }
     auto runPool = [&](std::size_t nTasks, const std::function<void(std::size_t)> &task) {
         std::atomic<std::size_t> next{0};
         auto worker = [&]() {
             for (std::size_t x; (x = next.fetch_add(1)) < nTasks;) task(x);
         };
-        unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
+        unsigned nThreads = hostThreads ? hostThreads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
         nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, nTasks)));
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
         worker();
         for (auto &t : pool) t.join();
     };
-    runPool(chunks.size(), [&](std::size_t x) {
-        DumpChunk &c = chunks[x];
-        std::size_t ctgIdx = contigs.id(ctgList[c.li].first), ctgOffset = ctgList[c.li].second ? 0 : 1;
-        const auto &res = results[2 * ctgIdx + ctgOffset];
+    runPool(chunkOf.size(), [&](std::size_t x) {
+        DumpFile &F = files[chunkOf[x].first];
+        const std::size_t c = chunkOf[x].second;
+        const auto &res = results[2 * F.ctgIdx + F.ctgOffset];
+        const std::size_t from = c * CHUNK, to = std::min(res.size(), from + CHUNK);
         SeqTools algo(graph, contigs, refs, ctgMapper, refMapper);
-        std::string &buf = c.text;
-        buf.reserve((c.to - c.from) * 64);
+        static thread_local std::string buf;
+        buf.clear();
+        buf.reserve(CHUNK * 72);
         char num[24];
         auto putInt = [&](long long v) {
             auto r = std::to_chars(num, num + sizeof num, v);
             buf.append(num, static_cast<std::size_t>(r.ptr - num));
         };
-        for (std::size_t q = c.from; q < c.to; ++q) {
+        for (std::size_t q = from; q < to; ++q) {
             const auto &s = res[q];
             DualPos p = graph.position(s.first);
             auto d1 = ctgMapper.singleToDual(p.first);
@@ -142,36 +162,30 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             putInt(d2.second);
             buf.push_back('\n');
         }
+        while (F.turn.load(std::memory_order_acquire) != c) std::this_thread::yield();
+        std::fwrite(buf.data(), 1, buf.size(), F.f);
+        F.turn.store(c + 1, std::memory_order_release);
     });
-    runPool(ctgList.size(), [&](std::size_t li) {
-        auto &ctgName = ctgList[li];
-        std::size_t ctgIdx = contigs.id(ctgName.first);
-        std::size_t ctgOffset = ctgName.second ? 0 : 1;
+    for (std::size_t li = 0; li < ctgList.size(); ++li) {
+        DumpFile &F = files[li];
+        std::fclose(F.f);
         std::stringstream log;
-        log << "[Travel] " << ctgIdx << " - " << contigs.name(ctgIdx) << " - " << contigs.length(ctgIdx) << "\n";
-        log << "[Travel] " << (ctgOffset == 0 ? "forward" : "reverse") << "\n";
-        auto &res = results[2 * ctgIdx + ctgOffset];
-        {
-            std::ofstream of(outDir + "/" + prefix + std::to_string(ctgIdx) + "_" + std::to_string(ctgOffset) + ".txt");
-            of << ctgName.first << "\t" << contigs.length(ctgIdx) << "\n";
-            for (std::size_t x = firstChunk[li]; x < firstChunk[li + 1]; ++x) {
-                of.write(chunks[x].text.data(), static_cast<std::streamsize>(chunks[x].text.size()));
-                std::string().swap(chunks[x].text);
-            }
-        }
-        if (SeqTools::seqSize(res) < contigs.length(ctgIdx) * startSplit * 0.9) res.clear();
+        log << "[Travel] " << F.ctgIdx << " - " << contigs.name(F.ctgIdx) << " - " << contigs.length(F.ctgIdx) << "\n";
+        log << "[Travel] " << (F.ctgOffset == 0 ? "forward" : "reverse") << "\n";
+        auto &res = results[2 * F.ctgIdx + F.ctgOffset];
+        if (SeqTools::seqSize(res) < contigs.length(F.ctgIdx) * startSplit * 0.9) res.clear();
         if (!res.empty()) {
             std::uint32_t lastCtgPos = graph.position(res.back().first).first;
             if (lastCtgPos != 0) {
                 auto dual = ctgMapper.singleToDual(lastCtgPos);
                 std::size_t idx = static_cast<std::size_t>(std::llabs(dual.first) - 1);
                 std::size_t fwd = dual.first > 0 ? 0 : 1;
-                if (idx != ctgIdx || fwd != ctgOffset) leapTarget[li] = static_cast<std::int64_t>(2 * idx + fwd);
+                if (idx != F.ctgIdx || fwd != F.ctgOffset) leapTarget[li] = static_cast<std::int64_t>(2 * idx + fwd);
             }
         }
         log << "[Travel] End\n";
         logs[li] = log.str();
-    });
+    }
     lap("per-contig paths + dumps");
     for (std::size_t li = 0; li < ctgList.size(); ++li) {
         out << logs[li];
