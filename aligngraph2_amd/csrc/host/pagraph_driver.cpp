@@ -1,5 +1,7 @@
 #include "pagraph_driver.hpp"
 
+#include <sstream>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -176,9 +178,25 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
 
         std::unordered_set<std::string> okCtg;  // same container as the reference: contig.txt order (quirk Q11)
         std::size_t blockNo = 0;
+        // Multi-GPU runs of ONE pagraph invocation (aligngraph2_amd/parallel.py: run_config_blocks): the config blocks are
+        // independent (pagraph.cpp:181-182 resets the graph between them), so every GPU's process gets a list of block
+        // numbers in PAGRAPH_BLOCKS ("0,3,5"), processes only those — under their ORIGINAL numbers, which are the output
+        // file prefixes — and writes its share of contig.txt to contig.txt.part<PAGRAPH_PART>; the launcher merges the parts.
+        std::set<std::size_t> onlyBlocks;
+        const char *blocksEnv = std::getenv("PAGRAPH_BLOCKS");
+        if (blocksEnv) {
+            std::stringstream ss(blocksEnv);
+            std::string tok;
+            while (std::getline(ss, tok, ','))
+                if (!tok.empty()) onlyBlocks.insert(static_cast<std::size_t>(std::stoull(tok)));
+        }
         HostGraph graph;  // (storage reused from block to block)
         std::vector<TravelSequence> precomputed;
         for (auto &cfg : configs) {
+            if (blocksEnv && onlyBlocks.count(blockNo) == 0) {
+                ++blockNo;
+                continue;
+            }
             backend.reset();
             std::cout << "Use Ref: " << cfg.ref << std::endl;
             SeqDb reads(opt.pre + "/" + cfg.readPath);
@@ -223,7 +241,8 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             ++blockNo;
             for (auto &s : successCtg) okCtg.emplace(s.first);
         }
-        std::ofstream ctgList(opt.out + "/contig.txt");
+        const char *part = std::getenv("PAGRAPH_PART");
+        std::ofstream ctgList(opt.out + (blocksEnv ? std::string("/contig.txt.part") + (part ? part : "0") : std::string("/contig.txt")));
         for (auto &c : okCtg) ctgList << c << "\n";
         return EXIT_SUCCESS;
     } catch (const std::exception &e) {

@@ -88,6 +88,68 @@ def pagraph_runner(argv_for_dir: Callable[[str], List[str]]):
     return run_one
 
 
+def read_config_blocks(pre_dir: str):
+    """config.txt as pre_process writes it (reference pre_process.cpp:271-287, read by pagraph.cpp:29-49): per block the
+    reference name, the read file, the two alignment files (relative to pre_dir), then (contig, 1|0) line pairs up to an
+    empty line.  Returns [(ref, read_file, ctg_aln, ref_aln, [(contig, forward)])]."""
+    lines = open(os.path.join(pre_dir, "config.txt")).read().split("\n")
+    blocks, i = [], 0
+    while i + 3 < len(lines):
+        if not lines[i].strip():
+            i += 1
+            continue
+        ref, reads, caln, raln = (lines[i + j].strip() for j in range(4))
+        i += 4
+        ctgs = []
+        while i + 1 < len(lines) and lines[i].strip():
+            ctgs.append((lines[i].strip(), lines[i + 1].strip() != "0"))
+            i += 2
+        blocks.append((ref, reads, caln, raln, ctgs))
+        i += 1
+    return blocks
+
+
+def run_config_blocks(pre_dir: str, out_dir: str, argv: Sequence[str], dist=None, exe: str | None = None) -> List[int]:
+    """The per-reference blocks of ONE pre_process output directory (the scheduler consumes pre_process'
+    config.txt directly, no per-directory loop in Python) spread over the GPUs of the node: blocks are weighed by the size of
+    their read + alignment files, dealt out longest-first (assign_blocks), and every rank runs the drop-in executable ONCE on
+    its GPU for its blocks (PAGRAPH_BLOCKS; output files keep the block's number as prefix, exactly as one process over all
+    blocks would write them).  Rank 0 merges the per-rank shares of contig.txt.  argv: the pagraph arguments (flags as
+    AlignGraph2.py passes them, -p pre_dir -o out_dir included).  Returns the exit codes of all ranks."""
+    from . import PAGRAPH, require_built
+    require_built()
+    blocks = read_config_blocks(pre_dir)
+    sizes = []
+    for _, reads, caln, raln, _ in blocks:
+        sizes.append(sum(os.path.getsize(os.path.join(pre_dir, f)) for f in (reads, caln, raln) if os.path.exists(os.path.join(pre_dir, f))))
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    mine = sorted(assign_blocks(sizes, world)[rank])
+    rc = 0
+    if mine:
+        env = dict(os.environ, PAGRAPH_DEVICE=str(local), PAGRAPH_BLOCKS=",".join(str(b) for b in mine), PAGRAPH_PART=str(rank))
+        rc = subprocess.run([exe or PAGRAPH, *argv], env=env).returncode
+    codes = [rc]
+    if dist is not None:
+        gathered: list = [None] * world
+        dist.all_gather_object(gathered, rc)
+        codes = list(gathered)
+    if rank == 0:
+        names = []
+        for r in range(world):
+            part = os.path.join(out_dir, f"contig.txt.part{r}")
+            if os.path.exists(part):
+                names += open(part).read().split()
+                os.remove(part)
+        with open(os.path.join(out_dir, "contig.txt"), "w") as f:
+            for n in dict.fromkeys(names):
+                f.write(n + "\n")
+    if dist is not None:
+        dist.barrier()
+    return codes
+
+
 # ======================================================================================================
 # ONE graph built by several GPUs (SURVEY.md §8e level 2; C side: include/pagraph_hip.h, pag_shard_*)
 # ======================================================================================================

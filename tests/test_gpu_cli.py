@@ -79,3 +79,24 @@ def test_walker_regrows_its_buffers_and_stays_exact(workdir, monkeypatch):
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     goldens.compare_out_dir(name, out)
+
+
+@pytest.mark.gpu
+def test_config_blocks_dealt_out_over_processes_equal_the_golden(workdir):
+    """PAGRAPH_BLOCKS: the blocks of one config.txt processed by different bin/pagraph processes (what parallel.
+    run_config_blocks does with one process per GPU) — here one after the other on the one GPU — and contig.txt merged."""
+    name = "two_blocks_both_orient_t16"
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / "blocks" / "in"))
+    out = str(workdir / "blocks" / "out")
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    for part, blocks in enumerate(("1", "0")):
+        r = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, PAGRAPH_BLOCKS=blocks, PAGRAPH_PART=str(part)), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    names = []
+    for part in range(2):
+        names += open(os.path.join(out, f"contig.txt.part{part}")).read().split()
+        os.remove(os.path.join(out, f"contig.txt.part{part}"))
+    open(os.path.join(out, "contig.txt"), "w").write("".join(n + "\n" for n in dict.fromkeys(names)))
+    goldens.compare_out_dir(name, out)

@@ -130,3 +130,34 @@ def test_tuple_exchange_world2_gloo_restores_the_canonical_order(tmp_path):
     mp.spawn(_shard_worker, args=(2, port, d, str(tmp_path)), nprocs=2, join=True)
     got = [open(tmp_path / f"rank{r}.txt").read().split() for r in range(2)]
     assert all(int(g[0]) > 100 and int(g[1]) > 100 for g in got)  # both owners received records
+
+
+# ---- config blocks of one pre_process directory over the ranks -------------------------------------------
+def _blocks_worker(rank, world, port, in_dir, out_dir, exe, argv):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = parallel.init("gloo")
+    codes = parallel.run_config_blocks(in_dir, out_dir, argv, dist, exe=exe)
+    assert codes == [0, 0]
+    dist.destroy_process_group()
+
+
+def test_config_blocks_over_two_ranks_equal_the_reference_outputs(tmp_path):
+    """The two-block golden (written by the compiled reference in ONE run) with its blocks dealt out over two ranks: each rank
+    runs the driver once for its block (here the oracle-backed harness build of the same driver, no GPU needed), rank 0 merges
+    contig.txt — the output directory must be the reference's, file for file."""
+    import subprocess
+    import goldens
+    import pagctl
+    import synth
+    subprocess.run(["make", "-C", pagctl.ROOT, "harness"], check=True, capture_output=True)
+    name = "two_blocks_both_orient_t16"
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(tmp_path / "in"))
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    exe = os.path.join(pagctl.ROOT, "tests", "harness", "bin", "pagraph_oracle")
+    argv = synth.pagraph_argv(exe, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])[1:]
+    assert len(parallel.read_config_blocks(ind)) == 2
+    port = 29500 + (os.getpid() + 41) % 1000
+    mp.spawn(_blocks_worker, args=(2, port, ind, out, exe, argv), nprocs=2, join=True)
+    goldens.compare_out_dir(name, out)
