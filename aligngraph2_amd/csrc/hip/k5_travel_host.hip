@@ -647,13 +647,28 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             o_st[j + 1] = o_st[j] + PG * spans[j];
             o_tb[j + 1] = o_tb[j] + spans[j] + 4;
         }
+        // the batch's buffers come out of the walk arena (one allocation of the handle, bump pointer, reset per pag_travel:
+        // a cold process otherwise spends seconds in thousands of hipMalloc calls); the per-(contig, group) slots take over
+        // when the arena is used up
         DevBuf b_sv = cbuf(i, grp, CB_SEQV), b_ss = cbuf(i, grp, CB_SEQS), b_av = cbuf(i, grp, CB_ARV), b_as = cbuf(i, grp, CB_ARS),
                b_ts = cbuf(i, grp, CB_TSET), b_ps = cbuf(i, grp, CB_PSET), b_st = cbuf(i, grp, CB_STAMP), b_tb = cbuf(i, grp, CB_TBITS);
         int r;
-        if ((r = b_sv.alloc(o_seq[nj] * 4)) || (r = b_ss.alloc(o_seq[nj] * 4)) || (r = b_av.alloc(o_seq[nj] * PG * 4)) ||
-            (r = b_as.alloc(o_seq[nj] * PG * 4)) || (r = b_ts.alloc(o_oc[nj] * 8)) || (r = b_ps.alloc(o_oc[nj] * PG * 8)) ||
-            (r = b_st.alloc(o_st[nj] * 4)) || (r = b_tb.alloc(o_tb[nj] * 4)))
-            return r;
+        {
+            const size_t need[8] = {(size_t)o_seq[nj] * 4, (size_t)o_seq[nj] * 4, (size_t)o_seq[nj] * PG * 4, (size_t)o_seq[nj] * PG * 4,
+                                    (size_t)o_oc[nj] * 8, (size_t)o_oc[nj] * PG * 8, (size_t)o_st[nj] * 4, (size_t)o_tb[nj] * 4};
+            DevBuf *bufs[8] = {&b_sv, &b_ss, &b_av, &b_as, &b_ts, &b_ps, &b_st, &b_tb};
+            size_t tot = 0;
+            for (size_t q = 0; q < 8; ++q) tot += (need[q] + 16 + 255) & ~(size_t)255;
+            if (g->walk_arena && g->walk_arena_used + tot <= g->walk_arena_cap) {
+                for (size_t q = 0; q < 8; ++q) {
+                    bufs[q]->p = (char *)g->walk_arena + g->walk_arena_used;
+                    g->walk_arena_used += (need[q] + 16 + 255) & ~(size_t)255;
+                }
+            } else {
+                for (size_t q = 0; q < 8; ++q)
+                    if ((r = bufs[q]->alloc(need[q]))) return r;
+            }
+        }
         PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, o_oc[nj] * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, o_oc[nj] * PG * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, o_st[nj] * 4, s));
@@ -969,6 +984,28 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     };
 
     if (!pinned(64u << 20)) return PAG_ENOMEM;  // (grown later if a batch needs more)
+    {   // the walk arena: sized for the first round of every contig (chain buffers over the whole strand + segment buffers)
+        // plus half again for resumed walks and later rounds; at most 40 % of the free device memory; kept by the handle
+        size_t want = 0;
+        for (uint32_t i = 0; i < n_sel; ++i) {
+            const CtgState &cs = st[i];
+            const size_t span = (size_t)(cs.inHi - cs.inLo) + 8, cap = cs.seqCap, oc = pow2_at_least(cap / 4 + 4096);
+            const size_t chain = cap * 8 + cap * 8 * TRAV_PROBE_GROUPS + oc * 8 * (1 + TRAV_PROBE_GROUPS) + span * 4 * (1 + TRAV_PROBE_GROUPS);
+            const size_t n_seg = cs.len / 12000 + 1, scap = 8192 + 8192, soc = pow2_at_least(scap / 4 + 4096), sspan = span / (n_seg ? n_seg : 1) * 2 + 4096;
+            const size_t seg = scap * 8 + scap * 8 * TRAV_PROBE_GROUPS + soc * 8 * (1 + TRAV_PROBE_GROUPS) + sspan * 4 * (1 + TRAV_PROBE_GROUPS);
+            want += chain * 3 + seg * n_seg * 3 / 2;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
+        if (g->walk_arena_cap < want) {
+            if (g->walk_arena) hipFree(g->walk_arena);
+            g->walk_arena = nullptr;
+            g->walk_arena_cap = 0;
+            if (hipMalloc(&g->walk_arena, want) == hipSuccess) g->walk_arena_cap = want;
+            else g->walk_arena = nullptr;  // (the slots do all the work then)
+        }
+        g->walk_arena_used = 0;
+    }
     const double tw0 = now_ms();
     t_walk0 = tw0;
     g->defer_free = true;

@@ -219,6 +219,7 @@ void pag_destroy(pag_graph *g) {
     if (g->wq_host) hipHostFree(g->wq_host);
     if (g->path_store) hipHostFree(g->path_store);
     if (g->pin_host) hipHostFree(g->pin_host);
+    if (g->walk_arena) hipFree(g->walk_arena);
     if (g->wq_next) hipFree(g->wq_next);
     if (g->walk_stream) hipStreamDestroy(g->walk_stream);
     if (g->solid_bits) hipFree(g->solid_bits);

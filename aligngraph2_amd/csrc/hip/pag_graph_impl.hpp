@@ -55,6 +55,9 @@ struct pag_graph {
     size_t path_cap = 0;
     std::vector<uint64_t> path_off, path_len;
     std::vector<uint8_t> path_valid;  // that orientation was traversed by the last pag_travel
+    // device arena of the walker's job buffers (bump pointer, reset by every pag_travel)
+    void *walk_arena = nullptr;
+    size_t walk_arena_cap = 0, walk_arena_used = 0;
     // pinned host staging area of the traversal (packed job results, uploads)
     void *pin_host = nullptr;
     size_t pin_bytes = 0;

@@ -102,10 +102,6 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         // handed back at the end: no copy
         if (2 * F.ctgIdx + F.ctgOffset < travelled.size()) res.swap(travelled[2 * F.ctgIdx + F.ctgOffset]);
         F.nChunks = (res.size() + CHUNK - 1) / CHUNK;
-        const std::string path = outDir + "/" + prefix + std::to_string(F.ctgIdx) + "_" + std::to_string(F.ctgOffset) + ".txt";
-        F.f = std::fopen(path.c_str(), "wb");
-        if (!F.f) throw std::runtime_error("cannot write " + path);
-        std::fprintf(F.f, "%s\t%zu\n", ctgList[li].first.c_str(), static_cast<std::size_t>(contigs.length(F.ctgIdx)));
     }
     // chunk c of every file before chunk c + 1 of any: the threads then append to as many different files as there are
     // threads (writing new pages of a file is what the kernel serialises)
@@ -130,6 +126,23 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         worker();
         for (auto &t : pool) t.join();
     };
+    // (opening truncates: giving back the pages of a previous run's files is work the kernel does per file, so in parallel)
+    std::atomic<bool> openFailed{false};
+    runPool(files.size(), [&](std::size_t li) {
+        DumpFile &F = files[li];
+        const std::string path = outDir + "/" + prefix + std::to_string(F.ctgIdx) + "_" + std::to_string(F.ctgOffset) + ".txt";
+        F.f = std::fopen(path.c_str(), "wb");
+        if (!F.f) {
+            openFailed = true;
+            return;
+        }
+        std::fprintf(F.f, "%s\t%zu\n", ctgList[li].first.c_str(), static_cast<std::size_t>(contigs.length(F.ctgIdx)));
+    });
+    if (openFailed) {
+        for (auto &F : files)
+            if (F.f) std::fclose(F.f);
+        throw std::runtime_error("cannot write the path dumps into " + outDir);
+    }
     runPool(chunkOf.size(), [&](std::size_t x) {
         DumpFile &F = files[chunkOf[x].first];
         const std::size_t c = chunkOf[x].second;

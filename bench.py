@@ -200,7 +200,7 @@ def main():
 
     # host copies of the contigs / reference for the traversal epilogue (sequence gap filling)
     ref_np = w.ref.cpu().numpy()
-    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_codes = w.contig_codes()
     ctg_seqs, keep1 = host_seqs(ctg_codes)
     ref_seqs, keep2 = host_seqs([ref_np])
     orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)

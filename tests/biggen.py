@@ -2,11 +2,13 @@
 
 Everything is built with torch on the chosen device, so that at bench scale (BASELINE.json config 2:
 100k x 10 kb reads vs a 50 Mb reference) the inputs are resident in HBM before the timed region starts.
-Model (simplified where it does not change the work): reference = i.i.d. ACGT with
-planted repeats; contigs = exact reference segments (mean `ctg_len`, gaps 1-20 kb, ~10 % stored
-reverse-complemented); reads = fixed reference span, uniform start, strand 50/50, PacBio-CLR-like
-errors 3 % sub / 4 % del / 5 % ins; read->ref and read->contig alignments from the simulation truth;
-solid k-mer set by the reference kmer_counter's rule (kmer_counter.cpp:68-77).
+Model: reference = i.i.d. ACGT with planted repeats; TARGET genome = the reference with 1 % SNPs
+and 0.2 % single-base indels (`target_snp`, `target_indel`; 0 / 0 gives the identity); contigs = segments of the
+target (mean `ctg_len`, gaps 1-20 kb, ~10 % stored reverse-complemented), so contig and reference coordinates
+drift apart and the contig->reference alignments carry gaps; reads = fixed span of the target, uniform start,
+strand 50/50, PacBio-CLR-like errors 3 % sub / 4 % del / 5 % ins; read->contig alignments from the simulation
+truth, read->reference alignments = that truth composed with the target->reference alignment; solid k-mer set by
+the reference kmer_counter's rule (kmer_counter.cpp:68-77).
 
 The same generator writes the TEXT form of a workload (FASTQ / 3-line ALN / FASTA / config / kmer.bin),
 which is what the compiled reference needs for the cpu_baseline leg and for parity checks.
@@ -63,6 +65,8 @@ class BigSpec:
     dele: float = 0.04
     ins: float = 0.05
     repeat_frac: float = 0.05
+    target_snp: float = 0.01      # SNPs of the target genome against the reference
+    target_indel: float = 0.002   # single-base indels (half insertions, half deletions)
     threads: int = 16  # the reference's -t: emission order + seed top-K
     eps: int = 10
     cov: int = 2
@@ -107,12 +111,58 @@ class BigWorkload:
             ref[b:b + L] = ref[a:a + L].clone()
         self.ref = ref
 
-        # contigs: exact reference segments
+        # target genome: per reference base keep / SNP / delete, and after it possibly one inserted base.  (Deletions are
+        # never adjacent and an insertion never follows a deleted base, so between two consecutive target bases at most
+        # one reference-only column exists and every indel column is flanked by columns with both bases.)
+        u = torch.rand(G, device=dev, generator=g)
+        t_del = u < sp.target_indel / 2
+        t_snp = (~t_del) & (u < sp.target_indel / 2 + sp.target_snp)
+        t_ins = torch.rand(G, device=dev, generator=g) < sp.target_indel / 2
+        t_del[0] = t_del[-1] = False
+        t_ins[-1] = False
+        t_del[1:] &= ~t_del[:-1]
+        t_del[1:] &= ~t_ins[:-1]  # (no reference-only column right behind a target-only one)
+        t_ins &= ~t_del
+        t_ins[:-1] &= ~t_del[1:]
+        t_snp &= ~t_del
+        shift0 = torch.randint(1, 4, (G,), dtype=torch.uint8, device=dev, generator=g)
+        tb = torch.where(t_snp, (ref + shift0) & 3, ref)
+        ins_b = torch.randint(0, 4, (G,), dtype=torch.uint8, device=dev, generator=g)
+        n_out = (~t_del).to(torch.int64) + t_ins.to(torch.int64)
+        o_end = torch.cumsum(n_out, 0)
+        o_beg = o_end - n_out
+        LT = int(o_end[-1].item())
+        tgt = torch.zeros(LT, dtype=torch.uint8, device=dev)
+        g2r = torch.zeros(LT, dtype=torch.int64, device=dev)     # reference cursor at the target base (exactAlign's r)
+        g_ins = torch.zeros(LT, dtype=torch.bool, device=dev)    # target base without a reference base
+        ar = torch.arange(G, device=dev)
+        keep = ~t_del
+        tgt[o_beg[keep]] = tb[keep]
+        g2r[o_beg[keep]] = ar[keep]
+        ipos = (o_end - 1)[t_ins]
+        tgt[ipos] = ins_b[t_ins]
+        g2r[ipos] = ar[t_ins] + 1
+        g_ins[ipos] = True
+        # reference-only columns in front of a target base (0 or 1)
+        adv = torch.where(g_ins, torch.zeros_like(g2r), torch.ones_like(g2r))
+        g_rdel = torch.zeros(LT, dtype=torch.int64, device=dev)
+        g_rdel[1:] = g2r[1:] - (g2r[:-1] + adv[:-1])
+        assert int(g_rdel.min().item()) >= 0 and int(g_rdel.max().item()) <= 1
+        self.tgt, self.g2r, self.g_ins, self.g_rdel = tgt, g2r, g_ins, g_rdel
+        del u, t_del, t_snp, t_ins, shift0, tb, ins_b, n_out, o_end, o_beg, ar, keep, ipos, adv
+        g_ins_np = g_ins.cpu().numpy()
+
+        # contigs: segments of the target; they begin and end on target bases that have a reference base
         ctgs = []
-        pos = int(rs.integers(0, max(1, min(sp.gap_hi, G // 50))))
-        while pos < G - 2000:
-            L = int(min(G - pos, max(2000, rs.normal(sp.ctg_len, sp.ctg_len * 0.2))))
-            ctgs.append((pos, pos + L, bool(rs.random() < sp.rev_ctg_frac)))
+        pos = int(rs.integers(0, max(1, min(sp.gap_hi, LT // 50))))
+        while pos < LT - 2000:
+            L = int(min(LT - pos, max(2000, rs.normal(sp.ctg_len, sp.ctg_len * 0.2))))
+            s0, e0 = pos, pos + L
+            while g_ins_np[s0]:
+                s0 += 1
+            while g_ins_np[e0 - 1]:
+                e0 -= 1
+            ctgs.append((s0, e0, bool(rs.random() < sp.rev_ctg_frac)))
             pos += L + int(rs.integers(sp.gap_lo, sp.gap_hi + 1))
         self.ctgs = ctgs
         nc = len(ctgs)
@@ -127,7 +177,11 @@ class BigWorkload:
         ce_t = torch.tensor([c[1] for c in ctgs], dtype=torch.int64, device=dev)
         crev_t = torch.tensor([c[2] for c in ctgs], dtype=torch.bool, device=dev)
 
-        starts = torch.randint(0, G - S, (n,), device=dev, generator=g)
+        starts = torch.randint(0, LT - S - 8, (n,), device=dev, generator=g)
+        for _ in range(4):  # a read's span begins and ends on target bases that have a reference base
+            bad = g_ins[starts] | g_ins[starts + S - 1]
+            starts = torch.where(bad, starts + 1, starts)
+        assert not bool((g_ins[starts] | g_ins[starts + S - 1]).any())
         rev = torch.rand(n, device=dev, generator=g) < 0.5
 
         read_len = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -146,7 +200,7 @@ class BigWorkload:
             m = hi - lo
             st = starts[lo:hi]
             idx = st[:, None] + torch.arange(S, device=dev)[None, :]
-            rb = ref[idx]  # [m, S] reference bases under the read
+            rb = tgt[idx]  # [m, S] target bases under the read
             u = torch.rand(m, S, device=dev, generator=g)
             is_del = u < sp.dele
             is_sub = (~is_del) & (u < sp.dele + sp.sub)
@@ -186,8 +240,8 @@ class BigWorkload:
             Lmax = int(flen.max().item())
             Lpad = (Lmax + 15) // 16 * 16
             frag = torch.zeros(m, Lpad + 16, dtype=torch.uint8, device=dev)
-            tgt = torch.where(emit, epos.long(), torch.full_like(epos.long(), Lpad + 15))
-            frag.scatter_(1, tgt, qcol)
+            tgt_col = torch.where(emit, epos.long(), torch.full_like(epos.long(), Lpad + 15))
+            frag.scatter_(1, tgt_col, qcol)
             frag = frag[:, :Lpad].contiguous()
             # stored read = fragment or its reverse complement
             ar = torch.arange(Lpad, device=dev)[None, :]
@@ -232,14 +286,39 @@ class BigWorkload:
                 wm = torch.arange(w.shape[1], device=dev)[None, :] < nw[:, None]
                 return w[wm].to(torch.int32), nw
 
-            w2, nw2 = pack_cols(cls, n_cols.long())
+            # read -> reference = (read -> target) o (target -> reference).  Per target base x of the span, in order: a
+            # reference-only column if the reference has a base the target lacks in front of x (class 1), the base's own
+            # column (both bases: 0 / 3 by comparing the READ base with the REFERENCE base; the read has it, the reference
+            # does not: 2; the reference has it, the read does not: 1; neither: no column), the read's insertion (2).
+            gi = g_ins[idx]
+            rd = g_rdel[idx].clone()
+            rd[:, 0] = 0
+            rbase = ref[g2r[idx].clamp(max=G - 1)]
+            base_present = ~(is_del & gi)
+            base_cls2 = torch.where(is_del, torch.ones_like(rb), torch.where(gi, torch.full_like(rb, 2),
+                                    torch.where(qb == rbase, torch.zeros_like(rb), torch.full_like(rb, 3))))
+            ncol2_per = rd.to(torch.int32) + base_present.to(torch.int32) + is_ins.to(torch.int32)
+            col2_end = torch.cumsum(ncol2_per, dim=1)
+            col2_0 = (col2_end - ncol2_per).long()  # first column of base x
+            n_cols2 = col2_end[:, -1].long()
+            C2pad = (int(n_cols2.max().item()) + 15) // 16 * 16
+            W2 = C2pad + 16
+            cls2 = torch.zeros(m, W2, dtype=torch.uint8, device=dev)
+            spare = torch.full_like(col2_0, W2 - 1)
+            cls2.scatter_(1, torch.where(rd > 0, col2_0, spare), torch.ones_like(rb))
+            cls2.scatter_(1, torch.where(base_present, col2_0 + rd, spare), base_cls2)
+            cls2.scatter_(1, torch.where(is_ins, col2_0 + rd + base_present.long(), spare), torch.full_like(rb, 2))
+            cls2 = cls2[:, :C2pad].contiguous()
+            w2, nw2 = pack_cols(cls2, n_cols2)
             diff2_chunks.append(w2)
             off2 = torch.cumsum(nw2, 0) - nw2 + w2_cursor
             w2_cursor += int(nw2.sum().item())
+            r_lo, r_hi = g2r[st], g2r[st + S - 1] + 1  # the reference interval under the read (both ends are aligned bases)
             rec2.append(dict(query=torch.arange(lo, hi, device=dev), target=torch.zeros(m, dtype=torch.int64, device=dev),
-                             t_begin=st, t_end=st + S, q_start=torch.zeros(m, dtype=torch.int64, device=dev), t_start=st,
-                             n_cols=n_cols.long(), n_valid=flen, diff_off=off2,
-                             flags=FLAG_ELIG + rv.long() * FLAG_REV, score=(cls == 0).sum(1) - (Cpad - n_cols.long())))
+                             t_begin=r_lo, t_end=r_hi, q_start=torch.zeros(m, dtype=torch.int64, device=dev), t_start=r_lo,
+                             n_cols=n_cols2, n_valid=flen, diff_off=off2,
+                             flags=FLAG_ELIG + rv.long() * FLAG_REV, score=(cls2 == 0).sum(1) - (C2pad - n_cols2)))
+            del gi, rd, rbase, base_present, base_cls2, ncol2_per, col2_end, col2_0, cls2, spare
 
             # ---- read -> contig alignments: up to two contigs per read
             j0 = torch.searchsorted(cs_t, st, right=True) - 1  # last contig starting at or before the read
@@ -315,7 +394,8 @@ class BigWorkload:
         self.aln1, self.qoff1, self.diff1 = finish_db(rec1, diff1_chunks)
         self.aln2, self.qoff2, self.diff2 = finish_db(rec2, diff2_chunks)
 
-        # contig table + identity contig->ref map (one entry per base, both orientations alike)
+        # contig table + contig->ref map (AlignReference: one entry per contig base = the reference cursor at that base,
+        # both orientations alike)
         ctab = np.zeros(nc, dtype=CTG_DTYPE)
         ent_off, ents = [], []
         cursor = 0
@@ -323,7 +403,7 @@ class BigWorkload:
             L = e - s
             ctab[c] = (L, 1, (ctg_start[c] + (2 * L if r else 0)) & 0xFFFFFFFF, 0, cursor + c)
             ent_off.append(torch.arange(cursor, cursor + L + 1, dtype=torch.int64, device=dev))
-            ents.append(torch.arange(s, e, dtype=torch.int64, device=dev) + ref_start[0])
+            ents.append(g2r[s:e] + ref_start[0])
             cursor += L
         self.ctab = ctab
         self.ctg_ent_off = torch.cat(ent_off).to(torch.int32)
@@ -420,6 +500,11 @@ class BigWorkload:
         inp.topk_ref = -1
         return inp
 
+    def contig_codes(self):
+        """the contig sequences as stored (2-bit codes): target segments, reverse-complemented where the contig is"""
+        t = self.tgt.cpu().numpy()
+        return [(3 - t[s:e][::-1]) if r else t[s:e] for s, e, r in self.ctgs]
+
     def solid_words(self) -> np.ndarray:
         """every u64 word of the equivalent solid-set file (header word first)"""
         if self.solid_codes is not None:
@@ -445,14 +530,34 @@ class BigWorkload:
                     f.write("\n".join(s[i:i + 100] for i in range(0, len(s), 100)) + "\n")
 
         fasta(os.path.join(out_dir, "ref.fasta"), [("ref1", ref)])
+        tgt = self.tgt.cpu().numpy()
+        g2r = self.g2r.cpu().numpy()
+        g_ins = self.g_ins.cpu().numpy()
+        g_rdel = self.g_rdel.cpu().numpy()
+        gap_tab = np.frombuffer(b"ACGT-", dtype=np.uint8)
         ctg_recs = []
         with open(os.path.join(out_dir, "aln"), "w") as f:
             for c, (s, e, r) in enumerate(self.ctgs):
-                seg = ref[s:e]
+                seg = tgt[s:e]
                 seq = (3 - seg[::-1]) if r else seg
                 ctg_recs.append((f"ctg{c}", seq))
-                row = acgt[seg].tobytes().decode()
-                f.write(f"ctg{c} ref1 {'R' if r else 'F'} NULL 0 {e - s} {e - s} {s} {e} {G}\n{row}\n{row}\n")
+                # the contig -> reference alignment in reference orientation: per target base an optional reference-only
+                # column in front of it, then its own column (target-only if the reference has no base there)
+                rd = g_rdel[s:e].copy()
+                rd[0] = 0
+                ncol = rd + 1
+                col0 = np.cumsum(ncol) - 1  # column of the target base
+                C = int(col0[-1]) + 1
+                q_row = np.full(C, 4, dtype=np.uint8)
+                t_row = np.full(C, 4, dtype=np.uint8)
+                q_row[col0] = seg
+                has_r = ~g_ins[s:e]
+                t_row[col0[has_r]] = ref[g2r[s:e][has_r]]
+                dcols = col0[rd > 0] - 1
+                t_row[dcols] = ref[g2r[s:e][rd > 0] - 1]
+                rb, re_ = int(g2r[s]), int(g2r[e - 1]) + 1
+                f.write(f"ctg{c} ref1 {'R' if r else 'F'} NULL 0 {e - s} {e - s} {rb} {re_} {G}\n"
+                        f"{gap_tab[q_row].tobytes().decode()}\n{gap_tab[t_row].tobytes().decode()}\n")
         fasta(os.path.join(out_dir, "ctg.fasta"), ctg_recs)
 
         packed = self.packed.cpu().numpy()
@@ -516,7 +621,7 @@ class BigWorkload:
             c = int(a["target"])
             if c not in ctg_seqs:
                 s, e, r = self.ctgs[c]
-                ctg_seqs[c] = ref[s:e]
+                ctg_seqs[c] = tgt[s:e]
             return ctg_seqs[c]
 
         write_aln(os.path.join(out_dir, "0.ctg.ref"), self.aln1, self.diff1, lambda a: f"ctg{int(a['target'])}",

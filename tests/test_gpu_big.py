@@ -54,7 +54,7 @@ def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_read
 
     # (2) whole product path vs the compiled reference on the text form
     ref_np = w.ref.cpu().numpy()
-    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_codes = w.contig_codes()
     ctg_seqs, k1 = bench.host_seqs(ctg_codes)
     ref_seqs, k2 = bench.host_seqs([ref_np])
     orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)

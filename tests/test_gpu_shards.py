@@ -74,7 +74,7 @@ def _sharded(hip, w, n_shards):
 def _traverse(host, g, w, out, orient):
     import bench
     ref_np = w.ref.cpu().numpy()
-    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_codes = w.contig_codes()
     ctg_seqs, k1 = bench.host_seqs(ctg_codes)
     ref_seqs, k2 = bench.host_seqs([ref_np])
     os.makedirs(out, exist_ok=True)

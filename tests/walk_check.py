@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--epsilon", type=int, default=10)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-host", action="store_true")
+    ap.add_argument("--modes", default="exact,speculative,uncut", help="device modes to run besides the host walk")
     ap.add_argument("--min-abundance", type=int, default=-1, help=">= 0: abundance cut of the solid set (needed for k > 14)")
     args = ap.parse_args()
     import torch
@@ -42,14 +43,14 @@ def main():
     st = pagctl.BuildStats()
     assert hip.pag_process(g, C.byref(inp), C.byref(st)) == 0, hip.pag_last_error()
     ref_np = w.ref.cpu().numpy()
-    ctg_codes = [(3 - ref_np[s:e][::-1]) if r else ref_np[s:e] for s, e, r in w.ctgs]
+    ctg_codes = w.contig_codes()
     ctg_seqs, k1 = bench.host_seqs(ctg_codes)
     ref_seqs, k2 = bench.host_seqs([ref_np])
     orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
     hostwalk = pagctl.walk_test_lib().pagt_traverse_hostwalk
     hostwalk.argtypes = host.pagh_traverse.argtypes
     res = {}
-    for mode in (["host walk"] if not args.no_host else []) + ["exact", "speculative", "uncut"]:
+    for mode in (["host walk"] if not args.no_host else []) + [m for m in args.modes.split(",") if m]:
         out = tempfile.mkdtemp(prefix="walkcheck_", dir="/dev/shm")
         ts = bench.TraverseStats()
         os.environ.pop("PAG_WALK_EXACT", None)
