@@ -128,8 +128,10 @@ def cpu_baseline(k, eps, cov, threads_flag):
 
 # (reads, read_span, ref_len, k, epsilon, seed) -> (path nodes, path checksum) verified against the host walk
 KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2 + r): v for r, v in enumerate([
-    (11927387, "a5be0e7e6768d02b"), (11921623, "fb604061f9706aee"), (11923285, "075d8b1aaf068b17"), (11919358, "86e94438bddea6ba"),
-    (11925391, "1a01e8987336b9e4"), (11929002, "1a7605fbef93d1ee"), (11922551, "24414d165e923e69"), (11924729, "5a52149c2e26d0d2")])}  # ranks 0..7
+    (11924900, "6372939f2ca5e736"), (11927706, "43b7948f5aab8638"), (11923389, "9e3fc4ea4cdd727b"), (11921428, "f6a4b5c0dd98720e"),
+    (11924769, "675e59b3ffabd4ce"), (11932987, "0faed8bfd2b28a01"), (11924043, "8da0bf7853e6aea3"), (11916048, "77849bdf3728dd81")])}  # ranks 0..7
+# (round 2, after the generator got its target genome with SNPs / indels back: tests/walk_check.py --seed 2..9, device walkers
+# = host restatement of the reference's traversal; logs of those runs: profiles/r02_walk_check_seeds.log)
 
 
 def main():

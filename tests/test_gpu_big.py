@@ -28,8 +28,8 @@ def _oracle_on(w_host):
 # reference PIPELINE's range (its kmer_counter stops at 15, quirk Q13) but inside pagraph's, which is what is compared
 @pytest.mark.gpu
 # all nine (k, epsilon) points of the sweep
-@pytest.mark.parametrize("k,eps,seed,n_reads", [(12, 10, 5, 1500), (14, 20, 5, 3000), (16, 5, 5, 3000), (12, 5, 5, 1500), (16, 20, 5, 3000),
-                                                (12, 20, 5, 1500), (14, 5, 5, 3000), (14, 10, 5, 3000), (16, 10, 5, 3000)])
+@pytest.mark.parametrize("k,eps,seed,n_reads", [(12, 10, 5, 4000), (14, 20, 5, 6000), (16, 5, 5, 6000), (12, 5, 5, 4000), (16, 20, 5, 6000),
+                                                (12, 20, 5, 4000), (14, 5, 5, 6000), (14, 10, 5, 6000), (16, 10, 5, 6000)])
 def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_reads, workdir):
     import torch
     import bench

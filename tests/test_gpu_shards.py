@@ -93,7 +93,7 @@ def test_n_shards_build_the_graph_of_one(n_shards, workdir):
     import biggen
     hip, host = bench.load_libs()
     _bind(hip)
-    sp = biggen.BigSpec(seed=7, ref_len=1_500_000, n_reads=3000, read_span=4000, k=14, eps=10, ctg_len=300_000, gap_lo=300, gap_hi=3000,
+    sp = biggen.BigSpec(seed=7, ref_len=1_500_000, n_reads=6000, read_span=4000, k=14, eps=10, ctg_len=300_000, gap_lo=300, gap_hi=3000,
                         rev_ctg_frac=0.3, threads=16, cov=2, solid_min_abundance=2, chunk_reads=512)
     w = biggen.BigWorkload(sp, device="cuda")
     torch.cuda.synchronize()
