@@ -11,6 +11,10 @@ CXXFLAGS := -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude -Ialigngraph2_amd/csrc/
 ifdef WALK_PROF
 PROF_FLAGS := -DPAG_WALK_PROF
 endif
+WALK_WINDOW ?= small
+ifeq ($(WALK_WINDOW),small)
+PROF_FLAGS += -DPAG_WALK_SMALL_WINDOW
+endif
 HIPFLAGS := $(PROF_FLAGS) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall -Wno-unused-value
 
 HOST_DIR := aligngraph2_amd/csrc/host

@@ -414,12 +414,24 @@ static_assert(GL == 8u || GL == 16u, "slot geometry");
 // vertices of the strand — refilled with wave-wide coalesced loads every couple of hundred steps.  The
 // window is a pure read cache: every mark is written through to the global arrays, and any access that
 // falls outside the window uses them directly.
+// Two window sizes: the large one fills a compute unit's LDS with ONE walker wave (fewest refills: best for a lone chain),
+// the small one (-DPAG_WALK_SMALL_WINDOW, the default build) leaves room for TWO waves per compute unit — the walks are
+// bound by the issue rate of one wave, so a second wave on another SIMD nearly doubles the rate at which the segment
+// jobs of a round drain, for ~3x as many (half as large) refills per wave.
+#ifdef PAG_WALK_SMALL_WINDOW
+constexpr uint32_t WIN_IDS = 512;
+constexpr uint32_t WIN_REC = 1792;
+constexpr uint32_t FILT_WORDS = 256;  // 16 Ki-bit membership filters in front of the outside-range hash sets
+constexpr uint32_t WIN_BACK = 64;    // ids kept behind the anchor at a refill
+constexpr uint32_t WIN_AHEAD = 96;
+#else
 constexpr uint32_t WIN_IDS = 1024;
 constexpr uint32_t WIN_REC = 4096;
-static_assert(WIN_IDS / 32u <= 64u, "one lane per word of the global-visited window");
 constexpr uint32_t FILT_WORDS = 1024;  // 64 Ki-bit membership filters in front of the outside-range hash sets
 constexpr uint32_t WIN_BACK = 128;   // ids kept behind the anchor at a refill
 constexpr uint32_t WIN_AHEAD = 160;
+#endif
+static_assert(WIN_IDS / 32u <= 64u, "one lane per word of the global-visited window");
 constexpr uint64_t SPEC_MARGIN = 50000;  // bases: no zombie within this distance of the can-leap threshold  // refill when the anchor gets this close to the upper end
 
 struct WalkLds {
@@ -2431,6 +2443,8 @@ void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, 
                       hipStream_t s) {
     if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k);
 }
+// walker waves (= 64-thread workgroups) that fit one compute unit: by the LDS a wave's window takes
+int trav_walk_waves_per_cu() { return sizeof(WalkLds) * 2 <= 160 * 1024 ? 2 : 1; }
 void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,
                                  uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_timeout, hipStream_t s) {
     k_walk_persistent<<<dim3(n_waves), dim3(64), 0, s>>>(G, jobs, outs, done, q, next, cap, k, idle_timeout);

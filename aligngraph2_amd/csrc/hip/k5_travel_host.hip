@@ -1020,7 +1020,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     if (n_live) {
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
-        trav_launch_walk_persistent(G, hjobs, houts, hdone, hq, g->wq_next, QCAP, k, (uint32_t)std::max(64, n_cu),
+        trav_launch_walk_persistent(G, hjobs, houts, hdone, hq, g->wq_next, QCAP, k, (uint32_t)std::max(64, n_cu * (std::getenv("PAG_WALK_WAVES_PER_CU") ? std::max(1, std::atoi(std::getenv("PAG_WALK_WAVES_PER_CU"))) : trav_walk_waves_per_cu())),
                                     (uint64_t)(std::getenv("PAG_WALK_IDLE_S") ? std::atoi(std::getenv("PAG_WALK_IDLE_S")) : 120) * 2400000000ull, g->walk_stream);
         if (hipGetLastError() != hipSuccess) {
             g->defer_free = false;
