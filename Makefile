@@ -11,7 +11,7 @@ CXXFLAGS := -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude -Ialigngraph2_amd/csrc/
 ifdef WALK_PROF
 PROF_FLAGS := -DPAG_WALK_PROF
 endif
-WALK_WINDOW ?= small
+WALK_WINDOW ?= large
 ifeq ($(WALK_WINDOW),small)
 PROF_FLAGS += -DPAG_WALK_SMALL_WINDOW
 endif

@@ -414,10 +414,11 @@ static_assert(GL == 8u || GL == 16u, "slot geometry");
 // vertices of the strand — refilled with wave-wide coalesced loads every couple of hundred steps.  The
 // window is a pure read cache: every mark is written through to the global arrays, and any access that
 // falls outside the window uses them directly.
-// Two window sizes: the large one fills a compute unit's LDS with ONE walker wave (fewest refills: best for a lone chain),
-// the small one (-DPAG_WALK_SMALL_WINDOW, the default build) leaves room for TWO waves per compute unit — the walks are
-// bound by the issue rate of one wave, so a second wave on another SIMD nearly doubles the rate at which the segment
-// jobs of a round drain, for ~3x as many (half as large) refills per wave.
+// Two window sizes: the large one (default build) fills a compute unit's LDS with ONE walker wave; the small one
+// (make WALK_WINDOW=small) leaves room for TWO waves per compute unit.  Measured at BASELINE configs[1]: the small window
+// alone costs 2.5 % (three times as many, half as large refills), but two resident walker waves per compute unit made the
+// walks 60 % SLOWER (553 vs 348 ms) — the waves are bound by instruction issue and latency, and two of them on one
+// compute unit evidently get in each other's way (shared instruction / scalar caches; the kernel is ~100 KB of code).
 #ifdef PAG_WALK_SMALL_WINDOW
 constexpr uint32_t WIN_IDS = 512;
 constexpr uint32_t WIN_REC = 1792;
