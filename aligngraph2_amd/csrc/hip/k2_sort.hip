@@ -6,7 +6,7 @@
 // emission order inside every k-mer bucket survives.
 //
 // One digit pass = three launches:
-//   sort_hist     per 4096-record tile: digit histogram in LDS -> hist[digit][tile]
+//   sort_hist     per tile: digit histogram in LDS -> hist[digit][tile]
 //   scan          exclusive prefix over hist (digit-major), giving every (digit, tile) its output base
 //   sort_scatter  per tile: wave-synchronous stable ranking (ballot match on the digit bits, per-wave
 //                 LDS counters), records staged through LDS in digit order, then written out in runs
@@ -33,19 +33,63 @@ constexpr int SMAXR = 256;        // max radix (8 bits)
 #define SORT_X 0  // timing experiments of tests/harness/sort_bench.hip (results wrong when non-zero)
 #endif
 
-__global__ __launch_bounds__(ST) void sort_hist(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t rmask,
-                                               uint32_t *__restrict__ hist, uint32_t n_tiles) {
-    __shared__ uint32_t h[SMAXR];
-    if (threadIdx.x < SMAXR) h[threadIdx.x] = 0;
-    __syncthreads();
-    uint64_t base = (uint64_t)blockIdx.x * STILE;
+// Digit histogram of every tile: the keys are read once, 16 bytes per lane, by persistent blocks of four waves; every wave
+// counts into its own LDS table (a quarter of the collisions), the tables are summed when the tile's column of
+// hist[digit][tile] is written.  The loads of the next tile are in flight while a tile is counted.
+constexpr int HT = 256;                    // threads per histogram block
+constexpr int HW = HT / 64;                // waves
+constexpr int HV = STILE / (4 * HT);       // uint4 loads per thread and tile
+static_assert(STILE % (4 * HT) == 0, "a tile is a whole number of 16-byte loads per thread");
+
+__global__ __launch_bounds__(HT) void sort_hist(const uint32_t *__restrict__ keys, uint64_t n, int shift, uint32_t rmask,
+                                                uint32_t *__restrict__ hist, uint32_t n_tiles, int aligned) {
+    __shared__ uint32_t h[2][HW][SMAXR];
+    const uint32_t w = threadIdx.x >> 6;
+    uint4 nx[HV];
+    auto request = [&](uint32_t tile) {
+        const uint64_t base = (uint64_t)tile * STILE;
+        if (aligned && tile < n_tiles && base + STILE <= n) {
+            const uint4 *src = (const uint4 *)(keys + base);
 #pragma unroll
-    for (int r = 0; r < SROUNDS; ++r) {
-        uint64_t i = base + (uint64_t)r * ST + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & rmask], 1u);
-    }
+            for (int r = 0; r < HV; ++r) nx[r] = src[r * HT + threadIdx.x];
+        }
+    };
+    for (uint32_t i = threadIdx.x; i < 2 * HW * SMAXR; i += HT) (&h[0][0][0])[i] = 0;
+    request(blockIdx.x);
     __syncthreads();
-    if (threadIdx.x <= rmask) hist[(uint64_t)threadIdx.x * n_tiles + blockIdx.x] = h[threadIdx.x];
+    uint32_t buf = 0;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1u) {
+        const uint64_t base = (uint64_t)tile * STILE;
+        uint32_t *hw = h[buf][w];
+        if (aligned && base + STILE <= n) {
+            uint4 cur[HV];
+#pragma unroll
+            for (int r = 0; r < HV; ++r) cur[r] = nx[r];
+            request(tile + gridDim.x);
+#pragma unroll
+            for (int r = 0; r < HV; ++r) {
+                atomicAdd(&hw[(cur[r].x >> shift) & rmask], 1u);
+                atomicAdd(&hw[(cur[r].y >> shift) & rmask], 1u);
+                atomicAdd(&hw[(cur[r].z >> shift) & rmask], 1u);
+                atomicAdd(&hw[(cur[r].w >> shift) & rmask], 1u);
+            }
+        } else {  // the last tile, or a key array that is not 16-byte aligned
+            request(tile + gridDim.x);
+            for (uint32_t j = threadIdx.x; j < (uint32_t)STILE; j += HT)
+                if (base + j < n) atomicAdd(&hw[(keys[base + j] >> shift) & rmask], 1u);
+        }
+        __syncthreads();
+        // the column of this tile; the table is cleared for the tile after next (the next one counts into the other table)
+        for (uint32_t d = threadIdx.x; d <= rmask; d += HT) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int ww = 0; ww < HW; ++ww) {
+                c += h[buf][ww][d];
+                h[buf][ww][d] = 0;
+            }
+            hist[(uint64_t)d * n_tiles + tile] = c;
+        }
+    }
 }
 
 struct ScatterStage {       // one tile staged in digit order, waiting to be written out
@@ -237,6 +281,13 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
     if (pending) write_out(L.stage[buf ^ 1u], pending_count);
 }
 
+static int scatter_blocks_cus(int dev) {
+    static int cus_of[64] = {0};
+    int &c = cus_of[dev & 63];
+    if (c == 0 && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+    return c > 0 ? c : 256;
+}
+
 static size_t sort_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // tmp layout: hist u32[R * n_tiles] | hist_scan u64[R * n_tiles] | scan tmp
@@ -283,6 +334,9 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
         scatter_blocks = cus * (per_cu > 0 ? per_cu : 1);
     }
     const uint32_t scatter_grid = n_tiles < (uint32_t)scatter_blocks ? n_tiles : (uint32_t)scatter_blocks;
+    int hist_per_cu = 8;
+    if (const char *e = getenv("PAG_SORT_HIST_PER_CU")) hist_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+    const int hist_blocks = scatter_blocks_cus(dev) * hist_per_cu;
     hipEvent_t ev[2 * 8];
     for (int i = 0; i < 2 * passes; ++i) PAG_HIP_TRY(hipEventCreate(&ev[i]));
     uint32_t *ka = k0, *kb = k1;
@@ -293,7 +347,8 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
         int b = key_bits - pass * bits < bits ? key_bits - pass * bits : bits;
         uint32_t rmask = (1u << b) - 1u;
         uint64_t used = (uint64_t)(rmask + 1) * n_tiles;
-        sort_hist<<<dim3(n_tiles), dim3(ST), 0, s>>>(ka, n, shift, rmask, hist, n_tiles);
+        const uint32_t hist_grid = n_tiles < (uint32_t)hist_blocks ? n_tiles : (uint32_t)hist_blocks;
+        sort_hist<<<dim3(hist_grid), dim3(HT), 0, s>>>(ka, n, shift, rmask, hist, n_tiles, ((uintptr_t)ka & 15u) == 0 ? 1 : 0);
         int rc = scan_u32_to_u64(hist, hist_scan, used, nullptr, scan_tmp, s);
         if (rc != PAG_OK) return rc;
         PAG_HIP_TRY(hipEventRecord(ev[2 * pass], s));

@@ -506,6 +506,11 @@ struct WalkCtx {
     uint32_t w_ab;      // the abundance copy L.wab starts this many ids before the window (16-byte aligned loads)
     uint32_t n_fill;
     uint32_t n_classify, n_probe, n_records;  // work counters
+    // what a later splice of this job's path into another walk has to know (TravJob::seq_x, TravJobOut::wd_*), per lane:
+    uint32_t x_elow, x_m0;         // running iteration: lowest coordinate of an examined contig-following record / lowest id
+                                   // of an examined record without a contig coordinate
+    uint32_t x_below, x_forced;    // whole job: window-dependent records below / at or above force_low
+    uint32_t force_low;
     int overflow;
     int spec_fail;  // a zombie probe ended in a leap (or could not be continued): the job has to be redone without speculation
     uint64_t max_probe;  // per lane: largest probe size (sum of steps) seen, wave maximum taken at the end of the job
@@ -665,6 +670,15 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
     win_fill(L, X, cur);
 }
 
+// bookkeeping for a later splice (see WalkCtx::x_*): every examined record passes here
+__device__ __forceinline__ void walk_note_record(WalkCtx &X, uint32_t v, uint32_t pc, bool ectg) {
+    X.x_m0 = ((pc == 0u) & (v < X.x_m0)) ? v : X.x_m0;
+    X.x_elow = ((pc != 0u) & ectg & (pc < X.x_elow)) ? pc : X.x_elow;
+    const bool wd = (pc != 0u) & !ectg;
+    X.x_below = (wd & (pc < X.force_low) & (pc > X.x_below)) ? pc : X.x_below;
+    X.x_forced = (wd & (pc >= X.force_low) & (pc < X.x_forced)) ? pc : X.x_forced;
+}
+
 // classifySuccessors (PAlgorithm.tcc:35-90) over the precomputed successor records of `cur`.
 // level 1: filter of graphTravel (global && travel); level 2: filter of walkStraight (&& probe).
 // Result: L.lst_v/lst_s[0] hold the chosen class in reference order, return = its size.
@@ -673,7 +687,7 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
 // on the strand, filter words for a target off it) and combines plain bit operations; the rare cases — a
 // strand vertex outside the window, a filter hit, a probe with more than two outside vertices, a leap —
 // are resolved afterwards under one branch each.
-__device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
+__device__ __forceinline__ int eval_record(const WalkLds &L, WalkCtx &X, const SuccRec &rec, bool can_leap, int level,
                                            uint32_t grp, const ProbeOut po, uint32_t epoch, uint32_t gen) {
     const uint32_t v = rec.tgt, pc = rec.pc;
     const uint32_t grade = (rec.meta >> 24) & 7u;
@@ -712,6 +726,7 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, const WalkCtx &X, c
         }
     }
     const bool free_pc = (pc == 0u) | ectg;  // no coordinate, or the edge follows the contig: the window tests do not apply
+    walk_note_record(X, v, pc, ectg);
     const bool hit_g = !free_pc & in_win(X.win_g0, X.win_g1, pc), hit_t = !free_pc & in_win(X.win_t0, X.win_t1, pc);
     const bool rev = (pc != 0u) & (pc >= X.C.rev_left) & (pc < X.C.rev_right);
     bool ok = !(gvis | hit_g | rev | tvis | hit_t);
@@ -1582,6 +1597,10 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.spec_fail = 0;
     X.max_probe = 0;
     if (J.mode & TRAV_MODE_SPEC) X.C.split_size = ~0ull;  // a piece walked ahead of its graphTravel: leaping is off
+    if (J.mode & TRAV_MODE_LEAP) X.C.split_size = 0ull;   // ... inside the leaping zone: leaping is on from the first vertex
+    X.force_low = (J.mode & TRAV_MODE_LEAP) ? J.win_low : 0u;
+    X.x_elow = X.x_m0 = X.x_forced = 0xFFFFFFFFu;
+    X.x_below = 0u;
     X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.w_ab = X.n_fill = 0;
 #ifdef PAG_WALK_PROF
     for (int q = 0; q < 12; ++q) {
@@ -1615,6 +1634,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     const uint64_t has_size = J.has_size;
     const uint32_t start = G.newid[J.start];
     win_add(X.win_t0, X.win_t1, (uint32_t)(G.upos[start] >> 32));
+    if ((J.mode & TRAV_MODE_LEAP) && J.win_low != 0u && J.win_low < X.win_t0) X.win_t0 = J.win_low;
 
     // stitch bookkeeping (see TravJobOut): the lowest coordinate the probes of the running iteration visited
     uint32_t it_low = 0xFFFFFFFFu, max_back = 0, max_chosen = 0, stopped = 0;
@@ -1651,9 +1671,24 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     const bool speculate = J.exact == 0;
     const uint64_t slot_cap = J.arena_cap / PROBE_GROUPS;
 
+    // iteration log of a TRAV_MODE_LEAP job: the entry of the boundary the running iteration started at is written when the
+    // iteration is over (next turn of the loop, or after the loop once the last zombie has stopped)
+    uint64_t log_idx = ~0ull;
+    auto flush_log = [&]() {
+        uint32_t el = X.x_elow, m0 = X.x_m0;
+        for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+            const uint32_t oe = (uint32_t)__shfl_xor((int)el, d2, 64), om = (uint32_t)__shfl_xor((int)m0, d2, 64);
+            el = oe < el ? oe : el;
+            m0 = om < m0 ? om : m0;
+        }
+        if (J.seq_x && log_idx != ~0ull && lane == 0)
+            J.seq_x[log_idx] = (1ull << 63) | ((uint64_t)(el < 0x7FFFFFFFu ? el : 0x7FFFFFFFu) << 32) | (uint64_t)m0;
+        X.x_elow = X.x_m0 = 0xFFFFFFFFu;
+    };
     uint64_t n_main = 0;
     for (;;) {
         ++n_main;
+        if (J.seq_x) flush_log();
         PROF_BEGIN(t_app);
         X.epoch = (uint32_t)n_main;  // marks appended in this iteration carry it; the probes launched after see all of them
         // append the chosen path to the sequence, mark it visited, widen the travel window
@@ -1750,6 +1785,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             ch_v = J.arena_v;
             ch_s = J.arena_s;
         }
+        log_idx = seq_len - 1;
         if (lc != 0 && (lc < X.C.ctg_left || lc >= X.C.ctg_right)) break;
         if (J.stop_pc != 0u && lc >= J.stop_pc) {  // (lc is on the own strand here) the piece ends at this iteration boundary
             stopped = 1;
@@ -1777,6 +1813,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                 cpc = L.pb_pc[f_grp][lane];
                 coff = L.pb_off[f_grp][lane];
                 const bool free_pc = (cpc == 0u) | (((cmeta >> 27) & 1u) != 0u);
+                walk_note_record(X, cv, cpc, ((cmeta >> 27) & 1u) != 0u);  // (examined again, now at the top level)
                 c = (free_pc || !in_win(X.win_t0, X.win_t1, cpc)) ? (int)L.pb_cls[f_grp][lane] : -1;
             }
             uint64_t mm = __ballot(c == 0);
@@ -2002,6 +2039,13 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         bool w = false;
         slots_step(L, X, S, J.arena_v, J.arena_s, slot_cap, &w, true);
     }
+    if (J.seq_x) flush_log();
+    uint32_t wd_below = X.x_below, wd_forced = X.x_forced;
+    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+        const uint32_t ob = (uint32_t)__shfl_xor((int)wd_below, d2, 64), of = (uint32_t)__shfl_xor((int)wd_forced, d2, 64);
+        wd_below = ob > wd_below ? ob : wd_below;
+        wd_forced = of < wd_forced ? of : wd_forced;
+    }
     {
         int sf = X.spec_fail;
         for (int d2 = 32; d2 >= 1; d2 >>= 1) sf |= __shfl_xor(sf, d2, 64);
@@ -2026,7 +2070,9 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         o.stopped = stopped;
         o.max_back = max_back;
         o.max_chosen = max_chosen;
-        o.reserved2 = 0;
+        o.wd_below_max = wd_below;
+        o.wd_forced_min = wd_forced;
+        o.reserved3 = 0;
         o.max_probe = mp_all;
 #ifdef PAG_WALK_PROF
         for (int q = 0; q < 12; ++q) {
@@ -2099,7 +2145,12 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
         if (ring >= 0) {
             const uint32_t slot = (uint32_t)ring * cap + idx % cap;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // buffers of the job were prepared by other kernels / copies
+            const uint64_t tb = wall_clock64();
             walk_job(L, G, jobs[slot].C, jobs[slot].J, &outs[slot], k);
+            if (lane == 0) {
+                outs[slot].t_begin = tb;
+                outs[slot].t_end = wall_clock64();
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(&done[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // same value from every lane
             t0 = __builtin_amdgcn_s_memtime();
@@ -2302,6 +2353,11 @@ __global__ void k_pack_paths(TravGraph G, const TravPackDesc *__restrict__ descs
         o[i] = v;
         o[D.len + i] = D.seq_s[i];
         o[2 * D.len + i] = (uint32_t)(G.upos[v] >> 32);
+        if (D.seq_x) {
+            const uint64_t x = D.seq_x[i];
+            o[3 * D.len + i] = (uint32_t)x;
+            o[4 * D.len + i] = (uint32_t)(x >> 32);
+        }
     }
 }
 
@@ -2461,13 +2517,44 @@ void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s
 // coordinate order + successor records.  key/val/key2/val2: u32/u64 [n_pos] scratch pairs for the sort;
 // cnt: u32 [n_pos + 1]; *n_succ_out receives the number of successor records (call twice: first with
 // G.succ == nullptr to size it, then with the allocation)
-int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, hipStream_t s) {
+// where the sorted keys stop being zero (keys ascending; *n0 preset to 0, stays 0 when key[0] != 0)
+__global__ void k_zero_prefix(const uint32_t *__restrict__ key, uint64_t n, unsigned long long *__restrict__ n0) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (key[i] == 0u && (i + 1 == n || key[i + 1] != 0u)) *n0 = i + 1;
+}
+// sort keys of the vertices without a contig coordinate: their reference coordinate
+__global__ void k_order_refkeys(const uint64_t *__restrict__ vpos, const uint64_t *__restrict__ old, uint64_t n, uint32_t *__restrict__ key) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        key[i] = (uint32_t)vpos[(uint32_t)old[i]];
+}
+
+// New ids: [vertices without a contig coordinate, by reference coordinate] ++ [the others, by contig coordinate]; equal
+// keys keep the k-mer-major order (stable sorts).  The order inside the first group is not needed by the walks — it makes
+// neighbours on the reference neighbours in memory, and it lets a splice of two walks bound the vertices of that kind a
+// walk has examined by an id (k5_travel_host.hip, try_merge_leap).  *n_zero receives the size of the first group.
+int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, hipStream_t s) {
     const uint64_t n = G.n_pos;
+    if (n_zero) *n_zero = 0;
     if (!n) return PAG_OK;
     k_order_keys<<<dim3(grid_for(n)), dim3(256), 0, s>>>(G.vpos, n, key, val);
     int in0 = 1, rc;
     if ((rc = sort_pairs(key, val, key2, val2, n, 32, sort_tmp, &in0, s, nullptr, nullptr))) return rc;
-    k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(in0 ? val : val2, n, G);
+    uint32_t *ks = in0 ? key : key2, *ko = in0 ? key2 : key;
+    uint64_t *vs = in0 ? val : val2, *vo = in0 ? val2 : val;
+    unsigned long long *d_n0 = (unsigned long long *)sort_tmp;  // (the sort is done with its scratch)
+    unsigned long long n0 = 0;
+    PAG_HIP_TRY(hipMemsetAsync(d_n0, 0, 8, s));
+    k_zero_prefix<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, n, d_n0);
+    PAG_HIP_TRY(hipMemcpyAsync(&n0, d_n0, 8, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    if (n0 > 1) {
+        k_order_refkeys<<<dim3(grid_for(n0)), dim3(256), 0, s>>>(G.vpos, vs, n0, ks);
+        int in0b = 1;
+        if ((rc = sort_pairs(ks, vs, ko, vo, n0, 32, sort_tmp, &in0b, s, nullptr, nullptr))) return rc;
+        if (!in0b) PAG_HIP_TRY(hipMemcpyAsync(vs, vo, n0 * 8, hipMemcpyDeviceToDevice, s));
+    }
+    if (n_zero) *n_zero = n0;
+    k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(vs, n, G);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }

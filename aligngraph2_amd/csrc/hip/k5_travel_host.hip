@@ -288,7 +288,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
             (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
             return rc;
-        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, s)))
+        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg, s)))
             return rc;
         uint64_t n_succ = 0, n_cand = 0;
         // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
@@ -517,7 +517,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // The result is vertex-for-vertex the path of the un-cut walk (PAG_WALK_PIECES=0 runs that, tests compare both with the
     // host restatement of the reference), and the critical path of a contig shrinks from the whole contig to one segment
     // plus the leaping zone.
-    enum { CB_SEQV = 0, CB_SEQS, CB_ARV, CB_ARS, CB_TSET, CB_PSET, CB_STAMP, CB_TBITS, CB_N };
+    enum { CB_SEQV = 0, CB_SEQS, CB_ARV, CB_ARS, CB_TSET, CB_PSET, CB_STAMP, CB_TBITS, CB_SEQX, CB_N };
     enum { GRP_ROUND = 0, GRP_CHAIN0 = 1, GRP_FINAL = 9, GROUPS = 10 };  // buffer groups per contig (chains: top-K <= 8)
     if (g->cpool.size() < (size_t)n_sel * GROUPS * CB_N) g->cpool.resize((size_t)n_sel * GROUPS * CB_N);
     auto cbuf = [&](uint32_t i, int grp, int b) { return DevBuf(g, &g->cpool[((size_t)i * GROUPS + grp) * CB_N + b]); };
@@ -572,10 +572,21 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         std::vector<uint32_t> sufmin;    // min coordinate over P[i ..]
         uint32_t max_back = 0, max_chosen = 0;
         uint64_t max_probe = 0;
+        // a segment inside the leaping zone (TRAV_MODE_LEAP), see try_merge_leap:
+        bool leap = false;
+        std::vector<uint8_t> boundary;   // P[i] is the last vertex of a chosen path of the segment's walk
+        std::vector<uint32_t> suf_elow;  // over the iterations that start at a boundary >= i: lowest coordinate of an examined
+                                         // contig-following record ...
+        std::vector<uint32_t> suf_m0;    // ... lowest id of an examined record without a contig coordinate
+        std::vector<uint32_t> prefmax0;  // highest id of a vertex without a contig coordinate in P[0 .. i] (0: none)
+        std::vector<uint32_t> prefmin;   // lowest non-zero coordinate in P[0 .. i]
+        uint32_t wd_below_max = 0, wd_forced_min = 0xFFFFFFFFu, win_low = 0;
     };
     struct Chain {  // one graphTravel: (contig, seed) of the running round
         Piece T;    // the validated path so far
         std::vector<uint32_t> prefmax;
+        std::vector<uint32_t> prefmax0;  // highest id of a vertex without a contig coordinate in T[0 .. i] (0: none)
+        uint32_t low_nz = 0xFFFFFFFFu;   // lowest non-zero coordinate of T
         uint64_t size = 0;  // sum of its steps
         bool final = false;
         int waiting_seg = -1;  // the segment whose job this chain waits for
@@ -606,6 +617,26 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     std::vector<JobRef> jref(NR * (size_t)QCAP);
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
     uint64_t n_adopted = 0, n_merge_fail = 0, n_seg_jobs = 0, n_resume_jobs = 0;
+    uint64_t n_leap_jobs = 0, n_leap_adopted = 0, n_leap_refused[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool use_leap_pieces = !(std::getenv("PAG_LEAP_PIECES") && std::atoi(std::getenv("PAG_LEAP_PIECES")) == 0);
+    // T grows by a job's new vertices or by an adopted stretch of a segment
+    auto extend_chain = [&](auto &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n) {
+        ch.T.v.insert(ch.T.v.end(), v, v + n);
+        ch.T.s.insert(ch.T.s.end(), sv, sv + n);
+        ch.T.pc.insert(ch.T.pc.end(), pc, pc + n);
+        const size_t n0 = ch.prefmax.size();
+        ch.prefmax.resize(n0 + n);
+        ch.prefmax0.resize(n0 + n);
+        uint32_t mx = n0 ? ch.prefmax[n0 - 1] : 0u, m0 = n0 ? ch.prefmax0[n0 - 1] : 0u;
+        for (size_t x = 0; x < n; ++x) {
+            mx = std::max(mx, pc[x]);
+            if (pc[x] == 0) m0 = std::max(m0, v[x] + 1u);  // (id + 1: 0 stands for "none")
+            else ch.low_nz = std::min(ch.low_nz, pc[x]);
+            ch.prefmax[n0 + x] = mx;
+            ch.prefmax0[n0 + x] = m0;
+            ch.size += sv[x];
+        }
+    };
     bool walker_up = false;
     auto shutdown_walker = [&]() {
         if (!walker_up) return;
@@ -626,6 +657,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         const Piece *init;  // RESUME: the path so far
         bool exact;
         uint32_t win_lo = 0, win_hi = 0;  // id range of the job's direct-mapped marks (0, 0: the whole strand)
+        uint32_t win_low = 0;             // TRAV_MODE_LEAP: forced lower end of the travel coordinate window
     };
     bool need_publish = false;
     // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
@@ -638,12 +670,14 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // one travel epoch / probe stamp per vertex of the job's id range (the whole strand, or the surroundings of a
         // segment); padded to a multiple of four so that the walker's window refills can use 16-byte loads
         const size_t nj = plans.size();
-        std::vector<uint64_t> o_seq(nj + 1, 0), o_oc(nj + 1, 0), o_st(nj + 1, 0), o_tb(nj + 1, 0), spans(nj, 0);
+        std::vector<uint64_t> o_seq(nj + 1, 0), o_oc(nj + 1, 0), o_st(nj + 1, 0), o_tb(nj + 1, 0), spans(nj, 0), o_x(nj + 1, 0);
         for (size_t j = 0; j < nj; ++j) {
+            o_x[j + 1] = o_x[j] + ((plans[j].mode & TRAV_MODE_LEAP) ? plans[j].cap : 0);
             const uint32_t lo = plans[j].win_hi ? plans[j].win_lo : cs.inLo, hi = plans[j].win_hi ? plans[j].win_hi : cs.inHi;
             spans[j] = ((uint64_t)(hi - lo) + 1 + 3) & ~3ull;
             o_seq[j + 1] = o_seq[j] + plans[j].cap;
-            o_oc[j + 1] = o_oc[j] + pow2_at_least(plans[j].cap / 4 + 4096);
+            // (a walk in the leaping zone visits vertices without a contig coordinate all the time: they live in the hash sets)
+            o_oc[j + 1] = o_oc[j] + pow2_at_least((plans[j].mode & TRAV_MODE_LEAP) ? plans[j].cap + 8192 : plans[j].cap / 4 + 4096);
             o_st[j + 1] = o_st[j] + PG * spans[j];
             o_tb[j + 1] = o_tb[j] + spans[j] + 4;
         }
@@ -651,24 +685,26 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // a cold process otherwise spends seconds in thousands of hipMalloc calls); the per-(contig, group) slots take over
         // when the arena is used up
         DevBuf b_sv = cbuf(i, grp, CB_SEQV), b_ss = cbuf(i, grp, CB_SEQS), b_av = cbuf(i, grp, CB_ARV), b_as = cbuf(i, grp, CB_ARS),
-               b_ts = cbuf(i, grp, CB_TSET), b_ps = cbuf(i, grp, CB_PSET), b_st = cbuf(i, grp, CB_STAMP), b_tb = cbuf(i, grp, CB_TBITS);
+               b_ts = cbuf(i, grp, CB_TSET), b_ps = cbuf(i, grp, CB_PSET), b_st = cbuf(i, grp, CB_STAMP), b_tb = cbuf(i, grp, CB_TBITS),
+               b_sx = cbuf(i, grp, CB_SEQX);
         int r;
         {
-            const size_t need[8] = {(size_t)o_seq[nj] * 4, (size_t)o_seq[nj] * 4, (size_t)o_seq[nj] * PG * 4, (size_t)o_seq[nj] * PG * 4,
-                                    (size_t)o_oc[nj] * 8, (size_t)o_oc[nj] * PG * 8, (size_t)o_st[nj] * 4, (size_t)o_tb[nj] * 4};
-            DevBuf *bufs[8] = {&b_sv, &b_ss, &b_av, &b_as, &b_ts, &b_ps, &b_st, &b_tb};
+            const size_t need[9] = {(size_t)o_seq[nj] * 4, (size_t)o_seq[nj] * 4, (size_t)o_seq[nj] * PG * 4, (size_t)o_seq[nj] * PG * 4,
+                                    (size_t)o_oc[nj] * 8, (size_t)o_oc[nj] * PG * 8, (size_t)o_st[nj] * 4, (size_t)o_tb[nj] * 4, (size_t)o_x[nj] * 8};
+            DevBuf *bufs[9] = {&b_sv, &b_ss, &b_av, &b_as, &b_ts, &b_ps, &b_st, &b_tb, &b_sx};
             size_t tot = 0;
-            for (size_t q = 0; q < 8; ++q) tot += (need[q] + 16 + 255) & ~(size_t)255;
+            for (size_t q = 0; q < 9; ++q) tot += (need[q] + 16 + 255) & ~(size_t)255;
             if (g->walk_arena && g->walk_arena_used + tot <= g->walk_arena_cap) {
-                for (size_t q = 0; q < 8; ++q) {
+                for (size_t q = 0; q < 9; ++q) {
                     bufs[q]->p = (char *)g->walk_arena + g->walk_arena_used;
                     g->walk_arena_used += (need[q] + 16 + 255) & ~(size_t)255;
                 }
             } else {
-                for (size_t q = 0; q < 8; ++q)
+                for (size_t q = 0; q < 9; ++q)
                     if ((r = bufs[q]->alloc(need[q]))) return r;
             }
         }
+        if (o_x[nj]) PAG_HIP_TRY(hipMemsetAsync(b_sx.p, 0, o_x[nj] * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, o_oc[nj] * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, o_oc[nj] * PG * 8, s));
         PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, o_st[nj] * 4, s));
@@ -705,6 +741,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.mode = pl.mode;
             J.stop_pc = pl.stop_pc;
             J.init_len = 0;
+            J.win_low = pl.win_low;
+            J.pad_ = 0;
+            J.seq_x = (pl.mode & TRAV_MODE_LEAP) ? b_sx.as<uint64_t>() + o_x[j] : nullptr;
             if (pl.mode & TRAV_MODE_RESUME) {
                 const uint64_t n0 = pl.init->v.size();
                 if (n0 == 0 || n0 > cap) {
@@ -734,6 +773,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 if (pl.mode & TRAV_MODE_RESUME) ++n_resume_jobs;
             } else {
                 ++n_seg_jobs;
+                if (pl.mode & TRAV_MODE_LEAP) ++n_leap_jobs;
             }
             n_posted[ring] += 1;
             n_live += 1;
@@ -753,6 +793,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     // ---- start of a round of contig i: its seeds are in cs.seeds.  Decides where the walk can be cut, finds the checkpoint
     //      vertices and posts the seed jobs and the segment jobs.
+    // stop coordinate of a job that walks up to segment q of the round (its checkpoint + the overlap)
+    auto stop_for = [&](const RoundState &R, size_t q) -> uint32_t {
+        const uint64_t x = (uint64_t)R.segs[q].x + seg_ov;
+        return (uint32_t)(R.segs[q].leap ? std::min<uint64_t>(x, 0xFFFFFFFFull) : std::min<uint64_t>(x, R.zone_end));
+    };
+    auto first_stop = [&](const RoundState &R) -> uint32_t { return stop_for(R, 0); };
     DevBuf b_ckreq = buf(), b_ckout = buf();
     auto start_round = [&](uint32_t i) -> int {
         CtgState &cs = st[i];
@@ -772,6 +818,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint32_t x0 = 0xFFFFFFFFu;
         for (auto &sd : cs.seeds) x0 = std::min(x0, sd.ctg);
         std::vector<uint32_t> ck_x;
+        size_t n_spec_ck = 0;
         if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
             const uint64_t H = (uint64_t)cs.varLen + k;
             // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
@@ -782,6 +829,16 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H - safety), (uint64_t)cs.ctgRight - 1);
                 for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
                 if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
+            }
+            n_spec_ck = ck_x.size();
+            if (use_leap_pieces) {
+                // the leaping zone gets segments of its own (TRAV_MODE_LEAP), from where the real walk has certainly begun to
+                // leap (the steps follow the coordinate closely, not exactly: a margin; every adoption is checked with the true
+                // size) to the end of the strand
+                const uint64_t drift = cs.len / 400 + 200;
+                const uint64_t first = (uint64_t)x0 + (split > H ? split - H + drift : seg_len);
+                for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + seg_len); x + seg_len / 4 < (uint64_t)cs.ctgRight - 1; x += seg_len)
+                    if (ck_x.empty() || x > (uint64_t)ck_x.back() + seg_len / 4) ck_x.push_back((uint32_t)x);
             }
         }
         if (!ck_x.empty()) {
@@ -807,17 +864,26 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 Seg sg;
                 sg.x = out[3 * q + 1];
                 sg.vid = out[3 * q];
+                sg.leap = q >= n_spec_ck;
+                sg.win_low = x0;
                 if (!R.segs.empty() && sg.x <= R.segs.back().x) continue;
                 R.segs.push_back(std::move(sg));
             }
-            for (size_t q = 0; q < R.segs.size(); ++q)
-                R.segs[q].stop = q + 1 < R.segs.size() ? (uint32_t)std::min<uint64_t>((uint64_t)R.segs[q + 1].x + seg_ov, R.zone_end) : R.zone_end;
-            if (R.segs.empty()) R.zone_end = 0;
+            for (size_t q = 0; q < R.segs.size(); ++q) {
+                const bool more = q + 1 < R.segs.size();
+                if (R.segs[q].leap) R.segs[q].stop = more ? (uint32_t)std::min<uint64_t>((uint64_t)R.segs[q + 1].x + seg_ov, 0xFFFFFFFFull) : 0u;  // 0: to the end
+                else R.segs[q].stop = more && !R.segs[q + 1].leap ? (uint32_t)std::min<uint64_t>((uint64_t)R.segs[q + 1].x + seg_ov, R.zone_end) : R.zone_end;
+            }
+            {
+                bool any_spec = false;
+                for (auto &sg : R.segs) any_spec = any_spec || !sg.leap;
+                if (!any_spec) R.zone_end = 0;
+            }
             if (!R.segs.empty()) {  // id ranges around the segments: [checkpoint - 2000, stop + 3000] in contig coordinates
                 std::vector<uint32_t> co(2 * R.segs.size()), ids(2 * R.segs.size());
                 for (size_t q = 0; q < R.segs.size(); ++q) {
                     co[2 * q] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)R.segs[q].x - std::min<uint64_t>(R.segs[q].x, 2000));
-                    co[2 * q + 1] = (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)R.segs[q].stop + 3000);
+                    co[2 * q + 1] = R.segs[q].stop ? (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)R.segs[q].stop + 3000) : cs.ctgRight;
                 }
                 if ((r = b_ckreq.alloc(co.size() * 4 + reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(co.size() * 4 + reqs.size() * 12))) return r;
                 PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s));
@@ -836,14 +902,20 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         std::vector<JobPlan> plans;
         const uint64_t cap_full = cs.seqCap;
         for (size_t sd = 0; sd < cs.seeds.size(); ++sd) {
-            const uint32_t stop = R.segs.empty() ? 0u : (uint32_t)std::min<uint64_t>((uint64_t)R.segs[0].x + seg_ov, R.zone_end);
+            const uint32_t stop = R.segs.empty() ? 0u : first_stop(R);
             plans.push_back(JobPlan{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false});
         }
-        for (size_t q = 0; q < R.segs.size(); ++q) {
-            const uint64_t spanc = (uint64_t)R.segs[q].stop - R.segs[q].x;
-            const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
-            plans.push_back(JobPlan{1, (int)q, cap, R.segs[q].vid, (uint32_t)TRAV_MODE_SPEC, R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi});
-        }
+        // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
+        static const bool leap_first = !(std::getenv("PAG_LEAP_FIRST") && std::atoi(std::getenv("PAG_LEAP_FIRST")) == 0);
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t q = 0; q < R.segs.size(); ++q) {
+                if (R.segs[q].leap != ((pass == 0) == leap_first)) continue;
+                const uint64_t spanc = (R.segs[q].stop ? (uint64_t)R.segs[q].stop : (uint64_t)cs.ctgRight) - R.segs[q].x;
+                const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
+                JobPlan pl{1, (int)q, cap, R.segs[q].vid, (uint32_t)(R.segs[q].leap ? TRAV_MODE_LEAP : TRAV_MODE_SPEC), R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi};
+                pl.win_low = R.segs[q].leap ? R.segs[q].win_low : 0u;
+                plans.push_back(pl);
+            }
         if (wdebug)
             std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_walk0, i,
                          R.round, cs.seeds.size(), R.segs.size(), R.zone_end, cs.ctgLeft, cs.ctgRight);
@@ -913,21 +985,74 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         const size_t last = lo;
         if (last == be && last + 1 < P.v.size()) return 0;
-        {
-            T.v.insert(T.v.end(), P.v.begin() + (be + 1), P.v.begin() + (last + 1));
-            T.s.insert(T.s.end(), P.s.begin() + (be + 1), P.s.begin() + (last + 1));
-            T.pc.insert(T.pc.end(), P.pc.begin() + (be + 1), P.pc.begin() + (last + 1));
-            const size_t n0 = ch.prefmax.size();
-            ch.prefmax.resize(n0 + (last - be));
-            uint32_t mx = ch.prefmax[n0 - 1];
-            for (size_t x = be + 1; x <= last; ++x) {
-                mx = std::max(mx, P.pc[x]);
-                ch.prefmax[n0 + (x - be - 1)] = mx;
-            }
-            ch.size += sg.cum[last] - sg.cum[be];
-        }
+        extend_chain(ch, P.v.data() + (be + 1), P.s.data() + (be + 1), P.pc.data() + (be + 1), last - be);
         n_adopted += last - be;
         return last + 1 == P.v.size() ? 1 : 2;
+    };
+
+    // Adoption of a finished segment of the LEAPING zone (TRAV_MODE_LEAP).  Leaping being possible, a classification admits
+    // more: Skip grades and landings on other contigs (PAlgorithm.tcc:69-86), hence vertices without a contig coordinate on
+    // the paths and records whose fate the coordinate windows decide (existCtgPos).  What an examined record's verdict
+    // depends on, besides the record: the contig's global marks and the landing rule (the same for both walks), the probe's
+    // own marks and window (fresh at an iteration boundary), the travel-visited set, the travel window, and whether leaping
+    // is possible.  The splice is exact if
+    //   (1) T ends at P[be], an iteration boundary of the segment's walk too (both walks classify that vertex at the top
+    //       level next, with no probe under way), and going backwards T and P agree on t + 1 >= 5 vertices and steps;
+    //   (2) the real walk can leap from here on (true sizes), as the segment's walk could all along;
+    //   (3) the travel windows agree: same upper end (the highest coordinate of T and of P[.. be]); the lower ends are lowM
+    //       (lowest coordinate of T) and the value forced on the segment's walk (win_low): no window-dependent record it
+    //       examined may lie between the two (the job reports the extremes of those records), and P[.. b) itself lies inside
+    //       the real walk's window;
+    //   (4) no examined record of an iteration that starts at P[be] or later leads to a vertex only ONE of the walks has
+    //       visited, D = T[.. a) + P[.. b).  A record is one of three kinds.  Window-dependent (a coordinate, not following
+    //       the contig): a target in D lies inside both travel windows by (3) and is rejected by both.  Contig-following: the
+    //       job logs, per iteration, the lowest coordinate of any such record it examined (elow): above every coordinate
+    //       in D.  No coordinate: the job logs the lowest new id of any such target (m0; these ids are ordered by the
+    //       reference coordinate, trav_order): above every id of that kind in D.  Records examined by probes of earlier
+    //       iterations that are still walking are logged with the iteration they are examined in.
+    // Then every verdict from P[be] on is the one the real walk reaches, and P[be + 1 ..] is its path.
+    // Returns 0: refused, 1: adopted to the end of P.
+    auto try_merge_leap = [&](uint32_t i, Chain &ch, Seg &sg) -> int {
+        CtgState &cs = st[i];
+        RoundState &R = RS[i];
+        Piece &T = ch.T;
+        const Piece &P = sg.P;
+        auto refuse = [&](int why) {
+            n_leap_refused[why & 7] += 1;
+            if (wdebug) std::fprintf(stderr, "[walk] contig %u: leap segment at %u refused (reason %d)\n", i, sg.x, why);
+            return 0;
+        };
+        if (!sg.usable || T.v.empty() || P.v.empty()) return refuse(0);
+        const size_t e = T.v.size() - 1;
+        const uint32_t cT = ch.prefmax[e];
+        size_t be = P.v.size();
+        for (size_t x = 0; x < P.v.size() && sg.sufmin[x] <= cT; ++x)
+            if (P.v[x] == T.v[e]) {
+                be = x;
+                break;
+            }
+        if (be == P.v.size()) return refuse(1);
+        if (!sg.boundary[be]) return refuse(2);
+        size_t t = 0;
+        while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
+        const size_t a = e - t, b = be - t;
+        if (t < 4) return refuse(1);
+        const uint64_t split = (uint64_t)(cs.len * startSplit);
+        if (R.has_size + k + ch.size < split) return refuse(3);
+        if (ch.prefmax[e] != sg.prefmax[be]) return refuse(4);
+        const uint32_t lowM = ch.low_nz;
+        if (sg.wd_below_max != 0u && sg.wd_below_max >= lowM) return refuse(5);
+        if (sg.wd_forced_min < lowM) return refuse(5);
+        if (b && sg.prefmin[b - 1] < lowM) return refuse(5);
+        const uint32_t dmax = std::max<uint32_t>(a ? ch.prefmax[a - 1] : 0u, b ? sg.prefmax[b - 1] : 0u);
+        if (sg.suf_elow[be] <= dmax) return refuse(6);
+        const uint32_t d0 = std::max<uint32_t>(a ? ch.prefmax0[a - 1] : 0u, b ? sg.prefmax0[b - 1] : 0u);  // (id + 1, 0: none)
+        if (d0 != 0u && sg.suf_m0[be] != 0xFFFFFFFFu && sg.suf_m0[be] + 1u <= d0) return refuse(7);
+        const size_t last = P.v.size() - 1;
+        extend_chain(ch, P.v.data() + (be + 1), P.s.data() + (be + 1), P.pc.data() + (be + 1), last - be);
+        n_adopted += last - be;
+        n_leap_adopted += 1;
+        return 1;
     };
 
     // what a chain does after its job has ended at a stop coordinate or after a segment it waits for has finished
@@ -936,7 +1061,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         Chain &ch = R.chains[(size_t)c];
         for (;;) {
             if (ch.final || ch.job >= 0) return PAG_OK;
-            const uint32_t cT = ch.T.pc.empty() ? 0u : ch.T.pc.back();
+            // (where the chain stands: its highest coordinate — its last vertex may have none in the leaping zone)
+            const uint32_t cT = ch.prefmax.empty() ? 0u : ch.prefmax.back();
             // the last segment that starts at or before the chain's end
             int j = -1;
             for (int q = (int)R.segs.size() - 1; q >= ch.next_seg; --q)
@@ -944,22 +1070,23 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                     j = q;
                     break;
                 }
-            if (j < 0 || cT == 0 || cT >= R.zone_end) {  // nothing ahead to adopt: walk to the end
+            if (j < 0 || cT == 0) {  // no segment to adopt here: walk on to the next checkpoint, or to the end
                 ch.waiting_seg = -1;
-                if (j < 0 && cT != 0 && cT < R.zone_end && ch.next_seg < (int)R.segs.size()) {
-                    // the chain has not reached the next checkpoint yet (its job stopped short): go on to it
-                    const Seg &nx = R.segs[(size_t)ch.next_seg];
-                    return post_resume(i, c, (uint32_t)std::min<uint64_t>((uint64_t)nx.x + seg_ov, R.zone_end));
-                }
+                if (cT != 0 && ch.next_seg < (int)R.segs.size()) return post_resume(i, c, stop_for(R, (size_t)ch.next_seg));
                 return post_resume(i, c, 0u);
             }
             Seg &sg = R.segs[(size_t)j];
+            if (!sg.leap && cT >= R.zone_end) {  // past the cut zone of the segments that cannot leap: on to the leaping zone's
+                ch.next_seg = j + 1;
+                while (ch.next_seg < (int)R.segs.size() && !R.segs[(size_t)ch.next_seg].leap) ++ch.next_seg;
+                continue;
+            }
             if (!sg.done) {
                 ch.waiting_seg = j;
                 return PAG_OK;
             }
             ch.waiting_seg = -1;
-            const int m = try_merge(i, ch, sg);
+            const int m = sg.leap ? try_merge_leap(i, ch, sg) : try_merge(i, ch, sg);
             ch.next_seg = j + 1;
             if (m == 1) {
                 if (!sg.stopped) {  // the segment's walk ended by itself, and so does the real one
@@ -968,7 +1095,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 }
                 continue;  // on to the next segment
             }
-            if (m == 2) return post_resume(i, c, 0u);  // the leaping zone begins
+            if (m == 2) {  // the leaping zone begins: exactly up to its first segment (if any)
+                while (ch.next_seg < (int)R.segs.size() && !R.segs[(size_t)ch.next_seg].leap) ++ch.next_seg;
+                continue;
+            }
             ++n_merge_fail;
             if (wdebug) std::fprintf(stderr, "[walk] contig %u chain %d: segment %d not adoptable, walking on exactly\n", i, c, j);
             // (the next turn of the loop finds no started segment any more and resumes up to the next checkpoint, or to the end)
@@ -1091,6 +1221,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             uint32_t jn;
             uint64_t from, len, off;       // the part of the sequence that is new; word offset of its 3 * len packed words
             const uint32_t *v, *s, *pc;     // ... in the pinned staging area (valid until the next batch)
+            const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: low / high words of the iteration log
         };
         std::vector<Got> got(fin.size());
         {
@@ -1105,9 +1236,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 G2.from = std::min<uint64_t>(jref[slot].init_len, o.seq_len);
                 G2.len = o.seq_len - G2.from;
                 G2.off = tot;
-                tot += 3 * G2.len;
+                tot += (J.seq_x ? 5 : 3) * G2.len;
                 max_len = std::max(max_len, G2.len);
-                descs[x] = TravPackDesc{J.seq_v + G2.from, J.seq_s + G2.from, G2.len, G2.off};
+                descs[x] = TravPackDesc{J.seq_v + G2.from, J.seq_s + G2.from, G2.len, G2.off, J.seq_x ? J.seq_x + G2.from : nullptr};
             }
             uint32_t *hp = (uint32_t *)pinned(tot * 4 + fin.size() * sizeof(TravPackDesc) + 256);
             if (!hp) return fail(PAG_ENOMEM);
@@ -1125,6 +1256,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 G2.v = hp + G2.off;
                 G2.s = G2.v + G2.len;
                 G2.pc = G2.s + G2.len;
+                if (hjobs[G2.jn].J.seq_x) {
+                    G2.xl = G2.pc + G2.len;
+                    G2.xh = G2.xl + G2.len;
+                }
             }
         }
         lap("fetch");
@@ -1166,20 +1301,47 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                         sg.cum[x] = (uint32_t)c2;
                         mx = std::max(mx, sg.P.pc[x]);
                         sg.prefmax[x] = mx;
-                        if (sg.P.pc[x] == 0) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
+                        if (sg.P.pc[x] == 0 && !sg.leap) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
                     }
                     uint32_t mn = 0xFFFFFFFFu;
-                    for (size_t x = n; x-- > 0;) {
-                        mn = std::min(mn, sg.P.pc[x]);
+                    for (size_t x = n; x-- > 0;) {  // (vertices without a coordinate do not count)
+                        if (sg.P.pc[x] != 0) mn = std::min(mn, sg.P.pc[x]);
                         sg.sufmin[x] = mn;
+                    }
+                    if (sg.leap) {
+                        sg.usable = sg.usable && G2.xl != nullptr;
+                        sg.boundary.assign(n, 0);
+                        sg.suf_elow.assign(n, 0xFFFFFFFFu);
+                        sg.suf_m0.assign(n, 0xFFFFFFFFu);
+                        sg.prefmax0.assign(n, 0);
+                        sg.prefmin.assign(n, 0xFFFFFFFFu);
+                        uint32_t el = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+                        for (size_t x = n; sg.usable && x-- > 0;) {
+                            if (G2.xh[x] >> 31) {
+                                sg.boundary[x] = 1;
+                                el = std::min(el, G2.xh[x] & 0x7FFFFFFFu);
+                                m0 = std::min(m0, G2.xl[x]);
+                            }
+                            sg.suf_elow[x] = el;
+                            sg.suf_m0[x] = m0;
+                        }
+                        uint32_t p0 = 0, pm = 0xFFFFFFFFu;
+                        for (size_t x = 0; x < n; ++x) {
+                            if (sg.P.pc[x] == 0) p0 = std::max(p0, sg.P.v[x] + 1u);
+                            else pm = std::min(pm, sg.P.pc[x]);
+                            sg.prefmax0[x] = p0;
+                            sg.prefmin[x] = pm;
+                        }
+                        sg.wd_below_max = o.wd_below_max;
+                        sg.wd_forced_min = o.wd_forced_min;
                     }
                     sg.max_back = o.max_back;
                     sg.max_chosen = std::max<uint32_t>(o.max_chosen, 1u);
                     sg.max_probe = o.max_probe;
                 }
                 if (wdebug)
-                    std::fprintf(stderr, "[walk] t=%.1f ms contig %u segment %d done: %llu vertices, %s, %s (classify %llu, back %u, chosen %u, probe %llu)\n", now_ms() - tw0, i, jr.idx,
-                                 (unsigned long long)o.seq_len, sg.stopped ? "stopped" : "ended", sg.usable ? "usable" : "NOT usable", (unsigned long long)o.n_classify,
+                    std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u segment %d done: %llu vertices, %s, %s (flags %d, outside %llu, classify %llu, back %u, chosen %u, probe %llu)\n", now_ms() - tw0,
+                                 (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)o.seq_len, sg.stopped ? "stopped" : "ended", sg.usable ? "usable" : "NOT usable", o.overflow, (unsigned long long)o.n_out, (unsigned long long)o.n_classify,
                                  o.max_back, o.max_chosen, (unsigned long long)o.max_probe);
                 continue;
             }
@@ -1205,22 +1367,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 continue;
             }
             // the new part of the path
-            {
-                ch.T.v.insert(ch.T.v.end(), G2.v, G2.v + G2.len);
-                ch.T.s.insert(ch.T.s.end(), G2.s, G2.s + G2.len);
-                ch.T.pc.insert(ch.T.pc.end(), G2.pc, G2.pc + G2.len);
-                const size_t n0 = ch.prefmax.size();
-                ch.prefmax.resize(n0 + G2.len);
-                uint32_t mx = n0 ? ch.prefmax[n0 - 1] : 0u;
-                for (size_t x = 0; x < G2.len; ++x) {
-                    mx = std::max(mx, G2.pc[x]);
-                    ch.prefmax[n0 + x] = mx;
-                    ch.size += G2.s[x];
-                }
-            }
+            extend_chain(ch, G2.v, G2.s, G2.pc, (size_t)G2.len);
             if (!o.stopped) ch.final = true;
             if (wdebug)
-                std::fprintf(stderr, "[walk] t=%.1f ms contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0, i, jr.idx, (unsigned long long)G2.len,
+                std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0,
+                             (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)G2.len,
                              ch.T.v.size(), o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
         }
         std::sort(touched.begin(), touched.end());
@@ -1525,10 +1676,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     pinned_parked.clear();
     t_walk = now_ms() - tw0;
     lap("walk");
-    if (timing || wdebug)
+    if (timing || wdebug) {
+        std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                     (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted, (unsigned long long)n_leap_refused[0], (unsigned long long)n_leap_refused[1], (unsigned long long)n_leap_refused[2],
+                     (unsigned long long)n_leap_refused[3], (unsigned long long)n_leap_refused[4], (unsigned long long)n_leap_refused[5], (unsigned long long)n_leap_refused[6], (unsigned long long)n_leap_refused[7]);
         std::fprintf(stderr, "[timing] pieces: %llu segment jobs, %llu resume jobs, %llu vertices adopted, %llu segments not adoptable\n", (unsigned long long)n_seg_jobs,
                      (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted, (unsigned long long)n_merge_fail);
-
+    }
 
     // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)
     for (auto &cs : st) {

@@ -84,11 +84,22 @@ struct TravJob {
     // walk continues a path whose first init_len vertices are already in seq_v / seq_s (the job marks them visited, sums
     // their steps, then classifies the last one as graphTravel would at that point).  stop_pc != 0: the job ends at the
     // first graphTravel iteration boundary whose last vertex has a contig coordinate >= stop_pc (on the own strand).
+    // bit 2 (TRAV_MODE_LEAP): a piece started ahead of the walk INSIDE the leaping zone, walked as if leaping were possible
+    // from its first vertex on (split size = 0), its travel window forced down to win_low (the walk it will be spliced
+    // into has everything from its seed on in that window), and with a log of its iterations in seq_x.
     uint32_t mode;
     uint32_t stop_pc;
     uint64_t init_len;
+    uint32_t win_low;   // TRAV_MODE_LEAP: lower end forced on the travel coordinate window
+    uint32_t pad_;
+    // TRAV_MODE_LEAP: [seq_cap] zeroed; entry i != 0 <=> seq_v[i] is the last vertex of a chosen path, i.e. graphTravel
+    // classified it at the top level (an iteration boundary).  Entry = 1 << 63 | elow << 32 | m0 about the iteration that
+    // STARTS there: elow = lowest contig coordinate (31 bits, saturated) of any successor record that follows the contig
+    // (isEdgeSimilar().first) examined until the next boundary, m0 = lowest new id of any examined record whose target has
+    // no contig coordinate (all ones: none); records examined by probes of earlier iterations that are still walking count.
+    uint64_t *seq_x;
 };
-enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2 };
+enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2, TRAV_MODE_LEAP = 4 };
 
 struct TravJobOut {
     uint64_t seq_len, seq_size;
@@ -101,8 +112,12 @@ struct TravJobOut {
     uint32_t max_back;      // max over iterations of (coordinate of the branch vertex - lowest coordinate any probe of that
                             // iteration visited); the initial walkStraight counts as an iteration
     uint32_t max_chosen;    // longest chosen path appended in one iteration (vertices)
-    uint32_t reserved2;
+    uint32_t wd_below_max;  // window-dependent records (a coordinate, not following the contig): the highest coordinate below
+                            // TravJob::win_low (0: none) ...
     uint64_t max_probe;     // largest size (sum of steps) of any probe, zombies included
+    uint32_t wd_forced_min; // ... and the lowest one at or above it (all ones: none)
+    uint32_t reserved3;
+    uint64_t t_begin, t_end;  // 100 MHz device clock when the wave took the job / finished it (PAG_WALK_DEBUG timeline)
 #ifdef PAG_WALK_PROF
     uint64_t prof_t[12];  // cycles per section of the walk (development aid, make WALK_PROF=1)
     uint32_t prof_c[12];
@@ -123,7 +138,8 @@ struct TravQueue {
 struct TravPackDesc {  // one finished job of a fetch batch (k_pack_paths)
     const uint32_t *seq_v, *seq_s;  // first new vertex / step of the job's sequence
     uint64_t len;                   // how many
-    uint64_t off;                   // word offset of the job's 3 * len words in the packed buffer
+    uint64_t off;                   // word offset of the job's 3 * len (5 * len with seq_x) words in the packed buffer
+    const uint64_t *seq_x;          // iteration log of a TRAV_MODE_LEAP job (null otherwise)
 };
 
 constexpr uint32_t TRAV_SEED_PARTS = 16;  // waves per re-seed window request (k_seed_window)
@@ -157,7 +173,7 @@ void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s);
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);
-int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, hipStream_t s);
+int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
 // bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
 int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s);
