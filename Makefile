@@ -11,9 +11,12 @@ CXXFLAGS := -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude -Ialigngraph2_amd/csrc/
 ifdef WALK_PROF
 PROF_FLAGS := -DPAG_WALK_PROF
 endif
-WALK_WINDOW ?= large
+WALK_WINDOW ?= tiny
 ifeq ($(WALK_WINDOW),small)
 PROF_FLAGS += -DPAG_WALK_SMALL_WINDOW
+endif
+ifeq ($(WALK_WINDOW),tiny)
+PROF_FLAGS += -DPAG_WALK_TINY_WINDOW
 endif
 HIPFLAGS := $(PROF_FLAGS) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall -Wno-unused-value
 

@@ -414,12 +414,19 @@ static_assert(GL == 8u || GL == 16u, "slot geometry");
 // vertices of the strand — refilled with wave-wide coalesced loads every couple of hundred steps.  The
 // window is a pure read cache: every mark is written through to the global arrays, and any access that
 // falls outside the window uses them directly.
-// Two window sizes: the large one (default build) fills a compute unit's LDS with ONE walker wave; the small one
-// (make WALK_WINDOW=small) leaves room for TWO waves per compute unit.  Measured at BASELINE configs[1]: the small window
-// alone costs 2.5 % (three times as many, half as large refills), but two resident walker waves per compute unit made the
-// walks 60 % SLOWER (553 vs 348 ms) — the waves are bound by instruction issue and latency, and two of them on one
-// compute unit evidently get in each other's way (shared instruction / scalar caches; the kernel is ~100 KB of code).
-#ifdef PAG_WALK_SMALL_WINDOW
+// Three window sizes (make WALK_WINDOW=tiny|small|large): they leave room for three, two or one walker wave per compute
+// unit.  A lone wave is fastest per step with the large window (the small one costs 2.5 %: three times as many refills),
+// and more waves per compute unit slow each other down (two: x 0.72 per wave) — which decided for ONE wave while a
+// contig's exact tail was the critical path (round 2, first cut: 348 ms, two waves 553 ms).  With the leaping zone cut
+// into pieces as well the walks are bound by the throughput of the whole grid, and more, slower waves win: 246 ms (large,
+// 256 waves), 180 ms (small, 512), 165 ms (tiny, 768) at BASELINE configs[1].  Default: tiny.
+#if defined(PAG_WALK_TINY_WINDOW)
+constexpr uint32_t WIN_IDS = 256;
+constexpr uint32_t WIN_REC = 832;
+constexpr uint32_t FILT_WORDS = 128;
+constexpr uint32_t WIN_BACK = 32;
+constexpr uint32_t WIN_AHEAD = 64;
+#elif defined(PAG_WALK_SMALL_WINDOW)
 constexpr uint32_t WIN_IDS = 512;
 constexpr uint32_t WIN_REC = 1792;
 constexpr uint32_t FILT_WORDS = 256;  // 16 Ki-bit membership filters in front of the outside-range hash sets
@@ -2501,7 +2508,10 @@ void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, 
     if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k);
 }
 // walker waves (= 64-thread workgroups) that fit one compute unit: by the LDS a wave's window takes
-int trav_walk_waves_per_cu() { return sizeof(WalkLds) * 2 <= 160 * 1024 ? 2 : 1; }
+int trav_walk_waves_per_cu() {
+    const size_t n = (160 * 1024) / sizeof(WalkLds);
+    return n >= 4 ? 4 : n >= 1 ? (int)n : 1;
+}
 void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,
                                  uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_timeout, hipStream_t s) {
     k_walk_persistent<<<dim3(n_waves), dim3(64), 0, s>>>(G, jobs, outs, done, q, next, cap, k, idle_timeout);

@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -158,6 +160,70 @@ int64_t append_seq(std::vector<LNode> &base, const std::vector<LNode> &tail, uin
 }
 
 }  // namespace
+
+namespace pagdev {
+// Worker threads for the host side of the stitch (see pag_travel).  A batch of independent items is published as an
+// immutable job object; the workers poll the pointer (a read-only load: no traffic on the line while nothing changes),
+// briefly spinning and then sleeping tens of microseconds between polls, and take item numbers from the job's counter.
+struct StitchPool {
+    struct Job {
+        std::function<void(size_t)> fn;
+        size_t n = 0;
+        alignas(64) std::atomic<size_t> next{0};
+        alignas(64) std::atomic<size_t> done{0};
+    };
+    std::vector<std::thread> th;
+    std::vector<Job *> jobs;  // every job of this pool's life (freed when the pool stops: a late worker may still hold one)
+    alignas(64) std::atomic<Job *> cur{nullptr};
+    alignas(64) std::atomic<bool> quit{false};
+    static void work(Job *j) {
+        for (size_t i2; (i2 = j->next.fetch_add(1, std::memory_order_acq_rel)) < j->n;) {
+            j->fn(i2);
+            j->done.fetch_add(1, std::memory_order_acq_rel);
+        }
+    }
+    void worker() {
+        Job *last = nullptr;
+        unsigned idle = 0;
+        while (!quit.load(std::memory_order_acquire)) {
+            Job *j = cur.load(std::memory_order_acquire);
+            if (j == last) {
+                if (++idle < 256) __builtin_ia32_pause();
+                else std::this_thread::sleep_for(std::chrono::microseconds(40));
+                continue;
+            }
+            idle = 0;
+            last = j;
+            work(j);
+        }
+    }
+    void start(unsigned workers) {
+        for (unsigned t = 0; t < workers; ++t) th.emplace_back([this] { worker(); });
+    }
+    void stop() {
+        quit.store(true, std::memory_order_release);
+        for (auto &t : th) t.join();
+        th.clear();
+        for (Job *j : jobs) delete j;
+        jobs.clear();
+    }
+    void run(size_t count, const std::function<void(size_t)> &f) {
+        if (count == 0) return;
+        if (th.empty() || count == 1) {
+            for (size_t i2 = 0; i2 < count; ++i2) f(i2);
+            return;
+        }
+        Job *j = new Job;
+        j->fn = f;
+        j->n = count;
+        jobs.push_back(j);
+        cur.store(j, std::memory_order_release);
+        work(j);
+        while (j->done.load(std::memory_order_acquire) < count) __builtin_ia32_pause();
+    }
+    ~StitchPool() { stop(); }
+};
+}  // namespace pagdev
 
 extern "C" {
 
@@ -557,6 +623,21 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     const uint64_t seg_ov = std::getenv("PAG_SEG_OVERLAP") ? std::strtoull(std::getenv("PAG_SEG_OVERLAP"), nullptr, 10) : 1500;
     const bool force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
 
+    // Worker threads for the host side of the stitch: with three walker waves per compute unit the device finishes a few
+    // thousand jobs in ~150 ms, and copying / indexing / splicing their paths on ONE thread took ~100 ms of that.  The
+    // workers spin while the walks run (a batch arrives every millisecond or so; waking sleeping threads would cost more
+    // than the work), and take the items of a batch from a shared counter.
+    pagdev::StitchPool spool;
+    std::mutex post_mu;  // posting jobs (buffers, rings, the side stream) is serial
+    double t_st[4] = {0, 0, 0, 0};  // stitch: bookkeeping / paths of finished jobs / chains moving on; posting (inside the others)
+    {
+        // Off by default.  Measured on the GPU box (16-CPU cgroup quota, busy host): 6 workers cut the path copies from 33 to
+        // 13 ms, but every HIP call of the control thread (posting, fetching, re-seeding) got several times slower and the
+        // walks took 230-450 ms instead of 165-180 ms.
+        unsigned want = 0;
+        if (const char *e = std::getenv("PAG_STITCH_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
+        spool.start(want);
+    }
     struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
         std::vector<uint32_t> v, s, pc;
     };
@@ -616,8 +697,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     };
     std::vector<JobRef> jref(NR * (size_t)QCAP);
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
-    uint64_t n_adopted = 0, n_merge_fail = 0, n_seg_jobs = 0, n_resume_jobs = 0;
-    uint64_t n_leap_jobs = 0, n_leap_adopted = 0, n_leap_refused[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];  // (touched by the stitch workers)
+    for (auto &x : n_leap_refused) x = 0;
+    uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
     const bool use_leap_pieces = !(std::getenv("PAG_LEAP_PIECES") && std::atoi(std::getenv("PAG_LEAP_PIECES")) == 0);
     // T grows by a job's new vertices or by an adopted stretch of a segment
     auto extend_chain = [&](auto &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n) {
@@ -664,6 +746,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // the walker only by publish())
     auto post_batch = [&](uint32_t i, int grp, const std::vector<JobPlan> &plans) -> int {
         if (plans.empty()) return PAG_OK;
+        std::lock_guard<std::mutex> post_lock(post_mu);
+        const double tp0 = now_ms();
+        struct PostTimer {
+            double t0, *acc;
+            ~PostTimer() { *acc += now_ms() - t0; }
+        } post_timer{tp0, &t_st[3]};
         CtgState &cs = st[i];
         RoundState &R = RS[i];
         const uint64_t PG = TRAV_PROBE_GROUPS;
@@ -824,7 +912,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
             // jobs; shorter ones pay more overlap and job start-up, longer ones lengthen the first piece of every chain)
             const uint64_t seg_len = seg_len_env ? seg_len_env : 12000;
-            const uint64_t safety = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 100 + 2000;
+            // (only decides how much is walked in parallel: every adoption is checked against the true sizes)
+            const uint64_t safety = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 1000 + 1500;
             if (split > H + safety + seg_len) {
                 const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H - safety), (uint64_t)cs.ctgRight - 1);
                 for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
@@ -835,10 +924,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 // the leaping zone gets segments of its own (TRAV_MODE_LEAP), from where the real walk has certainly begun to
                 // leap (the steps follow the coordinate closely, not exactly: a margin; every adoption is checked with the true
                 // size) to the end of the strand
+                // (a walk there makes three times the classifications per vertex: shorter pieces for the same job length)
+                static const uint64_t leap_len_env = std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 0;
+                const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
                 const uint64_t drift = cs.len / 400 + 200;
-                const uint64_t first = (uint64_t)x0 + (split > H ? split - H + drift : seg_len);
-                for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + seg_len); x + seg_len / 4 < (uint64_t)cs.ctgRight - 1; x += seg_len)
-                    if (ck_x.empty() || x > (uint64_t)ck_x.back() + seg_len / 4) ck_x.push_back((uint32_t)x);
+                const uint64_t first = (uint64_t)x0 + (split > H ? split - H + drift : lseg);
+                for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 < (uint64_t)cs.ctgRight - 1; x += lseg)
+                    if (ck_x.empty() || x > (uint64_t)ck_x.back() + lseg / 4) ck_x.push_back((uint32_t)x);
             }
         }
         if (!ck_x.empty()) {
@@ -1264,8 +1356,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         lap("fetch");
 
+        const double ts0 = now_ms();
         std::vector<uint32_t> touched;  // contigs with news
-        for (Got &G2 : got) {
+        // serial part: bookkeeping, and the (rare) jobs that have to be posted again
+        std::vector<size_t> heavy;  // items of `got` whose path has to be copied / indexed
+        for (size_t gx = 0; gx < got.size(); ++gx) {
+            Got &G2 = got[gx];
             const uint32_t slot = G2.jn;
             JobRef &jr = jref[slot];
             const TravJobOut o = houts[slot];
@@ -1282,67 +1378,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             touched.push_back(i);
             if (jr.kind == 1) {  // a segment
                 Seg &sg = R.segs[(size_t)jr.idx];
-                sg.done = true;
                 sg.usable = !overflow && !misspec && G2.len >= 8;
                 sg.stopped = o.stopped != 0;
-                if (sg.usable) {
-                    sg.P.v.assign(G2.v, G2.v + G2.len);
-                    sg.P.s.assign(G2.s, G2.s + G2.len);
-                    sg.P.pc.assign(G2.pc, G2.pc + G2.len);
-                    const size_t n = sg.P.v.size();
-                    sg.cum.resize(n);
-                    sg.prefmax.resize(n);
-                    sg.sufmin.resize(n);
-                    uint64_t c2 = 0;
-                    uint32_t mx = 0;
-                    for (size_t x = 0; x < n; ++x) {
-                        c2 += sg.P.s[x];
-                        if (c2 > 0xFFFFFFF0ull) sg.usable = false;  // (never: steps are read offsets)
-                        sg.cum[x] = (uint32_t)c2;
-                        mx = std::max(mx, sg.P.pc[x]);
-                        sg.prefmax[x] = mx;
-                        if (sg.P.pc[x] == 0 && !sg.leap) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
-                    }
-                    uint32_t mn = 0xFFFFFFFFu;
-                    for (size_t x = n; x-- > 0;) {  // (vertices without a coordinate do not count)
-                        if (sg.P.pc[x] != 0) mn = std::min(mn, sg.P.pc[x]);
-                        sg.sufmin[x] = mn;
-                    }
-                    if (sg.leap) {
-                        sg.usable = sg.usable && G2.xl != nullptr;
-                        sg.boundary.assign(n, 0);
-                        sg.suf_elow.assign(n, 0xFFFFFFFFu);
-                        sg.suf_m0.assign(n, 0xFFFFFFFFu);
-                        sg.prefmax0.assign(n, 0);
-                        sg.prefmin.assign(n, 0xFFFFFFFFu);
-                        uint32_t el = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
-                        for (size_t x = n; sg.usable && x-- > 0;) {
-                            if (G2.xh[x] >> 31) {
-                                sg.boundary[x] = 1;
-                                el = std::min(el, G2.xh[x] & 0x7FFFFFFFu);
-                                m0 = std::min(m0, G2.xl[x]);
-                            }
-                            sg.suf_elow[x] = el;
-                            sg.suf_m0[x] = m0;
-                        }
-                        uint32_t p0 = 0, pm = 0xFFFFFFFFu;
-                        for (size_t x = 0; x < n; ++x) {
-                            if (sg.P.pc[x] == 0) p0 = std::max(p0, sg.P.v[x] + 1u);
-                            else pm = std::min(pm, sg.P.pc[x]);
-                            sg.prefmax0[x] = p0;
-                            sg.prefmin[x] = pm;
-                        }
-                        sg.wd_below_max = o.wd_below_max;
-                        sg.wd_forced_min = o.wd_forced_min;
-                    }
-                    sg.max_back = o.max_back;
-                    sg.max_chosen = std::max<uint32_t>(o.max_chosen, 1u);
-                    sg.max_probe = o.max_probe;
-                }
-                if (wdebug)
-                    std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u segment %d done: %llu vertices, %s, %s (flags %d, outside %llu, classify %llu, back %u, chosen %u, probe %llu)\n", now_ms() - tw0,
-                                 (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)o.seq_len, sg.stopped ? "stopped" : "ended", sg.usable ? "usable" : "NOT usable", o.overflow, (unsigned long long)o.n_out, (unsigned long long)o.n_classify,
-                                 o.max_back, o.max_chosen, (unsigned long long)o.max_probe);
+                if (sg.usable) heavy.push_back(gx);
+                else sg.done = true;
                 continue;
             }
             Chain &ch = R.chains[(size_t)jr.idx];
@@ -1366,25 +1405,117 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 if ((rc = post_batch(i, GRP_CHAIN0 + jr.idx, plans))) return fail(rc);
                 continue;
             }
-            // the new part of the path
-            extend_chain(ch, G2.v, G2.s, G2.pc, (size_t)G2.len);
             if (!o.stopped) ch.final = true;
-            if (wdebug)
-                std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0,
-                             (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)G2.len,
-                             ch.T.v.size(), o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
+            heavy.push_back(gx);
         }
+        const double ts1 = now_ms();
+        // parallel part: the paths of the finished jobs (a job belongs to one segment or one chain: the items are independent)
+        spool.run(heavy.size(), [&](size_t hx) {
+            Got &G2 = got[heavy[hx]];
+            const uint32_t slot = G2.jn;
+            const JobRef &jr = jref[slot];
+            const TravJobOut o = houts[slot];
+            RoundState &R = RS[jr.ctg];
+            if (jr.kind != 1) {  // the new part of a chain's path
+                extend_chain(R.chains[(size_t)jr.idx], G2.v, G2.s, G2.pc, (size_t)G2.len);
+                return;
+            }
+            Seg &sg = R.segs[(size_t)jr.idx];
+            sg.P.v.assign(G2.v, G2.v + G2.len);
+            sg.P.s.assign(G2.s, G2.s + G2.len);
+            sg.P.pc.assign(G2.pc, G2.pc + G2.len);
+            const size_t n = sg.P.v.size();
+            sg.cum.resize(n);
+            sg.prefmax.resize(n);
+            sg.sufmin.resize(n);
+            uint64_t c2 = 0;
+            uint32_t mx = 0;
+            for (size_t x = 0; x < n; ++x) {
+                c2 += sg.P.s[x];
+                if (c2 > 0xFFFFFFF0ull) sg.usable = false;  // (never: steps are read offsets)
+                sg.cum[x] = (uint32_t)c2;
+                mx = std::max(mx, sg.P.pc[x]);
+                sg.prefmax[x] = mx;
+                if (sg.P.pc[x] == 0 && !sg.leap) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
+            }
+            uint32_t mn = 0xFFFFFFFFu;
+            for (size_t x = n; x-- > 0;) {  // (vertices without a coordinate do not count)
+                if (sg.P.pc[x] != 0) mn = std::min(mn, sg.P.pc[x]);
+                sg.sufmin[x] = mn;
+            }
+            if (sg.leap) {
+                sg.usable = sg.usable && G2.xl != nullptr;
+                sg.boundary.assign(n, 0);
+                sg.suf_elow.assign(n, 0xFFFFFFFFu);
+                sg.suf_m0.assign(n, 0xFFFFFFFFu);
+                sg.prefmax0.assign(n, 0);
+                sg.prefmin.assign(n, 0xFFFFFFFFu);
+                uint32_t el = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+                for (size_t x = n; sg.usable && x-- > 0;) {
+                    if (G2.xh[x] >> 31) {
+                        sg.boundary[x] = 1;
+                        el = std::min(el, G2.xh[x] & 0x7FFFFFFFu);
+                        m0 = std::min(m0, G2.xl[x]);
+                    }
+                    sg.suf_elow[x] = el;
+                    sg.suf_m0[x] = m0;
+                }
+                uint32_t p0 = 0, pm = 0xFFFFFFFFu;
+                for (size_t x = 0; x < n; ++x) {
+                    if (sg.P.pc[x] == 0) p0 = std::max(p0, sg.P.v[x] + 1u);
+                    else pm = std::min(pm, sg.P.pc[x]);
+                    sg.prefmax0[x] = p0;
+                    sg.prefmin[x] = pm;
+                }
+                sg.wd_below_max = o.wd_below_max;
+                sg.wd_forced_min = o.wd_forced_min;
+            }
+            sg.max_back = o.max_back;
+            sg.max_chosen = std::max<uint32_t>(o.max_chosen, 1u);
+            sg.max_probe = o.max_probe;
+            sg.done = true;
+        });
+        const double ts2 = now_ms();
+        if (wdebug)
+            for (Got &G2 : got) {
+                const uint32_t slot = G2.jn;
+                const JobRef &jr = jref[slot];
+                const TravJobOut o = houts[slot];
+                const uint32_t i = jr.ctg;
+                if (jr.kind == 1) {
+                    const Seg &sg = RS[i].segs[(size_t)jr.idx];
+                    std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u segment %d done: %llu vertices, %s, %s (flags %d, outside %llu, classify %llu, back %u, chosen %u, probe %llu)\n", now_ms() - tw0,
+                                 (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)o.seq_len, sg.stopped ? "stopped" : "ended", sg.usable ? "usable" : "NOT usable", o.overflow, (unsigned long long)o.n_out, (unsigned long long)o.n_classify,
+                                 o.max_back, o.max_chosen, (unsigned long long)o.max_probe);
+                } else if ((o.overflow & 7) == 0) {
+                    std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0,
+                                 (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)G2.len,
+                                 RS[i].chains[(size_t)jr.idx].T.v.size(), o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
+                }
+            }
         std::sort(touched.begin(), touched.end());
         touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-        for (uint32_t i : touched) {
-            RoundState &R = RS[i];
-            for (size_t c = 0; c < R.chains.size(); ++c) {
-                Chain &ch = R.chains[c];
-                if (ch.final || ch.job >= 0) continue;
-                if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
-                if ((rc = advance(i, (int)c))) return fail(rc);
-            }
+        {   // the chains of the touched contigs move on (adoptions, resumed walks): contigs are independent, posting is locked
+            std::atomic<int> first_rc{PAG_OK};
+            spool.run(touched.size(), [&](size_t tx) {
+                const uint32_t i = touched[tx];
+                RoundState &R = RS[i];
+                for (size_t c = 0; c < R.chains.size(); ++c) {
+                    Chain &ch = R.chains[c];
+                    if (ch.final || ch.job >= 0) continue;
+                    if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
+                    const int r2 = advance(i, (int)c);
+                    if (r2 != PAG_OK) {
+                        int expect = PAG_OK;
+                        first_rc.compare_exchange_strong(expect, r2);
+                    }
+                }
+            });
+            if ((rc = first_rc.load()) != PAG_OK) return fail(rc);
         }
+        t_st[0] += ts1 - ts0;
+        t_st[1] += ts2 - ts1;
+        t_st[2] += now_ms() - ts2;
         lap("stitch");
 
         // ---- contigs whose chains are all final: the round is decided
@@ -1677,11 +1808,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     t_walk = now_ms() - tw0;
     lap("walk");
     if (timing || wdebug) {
+        std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms\n", t_st[0], t_st[1], t_st[2], t_st[3]);
         std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
-                     (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted, (unsigned long long)n_leap_refused[0], (unsigned long long)n_leap_refused[1], (unsigned long long)n_leap_refused[2],
-                     (unsigned long long)n_leap_refused[3], (unsigned long long)n_leap_refused[4], (unsigned long long)n_leap_refused[5], (unsigned long long)n_leap_refused[6], (unsigned long long)n_leap_refused[7]);
+                     (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted.load(), (unsigned long long)n_leap_refused[0].load(), (unsigned long long)n_leap_refused[1].load(), (unsigned long long)n_leap_refused[2].load(),
+                     (unsigned long long)n_leap_refused[3].load(), (unsigned long long)n_leap_refused[4].load(), (unsigned long long)n_leap_refused[5].load(), (unsigned long long)n_leap_refused[6].load(), (unsigned long long)n_leap_refused[7].load());
         std::fprintf(stderr, "[timing] pieces: %llu segment jobs, %llu resume jobs, %llu vertices adopted, %llu segments not adoptable\n", (unsigned long long)n_seg_jobs,
-                     (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted, (unsigned long long)n_merge_fail);
+                     (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted.load(), (unsigned long long)n_merge_fail.load());
     }
 
     // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)

@@ -17,9 +17,11 @@ EXE = os.path.join(pagctl.ROOT, "aligngraph2_amd", "bin", "pagraph")
 # (every probe runs to its end before the choice) — both must reproduce the reference byte for byte
 # and the segment-parallel walk: at the default segment length the few-kb golden contigs are walked in one piece ("uncut"
 # is what the other two modes run); "pieces" cuts them every 400 bases so that checkpoints, adoption of segments and
-# resumed walks all happen on inputs whose exact outputs the reference wrote
+# resumed walks all happen on inputs whose exact outputs the reference wrote — the leaping zone included (its segments
+# can leap and are spliced under other conditions, k5_travel_host.hip try_merge_leap); "pieces-noleap" leaves the leaping
+# zone to one exact walk, as round 1 of the cut did
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact"])
+@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact", "pieces-noleap"])
 @pytest.mark.parametrize("name", goldens.case_names())
 def test_pagraph_matches_golden(name, mode, workdir):
     spec = goldens.load_spec(name)
@@ -28,18 +30,20 @@ def test_pagraph_matches_golden(name, mode, workdir):
     os.makedirs(out, exist_ok=True)
     argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
     env = dict(os.environ)
-    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES"):
+    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES", "PAG_LEAP_PIECES", "PAG_LEAP_FIRST"):
         env.pop(v, None)
     if mode.startswith("pieces"):
         env.update(PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200", PAGRAPH_TIMING="1")
     if mode.endswith("exact"):
         env["PAG_WALK_EXACT"] = "1"
+    if mode.endswith("noleap"):
+        env["PAG_LEAP_PIECES"] = "0"
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     assert "HIP gfx950" in r.stdout
     goldens.compare_out_dir(name, out)
     if mode == "pieces":
-        print([ln for ln in r.stderr.splitlines() if "pieces:" in ln])
+        print([ln for ln in r.stderr.splitlines() if "pieces:" in ln or "leaping zone:" in ln])
 
 
 @pytest.mark.gpu
