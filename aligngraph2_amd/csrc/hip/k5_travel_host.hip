@@ -15,8 +15,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
-#include <functional>
-#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -160,70 +158,6 @@ int64_t append_seq(std::vector<LNode> &base, const std::vector<LNode> &tail, uin
 }
 
 }  // namespace
-
-namespace pagdev {
-// Worker threads for the host side of the stitch (see pag_travel).  A batch of independent items is published as an
-// immutable job object; the workers poll the pointer (a read-only load: no traffic on the line while nothing changes),
-// briefly spinning and then sleeping tens of microseconds between polls, and take item numbers from the job's counter.
-struct StitchPool {
-    struct Job {
-        std::function<void(size_t)> fn;
-        size_t n = 0;
-        alignas(64) std::atomic<size_t> next{0};
-        alignas(64) std::atomic<size_t> done{0};
-    };
-    std::vector<std::thread> th;
-    std::vector<Job *> jobs;  // every job of this pool's life (freed when the pool stops: a late worker may still hold one)
-    alignas(64) std::atomic<Job *> cur{nullptr};
-    alignas(64) std::atomic<bool> quit{false};
-    static void work(Job *j) {
-        for (size_t i2; (i2 = j->next.fetch_add(1, std::memory_order_acq_rel)) < j->n;) {
-            j->fn(i2);
-            j->done.fetch_add(1, std::memory_order_acq_rel);
-        }
-    }
-    void worker() {
-        Job *last = nullptr;
-        unsigned idle = 0;
-        while (!quit.load(std::memory_order_acquire)) {
-            Job *j = cur.load(std::memory_order_acquire);
-            if (j == last) {
-                if (++idle < 256) __builtin_ia32_pause();
-                else std::this_thread::sleep_for(std::chrono::microseconds(40));
-                continue;
-            }
-            idle = 0;
-            last = j;
-            work(j);
-        }
-    }
-    void start(unsigned workers) {
-        for (unsigned t = 0; t < workers; ++t) th.emplace_back([this] { worker(); });
-    }
-    void stop() {
-        quit.store(true, std::memory_order_release);
-        for (auto &t : th) t.join();
-        th.clear();
-        for (Job *j : jobs) delete j;
-        jobs.clear();
-    }
-    void run(size_t count, const std::function<void(size_t)> &f) {
-        if (count == 0) return;
-        if (th.empty() || count == 1) {
-            for (size_t i2 = 0; i2 < count; ++i2) f(i2);
-            return;
-        }
-        Job *j = new Job;
-        j->fn = f;
-        j->n = count;
-        jobs.push_back(j);
-        cur.store(j, std::memory_order_release);
-        work(j);
-        while (j->done.load(std::memory_order_acquire) < count) __builtin_ia32_pause();
-    }
-    ~StitchPool() { stop(); }
-};
-}  // namespace pagdev
 
 extern "C" {
 
@@ -623,21 +557,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     const uint64_t seg_ov = std::getenv("PAG_SEG_OVERLAP") ? std::strtoull(std::getenv("PAG_SEG_OVERLAP"), nullptr, 10) : 1500;
     const bool force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
 
-    // Worker threads for the host side of the stitch: with three walker waves per compute unit the device finishes a few
-    // thousand jobs in ~150 ms, and copying / indexing / splicing their paths on ONE thread took ~100 ms of that.  The
-    // workers spin while the walks run (a batch arrives every millisecond or so; waking sleeping threads would cost more
-    // than the work), and take the items of a batch from a shared counter.
-    pagdev::StitchPool spool;
-    std::mutex post_mu;  // posting jobs (buffers, rings, the side stream) is serial
     double t_st[4] = {0, 0, 0, 0};  // stitch: bookkeeping / paths of finished jobs / chains moving on; posting (inside the others)
-    {
-        // Off by default.  Measured on the GPU box (16-CPU cgroup quota, busy host): 6 workers cut the path copies from 33 to
-        // 13 ms, but every HIP call of the control thread (posting, fetching, re-seeding) got several times slower and the
-        // walks took 230-450 ms instead of 165-180 ms.
-        unsigned want = 0;
-        if (const char *e = std::getenv("PAG_STITCH_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
-        spool.start(want);
-    }
+    // (The stitch below is serial on purpose.  Worker threads — spinning, polling or sleeping on a condition variable, 4 to
+    // 12 of them — cut the path copies from 33 to 10 ms on the GPU box (16-CPU cgroup quota, busy host), but every HIP call
+    // of this thread (posting, fetching, re-seeding) got several times slower while they were active and the walks took
+    // 180-450 ms instead of 165-180 ms.)
     struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
         std::vector<uint32_t> v, s, pc;
     };
@@ -697,7 +621,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     };
     std::vector<JobRef> jref(NR * (size_t)QCAP);
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
-    std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];  // (touched by the stitch workers)
+    std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];
     for (auto &x : n_leap_refused) x = 0;
     uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
     const bool use_leap_pieces = !(std::getenv("PAG_LEAP_PIECES") && std::atoi(std::getenv("PAG_LEAP_PIECES")) == 0);
@@ -746,7 +670,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // the walker only by publish())
     auto post_batch = [&](uint32_t i, int grp, const std::vector<JobPlan> &plans) -> int {
         if (plans.empty()) return PAG_OK;
-        std::lock_guard<std::mutex> post_lock(post_mu);
         const double tp0 = now_ms();
         struct PostTimer {
             double t0, *acc;
@@ -1410,7 +1333,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         const double ts1 = now_ms();
         // parallel part: the paths of the finished jobs (a job belongs to one segment or one chain: the items are independent)
-        spool.run(heavy.size(), [&](size_t hx) {
+        for (size_t hx = 0; hx < heavy.size(); ++hx) {
             Got &G2 = got[heavy[hx]];
             const uint32_t slot = G2.jn;
             const JobRef &jr = jref[slot];
@@ -1418,7 +1341,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             RoundState &R = RS[jr.ctg];
             if (jr.kind != 1) {  // the new part of a chain's path
                 extend_chain(R.chains[(size_t)jr.idx], G2.v, G2.s, G2.pc, (size_t)G2.len);
-                return;
+                continue;
             }
             Seg &sg = R.segs[(size_t)jr.idx];
             sg.P.v.assign(G2.v, G2.v + G2.len);
@@ -1474,7 +1397,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             sg.max_chosen = std::max<uint32_t>(o.max_chosen, 1u);
             sg.max_probe = o.max_probe;
             sg.done = true;
-        });
+        }
         const double ts2 = now_ms();
         if (wdebug)
             for (Got &G2 : got) {
@@ -1495,23 +1418,14 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
         std::sort(touched.begin(), touched.end());
         touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-        {   // the chains of the touched contigs move on (adoptions, resumed walks): contigs are independent, posting is locked
-            std::atomic<int> first_rc{PAG_OK};
-            spool.run(touched.size(), [&](size_t tx) {
-                const uint32_t i = touched[tx];
-                RoundState &R = RS[i];
-                for (size_t c = 0; c < R.chains.size(); ++c) {
-                    Chain &ch = R.chains[c];
-                    if (ch.final || ch.job >= 0) continue;
-                    if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
-                    const int r2 = advance(i, (int)c);
-                    if (r2 != PAG_OK) {
-                        int expect = PAG_OK;
-                        first_rc.compare_exchange_strong(expect, r2);
-                    }
-                }
-            });
-            if ((rc = first_rc.load()) != PAG_OK) return fail(rc);
+        for (uint32_t i : touched) {  // the chains of the touched contigs move on (adoptions, resumed walks)
+            RoundState &R = RS[i];
+            for (size_t c = 0; c < R.chains.size(); ++c) {
+                Chain &ch = R.chains[c];
+                if (ch.final || ch.job >= 0) continue;
+                if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
+                if ((rc = advance(i, (int)c))) return fail(rc);
+            }
         }
         t_st[0] += ts1 - ts0;
         t_st[1] += ts2 - ts1;
