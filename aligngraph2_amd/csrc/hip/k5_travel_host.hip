@@ -236,6 +236,30 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         return g->pin_host;
     };
 
+    // Pinned memory that keeps what it is given for the whole call: the fetched paths of finished jobs stay where the copy
+    // from the device put them (segments and chains refer to them by pointer).  64 MB chunks kept by the handle.
+    size_t fetch_chunk = 0, fetch_used = 0;
+    const size_t FETCH_CHUNK = 64u << 20;
+    auto fetch_alloc = [&](size_t bytes) -> void * {
+        bytes = (bytes + 255) & ~(size_t)255;
+        for (; fetch_chunk < g->fetch_chunks.size(); ++fetch_chunk, fetch_used = 0)
+            if (fetch_used + bytes <= g->fetch_chunk_bytes[fetch_chunk]) {
+                void *q = (char *)g->fetch_chunks[fetch_chunk] + fetch_used;
+                fetch_used += bytes;
+                return q;
+            }
+        void *q = nullptr;
+        const size_t want = std::max(FETCH_CHUNK, bytes);
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) {
+            set_error("pag_travel: hipHostMalloc(%zu) failed", want);
+            return nullptr;
+        }
+        g->fetch_chunks.push_back(q);
+        g->fetch_chunk_bytes.push_back(want);
+        fetch_used = bytes;  // (fetch_chunk is the index of the new chunk)
+        return q;
+    };
+
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
            b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(), b_ucnt = buf(),
@@ -565,32 +589,34 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
         std::vector<uint32_t> v, s, pc;
     };
+    struct View {  // a finished job's path where the fetch put it (pinned memory kept for the whole call)
+        const uint32_t *v = nullptr, *s = nullptr, *pc = nullptr;
+        const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: iteration log, low / high words
+        size_t n = 0;
+    };
     struct Seg {  // one segment job of a round
         uint32_t x = 0;      // checkpoint coordinate
         uint32_t stop = 0;   // its stop coordinate
         uint32_t vid = 0;    // start vertex (old id)
         uint32_t win_lo = 0, win_hi = 0;  // new-id range its job keeps direct-mapped marks for (around the segment)
         bool done = false, usable = false, stopped = false;
-        Piece P;
-        std::vector<uint32_t> cum;       // cum[i] = sum of the steps of P[0 .. i] (a segment is a few thousand vertices)
-        std::vector<uint32_t> prefmax;   // max coordinate over P[0 .. i]
-        std::vector<uint32_t> sufmin;    // min coordinate over P[i ..]
+        View P;  // (everything the splices need of it is computed from the arrays when a chain arrives: a few thousand entries)
         uint32_t max_back = 0, max_chosen = 0;
         uint64_t max_probe = 0;
         // a segment inside the leaping zone (TRAV_MODE_LEAP), see try_merge_leap:
         bool leap = false;
-        std::vector<uint8_t> boundary;   // P[i] is the last vertex of a chosen path of the segment's walk
-        std::vector<uint32_t> suf_elow;  // over the iterations that start at a boundary >= i: lowest coordinate of an examined
-                                         // contig-following record ...
-        std::vector<uint32_t> suf_m0;    // ... lowest id of an examined record without a contig coordinate
-        std::vector<uint32_t> prefmax0;  // highest id of a vertex without a contig coordinate in P[0 .. i] (0: none)
-        std::vector<uint32_t> prefmin;   // lowest non-zero coordinate in P[0 .. i]
         uint32_t wd_below_max = 0, wd_forced_min = 0xFFFFFFFFu, win_low = 0;
     };
     struct Chain {  // one graphTravel: (contig, seed) of the running round
         Piece T;    // the validated path so far
-        std::vector<uint32_t> prefmax;
-        std::vector<uint32_t> prefmax0;  // highest id of a vertex without a contig coordinate in T[0 .. i] (0: none)
+        // T grows piece by piece (a job's new vertices, an adopted stretch); per piece: where it starts and, over everything
+        // BEFORE it, the highest coordinate and the highest id (+ 1) of a vertex without a coordinate
+        struct Mark {
+            size_t start;
+            uint32_t mx, m0;
+        };
+        std::vector<Mark> marks;
+        uint32_t mx_all = 0, m0_all = 0;  // ... over all of T
         uint32_t low_nz = 0xFFFFFFFFu;   // lowest non-zero coordinate of T
         uint64_t size = 0;  // sum of its steps
         bool final = false;
@@ -626,22 +652,47 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
     const bool use_leap_pieces = !(std::getenv("PAG_LEAP_PIECES") && std::atoi(std::getenv("PAG_LEAP_PIECES")) == 0);
     // T grows by a job's new vertices or by an adopted stretch of a segment
-    auto extend_chain = [&](auto &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n) {
+    auto extend_chain = [&](Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n) {
+        if (n == 0) return;
+        ch.marks.push_back(Chain::Mark{ch.T.v.size(), ch.mx_all, ch.m0_all});
         ch.T.v.insert(ch.T.v.end(), v, v + n);
         ch.T.s.insert(ch.T.s.end(), sv, sv + n);
         ch.T.pc.insert(ch.T.pc.end(), pc, pc + n);
-        const size_t n0 = ch.prefmax.size();
-        ch.prefmax.resize(n0 + n);
-        ch.prefmax0.resize(n0 + n);
-        uint32_t mx = n0 ? ch.prefmax[n0 - 1] : 0u, m0 = n0 ? ch.prefmax0[n0 - 1] : 0u;
+        uint32_t mx = ch.mx_all, m0 = ch.m0_all, lo = ch.low_nz;
+        uint64_t sz = 0;
         for (size_t x = 0; x < n; ++x) {
-            mx = std::max(mx, pc[x]);
-            if (pc[x] == 0) m0 = std::max(m0, v[x] + 1u);  // (id + 1: 0 stands for "none")
-            else ch.low_nz = std::min(ch.low_nz, pc[x]);
-            ch.prefmax[n0 + x] = mx;
-            ch.prefmax0[n0 + x] = m0;
-            ch.size += sv[x];
+            const uint32_t c = pc[x];
+            mx = std::max(mx, c);
+            if (c == 0) m0 = std::max(m0, v[x] + 1u);  // (id + 1: 0 stands for "none")
+            else lo = std::min(lo, c);
+            sz += sv[x];
         }
+        ch.mx_all = mx;
+        ch.m0_all = m0;
+        ch.low_nz = lo;
+        ch.size += sz;
+    };
+    // highest coordinate / highest id + 1 of a coordinate-free vertex over T[0 .. idx)
+    auto chain_before = [&](const Chain &ch, size_t idx, uint32_t *mx_out, uint32_t *m0_out) {
+        uint32_t mx = 0, m0 = 0;
+        size_t from = 0;
+        if (!ch.marks.empty()) {
+            size_t lo = 0, hi = ch.marks.size() - 1;  // last piece that starts at or before idx
+            while (lo < hi) {
+                const size_t mid = (lo + hi + 1) / 2;
+                if (ch.marks[mid].start <= idx) lo = mid;
+                else hi = mid - 1;
+            }
+            mx = ch.marks[lo].mx;
+            m0 = ch.marks[lo].m0;
+            from = ch.marks[lo].start;
+        }
+        for (size_t x = from; x < idx; ++x) {
+            mx = std::max(mx, ch.T.pc[x]);
+            if (ch.T.pc[x] == 0) m0 = std::max(m0, ch.T.v[x] + 1u);
+        }
+        *mx_out = mx;
+        *m0_out = m0;
     };
     bool walker_up = false;
     auto shutdown_walker = [&]() {
@@ -968,41 +1019,43 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         CtgState &cs = st[i];
         RoundState &R = RS[i];
         Piece &T = ch.T;
-        const Piece &P = sg.P;
-        if (!sg.usable || T.v.empty() || P.v.empty()) return 0;
+        const View &P = sg.P;
+        if (!sg.usable || T.v.empty() || P.n == 0) return 0;
         const size_t e = T.v.size() - 1;
-        // the last vertex of T in P: P's coordinates grow (not strictly), sufmin says where the search can stop
-        size_t be = P.v.size();
-        for (size_t x = 0; x < P.v.size() && sg.sufmin[x] <= T.pc[e]; ++x)
+        size_t be = P.n;  // the last vertex of T in P
+        for (size_t x = 0; x < P.n; ++x)
             if (P.v[x] == T.v[e]) {
                 be = x;
                 break;
             }
-        if (be == P.v.size()) return 0;
+        if (be == P.n) return 0;
         size_t t = 0;
         while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
         const size_t a = e - t, b = be - t;
         if (t < 4) return 0;
-        const uint64_t dmax = std::max<uint64_t>(a ? ch.prefmax[a - 1] : 0u, b ? sg.prefmax[b - 1] : 0u);
+        uint32_t dT = 0, d0 = 0, dP = 0;
+        chain_before(ch, a, &dT, &d0);
+        for (size_t x = 0; x < b; ++x) dP = std::max(dP, P.pc[x]);
+        const uint64_t dmax = std::max(dT, dP);
         const size_t q = be + 1 > sg.max_chosen ? be + 1 - sg.max_chosen : 0;
-        const uint64_t low = sg.sufmin[q];
+        uint64_t low = 0xFFFFFFFFull;
+        for (size_t x = q; x < P.n; ++x) low = std::min<uint64_t>(low, P.pc[x]);
         if (low <= dmax + sg.max_back + deviation) return 0;
         const uint64_t split = (uint64_t)(cs.len * startSplit);
         const uint64_t base = R.has_size + k + ch.size + sg.max_probe + 1;
         if (base >= split) return 0;  // (no room: the caller resumes exactly)
         const uint64_t room = split - base;  // steps that may still be adopted
         // largest index whose cumulated steps behind P[be] stay below `room`
-        size_t lo = be, hi = P.v.size() - 1;
-        while (lo < hi) {
-            const size_t mid = (lo + hi + 1) / 2;
-            if ((uint64_t)(sg.cum[mid] - sg.cum[be]) < room) lo = mid;
-            else hi = mid - 1;
+        size_t last = be;
+        uint64_t cum = 0;
+        while (last + 1 < P.n && cum + P.s[last + 1] < room) {
+            cum += P.s[last + 1];
+            ++last;
         }
-        const size_t last = lo;
-        if (last == be && last + 1 < P.v.size()) return 0;
-        extend_chain(ch, P.v.data() + (be + 1), P.s.data() + (be + 1), P.pc.data() + (be + 1), last - be);
+        if (last == be && last + 1 < P.n) return 0;
+        extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be);
         n_adopted += last - be;
-        return last + 1 == P.v.size() ? 1 : 2;
+        return last + 1 == P.n ? 1 : 2;
     };
 
     // Adoption of a finished segment of the LEAPING zone (TRAV_MODE_LEAP).  Leaping being possible, a classification admits
@@ -1031,40 +1084,59 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         CtgState &cs = st[i];
         RoundState &R = RS[i];
         Piece &T = ch.T;
-        const Piece &P = sg.P;
+        const View &P = sg.P;
         auto refuse = [&](int why) {
             n_leap_refused[why & 7] += 1;
             if (wdebug) std::fprintf(stderr, "[walk] contig %u: leap segment at %u refused (reason %d)\n", i, sg.x, why);
             return 0;
         };
-        if (!sg.usable || T.v.empty() || P.v.empty()) return refuse(0);
+        if (!sg.usable || T.v.empty() || P.n == 0 || !P.xl) return refuse(0);
         const size_t e = T.v.size() - 1;
-        const uint32_t cT = ch.prefmax[e];
-        size_t be = P.v.size();
-        for (size_t x = 0; x < P.v.size() && sg.sufmin[x] <= cT; ++x)
+        size_t be = P.n;
+        for (size_t x = 0; x < P.n; ++x)
             if (P.v[x] == T.v[e]) {
                 be = x;
                 break;
             }
-        if (be == P.v.size()) return refuse(1);
-        if (!sg.boundary[be]) return refuse(2);
+        if (be == P.n) return refuse(1);
+        if (!(P.xh[be] >> 31)) return refuse(2);
         size_t t = 0;
         while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
         const size_t a = e - t, b = be - t;
         if (t < 4) return refuse(1);
         const uint64_t split = (uint64_t)(cs.len * startSplit);
         if (R.has_size + k + ch.size < split) return refuse(3);
-        if (ch.prefmax[e] != sg.prefmax[be]) return refuse(4);
+        // P[0 .. be]: highest coordinate; P[0 .. b): highest / lowest coordinate, highest id + 1 of a coordinate-free vertex
+        uint32_t p_top = 0, p_dmax = 0, p_min = 0xFFFFFFFFu, p_d0 = 0;
+        for (size_t x = 0; x <= be; ++x) {
+            const uint32_t c = P.pc[x];
+            p_top = std::max(p_top, c);
+            if (x < b) {
+                p_dmax = std::max(p_dmax, c);
+                if (c == 0) p_d0 = std::max(p_d0, P.v[x] + 1u);
+                else p_min = std::min(p_min, c);
+            }
+        }
+        if (ch.mx_all != p_top) return refuse(4);
         const uint32_t lowM = ch.low_nz;
         if (sg.wd_below_max != 0u && sg.wd_below_max >= lowM) return refuse(5);
         if (sg.wd_forced_min < lowM) return refuse(5);
-        if (b && sg.prefmin[b - 1] < lowM) return refuse(5);
-        const uint32_t dmax = std::max<uint32_t>(a ? ch.prefmax[a - 1] : 0u, b ? sg.prefmax[b - 1] : 0u);
-        if (sg.suf_elow[be] <= dmax) return refuse(6);
-        const uint32_t d0 = std::max<uint32_t>(a ? ch.prefmax0[a - 1] : 0u, b ? sg.prefmax0[b - 1] : 0u);  // (id + 1, 0: none)
-        if (d0 != 0u && sg.suf_m0[be] != 0xFFFFFFFFu && sg.suf_m0[be] + 1u <= d0) return refuse(7);
-        const size_t last = P.v.size() - 1;
-        extend_chain(ch, P.v.data() + (be + 1), P.s.data() + (be + 1), P.pc.data() + (be + 1), last - be);
+        if (p_min < lowM) return refuse(5);
+        // the iterations that start at a boundary >= be: lowest contig-following coordinate / coordinate-free id examined
+        uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+        for (size_t x = be; x < P.n; ++x)
+            if (P.xh[x] >> 31) {
+                elow = std::min(elow, P.xh[x] & 0x7FFFFFFFu);
+                m0 = std::min(m0, P.xl[x]);
+            }
+        uint32_t t_dmax = 0, t_d0 = 0;
+        chain_before(ch, a, &t_dmax, &t_d0);
+        const uint32_t dmax = std::max(t_dmax, p_dmax);
+        if (elow <= dmax) return refuse(6);
+        const uint32_t d0 = std::max(t_d0, p_d0);  // (id + 1, 0: none)
+        if (d0 != 0u && m0 != 0xFFFFFFFFu && m0 + 1u <= d0) return refuse(7);
+        const size_t last = P.n - 1;
+        extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be);
         n_adopted += last - be;
         n_leap_adopted += 1;
         return 1;
@@ -1077,7 +1149,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (;;) {
             if (ch.final || ch.job >= 0) return PAG_OK;
             // (where the chain stands: its highest coordinate — its last vertex may have none in the leaping zone)
-            const uint32_t cT = ch.prefmax.empty() ? 0u : ch.prefmax.back();
+            const uint32_t cT = ch.mx_all;
             // the last segment that starts at or before the chain's end
             int j = -1;
             for (int q = (int)R.segs.size() - 1; q >= ch.next_seg; --q)
@@ -1235,7 +1307,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         struct Got {
             uint32_t jn;
             uint64_t from, len, off;       // the part of the sequence that is new; word offset of its 3 * len packed words
-            const uint32_t *v, *s, *pc;     // ... in the pinned staging area (valid until the next batch)
+            const uint32_t *v, *s, *pc;     // ... in pinned memory that lives as long as this call (fetch_alloc)
             const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: low / high words of the iteration log
         };
         std::vector<Got> got(fin.size());
@@ -1255,7 +1327,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 max_len = std::max(max_len, G2.len);
                 descs[x] = TravPackDesc{J.seq_v + G2.from, J.seq_s + G2.from, G2.len, G2.off, J.seq_x ? J.seq_x + G2.from : nullptr};
             }
-            uint32_t *hp = (uint32_t *)pinned(tot * 4 + fin.size() * sizeof(TravPackDesc) + 256);
+            uint32_t *hp = (uint32_t *)fetch_alloc(tot * 4 + fin.size() * sizeof(TravPackDesc) + 256);
             if (!hp) return fail(PAG_ENOMEM);
             TravPackDesc *hd = (TravPackDesc *)(hp + ((tot + 3) & ~3ull));
             std::memcpy(hd, descs.data(), descs.size() * sizeof(TravPackDesc));
@@ -1344,52 +1416,17 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 continue;
             }
             Seg &sg = R.segs[(size_t)jr.idx];
-            sg.P.v.assign(G2.v, G2.v + G2.len);
-            sg.P.s.assign(G2.s, G2.s + G2.len);
-            sg.P.pc.assign(G2.pc, G2.pc + G2.len);
-            const size_t n = sg.P.v.size();
-            sg.cum.resize(n);
-            sg.prefmax.resize(n);
-            sg.sufmin.resize(n);
-            uint64_t c2 = 0;
-            uint32_t mx = 0;
-            for (size_t x = 0; x < n; ++x) {
-                c2 += sg.P.s[x];
-                if (c2 > 0xFFFFFFF0ull) sg.usable = false;  // (never: steps are read offsets)
-                sg.cum[x] = (uint32_t)c2;
-                mx = std::max(mx, sg.P.pc[x]);
-                sg.prefmax[x] = mx;
-                if (sg.P.pc[x] == 0 && !sg.leap) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
-            }
-            uint32_t mn = 0xFFFFFFFFu;
-            for (size_t x = n; x-- > 0;) {  // (vertices without a coordinate do not count)
-                if (sg.P.pc[x] != 0) mn = std::min(mn, sg.P.pc[x]);
-                sg.sufmin[x] = mn;
-            }
+            sg.P.v = G2.v;
+            sg.P.s = G2.s;
+            sg.P.pc = G2.pc;
+            sg.P.xl = G2.xl;
+            sg.P.xh = G2.xh;
+            sg.P.n = (size_t)G2.len;
+            if (!sg.leap)
+                for (size_t x = 0; x < sg.P.n; ++x)
+                    if (sg.P.pc[x] == 0) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
             if (sg.leap) {
                 sg.usable = sg.usable && G2.xl != nullptr;
-                sg.boundary.assign(n, 0);
-                sg.suf_elow.assign(n, 0xFFFFFFFFu);
-                sg.suf_m0.assign(n, 0xFFFFFFFFu);
-                sg.prefmax0.assign(n, 0);
-                sg.prefmin.assign(n, 0xFFFFFFFFu);
-                uint32_t el = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
-                for (size_t x = n; sg.usable && x-- > 0;) {
-                    if (G2.xh[x] >> 31) {
-                        sg.boundary[x] = 1;
-                        el = std::min(el, G2.xh[x] & 0x7FFFFFFFu);
-                        m0 = std::min(m0, G2.xl[x]);
-                    }
-                    sg.suf_elow[x] = el;
-                    sg.suf_m0[x] = m0;
-                }
-                uint32_t p0 = 0, pm = 0xFFFFFFFFu;
-                for (size_t x = 0; x < n; ++x) {
-                    if (sg.P.pc[x] == 0) p0 = std::max(p0, sg.P.v[x] + 1u);
-                    else pm = std::min(pm, sg.P.pc[x]);
-                    sg.prefmax0[x] = p0;
-                    sg.prefmin[x] = pm;
-                }
                 sg.wd_below_max = o.wd_below_max;
                 sg.wd_forced_min = o.wd_forced_min;
             }
@@ -1722,7 +1759,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     t_walk = now_ms() - tw0;
     lap("walk");
     if (timing || wdebug) {
-        std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms\n", t_st[0], t_st[1], t_st[2], t_st[3]);
+        std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms; fetch memory: chunk %zu of %zu\n", t_st[0], t_st[1], t_st[2], t_st[3],
+                     fetch_chunk + 1, g->fetch_chunks.size());
         std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
                      (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted.load(), (unsigned long long)n_leap_refused[0].load(), (unsigned long long)n_leap_refused[1].load(), (unsigned long long)n_leap_refused[2].load(),
                      (unsigned long long)n_leap_refused[3].load(), (unsigned long long)n_leap_refused[4].load(), (unsigned long long)n_leap_refused[5].load(), (unsigned long long)n_leap_refused[6].load(), (unsigned long long)n_leap_refused[7].load());

@@ -219,6 +219,9 @@ void pag_destroy(pag_graph *g) {
     if (g->wq_host) hipHostFree(g->wq_host);
     if (g->path_store) hipHostFree(g->path_store);
     if (g->pin_host) hipHostFree(g->pin_host);
+    for (void *q : g->fetch_chunks) hipHostFree(q);
+    g->fetch_chunks.clear();
+    g->fetch_chunk_bytes.clear();
     if (g->walk_arena) hipFree(g->walk_arena);
     if (g->wq_next) hipFree(g->wq_next);
     if (g->walk_stream) hipStreamDestroy(g->walk_stream);
