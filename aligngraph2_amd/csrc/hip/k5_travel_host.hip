@@ -1254,7 +1254,21 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     DevBuf b_fetch = buf(), b_fdesc = buf();
     uint32_t scan_from[TRAV_RINGS] = {0, 0, 0};  // per ring: every job number below it has been handled
-    double t_progress = now_ms(), t_first_fin = 0;
+    double t_progress = now_ms(), t_first_fin = 0, t_query = now_ms();
+    // Waiting for the walker: a busy wait (pause instructions), not a sleep — on a loaded host a 20 us sleep comes back after
+    // a millisecond or more, and every finished job that waits for this thread holds up the jobs that depend on it.  Only
+    // after 5 ms without any news does the thread start yielding its time slice.
+    double t_last_news = now_ms();
+    auto idle_wait = [&](double us) {
+        const double t0w = now_ms();
+        if (t0w - t_last_news > 5.0) {
+            std::this_thread::sleep_for(std::chrono::microseconds((long)us));
+            return;
+        }
+        while ((now_ms() - t0w) * 1000.0 < us) {
+            for (int q = 0; q < 32; ++q) __builtin_ia32_pause();
+        }
+    };
     while (n_live) {
         // ---- jobs that have finished since the last look
         std::vector<uint32_t> fin;
@@ -1279,13 +1293,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
             if (t_first_fin == 0) t_first_fin = now_ms();
             if (!urgent) {
-                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                idle_wait(20.0);
                 continue;
             }
             t_first_fin = 0;
         }
         if (fin.empty()) {
-            if (hipStreamQuery(g->walk_stream) == hipSuccess) {  // the grid is gone although jobs are outstanding
+            if (now_ms() - t_query > 2.0 && (t_query = now_ms(), hipStreamQuery(g->walk_stream) == hipSuccess)) {  // the grid is gone although jobs are outstanding
                 walker_up = false;
                 set_error("pag_travel: the walker stopped with jobs outstanding");
                 return fail(PAG_EFAULT);
@@ -1297,10 +1311,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 set_error("pag_travel: no walk job finished within 60 s (posted %u + %u + %u, tickets taken %u, jobs outstanding %u)", n_posted[0], n_posted[1], n_posted[2], ticket, n_live);
                 return fail(PAG_EFAULT);
             }
-            std::this_thread::sleep_for(std::chrono::microseconds(30));
+            idle_wait(30.0);
             continue;
         }
         t_progress = now_ms();
+        t_last_news = t_progress;
         lap("walk");
 
         // ---- their paths: vertices, steps and contig coordinates to the host (one round trip for the batch)
