@@ -94,6 +94,13 @@ def cpu_baseline(k, eps, cov, threads_flag):
     import pagctl
     import synth
     ncores = os.cpu_count() or 1
+    quota = None  # CPUs the container may use (cgroup v2 cpu.max), if limited: the reference's threads share them
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     sp = biggen.BigSpec(seed=99, ref_len=2_000_000, n_reads=2000, read_span=10_000, k=k, ctg_len=500_000, eps=eps, cov=cov,
                         threads=threads_flag, solid_min_abundance=2, chunk_reads=1000)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
@@ -114,7 +121,8 @@ def cpu_baseline(k, eps, cov, threads_flag):
             if r.returncode != 0:
                 raise RuntimeError("reference pagraph failed: " + r.stderr[-500:])
             return {"value": w.n_bases / dt, "unit": "aligned-read-bases/s", "cores": t_use, "kind": "reference",
-                    "sample": sample + f"; compiled reference pagraph -t {t_use} (-O3), wall {dt:.1f} s incl. its file parsing"}
+                    "sample": sample + f"; compiled reference pagraph -t {t_use} (-O3), wall {dt:.1f} s incl. its file parsing"
+                    + (f"; the host's cgroup CPU quota is {quota:g} CPUs" if quota else "")}
         inp = pagctl.LoadedInput(tmp, threads=threads_flag, eps=eps, cov=cov)
         t0 = time.time()
         pagctl.run_oracle(inp)
@@ -369,8 +377,8 @@ def main():
                 "walk_jobs": int(ts.walk_jobs), "walk_rounds_longest_chain": int(ts.walk_rounds),
                 "walk_path_vertices": int(ts.walk_steps), "walk_classifications": int(ts.walk_classifications),
                 "kmer_counter_on_device": kc,
-                "time_share": "walks (latency-bound, k_walk_persistent) dominate the step; the roofline object grades the "
-                              "dominant BANDWIDTH-bound kernel of the build",
+                "time_share": "successor records ~30 %, walks (k_walk_persistent) ~25 %, host outputs ~20 %, build ~15 % of a step; "
+                              "the roofline object grades the dominant BANDWIDTH-bound kernel of the build",
             },
             "roofline": {"bound": "hbm", "kernel": "pagdev::sort_scatter (k-mer sort, one radix pass)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
