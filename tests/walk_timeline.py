@@ -1,3 +1,6 @@
+"""Development aid: busy walker waves per 10 ms and the last jobs to finish, from the stderr of a run with PAG_WALK_DEBUG=1
+(the job lines carry the device clock at which a wave took / finished the job).
+  PAG_WALK_DEBUG=1 PAGRAPH_TIMING=1 python bench.py --steps 2 --warmup 1 2> walk.log; python tests/walk_timeline.py walk.log [waves]"""
 import re,sys
 import numpy as np
 txt=open(sys.argv[1]).read().splitlines()
