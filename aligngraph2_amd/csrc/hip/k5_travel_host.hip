@@ -548,7 +548,17 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // rings of job records, served in order: 0 chain jobs (what a contig's progress waits for), 1 segment jobs of contigs
     // in a later round (they are further along their critical path), 2 segment jobs of first rounds.  slot = ring * QCAP +
     // number mod QCAP
-    const uint32_t QCAP = 32768, NR = TRAV_RINGS;
+    // A ring holds the jobs of a round that are in flight; a slot is reused QCAP postings later.  Sized by what the contigs
+    // of this call can post in one round (segments every few kb of every strand, top-K <= 8 chains each), twice over.
+    uint32_t QCAP = 32768;
+    {
+        const uint64_t seg_min = std::max<uint64_t>(256, std::min<uint64_t>(std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 12000,
+                                                                            std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 6000) / 2);
+        uint64_t est = 0;
+        for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / seg_min + 16;
+        while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
+    }
+    const uint32_t NR = TRAV_RINGS;
     const size_t q_need = 256 + NR * (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
     if (g->wq_bytes < q_need) {
         if (g->wq_host) hipHostFree(g->wq_host);

@@ -286,6 +286,19 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     out << "[Assembly] Start" << std::endl;
     std::size_t nameCnt = 0;
     SeqTools algo(graph, contigs, refs, ctgMapper, refMapper);
+    // Pass 1 (serial, cheap): which chains are written, under which names, from which pieces — and the log lines, in the
+    // reference's order.  Pass 2: every consensus piece of every chain is rendered by a pool of host threads (a chain is
+    // often ONE contig: a pool per chain would render the chains one after the other), then the chains' files are written
+    // side by side.
+    struct ChainOut {
+        std::size_t i = 0;
+        std::string name, base;
+        std::vector<std::size_t> order;  // results[] indices of its pieces, in chain order
+        std::vector<std::pair<std::pair<std::string, bool>, std::size_t>> conInf;
+        std::size_t totalLen = 0, maxLen = 0, cmbLen = 0, firstPiece = 0;
+    };
+    std::vector<ChainOut> chains;
+    std::size_t nPieces = 0;
     for (auto &ctgName : starts) {
         std::size_t ctgIdx = contigs.id(ctgName.first);
         std::size_t i = ctgIdx * 2 + (ctgName.second ? 0 : 1);
@@ -306,46 +319,62 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             out << "Ignore output" << std::endl;
             continue;
         }
-        const std::size_t lineSize = 70;
-        std::string base = outDir + "/" + prefix + std::to_string(i / 2) + "_" + std::to_string(i % 2);
-        {
-            std::ofstream help(base + ".help");
-            help << totalLen << "\n" << maxLen << "\n";
-        }
-        std::ofstream fasta(base + ".fasta");
-        std::ofstream con(base + ".con");
-        fasta << ">" << name << "\n";
-        std::size_t cmbLen = 0;
-        std::vector<std::pair<std::pair<std::string, bool>, std::size_t>> conInf;
-        // the chain's consensus pieces are independent: rendered by a pool of host threads, then written
-        // out in chain order as 70-column lines
-        std::vector<std::size_t> order;
+        ChainOut co;
+        co.i = i;
+        co.name = name;
+        co.base = outDir + "/" + prefix + std::to_string(i / 2) + "_" + std::to_string(i % 2);
+        co.totalLen = totalLen;
+        co.maxLen = maxLen;
+        co.firstPiece = nPieces;
         combatSeq(results, graph, ctgMapper, i / 2, i % 2 == 0, [&](std::size_t ctgId, bool forward, std::size_t) -> bool {
             out << i << "=" << ctgId << std::endl;
-            conInf.push_back({{contigs.name(ctgId), forward}, contigs.length(ctgId)});
-            order.push_back(ctgId * 2 + (forward ? 0 : 1));
+            co.conInf.push_back({{contigs.name(ctgId), forward}, contigs.length(ctgId)});
+            co.order.push_back(ctgId * 2 + (forward ? 0 : 1));
             return true;
         });
-        std::vector<std::string> pieces(order.size());
-        {
-            std::atomic<std::size_t> nextPiece{0};
-            auto render = [&]() {
-                for (std::size_t x; (x = nextPiece.fetch_add(1)) < order.size();)
-                    pieces[x] = algo.seqToString(results[order[x]], deviation, errorRate);
+        nPieces += co.order.size();
+        out << "Out file: " << co.base << ".fasta" << std::endl;
+        for (auto &s : connected) success.emplace(contigs.name(s.first), s.second);
+        chains.push_back(std::move(co));
+    }
+    {
+        std::vector<std::string> pieces(nPieces);
+        std::vector<std::pair<std::size_t, std::size_t>> pieceOf(nPieces);  // (chain, index inside it)
+        for (std::size_t c = 0; c < chains.size(); ++c)
+            for (std::size_t x = 0; x < chains[c].order.size(); ++x) pieceOf[chains[c].firstPiece + x] = {c, x};
+        auto runPool = [&](std::size_t n, const std::function<void(std::size_t)> &fn) {
+            std::atomic<std::size_t> next{0};
+            auto worker = [&]() {
+                for (std::size_t x; (x = next.fetch_add(1)) < n;) fn(x);
             };
             unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
-            nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, order.size())));
+            nThreads = static_cast<unsigned>(std::min<std::size_t>(std::min(nThreads, 64u), std::max<std::size_t>(1, n)));
             std::vector<std::thread> pool;
-            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(render);
-            render();
+            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
+            worker();
             for (auto &t : pool) t.join();
-        }
-        {
+        };
+        runPool(nPieces, [&](std::size_t x) {
+            const ChainOut &co = chains[pieceOf[x].first];
+            pieces[x] = algo.seqToString(results[co.order[pieceOf[x].second]], deviation, errorRate);
+        });
+        runPool(chains.size(), [&](std::size_t c) {
+            ChainOut &co = chains[c];
+            const std::size_t lineSize = 70;
+            {
+                std::ofstream help(co.base + ".help");
+                help << co.totalLen << "\n" << co.maxLen << "\n";
+            }
+            std::ofstream fasta(co.base + ".fasta");
+            std::ofstream con(co.base + ".con");
+            fasta << ">" << co.name << "\n";
+            std::size_t cmbLen = 0;
             std::string line;
             line.reserve(lineSize + 1);
             std::string buf;
             buf.reserve(1 << 20);
-            for (auto &piece : pieces) {
+            for (std::size_t x = 0; x < co.order.size(); ++x) {
+                std::string &piece = pieces[co.firstPiece + x];
                 cmbLen += piece.size();
                 std::size_t at = 0;
                 while (at < piece.size()) {
@@ -369,16 +398,16 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                 buf.push_back('\n');
             }
             fasta.write(buf.data(), static_cast<std::streamsize>(buf.size()));
-        }
-        con << name << "\t" << cmbLen << "\n";
-        for (auto &c : conInf) con << c.first.first << "\t" << (c.first.second ? "FORWARD" : "REV") << "\t" << c.second << "\n";
-        out << "Out file: " << base << ".fasta" << std::endl;
-        for (auto &s : connected) success.emplace(contigs.name(s.first), s.second);
-        if (stats) {
-            stats->nChains++;
-            stats->nFastaBases += cmbLen;
-        }
+            con << co.name << "\t" << cmbLen << "\n";
+            for (auto &ci : co.conInf) con << ci.first.first << "\t" << (ci.first.second ? "FORWARD" : "REV") << "\t" << ci.second << "\n";
+            co.cmbLen = cmbLen;
+        });
     }
+    if (stats)
+        for (auto &co : chains) {
+            stats->nChains++;
+            stats->nFastaBases += co.cmbLen;
+        }
     lap("emit chains");
     if (stats) {
         stats->nContigs = ctgSet.size();

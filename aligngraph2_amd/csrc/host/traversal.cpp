@@ -39,7 +39,23 @@ std::string SeqTools::seqToString(const TravelSequence &seq, std::size_t deviati
     str.append(g_.kmerString(seq[0].first.node));
     const int kmerSize = static_cast<int>(g_.k);
 
+    {   // (the usual size: one base per unit of step, plus the first k-mer)
+        std::size_t total = static_cast<std::size_t>(kmerSize);
+        for (std::size_t i = 1; i < seq.size(); ++i) total += static_cast<std::size_t>(std::max(seq[i].second, 0));
+        str.reserve(total + 16);
+    }
     for (std::size_t i = 1; i < seq.size(); ++i) {
+        const int kmerDist = seq[i].second;
+        const std::uint32_t code = g_.nodeCode[seq[i].first.node];
+        if (kmerDist <= kmerSize) {
+            // the step is covered by the k-mer itself: its last kmerDist bases (nothing of what follows is needed — the
+            // similarity tests and coordinate mappings only choose where the bases of a LONGER step are read from)
+            for (int j = 0; j < kmerDist; ++j) {
+                const int at = kmerSize - kmerDist + j;  // base index inside the k-mer, first base most significant
+                str.push_back("ACGT"[(code >> (2 * (kmerSize - 1 - at))) & 3u]);
+            }
+            continue;
+        }
         DualPos prev = g_.position(seq[i - 1].first), now = g_.position(seq[i].first);
         auto similar = isEdgeSimilar(prev, now, seq[i].second, deviation, errorRate);
         bool useCtg = similar.first;
@@ -50,7 +66,6 @@ std::string SeqTools::seqToString(const TravelSequence &seq, std::size_t deviati
         auto startPos = mapper.singleToDual(useCtg ? prev.first : prev.second);
         auto endPos = mapper.singleToDual(useCtg ? now.first : now.second);
 
-        int kmerDist = seq[i].second;
         std::int64_t posDist = endPos.second - startPos.second;
         std::int64_t selIdx = std::llabs(endPos.first) - 1;
         bool selForward = endPos.first > 0;
