@@ -218,19 +218,24 @@ __device__ __forceinline__ void gs_insert_single(uint64_t *tab, uint32_t mask, u
 // once, in parallel, into per-vertex successor records stored in that order.  A walk then streams
 // through nearly consecutive memory: records, visit stamps and offsets of consecutive path vertices are
 // neighbours.
+// sort records: key = contig coordinate, payload = reference coordinate << 32 | vertex id (the position travels with the
+// record, so that applying the order does not have to gather it back)
 __global__ void k_order_keys(const uint64_t *__restrict__ vpos, uint64_t n, uint32_t *__restrict__ key, uint64_t *__restrict__ val) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        key[i] = (uint32_t)(vpos[i] >> 32);
-        val[i] = i;
+        const uint64_t p = vpos[i];
+        key[i] = (uint32_t)(p >> 32);
+        val[i] = (p << 32) | i;
     }
 }
 
-__global__ void k_order_apply(const uint64_t *__restrict__ sorted_old, uint64_t n, TravGraph G) {
+__global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uint64_t *__restrict__ sorted_val, uint64_t n, uint64_t n_zero, TravGraph G) {
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t v = (uint32_t)sorted_old[u];
+        const uint64_t x = sorted_val[u];
+        const uint32_t v = (uint32_t)x;
         G.uold[u] = v;
         G.newid[v] = (uint32_t)u;
-        G.upos[u] = G.vpos[v];
+        // (the first n_zero keys were overwritten by the second sort: their contig coordinate is 0)
+        G.upos[u] = ((uint64_t)(u < n_zero ? 0u : sorted_ctg[u]) << 32) | (x >> 32);
         G.ucnt[u] = G.vcnt[v];
     }
 }
@@ -2532,10 +2537,10 @@ __global__ void k_zero_prefix(const uint32_t *__restrict__ key, uint64_t n, unsi
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         if (key[i] == 0u && (i + 1 == n || key[i + 1] != 0u)) *n0 = i + 1;
 }
-// sort keys of the vertices without a contig coordinate: their reference coordinate
-__global__ void k_order_refkeys(const uint64_t *__restrict__ vpos, const uint64_t *__restrict__ old, uint64_t n, uint32_t *__restrict__ key) {
+// sort keys of the vertices without a contig coordinate: their reference coordinate (the payload's upper half)
+__global__ void k_order_refkeys(const uint64_t *__restrict__ val, uint64_t n, uint32_t *__restrict__ key) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        key[i] = (uint32_t)vpos[(uint32_t)old[i]];
+        key[i] = (uint32_t)(val[i] >> 32);
 }
 
 // New ids: [vertices without a contig coordinate, by reference coordinate] ++ [the others, by contig coordinate]; equal
@@ -2558,13 +2563,13 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     PAG_HIP_TRY(hipMemcpyAsync(&n0, d_n0, 8, hipMemcpyDeviceToHost, s));
     PAG_HIP_TRY(hipStreamSynchronize(s));
     if (n0 > 1) {
-        k_order_refkeys<<<dim3(grid_for(n0)), dim3(256), 0, s>>>(G.vpos, vs, n0, ks);
+        k_order_refkeys<<<dim3(grid_for(n0)), dim3(256), 0, s>>>(vs, n0, ks);
         int in0b = 1;
         if ((rc = sort_pairs(ks, vs, ko, vo, n0, 32, sort_tmp, &in0b, s, nullptr, nullptr))) return rc;
         if (!in0b) PAG_HIP_TRY(hipMemcpyAsync(vs, vo, n0 * 8, hipMemcpyDeviceToDevice, s));
     }
     if (n_zero) *n_zero = n0;
-    k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(vs, n, G);
+    k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, vs, n, n0 > 1 ? n0 : 0, G);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
