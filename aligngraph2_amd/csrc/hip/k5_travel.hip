@@ -287,16 +287,28 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                 }
                 j0 = lim;
             }
-            for (uint32_t j = j0; j < q; ++j) {
-                const uint32_t p = p0 + j;
-                const uint64_t pp = G.vpos[p];
-                const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
-                uint32_t esim;
-                int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
-                if (grade == G_OOPS) continue;
-                if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
-                if (MODE != 0) emit(p, pc, step, grade, esim);
-                ++n;
+            // four candidates per turn, their positions requested together: one at a time, every candidate cost a full memory
+            // round trip (load -> f64 tests -> next load) and the kernel ran at a third of the miss rate the memory system
+            // sustains (k_succ<0>: 45 -> 36 ms).  Batching the EDGES the same way (targets, offsets and first positions of four
+            // edges in flight) was slower (48 ms: a node has 2.65 edges on average, the rest of the batch is wasted loads and
+            // registers), and so were four lanes per vertex (51 ms).
+            for (uint32_t jb = j0; jb < q; jb += 4u) {
+                uint64_t pq[4];
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) pq[t] = G.vpos[p0 + (jb + t < q ? jb + t : q - 1u)];
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) {
+                    const uint32_t j = jb + t;
+                    if (j >= q) break;
+                    const uint32_t p = p0 + j;
+                    const uint32_t pc = (uint32_t)(pq[t] >> 32), pr = (uint32_t)pq[t];
+                    uint32_t esim;
+                    int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
+                    if (grade == G_OOPS) continue;
+                    if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
+                    if (MODE != 0) emit(p, pc, step, grade, esim);
+                    ++n;
+                }
             }
             base += q;
         }
