@@ -268,10 +268,26 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
             r.toff = 0;  // the target's own record range is linked in afterwards
             out[n] = r;
         };
-        for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
-            const uint32_t to = G.eto[e], step = G.estep[e];
-            if (to == PAG_NONE) continue;
-            const uint32_t p0 = G.npos_off[to], q = G.npos_off[to + 1] - p0;
+        const uint32_t e_lo = G.nedge_off[node], e_hi = G.nedge_off[node + 1];
+        for (uint32_t eb = e_lo; eb < e_hi; eb += 4u) {
+          // (targets and position ranges of up to four edges requested together: two round trips for the four; k_succ<0>
+          // 36 -> 34 ms, k_succ<1> 49 -> 46 ms)
+          uint32_t to4[4], st4[4], p04[4], q4[4];
+#pragma unroll
+          for (uint32_t t = 0; t < 4u; ++t) {
+              const bool have = eb + t < e_hi;
+              to4[t] = have ? G.eto[eb + t] : PAG_NONE;
+              st4[t] = have ? G.estep[eb + t] : 0u;
+          }
+#pragma unroll
+          for (uint32_t t = 0; t < 4u; ++t) {
+              p04[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t]] : 0u;
+              q4[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t] + 1] - p04[t] : 0u;
+          }
+#pragma unroll
+          for (uint32_t t4 = 0; t4 < 4u; ++t4) {
+            const uint32_t step = st4[t4], p0 = p04[t4], q = q4[t4];
+            if (q == 0u) continue;
             uint32_t j0 = 0;
             if (MODE == 1 && amask) {  // the candidates the mask covers: accepted ones only
                 const uint32_t lim = base < 64u ? (q < 64u - base ? q : 64u - base) : 0u;
@@ -289,9 +305,10 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
             }
             // four candidates per turn, their positions requested together: one at a time, every candidate cost a full memory
             // round trip (load -> f64 tests -> next load) and the kernel ran at a third of the miss rate the memory system
-            // sustains (k_succ<0>: 45 -> 36 ms).  Batching the EDGES the same way (targets, offsets and first positions of four
-            // edges in flight) was slower (48 ms: a node has 2.65 edges on average, the rest of the batch is wasted loads and
-            // registers), and so were four lanes per vertex (51 ms).
+            // sustains (k_succ<0>: 45 -> 36 ms).  Also having the first positions of four edges in flight was slower (48 ms:
+            // a node has 2.65 edges on average, the rest is wasted loads and registers), eight candidates per turn no better
+            // (35.6 ms), four lanes per vertex slower (51 ms), and keeping the first four accepted candidates of every vertex
+            // in a side array for the filling pass cost the counting pass more (+14 ms) than it saved the other (-5 ms).
             for (uint32_t jb = j0; jb < q; jb += 4u) {
                 uint64_t pq[4];
 #pragma unroll
@@ -311,6 +328,7 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                 }
             }
             base += q;
+          }
         }
         if (MODE != 1) cnt[u] = n;
         if (MODE == 0 && amask) amask[v] = mask;
