@@ -879,6 +879,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         R.active = true;
         R.segs.clear();
         R.chains.assign(cs.seeds.size(), Chain{});
+        for (auto &ch : R.chains)  // (their path arrays come out of the handle's pool: capacity — and touched pages — of earlier rounds)
+            for (auto *vec : {&ch.T.v, &ch.T.s, &ch.T.pc})
+                if (!g->u32_pool.empty()) {
+                    vec->swap(g->u32_pool.back());
+                    g->u32_pool.pop_back();
+                    vec->clear();
+                }
         R.zone_end = 0;
         R.live_jobs = 0;
         R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
@@ -1595,6 +1602,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             for (size_t x = 0; x < P.len; ++x) longest[i][x] = LNode{ch.T.v[x], (int32_t)ch.T.s[x], ch.T.pc[x]};
         }
         for (uint32_t i : batch) {  // the host copies of the round are spent
+            for (auto &ch : RS[i].chains)
+                for (auto *vec : {&ch.T.v, &ch.T.s, &ch.T.pc})
+                    if (vec->capacity() && g->u32_pool.size() < 4096) {
+                        g->u32_pool.emplace_back();
+                        g->u32_pool.back().swap(*vec);
+                    }
             RS[i].chains.clear();
             RS[i].segs.clear();
         }
