@@ -552,10 +552,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // of this call can post in one round (segments every few kb of every strand, top-K <= 8 chains each), twice over.
     uint32_t QCAP = 32768;
     {
-        const uint64_t seg_min = std::max<uint64_t>(256, std::min<uint64_t>(std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 12000,
-                                                                            std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 6000) / 2);
+        const uint64_t sl = std::max<uint64_t>(128, std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 12000);
+        const uint64_t ll = std::max<uint64_t>(128, std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : sl / 2);
         uint64_t est = 0;
-        for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / seg_min + 16;
+        for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / sl + (uint64_t)st[i].len / ll + 32;  // (every strand as if all of it were both zones)
         while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
     }
     const uint32_t NR = TRAV_RINGS;
@@ -1227,7 +1227,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             const size_t chain = cap * 8 + cap * 8 * TRAV_PROBE_GROUPS + oc * 8 * (1 + TRAV_PROBE_GROUPS) + span * 4 * (1 + TRAV_PROBE_GROUPS);
             const size_t n_seg = cs.len / 12000 + 1, scap = 8192 + 8192, soc = pow2_at_least(scap / 4 + 4096), sspan = span / (n_seg ? n_seg : 1) * 2 + 4096;
             const size_t seg = scap * 8 + scap * 8 * TRAV_PROBE_GROUPS + soc * 8 * (1 + TRAV_PROBE_GROUPS) + sspan * 4 * (1 + TRAV_PROBE_GROUPS);
-            want += chain * 3 + seg * n_seg * 3 / 2;
+            // segments of the leaping zone (the last tenth of the strand + margin, half as long, far larger hash sets, a log)
+            const size_t n_lseg = cs.len / 8 / 6000 + 2, lcap = 3000 + 8192, loc = pow2_at_least(lcap + 8192), lspan = sspan;
+            const size_t lseg = lcap * 8 + lcap * 8 * TRAV_PROBE_GROUPS + lcap * 8 + loc * 8 * (1 + TRAV_PROBE_GROUPS) + lspan * 4 * (1 + TRAV_PROBE_GROUPS);
+            want += chain * 3 + (seg * n_seg + lseg * n_lseg) * 3 / 2;
         }
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
@@ -1797,8 +1800,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     t_walk = now_ms() - tw0;
     lap("walk");
     if (timing || wdebug) {
-        std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms; fetch memory: chunk %zu of %zu\n", t_st[0], t_st[1], t_st[2], t_st[3],
-                     fetch_chunk + 1, g->fetch_chunks.size());
+        std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms; fetch memory: chunk %zu of %zu; walk arena: %.2f of %.2f GB used\n", t_st[0], t_st[1], t_st[2], t_st[3],
+                     fetch_chunk + 1, g->fetch_chunks.size(), g->walk_arena_used / 1e9, g->walk_arena_cap / 1e9);
         std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
                      (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted.load(), (unsigned long long)n_leap_refused[0].load(), (unsigned long long)n_leap_refused[1].load(), (unsigned long long)n_leap_refused[2].load(),
                      (unsigned long long)n_leap_refused[3].load(), (unsigned long long)n_leap_refused[4].load(), (unsigned long long)n_leap_refused[5].load(), (unsigned long long)n_leap_refused[6].load(), (unsigned long long)n_leap_refused[7].load());
