@@ -727,6 +727,34 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint32_t win_low = 0;             // TRAV_MODE_LEAP: forced lower end of the travel coordinate window
     };
     bool need_publish = false;
+    // a prepared job enters its ring (in posting order; the walker takes the rings' jobs in that order)
+    struct Deferred {
+        TravPosted P;
+        JobRef jr;
+    };
+    std::vector<std::vector<Deferred>> deferred(n_sel);
+    bool defer_ring2 = false;
+    auto commit_job = [&](uint32_t ring, const TravPosted &P, const JobRef &jr2, uint32_t mode, uint32_t stop_pc) -> int {
+        const uint32_t jn = n_posted[ring], slot = ring * QCAP + jn % QCAP;
+        if (jref[slot].live) {
+            set_error("pag_travel: the job ring is full (%u jobs in flight)", QCAP);
+            return PAG_ENOMEM;
+        }
+        hjobs[slot] = P;
+        hdone[slot] = 0;
+        jref[slot] = jr2;
+        if (jr2.kind == 0) {
+            Chain &ch = RS[jr2.ctg].chains[(size_t)jr2.idx];
+            ch.job = (int)slot;
+            ch.job_mode = mode;
+            ch.job_stop = stop_pc;
+        }
+        n_posted[ring] += 1;
+        n_live += 1;
+        RS[jr2.ctg].live_jobs += 1;
+        jobs_total += 1;
+        return PAG_OK;
+    };
     // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
     // the walker only by publish())
     auto post_batch = [&](uint32_t i, int grp, const std::vector<JobPlan> &plans) -> int {
@@ -785,13 +813,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (size_t j = 0; j < nj; ++j) {
             const JobPlan &pl = plans[j];
             const uint32_t ring = pl.kind == 0 ? 0u : (R.round > 1 ? 1u : 2u);
-            const uint32_t jn = n_posted[ring], slot = ring * QCAP + jn % QCAP;
-            if (jref[slot].live) {
-                set_error("pag_travel: the job ring is full (%u jobs in flight)", QCAP);
-                return PAG_ENOMEM;
-            }
             const uint64_t cap = pl.cap, oc = o_oc[j + 1] - o_oc[j];
-            TravPosted &P = hjobs[slot];
+            TravPosted P{};
             TravJob &J = P.J;
             J.ctg = i;
             J.start = pl.start_vid;
@@ -831,26 +854,24 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 P.C.in_lo = pl.win_lo;
                 P.C.in_hi = pl.win_hi;
             }
-            hdone[slot] = 0;
-            jref[slot].ctg = i;
-            jref[slot].kind = pl.kind;
-            jref[slot].idx = pl.idx;
-            jref[slot].init_len = J.init_len;
-            jref[slot].live = true;
+            JobRef jr2;
+            jr2.ctg = i;
+            jr2.kind = pl.kind;
+            jr2.idx = pl.idx;
+            jr2.init_len = J.init_len;
+            jr2.live = true;
             if (pl.kind == 0) {
-                Chain &ch = R.chains[(size_t)pl.idx];
-                ch.job = (int)slot;
-                ch.job_mode = pl.mode;
-                ch.job_stop = pl.stop_pc;
                 if (pl.mode & TRAV_MODE_RESUME) ++n_resume_jobs;
             } else {
                 ++n_seg_jobs;
                 if (pl.mode & TRAV_MODE_LEAP) ++n_leap_jobs;
             }
-            n_posted[ring] += 1;
-            n_live += 1;
-            R.live_jobs += 1;
-            jobs_total += 1;
+            if (defer_ring2 && ring == 2u) {  // (first rounds before the walker starts: the ring order is decided later)
+                deferred[i].push_back(Deferred{P, jr2});
+                continue;
+            }
+            int r2;
+            if ((r2 = commit_job(ring, P, jr2, pl.mode, pl.stop_pc))) return r2;
         }
         need_publish = true;
         return PAG_OK;
@@ -920,8 +941,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
                 const uint64_t drift = cs.len / 400 + 200;
                 const uint64_t first = (uint64_t)x0 + (split > H ? split - H + drift : lseg);
-                for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 < (uint64_t)cs.ctgRight - 1; x += lseg)
-                    if (ck_x.empty() || x > (uint64_t)ck_x.back() + lseg / 4) ck_x.push_back((uint32_t)x);
+                // (the last stretch of the strand in shorter pieces still: the job that reaches the end of the strand is the
+                // last one of its round, and a contig that needs a second round waits for it twice)
+                static const uint64_t end_div = std::getenv("PAG_LEAP_END_DIV") ? std::max<uint64_t>(1, std::strtoull(std::getenv("PAG_LEAP_END_DIV"), nullptr, 10)) : 2;
+                const uint64_t end_zone = (uint64_t)cs.ctgRight > 2 * lseg ? (uint64_t)cs.ctgRight - 2 * lseg : 0;
+                for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 / end_div < (uint64_t)cs.ctgRight - 1; x += (x >= end_zone ? std::max<uint64_t>(lseg / end_div, seg_ov) : lseg))
+                    if (ck_x.empty() || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
             }
         }
         if (!ck_x.empty()) {
@@ -1251,8 +1276,28 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         std::vector<uint32_t> order(n_sel);
         for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a2, uint32_t b2) { return st[a2].len > st[b2].len; });
+        // First rounds: the contigs' segment jobs enter the ring interleaved, a few per contig and turn (a contig's leap
+        // segments first).  Posted contig by contig, the last contigs of the list finish their first round when the grid
+        // runs empty — and those of them that need a second round (a re-seed after a walk that ended early) start it then:
+        // every contig's first round now ends at about the same time, earlier than the last ones did.
+        static const uint32_t interleave = std::getenv("PAG_POST_INTERLEAVE") ? (uint32_t)std::atoi(std::getenv("PAG_POST_INTERLEAVE")) : 8u;
+        defer_ring2 = interleave != 0;
         for (uint32_t i : order)
             if (!st[i].done && (rc = start_round(i))) return fail(rc);
+        defer_ring2 = false;
+        if (interleave) {
+            std::vector<size_t> at(n_sel, 0);
+            for (bool more = true; more;) {
+                more = false;
+                for (uint32_t i : order) {
+                    auto &dq = deferred[i];
+                    for (uint32_t c = 0; c < interleave && at[i] < dq.size(); ++c, ++at[i])
+                        if ((rc = commit_job(2u, dq[at[i]].P, dq[at[i]].jr, dq[at[i]].P.J.mode, dq[at[i]].P.J.stop_pc))) return fail(rc);
+                    more = more || at[i] < dq.size();
+                }
+            }
+            for (auto &dq : deferred) std::vector<Deferred>().swap(dq);
+        }
     }
     if (n_live) {
         int n_cu = 256;
