@@ -618,14 +618,17 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint32_t wd_below_max = 0, wd_forced_min = 0xFFFFFFFFu, win_low = 0;
     };
     struct Chain {  // one graphTravel: (contig, seed) of the running round
-        Piece T;    // the validated path so far
-        // T grows piece by piece (a job's new vertices, an adopted stretch); per piece: where it starts and, over everything
-        // BEFORE it, the highest coordinate and the highest id (+ 1) of a vertex without a coordinate
-        struct Mark {
-            size_t start;
+        // The validated path so far, T, is a list of parts that stay where the fetches put them (pinned memory kept for the
+        // whole call): a job's new vertices, an adopted stretch of a segment's path.  Nothing is copied when T grows; the
+        // flat arrays a resumed walk or the splice needs are put together when they are needed.  Per part: where it starts in
+        // T and, over everything BEFORE it, the highest coordinate and the highest id (+ 1) of a vertex without a coordinate.
+        struct Part {
+            const uint32_t *v, *s, *pc;
+            size_t n, start;
             uint32_t mx, m0;
         };
-        std::vector<Mark> marks;
+        std::vector<Part> parts;
+        size_t len = 0;  // vertices of T
         uint32_t mx_all = 0, m0_all = 0;  // ... over all of T
         uint32_t low_nz = 0xFFFFFFFFu;   // lowest non-zero coordinate of T
         uint64_t size = 0;  // sum of its steps
@@ -662,48 +665,87 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
     const bool use_leap_pieces = !(std::getenv("PAG_LEAP_PIECES") && std::atoi(std::getenv("PAG_LEAP_PIECES")) == 0);
     // T grows by a job's new vertices or by an adopted stretch of a segment
-    auto extend_chain = [&](Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n) {
-        if (n == 0) return;
-        ch.marks.push_back(Chain::Mark{ch.T.v.size(), ch.mx_all, ch.m0_all});
-        ch.T.v.insert(ch.T.v.end(), v, v + n);
-        ch.T.s.insert(ch.T.s.end(), sv, sv + n);
-        ch.T.pc.insert(ch.T.pc.end(), pc, pc + n);
-        uint32_t mx = ch.mx_all, m0 = ch.m0_all, lo = ch.low_nz;
+    struct PartAgg {  // over the vertices of a part: highest coordinate, highest id + 1 of a coordinate-free vertex, lowest
+                      // non-zero coordinate, sum of the steps
+        uint32_t mx = 0, m0 = 0, lo = 0xFFFFFFFFu;
         uint64_t sz = 0;
-        for (size_t x = 0; x < n; ++x) {
-            const uint32_t c = pc[x];
+        void add(uint32_t v, uint32_t st, uint32_t c) {
             mx = std::max(mx, c);
-            if (c == 0) m0 = std::max(m0, v[x] + 1u);  // (id + 1: 0 stands for "none")
+            if (c == 0) m0 = std::max(m0, v + 1u);  // (id + 1: 0 stands for "none")
             else lo = std::min(lo, c);
-            sz += sv[x];
+            sz += st;
         }
-        ch.mx_all = mx;
-        ch.m0_all = m0;
-        ch.low_nz = lo;
-        ch.size += sz;
+    };
+    auto extend_chain = [&](Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n, const PartAgg *known = nullptr) {
+        if (n == 0) return;
+        ch.parts.push_back(Chain::Part{v, sv, pc, n, ch.len, ch.mx_all, ch.m0_all});
+        ch.len += n;
+        PartAgg a;
+        if (known) a = *known;  // (the caller has been over the part already)
+        else
+            for (size_t x = 0; x < n; ++x) a.add(v[x], sv[x], pc[x]);
+        ch.mx_all = std::max(ch.mx_all, a.mx);
+        ch.m0_all = std::max(ch.m0_all, a.m0);
+        ch.low_nz = std::min(ch.low_nz, a.lo);
+        ch.size += a.sz;
+    };
+    // the part of T that holds index idx (idx < ch.len)
+    auto part_of = [&](const Chain &ch, size_t idx) -> size_t {
+        size_t lo = 0, hi = ch.parts.size() - 1;
+        while (lo < hi) {
+            const size_t mid = (lo + hi + 1) / 2;
+            if (ch.parts[mid].start <= idx) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
     };
     // highest coordinate / highest id + 1 of a coordinate-free vertex over T[0 .. idx)
     auto chain_before = [&](const Chain &ch, size_t idx, uint32_t *mx_out, uint32_t *m0_out) {
         uint32_t mx = 0, m0 = 0;
-        size_t from = 0;
-        if (!ch.marks.empty()) {
-            size_t lo = 0, hi = ch.marks.size() - 1;  // last piece that starts at or before idx
-            while (lo < hi) {
-                const size_t mid = (lo + hi + 1) / 2;
-                if (ch.marks[mid].start <= idx) lo = mid;
-                else hi = mid - 1;
+        if (idx > 0 && !ch.parts.empty()) {
+            const size_t pi = part_of(ch, idx - 1);
+            const Chain::Part &pt = ch.parts[pi];
+            mx = pt.mx;
+            m0 = pt.m0;
+            for (size_t x = 0; x < idx - pt.start; ++x) {
+                mx = std::max(mx, pt.pc[x]);
+                if (pt.pc[x] == 0) m0 = std::max(m0, pt.v[x] + 1u);
             }
-            mx = ch.marks[lo].mx;
-            m0 = ch.marks[lo].m0;
-            from = ch.marks[lo].start;
-        }
-        for (size_t x = from; x < idx; ++x) {
-            mx = std::max(mx, ch.T.pc[x]);
-            if (ch.T.pc[x] == 0) m0 = std::max(m0, ch.T.v[x] + 1u);
         }
         *mx_out = mx;
         *m0_out = m0;
     };
+    // T as flat arrays (vertices / steps / coordinates; a null destination is skipped)
+    auto flatten_chain = [&](const Chain &ch, uint32_t *dv, uint32_t *ds, uint32_t *dpc) {
+        for (const Chain::Part &pt : ch.parts) {
+            if (dv) std::memcpy(dv + pt.start, pt.v, pt.n * 4);
+            if (ds) std::memcpy(ds + pt.start, pt.s, pt.n * 4);
+            if (dpc) std::memcpy(dpc + pt.start, pt.pc, pt.n * 4);
+        }
+    };
+    // how many vertices T and a segment's path P have in common going backwards from T's last vertex = P[be] (beyond that
+    // pair itself: same vertices, same steps from the second common vertex on)
+    auto common_back = [&](const Chain &ch, const View &P, size_t be) -> size_t {
+        size_t t = 0;
+        if (ch.len == 0) return 0;
+        size_t pi = ch.parts.size() - 1, off = ch.parts[pi].n;  // T[e - t] = parts[pi][off - 1] while walking back
+        // invariant: (pi, off - 1) addresses T[e - t]
+        while (t < ch.len - 1 && t < be) {
+            // step of T[e - t] and vertex of T[e - t - 1]
+            const uint32_t st_cur = ch.parts[pi].s[off - 1];
+            size_t pj = pi, oj = off - 1;  // (pj, oj - 1) will address T[e - t - 1]
+            if (oj == 0) {
+                pj = pi - 1;
+                oj = ch.parts[pj].n;
+            }
+            if (ch.parts[pj].v[oj - 1] != P.v[be - t - 1] || st_cur != P.s[be - t]) break;
+            ++t;
+            pi = pj;
+            off = oj;
+        }
+        return t;
+    };
+
     bool walker_up = false;
     auto shutdown_walker = [&]() {
         if (!walker_up) return;
@@ -721,7 +763,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint64_t cap;       // sequence capacity (vertices)
         uint32_t start_vid; // old id of the start vertex
         uint32_t mode, stop_pc;
-        const Piece *init;  // RESUME: the path so far
+        const Chain *init;  // RESUME: the chain whose path so far the job continues
         bool exact;
         uint32_t win_lo = 0, win_hi = 0;  // id range of the job's direct-mapped marks (0, 0: the whole strand)
         uint32_t win_low = 0;             // TRAV_MODE_LEAP: forced lower end of the travel coordinate window
@@ -840,14 +882,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             J.pad_ = 0;
             J.seq_x = (pl.mode & TRAV_MODE_LEAP) ? b_sx.as<uint64_t>() + o_x[j] : nullptr;
             if (pl.mode & TRAV_MODE_RESUME) {
-                const uint64_t n0 = pl.init->v.size();
+                const uint64_t n0 = pl.init->len;
                 if (n0 == 0 || n0 > cap) {
                     set_error("pag_travel: resume job with a %llu-vertex path in a %llu-vertex buffer", (unsigned long long)n0, (unsigned long long)cap);
                     return PAG_EFAULT;
                 }
                 J.init_len = n0;
-                PAG_HIP_TRY(hipMemcpyAsync(J.seq_v, pl.init->v.data(), n0 * 4, hipMemcpyHostToDevice, s));
-                PAG_HIP_TRY(hipMemcpyAsync(J.seq_s, pl.init->s.data(), n0 * 4, hipMemcpyHostToDevice, s));
+                // (put together in pinned memory: the copies below are asynchronous for real)
+                uint32_t *flat = (uint32_t *)fetch_alloc(n0 * 8);
+                if (!flat) return PAG_ENOMEM;
+                flatten_chain(*pl.init, flat, flat + n0, nullptr);
+                PAG_HIP_TRY(hipMemcpyAsync(J.seq_v, flat, n0 * 4, hipMemcpyHostToDevice, s));
+                PAG_HIP_TRY(hipMemcpyAsync(J.seq_s, flat + n0, n0 * 4, hipMemcpyHostToDevice, s));
             }
             P.C = tc[i];
             if (pl.win_hi) {  // a segment job: direct-mapped marks only around the segment
@@ -900,13 +946,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         R.active = true;
         R.segs.clear();
         R.chains.assign(cs.seeds.size(), Chain{});
-        for (auto &ch : R.chains)  // (their path arrays come out of the handle's pool: capacity — and touched pages — of earlier rounds)
-            for (auto *vec : {&ch.T.v, &ch.T.s, &ch.T.pc})
-                if (!g->u32_pool.empty()) {
-                    vec->swap(g->u32_pool.back());
-                    g->u32_pool.pop_back();
-                    vec->clear();
-                }
         R.zone_end = 0;
         R.live_jobs = 0;
         R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
@@ -1034,8 +1073,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     auto post_resume = [&](uint32_t i, int c, uint32_t stop) -> int {
         CtgState &cs = st[i];
         Chain &ch = RS[i].chains[(size_t)c];
-        const uint64_t cap = std::max<uint64_t>(cs.seqCap * ch.grow, ch.T.v.size() + cs.seqCap / 4 + 4096);
-        std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)TRAV_MODE_RESUME, stop, &ch.T, ch.exact}};
+        const uint64_t cap = std::max<uint64_t>(cs.seqCap * ch.grow, ch.len + cs.seqCap / 4 + 4096);
+        std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)TRAV_MODE_RESUME, stop, &ch, ch.exact}};
         return post_batch(i, GRP_CHAIN0 + c, plans);
     };
 
@@ -1060,19 +1099,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     auto try_merge = [&](uint32_t i, Chain &ch, Seg &sg) -> int {
         CtgState &cs = st[i];
         RoundState &R = RS[i];
-        Piece &T = ch.T;
         const View &P = sg.P;
-        if (!sg.usable || T.v.empty() || P.n == 0) return 0;
-        const size_t e = T.v.size() - 1;
+        if (!sg.usable || ch.len == 0 || P.n == 0) return 0;
+        const size_t e = ch.len - 1;
+        const uint32_t last_v = ch.parts.back().v[ch.parts.back().n - 1];
         size_t be = P.n;  // the last vertex of T in P
         for (size_t x = 0; x < P.n; ++x)
-            if (P.v[x] == T.v[e]) {
+            if (P.v[x] == last_v) {
                 be = x;
                 break;
             }
         if (be == P.n) return 0;
-        size_t t = 0;
-        while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
+        const size_t t = common_back(ch, P, be);
         const size_t a = e - t, b = be - t;
         if (t < 4) return 0;
         uint32_t dT = 0, d0 = 0, dP = 0;
@@ -1080,22 +1118,29 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (size_t x = 0; x < b; ++x) dP = std::max(dP, P.pc[x]);
         const uint64_t dmax = std::max(dT, dP);
         const size_t q = be + 1 > sg.max_chosen ? be + 1 - sg.max_chosen : 0;
-        uint64_t low = 0xFFFFFFFFull;
-        for (size_t x = q; x < P.n; ++x) low = std::min<uint64_t>(low, P.pc[x]);
-        if (low <= dmax + sg.max_back + deviation) return 0;
         const uint64_t split = (uint64_t)(cs.len * startSplit);
         const uint64_t base = R.has_size + k + ch.size + sg.max_probe + 1;
         if (base >= split) return 0;  // (no room: the caller resumes exactly)
         const uint64_t room = split - base;  // steps that may still be adopted
-        // largest index whose cumulated steps behind P[be] stay below `room`
+        // ONE pass over P[q ..]: the lowest coordinate (condition 2), how far the steps behind P[be] stay below `room`
+        // (condition 3: `last`), and what the chain has to know about the adopted stretch
+        uint64_t low = 0xFFFFFFFFull;
+        for (size_t x = q; x <= be; ++x) low = std::min<uint64_t>(low, P.pc[x]);
         size_t last = be;
-        uint64_t cum = 0;
-        while (last + 1 < P.n && cum + P.s[last + 1] < room) {
-            cum += P.s[last + 1];
-            ++last;
+        PartAgg agg;
+        bool open = true;
+        for (size_t x = be + 1; x < P.n; ++x) {
+            low = std::min<uint64_t>(low, P.pc[x]);
+            if (open && agg.sz + P.s[x] < room) {
+                agg.add(P.v[x], P.s[x], P.pc[x]);
+                last = x;
+            } else {
+                open = false;
+            }
         }
+        if (low <= dmax + sg.max_back + deviation) return 0;
         if (last == be && last + 1 < P.n) return 0;
-        extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be);
+        extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg);
         n_adopted += last - be;
         return last + 1 == P.n ? 1 : 2;
     };
@@ -1125,25 +1170,24 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     auto try_merge_leap = [&](uint32_t i, Chain &ch, Seg &sg) -> int {
         CtgState &cs = st[i];
         RoundState &R = RS[i];
-        Piece &T = ch.T;
         const View &P = sg.P;
         auto refuse = [&](int why) {
             n_leap_refused[why & 7] += 1;
             if (wdebug) std::fprintf(stderr, "[walk] contig %u: leap segment at %u refused (reason %d)\n", i, sg.x, why);
             return 0;
         };
-        if (!sg.usable || T.v.empty() || P.n == 0 || !P.xl) return refuse(0);
-        const size_t e = T.v.size() - 1;
+        if (!sg.usable || ch.len == 0 || P.n == 0 || !P.xl) return refuse(0);
+        const size_t e = ch.len - 1;
+        const uint32_t last_v = ch.parts.back().v[ch.parts.back().n - 1];
         size_t be = P.n;
         for (size_t x = 0; x < P.n; ++x)
-            if (P.v[x] == T.v[e]) {
+            if (P.v[x] == last_v) {
                 be = x;
                 break;
             }
         if (be == P.n) return refuse(1);
         if (!(P.xh[be] >> 31)) return refuse(2);
-        size_t t = 0;
-        while (t < e && t < be && T.v[e - t - 1] == P.v[be - t - 1] && T.s[e - t] == P.s[be - t]) ++t;
+        const size_t t = common_back(ch, P, be);
         const size_t a = e - t, b = be - t;
         if (t < 4) return refuse(1);
         const uint64_t split = (uint64_t)(cs.len * startSplit);
@@ -1164,13 +1208,17 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if (sg.wd_below_max != 0u && sg.wd_below_max >= lowM) return refuse(5);
         if (sg.wd_forced_min < lowM) return refuse(5);
         if (p_min < lowM) return refuse(5);
-        // the iterations that start at a boundary >= be: lowest contig-following coordinate / coordinate-free id examined
+        // ONE pass over P[be ..]: the iterations that start at a boundary >= be (lowest contig-following coordinate /
+        // coordinate-free id examined), and what the chain has to know about the adopted stretch
         uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
-        for (size_t x = be; x < P.n; ++x)
+        PartAgg agg;
+        for (size_t x = be; x < P.n; ++x) {
             if (P.xh[x] >> 31) {
                 elow = std::min(elow, P.xh[x] & 0x7FFFFFFFu);
                 m0 = std::min(m0, P.xl[x]);
             }
+            if (x > be) agg.add(P.v[x], P.s[x], P.pc[x]);
+        }
         uint32_t t_dmax = 0, t_d0 = 0;
         chain_before(ch, a, &t_dmax, &t_d0);
         const uint32_t dmax = std::max(t_dmax, p_dmax);
@@ -1178,7 +1226,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         const uint32_t d0 = std::max(t_d0, p_d0);  // (id + 1, 0: none)
         if (d0 != 0u && m0 != 0xFFFFFFFFu && m0 + 1u <= d0) return refuse(7);
         const size_t last = P.n - 1;
-        extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be);
+        extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg);
         n_adopted += last - be;
         n_leap_adopted += 1;
         return 1;
@@ -1475,8 +1523,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
             if (misspec || overflow) {  // the same job again (its path so far, if any, is still on the host)
                 std::vector<JobPlan> plans;
-                const uint64_t cap = std::max<uint64_t>(st[i].seqCap * ch.grow, ch.T.v.size() + st[i].seqCap / 4 + 4096);
-                plans.push_back(JobPlan{0, jr.idx, cap, st[i].seeds[(size_t)jr.idx].vid, ch.job_mode, ch.job_stop, (ch.job_mode & TRAV_MODE_RESUME) ? &ch.T : nullptr, ch.exact});
+                const uint64_t cap = std::max<uint64_t>(st[i].seqCap * ch.grow, ch.len + st[i].seqCap / 4 + 4096);
+                plans.push_back(JobPlan{0, jr.idx, cap, st[i].seeds[(size_t)jr.idx].vid, ch.job_mode, ch.job_stop, (ch.job_mode & TRAV_MODE_RESUME) ? &ch : nullptr, ch.exact});
                 if ((rc = post_batch(i, GRP_CHAIN0 + jr.idx, plans))) return fail(rc);
                 continue;
             }
@@ -1530,7 +1578,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 } else if ((o.overflow & 7) == 0) {
                     std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0,
                                  (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)G2.len,
-                                 RS[i].chains[(size_t)jr.idx].T.v.size(), o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
+                                 RS[i].chains[(size_t)jr.idx].len, o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
                 }
             }
         std::sort(touched.begin(), touched.end());
@@ -1586,7 +1634,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 for (size_t sd = 0; sd < R.chains.size(); ++sd) {
                     const Chain &ch = R.chains[sd];
                     const size_t len = ch.size;
-                    const uint32_t last_ctg = ch.T.pc.empty() ? 0u : ch.T.pc.back();
+                    const uint32_t last_ctg = ch.len == 0 ? 0u : ch.parts.back().pc[ch.parts.back().n - 1];
                     P.leap = last_ctg != 0 && mapper.singleToDual(last_ctg).first != cs.chosenOne;
                     if (!P.leap && sd > 0 && prm->min_len > 0 && len < prm->min_len) continue;
                     if (len > maxLen || P.leap) {
@@ -1599,7 +1647,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 }
                 if (P.chosen >= 0) {
                     P.off = tot;
-                    P.len = R.chains[(size_t)P.chosen].T.v.size();
+                    P.len = R.chains[(size_t)P.chosen].len;
                     tot += P.len;
                 }
             }
@@ -1611,7 +1659,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
                 if (P.chosen < 0 || P.len == 0) continue;
-                std::memcpy(hp + P.off, RS[i].chains[(size_t)P.chosen].T.v.data(), P.len * 4);
+                flatten_chain(RS[i].chains[(size_t)P.chosen], hp + P.off, nullptr, nullptr);
             }
             if (tot) hipMemcpyAsync(b_gather.p, hp, tot * 4, hipMemcpyHostToDevice, s);
             for (uint32_t i : batch) {
@@ -1620,8 +1668,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 const Chain &ch = RS[i].chains[(size_t)P.chosen];
                 CtgState &cs = st[i];
                 {   // globalUniqueTable on the device: its hash set (vertices outside the strand's id range) grows as needed
-                    for (uint32_t u : ch.T.v)
-                        if (u < cs.inLo || u >= cs.inHi) cs.outsideU.push_back(u);
+                    for (const Chain::Part &pt : ch.parts)
+                        for (size_t x = 0; x < pt.n; ++x)
+                            if (pt.v[x] < cs.inLo || pt.v[x] >= cs.inHi) cs.outsideU.push_back(pt.v[x]);
                     if ((uint64_t)cs.outsideU.size() * 2 > cs.gcap) {
                         uint32_t ncap = cs.gcap;
                         while ((uint64_t)cs.outsideU.size() * 4 > ncap) ncap *= 2;
@@ -1647,15 +1696,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             if (P.chosen < 0 || P.len == 0) continue;
             const Chain &ch = RS[i].chains[(size_t)P.chosen];
             longest[i].resize(P.len);
-            for (size_t x = 0; x < P.len; ++x) longest[i][x] = LNode{ch.T.v[x], (int32_t)ch.T.s[x], ch.T.pc[x]};
+            for (const Chain::Part &pt : ch.parts)
+                for (size_t x = 0; x < pt.n; ++x) longest[i][pt.start + x] = LNode{pt.v[x], (int32_t)pt.s[x], pt.pc[x]};
         }
         for (uint32_t i : batch) {  // the host copies of the round are spent
-            for (auto &ch : RS[i].chains)
-                for (auto *vec : {&ch.T.v, &ch.T.s, &ch.T.pc})
-                    if (vec->capacity() && g->u32_pool.size() < 4096) {
-                        g->u32_pool.emplace_back();
-                        g->u32_pool.back().swap(*vec);
-                    }
             RS[i].chains.clear();
             RS[i].segs.clear();
         }

@@ -58,7 +58,6 @@ struct pag_graph {
     // device arena of the walker's job buffers (bump pointer, reset by every pag_travel)
     void *walk_arena = nullptr;
     size_t walk_arena_cap = 0, walk_arena_used = 0;
-    std::vector<std::vector<uint32_t>> u32_pool;  // spent path arrays of the walk control (capacity kept for the next round / call)
     std::vector<void *> fetch_chunks;  // pinned chunks for the paths fetched from the walker (pag_travel)
     std::vector<size_t> fetch_chunk_bytes;
     uint64_t n_zero_ctg = 0;  // new ids below it: vertices without a contig coordinate, in reference-coordinate order
