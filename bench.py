@@ -409,6 +409,20 @@ def main():
                     line["config"]["file_to_file_bases_per_s"] = rec["ours"]["bases_per_s"]
                     line["config"]["file_to_file_note"] = ("bin/pagraph on the same text files, wall clock incl. parsing and upload; cached: "
                                                            "profiles/r02_c2_text_runs.json")
+                    # what the product's own ingest costs in that run (host code: parsers, then GraphInput = eligibility /
+                    # flips / n_valid / contig->reference entries, the inputs this bench takes from its generator)
+                    phases = {}
+                    for ln in rec["ours"].get("stderr_tail", "").splitlines():
+                        for key, tag in (("load_global_inputs_s", "load global inputs + create"), ("load_block_inputs_s", "load block inputs"),
+                                         ("graph_input_s", "GraphInput (preProcess)"), ("traversal_s", "] traversal "),
+                                         ("write_s", "traverse + write")):
+                            if tag in ln:
+                                try:
+                                    phases[key] = float(ln.split(tag)[1].split()[0])
+                                except (ValueError, IndexError):
+                                    pass
+                    if phases:
+                        line["config"]["file_to_file_phases"] = phases
             except Exception:
                 pass
         print(json.dumps(line), flush=True)
