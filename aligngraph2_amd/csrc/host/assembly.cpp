@@ -1,4 +1,5 @@
 #include "assembly.hpp"
+#include "host_threads.hpp"
 
 #include <functional>
 
@@ -119,7 +120,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         auto worker = [&]() {
             for (std::size_t x; (x = next.fetch_add(1)) < nTasks;) task(x);
         };
-        unsigned nThreads = hostThreads ? hostThreads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+        unsigned nThreads = hostThreads ? hostThreads : std::min(64u, std::max(1u, usableCpus()));
         nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, nTasks)));
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
@@ -347,7 +348,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             auto worker = [&]() {
                 for (std::size_t x; (x = next.fetch_add(1)) < n;) fn(x);
             };
-            unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
+            unsigned nThreads = hostThreads ? hostThreads : std::max(1u, usableCpus());
             nThreads = static_cast<unsigned>(std::min<std::size_t>(std::min(nThreads, 64u), std::max<std::size_t>(1, n)));
             std::vector<std::thread> pool;
             for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
@@ -427,7 +428,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
             }
         };
         {
-            unsigned nThreads = hostThreads ? hostThreads : std::max(1u, std::thread::hardware_concurrency());
+            unsigned nThreads = hostThreads ? hostThreads : std::max(1u, usableCpus());
             nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, results.size())));
             std::vector<std::thread> pool;
             for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(sumWorker);

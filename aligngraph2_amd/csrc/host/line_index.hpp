@@ -3,6 +3,7 @@
 // (no '\n', a '\r' stays, a last line without '\n' counts, a trailing '\n' does not open an empty last line).
 #pragma once
 #include <algorithm>
+#include "host_threads.hpp"
 #include <atomic>
 #include <cstdint>
 #include <cstring>
@@ -14,7 +15,7 @@
 namespace pagh {
 
 inline unsigned hostThreads(std::size_t work_items, unsigned cap = 32) {
-    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned hw = std::max(1u, usableCpus());
     return static_cast<unsigned>(std::max<std::size_t>(1, std::min<std::size_t>(std::min(hw, cap), work_items)));
 }
 

@@ -5,6 +5,7 @@
 // de-duplication or ordering is needed).  Contigs fill disjoint slices, so they are filled by a pool of threads.
 #pragma once
 #include <algorithm>
+#include "host_threads.hpp"
 #include <atomic>
 #include <cstdint>
 #include <thread>
@@ -58,7 +59,7 @@ inline void buildPathGraph(const std::vector<std::pair<const pag_path_node *, st
             }
         }
     };
-    unsigned nThreads = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+    unsigned nThreads = threads ? threads : std::max(1u, usableCpus());
     nThreads = static_cast<unsigned>(std::min<std::size_t>(nThreads, std::max<std::size_t>(1, paths.size())));
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(worker);
