@@ -129,6 +129,7 @@ double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock
 int runPagraph(int argc, char **argv, GraphBackend &backend) {
     const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
     double tPrev = nowSec();
+    const double tStart = tPrev;
     auto lap = [&](const char *what) {
         double t = nowSec();
         if (timing) std::cerr << "[timing] " << what << " " << (t - tPrev) << " s" << std::endl;
@@ -162,6 +163,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         std::cout << "Loading KMer" << std::endl;
         KmerFile kmers(opt.kmer);
         std::cout << "Done! k=" << kmers.k() << std::endl;
+        lap("  solid k-mer file");
         std::cout << "Loading Contigs" << std::endl;
         SeqDb contigs(opt.contig);
         std::cout << "Done! contigs number=" << contigs.size() << std::endl;
@@ -171,10 +173,12 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         std::cout << "Loading ContigToRef" << std::endl;
         AlnDb ctgToRef(opt.aln, AlnDb::Flavor::MummerV2);
         std::cout << "Done! number=" << ctgToRef.size() << std::endl;
+        lap("  contigs, references, contig->reference alignments");
         std::cout << "Building original pa Graph [" << backend.name() << "]" << std::endl;
         backend.create(kmers.words(), static_cast<unsigned>(kmers.k()));
         std::cout << "Done! kmer number=" << backend.solidCount() << std::endl;
-        lap("load global inputs + create");
+        lap("  solid set -> device (create)");
+        if (timing) std::cerr << "[timing] load global inputs + create " << (nowSec() - tStart) << " s" << std::endl;
 
         std::unordered_set<std::string> okCtg;  // same container as the reference: contig.txt order (quirk Q11)
         std::size_t blockNo = 0;

@@ -71,7 +71,9 @@ SeqDb::SeqDb(const std::string &path) {
 
     std::ifstream in(path);
     std::string line;
-    if (fasta) {
+    if (fasta && loadFastaParallel(path)) {
+        // (done)
+    } else if (fasta) {
         // multi-line records; only '>' starts a record; text before the first header is glued to
         // the first record (the reference never clears its buffer there, SeqHelper.cpp:39-49)
         std::string header, buffer;
@@ -146,6 +148,75 @@ bool SeqDb::loadFastqParallel(const std::string &path) {
     });
     for (std::size_t r = 0; r < nRec; ++r) nameToId_[names_[first + r]] = first + r;  // later duplicates win
     lastName_.assign(fl.data(4 * (nRec - 1)) + tok[nRec - 1].first, tok[nRec - 1].second);
+    return true;
+}
+
+// The records of the sequential FASTA loop above — only '>' starts a record, its lines are concatenated, whatever precedes the
+// first header is glued to the first record — with the lines found, copied and packed by a pool of threads (a 50 Mb reference
+// is ONE record: the work is split by base ranges, not by records).  Returns false (nothing loaded) for what is left to
+// the sequential path: a record of 2^32 bases or more.
+bool SeqDb::loadFastaParallel(const std::string &path) {
+    FileLines fl;
+    if (!fl.load(path)) return false;
+    const std::size_t nLines = fl.size();
+    std::vector<std::size_t> headers;  // line numbers that start a record
+    {
+        std::vector<std::uint8_t> isHeader(nLines, 0);
+        parallelFor(nLines, 1 << 16, [&](std::size_t i) { isHeader[i] = fl.length(i) > 0 && fl.data(i)[0] == '>'; });
+        for (std::size_t i = 0; i < nLines; ++i)
+            if (isHeader[i]) headers.push_back(i);
+    }
+    if (headers.empty()) return true;  // no record at all
+    const std::size_t nRec = headers.size();
+    // sequence lines of record r: [headers[r] + 1, headers[r + 1]); the first record also owns the lines before its header
+    std::vector<std::size_t> lineOff(nLines + 1, 0);  // bases before line i (header lines count as empty)
+    for (std::size_t i = 0; i < nLines; ++i) lineOff[i + 1] = lineOff[i] + ((fl.length(i) > 0 && fl.data(i)[0] == '>') ? 0 : fl.length(i));
+    auto recBegin = [&](std::size_t r) { return r == 0 ? lineOff[0] : lineOff[headers[r]]; };
+    auto recEnd = [&](std::size_t r) { return r + 1 < nRec ? lineOff[headers[r + 1]] : lineOff[nLines]; };
+    for (std::size_t r = 0; r < nRec; ++r)
+        if (recEnd(r) - recBegin(r) > 0xFFFFFFFFull) return false;
+    // all bases in one buffer, in file order (every line knows where it goes)
+    std::vector<char> flat(lineOff[nLines] + 4, 'A');
+    parallelFor(nLines, 1 << 12, [&](std::size_t i) {
+        const std::size_t n = lineOff[i + 1] - lineOff[i];
+        if (n) std::memcpy(flat.data() + lineOff[i], fl.data(i), n);
+    });
+    const std::size_t first = names_.size();
+    for (std::size_t r = 0; r < nRec; ++r) {
+        std::stringstream ss;  // (the name as add() takes it: first token of the header line, minus its first character)
+        ss << fl.str(headers[r]);
+        ss >> lastName_;
+        const std::string name = lastName_.empty() ? std::string() : lastName_.substr(1);
+        const std::size_t n = recEnd(r) - recBegin(r);
+        nameToId_[name] = names_.size();  // later duplicates win
+        names_.push_back(name);
+        len_.push_back(static_cast<std::uint32_t>(n));
+        byteOff_.push_back(packed_.size());
+        totalBases_ += n;
+        const std::size_t nBytes = (n + 3) / 4;
+        packed_.resize(packed_.size() + ((nBytes + 3) & ~std::size_t(3)), 0);
+    }
+    // pack: chunks of 2^16 output bytes of every record
+    struct Job {
+        std::size_t rec, byteLo, byteHi;
+    };
+    std::vector<Job> jobs;
+    for (std::size_t r = 0; r < nRec; ++r) {
+        const std::size_t nBytes = (static_cast<std::size_t>(len_[first + r]) + 3) / 4;
+        for (std::size_t b = 0; b < nBytes; b += 1 << 16) jobs.push_back(Job{r, b, std::min(nBytes, b + (1 << 16))});
+    }
+    parallelFor(jobs.size(), 1, [&](std::size_t j) {
+        const Job &jb = jobs[j];
+        const char *sq = flat.data() + recBegin(jb.rec);
+        const std::size_t n = len_[first + jb.rec];
+        std::uint8_t *out = packed_.data() + byteOff_[first + jb.rec];
+        for (std::size_t b = jb.byteLo; b < jb.byteHi; ++b) {
+            const std::size_t i = 4 * b;
+            unsigned v = 0;
+            for (std::size_t q = 0; q < 4 && i + q < n; ++q) v |= encodeBase(sq[i + q]) << (2 * q);
+            out[b] = static_cast<std::uint8_t>(v);
+        }
+    });
     return true;
 }
 

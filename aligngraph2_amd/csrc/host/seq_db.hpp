@@ -45,6 +45,7 @@ public:
 
 private:
     bool loadFastqParallel(const std::string &path);
+    bool loadFastaParallel(const std::string &path);
     std::vector<std::string> names_;
     std::vector<std::uint32_t> len_;
     std::vector<std::uint64_t> byteOff_;
