@@ -1,5 +1,6 @@
 #include "seq_db.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -71,7 +72,8 @@ SeqDb::SeqDb(const std::string &path) {
 
     std::ifstream in(path);
     std::string line;
-    if (fasta && loadFastaParallel(path)) {
+    const bool sequential = std::getenv("PAGH_SEQUENTIAL_LOADERS") != nullptr;  // (tests: the plain loops below)
+    if (fasta && !sequential && loadFastaParallel(path)) {
         // (done)
     } else if (fasta) {
         // multi-line records; only '>' starts a record; text before the first header is glued to
@@ -89,7 +91,7 @@ SeqDb::SeqDb(const std::string &path) {
             }
         }
         if (!header.empty()) add(header, buffer);
-    } else if (!loadFastqParallel(path)) {
+    } else if (sequential || !loadFastqParallel(path)) {
         // 4-line FASTQ records; a trailing partial record is dropped (SeqHelper.cpp:13-26)
         std::string l1, l2, l3, l4;
         while (std::getline(in, l1) && std::getline(in, l2) && std::getline(in, l3) && std::getline(in, l4)) {

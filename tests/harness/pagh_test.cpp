@@ -60,6 +60,25 @@ const uint64_t *pagh_kmer_words(void *h, uint64_t *n, uint64_t *k) {
     return L->kmers->words().data();
 }
 
+// SeqDb of a file, condensed: out[0] = sequences, out[1] = bases, out[2] = FNV-1a over names, lengths and packed bases
+// (tests/test_loaders.py compares the thread-pool loaders with the sequential loops, PAGH_SEQUENTIAL_LOADERS=1)
+void pagt_seqdb_digest(const char *path, uint64_t *out) {
+    pagh::SeqDb db(path);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t x) { h = (h ^ x) * 1099511628211ull; };
+    for (std::size_t i = 0; i < db.size(); ++i) {
+        for (char c : db.name(i)) mix(static_cast<unsigned char>(c));
+        mix(0xFFu);
+        mix(db.length(i));
+        const std::string sq = db.toString(i, true);
+        for (char c : sq) mix(static_cast<unsigned char>(c));
+        mix(db.id(db.name(i)));
+    }
+    out[0] = db.size();
+    out[1] = db.totalBases();
+    out[2] = h;
+}
+
 uint64_t pagh_total_read_bases(void *h) { return static_cast<Loaded *>(h)->reads->totalBases(); }
 
 void pagh_free(void *h) { delete static_cast<Loaded *>(h); }

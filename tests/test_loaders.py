@@ -1,0 +1,49 @@
+"""CPU: the thread-pool sequence loaders (mapped file, parallel line index, FASTA records packed by base ranges, FASTQ records
+packed per read) against the sequential getline loops they replace (PAGH_SEQUENTIAL_LOADERS=1), on inputs with the
+corner cases the reference's reader has: text before the first header, empty lines, CRLF, no final newline, lower case,
+other letters, duplicate names, a lone header, an empty file."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+import pagctl
+
+CASES = {
+    "plain.fa": b">a desc\nACGTACGTAC\nGGTT\n>b\nTTTT\n",
+    "prefix.fa": b";comment first\nGATTACA\n>first rec\nACGT\nAC\n>second\n\nGG\n\n",
+    "crlf.fa": b">r1\r\nACGT\r\nTTGA\r\n>r2\r\nCC\r\n",
+    "nonl.fa": b">only\nACGTNNNNacgtRYKM",
+    "dup.fa": b">same\nAAAA\n>same\nCCCCCC\n>other\n>empty_next\n\n>last\nT",
+    "long.fa": b">big one\n" + b"\n".join((b"ACGTTGCAAGCT" * 9)[:100] for _ in range(5000)) + b"\nACG\n>tail\nA\n",
+    "reads.fq": b"".join(b"@r%d extra\n%s\n+\n%s\n" % (i, (b"ACGTTGCA" * (i % 7 + 1))[: 5 + i % 11], b"I" * (5 + i % 11)) for i in range(300)),
+    "partial.fq": b"@a\nACGT\n+\nIIII\n@b\nGG\n+\n",
+    "empty.fa": b"",
+}
+
+
+def digest(lib, path):
+    out = (C.c_uint64 * 3)()
+    lib.pagt_seqdb_digest(path.encode(), out)
+    return tuple(out)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_parallel_loader_equals_sequential(name, tmp_path):
+    path = str(tmp_path / name)
+    with open(path, "wb") as f:
+        f.write(CASES[name])
+    lib = pagctl.test_lib()
+    lib.pagt_seqdb_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
+    lib.pagt_seqdb_digest.restype = None
+    fast = digest(lib, path)
+    # the sequential loops in a child process (the switch is read from the environment)
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import pagctl; lib = pagctl.test_lib(); "
+            "lib.pagt_seqdb_digest.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]; lib.pagt_seqdb_digest.restype = None; "
+            "out = (C.c_uint64 * 3)(); lib.pagt_seqdb_digest(%r.encode(), out); print(*out)") % (os.path.dirname(os.path.abspath(__file__)), path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PAGH_SEQUENTIAL_LOADERS="1"))
+    assert r.returncode == 0, r.stderr
+    slow = tuple(int(x) for x in r.stdout.split())
+    assert fast == slow
