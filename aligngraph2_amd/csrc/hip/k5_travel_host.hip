@@ -958,6 +958,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         for (auto &sd : cs.seeds) x0 = std::min(x0, sd.ctg);
         std::vector<uint32_t> ck_x;
         size_t n_spec_ck = 0;
+        uint32_t seed_lo = 0, seed_hi = 0;  // id range for the walks of the seeds up to the first checkpoint (0, 0: the strand)
         if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
             const uint64_t H = (uint64_t)cs.varLen + k;
             // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
@@ -1027,30 +1028,44 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 if (!any_spec) R.zone_end = 0;
             }
             if (!R.segs.empty()) {  // id ranges around the segments: [checkpoint - 2000, stop + 3000] in contig coordinates
-                std::vector<uint32_t> co(2 * R.segs.size()), ids(2 * R.segs.size());
-                for (size_t q = 0; q < R.segs.size(); ++q) {
+                const size_t nq = R.segs.size();
+                std::vector<uint32_t> co(2 * nq + 2), ids(2 * nq + 2);
+                for (size_t q = 0; q < nq; ++q) {
                     co[2 * q] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)R.segs[q].x - std::min<uint64_t>(R.segs[q].x, 2000));
                     co[2 * q + 1] = R.segs[q].stop ? (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)R.segs[q].stop + 3000) : cs.ctgRight;
                 }
+                // ... and around the seeds' own first piece: [lowest seed - 2000, first stop + 3000]
+                co[2 * nq] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)x0 - std::min<uint64_t>(x0, 2000));
+                co[2 * nq + 1] = (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)first_stop(R) + 3000);
                 if ((r = b_ckreq.alloc(co.size() * 4 + reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(co.size() * 4 + reqs.size() * 12))) return r;
                 PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s));
                 trav_launch_id_bounds(G, b_ckreq.as<uint32_t>(), (uint32_t)co.size(), b_ckout.as<uint32_t>(), s);
                 PAG_HIP_TRY(hipMemcpyAsync(ids.data(), b_ckout.p, ids.size() * 4, hipMemcpyDeviceToHost, s));
                 PAG_HIP_TRY(hipStreamSynchronize(s));
-                for (size_t q = 0; q < R.segs.size(); ++q) {
+                auto window = [&](size_t q, uint32_t *wlo, uint32_t *whi) {
                     uint32_t lo = std::max(ids[2 * q], cs.inLo), hi = std::min(ids[2 * q + 1], cs.inHi);
                     lo = cs.inLo + ((lo - cs.inLo) & ~31u);  // (the strand's global-visited bitmap is read word-wise from here)
                     if (hi <= lo) hi = std::min<uint32_t>(cs.inHi, lo + 64);
-                    R.segs[q].win_lo = lo;
-                    R.segs[q].win_hi = hi;
-                }
+                    *wlo = lo;
+                    *whi = hi;
+                };
+                for (size_t q = 0; q < nq; ++q) window(q, &R.segs[q].win_lo, &R.segs[q].win_hi);
+                if (first_stop(R) != 0u) window(nq, &seed_lo, &seed_hi);
             }
         }
         std::vector<JobPlan> plans;
         const uint64_t cap_full = cs.seqCap;
         for (size_t sd = 0; sd < cs.seeds.size(); ++sd) {
             const uint32_t stop = R.segs.empty() ? 0u : first_stop(R);
-            plans.push_back(JobPlan{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false});
+            // (a seed's walk that stops at the first checkpoint is a piece like the segments: direct-mapped marks around it,
+            // a sequence buffer for its stretch; the full-strand arrays, 130 MB per job at configs[1], are for resumed walks)
+            JobPlan pl{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false};
+            if (stop != 0u && seed_hi != 0u && cs.seeds[sd].ctg <= stop) {
+                pl.win_lo = seed_lo;
+                pl.win_hi = seed_hi;
+                pl.cap = std::min<uint64_t>(cap_full, ((uint64_t)stop - cs.seeds[sd].ctg) / 2 + 8192);
+            }
+            plans.push_back(pl);
         }
         // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
         static const bool leap_first = !(std::getenv("PAG_LEAP_FIRST") && std::atoi(std::getenv("PAG_LEAP_FIRST")) == 0);
@@ -1303,7 +1318,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             // segments of the leaping zone (the last tenth of the strand + margin, half as long, far larger hash sets, a log)
             const size_t n_lseg = cs.len / 8 / 6000 + 2, lcap = 3000 + 8192, loc = pow2_at_least(lcap + 8192), lspan = sspan;
             const size_t lseg = lcap * 8 + lcap * 8 * TRAV_PROBE_GROUPS + lcap * 8 + loc * 8 * (1 + TRAV_PROBE_GROUPS) + lspan * 4 * (1 + TRAV_PROBE_GROUPS);
-            want += chain * 3 + (seg * n_seg + lseg * n_lseg) * 3 / 2;
+            // (full-strand buffers: the resumed walks — the seeds' own first pieces are sized like segments)
+            want += chain * 3 / 2 + (seg * (n_seg + 8) + lseg * n_lseg) * 3 / 2;
         }
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);

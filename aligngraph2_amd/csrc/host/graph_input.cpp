@@ -1,4 +1,5 @@
 #include "graph_input.hpp"
+#include "line_index.hpp"
 
 #include <algorithm>
 #include <stdexcept>
@@ -41,61 +42,85 @@ void GraphInput::buildCtgMap(const SeqDb &ctgs, const SeqDb &refs, const AlnDb &
     ctgTab_.assign(ctgs.size(), pag_ctg{});
     ctgEntOff_.clear();
     ctgEnt_.clear();
+    const std::size_t nCtg = ctgs.size();
 
-    for (std::size_t c = 0; c < ctgs.size(); ++c) {
+    // Aligner::simpleAlign (Aligner.cpp:152-186): alignments of a contig, list order, only the accepted reference and only
+    // the configured orientation; two sweeps (count, fill).  The contigs are independent: both sweeps run on the thread pool,
+    // the offsets in between are a serial prefix sum over the contigs.
+    auto sweep = [&](std::size_t c, bool fill, std::vector<std::uint32_t> &cnt, std::uint32_t *cursor) {
+        const std::size_t len = ctgs.length(c);
+        for (auto &e : lists[c]) {
+            if (!refAccepted_[e.tgt]) continue;
+            const AlnRecord &r = ctgToRef[e.rec];
+            if (r.forward != ctgForward_[c]) continue;
+            std::size_t cb = r.queryBegin, ce = r.queryEnd;
+            if (!r.forward) flip(cb, ce, len);
+            std::size_t span = ce > cb ? ce - cb : 0;
+            std::size_t k = 0;
+            ctgToRef.exactAlign(r, cb, r.refBegin, true, [&](std::size_t, std::size_t refCur) {
+                // AlignReference::insert: base cb + k receives (refIdx + 1, refPos[k]) for k < ce - cb
+                std::size_t b = cb + k;
+                if (k < span && b < len) {
+                    if (!fill) {
+                        ++cnt[b];
+                    } else {
+                        ctgEnt_[cursor[b]++] = static_cast<std::uint32_t>(
+                            refMapper_.dualToSingle(static_cast<std::int64_t>(e.tgt) + 1, static_cast<std::int64_t>(refCur)));
+                    }
+                }
+                ++k;
+            });
+        }
+    };
+    std::vector<std::vector<std::uint32_t>> cnt(nCtg);
+    std::vector<std::size_t> runOf(nCtg, 0);  // entries of the contig, AlignReference::addExtraPosition included
+    parallelFor(nCtg, 1, [&](std::size_t c) {
+        if (!ctgSelected_[c]) return;
+        const std::size_t len = ctgs.length(c);
+        cnt[c].assign(len, 0);
+        sweep(c, false, cnt[c], nullptr);
+        std::size_t run = 0;
+        std::uint32_t multi = 0;
+        for (std::size_t b = 0; b < len; ++b) {
+            run += cnt[c][b] ? cnt[c][b] : 1;  // (AlignReference.cpp:69-79: empty lists get (0, 0) -> 0)
+            if (cnt[c][b] > 1) multi = 1;
+        }
+        runOf[c] = run;
+        ctgTab_[c].multi = multi;
+    });
+    std::vector<std::size_t> entBase(nCtg, 0);
+    std::size_t offTotal = 0, entTotal = 0;
+    for (std::size_t c = 0; c < nCtg; ++c) {
         pag_ctg &t = ctgTab_[c];
-        std::size_t len = ctgs.length(c);
+        const std::size_t len = ctgs.length(c);
         t.len = static_cast<std::uint32_t>(len);
         t.selected = ctgSelected_[c] ? 1u : 0u;
         std::int64_t dual = ctgForward_[c] ? static_cast<std::int64_t>(c) + 1 : -static_cast<std::int64_t>(c) - 1;
         t.single_base = static_cast<std::uint32_t>(ctgMapper_.dualToSingle(dual, 0));
-        t.map_off = ctgEntOff_.size();
+        t.map_off = offTotal;
+        entBase[c] = entTotal;
         if (!ctgSelected_[c]) continue;
-
-        // Aligner::simpleAlign (Aligner.cpp:152-186): alignments of this contig, list order, only the
-        // accepted reference and only the configured orientation; two sweeps (count, fill).
-        std::vector<std::uint32_t> cnt(len, 0);
-        auto sweep = [&](bool fill, std::vector<std::uint32_t> &cursor) {
-            for (auto &e : lists[c]) {
-                if (!refAccepted_[e.tgt]) continue;
-                const AlnRecord &r = ctgToRef[e.rec];
-                if (r.forward != ctgForward_[c]) continue;
-                std::size_t cb = r.queryBegin, ce = r.queryEnd;
-                if (!r.forward) flip(cb, ce, len);
-                std::size_t span = ce > cb ? ce - cb : 0;
-                std::size_t k = 0;
-                ctgToRef.exactAlign(r, cb, r.refBegin, true, [&](std::size_t, std::size_t refCur) {
-                    // AlignReference::insert: base cb + k receives (refIdx + 1, refPos[k]) for k < ce - cb
-                    std::size_t b = cb + k;
-                    if (k < span && b < len) {
-                        if (!fill) {
-                            ++cnt[b];
-                        } else {
-                            ctgEnt_[cursor[b]++] = static_cast<std::uint32_t>(
-                                refMapper_.dualToSingle(static_cast<std::int64_t>(e.tgt) + 1,
-                                                        static_cast<std::int64_t>(refCur)));
-                        }
-                    }
-                    ++k;
-                });
-            }
-        };
-        std::vector<std::uint32_t> none;
-        sweep(false, none);
-        // AlignReference::addExtraPosition (AlignReference.cpp:69-79): empty lists get (0, 0) -> 0
-        std::vector<std::uint32_t> cursor(len);
-        std::size_t base = ctgEnt_.size();
-        std::size_t run = base;
-        for (std::size_t b = 0; b < len; ++b) {
-            ctgEntOff_.push_back(fitU32(run, "contig map offset"));
-            cursor[b] = static_cast<std::uint32_t>(run);
-            run += cnt[b] ? cnt[b] : 1;
-            if (cnt[b] > 1) t.multi = 1;
-        }
-        ctgEntOff_.push_back(fitU32(run, "contig map offset"));
-        ctgEnt_.resize(run, 0);
-        sweep(true, cursor);
+        offTotal += len + 1;
+        entTotal += runOf[c];
+        fitU32(entTotal, "contig map offset");
     }
+    ctgEntOff_.assign(offTotal, 0);
+    ctgEnt_.assign(entTotal, 0);
+    parallelFor(nCtg, 1, [&](std::size_t c) {
+        if (!ctgSelected_[c]) return;
+        const std::size_t len = ctgs.length(c);
+        std::vector<std::uint32_t> cursor(len);
+        std::size_t run = entBase[c];
+        std::uint32_t *off = ctgEntOff_.data() + ctgTab_[c].map_off;
+        for (std::size_t b = 0; b < len; ++b) {
+            off[b] = static_cast<std::uint32_t>(run);
+            cursor[b] = static_cast<std::uint32_t>(run);
+            run += cnt[c][b] ? cnt[c][b] : 1;
+        }
+        off[len] = static_cast<std::uint32_t>(run);
+        sweep(c, true, cnt[c], cursor.data());
+        std::vector<std::uint32_t>().swap(cnt[c]);
+    });
     if (ctgEntOff_.empty()) ctgEntOff_.push_back(0);
     ctgEnt_.push_back(0);  // never-empty buffers
 }
