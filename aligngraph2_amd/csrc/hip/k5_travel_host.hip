@@ -1323,7 +1323,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
-        if (g->walk_arena_cap < want) {
+        if (g->walk_arena_cap < want / 10 * 7) {  // (an arena that is there — pag_reserve_walk_arena, an earlier call — is kept
+                                                  // unless it is much too small: what does not fit goes to the slots)
             if (g->walk_arena) hipFree(g->walk_arena);
             g->walk_arena = nullptr;
             g->walk_arena_cap = 0;

@@ -603,6 +603,26 @@ int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats)
     return PAG_OK;
 }
 
+extern "C" int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases) {
+    if (!g) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    // (~1.2 KB per contig base is what pag_travel's own estimate comes to at sequencing coverage; it caps itself likewise)
+    size_t want = (size_t)contig_bases * 1200 + (64u << 20);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) / 4);
+    if (g->walk_arena_cap >= want) return PAG_OK;
+    if (g->walk_arena) hipFree(g->walk_arena);
+    g->walk_arena = nullptr;
+    g->walk_arena_cap = 0;
+    if (hipMalloc(&g->walk_arena, want) != hipSuccess) {
+        g->walk_arena = nullptr;
+        (void)hipGetLastError();
+        return PAG_OK;  // (pag_travel tries again, or works without the arena)
+    }
+    g->walk_arena_cap = want;
+    return PAG_OK;
+}
+
 // ---- one graph built by several GPUs (see include/pagraph_hip.h)
 static int log2_shards(uint32_t n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : -1; }
 

@@ -10,6 +10,8 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <exception>
 #include <unordered_set>
 
 #include "aln_db.hpp"
@@ -202,6 +204,25 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 continue;
             }
             backend.reset();
+            // (the device memory of the walks is asked for while the block's text files are parsed: the first large
+            // allocation of a process can take seconds)
+            std::uint64_t ctgBases = 0;
+            for (auto &c : cfg.contigs)
+                if (contigs.contains(c.first)) ctgBases += contigs.length(contigs.id(c.first));
+            std::exception_ptr reserveError;
+            std::thread reserver([&] {
+                try {
+                    backend.reserveForContigs(ctgBases);
+                } catch (...) {
+                    reserveError = std::current_exception();
+                }
+            });
+            struct Joiner {
+                std::thread &t;
+                ~Joiner() {
+                    if (t.joinable()) t.join();
+                }
+            } joiner{reserver};
             std::cout << "Use Ref: " << cfg.ref << std::endl;
             SeqDb reads(opt.pre + "/" + cfg.readPath);
             std::cout << "Done! reads number=" << reads.size() << std::endl;
@@ -210,6 +231,8 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             AlnDb readToRef(opt.pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat);
             std::cout << "Done! aln number=" << readToRef.size() << std::endl;
 
+            reserver.join();
+            if (reserveError) std::rethrow_exception(reserveError);
             lap("load block inputs");
             std::cout << "Pre Process" << std::endl;
             GraphInput input(reads, contigs, refs, readToCtg, readToRef, ctgToRef, cfg, params);

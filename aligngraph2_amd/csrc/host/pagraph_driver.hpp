@@ -27,6 +27,8 @@ public:
     virtual void create(const std::vector<std::uint64_t> &kmerWords, unsigned k) = 0;
     virtual std::uint64_t solidCount() = 0;
     virtual void reset() = 0;
+    // optional: get ready for traversals over contigs of that many bases in total (may run beside the input parsing)
+    virtual void reserveForContigs(std::uint64_t /*bases*/) {}
     virtual void process(const pag_build_input &in, pag_build_stats &stats) = 0;
     virtual void exportCsr(HostGraph &out) = 0;
     // PAlgorithm::travelSequence for every (contig, orientation) of ctgSet (PAssembly.cpp:30-36): fills `graph` with (at

@@ -270,6 +270,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                const pag_travel_params *params, pag_travel_stats *stats);
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);
 const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len);
+/* Optional: have the device memory the walks of pag_travel take their job buffers from (one arena per handle, kept between
+ * calls) allocated NOW, for contigs of `contig_bases` bases in total.  May be called from another thread while the caller
+ * parses its inputs (no other call on the handle may run at the same time): a first large allocation of a process can take
+ * seconds.  pag_travel sizes the arena itself when this was not called or asked for too little. */
+int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases);
 /* ---- kmer_counter on the device (replaces PAGraph/src/main/kmer_counter.cpp:19-96) ----------------
  * Counts every k-mer of the forward strand of every read (KmerHelper::kmer2Code, KmerHelper.cpp:7-25) in a dense 4^k
  * table, derives the minimum abundance by the reference's rule (the first occurring abundance a, ascending, with
