@@ -14,9 +14,9 @@ public:
     explicit HipBackend(int device) : device_(device) {}
     ~HipBackend() override { pag_destroy(g_); }
     const char *name() const override { return "HIP gfx950"; }
-    void create(const std::vector<std::uint64_t> &words, unsigned k) override {
+    void create(const std::uint64_t *words, std::size_t nWords, unsigned k) override {
         int err = 0;
-        g_ = pag_create(words.data(), words.size(), k, device_, &err);
+        g_ = pag_create(words, nWords, k, device_, &err);
         if (!g_) throw std::runtime_error(std::string("pag_create failed (") + std::to_string(err) + "): " + pag_last_error());
     }
     std::uint64_t solidCount() override { return pag_solid_count(g_); }

@@ -177,7 +177,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         std::cout << "Done! number=" << ctgToRef.size() << std::endl;
         lap("  contigs, references, contig->reference alignments");
         std::cout << "Building original pa Graph [" << backend.name() << "]" << std::endl;
-        backend.create(kmers.words(), static_cast<unsigned>(kmers.k()));
+        backend.create(kmers.data(), kmers.size(), static_cast<unsigned>(kmers.k()));
         std::cout << "Done! kmer number=" << backend.solidCount() << std::endl;
         lap("  solid set -> device (create)");
         if (timing) std::cerr << "[timing] load global inputs + create " << (nowSec() - tStart) << " s" << std::endl;

@@ -24,7 +24,7 @@ public:
     virtual ~GraphBackend() = default;
     virtual const char *name() const = 0;
     // PABruijnGraph::PABruijnGraph: every word of the solid-set file (header word included)
-    virtual void create(const std::vector<std::uint64_t> &kmerWords, unsigned k) = 0;
+    virtual void create(const std::uint64_t *kmerWords, std::size_t nWords, unsigned k) = 0;
     virtual std::uint64_t solidCount() = 0;
     virtual void reset() = 0;
     // optional: get ready for traversals over contigs of that many bases in total (may run beside the input parsing)

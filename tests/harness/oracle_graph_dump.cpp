@@ -36,7 +36,7 @@ int main(int argc, char **argv) {
     SeqDb ctgs(argOf(argc, argv, "-c", ""));
     SeqDb refs(argOf(argc, argv, "-R", ""));
     AlnDb ctgToRef(argOf(argc, argv, "-a", ""), AlnDb::Flavor::MummerV2);
-    pago_graph *g = pago_create(kf.words().data(), kf.words().size(), static_cast<uint32_t>(kf.k()));
+    pago_graph *g = pago_create(kf.data(), kf.size(), static_cast<uint32_t>(kf.k()));
 
     auto blocks = loadConfig(preDir + "/config.txt");
     std::size_t blockNo = 0;

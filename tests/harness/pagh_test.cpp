@@ -55,9 +55,9 @@ const pag_build_input *pagh_view(void *h) { return &static_cast<Loaded *>(h)->in
 
 const uint64_t *pagh_kmer_words(void *h, uint64_t *n, uint64_t *k) {
     auto *L = static_cast<Loaded *>(h);
-    *n = L->kmers->words().size();
+    *n = L->kmers->size();
     *k = L->kmers->k();
-    return L->kmers->words().data();
+    return L->kmers->data();
 }
 
 // SeqDb of a file, condensed: out[0] = sequences, out[1] = bases, out[2] = FNV-1a over names, lengths and packed bases

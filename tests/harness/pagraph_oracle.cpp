@@ -13,7 +13,7 @@ class OracleBackend final : public pagh::GraphBackend {
 public:
     ~OracleBackend() override { pago_destroy(g_); }
     const char *name() const override { return "C oracle (test harness)"; }
-    void create(const std::vector<std::uint64_t> &words, unsigned k) override { g_ = pago_create(words.data(), words.size(), k); }
+    void create(const std::uint64_t *words, std::size_t nWords, unsigned k) override { g_ = pago_create(words, nWords, k); }
     std::uint64_t solidCount() override { return pago_solid_count(g_); }
     void reset() override { pago_reset(g_); }
     void process(const pag_build_input &in, pag_build_stats &stats) override {
