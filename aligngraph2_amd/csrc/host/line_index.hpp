@@ -63,7 +63,7 @@ public:
                 index();
                 return true;
             }
-            void *m = ::mmap(nullptr, static_cast<std::size_t>(st.st_size), PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            void *m = ::mmap(nullptr, static_cast<std::size_t>(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) {
                 map_ = m;
                 mapBytes_ = static_cast<std::size_t>(st.st_size);
