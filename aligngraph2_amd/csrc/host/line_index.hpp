@@ -19,7 +19,7 @@
 
 namespace pagh {
 
-inline unsigned hostThreads(std::size_t work_items, unsigned cap = 32) {
+inline unsigned hostThreads(std::size_t work_items, unsigned cap = 64) {
     unsigned hw = std::max(1u, usableCpus());
     return static_cast<unsigned>(std::max<std::size_t>(1, std::min<std::size_t>(std::min(hw, cap), work_items)));
 }
