@@ -2,6 +2,7 @@
 on fresh seeded inputs, against the compiled reference binary itself (oracle/_ref/pagraph travels to
 the GPU box prebuilt).  Byte-exact on every output file."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -44,6 +45,27 @@ def test_pagraph_matches_golden(name, mode, workdir):
     goldens.compare_out_dir(name, out)
     if mode == "pieces":
         print([ln for ln in r.stderr.splitlines() if "pieces:" in ln or "leaping zone:" in ln])
+        for ln in r.stderr.splitlines():
+            m = re.search(r"leaping zone: (\d+) segment jobs, (\d+) adopted", ln)
+            if m:
+                _LEAP_SEEN["jobs"] += int(m.group(1))
+                _LEAP_SEEN["adopted"] += int(m.group(2))
+            m = re.search(r"pieces: (\d+) segment jobs, (\d+) resume jobs, (\d+) vertices adopted", ln)
+            if m:
+                _LEAP_SEEN["vertices"] += int(m.group(3))
+
+
+_LEAP_SEEN = {"jobs": 0, "adopted": 0, "vertices": 0}
+
+
+@pytest.mark.gpu
+def test_pieces_mode_really_spliced_on_the_goldens():
+    """The "pieces" runs above (same process, earlier in this file) must have adopted segments — in the leaping zone too:
+    outputs that equal the goldens because every splice was refused would prove nothing about the splice conditions."""
+    if _LEAP_SEEN["jobs"] == 0:
+        pytest.skip("the pieces-mode golden tests did not run in this session")
+    assert _LEAP_SEEN["vertices"] > 1000
+    assert _LEAP_SEEN["adopted"] >= 3
 
 
 @pytest.mark.gpu
