@@ -2577,13 +2577,14 @@ __global__ void k_order_refkeys(const uint64_t *__restrict__ val, uint64_t n, ui
 // keys keep the k-mer-major order (stable sorts).  The order inside the first group is not needed by the walks — it makes
 // neighbours on the reference neighbours in memory, and it lets a splice of two walks bound the vertices of that kind a
 // walk has examined by an id (k5_travel_host.hip, try_merge_leap).  *n_zero receives the size of the first group.
-int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, hipStream_t s) {
+int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,
+               int ref_bits, hipStream_t s) {
     const uint64_t n = G.n_pos;
     if (n_zero) *n_zero = 0;
     if (!n) return PAG_OK;
     k_order_keys<<<dim3(grid_for(n)), dim3(256), 0, s>>>(G.vpos, n, key, val);
     int in0 = 1, rc;
-    if ((rc = sort_pairs(key, val, key2, val2, n, 32, sort_tmp, &in0, s, nullptr, nullptr))) return rc;
+    if ((rc = sort_pairs(key, val, key2, val2, n, ctg_bits, sort_tmp, &in0, s, nullptr, nullptr))) return rc;
     uint32_t *ks = in0 ? key : key2, *ko = in0 ? key2 : key;
     uint64_t *vs = in0 ? val : val2, *vo = in0 ? val2 : val;
     unsigned long long *d_n0 = (unsigned long long *)sort_tmp;  // (the sort is done with its scratch)
@@ -2595,7 +2596,7 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     if (n0 > 1) {
         k_order_refkeys<<<dim3(grid_for(n0)), dim3(256), 0, s>>>(vs, n0, ks);
         int in0b = 1;
-        if ((rc = sort_pairs(ks, vs, ko, vo, n0, 32, sort_tmp, &in0b, s, nullptr, nullptr))) return rc;
+        if ((rc = sort_pairs(ks, vs, ko, vo, n0, ref_bits, sort_tmp, &in0b, s, nullptr, nullptr))) return rc;
         if (!in0b) PAG_HIP_TRY(hipMemcpyAsync(vs, vo, n0 * 8, hipMemcpyDeviceToDevice, s));
     }
     if (n_zero) *n_zero = n0;

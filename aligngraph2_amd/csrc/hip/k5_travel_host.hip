@@ -312,7 +312,15 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
             (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
             return rc;
-        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg, s)))
+        // (key widths of the two sorts: the single-coordinate spaces of the contigs and of the references)
+        auto bits_of = [](const uint32_t *len, uint64_t n) {
+            const uint64_t space = Mapper(len, n).starts.empty() ? 1 : Mapper(len, n).starts.back();
+            int b = 1;
+            while (b < 32 && (space >> b) != 0) ++b;
+            return b;
+        };
+        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg,
+                             bits_of(ctgs->len, ctgs->n_seqs), bits_of(ref_len, n_refs), s)))
             return rc;
         uint64_t n_succ = 0, n_cand = 0;
         // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a

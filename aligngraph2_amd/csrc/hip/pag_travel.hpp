@@ -173,7 +173,8 @@ void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s);
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);
-int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, hipStream_t s);
+int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,
+               int ref_bits, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
 // bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
 int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s);
