@@ -117,6 +117,7 @@ struct CtgState {
     int64_t varLen = 0;
     std::deque<uint32_t> ctgQ, refQ;
     bool finalLeap = false, done = false;
+    bool delivered = false;  // its finished sequence has been filtered, gathered and sent to the host
     bool committed = false;  // a walk has been recorded in the global visited structures (device: gbits / gset)
     uint32_t gwinLo = 0xFFFFFFFFu, gwinHi = 0;
     uint32_t *gset = nullptr;   // device: global visited, vertices outside the strand's id range
@@ -180,6 +181,7 @@ const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_i
         return nullptr;
     }
     if (len) *len = g->path_len[slot];
+    if (slot < g->path_ptr.size() && g->path_ptr[slot]) return g->path_ptr[slot];
     return g->path_store + g->path_off[slot];
 }
 
@@ -382,6 +384,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     g->path_off.assign(2 * (size_t)n_ctgs, 0);
     g->path_len.assign(2 * (size_t)n_ctgs, 0);
     g->path_valid.assign(2 * (size_t)n_ctgs, 0);
+    g->path_ptr.assign(2 * (size_t)n_ctgs, nullptr);
     std::vector<CtgState> st;
     uint64_t nodes_total = 0;
     // one entry per (contig, orientation): a contig selected with both orientations is two independent traversals
@@ -1390,6 +1393,68 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     }
     lap("round prep");
 
+    // filterSequence / "Pump it" of a finished contig (PAlgorithm.cpp:409-423)
+    auto filter_travel = [&](CtgState &cs) {
+        auto &seq = cs.travel;
+        if (!cs.finalLeap) {
+            const size_t windowSize = 10;
+            if (seq.size() >= windowSize) {
+                size_t startIdx = seq.size() - seq.size() / 90;
+                for (size_t i = startIdx; i < seq.size() - windowSize + 1; ++i) {
+                    uint32_t firstPos = seq[i].ctg;
+                    uint32_t secondPos = seq[std::min(seq.size(), i + windowSize) - 1].ctg;
+                    if (secondPos != 0 && firstPos != 0 && secondPos < firstPos) {
+                        seq.resize(i + 1);
+                        break;
+                    }
+                }
+            }
+        } else if (!seq.empty()) {
+            auto d = mapper.singleToDual(seq.back().ctg);
+            uint64_t a = (uint64_t)std::llabs(d.first);
+            if (a == (uint64_t)cs.ci + 1 || (a >= 1 && a <= mapper.sizes.size() &&
+                                             (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit)))
+                seq.pop_back();
+        }
+    };
+    // A contig whose traversal is over is DELIVERED while the others still walk: its sequence is filtered, the full records of
+    // its vertices are gathered on the device and copied (asynchronously, stream s) into pinned memory that lives until the
+    // next call — at configs[1] the one gather + 380 MB copy for all contigs used to follow the last walk (15 ms).
+    // Device buffers from the walk arena; without room there the contig is left to the epilogue.
+    auto deliver_contig = [&](uint32_t i) -> int {
+        CtgState &cs = st[i];
+        static const bool early = !(std::getenv("PAG_DELIVER_EARLY") && std::atoi(std::getenv("PAG_DELIVER_EARLY")) == 0);
+        if (cs.delivered || !cs.done || !early) return PAG_OK;
+        const size_t n = cs.travel.size();
+        const size_t need = ((n * 8 + 255) & ~(size_t)255) + 512;
+        if (!g->walk_arena || g->walk_arena_used + need > g->walk_arena_cap) return PAG_OK;
+        filter_travel(cs);
+        const size_t m = cs.travel.size();
+        const size_t slot2 = 2 * (size_t)cs.ci + (cs.forward ? 0 : 1);
+        cs.delivered = true;
+        g->path_off[slot2] = 0;
+        g->path_len[slot2] = m;
+        g->path_valid[slot2] = 1;
+        if (m == 0) return PAG_OK;
+        uint32_t *hp = (uint32_t *)fetch_alloc(m * 8);
+        pag_path_node *dst = (pag_path_node *)fetch_alloc(m * sizeof(pag_path_node));
+        if (!hp || !dst) return PAG_ENOMEM;
+        for (size_t x = 0; x < m; ++x) {
+            hp[x] = cs.travel[x].u;
+            hp[m + x] = (uint32_t)cs.travel[x].step;
+        }
+        uint32_t *d_ids = (uint32_t *)((char *)g->walk_arena + g->walk_arena_used);
+        g->walk_arena_used += (m * 8 + 255) & ~(size_t)255;
+        // A stream of its own (behind this work on stream s the fetches of finished jobs would wait), and the gather kernel
+        // writes the records straight into the pinned host array: a device-to-host copy of 32 bytes per vertex would
+        // occupy the copy engine the fetches need (measured: their lap 9 -> 24 ms per step).
+        if (!g->deliver_stream) PAG_HIP_TRY(hipStreamCreateWithFlags(&g->deliver_stream, hipStreamNonBlocking));
+        PAG_HIP_TRY(hipMemcpyAsync(d_ids, hp, m * 8, hipMemcpyHostToDevice, g->deliver_stream));
+        trav_launch_gather_path(G, d_ids, d_ids + m, m, dst, g->deliver_stream);
+        g->path_ptr[slot2] = dst;
+        return PAG_OK;
+    };
+
     DevBuf b_fetch = buf(), b_fdesc = buf();
     uint32_t scan_from[TRAV_RINGS] = {0, 0, 0};  // per ring: every job number below it has been handled
     double t_progress = now_ms(), t_first_fin = 0, t_query = now_ms();
@@ -1900,6 +1965,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 else next_round.push_back(req_cs[q]);
             }
         }
+        for (uint32_t i : batch)
+            if (st[i].done && (rc = deliver_contig(i))) return fail(rc);
         lap("reseed");
         // ---- post the follow-up rounds
         for (uint32_t i : next_round)
@@ -1923,34 +1990,14 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                      (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted.load(), (unsigned long long)n_merge_fail.load());
     }
 
-    // ---- epilogue per contig: filterSequence / "Pump it" (PAlgorithm.cpp:409-423)
-    for (auto &cs : st) {
-        auto &seq = cs.travel;
-        if (!cs.finalLeap) {
-            const size_t windowSize = 10;
-            if (seq.size() >= windowSize) {
-                size_t startIdx = seq.size() - seq.size() / 90;
-                for (size_t i = startIdx; i < seq.size() - windowSize + 1; ++i) {
-                    uint32_t firstPos = seq[i].ctg;
-                    uint32_t secondPos = seq[std::min(seq.size(), i + windowSize) - 1].ctg;
-                    if (secondPos != 0 && firstPos != 0 && secondPos < firstPos) {
-                        seq.resize(i + 1);
-                        break;
-                    }
-                }
-            }
-        } else if (!seq.empty()) {
-            auto d = mapper.singleToDual(seq.back().ctg);
-            uint64_t a = (uint64_t)std::llabs(d.first);
-            if (a == (uint64_t)cs.ci + 1 || (a >= 1 && a <= mapper.sizes.size() &&
-                                             (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit)))
-                seq.pop_back();
-        }
-    }
-    {   // the full records of the finished sequences: one gather for all contigs, results straight into the pinned array
-        // the handle keeps for pag_travel_path()
+    // ---- epilogue: whatever has not been delivered while the walks ran (see deliver_contig)
+    for (uint32_t i = 0; i < n_sel; ++i)
+        if (!st[i].delivered) filter_travel(st[i]);
+    {   // the full records of those sequences: one gather, results straight into the pinned array the handle keeps for
+        // pag_travel_path()
         uint64_t tot = 0;
-        for (auto &cs : st) tot += cs.travel.size();
+        for (auto &cs : st)
+            if (!cs.delivered) tot += cs.travel.size();
         if (g->path_cap < tot + 1) {
             if (g->path_store) hipHostFree(g->path_store);
             g->path_store = nullptr;
@@ -1966,6 +2013,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         if (!hp) return PAG_ENOMEM;
         uint64_t at = 0;
         for (auto &cs : st) {
+            if (cs.delivered) continue;
             const size_t slot2 = 2 * (size_t)cs.ci + (cs.forward ? 0 : 1);
             g->path_off[slot2] = at;
             g->path_len[slot2] = cs.travel.size();
@@ -1982,8 +2030,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             PAG_HIP_TRY(hipMemcpyAsync(b_fin.p, hp, tot * 8, hipMemcpyHostToDevice, s));
             trav_launch_gather_path(G, b_fin.as<uint32_t>(), b_fin.as<uint32_t>() + tot, tot, b_gather.as<pag_path_node>(), s);
             PAG_HIP_TRY(hipMemcpyAsync(g->path_store, b_gather.p, tot * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
         }
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (g->deliver_stream) PAG_HIP_TRY(hipStreamSynchronize(g->deliver_stream));  // (the deliveries made during the walks)
     }
     lap("epilogue");
     if (timing) {

@@ -74,6 +74,7 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->path_off.clear();  // (the pinned storage stays)
     g->path_len.clear();
     g->path_valid.clear();
+    g->path_ptr.clear();
 }
 
 __global__ void chunk_counts(const pag_aln *__restrict__ aln, uint64_t n, uint32_t *__restrict__ out) {
@@ -218,6 +219,7 @@ void pag_destroy(pag_graph *g) {
     for (void *q : g->deferred) hipFree(q);
     if (g->wq_host) hipHostFree(g->wq_host);
     if (g->path_store) hipHostFree(g->path_store);
+    if (g->deliver_stream) hipStreamDestroy(g->deliver_stream);
     if (g->pin_host) hipHostFree(g->pin_host);
     for (void *q : g->fetch_chunks) hipHostFree(q);
     g->fetch_chunks.clear();

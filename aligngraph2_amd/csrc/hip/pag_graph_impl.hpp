@@ -54,6 +54,8 @@ struct pag_graph {
     pag_path_node *path_store = nullptr;
     size_t path_cap = 0;
     std::vector<uint64_t> path_off, path_len;
+    hipStream_t deliver_stream = nullptr;  // copies of finished contigs' paths while the walks run (pag_travel)
+    std::vector<const pag_path_node *> path_ptr;  // non-null: the orientation's path, delivered while the walks ran (pinned fetch memory)
     std::vector<uint8_t> path_valid;  // that orientation was traversed by the last pag_travel
     // device arena of the walker's job buffers (bump pointer, reset by every pag_travel)
     void *walk_arena = nullptr;
