@@ -1549,10 +1549,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             if (!hp) return fail(PAG_ENOMEM);
             TravPackDesc *hd = (TravPackDesc *)(hp + ((tot + 3) & ~3ull));
             std::memcpy(hd, descs.data(), descs.size() * sizeof(TravPackDesc));
-            if ((rc = b_fetch.alloc(tot * 4 + 64)) || (rc = b_fdesc.alloc(descs.size() * sizeof(TravPackDesc)))) return fail(rc);
-            hipMemcpyAsync(b_fdesc.p, hd, descs.size() * sizeof(TravPackDesc), hipMemcpyHostToDevice, s);
-            trav_launch_pack_paths(G, b_fdesc.as<TravPackDesc>(), (uint32_t)descs.size(), max_len, b_fetch.as<uint32_t>(), s);
-            if (tot) hipMemcpyAsync(hp, b_fetch.p, tot * 4, hipMemcpyDeviceToHost, s);
+            // the pack kernel reads its descriptors from, and writes the packed paths to, the pinned host memory directly: one
+            // launch + one synchronisation per batch instead of copy + launch + copy + synchronisation (every call of this
+            // thread is on the critical path of some chain)
+            static const bool direct = !(std::getenv("PAG_FETCH_DIRECT") && std::atoi(std::getenv("PAG_FETCH_DIRECT")) == 0);
+            if (direct) {
+                trav_launch_pack_paths(G, hd, (uint32_t)descs.size(), max_len, hp, s);
+            } else {
+                if ((rc = b_fetch.alloc(tot * 4 + 64)) || (rc = b_fdesc.alloc(descs.size() * sizeof(TravPackDesc)))) return fail(rc);
+                hipMemcpyAsync(b_fdesc.p, hd, descs.size() * sizeof(TravPackDesc), hipMemcpyHostToDevice, s);
+                trav_launch_pack_paths(G, b_fdesc.as<TravPackDesc>(), (uint32_t)descs.size(), max_len, b_fetch.as<uint32_t>(), s);
+                if (tot) hipMemcpyAsync(hp, b_fetch.p, tot * 4, hipMemcpyDeviceToHost, s);
+            }
             if (hipStreamSynchronize(s) != hipSuccess) {
                 set_error("pag_travel: stream failure while fetching paths");
                 return fail(PAG_EFAULT);
