@@ -2143,18 +2143,26 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
 // a wave claims the next index from a device counter, waits until that entry is posted, runs it, writes the
 // result record, makes its device-memory writes visible (system release) and raises done[index].
 // A job starts with a system-scope acquire: buffers of the job were prepared by other kernels / copies.
+//
+// FORWARD PROGRESS.  A wave never waits for the host longer than `idle_ticks` (100 MHz clock): a wave that has found no
+// claimable job for that long leaves, and the host starts new waves when it posts work for which too few are left
+// (WalkerGrid, k5_travel_host.hip).  A grid that cannot be resident as a whole — another process has filled the compute
+// units' LDS with walkers of its own — therefore stalls the dispatcher only until running jobs end or idle waves leave,
+// never until a host acts that may itself be queued behind the stalled dispatch.  q->started / q->exited (system scope)
+// tell the host how many waves it has.
 __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done,
-                                                        const TravQueue *q, uint32_t *next, uint32_t cap, uint32_t k,
-                                                        uint64_t idle_timeout) {
+                                                        TravQueue *q, uint32_t *next, uint32_t cap, uint32_t k,
+                                                        uint64_t idle_ticks) {
     __shared__ WalkLds L;
     const uint32_t lane = lane_id();
+    if (lane == 0) __hip_atomic_fetch_add(&q->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // TRAV_RINGS rings of job records, served in order: the jobs a contig's progress waits for (the walk of a seed, a
     // resumed walk) are taken before the segment jobs that only run ahead of it, and those of contigs in a later round
     // before those of the first round (see k5_travel_host.hip).  A wave claims the next job number of a
     // ring with a compare-and-swap on the ring's counter when the host has posted beyond it; slot = ring * cap + number
     // mod cap.  Single-exit scalar loop: every value that steers it is wave-uniform by construction (readfirstlane).
     bool alive = true;
-    uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint64_t t0 = wall_clock64();
     uint32_t naps = 1;
     while (alive) {
         // One relaxed 8-byte read of host memory per poll (posted[0] | posted[1] << 32), polls of an idle wave spaced out up
@@ -2195,10 +2203,10 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(&done[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // same value from every lane
-            t0 = __builtin_amdgcn_s_memtime();
+            t0 = wall_clock64();
             naps = 1;
         } else {
-            if (bye != 0u || __builtin_amdgcn_s_memtime() - t0 > idle_timeout) {  // host done, or host gone
+            if (bye != 0u || wall_clock64() - t0 > idle_ticks) {  // host done, or nothing to do for too long (see above)
                 alive = false;
             } else {
                 for (uint32_t z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(127);
@@ -2206,6 +2214,7 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
             }
         }
     }
+    if (lane == 0) __hip_atomic_fetch_add(&q->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // =================================================================================================
@@ -2542,14 +2551,19 @@ void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, 
                       hipStream_t s) {
     if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k);
 }
-// walker waves (= 64-thread workgroups) that fit one compute unit: by the LDS a wave's window takes
+// walker waves (= 64-thread workgroups) that fit one compute unit: what the runtime's occupancy calculation says for
+// the kernel as built (the LDS a wave's window takes decides), at most 4
 int trav_walk_waves_per_cu() {
-    const size_t n = (160 * 1024) / sizeof(WalkLds);
-    return n >= 4 ? 4 : n >= 1 ? (int)n : 1;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_walk_persistent, 64, 0) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = (int)((160 * 1024) / sizeof(WalkLds));
+    }
+    return n >= 4 ? 4 : n >= 1 ? n : 1;
 }
-void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,
-                                 uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_timeout, hipStream_t s) {
-    k_walk_persistent<<<dim3(n_waves), dim3(64), 0, s>>>(G, jobs, outs, done, q, next, cap, k, idle_timeout);
+void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, TravQueue *q,
+                                 uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_ticks, hipStream_t s) {
+    k_walk_persistent<<<dim3(n_waves), dim3(64), 0, s>>>(G, jobs, outs, done, q, next, cap, k, idle_ticks);
 }
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s) {

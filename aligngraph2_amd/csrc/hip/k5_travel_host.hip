@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "pag_graph_impl.hpp"
+#include "walker_grid.hpp"
 
 using namespace pagdev;
 
@@ -579,13 +580,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         g->wq_bytes = q_need;
     }
     if (!g->wq_next) PAG_HIP_TRY(hipMalloc((void **)&g->wq_next, 256));
-    if (!g->walk_stream) {
-        // the resident grid gets a stream of its own priority class: the runtime multiplexes streams onto a few
-        // hardware queues, and work of this call's side stream must never be queued behind the walker
-        int lo = 0, hi = 0;
-        PAG_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        PAG_HIP_TRY(hipStreamCreateWithPriority(&g->walk_stream, hipStreamNonBlocking, hi));
-    }
     TravQueue *hq = (TravQueue *)g->wq_host;
     TravPosted *hjobs = (TravPosted *)((char *)g->wq_host + 256);
     TravJobOut *houts = (TravJobOut *)(hjobs + NR * (size_t)QCAP);
@@ -757,12 +751,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         return t;
     };
 
-    bool walker_up = false;
+    WalkerGrid walkers;
     auto shutdown_walker = [&]() {
-        if (!walker_up) return;
-        __atomic_store_n(&hq->exit, 1u, __ATOMIC_RELEASE);
-        hipStreamSynchronize(g->walk_stream);
-        walker_up = false;
+        if (!walkers.up) return;
+        walkers.shutdown();
         g->defer_free = false;
         for (void *q : g->deferred) hipFree(q);
         g->deferred.clear();
@@ -938,7 +930,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         PAG_HIP_TRY(hipStreamSynchronize(s));
         for (uint32_t r = NR; r-- > 0;) __atomic_store_n(&hq->posted[r], n_posted[r], __ATOMIC_RELEASE);
         need_publish = false;
-        return PAG_OK;
+        return walkers.g ? walkers.ensure(n_live) : PAG_OK;  // (before the first launch: pag_travel starts the waves itself)
     };
 
     // ---- start of a round of contig i: its seeds are in cs.seeds.  Decides where the walk can be cut, finds the checkpoint
@@ -1376,18 +1368,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         }
     }
     if (n_live) {
-        int n_cu = 256;
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, g->device);
-        trav_launch_walk_persistent(G, hjobs, houts, hdone, hq, g->wq_next, QCAP, k, (uint32_t)std::max(64, n_cu * (std::getenv("PAG_WALK_WAVES_PER_CU") ? std::max(1, std::atoi(std::getenv("PAG_WALK_WAVES_PER_CU"))) : trav_walk_waves_per_cu())),
-                                    (uint64_t)(std::getenv("PAG_WALK_IDLE_S") ? std::atoi(std::getenv("PAG_WALK_IDLE_S")) : 120) * 2400000000ull, g->walk_stream);
-        if (hipGetLastError() != hipSuccess) {
+        walkers.init(g, G, hjobs, houts, hdone, hq, QCAP, k);
+        if ((rc = publish())) return fail(rc);  // (the jobs' buffers are ready, the rings are visible)
+        if ((rc = walkers.ensure(n_live))) {
             g->defer_free = false;
-            set_error("pag_travel: walker launch failed");
-            return PAG_EFAULT;
+            return rc;
         }
-        if (wdebug) std::fprintf(stderr, "[walk] walker launched, %u + %u + %u jobs prepared\n", n_posted[0], n_posted[1], n_posted[2]);
-        walker_up = true;
-        if ((rc = publish())) return fail(rc);
+        if (wdebug) std::fprintf(stderr, "[walk] %u walker waves launched (at most %u), %u + %u + %u jobs posted\n", walkers.launched, walkers.max_waves, n_posted[0], n_posted[1], n_posted[2]);
     } else {
         g->defer_free = false;
     }
@@ -1457,7 +1444,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
 
     DevBuf b_fetch = buf(), b_fdesc = buf();
     uint32_t scan_from[TRAV_RINGS] = {0, 0, 0};  // per ring: every job number below it has been handled
-    double t_progress = now_ms(), t_first_fin = 0, t_query = now_ms();
+    double t_progress = now_ms(), t_first_fin = 0;
     // Waiting for the walker: a busy wait (pause instructions), not a sleep — on a loaded host a 20 us sleep comes back after
     // a millisecond or more, and every finished job that waits for this thread holds up the jobs that depend on it.  Only
     // after 5 ms without any news does the thread start yielding its time slice.
@@ -1502,16 +1489,15 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             t_first_fin = 0;
         }
         if (fin.empty()) {
-            if (now_ms() - t_query > 2.0 && (t_query = now_ms(), hipStreamQuery(g->walk_stream) == hipSuccess)) {  // the grid is gone although jobs are outstanding
-                walker_up = false;
-                set_error("pag_travel: the walker stopped with jobs outstanding");
-                return fail(PAG_EFAULT);
-            }
-            if (now_ms() - t_progress > 60000.0) {  // no job finished for a minute: give up instead of hanging
-                uint32_t ticket = 0;
-                hipMemcpyAsync(&ticket, g->wq_next, 4, hipMemcpyDeviceToHost, s);
+            // waves that found nothing to do have left (k_walk_persistent): jobs that are outstanding get new ones
+            if ((rc = walkers.ensure(n_live))) return fail(rc);
+            static const double idle_limit_ms = (std::getenv("PAG_WALK_IDLE_S") ? std::atof(std::getenv("PAG_WALK_IDLE_S")) : 60.0) * 1000.0;
+            if (now_ms() - t_progress > idle_limit_ms) {  // no job finished for a minute: give up instead of hanging
+                uint32_t ticket[TRAV_RINGS] = {0, 0, 0};
+                hipMemcpyAsync(ticket, g->wq_next, sizeof(ticket), hipMemcpyDeviceToHost, s);
                 hipStreamSynchronize(s);
-                set_error("pag_travel: no walk job finished within 60 s (posted %u + %u + %u, tickets taken %u, jobs outstanding %u)", n_posted[0], n_posted[1], n_posted[2], ticket, n_live);
+                set_error("pag_travel: no walk job finished within %.0f s (posted %u + %u + %u, claimed %u + %u + %u, jobs outstanding %u, walker waves started %u / left %u of %u launched)",
+                          idle_limit_ms / 1000.0, n_posted[0], n_posted[1], n_posted[2], ticket[0], ticket[1], ticket[2], n_live, walkers.started(), walkers.exited(), walkers.launched);
                 return fail(PAG_EFAULT);
             }
             idle_wait(30.0);

@@ -226,7 +226,7 @@ void pag_destroy(pag_graph *g) {
     g->fetch_chunk_bytes.clear();
     if (g->walk_arena) hipFree(g->walk_arena);
     if (g->wq_next) hipFree(g->wq_next);
-    if (g->walk_stream) hipStreamDestroy(g->walk_stream);
+    for (hipStream_t ws : g->walk_streams) hipStreamDestroy(ws);
     if (g->solid_bits) hipFree(g->solid_bits);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;

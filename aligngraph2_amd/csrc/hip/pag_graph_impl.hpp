@@ -43,7 +43,7 @@ struct pag_graph {
     void *wq_host = nullptr;
     size_t wq_bytes = 0;
     uint32_t *wq_next = nullptr;
-    hipStream_t walk_stream = nullptr;
+    std::vector<hipStream_t> walk_streams;  // the walker launches' streams (WalkerGrid, walker_grid.hpp)
     // traversal state (k5_travel_host.hip)
     pagdev::TravGraph tg{};
     bool tg_ready = false;

@@ -133,6 +133,7 @@ constexpr int TRAV_RINGS = 3;
 struct TravQueue {
     uint32_t posted[TRAV_RINGS];  // per ring: job numbers below it are valid (host writes, release); ring 0 is served first
     uint32_t exit;                // host: no further jobs will be posted
+    uint32_t started, exited;     // device: walker waves that have begun / left (system-scope atomics), see k_walk_persistent
 };
 
 struct TravPackDesc {  // one finished job of a fetch batch (k_pack_paths)
@@ -168,8 +169,8 @@ void trav_launch_gather_pc(TravGraph G, const uint32_t *seq_v, uint64_t len, uin
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s);
 int trav_walk_waves_per_cu();
-void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, const TravQueue *q,
-                                 uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_timeout, hipStream_t s);
+void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, TravQueue *q,
+                                 uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_ticks, hipStream_t s);
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s);
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);

@@ -167,6 +167,7 @@ def main():
     one_device = os.environ.get("PAG_BENCH_SINGLE_DEVICE") == "1"
     if one_device:
         local = 0
+        os.environ["PAG_DEVICE_SHARERS"] = str(world)  # (the walker grid is a share of the device, walker_grid.hpp)
     torch.cuda.set_device(local)
     from aligngraph2_amd import parallel
     dist = parallel.init("gloo" if one_device else "nccl")  # RCCL; only the barrier and two 8-byte all-reduces use it

@@ -107,6 +107,48 @@ def test_walker_regrows_its_buffers_and_stays_exact(workdir, monkeypatch):
     goldens.compare_out_dir(name, out)
 
 
+# The walker waves are elastic (walker_grid.hpp): the result must not depend on how many of them the device carries, on
+# waves leaving for lack of work and being replaced, or on a grid larger than the device can hold at once.
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", ["8-waves", "1-wave", "leave-at-once", "oversubscribed"])
+@pytest.mark.parametrize("name", goldens.case_names()[:3])
+def test_walks_do_not_depend_on_the_walker_grid(name, grid, workdir):
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / name / "in"))
+    out = str(workdir / name / ("out_grid_" + grid))
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    env = dict(os.environ, PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200")
+    env.update({"8-waves": {"PAG_WALK_WAVES": "8"}, "1-wave": {"PAG_WALK_WAVES": "1"},
+                "leave-at-once": {"PAG_WALK_WAVES": "16", "PAG_WALK_IDLE_US": "1"},     # every idle wave leaves: constant relaunching
+                "oversubscribed": {"PAG_WALK_WAVES_PER_CU": "8"}}[grid])                # twice what the LDS lets be resident
+    r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    goldens.compare_out_dir(name, out)
+
+
+@pytest.mark.gpu
+def test_two_pagraph_processes_share_the_device(workdir):
+    """Two drop-in processes at the same time on ONE GPU, each wanting a full grid of walkers (the LDS of every compute unit):
+    both must finish, with the goldens' outputs (the caller of AlignGraph2.py may run several pipelines on a node)."""
+    names = goldens.case_names()[:2]
+    procs = []
+    inputs = {name: goldens.materialize_inputs(name, str(workdir / "share" / name / "in")) for name in names}
+    for rep in range(3):
+        for name in names:
+            spec = goldens.load_spec(name)
+            ind = inputs[name]
+            out = str(workdir / "share" / f"{name}_{rep}")
+            os.makedirs(out, exist_ok=True)
+            argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+            env = dict(os.environ, PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200", PAG_WALK_IDLE_S="20")
+            procs.append((name, out, subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)))
+    for name, out, pr in procs:
+        so, se = pr.communicate(timeout=300)
+        assert pr.returncode == 0, se[-2000:] + so[-2000:]
+        goldens.compare_out_dir(name, out)
+
+
 @pytest.mark.gpu
 def test_config_blocks_dealt_out_over_processes_equal_the_golden(workdir):
     """PAGRAPH_BLOCKS: the blocks of one config.txt processed by different bin/pagraph processes (what parallel.
