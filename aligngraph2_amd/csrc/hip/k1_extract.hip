@@ -26,13 +26,20 @@ namespace pagdev {
 constexpr int TILE = 1024;  // read positions per tile: 64 lanes x 16
 constexpr int CHUNK = 1024; // alignment columns per colidx chunk: 64 lanes x 16
 
+// Kept samples are at least `outer` positions apart (sampleSequence), so a tile of 1024 positions holds at most
+// ceil(1024 / outer) of them: with the pipeline's outer = 3 (pagraph.cpp:113) the per-sample arrays need 342 entries, not
+// 1024 — 4.6 KB of LDS per wave instead of 12.5 KB, which is what decides how many waves a compute unit carries (the
+// kernel is bound by its chain of LDS round trips and gathers per tile, not by bandwidth: 12 waves per unit before,
+// as many as the registers allow now).  MAXS = 1024 is the build for outer < 3.
+template <int MAXS>
 struct WaveLds {
     uint32_t kept[64];   // per lane-slot: 16-bit mask of kept positions
     uint32_t rank[64];   // per lane-slot: tile-local rank of its first kept sample
-    uint32_t scode[TILE]; // per tile-local sample: k-mer code
-    uint32_t scnt[TILE];  // per sample: tuple count, then exclusive offset inside the tile
-    uint32_t srun[TILE];  // per sample: tuples written so far
+    uint32_t scode[MAXS]; // per tile-local sample: k-mer code
+    uint32_t scnt[MAXS];  // per sample: tuple count, then exclusive offset inside the tile
+    uint32_t srun[MAXS];  // per sample: tuples written so far
 };
+constexpr int MAXS_SPACED = 352;  // >= ceil(1024 / 3), a multiple of 16
 
 // ---------------------------------------------------------------------------------------------
 // column index: for every alignment, per 1024-column chunk in WALK order, the number of emitting
@@ -240,9 +247,9 @@ __device__ __forceinline__ uint32_t tab_compose(uint32_t first, uint32_t then, u
     return out;
 }
 
-template <bool EMIT>
+template <bool EMIT, int MAXS>
 __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
-    __shared__ WaveLds L;
+    __shared__ WaveLds<MAXS> L;
     const uint32_t job = blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t r = A.emit_order[job >> 1];
@@ -446,20 +453,21 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
                 });
                 __syncthreads();
             });
-            // exclusive scan of scnt over the tile's samples (16 per lane)
+            // exclusive scan of scnt over the tile's samples (PER per lane)
             {
-                uint32_t loc[16], sum = 0;
+                constexpr int PER = MAXS / 64 + (MAXS % 64 ? 1 : 0);
+                uint32_t loc[PER], sum = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    uint32_t idx = lane * 16 + i;
+                for (int i = 0; i < PER; ++i) {
+                    uint32_t idx = lane * PER + i;
                     loc[i] = idx < tile_samples ? L.scnt[idx] : 0u;
                     sum += loc[i];
                 }
                 uint32_t ex = wave_excl_sum(sum, &tile_tuples);
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    uint32_t idx = lane * 16 + i;
+                for (int i = 0; i < PER; ++i) {
+                    uint32_t idx = lane * PER + i;
                     if (idx < tile_samples) L.scnt[idx] = ex;
                     ex += loc[i];
                 }
@@ -513,8 +521,13 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
 int launch_extract(const ExtractArgs &a, bool emit, hipStream_t s) {
     if (a.n_reads == 0) return PAG_OK;
     dim3 grid(2u * a.n_reads), block(64);
-    if (emit) extract_kernel<true><<<grid, block, 0, s>>>(a);
-    else extract_kernel<false><<<grid, block, 0, s>>>(a);
+    if (a.outer >= 3) {
+        if (emit) extract_kernel<true, MAXS_SPACED><<<grid, block, 0, s>>>(a);
+        else extract_kernel<false, MAXS_SPACED><<<grid, block, 0, s>>>(a);
+    } else {
+        if (emit) extract_kernel<true, TILE><<<grid, block, 0, s>>>(a);
+        else extract_kernel<false, TILE><<<grid, block, 0, s>>>(a);
+    }
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
