@@ -69,7 +69,12 @@ $(B)/pag_oracle.o: oracle/pag_oracle.c oracle/pag_oracle.h include/pagraph_hip.h
 	@mkdir -p $(B)
 	$(CC) -O2 -std=c99 -Wall -Wextra -fPIC -Iinclude -c $< -o $@
 
-HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS))
+# (the host restatement of the preparation stage is test infrastructure too: the product prepares on the device)
+$(B)/graph_input.o: tests/harness/graph_input.cpp tests/harness/graph_input.hpp $(wildcard $(HOST_DIR)/*.hpp)
+	@mkdir -p $(B)
+	$(CXX) $(CXXFLAGS) -Itests/harness -c $< -o $@
+
+HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS)) $(B)/graph_input.o
 HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle \
            tests/harness/bin/seg_kernels_test tests/harness/bin/sort_bench tests/harness/bin/libpagh_walk_test.so
 harness: $(HARNESS)
@@ -86,11 +91,11 @@ tests/harness/bin/sort_bench: tests/harness/sort_bench.hip $(HIP_DIR)/k2_sort.hi
 
 tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
 	@mkdir -p tests/harness/bin
-	$(CXX) $(CXXFLAGS) -Ioracle -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o -lm -pthread
+	$(CXX) $(CXXFLAGS) -Ioracle -Itests/harness -o $@ $< $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o -lm -pthread
 
 tests/harness/bin/libpagh_test.so: tests/harness/pagh_test.cpp $(HOST_NOHIP_OBJS)
 	@mkdir -p tests/harness/bin
-	$(CXX) $(CXXFLAGS) -shared -o $@ $< $(HOST_NOHIP_OBJS) -pthread
+	$(CXX) $(CXXFLAGS) -Itests/harness -shared -o $@ $< $(HOST_NOHIP_OBJS) -pthread
 
 # host restatement of the reference's traversal: test infrastructure, linked into harness programs only
 $(B)/host_walk.o: tests/harness/host_walk.cpp tests/harness/host_walk.hpp $(wildcard $(HOST_DIR)/*.hpp)

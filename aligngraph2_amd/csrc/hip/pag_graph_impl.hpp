@@ -32,7 +32,7 @@ struct pag_graph {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Slot pool[128];
+    Slot pool[192];
     // per-contig walker buffers (k5_travel_host.hip), grown on demand like the slots above
     std::vector<Slot> cpool;
     // while the persistent walker is resident nothing may be hipFree'd (it synchronises the device): replaced
@@ -108,7 +108,7 @@ struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_dest
 };
 
 
-// slot numbers 0..63 belong to pag_process (pag_api.hip), 64.. to the traversal
+// slot numbers 0..63 belong to pag_process (pag_api.hip), 64..127 to the traversal, 128.. to pag_prepare (k_prepare.hip)
 enum { TRAV_SLOT0 = 64 };
 
 }  // namespace pagdev

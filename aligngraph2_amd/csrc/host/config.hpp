@@ -7,7 +7,7 @@
 #include <string>
 #include <vector>
 
-#include "graph_input.hpp"
+#include "raw_input.hpp"
 
 namespace pagh {
 

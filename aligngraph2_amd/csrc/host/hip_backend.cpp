@@ -22,6 +22,7 @@ public:
     std::uint64_t solidCount() override { return pag_solid_count(g_); }
     void reset() override { check(pag_reset(g_), "pag_reset"); }
     void reserveForContigs(std::uint64_t bases) override { check(pag_reserve_walk_arena(g_, bases), "pag_reserve_walk_arena"); }
+    void prepare(const RawInput &raw, pag_build_input &out) override { check(pag_prepare(g_, &raw.view(), &out), "pag_prepare"); }
     void process(const pag_build_input &in, pag_build_stats &stats) override { check(pag_process(g_, &in, &stats), "pag_process"); }
     void exportCsr(HostGraph &out) override {
         std::uint64_t nn = 0, np = 0, ne = 0;

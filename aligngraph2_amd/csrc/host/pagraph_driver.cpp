@@ -17,7 +17,7 @@
 #include "aln_db.hpp"
 #include "assembly.hpp"
 #include "config.hpp"
-#include "graph_input.hpp"
+#include "raw_input.hpp"
 #include "kmer_file.hpp"
 #include "path_graph.hpp"
 #include "seq_db.hpp"
@@ -235,14 +235,17 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             if (reserveError) std::rethrow_exception(reserveError);
             lap("load block inputs");
             std::cout << "Pre Process" << std::endl;
-            GraphInput input(reads, contigs, refs, readToCtg, readToRef, ctgToRef, cfg, params);
+            RawInput raw(reads, contigs, refs, readToCtg, readToRef, ctgToRef, cfg, params);
+            pag_build_input input{};
+            backend.prepare(raw, input);
+            const PositionMapper ctgMapper(contigs), refMapper(refs);
             std::set<std::pair<std::string, bool>> usedCtg;
             for (auto &c : cfg.contigs) usedCtg.emplace(c);
 
-            lap("GraphInput (preProcess)");
+            lap("prepare (lists, filters, contig->reference map)");
             std::cout << "[PositionProcessor] Running read to contig..." << std::endl;
             pag_build_stats st{};
-            backend.process(input.view(), st);
+            backend.process(input, st);
             std::cout << "\n\tmerge edge = " << st.merge_edge[0] << "\n\ttotal pos = " << st.total_pos[0]
                       << "\n\tmerge pos = " << st.merge_pos[0] << "\n\n\n\tmerge edge = " << st.merge_edge[1]
                       << "\n\ttotal pos = " << st.total_pos[1] << "\n\tmerge pos = " << st.merge_pos[1] << std::endl;
@@ -256,13 +259,13 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 tp.error_rate = errorRate;
                 tp.start_split = startSplit;
                 tp.min_len = opt.minLen;
-                GraphBackend::TravelContext ctx{contigs, refs, input.ctgMapper(), input.refMapper(), usedCtg,
+                GraphBackend::TravelContext ctx{contigs, refs, ctgMapper, refMapper, usedCtg,
                                                 static_cast<unsigned>(kmers.k())};
                 backend.travel(ctx, tp, graph, precomputed);
                 lap("traversal");
             }
-            auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, input.ctgMapper(),
-                                       input.refMapper(), usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
+            auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, ctgMapper,
+                                       refMapper, usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
                                        opt.threads, 0, nullptr, false, precomputed);
             lap("traverse + write");
             ++blockNo;

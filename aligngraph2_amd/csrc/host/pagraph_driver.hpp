@@ -14,6 +14,7 @@
 #include "host_graph.hpp"
 #include "pagraph_hip.h"
 #include "position_mapper.hpp"
+#include "raw_input.hpp"
 #include "seq_db.hpp"
 #include "traversal.hpp"
 
@@ -29,6 +30,9 @@ public:
     virtual void reset() = 0;
     // optional: get ready for traversals over contigs of that many bases in total (may run beside the input parsing)
     virtual void reserveForContigs(std::uint64_t /*bases*/) {}
+    // the bookkeeping around the two passes (per-query lists, filters, flips, contig->reference map): the product backend
+    // runs it on the device (pag_prepare) and returns a device-resident input; valid until the next prepare()
+    virtual void prepare(const RawInput &raw, pag_build_input &out) = 0;
     virtual void process(const pag_build_input &in, pag_build_stats &stats) = 0;
     virtual void exportCsr(HostGraph &out) = 0;
     // PAlgorithm::travelSequence for every (contig, orientation) of ctgSet (PAssembly.cpp:30-36): fills `graph` with (at

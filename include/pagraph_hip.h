@@ -176,6 +176,47 @@ int pag_reset(pag_graph *g);
 /* PositionProcessor::process (PositionProcessor.cpp:79-151): both extraction passes, mergeEdge,
  * mergeKmerPosition, sortKmerPosition — as one device pipeline. */
 int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats);
+/* ---- the bookkeeping around the two passes, on the device ---------------------------------------
+ * Aligner::mergeAlignInfHelper (PAGraph/src/tools/align/Aligner.cpp:32-56: per-query lists, std::sort by score), the static
+ * filters and flipPosition at the top of parseToCtg / parseToRef (Aligner.tcc:40-71, 121-152), Aligner::simpleAlign with
+ * AlignReference::insert / addExtraPosition (Aligner.cpp:97-202, AlignReference.cpp:41-79), the PositionMapper tables
+ * (PositionMapper.cpp:16-42) and the emission order — from alignment records AS THE PARSER LEAVES THEM (names resolved to
+ * sequence indices).  pag_prepare fills a DEVICE-resident pag_build_input whose arrays belong to the handle (valid until the
+ * next pag_prepare / pag_destroy); pag_process takes it as it is. */
+typedef struct pag_raw_aln {
+    uint32_t query;  /* index of the query sequence (a read; a contig in the contig->reference database), PAG_NONE: unknown name */
+    uint32_t target; /* index of the target sequence (contig / reference), PAG_NONE: unknown name */
+    uint64_t score;  /* read databases: header column 4; contig->reference: qEnd - qBegin (MummerAlignDatabaseV2.cpp:38) */
+    uint64_t q_begin, q_end, t_begin, t_end; /* header intervals (half-open, forward strand of the query / target) */
+    uint64_t diff_off;                       /* first 32-bit word of the record's column classes in pag_raw_db.diff */
+    uint32_t n_cols, n_emit, n_radv;         /* columns; columns that emit a query base; columns that advance the target */
+    uint32_t forward;                        /* header strand column: 1 = F */
+} pag_raw_aln;
+typedef struct pag_raw_db {
+    uint64_t n;
+    const pag_raw_aln *rec; /* HOST memory, database order (AlnDb: sorted by score as the reference's databases are) */
+    const uint32_t *diff;   /* column classes, 2 bits per column (host or device, pag_raw_input.bulk_on_device) */
+    uint64_t n_diff_words;
+} pag_raw_db;
+typedef struct pag_raw_input {
+    uint32_t bulk_on_device; /* where the bulk arrays live: reads.byte_off / len / packed and the three diff arrays */
+    uint32_t n_threads;      /* the reference's -t: emission order (thread-major strided) */
+    pag_seqs reads;
+    pag_raw_db read_to_ctg, read_to_ref, ctg_to_ref;
+    uint64_t n_ctgs;             /* ALL contigs of the -c file (the coordinate space is laid out over all of them) */
+    const uint32_t *ctg_len;     /* host */
+    const uint8_t *ctg_selected; /* host: listed in the config block (Aligner::_ctgFilterFlag) */
+    const uint8_t *ctg_forward;  /* host: orientation the block lists it with */
+    uint64_t n_refs;
+    const uint32_t *ref_len;     /* host */
+    const uint8_t *ref_accepted; /* host: the block's reference sequence (Aligner::_refFilterFlag) */
+    double read_to_ctg_ratio, read_to_ref_ratio; /* 0.35 / 0.10 (pagraph.cpp:118-121) */
+    uint32_t eps, cov_filter, outer_sample;
+    int32_t topk_ctg, topk_ref;
+    uint32_t reserved;
+} pag_raw_input;
+int pag_prepare(pag_graph *g, const pag_raw_input *raw, pag_build_input *out);
+
 /* ---- one graph built by several GPUs (SURVEY §8e level 2) ------------------------------------------------------
  * The reference keeps all graph state per k-mer (node/KMerAdjNode.hpp:19-23; PABruijnGraph::mergeKmerPosition /
  * mergeEdge loop over the k-mers, PABruijnGraph.cpp:259-297) and extracts read by read (PositionProcessor.cpp:86-124),

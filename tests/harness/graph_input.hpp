@@ -1,5 +1,7 @@
-// Builds the flat, device-friendly description of one config block (one reference sequence) that
-// the C ABI consumes (include/pagraph_hip.h: pag_build_input).
+// tests/harness/graph_input.hpp — TEST HARNESS (never part of the product).
+// The HOST restatement of the preparation stage: builds the flat description of one config block (pag_build_input) that
+// the product's device stage (pag_prepare, csrc/hip/k_prepare.hip) produces in HBM.  The tests compare the two array by
+// array; the oracle-backed harness programs (no GPU) run on this one.
 //
 // This is the host half of what the reference does around its two hot loops: per-query alignment
 // lists in score order (Aligner::mergeAlignInfHelper, PAGraph/src/tools/align/Aligner.cpp:32-56),
@@ -16,26 +18,10 @@
 #include "aln_db.hpp"
 #include "pagraph_hip.h"
 #include "position_mapper.hpp"
+#include "raw_input.hpp"
 #include "seq_db.hpp"
 
 namespace pagh {
-
-struct BlockConfig {  // one block of config.txt (reference pagraph.cpp:21-49)
-    std::string ref;
-    std::vector<std::pair<std::string, bool>> contigs;  // (name, forward)
-    std::string readPath, ctgAlnPath, refAlnPath;
-};
-
-struct BuildParams {  // hard-coded in the reference main (pagraph.cpp:110-125)
-    unsigned threads = 16;
-    std::size_t epsilon = 10;
-    std::size_t covFilter = 1;
-    int outerSample = 3;
-    int readToCtgTopK = -1;
-    int readToRefTopK = -1;
-    double readToCtgRatio = 0.35;
-    double readToRefRatio = 0.10;
-};
 
 class GraphInput {
 public:

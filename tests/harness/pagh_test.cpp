@@ -18,7 +18,10 @@ struct Loaded {
     std::unique_ptr<pagh::KmerFile> kmers;
     std::unique_ptr<pagh::SeqDb> reads, ctgs, refs;
     std::unique_ptr<pagh::AlnDb> readToCtg, readToRef, ctgToRef;
-    std::unique_ptr<pagh::GraphInput> input;
+    std::unique_ptr<pagh::GraphInput> input;   // the host restatement of the preparation stage (checker)
+    pagh::BlockConfig cfg;
+    pagh::BuildParams params;
+    std::unique_ptr<pagh::RawInput> raw;       // what the product hands to pag_prepare
 };
 }  // namespace
 
@@ -42,8 +45,12 @@ void *pagh_load(const char *dir, unsigned block, unsigned threads, uint64_t eps,
         p.threads = threads;
         p.epsilon = eps;
         p.covFilter = cov;
+        L->cfg = b;
+        L->params = p;
         L->input = std::make_unique<pagh::GraphInput>(*L->reads, *L->ctgs, *L->refs, *L->readToCtg, *L->readToRef,
-                                                      *L->ctgToRef, b, p);
+                                                      *L->ctgToRef, L->cfg, L->params);
+        L->raw = std::make_unique<pagh::RawInput>(*L->reads, *L->ctgs, *L->refs, *L->readToCtg, *L->readToRef, *L->ctgToRef, L->cfg,
+                                                  L->params);
         return L.release();
     } catch (const std::exception &e) {
         std::fprintf(stderr, "pagh_load: %s\n", e.what());
@@ -52,6 +59,7 @@ void *pagh_load(const char *dir, unsigned block, unsigned threads, uint64_t eps,
 }
 
 const pag_build_input *pagh_view(void *h) { return &static_cast<Loaded *>(h)->input->view(); }
+const pag_raw_input *pagh_raw_view(void *h) { return &static_cast<Loaded *>(h)->raw->view(); }
 
 const uint64_t *pagh_kmer_words(void *h, uint64_t *n, uint64_t *k) {
     auto *L = static_cast<Loaded *>(h);

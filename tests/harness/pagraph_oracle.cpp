@@ -4,6 +4,9 @@
 // against the reference's golden outputs on a machine without a GPU.
 #include <stdexcept>
 
+#include <memory>
+
+#include "graph_input.hpp"
 #include "host_walk.hpp"
 #include "pag_oracle.h"
 #include "pagraph_driver.hpp"
@@ -16,6 +19,11 @@ public:
     void create(const std::uint64_t *words, std::size_t nWords, unsigned k) override { g_ = pago_create(words, nWords, k); }
     std::uint64_t solidCount() override { return pago_solid_count(g_); }
     void reset() override { pago_reset(g_); }
+    // the host restatement of the preparation stage (tests/harness/graph_input.cpp)
+    void prepare(const pagh::RawInput &raw, pag_build_input &out) override {
+        input_ = std::make_unique<pagh::GraphInput>(raw.reads, raw.ctgs, raw.refs, raw.readToCtg, raw.readToRef, raw.ctgToRef, raw.cfg, raw.params);
+        out = input_->view();
+    }
     void process(const pag_build_input &in, pag_build_stats &stats) override {
         if (pago_process(g_, &in, &stats) != PAG_OK) throw std::runtime_error("pago_process failed");
     }
@@ -38,6 +46,7 @@ public:
 
 private:
     pago_graph *g_ = nullptr;
+    std::unique_ptr<pagh::GraphInput> input_;
 };
 }  // namespace
 

@@ -106,6 +106,8 @@ def test_lib():
         lib.pagh_load.restype = C.c_void_p
         lib.pagh_view.argtypes = [C.c_void_p]
         lib.pagh_view.restype = C.c_void_p
+        lib.pagh_raw_view.argtypes = [C.c_void_p]
+        lib.pagh_raw_view.restype = C.c_void_p
         lib.pagh_kmer_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.pagh_kmer_words.restype = C.c_void_p
         lib.pagh_total_read_bases.argtypes = [C.c_void_p]
@@ -135,7 +137,8 @@ class LoadedInput:
         self.h = self.lib.pagh_load(in_dir.encode(), block, threads, eps, cov)
         if not self.h:
             raise RuntimeError(f"pagh_load failed for {in_dir}")
-        self.view = self.lib.pagh_view(self.h)
+        self.view = self.lib.pagh_view(self.h)          # the HOST restatement of the preparation stage (checker)
+        self.raw_view = self.lib.pagh_raw_view(self.h)  # what the product hands to pag_prepare
         n, k = C.c_uint64(), C.c_uint64()
         self.kmer_words = self.lib.pagh_kmer_words(self.h, C.byref(n), C.byref(k))
         self.n_kmer_words, self.k = n.value, k.value
@@ -147,9 +150,33 @@ class LoadedInput:
             self.h = None
 
 
-def _run(lib, prefix, g, inp: LoadedInput, streams: bool):
+def _prepared_view(lib, g, inp: LoadedInput):
+    """pag_prepare: the product's device-side preparation of the block -> a device-resident pag_build_input"""
+    import biggen
+    out = biggen.PagBuildInput()
+    lib.pag_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib.pag_prepare(g, inp.raw_view, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"pag_prepare failed rc={rc} {lib.pag_last_error().decode()}")
+    return out
+
+
+def device_bytes(ptr, n):
+    """n bytes of device memory as a numpy array (through torch's HIP runtime)"""
+    import torch
+    rt = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    buf = np.empty(n, dtype=np.uint8)
+    if n:
+        rc = rt.hipMemcpy(buf.ctypes.data, ptr, n, 2)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy failed ({rc})")
+    return buf
+
+
+def _run(lib, prefix, g, inp: LoadedInput, streams: bool, prepared=None):
     st = BuildStats()
-    rc = getattr(lib, prefix + "_process")(g, inp.view, C.byref(st))
+    rc = getattr(lib, prefix + "_process")(g, C.byref(prepared) if prepared is not None else inp.view, C.byref(st))
     if rc != 0:
         msg = lib.pag_last_error().decode() if prefix == "pag" else ""
         raise RuntimeError(f"{prefix}_process failed rc={rc} {msg}")
@@ -189,7 +216,9 @@ def run_oracle(inp: LoadedInput, streams: bool = False):
         lib.pago_destroy(g)
 
 
-def run_hip(inp: LoadedInput, streams: bool = False, device: int = 0):
+def run_hip(inp: LoadedInput, streams: bool = False, device: int = 0, prepare: bool = True):
+    """The product path: pag_prepare (device) -> pag_process.  prepare=False feeds pag_process the host restatement's
+    arrays instead (the path the C ABI also accepts: host-resident pag_build_input)."""
     lib = hip_lib()
     if streams:
         os.environ["PAG_DEBUG_KEEP_STREAMS"] = "1"
@@ -200,7 +229,7 @@ def run_hip(inp: LoadedInput, streams: bool = False, device: int = 0):
     if not g:
         raise RuntimeError(f"pag_create failed rc={err.value}: {lib.pag_last_error().decode()}")
     try:
-        return _run(lib, "pag", g, inp, streams)
+        return _run(lib, "pag", g, inp, streams, _prepared_view(lib, g, inp) if prepare else None)
     finally:
         lib.pag_destroy(g)
 
