@@ -29,6 +29,9 @@ ALN_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("t_begin", "<u4"), (
 CTG_DTYPE = np.dtype([("len", "<u4"), ("selected", "<u4"), ("single_base", "<u4"), ("multi", "<u4"), ("map_off", "<u8")])
 REF_DTYPE = np.dtype([("len", "<u4"), ("accepted", "<u4"), ("single_base", "<u4"), ("reserved", "<u4")])
 FLAG_REV, FLAG_BACK, FLAG_ELIG = 1, 2, 4
+# pag_raw_aln (include/pagraph_hip.h): an ALN record as the parser leaves it, names resolved to indices
+RAW_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("score", "<u8"), ("q_begin", "<u8"), ("q_end", "<u8"), ("t_begin", "<u8"),
+                      ("t_end", "<u8"), ("diff_off", "<u8"), ("n_cols", "<u4"), ("n_emit", "<u4"), ("n_radv", "<u4"), ("forward", "<u4")])
 
 
 class PagSeqs(C.Structure):
@@ -46,6 +49,19 @@ class PagBuildInput(C.Structure):
                 ("read_to_ctg", PagAlnDb), ("read_to_ref", PagAlnDb), ("n_ctgs", C.c_uint64), ("ctgs", C.c_void_p),
                 ("ctg_ent_off", C.c_void_p), ("n_ctg_ent_off", C.c_uint64), ("ctg_ent", C.c_void_p),
                 ("n_ctg_ent", C.c_uint64), ("n_refs", C.c_uint64), ("refs", C.c_void_p), ("eps", C.c_uint32),
+                ("cov_filter", C.c_uint32), ("outer_sample", C.c_uint32), ("topk_ctg", C.c_int32), ("topk_ref", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
+class PagRawDb(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("rec", C.c_void_p), ("diff", C.c_void_p), ("n_diff_words", C.c_uint64)]
+
+
+class PagRawInput(C.Structure):
+    _fields_ = [("bulk_on_device", C.c_uint32), ("n_threads", C.c_uint32), ("reads", PagSeqs), ("read_to_ctg", PagRawDb),
+                ("read_to_ref", PagRawDb), ("ctg_to_ref", PagRawDb), ("n_ctgs", C.c_uint64), ("ctg_len", C.c_void_p),
+                ("ctg_selected", C.c_void_p), ("ctg_forward", C.c_void_p), ("n_refs", C.c_uint64), ("ref_len", C.c_void_p),
+                ("ref_accepted", C.c_void_p), ("read_to_ctg_ratio", C.c_double), ("read_to_ref_ratio", C.c_double), ("eps", C.c_uint32),
                 ("cov_filter", C.c_uint32), ("outer_sample", C.c_uint32), ("topk_ctg", C.c_int32), ("topk_ref", C.c_int32),
                 ("reserved", C.c_uint32)]
 
@@ -387,12 +403,15 @@ class BigWorkload:
             arr = np.zeros(na, dtype=ALN_DTYPE)
             for kk in ("query", "target", "t_begin", "t_end", "q_start", "t_start", "n_cols", "n_valid", "diff_off", "flags"):
                 arr[kk] = f[kk].cpu().numpy()
+            self._scores.append(f["score"].cpu().numpy().astype(np.uint64))
             qoff = torch.searchsorted(f["query"].contiguous(), torch.arange(n + 1, device=dev)).to(torch.int64)
             diff = torch.cat(diff_chunks + [torch.zeros(8, dtype=torch.int32, device=dev)]) if diff_chunks else torch.zeros(8, dtype=torch.int32, device=dev)
             return arr, qoff, diff
 
+        self._scores = []
         self.aln1, self.qoff1, self.diff1 = finish_db(rec1, diff1_chunks)
         self.aln2, self.qoff2, self.diff2 = finish_db(rec2, diff2_chunks)
+        self.score1, self.score2 = self._scores
 
         # contig table + contig->ref map (AlignReference: one entry per contig base = the reference cursor at that base,
         # both orientations alike)
@@ -499,6 +518,119 @@ class BigWorkload:
         inp.topk_ctg = -1
         inp.topk_ref = -1
         return inp
+
+    # ------------------------------------------------------------------ C-ABI view: records as the PARSER leaves them
+    def raw_input(self) -> PagRawInput:
+        """The block the way bin/pagraph's parsers hand it to pag_prepare (include/pagraph_hip.h): alignment records with
+        their HEADER fields (what write_text puts on the header lines: intervals on the forward strands, the strand column,
+        the score), in database order = by score, descending (AlnDb::sortByScore); contig / reference tables; the bulk
+        arrays (packed reads, column classes) stay where they are (HBM).  The eligibility tests, flips, n_valid, the
+        per-read lists and the contig->reference map are the device stage's work."""
+        sp = self.spec
+        dev = self.dev
+        keep = {}
+
+        def class_counts(diff, arr):
+            # per record: columns of class 1 (target only) and class 2 (query only); padding columns are class 0
+            w = diff.to(torch.int64) & 0xFFFFFFFF
+            lo, hi = w & 0x55555555, (w >> 1) & 0x55555555
+            c1 = lo & ~hi & 0x55555555
+            c2 = hi & ~lo & 0x55555555
+
+            def popc(x):
+                x = x - ((x >> 1) & 0x55555555)
+                x = (x & 0x33333333) + ((x >> 2) & 0x33333333)
+                x = (x + (x >> 4)) & 0x0F0F0F0F
+                return (x * 0x01010101 >> 24) & 0xFF
+            z = torch.zeros(1, dtype=torch.int64, device=diff.device)
+            s1 = torch.cat([z, torch.cumsum(popc(c1), 0)])
+            s2 = torch.cat([z, torch.cumsum(popc(c2), 0)])
+            off = torch.from_numpy(arr["diff_off"].astype(np.int64)).to(diff.device)
+            nw = torch.from_numpy(((arr["n_cols"].astype(np.int64) + 15) // 16)).to(diff.device)
+            return (s1[off + nw] - s1[off]).cpu().numpy(), (s2[off + nw] - s2[off]).cpu().numpy()
+
+        rlen = self.read_len.cpu().numpy().astype(np.int64)
+
+        def raw_db(arr, diff, tlen_of, scores):
+            n = len(arr)
+            raw = np.zeros(n, dtype=RAW_DTYPE)
+            k1, k2 = class_counts(diff, arr) if n else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+            ncol = arr["n_cols"].astype(np.int64)
+            n_emit, n_radv = ncol - k1, ncol - k2
+            rev = (arr["flags"] & FLAG_REV) != 0
+            back = (arr["flags"] & FLAG_BACK) != 0
+            qs, ts = arr["q_start"].astype(np.int64), arr["t_start"].astype(np.int64)
+            nrd = rlen[arr["query"]]
+            tlen = tlen_of(arr)
+            raw["query"], raw["target"] = arr["query"], arr["target"]
+            raw["score"] = scores
+            raw["q_begin"] = np.where(rev, nrd - (qs + n_emit), qs)
+            raw["q_end"] = np.where(rev, nrd - qs, qs + n_emit)
+            raw["t_begin"] = np.where(back, tlen - (ts + n_radv), ts)
+            raw["t_end"] = np.where(back, tlen - ts, ts + n_radv)
+            raw["forward"] = np.where(back, rev, ~rev)
+            raw["diff_off"], raw["n_cols"], raw["n_emit"], raw["n_radv"] = arr["diff_off"], ncol, n_emit, n_radv
+            order = np.argsort(-scores.astype(np.int64), kind="stable")  # the database is sorted by score
+            raw = np.ascontiguousarray(raw[order])
+            keep[id(raw)] = raw
+            return PagRawDb(n, raw.ctypes.data, diff.data_ptr(), diff.numel()), raw
+
+        clen = np.array([e - s for s, e, _ in self.ctgs], dtype=np.int64)
+        db1, self.raw1 = raw_db(self.aln1, self.diff1, lambda a: clen[a["target"]], self.score1)
+        db2, self.raw2 = raw_db(self.aln2, self.diff2, lambda a: np.full(len(a), len(self.ref), np.int64), self.score2)
+        # contig -> reference: one record per contig (write_text's `aln` file), score = qEnd - qBegin
+        ctg_diff, ctg_raw = self._ctg_to_ref_db()
+        keep["ctg_diff"] = ctg_diff
+        db3 = PagRawDb(len(ctg_raw), ctg_raw.ctypes.data, ctg_diff.data_ptr(), ctg_diff.numel())
+        inp = PagRawInput()
+        inp.bulk_on_device = 1 if dev.type == "cuda" else 0
+        inp.n_threads = sp.threads
+        inp.reads = PagSeqs(sp.n_reads, self.read_byte_off.data_ptr(), self.read_len.data_ptr(), self.packed.data_ptr(), self.packed.numel())
+        inp.read_to_ctg, inp.read_to_ref, inp.ctg_to_ref = db1, db2, db3
+        t_clen = clen.astype(np.uint32)
+        t_sel = np.ones(len(clen), np.uint8)
+        t_fwd = np.array([0 if r else 1 for _, _, r in self.ctgs], np.uint8)
+        t_rlen = np.array([len(self.ref)], np.uint32)
+        t_racc = np.ones(1, np.uint8)
+        keep.update(tables=(t_clen, t_sel, t_fwd, t_rlen, t_racc, ctg_raw))
+        inp.n_ctgs, inp.ctg_len, inp.ctg_selected, inp.ctg_forward = len(clen), t_clen.ctypes.data, t_sel.ctypes.data, t_fwd.ctypes.data
+        inp.n_refs, inp.ref_len, inp.ref_accepted = 1, t_rlen.ctypes.data, t_racc.ctypes.data
+        inp.read_to_ctg_ratio, inp.read_to_ref_ratio = 0.35, 0.10
+        inp.eps, inp.cov_filter, inp.outer_sample, inp.topk_ctg, inp.topk_ref = sp.eps, sp.cov, 3, -1, -1
+        self._raw_keep = keep
+        return inp
+
+    def _ctg_to_ref_db(self):
+        """the contig->reference alignments of write_text as column classes + raw records (built on the device)"""
+        dev = self.dev
+        G = len(self.ref)
+        words, recs, cursor = [], np.zeros(len(self.ctgs), dtype=RAW_DTYPE), 0
+        for c, (s, e, r) in enumerate(self.ctgs):
+            seg = self.tgt[s:e]
+            rd = self.g_rdel[s:e].clone().to(torch.int64)
+            rd[0] = 0
+            ncol = rd + 1
+            col0 = torch.cumsum(ncol, 0) - 1
+            Ccols = int(col0[-1].item()) + 1
+            has_r = ~self.g_ins[s:e]
+            # class per column: reference-only columns (query gap) = 1; the base's own column: 2 if the reference has no
+            # base there, else 0 / 3 by comparing the bases
+            cls = torch.ones(Ccols, dtype=torch.int64, device=dev)
+            rbase = self.ref[self.g2r[s:e].clamp(max=G - 1)]
+            own = torch.where(has_r, torch.where(seg == rbase, torch.zeros_like(col0), torch.full_like(col0, 3)), torch.full_like(col0, 2))
+            cls[col0] = own
+            pad = (-Ccols) % 16
+            cw = torch.cat([cls, torch.zeros(pad, dtype=torch.int64, device=dev)]).view(-1, 16)
+            w = (cw << (2 * torch.arange(16, device=dev))).sum(-1)
+            words.append(w)
+            rb, re_ = int(self.g2r[s].item()), int(self.g2r[e - 1].item()) + 1
+            n1, n2 = int((cls == 1).sum().item()), int((cls == 2).sum().item())
+            recs[c] = (c, 0, e - s, 0, e - s, rb, re_, cursor, Ccols, Ccols - n1, Ccols - n2, 0 if r else 1)
+            cursor += w.numel()
+        diff = torch.cat(words + [torch.zeros(8, dtype=torch.int64, device=dev)])
+        diff = torch.where(diff >= 2 ** 31, diff - 2 ** 32, diff).to(torch.int32)
+        order = np.argsort(-recs["score"].astype(np.int64), kind="stable")
+        return diff, np.ascontiguousarray(recs[order])
 
     def contig_codes(self):
         """the contig sequences as stored (2-bit codes): target segments, reverse-complemented where the contig is"""

@@ -111,3 +111,55 @@ def test_prepare_equals_host_restatement_on_fresh_inputs(case, workdir):
         pagctl.compare_results(pagctl.run_hip(inp, streams=True), pagctl.run_oracle(inp, streams=True), label=case)
     finally:
         inp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,threads", [(12, 16), (14, 7)])
+def test_prepare_of_the_bench_generator_equals_its_own_digest(k, threads):
+    """bench.py's step starts from the generator's records in PARSER form (BigWorkload.raw_input: header intervals, strand
+    column, score) and lets pag_prepare derive what the generator also knows from its simulation truth (build_input:
+    q_start / t_start / n_valid / flags, the per-read lists, the contig->reference map): the two must agree array for
+    array — and so does the graph built from either."""
+    import torch
+    sp = biggen.BigSpec(seed=5, ref_len=1_500_000, n_reads=2500, read_span=6000, k=k, ctg_len=200_000, eps=10, cov=2, threads=threads,
+                        chunk_reads=1000)
+    w = biggen.BigWorkload(sp, device="cuda:0")
+    torch.cuda.synchronize()
+    lib = pagctl.hip_lib()
+    lib.pag_create_from_bitmap.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.pag_create_from_bitmap.restype = C.c_void_p
+    lib.pag_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    err = C.c_int()
+    g = lib.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, sp.k, 1, 0, C.byref(err))
+    assert g
+    try:
+        raw = w.raw_input()
+        d = biggen.PagBuildInput()
+        assert lib.pag_prepare(g, C.byref(raw), C.byref(d)) == 0, lib.pag_last_error()
+        h = w.build_input()
+
+        def dev(ptr, n, dt):
+            return pagctl.device_bytes(ptr, n * np.dtype(dt).itemsize).view(dt)
+        nr = sp.n_reads
+        np.testing.assert_array_equal(dev(d.emit_order, nr, "<u4"), dev(h.emit_order, nr, "<u4"))
+        np.testing.assert_array_equal(dev(d.ctgs, d.n_ctgs, biggen.CTG_DTYPE), dev(h.ctgs, h.n_ctgs, biggen.CTG_DTYPE))
+        np.testing.assert_array_equal(dev(d.refs, 1, biggen.REF_DTYPE), dev(h.refs, 1, biggen.REF_DTYPE))
+        n_off = int(h.n_ctg_ent_off)
+        assert d.n_ctg_ent_off == n_off
+        np.testing.assert_array_equal(dev(d.ctg_ent_off, n_off, "<u4"), dev(h.ctg_ent_off, n_off, "<u4"))
+        n_ent = int(dev(h.ctg_ent_off, n_off, "<u4")[-1])
+        np.testing.assert_array_equal(dev(d.ctg_ent, n_ent, "<u4"), dev(h.ctg_ent, n_ent, "<u4"))
+        for which in ("read_to_ctg", "read_to_ref"):
+            dd, hh = getattr(d, which), getattr(h, which)
+            assert dd.n_aln == hh.n_aln, which
+            np.testing.assert_array_equal(dev(dd.query_off, nr + 1, "<u8"), dev(hh.query_off, nr + 1, "<u8"), err_msg=which)
+            a, b = dev(dd.aln, dd.n_aln, biggen.ALN_DTYPE), dev(hh.aln, hh.n_aln, biggen.ALN_DTYPE)
+            for f in biggen.ALN_DTYPE.names:
+                np.testing.assert_array_equal(a[f], b[f], err_msg=f"{which}.{f}")
+        st1, st2 = pagctl.BuildStats(), pagctl.BuildStats()
+        assert lib.pag_process(g, C.byref(d), C.byref(st1)) == 0, lib.pag_last_error()
+        assert lib.pag_process(g, C.byref(h), C.byref(st2)) == 0, lib.pag_last_error()
+        assert st1.counts() == st2.counts() and (st1.n_nodes, st1.n_pos, st1.n_uniq_edges) == (st2.n_nodes, st2.n_pos, st2.n_uniq_edges)
+        assert st1.n_pos > 100000
+    finally:
+        lib.pag_destroy(g)
