@@ -159,6 +159,143 @@ int64_t append_seq(std::vector<LNode> &base, const std::vector<LNode> &tail, uin
     return dLen;
 }
 
+
+// The traversal's view of a finished graph: compact CSR with dense ids, vertices renumbered by contig coordinate, and the
+// successor records of every vertex (searchSuccessors + checkPosition for all of them, PABruijnGraph.cpp:143-197) — built
+// once per graph and pair of (deviation, error rate), kept in the handle (g->tg).  Pool slots TRAV_SLOT0 .. + TRAV_GRAPH_SLOTS.
+constexpr int TRAV_GRAPH_SLOTS = 22;
+int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, const uint32_t *ref_len, uint64_t n_refs, uint64_t deviation,
+                       double errorRate, TravGraph *G_out, double *ms_out) {
+    hipStream_t s = g->stream;
+    const uint32_t k = g->k;
+    int rc;
+    int slot = TRAV_SLOT0;
+    auto buf = [&](void) { return DevBuf(g, slot++); };
+    if (ms_out) *ms_out = 0;
+    if (g->tg_ready && (g->tg_dev != deviation || g->tg_err != errorRate)) g->tg_ready = false;
+    if (g->tg_ready) {
+        *G_out = g->tg;
+        return PAG_OK;
+    }
+    // ---- compact CSR (once per built graph)
+    DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
+           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(), b_ucnt = buf(),
+           b_soff = buf(), b_succ = buf(), b_ok0 = buf(), b_ov0 = buf(), b_ok1 = buf(), b_ov1 = buf(), b_otmp = buf();
+    const uint64_t nn = g->stats.n_nodes, np = g->stats.n_pos, ne = g->stats.n_uniq_edges;
+    if (np >= 0xFFFFFFF0ull || ne >= 0xFFFFFFF0ull) {
+        set_error("pag_travel: more than 2^32 vertices/edges");
+        return PAG_EINVAL;
+    }
+    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
+    if ((rc = b_ncode.alloc((nn + 1) * 4)) || (rc = b_npos.alloc((nn + 2) * 4)) || (rc = b_nedge.alloc((nn + 2) * 4)) ||
+        (rc = b_vpos.alloc((np + 1) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
+        (rc = b_eto.alloc((ne + 1) * 4)) || (rc = b_estep.alloc((ne + 1) * 4)) || (rc = b_bitmap.alloc(n_words * 8)) ||
+        (rc = b_rank.alloc(n_words * 4)) || (rc = b_uold.alloc((np + 1) * 4)) || (rc = b_newid.alloc((np + 1) * 4)) ||
+        (rc = b_upos.alloc((np + 1) * 8)) || (rc = b_ucnt.alloc((np + 1) * 4)) || (rc = b_soff.alloc((np + 2) * 4)))
+        return rc;
+    TravGraph G{};
+    G.n_nodes = nn;
+    G.n_pos = np;
+    G.n_edges = ne;
+    G.ncode = b_ncode.as<uint32_t>();
+    G.npos_off = b_npos.as<uint32_t>();
+    G.nedge_off = b_nedge.as<uint32_t>();
+    G.vpos = b_vpos.as<uint64_t>();
+    G.vcnt = b_vcnt.as<uint16_t>();
+    G.vnode = b_vnode.as<uint32_t>();
+    G.eto = b_eto.as<uint32_t>();
+    G.estep = b_estep.as<uint32_t>();
+    G.bitmap = b_bitmap.as<uint64_t>();
+    G.rank = b_rank.as<uint32_t>();
+    G.uold = b_uold.as<uint32_t>();
+    G.newid = b_newid.as<uint32_t>();
+    G.upos = b_upos.as<uint64_t>();
+    G.ucnt = b_ucnt.as<uint32_t>();
+    G.succ_off = b_soff.as<uint32_t>();
+    double t_compact = 0;
+    {
+        const double t0 = now_ms();
+        size_t tb = trav_compact_tmp_bytes(g->n_t, g->n_e, k, nn);
+        if ((rc = b_ctmp.alloc(tb))) return rc;
+        if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
+                               b_ctmp.p, tb, s)))
+            return rc;
+        // coordinate order, then the static half of the epsilon-join for every vertex
+        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
+            (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
+            return rc;
+        // (key widths of the two sorts: the single-coordinate spaces of the contigs and of the references)
+        auto bits_of = [](const uint32_t *len, uint64_t n) {
+            const uint64_t space = Mapper(len, n).starts.empty() ? 1 : Mapper(len, n).starts.back();
+            int b = 1;
+            while (b < 32 && (space >> b) != 0) ++b;
+            return b;
+        };
+        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg,
+                             bits_of(ctg_len, n_ctgs), bits_of(ref_len, n_refs), s)))
+            return rc;
+        uint64_t n_succ = 0, n_cand = 0;
+        // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
+        // staging array laid out by the candidate-pair bound (b_ok1 = bound per vertex, b_ov1 = its prefix,
+        // b_ov0[np + 1] = total), then moved to coordinate order.  Staging = 16 B per CANDIDATE (about twice the
+        // records); it reuses the compaction scratch slot.
+        const SuccRec *stage = nullptr;
+        const uint64_t *stage_off = nullptr;
+        // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
+        // records, see DESIGN.md, and computing the bound is not free)
+        if (!std::getenv("PAG_SUCC_TWO_PASS") && np <= (64ull << 20)) {
+            if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
+                return rc;
+            PAG_HIP_TRY(hipMemcpyAsync(&n_cand, b_ov0.as<uint64_t>() + np + 1, 8, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            size_t free_b = 0, total_b = 0;
+            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const size_t want = (n_cand + 1) * sizeof(SuccRec);
+            // the final array (<= the staging size) has to fit as well; keep a margin for the walk buffers
+            if (want <= b_ctmp.sl->cap || want < (free_b + b_ctmp.sl->cap) / 4) {
+                if (b_ctmp.alloc(want) == PAG_OK) {
+                    stage = b_ctmp.as<SuccRec>();
+                    stage_off = b_ov1.as<uint64_t>();
+                }
+            }
+        }
+        // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
+        uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
+        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
+        if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
+                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
+            return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (n_succ >= 0xFFFFFFF0ull) {
+            set_error("pag_travel: more than 2^32 successor records");
+            return PAG_EINVAL;
+        }
+        if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
+        G.succ = b_succ.as<SuccRec>();
+        G.n_succ = n_succ;
+        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, s))) return rc;
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        g->tg = G;
+        g->tg_dev = deviation;
+        g->tg_err = errorRate;
+        g->tg_ready = true;
+        if (std::getenv("PAGRAPH_TIMING"))
+            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%s, %llu candidate pairs)\n", (unsigned long long)n_succ,
+                         (unsigned long long)np, stage ? "staged, one evaluation" : "two passes", (unsigned long long)n_cand);
+        t_compact = now_ms() - t0;
+    }
+
+    static_assert(TRAV_GRAPH_SLOTS == 22, "slots of the traversal graph");
+    if (slot != TRAV_SLOT0 + TRAV_GRAPH_SLOTS) {
+        set_error("trav_prepare_graph: slot bookkeeping");
+        return PAG_EFAULT;
+    }
+    *G_out = G;
+    if (ms_out) *ms_out = t_compact;
+    return PAG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -189,6 +326,14 @@ const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_i
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
     if (g && 2 * ctg_index + 1 < g->path_valid.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
     return pag_travel_path_oriented(g, ctg_index, 1, len);
+}
+
+// the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
+int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm, double *ms) {
+    if (!g || !ctgs || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    TravGraph G{};
+    return trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, prm->deviation, prm->error_rate, &G, ms);
 }
 
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
@@ -263,119 +408,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         return q;
     };
 
-    // ---- compact CSR (once per built graph)
-    DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
-           b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(), b_ucnt = buf(),
-           b_soff = buf(), b_succ = buf(), b_ok0 = buf(), b_ov0 = buf(), b_ok1 = buf(), b_ov1 = buf(), b_otmp = buf();
-    const uint64_t nn = g->stats.n_nodes, np = g->stats.n_pos, ne = g->stats.n_uniq_edges;
-    if (np >= 0xFFFFFFF0ull || ne >= 0xFFFFFFF0ull) {
-        set_error("pag_travel: more than 2^32 vertices/edges");
-        return PAG_EINVAL;
-    }
-    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
-    if ((rc = b_ncode.alloc((nn + 1) * 4)) || (rc = b_npos.alloc((nn + 2) * 4)) || (rc = b_nedge.alloc((nn + 2) * 4)) ||
-        (rc = b_vpos.alloc((np + 1) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
-        (rc = b_eto.alloc((ne + 1) * 4)) || (rc = b_estep.alloc((ne + 1) * 4)) || (rc = b_bitmap.alloc(n_words * 8)) ||
-        (rc = b_rank.alloc(n_words * 4)) || (rc = b_uold.alloc((np + 1) * 4)) || (rc = b_newid.alloc((np + 1) * 4)) ||
-        (rc = b_upos.alloc((np + 1) * 8)) || (rc = b_ucnt.alloc((np + 1) * 4)) || (rc = b_soff.alloc((np + 2) * 4)))
-        return rc;
+    // ---- compact CSR, coordinate order, successor records (once per built graph)
     TravGraph G{};
-    G.n_nodes = nn;
-    G.n_pos = np;
-    G.n_edges = ne;
-    G.ncode = b_ncode.as<uint32_t>();
-    G.npos_off = b_npos.as<uint32_t>();
-    G.nedge_off = b_nedge.as<uint32_t>();
-    G.vpos = b_vpos.as<uint64_t>();
-    G.vcnt = b_vcnt.as<uint16_t>();
-    G.vnode = b_vnode.as<uint32_t>();
-    G.eto = b_eto.as<uint32_t>();
-    G.estep = b_estep.as<uint32_t>();
-    G.bitmap = b_bitmap.as<uint64_t>();
-    G.rank = b_rank.as<uint32_t>();
-    G.uold = b_uold.as<uint32_t>();
-    G.newid = b_newid.as<uint32_t>();
-    G.upos = b_upos.as<uint64_t>();
-    G.ucnt = b_ucnt.as<uint32_t>();
-    G.succ_off = b_soff.as<uint32_t>();
     double t_compact = 0;
-    if (g->tg_ready && (g->tg_dev != deviation || g->tg_err != errorRate)) g->tg_ready = false;
-    if (g->tg_ready) {
-        G.succ = g->tg.succ;
-        G.n_succ = g->tg.n_succ;
-    }
-    if (!g->tg_ready) {
-        const double t0 = now_ms();
-        size_t tb = trav_compact_tmp_bytes(g->n_t, g->n_e, k, nn);
-        if ((rc = b_ctmp.alloc(tb))) return rc;
-        if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
-                               b_ctmp.p, tb, s)))
-            return rc;
-        // coordinate order, then the static half of the epsilon-join for every vertex
-        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
-            (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
-            return rc;
-        // (key widths of the two sorts: the single-coordinate spaces of the contigs and of the references)
-        auto bits_of = [](const uint32_t *len, uint64_t n) {
-            const uint64_t space = Mapper(len, n).starts.empty() ? 1 : Mapper(len, n).starts.back();
-            int b = 1;
-            while (b < 32 && (space >> b) != 0) ++b;
-            return b;
-        };
-        if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg,
-                             bits_of(ctgs->len, ctgs->n_seqs), bits_of(ref_len, n_refs), s)))
-            return rc;
-        uint64_t n_succ = 0, n_cand = 0;
-        // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
-        // staging array laid out by the candidate-pair bound (b_ok1 = bound per vertex, b_ov1 = its prefix,
-        // b_ov0[np + 1] = total), then moved to coordinate order.  Staging = 16 B per CANDIDATE (about twice the
-        // records); it reuses the compaction scratch slot.
-        const SuccRec *stage = nullptr;
-        const uint64_t *stage_off = nullptr;
-        // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
-        // records, see DESIGN.md, and computing the bound is not free)
-        if (!std::getenv("PAG_SUCC_TWO_PASS") && np <= (64ull << 20)) {
-            if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
-                return rc;
-            PAG_HIP_TRY(hipMemcpyAsync(&n_cand, b_ov0.as<uint64_t>() + np + 1, 8, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
-            size_t free_b = 0, total_b = 0;
-            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const size_t want = (n_cand + 1) * sizeof(SuccRec);
-            // the final array (<= the staging size) has to fit as well; keep a margin for the walk buffers
-            if (want <= b_ctmp.sl->cap || want < (free_b + b_ctmp.sl->cap) / 4) {
-                if (b_ctmp.alloc(want) == PAG_OK) {
-                    stage = b_ctmp.as<SuccRec>();
-                    stage_off = b_ov1.as<uint64_t>();
-                }
-            }
-        }
-        // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
-        uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
-        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
-        if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
-            return rc;
-        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
-        PAG_HIP_TRY(hipStreamSynchronize(s));
-        if (n_succ >= 0xFFFFFFF0ull) {
-            set_error("pag_travel: more than 2^32 successor records");
-            return PAG_EINVAL;
-        }
-        if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
-        G.succ = b_succ.as<SuccRec>();
-        G.n_succ = n_succ;
-        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, s))) return rc;
-        PAG_HIP_TRY(hipStreamSynchronize(s));
-        g->tg = G;
-        g->tg_dev = deviation;
-        g->tg_err = errorRate;
-        g->tg_ready = true;
-        if (std::getenv("PAGRAPH_TIMING"))
-            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%s, %llu candidate pairs)\n", (unsigned long long)n_succ,
-                         (unsigned long long)np, stage ? "staged, one evaluation" : "two passes", (unsigned long long)n_cand);
-        t_compact = now_ms() - t0;
-    }
+    if ((rc = trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, deviation, errorRate, &G, &t_compact))) return rc;
+    slot += TRAV_GRAPH_SLOTS;
+    const uint64_t np = G.n_pos;
+    (void)np;
 
     lap("compact");
     // ---- contigs: packed bases, mapper tables, per-strand node tables

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 
 #include "assembly.hpp"
 #include "host_graph.hpp"
@@ -49,6 +50,16 @@ namespace {
 struct HandleCache {
     pagh::HostGraph graph;
     std::vector<pagh::TravelSequence> travelled;
+    // the host half of a pagh_traverse_begin() that has not been collected by pagh_traverse_end() yet
+    std::thread worker;
+    bool pending = false;
+    int rc = PAG_OK;
+    pagh_traverse_stats stats{};
+    std::string error;
+    std::vector<const pag_path_node *> paths;
+    std::vector<std::uint64_t> lens;
+    double tBegin = 0, tHost = 0;
+    pag_travel_stats tst{};
 };
 std::mutex g_cacheLock;
 std::map<const pag_graph *, std::unique_ptr<HandleCache>> g_cache;
@@ -61,8 +72,15 @@ HandleCache &cacheOf(const pag_graph *g) {
 }  // namespace
 
 void pagh_release(pag_graph *g) {
-    std::lock_guard<std::mutex> l(g_cacheLock);
-    g_cache.erase(g);
+    std::unique_ptr<HandleCache> hc;
+    {
+        std::lock_guard<std::mutex> l(g_cacheLock);
+        auto it = g_cache.find(g);
+        if (it == g_cache.end()) return;
+        hc = std::move(it->second);
+        g_cache.erase(it);
+    }
+    if (hc && hc->worker.joinable()) hc->worker.join();
 }
 
 // chain selection + writers over finished travel sequences (PAssembly::testTravel5 after its travelSequence loop,
@@ -83,7 +101,10 @@ int pagh_assemble_paths(pag_graph *cache_key, uint32_t k, const pag_seqs *ctgs, 
             if (o == PAG_ORIENT_FORWARD || o == PAG_ORIENT_BOTH) ctgSet.emplace(contigDb.name(i), true);
             if (o == PAG_ORIENT_REVERSE || o == PAG_ORIENT_BOTH) ctgSet.emplace(contigDb.name(i), false);
         }
-        HandleCache &hc = cacheOf(cache_key);
+        // (no key: nothing is kept between calls, and callers without a handle of their own do not share storage)
+        std::unique_ptr<HandleCache> local;
+        if (!cache_key) local.reset(new HandleCache());
+        HandleCache &hc = cache_key ? cacheOf(cache_key) : *local;
         std::vector<std::pair<const pag_path_node *, std::uint64_t>> views(2 * ctgs->n_seqs, {nullptr, 0});
         for (std::uint64_t c = 0; c < 2 * ctgs->n_seqs; ++c)
             if (paths[c] && path_len[c]) views[c] = {paths[c], path_len[c]};
@@ -113,10 +134,12 @@ int pagh_assemble_paths(pag_graph *cache_key, uint32_t k, const pag_seqs *ctgs, 
     }
 }
 
-int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
-                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
-                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
+// pagh_traverse in two halves (see include/pagraph_host.h): the device traversal, then the host half on a thread of its own
+static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                          const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                          uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, bool wait_at_once) {
     if (!g || !ctgs || !refs || !ctg_orient || !out_dir) return PAG_EINVAL;
+    HandleCache &hc = cacheOf(g);
     const double t0 = nowMs();
     pag_travel_params tp{};
     tp.ref_threads = ref_threads;
@@ -124,8 +147,27 @@ int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *co
     tp.error_rate = 0.15;
     tp.start_split = 0.90;
     tp.min_len = min_len;
-    pag_travel_stats tst{};
-    int rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &tst);
+    // the traversal's view of the new graph (successor records: device work, this thread only waits) still runs beside the
+    // previous block's host half ...
+    double msPrep = 0;
+    int rc = pag_travel_prepare(g, ctgs, refs->len, refs->n_seqs, &tp, &msPrep);
+    if (rc != PAG_OK) {
+        setErr("pag_travel_prepare: %s", pag_last_error());
+        return rc;
+    }
+    // ... which reads travel sequences in pinned memory that the walks of the next pag_travel reuse: wait for it here
+    const bool overlapped = hc.worker.joinable();
+    if (overlapped) hc.worker.join();
+    if (hc.pending && hc.rc != PAG_OK) {  // (never collected: its error is this call's)
+        hc.pending = false;
+        setErr("%s", hc.error.c_str());
+        return hc.rc;
+    }
+    hc.tst = pag_travel_stats{};
+    rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &hc.tst);
+    hc.tst.ms_compact += msPrep;
+    hc.tst.ms_total += msPrep;
+    const pag_travel_stats &tst = hc.tst;
     if (std::getenv("PAGRAPH_TIMING"))
         std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
                      tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
@@ -135,31 +177,80 @@ int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *co
         setErr("pag_travel: %s", pag_last_error());
         return rc;
     }
-    std::vector<const pag_path_node *> paths(2 * ctgs->n_seqs, nullptr);
-    std::vector<std::uint64_t> lens(2 * ctgs->n_seqs, 0);
+    hc.paths.assign(2 * ctgs->n_seqs, nullptr);
+    hc.lens.assign(2 * ctgs->n_seqs, 0);
     for (std::uint64_t c = 0; c < ctgs->n_seqs; ++c)
         for (int rev = 0; rev < 2; ++rev) {
             std::uint64_t len = 0;
             const pag_path_node *p = pag_travel_path_oriented(g, c, rev == 0, &len);
             if (p && len) {
-                paths[2 * c + rev] = p;
-                lens[2 * c + rev] = len;
+                hc.paths[2 * c + rev] = p;
+                hc.lens[2 * c + rev] = len;
             }
         }
-    const double t1 = nowMs();
-    rc = pagh_assemble_paths(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, paths.data(), lens.data(), ref_threads, epsilon, min_len,
-                             out_dir, prefix, host_threads, stats);
-    if (rc == PAG_OK && stats) {
-        stats->ms_export += t1 - t0;  // (device traversal included, as before)
-        stats->ms_total += t1 - t0;
-        stats->ms_successors = tst.ms_compact;
-        stats->ms_walk = tst.ms_walk;
-        stats->walk_rounds = tst.rounds;
-        stats->walk_jobs = tst.jobs;
-        stats->walk_steps = tst.walk_steps;
-        stats->walk_classifications = tst.classify_calls;
+    hc.tBegin = t0;
+    hc.tHost = nowMs();
+    hc.pending = true;
+    hc.rc = PAG_OK;
+    hc.stats = pagh_traverse_stats{};
+    const std::string outDir(out_dir), pre(prefix ? prefix : "0_");
+    HandleCache *h = &hc;
+    // While the host half runs beside the next block's device work, its pool stays small: a burst of 64 threads uses up a
+    // container's CPU quota for the period (measured on the GPU box, 16-CPU quota: the caller's launches of the next block's
+    // sort stalled, 24 -> 74 ms).  pagh_traverse() itself (begin + end back to back) keeps the full pool.
+    unsigned poolThreads = host_threads;
+    if (!wait_at_once && poolThreads == 0) {
+        static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 8u;
+        poolThreads = cap;
     }
-    return rc;
+    hc.worker = std::thread([=]() {
+        h->rc = pagh_assemble_paths(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, h->paths.data(), h->lens.data(), ref_threads, epsilon,
+                                    min_len, outDir.c_str(), pre.c_str(), poolThreads, &h->stats);
+        if (h->rc != PAG_OK) h->error = g_err;  // (this thread's message)
+    });
+    return PAG_OK;
+}
+
+int pagh_traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                        const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                        uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads) {
+    return traverse_begin(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, ref_threads, epsilon, min_len, out_dir, prefix, host_threads, false);
+}
+
+int pagh_traverse_end(pag_graph *g, pagh_traverse_stats *stats) {
+    if (!g) return PAG_EINVAL;
+    HandleCache &hc = cacheOf(g);
+    if (hc.worker.joinable()) hc.worker.join();
+    if (!hc.pending) {
+        setErr("pagh_traverse_end: no traversal has been begun on this handle");
+        return PAG_EINVAL;
+    }
+    hc.pending = false;
+    if (hc.rc != PAG_OK) {
+        setErr("%s", hc.error.c_str());
+        return hc.rc;
+    }
+    if (stats) {
+        *stats = hc.stats;
+        const double dev = hc.tHost - hc.tBegin;
+        stats->ms_export += dev;  // (device traversal included, as before)
+        stats->ms_total += dev;
+        stats->ms_successors = hc.tst.ms_compact;
+        stats->ms_walk = hc.tst.ms_walk;
+        stats->walk_rounds = hc.tst.rounds;
+        stats->walk_jobs = hc.tst.jobs;
+        stats->walk_steps = hc.tst.walk_steps;
+        stats->walk_classifications = hc.tst.classify_calls;
+    }
+    return PAG_OK;
+}
+
+int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                  const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                  uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads, pagh_traverse_stats *stats) {
+    const int rc = traverse_begin(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, ref_threads, epsilon, min_len, out_dir, prefix,
+                                  host_threads, true);
+    return rc != PAG_OK ? rc : pagh_traverse_end(g, stats);
 }
 
 }  // extern "C"

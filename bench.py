@@ -64,6 +64,12 @@ def load_libs():
                                    C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32,
                                    C.POINTER(TraverseStats)]
     host.pagh_traverse.restype = C.c_int
+    host.pagh_traverse_begin.argtypes = host.pagh_traverse.argtypes[:-1]
+    host.pagh_traverse_begin.restype = C.c_int
+    host.pagh_traverse_end.argtypes = [C.c_void_p, C.POINTER(TraverseStats)]
+    host.pagh_traverse_end.restype = C.c_int
+    host.pagh_release.argtypes = [C.c_void_p]
+    host.pagh_release.restype = None
     host.pagh_last_error.restype = C.c_char_p
     return hip, host
 
@@ -286,12 +292,50 @@ def main():
         if rc != 0:
             raise SystemExit(f"pag_process failed ({rc}): {hip.pag_last_error().decode()}")
         if not args.build_only:
+            # The host half of a block's traversal (path graph, chain selection, the output files) runs on host threads
+            # beside the NEXT block's pag_prepare / pag_process (pagh_traverse_begin / _end, include/pagraph_host.h): the blocks
+            # of a run are independent.  The last block's host half is collected inside the timed region (finish()).
             tp1 = time.perf_counter()
-            rc = host.pagh_traverse(g, spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, spec.threads,
-                                    spec.eps, 50, out_dir.encode(), b"0_", 0, C.byref(ts))
+            # (the successor records of the new graph are device work: built before the previous block's host half is waited for)
+            ms_succ = C.c_double()
+            rc = hip.pag_travel_prepare(g, C.byref(ctg_seqs), ref_len_u32.ctypes.data, 1, C.byref(tparams1), C.byref(ms_succ))
             if rc != 0:
-                raise SystemExit(f"pagh_traverse failed ({rc}): {host.pagh_last_error().decode()}")
+                raise SystemExit(f"pag_travel_prepare failed ({rc}): {hip.pag_last_error().decode()}")
+            succ_ms.append(ms_succ.value)
+            collect()
+            rc = host.pagh_traverse_begin(g, spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, spec.threads,
+                                          spec.eps, 50, out_dir.encode(), b"0_", 0)
+            if rc != 0:
+                raise SystemExit(f"pagh_traverse_begin failed ({rc}): {host.pagh_last_error().decode()}")
+            pending["n"] = 1
             wall["traverse"] += time.perf_counter() - tp1
+
+    pending = {"n": 0}
+    trav_ms, succ_ms = [], []
+
+    class TravelParams1(C.Structure):
+        _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
+                    ("start_split", C.c_double), ("min_len", C.c_uint64)]
+    tparams1 = TravelParams1(spec.threads, 0, 2 * spec.eps, 0.15, 0.90, 50)
+    ref_len_u32 = np.array([len(ref_np)], dtype=np.uint32)
+    hip.pag_travel_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    hip.pag_travel_prepare.restype = C.c_int
+
+    def collect():
+        """statistics (and errors) of the block whose host half is still running, if any"""
+        if not pending["n"]:
+            return
+        pending["n"] = 0
+        rc = host.pagh_traverse_end(g, C.byref(ts))
+        if rc != 0:
+            raise SystemExit(f"pagh_traverse failed ({rc}): {host.pagh_last_error().decode()}")
+        check_repeatable()
+        trav_ms.append(ts.ms_total)
+
+    def finish():
+        tp1 = time.perf_counter()
+        collect()
+        wall["traverse"] += time.perf_counter() - tp1
 
     def sync():
         if dist:
@@ -303,6 +347,8 @@ def main():
     def check_repeatable():
         # idempotence: every step must reproduce the same graph (counts, sizes, path checksum)
         nonlocal first
+        # (one block per rank: the traversal statistics arrive a block late — collect() — while the build's are the current
+        # block's; every block is the same block, so neither may ever change)
         sig = (st.counts(), st.n_nodes, st.n_pos, st.n_uniq_edges, ts.n_path_nodes, ts.path_checksum)
         if first is None:
             first = sig
@@ -322,17 +368,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
-        check_repeatable()
+        if args.build_only or shard:
+            check_repeatable()
+    finish()
     sync()
     wall["prepare"] = wall["process"] = wall["traverse"] = 0.0
+    trav_ms.clear()
     t0 = time.perf_counter()
-    sort_ms, build_ms, trav_ms = [], [], []
+    sort_ms, build_ms = [], []
     for _ in range(args.steps):
         step()
-        check_repeatable()
+        if args.build_only or shard:
+            check_repeatable()
+            trav_ms.append(ts.ms_total)
         sort_ms.append(st.ms_sort_kernel)
         build_ms.append(st.ms_total if st.ms_total > 0 else wall["process"] * 1e3 / max(1, len(build_ms) + 1))  # (sharded build: wall time)
-        trav_ms.append(ts.ms_total)
+    finish()  # (the last block's host half: inside the timed region)
     sync()
     dt = time.perf_counter() - t0
     check_known_answer()  # (outside the timed region)
@@ -389,12 +440,13 @@ def main():
                 "path_nodes": int(ts.n_path_nodes), "path_checksum": f"{int(ts.path_checksum):016x}",
                 # the traversal is a latency-bound serial chain (no HBM roofline): what bounds it is the longest
                 # chain of dependent walk steps and the time per step, reported here instead
-                "ms_successor_records": ts.ms_successors, "ms_walk": ts.ms_walk,
+                "ms_successor_records": float(np.mean(succ_ms[-args.steps:])) if succ_ms else ts.ms_successors, "ms_walk": ts.ms_walk,
                 "walk_jobs": int(ts.walk_jobs), "walk_rounds_longest_chain": int(ts.walk_rounds),
                 "walk_path_vertices": int(ts.walk_steps), "walk_classifications": int(ts.walk_classifications),
                 "kmer_counter_on_device": kc,
-                "time_share": "successor records ~30 %, walks (k_walk_persistent) ~25 %, host outputs ~20 %, build ~15 % of a step; "
-                              "the roofline object grades the dominant BANDWIDTH-bound kernel of the build",
+                "time_share": "successor records ~35 %, walks (k_walk_persistent + their control thread) ~38 %, build ~17 %, pag_prepare ~2 % of a step; "
+                              "the host half of a block (path graph, chains, 535 MB of output files, ~200 ms on 8 threads) runs beside the next "
+                              "block's device work; the roofline object grades the k-mer sort",
             },
             # SURVEY §8d's figure for the graded kernel = the WHOLE k-mer sort (both streams, every radix pass, histograms and
             # scans included): algorithmic bytes = one read + one write of every 12-byte record, independent of the number of
@@ -447,6 +499,7 @@ def main():
                 pass
         print(json.dumps(line), flush=True)
     shutil.rmtree(out_dir, ignore_errors=True)
+    host.pagh_release(g)
     hip.pag_destroy(g)
     if dist:
         dist.destroy_process_group()

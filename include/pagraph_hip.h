@@ -307,6 +307,11 @@ typedef struct pag_travel_stats {
  * After success, pag_travel_path_oriented(g, i, forward, &len) returns the path of contig i in that orientation
  * (library-owned, valid until the next pag_travel / pag_process / pag_destroy on the handle; NULL / 0 if that
  * orientation was not traversed); pag_travel_path(g, i, &len) = the forward path if there is one, else the reverse. */
+/* The first part of pag_travel on its own: the traversal's view of the graph (compact CSR, coordinate order, successor
+ * records), kept in the handle until the graph changes; a following pag_travel with the same parameters goes straight to the
+ * walks.  *ms (may be NULL) receives its wall time. */
+int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm,
+                       double *ms);
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *params, pag_travel_stats *stats);
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);

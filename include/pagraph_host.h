@@ -37,16 +37,27 @@ int pagh_traverse(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *co
                   const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads,
                   uint64_t epsilon, uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
                   pagh_traverse_stats *stats);
+/* pagh_traverse in two halves, so that the host half of block n (path graph, chain selection, the output files: host threads
+ * only) runs beside the device work of block n + 1 (the reference's config blocks are independent, pagraph.cpp:181-182).
+ * begin(): the device traversal (pag_travel); the host half then starts on a thread of its own and begin() returns.
+ * end(): waits for it and hands out its statistics / error.  A begin() on a handle whose previous host half is still
+ * running waits for it first (the travel sequences it reads live in pinned memory the next pag_travel reuses); pag_prepare
+ * and pag_process of the next block need not wait.  The arrays passed to begin() must stay valid until end(). */
+int pagh_traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names, const pag_seqs *refs,
+                        const char *const *ref_names, const int32_t *ctg_orient, uint32_t ref_threads, uint64_t epsilon,
+                        uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads);
+int pagh_traverse_end(pag_graph *g, pagh_traverse_stats *stats);
 /* The second half of pagh_traverse on travel sequences obtained elsewhere — e.g. walked by several GPUs, each for a part of
  * the contigs (pag_travel with the other contigs PAG_ORIENT_NONE), and gathered: paths[2 * c + (reverse ? 1 : 0)] /
  * path_len[...] = the sequence of contig c in that orientation (NULL / 0: none).  ctg_orient lists ALL contigs of the
- * block, as config.txt does.  cache_key: any pointer under which host storage is kept between calls (may be NULL). */
+ * block, as config.txt does.  cache_key: any pointer under which host storage is kept between calls (NULL: nothing is kept). */
 int pagh_assemble_paths(pag_graph *cache_key, uint32_t k, const pag_seqs *ctgs, const char *const *ctg_names,
                         const pag_seqs *refs, const char *const *ref_names, const int32_t *ctg_orient,
                         const pag_path_node *const *paths, const uint64_t *path_len, uint32_t ref_threads, uint64_t epsilon,
                         uint64_t min_len, const char *out_dir, const char *prefix, uint32_t host_threads,
                         pagh_traverse_stats *stats);
-/* Drops the host storage kept for a graph handle between pagh_traverse calls (call before pag_destroy). */
+/* Drops the host storage kept for a graph handle between pagh_traverse calls; waits for a host half still running.  Call it
+ * before pag_destroy of a handle that was traversed. */
 void pagh_release(pag_graph *g);
 const char *pagh_last_error(void);
 

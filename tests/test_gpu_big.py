@@ -86,6 +86,7 @@ def test_device_resident_input_matches_oracle_and_reference(k, eps, seed, n_read
     finally:
         os.environ.pop("PAG_WALK_EXACT", None)
     assert rc == 0, host.pagh_last_error()
+    host.pagh_release(g)
     hip.pag_destroy(g)
     assert (ts.n_path_nodes, ts.n_path_bases, ts.path_checksum) == (ts2.n_path_nodes, ts2.n_path_bases, ts2.path_checksum)
     assert (ts.n_path_nodes, ts.n_path_bases, ts.path_checksum) == (ts3.n_path_nodes, ts3.n_path_bases, ts3.path_checksum)

@@ -78,6 +78,7 @@ def main():
                     print(f"        [{j}] {a[j].decode() if j < len(a) else '-':60s} | {b[j].decode() if j < len(b) else '-'}", flush=True)
         else:
             res["files"] = files
+    host.pagh_release(g)
     hip.pag_destroy(g)
     vals = {v for k, v in res.items() if k != "files"}
     print("ALL EQUAL" if len(vals) == 1 else "MISMATCH")
