@@ -254,6 +254,20 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
     // again.
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t u = G.newid[v];
+        if (G.incomplete && u < G.n_zero && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u)) {
+            // its successors may lie outside the region this rank holds: one poison record in their place
+            if (MODE != 1) cnt[u] = 1u;
+            if (MODE == 0 && amask) amask[v] = 0ull;
+            if (MODE != 0) {
+                SuccRec r;
+                r.tgt = u;
+                r.pc = 0;
+                r.meta = 1u | (GRADE_POISON << 24);
+                r.toff = 0;
+                (MODE == 1 ? G.succ + G.succ_off[u] : stage + stage_off[v])[0] = r;
+            }
+            continue;
+        }
         const uint64_t rootp = G.vpos[v];
         const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
         const uint32_t node = G.vnode[v];
@@ -344,7 +358,7 @@ __global__ void k_succ_bound(TravGraph G, uint32_t *__restrict__ ub) {
             const uint32_t to = G.eto[e];
             if (to != PAG_NONE) n += G.npos_off[to + 1] - G.npos_off[to];
         }
-        ub[v] = n;
+        ub[v] = n ? n : (G.incomplete ? 1u : 0u);  // (room for a poison record, see k_succ)
     }
 }
 
@@ -552,6 +566,7 @@ struct WalkCtx {
     uint32_t x_elow, x_m0;         // running iteration: lowest coordinate of an examined contig-following record / lowest id
                                    // of an examined record without a contig coordinate
     uint32_t x_below, x_forced;    // whole job: window-dependent records below / at or above force_low
+    uint32_t x_poison;             // whole job: a poison record was examined (TravGraph::incomplete)
     uint32_t force_low;
     int overflow;
     int spec_fail;  // a zombie probe ended in a leap (or could not be continued): the job has to be redone without speculation
@@ -713,7 +728,8 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
 }
 
 // bookkeeping for a later splice (see WalkCtx::x_*): every examined record passes here
-__device__ __forceinline__ void walk_note_record(WalkCtx &X, uint32_t v, uint32_t pc, bool ectg) {
+__device__ __forceinline__ void walk_note_record(WalkCtx &X, uint32_t v, uint32_t pc, bool ectg, uint32_t grade = 0u) {
+    X.x_poison |= grade == GRADE_POISON ? 1u : 0u;
     X.x_m0 = ((pc == 0u) & (v < X.x_m0)) ? v : X.x_m0;
     X.x_elow = ((pc != 0u) & ectg & (pc < X.x_elow)) ? pc : X.x_elow;
     const bool wd = (pc != 0u) & !ectg;
@@ -768,7 +784,7 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, WalkCtx &X, const S
         }
     }
     const bool free_pc = (pc == 0u) | ectg;  // no coordinate, or the edge follows the contig: the window tests do not apply
-    walk_note_record(X, v, pc, ectg);
+    walk_note_record(X, v, pc, ectg, grade);
     const bool hit_g = !free_pc & in_win(X.win_g0, X.win_g1, pc), hit_t = !free_pc & in_win(X.win_t0, X.win_t1, pc);
     const bool rev = (pc != 0u) & (pc >= X.C.rev_left) & (pc < X.C.rev_right);
     bool ok = !(gvis | hit_g | rev | tvis | hit_t);
@@ -789,7 +805,8 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, WalkCtx &X, const S
         ok = !((double)(int64_t)off > (double)sz * X.C.leap_min) & can_leap;
     }
     // class by grade through a nibble table: Amazing 0, Excellent 1, Good 2, Skip 3 (only once leaping is allowed)
-    const uint32_t table = can_leap ? 0x0123Fu : 0x012FFu;
+    // (grade 7 = the poison record of a vertex whose successors lie outside the region this rank holds: never accepted)
+    const uint32_t table = can_leap ? 0xFFF0123Fu : 0xFFF012FFu;
     const uint32_t c4 = leap ? 0u : (table >> (grade * 4u)) & 0xFu;
     return (ok & (c4 != 0xFu)) ? (int)c4 : -1;
 }
@@ -1462,9 +1479,13 @@ __device__ __forceinline__ bool probe_slots(WalkLds &L, WalkCtx &X, Slot &S, uin
     PROF_END(X, 4, t_steps);
     X.overflow = __ballot(X.overflow != 0) ? 1 : 0;
     {
-        int sf = X.spec_fail;
-        for (int d2 = 32; d2 >= 1; d2 >>= 1) sf |= __shfl_xor(sf, d2, 64);
+        int sf = X.spec_fail, pz = (int)X.x_poison;
+        for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+            sf |= __shfl_xor(sf, d2, 64);
+            pz |= __shfl_xor(pz, d2, 64);
+        }
         X.spec_fail = sf;
+        X.x_poison = (uint32_t)pz;
     }
     __syncthreads();  // paths written by the groups are read by all lanes afterwards
     return !wide;
@@ -1643,6 +1664,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.force_low = (J.mode & TRAV_MODE_LEAP) ? J.win_low : 0u;
     X.x_elow = X.x_m0 = X.x_forced = 0xFFFFFFFFu;
     X.x_below = 0u;
+    X.x_poison = 0u;
     X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.w_ab = X.n_fill = 0;
 #ifdef PAG_WALK_PROF
     for (int q = 0; q < 12; ++q) {
@@ -2089,9 +2111,13 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         wd_forced = of < wd_forced ? of : wd_forced;
     }
     {
-        int sf = X.spec_fail;
-        for (int d2 = 32; d2 >= 1; d2 >>= 1) sf |= __shfl_xor(sf, d2, 64);
+        int sf = X.spec_fail, pz = (int)X.x_poison;
+        for (int d2 = 32; d2 >= 1; d2 >>= 1) {
+            sf |= __shfl_xor(sf, d2, 64);
+            pz |= __shfl_xor(pz, d2, 64);
+        }
         X.spec_fail = sf;
+        X.x_poison = (uint32_t)pz;
     }
     uint64_t mp_all = X.max_probe;
     for (int d2 = 32; d2 >= 1; d2 >>= 1) {
@@ -2114,7 +2140,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         o.max_chosen = max_chosen;
         o.wd_below_max = wd_below;
         o.wd_forced_min = wd_forced;
-        o.reserved3 = 0;
+        o.poison = X.x_poison;
         o.max_probe = mp_all;
 #ifdef PAG_WALK_PROF
         for (int q = 0; q < 12; ++q) {
@@ -2572,6 +2598,63 @@ void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uin
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s) {
     if (n) k_ranges<<<dim3((n + 63) / 64), dim3(64), 0, s>>>(G, ctgs, n);
 }
+
+// ---- a graph that holds a region of the block only (one rank of a sharded build) ----------------------------------
+// largest step of any edge (bounds how far a successor's coordinate can lie from its source's)
+__global__ void k_max_step(const uint32_t *__restrict__ estep, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = estep[i] > m ? estep[i] : m;
+    m = wave_max_u32(m);
+    if (lane_id() == 0 && m) atomicMax(out, m);
+}
+// incomplete[u] for the coordinate-free vertices (new ids 0 .. n_zero, ordered by reference coordinate): the vertex lies
+// within `margin` of an OPEN end of the reference band it is in (iv: sorted disjoint [lo, hi) pairs; open[2 i], open[2 i + 1]:
+// the graph goes on beyond that end, on another rank) — or in no band at all (cannot happen for a selected vertex)
+__global__ void k_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *__restrict__ iv, const uint8_t *__restrict__ open, uint32_t n_iv,
+                                  uint32_t margin, uint32_t *__restrict__ bits) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (u < n_zero) {
+        const uint32_t r = (uint32_t)G.upos[u];
+        uint32_t lo = 0, hi = n_iv;  // last interval with lo <= r
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (iv[2 * mid] <= r) lo = mid;
+            else hi = mid;
+        }
+        bad = n_iv == 0 || r < iv[2 * lo] || r >= iv[2 * lo + 1];
+        if (!bad) {
+            bad = (open[2 * lo] && r - iv[2 * lo] < margin) || (open[2 * lo + 1] && iv[2 * lo + 1] - r <= margin);
+        }
+    }
+    const uint64_t m = __ballot(bad);
+    if ((threadIdx.x & 63u) == 0 && u < ((n_zero + 63u) & ~63u)) {
+        bits[u >> 5] = (uint32_t)m;
+        bits[(u >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+}
+int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
+                         uint32_t *bits, void *tmp, hipStream_t s) {
+    // tmp: u32 max step | intervals | open flags
+    uint32_t *d_max = (uint32_t *)tmp;
+    uint32_t *d_iv = d_max + 64;
+    uint8_t *d_open = (uint8_t *)(d_iv + 2 * (size_t)n_iv + 2);
+    PAG_HIP_TRY(hipMemsetAsync(d_max, 0, 4, s));
+    if (G.n_edges) k_max_step<<<dim3(grid_for(G.n_edges)), dim3(256), 0, s>>>(G.estep, G.n_edges, d_max);
+    if (n_iv) {
+        PAG_HIP_TRY(hipMemcpyAsync(d_iv, iv_host, 2 * (size_t)n_iv * 4, hipMemcpyHostToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(d_open, open_host, 2 * (size_t)n_iv, hipMemcpyHostToDevice, s));
+    }
+    uint32_t max_step = 0;
+    PAG_HIP_TRY(hipMemcpyAsync(&max_step, d_max, 4, hipMemcpyDeviceToHost, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    // a successor's coordinate lies within step + deviation, or step x (1 + error rate), of its source's (checkPosition)
+    const uint64_t margin = (uint64_t)((double)max_step * (1.0 + err)) + dev + 2;
+    if (n_zero) k_mark_incomplete<<<dim3((n_zero + 255) / 256), dim3(256), 0, s>>>(G, n_zero, d_iv, d_open, n_iv, (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu), bits);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv) { return 256 + (2 * (size_t)n_iv + 2) * 4 + 2 * (size_t)n_iv + 64; }
 
 // coordinate order + successor records.  key/val/key2/val2: u32/u64 [n_pos] scratch pairs for the sort;
 // cnt: u32 [n_pos + 1]; *n_succ_out receives the number of successor records (call twice: first with

@@ -163,7 +163,7 @@ int64_t append_seq(std::vector<LNode> &base, const std::vector<LNode> &tail, uin
 // The traversal's view of a finished graph: compact CSR with dense ids, vertices renumbered by contig coordinate, and the
 // successor records of every vertex (searchSuccessors + checkPosition for all of them, PABruijnGraph.cpp:143-197) — built
 // once per graph and pair of (deviation, error rate), kept in the handle (g->tg).  Pool slots TRAV_SLOT0 .. + TRAV_GRAPH_SLOTS.
-constexpr int TRAV_GRAPH_SLOTS = 22;
+constexpr int TRAV_GRAPH_SLOTS = 22;  // (+ 2 behind them for a regional graph's incomplete-vertex bitmap)
 int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, const uint32_t *ref_len, uint64_t n_refs, uint64_t deviation,
                        double errorRate, TravGraph *G_out, double *ms_out) {
     hipStream_t s = g->stream;
@@ -234,6 +234,18 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg,
                              bits_of(ctg_len, n_ctgs), bits_of(ref_len, n_refs), s)))
             return rc;
+        // a graph that holds a region of the block only: which coordinate-free vertices may have successors beyond it
+        G.incomplete = nullptr;
+        G.n_zero = (uint32_t)g->n_zero_ctg;
+        if (g->regional) {
+            DevBuf b_inc(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS), b_inct(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 1);
+            const uint32_t n_iv = (uint32_t)(g->region_ref_iv.size() / 2);
+            if ((rc = b_inc.alloc(((size_t)G.n_zero / 32 + 4) * 4)) || (rc = b_inct.alloc(trav_mark_incomplete_tmp_bytes(n_iv)))) return rc;
+            if ((rc = trav_mark_incomplete(G, G.n_zero, g->region_ref_iv.data(), g->region_ref_open.data(), n_iv, (uint32_t)deviation, errorRate,
+                                           b_inc.as<uint32_t>(), b_inct.p, s)))
+                return rc;
+            G.incomplete = b_inc.as<uint32_t>();
+        }
         uint64_t n_succ = 0, n_cand = 0;
         // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
         // staging array laid out by the candidate-pair bound (b_ok1 = bound per vertex, b_ov1 = its prefix,
@@ -412,7 +424,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     TravGraph G{};
     double t_compact = 0;
     if ((rc = trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, deviation, errorRate, &G, &t_compact))) return rc;
-    slot += TRAV_GRAPH_SLOTS;
+    slot += TRAV_GRAPH_SLOTS + 2;
     const uint64_t np = G.n_pos;
     (void)np;
 
@@ -1621,6 +1633,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             probe_total += o.n_probe;
             record_total += o.n_records;
             const bool overflow = (o.overflow & 3) != 0, misspec = (o.overflow & 4) != 0;
+            if (o.poison) {
+                // (a regional graph, pag_shard_select: the walk reached a vertex whose successors another rank holds)
+                set_error("pag_travel: a walk of contig %u left the region of the graph this rank holds (reference band halo too small: raise PAG_SHARD_HALO)", st[i].ci);
+                return fail(PAG_ERANGE);
+            }
             touched.push_back(i);
             if (jr.kind == 1) {  // a segment
                 Seg &sg = R.segs[(size_t)jr.idx];

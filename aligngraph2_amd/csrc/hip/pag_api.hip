@@ -71,6 +71,9 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->eseg = nullptr;
     g->n_t = g->n_e = 0;
     g->tg_ready = false;
+    g->regional = false;
+    g->region_ref_iv.clear();
+    g->region_ref_open.clear();
     g->path_off.clear();  // (the pinned storage stays)
     g->path_len.clear();
     g->path_valid.clear();

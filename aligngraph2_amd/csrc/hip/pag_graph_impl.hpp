@@ -32,7 +32,7 @@ struct pag_graph {
         void *p = nullptr;
         size_t cap = 0;
     };
-    Slot pool[192];
+    Slot pool[256];
     // per-contig walker buffers (k5_travel_host.hip), grown on demand like the slots above
     std::vector<Slot> cpool;
     // while the persistent walker is resident nothing may be hipFree'd (it synchronises the device): replaced
@@ -62,6 +62,11 @@ struct pag_graph {
     size_t walk_arena_cap = 0, walk_arena_used = 0;
     std::vector<void *> fetch_chunks;  // pinned chunks for the paths fetched from the walker (pag_travel)
     std::vector<size_t> fetch_chunk_bytes;
+    // the graph holds only a region of the block (pag_shard_set_region after pag_shard_import): the reference bands of its
+    // coordinate-free vertices, [lo, hi) pairs sorted, and which ends are open (the block goes on beyond them, on other ranks)
+    bool regional = false;
+    std::vector<uint32_t> region_ref_iv;
+    std::vector<uint8_t> region_ref_open;
     uint64_t n_zero_ctg = 0;  // new ids below it: vertices without a contig coordinate, in reference-coordinate order
     // pinned host staging area of the traversal (packed job results, uploads)
     void *pin_host = nullptr;
@@ -108,7 +113,7 @@ struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_dest
 };
 
 
-// slot numbers 0..63 belong to pag_process (pag_api.hip), 64..127 to the traversal, 128.. to pag_prepare (k_prepare.hip)
+// slot numbers 0..63 belong to pag_process (pag_api.hip), 64..127 to the traversal, 128..191 to pag_prepare (k_prepare.hip), 192.. to pag_shard_select
 enum { TRAV_SLOT0 = 64 };
 
 }  // namespace pagdev

@@ -32,7 +32,13 @@ struct TravGraph {
     uint32_t *succ_off;   // [n_pos + 1] successor records of new id u
     struct SuccRec *succ; // [n_succ]
     uint64_t n_succ;
+    // a graph that holds only a REGION of the block's vertices (pag_shard_select, one rank of a sharded build): bit u set =
+    // the successors of coordinate-free vertex u (new id < n_zero) may lie outside the region.  Such a vertex has ONE
+    // record of grade GRADE_POISON instead of its successors; a walk that examines it reports a fault (TravJobOut::poison).
+    const uint32_t *incomplete;  // null: the whole graph is here
+    uint32_t n_zero;
 };
+constexpr uint32_t GRADE_POISON = 7u;
 
 // one graded successor of a vertex (searchSuccessors + checkPosition != Oops), in reference order
 struct alignas(16) SuccRec {
@@ -116,7 +122,7 @@ struct TravJobOut {
                             // TravJob::win_low (0: none) ...
     uint64_t max_probe;     // largest size (sum of steps) of any probe, zombies included
     uint32_t wd_forced_min; // ... and the lowest one at or above it (all ones: none)
-    uint32_t reserved3;
+    uint32_t poison;        // 1: the walk examined the records of a vertex whose successors this rank does not hold (TravGraph::incomplete)
     uint64_t t_begin, t_end;  // 100 MHz device clock when the wave took the job / finished it (PAG_WALK_DEBUG timeline)
 #ifdef PAG_WALK_PROF
     uint64_t prof_t[12];  // cycles per section of the walk (development aid, make WALK_PROF=1)
@@ -174,6 +180,9 @@ void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s);
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);
+int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
+                         uint32_t *bits, void *tmp, hipStream_t s);
+size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv);
 int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,
                int ref_bits, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair

@@ -1,11 +1,16 @@
 """Multi-GPU layer of the PAGraph hot path: one process per GPU, torch.distributed (RCCL on GPUs, gloo
-in CPU tests).
+in CPU tests).  Two levels:
 
-The path shards by reference sequence (SURVEY.md §8e level 1): AlignGraph2 already runs one pagraph per
-per-reference sub-directory, sequentially (reference AlignGraph2.py:399-431); config blocks are
-independent after resetAllNodes (pagraph.cpp:181-182).  So the units are distributed over the ranks with
-NO data-path collective; the only communication is the barrier / max / sum around the timed region and
-the gathering of exit codes.
+Level 1 — blocks over GPUs (run_sharded, run_config_blocks): the path shards by reference sequence; AlignGraph2 already
+runs one pagraph per per-reference sub-directory, sequentially (reference AlignGraph2.py:399-431), and config blocks are
+independent after resetAllNodes (pagraph.cpp:181-182).  The units are distributed over the ranks with NO data-path
+collective; the only communication is the barrier / max / sum around the timed region and the gathering of exit codes.
+
+Level 2 — ONE block over GPUs (ShardedBuild, build_sharded, regions_for, deal_contigs, gather_paths): reads are split for
+the extraction, k-mer ranges for sort / cluster / edges with one all-to-all(v) of tuples in between; the traversal side is
+partitioned by the contigs a rank is dealt: every rank receives, from every k-mer owner, only the vertices its traversals
+can examine (pag_shard_select: its contigs' strands, the landing zones of all contigs, the coordinate-free vertices of the
+reference bands its contigs map to) — one more all-to-all(v) instead of an all-gather of the whole graph.
 """
 from __future__ import annotations
 
@@ -185,6 +190,96 @@ class ShardSlice(_C.Structure):
                 ("tcnt", _C.c_void_p), ("ekey", _C.c_void_p), ("eval", _C.c_void_p), ("eseg", _C.c_void_p), ("stats", BuildStats)]
 
 
+class Region(_C.Structure):
+    """pag_region (include/pagraph_hip.h)"""
+    _fields_ = [("n_ctg_iv", _C.c_uint64), ("ctg_iv", _C.c_void_p), ("n_ref_iv", _C.c_uint64), ("ref_iv", _C.c_void_p), ("ref_open", _C.c_void_p)]
+
+
+def bind_shard_api(hip):
+    """ctypes signatures of the pag_shard_* entry points (include/pagraph_hip.h)"""
+    vp, u64 = _C.c_void_p, _C.c_uint64
+    hip.pag_shard_extract.argtypes = [vp, vp, _C.c_uint32, _C.c_uint32, _C.POINTER(u64)]
+    hip.pag_shard_take.argtypes = [vp, vp, vp, vp, vp]
+    hip.pag_shard_build.argtypes = [vp, vp, vp, u64, u64, vp, vp, u64, u64, _C.c_uint32, _C.POINTER(BuildStats)]
+    hip.pag_shard_export.argtypes = [vp, _C.POINTER(ShardSlice)]
+    hip.pag_shard_take_slice.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    hip.pag_shard_import.argtypes = [vp, _C.POINTER(ShardSlice), _C.c_uint32, _C.POINTER(BuildStats)]
+    hip.pag_shard_select.argtypes = [vp, _C.POINTER(Region), _C.POINTER(ShardSlice)]
+    hip.pag_shard_set_region.argtypes = [vp, _C.POINTER(Region)]
+    hip.pag_shard_release_build.argtypes = [vp]
+    for f in ("pag_shard_extract", "pag_shard_take", "pag_shard_build", "pag_shard_export", "pag_shard_take_slice", "pag_shard_import",
+              "pag_shard_select", "pag_shard_set_region"):
+        getattr(hip, f).restype = _C.c_int
+    hip.pag_last_error.restype = _C.c_char_p
+
+
+def mapper_starts(lengths):
+    """PositionMapper layout (position/PositionMapper.cpp:16-31): start of every sequence's forward strand + the extra end"""
+    st = []
+    for i, n in enumerate(lengths):
+        st.append(int(n) if i == 0 else st[-1] + 3 * int(lengths[i - 1]) + max(int(lengths[i - 1]), int(n)))
+    if st:
+        st.append(st[-1] + 4 * int(lengths[-1]))
+    return st
+
+
+def _merge(ivs):
+    out = []
+    for lo, hi in sorted(ivs):
+        if hi <= lo:
+            continue
+        if out and lo <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], hi)
+        else:
+            out.append([lo, hi])
+    return out
+
+
+def regions_for(deal, ctg_len, orient, ctg_alns, ref_len, halo=200_000, start_split=0.90):
+    """What every rank of a sharded build needs of the finished graph (see pag_shard_select in include/pagraph_hip.h).
+
+    deal[r]: the contigs rank r traverses; orient[c]: PAG_ORIENT_* (-1 none, 0 reverse, 1 forward, 2 both) as config.txt
+    lists them; ctg_alns: the contig->reference alignments as (contig, reference index, t_begin, t_end) of every listed
+    alignment (whatever its strand: a superset costs memory, never correctness); ref_len: reference lengths.
+    Returns, per rank, dict(ctg_iv, ref_iv, ref_open) of numpy arrays + a keep-alive Region()."""
+    import numpy as np
+    cst, rst = mapper_starts(ctg_len), mapper_starts(ref_len)
+    leap_min = 1.0 - start_split
+    # landing zones: the first leap_min of EVERY contig strand (offset <= len * leap_min survives the leap rule)
+    landing = []
+    for c, n in enumerate(ctg_len):
+        z = int(float(n) * leap_min) + 2
+        z = min(z, int(n))
+        landing += [(cst[c], cst[c] + z), (cst[c] + 2 * int(n), cst[c] + 2 * int(n) + z)]
+    out = []
+    for mine in deal:
+        civ, riv = list(landing), []
+        for c in mine:
+            n = int(ctg_len[c])
+            if orient[c] in (1, 2):
+                civ.append((cst[c], cst[c] + n))
+            if orient[c] in (0, 2):
+                civ.append((cst[c] + 2 * n, cst[c] + 3 * n))
+            for (cc, ri, tb, te) in ctg_alns:
+                if cc != c:
+                    continue
+                lo, hi = rst[ri], rst[ri] + int(ref_len[ri])
+                riv.append((max(lo, rst[ri] + int(tb) - halo), min(hi, rst[ri] + int(te) + halo)))
+        civ, riv = _merge(civ), _merge(riv)
+        ref_ends = {}
+        for ri, n in enumerate(ref_len):
+            ref_ends[rst[ri]] = 0
+            ref_ends[rst[ri] + int(n)] = 0
+        ropen = []
+        for lo, hi in riv:
+            ropen += [0 if lo in ref_ends else 1, 0 if hi in ref_ends else 1]
+        d = dict(ctg_iv=np.array(civ, dtype=np.uint32).reshape(-1), ref_iv=np.array(riv, dtype=np.uint32).reshape(-1),
+                 ref_open=np.array(ropen, dtype=np.uint8))
+        d["region"] = Region(len(civ), d["ctg_iv"].ctypes.data, len(riv), d["ref_iv"].ctypes.data, d["ref_open"].ctypes.data)
+        out.append(d)
+    return out
+
+
 def layout_received(chunks, counts_to_me):
     """The records an owner receives, in the order pag_shard_build expects.
 
@@ -297,6 +392,36 @@ class ShardedBuild:
             raise RuntimeError(f"pag_shard_take_slice failed ({rc}): {self.hip.pag_last_error().decode()}")
         return out, BuildStats.from_buffer_copy(bytes(sl.stats))
 
+    def _slice_tensors(self, sl):
+        torch = self.torch
+        out = {}
+        for name, n, dt in (("tkey", sl.n_t, torch.int32), ("tval", sl.n_t, torch.int64), ("tseg", sl.n_t, torch.int32),
+                            ("tcnt", sl.n_t, torch.int16), ("ekey", sl.n_e, torch.int32), ("eval", sl.n_e, torch.int64),
+                            ("eseg", sl.n_e, torch.int32)):
+            out[name] = torch.empty(int(n), dtype=dt, device=self.device)
+        return out
+
+    def select(self, region):
+        """the part of this owner's slice inside `region` (regions_for) as torch tensors + the stats that go with it"""
+        torch = self.torch
+        sl = self.Slice()
+        rc = self.hip.pag_shard_select(_C.c_void_p(self.g), _C.byref(region["region"]), _C.byref(sl))
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_select failed ({rc}): {self.hip.pag_last_error().decode()}")
+        out = self._slice_tensors(sl)
+        rt = _hip_runtime()
+        for name, t in out.items():
+            if t.numel():
+                rc = rt.hipMemcpy(_C.c_void_p(t.data_ptr()), _C.c_void_p(getattr(sl, name)), t.numel() * t.element_size(), 3)  # device to device
+                if rc != 0:
+                    raise RuntimeError(f"hipMemcpy failed ({rc})")
+        return out, BuildStats.from_buffer_copy(bytes(sl.stats))
+
+    def set_region(self, region):
+        rc = self.hip.pag_shard_set_region(_C.c_void_p(self.g), _C.byref(region["region"]))
+        if rc != 0:
+            raise RuntimeError(f"pag_shard_set_region failed ({rc}): {self.hip.pag_last_error().decode()}")
+
     def import_all(self, slices, stats_list):
         """the whole graph from the slices of all owners (lists in owner order) -> total count lines"""
         parts = (self.Slice * len(slices))()
@@ -313,9 +438,24 @@ class ShardedBuild:
         return tot
 
 
-def build_sharded(hip, g, inp, eps, dist, device):
+_rt = {}
+
+
+def _hip_runtime():
+    """the HIP runtime torch loaded (device-to-device copies out of the handle's buffers)"""
+    if "rt" not in _rt:
+        import torch
+        rt = _C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        rt.hipMemcpy.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_int]
+        _rt["rt"] = rt
+    return _rt["rt"]
+
+
+def build_sharded(hip, g, inp, eps, dist, device, regions=None):
     """One config block built by all ranks of `dist` (each rank passes the SAME input; it extracts its share of the reads).
-    Afterwards every rank's handle holds the whole graph.  Returns the total count lines (pag_build_stats)."""
+    regions = None: afterwards every rank's handle holds the whole graph (all-gather of the owners' slices).
+    regions = regions_for(...): every rank receives, from every owner, the part of the graph its traversals need (one
+    all-to-all(v)), and the handle knows its region.  Returns the total count lines (pag_build_stats)."""
     import numpy as np
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -336,6 +476,8 @@ def build_sharded(hip, g, inp, eps, dist, device):
     del tuples, edges
     sb.build(rt, t1, re, e1, eps)
     del rt, re
+    if regions is not None:
+        return _exchange_selected(sb, regions, dist, cdev, device, all_gather)
     sl, st = sb.export()
     # all-gather of the slices (padded to the largest; sizes first)
     all_sizes = [x.cpu().tolist() for x in all_gather(torch.tensor([sl["tkey"].numel(), sl["ekey"].numel()], dtype=torch.int64))]
@@ -353,9 +495,63 @@ def build_sharded(hip, g, inp, eps, dist, device):
     return sb.import_all(slices, stats_list)
 
 
-def deal_contigs(lengths, world):
-    """contigs -> ranks for the traversal (longest first, as assign_blocks)"""
-    return assign_blocks(list(lengths), world)
+def _exchange_selected(sb, regions, dist, cdev, device, all_gather):
+    """every owner selects, for every rank, the part of its slice inside that rank's region; one all-to-all(v) per array"""
+    import torch
+    rank, world = sb.rank, sb.world
+    sel, stats = [], []
+    for d in range(world):
+        t, st = sb.select(regions[d])
+        sel.append(t)
+        stats.append(st)
+    names = ("tkey", "tval", "tseg", "tcnt", "ekey", "eval", "eseg")
+    mine = torch.tensor([[sel[d]["tkey"].numel(), sel[d]["ekey"].numel()] for d in range(world)], dtype=torch.int64)
+    sizes = torch.stack(all_gather(mine)).cpu().numpy()  # [owner][dest][2]
+    slices = [dict() for _ in range(world)]
+    for name in names:
+        which = 0 if name[0] == "t" else 1
+        send_splits = [int(sizes[rank][d][which]) for d in range(world)]
+        recv_splits = [int(sizes[o][rank][which]) for o in range(world)]
+        src = torch.cat([sel[d][name] for d in range(world)]).to(cdev).contiguous().view(torch.uint8)
+        esz = sel[0][name].element_size()
+        recv = torch.empty(sum(recv_splits) * esz, dtype=torch.uint8, device=cdev)
+        dist.all_to_all_single(recv, src, [n * esz for n in recv_splits], [n * esz for n in send_splits])
+        chunks = torch.split(recv, [n * esz for n in recv_splits])
+        for o in range(world):
+            slices[o][name] = chunks[o].to(device).contiguous().view(sel[0][name].dtype)
+    # the owners' stats that go with their selections for this rank
+    blob = torch.cat([torch.frombuffer(bytearray(bytes(stats[d])), dtype=torch.uint8) for d in range(world)]).to(cdev)
+    n_st = len(bytes(stats[0]))
+    rblob = torch.empty_like(blob)
+    dist.all_to_all_single(rblob, blob, [n_st] * world, [n_st] * world)
+    stats_list = [BuildStats.from_buffer_copy(bytes(rblob[o * n_st:(o + 1) * n_st].cpu().numpy().tobytes())) for o in range(world)]
+    tot = sb.import_all(slices, stats_list)
+    sb.set_region(regions[rank])
+    # the build's device memory (and torch's copies of the exchanged arrays) goes back before the traversal needs it
+    del sel, slices, src, recv, chunks
+    sb.hip.pag_shard_release_build(_C.c_void_p(sb.g))
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return tot
+
+
+def deal_contigs(lengths, world, ref_begin=None):
+    """contigs -> ranks for the traversal.  Without positions: longest first (assign_blocks).  ref_begin[c] = where contig c
+    maps to on the reference (single coordinate): CONTIGUOUS runs of contigs in reference order, balanced by length — the
+    reference bands of a rank's contigs then merge into one stretch and the halo (regions_for) is paid twice per rank
+    instead of twice per contig."""
+    if ref_begin is None:
+        return assign_blocks(list(lengths), world)
+    order = sorted(range(len(lengths)), key=lambda c: (ref_begin[c], c))
+    total = float(sum(lengths)) or 1.0
+    out, acc, r = [[] for _ in range(world)], 0.0, 0
+    for c in order:
+        # (a contig goes to the rank in whose share of the total its middle falls)
+        mid = acc + lengths[c] / 2.0
+        r = min(world - 1, int(mid / total * world))
+        out[r].append(c)
+        acc += lengths[c]
+    return out
 
 
 def gather_paths(hip, g, mine, n_ctgs, dist, device):

@@ -237,17 +237,22 @@ def main():
     wall = {"prepare": 0.0, "process": 0.0, "traverse": 0.0}
     dev_name = f"cuda:{local}"
     if shard:
-        import test_gpu_shards  # (ctypes signatures of the shard entry points)
-        test_gpu_shards._bind(hip)
+        parallel.bind_shard_api(hip)
         hip.pag_travel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         host.pagh_assemble_paths.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p]
-        deal = parallel.deal_contigs([e - s for s, e, _ in w.ctgs], world)
+        deal = parallel.deal_contigs([e - s for s, e, _ in w.ctgs], world, ref_begin=[int(s) for s, _, _ in w.ctgs])
         my_orient = np.full(len(w.ctgs), -1, dtype=np.int32)
         for c in deal[rank]:
             my_orient[c] = orient[c]
         my_slots = {2 * c + (0 if orient[c] else 1) for c in deal[rank]}
         ref_len_arr = np.array([len(ref_np)], dtype=np.uint32)
+        # what each rank needs of the finished graph for the contigs it was dealt (the traversal side partitioned too)
+        g2r_np = w.g2r.cpu().numpy()
+        ctg_alns = [(c, 0, int(g2r_np[s]), int(g2r_np[e - 1]) + 1) for c, (s, e, _) in enumerate(w.ctgs)]
+        halo = int(os.environ.get("PAG_SHARD_HALO", "200000"))
+        regions = None if os.environ.get("PAG_SHARD_WHOLE_GRAPH") == "1" else \
+            parallel.regions_for(deal, [e - s for s, e, _ in w.ctgs], orient, ctg_alns, [len(ref_np)], halo=halo)
 
         class TravelParams(C.Structure):
             _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
@@ -259,7 +264,7 @@ def main():
         # the travel sequences gathered, rank 0 selects the chains and writes the outputs
         nonlocal st
         tp0 = time.perf_counter()
-        st = parallel.build_sharded(hip, g, inp, spec.eps, dist, dev_name)
+        st = parallel.build_sharded(hip, g, inp, spec.eps, dist, dev_name, regions=regions)
         wall["process"] += time.perf_counter() - tp0
         if args.build_only:
             return
@@ -428,7 +433,8 @@ def main():
                 "edge_tuples": int(st.n_edges[0] + st.n_edges[1]),
                 "vertices": int(st.n_pos),
                 "sharding": ("ONE block over all GPUs: reads split for the extraction, k-mer ranges for sort/cluster/edges, all-to-all(v) of "
-                             "tuples + all-gather of the slices, contigs dealt out for the walks") if shard else
+                             "tuples; contigs dealt out for the walks, every rank receives only the region of the graph its contigs need "
+                             "(pag_shard_select, a second all-to-all(v))") if shard else
                             "one reference-sequence block per GPU, no data-path collective",
                 "ms_build_device": float(np.mean(build_ms)),
                 "ms_prepare_wall": wall["prepare"] / args.steps * 1e3, "ms_pag_process_wall": wall["process"] / args.steps * 1e3, "ms_pagh_traverse_wall": wall["traverse"] / args.steps * 1e3,

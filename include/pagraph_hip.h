@@ -260,6 +260,31 @@ int pag_shard_export(const pag_graph *g, pag_shard_slice *out);
 int pag_shard_take_slice(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *tseg, uint16_t *tcnt, uint32_t *ekey, uint64_t *eval,
                          uint32_t *eseg);
 int pag_shard_import(pag_graph *g, const pag_shard_slice *parts, uint32_t n_parts, pag_build_stats *total);
+/* The traversal side partitioned too (a block larger than one GPU's memory: BASELINE configs[2]).  Contigs are traversed
+ * independently (PAssembly.cpp:30-79), so a rank only needs the vertices the traversals it was dealt can examine:
+ *   - every vertex whose contig coordinate lies on the traversed strands of its contigs, or in the landing zone (the first
+ *     1 - startSplit of a strand) of ANY contig strand — a vertex with a contig coordinate anywhere else is dropped by
+ *     every classification that meets it (leap rule, PAlgorithm.tcc:60-67), present or not;
+ *   - the vertices WITHOUT a contig coordinate whose reference coordinate lies in the bands its contigs map to, plus a halo.
+ * pag_shard_select (on the owner, after pag_shard_build): the part of the owner's slice inside a region, in slice layout
+ *   (valid until the next select on the handle; stats = the owner's share of the count lines + the selected sizes).
+ * pag_shard_import takes the selections of all owners (owner order) exactly like whole slices;
+ * pag_shard_set_region then tells the handle which reference bands it holds: a walk that comes within one successor's
+ *   reach (max step x (1 + error rate) + deviation) of an OPEN band end makes pag_travel fail with PAG_ERANGE — never a
+ *   silently different path.
+ * Intervals: [lo, hi) pairs of single coordinates, sorted, disjoint; host memory. */
+typedef struct pag_region {
+    uint64_t n_ctg_iv;
+    const uint32_t *ctg_iv;  /* [2 * n_ctg_iv] contig single coordinates (PositionMapper over the contigs) */
+    uint64_t n_ref_iv;
+    const uint32_t *ref_iv;  /* [2 * n_ref_iv] reference single coordinates of coordinate-free vertices */
+    const uint8_t *ref_open; /* [2 * n_ref_iv] 1: the block goes on beyond that end of the band (0: end of the reference) */
+} pag_region;
+int pag_shard_select(pag_graph *g, const pag_region *region, pag_shard_slice *out);
+int pag_shard_set_region(pag_graph *g, const pag_region *region);
+/* hands back the device memory of the build stages (inputs, streams, scratch, the owner's slice and selections) once the
+ * rank has imported what it traverses; the imported graph stays.  The solid set stays too. */
+int pag_shard_release_build(pag_graph *g);
 
 /* sizes of the finished graph, then the graph itself into caller buffers */
 int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);

@@ -34,17 +34,12 @@ def _bind(hip):
     hip.pag_create_from_bitmap.restype = C.c_void_p
     hip.pag_export_csr.argtypes = [C.c_void_p, C.POINTER(pagctl.Csr)]
     hip.pag_csr_sizes.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint64)] * 3
-    hip.pag_shard_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
-    hip.pag_shard_take.argtypes = [C.c_void_p] * 5
-    hip.pag_shard_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
-                                    C.c_uint32, C.c_void_p]
-    hip.pag_shard_export.argtypes = [C.c_void_p, C.c_void_p]
-    hip.pag_shard_take_slice.argtypes = [C.c_void_p] * 8
-    hip.pag_shard_import.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    parallel.bind_shard_api(hip)
 
 
-def _sharded(hip, w, n_shards):
-    """the emulated N-rank build; returns the N handles, each holding the WHOLE graph afterwards, and the total stats"""
+def _sharded(hip, w, n_shards, regions=None):
+    """the emulated N-rank build; returns the N handles and the total stats.  regions = None: every handle holds the WHOLE
+    graph afterwards; regions = parallel.regions_for(...): handle r holds what rank r's traversals need (pag_shard_select)"""
     import torch
     sp = w.spec
     inp = w.build_input()
@@ -62,10 +57,19 @@ def _sharded(hip, w, n_shards):
         rt, t1 = parallel.exchange_stream(ext[r][1], allc[:, :, 0:2], r, n_shards, peers=[e[1] for e in ext])
         re_, e1 = parallel.exchange_stream(ext[r][2], allc[:, :, 2:4], r, n_shards, peers=[e[2] for e in ext])
         sb.build(rt, t1, re_, e1, sp.eps)
-        sl, st = sb.export()
+        if regions is None:
+            sl, st = sb.export()
+        else:  # (what this owner sends to every rank; all selections before any import: an import replaces the handle's graph)
+            sl, st = zip(*[sb.select(regions[d]) for d in range(n_shards)])
         slices.append(sl)
         stats.append(st)
-    totals = [sb.import_all(slices, stats) for sb in sbs]
+    if regions is None:
+        totals = [sb.import_all(slices, stats) for sb in sbs]
+    else:
+        totals = []
+        for d, sb in enumerate(sbs):
+            totals.append(sb.import_all([slices[o][d] for o in range(n_shards)], [stats[o][d] for o in range(n_shards)]))
+            sb.set_region(regions[d])
     torch.cuda.synchronize()
     assert all(t.counts() == totals[0].counts() for t in totals)
     return gs, totals[0]
@@ -166,6 +170,111 @@ def test_n_shards_build_the_graph_of_one(n_shards, workdir):
         hip.pag_destroy(C.c_void_p(g))
 
 
+def _walk_dealt_and_assemble(hip, host, gs, w, deal, orient, seqs, out):
+    """every "rank" walks the contigs it was dealt on ITS handle; the travel sequences are gathered for one chain selection"""
+    import bench
+    sp = w.spec
+    n_ctg = len(w.ctgs)
+    hip.pag_travel_path_oriented.restype = C.c_void_p
+    hip.pag_travel_path_oriented.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    hip.pag_travel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    paths = (C.c_void_p * (2 * n_ctg))()
+    lens = (C.c_uint64 * (2 * n_ctg))()
+    keep = []
+
+    class TravelParams(C.Structure):
+        _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
+                    ("start_split", C.c_double), ("min_len", C.c_uint64)]
+    prm = TravelParams(sp.threads, 0, 2 * sp.eps, 0.15, 0.90, 50)
+    ctg_seqs, ref_seqs = seqs[0], seqs[1]
+    ref_len = np.array([len(w.ref)], dtype=np.uint32)
+    for r, g in enumerate(gs):
+        mine = np.array([orient[c] if c in deal[r] else -1 for c in range(n_ctg)], dtype=np.int32)
+        rc = hip.pag_travel(g, C.byref(ctg_seqs), mine.ctypes.data, ref_len.ctypes.data, 1, C.byref(prm), None)
+        if rc != 0:
+            return rc, hip.pag_last_error().decode()
+        for c in range(n_ctg):
+            if mine[c] < 0:
+                continue
+            n = C.c_uint64()
+            p = hip.pag_travel_path_oriented(g, c, int(mine[c] != 0), C.byref(n))
+            buf = C.create_string_buffer(C.string_at(p, n.value * 24), n.value * 24) if n.value else None  # (the "gather")
+            keep.append(buf)
+            slot = 2 * c + (0 if mine[c] else 1)
+            paths[slot] = C.cast(buf, C.c_void_p).value if buf is not None else None
+            lens[slot] = n.value
+    os.makedirs(out, exist_ok=True)
+    tsG = bench.TraverseStats()
+    host.pagh_assemble_paths.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p]
+    rc = host.pagh_assemble_paths(None, sp.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, paths, lens, sp.threads, sp.eps, 50,
+                                  out.encode(), b"0_", 0, C.byref(tsG))
+    assert rc == 0, host.pagh_last_error()
+    return 0, tsG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards", [2, 4])
+def test_ranks_hold_their_region_only_and_walk_the_same_paths(n_shards, workdir):
+    """The traversal side partitioned (BASELINE configs[2] does not fit one GPU): every "rank" imports, from every k-mer owner,
+    only what pag_shard_select gives it for its region — its contigs' strands, the landing zones, the coordinate-free
+    vertices of its reference bands — holds a fraction of the vertices, and the gathered outputs equal the one-GPU run byte
+    for byte.  With NO halo the walks of the leaping zones leave the bands: that must be REPORTED (PAG_ERANGE), never a
+    silently different path."""
+    import torch
+    import bench
+    import biggen
+    hip, host = bench.load_libs()
+    _bind(hip)
+    sp = biggen.BigSpec(seed=11, ref_len=3_000_000, n_reads=12000, read_span=4000, k=14, eps=10, ctg_len=250_000, gap_lo=300, gap_hi=3000,
+                        rev_ctg_frac=0.3, threads=16, cov=2, solid_min_abundance=2, chunk_reads=512)
+    w = biggen.BigWorkload(sp, device="cuda")
+    torch.cuda.synchronize()
+    inp = w.build_input()
+    err = C.c_int()
+    g1 = hip.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, sp.k, 1, 0, C.byref(err))
+    st1 = pagctl.BuildStats()
+    assert hip.pag_process(C.c_void_p(g1), C.byref(inp), C.byref(st1)) == 0, hip.pag_last_error()
+    orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
+    one = str(workdir / f"reg{n_shards}_one")
+    ts1, seqs = _traverse(host, g1, w, one, orient)
+    host.pagh_release(C.c_void_p(g1))
+    hip.pag_destroy(C.c_void_p(g1))
+
+    ctg_len = [e - s for s, e, _ in w.ctgs]
+    g2r = w.g2r.cpu().numpy()
+    deal = parallel.deal_contigs(ctg_len, n_shards, ref_begin=[int(g2r[s]) for s, _, _ in w.ctgs])
+    alns = [(c, 0, int(g2r[s]), int(g2r[e - 1]) + 1) for c, (s, e, _) in enumerate(w.ctgs)]
+    for halo, must_work in ((60_000, True), (0, False)):
+        regions = parallel.regions_for(deal, ctg_len, orient, alns, [len(w.ref)], halo=halo)
+        gs, tot = _sharded(hip, w, n_shards, regions=regions)
+        assert tot.counts() == st1.counts()  # (the count lines stay the block's)
+        held = []
+        for g in gs:
+            nn, npos, ne = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            hip.pag_csr_sizes(C.c_void_p(g), C.byref(nn), C.byref(npos), C.byref(ne))
+            held.append(npos.value / st1.n_pos)
+        out = str(workdir / f"reg{n_shards}_halo{halo}")
+        rc, res = _walk_dealt_and_assemble(hip, host, gs, w, deal, orient, seqs, out)
+        for g in gs:
+            hip.pag_destroy(C.c_void_p(g))
+        if must_work:
+            assert rc == 0, res
+            # a fraction of the graph per rank: its share of the contigs + the landing zones + the halo of its bands
+            assert max(held) < 1.0 / n_shards + 0.15, held
+            assert sum(held) < 1.0 + 0.15 * n_shards, held
+            print(f"{n_shards} ranks hold {[round(h, 3) for h in held]} of the vertices")
+        else:
+            assert rc in (0, -34), res  # PAG_ERANGE: reported, never silently different
+            if rc != 0:
+                assert "left the region" in res
+                continue
+        for f in os.listdir(one):
+            assert open(os.path.join(out, f), "rb").read() == open(os.path.join(one, f), "rb").read(), f"halo {halo}: {f}"
+        assert sorted(os.listdir(out)) == sorted(os.listdir(one))
+        assert (res.n_path_nodes, res.n_path_bases, res.path_checksum) == (ts1.n_path_nodes, ts1.n_path_bases, ts1.path_checksum)
+
+
 @pytest.mark.gpu
 def test_bench_shard_mode_two_processes_equal_one(workdir):
     """bench.py --mode shard with TWO processes (one device, gloo staged through the host: the PAG_BENCH_SINGLE_DEVICE hook) —
@@ -185,5 +294,7 @@ def test_bench_shard_mode_two_processes_equal_one(workdir):
     assert two.returncode == 0, two.stderr[-3000:]
     d2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][0])
     assert d2["n_gpus"] == 2 and d2["scaling"] == "strong"
-    for kk in ("position_tuples", "edge_tuples", "vertices", "path_nodes", "path_bases", "path_checksum", "chains"):
+    for kk in ("position_tuples", "edge_tuples", "path_nodes", "path_bases", "path_checksum", "chains"):
         assert d1["config"][kk] == d2["config"][kk], kk
+    # (rank 0 holds its region of the graph, not the whole of it)
+    assert d2["config"]["vertices"] < d1["config"]["vertices"]
