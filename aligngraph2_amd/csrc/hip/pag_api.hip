@@ -825,6 +825,23 @@ int pag_shard_import(pag_graph *g, const pag_shard_slice *parts, uint32_t n_part
     return PAG_OK;
 }
 
+// the graph arrays are already in the import slots (52 .. 58: received there, shard_comm.hip): the handle takes them over
+int pag_shard_adopt(pag_graph *g, uint64_t T, uint64_t E, const pag_build_stats *st) {
+    if (!g || !st) return PAG_EINVAL;
+    free_graph_results(g);
+    g->n_t = T;
+    g->n_e = E;
+    g->tkey = (uint32_t *)g->pool[52].p;
+    g->tval = (uint64_t *)g->pool[53].p;
+    g->tseg = (uint32_t *)g->pool[54].p;
+    g->tcnt = (uint16_t *)g->pool[55].p;
+    g->ekey = (uint32_t *)g->pool[56].p;
+    g->eval = (uint64_t *)g->pool[57].p;
+    g->eseg = (uint32_t *)g->pool[58].p;
+    g->stats = *st;
+    return PAG_OK;
+}
+
 int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges) {
     if (!g) return PAG_EINVAL;
     if (n_nodes) *n_nodes = g->stats.n_nodes;

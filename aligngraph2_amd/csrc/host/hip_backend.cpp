@@ -1,7 +1,10 @@
 #include "hip_backend.hpp"
 
 #include "path_graph.hpp"
+#include "shard_plan.hpp"
 
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -11,8 +14,35 @@ namespace {
 
 class HipBackend final : public GraphBackend {
 public:
-    explicit HipBackend(int device) : device_(device) {}
-    ~HipBackend() override { pag_destroy(g_); }
+    explicit HipBackend(int device) : device_(device) {
+        // PAGRAPH_SHARD=r/N (or "env": RANK / WORLD_SIZE as torchrun sets them): this process is rank r of N that build every
+        // config block TOGETHER, one process per GPU of the node; PAGRAPH_SHARD_DIR = a fresh directory all of them see;
+        // PAGRAPH_SHARD_TRANSPORT = rccl (default) | host (ranks sharing one device: test boxes)
+        const char *sh = std::getenv("PAGRAPH_SHARD");
+        if (!sh || !*sh) return;
+        int r = 0, n = 1;
+        if (std::strcmp(sh, "env") == 0) {
+            r = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0;
+            n = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
+        } else if (std::sscanf(sh, "%d/%d", &r, &n) != 2) {
+            throw std::runtime_error("PAGRAPH_SHARD must be r/N or env");
+        }
+        if (n <= 1) return;
+        const char *dir = std::getenv("PAGRAPH_SHARD_DIR");
+        if (!dir) throw std::runtime_error("PAGRAPH_SHARD needs PAGRAPH_SHARD_DIR (a fresh directory every rank sees)");
+        if (n != 2 && n != 4 && n != 8) throw std::runtime_error("PAGRAPH_SHARD: 2, 4 or 8 ranks");
+        int err = 0;
+        comm_ = pag_comm_create(r, n, dir, device_, std::getenv("PAGRAPH_SHARD_TRANSPORT"), &err);
+        if (!comm_) throw std::runtime_error(std::string("pag_comm_create failed (") + std::to_string(err) + "): " + pag_last_error());
+        rank_ = static_cast<unsigned>(r);
+        world_ = static_cast<unsigned>(n);
+    }
+    ~HipBackend() override {
+        pag_destroy(g_);
+        pag_comm_destroy(comm_);
+    }
+    unsigned shardRank() const override { return rank_; }
+    unsigned shardWorld() const override { return world_; }
     const char *name() const override { return "HIP gfx950"; }
     void create(const std::uint64_t *words, std::size_t nWords, unsigned k) override {
         int err = 0;
@@ -22,8 +52,24 @@ public:
     std::uint64_t solidCount() override { return pag_solid_count(g_); }
     void reset() override { check(pag_reset(g_), "pag_reset"); }
     void reserveForContigs(std::uint64_t bases) override { check(pag_reserve_walk_arena(g_, bases), "pag_reserve_walk_arena"); }
-    void prepare(const RawInput &raw, pag_build_input &out) override { check(pag_prepare(g_, &raw.view(), &out), "pag_prepare"); }
-    void process(const pag_build_input &in, pag_build_stats &stats) override { check(pag_process(g_, &in, &stats), "pag_process"); }
+    void prepare(const RawInput &raw, pag_build_input &out) override {
+        check(pag_prepare(g_, &raw.view(), &out), "pag_prepare");
+        if (!comm_) return;
+        // who traverses which contigs of this block, and what of the graph that takes (shard_plan.hpp)
+        std::vector<std::int32_t> orient(raw.ctgs.size(), PAG_ORIENT_NONE);
+        for (auto &c : raw.cfg.contigs) {
+            if (!raw.ctgs.contains(c.first)) continue;
+            std::int32_t &o = orient[raw.ctgs.id(c.first)];
+            const std::int32_t mine = c.second ? PAG_ORIENT_FORWARD : PAG_ORIENT_REVERSE;
+            o = (o == PAG_ORIENT_NONE || o == mine) ? mine : PAG_ORIENT_BOTH;
+        }
+        const std::uint64_t halo = std::getenv("PAG_SHARD_HALO") ? std::strtoull(std::getenv("PAG_SHARD_HALO"), nullptr, 10) : 200000;
+        plan_ = planShards(raw, orient, world_, halo, 0.90);
+    }
+    void process(const pag_build_input &in, pag_build_stats &stats) override {
+        if (!comm_) check(pag_process(g_, &in, &stats), "pag_process");
+        else check(pag_shard_run(g_, comm_, &in, plan_.regions.data(), &stats), "pag_shard_run");
+    }
     void exportCsr(HostGraph &out) override {
         std::uint64_t nn = 0, np = 0, ne = 0;
         check(pag_csr_sizes(g_, &nn, &np, &ne), "pag_csr_sizes");
@@ -40,7 +86,9 @@ public:
         std::vector<std::int32_t> orient(contigs.size(), PAG_ORIENT_NONE);
         for (auto &c : ctx.ctgSet) {
             if (!contigs.contains(c.first)) continue;
-            std::int32_t &o = orient[contigs.id(c.first)];
+            const std::size_t id = contigs.id(c.first);
+            if (comm_ && (id >= plan_.ownerOf.size() || plan_.ownerOf[id] != static_cast<int>(rank_))) continue;  // (another rank's)
+            std::int32_t &o = orient[id];
             const std::int32_t mine = c.second ? PAG_ORIENT_FORWARD : PAG_ORIENT_REVERSE;
             o = (o == PAG_ORIENT_NONE || o == mine) ? mine : PAG_ORIENT_BOTH;
         }
@@ -55,6 +103,58 @@ public:
                 const pag_path_node *p = pag_travel_path_oriented(g_, c, rev == 0, &len);
                 if (p && len) views[2 * c + rev] = {p, len};
             }
+        if (comm_) {
+            // the travel sequences of all ranks to rank 0 (which selects the chains and writes the block's outputs):
+            // per rank [n][(slot, length) x n][records ...]
+            std::vector<char> blob;
+            std::uint64_t n = 0;
+            for (auto &v : views) n += v.second ? 1 : 0;
+            blob.resize(8 + n * 16);
+            std::memcpy(blob.data(), &n, 8);
+            std::size_t at = 8;
+            for (std::uint64_t sl = 0; sl < views.size(); ++sl)
+                if (views[sl].second) {
+                    std::memcpy(blob.data() + at, &sl, 8);
+                    std::memcpy(blob.data() + at + 8, &views[sl].second, 8);
+                    at += 16;
+                }
+            for (auto &v : views)
+                if (v.second) {
+                    const std::size_t bytes = v.second * sizeof(pag_path_node);
+                    blob.resize(blob.size() + bytes);
+                    std::memcpy(blob.data() + blob.size() - bytes, v.first, bytes);
+                }
+            std::vector<std::uint64_t> sizes(world_), got(world_);
+            const std::uint64_t mineBytes = blob.size();
+            check(pag_comm_all_gather(comm_, &mineBytes, 8, sizes.data()), "pag_comm_all_gather");
+            std::uint64_t totalBytes = 0;
+            for (auto x : sizes) totalBytes += x;
+            if (rank_ == 0) gathered_.resize(totalBytes);
+            check(pag_comm_gather_v(comm_, blob.data(), blob.size(), 0, rank_ == 0 ? gathered_.data() : nullptr, rank_ == 0 ? gathered_.size() : 0, got.data(),
+                                    nullptr),
+                  "pag_comm_gather_v");
+            if (rank_ != 0) {
+                graph = HostGraph{};
+                travelled.clear();
+                return;
+            }
+            std::fill(views.begin(), views.end(), std::pair<const pag_path_node *, std::uint64_t>{nullptr, 0});
+            std::size_t base = 0;
+            for (unsigned r = 0; r < world_; ++r) {
+                const char *b = gathered_.data() + base;
+                std::uint64_t cnt = 0;
+                std::memcpy(&cnt, b, 8);
+                const char *rec = b + 8 + cnt * 16;
+                for (std::uint64_t e = 0; e < cnt; ++e) {
+                    std::uint64_t sl = 0, len = 0;
+                    std::memcpy(&sl, b + 8 + e * 16, 8);
+                    std::memcpy(&len, b + 8 + e * 16 + 8, 8);
+                    if (sl < views.size()) views[sl] = {reinterpret_cast<const pag_path_node *>(rec), len};
+                    rec += len * sizeof(pag_path_node);
+                }
+                base += sizes[r];
+            }
+        }
         buildPathGraph(views, ctx.k, graph, travelled);
     }
 
@@ -64,6 +164,10 @@ private:
     }
     int device_;
     pag_graph *g_ = nullptr;
+    pag_comm *comm_ = nullptr;
+    unsigned rank_ = 0, world_ = 1;
+    ShardPlan plan_;
+    std::vector<char> gathered_;  // rank 0: the travel sequences of all ranks (the path graph refers to them)
 };
 
 }  // namespace

@@ -264,6 +264,10 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 backend.travel(ctx, tp, graph, precomputed);
                 lap("traversal");
             }
+            if (backend.shardRank() != 0) {  // (rank 0 has the travel sequences of all ranks and writes the block's outputs)
+                ++blockNo;
+                continue;
+            }
             auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, ctgMapper,
                                        refMapper, usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
                                        opt.threads, 0, nullptr, false, precomputed);
@@ -271,6 +275,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             ++blockNo;
             for (auto &s : successCtg) okCtg.emplace(s.first);
         }
+        if (backend.shardRank() != 0) return EXIT_SUCCESS;
         const char *part = std::getenv("PAGRAPH_PART");
         std::ofstream ctgList(opt.out + (blocksEnv ? std::string("/contig.txt.part") + (part ? part : "0") : std::string("/contig.txt")));
         for (auto &c : okCtg) ctgList << c << "\n";

@@ -34,6 +34,10 @@ public:
     // runs it on the device (pag_prepare) and returns a device-resident input; valid until the next prepare()
     virtual void prepare(const RawInput &raw, pag_build_input &out) = 0;
     virtual void process(const pag_build_input &in, pag_build_stats &stats) = 0;
+    // ONE block built by several processes, one per GPU (PAGRAPH_SHARD=r/N): every rank runs the driver; rank 0 writes the
+    // block's outputs.  shardRank() / shardWorld() = 0 / 1 for an ordinary run.
+    virtual unsigned shardRank() const { return 0; }
+    virtual unsigned shardWorld() const { return 1; }
     virtual void exportCsr(HostGraph &out) = 0;
     // PAlgorithm::travelSequence for every (contig, orientation) of ctgSet (PAssembly.cpp:30-36): fills `graph` with (at
     // least) the vertices on the travel sequences and travelled[2 * contig + (reverse ? 1 : 0)].  The product backend

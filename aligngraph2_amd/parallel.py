@@ -535,6 +535,38 @@ def _exchange_selected(sb, regions, dist, cdev, device, all_gather):
     return tot
 
 
+def native_comm(hip, dist, device_ordinal, transport=None):
+    """The library's own communicator (include/pagraph_hip.h: pag_comm) for the ranks of `dist`: a rendezvous directory is
+    made by rank 0 and announced through torch.distributed; the bulk exchanges then run inside the library (RCCL over xGMI,
+    or the "host" transport when the ranks share one device) — no torch tensors in the data path."""
+    import tempfile
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [tempfile.mkdtemp(prefix="pagshard_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    hip.pag_comm_create.restype = _C.c_void_p
+    hip.pag_comm_create.argtypes = [_C.c_int, _C.c_int, _C.c_char_p, _C.c_int, _C.c_char_p, _C.POINTER(_C.c_int)]
+    hip.pag_comm_destroy.argtypes = [_C.c_void_p]
+    hip.pag_comm_bytes_sent.argtypes = [_C.c_void_p]
+    hip.pag_comm_bytes_sent.restype = _C.c_uint64
+    hip.pag_shard_run.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_void_p, _C.POINTER(BuildStats)]
+    hip.pag_shard_run.restype = _C.c_int
+    err = _C.c_int()
+    c = hip.pag_comm_create(rank, world, box[0].encode(), device_ordinal, transport.encode() if transport else None, _C.byref(err))
+    if not c:
+        raise RuntimeError(f"pag_comm_create failed ({err.value}): {hip.pag_last_error().decode()}")
+    return c, box[0]
+
+
+def build_sharded_native(hip, g, comm, inp, regions):
+    """build_sharded with the exchanges inside the library (pag_shard_run): regions = regions_for(...) of ALL ranks"""
+    arr = (Region * len(regions))(*[r["region"] for r in regions])
+    st = BuildStats()
+    rc = hip.pag_shard_run(_C.c_void_p(g), _C.c_void_p(comm), _C.byref(inp), arr, _C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"pag_shard_run failed ({rc}): {hip.pag_last_error().decode()}")
+    return st
+
+
 def deal_contigs(lengths, world, ref_begin=None):
     """contigs -> ranks for the traversal.  Without positions: longest first (assign_blocks).  ref_begin[c] = where contig c
     maps to on the reference (single coordinate): CONTIGUOUS runs of contigs in reference order, balanced by length — the

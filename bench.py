@@ -253,6 +253,11 @@ def main():
         halo = int(os.environ.get("PAG_SHARD_HALO", "200000"))
         regions = None if os.environ.get("PAG_SHARD_WHOLE_GRAPH") == "1" else \
             parallel.regions_for(deal, [e - s for s, e, _ in w.ctgs], orient, ctg_alns, [len(ref_np)], halo=halo)
+        # the exchanges run inside the library (pag_shard_run: RCCL over xGMI, device buffers, no torch tensors in the data
+        # path); PAG_SHARD_TORCH_EXCHANGE=1 keeps the torch.distributed version of the same steps (parallel.build_sharded)
+        native = regions is not None and os.environ.get("PAG_SHARD_TORCH_EXCHANGE") != "1"
+        if native:
+            shard_comm, shard_dir = parallel.native_comm(hip, dist, local, "host" if one_device else "rccl")
 
         class TravelParams(C.Structure):
             _fields_ = [("ref_threads", C.c_uint32), ("reserved", C.c_uint32), ("deviation", C.c_uint64), ("error_rate", C.c_double),
@@ -264,7 +269,10 @@ def main():
         # the travel sequences gathered, rank 0 selects the chains and writes the outputs
         nonlocal st
         tp0 = time.perf_counter()
-        st = parallel.build_sharded(hip, g, inp, spec.eps, dist, dev_name, regions=regions)
+        if native:
+            st = parallel.build_sharded_native(hip, g, shard_comm, inp, regions)
+        else:
+            st = parallel.build_sharded(hip, g, inp, spec.eps, dist, dev_name, regions=regions)
         wall["process"] += time.perf_counter() - tp0
         if args.build_only:
             return

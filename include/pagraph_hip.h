@@ -285,6 +285,31 @@ int pag_shard_set_region(pag_graph *g, const pag_region *region);
 /* hands back the device memory of the build stages (inputs, streams, scratch, the owner's slice and selections) once the
  * rank has imported what it traverses; the imported graph stays.  The solid set stays too. */
 int pag_shard_release_build(pag_graph *g);
+/* (internal to the library's own exchange: the graph arrays were received into the import buffers) */
+int pag_shard_adopt(pag_graph *g, uint64_t n_t, uint64_t n_e, const pag_build_stats *stats);
+
+/* ---- the communicator of a sharded run and the whole sharded build behind one call --------------------------------
+ * One process per GPU of ONE node.  rendezvous_dir: a directory all ranks see (e.g. under /dev/shm), fresh per job; small
+ * host tables and the RCCL unique id go through files in it.  transport "rccl" (NULL = default): the bulk all-to-all(v)s of
+ * device buffers are grouped ncclSend / ncclRecv over xGMI (librccl loaded at run time); "host": through files of the
+ * rendezvous directory — for ranks that share ONE device, where RCCL refuses to work (single-GPU test boxes).
+ * Every rank calls the collectives in the same order. */
+typedef struct pag_comm pag_comm;
+pag_comm *pag_comm_create(int rank, int world, const char *rendezvous_dir, int device_ordinal, const char *transport, int *err);
+void pag_comm_destroy(pag_comm *c);
+int pag_comm_rank(const pag_comm *c);
+int pag_comm_world(const pag_comm *c);
+uint64_t pag_comm_bytes_sent(const pag_comm *c); /* payload of the bulk exchanges that left this rank so far */
+int pag_comm_barrier(pag_comm *c);
+int pag_comm_all_gather(pag_comm *c, const void *mine_host, uint64_t bytes, void *all_host);
+int pag_comm_gather_v(pag_comm *c, const void *mine_host, uint64_t bytes, int root, void *out_host, uint64_t out_cap, uint64_t *sizes,
+                      uint64_t *need);
+int pag_comm_all_to_all_v(pag_comm *c, const void *send_dev, const uint64_t *send_bytes, void *recv_dev, const uint64_t *recv_bytes);
+/* pag_process for ONE block over all ranks of `c` (every rank passes the same prepared input): own read range extracted,
+ * tuples to their k-mer owners, K2-K4 on the owned range, every rank's region (regions[world], the same array on all
+ * ranks: pag_shard_select) sent to it and received straight into the handle's graph; the handle then holds what THIS
+ * rank's traversals need (pag_shard_set_region done, the build's memory released).  total: the block's count lines. */
+int pag_shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const pag_region *regions, pag_build_stats *total);
 
 /* sizes of the finished graph, then the graph itself into caller buffers */
 int pag_csr_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges);

@@ -150,6 +150,32 @@ def test_two_pagraph_processes_share_the_device(workdir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("name", ["join_fwd_t1", "join_rev_t16", "three_ctg_multi_t4", "two_blocks_both_orient_t16"])
+def test_one_block_built_by_several_pagraph_processes(name, world, workdir):
+    """PAGRAPH_SHARD=r/N: N drop-in processes (one per GPU on a real node; here they share the one device and exchange
+    through the rendezvous directory, PAGRAPH_SHARD_TRANSPORT=host) build every config block TOGETHER — reads split for the
+    extraction, k-mer ranges for sort / cluster / edges, every rank holding only the region of the graph its contigs need —
+    and rank 0 writes the outputs: byte for byte the reference's golden files."""
+    import tempfile
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / f"shardexe{world}" / name / "in"))
+    out = str(workdir / f"shardexe{world}" / name / "out")
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    rdv = tempfile.mkdtemp(prefix="pagshard_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PAGRAPH_SHARD=f"{r}/{world}", PAGRAPH_SHARD_DIR=rdv, PAGRAPH_SHARD_TRANSPORT="host", PAG_COMM_TIMEOUT_S="120",
+                   PAG_DEVICE_SHARERS=str(world))
+        procs.append(subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    for r, pr in enumerate(procs):
+        so, se = pr.communicate(timeout=300)
+        assert pr.returncode == 0, f"rank {r}: " + se[-2000:] + so[-1000:]
+    goldens.compare_out_dir(name, out)
+
+
+@pytest.mark.gpu
 def test_config_blocks_dealt_out_over_processes_equal_the_golden(workdir):
     """PAGRAPH_BLOCKS: the blocks of one config.txt processed by different bin/pagraph processes (what parallel.
     run_config_blocks does with one process per GPU) — here one after the other on the one GPU — and contig.txt merged."""

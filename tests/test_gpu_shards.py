@@ -298,3 +298,32 @@ def test_bench_shard_mode_two_processes_equal_one(workdir):
         assert d1["config"][kk] == d2["config"][kk], kk
     # (rank 0 holds its region of the graph, not the whole of it)
     assert d2["config"]["vertices"] < d1["config"]["vertices"]
+
+
+@pytest.mark.gpu
+def test_library_communicator_over_rccl_with_itself():
+    """The RCCL transport of the library's communicator (grouped ncclSend / ncclRecv of device buffers) cannot be run between
+    two ranks on a one-GPU box; a world of ONE exercises every RCCL call it makes (library loaded at run time, unique id
+    through the rendezvous directory, communicator, a grouped send / receive with itself)."""
+    import tempfile
+    import torch
+    hip = pagctl.hip_lib()
+    hip.pag_comm_create.restype = C.c_void_p
+    hip.pag_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+    hip.pag_comm_all_to_all_v.argtypes = [C.c_void_p] * 5
+    hip.pag_comm_destroy.argtypes = [C.c_void_p]
+    os.environ["PAG_COMM_FORCE_RCCL"] = "1"
+    try:
+        d = tempfile.mkdtemp(prefix="pagcomm_")
+        err = C.c_int()
+        c = hip.pag_comm_create(0, 1, d.encode(), 0, b"rccl", C.byref(err))
+        assert c, hip.pag_last_error()
+        src = torch.arange(1 << 20, dtype=torch.int32, device="cuda")
+        dst = torch.zeros_like(src)
+        n = (C.c_uint64 * 1)(src.numel() * 4)
+        assert hip.pag_comm_all_to_all_v(c, src.data_ptr(), n, dst.data_ptr(), n) == 0, hip.pag_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst)
+        hip.pag_comm_destroy(c)
+    finally:
+        os.environ.pop("PAG_COMM_FORCE_RCCL", None)
