@@ -76,7 +76,8 @@ $(B)/graph_input.o: tests/harness/graph_input.cpp tests/harness/graph_input.hpp 
 
 HOST_NOHIP_OBJS := $(filter-out $(B)/host/hip_backend.o $(B)/host/traverse_api.o,$(HOST_OBJS)) $(B)/graph_input.o
 HARNESS := tests/harness/bin/oracle_graph_dump tests/harness/bin/libpagh_test.so tests/harness/bin/pagraph_oracle \
-           tests/harness/bin/seg_kernels_test tests/harness/bin/sort_bench tests/harness/bin/libpagh_walk_test.so
+           tests/harness/bin/seg_kernels_test tests/harness/bin/sort_bench tests/harness/bin/libpagh_walk_test.so \
+           tests/harness/bin/libpagh_stitch_test.so
 harness: $(HARNESS)
 
 # kernel-level check of K3/K4 against a sequential restatement (needs a GPU to run)
@@ -110,6 +111,11 @@ tests/harness/bin/pagraph_oracle: tests/harness/pagraph_oracle.cpp $(HOST_NOHIP_
 tests/harness/bin/libpagh_walk_test.so: tests/harness/pagh_walk_test.cpp $(HOST_NOHIP_OBJS) $(B)/host_walk.o aligngraph2_amd/libpagraph_hip.so
 	@mkdir -p tests/harness/bin
 	$(CXX) $(CXXFLAGS) -Itests/harness -shared -o $@ $< $(HOST_NOHIP_OBJS) $(B)/host_walk.o -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/../../../aligngraph2_amd' -pthread
+
+# the host bookkeeping of walks cut into pieces (walk_stitch.hpp: plain C++, no device code) for CPU unit tests
+tests/harness/bin/libpagh_stitch_test.so: tests/harness/stitch_test.cpp $(HIP_DIR)/walk_stitch.hpp
+	@mkdir -p tests/harness/bin
+	$(CXX) $(CXXFLAGS) -I$(HIP_DIR) -shared -o $@ $<
 
 clean:
 	rm -rf $(B) aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin tests/harness/bin

@@ -1,0 +1,315 @@
+// walk_stitch.hpp — the host bookkeeping of a graphTravel that was walked in PIECES (k5_travel_host.hip, "PIECES"): the
+// validated path of a chain as a list of parts, and the conditions under which the rest of a finished segment's path is
+// adopted by a chain (try_merge outside the leaping zone, try_merge_leap inside it).  No device code, no HIP: plain data in,
+// a decision out — unit-tested on recorded job outputs (tests/test_walk_stitch.py through tests/harness/stitch_test.cpp).
+//
+// Reference semantics these conditions protect: PAlgorithm::graphTravel / walkStraight / classifySuccessors
+// (PAGraph/src/tools/graph/PAlgorithm.tcc:35-298) — an adoption must leave the path vertex for vertex what the un-cut walk
+// produces.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace pagdev {
+namespace stitch {
+
+struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
+    std::vector<uint32_t> v, s, pc;
+};
+struct View {  // a finished job's path where the fetch put it (pinned memory kept for the whole call)
+    const uint32_t *v = nullptr, *s = nullptr, *pc = nullptr;
+    const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: iteration log, low / high words
+    size_t n = 0;
+};
+struct Seg {  // one segment job of a round
+    uint32_t x = 0;      // checkpoint coordinate
+    uint32_t stop = 0;   // its stop coordinate
+    uint32_t vid = 0;    // start vertex (old id)
+    uint32_t win_lo = 0, win_hi = 0;  // new-id range its job keeps direct-mapped marks for (around the segment)
+    bool done = false, usable = false, stopped = false;
+    View P;  // (everything the splices need of it is computed from the arrays when a chain arrives: a few thousand entries)
+    uint32_t max_back = 0, max_chosen = 0;
+    uint64_t max_probe = 0;
+    // a segment inside the leaping zone (TRAV_MODE_LEAP), see try_merge_leap:
+    bool leap = false;
+    uint32_t wd_below_max = 0, wd_forced_min = 0xFFFFFFFFu, win_low = 0;
+};
+struct Chain {  // one graphTravel: (contig, seed) of the running round
+    // The validated path so far, T, is a list of parts that stay where the fetches put them (pinned memory kept for the
+    // whole call): a job's new vertices, an adopted stretch of a segment's path.  Nothing is copied when T grows; the
+    // flat arrays a resumed walk or the splice needs are put together when they are needed.  Per part: where it starts in
+    // T and, over everything BEFORE it, the highest coordinate and the highest id (+ 1) of a vertex without a coordinate.
+    struct Part {
+        const uint32_t *v, *s, *pc;
+        size_t n, start;
+        uint32_t mx, m0;
+    };
+    std::vector<Part> parts;
+    size_t len = 0;  // vertices of T
+    uint32_t mx_all = 0, m0_all = 0;  // ... over all of T
+    uint32_t low_nz = 0xFFFFFFFFu;   // lowest non-zero coordinate of T
+    uint64_t size = 0;  // sum of its steps
+    bool final = false;
+    int waiting_seg = -1;  // the segment whose job this chain waits for
+    int next_seg = 0;
+    uint32_t grow = 1;
+    bool exact = false;
+    int job = -1;          // outstanding job number, -1: none
+    // the job that is outstanding (to repeat it with larger buffers / without speculation)
+    uint32_t job_mode = 0, job_stop = 0;
+};
+struct RoundState {
+    uint32_t round = 0;
+    bool active = false;
+    std::vector<Seg> segs;
+    std::vector<Chain> chains;
+    uint32_t zone_end = 0;  // coordinate from which the walk is no longer cut (0: no segments this round)
+    uint32_t live_jobs = 0;
+    uint64_t has_size = 0;
+};
+
+// T grows by a job's new vertices or by an adopted stretch of a segment
+struct PartAgg {  // over the vertices of a part: highest coordinate, highest id + 1 of a coordinate-free vertex, lowest
+                  // non-zero coordinate, sum of the steps
+    uint32_t mx = 0, m0 = 0, lo = 0xFFFFFFFFu;
+    uint64_t sz = 0;
+    void add(uint32_t v, uint32_t st, uint32_t c) {
+        mx = std::max(mx, c);
+        if (c == 0) m0 = std::max(m0, v + 1u);  // (id + 1: 0 stands for "none")
+        else lo = std::min(lo, c);
+        sz += st;
+    }
+};
+inline void extend_chain(Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n, const PartAgg *known = nullptr) {
+    if (n == 0) return;
+    ch.parts.push_back(Chain::Part{v, sv, pc, n, ch.len, ch.mx_all, ch.m0_all});
+    ch.len += n;
+    PartAgg a;
+    if (known) a = *known;  // (the caller has been over the part already)
+    else
+        for (size_t x = 0; x < n; ++x) a.add(v[x], sv[x], pc[x]);
+    ch.mx_all = std::max(ch.mx_all, a.mx);
+    ch.m0_all = std::max(ch.m0_all, a.m0);
+    ch.low_nz = std::min(ch.low_nz, a.lo);
+    ch.size += a.sz;
+}
+// the part of T that holds index idx (idx < ch.len)
+inline size_t part_of(const Chain &ch, size_t idx) {
+    size_t lo = 0, hi = ch.parts.size() - 1;
+    while (lo < hi) {
+        const size_t mid = (lo + hi + 1) / 2;
+        if (ch.parts[mid].start <= idx) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+// highest coordinate / highest id + 1 of a coordinate-free vertex over T[0 .. idx)
+inline void chain_before(const Chain &ch, size_t idx, uint32_t *mx_out, uint32_t *m0_out) {
+    uint32_t mx = 0, m0 = 0;
+    if (idx > 0 && !ch.parts.empty()) {
+        const size_t pi = part_of(ch, idx - 1);
+        const Chain::Part &pt = ch.parts[pi];
+        mx = pt.mx;
+        m0 = pt.m0;
+        for (size_t x = 0; x < idx - pt.start; ++x) {
+            mx = std::max(mx, pt.pc[x]);
+            if (pt.pc[x] == 0) m0 = std::max(m0, pt.v[x] + 1u);
+        }
+    }
+    *mx_out = mx;
+    *m0_out = m0;
+}
+// T as flat arrays (vertices / steps / coordinates; a null destination is skipped)
+inline void flatten_chain(const Chain &ch, uint32_t *dv, uint32_t *ds, uint32_t *dpc) {
+    for (const Chain::Part &pt : ch.parts) {
+        if (dv) std::memcpy(dv + pt.start, pt.v, pt.n * 4);
+        if (ds) std::memcpy(ds + pt.start, pt.s, pt.n * 4);
+        if (dpc) std::memcpy(dpc + pt.start, pt.pc, pt.n * 4);
+    }
+}
+// how many vertices T and a segment's path P have in common going backwards from T's last vertex = P[be] (beyond that
+// pair itself: same vertices, same steps from the second common vertex on)
+inline size_t common_back(const Chain &ch, const View &P, size_t be) {
+    size_t t = 0;
+    if (ch.len == 0) return 0;
+    size_t pi = ch.parts.size() - 1, off = ch.parts[pi].n;  // T[e - t] = parts[pi][off - 1] while walking back
+    // invariant: (pi, off - 1) addresses T[e - t]
+    while (t < ch.len - 1 && t < be) {
+        // step of T[e - t] and vertex of T[e - t - 1]
+        const uint32_t st_cur = ch.parts[pi].s[off - 1];
+        size_t pj = pi, oj = off - 1;  // (pj, oj - 1) will address T[e - t - 1]
+        if (oj == 0) {
+            pj = pi - 1;
+            oj = ch.parts[pj].n;
+        }
+        if (ch.parts[pj].v[oj - 1] != P.v[be - t - 1] || st_cur != P.s[be - t]) break;
+        ++t;
+        pi = pj;
+        off = oj;
+    }
+    return t;
+}
+
+
+// what a splice needs to know about the round it happens in
+struct MergeCtx {
+    uint32_t k = 0;
+    uint64_t deviation = 0;
+    uint64_t split = 0;     // (uint64_t)(contig length * startSplit): from hasSize + nowSize >= split on a walk can leap
+    uint64_t has_size = 0;  // the round's hasSize (sum of the steps of the contig's path so far)
+};
+
+// Adoption of a finished segment by a chain whose last vertex lies inside it.
+//
+// Let T be the chain's path (its walk stands at an iteration boundary of graphTravel behind T's last vertex) and P the
+// segment's path.  Condition: the last vertex of T is P[be], and going backwards T and P agree on t + 1 vertices
+// (T[e - j] == P[be - j], same steps from the second common vertex on).  While leaping is impossible every successor a
+// classification can accept follows the contig (isEdgeSimilar on the contig coordinate: PABruijnGraph.cpp:385-400 and the
+// grade table of checkPosition :158-164 leave nothing else once Skip and leaps are excluded, PAlgorithm.tcc:69-86), so
+//   (a) the coordinate windows (existCtgPos) never decide anything, and
+//   (b) an accepted successor of a vertex at coordinate c lies at >= c + step - deviation > c - deviation.
+// Hence the ONLY state through which the past acts on the continuation are the visited sets, and the two walks differ in
+// them by D = vertices of T before the common stretch (+) vertices of P before it.  P's job reports how far below the
+// coordinate of an iteration's branch vertex any of its probes went (max_back) and how long its chosen paths were
+// (max_chosen): every candidate vertex the segment's walk examined in an iteration that contributes a vertex behind P[be]
+// has a coordinate > min(coord of P[q ..]) - max_back - deviation with q = be + 1 - max_chosen.  If that bound exceeds
+// the largest coordinate in D, no vertex of D was ever a candidate: the real walk, continuing from T, takes exactly P's
+// decisions, and P[be + 1 ..] is its path — as far as leaping stays impossible for it, which is checked with the true
+// sizes: hasSize + k + (steps of T) + (steps adopted) + (largest probe of the segment's walk) < split size.
+// Returns 0: not adoptable (now), 1: adopted up to the end of P, 2: adopted up to where leaping may begin.
+inline int try_merge(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adopted) {
+    const View &P = sg.P;
+    if (!sg.usable || ch.len == 0 || P.n == 0) return 0;
+    const size_t e = ch.len - 1;
+    const uint32_t last_v = ch.parts.back().v[ch.parts.back().n - 1];
+    size_t be = P.n;  // the last vertex of T in P
+    for (size_t x = 0; x < P.n; ++x)
+        if (P.v[x] == last_v) {
+            be = x;
+            break;
+        }
+    if (be == P.n) return 0;
+    const size_t t = common_back(ch, P, be);
+    const size_t a = e - t, b = be - t;
+    if (t < 4) return 0;
+    uint32_t dT = 0, d0 = 0, dP = 0;
+    chain_before(ch, a, &dT, &d0);
+    for (size_t x = 0; x < b; ++x) dP = std::max(dP, P.pc[x]);
+    const uint64_t dmax = std::max(dT, dP);
+    const size_t q = be + 1 > sg.max_chosen ? be + 1 - sg.max_chosen : 0;
+    const uint64_t split = M.split;
+    const uint64_t base = M.has_size + M.k + ch.size + sg.max_probe + 1;
+    if (base >= split) return 0;  // (no room: the caller resumes exactly)
+    const uint64_t room = split - base;  // steps that may still be adopted
+    // ONE pass over P[q ..]: the lowest coordinate (condition 2), how far the steps behind P[be] stay below `room`
+    // (condition 3: `last`), and what the chain has to know about the adopted stretch
+    uint64_t low = 0xFFFFFFFFull;
+    for (size_t x = q; x <= be; ++x) low = std::min<uint64_t>(low, P.pc[x]);
+    size_t last = be;
+    PartAgg agg;
+    bool open = true;
+    for (size_t x = be + 1; x < P.n; ++x) {
+        low = std::min<uint64_t>(low, P.pc[x]);
+        if (open && agg.sz + P.s[x] < room) {
+            agg.add(P.v[x], P.s[x], P.pc[x]);
+            last = x;
+        } else {
+            open = false;
+        }
+    }
+    if (low <= dmax + sg.max_back + M.deviation) return 0;
+    if (last == be && last + 1 < P.n) return 0;
+    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg);
+    if (adopted) *adopted += last - be;
+    return last + 1 == P.n ? 1 : 2;
+}
+
+// Adoption of a finished segment of the LEAPING zone (TRAV_MODE_LEAP).  Leaping being possible, a classification admits
+// more: Skip grades and landings on other contigs (PAlgorithm.tcc:69-86), hence vertices without a contig coordinate on
+// the paths and records whose fate the coordinate windows decide (existCtgPos).  What an examined record's verdict
+// depends on, besides the record: the contig's global marks and the landing rule (the same for both walks), the probe's
+// own marks and window (fresh at an iteration boundary), the travel-visited set, the travel window, and whether leaping
+// is possible.  The splice is exact if
+//   (1) T ends at P[be], an iteration boundary of the segment's walk too (both walks classify that vertex at the top
+//       level next, with no probe under way), and going backwards T and P agree on t + 1 >= 5 vertices and steps;
+//   (2) the real walk can leap from here on (true sizes), as the segment's walk could all along;
+//   (3) the travel windows agree: same upper end (the highest coordinate of T and of P[.. be]); the lower ends are lowM
+//       (lowest coordinate of T) and the value forced on the segment's walk (win_low): no window-dependent record it
+//       examined may lie between the two (the job reports the extremes of those records), and P[.. b) itself lies inside
+//       the real walk's window;
+//   (4) no examined record of an iteration that starts at P[be] or later leads to a vertex only ONE of the walks has
+//       visited, D = T[.. a) + P[.. b).  A record is one of three kinds.  Window-dependent (a coordinate, not following
+//       the contig): a target in D lies inside both travel windows by (3) and is rejected by both.  Contig-following: the
+//       job logs, per iteration, the lowest coordinate of any such record it examined (elow): above every coordinate
+//       in D.  No coordinate: the job logs the lowest new id of any such target (m0; these ids are ordered by the
+//       reference coordinate, trav_order): above every id of that kind in D.  Records examined by probes of earlier
+//       iterations that are still walking are logged with the iteration they are examined in.
+// Then every verdict from P[be] on is the one the real walk reaches, and P[be + 1 ..] is its path.
+// Returns 0: refused, 1: adopted to the end of P.
+inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adopted, int *why_out = nullptr) {
+    const View &P = sg.P;
+    auto refuse = [&](int why) {
+        if (why_out) *why_out = why;
+        return 0;
+    };
+    if (!sg.usable || ch.len == 0 || P.n == 0 || !P.xl) return refuse(0);
+    const size_t e = ch.len - 1;
+    const uint32_t last_v = ch.parts.back().v[ch.parts.back().n - 1];
+    size_t be = P.n;
+    for (size_t x = 0; x < P.n; ++x)
+        if (P.v[x] == last_v) {
+            be = x;
+            break;
+        }
+    if (be == P.n) return refuse(1);
+    if (!(P.xh[be] >> 31)) return refuse(2);
+    const size_t t = common_back(ch, P, be);
+    const size_t a = e - t, b = be - t;
+    if (t < 4) return refuse(1);
+    const uint64_t split = M.split;
+    if (M.has_size + M.k + ch.size < split) return refuse(3);
+    // P[0 .. be]: highest coordinate; P[0 .. b): highest / lowest coordinate, highest id + 1 of a coordinate-free vertex
+    uint32_t p_top = 0, p_dmax = 0, p_min = 0xFFFFFFFFu, p_d0 = 0;
+    for (size_t x = 0; x <= be; ++x) {
+        const uint32_t c = P.pc[x];
+        p_top = std::max(p_top, c);
+        if (x < b) {
+            p_dmax = std::max(p_dmax, c);
+            if (c == 0) p_d0 = std::max(p_d0, P.v[x] + 1u);
+            else p_min = std::min(p_min, c);
+        }
+    }
+    if (ch.mx_all != p_top) return refuse(4);
+    const uint32_t lowM = ch.low_nz;
+    if (sg.wd_below_max != 0u && sg.wd_below_max >= lowM) return refuse(5);
+    if (sg.wd_forced_min < lowM) return refuse(5);
+    if (p_min < lowM) return refuse(5);
+    // ONE pass over P[be ..]: the iterations that start at a boundary >= be (lowest contig-following coordinate /
+    // coordinate-free id examined), and what the chain has to know about the adopted stretch
+    uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+    PartAgg agg;
+    for (size_t x = be; x < P.n; ++x) {
+        if (P.xh[x] >> 31) {
+            elow = std::min(elow, P.xh[x] & 0x7FFFFFFFu);
+            m0 = std::min(m0, P.xl[x]);
+        }
+        if (x > be) agg.add(P.v[x], P.s[x], P.pc[x]);
+    }
+    uint32_t t_dmax = 0, t_d0 = 0;
+    chain_before(ch, a, &t_dmax, &t_d0);
+    const uint32_t dmax = std::max(t_dmax, p_dmax);
+    if (elow <= dmax) return refuse(6);
+    const uint32_t d0 = std::max(t_d0, p_d0);  // (id + 1, 0: none)
+    if (d0 != 0u && m0 != 0xFFFFFFFFu && m0 + 1u <= d0) return refuse(7);
+    const size_t last = P.n - 1;
+    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg);
+    if (adopted) *adopted += last - be;
+    if (why_out) *why_out = -1;
+    return 1;
+}
+
+
+}  // namespace stitch
+}  // namespace pagdev

@@ -4,7 +4,12 @@
 both whole programs, file parsing included.  Writes a JSON record that bench.py quotes as the like-for-like CPU baseline
 (`cpu_baseline.full_workload`) and as `file_to_file_bases_per_s`; the record is committed under profiles/.
 
-usage: python tests/c2_text_runs.py OUT.json [--reads N --ref-len L]"""
+--compare: the reference runs with `-t 16` under the thread-serialising shim (oracle/_ref/libserial_threads.so: the
+deterministic order the product reproduces) instead, its output directory is kept, and EVERY output file of the
+drop-in executable is compared with it byte for byte (contig.txt as a set, quirk Q11): the whole product — parsers,
+pag_prepare, build, device walkers, writers — pinned once at full BASELINE configs[1] size.
+
+usage: python tests/c2_text_runs.py OUT.json [--reads N --ref-len L] [--compare]"""
 import argparse
 import json
 import os
@@ -26,6 +31,7 @@ def main():
     ap.add_argument("--ref-len", type=int, default=50_000_000)
     ap.add_argument("--ref-threads", type=int, default=64)
     ap.add_argument("--skip-reference", action="store_true", help="only time the drop-in executable")
+    ap.add_argument("--compare", action="store_true", help="reference -t 16 under the serialising shim; byte-compare all output files")
     args = ap.parse_args()
     import biggen
     import synth
@@ -43,7 +49,10 @@ def main():
     print(rec, flush=True)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "pagraph")
     ours = os.path.join(ROOT, "aligngraph2_amd", "bin", "pagraph")
-    for name, exe, threads, env in (("reference", ref_bin, args.ref_threads, {}), ("ours", ours, 16, {"PAGRAPH_TIMING": "1"})):
+    ref_env, ref_threads = {}, args.ref_threads
+    if args.compare:
+        ref_env, ref_threads = {"LD_PRELOAD": os.path.join(ROOT, "oracle", "_ref", "libserial_threads.so")}, 16
+    for name, exe, threads, env in (("ours", ours, 16, {"PAGRAPH_TIMING": "1"}), ("reference", ref_bin, ref_threads, ref_env)):
         if name == "reference" and args.skip_reference:
             continue
         out = f"/dev/shm/c2_out_{name}"
@@ -58,7 +67,28 @@ def main():
                      "count_lines": [ln.strip() for ln in r.stdout.splitlines() if ln.strip().startswith(("merge edge", "total pos", "merge pos"))],
                      "stderr_tail": r.stderr[-3000:] if name == "ours" else r.stderr[-300:]}
         print(name, rec[name]["wall_s"], rec[name]["bases_per_s"], flush=True)
-        shutil.rmtree(out, ignore_errors=True)
+        if not args.compare:
+            shutil.rmtree(out, ignore_errors=True)
+    if args.compare and "reference" in rec and rec["reference"]["returncode"] == 0 and rec["ours"]["returncode"] == 0:
+        a, b = "/dev/shm/c2_out_reference", "/dev/shm/c2_out_ours"
+        fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+        diff, total_bytes = [], 0
+        for f in sorted(set(fa) | set(fb)):
+            if f not in fa or f not in fb:
+                diff.append(f + " (missing on one side)")
+                continue
+            x, y = open(os.path.join(a, f), "rb").read(), open(os.path.join(b, f), "rb").read()
+            total_bytes += len(x)
+            if f == "contig.txt":
+                x, y = sorted(x.split()), sorted(y.split())
+            if x != y:
+                diff.append(f)
+        rec["compare"] = {"reference": "oracle/_ref/pagraph -t 16 under libserial_threads.so", "files_reference": len(fa), "files_ours": len(fb),
+                          "bytes_compared": total_bytes, "differing_files": diff, "identical": not diff and fa == fb,
+                          "count_lines_equal": rec["reference"]["count_lines"] == rec["ours"]["count_lines"]}
+        print("compare:", rec["compare"], flush=True)
+        shutil.rmtree(a, ignore_errors=True)
+        shutil.rmtree(b, ignore_errors=True)
     shutil.rmtree(d, ignore_errors=True)
     json.dump(rec, open(args.out, "w"), indent=1)
 

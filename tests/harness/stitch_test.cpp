@@ -1,0 +1,71 @@
+// tests/harness/stitch_test.cpp — TEST SUPPORT (never part of the product).
+// C wrappers over the host bookkeeping of a walk cut into pieces (aligngraph2_amd/csrc/hip/walk_stitch.hpp) so that
+// tests/test_walk_stitch.py can drive the adoption conditions on recorded / constructed job outputs without a GPU.
+#include <cstdint>
+#include <vector>
+
+#include "walk_stitch.hpp"
+
+using namespace pagdev::stitch;
+
+extern "C" {
+
+// A chain T made of `n_parts` parts (part p = vertices [part_off[p], part_off[p + 1]) of the flat arrays) meets a segment P.
+// leap = 0: try_merge, 1: try_merge_leap (xl / xh: the iteration log).  out[0] = decision, out[1] = vertices adopted,
+// out[2] = refusal reason (leap), out[3] = chain length afterwards, out[4] = chain size (sum of steps) afterwards,
+// out[5] = mx_all afterwards.  tail_out (may be null): the adopted vertices.
+int pagt_stitch(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, const uint32_t *pv,
+                const uint32_t *ps, const uint32_t *ppc, const uint32_t *pxl, const uint32_t *pxh, uint64_t pn, uint32_t max_back, uint32_t max_chosen,
+                uint64_t max_probe, uint32_t wd_below_max, uint32_t wd_forced_min, int usable, uint32_t k, uint64_t deviation, uint64_t split,
+                uint64_t has_size, int leap, uint64_t *out, uint32_t *tail_out) {
+    Chain ch;
+    for (uint32_t p = 0; p < n_parts; ++p)
+        extend_chain(ch, tv + part_off[p], ts + part_off[p], tpc + part_off[p], (size_t)(part_off[p + 1] - part_off[p]));
+    Seg sg;
+    sg.P.v = pv;
+    sg.P.s = ps;
+    sg.P.pc = ppc;
+    sg.P.xl = pxl;
+    sg.P.xh = pxh;
+    sg.P.n = (size_t)pn;
+    sg.usable = usable != 0;
+    sg.done = true;
+    sg.leap = leap != 0;
+    sg.max_back = max_back;
+    sg.max_chosen = max_chosen;
+    sg.max_probe = max_probe;
+    sg.wd_below_max = wd_below_max;
+    sg.wd_forced_min = wd_forced_min;
+    MergeCtx M;
+    M.k = k;
+    M.deviation = deviation;
+    M.split = split;
+    M.has_size = has_size;
+    const size_t before = ch.len;
+    uint64_t adopted = 0;
+    int why = -1;
+    const int m = leap ? try_merge_leap(M, ch, sg, &adopted, &why) : try_merge(M, ch, sg, &adopted);
+    out[0] = (uint64_t)m;
+    out[1] = adopted;
+    out[2] = (uint64_t)(int64_t)why;
+    out[3] = ch.len;
+    out[4] = ch.size;
+    out[5] = ch.mx_all;
+    if (tail_out && ch.len > before) {
+        std::vector<uint32_t> flat(ch.len);
+        flatten_chain(ch, flat.data(), nullptr, nullptr);
+        for (size_t x = before; x < ch.len; ++x) tail_out[x - before] = flat[x];
+    }
+    return 0;
+}
+
+// chain_before / common_back on their own
+void pagt_chain_before(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, uint64_t idx, uint32_t *mx,
+                       uint32_t *m0) {
+    Chain ch;
+    for (uint32_t p = 0; p < n_parts; ++p)
+        extend_chain(ch, tv + part_off[p], ts + part_off[p], tpc + part_off[p], (size_t)(part_off[p + 1] - part_off[p]));
+    chain_before(ch, (size_t)idx, mx, m0);
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+"""CPU: the adoption conditions of a walk cut into pieces (aligngraph2_amd/csrc/hip/walk_stitch.hpp: try_merge outside the
+leaping zone, try_merge_leap inside it) on constructed job outputs — each condition of the justification in that header is
+driven to both sides of its threshold, and the result is compared with an independent restatement of the conditions
+written from their description (below), not from the C++."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tests", "harness", "bin", "libpagh_stitch_test.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.run(["make", "-C", ROOT, LIB[len(ROOT) + 1:]], check=True, capture_output=True)
+    return C.CDLL(LIB)
+
+
+def _u32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+def stitch(lib, T, parts, P, *, leap=False, log=None, max_back=0, max_chosen=1, max_probe=0, wd_below=0, wd_forced=0xFFFFFFFF, usable=True,
+           k=14, dev=20, split=10 ** 9, has_size=0):
+    """T, P: lists of (vertex, step, coordinate); parts: lengths of T's parts; log: per P entry (boundary?, elow, m0)"""
+    tv, ts, tpc = (_u32([x[i] for x in T]) for i in range(3))
+    pv, ps, ppc = (_u32([x[i] for x in P]) for i in range(3))
+    off = np.concatenate([[0], np.cumsum(parts)]).astype(np.uint64)
+    assert int(off[-1]) == len(T)
+    xl = xh = None
+    if log is not None:
+        xl = _u32([m0 for _, _, m0 in log])
+        xh = _u32([((1 << 31) | (elow & 0x7FFFFFFF)) if b else 0 for b, elow, _ in log])
+    out = (C.c_uint64 * 6)()
+    tail = np.zeros(len(P) + 1, dtype=np.uint32)
+    lib.pagt_stitch.argtypes = [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                                                     C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                                                                     C.c_void_p, C.c_void_p]
+    lib.pagt_stitch(tv.ctypes.data, ts.ctypes.data, tpc.ctypes.data, off.ctypes.data, len(parts), pv.ctypes.data, ps.ctypes.data, ppc.ctypes.data,
+                    xl.ctypes.data if xl is not None else None, xh.ctypes.data if xh is not None else None, len(P), max_back, max_chosen, max_probe,
+                    wd_below, wd_forced, int(usable), k, dev, split, has_size, int(leap), out, tail.ctypes.data)
+    decision, adopted, why = int(out[0]), int(out[1]), C.c_int64(out[2]).value
+    return decision, adopted, why, int(out[3]), int(out[4]), list(tail[:adopted])
+
+
+def line(v0, n, c0, step=3):
+    """n consecutive path vertices v0, v0 + 1, .. at coordinates c0, c0 + step, .."""
+    return [(v0 + i, step, c0 + i * step) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# outside the leaping zone
+# ---------------------------------------------------------------------------------------------------------------------
+def expect_merge(T, P, max_back, max_chosen, max_probe, k, dev, split, has_size):
+    """the conditions as walk_stitch.hpp states them in words"""
+    last = T[-1][0]
+    pv = [x[0] for x in P]
+    if last not in pv:
+        return 0, 0
+    be = pv.index(last)
+    t = 0  # common vertices going backwards beyond the pair itself (same vertices, same steps from the second one on)
+    while t < len(T) - 1 and t < be and T[-2 - t][0] == P[be - t - 1][0] and T[-1 - t][1] == P[be - t][1]:
+        t += 1
+    if t < 4:
+        return 0, 0
+    a, b = len(T) - 1 - t, be - t
+    dmax = max([x[2] for x in T[:a]] + [x[2] for x in P[:b]] + [0])
+    size_T = sum(x[1] for x in T)
+    base = has_size + k + size_T + max_probe + 1
+    if base >= split:
+        return 0, 0
+    room = split - base
+    q = max(0, be + 1 - max_chosen)
+    low = min(x[2] for x in P[q:])
+    lastx, acc = be, 0
+    for x in range(be + 1, len(P)):
+        if acc + P[x][1] < room:
+            acc += P[x][1]
+            lastx = x
+        else:
+            break
+    if low <= dmax + max_back + dev:
+        return 0, 0
+    if lastx == be and be + 1 < len(P):
+        return 0, 0
+    return (1 if lastx + 1 == len(P) else 2), lastx - be
+
+
+@pytest.mark.parametrize("case", ["adopt", "short_overlap", "step_mismatch", "not_on_segment", "d_too_close", "d_just_far_enough", "probe_went_back",
+                                  "room_runs_out", "no_room", "unusable", "parts"])
+def test_try_merge(lib, case):
+    kw = dict(max_back=0, max_chosen=2, max_probe=50, k=14, dev=20, split=10 ** 7, has_size=0)
+    P = line(1000, 40, 5000, step=10)
+    T = line(100, 10, 4000) + P[5:12]          # the chain reached P[11] walking P[5..11] itself: 6 common vertices behind the pair
+    parts = [10, 7]
+    if case == "short_overlap":
+        T = line(100, 10, 4000) + P[8:12]       # 3 common vertices only
+        parts = [10, 4]
+    elif case == "step_mismatch":
+        T = line(100, 10, 4000) + [(v, s + (1 if i == 5 else 0), c) for i, (v, s, c) in enumerate(P[5:12])]
+    elif case == "not_on_segment":
+        T = line(100, 17, 4000)
+        parts = [17]
+    elif case == "d_too_close":
+        T = [(100 + i, 3, 5076 + i) for i in range(10)] + P[5:12]   # a vertex only the chain has visited within reach of P's candidates
+    elif case == "d_just_far_enough":
+        # low = coord of P[be + 1 - max_chosen] = P[10] = 5100; D's highest coordinate must be < 5100 - 20 - 0
+        T = line(100, 10, 4000)[:-1] + [(199, 3, 5079)] + P[5:12]
+    elif case == "probe_went_back":
+        kw["max_back"] = 1100                    # a probe of the segment's walk went 1100 below its branch vertex: D is within its reach
+    elif case == "room_runs_out":
+        kw["split"] = 14 + sum(x[1] for x in T) + 50 + 1 + 10 * 10   # room for 9 more steps of 10 (strictly below)
+    elif case == "no_room":
+        kw["split"] = 14 + sum(x[1] for x in T) + 50
+    elif case == "parts":
+        parts = [3, 4, 3, 2, 5]
+    usable = case != "unusable"
+    got = stitch(lib, T, parts, P, usable=usable, **kw)
+    want = expect_merge(T, P, kw["max_back"], kw["max_chosen"], kw["max_probe"], kw["k"], kw["dev"], kw["split"], kw["has_size"]) if usable else (0, 0)
+    assert (got[0], got[1]) == want, (case, got, want)
+    expected_decision = {"adopt": 1, "short_overlap": 0, "step_mismatch": 0, "not_on_segment": 0, "d_too_close": 0, "d_just_far_enough": 1,
+                         "probe_went_back": 0, "room_runs_out": 2, "no_room": 0, "unusable": 0, "parts": 1}[case]
+    assert got[0] == expected_decision, (case, got)
+    if got[0]:
+        be = [x[0] for x in P].index(T[-1][0])
+        assert got[5] == [x[0] for x in P[be + 1:be + 1 + got[1]]]           # the adopted stretch is P behind the junction
+        assert got[3] == len(T) + got[1] and got[4] == sum(x[1] for x in T) + sum(x[1] for x in P[be + 1:be + 1 + got[1]])
+    if case == "room_runs_out":
+        assert got[1] == 9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inside the leaping zone
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,decision,why", [("adopt", 1, -1), ("no_log", 0, 0), ("not_a_boundary", 0, 2), ("cannot_leap_yet", 0, 3),
+                                                ("window_top_differs", 0, 4), ("window_bottom_record", 0, 5), ("forced_record_below", 0, 5),
+                                                ("segment_started_below_window", 0, 5), ("contig_following_record_in_d", 0, 6),
+                                                ("coordinate_free_record_in_d", 0, 7), ("coordinate_free_record_beyond_d", 1, -1)])
+def test_try_merge_leap(lib, case, decision, why):
+    P = line(1000, 30, 90000)
+    T = line(100, 10, 80000) + P[3:13]                   # T ends at P[12]; 9 common vertices behind the pair
+    parts = [10, 10]
+    log = [(i % 4 == 0, 90000 + 3 * i - 5, 0xFFFFFFFF) for i in range(30)]   # boundaries every 4th vertex, elow a little below them
+    kw = dict(k=14, dev=20, split=1000, has_size=5000, wd_below=0, wd_forced=0xFFFFFFFF)
+    if case == "no_log":
+        log = None
+    elif case == "not_a_boundary":
+        log[12] = (False, 0, 0xFFFFFFFF)
+    elif case == "cannot_leap_yet":
+        kw["split"], kw["has_size"] = 10 ** 6, 0
+    elif case == "window_top_differs":
+        T = line(100, 9, 80000) + [(199, 3, 95000)] + P[3:13]     # the chain's window reaches higher than P[.. be]'s
+    elif case == "window_bottom_record":
+        kw["wd_below"] = 80000                                      # a window-dependent record examined at the chain's lowest coordinate
+    elif case == "forced_record_below":
+        kw["wd_forced"] = 79000
+    elif case == "segment_started_below_window":
+        P = [(999, 3, 70000)] + P
+        T = line(100, 10, 80000) + P[4:14]
+        log = [(False, 0, 0xFFFFFFFF)] + log
+        log[13] = (True, 90030, 0xFFFFFFFF)
+    elif case == "contig_following_record_in_d":
+        log[16] = (True, 80010, 0xFFFFFFFF)                         # an iteration behind the junction examined a record at a coordinate of D
+    elif case in ("coordinate_free_record_in_d", "coordinate_free_record_beyond_d"):
+        T = line(100, 9, 80000) + [(7, 3, 0)] + P[3:13]             # the chain visited coordinate-free vertex 7 before the common stretch
+        log[20] = (True, 90050, 5 if case.endswith("in_d") else 8)  # ... and a later iteration examined one at / beyond it (ids follow the reference)
+    got = stitch(lib, T, parts, P, leap=True, log=log, **kw)
+    assert (got[0], got[2]) == (decision, why), (case, got)
+    if decision:
+        be = [x[0] for x in P].index(T[-1][0])
+        assert got[1] == len(P) - 1 - be and got[5] == [x[0] for x in P[be + 1:]]
+
+
+def test_chain_before_over_parts(lib):
+    rng = np.random.default_rng(3)
+    n = 200
+    T = [(int(rng.integers(1, 10 ** 6)), 3, int(rng.integers(0, 2) * rng.integers(1, 10 ** 6))) for _ in range(n)]
+    tv, ts, tpc = (_u32([x[i] for x in T]) for i in range(3))
+    for parts in ([200], [1, 199], [50, 50, 50, 50], [7] * 28 + [4]):
+        off = np.concatenate([[0], np.cumsum(parts)]).astype(np.uint64)
+        lib.pagt_chain_before.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        for idx in (0, 1, 49, 50, 51, 199, 200):
+            mx, m0 = C.c_uint32(), C.c_uint32()
+            lib.pagt_chain_before(tv.ctypes.data, ts.ctypes.data, tpc.ctypes.data, off.ctypes.data, len(parts), idx, C.byref(mx), C.byref(m0))
+            want_mx = max([x[2] for x in T[:idx]] + [0])
+            want_m0 = max([x[0] + 1 for x in T[:idx] if x[2] == 0] + [0])
+            assert (mx.value, m0.value) == (want_mx, want_m0), (parts, idx)
