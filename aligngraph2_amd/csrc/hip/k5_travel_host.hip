@@ -621,6 +621,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         uint64_t est = 0;
         for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / sl + (uint64_t)st[i].len / ll + 32;  // (every strand as if all of it were both zones)
         while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
+        if (const char *e = std::getenv("PAG_DEBUG_RING")) QCAP = (uint32_t)std::max(4, std::atoi(e));  // tests: a ring far smaller than a round
     }
     const uint32_t NR = TRAV_RINGS;
     const size_t q_need = 256 + NR * (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
@@ -696,26 +697,42 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     };
     std::vector<std::vector<Deferred>> deferred(n_sel);
     bool defer_ring2 = false;
-    auto commit_job = [&](uint32_t ring, const TravPosted &P, const JobRef &jr2, uint32_t mode, uint32_t stop_pc) -> int {
+    // A job enters its ring when the slot it takes (its number mod QCAP) is free again; until then it waits in the ring's
+    // backlog, in posting order (a ring smaller than the jobs of a round is a matter of flow control, not an error).
+    struct Backlogged {
+        TravPosted P;
+        JobRef jr;
+    };
+    std::deque<Backlogged> backlog[TRAV_RINGS];
+    auto place_job = [&](uint32_t ring, const TravPosted &P, const JobRef &jr2) -> bool {
         const uint32_t jn = n_posted[ring], slot = ring * QCAP + jn % QCAP;
-        if (jref[slot].live) {
-            set_error("pag_travel: the job ring is full (%u jobs in flight)", QCAP);
-            return PAG_ENOMEM;
-        }
+        if (jref[slot].live) return false;
         hjobs[slot] = P;
         hdone[slot] = 0;
         jref[slot] = jr2;
+        if (jr2.kind == 0) RS[jr2.ctg].chains[(size_t)jr2.idx].job = (int)slot;
+        n_posted[ring] += 1;
+        return true;
+    };
+    auto commit_job = [&](uint32_t ring, const TravPosted &P, const JobRef &jr2, uint32_t mode, uint32_t stop_pc) -> int {
         if (jr2.kind == 0) {
             Chain &ch = RS[jr2.ctg].chains[(size_t)jr2.idx];
-            ch.job = (int)slot;
+            ch.job = 0x7FFFFFFF;  // (outstanding; the slot number follows when the job enters the ring)
             ch.job_mode = mode;
             ch.job_stop = stop_pc;
         }
-        n_posted[ring] += 1;
         n_live += 1;
         RS[jr2.ctg].live_jobs += 1;
         jobs_total += 1;
+        if (!backlog[ring].empty() || !place_job(ring, P, jr2)) backlog[ring].push_back(Backlogged{P, jr2});
         return PAG_OK;
+    };
+    auto flush_backlog = [&]() {
+        for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
+            while (!backlog[ring].empty() && place_job(ring, backlog[ring].front().P, backlog[ring].front().jr)) {
+                backlog[ring].pop_front();
+                need_publish = true;
+            }
     };
     // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
     // the walker only by publish())
@@ -1394,8 +1411,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 if (wdebug) std::fprintf(stderr, "[walk] contig %u chain %d: speculation failed, exact walk\n", i, jr.idx);
             } else if (overflow) {
                 if (misspec) ch.exact = true;
-                if (ch.grow >= 64) {
-                    set_error("pag_travel: walker buffers overflow even at 64x capacity");
+                if (ch.grow >= (1u << 24)) {  // (the buffers double until the walk fits; a device allocation that fails reports itself)
+                    set_error("pag_travel: walker buffers overflow at %u times their first size", ch.grow);
                     return fail(PAG_ENOMEM);
                 }
                 ch.grow *= 2;
@@ -1486,6 +1503,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             // (segment jobs that are still walking use buffers the next round takes over: the round waits for them)
             if (all && R.live_jobs == 0) batch.push_back(i);
         }
+        flush_backlog();
         if (batch.empty()) {
             if ((rc = publish())) return fail(rc);
             lap("round prep");
@@ -1760,6 +1778,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // ---- post the follow-up rounds
         for (uint32_t i : next_round)
             if ((rc = start_round(i))) return fail(rc);
+        flush_backlog();
         if ((rc = publish())) return fail(rc);
         lap("round prep");
     }

@@ -105,12 +105,22 @@ def test_walker_regrows_its_buffers_and_stays_exact(workdir, monkeypatch):
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     goldens.compare_out_dir(name, out)
+    # ... from 16 vertices on, on the golden with the longest paths (far beyond 64 doublings' worth of the old limit)
+    name = "join_fwd_t1"
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / "regrow16" / "in"))
+    out = str(workdir / "regrow16" / "out")
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    r = subprocess.run(argv, capture_output=True, text=True, env=dict(os.environ, PAG_DEBUG_SEQCAP="16", PAG_WALK_PIECES="0"), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    goldens.compare_out_dir(name, out)
 
 
 # The walker waves are elastic (walker_grid.hpp): the result must not depend on how many of them the device carries, on
 # waves leaving for lack of work and being replaced, or on a grid larger than the device can hold at once.
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid", ["8-waves", "1-wave", "leave-at-once", "oversubscribed"])
+@pytest.mark.parametrize("grid", ["8-waves", "1-wave", "leave-at-once", "oversubscribed", "tiny-ring"])
 @pytest.mark.parametrize("name", goldens.case_names()[:3])
 def test_walks_do_not_depend_on_the_walker_grid(name, grid, workdir):
     spec = goldens.load_spec(name)
@@ -121,7 +131,8 @@ def test_walks_do_not_depend_on_the_walker_grid(name, grid, workdir):
     env = dict(os.environ, PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200")
     env.update({"8-waves": {"PAG_WALK_WAVES": "8"}, "1-wave": {"PAG_WALK_WAVES": "1"},
                 "leave-at-once": {"PAG_WALK_WAVES": "16", "PAG_WALK_IDLE_US": "1"},     # every idle wave leaves: constant relaunching
-                "oversubscribed": {"PAG_WALK_WAVES_PER_CU": "8"}}[grid])                # twice what the LDS lets be resident
+                "oversubscribed": {"PAG_WALK_WAVES_PER_CU": "8"},                       # twice what the LDS lets be resident
+                "tiny-ring": {"PAG_DEBUG_RING": "4"}}[grid])                             # rings of 4 jobs: a round's jobs wait in the backlog
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     goldens.compare_out_dir(name, out)
