@@ -614,7 +614,8 @@ extern "C" int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases) {
     // (~1.2 KB per contig base is what pag_travel's own estimate comes to at sequencing coverage; it caps itself likewise)
     size_t want = (size_t)contig_bases * 1200 + (64u << 20);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) / 4);
+    // (the same cap as pag_travel's own estimate: an arena reserved here must not be thrown away there as too small)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
     if (g->walk_arena_cap >= want) return PAG_OK;
     if (g->walk_arena) hipFree(g->walk_arena);
     g->walk_arena = nullptr;

@@ -119,7 +119,9 @@ def run_config_blocks(pre_dir: str, out_dir: str, argv: Sequence[str], dist=None
     config.txt directly, no per-directory loop in Python) spread over the GPUs of the node: blocks are weighed by the size of
     their read + alignment files, dealt out longest-first (assign_blocks), and every rank runs the drop-in executable ONCE on
     its GPU for its blocks (PAGRAPH_BLOCKS; output files keep the block's number as prefix, exactly as one process over all
-    blocks would write them).  Rank 0 merges the per-rank shares of contig.txt.  argv: the pagraph arguments (flags as
+    blocks would write them).  Rank 0 merges the per-rank shares of contig.txt — a SET of names: the reference writes it in
+    std::unordered_set iteration order (quirk Q11) and its only consumer reads it as a set (script/extract.py:11-13), so the
+    merged file lists the names in rank order of first appearance; compare it sorted.  argv: the pagraph arguments (flags as
     AlignGraph2.py passes them, -p pre_dir -o out_dir included).  Returns the exit codes of all ranks."""
     from . import PAGRAPH, require_built
     require_built()
