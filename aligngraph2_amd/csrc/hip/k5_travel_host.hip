@@ -139,28 +139,6 @@ uint64_t pow2_at_least(uint64_t x) {
     return p;
 }
 
-// PAlgorithm::appendSeq (PAlgorithm.cpp:110-142) on path records
-int64_t append_seq(std::vector<LNode> &base, const std::vector<LNode> &tail, uint32_t k) {
-    if (tail.empty()) return 0;
-    int64_t dLen = 0;
-    const LNode &head = tail.front();
-    int32_t dist = (int32_t)k;
-    while (!base.empty() && (base.back().ctg == 0 || head.ctg <= base.back().ctg)) {
-        dLen -= base.back().step;
-        base.pop_back();
-    }
-    if (!base.empty()) dist = (int32_t)(head.ctg - base.back().ctg);
-    for (auto &n : tail) {
-        dLen += n.step;
-        base.push_back(n);
-    }
-    LNode &first = base[base.size() - tail.size()];
-    dLen -= first.step - dist;
-    first.step = dist;
-    return dLen;
-}
-
-
 // The traversal's view of a finished graph: compact CSR with dense ids, vertices renumbered by contig coordinate, and the
 // successor records of every vertex (searchSuccessors + checkPosition for all of them, PABruijnGraph.cpp:143-197) — built
 // once per graph and pair of (deviation, error rate), kept in the handle (g->tg).  Pool slots TRAV_SLOT0 .. + TRAV_GRAPH_SLOTS.
@@ -1618,48 +1596,86 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             uint32_t *hp = (uint32_t *)pinned(tot * 4 + 256);
             if (!hp) return fail(PAG_ENOMEM);
             if ((rc = b_gather.alloc(tot * 4 + 64))) return fail(rc);
-            for (uint32_t i : batch) {
+            // ONE pass over the chosen walk of every contig of the batch (its parts lie where the fetches put them): the
+            // vertex ids for the device, the walk appended to the contig's running path (appendSeq, PAlgorithm.cpp:110-142),
+            // the coordinate window of the global table, the vertices outside the strand's id range.  (Five passes and two
+            // copies of the walk before: 14 M path vertices per block at configs[1], on the thread every contig waits for.)
+            auto take_walk = [&](uint32_t i) {
                 const Pick &P = picks[i];
-                if (P.chosen < 0 || P.len == 0) continue;
-                flatten_chain(RS[i].chains[(size_t)P.chosen], hp + P.off, nullptr, nullptr);
+                if (P.chosen < 0 || P.len == 0) return;
+                const Chain &ch = RS[i].chains[(size_t)P.chosen];
+                CtgState &cs = st[i];
+                std::vector<LNode> &base = cs.travel;
+                int64_t dLen = 0;
+                const uint32_t head_ctg = ch.parts.front().pc[0];
+                int32_t dist = (int32_t)k;
+                while (!base.empty() && (base.back().ctg == 0 || head_ctg <= base.back().ctg)) {
+                    dLen -= base.back().step;
+                    base.pop_back();
+                }
+                if (!base.empty()) dist = (int32_t)(head_ctg - base.back().ctg);
+                const size_t at0 = base.size();
+                base.resize(at0 + P.len);
+                LNode *dst = base.data() + at0;
+                uint32_t *ids = hp + P.off;
+                uint32_t wlo = cs.gwinLo, whi = cs.gwinHi;
+                const uint32_t in_lo = cs.inLo, in_hi = cs.inHi;
+                for (const Chain::Part &pt : ch.parts) {
+                    LNode *d = dst + pt.start;
+                    uint32_t *idp = ids + pt.start;
+                    for (size_t x = 0; x < pt.n; ++x) {
+                        const uint32_t v = pt.v[x], c = pt.pc[x];
+                        const int32_t stp = (int32_t)pt.s[x];
+                        d[x] = LNode{v, stp, c};
+                        idp[x] = v;
+                        dLen += stp;
+                        if (c != 0) {
+                            wlo = std::min(wlo, c);
+                            whi = std::max(whi, c);
+                        }
+                        if (v < in_lo || v >= in_hi) cs.outsideU.push_back(v);
+                    }
+                }
+                cs.gwinLo = wlo;
+                cs.gwinHi = whi;
+                LNode &first = base[at0];
+                dLen -= first.step - dist;
+                first.step = dist;
+                cs.varLen += dLen;
+            };
+            {
+                unsigned nthr = std::min<unsigned>((unsigned)batch.size(), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+                std::atomic<size_t> nxt{0};
+                auto worker = [&]() {
+                    for (size_t x; (x = nxt.fetch_add(1)) < batch.size();) take_walk(batch[x]);
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+                worker();
+                for (auto &t : pool) t.join();
             }
             if (tot) hipMemcpyAsync(b_gather.p, hp, tot * 4, hipMemcpyHostToDevice, s);
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
                 if (P.chosen < 0 || P.len == 0) continue;
-                const Chain &ch = RS[i].chains[(size_t)P.chosen];
                 CtgState &cs = st[i];
-                {   // globalUniqueTable on the device: its hash set (vertices outside the strand's id range) grows as needed
-                    for (const Chain::Part &pt : ch.parts)
-                        for (size_t x = 0; x < pt.n; ++x)
-                            if (pt.v[x] < cs.inLo || pt.v[x] >= cs.inHi) cs.outsideU.push_back(pt.v[x]);
-                    if ((uint64_t)cs.outsideU.size() * 2 > cs.gcap) {
-                        uint32_t ncap = cs.gcap;
-                        while ((uint64_t)cs.outsideU.size() * 4 > ncap) ncap *= 2;
-                        DevBuf b_ng = cbuf(i, GRP_FINAL, CB_TSET), b_ou = cbuf(i, GRP_FINAL, CB_PSET);
-                        if ((rc = b_ng.alloc((size_t)ncap * 4)) || (rc = b_ou.alloc(cs.outsideU.size() * 4))) return fail(rc);
-                        hipMemsetAsync(b_ng.p, 0xFF, (size_t)ncap * 4, s);
-                        // (the vertices of this round's path are inserted by the commit below; the earlier ones here)
-                        hipMemcpyAsync(b_ou.p, cs.outsideU.data(), cs.outsideU.size() * 4, hipMemcpyHostToDevice, s);
-                        trav_launch_commit(b_ou.as<uint32_t>(), cs.outsideU.size(), 0u, 0u, nullptr, b_ng.as<uint32_t>(), ncap - 1, s);
-                        cs.gset = b_ng.as<uint32_t>();
-                        cs.gcap = ncap;
-                    }
+                // globalUniqueTable on the device: its hash set (vertices outside the strand's id range) grows as needed
+                if ((uint64_t)cs.outsideU.size() * 2 > cs.gcap) {
+                    uint32_t ncap = cs.gcap;
+                    while ((uint64_t)cs.outsideU.size() * 4 > ncap) ncap *= 2;
+                    DevBuf b_ng = cbuf(i, GRP_FINAL, CB_TSET), b_ou = cbuf(i, GRP_FINAL, CB_PSET);
+                    if ((rc = b_ng.alloc((size_t)ncap * 4)) || (rc = b_ou.alloc(cs.outsideU.size() * 4))) return fail(rc);
+                    hipMemsetAsync(b_ng.p, 0xFF, (size_t)ncap * 4, s);
+                    // (the vertices of this round's path are inserted by the commit below; the earlier ones here)
+                    hipMemcpyAsync(b_ou.p, cs.outsideU.data(), cs.outsideU.size() * 4, hipMemcpyHostToDevice, s);
+                    trav_launch_commit(b_ou.as<uint32_t>(), cs.outsideU.size(), 0u, 0u, nullptr, b_ng.as<uint32_t>(), ncap - 1, s);
+                    cs.gset = b_ng.as<uint32_t>();
+                    cs.gcap = ncap;
                 }
                 // record the walk in the device-side global visited set of this contig
                 trav_launch_commit(b_gather.as<uint32_t>() + P.off, P.len, cs.inLo, cs.inHi, cs.gbits, cs.gset, cs.gcap - 1, s);
                 cs.committed = true;
             }
-        }
-        // the chosen walks as the splice needs them (host data of the chains, no device round trip)
-        std::vector<std::vector<LNode>> longest(n_sel);
-        for (uint32_t i : batch) {
-            const Pick &P = picks[i];
-            if (P.chosen < 0 || P.len == 0) continue;
-            const Chain &ch = RS[i].chains[(size_t)P.chosen];
-            longest[i].resize(P.len);
-            for (const Chain::Part &pt : ch.parts)
-                for (size_t x = 0; x < pt.n; ++x) longest[i][pt.start + x] = LNode{pt.v[x], (int32_t)pt.s[x], pt.pc[x]};
         }
         for (uint32_t i : batch) {  // the host copies of the round are spent
             RS[i].chains.clear();
@@ -1674,7 +1690,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             CtgState &cs = st[i];
             const Pick &P = picks[i];
             const bool leap = P.leap;
-            cs.varLen += append_seq(cs.travel, longest[i], k);
+            // (the walk was appended to cs.travel by take_walk above)
             if (P.chooseCtgPos != 0) {
                 cs.ctgQ.push_back((uint32_t)P.chooseCtgPos);
                 while (cs.ctgQ.size() > 4) cs.ctgQ.pop_front();
@@ -1683,13 +1699,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 cs.refQ.push_back((uint32_t)P.chooseRefPos);
                 while (cs.refQ.size() > 4) cs.refQ.pop_front();
             }
-            for (auto &n : longest[i]) {
-                if (n.ctg != 0) {
-                    cs.gwinLo = std::min(cs.gwinLo, n.ctg);
-                    cs.gwinHi = std::max(cs.gwinHi, n.ctg);
-                }
-            }
-            std::vector<LNode>().swap(longest[i]);
             bool ctgRepeat = false, refRepeat = false;
             if (cs.ctgQ.size() >= 4) {
                 auto mm = std::minmax_element(cs.ctgQ.begin(), cs.ctgQ.end());
