@@ -2633,41 +2633,6 @@ __global__ void k_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *
         bits[(u >> 5) + 1] = (uint32_t)(m >> 32);
     }
 }
-// Lazy successor records (one GPU, the whole graph): where can a walk move onto a vertex WITHOUT a contig coordinate at all?
-// Only while it can leap (Skip grade, PAlgorithm.tcc:69-86 with checkPosition's table PABruijnGraph.cpp:158-164), i.e. in
-// the last (1 - startSplit) of a contig and beyond its end.  Per contig strand: the range of reference coordinates of its
-// vertices whose offset lies in the last `tail_pct` percent of the strand (atomic min / max; band[2 s] = lo, band[2 s + 1] = hi).
-__global__ void k_leap_bands(TravGraph G, uint32_t n_zero, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ sizes, uint32_t n_ctgs,
-                             uint32_t tail_pct, uint32_t *__restrict__ band) {
-    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + n_zero; u < G.n_pos; u += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t p = G.upos[u];
-        const uint32_t pc = (uint32_t)(p >> 32), pr = (uint32_t)p;
-        if (pc == 0u || pr == 0u) continue;
-        uint32_t lo = 0, hi = n_ctgs + 1;  // upper_bound(starts, pc)
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (starts[mid] <= (uint64_t)pc) lo = mid + 1;
-            else hi = mid;
-        }
-        const uint32_t idx = lo ? lo - 1 : 0;
-        if (idx >= n_ctgs) continue;
-        uint64_t off = (uint64_t)pc - starts[idx];
-        const uint64_t sz = sizes[idx];
-        uint32_t strand = 2 * idx;
-        if (off >= 2 * sz) {
-            off -= 2 * sz;
-            strand += 1;
-        }
-        if (off >= sz || off * 100 < sz * (100 - tail_pct)) continue;
-        atomicMin(&band[2 * strand], pr);
-        atomicMax(&band[2 * strand + 1], pr);
-    }
-}
-void trav_launch_leap_bands(TravGraph G, uint32_t n_zero, const uint64_t *starts, const uint64_t *sizes, uint32_t n_ctgs, uint32_t tail_pct, uint32_t *band,
-                            hipStream_t s) {
-    if (G.n_pos > n_zero) k_leap_bands<<<dim3(grid_for(G.n_pos - n_zero)), dim3(256), 0, s>>>(G, n_zero, starts, sizes, n_ctgs, tail_pct, band);
-}
-
 int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
                          uint32_t *bits, void *tmp, hipStream_t s) {
     // tmp: u32 max step | intervals | open flags

@@ -225,56 +225,6 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
                 return rc;
             G.incomplete = b_inc.as<uint32_t>();
         }
-        // LAZY successor records (the whole graph on this GPU): a walk moves onto a vertex without a contig coordinate only
-        // where it can leap — the end of a contig and what lies beyond it — so those vertices get their records only inside
-        // the reference bands the ends of the contigs map to (+ PAG_SUCC_LAZY_MARGIN); the others get a poison record
-        // (k_succ).  A walk that examines one is REPORTED by its job (TravJobOut::poison): pag_travel then builds all
-        // records (succ_lazy_off) and walks again.  At configs[1]: 0 such walks, 37 % fewer records to build.
-        static const bool lazy_env = !(std::getenv("PAG_SUCC_LAZY") && std::atoi(std::getenv("PAG_SUCC_LAZY")) == 0);
-        g->tg_lazy = false;
-        if (!g->regional && lazy_env && !g->succ_lazy_off && G.n_zero > 0 && n_ctgs > 0) {
-            const Mapper cm(ctg_len, n_ctgs);
-            const uint32_t nc = (uint32_t)n_ctgs;
-            DevBuf b_inc(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS), b_inct(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 1);
-            const size_t tab_bytes = ((size_t)nc + 2) * 16 + (size_t)nc * 16 + 256;
-            if ((rc = b_inct.alloc(tab_bytes + trav_mark_incomplete_tmp_bytes(2 * nc)))) return rc;
-            uint64_t *d_starts = (uint64_t *)b_inct.p, *d_sizes = d_starts + nc + 2;
-            uint32_t *d_band = (uint32_t *)(d_sizes + nc + 2);
-            std::vector<uint32_t> band(4 * (size_t)nc);
-            for (uint32_t x = 0; x < 2 * nc; ++x) {
-                band[2 * x] = 0xFFFFFFFFu;
-                band[2 * x + 1] = 0u;
-            }
-            PAG_HIP_TRY(hipMemcpyAsync(d_starts, cm.starts.data(), cm.starts.size() * 8, hipMemcpyHostToDevice, s));
-            PAG_HIP_TRY(hipMemcpyAsync(d_sizes, cm.sizes.data(), cm.sizes.size() * 8, hipMemcpyHostToDevice, s));
-            PAG_HIP_TRY(hipMemcpyAsync(d_band, band.data(), band.size() * 4, hipMemcpyHostToDevice, s));
-            static const uint32_t tail_pct = std::getenv("PAG_SUCC_LAZY_TAIL") ? (uint32_t)std::atoi(std::getenv("PAG_SUCC_LAZY_TAIL")) : 15u;
-            static const uint64_t margin = std::getenv("PAG_SUCC_LAZY_MARGIN") ? std::strtoull(std::getenv("PAG_SUCC_LAZY_MARGIN"), nullptr, 10) : 100000ull;
-            trav_launch_leap_bands(G, G.n_zero, d_starts, d_sizes, nc, tail_pct, d_band, s);
-            PAG_HIP_TRY(hipMemcpyAsync(band.data(), d_band, band.size() * 4, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
-            std::vector<std::pair<uint64_t, uint64_t>> iv;
-            for (uint32_t x = 0; x < 2 * nc; ++x)
-                if (band[2 * x] <= band[2 * x + 1]) iv.emplace_back(band[2 * x] > margin ? band[2 * x] - margin : 1, (uint64_t)band[2 * x + 1] + margin + 1);
-            std::sort(iv.begin(), iv.end());
-            std::vector<uint32_t> flat;
-            for (auto &x : iv) {
-                const uint32_t lo = (uint32_t)x.first, hi = (uint32_t)std::min<uint64_t>(x.second, 0xFFFFFFFFull);
-                if (!flat.empty() && lo <= flat.back()) flat.back() = std::max(flat.back(), hi);
-                else {
-                    flat.push_back(lo);
-                    flat.push_back(hi);
-                }
-            }
-            const uint32_t n_iv = (uint32_t)(flat.size() / 2);
-            std::vector<uint8_t> open(flat.size(), 1);
-            if ((rc = b_inc.alloc(((size_t)G.n_zero / 32 + 4) * 4))) return rc;
-            if ((rc = trav_mark_incomplete(G, G.n_zero, flat.data(), open.data(), n_iv, (uint32_t)deviation, errorRate, b_inc.as<uint32_t>(),
-                                           (char *)b_inct.p + tab_bytes, s)))
-                return rc;
-            G.incomplete = b_inc.as<uint32_t>();
-            g->tg_lazy = true;
-        }
         uint64_t n_succ = 0, n_cand = 0;
         // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
         // staging array laid out by the candidate-pair bound (b_ok1 = bound per vertex, b_ov1 = its prefix,
@@ -1304,6 +1254,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // ---- jobs that have finished since the last look
         std::vector<uint32_t> fin;
         for (uint32_t ring = 0; ring < NR; ++ring) {
+            // (at most QCAP jobs of a ring are in flight: a slot is taken again only when the job QCAP numbers earlier has been
+            // handled — without this clamp a ring far smaller than a round would be scanned around more than once)
+            if (n_posted[ring] > QCAP && scan_from[ring] < n_posted[ring] - QCAP) scan_from[ring] = n_posted[ring] - QCAP;
             while (scan_from[ring] < n_posted[ring] && !jref[ring * QCAP + scan_from[ring] % QCAP].live) ++scan_from[ring];
             for (uint32_t jn = scan_from[ring]; jn < n_posted[ring]; ++jn) {
                 const uint32_t slot = ring * QCAP + jn % QCAP;
@@ -1424,15 +1377,6 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             record_total += o.n_records;
             const bool overflow = (o.overflow & 3) != 0, misspec = (o.overflow & 4) != 0;
             if (o.poison) {
-                if (g->tg_lazy && !g->regional) {
-                    // (lazy successor records: this walk needs some that were left out — all of them are built, and the
-                    // traversals of the call start again)
-                    if (wdebug || timing) std::fprintf(stderr, "[walk] contig %u examined a vertex without successor records (lazy build): building all of them, walking again\n", st[i].ci);
-                    fail(PAG_OK);
-                    g->succ_lazy_off = true;
-                    g->tg_ready = false;
-                    return pag_travel(g, ctgs, orient, ref_len, n_refs, prm, stats);
-                }
                 // (a regional graph, pag_shard_select: the walk reached a vertex whose successors another rank holds)
                 set_error("pag_travel: a walk of contig %u left the region of the graph this rank holds (reference band halo too small: raise PAG_SHARD_HALO)", st[i].ci);
                 return fail(PAG_ERANGE);

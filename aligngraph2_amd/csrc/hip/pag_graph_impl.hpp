@@ -64,8 +64,6 @@ struct pag_graph {
     std::vector<size_t> fetch_chunk_bytes;
     // the graph holds only a region of the block (pag_shard_set_region after pag_shard_import): the reference bands of its
     // coordinate-free vertices, [lo, hi) pairs sorted, and which ends are open (the block goes on beyond them, on other ranks)
-    bool succ_lazy_off = false;  // a walk needed successor records that were left out (lazy mode): they are all built from now on
-    bool tg_lazy = false;        // the current traversal graph was built lazily
     bool regional = false;
     std::vector<uint32_t> region_ref_iv;
     std::vector<uint8_t> region_ref_open;

@@ -183,8 +183,7 @@ void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s
 int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
                          uint32_t *bits, void *tmp, hipStream_t s);
 size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv);
-void trav_launch_leap_bands(TravGraph G, uint32_t n_zero, const uint64_t *starts, const uint64_t *sizes, uint32_t n_ctgs, uint32_t tail_pct, uint32_t *band,
-                            hipStream_t s);
+
 int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,
                int ref_bits, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair

@@ -69,6 +69,10 @@ struct WalkerGrid {
     // control thread, so a few missing waves are not replaced one by one).
     int ensure(uint32_t outstanding) {
         if (!outstanding) return PAG_OK;
+        if (outstanding > (1u << 28)) {  // (a count that has wrapped: never start waves for it)
+            set_error("pag_travel: job accounting is off (%u jobs outstanding)", outstanding);
+            return PAG_EFAULT;
+        }
         const uint32_t want = std::min(max_waves, outstanding);
         const uint32_t h = have();
         if (h >= want) return PAG_OK;
