@@ -185,11 +185,19 @@ __device__ __forceinline__ void lane_codes(const uint32_t *__restrict__ words, u
 
 // Solid-set membership of every k-mer start of every read strand that some alignment (of either pass)
 // touches: ONE random bitmap gather per read position for the whole build.  The four extraction launches
-// (count / emit x pass 1 / pass 2) then read a 16-bit mask per 16 positions instead of gathering again —
+// (count / emit x pass 1 / pass 2) then read 16-bit masks per 16 positions instead of gathering again —
 // the gathers (a 64-byte line each from a 4^k-bit table that no L2 holds) were 98 % of their HBM traffic.
+//
+// XCD SLICES (round 3).  The table (32 MB at k = 14) is eight times an XCD's 4 MB L2, so every gather of the one-wave-per-
+// strand version missed it: 57 GB of line fetches for < 1 GB of input, 15.7 ms at configs[1].  Now EIGHT workgroups visit
+// every strand, workgroup number b on XCD b mod 8 (consecutive workgroups go round the XCDs), and workgroup b only looks
+// up the codes whose top three bits are b mod 8: each XCD's L2 then only ever sees its own eighth of the table.  Every
+// workgroup derives all codes of its tiles (a few ALU instructions each) and writes its own mask array; the extraction
+// ORs the eight.
+constexpr uint32_t SOLID_SLICES = 8;
 __global__ __launch_bounds__(64) void solid_mask_kernel(ExtractArgs A, const pag_aln *__restrict__ aln2,
                                                         const uint64_t *__restrict__ qoff2, uint16_t *__restrict__ mask) {
-    const uint32_t job = blockIdx.x;
+    const uint32_t job = blockIdx.x / SOLID_SLICES, slice = blockIdx.x % SOLID_SLICES;
     const uint32_t lane = lane_id();
     const uint32_t r = A.emit_order[job >> 1];
     const uint32_t strand = job & 1u;
@@ -197,6 +205,7 @@ __global__ __launch_bounds__(64) void solid_mask_kernel(ExtractArgs A, const pag
     const uint32_t k = A.k;
     if (len < k) return;
     const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+    const uint32_t slice_shift = 2 * k - 3;  // (k >= 2)
     const uint32_t *__restrict__ words = (const uint32_t *)(A.packed + A.read_off[r]);
     const uint32_t n_pos = len - k + 1;
     // union of the intervals any eligible alignment of this strand covers (both databases)
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(64) void solid_mask_kernel(ExtractArgs A, const pag
     }
     if (hi > n_pos) hi = n_pos;
     if (lo >= hi) return;
-    uint16_t *m = mask + 2ull * (A.read_off[r] >> 2) + strand;
+    uint16_t *m = mask + (uint64_t)slice * A.solid_mask_stride + 2ull * (A.read_off[r] >> 2) + strand;
     for (uint32_t t0 = lo & ~(uint32_t)(TILE - 1); t0 < hi; t0 += TILE) {
         const uint32_t p0 = t0 + lane * 16;
         const uint32_t n_mine = p0 >= n_pos ? 0u : (n_pos - p0 > 16 ? 16u : n_pos - p0);
@@ -224,17 +233,18 @@ __global__ __launch_bounds__(64) void solid_mask_kernel(ExtractArgs A, const pag
         uint32_t bits = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            if ((uint32_t)j < n_mine) bits |= ((A.solid_bits[code[j] >> 5] >> (code[j] & 31u)) & 1u) << j;
+            if ((uint32_t)j < n_mine && (code[j] >> slice_shift) == slice) bits |= ((A.solid_bits[code[j] >> 5] >> (code[j] & 31u)) & 1u) << j;
         m[2ull * (p0 >> 4)] = (uint16_t)bits;
     }
 }
 
 int launch_solid_mask(const ExtractArgs &a, const pag_aln *aln2, const uint64_t *qoff2, uint16_t *mask, hipStream_t s) {
     if (a.n_reads == 0) return PAG_OK;
-    solid_mask_kernel<<<dim3(2u * a.n_reads), dim3(64), 0, s>>>(a, aln2, qoff2, mask);
+    solid_mask_kernel<<<dim3(SOLID_SLICES * 2u * a.n_reads), dim3(64), 0, s>>>(a, aln2, qoff2, mask);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
+uint32_t solid_mask_slices() { return SOLID_SLICES; }
 
 // ---------------------------------------------------------------------------------------------
 // sampler automaton: state = min(S, positions since the last kept sample), S = "free".
@@ -322,8 +332,12 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
         if (A.all_solid) {
             cand = ne;
         } else if (ne) {
-            // the solid bits of this strand were gathered once by solid_mask_kernel
-            cand = ne & (uint32_t)A.solid_mask[2ull * ((A.read_off[r] >> 2) + (p0 >> 4)) + strand];
+            // the solid bits of this strand were gathered once by solid_mask_kernel, one array per table slice
+            const uint64_t mi = 2ull * ((A.read_off[r] >> 2) + (p0 >> 4)) + strand;
+            uint32_t sm = 0;
+#pragma unroll
+            for (uint32_t sl = 0; sl < SOLID_SLICES; ++sl) sm |= A.solid_mask[(uint64_t)sl * A.solid_mask_stride + mi];
+            cand = ne & sm;
         }
 
         // ---- C. greedy sampling as an associative scan of state-transition tables

@@ -348,7 +348,7 @@ int extract_stage(pag_graph *g, const pag_build_input *in, uint64_t emit_lo, uin
     DevBuf b_smask(g, 51);
     if (!g->all_solid) {
         // mask entries: 2 strands x one u16 per 16 bases (= per packed 32-bit word of the reads)
-        if ((rc = b_smask.alloc((in->reads.packed_bytes / 4 + 16) * 2 * sizeof(uint16_t)))) return rc;
+        if ((rc = b_smask.alloc((in->reads.packed_bytes / 4 + 16) * 2 * sizeof(uint16_t) * solid_mask_slices()))) return rc;
     }
     ExtractArgs xa[2];
     for (int pass = 0; pass < 2; ++pass) {
@@ -373,6 +373,7 @@ int extract_stage(pag_graph *g, const pag_build_input *in, uint64_t emit_lo, uin
         a.refs = d_ref;
         a.solid_bits = g->solid_bits;
         a.solid_mask = g->all_solid ? nullptr : b_smask.as<uint16_t>();
+        a.solid_mask_stride = (in->reads.packed_bytes / 4 + 16) * 2;
         a.all_solid = g->all_solid;
         a.k = g->k;
         a.outer = in->outer_sample;

@@ -108,7 +108,8 @@ struct ExtractArgs {
     const pag_ref *refs;
     // solid set
     const uint32_t *solid_bits;
-    const uint16_t *solid_mask;  // per (read word, strand): solid bits of 16 k-mer starts (solid_mask_kernel)
+    const uint16_t *solid_mask;  // per table slice, (read word, strand): solid bits of 16 k-mer starts (solid_mask_kernel)
+    uint64_t solid_mask_stride;  // entries of one slice's array
     int all_solid;
     uint32_t k;
     uint32_t outer;
@@ -127,6 +128,7 @@ int launch_colidx(const pag_aln *aln, uint64_t n_aln, const uint32_t *diff, cons
                   hipStream_t s);
 int launch_extract(const ExtractArgs &a, bool emit, hipStream_t s);
 int launch_solid_mask(const ExtractArgs &a, const pag_aln *aln2, const uint64_t *qoff2, uint16_t *mask, hipStream_t s);
+uint32_t solid_mask_slices();
 
 // coverage filter (pass 2): cov_ok[i] for every alignment
 int launch_cov_filter(const pag_aln *aln, uint64_t n_aln, const pag_ref *refs_dev, const pag_ref *refs_host,

@@ -160,7 +160,11 @@ def main():
     ap.add_argument("--epsilon", type=int, default=10)
     ap.add_argument("--mode", choices=["blocks", "shard"], default="blocks", help="N > 1: one block per rank, or ONE block over all ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solid-min-abundance", type=int, default=-1, help="solid set = k-mers at least this abundant (default: kmer_counter's rule; k = 16 needs it)")
     ap.add_argument("--build-only", action="store_true", help="diagnostic: skip traversal (NOT a valid bench line)")
+    ap.add_argument("--file-to-file", action="store_true",
+                    help="also write the workload as TEXT files (/dev/shm, ~25 s) and time the drop-in executable on them, live: "
+                         "config.file_to_file_* (never part of `value`)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,7 +186,7 @@ def main():
     hip, host = load_libs()
     shard = args.mode == "shard" and world > 1
     spec = biggen.BigSpec(seed=2 + (0 if shard else rank), ref_len=args.ref_len, n_reads=args.reads, read_span=args.read_span, k=args.k,
-                          eps=args.epsilon, cov=2, threads=16)
+                          eps=args.epsilon, cov=2, threads=16, solid_min_abundance=args.solid_min_abundance)
     w = biggen.BigWorkload(spec, device=f"cuda:{local}")
     torch.cuda.synchronize()
     # The step starts from the block as bin/pagraph's parsers leave it (records with their header fields, database order;
@@ -484,23 +488,25 @@ def main():
             # through the drop-in executable, both whole programs with their file parsing — measured once on the GPU box by
             # tests/c2_text_runs.py, the record is kept under profiles/ (a cached measurement, quoted with its provenance)
             try:
-                rec = json.load(open(os.path.join(ROOT, "profiles", "r02_c2_text_runs.json")))
+                rec = json.load(open(os.path.join(ROOT, "profiles", "r03_c2_text_parity.json")))
                 default_wl = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon) == (100_000, 10_000, 50_000_000, 14, 10)
                 if default_wl and rec.get("reference", {}).get("returncode") == 0:
                     line["cpu_baseline"]["full_workload"] = {
                         "value": rec["reference"]["bases_per_s"], "unit": "aligned-read-bases/s", "cores": rec["reference"]["threads_flag"],
                         "kind": "reference", "wall_s": rec["reference"]["wall_s"],
-                        "sample": rec["workload"] + "; cached: profiles/r02_c2_text_runs.json (tests/c2_text_runs.py, GPU box host)"}
+                        "sample": rec["workload"] + "; compiled reference -t 16 under the thread-serialising shim (the run whose 53 output files the drop-in "
+                                  "reproduces byte for byte); cached: profiles/r03_c2_text_parity.json (tests/c2_text_runs.py --compare, GPU box host); "
+                                  "round 2 measured the same program at -t 64 without the shim: 319 s (profiles/r02_c2_text_runs.json)"}
                 if default_wl and rec.get("ours", {}).get("returncode") == 0:
                     line["config"]["file_to_file_bases_per_s"] = rec["ours"]["bases_per_s"]
                     line["config"]["file_to_file_note"] = ("bin/pagraph on the same text files, wall clock incl. parsing and upload; cached: "
-                                                           "profiles/r02_c2_text_runs.json")
+                                                           "profiles/r03_c2_text_parity.json (python bench.py --file-to-file measures it live)")
                     # what the product's own ingest costs in that run (host code: parsers, then GraphInput = eligibility /
                     # flips / n_valid / contig->reference entries, the inputs this bench takes from its generator)
                     phases = {}
                     for ln in rec["ours"].get("stderr_tail", "").splitlines():
                         for key, tag in (("load_global_inputs_s", "load global inputs + create"), ("load_block_inputs_s", "load block inputs"),
-                                         ("graph_input_s", "GraphInput (preProcess)"), ("traversal_s", "] traversal "),
+                                         ("prepare_s", "prepare (lists, filters, contig->reference map)"), ("traversal_s", "] traversal "),
                                          ("write_s", "traverse + write")):
                             if tag in ln:
                                 try:
@@ -511,10 +517,42 @@ def main():
                         line["config"]["file_to_file_phases"] = phases
             except Exception:
                 pass
+    if rank == 0 and args.file_to_file and world == 1:
+        # live: the same workload as text files through the drop-in executable, a cold process, parsing included (the bench's own
+        # device memory is handed back first: the executable sizes its pools by what is free)
+        import synth
+        tdir = tempfile.mkdtemp(prefix="pagf2f_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            w.write_text(tdir)
+            n_bases_w = w.n_bases
+            host.pagh_release(g)
+            hip.pag_destroy(g)
+            g = None
+            del w, raw, inp
+            torch.cuda.empty_cache()
+            odir = os.path.join(tdir, "out")
+            os.makedirs(odir)
+            exe = os.path.join(ROOT, "aligngraph2_amd", "bin", "pagraph")
+            tf = time.time()
+            r = subprocess.run(synth.pagraph_argv(exe, tdir, odir, threads=spec.threads, epsilon=spec.eps, cov=spec.cov), capture_output=True, text=True,
+                               env=dict(os.environ, PAGRAPH_DEVICE=str(local), PAGRAPH_TIMING="1"))
+            dtf = time.time() - tf
+            line["config"]["file_to_file_live"] = {"returncode": r.returncode, "wall_s": dtf, "bases_per_s": n_bases_w / dtf,
+                                                   "input_bytes": sum(os.path.getsize(os.path.join(tdir, f)) for f in os.listdir(tdir) if os.path.isfile(os.path.join(tdir, f))),
+                                                   "output_files": len(os.listdir(odir)),
+                                                   "phases": [ln.replace("[timing] ", "") for ln in r.stderr.splitlines()
+                                                              if ln.startswith("[timing] ") and any(t in ln for t in ("load global", "load block", "prepare (", "graph build", "] traversal", "traverse + write"))],
+                                                   "note": "started by the bench process right after it gave ~200 GB of device memory back; a pagraph process on an "
+                                                           "idle box: profiles/r03_c2_text_parity.json",
+                                                   "stderr_tail": r.stderr[-300:] if r.returncode else ""}
+        finally:
+            shutil.rmtree(tdir, ignore_errors=True)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     shutil.rmtree(out_dir, ignore_errors=True)
-    host.pagh_release(g)
-    hip.pag_destroy(g)
+    if g is not None:
+        host.pagh_release(g)
+        hip.pag_destroy(g)
     if dist:
         dist.destroy_process_group()
 
