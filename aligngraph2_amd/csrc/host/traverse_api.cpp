@@ -156,8 +156,10 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
         return rc;
     }
     // ... which reads travel sequences in pinned memory that the walks of the next pag_travel reuse: wait for it here
+    const double tA = nowMs();
     const bool overlapped = hc.worker.joinable();
     if (overlapped) hc.worker.join();
+    const double tB = nowMs();
     if (hc.pending && hc.rc != PAG_OK) {  // (never collected: its error is this call's)
         hc.pending = false;
         setErr("%s", hc.error.c_str());
@@ -165,6 +167,7 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
     }
     hc.tst = pag_travel_stats{};
     rc = pag_travel(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &hc.tst);
+    const double tC = nowMs();
     hc.tst.ms_compact += msPrep;
     hc.tst.ms_total += msPrep;
     const pag_travel_stats &tst = hc.tst;
@@ -190,6 +193,9 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
         }
     hc.tBegin = t0;
     hc.tHost = nowMs();
+    if (std::getenv("PAGRAPH_TIMING"))
+        std::fprintf(stderr, "[timing] traverse_begin: successor stage %.1f ms, wait for the previous host half %.1f ms, pag_travel %.1f ms, views %.1f ms\n", tA - t0, tB - tA,
+                     tC - tB, hc.tHost - tC);
     hc.pending = true;
     hc.rc = PAG_OK;
     hc.stats = pagh_traverse_stats{};
@@ -200,7 +206,9 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
     // sort stalled, 24 -> 74 ms).  pagh_traverse() itself (begin + end back to back) keeps the full pool.
     unsigned poolThreads = host_threads;
     if (!wait_at_once && poolThreads == 0) {
-        static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 8u;
+        // (measured at configs[1] on the GPU box, 16-CPU quota: ms per block 512 / 453 / 443 / 437 / 430 with 6 / 8 / 12 / 16 / 24 threads;
+        // 12 leaves the caller's thread and the walks' control thread their CPUs)
+        static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 12u;
         poolThreads = cap;
     }
     hc.worker = std::thread([=]() {

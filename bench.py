@@ -151,7 +151,7 @@ KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2 + r): v for r, v in enume
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--read-span", type=int, default=10_000)
@@ -238,7 +238,7 @@ def main():
     st = pagctl.BuildStats()
     ts = TraverseStats()
 
-    wall = {"prepare": 0.0, "process": 0.0, "traverse": 0.0}
+    wall = {"prepare": 0.0, "process": 0.0, "traverse": 0.0, "collect": 0.0, "succ": 0.0, "begin": 0.0}
     dev_name = f"cuda:{local}"
     if shard:
         parallel.bind_shard_api(hip)
@@ -315,16 +315,22 @@ def main():
             tp1 = time.perf_counter()
             # (the successor records of the new graph are device work: built before the previous block's host half is waited for)
             ms_succ = C.c_double()
+            ts0 = time.perf_counter()
             rc = hip.pag_travel_prepare(g, C.byref(ctg_seqs), ref_len_u32.ctypes.data, 1, C.byref(tparams1), C.byref(ms_succ))
             if rc != 0:
                 raise SystemExit(f"pag_travel_prepare failed ({rc}): {hip.pag_last_error().decode()}")
             succ_ms.append(ms_succ.value)
+            wall["succ"] += time.perf_counter() - ts0
+            tc0 = time.perf_counter()
             collect()
+            wall["collect"] += time.perf_counter() - tc0
+            tb0 = time.perf_counter()
             rc = host.pagh_traverse_begin(g, spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, orient.ctypes.data, spec.threads,
                                           spec.eps, 50, out_dir.encode(), b"0_", 0)
             if rc != 0:
                 raise SystemExit(f"pagh_traverse_begin failed ({rc}): {host.pagh_last_error().decode()}")
             pending["n"] = 1
+            wall["begin"] += time.perf_counter() - tb0
             wall["traverse"] += time.perf_counter() - tp1
 
     pending = {"n": 0}
@@ -389,7 +395,8 @@ def main():
             check_repeatable()
     finish()
     sync()
-    wall["prepare"] = wall["process"] = wall["traverse"] = 0.0
+    for kk in wall:
+        wall[kk] = 0.0
     trav_ms.clear()
     t0 = time.perf_counter()
     sort_ms, build_ms = [], []
@@ -449,7 +456,8 @@ def main():
                              "(pag_shard_select, a second all-to-all(v))") if shard else
                             "one reference-sequence block per GPU, no data-path collective",
                 "ms_build_device": float(np.mean(build_ms)),
-                "ms_prepare_wall": wall["prepare"] / args.steps * 1e3, "ms_pag_process_wall": wall["process"] / args.steps * 1e3, "ms_pagh_traverse_wall": wall["traverse"] / args.steps * 1e3,
+                "ms_prepare_wall": wall["prepare"] / args.steps * 1e3, "ms_wait_for_previous_host_half": wall["collect"] / args.steps * 1e3,
+                "ms_successor_stage_wall": wall["succ"] / args.steps * 1e3, "ms_walks_wall": wall["begin"] / args.steps * 1e3, "ms_pag_process_wall": wall["process"] / args.steps * 1e3, "ms_pagh_traverse_wall": wall["traverse"] / args.steps * 1e3,
                 "ms_extract": st.ms_extract, "ms_sort": st.ms_sort, "ms_cluster": st.ms_cluster, "ms_edges": st.ms_edges,
                 "ms_traverse_total": float(np.mean(trav_ms)), "ms_traverse_device_walk": ts.ms_export,
                 "ms_traverse_host_epilogue": ts.ms_traverse,
