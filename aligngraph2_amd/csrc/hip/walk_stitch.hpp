@@ -113,10 +113,18 @@ inline void chain_before(const Chain &ch, size_t idx, uint32_t *mx_out, uint32_t
         const Chain::Part &pt = ch.parts[pi];
         mx = pt.mx;
         m0 = pt.m0;
-        for (size_t x = 0; x < idx - pt.start; ++x) {
-            mx = std::max(mx, pt.pc[x]);
-            if (pt.pc[x] == 0) m0 = std::max(m0, pt.v[x] + 1u);
+        // (branch-free: the compiler vectorises it — a splice asks for the prefix up to a few hundred vertices before the end
+        // of a part of thousands)
+        const size_t cnt = idx - pt.start;
+        const uint32_t *pc = pt.pc, *pv = pt.v;
+        uint32_t mx2 = 0, m02 = 0;
+        for (size_t x = 0; x < cnt; ++x) {
+            const uint32_t c = pc[x];
+            mx2 = std::max(mx2, c);
+            m02 = std::max(m02, c == 0u ? pv[x] + 1u : 0u);
         }
+        mx = std::max(mx, mx2);
+        m0 = std::max(m0, m02);
     }
     *mx_out = mx;
     *m0_out = m0;
@@ -209,14 +217,40 @@ inline int try_merge(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adop
     for (size_t x = q; x <= be; ++x) low = std::min<uint64_t>(low, P.pc[x]);
     size_t last = be;
     PartAgg agg;
-    bool open = true;
-    for (size_t x = be + 1; x < P.n; ++x) {
-        low = std::min<uint64_t>(low, P.pc[x]);
-        if (open && agg.sz + P.s[x] < room) {
-            agg.add(P.v[x], P.s[x], P.pc[x]);
-            last = x;
+    {
+        // (plain reductions the compiler vectorises: this loop runs over every adopted vertex of a block, 14 M at configs[1],
+        // on the thread every contig waits for)
+        const size_t n_tail = P.n - (be + 1);
+        const uint32_t *tv = P.v + (be + 1), *ts = P.s + (be + 1), *tp = P.pc + (be + 1);
+        uint32_t lo_all = 0xFFFFFFFFu;
+        uint64_t sum = 0;
+        for (size_t x = 0; x < n_tail; ++x) {
+            lo_all = std::min(lo_all, tp[x]);
+            sum += ts[x];
+        }
+        low = std::min<uint64_t>(low, lo_all);
+        if (sum < room) {  // the whole rest fits below the size at which leaping begins (every prefix sum does)
+            uint32_t mx = 0, m0 = 0, lo_nz = 0xFFFFFFFFu;
+            for (size_t x = 0; x < n_tail; ++x) {
+                const uint32_t c = tp[x];
+                mx = std::max(mx, c);
+                m0 = std::max(m0, c == 0u ? tv[x] + 1u : 0u);
+                lo_nz = std::min(lo_nz, c == 0u ? 0xFFFFFFFFu : c);
+            }
+            agg.mx = mx;
+            agg.m0 = m0;
+            agg.lo = lo_nz;
+            agg.sz = sum;
+            last = P.n - 1;
         } else {
-            open = false;
+            for (size_t x = 0; x < n_tail; ++x) {
+                if (agg.sz + ts[x] < room) {
+                    agg.add(tv[x], ts[x], tp[x]);
+                    last = be + 1 + x;
+                } else {
+                    break;
+                }
+            }
         }
     }
     if (low <= dmax + sg.max_back + M.deviation) return 0;
@@ -291,12 +325,12 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
     uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
     PartAgg agg;
     for (size_t x = be; x < P.n; ++x) {
-        if (P.xh[x] >> 31) {
-            elow = std::min(elow, P.xh[x] & 0x7FFFFFFFu);
-            m0 = std::min(m0, P.xl[x]);
-        }
-        if (x > be) agg.add(P.v[x], P.s[x], P.pc[x]);
+        const uint32_t h = P.xh[x];
+        const bool bd = (h >> 31) != 0u;
+        elow = std::min(elow, bd ? (h & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+        m0 = std::min(m0, bd ? P.xl[x] : 0xFFFFFFFFu);
     }
+    for (size_t x = be + 1; x < P.n; ++x) agg.add(P.v[x], P.s[x], P.pc[x]);
     uint32_t t_dmax = 0, t_d0 = 0;
     chain_before(ch, a, &t_dmax, &t_d0);
     const uint32_t dmax = std::max(t_dmax, p_dmax);
