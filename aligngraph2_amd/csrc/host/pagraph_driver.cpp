@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
+#include <memory>
 #include <iostream>
 #include <set>
 #include <stdexcept>
@@ -198,8 +200,24 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         }
         HostGraph graph;  // (storage reused from block to block)
         std::vector<TravelSequence> precomputed;
+        // The text files of the NEXT block this process will handle are parsed while the current block is on the device
+        // (the parsers' threads are idle then; PAGRAPH_PREFETCH=0 parses every block when its turn comes, as the
+        // reference does, and holds one block's inputs in host memory instead of two).
+        struct BlockFiles {
+            SeqDb reads;
+            AlnDb readToCtg, readToRef;
+            BlockFiles(const std::string &pre, const BlockConfig &cfg)
+                : reads(pre + "/" + cfg.readPath),
+                  readToCtg(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat),
+                  readToRef(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat) {}
+        };
+        const bool prefetch = !(std::getenv("PAGRAPH_PREFETCH") && std::atoi(std::getenv("PAGRAPH_PREFETCH")) == 0);
+        auto mine = [&](std::size_t no) { return !blocksEnv || onlyBlocks.count(no) != 0; };
+        auto loadBlock = [&opt, &configs](std::size_t no) { return std::make_unique<BlockFiles>(opt.pre, configs[no]); };
+        std::future<std::unique_ptr<BlockFiles>> ahead;
+        std::size_t aheadNo = static_cast<std::size_t>(-1);
         for (auto &cfg : configs) {
-            if (blocksEnv && onlyBlocks.count(blockNo) == 0) {
+            if (!mine(blockNo)) {
                 ++blockNo;
                 continue;
             }
@@ -224,16 +242,24 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 }
             } joiner{reserver};
             std::cout << "Use Ref: " << cfg.ref << std::endl;
-            SeqDb reads(opt.pre + "/" + cfg.readPath);
+            std::unique_ptr<BlockFiles> files = (ahead.valid() && aheadNo == blockNo) ? ahead.get() : loadBlock(blockNo);
+            const SeqDb &reads = files->reads;
+            const AlnDb &readToCtg = files->readToCtg, &readToRef = files->readToRef;
             std::cout << "Done! reads number=" << reads.size() << std::endl;
-            AlnDb readToCtg(opt.pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat);
             std::cout << "Done! aln number=" << readToCtg.size() << std::endl;
-            AlnDb readToRef(opt.pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat);
             std::cout << "Done! aln number=" << readToRef.size() << std::endl;
 
             reserver.join();
             if (reserveError) std::rethrow_exception(reserveError);
             lap("load block inputs");
+            if (prefetch) {
+                std::size_t nextNo = blockNo + 1;
+                while (nextNo < configs.size() && !mine(nextNo)) ++nextNo;
+                if (nextNo < configs.size()) {
+                    aheadNo = nextNo;
+                    ahead = std::async(std::launch::async, loadBlock, nextNo);
+                }
+            }
             std::cout << "Pre Process" << std::endl;
             RawInput raw(reads, contigs, refs, readToCtg, readToRef, ctgToRef, cfg, params);
             pag_build_input input{};

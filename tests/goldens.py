@@ -4,6 +4,8 @@ import gzip
 import hashlib
 import json
 import os
+import re
+import subprocess
 import tarfile
 
 import synth
@@ -69,3 +71,47 @@ def compare_out_dir(name, out_dir):
         if f == "contig.txt":  # a set: the reference writes it in hash order
             got = b"".join(sorted(got.splitlines(keepends=True)))
         assert got == data, f"{name}: {f} differs from the reference's golden output"
+
+
+def check_blocks_parsed_ahead(exe, blocks, work):
+    """The two-block golden's config.txt written twice over (blocks 2 and 3 read the files of blocks 0 and 1), run by `exe`
+    (a pagraph_driver.cpp program) with and without parsing the next block ahead (PAGRAPH_PREFETCH): every block's outputs
+    must be the golden's bytes under its own prefix — with all blocks handled, and with blocks skipped (PAGRAPH_BLOCKS =
+    `blocks`) between the one that runs and the one parsed ahead."""
+    name = "two_blocks_both_orient_t16"
+    spec = load_spec(name)
+    ind = materialize_inputs(name, os.path.join(work, "in"))
+    cfg_path = os.path.join(ind, "config.txt")
+    text = open(cfg_path).read()
+    open(cfg_path, "w").write(text.rstrip("\n") + "\n\n" + text)
+    want = golden_out_files(name)
+    outs = {}
+    for ahead in ("1", "0"):
+        out = os.path.join(work, "out" + ahead)
+        os.makedirs(out, exist_ok=True)
+        argv = synth.pagraph_argv(exe, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+        env = dict(os.environ, PAGRAPH_PREFETCH=ahead)
+        if blocks:
+            env.update(PAGRAPH_BLOCKS=blocks, PAGRAPH_PART="0")
+        r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+        outs[ahead] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out))}
+    assert sorted(outs["1"]) == sorted(outs["0"])
+    handled = [int(b) for b in blocks.split(",")] if blocks else [0, 1, 2, 3]
+    seen = set()
+    for f, data in outs["1"].items():
+        if f.startswith("contig.txt"):
+            assert sorted(data.splitlines()) == sorted(outs["0"][f].splitlines())
+            continue
+        assert data == outs["0"][f], f
+        no, rest = f.split("_", 1)
+        no = int(no)
+        assert no in handled, f
+        seen.add(no)
+        golden = want[f"{no % 2}_{rest}"]
+        if rest.endswith((".con", ".fasta")):  # (the sequence names inside start with the block number too)
+            golden = re.sub(rb"(?m)^(>?)%d_" % (no % 2), rb"\g<1>%d_" % no, golden)
+        assert data == golden, f"{f} differs from the golden bytes of block {no % 2}"
+    assert seen == set(handled)
+    for b in handled:
+        assert sum(1 for f in outs["1"] if f.startswith(f"{b}_")) == sum(1 for f in want if f.startswith(f"{b % 2}_"))

@@ -205,3 +205,11 @@ def test_config_blocks_dealt_out_over_processes_equal_the_golden(workdir):
         os.remove(os.path.join(out, f"contig.txt.part{part}"))
     open(os.path.join(out, "contig.txt"), "w").write("".join(n + "\n" for n in dict.fromkeys(names)))
     goldens.compare_out_dir(name, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", [None, "0,2,3", "1,3"])
+def test_next_block_is_parsed_ahead_without_changing_any_output(blocks, workdir):
+    """The driver parses the next block's text files while the current block is on the device (pagraph_driver.cpp):
+    goldens.check_blocks_parsed_ahead, here with the HIP backend."""
+    goldens.check_blocks_parsed_ahead(EXE, blocks, str(workdir / ("ahead_" + (blocks or "all").replace(",", "_"))))

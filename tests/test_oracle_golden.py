@@ -51,6 +51,12 @@ def test_host_pipeline_outputs_equal_reference_outputs(name, workdir):
     goldens.compare_out_dir(name, out)
 
 
+@pytest.mark.parametrize("blocks", [None, "0,2,3", "1,3"])
+def test_driver_parses_the_next_block_ahead(blocks, workdir):
+    """host logic of pagraph_driver.cpp (the loop over config blocks), with the oracle as the backend"""
+    goldens.check_blocks_parsed_ahead(os.path.join(BIN, "pagraph_oracle"), blocks, str(workdir / ("ahead_" + (blocks or "all").replace(",", "_"))))
+
+
 def test_function_level_goldens():
     lib = pagctl.oracle_lib()
     # k-mer codec
