@@ -58,7 +58,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads, AssembleStats *stats, bool quiet,
-                                                std::vector<TravelSequence> &travelled) {
+                                                std::vector<TravelSequence> &travelled, std::ostream *logTo) {
     (void)minLen;     // (both only steer the walk itself, which has already happened: PAlgorithm::travelSequence on the device)
     (void)threadNum;
     const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
@@ -71,7 +71,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         tLap = t;
     };
     std::ostream nullOut(nullptr);
-    std::ostream &out = quiet ? nullOut : std::cout;
+    std::ostream &out = quiet ? nullOut : logTo ? *logTo : std::cout;  // (logTo: a block assembled beside the next block's device work keeps its log in one piece)
     std::set<std::pair<std::string, bool>> success;
     std::vector<TravelSequence> results(contigs.size() * 2);
     std::vector<std::size_t> inDegrees(contigs.size() * 2);

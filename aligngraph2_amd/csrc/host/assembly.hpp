@@ -2,6 +2,7 @@
 // Restates PAssembly::testTravel5 + combatSeq + UnionSet (reference PAGraph/src/tools/graph/
 // PAssembly.cpp:11-336, PAssembly.tcc:2-31, UnionSet.cpp:7-20).
 #pragma once
+#include <iosfwd>
 #include <set>
 #include <string>
 #include <utility>
@@ -31,6 +32,6 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads, AssembleStats *stats, bool quiet,
-                                                std::vector<TravelSequence> &travelled);
+                                                std::vector<TravelSequence> &travelled, std::ostream *logTo = nullptr);
 
 }  // namespace pagh

@@ -80,6 +80,28 @@ public:
 
     void travel(const TravelContext &ctx, const pag_travel_params &params, HostGraph &graph,
                 std::vector<TravelSequence> &travelled) override {
+        TravelViews tv;
+        travelWalks(ctx, params, tv);  // (pag_travel prepares the graph's traversal view itself when nobody has)
+        if (comm_ && rank_ != 0) {
+            graph = HostGraph{};
+            travelled.clear();
+            return;
+        }
+        buildPathGraph(tv.views, ctx.k, graph, travelled);
+        gathered_.swap(tv.gathered);  // (the path graph refers to it)
+    }
+
+    bool travelsInHalves() const override { return true; }
+
+    void travelPrepare(const TravelContext &ctx, const pag_travel_params &params) override {
+        std::vector<std::uint32_t> refLen;
+        for (std::size_t i = 0; i < ctx.refs.size(); ++i) refLen.push_back(ctx.refs.length(i));
+        const SeqDb &contigs = ctx.contigs;
+        pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(), contigs.packed().size()};
+        check(pag_travel_prepare(g_, &cs, refLen.data(), refLen.size(), &params, nullptr), "pag_travel_prepare");
+    }
+
+    void travelWalks(const TravelContext &ctx, const pag_travel_params &params, TravelViews &out) override {
         const SeqDb &contigs = ctx.contigs;
         // orientation(s) per contig as PAssembly::testTravel5 walks its ctgSet (PAssembly.cpp:28-36): a contig listed with
         // both orientations is traversed twice, as two independent entries
@@ -96,7 +118,9 @@ public:
         for (std::size_t i = 0; i < ctx.refs.size(); ++i) refLen.push_back(ctx.refs.length(i));
         pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(), contigs.packed().size()};
         check(pag_travel(g_, &cs, orient.data(), refLen.data(), refLen.size(), &params, nullptr), "pag_travel");
-        std::vector<std::pair<const pag_path_node *, std::uint64_t>> views(2 * contigs.size(), {nullptr, 0});
+        std::vector<std::pair<const pag_path_node *, std::uint64_t>> &views = out.views;
+        std::vector<char> &gathered = out.gathered;
+        views.assign(2 * contigs.size(), {nullptr, 0});
         for (std::uint64_t c = 0; c < contigs.size(); ++c)
             for (int rev = 0; rev < 2; ++rev) {
                 std::uint64_t len = 0;
@@ -129,19 +153,15 @@ public:
             check(pag_comm_all_gather(comm_, &mineBytes, 8, sizes.data()), "pag_comm_all_gather");
             std::uint64_t totalBytes = 0;
             for (auto x : sizes) totalBytes += x;
-            if (rank_ == 0) gathered_.resize(totalBytes);
-            check(pag_comm_gather_v(comm_, blob.data(), blob.size(), 0, rank_ == 0 ? gathered_.data() : nullptr, rank_ == 0 ? gathered_.size() : 0, got.data(),
+            if (rank_ == 0) gathered.resize(totalBytes);
+            check(pag_comm_gather_v(comm_, blob.data(), blob.size(), 0, rank_ == 0 ? gathered.data() : nullptr, rank_ == 0 ? gathered.size() : 0, got.data(),
                                     nullptr),
                   "pag_comm_gather_v");
-            if (rank_ != 0) {
-                graph = HostGraph{};
-                travelled.clear();
-                return;
-            }
+            if (rank_ != 0) return;
             std::fill(views.begin(), views.end(), std::pair<const pag_path_node *, std::uint64_t>{nullptr, 0});
             std::size_t base = 0;
             for (unsigned r = 0; r < world_; ++r) {
-                const char *b = gathered_.data() + base;
+                const char *b = gathered.data() + base;
                 std::uint64_t cnt = 0;
                 std::memcpy(&cnt, b, 8);
                 const char *rec = b + 8 + cnt * 16;
@@ -155,7 +175,6 @@ public:
                 base += sizes[r];
             }
         }
-        buildPathGraph(views, ctx.k, graph, travelled);
     }
 
 private:

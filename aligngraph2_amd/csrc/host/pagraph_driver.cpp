@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <memory>
 #include <iostream>
@@ -198,8 +199,43 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             while (std::getline(ss, tok, ','))
                 if (!tok.empty()) onlyBlocks.insert(static_cast<std::size_t>(std::stoull(tok)));
         }
-        HostGraph graph;  // (storage reused from block to block)
-        std::vector<TravelSequence> precomputed;
+        HostGraph graphs[2];  // (storage reused from block to block; two sets: a block's host half runs beside the next block)
+        std::vector<TravelSequence> precomputed[2];
+        GraphBackend::TravelViews tviews[2];
+        const bool halves = backend.travelsInHalves() && !(std::getenv("PAGRAPH_OVERLAP") && std::atoi(std::getenv("PAGRAPH_OVERLAP")) == 0);
+        std::size_t nHalves = 0;
+        // the host half of the block before: joined before the next walks (and before anything is thrown past it)
+        struct HostHalf {
+            std::thread th;
+            std::exception_ptr err;
+            std::set<std::pair<std::string, bool>> success;
+            std::ostringstream log;
+            void start(std::function<std::set<std::pair<std::string, bool>>()> work) {
+                th = std::thread([this, work]() {
+                    try {
+                        success = work();
+                    } catch (...) {
+                        err = std::current_exception();
+                    }
+                });
+            }
+            void join(std::unordered_set<std::string> &ok) {
+                if (!th.joinable()) return;
+                th.join();
+                std::cout << log.str() << std::flush;
+                log.str(std::string());
+                if (err) {
+                    std::exception_ptr e = err;
+                    err = nullptr;
+                    std::rethrow_exception(e);
+                }
+                for (auto &s : success) ok.emplace(s.first);
+                success.clear();
+            }
+            ~HostHalf() {
+                if (th.joinable()) th.join();
+            }
+        } half;
         // The text files of the NEXT block this process will handle are parsed while the current block is on the device
         // (the parsers' threads are idle then; PAGRAPH_PREFETCH=0 parses every block when its turn comes, as the
         // reference does, and holds one block's inputs in host memory instead of two).
@@ -278,29 +314,61 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             std::cout << "[PositionProcessor] Done!" << std::endl;
 
             lap("graph build (process)");
-            {
-                pag_travel_params tp{};
-                tp.ref_threads = opt.threads;
-                tp.deviation = opt.epsilon * 2;
-                tp.error_rate = errorRate;
-                tp.start_split = startSplit;
-                tp.min_len = opt.minLen;
-                GraphBackend::TravelContext ctx{contigs, refs, ctgMapper, refMapper, usedCtg,
-                                                static_cast<unsigned>(kmers.k())};
-                backend.travel(ctx, tp, graph, precomputed);
+            pag_travel_params tp{};
+            tp.ref_threads = opt.threads;
+            tp.deviation = opt.epsilon * 2;
+            tp.error_rate = errorRate;
+            tp.start_split = startSplit;
+            tp.min_len = opt.minLen;
+            const std::string prefix = std::to_string(blockNo) + "_";
+            if (!halves) {
+                GraphBackend::TravelContext ctx{contigs, refs, ctgMapper, refMapper, usedCtg, static_cast<unsigned>(kmers.k())};
+                backend.travel(ctx, tp, graphs[0], precomputed[0]);
                 lap("traversal");
-            }
-            if (backend.shardRank() != 0) {  // (rank 0 has the travel sequences of all ranks and writes the block's outputs)
+                if (backend.shardRank() != 0) {  // (rank 0 has the travel sequences of all ranks and writes the block's outputs)
+                    ++blockNo;
+                    continue;
+                }
+                auto successCtg = assemble(opt.out, prefix, graphs[0], contigs, refs, ctgMapper, refMapper, usedCtg, opt.epsilon * 2, errorRate,
+                                           startSplit, opt.minLen, opt.threads, 0, nullptr, false, precomputed[0]);
+                lap("traverse + write");
                 ++blockNo;
+                for (auto &s : successCtg) okCtg.emplace(s.first);
                 continue;
             }
-            auto successCtg = assemble(opt.out, std::to_string(blockNo) + "_", graph, contigs, refs, ctgMapper,
-                                       refMapper, usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
-                                       opt.threads, 0, nullptr, false, precomputed);
-            lap("traverse + write");
-            ++blockNo;
-            for (auto &s : successCtg) okCtg.emplace(s.first);
+            // The block's host half — path graph, chain selection, the output files — runs on a thread of its own beside the
+            // next block's device work (the blocks are independent; pagraph.cpp:181-182 resets the graph between them).
+            {
+                GraphBackend::TravelContext ctx{contigs, refs, ctgMapper, refMapper, usedCtg, static_cast<unsigned>(kmers.k())};
+                backend.travelPrepare(ctx, tp);  // (successor records: device work, the previous block's host half still runs)
+                lap("successor records");
+                half.join(okCtg);  // ... which reads travel sequences in memory the next walks reuse
+                lap("wait for the previous block's host half");
+                const std::size_t slot = nHalves++ & 1u;
+                backend.travelWalks(ctx, tp, tviews[slot]);
+                lap("walks");
+                if (backend.shardRank() != 0) {
+                    ++blockNo;
+                    continue;
+                }
+                // (beside another block's device work the pool stays small: a burst of threads uses up a container's CPU
+                // quota and stalls the device's control threads, traverse_api.cpp)
+                std::size_t nextNo = blockNo + 1;
+                while (nextNo < configs.size() && !mine(nextNo)) ++nextNo;
+                unsigned poolThreads = 0;
+                if (nextNo < configs.size())
+                    poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? static_cast<unsigned>(std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS")))) : 12u;
+                half.start([&, slot, prefix, usedCtg, poolThreads, tp]() {
+                    const PositionMapper cm(contigs), rm(refs);
+                    buildPathGraph(tviews[slot].views, static_cast<unsigned>(kmers.k()), graphs[slot], precomputed[slot]);
+                    return assemble(opt.out, prefix, graphs[slot], contigs, refs, cm, rm, usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
+                                    opt.threads, poolThreads, nullptr, false, precomputed[slot], &half.log);
+                });
+                ++blockNo;
+            }
         }
+        half.join(okCtg);
+        lap("last block's host half");
         if (backend.shardRank() != 0) return EXIT_SUCCESS;
         const char *part = std::getenv("PAGRAPH_PART");
         std::ofstream ctgList(opt.out + (blocksEnv ? std::string("/contig.txt.part") + (part ? part : "0") : std::string("/contig.txt")));

@@ -52,6 +52,18 @@ public:
     };
     virtual void travel(const TravelContext &ctx, const pag_travel_params &params, HostGraph &graph,
                         std::vector<TravelSequence> &travelled) = 0;
+    // travel() in halves, for a backend whose walks leave the host free: travelPrepare() = the traversal's view of the
+    // graph just built (successor records: device work that may run while the PREVIOUS block's travel sequences are still
+    // being read), travelWalks() = the walks; they leave the travel sequences as views into memory that stays valid
+    // until the next travelWalks().  The driver then runs the block's host half (buildPathGraph, assemble) on a thread of
+    // its own beside the next block's device work.
+    struct TravelViews {
+        std::vector<std::pair<const pag_path_node *, std::uint64_t>> views;  // 2 * contig + (reverse ? 1 : 0)
+        std::vector<char> gathered;                                          // (a sharded run: what the other ranks sent)
+    };
+    virtual bool travelsInHalves() const { return false; }
+    virtual void travelPrepare(const TravelContext &, const pag_travel_params &) {}
+    virtual void travelWalks(const TravelContext &, const pag_travel_params &, TravelViews &) {}
 };
 
 int runPagraph(int argc, char **argv, GraphBackend &backend);

@@ -24,6 +24,47 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 
+def multi_block(args, rec, d, ours, n_bases):
+    """one run of several config blocks through the drop-in, in the driver's modes; every mode must write the same bytes"""
+    import hashlib
+    import synth
+    cfg = os.path.join(d, "config.txt")
+    text = open(cfg).read().rstrip("\n") + "\n\n"
+    open(cfg, "w").write(text * args.blocks)
+    rec["blocks"] = args.blocks
+    rec["modes"] = {}
+    digests = {}
+    modes = [("block after block", {"PAGRAPH_PREFETCH": "0", "PAGRAPH_OVERLAP": "0"}),
+             ("next block parsed ahead", {"PAGRAPH_PREFETCH": "1", "PAGRAPH_OVERLAP": "0"}),
+             ("parsed ahead + host half beside the next block", {"PAGRAPH_PREFETCH": "1", "PAGRAPH_OVERLAP": "1"}),
+             ("writing the packed sidecars (.pagaln)", {"PAGRAPH_PREFETCH": "1", "PAGRAPH_OVERLAP": "1", "PAGRAPH_ALN_SIDECAR": "1"}),
+             ("from the packed sidecars", {"PAGRAPH_PREFETCH": "1", "PAGRAPH_OVERLAP": "1"}),
+             ("from the packed sidecars, block after block", {"PAGRAPH_PREFETCH": "0", "PAGRAPH_OVERLAP": "0"})]
+    for name, env in modes:
+        out = "/dev/shm/c2_out_multi"
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        t0 = time.time()
+        r = subprocess.run(synth.pagraph_argv(ours, d, out, threads=16, epsilon=10, cov=2), capture_output=True, text=True,
+                           env=dict(os.environ, PAGRAPH_TIMING="1", **env))
+        dt = time.time() - t0
+        h = hashlib.sha256()
+        for f in sorted(os.listdir(out)):
+            data = open(os.path.join(out, f), "rb").read()
+            if f == "contig.txt":
+                data = b"\n".join(sorted(data.split()))
+            h.update(f.encode() + b"\0" + hashlib.sha256(data).digest())
+        digests[name] = h.hexdigest()
+        rec["modes"][name] = {"env": env, "returncode": r.returncode, "wall_s": dt, "s_per_block": dt / args.blocks, "bases_per_s": n_bases * args.blocks / dt,
+                              "output_files": len(os.listdir(out)), "outputs_sha256": digests[name],
+                              "timing_lines": [ln for ln in r.stderr.splitlines() if ln.startswith("[timing] ") and not ln.startswith("[timing]   ") and
+                                               any(w in ln for w in ("load block", "successor records ", "wait for", "walks", "host half", "traversal", "traverse + write", "graph build", "prepare (", "load global"))][-40:],
+                              "stderr_tail": r.stderr[-600:] if r.returncode else ""}
+        print(name, round(dt, 2), "s", round(dt / args.blocks, 2), "s/block", digests[name][:12], "rc", r.returncode, flush=True)
+        shutil.rmtree(out, ignore_errors=True)
+    rec["all_modes_wrote_the_same_bytes"] = len(set(digests.values())) == 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
@@ -32,6 +73,8 @@ def main():
     ap.add_argument("--ref-threads", type=int, default=64)
     ap.add_argument("--skip-reference", action="store_true", help="only time the drop-in executable")
     ap.add_argument("--compare", action="store_true", help="reference -t 16 under the serialising shim; byte-compare all output files")
+    ap.add_argument("--blocks", type=int, default=1, help="> 1: config.txt written that many times over (every block reads the same files); "
+                    "the drop-in alone, block after block / next block parsed ahead / host half beside the next block / packed sidecars")
     args = ap.parse_args()
     import biggen
     import synth
@@ -49,6 +92,11 @@ def main():
     print(rec, flush=True)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "pagraph")
     ours = os.path.join(ROOT, "aligngraph2_amd", "bin", "pagraph")
+    if args.blocks > 1:
+        multi_block(args, rec, d, ours, n_bases)
+        shutil.rmtree(d, ignore_errors=True)
+        json.dump(rec, open(args.out, "w"), indent=1)
+        return
     ref_env, ref_threads = {}, args.ref_threads
     if args.compare:
         ref_env, ref_threads = {"LD_PRELOAD": os.path.join(ROOT, "oracle", "_ref", "libserial_threads.so")}, 16

@@ -75,7 +75,8 @@ def compare_out_dir(name, out_dir):
 
 def check_blocks_parsed_ahead(exe, blocks, work):
     """The two-block golden's config.txt written twice over (blocks 2 and 3 read the files of blocks 0 and 1), run by `exe`
-    (a pagraph_driver.cpp program) with and without parsing the next block ahead (PAGRAPH_PREFETCH): every block's outputs
+    (a pagraph_driver.cpp program) with and without parsing the next block ahead (PAGRAPH_PREFETCH) and running a block's host
+    half beside the next block's device work (PAGRAPH_OVERLAP; the HIP backend): every block's outputs
     must be the golden's bytes under its own prefix — with all blocks handled, and with blocks skipped (PAGRAPH_BLOCKS =
     `blocks`) between the one that runs and the one parsed ahead."""
     name = "two_blocks_both_orient_t16"
@@ -90,7 +91,7 @@ def check_blocks_parsed_ahead(exe, blocks, work):
         out = os.path.join(work, "out" + ahead)
         os.makedirs(out, exist_ok=True)
         argv = synth.pagraph_argv(exe, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
-        env = dict(os.environ, PAGRAPH_PREFETCH=ahead)
+        env = dict(os.environ, PAGRAPH_PREFETCH=ahead, PAGRAPH_OVERLAP=ahead)
         if blocks:
             env.update(PAGRAPH_BLOCKS=blocks, PAGRAPH_PART="0")
         r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
