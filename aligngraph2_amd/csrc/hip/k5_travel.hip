@@ -2419,21 +2419,60 @@ __global__ __launch_bounds__(64) void k_checkpoints(TravGraph G, const TravConti
 }
 
 // The new parts of the sequences of a batch of finished jobs, packed for ONE copy to the host: per job its vertices (new
-// ids), its steps and the contig coordinates of its vertices, each `len` words, at out + off.
+// ids), its steps and the contig coordinates of its vertices (+ the two words of the iteration log of a TRAV_MODE_LEAP
+// job), each `len` words, at out + off — and behind them the job's BLOCK TABLES (walk_stitch.hpp: AGG_WORDS words per 64
+// entries, + AGG_XWORDS for a leap job): a wave copies 64 consecutive entries per turn and reduces them while it holds them.
 __global__ void k_pack_paths(TravGraph G, const TravPackDesc *__restrict__ descs, uint32_t n, uint32_t *__restrict__ out) {
     const uint32_t j = blockIdx.y;
     if (j >= n) return;
     const TravPackDesc D = descs[j];
     uint32_t *o = out + D.off;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < D.len; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t v = D.seq_v[i];
-        o[i] = v;
-        o[D.len + i] = D.seq_s[i];
-        o[2 * D.len + i] = (uint32_t)(G.upos[v] >> 32);
+    const uint32_t lane = lane_id();
+    const uint64_t n_arrays = D.seq_x ? 5 : 3;
+    uint32_t *agg = o + n_arrays * D.len;
+    uint32_t *xagg = agg + ((D.len + 63) / 64) * 5;
+    // (wave-uniform loop: every lane of a wave takes part in the reductions of its block)
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < D.len; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + lane;
+        const bool valid = i < D.len;
+        uint32_t v = 0, st = 0, c = 0, xl = 0, xh = 0;
+        if (valid) {
+            v = D.seq_v[i];
+            st = D.seq_s[i];
+            c = (uint32_t)(G.upos[v] >> 32);
+            o[i] = v;
+            o[D.len + i] = st;
+            o[2 * D.len + i] = c;
+            if (D.seq_x) {
+                const uint64_t x = D.seq_x[i];
+                xl = (uint32_t)x;
+                xh = (uint32_t)(x >> 32);
+                o[3 * D.len + i] = xl;
+                o[4 * D.len + i] = xh;
+            }
+        }
+        const uint32_t mx = wave_max_u32(valid ? c : 0u);
+        const uint32_t m0 = wave_max_u32(valid && c == 0u ? v + 1u : 0u);
+        const uint32_t lo = wave_min_u32(valid ? c : 0xFFFFFFFFu);
+        const uint32_t lnz = wave_min_u32(valid && c != 0u ? c : 0xFFFFFFFFu);
+        const uint32_t sum = wave_sum(valid ? st : 0u);
+        const uint64_t blk = i0 >> 6;
+        if (lane == 0) {
+            uint32_t *a = agg + blk * 5;
+            a[0] = mx;
+            a[1] = m0;
+            a[2] = lo;
+            a[3] = lnz;
+            a[4] = sum;
+        }
         if (D.seq_x) {
-            const uint64_t x = D.seq_x[i];
-            o[3 * D.len + i] = (uint32_t)x;
-            o[4 * D.len + i] = (uint32_t)(x >> 32);
+            const bool bd = valid && (xh >> 31) != 0u;
+            const uint32_t elow = wave_min_u32(bd ? (xh & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+            const uint32_t xm0 = wave_min_u32(bd ? xl : 0xFFFFFFFFu);
+            if (lane == 0) {
+                xagg[blk * 2] = elow;
+                xagg[blk * 2 + 1] = xm0;
+            }
         }
     }
 }

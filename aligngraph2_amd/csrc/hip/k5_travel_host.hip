@@ -105,9 +105,13 @@ struct LNode {
     uint32_t u;
     int32_t step;
     uint32_t ctg;
+    LNode() {}  // (left as it is by vector::resize: a round's path is written over the new elements right away, 14 M of them at configs[1])
+    LNode(uint32_t uu, int32_t st, uint32_t c) : u(uu), step(st), ctg(c) {}
 };
 
 struct CtgState {
+    size_t pendingFirst = 0;       // (choose + gather: the first vertex of the round's path in `travel`, and the step it gets)
+    int32_t pendingFirstStep = 0;
     uint32_t ci = 0;  // contig index
     bool forward = true;
     int64_t chosenOne = 0;
@@ -1304,10 +1308,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // ---- their paths: vertices, steps and contig coordinates to the host (one round trip for the batch)
         struct Got {
             uint32_t jn;
-            uint64_t from, len, off;       // the part of the sequence that is new; word offset of its 3 * len packed words
+            uint64_t from, len, off;       // the part of the sequence that is new; word offset of its packed words (trav_pack_words)
             const uint32_t *v, *s, *pc;     // ... in pinned memory that lives as long as this call (fetch_alloc)
             const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: low / high words of the iteration log
+            const uint32_t *agg = nullptr, *xagg = nullptr;  // block tables of those arrays (walk_stitch.hpp; written by k_pack_paths)
         };
+        static_assert(AGG_BLOCK == 64 && AGG_WORDS == 5 && AGG_XWORDS == 2, "k_pack_paths writes these tables");
         std::vector<Got> got(fin.size());
         {
             uint64_t tot = 0, max_len = 0;
@@ -1321,7 +1327,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 G2.from = std::min<uint64_t>(jref[slot].init_len, o.seq_len);
                 G2.len = o.seq_len - G2.from;
                 G2.off = tot;
-                tot += (J.seq_x ? 5 : 3) * G2.len;
+                tot += trav_pack_words(G2.len, J.seq_x != nullptr);
                 max_len = std::max(max_len, G2.len);
                 descs[x] = TravPackDesc{J.seq_v + G2.from, J.seq_s + G2.from, G2.len, G2.off, J.seq_x ? J.seq_x + G2.from : nullptr};
             }
@@ -1345,14 +1351,33 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 set_error("pag_travel: stream failure while fetching paths");
                 return fail(PAG_EFAULT);
             }
+            static const bool check_aggs = std::getenv("PAG_DEBUG_CHECK_AGGS") != nullptr;
+            static const bool use_aggs = !(std::getenv("PAG_FETCH_TABLES") && std::atoi(std::getenv("PAG_FETCH_TABLES")) == 0);  // (0: every entry is read, for comparisons)
             for (Got &G2 : got) {
                 G2.v = hp + G2.off;
                 G2.s = G2.v + G2.len;
                 G2.pc = G2.s + G2.len;
+                G2.agg = G2.pc + G2.len;
                 if (hjobs[G2.jn].J.seq_x) {
                     G2.xl = G2.pc + G2.len;
                     G2.xh = G2.xl + G2.len;
+                    G2.agg = G2.xh + G2.len;
+                    G2.xagg = G2.agg + agg_blocks((size_t)G2.len) * AGG_WORDS;
                 }
+                if (check_aggs) {  // (tests: the device's block tables against the host's definition of them)
+                    std::vector<uint32_t> want(agg_blocks((size_t)G2.len) * AGG_WORDS), wantx(agg_blocks((size_t)G2.len) * AGG_XWORDS);
+                    build_block_aggs(G2.v, G2.s, G2.pc, (size_t)G2.len, want.data());
+                    bool same = std::memcmp(want.data(), G2.agg, want.size() * 4) == 0;
+                    if (G2.xagg) {
+                        build_block_xaggs(G2.xl, G2.xh, (size_t)G2.len, wantx.data());
+                        same = same && std::memcmp(wantx.data(), G2.xagg, wantx.size() * 4) == 0;
+                    }
+                    if (!same) {
+                        set_error("pag_travel: block tables of a fetched path differ from their definition (job %u, %llu entries)", G2.jn, (unsigned long long)G2.len);
+                        return fail(PAG_EFAULT);
+                    }
+                }
+                if (!use_aggs) G2.agg = G2.xagg = nullptr;
             }
         }
         lap("fetch");
@@ -1423,7 +1448,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             const TravJobOut o = houts[slot];
             RoundState &R = RS[jr.ctg];
             if (jr.kind != 1) {  // the new part of a chain's path
-                extend_chain(R.chains[(size_t)jr.idx], G2.v, G2.s, G2.pc, (size_t)G2.len);
+                extend_chain(R.chains[(size_t)jr.idx], G2.v, G2.s, G2.pc, (size_t)G2.len, nullptr, G2.agg, 0);
                 continue;
             }
             Seg &sg = R.segs[(size_t)jr.idx];
@@ -1433,9 +1458,10 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             sg.P.xl = G2.xl;
             sg.P.xh = G2.xh;
             sg.P.n = (size_t)G2.len;
-            if (!sg.leap)
-                for (size_t x = 0; x < sg.P.n; ++x)
-                    if (sg.P.pc[x] == 0) sg.usable = false;  // (cannot happen while leaping is off; never adopt such a path)
+            sg.P.agg = G2.agg;
+            sg.P.xagg = G2.xagg;
+            // (a coordinate-free vertex cannot happen while leaping is off; never adopt such a path)
+            if (!sg.leap && range_agg(sg.P.v, sg.P.s, sg.P.pc, sg.P.agg, 0, sg.P.n).lo_all == 0u) sg.usable = false;
             if (sg.leap) {
                 sg.usable = sg.usable && G2.xl != nullptr;
                 sg.wd_below_max = o.wd_below_max;
@@ -1544,9 +1570,23 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             // vertex ids for the device, the walk appended to the contig's running path (appendSeq, PAlgorithm.cpp:110-142),
             // the coordinate window of the global table, the vertices outside the strand's id range.  (Five passes and two
             // copies of the walk before: 14 M path vertices per block at configs[1], on the thread every contig waits for.)
-            auto take_walk = [&](uint32_t i) {
+            // The chosen chains' parts are copied to the contigs' paths (cs.travel) and to the id list of the commit in chunks,
+            // by a small pool of threads: a round of a long contig is millions of vertices in a handful of parts, and the
+            // entries are in pinned memory the device wrote (first read = DRAM latency).  What the loop used to add up on
+            // the way — the steps, the coordinate window — the chain knows already.
+            struct CopyChunk {
+                uint32_t i;            // contig
+                const Chain::Part *pt;
+                size_t x0, x1;         // entries of the part
+                LNode *dst;            // of the part's first entry
+                uint32_t *ids;
+                std::vector<uint32_t> outside;  // vertices outside the strand's id range, in order
+            };
+            std::vector<CopyChunk> chunks;
+            const size_t CHUNK = 1u << 17;
+            for (uint32_t i : batch) {
                 const Pick &P = picks[i];
-                if (P.chosen < 0 || P.len == 0) return;
+                if (P.chosen < 0 || P.len == 0) continue;
                 const Chain &ch = RS[i].chains[(size_t)P.chosen];
                 CtgState &cs = st[i];
                 std::vector<LNode> &base = cs.travel;
@@ -1562,41 +1602,49 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 base.resize(at0 + P.len);
                 LNode *dst = base.data() + at0;
                 uint32_t *ids = hp + P.off;
-                uint32_t wlo = cs.gwinLo, whi = cs.gwinHi;
-                const uint32_t in_lo = cs.inLo, in_hi = cs.inHi;
-                for (const Chain::Part &pt : ch.parts) {
-                    LNode *d = dst + pt.start;
-                    uint32_t *idp = ids + pt.start;
-                    for (size_t x = 0; x < pt.n; ++x) {
-                        const uint32_t v = pt.v[x], c = pt.pc[x];
-                        const int32_t stp = (int32_t)pt.s[x];
-                        d[x] = LNode{v, stp, c};
-                        idp[x] = v;
-                        dLen += stp;
-                        if (c != 0) {
-                            wlo = std::min(wlo, c);
-                            whi = std::max(whi, c);
-                        }
-                        if (v < in_lo || v >= in_hi) cs.outsideU.push_back(v);
-                    }
+                for (const Chain::Part &pt : ch.parts)
+                    for (size_t x0 = 0; x0 < pt.n; x0 += CHUNK)
+                        chunks.push_back(CopyChunk{i, &pt, x0, std::min(pt.n, x0 + CHUNK), dst + pt.start, ids + pt.start, {}});
+                dLen += (int64_t)ch.size;
+                if (ch.low_nz != 0xFFFFFFFFu) {  // (some vertex has a coordinate)
+                    cs.gwinLo = std::min(cs.gwinLo, ch.low_nz);
+                    cs.gwinHi = std::max(cs.gwinHi, ch.mx_all);
                 }
-                cs.gwinLo = wlo;
-                cs.gwinHi = whi;
-                LNode &first = base[at0];
-                dLen -= first.step - dist;
-                first.step = dist;
-                cs.varLen += dLen;
-            };
+                // the first vertex of the round's path: its step is the distance to the path so far (set after the copy)
+                cs.varLen += dLen - ((int64_t)ch.parts.front().s[0] - dist);
+                cs.pendingFirst = at0;
+                cs.pendingFirstStep = dist;
+            }
             {
-                unsigned nthr = std::min<unsigned>((unsigned)batch.size(), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
                 std::atomic<size_t> nxt{0};
                 auto worker = [&]() {
-                    for (size_t x; (x = nxt.fetch_add(1)) < batch.size();) take_walk(batch[x]);
+                    for (size_t c; (c = nxt.fetch_add(1)) < chunks.size();) {
+                        CopyChunk &C = chunks[c];
+                        const Chain::Part &pt = *C.pt;
+                        const uint32_t in_lo = st[C.i].inLo, in_hi = st[C.i].inHi;
+                        for (size_t x = C.x0; x < C.x1; ++x) {
+                            const uint32_t v = pt.v[x];
+                            C.dst[x] = LNode(v, (int32_t)pt.s[x], pt.pc[x]);
+                            C.ids[x] = v;
+                            if (v < in_lo || v >= in_hi) C.outside.push_back(v);
+                        }
+                    }
                 };
+                // (measured at configs[1] on the GPU box, 16-CPU quota, the previous block's host half running beside: 430 ms per block with
+                // one thread, 436 with six — the copy is no longer what the round waits for; PAG_TAKE_THREADS for hosts with CPUs to spare)
+                static const unsigned cap = std::getenv("PAG_TAKE_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAG_TAKE_THREADS"))) : 1u;
+                const unsigned nthr = (unsigned)std::min<size_t>(chunks.size(), std::max(1u, std::min(cap, std::thread::hardware_concurrency())));
                 std::vector<std::thread> pool;
                 for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
                 worker();
                 for (auto &t : pool) t.join();
+            }
+            for (CopyChunk &C : chunks)  // (in the order of the path)
+                if (!C.outside.empty()) st[C.i].outsideU.insert(st[C.i].outsideU.end(), C.outside.begin(), C.outside.end());
+            for (uint32_t i : batch) {
+                const Pick &P = picks[i];
+                if (P.chosen < 0 || P.len == 0) continue;
+                st[i].travel[st[i].pendingFirst].step = st[i].pendingFirstStep;
             }
             if (tot) hipMemcpyAsync(b_gather.p, hp, tot * 4, hipMemcpyHostToDevice, s);
             for (uint32_t i : batch) {

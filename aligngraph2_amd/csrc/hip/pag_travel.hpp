@@ -145,9 +145,13 @@ struct TravQueue {
 struct TravPackDesc {  // one finished job of a fetch batch (k_pack_paths)
     const uint32_t *seq_v, *seq_s;  // first new vertex / step of the job's sequence
     uint64_t len;                   // how many
-    uint64_t off;                   // word offset of the job's 3 * len (5 * len with seq_x) words in the packed buffer
+    uint64_t off;                   // word offset of the job's words in the packed buffer: 3 * len (5 * len with seq_x) + its block tables
+                                    // (trav_pack_words)
     const uint64_t *seq_x;          // iteration log of a TRAV_MODE_LEAP job (null otherwise)
 };
+
+// words a job of `len` entries takes in the packed buffer (k_pack_paths): its arrays, then 5 (+ 2 for a leap job) per 64 entries
+inline uint64_t trav_pack_words(uint64_t len, bool leap) { return (leap ? 5 : 3) * len + ((len + 63) / 64) * (leap ? 7 : 5); }
 
 constexpr uint32_t TRAV_SEED_PARTS = 16;  // waves per re-seed window request (k_seed_window)
 

@@ -48,14 +48,33 @@ __device__ __forceinline__ uint64_t block_excl_sum64(uint64_t v, uint64_t *block
     return ex + base;
 }
 
+// Element j of a tile belongs to wave j / 1024, round (j % 1024) / 256, lane (j % 256) / 4: a wave's load instruction reads
+// 1 KB of consecutive input (16 bytes per lane), its store instructions 2 KB of consecutive output.
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+constexpr int SCAN_WAVE_ITEMS = SCAN_TILE / SCAN_WAVES;  // 1024
+constexpr int SCAN_ROUNDS = SCAN_WAVE_ITEMS / 256;       // 4 rounds of 64 lanes x 4 items
+static_assert(SCAN_WAVE_ITEMS % 256 == 0, "a wave's share of a tile is a whole number of 1 KB rounds");
+
+__device__ __forceinline__ uint4 scan_load4(const uint32_t *__restrict__ in, uint64_t i, uint64_t n, bool vec) {
+    if (vec && i + 4 <= n) return *(const uint4 *)(in + i);
+    uint4 v;
+    v.x = i < n ? in[i] : 0u;
+    v.y = i + 1 < n ? in[i + 1] : 0u;
+    v.z = i + 2 < n ? in[i + 2] : 0u;
+    v.w = i + 3 < n ? in[i + 3] : 0u;
+    return v;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums(const uint32_t *__restrict__ in, uint64_t n,
-                                                              uint64_t *__restrict__ tile_sums) {
+                                                              uint64_t *__restrict__ tile_sums, int vec) {
     __shared__ uint64_t lds[8];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    const uint64_t wave_base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)(threadIdx.x >> 6) * SCAN_WAVE_ITEMS;
     uint64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < n) s += in[base + i];
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        const uint4 v = scan_load4(in, wave_base + (uint64_t)r * 256 + lane_id() * 4u, n, vec != 0);
+        s += (uint64_t)v.x + v.y + v.z + v.w;
+    }
     uint64_t tot;
     block_excl_sum64(s, &tot, lds);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
@@ -79,22 +98,45 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_scan(uint64_t *__
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const uint32_t *__restrict__ in, uint64_t n,
                                                           const uint64_t *__restrict__ tile_sums,
-                                                          uint64_t *__restrict__ out) {
+                                                          uint64_t *__restrict__ out, int vec) {
     __shared__ uint64_t lds[8];
-    uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint64_t s = 0;
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+    const uint64_t wave_base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)w * SCAN_WAVE_ITEMS;
+    uint4 v[SCAN_ROUNDS];
+    uint64_t ex[SCAN_ROUNDS];  // exclusive prefix of the lane's four items inside the wave's share
+    uint64_t carry = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        s += v[i];
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        v[r] = scan_load4(in, wave_base + (uint64_t)r * 256 + lane * 4u, n, vec != 0);
+        uint64_t tot;
+        ex[r] = carry + wave_excl_sum64((uint64_t)v[r].x + v[r].y + v[r].z + v[r].w, &tot);
+        carry += tot;
     }
-    uint64_t tot;
-    uint64_t ex = block_excl_sum64(s, &tot, lds) + tile_sums[blockIdx.x];
+    // the waves' totals -> every wave's base inside the tile
+    if (lane == 0) lds[w] = carry;
+    __syncthreads();
+    uint64_t base = tile_sums[blockIdx.x];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i < n) out[base + i] = ex;
-        ex += v[i];
+    for (int i = 0; i < SCAN_WAVES; ++i)
+        if ((uint32_t)i < w) base += lds[i];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROUNDS; ++r) {
+        const uint64_t i = wave_base + (uint64_t)r * 256 + lane * 4u;
+        const uint64_t e0 = base + ex[r], e1 = e0 + v[r].x, e2 = e1 + v[r].y, e3 = e2 + v[r].z;
+        if (vec && i + 4 <= n) {
+            ulonglong2 a, b;
+            a.x = e0;
+            a.y = e1;
+            b.x = e2;
+            b.y = e3;
+            *(ulonglong2 *)(out + i) = a;
+            *(ulonglong2 *)(out + i + 2) = b;
+        } else {
+            if (i < n) out[i] = e0;
+            if (i + 1 < n) out[i + 1] = e1;
+            if (i + 2 < n) out[i + 2] = e2;
+            if (i + 3 < n) out[i + 3] = e3;
+        }
     }
 }
 
@@ -107,9 +149,11 @@ int scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tot
     }
     uint64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     uint64_t *tile_sums = (uint64_t *)tmp;
-    scan_tile_sums<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(in, n, tile_sums);
+    // 16-byte loads and stores when both arrays allow them (pool slots do; a caller's offset view may not)
+    const int vec = (((uintptr_t)in | (uintptr_t)out) & 15u) == 0 ? 1 : 0;
+    scan_tile_sums<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(in, n, tile_sums, vec);
     scan_tile_sums_scan<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(tile_sums, n_tiles, total_dev);
-    scan_apply<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(in, n, tile_sums, out);
+    scan_apply<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(in, n, tile_sums, out, vec);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
@@ -224,7 +268,7 @@ int launch_cov_filter(const pag_aln *aln, uint64_t n_aln, const pag_ref *refs_de
         uint64_t len = refs_host[r].len;
         uint64_t n_tiles = (len + SCAN_TILE - 1) / SCAN_TILE;
         const uint32_t *d = diff + base_host[r];
-        scan_tile_sums<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(d, len, tile_sums);
+        scan_tile_sums<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(d, len, tile_sums, ((uintptr_t)d & 15u) == 0 ? 1 : 0);
         scan_tile_sums_scan<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(tile_sums, n_tiles, nullptr);
         cov_count_low<<<dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, s>>>(d, len, tile_sums, cov_filter, n_low + r);
     }

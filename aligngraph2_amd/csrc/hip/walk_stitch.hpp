@@ -18,10 +18,51 @@ namespace stitch {
 struct Piece {  // host copy of a path: vertices (new ids), steps, contig coordinates
     std::vector<uint32_t> v, s, pc;
 };
+// Block tables of a fetched path: the pack kernel (k_pack_paths) reduces every 64 consecutive entries of a job's path while
+// it copies them, so that the conditions below — which ask for maxima / minima / sums over stretches of thousands of
+// entries — read a few dozen table rows plus the entries of the two blocks at the ends of a stretch instead of every entry
+// (the entries are in pinned memory the device has just written: reading them is DRAM latency on the one thread every
+// chain waits for).  build_block_aggs / build_block_xaggs are the same reductions on the host: the definition, the unit
+// tests' input, and what PAG_DEBUG_CHECK_AGGS=1 holds the device's tables against.
+constexpr size_t AGG_BLOCK = 64;
+constexpr size_t AGG_WORDS = 5;   // per block: highest coordinate, highest id + 1 of a coordinate-free vertex, lowest coordinate,
+                                  // lowest non-zero coordinate (0xFFFFFFFF: none), sum of the steps
+constexpr size_t AGG_XWORDS = 2;  // TRAV_MODE_LEAP, over the block's iteration boundaries: lowest contig-following coordinate,
+                                  // lowest coordinate-free id examined (0xFFFFFFFF: none)
+inline size_t agg_blocks(size_t n) { return (n + AGG_BLOCK - 1) / AGG_BLOCK; }
+inline void build_block_aggs(const uint32_t *v, const uint32_t *s, const uint32_t *pc, size_t n, uint32_t *out) {
+    for (size_t b = 0; b < agg_blocks(n); ++b) {
+        uint32_t mx = 0, m0 = 0, lo = 0xFFFFFFFFu, lnz = 0xFFFFFFFFu, sum = 0;
+        for (size_t x = b * AGG_BLOCK; x < std::min(n, (b + 1) * AGG_BLOCK); ++x) {
+            const uint32_t c = pc[x];
+            mx = std::max(mx, c);
+            lo = std::min(lo, c);
+            if (c == 0) m0 = std::max(m0, v[x] + 1u);
+            else lnz = std::min(lnz, c);
+            sum += s[x];
+        }
+        uint32_t *o = out + b * AGG_WORDS;
+        o[0] = mx, o[1] = m0, o[2] = lo, o[3] = lnz, o[4] = sum;
+    }
+}
+inline void build_block_xaggs(const uint32_t *xl, const uint32_t *xh, size_t n, uint32_t *out) {
+    for (size_t b = 0; b < agg_blocks(n); ++b) {
+        uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+        for (size_t x = b * AGG_BLOCK; x < std::min(n, (b + 1) * AGG_BLOCK); ++x)
+            if (xh[x] >> 31) {
+                elow = std::min(elow, xh[x] & 0x7FFFFFFFu);
+                m0 = std::min(m0, xl[x]);
+            }
+        out[b * AGG_XWORDS] = elow;
+        out[b * AGG_XWORDS + 1] = m0;
+    }
+}
+
 struct View {  // a finished job's path where the fetch put it (pinned memory kept for the whole call)
     const uint32_t *v = nullptr, *s = nullptr, *pc = nullptr;
     const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: iteration log, low / high words
     size_t n = 0;
+    const uint32_t *agg = nullptr, *xagg = nullptr;  // block tables of the arrays above (null: none, every entry is read)
 };
 struct Seg {  // one segment job of a round
     uint32_t x = 0;      // checkpoint coordinate
@@ -45,6 +86,8 @@ struct Chain {  // one graphTravel: (contig, seed) of the running round
         const uint32_t *v, *s, *pc;
         size_t n, start;
         uint32_t mx, m0;
+        const uint32_t *agg;  // block table of the fetched path the part is a stretch of (null: none) ...
+        size_t org;           // ... in which the part begins at entry `org`
     };
     std::vector<Part> parts;
     size_t len = 0;  // vertices of T
@@ -82,14 +125,91 @@ struct PartAgg {  // over the vertices of a part: highest coordinate, highest id
         sz += st;
     }
 };
-inline void extend_chain(Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n, const PartAgg *known = nullptr) {
+// the reductions over entries [i, j) of a fetched path (v, s, pc: its arrays from entry 0; agg: its block table or null)
+struct RangeAgg {
+    uint32_t mx = 0, m0 = 0, lo_all = 0xFFFFFFFFu, lo_nz = 0xFFFFFFFFu;
+    uint64_t sz = 0;
+    void entries(const uint32_t *v, const uint32_t *s, const uint32_t *pc, size_t i, size_t j) {
+        // (branch-free: the compiler vectorises it)
+        uint32_t a = 0, b = 0, c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu;
+        uint64_t sum = 0;
+        for (size_t x = i; x < j; ++x) {
+            const uint32_t c = pc[x];
+            a = std::max(a, c);
+            b = std::max(b, c == 0u ? v[x] + 1u : 0u);
+            c0 = std::min(c0, c);
+            c1 = std::min(c1, c == 0u ? 0xFFFFFFFFu : c);
+            sum += s[x];
+        }
+        mx = std::max(mx, a);
+        m0 = std::max(m0, b);
+        lo_all = std::min(lo_all, c0);
+        lo_nz = std::min(lo_nz, c1);
+        sz += sum;
+    }
+};
+inline RangeAgg range_agg(const uint32_t *v, const uint32_t *s, const uint32_t *pc, const uint32_t *agg, size_t i, size_t j) {
+    RangeAgg r;
+    if (i >= j) return r;
+    const size_t bi = (i + AGG_BLOCK - 1) / AGG_BLOCK, bj = j / AGG_BLOCK;  // whole blocks [bi, bj)
+    if (!agg || bi >= bj) {
+        r.entries(v, s, pc, i, j);
+        return r;
+    }
+    r.entries(v, s, pc, i, bi * AGG_BLOCK);
+    for (size_t b = bi; b < bj; ++b) {
+        const uint32_t *o = agg + b * AGG_WORDS;
+        r.mx = std::max(r.mx, o[0]);
+        r.m0 = std::max(r.m0, o[1]);
+        r.lo_all = std::min(r.lo_all, o[2]);
+        r.lo_nz = std::min(r.lo_nz, o[3]);
+        r.sz += o[4];
+    }
+    r.entries(v, s, pc, bj * AGG_BLOCK, j);
+    return r;
+}
+// lowest contig-following coordinate / coordinate-free id the iterations that start at a boundary in [i, j) examined
+inline void range_xagg(const uint32_t *xl, const uint32_t *xh, const uint32_t *xagg, size_t i, size_t j, uint32_t *elow_out, uint32_t *m0_out) {
+    uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+    auto entries = [&](size_t a, size_t b) {
+        for (size_t x = a; x < b; ++x) {
+            const uint32_t h = xh[x];
+            const bool bd = (h >> 31) != 0u;
+            elow = std::min(elow, bd ? (h & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+            m0 = std::min(m0, bd ? xl[x] : 0xFFFFFFFFu);
+        }
+    };
+    const size_t bi = (i + AGG_BLOCK - 1) / AGG_BLOCK, bj = j / AGG_BLOCK;
+    if (!xagg || bi >= bj) {
+        if (i < j) entries(i, j);
+    } else {
+        entries(i, bi * AGG_BLOCK);
+        for (size_t b = bi; b < bj; ++b) {
+            elow = std::min(elow, xagg[b * AGG_XWORDS]);
+            m0 = std::min(m0, xagg[b * AGG_XWORDS + 1]);
+        }
+        entries(bj * AGG_BLOCK, j);
+    }
+    *elow_out = elow;
+    *m0_out = m0;
+}
+
+// (agg, org: the block table of the fetched path the new part is a stretch of, and the entry it begins at)
+inline void extend_chain(Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n, const PartAgg *known = nullptr,
+                         const uint32_t *agg = nullptr, size_t org = 0) {
     if (n == 0) return;
-    ch.parts.push_back(Chain::Part{v, sv, pc, n, ch.len, ch.mx_all, ch.m0_all});
+    ch.parts.push_back(Chain::Part{v, sv, pc, n, ch.len, ch.mx_all, ch.m0_all, agg, org});
     ch.len += n;
     PartAgg a;
-    if (known) a = *known;  // (the caller has been over the part already)
-    else
-        for (size_t x = 0; x < n; ++x) a.add(v[x], sv[x], pc[x]);
+    if (known) {
+        a = *known;  // (the caller has been over the part already)
+    } else {
+        const RangeAgg r = range_agg(v - org, sv - org, pc - org, agg, org, org + n);
+        a.mx = r.mx;
+        a.m0 = r.m0;
+        a.lo = r.lo_nz;
+        a.sz = r.sz;
+    }
     ch.mx_all = std::max(ch.mx_all, a.mx);
     ch.m0_all = std::max(ch.m0_all, a.m0);
     ch.low_nz = std::min(ch.low_nz, a.lo);
@@ -113,18 +233,11 @@ inline void chain_before(const Chain &ch, size_t idx, uint32_t *mx_out, uint32_t
         const Chain::Part &pt = ch.parts[pi];
         mx = pt.mx;
         m0 = pt.m0;
-        // (branch-free: the compiler vectorises it — a splice asks for the prefix up to a few hundred vertices before the end
-        // of a part of thousands)
+        // (a splice asks for the prefix up to a few hundred vertices before the end of a part of thousands)
         const size_t cnt = idx - pt.start;
-        const uint32_t *pc = pt.pc, *pv = pt.v;
-        uint32_t mx2 = 0, m02 = 0;
-        for (size_t x = 0; x < cnt; ++x) {
-            const uint32_t c = pc[x];
-            mx2 = std::max(mx2, c);
-            m02 = std::max(m02, c == 0u ? pv[x] + 1u : 0u);
-        }
-        mx = std::max(mx, mx2);
-        m0 = std::max(m0, m02);
+        const RangeAgg r = range_agg(pt.v - pt.org, pt.s - pt.org, pt.pc - pt.org, pt.agg, pt.org, pt.org + cnt);
+        mx = std::max(mx, r.mx);
+        m0 = std::max(m0, r.m0);
     }
     *mx_out = mx;
     *m0_out = m0;
@@ -218,31 +331,19 @@ inline int try_merge(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adop
     size_t last = be;
     PartAgg agg;
     {
-        // (plain reductions the compiler vectorises: this loop runs over every adopted vertex of a block, 14 M at configs[1],
-        // on the thread every contig waits for)
-        const size_t n_tail = P.n - (be + 1);
-        const uint32_t *tv = P.v + (be + 1), *ts = P.s + (be + 1), *tp = P.pc + (be + 1);
-        uint32_t lo_all = 0xFFFFFFFFu;
-        uint64_t sum = 0;
-        for (size_t x = 0; x < n_tail; ++x) {
-            lo_all = std::min(lo_all, tp[x]);
-            sum += ts[x];
-        }
-        low = std::min<uint64_t>(low, lo_all);
-        if (sum < room) {  // the whole rest fits below the size at which leaping begins (every prefix sum does)
-            uint32_t mx = 0, m0 = 0, lo_nz = 0xFFFFFFFFu;
-            for (size_t x = 0; x < n_tail; ++x) {
-                const uint32_t c = tp[x];
-                mx = std::max(mx, c);
-                m0 = std::max(m0, c == 0u ? tv[x] + 1u : 0u);
-                lo_nz = std::min(lo_nz, c == 0u ? 0xFFFFFFFFu : c);
-            }
-            agg.mx = mx;
-            agg.m0 = m0;
-            agg.lo = lo_nz;
-            agg.sz = sum;
+        // (these reductions run over every adopted vertex of a block, 14 M at configs[1], on the thread every contig waits for:
+        // the block table answers them)
+        const RangeAgg r = range_agg(P.v, P.s, P.pc, P.agg, be + 1, P.n);
+        low = std::min<uint64_t>(low, r.lo_all);
+        if (r.sz < room) {  // the whole rest fits below the size at which leaping begins (every prefix sum does)
+            agg.mx = r.mx;
+            agg.m0 = r.m0;
+            agg.lo = r.lo_nz;
+            agg.sz = r.sz;
             last = P.n - 1;
         } else {
+            const size_t n_tail = P.n - (be + 1);
+            const uint32_t *tv = P.v + (be + 1), *ts = P.s + (be + 1), *tp = P.pc + (be + 1);
             for (size_t x = 0; x < n_tail; ++x) {
                 if (agg.sz + ts[x] < room) {
                     agg.add(tv[x], ts[x], tp[x]);
@@ -255,7 +356,7 @@ inline int try_merge(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adop
     }
     if (low <= dmax + sg.max_back + M.deviation) return 0;
     if (last == be && last + 1 < P.n) return 0;
-    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg);
+    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1);
     if (adopted) *adopted += last - be;
     return last + 1 == P.n ? 1 : 2;
 }
@@ -323,14 +424,15 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
     // ONE pass over P[be ..]: the iterations that start at a boundary >= be (lowest contig-following coordinate /
     // coordinate-free id examined), and what the chain has to know about the adopted stretch
     uint32_t elow = 0xFFFFFFFFu, m0 = 0xFFFFFFFFu;
+    range_xagg(P.xl, P.xh, P.xagg, be, P.n, &elow, &m0);
     PartAgg agg;
-    for (size_t x = be; x < P.n; ++x) {
-        const uint32_t h = P.xh[x];
-        const bool bd = (h >> 31) != 0u;
-        elow = std::min(elow, bd ? (h & 0x7FFFFFFFu) : 0xFFFFFFFFu);
-        m0 = std::min(m0, bd ? P.xl[x] : 0xFFFFFFFFu);
+    {
+        const RangeAgg r = range_agg(P.v, P.s, P.pc, P.agg, be + 1, P.n);
+        agg.mx = r.mx;
+        agg.m0 = r.m0;
+        agg.lo = r.lo_nz;
+        agg.sz = r.sz;
     }
-    for (size_t x = be + 1; x < P.n; ++x) agg.add(P.v[x], P.s[x], P.pc[x]);
     uint32_t t_dmax = 0, t_d0 = 0;
     chain_before(ch, a, &t_dmax, &t_d0);
     const uint32_t dmax = std::max(t_dmax, p_dmax);
@@ -338,7 +440,7 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
     const uint32_t d0 = std::max(t_d0, p_d0);  // (id + 1, 0: none)
     if (d0 != 0u && m0 != 0xFFFFFFFFu && m0 + 1u <= d0) return refuse(7);
     const size_t last = P.n - 1;
-    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg);
+    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1);
     if (adopted) *adopted += last - be;
     if (why_out) *why_out = -1;
     return 1;

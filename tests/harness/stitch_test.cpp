@@ -8,7 +8,46 @@
 
 using namespace pagdev::stitch;
 
+namespace {
+// pagt_use_tables(1): the paths get block tables (walk_stitch.hpp: what the pack kernel attaches to a fetched path) — T's parts
+// as stretches of ONE fetched path (the flat arrays), so that parts begin in the middle of blocks
+bool g_tables = false;
+struct Tables {
+    std::vector<uint32_t> agg, xagg;
+    const uint32_t *a(const uint32_t *v, const uint32_t *s, const uint32_t *pc, size_t n) {
+        if (!g_tables) return nullptr;
+        agg.assign(agg_blocks(n) * AGG_WORDS + 1, 0);
+        build_block_aggs(v, s, pc, n, agg.data());
+        return agg.data();
+    }
+    const uint32_t *x(const uint32_t *xl, const uint32_t *xh, size_t n) {
+        if (!g_tables || !xl) return nullptr;
+        xagg.assign(agg_blocks(n) * AGG_XWORDS + 1, 0);
+        build_block_xaggs(xl, xh, n, xagg.data());
+        return xagg.data();
+    }
+};
+void build_chain(Chain &ch, Tables &tt, const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts) {
+    const uint32_t *ta = tt.a(tv, ts, tpc, (size_t)part_off[n_parts]);
+    for (uint32_t p = 0; p < n_parts; ++p)
+        extend_chain(ch, tv + part_off[p], ts + part_off[p], tpc + part_off[p], (size_t)(part_off[p + 1] - part_off[p]), nullptr, ta, (size_t)part_off[p]);
+}
+}  // namespace
+
 extern "C" {
+
+void pagt_use_tables(int on) { g_tables = on != 0; }
+
+// the reductions over entries [i, j) of a path, with or without its block table: out = mx, m0, lo_all, lo_nz, sz
+void pagt_range_agg(const uint32_t *v, const uint32_t *s, const uint32_t *pc, uint64_t n, uint64_t i, uint64_t j, uint64_t *out) {
+    Tables tt;
+    const RangeAgg r = range_agg(v, s, pc, tt.a(v, s, pc, (size_t)n), (size_t)i, (size_t)j);
+    out[0] = r.mx, out[1] = r.m0, out[2] = r.lo_all, out[3] = r.lo_nz, out[4] = r.sz;
+}
+void pagt_range_xagg(const uint32_t *xl, const uint32_t *xh, uint64_t n, uint64_t i, uint64_t j, uint32_t *out) {
+    Tables tt;
+    range_xagg(xl, xh, tt.x(xl, xh, (size_t)n), (size_t)i, (size_t)j, out, out + 1);
+}
 
 // A chain T made of `n_parts` parts (part p = vertices [part_off[p], part_off[p + 1]) of the flat arrays) meets a segment P.
 // leap = 0: try_merge, 1: try_merge_leap (xl / xh: the iteration log).  out[0] = decision, out[1] = vertices adopted,
@@ -19,9 +58,11 @@ int pagt_stitch(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, con
                 uint64_t max_probe, uint32_t wd_below_max, uint32_t wd_forced_min, int usable, uint32_t k, uint64_t deviation, uint64_t split,
                 uint64_t has_size, int leap, uint64_t *out, uint32_t *tail_out) {
     Chain ch;
-    for (uint32_t p = 0; p < n_parts; ++p)
-        extend_chain(ch, tv + part_off[p], ts + part_off[p], tpc + part_off[p], (size_t)(part_off[p + 1] - part_off[p]));
+    Tables tt, tp, tx;
+    build_chain(ch, tt, tv, ts, tpc, part_off, n_parts);
     Seg sg;
+    sg.P.agg = tp.a(pv, ps, ppc, (size_t)pn);
+    sg.P.xagg = tx.x(pxl, pxh, (size_t)pn);
     sg.P.v = pv;
     sg.P.s = ps;
     sg.P.pc = ppc;
@@ -63,8 +104,8 @@ int pagt_stitch(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, con
 void pagt_chain_before(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, uint64_t idx, uint32_t *mx,
                        uint32_t *m0) {
     Chain ch;
-    for (uint32_t p = 0; p < n_parts; ++p)
-        extend_chain(ch, tv + part_off[p], ts + part_off[p], tpc + part_off[p], (size_t)(part_off[p + 1] - part_off[p]));
+    Tables tt;
+    build_chain(ch, tt, tv, ts, tpc, part_off, n_parts);
     chain_before(ch, (size_t)idx, mx, m0);
 }
 

@@ -65,3 +65,17 @@ def test_radix_sort_is_a_stable_sort(n, bits):
         pytest.skip("tests/harness/bin/sort_bench not built")
     r = subprocess.run([exe, str(n), str(bits)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "check: 0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,offset", [(1, 0), (3, 0), (4, 0), (1023, 0), (4096, 0), (4097, 0), (4099, 1), (65536, 2), (1000003, 0), (1000003, 3),
+                                      (11214848, 0), (30000001, 4)])
+def test_exclusive_scan_u32_to_u64(n, offset):
+    """util.hip's scan (16-byte loads and stores where the views allow them; used by every compaction and by the sort's
+    histogram prefix): full and partial tiles, views that are not 16-byte aligned, sums beyond 2^32, nothing written past
+    the end — against a sequential sum (tests/harness/sort_bench.hip, scan mode)."""
+    exe = os.path.join(pagctl.ROOT, "tests", "harness", "bin", "sort_bench")
+    if not os.path.exists(exe):
+        pytest.skip("tests/harness/bin/sort_bench not built")
+    r = subprocess.run([exe, "scan", str(n), str(offset)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "check: 0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]

@@ -34,7 +34,8 @@ def test_pagraph_matches_golden(name, mode, workdir):
     for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES", "PAG_LEAP_PIECES", "PAG_LEAP_FIRST"):
         env.pop(v, None)
     if mode.startswith("pieces"):
-        env.update(PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200", PAGRAPH_TIMING="1")
+        # (PAG_DEBUG_CHECK_AGGS: the block tables the pack kernel attaches to every fetched path are recomputed on the host and compared)
+        env.update(PAG_SEG_LEN="400", PAG_SEG_OVERLAP="150", PAG_SEG_SAFETY="200", PAGRAPH_TIMING="1", PAG_DEBUG_CHECK_AGGS="1")
     if mode.endswith("exact"):
         env["PAG_WALK_EXACT"] = "1"
     if mode.endswith("noleap"):

@@ -40,11 +40,17 @@ def stitch(lib, T, parts, P, *, leap=False, log=None, max_back=0, max_chosen=1, 
     lib.pagt_stitch.argtypes = [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                                                                      C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                                                                      C.c_void_p, C.c_void_p]
-    lib.pagt_stitch(tv.ctypes.data, ts.ctypes.data, tpc.ctypes.data, off.ctypes.data, len(parts), pv.ctypes.data, ps.ctypes.data, ppc.ctypes.data,
-                    xl.ctypes.data if xl is not None else None, xh.ctypes.data if xh is not None else None, len(P), max_back, max_chosen, max_probe,
-                    wd_below, wd_forced, int(usable), k, dev, split, has_size, int(leap), out, tail.ctypes.data)
-    decision, adopted, why = int(out[0]), int(out[1]), C.c_int64(out[2]).value
-    return decision, adopted, why, int(out[3]), int(out[4]), list(tail[:adopted])
+    results = []
+    for tables in (0, 1):  # every entry read / through the block tables the pack kernel attaches to a fetched path: the same answers
+        lib.pagt_use_tables(tables)
+        lib.pagt_stitch(tv.ctypes.data, ts.ctypes.data, tpc.ctypes.data, off.ctypes.data, len(parts), pv.ctypes.data, ps.ctypes.data, ppc.ctypes.data,
+                        xl.ctypes.data if xl is not None else None, xh.ctypes.data if xh is not None else None, len(P), max_back, max_chosen, max_probe,
+                        wd_below, wd_forced, int(usable), k, dev, split, has_size, int(leap), out, tail.ctypes.data)
+        decision, adopted, why = int(out[0]), int(out[1]), C.c_int64(out[2]).value
+        results.append((decision, adopted, why, int(out[3]), int(out[4]), list(tail[:adopted]), int(out[5])))
+    lib.pagt_use_tables(0)
+    assert results[0] == results[1], (results[0][:5], results[1][:5])
+    return results[0][:6]
 
 
 def line(v0, n, c0, step=3):
@@ -176,6 +182,13 @@ def test_try_merge_leap(lib, case, decision, why):
 
 
 def test_chain_before_over_parts(lib):
+    for tables in (0, 1):
+        lib.pagt_use_tables(tables)
+        _chain_before_over_parts(lib)
+    lib.pagt_use_tables(0)
+
+
+def _chain_before_over_parts(lib):
     rng = np.random.default_rng(3)
     n = 200
     T = [(int(rng.integers(1, 10 ** 6)), 3, int(rng.integers(0, 2) * rng.integers(1, 10 ** 6))) for _ in range(n)]
@@ -189,3 +202,63 @@ def test_chain_before_over_parts(lib):
             want_mx = max([x[2] for x in T[:idx]] + [0])
             want_m0 = max([x[0] + 1 for x in T[:idx] if x[2] == 0] + [0])
             assert (mx.value, m0.value) == (want_mx, want_m0), (parts, idx)
+
+
+def test_block_tables_answer_like_the_entries(lib):
+    """range_agg / range_xagg (walk_stitch.hpp) over random stretches of a long path: through the 64-entry block tables = over
+    the entries = a plain restatement"""
+    rng = np.random.default_rng(11)
+    n = 3000
+    v = _u32(rng.integers(1, 10 ** 6, n))
+    s = _u32(rng.integers(1, 50, n))
+    pc = _u32(np.where(rng.random(n) < 0.05, 0, rng.integers(1000, 10 ** 6, n)))
+    xl = _u32(rng.integers(0, 10 ** 6, n))
+    xh = _u32(np.where(rng.random(n) < 0.3, (1 << 31) | rng.integers(0, 10 ** 6, n), rng.integers(0, 10 ** 6, n)))
+    lib.pagt_range_agg.argtypes = [C.c_void_p] * 3 + [C.c_uint64] * 3 + [C.c_void_p]
+    lib.pagt_range_xagg.argtypes = [C.c_void_p] * 2 + [C.c_uint64] * 3 + [C.c_void_p]
+    ranges = [(0, n), (0, 0), (5, 5), (0, 64), (1, 64), (0, 65), (63, 129), (64, 128), (100, 101), (2999, 3000), (2944, 3000), (2943, 2999)]
+    ranges += [tuple(sorted(int(x) for x in rng.integers(0, n + 1, 2))) for _ in range(300)]
+    for i, j in ranges:
+        want = (int(pc[i:j].max(initial=0)), int(max([int(v[x]) + 1 for x in range(i, j) if pc[x] == 0] + [0])), int(pc[i:j].min(initial=0xFFFFFFFF)),
+                int(min([int(pc[x]) for x in range(i, j) if pc[x] != 0] + [0xFFFFFFFF])), int(s[i:j].sum()))
+        bd = [x for x in range(i, j) if xh[x] >> 31]
+        wantx = (min([int(xh[x]) & 0x7FFFFFFF for x in bd] + [0xFFFFFFFF]), min([int(xl[x]) for x in bd] + [0xFFFFFFFF]))
+        for tables in (0, 1):
+            lib.pagt_use_tables(tables)
+            out = (C.c_uint64 * 5)()
+            lib.pagt_range_agg(v.ctypes.data, s.ctypes.data, pc.ctypes.data, n, i, j, out)
+            assert tuple(int(x) for x in out) == want, (i, j, tables)
+            outx = (C.c_uint32 * 2)()
+            lib.pagt_range_xagg(xl.ctypes.data, xh.ctypes.data, n, i, j, outx)
+            assert tuple(int(x) for x in outx) == wantx, (i, j, tables)
+    lib.pagt_use_tables(0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_long_paths_through_the_block_tables(lib, seed):
+    """adoptions at the scale of real jobs (thousands of entries, parts that begin and end inside blocks): the decision, the
+    adopted stretch and the chain's aggregates are the same with and without the tables (stitch() asserts it), leap and not"""
+    rng = np.random.default_rng(100 + seed)
+    n_p = int(rng.integers(2000, 6000))
+    P = line(5000, n_p, 200000, step=int(rng.integers(3, 9)))
+    be = int(rng.integers(200, 700))
+    t = int(rng.integers(6, 150))
+    head = line(100, int(rng.integers(300, 3000)), 100000)
+    T = head + P[be - t:be + 1]
+    cut = sorted(set(int(x) for x in rng.integers(1, len(T) - 1, 5)))
+    parts = [b - a for a, b in zip([0] + cut, cut + [len(T)])]
+    got = stitch(lib, T, parts, P, max_back=int(rng.integers(0, 50)), max_chosen=int(rng.integers(1, 5)), max_probe=50, k=14, dev=20, split=10 ** 9, has_size=0)
+    assert got[0] == 1 and got[1] == n_p - 1 - be
+    # room runs out somewhere inside the rest
+    size_T = sum(x[1] for x in T)
+    room_steps = int(rng.integers(10, n_p - be - 10))
+    got = stitch(lib, T, parts, P, max_back=0, max_chosen=2, max_probe=50, k=14, dev=20, split=14 + size_T + 50 + 1 + room_steps * P[0][1] + 1, has_size=0)
+    assert got[0] == 2 and got[1] == room_steps
+    # the leaping zone: boundaries everywhere, one iteration far behind the junction examined a record inside D / none did
+    log = [(True, 200000 + P[0][1] * i - 5, 0xFFFFFFFF) for i in range(n_p)]
+    ok = stitch(lib, T, parts, P, leap=True, log=log, k=14, dev=20, split=1000, has_size=5000)
+    assert (ok[0], ok[2]) == (1, -1) and ok[1] == n_p - 1 - be
+    far = int(rng.integers(be + 70, n_p))
+    log[far] = (True, 100010, 0xFFFFFFFF)
+    bad = stitch(lib, T, parts, P, leap=True, log=log, k=14, dev=20, split=1000, has_size=5000)
+    assert (bad[0], bad[2]) == (0, 6)
