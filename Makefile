@@ -33,7 +33,7 @@ HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pag
 .PHONY: all product harness oracle clean
 all: product harness oracle
 
-product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph aligngraph2_amd/bin/kmer_counter aligngraph2_amd/bin/pre_process aligngraph2_amd/bin/pa_cns aligngraph2_amd/libpagraph_host.so
+product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph aligngraph2_amd/bin/kmer_counter aligngraph2_amd/bin/pre_process aligngraph2_amd/bin/pa_cns aligngraph2_amd/bin/paf2aln aligngraph2_amd/libpagraph_host.so
 
 $(B)/host/%.o: $(HOST_DIR)/%.cpp $(wildcard $(HOST_DIR)/*.hpp) include/pagraph_hip.h
 	@mkdir -p $(B)/host
@@ -62,6 +62,10 @@ aligngraph2_amd/bin/pre_process: $(HOST_DIR)/pre_process_main.cpp $(HOST_DIR)/li
 aligngraph2_amd/bin/pa_cns: $(HOST_DIR)/pa_cns_main.cpp $(B)/host/seq_db.o $(wildcard $(HOST_DIR)/*.hpp)
 	@mkdir -p aligngraph2_amd/bin
 	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/host/seq_db.o -pthread
+
+aligngraph2_amd/bin/paf2aln: $(HOST_DIR)/paf2aln_main.cpp
+	@mkdir -p aligngraph2_amd/bin
+	$(CXX) $(CXXFLAGS) -o $@ $< -pthread
 
 aligngraph2_amd/libpagraph_host.so: $(B)/libpagh_host.a aligngraph2_amd/libpagraph_hip.so
 	$(CXX) -shared -o $@ -Wl,--whole-archive $(B)/libpagh_host.a -Wl,--no-whole-archive -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN' -pthread
