@@ -25,7 +25,7 @@ HIP_DIR  := aligngraph2_amd/csrc/hip
 B        := build
 
 HOST_SRCS := $(wildcard $(HOST_DIR)/*.cpp)
-HOST_LIB_SRCS := $(filter-out $(HOST_DIR)/pagraph_main.cpp $(HOST_DIR)/kmer_counter_main.cpp $(HOST_DIR)/pre_process_main.cpp $(HOST_DIR)/pa_cns_main.cpp,$(HOST_SRCS))
+HOST_LIB_SRCS := $(filter-out %_main.cpp,$(HOST_SRCS))
 HOST_OBJS := $(patsubst $(HOST_DIR)/%.cpp,$(B)/host/%.o,$(HOST_LIB_SRCS))
 HIP_SRCS  := $(wildcard $(HIP_DIR)/*.hip)
 HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pagraph_hip.h
@@ -40,6 +40,7 @@ $(B)/host/%.o: $(HOST_DIR)/%.cpp $(wildcard $(HOST_DIR)/*.hpp) include/pagraph_h
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
 $(B)/libpagh_host.a: $(HOST_OBJS)
+	@rm -f $@
 	ar rcs $@ $^
 
 aligngraph2_amd/libpagraph_hip.so: $(HIP_SRCS) $(HIP_HDRS)

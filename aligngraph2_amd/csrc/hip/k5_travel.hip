@@ -240,112 +240,161 @@ __global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uin
     }
 }
 
-// MODE 0: count the records of every vertex (cnt[u]).  MODE 1: write them to their final place succ[succ_off[u] ..]
-// (needs MODE 0 + scan first: the two-pass path).  MODE 2: write them to a staging array at stage_off[v] — offsets from
-// the cheap upper bound of k_succ_bound, so no counting pass is needed — and count; k_succ_place moves them afterwards.
+// The candidate pairs of one vertex v (searchSuccessors + checkPosition + isEdgeSimilar, PABruijnGraph.cpp:143-197,385-400):
+// every position of every target node of its k-mer node, in CSR order.  WHAT = 0: count the accepted ones, and note in
+// `mask` which of the first 64 candidates they are.  WHAT = 1: write the accepted ones to out[0 ..] — the first 64
+// candidates through `mask` (nine in ten candidates are rejects: only the accepted ones are touched again), the rest
+// evaluated again.  WHAT = 2: evaluate every candidate once and write the accepted ones as they come.  Returns their number.
+template <int WHAT>
+__device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out) {
+    constexpr int MODE = WHAT;  // (0 counts, 1 fills through the mask, 2 writes while it evaluates)
+    const uint64_t rootp = G.vpos[v];
+    const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
+    const uint32_t node = G.vnode[v];
+    uint32_t n = 0, base = 0;
+    const bool amask = true;  // (the mask is always there; a caller without one passes 0 and WHAT = 2)
+    auto emit = [&](uint32_t p, uint32_t pc, uint32_t step, int grade, uint32_t esim) {
+        SuccRec r;
+        r.tgt = G.newid[p];
+        r.pc = pc;
+        r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+        r.toff = 0;  // the target's own record range is linked in afterwards
+        out[n] = r;
+    };
+    const uint32_t e_lo = G.nedge_off[node], e_hi = G.nedge_off[node + 1];
+    for (uint32_t eb = e_lo; eb < e_hi; eb += 4u) {
+      // (targets and position ranges of up to four edges requested together: two round trips for the four; k_succ<0>
+      // 36 -> 34 ms, k_succ<1> 49 -> 46 ms)
+      uint32_t to4[4], st4[4], p04[4], q4[4];
+#pragma unroll
+      for (uint32_t t = 0; t < 4u; ++t) {
+          const bool have = eb + t < e_hi;
+          to4[t] = have ? G.eto[eb + t] : PAG_NONE;
+          st4[t] = have ? G.estep[eb + t] : 0u;
+      }
+#pragma unroll
+      for (uint32_t t = 0; t < 4u; ++t) {
+          p04[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t]] : 0u;
+          q4[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t] + 1] - p04[t] : 0u;
+      }
+#pragma unroll
+      for (uint32_t t4 = 0; t4 < 4u; ++t4) {
+        const uint32_t step = st4[t4], p0 = p04[t4], q = q4[t4];
+        if (q == 0u) continue;
+        uint32_t j0 = 0;
+        if (MODE == 1 && amask) {  // the candidates the mask covers: accepted ones only
+            const uint32_t lim = base < 64u ? (q < 64u - base ? q : 64u - base) : 0u;
+            uint64_t sub = lim ? (mask >> base) & (lim == 64u ? ~0ull : ((1ull << lim) - 1ull)) : 0ull;
+            while (sub) {
+                const uint32_t p = p0 + (uint32_t)(__ffsll((long long)sub) - 1);
+                sub &= sub - 1ull;
+                const uint64_t pp = G.vpos[p];
+                uint32_t esim;
+                const int grade = d_check_position(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, &esim);
+                emit(p, (uint32_t)(pp >> 32), step, grade, esim);
+                ++n;
+            }
+            j0 = lim;
+        }
+        // four candidates per turn, their positions requested together: one at a time, every candidate cost a full memory
+        // round trip (load -> f64 tests -> next load) and the kernel ran at a third of the miss rate the memory system
+        // sustains (k_succ<0>: 45 -> 36 ms).  Also having the first positions of four edges in flight was slower (48 ms:
+        // a node has 2.65 edges on average, the rest is wasted loads and registers), eight candidates per turn no better
+        // (35.6 ms), four lanes per vertex slower (51 ms), and keeping the first four accepted candidates of every vertex
+        // in a side array for the filling pass cost the counting pass more (+14 ms) than it saved the other (-5 ms).
+        for (uint32_t jb = j0; jb < q; jb += 4u) {
+            uint64_t pq[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) pq[t] = G.vpos[p0 + (jb + t < q ? jb + t : q - 1u)];
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+                const uint32_t j = jb + t;
+                if (j >= q) break;
+                const uint32_t p = p0 + j;
+                const uint32_t pc = (uint32_t)(pq[t] >> 32), pr = (uint32_t)pq[t];
+                uint32_t esim;
+                int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
+                if (grade == G_OOPS) continue;
+                if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
+                if (MODE != 0) emit(p, pc, step, grade, esim);
+                ++n;
+            }
+        }
+        base += q;
+      }
+    }
+    return n;
+}
+
+// Threads run over the vertices in k-mer-major order (the order of the CSR): neighbouring threads belong to the same k-mer
+// node, so the node's edge list and the position lists of its target nodes are shared through the caches; only the
+// per-vertex results go to coordinate-ordered (random) places.
+// MODE 0: count the records of every vertex (cnt[u]) and leave the acceptance mask of its first 64 candidates (amask[v]).
+// MODE 1: write them to their final place succ[succ_off[u] ..] (after MODE 0 + scan: the two-pass path).
+// MODE 2: write them to a staging array at stage_off[v] — offsets from the cheap upper bound of k_succ_bound — and count;
+//         k_succ_place moves them to coordinate order afterwards.
+// MODE 3: count, then APPEND to the staging array: a wave adds up its 64 counts, takes that much of the array with one
+//         atomic add on `cursor`, and every thread goes over its accepted candidates once more (through the mask, in the
+//         caches now) to write them; stage_off_out[v] = where.  Records that do not fit (cursor beyond `capacity`) are not
+//         written: the host sees the cursor and falls back to the two-pass path.  One walk over the edge lists and
+//         target lists instead of two, and the records reach coordinate order by k_succ_place's gather (reads of whole
+//         64-byte pieces) instead of by scattered 16-byte writes.
 template <int MODE>
 __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
-                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask) {
-    // Threads run over the vertices in k-mer-major order (the order of the CSR): neighbouring threads belong to the
-    // same k-mer node, so the node's edge list and the position lists of its target nodes are shared through the
-    // caches; only the per-vertex results go to coordinate-ordered (random) places.
-    // amask[v] (two-pass path): which of the vertex's first 64 candidate pairs the counting pass accepted, so that the
-    // filling pass only touches those (nine in ten candidates are rejects); candidates from the 65th on are evaluated
-    // again.
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t u = G.newid[v];
-        if (G.incomplete && u < G.n_zero && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u)) {
+                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask, unsigned long long *__restrict__ cursor, uint64_t capacity,
+                       uint64_t *__restrict__ stage_off_out) {
+    // (MODE 3: every lane of a wave takes part in the wave's prefix sum: the loop runs over whole waves)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); v0 < G.n_pos; v0 += stride) {
+        const uint64_t v = v0 + lane_id();
+        const bool valid = v < G.n_pos;
+        uint32_t n = 0;
+        uint64_t mask = 0ull;
+        uint32_t u = 0;
+        bool poison = false;
+        if (valid) {
+            u = G.newid[v];
             // its successors may lie outside the region this rank holds: one poison record in their place
-            if (MODE != 1) cnt[u] = 1u;
-            if (MODE == 0 && amask) amask[v] = 0ull;
-            if (MODE != 0) {
+            poison = G.incomplete && u < G.n_zero && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+            if (poison) n = 1u;
+            else if (MODE == 0 || MODE == 3) n = succ_vertex<0>(G, v, dev, err, mask, nullptr);
+        }
+        SuccRec *out = nullptr;
+        if (MODE == 1 && valid) out = G.succ + G.succ_off[u];
+        if (MODE == 2 && valid) out = stage + stage_off[v];
+        if (MODE == 3) {
+            uint32_t tot;
+            const uint32_t ex = wave_excl_sum(n, &tot);
+            unsigned long long wave_base = 0;
+            if (lane_id() == 0 && tot) wave_base = atomicAdd(cursor, (unsigned long long)tot);
+            wave_base = __shfl(wave_base, 0, 64);
+            const uint64_t off = wave_base + ex;
+            if (valid) stage_off_out[v] = off;
+            out = off + n <= capacity ? stage + off : nullptr;
+        }
+        if (valid && MODE != 0 && out) {
+            if (poison) {
                 SuccRec r;
                 r.tgt = u;
                 r.pc = 0;
                 r.meta = 1u | (GRADE_POISON << 24);
                 r.toff = 0;
-                (MODE == 1 ? G.succ + G.succ_off[u] : stage + stage_off[v])[0] = r;
-            }
-            continue;
-        }
-        const uint64_t rootp = G.vpos[v];
-        const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
-        const uint32_t node = G.vnode[v];
-        uint32_t n = 0, base = 0;
-        uint64_t mask = MODE == 1 && amask ? amask[v] : 0ull;
-        SuccRec *out = MODE == 1 ? G.succ + G.succ_off[u] : MODE == 2 ? stage + stage_off[v] : nullptr;
-        auto emit = [&](uint32_t p, uint32_t pc, uint32_t step, int grade, uint32_t esim) {
-            SuccRec r;
-            r.tgt = G.newid[p];
-            r.pc = pc;
-            r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
-            r.toff = 0;  // the target's own record range is linked in afterwards
-            out[n] = r;
-        };
-        const uint32_t e_lo = G.nedge_off[node], e_hi = G.nedge_off[node + 1];
-        for (uint32_t eb = e_lo; eb < e_hi; eb += 4u) {
-          // (targets and position ranges of up to four edges requested together: two round trips for the four; k_succ<0>
-          // 36 -> 34 ms, k_succ<1> 49 -> 46 ms)
-          uint32_t to4[4], st4[4], p04[4], q4[4];
-#pragma unroll
-          for (uint32_t t = 0; t < 4u; ++t) {
-              const bool have = eb + t < e_hi;
-              to4[t] = have ? G.eto[eb + t] : PAG_NONE;
-              st4[t] = have ? G.estep[eb + t] : 0u;
-          }
-#pragma unroll
-          for (uint32_t t = 0; t < 4u; ++t) {
-              p04[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t]] : 0u;
-              q4[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t] + 1] - p04[t] : 0u;
-          }
-#pragma unroll
-          for (uint32_t t4 = 0; t4 < 4u; ++t4) {
-            const uint32_t step = st4[t4], p0 = p04[t4], q = q4[t4];
-            if (q == 0u) continue;
-            uint32_t j0 = 0;
-            if (MODE == 1 && amask) {  // the candidates the mask covers: accepted ones only
-                const uint32_t lim = base < 64u ? (q < 64u - base ? q : 64u - base) : 0u;
-                uint64_t sub = lim ? (mask >> base) & (lim == 64u ? ~0ull : ((1ull << lim) - 1ull)) : 0ull;
-                while (sub) {
-                    const uint32_t p = p0 + (uint32_t)(__ffsll((long long)sub) - 1);
-                    sub &= sub - 1ull;
-                    const uint64_t pp = G.vpos[p];
-                    uint32_t esim;
-                    const int grade = d_check_position(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, &esim);
-                    emit(p, (uint32_t)(pp >> 32), step, grade, esim);
-                    ++n;
+                out[0] = r;
+            } else if (MODE == 1) {
+                if (amask) {
+                    mask = amask[v];
+                    succ_vertex<1>(G, v, dev, err, mask, out);
+                } else {
+                    succ_vertex<2>(G, v, dev, err, mask, out);
                 }
-                j0 = lim;
+            } else if (MODE == 2) {
+                n = succ_vertex<2>(G, v, dev, err, mask, out);
+            } else if (n) {
+                succ_vertex<1>(G, v, dev, err, mask, out);
             }
-            // four candidates per turn, their positions requested together: one at a time, every candidate cost a full memory
-            // round trip (load -> f64 tests -> next load) and the kernel ran at a third of the miss rate the memory system
-            // sustains (k_succ<0>: 45 -> 36 ms).  Also having the first positions of four edges in flight was slower (48 ms:
-            // a node has 2.65 edges on average, the rest is wasted loads and registers), eight candidates per turn no better
-            // (35.6 ms), four lanes per vertex slower (51 ms), and keeping the first four accepted candidates of every vertex
-            // in a side array for the filling pass cost the counting pass more (+14 ms) than it saved the other (-5 ms).
-            for (uint32_t jb = j0; jb < q; jb += 4u) {
-                uint64_t pq[4];
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) pq[t] = G.vpos[p0 + (jb + t < q ? jb + t : q - 1u)];
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) {
-                    const uint32_t j = jb + t;
-                    if (j >= q) break;
-                    const uint32_t p = p0 + j;
-                    const uint32_t pc = (uint32_t)(pq[t] >> 32), pr = (uint32_t)pq[t];
-                    uint32_t esim;
-                    int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
-                    if (grade == G_OOPS) continue;
-                    if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
-                    if (MODE != 0) emit(p, pc, step, grade, esim);
-                    ++n;
-                }
-            }
-            base += q;
-          }
         }
-        if (MODE != 1) cnt[u] = n;
-        if (MODE == 0 && amask) amask[v] = mask;
+        if (valid && MODE != 1) cnt[u] = n;
+        if (valid && MODE == 0 && amask) amask[v] = mask;
     }
 }
 
@@ -2744,8 +2793,24 @@ int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
                     const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, hipStream_t s) {
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
-    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr);
-    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask);
+    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr, nullptr, 0, nullptr);
+    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask, nullptr, 0, nullptr);
+    PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
+    int rc;
+    if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
+    k_narrow<<<dim3(grid_for(n + 1)), dim3(256), 0, s>>>(scan_out, n + 1, G.succ_off);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+// count + append (k_succ<3>): cnt[u], stage_off_out[v] and the staged records; *cursor_dev (zeroed here) ends at the number of
+// records — beyond `capacity`: the staging array is incomplete and the caller takes the two-pass path.  Then the scan of
+// the counts as trav_succ_count does it.
+int trav_succ_append(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
+                     uint64_t *stage_off_out, SuccRec *stage, uint64_t capacity, uint64_t *cursor_dev, hipStream_t s) {
+    const uint64_t n = G.n_pos;
+    if (!n) return PAG_OK;
+    PAG_HIP_TRY(hipMemsetAsync(cursor_dev, 0, 8, s));
+    k_succ<3><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, stage, nullptr, (unsigned long long *)cursor_dev, capacity, stage_off_out);
     PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
     int rc;
     if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
@@ -2769,7 +2834,7 @@ int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const 
     if (stage) {
         k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
     } else {
-        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask);
+        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, nullptr, 0, nullptr);
         if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
     }
     PAG_HIP_TRY(hipGetLastError());

@@ -238,7 +238,10 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         const uint64_t *stage_off = nullptr;
         // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
         // records, see DESIGN.md, and computing the bound is not free)
-        if (!std::getenv("PAG_SUCC_TWO_PASS") && np <= (64ull << 20)) {
+        // PAG_SUCC_MODE=bound|append|twopass forces one of the three ways (tests compare their records); PAG_SUCC_TWO_PASS=1 is twopass
+        const char *mode_env = std::getenv("PAG_SUCC_MODE");
+        const std::string mode = mode_env ? mode_env : (std::getenv("PAG_SUCC_TWO_PASS") ? "twopass" : "");
+        if ((mode.empty() && np <= (64ull << 20)) || mode == "bound") {
             if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
                 return rc;
             PAG_HIP_TRY(hipMemcpyAsync(&n_cand, b_ov0.as<uint64_t>() + np + 1, 8, hipMemcpyDeviceToHost, s));
@@ -254,14 +257,46 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
                 }
             }
         }
+        // Count + append: one walk over the candidates, the accepted ones appended to a staging array sized by an estimate
+        // (3 records per vertex; 2.2 at configs[1]) and gathered into coordinate order afterwards.  b_ov1 = where a vertex's
+        // records were staged, b_ov0[np + 3] = the append cursor.  An estimate that turns out too small costs the two-pass
+        // path on top (the counts are taken again).
+        bool appended = false;
+        if (!stage && (mode.empty() || mode == "append")) {
+            const uint64_t cap_env = std::getenv("PAG_SUCC_APPEND_PER_VERTEX") ? std::strtoull(std::getenv("PAG_SUCC_APPEND_PER_VERTEX"), nullptr, 10) : 3;
+            const uint64_t capacity = np * std::max<uint64_t>(cap_env, 1) + 4096;
+            size_t free_b = 0, total_b = 0;
+            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const size_t want = (capacity + 1) * sizeof(SuccRec);
+            if ((want <= b_ctmp.sl->cap || want < (free_b + b_ctmp.sl->cap) / 4) && b_ctmp.alloc(want) == PAG_OK) {
+                uint64_t got[2] = {0, 0};  // total of the counts, cursor
+                if ((rc = trav_succ_append(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 2,
+                                           b_ov1.as<uint64_t>(), b_ctmp.as<SuccRec>(), capacity, b_ov0.as<uint64_t>() + np + 3, s)))
+                    return rc;
+                PAG_HIP_TRY(hipMemcpyAsync(got, b_ov0.as<uint64_t>() + np + 2, 16, hipMemcpyDeviceToHost, s));
+                PAG_HIP_TRY(hipStreamSynchronize(s));
+                if (got[1] <= capacity) {
+                    appended = true;
+                    n_succ = got[0];
+                    stage = b_ctmp.as<SuccRec>();
+                    stage_off = b_ov1.as<uint64_t>();
+                } else if (std::getenv("PAGRAPH_TIMING")) {
+                    std::fprintf(stderr, "[timing] successor records: %llu do not fit the staging estimate (%llu), two passes\n", (unsigned long long)got[1], (unsigned long long)capacity);
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
         uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
-        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
-        if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
-            return rc;
-        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
-        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (!appended) {
+            // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
+            if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
+                                      b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
+                return rc;
+            PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
         if (n_succ >= 0xFFFFFFF0ull) {
             set_error("pag_travel: more than 2^32 successor records");
             return PAG_EINVAL;
@@ -277,7 +312,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         g->tg_ready = true;
         if (std::getenv("PAGRAPH_TIMING"))
             std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%s, %llu candidate pairs)\n", (unsigned long long)n_succ,
-                         (unsigned long long)np, stage ? "staged, one evaluation" : "two passes", (unsigned long long)n_cand);
+                         (unsigned long long)np, appended ? "appended to a staging array, one walk" : stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
         t_compact = now_ms() - t0;
     }
 
@@ -321,6 +356,22 @@ const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_i
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
     if (g && 2 * ctg_index + 1 < g->path_valid.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
     return pag_travel_path_oriented(g, ctg_index, 1, len);
+}
+
+// test hooks: the successor records of the prepared traversal graph (after pag_travel_prepare), copied to the host:
+// succ_off[n_pos + 1], then n_succ records of 16 bytes (target, contig coordinate, step | grade | flags | count, target's offset)
+int pag_debug_succ_sizes(const pag_graph *g, uint64_t *n_pos, uint64_t *n_succ) {
+    if (!g || !g->tg_ready || !n_pos || !n_succ) return PAG_EINVAL;
+    *n_pos = g->tg.n_pos;
+    *n_succ = g->tg.n_succ;
+    return PAG_OK;
+}
+int pag_debug_succ(const pag_graph *g, uint32_t *succ_off, void *recs) {
+    if (!g || !g->tg_ready || !succ_off || !recs) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    PAG_HIP_TRY(hipMemcpy(succ_off, g->tg.succ_off, (g->tg.n_pos + 1) * 4, hipMemcpyDeviceToHost));
+    PAG_HIP_TRY(hipMemcpy(recs, g->tg.succ, g->tg.n_succ * sizeof(SuccRec), hipMemcpyDeviceToHost));
+    return PAG_OK;
 }
 
 // the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
