@@ -333,46 +333,26 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
 // MODE 1: write them to their final place succ[succ_off[u] ..] (after MODE 0 + scan: the two-pass path).
 // MODE 2: write them to a staging array at stage_off[v] — offsets from the cheap upper bound of k_succ_bound — and count;
 //         k_succ_place moves them to coordinate order afterwards.
-// MODE 3: count, then APPEND to the staging array: a wave adds up its 64 counts, takes that much of the array with one
-//         atomic add on `cursor`, and every thread goes over its accepted candidates once more (through the mask, in the
-//         caches now) to write them; stage_off_out[v] = where.  Records that do not fit (cursor beyond `capacity`) are not
-//         written: the host sees the cursor and falls back to the two-pass path.  One walk over the edge lists and
-//         target lists instead of two, and the records reach coordinate order by k_succ_place's gather (reads of whole
-//         64-byte pieces) instead of by scattered 16-byte writes.
+// (Measured and not kept, round 3: count, then APPEND to a staging array in the same kernel — a wave adds up its counts, takes
+// that much of the array with one atomic add, every thread goes over its accepted candidates once more — and gather the
+// records into coordinate order afterwards (k_succ_place): 82 + 31 ms at configs[1] against 37 + 45 + 6 ms for count, fill
+// and link: the second walk over the candidates is what the fill pass costs, not its scattered writes, and it is no
+// cheaper inside the counting thread.)
 template <int MODE>
 __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
-                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask, unsigned long long *__restrict__ cursor, uint64_t capacity,
-                       uint64_t *__restrict__ stage_off_out) {
-    // (MODE 3: every lane of a wave takes part in the wave's prefix sum: the loop runs over whole waves)
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t v0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); v0 < G.n_pos; v0 += stride) {
-        const uint64_t v = v0 + lane_id();
-        const bool valid = v < G.n_pos;
+                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask) {
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t n = 0;
         uint64_t mask = 0ull;
-        uint32_t u = 0;
-        bool poison = false;
-        if (valid) {
-            u = G.newid[v];
-            // its successors may lie outside the region this rank holds: one poison record in their place
-            poison = G.incomplete && u < G.n_zero && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
-            if (poison) n = 1u;
-            else if (MODE == 0 || MODE == 3) n = succ_vertex<0>(G, v, dev, err, mask, nullptr);
-        }
+        const uint32_t u = G.newid[v];
+        // its successors may lie outside the region this rank holds: one poison record in their place
+        const bool poison = G.incomplete && u < G.n_zero && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+        if (poison) n = 1u;
+        else if (MODE == 0) n = succ_vertex<0>(G, v, dev, err, mask, nullptr);
         SuccRec *out = nullptr;
-        if (MODE == 1 && valid) out = G.succ + G.succ_off[u];
-        if (MODE == 2 && valid) out = stage + stage_off[v];
-        if (MODE == 3) {
-            uint32_t tot;
-            const uint32_t ex = wave_excl_sum(n, &tot);
-            unsigned long long wave_base = 0;
-            if (lane_id() == 0 && tot) wave_base = atomicAdd(cursor, (unsigned long long)tot);
-            wave_base = __shfl(wave_base, 0, 64);
-            const uint64_t off = wave_base + ex;
-            if (valid) stage_off_out[v] = off;
-            out = off + n <= capacity ? stage + off : nullptr;
-        }
-        if (valid && MODE != 0 && out) {
+        if (MODE == 1) out = G.succ + G.succ_off[u];
+        if (MODE == 2) out = stage + stage_off[v];
+        if (MODE != 0 && out) {
             if (poison) {
                 SuccRec r;
                 r.tgt = u;
@@ -389,12 +369,10 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                 }
             } else if (MODE == 2) {
                 n = succ_vertex<2>(G, v, dev, err, mask, out);
-            } else if (n) {
-                succ_vertex<1>(G, v, dev, err, mask, out);
             }
         }
-        if (valid && MODE != 1) cnt[u] = n;
-        if (valid && MODE == 0 && amask) amask[v] = mask;
+        if (MODE != 1) cnt[u] = n;
+        if (MODE == 0 && amask) amask[v] = mask;
     }
 }
 
@@ -2793,24 +2771,8 @@ int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
                     const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, hipStream_t s) {
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
-    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr, nullptr, 0, nullptr);
-    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask, nullptr, 0, nullptr);
-    PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
-    int rc;
-    if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
-    k_narrow<<<dim3(grid_for(n + 1)), dim3(256), 0, s>>>(scan_out, n + 1, G.succ_off);
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-// count + append (k_succ<3>): cnt[u], stage_off_out[v] and the staged records; *cursor_dev (zeroed here) ends at the number of
-// records — beyond `capacity`: the staging array is incomplete and the caller takes the two-pass path.  Then the scan of
-// the counts as trav_succ_count does it.
-int trav_succ_append(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                     uint64_t *stage_off_out, SuccRec *stage, uint64_t capacity, uint64_t *cursor_dev, hipStream_t s) {
-    const uint64_t n = G.n_pos;
-    if (!n) return PAG_OK;
-    PAG_HIP_TRY(hipMemsetAsync(cursor_dev, 0, 8, s));
-    k_succ<3><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, stage, nullptr, (unsigned long long *)cursor_dev, capacity, stage_off_out);
+    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr);
+    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask);
     PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
     int rc;
     if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
@@ -2834,7 +2796,7 @@ int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const 
     if (stage) {
         k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
     } else {
-        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, nullptr, 0, nullptr);
+        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask);
         if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
     }
     PAG_HIP_TRY(hipGetLastError());

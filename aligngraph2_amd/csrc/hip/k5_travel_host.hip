@@ -238,7 +238,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         const uint64_t *stage_off = nullptr;
         // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
         // records, see DESIGN.md, and computing the bound is not free)
-        // PAG_SUCC_MODE=bound|append|twopass forces one of the three ways (tests compare their records); PAG_SUCC_TWO_PASS=1 is twopass
+        // PAG_SUCC_MODE=bound|twopass forces one of the two ways (tests compare their records); PAG_SUCC_TWO_PASS=1 is twopass
         const char *mode_env = std::getenv("PAG_SUCC_MODE");
         const std::string mode = mode_env ? mode_env : (std::getenv("PAG_SUCC_TWO_PASS") ? "twopass" : "");
         if ((mode.empty() && np <= (64ull << 20)) || mode == "bound") {
@@ -257,46 +257,14 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
                 }
             }
         }
-        // Count + append: one walk over the candidates, the accepted ones appended to a staging array sized by an estimate
-        // (3 records per vertex; 2.2 at configs[1]) and gathered into coordinate order afterwards.  b_ov1 = where a vertex's
-        // records were staged, b_ov0[np + 3] = the append cursor.  An estimate that turns out too small costs the two-pass
-        // path on top (the counts are taken again).
-        bool appended = false;
-        if (!stage && (mode.empty() || mode == "append")) {
-            const uint64_t cap_env = std::getenv("PAG_SUCC_APPEND_PER_VERTEX") ? std::strtoull(std::getenv("PAG_SUCC_APPEND_PER_VERTEX"), nullptr, 10) : 3;
-            const uint64_t capacity = np * std::max<uint64_t>(cap_env, 1) + 4096;
-            size_t free_b = 0, total_b = 0;
-            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const size_t want = (capacity + 1) * sizeof(SuccRec);
-            if ((want <= b_ctmp.sl->cap || want < (free_b + b_ctmp.sl->cap) / 4) && b_ctmp.alloc(want) == PAG_OK) {
-                uint64_t got[2] = {0, 0};  // total of the counts, cursor
-                if ((rc = trav_succ_append(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 2,
-                                           b_ov1.as<uint64_t>(), b_ctmp.as<SuccRec>(), capacity, b_ov0.as<uint64_t>() + np + 3, s)))
-                    return rc;
-                PAG_HIP_TRY(hipMemcpyAsync(got, b_ov0.as<uint64_t>() + np + 2, 16, hipMemcpyDeviceToHost, s));
-                PAG_HIP_TRY(hipStreamSynchronize(s));
-                if (got[1] <= capacity) {
-                    appended = true;
-                    n_succ = got[0];
-                    stage = b_ctmp.as<SuccRec>();
-                    stage_off = b_ov1.as<uint64_t>();
-                } else if (std::getenv("PAGRAPH_TIMING")) {
-                    std::fprintf(stderr, "[timing] successor records: %llu do not fit the staging estimate (%llu), two passes\n", (unsigned long long)got[1], (unsigned long long)capacity);
-                }
-            } else {
-                (void)hipGetLastError();
-            }
-        }
         // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
         uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
-        if (!appended) {
-            // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
-            if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                      b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
-                return rc;
-            PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
-        }
+        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
+        if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
+                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
+            return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
         if (n_succ >= 0xFFFFFFF0ull) {
             set_error("pag_travel: more than 2^32 successor records");
             return PAG_EINVAL;
@@ -312,7 +280,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         g->tg_ready = true;
         if (std::getenv("PAGRAPH_TIMING"))
             std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%s, %llu candidate pairs)\n", (unsigned long long)n_succ,
-                         (unsigned long long)np, appended ? "appended to a staging array, one walk" : stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
+                         (unsigned long long)np, stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
         t_compact = now_ms() - t0;
     }
 

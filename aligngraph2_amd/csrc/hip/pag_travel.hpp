@@ -192,8 +192,6 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
                int ref_bits, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
 // bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
-int trav_succ_append(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                     uint64_t *stage_off_out, SuccRec *stage, uint64_t capacity, uint64_t *cursor_dev, hipStream_t s);
 int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s);
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
                     const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, hipStream_t s);
