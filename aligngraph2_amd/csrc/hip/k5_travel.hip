@@ -1882,6 +1882,12 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             stopped = 1;
             break;
         }
+        // (TRAV_MODE_UNTIL_LEAP: a resumed walk that only has to cross the point from which leaping is possible — the pieces
+        // of the leaping zone take over there — ends at the first iteration boundary with hasSize + nowSize >= split size)
+        if ((J.mode & TRAV_MODE_UNTIL_LEAP) && (has_size + now_size) >= X.C.split_size) {
+            stopped = 1;
+            break;
+        }
         it_low = lc != 0u ? lc : 0xFFFFFFFFu;
         PROF_END(X, 0, t_app);
         PROF_BEGIN(t_cls);

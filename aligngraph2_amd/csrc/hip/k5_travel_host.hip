@@ -884,6 +884,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         R.active = true;
         R.segs.clear();
         R.chains.assign(cs.seeds.size(), Chain{});
+        R.n_spec = 0;
         R.zone_end = 0;
         R.live_jobs = 0;
         R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
@@ -902,10 +903,16 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
             // jobs; shorter ones pay more overlap and job start-up, longer ones lengthen the first piece of every chain)
             const uint64_t seg_len = seg_len_env ? seg_len_env : 12000;
-            // (only decides how much is walked in parallel: every adoption is checked against the true sizes)
-            const uint64_t safety = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 1000 + 1500;
-            if (split > H + safety + seg_len) {
-                const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H - safety), (uint64_t)cs.ctgRight - 1);
+            // The two kinds of segments OVERLAP around the coordinate where leaping becomes possible (x0 + split - H if the steps
+            // followed the coordinate exactly; they do not quite: `margin` on either side).  A chain adopts segments that
+            // cannot leap up to where its true size allows (try_merge cuts the adoption there), crosses the point with a short
+            // exact walk (TRAV_MODE_UNTIL_LEAP) and goes on with the pieces of the leaping zone that were started before the
+            // point.  (Until round 3 the kinds were kept apart by the margins and every contig walked the ~10 kb between them
+            // exactly, 30-48 ms at the end of its round.)  Only decides how much is walked in parallel: every adoption is
+            // checked against the true sizes.
+            const uint64_t margin = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 400 + 200;
+            if (split > H + seg_len) {
+                const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H) + margin, (uint64_t)cs.ctgRight - 1);
                 for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
                 if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
             }
@@ -917,14 +924,18 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 // (a walk there makes three times the classifications per vertex: shorter pieces for the same job length)
                 static const uint64_t leap_len_env = std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 0;
                 const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
-                const uint64_t drift = cs.len / 400 + 200;
-                const uint64_t first = (uint64_t)x0 + (split > H ? split - H + drift : lseg);
+                // (how far before x0 + split - H the first piece starts: at configs[1] the steps of a path add up to 0.6 % more than
+                // the coordinates it covers — leaping begins ~7 kb earlier than the coordinate says on a 1.2 Mb contig; pieces
+                // started too early cost a few jobs, pieces started too late an exact walk on the contig's critical path)
+                const uint64_t left = std::getenv("PAG_LEAP_LEFT") ? std::strtoull(std::getenv("PAG_LEAP_LEFT"), nullptr, 10)
+                                      : std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 64 + 500;
+                const uint64_t first = (uint64_t)x0 + (split > H + left + lseg ? split - H - left : lseg);
                 // (the last stretch of the strand in shorter pieces still: the job that reaches the end of the strand is the
                 // last one of its round, and a contig that needs a second round waits for it twice)
                 static const uint64_t end_div = std::getenv("PAG_LEAP_END_DIV") ? std::max<uint64_t>(1, std::strtoull(std::getenv("PAG_LEAP_END_DIV"), nullptr, 10)) : 2;
                 const uint64_t end_zone = (uint64_t)cs.ctgRight > 2 * lseg ? (uint64_t)cs.ctgRight - 2 * lseg : 0;
                 for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 / end_div < (uint64_t)cs.ctgRight - 1; x += (x >= end_zone ? std::max<uint64_t>(lseg / end_div, seg_ov) : lseg))
-                    if (ck_x.empty() || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
+                    if (ck_x.size() == n_spec_ck || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
             }
         }
         if (!ck_x.empty()) {
@@ -952,9 +963,11 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 sg.vid = out[3 * q];
                 sg.leap = q >= n_spec_ck;
                 sg.win_low = x0;
-                if (!R.segs.empty() && sg.x <= R.segs.back().x) continue;
+                if (!R.segs.empty() && R.segs.back().leap == sg.leap && sg.x <= R.segs.back().x) continue;  // (increasing within a kind)
                 R.segs.push_back(std::move(sg));
             }
+            R.n_spec = 0;
+            for (auto &sg : R.segs) R.n_spec += sg.leap ? 0 : 1;
             for (size_t q = 0; q < R.segs.size(); ++q) {
                 const bool more = q + 1 < R.segs.size();
                 if (R.segs[q].leap) R.segs[q].stop = more ? (uint32_t)std::min<uint64_t>((uint64_t)R.segs[q + 1].x + seg_ov, 0xFFFFFFFFull) : 0u;  // 0: to the end
@@ -1023,11 +1036,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     };
 
     // continue chain c of contig i exactly: the path so far goes to the walker as a RESUME job
-    auto post_resume = [&](uint32_t i, int c, uint32_t stop) -> int {
+    // (until_leap: only as far as the first iteration boundary from which the walk can leap, TRAV_MODE_UNTIL_LEAP)
+    auto post_resume = [&](uint32_t i, int c, uint32_t stop, bool until_leap = false) -> int {
         CtgState &cs = st[i];
         Chain &ch = RS[i].chains[(size_t)c];
         const uint64_t cap = std::max<uint64_t>(cs.seqCap * ch.grow, ch.len + cs.seqCap / 4 + 4096);
-        std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)TRAV_MODE_RESUME, stop, &ch, ch.exact}};
+        std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)(TRAV_MODE_RESUME | (until_leap ? TRAV_MODE_UNTIL_LEAP : 0)), stop, &ch, ch.exact}};
         return post_batch(i, GRP_CHAIN0 + c, plans);
     };
 
@@ -1062,26 +1076,34 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     auto advance = [&](uint32_t i, int c) -> int {
         RoundState &R = RS[i];
         Chain &ch = R.chains[(size_t)c];
+        const MergeCtx M = merge_ctx(i);
+        const int n_spec = (int)R.n_spec, n_all = (int)R.segs.size();
         for (;;) {
             if (ch.final || ch.job >= 0) return PAG_OK;
             // (where the chain stands: its highest coordinate — its last vertex may have none in the leaping zone)
             const uint32_t cT = ch.mx_all;
-            // the last segment that starts at or before the chain's end
+            // Can the real walk leap from here on (true sizes)?  Then only the pieces of the leaping zone can be adopted
+            // (try_merge_leap's condition 2), before that only the segments that cannot leap (try_merge's condition 3).
+            const bool can = M.has_size + M.k + ch.size >= M.split;
+            const int lo = can ? std::max(ch.next_leap, n_spec) : std::min(ch.next_seg, n_spec), hi = can ? n_all : n_spec;
+            // the last segment of that kind that starts at or before the chain's end
             int j = -1;
-            for (int q = (int)R.segs.size() - 1; q >= ch.next_seg; --q)
+            for (int q = hi - 1; q >= lo; --q)
                 if (R.segs[(size_t)q].x <= cT) {
                     j = q;
                     break;
                 }
-            if (j < 0 || cT == 0) {  // no segment to adopt here: walk on to the next checkpoint, or to the end
+            if (j < 0 || cT == 0) {  // no segment to adopt here: walk on exactly
                 ch.waiting_seg = -1;
-                if (cT != 0 && ch.next_seg < (int)R.segs.size()) return post_resume(i, c, stop_for(R, (size_t)ch.next_seg));
-                return post_resume(i, c, 0u);
+                if (cT == 0) return post_resume(i, c, 0u);
+                if (lo < hi) return post_resume(i, c, stop_for(R, (size_t)lo));  // ... to the next checkpoint of the kind
+                // past the segments that cannot leap and not yet able to leap: across that point, where the pieces of the
+                // leaping zone (if any) take over; otherwise to the end
+                return post_resume(i, c, 0u, !can && n_all > n_spec);
             }
             Seg &sg = R.segs[(size_t)j];
-            if (!sg.leap && cT >= R.zone_end) {  // past the cut zone of the segments that cannot leap: on to the leaping zone's
-                ch.next_seg = j + 1;
-                while (ch.next_seg < (int)R.segs.size() && !R.segs[(size_t)ch.next_seg].leap) ++ch.next_seg;
+            if (!sg.leap && cT >= R.zone_end) {  // past the zone of the segments that cannot leap
+                ch.next_seg = n_spec;
                 continue;
             }
             if (!sg.done) {
@@ -1090,7 +1112,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
             ch.waiting_seg = -1;
             const int m = sg.leap ? try_merge_leap(i, ch, sg) : try_merge(i, ch, sg);
-            ch.next_seg = j + 1;
+            (sg.leap ? ch.next_leap : ch.next_seg) = j + 1;
             if (m == 1) {
                 if (!sg.stopped) {  // the segment's walk ended by itself, and so does the real one
                     ch.final = true;
@@ -1098,13 +1120,13 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 }
                 continue;  // on to the next segment
             }
-            if (m == 2) {  // the leaping zone begins: exactly up to its first segment (if any)
-                while (ch.next_seg < (int)R.segs.size() && !R.segs[(size_t)ch.next_seg].leap) ++ch.next_seg;
+            if (m == 2) {  // adopted up to where leaping may begin: nothing more of this kind
+                ch.next_seg = n_spec;
                 continue;
             }
             ++n_merge_fail;
             if (wdebug) std::fprintf(stderr, "[walk] contig %u chain %d: segment %d not adoptable, walking on exactly\n", i, c, j);
-            // (the next turn of the loop finds no started segment any more and resumes up to the next checkpoint, or to the end)
+            // (the next turn of the loop finds no started segment of the kind any more and resumes up to the next checkpoint, or to the end)
         }
     };
 

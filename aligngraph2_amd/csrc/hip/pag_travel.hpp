@@ -105,7 +105,7 @@ struct TravJob {
     // no contig coordinate (all ones: none); records examined by probes of earlier iterations that are still walking count.
     uint64_t *seq_x;
 };
-enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2, TRAV_MODE_LEAP = 4 };
+enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2, TRAV_MODE_LEAP = 4, TRAV_MODE_UNTIL_LEAP = 8 };  // (8: with RESUME, see k_walk's stop rules)
 
 struct TravJobOut {
     uint64_t seq_len, seq_size;

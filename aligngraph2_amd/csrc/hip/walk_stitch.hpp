@@ -96,7 +96,8 @@ struct Chain {  // one graphTravel: (contig, seed) of the running round
     uint64_t size = 0;  // sum of its steps
     bool final = false;
     int waiting_seg = -1;  // the segment whose job this chain waits for
-    int next_seg = 0;
+    int next_seg = 0;    // the next segment that cannot leap (index into the round's segments) ...
+    int next_leap = 0;   // ... and the next one of the leaping zone the chain has not been through yet
     uint32_t grow = 1;
     bool exact = false;
     int job = -1;          // outstanding job number, -1: none
@@ -106,7 +107,8 @@ struct Chain {  // one graphTravel: (contig, seed) of the running round
 struct RoundState {
     uint32_t round = 0;
     bool active = false;
-    std::vector<Seg> segs;
+    std::vector<Seg> segs;   // the segments that cannot leap, by checkpoint coordinate, then those of the leaping zone, by coordinate
+    size_t n_spec = 0;       // how many of the first kind (the two kinds overlap around the coordinate where leaping begins)
     std::vector<Chain> chains;
     uint32_t zone_end = 0;  // coordinate from which the walk is no longer cut (0: no segments this round)
     uint32_t live_jobs = 0;
