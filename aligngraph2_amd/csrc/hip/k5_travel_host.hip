@@ -877,90 +877,122 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     };
     auto first_stop = [&](const RoundState &R) -> uint32_t { return stop_for(R, 0); };
     DevBuf b_ckreq = buf(), b_ckout = buf();
-    auto start_round = [&](uint32_t i) -> int {
-        CtgState &cs = st[i];
-        RoundState &R = RS[i];
-        R.round += 1;
-        R.active = true;
-        R.segs.clear();
-        R.chains.assign(cs.seeds.size(), Chain{});
-        R.n_spec = 0;
-        R.zone_end = 0;
-        R.live_jobs = 0;
-        R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
-        rounds = std::max<uint64_t>(rounds, R.round);
-        const uint64_t split = (uint64_t)(cs.len * startSplit);
-        // where leaping becomes possible: hasSize + nowSize >= split, nowSize = k + the steps walked.  The steps follow the
-        // contig coordinate closely but not exactly, so the zone is left with a margin; WHERE the walk is cut only decides how
-        // much of it runs in parallel, every adoption is checked against the true sizes (try_merge).
-        uint32_t x0 = 0xFFFFFFFFu;
-        for (auto &sd : cs.seeds) x0 = std::min(x0, sd.ctg);
+    // The rounds of several contigs are prepared together: their checkpoint vertices come from ONE launch of k_checkpoints and
+    // the id ranges around their segments from ONE launch of k_id_bounds (two synchronisations per call; contig by contig
+    // the 48 first rounds of configs[1] were ~100 small launches and synchronisations, ~10 ms before the first job).
+    struct RoundPlan {
         std::vector<uint32_t> ck_x;
         size_t n_spec_ck = 0;
-        uint32_t seed_lo = 0, seed_hi = 0;  // id range for the walks of the seeds up to the first checkpoint (0, 0: the strand)
-        if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
-            const uint64_t H = (uint64_t)cs.varLen + k;
-            // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
-            // jobs; shorter ones pay more overlap and job start-up, longer ones lengthen the first piece of every chain)
-            const uint64_t seg_len = seg_len_env ? seg_len_env : 12000;
-            // The two kinds of segments OVERLAP around the coordinate where leaping becomes possible (x0 + split - H if the steps
-            // followed the coordinate exactly; they do not quite: `margin` on either side).  A chain adopts segments that
-            // cannot leap up to where its true size allows (try_merge cuts the adoption there), crosses the point with a short
-            // exact walk (TRAV_MODE_UNTIL_LEAP) and goes on with the pieces of the leaping zone that were started before the
-            // point.  (Until round 3 the kinds were kept apart by the margins and every contig walked the ~10 kb between them
-            // exactly, 30-48 ms at the end of its round.)  Only decides how much is walked in parallel: every adoption is
-            // checked against the true sizes.
-            const uint64_t margin = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 400 + 200;
-            if (split > H + seg_len) {
-                const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H) + margin, (uint64_t)cs.ctgRight - 1);
-                for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
-                if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
+        uint32_t x0 = 0xFFFFFFFFu, seed_lo = 0, seed_hi = 0;
+        size_t req_off = 0, co_off = 0;
+        bool has_co = false;
+    };
+    auto start_rounds = [&](const std::vector<uint32_t> &which) -> int {
+        std::vector<RoundPlan> RP(which.size());
+        std::vector<TravSeedReq> reqs;
+        // ---- per contig: the round's state, the checkpoint coordinates of its segments
+        for (size_t w = 0; w < which.size(); ++w) {
+            const uint32_t i = which[w];
+            RoundPlan &P = RP[w];
+            std::vector<uint32_t> &ck_x = P.ck_x;
+            size_t &n_spec_ck = P.n_spec_ck;
+            uint32_t &x0 = P.x0;
+            CtgState &cs = st[i];
+            RoundState &R = RS[i];
+            R.round += 1;
+            R.active = true;
+            R.segs.clear();
+            R.chains.assign(cs.seeds.size(), Chain{});
+            R.n_spec = 0;
+            R.zone_end = 0;
+            R.live_jobs = 0;
+            R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
+            rounds = std::max<uint64_t>(rounds, R.round);
+            const uint64_t split = (uint64_t)(cs.len * startSplit);
+            // where leaping becomes possible: hasSize + nowSize >= split, nowSize = k + the steps walked.  The steps follow the
+            // contig coordinate closely but not exactly, so the zone is left with a margin; WHERE the walk is cut only decides how
+            // much of it runs in parallel, every adoption is checked against the true sizes (try_merge).
+            for (auto &sd : cs.seeds) x0 = std::min(x0, sd.ctg);
+            if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
+                const uint64_t H = (uint64_t)cs.varLen + k;
+                // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
+                // jobs; shorter ones pay more overlap and job start-up, longer ones lengthen the first piece of every chain)
+                const uint64_t seg_len = seg_len_env ? seg_len_env : 12000;
+                // The two kinds of segments OVERLAP around the coordinate where leaping becomes possible (x0 + split - H if the steps
+                // followed the coordinate exactly; they do not quite: `margin` on either side).  A chain adopts segments that
+                // cannot leap up to where its true size allows (try_merge cuts the adoption there), crosses the point with a short
+                // exact walk (TRAV_MODE_UNTIL_LEAP) and goes on with the pieces of the leaping zone that were started before the
+                // point.  (Until round 3 the kinds were kept apart by the margins and every contig walked the ~10 kb between them
+                // exactly, 30-48 ms at the end of its round.)  Only decides how much is walked in parallel: every adoption is
+                // checked against the true sizes.
+                const uint64_t margin = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 400 + 200;
+                if (split > H + seg_len) {
+                    const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H) + margin, (uint64_t)cs.ctgRight - 1);
+                    for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
+                    if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
+                }
+                n_spec_ck = ck_x.size();
+                if (use_leap_pieces) {
+                    // the leaping zone gets segments of its own (TRAV_MODE_LEAP), from where the real walk has certainly begun to
+                    // leap (the steps follow the coordinate closely, not exactly: a margin; every adoption is checked with the true
+                    // size) to the end of the strand
+                    // (a walk there makes three times the classifications per vertex: shorter pieces for the same job length)
+                    static const uint64_t leap_len_env = std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 0;
+                    const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
+                    // (how far before x0 + split - H the first piece starts: at configs[1] the steps of a path add up to 0.6 % more than
+                    // the coordinates it covers — leaping begins ~7 kb earlier than the coordinate says on a 1.2 Mb contig; pieces
+                    // started too early cost a few jobs, pieces started too late an exact walk on the contig's critical path)
+                    const uint64_t left = std::getenv("PAG_LEAP_LEFT") ? std::strtoull(std::getenv("PAG_LEAP_LEFT"), nullptr, 10)
+                                          : std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 64 + 500;
+                    const uint64_t first = (uint64_t)x0 + (split > H + left + lseg ? split - H - left : lseg);
+                    // (the last stretch of the strand in shorter pieces still: the job that reaches the end of the strand is the
+                    // last one of its round, and a contig that needs a second round waits for it twice)
+                    static const uint64_t end_div = std::getenv("PAG_LEAP_END_DIV") ? std::max<uint64_t>(1, std::strtoull(std::getenv("PAG_LEAP_END_DIV"), nullptr, 10)) : 2;
+                    const uint64_t end_zone = (uint64_t)cs.ctgRight > 2 * lseg ? (uint64_t)cs.ctgRight - 2 * lseg : 0;
+                    for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 / end_div < (uint64_t)cs.ctgRight - 1; x += (x >= end_zone ? std::max<uint64_t>(lseg / end_div, seg_ov) : lseg))
+                        if (ck_x.size() == n_spec_ck || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
+                }
             }
-            n_spec_ck = ck_x.size();
-            if (use_leap_pieces) {
-                // the leaping zone gets segments of its own (TRAV_MODE_LEAP), from where the real walk has certainly begun to
-                // leap (the steps follow the coordinate closely, not exactly: a margin; every adoption is checked with the true
-                // size) to the end of the strand
-                // (a walk there makes three times the classifications per vertex: shorter pieces for the same job length)
-                static const uint64_t leap_len_env = std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 0;
-                const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
-                // (how far before x0 + split - H the first piece starts: at configs[1] the steps of a path add up to 0.6 % more than
-                // the coordinates it covers — leaping begins ~7 kb earlier than the coordinate says on a 1.2 Mb contig; pieces
-                // started too early cost a few jobs, pieces started too late an exact walk on the contig's critical path)
-                const uint64_t left = std::getenv("PAG_LEAP_LEFT") ? std::strtoull(std::getenv("PAG_LEAP_LEFT"), nullptr, 10)
-                                      : std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 64 + 500;
-                const uint64_t first = (uint64_t)x0 + (split > H + left + lseg ? split - H - left : lseg);
-                // (the last stretch of the strand in shorter pieces still: the job that reaches the end of the strand is the
-                // last one of its round, and a contig that needs a second round waits for it twice)
-                static const uint64_t end_div = std::getenv("PAG_LEAP_END_DIV") ? std::max<uint64_t>(1, std::strtoull(std::getenv("PAG_LEAP_END_DIV"), nullptr, 10)) : 2;
-                const uint64_t end_zone = (uint64_t)cs.ctgRight > 2 * lseg ? (uint64_t)cs.ctgRight - 2 * lseg : 0;
-                for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 / end_div < (uint64_t)cs.ctgRight - 1; x += (x >= end_zone ? std::max<uint64_t>(lseg / end_div, seg_ov) : lseg))
-                    if (ck_x.size() == n_spec_ck || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
-            }
-        }
-        if (!ck_x.empty()) {
-            std::vector<TravSeedReq> reqs(ck_x.size());
+            P.req_off = reqs.size();
             for (size_t q = 0; q < ck_x.size(); ++q) {
                 const uint64_t off = ck_x[q] - cs.ctgLeft;
-                reqs[q].ctg = i;
-                reqs[q].pad = 0;
-                reqs[q].pos = off;
-                reqs[q].left = off - std::min<uint64_t>(off, 64);
-                reqs[q].right = off + 64;
+                TravSeedReq rq;
+                rq.ctg = i;
+                rq.pad = 0;
+                rq.pos = off;
+                rq.left = off - std::min<uint64_t>(off, 64);
+                rq.right = off + 64;
+                reqs.push_back(rq);
             }
-            int r;
+        }
+        // ---- the checkpoint vertices of all of them
+        std::vector<uint32_t> out(reqs.size() * 3);
+        int r;
+        if (!reqs.empty()) {
             if ((r = b_ckreq.alloc(reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(reqs.size() * 12))) return r;
             if ((r = upload_contigs())) return r;
-            std::vector<uint32_t> out(reqs.size() * 3);
             PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, reqs.data(), reqs.size() * sizeof(TravSeedReq), hipMemcpyHostToDevice, s));
             trav_launch_checkpoints(G, b_tc.as<TravContig>(), b_ckreq.as<TravSeedReq>(), (uint32_t)reqs.size(), deviation, b_ckout.as<uint32_t>(), s);
             PAG_HIP_TRY(hipMemcpyAsync(out.data(), b_ckout.p, out.size() * 4, hipMemcpyDeviceToHost, s));
             PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
+        // ---- per contig: its segments, and the contig coordinates their id ranges are asked for
+        std::vector<uint32_t> co;
+        for (size_t w = 0; w < which.size(); ++w) {
+            const uint32_t i = which[w];
+            RoundPlan &P = RP[w];
+            CtgState &cs = st[i];
+            RoundState &R = RS[i];
+            const std::vector<uint32_t> &ck_x = P.ck_x;
+            const size_t n_spec_ck = P.n_spec_ck;
+            const uint32_t x0 = P.x0;
+            if (ck_x.empty()) continue;
+            const uint32_t *out_c = out.data() + 3 * P.req_off;
             for (size_t q = 0; q < ck_x.size(); ++q) {
-                if (out[3 * q] == PAG_NONE) continue;
+                if (out_c[3 * q] == PAG_NONE) continue;
                 Seg sg;
-                sg.x = out[3 * q + 1];
-                sg.vid = out[3 * q];
+                sg.x = out_c[3 * q + 1];
+                sg.vid = out_c[3 * q];
                 sg.leap = q >= n_spec_ck;
                 sg.win_low = x0;
                 if (!R.segs.empty() && R.segs.back().leap == sg.leap && sg.x <= R.segs.back().x) continue;  // (increasing within a kind)
@@ -980,21 +1012,39 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             }
             if (!R.segs.empty()) {  // id ranges around the segments: [checkpoint - 2000, stop + 3000] in contig coordinates
                 const size_t nq = R.segs.size();
-                std::vector<uint32_t> co(2 * nq + 2), ids(2 * nq + 2);
+                P.has_co = true;
+                P.co_off = co.size();
+                co.resize(co.size() + 2 * nq + 2);
+                uint32_t *cc = co.data() + P.co_off;
                 for (size_t q = 0; q < nq; ++q) {
-                    co[2 * q] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)R.segs[q].x - std::min<uint64_t>(R.segs[q].x, 2000));
-                    co[2 * q + 1] = R.segs[q].stop ? (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)R.segs[q].stop + 3000) : cs.ctgRight;
+                    cc[2 * q] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)R.segs[q].x - std::min<uint64_t>(R.segs[q].x, 2000));
+                    cc[2 * q + 1] = R.segs[q].stop ? (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)R.segs[q].stop + 3000) : cs.ctgRight;
                 }
                 // ... and around the seeds' own first piece: [lowest seed - 2000, first stop + 3000]
-                co[2 * nq] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)x0 - std::min<uint64_t>(x0, 2000));
-                co[2 * nq + 1] = (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)first_stop(R) + 3000);
-                if ((r = b_ckreq.alloc(co.size() * 4 + reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(co.size() * 4 + reqs.size() * 12))) return r;
-                PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s));
-                trav_launch_id_bounds(G, b_ckreq.as<uint32_t>(), (uint32_t)co.size(), b_ckout.as<uint32_t>(), s);
-                PAG_HIP_TRY(hipMemcpyAsync(ids.data(), b_ckout.p, ids.size() * 4, hipMemcpyDeviceToHost, s));
-                PAG_HIP_TRY(hipStreamSynchronize(s));
+                cc[2 * nq] = (uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)x0 - std::min<uint64_t>(x0, 2000));
+                cc[2 * nq + 1] = (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)first_stop(R) + 3000);
+            }
+        }
+        std::vector<uint32_t> ids(co.size());
+        if (!co.empty()) {
+            if ((r = b_ckreq.alloc(co.size() * 4)) || (r = b_ckout.alloc(co.size() * 4))) return r;
+            PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s));
+            trav_launch_id_bounds(G, b_ckreq.as<uint32_t>(), (uint32_t)co.size(), b_ckout.as<uint32_t>(), s);
+            PAG_HIP_TRY(hipMemcpyAsync(ids.data(), b_ckout.p, ids.size() * 4, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
+        // ---- per contig: the id ranges, the jobs
+        for (size_t w = 0; w < which.size(); ++w) {
+            const uint32_t i = which[w];
+            RoundPlan &P = RP[w];
+            CtgState &cs = st[i];
+            RoundState &R = RS[i];
+            uint32_t seed_lo = 0, seed_hi = 0;  // id range for the walks of the seeds up to the first checkpoint (0, 0: the strand)
+            if (P.has_co) {
+                const size_t nq = R.segs.size();
+                const uint32_t *idc = ids.data() + P.co_off;
                 auto window = [&](size_t q, uint32_t *wlo, uint32_t *whi) {
-                    uint32_t lo = std::max(ids[2 * q], cs.inLo), hi = std::min(ids[2 * q + 1], cs.inHi);
+                    uint32_t lo = std::max(idc[2 * q], cs.inLo), hi = std::min(idc[2 * q + 1], cs.inHi);
                     lo = cs.inLo + ((lo - cs.inLo) & ~31u);  // (the strand's global-visited bitmap is read word-wise from here)
                     if (hi <= lo) hi = std::min<uint32_t>(cs.inHi, lo + 64);
                     *wlo = lo;
@@ -1003,36 +1053,37 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
                 for (size_t q = 0; q < nq; ++q) window(q, &R.segs[q].win_lo, &R.segs[q].win_hi);
                 if (first_stop(R) != 0u) window(nq, &seed_lo, &seed_hi);
             }
-        }
-        std::vector<JobPlan> plans;
-        const uint64_t cap_full = cs.seqCap;
-        for (size_t sd = 0; sd < cs.seeds.size(); ++sd) {
-            const uint32_t stop = R.segs.empty() ? 0u : first_stop(R);
-            // (a seed's walk that stops at the first checkpoint is a piece like the segments: direct-mapped marks around it,
-            // a sequence buffer for its stretch; the full-strand arrays, 130 MB per job at configs[1], are for resumed walks)
-            JobPlan pl{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false};
-            if (stop != 0u && seed_hi != 0u && cs.seeds[sd].ctg <= stop) {
-                pl.win_lo = seed_lo;
-                pl.win_hi = seed_hi;
-                pl.cap = std::min<uint64_t>(cap_full, ((uint64_t)stop - cs.seeds[sd].ctg) / 2 + 8192);
-            }
-            plans.push_back(pl);
-        }
-        // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
-        static const bool leap_first = !(std::getenv("PAG_LEAP_FIRST") && std::atoi(std::getenv("PAG_LEAP_FIRST")) == 0);
-        for (int pass = 0; pass < 2; ++pass)
-            for (size_t q = 0; q < R.segs.size(); ++q) {
-                if (R.segs[q].leap != ((pass == 0) == leap_first)) continue;
-                const uint64_t spanc = (R.segs[q].stop ? (uint64_t)R.segs[q].stop : (uint64_t)cs.ctgRight) - R.segs[q].x;
-                const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
-                JobPlan pl{1, (int)q, cap, R.segs[q].vid, (uint32_t)(R.segs[q].leap ? TRAV_MODE_LEAP : TRAV_MODE_SPEC), R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi};
-                pl.win_low = R.segs[q].leap ? R.segs[q].win_low : 0u;
+            std::vector<JobPlan> plans;
+            const uint64_t cap_full = cs.seqCap;
+            for (size_t sd = 0; sd < cs.seeds.size(); ++sd) {
+                const uint32_t stop = R.segs.empty() ? 0u : first_stop(R);
+                // (a seed's walk that stops at the first checkpoint is a piece like the segments: direct-mapped marks around it,
+                // a sequence buffer for its stretch; the full-strand arrays, 130 MB per job at configs[1], are for resumed walks)
+                JobPlan pl{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false};
+                if (stop != 0u && seed_hi != 0u && cs.seeds[sd].ctg <= stop) {
+                    pl.win_lo = seed_lo;
+                    pl.win_hi = seed_hi;
+                    pl.cap = std::min<uint64_t>(cap_full, ((uint64_t)stop - cs.seeds[sd].ctg) / 2 + 8192);
+                }
                 plans.push_back(pl);
             }
-        if (wdebug)
-            std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_walk0, i,
-                         R.round, cs.seeds.size(), R.segs.size(), R.zone_end, cs.ctgLeft, cs.ctgRight);
-        return post_batch(i, GRP_ROUND, plans);
+            // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
+            static const bool leap_first = !(std::getenv("PAG_LEAP_FIRST") && std::atoi(std::getenv("PAG_LEAP_FIRST")) == 0);
+            for (int pass = 0; pass < 2; ++pass)
+                for (size_t q = 0; q < R.segs.size(); ++q) {
+                    if (R.segs[q].leap != ((pass == 0) == leap_first)) continue;
+                    const uint64_t spanc = (R.segs[q].stop ? (uint64_t)R.segs[q].stop : (uint64_t)cs.ctgRight) - R.segs[q].x;
+                    const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
+                    JobPlan pl{1, (int)q, cap, R.segs[q].vid, (uint32_t)(R.segs[q].leap ? TRAV_MODE_LEAP : TRAV_MODE_SPEC), R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi};
+                    pl.win_low = R.segs[q].leap ? R.segs[q].win_low : 0u;
+                    plans.push_back(pl);
+                }
+            if (wdebug)
+                std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_walk0, i,
+                             R.round, cs.seeds.size(), R.segs.size(), R.zone_end, cs.ctgLeft, cs.ctgRight);
+            if ((r = post_batch(i, GRP_ROUND, plans))) return r;
+        }
+        return PAG_OK;
     };
 
     // continue chain c of contig i exactly: the path so far goes to the walker as a RESUME job
@@ -1186,8 +1237,12 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         // every contig's first round now ends at about the same time, earlier than the last ones did.
         static const uint32_t interleave = std::getenv("PAG_POST_INTERLEAVE") ? (uint32_t)std::atoi(std::getenv("PAG_POST_INTERLEAVE")) : 8u;
         defer_ring2 = interleave != 0;
-        for (uint32_t i : order)
-            if (!st[i].done && (rc = start_round(i))) return fail(rc);
+        {
+            std::vector<uint32_t> first_rounds;
+            for (uint32_t i : order)
+                if (!st[i].done) first_rounds.push_back(i);
+            if ((rc = start_rounds(first_rounds))) return fail(rc);
+        }
         defer_ring2 = false;
         if (interleave) {
             std::vector<size_t> at(n_sel, 0);
@@ -1883,8 +1938,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             if (st[i].done && (rc = deliver_contig(i))) return fail(rc);
         lap("reseed");
         // ---- post the follow-up rounds
-        for (uint32_t i : next_round)
-            if ((rc = start_round(i))) return fail(rc);
+        if (!next_round.empty() && (rc = start_rounds(next_round))) return fail(rc);
         flush_backlog();
         if ((rc = publish())) return fail(rc);
         lap("round prep");
