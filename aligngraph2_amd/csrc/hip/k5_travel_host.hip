@@ -871,11 +871,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // ---- start of a round of contig i: its seeds are in cs.seeds.  Decides where the walk can be cut, finds the checkpoint
     //      vertices and posts the seed jobs and the segment jobs.
     // stop coordinate of a job that walks up to segment q of the round (its checkpoint + the overlap)
-    auto stop_for = [&](const RoundState &R, size_t q) -> uint32_t {
-        const uint64_t x = (uint64_t)R.segs[q].x + seg_ov;
-        return (uint32_t)(R.segs[q].leap ? std::min<uint64_t>(x, 0xFFFFFFFFull) : std::min<uint64_t>(x, R.zone_end));
-    };
-    auto first_stop = [&](const RoundState &R) -> uint32_t { return stop_for(R, 0); };
+    auto first_stop = [&](const RoundState &R) -> uint32_t { return stitch::stop_for(R, 0, seg_ov); };
     DevBuf b_ckreq = buf(), b_ckout = buf();
     // The rounds of several contigs are prepared together: their checkpoint vertices come from ONE launch of k_checkpoints and
     // the id ranges around their segments from ONE launch of k_id_bounds (two synchronisations per call; contig by contig
@@ -1105,80 +1101,21 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
         M.has_size = RS[i].has_size;
         return M;
     };
-    auto try_merge = [&](uint32_t i, Chain &ch, Seg &sg) -> int {
-        uint64_t got = 0;
-        const int m = stitch::try_merge(merge_ctx(i), ch, sg, &got);
-        n_adopted += got;
-        return m;
-    };
-    auto try_merge_leap = [&](uint32_t i, Chain &ch, Seg &sg) -> int {
-        uint64_t got = 0;
-        int why = -1;
-        const int m = stitch::try_merge_leap(merge_ctx(i), ch, sg, &got, &why);
-        n_adopted += got;
-        if (m) n_leap_adopted += 1;
-        else {
-            n_leap_refused[why & 7] += 1;
-            if (wdebug) std::fprintf(stderr, "[walk] contig %u: leap segment at %u refused (reason %d)\n", i, sg.x, why);
-        }
-        return m;
-    };
     // what a chain does after its job has ended at a stop coordinate or after a segment it waits for has finished
+    // (walk_stitch.hpp advance_chain: adoptions, then how the chain goes on)
+    AdvanceStats adv_stats;
     auto advance = [&](uint32_t i, int c) -> int {
         RoundState &R = RS[i];
         Chain &ch = R.chains[(size_t)c];
-        const MergeCtx M = merge_ctx(i);
-        const int n_spec = (int)R.n_spec, n_all = (int)R.segs.size();
-        for (;;) {
-            if (ch.final || ch.job >= 0) return PAG_OK;
-            // (where the chain stands: its highest coordinate — its last vertex may have none in the leaping zone)
-            const uint32_t cT = ch.mx_all;
-            // Can the real walk leap from here on (true sizes)?  Then only the pieces of the leaping zone can be adopted
-            // (try_merge_leap's condition 2), before that only the segments that cannot leap (try_merge's condition 3).
-            const bool can = M.has_size + M.k + ch.size >= M.split;
-            const int lo = can ? std::max(ch.next_leap, n_spec) : std::min(ch.next_seg, n_spec), hi = can ? n_all : n_spec;
-            // the last segment of that kind that starts at or before the chain's end
-            int j = -1;
-            for (int q = hi - 1; q >= lo; --q)
-                if (R.segs[(size_t)q].x <= cT) {
-                    j = q;
-                    break;
-                }
-            if (j < 0 || cT == 0) {  // no segment to adopt here: walk on exactly
-                ch.waiting_seg = -1;
-                if (cT == 0) return post_resume(i, c, 0u);
-                if (lo < hi) return post_resume(i, c, stop_for(R, (size_t)lo));  // ... to the next checkpoint of the kind
-                // past the segments that cannot leap and not yet able to leap: across that point, where the pieces of the
-                // leaping zone (if any) take over; otherwise to the end
-                return post_resume(i, c, 0u, !can && n_all > n_spec);
-            }
-            Seg &sg = R.segs[(size_t)j];
-            if (!sg.leap && cT >= R.zone_end) {  // past the zone of the segments that cannot leap
-                ch.next_seg = n_spec;
-                continue;
-            }
-            if (!sg.done) {
-                ch.waiting_seg = j;
-                return PAG_OK;
-            }
-            ch.waiting_seg = -1;
-            const int m = sg.leap ? try_merge_leap(i, ch, sg) : try_merge(i, ch, sg);
-            (sg.leap ? ch.next_leap : ch.next_seg) = j + 1;
-            if (m == 1) {
-                if (!sg.stopped) {  // the segment's walk ended by itself, and so does the real one
-                    ch.final = true;
-                    return PAG_OK;
-                }
-                continue;  // on to the next segment
-            }
-            if (m == 2) {  // adopted up to where leaping may begin: nothing more of this kind
-                ch.next_seg = n_spec;
-                continue;
-            }
-            ++n_merge_fail;
-            if (wdebug) std::fprintf(stderr, "[walk] contig %u chain %d: segment %d not adoptable, walking on exactly\n", i, c, j);
-            // (the next turn of the loop finds no started segment of the kind any more and resumes up to the next checkpoint, or to the end)
-        }
+        const uint64_t fails_before = adv_stats.merge_fail;
+        const Next nx = advance_chain(R, ch, merge_ctx(i), seg_ov, adv_stats);
+        n_adopted = adv_stats.adopted;
+        n_leap_adopted = adv_stats.leap_adopted;
+        n_merge_fail = adv_stats.merge_fail;
+        for (int w = 0; w < 8; ++w) n_leap_refused[w] = adv_stats.leap_refused[w];
+        if (wdebug && adv_stats.merge_fail != fails_before) std::fprintf(stderr, "[walk] contig %u chain %d: a segment was not adoptable, walking on exactly\n", i, c);
+        if (nx.what == Next::Resume) return post_resume(i, c, nx.stop, nx.until_leap);
+        return PAG_OK;
     };
 
     auto fail = [&](int rc2) {

@@ -448,6 +448,91 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
     return 1;
 }
 
+// ---- what a chain does next --------------------------------------------------------------------------------------------
+// A round's segments: R.segs[0 .. n_spec) cannot leap, R.segs[n_spec ..) are the pieces of the leaping zone, each kind by
+// checkpoint coordinate; the kinds OVERLAP around the coordinate where leaping becomes possible.  Which kind a chain may
+// adopt is decided by its TRUE size: before hasSize + k + (its steps) reaches the split size only segments that cannot leap
+// (try_merge's condition 3), from then on only pieces of the leaping zone (try_merge_leap's condition 2).
+
+// the coordinate at (or beyond) which the walk towards segment q stops: a little into the segment, so that the two paths
+// have a stretch in common
+inline uint32_t stop_for(const RoundState &R, size_t q, uint64_t seg_ov) {
+    const uint64_t x = (uint64_t)R.segs[q].x + seg_ov;
+    return (uint32_t)(R.segs[q].leap ? std::min<uint64_t>(x, 0xFFFFFFFFull) : std::min<uint64_t>(x, R.zone_end));
+}
+
+struct Next {  // what the caller has to do for the chain
+    enum What { Nothing, Resume } what = Nothing;  // Nothing: it is final, waits for a job or for a segment (ch.waiting_seg)
+    uint32_t stop = 0;        // Resume: continue the chain exactly, up to this coordinate (0: to the end) ...
+    bool until_leap = false;  // ... or only to the first iteration boundary from which the walk can leap (TRAV_MODE_UNTIL_LEAP)
+};
+struct AdvanceStats {
+    uint64_t adopted = 0, leap_adopted = 0, merge_fail = 0;
+    uint64_t leap_refused[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+// Called when a chain's job has ended at a stop coordinate, or a segment it waits for has finished: adopts what can be
+// adopted, then says how the chain goes on.
+inline Next advance_chain(RoundState &R, Chain &ch, const MergeCtx &M, uint64_t seg_ov, AdvanceStats &S, int *last_refusal = nullptr) {
+    const int n_spec = (int)R.n_spec, n_all = (int)R.segs.size();
+    for (;;) {
+        if (ch.final || ch.job >= 0) return Next{};
+        // (where the chain stands: its highest coordinate — its last vertex may have none in the leaping zone)
+        const uint32_t cT = ch.mx_all;
+        const bool can = M.has_size + M.k + ch.size >= M.split;  // the real walk can leap from here on
+        const int lo = can ? std::max(ch.next_leap, n_spec) : std::min(ch.next_seg, n_spec), hi = can ? n_all : n_spec;
+        // the last segment of that kind that starts at or before the chain's end
+        int j = -1;
+        for (int q = hi - 1; q >= lo; --q)
+            if (R.segs[(size_t)q].x <= cT) {
+                j = q;
+                break;
+            }
+        if (j < 0 || cT == 0) {  // no segment to adopt here: walk on exactly
+            ch.waiting_seg = -1;
+            if (cT == 0) return Next{Next::Resume, 0u, false};
+            if (lo < hi) return Next{Next::Resume, stop_for(R, (size_t)lo, seg_ov), false};  // ... to the next checkpoint of the kind
+            // past the segments that cannot leap and not yet able to leap: across that point, where the pieces of the
+            // leaping zone (if any) take over; otherwise to the end
+            return Next{Next::Resume, 0u, !can && n_all > n_spec};
+        }
+        Seg &sg = R.segs[(size_t)j];
+        if (!sg.leap && cT >= R.zone_end) {  // past the zone of the segments that cannot leap
+            ch.next_seg = n_spec;
+            continue;
+        }
+        if (!sg.done) {
+            ch.waiting_seg = j;
+            return Next{};
+        }
+        ch.waiting_seg = -1;
+        uint64_t got = 0;
+        int why = -1;
+        const int m = sg.leap ? try_merge_leap(M, ch, sg, &got, &why) : try_merge(M, ch, sg, &got);
+        S.adopted += got;
+        if (sg.leap) {
+            if (m) S.leap_adopted += 1;
+            else {
+                S.leap_refused[why & 7] += 1;
+                if (last_refusal) *last_refusal = why;
+            }
+        }
+        (sg.leap ? ch.next_leap : ch.next_seg) = j + 1;
+        if (m == 1) {
+            if (!sg.stopped) {  // the segment's walk ended by itself, and so does the real one
+                ch.final = true;
+                return Next{};
+            }
+            continue;  // on to the next segment
+        }
+        if (m == 2) {  // adopted up to where leaping may begin: nothing more of this kind
+            ch.next_seg = n_spec;
+            continue;
+        }
+        S.merge_fail += 1;
+        // (the next turn of the loop finds no started segment of the kind any more and resumes up to the next checkpoint, or to the end)
+    }
+}
 
 }  // namespace stitch
 }  // namespace pagdev

@@ -24,6 +24,18 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 
+def _digests(out_dir):
+    """SHA-256 per output file (contig.txt as a sorted set: the reference writes it in hash order)"""
+    import hashlib
+    dig = {}
+    for f in sorted(os.listdir(out_dir)):
+        data = open(os.path.join(out_dir, f), "rb").read()
+        if f == "contig.txt":
+            data = b"\n".join(sorted(data.split()))
+        dig[f] = hashlib.sha256(data).hexdigest()
+    return dig
+
+
 def multi_block(args, rec, d, ours, n_bases):
     """one run of several config blocks through the drop-in, in the driver's modes; every mode must write the same bytes"""
     import hashlib
@@ -73,6 +85,8 @@ def main():
     ap.add_argument("--ref-threads", type=int, default=64)
     ap.add_argument("--skip-reference", action="store_true", help="only time the drop-in executable")
     ap.add_argument("--compare", action="store_true", help="reference -t 16 under the serialising shim; byte-compare all output files")
+    ap.add_argument("--compare-with", default=None, help="a JSON written by an earlier --compare run of the same workload: the drop-in's output files are "
+                    "held against the reference's per-file SHA-256 kept there (no reference run)")
     ap.add_argument("--blocks", type=int, default=1, help="> 1: config.txt written that many times over (every block reads the same files); "
                     "the drop-in alone, block after block / next block parsed ahead / host half beside the next block / packed sidecars")
     args = ap.parse_args()
@@ -101,7 +115,7 @@ def main():
     if args.compare:
         ref_env, ref_threads = {"LD_PRELOAD": os.path.join(ROOT, "oracle", "_ref", "libserial_threads.so")}, 16
     for name, exe, threads, env in (("ours", ours, 16, {"PAGRAPH_TIMING": "1"}), ("reference", ref_bin, ref_threads, ref_env)):
-        if name == "reference" and args.skip_reference:
+        if name == "reference" and (args.skip_reference or args.compare_with):
             continue
         out = f"/dev/shm/c2_out_{name}"
         shutil.rmtree(out, ignore_errors=True)
@@ -115,6 +129,13 @@ def main():
                      "count_lines": [ln.strip() for ln in r.stdout.splitlines() if ln.strip().startswith(("merge edge", "total pos", "merge pos"))],
                      "stderr_tail": r.stderr[-3000:] if name == "ours" else r.stderr[-300:]}
         print(name, rec[name]["wall_s"], rec[name]["bases_per_s"], flush=True)
+        if name == "ours" and args.compare_with:
+            want = json.load(open(args.compare_with))["compare"]["reference_sha256"]
+            got = _digests(out)
+            diff = sorted(f for f in set(want) | set(got) if want.get(f) != got.get(f))
+            rec["compare"] = {"reference": "per-file SHA-256 of the reference's outputs kept in " + os.path.basename(args.compare_with), "files_reference": len(want),
+                              "files_ours": len(got), "differing_files": diff, "identical": not diff}
+            print("compare:", rec["compare"], flush=True)
         if not args.compare:
             shutil.rmtree(out, ignore_errors=True)
     if args.compare and "reference" in rec and rec["reference"]["returncode"] == 0 and rec["ours"]["returncode"] == 0:
@@ -131,7 +152,7 @@ def main():
                 x, y = sorted(x.split()), sorted(y.split())
             if x != y:
                 diff.append(f)
-        rec["compare"] = {"reference": "oracle/_ref/pagraph -t 16 under libserial_threads.so", "files_reference": len(fa), "files_ours": len(fb),
+        rec["compare"] = {"reference_sha256": _digests(a), "reference": "oracle/_ref/pagraph -t 16 under libserial_threads.so", "files_reference": len(fa), "files_ours": len(fb),
                           "bytes_compared": total_bytes, "differing_files": diff, "identical": not diff and fa == fb,
                           "count_lines_equal": rec["reference"]["count_lines"] == rec["ours"]["count_lines"]}
         print("compare:", rec["compare"], flush=True)

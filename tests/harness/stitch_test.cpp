@@ -100,6 +100,67 @@ int pagt_stitch(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, con
     return 0;
 }
 
+// advance_chain: a round with n_seg segments (the first n_spec cannot leap; segment q's path = entries [seg_off[q], seg_off[q + 1]) of
+// the flat arrays, max_back 0 / max_chosen 2 / max_probe 50 for all) and one chain.  out: what (0 nothing, 1 resume), stop,
+// until_leap, chain length, next_seg, next_leap, waiting_seg, final, vertices adopted, merges failed, leap pieces adopted,
+// last leap refusal reason.
+int pagt_advance(uint32_t n_seg, uint32_t n_spec, uint32_t zone_end, const uint32_t *seg_x, const uint32_t *seg_done, const uint32_t *seg_stopped,
+                 const uint32_t *seg_usable, const uint64_t *seg_off, const uint32_t *pv, const uint32_t *ps, const uint32_t *ppc, const uint32_t *pxl,
+                 const uint32_t *pxh, const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, uint32_t k,
+                 uint64_t deviation, uint64_t split, uint64_t has_size, uint64_t seg_ov, int64_t *out) {
+    RoundState R;
+    R.n_spec = n_spec;
+    R.zone_end = zone_end;
+    std::vector<Tables> tabs(2 * (size_t)n_seg + 1);
+    for (uint32_t q = 0; q < n_seg; ++q) {
+        Seg sg;
+        sg.x = seg_x[q];
+        sg.leap = q >= n_spec;
+        sg.done = seg_done[q] != 0;
+        sg.stopped = seg_stopped[q] != 0;
+        sg.usable = seg_usable[q] != 0;
+        const size_t o = (size_t)seg_off[q], n = (size_t)(seg_off[q + 1] - seg_off[q]);
+        sg.P.v = pv + o;
+        sg.P.s = ps + o;
+        sg.P.pc = ppc + o;
+        sg.P.n = n;
+        if (sg.leap && pxl) {
+            sg.P.xl = pxl + o;
+            sg.P.xh = pxh + o;
+            sg.P.xagg = tabs[2 * q + 1].x(sg.P.xl, sg.P.xh, n);
+        }
+        sg.P.agg = tabs[2 * q].a(sg.P.v, sg.P.s, sg.P.pc, n);
+        sg.max_back = 0;
+        sg.max_chosen = 2;
+        sg.max_probe = 50;
+        R.segs.push_back(sg);
+    }
+    R.chains.assign(1, Chain{});
+    Chain &ch = R.chains[0];
+    build_chain(ch, tabs[2 * (size_t)n_seg], tv, ts, tpc, part_off, n_parts);
+    MergeCtx M;
+    M.k = k;
+    M.deviation = deviation;
+    M.split = split;
+    M.has_size = has_size;
+    AdvanceStats S;
+    int why = -1;
+    const Next nx = advance_chain(R, ch, M, seg_ov, S, &why);
+    out[0] = nx.what == Next::Resume ? 1 : 0;
+    out[1] = nx.stop;
+    out[2] = nx.until_leap ? 1 : 0;
+    out[3] = (int64_t)ch.len;
+    out[4] = ch.next_seg;
+    out[5] = ch.next_leap;
+    out[6] = ch.waiting_seg;
+    out[7] = ch.final ? 1 : 0;
+    out[8] = (int64_t)S.adopted;
+    out[9] = (int64_t)S.merge_fail;
+    out[10] = (int64_t)S.leap_adopted;
+    out[11] = why;
+    return 0;
+}
+
 // chain_before / common_back on their own
 void pagt_chain_before(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, uint64_t idx, uint32_t *mx,
                        uint32_t *m0) {

@@ -262,3 +262,103 @@ def test_long_paths_through_the_block_tables(lib, seed):
     log[far] = (True, 100010, 0xFFFFFFFF)
     bad = stitch(lib, T, parts, P, leap=True, log=log, k=14, dev=20, split=1000, has_size=5000)
     assert (bad[0], bad[2]) == (0, 6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# what a chain does next (advance_chain): the two kinds of segments overlap around the point where leaping begins
+# ---------------------------------------------------------------------------------------------------------------------
+def advance(lib, T, segs, n_spec, zone_end, *, parts=None, split=10 ** 9, has_size=0, k=14, dev=20, seg_ov=150):
+    """segs: list of dicts x, path (list of (v, s, pc)), done, stopped, usable, log (leap pieces)"""
+    flat = [e for sg in segs for e in sg["path"]]
+    off = np.concatenate([[0], np.cumsum([len(sg["path"]) for sg in segs])]).astype(np.uint64)
+    pv, ps, ppc = (_u32([e[i] for e in flat] + [0]) for i in range(3))
+    logs = [lg for sg in segs for lg in sg.get("log", [(False, 0, 0xFFFFFFFF)] * len(sg["path"]))]
+    xl = _u32([m0 for _, _, m0 in logs] + [0])
+    xh = _u32([((1 << 31) | (e & 0x7FFFFFFF)) if b else 0 for b, e, _ in logs] + [0])
+    tv, ts, tpc = (_u32([e[i] for e in T]) for i in range(3))
+    parts = parts or [len(T)]
+    poff = np.concatenate([[0], np.cumsum(parts)]).astype(np.uint64)
+    sx, sdone, sstop, suse = (_u32([int(sg.get(key, default)) for sg in segs] + [0]) for key, default in (("x", 0), ("done", True), ("stopped", True), ("usable", True)))
+    out = (C.c_int64 * 12)()
+    lib.pagt_advance.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 14 + [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    res = []
+    for tables in (0, 1):
+        lib.pagt_use_tables(tables)
+        lib.pagt_advance(len(segs), n_spec, zone_end, sx.ctypes.data, sdone.ctypes.data, sstop.ctypes.data, suse.ctypes.data, off.ctypes.data, pv.ctypes.data, ps.ctypes.data, ppc.ctypes.data, xl.ctypes.data, xh.ctypes.data,
+                         tv.ctypes.data, ts.ctypes.data, tpc.ctypes.data, poff.ctypes.data, len(parts), k, dev, split, has_size, seg_ov, out)
+        res.append(dict(zip(("what", "stop", "until_leap", "len", "next_seg", "next_leap", "waiting", "final", "adopted", "fails", "leap_adopted", "why"),
+                            [int(x) for x in out])))
+    lib.pagt_use_tables(0)
+    assert res[0] == res[1]
+    return res[0]
+
+
+def _round(n_vertices=400, step=10, c0=100000, cuts=(60, 160, 260), m=20):
+    """a strand of n_vertices vertices; segments that cannot leap start at the vertices `cuts` and run m vertices into the next"""
+    B = line(1000, n_vertices, c0, step=step)
+    ends = list(cuts[1:]) + [n_vertices - m]
+    segs = [{"x": B[a][2], "path": B[a:b + m]} for a, b in zip(cuts, ends)]
+    T = B[:cuts[0] + m]
+    return B, T, segs
+
+
+def test_advance_adopts_segment_after_segment_and_waits_for_an_unfinished_one(lib):
+    B, T, segs = _round()
+    zone_end = B[-1][2] + 1000
+    segs[2]["done"] = False
+    r = advance(lib, T, segs, 3, zone_end)
+    assert (r["what"], r["waiting"], r["next_seg"], r["len"]) == (0, 2, 2, 260 + 20) and r["adopted"] == 260 + 20 - len(T)
+    segs[2]["done"] = True
+    segs[2]["stopped"] = False                      # the last segment's walk ended by itself: so does the real one
+    r = advance(lib, T, segs, 3, zone_end)
+    assert (r["what"], r["final"], r["len"]) == (0, 1, len(B))
+
+
+def test_advance_walks_on_exactly_where_nothing_can_be_adopted(lib):
+    B, T, segs = _round()
+    zone_end = B[-1][2] + 1000
+    segs[1]["usable"] = False                       # (its job overflowed, say): adopted up to it, then exactly to the next checkpoint
+    r = advance(lib, T, segs, 3, zone_end)
+    assert (r["what"], r["until_leap"], r["fails"], r["next_seg"]) == (1, 0, 1, 2)
+    assert r["stop"] == segs[2]["x"] + 150 and r["len"] == 160 + 20
+    # a chain that has not reached the first checkpoint walks on to it
+    r = advance(lib, T[:30], segs, 3, zone_end)
+    assert (r["what"], r["stop"], r["len"]) == (1, segs[0]["x"] + 150, 30)
+
+
+def test_advance_crosses_the_point_where_leaping_begins(lib):
+    """the kinds overlap: segments that cannot leap are adopted up to where the chain's TRUE size allows, a short exact walk
+    (until_leap) crosses the point, the pieces of the leaping zone started before it take over"""
+    B, T, segs = _round()
+    step = 10
+    zone_end = B[-1][2] + 1000
+    # leaping begins when k + steps reaches the size at vertex 200 (inside segment 1)
+    split = 14 + 200 * step
+    leap = [{"x": B[a][2], "path": B[a:], "stopped": False, "log": [(True, B[a + i][2] - 5, 0xFFFFFFFF) for i in range(len(B) - a)]} for a in (150, 230)]
+    allsegs = segs + leap
+    r = advance(lib, T, allsegs, 3, zone_end, split=split)
+    # cut max_probe + 1 = 51 steps before the point (5 vertices and a bit), nothing of the leaping zone tried yet: cross the point exactly
+    assert (r["what"], r["until_leap"], r["stop"]) == (1, 1, 0) and r["next_seg"] == 3 and r["leap_adopted"] == 0
+    assert 190 <= r["len"] <= 196 and r["fails"] == 0
+    # ... the exact walk has ended a few vertices behind the point (its path: the strand's own vertices): the piece that started
+    # BEFORE the point is adopted to its end, which is the end of the strand
+    T2 = B[:203]
+    r = advance(lib, T2, allsegs, 3, zone_end, split=split, parts=[80, 123])
+    assert (r["what"], r["final"], r["len"], r["leap_adopted"], r["why"]) == (0, 1, len(B), 1, -1)
+    # without pieces of the leaping zone the exact walk goes to the end
+    r = advance(lib, T, segs, 3, zone_end, split=split)
+    assert (r["what"], r["until_leap"], r["stop"]) == (1, 0, 0)
+    # a chain that can leap never adopts a segment that cannot (and the other way round): with only such segments left it walks on
+    r = advance(lib, T2, segs, 3, zone_end, split=split)
+    assert (r["what"], r["until_leap"], r["stop"], r["len"]) == (1, 0, 0, len(T2))
+
+
+def test_advance_past_the_zone_of_the_segments_that_cannot_leap(lib):
+    B, T, segs = _round()
+    zone_end = B[170][2]                            # the zone ends inside segment 1
+    leap = [{"x": B[300][2], "path": B[300:], "stopped": False, "log": [(True, B[300 + i][2] - 5, 0xFFFFFFFF) for i in range(len(B) - 300)]}]
+    for sg in segs:
+        sg["path"] = [e for e in sg["path"] if e[2] <= zone_end + 200]
+    r = advance(lib, T, segs[:2] + leap, 2, zone_end)
+    # adopted to the end of the zone; leaping is still impossible (true size): across the point, however far that is
+    assert (r["what"], r["until_leap"], r["next_seg"]) == (1, 1, 2)
