@@ -617,6 +617,25 @@ extern "C" int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases) {
     size_t free_b = 0, total_b = 0;
     // (the same cap as pag_travel's own estimate: an arena reserved here must not be thrown away there as too small)
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
+    // the pinned memory the fetched paths of the walks' jobs land in (64 MB chunks kept by the handle, pag_travel's
+    // fetch_alloc): ~14 bytes per contig base at sequencing coverage; a cold process otherwise pins them one by one between
+    // the walks' first fetches (5 ms each)
+    {
+        const size_t FETCH_CHUNK = 64u << 20;
+        size_t have = 0;
+        for (size_t b : g->fetch_chunk_bytes) have += b;
+        const size_t want_pinned = std::min<size_t>((size_t)contig_bases * 14, (size_t)4 << 30);
+        while (have < want_pinned) {
+            void *q = nullptr;
+            if (hipHostMalloc(&q, FETCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                break;  // (pag_travel asks again when it needs the memory, and reports a failure there)
+            }
+            g->fetch_chunks.push_back(q);
+            g->fetch_chunk_bytes.push_back(FETCH_CHUNK);
+            have += FETCH_CHUNK;
+        }
+    }
     if (g->walk_arena_cap >= want) return PAG_OK;
     if (g->walk_arena) hipFree(g->walk_arena);
     g->walk_arena = nullptr;
