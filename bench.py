@@ -515,8 +515,9 @@ def main():
                     for ln in rec["ours"].get("stderr_tail", "").splitlines():
                         for key, tag in (("load_global_inputs_s", "load global inputs + create"), ("load_block_inputs_s", "load block inputs"),
                                          ("prepare_s", "prepare (lists, filters, contig->reference map)"), ("traversal_s", "] traversal "),
-                                         ("write_s", "traverse + write")):
-                            if tag in ln:
+                                         ("write_s", "traverse + write"), ("build_s", "graph build (process)"), ("successor_records_s", "] successor records "),
+                                         ("walks_s", "] walks "), ("host_half_s", "block's host half ")):
+                            if tag in ln and ln.rstrip().endswith(" s"):
                                 try:
                                     phases[key] = float(ln.split(tag)[1].split()[0])
                                 except (ValueError, IndexError):
