@@ -327,3 +327,32 @@ def test_library_communicator_over_rccl_with_itself():
         hip.pag_comm_destroy(c)
     finally:
         os.environ.pop("PAG_COMM_FORCE_RCCL", None)
+
+
+@pytest.mark.gpu
+def test_bench_default_mode_two_processes(workdir):
+    """bench.py as the driver launches it for the scaling runs (torch.distributed.run, --gpus N, the default mode: one block
+    per rank, no data-path collective) with TWO processes on the one device of the box: the line must be the whole job's —
+    twice the bases of one rank over the slowest rank's time — and rank 0's block must be the block a single process builds."""
+    import json
+    import subprocess
+    size = ["--reads", "3000", "--ref-len", "3000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(pagctl.ROOT, "bench.py")] + size, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    env = dict(os.environ, PAG_BENCH_SINGLE_DEVICE="1")
+    port = 29300 + os.getpid() % 300
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(pagctl.ROOT, "bench.py"), "--gpus", "2"] + size,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [ln for ln in two.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "weak" and d2["steps"] == 2 and d2["metric"] == d1["metric"]
+    for kk in ("position_tuples", "edge_tuples", "path_nodes", "path_bases", "path_checksum", "chains", "vertices"):
+        assert d1["config"][kk] == d2["config"][kk], kk   # (rank 0 runs the seed a single process runs)
+    per_step_bases = d2["value"] * d2["ms_per_step"] / 1e3
+    one_step_bases = d1["value"] * d1["ms_per_step"] / 1e3
+    assert 1.8 * one_step_bases < per_step_bases < 2.2 * one_step_bases   # (rank 1 has its own seed: about as many bases)
+    assert d2["roofline"]["frac"] > 0
