@@ -27,6 +27,8 @@ def test_full_size_text_run_equals_the_reference_digests(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rec = json.load(open(out))
     assert rec["ours"]["returncode"] == 0, rec["ours"]["stderr_tail"][-1500:]
+    kept = json.load(open(DIGESTS))
+    assert rec["input_bytes"] == kept["input_bytes"], "the generator no longer writes the text files the reference's digests were taken on (tests/biggen.py drift)"
     cmp = rec["compare"]
     assert cmp["files_ours"] == cmp["files_reference"] == 53
     assert cmp["identical"], cmp["differing_files"]
