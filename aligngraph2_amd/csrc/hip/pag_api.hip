@@ -74,7 +74,11 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->regional = false;
     g->region_ref_iv.clear();
     g->region_ref_open.clear();
-    g->path_off.clear();  // (the pinned storage stays)
+    // CONTRACT (pagraph_hip.h, pag_travel_path): the pinned storage behind the paths (path_store, fetch_chunks) is NOT
+    // released or re-pinned here, nor in pag_reserve_walk_arena / pag_prepare / pag_process: the previous block's host half
+    // (pagh_traverse_begin, pagraph_driver's HostHalf) reads the raw pointers it was handed while this runs for the next
+    // block.  Only the next pag_travel (which waits for that host half) and pag_destroy may touch that memory.
+    g->path_off.clear();
     g->path_len.clear();
     g->path_valid.clear();
     g->path_ptr.clear();

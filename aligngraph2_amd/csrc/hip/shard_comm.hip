@@ -11,8 +11,11 @@
 // Order argument for bit-identity with one GPU: see include/pagraph_hip.h (pag_shard_*) — rank r extracts the r-th contiguous
 // range of the emission order, owners lay the received records out as [pass 1 from rank 0] .. [pass 1 from rank N-1]
 // [pass 2 from rank 0] .. and sort stably by k-mer.
+#include <dirent.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <rccl/rccl.h>  // types and prototypes only: the entry points are resolved with dlsym (no link-time dependency)
+#include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -21,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -29,20 +33,19 @@
 
 namespace {
 
-// the few RCCL entry points used (rccl.h): resolved with dlsym so that the library only depends on RCCL when it is asked for
+// the few RCCL entry points used, with the signatures rccl.h declares them with (decltype of the prototypes), resolved
+// with dlsym so that the library only depends on RCCL when it is asked for
 struct Rccl {
     void *lib = nullptr;
-    struct UniqueId {
-        char internal[128];
-    };
-    int (*GetUniqueId)(UniqueId *) = nullptr;
-    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool load() {
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -50,20 +53,47 @@ struct Rccl {
         }
         if (!lib) return false;
         auto sym = [&](const char *n) { return dlsym(lib, n); };
-        GetUniqueId = (int (*)(UniqueId *))sym("ncclGetUniqueId");
-        CommInitRank = (int (*)(void **, int, UniqueId, int))sym("ncclCommInitRank");
-        CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
-        GroupStart = (int (*)())sym("ncclGroupStart");
-        GroupEnd = (int (*)())sym("ncclGroupEnd");
-        Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))sym("ncclSend");
-        Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))sym("ncclRecv");
-        GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         return GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv;
     }
 };
-constexpr int NCCL_UINT8 = 1;  // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat), 0 if it does not exist: (pid, start
+// time) names ONE process for as long as the machine is up
+unsigned long long proc_start(long pid) {
+    char path[64];
+    std::snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return 0;
+    char buf[1024];
+    const size_t n = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[n] = 0;
+    const char *p = std::strrchr(buf, ')');  // (the command name may hold blanks and parentheses)
+    if (!p) return 0;
+    unsigned long long v = 0;
+    int field = 2;
+    for (++p; *p && field < 22;) {
+        while (*p == ' ') ++p;
+        ++field;
+        if (field == 22) {
+            v = std::strtoull(p, nullptr, 10);
+            break;
+        }
+        while (*p && *p != ' ') ++p;
+    }
+    return v;
+}
 
 }  // namespace
 
@@ -72,21 +102,33 @@ struct pag_comm {
     std::string dir;
     bool use_rccl = false;
     Rccl rccl;
-    void *comm = nullptr;
+    ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     uint64_t seq = 0;       // every collective of the job takes the next number (all ranks call them in the same order)
     double timeout_s = 600;
     uint64_t bytes_sent = 0;  // payload of the bulk exchanges that left this rank (wire volume)
+    // Every file of the job carries the job's nonce in its name (agreed at creation, see handshake()): what an earlier
+    // job — crashed, or still running in the same directory — left or leaves there is never read.
+    unsigned long long job = 0;
+    bool aborted = false;
+    std::vector<std::pair<uint64_t, std::string>> kept;  // all-gather files of mine that peers may still read: (collective, path)
 
     std::string path(const char *tag, uint64_t n, int a, int b = -1) const {
-        char buf[96];
-        if (b >= 0) std::snprintf(buf, sizeof buf, "/%s%llu_%d_%d", tag, (unsigned long long)n, a, b);
-        else std::snprintf(buf, sizeof buf, "/%s%llu_%d", tag, (unsigned long long)n, a);
+        char buf[128];
+        if (b >= 0) std::snprintf(buf, sizeof buf, "/j%016llx_%s%llu_%d_%d", job, tag, (unsigned long long)n, a, b);
+        else std::snprintf(buf, sizeof buf, "/j%016llx_%s%llu_%d", job, tag, (unsigned long long)n, a);
+        return dir + buf;
+    }
+    std::string abort_path(int r) const {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "/j%016llx_abort_%d", job, r);
         return dir + buf;
     }
     // a file that appears complete or not at all (written under another name, then renamed)
     int put_file(const std::string &p, const void *data, size_t bytes) const {
-        const std::string tmp = p + ".part";
+        char suffix[48];
+        std::snprintf(suffix, sizeof suffix, ".part%d_%ld", rank, (long)getpid());
+        const std::string tmp = p + suffix;
         FILE *f = std::fopen(tmp.c_str(), "wb");
         if (!f) {
             pagdev::set_error("pag_comm: cannot write %s", tmp.c_str());
@@ -99,10 +141,37 @@ struct pag_comm {
         }
         return PAG_OK;
     }
+    static bool slurp(const std::string &p, std::vector<char> &out) {
+        FILE *f = std::fopen(p.c_str(), "rb");
+        if (!f) return false;
+        out.clear();
+        char buf[4096];
+        size_t n;
+        while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+        std::fclose(f);
+        return true;
+    }
+    // a peer that failed says so (pag_comm_abort): the waiting ranks report ITS message at once instead of timing out
+    bool peer_aborted() const {
+        if (!job) return false;
+        std::vector<char> msg;
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) continue;
+            struct stat st;
+            const std::string ap = abort_path(r);
+            if (stat(ap.c_str(), &st) != 0) continue;
+            slurp(ap, msg);
+            msg.push_back(0);
+            pagdev::set_error("pag_comm: rank %d has failed: %s", r, msg.data());
+            return true;
+        }
+        return false;
+    }
     int get_file(const std::string &p, std::vector<char> &out, bool remove_after) const {
         const double t0 = now_s();
         struct stat st;
-        while (stat(p.c_str(), &st) != 0) {
+        for (unsigned spin = 0; stat(p.c_str(), &st) != 0; ++spin) {
+            if ((spin & 63u) == 63u && peer_aborted()) return PAG_EFAULT;
             if (now_s() - t0 > timeout_s) {
                 pagdev::set_error("pag_comm: rank %d waited %.0f s for %s (a peer has failed or never started)", rank, timeout_s, p.c_str());
                 return PAG_EFAULT;
@@ -119,6 +188,89 @@ struct pag_comm {
         std::fclose(f);
         if (remove_after) std::remove(p.c_str());
         return PAG_OK;
+    }
+    // all-gather files of collectives before `done` have been read by every peer (each of them has since written a file
+    // of a later collective, which it only does after leaving the earlier one)
+    void drop_kept(uint64_t done) {
+        size_t w = 0;
+        for (size_t i = 0; i < kept.size(); ++i) {
+            if (kept[i].first < done) std::remove(kept[i].second.c_str());
+            else kept[w++] = kept[i];
+        }
+        kept.resize(w);
+    }
+
+    // The ranks of ONE job find each other in a directory that may hold the files of other jobs.  Every rank publishes
+    // hello_<rank> = (pid, process start time, a random word); rank 0 waits until every rank's hello names a LIVE process
+    // (what a crashed job left names a dead one and is ignored until its successor overwrites it), draws the job's nonce and
+    // answers every rank with job_<rank> = (nonce, the random word it saw).  A rank takes the answer that echoes ITS word —
+    // an answer left by an earlier job echoes another.  Two live jobs in one directory: the second hello of a rank
+    // overwrites the first, one of the two jobs never gets its echo and times out with a message that says so.
+    int handshake() {
+        if (world == 1) {
+            job = std::random_device{}() | ((unsigned long long)std::random_device{}() << 32) | 1ull;
+            return PAG_OK;
+        }
+        struct Hello {
+            long long pid;
+            unsigned long long start, word;
+        } me{(long long)getpid(), proc_start(getpid()), std::random_device{}() | ((unsigned long long)std::random_device{}() << 32)};
+        struct Job {
+            unsigned long long nonce, word;
+        };
+        char name[64];
+        std::snprintf(name, sizeof name, "/hello_%d", rank);
+        int rc = put_file(dir + name, &me, sizeof me);
+        if (rc) return rc;
+        const double t0 = now_s();
+        std::vector<char> blob;
+        if (rank == 0) {
+            std::vector<Hello> seen(world);
+            seen[0] = me;
+            for (int r = 1; r < world; ++r) {
+                std::snprintf(name, sizeof name, "/hello_%d", r);
+                for (;;) {
+                    Hello h{};
+                    if (slurp(dir + name, blob) && blob.size() == sizeof h) {
+                        std::memcpy(&h, blob.data(), sizeof h);
+                        if (h.start != 0 && proc_start((long)h.pid) == h.start) {
+                            seen[r] = h;
+                            break;
+                        }
+                    }
+                    if (now_s() - t0 > timeout_s) {
+                        pagdev::set_error("pag_comm_create: rank 0 waited %.0f s for a live rank %d in %s", timeout_s, r, dir.c_str());
+                        return PAG_EFAULT;
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(500));
+                }
+            }
+            job = std::random_device{}() | ((unsigned long long)std::random_device{}() << 32) | 1ull;
+            for (int r = 1; r < world; ++r) {
+                Job j{job, seen[r].word};
+                std::snprintf(name, sizeof name, "/job_%d", r);
+                if ((rc = put_file(dir + name, &j, sizeof j))) return rc;
+            }
+            return PAG_OK;
+        }
+        std::snprintf(name, sizeof name, "/job_%d", rank);
+        for (;;) {
+            Job j{};
+            if (slurp(dir + name, blob) && blob.size() == sizeof j) {
+                std::memcpy(&j, blob.data(), sizeof j);
+                if (j.word == me.word) {
+                    job = j.nonce;
+                    std::remove((dir + name).c_str());
+                    return PAG_OK;
+                }
+            }
+            if (now_s() - t0 > timeout_s) {
+                pagdev::set_error("pag_comm_create: rank %d waited %.0f s for rank 0's answer in %s (no rank 0, or another job is using the directory)",
+                                  rank, timeout_s, dir.c_str());
+                return PAG_EFAULT;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(500));
+        }
     }
 };
 
@@ -142,30 +294,38 @@ pag_comm *pag_comm_create(int rank, int world, const char *rendezvous_dir, int d
         delete c;
         return fail(PAG_ENODEV);
     }
+    if (c->handshake() != PAG_OK) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return fail(PAG_EFAULT);
+    }
     const bool want_rccl = !transport || std::strcmp(transport, "rccl") == 0;
     // (PAG_COMM_FORCE_RCCL=1: also for a world of one — exercises the RCCL calls on a single-GPU box)
     if (want_rccl && (world > 1 || (std::getenv("PAG_COMM_FORCE_RCCL") && transport && std::strcmp(transport, "rccl") == 0))) {
         if (!c->rccl.load()) {
             pagdev::set_error("pag_comm_create: librccl.so not found (transport \"host\" goes through the rendezvous directory)");
-            delete c;
+            pag_comm_destroy(c);
             return fail(PAG_ENODEV);
         }
-        Rccl::UniqueId id{};
+        ncclUniqueId id{};
         std::vector<char> blob;
         int rc = PAG_OK;
+        const std::string idp = c->path("rcclid", 0, 0);
         if (rank == 0) {
-            if (c->rccl.GetUniqueId(&id) != 0) rc = PAG_EFAULT;
-            else rc = c->put_file(c->dir + "/rccl_id", &id, sizeof id);
+            if (c->rccl.GetUniqueId(&id) != ncclSuccess) rc = PAG_EFAULT;
+            else rc = c->put_file(idp, &id, sizeof id);
         } else {
-            rc = c->get_file(c->dir + "/rccl_id", blob, false);
+            rc = c->get_file(idp, blob, false);
             if (rc == PAG_OK && blob.size() == sizeof id) std::memcpy(&id, blob.data(), sizeof id);
             else if (rc == PAG_OK) rc = PAG_EFAULT;
         }
-        int nrc = rc == PAG_OK ? c->rccl.CommInitRank(&c->comm, world, id, rank) : -1;
-        if (rc != PAG_OK || nrc != 0) {
+        const ncclResult_t nrc = rc == PAG_OK ? c->rccl.CommInitRank(&c->comm, world, id, rank) : ncclSystemError;
+        if (rank == 0 && rc == PAG_OK) c->kept.push_back({0, idp});  // (read by every peer before its CommInitRank returns)
+        if (rc != PAG_OK || nrc != ncclSuccess) {
             pagdev::set_error("pag_comm_create: RCCL communicator of %d ranks failed (%s)", world,
-                              nrc > 0 && c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "rendezvous");
-            delete c;
+                              rc == PAG_OK && c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "rendezvous");
+            c->comm = nullptr;
+            pag_comm_destroy(c);
             return fail(PAG_EFAULT);
         }
         c->use_rccl = true;
@@ -176,13 +336,34 @@ pag_comm *pag_comm_create(int rank, int world, const char *rendezvous_dir, int d
 
 void pag_comm_destroy(pag_comm *c) {
     if (!c) return;
-    if (c->comm) c->rccl.CommDestroy(c->comm);
+    if (c->comm) {
+        // a communicator whose job failed may have peers that never arrive: abort instead of the collective destroy
+        if (c->aborted && c->rccl.CommAbort) c->rccl.CommAbort(c->comm);
+        else c->rccl.CommDestroy(c->comm);
+    }
     if (c->stream) hipStreamDestroy(c->stream);
+    // (the files of this rank's LAST all-gather may still be read by a peer; whatever stays carries the job's nonce and is
+    // never taken for another job's)
+    if (!c->kept.empty()) c->drop_kept(c->kept.back().first);
+    char name[64];
+    std::snprintf(name, sizeof name, "/hello_%d", c->rank);
+    std::remove((c->dir + name).c_str());
     delete c;
 }
 int pag_comm_rank(const pag_comm *c) { return c ? c->rank : -1; }
 int pag_comm_world(const pag_comm *c) { return c ? c->world : 0; }
 uint64_t pag_comm_bytes_sent(const pag_comm *c) { return c ? c->bytes_sent : 0; }
+
+// This rank cannot go on (message: why): every peer that waits for it — now or later — fails at once with that message
+// instead of waiting for its timeout.
+void pag_comm_abort(pag_comm *c, const char *message) {
+    if (!c || c->aborted) return;
+    c->aborted = true;
+    if (c->world == 1 || !c->job) return;
+    const char *m = message && *message ? message : "(no message)";
+    const std::string keep(m);  // (put_file may overwrite the error buffer `message` points into)
+    c->put_file(c->abort_path(c->rank), keep.data(), keep.size());
+}
 
 // every rank contributes `bytes` of host memory; all[r * bytes ..] = rank r's
 int pag_comm_all_gather(pag_comm *c, const void *mine, uint64_t bytes, void *all) {
@@ -192,8 +373,14 @@ int pag_comm_all_gather(pag_comm *c, const void *mine, uint64_t bytes, void *all
         std::memcpy(all, mine, bytes);
         return PAG_OK;
     }
-    int rc = c->put_file(c->path("g", n, c->rank), mine, bytes);
+    if (c->aborted) {
+        pagdev::set_error("pag_comm: this rank has aborted the job");
+        return PAG_EFAULT;
+    }
+    const std::string minep = c->path("g", n, c->rank);
+    int rc = c->put_file(minep, mine, bytes);
     if (rc) return rc;
+    c->kept.push_back({n, minep});
     std::vector<char> blob;
     for (int r = 0; r < c->world; ++r) {
         if ((rc = c->get_file(c->path("g", n, r), blob, false))) return rc;
@@ -203,6 +390,7 @@ int pag_comm_all_gather(pag_comm *c, const void *mine, uint64_t bytes, void *all
         }
         std::memcpy((char *)all + (size_t)r * bytes, blob.data(), bytes);
     }
+    c->drop_kept(n);  // every peer has written its file of collective n: it has left every earlier collective
     return PAG_OK;
 }
 int pag_comm_barrier(pag_comm *c) {
@@ -248,14 +436,20 @@ int pag_comm_all_to_all_v(pag_comm *c, const void *send, const uint64_t *send_by
     }
     if (send_bytes[c->rank] != recv_bytes[c->rank]) return PAG_EINVAL;
     if (c->use_rccl) {
-        int rc = c->rccl.GroupStart();
-        for (int r = 0; r < c->world && rc == 0; ++r) {
-            if (send_bytes[r]) rc = c->rccl.Send((const char *)send + so[r], send_bytes[r], NCCL_UINT8, r, c->comm, c->stream);
-            if (rc == 0 && recv_bytes[r]) rc = c->rccl.Recv((char *)recv + ro[r], recv_bytes[r], NCCL_UINT8, r, c->comm, c->stream);
+        // a grouped Send / Recv whose peer never arrives waits for ever: the ranks first meet through the rendezvous directory
+        // (where a failed peer's abort marker is seen), and only a complete set of ranks enters RCCL
+        if (c->world > 1) {
+            const int brc = pag_comm_barrier(c);
+            if (brc) return brc;
         }
-        const int rc2 = c->rccl.GroupEnd();
-        if (rc != 0 || rc2 != 0) {
-            pagdev::set_error("pag_comm_all_to_all_v: RCCL error %s", c->rccl.GetErrorString ? c->rccl.GetErrorString(rc ? rc : rc2) : "?");
+        ncclResult_t rc = c->rccl.GroupStart();
+        for (int r = 0; r < c->world && rc == ncclSuccess; ++r) {
+            if (send_bytes[r]) rc = c->rccl.Send((const char *)send + so[r], send_bytes[r], ncclUint8, r, c->comm, c->stream);
+            if (rc == ncclSuccess && recv_bytes[r]) rc = c->rccl.Recv((char *)recv + ro[r], recv_bytes[r], ncclUint8, r, c->comm, c->stream);
+        }
+        const ncclResult_t rc2 = c->rccl.GroupEnd();
+        if (rc != ncclSuccess || rc2 != ncclSuccess) {
+            pagdev::set_error("pag_comm_all_to_all_v: RCCL error %s", c->rccl.GetErrorString ? c->rccl.GetErrorString(rc != ncclSuccess ? rc : rc2) : "?");
             return PAG_EFAULT;
         }
         PAG_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -290,9 +484,15 @@ int pag_comm_all_to_all_v(pag_comm *c, const void *send, const uint64_t *send_by
 //   region set, the build's memory released.
 // regions[world]: what every rank traverses (the same on all ranks); total: the block's count lines.
 // ---------------------------------------------------------------------------------------------------------------------
+static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const pag_region *regions, pag_build_stats *total);
 int pag_shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const pag_region *regions, pag_build_stats *total) {
-    using namespace pagdev;
     if (!g || !c || !in || !regions) return PAG_EINVAL;
+    const int rc = shard_run(g, c, in, regions, total);
+    if (rc != PAG_OK) pag_comm_abort(c, pag_last_error());  // the peers learn why instead of waiting for this rank
+    return rc;
+}
+static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const pag_region *regions, pag_build_stats *total) {
+    using namespace pagdev;
     const int W = c->world, me = c->rank;
     int rc;
     std::vector<uint64_t> counts(4 * (size_t)W), allc(4 * (size_t)W * W);

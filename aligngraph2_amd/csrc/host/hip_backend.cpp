@@ -179,7 +179,10 @@ public:
 
 private:
     void check(int rc, const char *what) {
-        if (rc != PAG_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + pag_last_error());
+        if (rc == PAG_OK) return;
+        const std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + pag_last_error();
+        if (comm_) pag_comm_abort(comm_, msg.c_str());  // the other ranks of a sharded run stop with this message
+        throw std::runtime_error(msg);
     }
     int device_;
     pag_graph *g_ = nullptr;

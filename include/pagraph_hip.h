@@ -289,8 +289,12 @@ int pag_shard_release_build(pag_graph *g);
 int pag_shard_adopt(pag_graph *g, uint64_t n_t, uint64_t n_e, const pag_build_stats *stats);
 
 /* ---- the communicator of a sharded run and the whole sharded build behind one call --------------------------------
- * One process per GPU of ONE node.  rendezvous_dir: a directory all ranks see (e.g. under /dev/shm), fresh per job; small
- * host tables and the RCCL unique id go through files in it.  transport "rccl" (NULL = default): the bulk all-to-all(v)s of
+ * One process per GPU of ONE node.  rendezvous_dir: a directory all ranks see (e.g. under /dev/shm); small host tables and
+ * the RCCL unique id go through files in it.  The directory need not be fresh: the ranks of a job agree on a job nonce when
+ * the communicator is created (only LIVE processes count as ranks) and every file of the job carries it in its name, so
+ * what a crashed or concurrent job left there is never read.  A rank that fails calls pag_comm_abort (pag_shard_run does
+ * it itself): its peers return PAG_EFAULT at once, with that rank's message in pag_last_error(), instead of waiting for
+ * PAG_COMM_TIMEOUT_S; a bulk exchange over RCCL is only entered by a complete set of ranks that met through the directory.  transport "rccl" (NULL = default): the bulk all-to-all(v)s of
  * device buffers are grouped ncclSend / ncclRecv over xGMI (librccl loaded at run time); "host": through files of the
  * rendezvous directory — for ranks that share ONE device, where RCCL refuses to work (single-GPU test boxes).
  * Every rank calls the collectives in the same order. */
@@ -300,6 +304,7 @@ void pag_comm_destroy(pag_comm *c);
 int pag_comm_rank(const pag_comm *c);
 int pag_comm_world(const pag_comm *c);
 uint64_t pag_comm_bytes_sent(const pag_comm *c); /* payload of the bulk exchanges that left this rank so far */
+void pag_comm_abort(pag_comm *c, const char *message);
 int pag_comm_barrier(pag_comm *c);
 int pag_comm_all_gather(pag_comm *c, const void *mine_host, uint64_t bytes, void *all_host);
 int pag_comm_gather_v(pag_comm *c, const void *mine_host, uint64_t bytes, int root, void *out_host, uint64_t out_cap, uint64_t *sizes,
@@ -355,8 +360,9 @@ typedef struct pag_travel_stats {
 /* ctgs: HOST memory (2-bit packed); orient[i]: PAG_ORIENT_*.
  * ref_len[n_refs]: lengths of the reference sequences (their PositionMapper is needed for the repeat check).
  * After success, pag_travel_path_oriented(g, i, forward, &len) returns the path of contig i in that orientation
- * (library-owned, valid until the next pag_travel / pag_process / pag_destroy on the handle; NULL / 0 if that
- * orientation was not traversed); pag_travel_path(g, i, &len) = the forward path if there is one, else the reverse. */
+ * (library-owned PINNED memory, valid until the next pag_travel or pag_destroy on the handle — NOT invalidated by
+ * pag_reset / pag_prepare / pag_process / pag_travel_prepare / pag_reserve_walk_arena, which the drivers run for the next
+ * block while the previous block's host half still reads these paths; NULL / 0 if that orientation was not traversed); pag_travel_path(g, i, &len) = the forward path if there is one, else the reverse. */
 /* The first part of pag_travel on its own: the traversal's view of the graph (compact CSR, coordinate order, successor
  * records), kept in the handle until the graph changes; a following pag_travel with the same parameters goes straight to the
  * walks.  *ms (may be NULL) receives its wall time. */
