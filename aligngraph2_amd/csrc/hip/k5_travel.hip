@@ -57,6 +57,114 @@ __global__ void k_compact_nodes(const uint32_t *__restrict__ tkey, const uint64_
     }
 }
 
+// ---- a view that leaves out what no traversal of this handle can examine (trav_view_region, k5_travel_host.hip) --------
+// [lo, hi) pairs, sorted and disjoint
+__device__ __forceinline__ bool iv_contains(const uint32_t *__restrict__ iv, uint32_t n, uint32_t x, uint32_t *which = nullptr) {
+    if (!n) return false;
+    uint32_t lo = 0, hi = n;  // last interval with lo <= x
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (iv[2 * mid] <= x) lo = mid;
+        else hi = mid;
+    }
+    if (which) *which = lo;
+    return x >= iv[2 * lo] && x < iv[2 * lo + 1];
+}
+// lowest / highest reference coordinate among the positions whose contig coordinate lies in zone z (lo[z] preset to all
+// ones, hi[z] to 0).  One thread per tuple slot: slots behind a segment's leaders still hold positions of the k-mer's
+// reads (members of the clusters), which lie within epsilon of a leader — they widen nothing.
+constexpr uint32_t ZONE_LDS = 2048;
+__global__ void k_zone_bands(const uint64_t *__restrict__ tval, uint64_t T, const uint32_t *__restrict__ zones, uint32_t n_z,
+                             uint32_t *__restrict__ lo, uint32_t *__restrict__ hi) {
+    __shared__ uint32_t s_lo[ZONE_LDS], s_hi[ZONE_LDS], s_z[2 * ZONE_LDS];
+    const bool lds = n_z <= ZONE_LDS;
+    if (lds) {
+        for (uint32_t z = threadIdx.x; z < n_z; z += blockDim.x) {
+            s_lo[z] = 0xFFFFFFFFu;
+            s_hi[z] = 0u;
+            s_z[2 * z] = zones[2 * z];
+            s_z[2 * z + 1] = zones[2 * z + 1];
+        }
+        __syncthreads();
+    }
+    const uint32_t *zz = lds ? s_z : zones;
+    const uint32_t z_first = n_z ? zones[0] : 0u, z_last = n_z ? zones[2 * n_z - 1] : 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = tval[i];
+        const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
+        uint32_t z;
+        if (c < z_first || c >= z_last || r == 0u || !iv_contains(zz, n_z, c, &z)) continue;
+        if (lds) {
+            atomicMin(&s_lo[z], r);
+            atomicMax(&s_hi[z], r);
+        } else {
+            atomicMin(&lo[z], r);
+            atomicMax(&hi[z], r);
+        }
+    }
+    if (lds) {
+        __syncthreads();
+        for (uint32_t z = threadIdx.x; z < n_z; z += blockDim.x)
+            if (s_hi[z] != 0u) {
+                atomicMin(&lo[z], s_lo[z]);
+                atomicMax(&hi[z], s_hi[z]);
+            }
+    }
+}
+// per k-mer segment head: which of its leaders the view keeps (keep[] over their slots, zeroed before), head flag of the
+// segments that keep at least one.  A vertex with a contig coordinate is kept by it, one without by its reference coordinate.
+// The interval tables are searched in LDS (a search is ~8 dependent loads per leader: from global memory they were the
+// whole cost of the kernel, 34 ms at BASELINE configs[1]).
+constexpr uint32_t PRUNE_LDS = 4096;  // interval ends (u32) the block keeps in LDS
+__global__ void k_prune_flags(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg, uint64_t T,
+                              const uint32_t *__restrict__ civ, uint32_t n_civ, const uint32_t *__restrict__ riv, uint32_t n_riv,
+                              uint32_t *__restrict__ keep, uint32_t *__restrict__ hflag) {
+    __shared__ uint32_t s_iv[PRUNE_LDS];
+    const bool lds = 2u * (n_civ + n_riv) <= PRUNE_LDS;
+    if (lds) {
+        for (uint32_t x = threadIdx.x; x < 2u * n_civ; x += blockDim.x) s_iv[x] = civ[x];
+        for (uint32_t x = threadIdx.x; x < 2u * n_riv; x += blockDim.x) s_iv[2u * n_civ + x] = riv[x];
+        __syncthreads();
+    }
+    const uint32_t *cv = lds ? s_iv : civ, *rv = lds ? s_iv + 2u * n_civ : riv;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t kx = tkey[i];
+        uint32_t kept = 0;
+        if (i == 0 || tkey[i - 1] != kx) {
+            const uint32_t len = tseg[i];
+            for (uint32_t l = 0; l < len; ++l) {
+                const uint64_t p = tval[i + l];
+                const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
+                const bool k = c != 0u ? iv_contains(cv, n_civ, c) : iv_contains(rv, n_riv, r);
+                if (k) keep[i + l] = 1u;
+                kept += k ? 1u : 0u;
+            }
+        }
+        hflag[i] = kept ? 1u : 0u;
+    }
+}
+__global__ void k_compact_nodes_kept(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg,
+                                     const uint16_t *__restrict__ tcnt, uint64_t T, const uint32_t *__restrict__ hflag, const uint32_t *__restrict__ keep,
+                                     const uint64_t *__restrict__ node_idx, const uint64_t *__restrict__ pos_off, TravGraph G) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (!hflag[i]) continue;
+        const uint32_t kx = tkey[i];
+        const uint64_t n = node_idx[i];
+        uint64_t p = pos_off[i];
+        G.ncode[n] = kx;
+        G.npos_off[n] = (uint32_t)p;
+        atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
+        const uint32_t len = tseg[i];
+        for (uint32_t l = 0; l < len; ++l) {
+            if (!keep[i + l]) continue;
+            G.vpos[p] = tval[i + l];
+            G.vcnt[p] = tcnt[i + l];
+            G.vnode[p] = (uint32_t)n;
+            ++p;
+        }
+    }
+}
+
 __global__ void k_popc_words(const uint64_t *__restrict__ bitmap, uint64_t n_words, uint32_t *__restrict__ out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = (uint32_t)__popcll(bitmap[i]);
@@ -345,30 +453,36 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
         uint32_t n = 0;
         uint64_t mask = 0ull;
         const uint32_t u = G.newid[v];
-        // its successors may lie outside the region this rank holds: one poison record in their place
-        const bool poison = G.incomplete && u < G.n_zero && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+        // successors of it may lie outside the region this graph holds (k_mark_incomplete).  A coordinate-free vertex gets one
+        // poison record IN PLACE of its successors; a vertex on a contig keeps its successors — those that follow the contig
+        // are all here — and gets one marker record behind them that only counts where a walk could take a Skip grade
+        const bool inc = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+        const bool poison = inc && u < G.n_zero, marker = inc && u >= G.n_zero;
         if (poison) n = 1u;
-        else if (MODE == 0) n = succ_vertex<0>(G, v, dev, err, mask, nullptr);
+        else if (MODE == 0) n = succ_vertex<0>(G, v, dev, err, mask, nullptr) + (marker ? 1u : 0u);
         SuccRec *out = nullptr;
         if (MODE == 1) out = G.succ + G.succ_off[u];
         if (MODE == 2) out = stage + stage_off[v];
         if (MODE != 0 && out) {
+            SuccRec r;
+            r.tgt = u;
+            r.pc = 0u;  // (no coordinate: neither a leap nor subject to the coordinate windows; the grade alone rejects it)
+            r.meta = 1u | ((poison ? GRADE_POISON : GRADE_POISON_IF_LEAP) << 24);
+            r.toff = 0;
             if (poison) {
-                SuccRec r;
-                r.tgt = u;
-                r.pc = 0;
-                r.meta = 1u | (GRADE_POISON << 24);
-                r.toff = 0;
                 out[0] = r;
             } else if (MODE == 1) {
+                uint32_t m;
                 if (amask) {
                     mask = amask[v];
-                    succ_vertex<1>(G, v, dev, err, mask, out);
+                    m = succ_vertex<1>(G, v, dev, err, mask, out);
                 } else {
-                    succ_vertex<2>(G, v, dev, err, mask, out);
+                    m = succ_vertex<2>(G, v, dev, err, mask, out);
                 }
+                if (marker) out[m] = r;
             } else if (MODE == 2) {
                 n = succ_vertex<2>(G, v, dev, err, mask, out);
+                if (marker) out[n++] = r;
             }
         }
         if (MODE != 1) cnt[u] = n;
@@ -385,7 +499,7 @@ __global__ void k_succ_bound(TravGraph G, uint32_t *__restrict__ ub) {
             const uint32_t to = G.eto[e];
             if (to != PAG_NONE) n += G.npos_off[to + 1] - G.npos_off[to];
         }
-        ub[v] = n ? n : (G.incomplete ? 1u : 0u);  // (room for a poison record, see k_succ)
+        ub[v] = n + (G.incomplete ? 1u : 0u);  // (room for a poison / marker record, see k_succ)
     }
 }
 
@@ -755,8 +869,14 @@ __device__ __forceinline__ void win_follow(WalkLds &L, WalkCtx &X, uint32_t cur,
 }
 
 // bookkeeping for a later splice (see WalkCtx::x_*): every examined record passes here
-__device__ __forceinline__ void walk_note_record(WalkCtx &X, uint32_t v, uint32_t pc, bool ectg, uint32_t grade = 0u) {
-    X.x_poison |= grade == GRADE_POISON ? 1u : 0u;
+__device__ __forceinline__ void walk_note_record(WalkCtx &X, uint32_t v, uint32_t pc, bool ectg, uint32_t grade = 0u, bool can_leap = false) {
+    // the marker records of a graph that holds a region only (TravGraph::incomplete): grade 7 stands for ALL successors of its
+    // vertex; grade 6 stands for the coordinate-free ones of a vertex on a contig (grade Skip), which a classification only
+    // admits once leaping is possible.  They are no successors: nothing else is noted about them.
+    X.x_poison |= ((grade == GRADE_POISON) | ((grade == GRADE_POISON_IF_LEAP) & can_leap)) ? 1u : 0u;
+    const bool real = grade < GRADE_POISON_IF_LEAP;
+    pc = real ? pc : 0xFFFFFFFFu;
+    ectg = real ? ectg : true;  // (pc != 0 and "follows the contig" with a coordinate above every window: no entry below moves)
     X.x_m0 = ((pc == 0u) & (v < X.x_m0)) ? v : X.x_m0;
     X.x_elow = ((pc != 0u) & ectg & (pc < X.x_elow)) ? pc : X.x_elow;
     const bool wd = (pc != 0u) & !ectg;
@@ -811,7 +931,7 @@ __device__ __forceinline__ int eval_record(const WalkLds &L, WalkCtx &X, const S
         }
     }
     const bool free_pc = (pc == 0u) | ectg;  // no coordinate, or the edge follows the contig: the window tests do not apply
-    walk_note_record(X, v, pc, ectg, grade);
+    walk_note_record(X, v, pc, ectg, grade, can_leap);
     const bool hit_g = !free_pc & in_win(X.win_g0, X.win_g1, pc), hit_t = !free_pc & in_win(X.win_t0, X.win_t1, pc);
     const bool rev = (pc != 0u) & (pc >= X.C.rev_left) & (pc < X.C.rev_right);
     bool ok = !(gvis | hit_g | rev | tvis | hit_t);
@@ -2567,8 +2687,11 @@ static unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 
 
 int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
                  const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
-                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s) {
-    // tmp: flags u32[max(T, E, words, nodes + 1)] | scan out u64[same] | scan out 2 u64[T] | scan tmp
+                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view,
+                 uint64_t *counts_out) {
+    // tmp: flags u32[max(T, E, words, nodes + 1)] | scan out u64[same] | scan out 2 u64[T] | keep u32[T] | scan tmp
+    // view != null: only the vertices inside its intervals (device arrays) are taken; counts_out[3] = nodes, vertices, edges
+    // of the view (n_nodes / n_pos / n_edges are then upper bounds: what the arrays of G were sized for)
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
     uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
     char *p = (char *)tmp;
@@ -2580,6 +2703,8 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     uint32_t *flags = (uint32_t *)take(m * 4);
     uint64_t *sc1 = (uint64_t *)take(m * 8);
     uint64_t *sc2 = (uint64_t *)take(m * 8);
+    uint32_t *keep = (uint32_t *)take(m * 4);
+    uint64_t *totals = (uint64_t *)take(64);
     void *scan_tmp = take(scan_tmp_bytes(m));
     if ((size_t)(p - (char *)tmp) > tmp_bytes) {
         set_error("trav_compact: scratch too small");
@@ -2587,25 +2712,58 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     }
     PAG_HIP_TRY(hipMemsetAsync(G.bitmap, 0, n_words * 8, s));
     int rc;
-    if (T) {
+    if (view) {
+        uint64_t h[2] = {0, 0};
+        if (T) {
+            PAG_HIP_TRY(hipMemsetAsync(keep, 0, T * 4, s));
+            k_prune_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, T, view->civ, view->n_civ, view->riv, view->n_riv, keep, flags);
+            if ((rc = scan_u32_to_u64(flags, sc1, T, totals, scan_tmp, s))) return rc;
+            if ((rc = scan_u32_to_u64(keep, sc2, T, totals + 1, scan_tmp, s))) return rc;
+            k_compact_nodes_kept<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, tcnt, T, flags, keep, sc1, sc2, G);
+            PAG_HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
+        if (h[0] > n_nodes || h[1] > n_pos) {
+            set_error("trav_compact: the view holds more than the graph");
+            return PAG_EFAULT;
+        }
+        n_nodes = h[0];
+        n_pos = h[1];
+        G.n_nodes = n_nodes;
+        G.n_pos = n_pos;
+    } else if (T) {
         k_head_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, T, flags);
         if ((rc = scan_u32_to_u64(flags, sc1, T, nullptr, scan_tmp, s))) return rc;
         if ((rc = scan_u32_to_u64(tseg, sc2, T, nullptr, scan_tmp, s))) return rc;
         k_compact_nodes<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, tcnt, T, sc1, sc2, G);
     }
-    uint32_t np32 = (uint32_t)n_pos, ne32 = (uint32_t)n_edges;
+    uint32_t np32 = (uint32_t)n_pos;
     PAG_HIP_TRY(hipMemcpyAsync(G.npos_off + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
     // rank directory
     k_popc_words<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(G.bitmap, n_words, flags);
     if ((rc = scan_u32_to_u64(flags, sc1, n_words, nullptr, scan_tmp, s))) return rc;
     k_narrow<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(sc1, n_words, G.rank);
-    // edges
+    // edges (of the k-mers that own a node: node_of_code finds no node for the others)
     PAG_HIP_TRY(hipMemsetAsync(flags, 0, (n_nodes + 1) * 4, s));
     if (E) k_edge_counts<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eseg, E, G, flags);
-    if ((rc = scan_u32_to_u64(flags, sc1, n_nodes + 1, nullptr, scan_tmp, s))) return rc;
+    if ((rc = scan_u32_to_u64(flags, sc1, n_nodes + 1, view ? totals + 2 : nullptr, scan_tmp, s))) return rc;
     k_narrow<<<dim3(grid_for(n_nodes + 1)), dim3(256), 0, s>>>(sc1, n_nodes + 1, G.nedge_off);
     if (E) k_compact_edges<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eval, eseg, E, G);
-    (void)ne32;
+    if (view) {
+        uint64_t ne = 0;
+        PAG_HIP_TRY(hipMemcpyAsync(&ne, totals + 2, 8, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        if (ne > n_edges) {
+            set_error("trav_compact: the view holds more edges than the graph");
+            return PAG_EFAULT;
+        }
+        n_edges = ne;
+    }
+    if (counts_out) {
+        counts_out[0] = n_nodes;
+        counts_out[1] = n_pos;
+        counts_out[2] = n_edges;
+    }
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
@@ -2613,7 +2771,17 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes) {
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
     uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
-    return ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024;
+    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024 + 256;
+}
+
+// reference bands of the zones (k_zone_bands): lo / hi [n_z] device arrays, preset here
+int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev, uint32_t n_z, uint32_t *lo_dev, uint32_t *hi_dev, hipStream_t s) {
+    if (!n_z) return PAG_OK;
+    PAG_HIP_TRY(hipMemsetAsync(lo_dev, 0xFF, (size_t)n_z * 4, s));
+    PAG_HIP_TRY(hipMemsetAsync(hi_dev, 0, (size_t)n_z * 4, s));
+    if (T) k_zone_bands<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tval, T, zones_dev, n_z, lo_dev, hi_dev);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
 }
 
 void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
@@ -2679,14 +2847,18 @@ __global__ void k_max_step(const uint32_t *__restrict__ estep, uint64_t n, uint3
     m = wave_max_u32(m);
     if (lane_id() == 0 && m) atomicMax(out, m);
 }
-// incomplete[u] for the coordinate-free vertices (new ids 0 .. n_zero, ordered by reference coordinate): the vertex lies
-// within `margin` of an OPEN end of the reference band it is in (iv: sorted disjoint [lo, hi) pairs; open[2 i], open[2 i + 1]:
-// the graph goes on beyond that end, on another rank) — or in no band at all (cannot happen for a selected vertex)
+// incomplete[u] for every vertex u (new ids; 0 .. n_zero: the coordinate-free ones, ordered by reference coordinate): its
+// REFERENCE coordinate lies within `margin` of an OPEN end of the reference band it is in (iv: sorted disjoint [lo, hi)
+// pairs; open[2 i], open[2 i + 1]: the graph goes on beyond that end, on another rank) — or in no band at all.  For a
+// coordinate-free vertex the latter cannot happen (it was selected by its band); a vertex WITH a contig coordinate was
+// selected by that coordinate whatever its reference coordinate is, and its coordinate-free successors (grade Skip,
+// checkPosition with pos2.first == 0: PABruijnGraph.cpp:143-165) live around its reference coordinate — outside the bands
+// they are on another rank.  A vertex without a reference coordinate has no successor that is found through one.
 __global__ void k_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *__restrict__ iv, const uint8_t *__restrict__ open, uint32_t n_iv,
                                   uint32_t margin, uint32_t *__restrict__ bits) {
-    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
-    if (u < n_zero) {
+    if (u < G.n_pos) {
         const uint32_t r = (uint32_t)G.upos[u];
         uint32_t lo = 0, hi = n_iv;  // last interval with lo <= r
         while (hi - lo > 1) {
@@ -2698,9 +2870,10 @@ __global__ void k_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *
         if (!bad) {
             bad = (open[2 * lo] && r - iv[2 * lo] < margin) || (open[2 * lo + 1] && iv[2 * lo + 1] - r <= margin);
         }
+        if (u >= n_zero && r == 0u) bad = false;
     }
     const uint64_t m = __ballot(bad);
-    if ((threadIdx.x & 63u) == 0 && u < ((n_zero + 63u) & ~63u)) {
+    if ((threadIdx.x & 63u) == 0 && u < ((G.n_pos + 63ull) & ~63ull)) {
         bits[u >> 5] = (uint32_t)m;
         bits[(u >> 5) + 1] = (uint32_t)(m >> 32);
     }
@@ -2722,7 +2895,7 @@ int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, 
     PAG_HIP_TRY(hipStreamSynchronize(s));
     // a successor's coordinate lies within step + deviation, or step x (1 + error rate), of its source's (checkPosition)
     const uint64_t margin = (uint64_t)((double)max_step * (1.0 + err)) + dev + 2;
-    if (n_zero) k_mark_incomplete<<<dim3((n_zero + 255) / 256), dim3(256), 0, s>>>(G, n_zero, d_iv, d_open, n_iv, (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu), bits);
+    if (G.n_pos) k_mark_incomplete<<<dim3((unsigned)((G.n_pos + 255) / 256)), dim3(256), 0, s>>>(G, n_zero, d_iv, d_open, n_iv, (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu), bits);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }

@@ -146,9 +146,164 @@ uint64_t pow2_at_least(uint64_t x) {
 // The traversal's view of a finished graph: compact CSR with dense ids, vertices renumbered by contig coordinate, and the
 // successor records of every vertex (searchSuccessors + checkPosition for all of them, PABruijnGraph.cpp:143-197) — built
 // once per graph and pair of (deviation, error rate), kept in the handle (g->tg).  Pool slots TRAV_SLOT0 .. + TRAV_GRAPH_SLOTS.
-constexpr int TRAV_GRAPH_SLOTS = 22;  // (+ 2 behind them for a regional graph's incomplete-vertex bitmap)
+constexpr int TRAV_GRAPH_SLOTS = 22;  // (+ 2 behind them for a regional graph's incomplete-vertex bitmap, + 2 for the view's scratch)
+constexpr int TRAV_EXTRA_SLOTS = 4;
+
+// ---- the view of ONE handle's traversals -----------------------------------------------------------------------------
+// A traversal of contig strand S (PAlgorithm::travelSequence for one (contig, orientation)) only ever examines
+//   * the vertices on S;
+//   * vertices with a contig coordinate elsewhere as leap targets, and a leap that lands beyond the first (1 - startSplit)
+//     of its strand is dropped (classifySuccessors, PAlgorithm.tcc:60-67): the landing zones of every strand are enough;
+//   * vertices WITHOUT a contig coordinate once it can take a Skip grade, i.e. once hasSize + nowSize >= ctgLen x startSplit
+//     (PAlgorithm.tcc:69-86) — in the last tenth of the strand and beyond its end, along the reference, until it lands.
+// Present or absent, anything else never changes a classification (the argument of pag_shard_select, k_select.hip, which cuts
+// a block's graph the same way for the ranks of a multi-GPU run), so the view is built from these alone: at BASELINE
+// configs[1] 4 of 10 vertices — the opposite strand of every contig (every read is emitted on both strands, one is
+// traversed) and the coordinate-free vertices along the first 9/10 of every contig are left out, and the successor stage —
+// 42 % of a step in round 3 — runs over what is left.  NEVER SILENTLY WRONG: a coordinate-free vertex within a successor's
+// reach of an open band end carries a poison record, and a vertex on a strand whose reference coordinate lies in no band (its
+// coordinate-free successors were left out) carries a marker record that counts wherever a Skip grade could be taken
+// (k_mark_incomplete, k_succ); a walk that examines one reports it and pag_travel walks again on the whole graph's view
+// (g->view_off).  Zones start PAG_VIEW_MARGIN (3 % of the contig, at least 4 kb) before the coordinate where leaping
+// would begin if steps and coordinates agreed: the pieces of the leaping zone start a little before it (PAG_LEAP_LEFT) and
+// the sum of the steps runs ahead of the coordinate by ~0.6 %.  Bands reach PAG_VIEW_HALO (100 kb) beyond the reference
+// stretch the zone's vertices map to.
+struct ViewRegion {
+    std::vector<uint32_t> civ, riv;  // [lo, hi) pairs, sorted, disjoint
+    std::vector<uint8_t> ropen;      // per band end: the graph goes on beyond it
+};
+void merge_intervals(std::vector<std::pair<uint64_t, uint64_t>> &iv) {
+    std::sort(iv.begin(), iv.end());
+    size_t w = 0;
+    for (size_t i = 0; i < iv.size(); ++i) {
+        if (iv[i].second <= iv[i].first) continue;
+        if (w && iv[i].first <= iv[w - 1].second) iv[w - 1].second = std::max(iv[w - 1].second, iv[i].second);
+        else iv[w++] = iv[i];
+    }
+    iv.resize(w);
+}
+int trav_view_region(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                     double startSplit, DevBuf &scratch, ViewRegion *out) {
+    hipStream_t s = g->stream;
+    const Mapper cm(ctg_len, n_ctgs), rm(ref_len, n_refs);
+    uint64_t halo = 100000;
+    if (const char *e = std::getenv("PAG_VIEW_HALO")) halo = (uint64_t)std::max(0ll, std::atoll(e));
+    double margin_frac = 0.03;
+    uint64_t margin_min = 4000;
+    if (const char *e = std::getenv("PAG_VIEW_MARGIN")) {
+        margin_min = (uint64_t)std::max(0ll, std::atoll(e));
+        margin_frac = 0.0;
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> civ, zones;
+    const double leap_min = 1.0 - startSplit;
+    for (uint64_t c = 0; c < n_ctgs; ++c) {
+        const uint64_t n = ctg_len[c];
+        const uint64_t z = std::min<uint64_t>(n, (uint64_t)((double)n * leap_min) + 2);
+        for (int rev = 0; rev < 2; ++rev) {
+            const int64_t one = rev ? -(int64_t)c - 1 : (int64_t)c + 1;
+            const uint64_t left = cm.dualToSingle(one, 0);
+            civ.push_back({left, left + z});  // landing zone of every strand
+            const int32_t o = orient[c];
+            const bool walked = o == PAG_ORIENT_BOTH || (!rev && o == PAG_ORIENT_FORWARD) || (rev && o == PAG_ORIENT_REVERSE);
+            if (!walked) continue;
+            civ.push_back({left, left + n});
+            const uint64_t split = (uint64_t)((double)n * startSplit);
+            const uint64_t margin = std::max<uint64_t>(margin_min, (uint64_t)((double)n * margin_frac));
+            zones.push_back({left + (split > margin ? split - margin : 0), left + n});
+        }
+    }
+    merge_intervals(civ);
+    std::sort(zones.begin(), zones.end());  // (strands are disjoint: so are their zones)
+    // reference stretch every zone's vertices map to
+    const uint32_t nz = (uint32_t)zones.size();
+    std::vector<uint32_t> zflat(2 * (size_t)nz), zlo(nz), zhi(nz);
+    for (uint32_t i = 0; i < nz; ++i) {
+        zflat[2 * i] = (uint32_t)zones[i].first;
+        zflat[2 * i + 1] = (uint32_t)zones[i].second;
+    }
+    int rc;
+    if ((rc = scratch.alloc(((size_t)nz * 4 + 16) * 4))) return rc;
+    uint32_t *d_z = scratch.as<uint32_t>(), *d_lo = d_z + 2 * (size_t)nz, *d_hi = d_lo + nz;
+    if (nz) {
+        PAG_HIP_TRY(hipMemcpyAsync(d_z, zflat.data(), zflat.size() * 4, hipMemcpyHostToDevice, s));
+        if ((rc = trav_zone_bands(g->tval, g->n_t, d_z, nz, d_lo, d_hi, s))) return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(zlo.data(), d_lo, (size_t)nz * 4, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipMemcpyAsync(zhi.data(), d_hi, (size_t)nz * 4, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+    }
+    // strand ranges of the references in the single-coordinate space (PositionMapper): [start, start + len) and
+    // [start + 2 len, start + 3 len); no position lies between them
+    auto range_of = [&](uint64_t x, uint64_t *lo, uint64_t *hi) {
+        const auto d = rm.singleToDual(x);
+        const size_t i = (size_t)(d.first > 0 ? d.first - 1 : -d.first - 1);
+        if (d.first == 0 || i >= rm.sizes.size()) {
+            *lo = 0;
+            *hi = ~0ull;
+            return;
+        }
+        *lo = rm.starts[i] + (d.first > 0 ? 0 : 2 * rm.sizes[i]);
+        *hi = *lo + rm.sizes[i];
+    };
+    struct Band {
+        uint64_t lo, hi;
+        bool olo, ohi;
+    };
+    std::vector<Band> bands;
+    for (uint32_t i = 0; i < nz; ++i) {
+        if (zhi[i] == 0u || zlo[i] > zhi[i]) continue;  // (no vertex of the zone has a reference coordinate)
+        uint64_t a0, a1, b0, b1;
+        range_of(zlo[i], &a0, &a1);
+        range_of(zhi[i], &b0, &b1);
+        Band b;
+        b.lo = zlo[i] > halo ? zlo[i] - halo : 0;
+        b.hi = (uint64_t)zhi[i] + halo + 1;
+        b.olo = b.lo > a0;
+        b.ohi = b.hi < b1;
+        b.lo = std::max(b.lo, a0);
+        b.hi = std::min<uint64_t>(std::min(b.hi, b1), 0xFFFFFFFFull);
+        bands.push_back(b);
+    }
+    std::sort(bands.begin(), bands.end(), [](const Band &x, const Band &y) { return x.lo < y.lo || (x.lo == y.lo && x.hi < y.hi); });
+    std::vector<Band> merged;
+    for (const Band &b : bands) {
+        if (!merged.empty() && b.lo <= merged.back().hi) {
+            if (b.hi > merged.back().hi) {
+                merged.back().hi = b.hi;
+                merged.back().ohi = b.ohi;
+            }
+        } else {
+            merged.push_back(b);
+        }
+    }
+    out->civ.clear();
+    out->riv.clear();
+    out->ropen.clear();
+    for (auto &c : civ) {
+        out->civ.push_back((uint32_t)c.first);
+        out->civ.push_back((uint32_t)std::min<uint64_t>(c.second, 0xFFFFFFFFull));
+    }
+    for (const Band &b : merged) {
+        out->riv.push_back((uint32_t)b.lo);
+        out->riv.push_back((uint32_t)b.hi);
+        out->ropen.push_back(b.olo ? 1 : 0);
+        out->ropen.push_back(b.ohi ? 1 : 0);
+    }
+    return PAG_OK;
+}
+// the strands `want` traverses are among those the view was built for
+bool view_serves(const std::vector<int32_t> &have, const int32_t *want, uint64_t n) {
+    if (have.size() != n) return false;
+    for (uint64_t c = 0; c < n; ++c) {
+        const int32_t w = want[c], h = have[c];
+        if (w == PAG_ORIENT_NONE || h == PAG_ORIENT_BOTH || w == h) continue;
+        return false;
+    }
+    return true;
+}
+
+// orient == nullptr: the view of the whole graph (serves any traversal)
 int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, const uint32_t *ref_len, uint64_t n_refs, uint64_t deviation,
-                       double errorRate, TravGraph *G_out, double *ms_out) {
+                       double errorRate, TravGraph *G_out, double *ms_out, const int32_t *orient = nullptr, double startSplit = 0.9) {
     hipStream_t s = g->stream;
     const uint32_t k = g->k;
     int rc;
@@ -156,10 +311,14 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
     auto buf = [&](void) { return DevBuf(g, slot++); };
     if (ms_out) *ms_out = 0;
     if (g->tg_ready && (g->tg_dev != deviation || g->tg_err != errorRate)) g->tg_ready = false;
+    if (g->tg_ready && g->view_pruned && !(orient && view_serves(g->view_orient, orient, n_ctgs))) g->tg_ready = false;
     if (g->tg_ready) {
         *G_out = g->tg;
         return PAG_OK;
     }
+    // a graph that is one rank's region of a sharded build is cut already (pag_shard_select); PAG_TRAVEL_VIEW=whole: never cut
+    const char *view_env = std::getenv("PAG_TRAVEL_VIEW");
+    const bool prune = orient && !g->regional && !g->view_off && !(view_env && std::strcmp(view_env, "whole") == 0);
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
            b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(), b_ucnt = buf(),
@@ -200,9 +359,42 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         const double t0 = now_ms();
         size_t tb = trav_compact_tmp_bytes(g->n_t, g->n_e, k, nn);
         if ((rc = b_ctmp.alloc(tb))) return rc;
+        ViewRegion vr;
+        TravView tv{};
+        DevBuf b_view(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 2), b_viewiv(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 3);
+        g->view_pruned = false;
+        if (prune) {
+            if ((rc = trav_view_region(g, ctg_len, n_ctgs, orient, ref_len, n_refs, startSplit, b_view, &vr))) return rc;
+            if ((rc = b_viewiv.alloc((vr.civ.size() + vr.riv.size() + 8) * 4))) return rc;
+            uint32_t *d = b_viewiv.as<uint32_t>();
+            if (!vr.civ.empty()) PAG_HIP_TRY(hipMemcpyAsync(d, vr.civ.data(), vr.civ.size() * 4, hipMemcpyHostToDevice, s));
+            if (!vr.riv.empty()) PAG_HIP_TRY(hipMemcpyAsync(d + vr.civ.size(), vr.riv.data(), vr.riv.size() * 4, hipMemcpyHostToDevice, s));
+            tv.civ = d;
+            tv.n_civ = (uint32_t)(vr.civ.size() / 2);
+            tv.riv = d + vr.civ.size();
+            tv.n_riv = (uint32_t)(vr.riv.size() / 2);
+            if (std::getenv("PAGRAPH_TIMING")) {
+                uint64_t cl = 0, rl = 0;
+                for (size_t i = 0; i + 1 < vr.civ.size(); i += 2) cl += vr.civ[i + 1] - vr.civ[i];
+                for (size_t i = 0; i + 1 < vr.riv.size(); i += 2) rl += vr.riv[i + 1] - vr.riv[i];
+                std::fprintf(stderr, "[timing] view region: %zu contig intervals covering %llu coordinates, %zu reference bands covering %llu\n", vr.civ.size() / 2,
+                             (unsigned long long)cl, vr.riv.size() / 2, (unsigned long long)rl);
+            }
+        }
+        uint64_t counts[3] = {nn, np, ne};
         if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
-                               b_ctmp.p, tb, s)))
+                               b_ctmp.p, tb, s, prune ? &tv : nullptr, counts)))
             return rc;
+        if (prune) {
+            G.n_nodes = counts[0];
+            G.n_pos = counts[1];
+            G.n_edges = counts[2];
+            g->view_pruned = true;
+            g->view_orient.assign(orient, orient + n_ctgs);
+        }
+        g->view_counts[0] = G.n_nodes;
+        g->view_counts[1] = G.n_pos;
+        g->view_counts[2] = G.n_edges;
         // coordinate order, then the static half of the epsilon-join for every vertex
         if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
             (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
@@ -220,12 +412,14 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         // a graph that holds a region of the block only: which coordinate-free vertices may have successors beyond it
         G.incomplete = nullptr;
         G.n_zero = (uint32_t)g->n_zero_ctg;
-        if (g->regional) {
+        if (g->regional || prune) {
+            // (one rank's region of a sharded build: the bands it was given; this handle's own view: the bands it took)
+            const std::vector<uint32_t> &riv = prune ? vr.riv : g->region_ref_iv;
+            const std::vector<uint8_t> &ropen = prune ? vr.ropen : g->region_ref_open;
             DevBuf b_inc(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS), b_inct(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 1);
-            const uint32_t n_iv = (uint32_t)(g->region_ref_iv.size() / 2);
-            if ((rc = b_inc.alloc(((size_t)G.n_zero / 32 + 4) * 4)) || (rc = b_inct.alloc(trav_mark_incomplete_tmp_bytes(n_iv)))) return rc;
-            if ((rc = trav_mark_incomplete(G, G.n_zero, g->region_ref_iv.data(), g->region_ref_open.data(), n_iv, (uint32_t)deviation, errorRate,
-                                           b_inc.as<uint32_t>(), b_inct.p, s)))
+            const uint32_t n_iv = (uint32_t)(riv.size() / 2);
+            if ((rc = b_inc.alloc(((size_t)G.n_pos / 32 + 4) * 4)) || (rc = b_inct.alloc(trav_mark_incomplete_tmp_bytes(n_iv)))) return rc;
+            if ((rc = trav_mark_incomplete(G, G.n_zero, riv.data(), ropen.data(), n_iv, (uint32_t)deviation, errorRate, b_inc.as<uint32_t>(), b_inct.p, s)))
                 return rc;
             G.incomplete = b_inc.as<uint32_t>();
         }
@@ -279,8 +473,10 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         g->tg_err = errorRate;
         g->tg_ready = true;
         if (std::getenv("PAGRAPH_TIMING"))
-            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%s, %llu candidate pairs)\n", (unsigned long long)n_succ,
-                         (unsigned long long)np, stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
+            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%llu without a contig coordinate) of %llu (%s view: %llu of %llu nodes, %llu of %llu edges; %s, %llu candidate pairs)\n",
+                         (unsigned long long)n_succ, (unsigned long long)G.n_pos, (unsigned long long)g->n_zero_ctg, (unsigned long long)np, g->view_pruned ? "cut" : "whole", (unsigned long long)G.n_nodes,
+                         (unsigned long long)nn, (unsigned long long)G.n_edges, (unsigned long long)ne,
+                         stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
         t_compact = now_ms() - t0;
     }
 
@@ -344,15 +540,47 @@ int pag_debug_succ(const pag_graph *g, uint32_t *succ_off, void *recs) {
 
 // the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
 int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm, double *ms) {
+    return pag_travel_prepare_for(g, ctgs, nullptr, ref_len, n_refs, prm, ms);
+}
+// ... for the traversals pag_travel will be asked for (orient as pag_travel takes it; NULL: any): the view then holds what
+// those traversals can examine and nothing else (trav_view_region above)
+int pag_travel_prepare_for(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                           const pag_travel_params *prm, double *ms) {
     if (!g || !ctgs || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
     PAG_HIP_TRY(hipSetDevice(g->device));
     TravGraph G{};
-    return trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, prm->deviation, prm->error_rate, &G, ms);
+    return trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, prm->deviation, prm->error_rate, &G, ms, orient, prm->start_split);
+}
+int pag_travel_view_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges, uint64_t *n_succ, int *cut, uint64_t *fallbacks) {
+    if (!g || !g->tg_ready) return PAG_EINVAL;
+    if (n_nodes) *n_nodes = g->view_counts[0];
+    if (n_pos) *n_pos = g->view_counts[1];
+    if (n_edges) *n_edges = g->view_counts[2];
+    if (n_succ) *n_succ = g->tg.n_succ;
+    if (cut) *cut = g->view_pruned ? 1 : 0;
+    if (fallbacks) *fallbacks = g->view_fallbacks;
+    return PAG_OK;
 }
 
+static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                       const pag_travel_params *prm, pag_travel_stats *stats);
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *prm, pag_travel_stats *stats) {
     if (!g || !ctgs || !orient || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
+    int rc = travel_once(g, ctgs, orient, ref_len, n_refs, prm, stats);
+    if (rc == PAG_ERANGE && g->view_pruned && !g->regional) {
+        // a walk examined a vertex whose successors this handle's own view left out (trav_view_region): nothing of that walk is
+        // kept — the whole graph's view is built and every contig walked again (the outputs are those of the un-cut graph)
+        if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] a walk left the view: %s; walking again on the whole graph\n", pag_last_error());
+        g->view_off = true;
+        g->tg_ready = false;
+        g->view_fallbacks += 1;
+        rc = travel_once(g, ctgs, orient, ref_len, n_refs, prm, stats);
+    }
+    return rc;
+}
+static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                       const pag_travel_params *prm, pag_travel_stats *stats) {
     PAG_HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = g->stream;
     const double t_begin = now_ms();
@@ -425,8 +653,8 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     // ---- compact CSR, coordinate order, successor records (once per built graph)
     TravGraph G{};
     double t_compact = 0;
-    if ((rc = trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, deviation, errorRate, &G, &t_compact))) return rc;
-    slot += TRAV_GRAPH_SLOTS + 2;
+    if ((rc = trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, deviation, errorRate, &G, &t_compact, orient, startSplit))) return rc;
+    slot += TRAV_GRAPH_SLOTS + TRAV_EXTRA_SLOTS;
     const uint64_t np = G.n_pos;
     (void)np;
 
@@ -1436,7 +1664,9 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
             const bool overflow = (o.overflow & 3) != 0, misspec = (o.overflow & 4) != 0;
             if (o.poison) {
                 // (a regional graph, pag_shard_select: the walk reached a vertex whose successors another rank holds)
-                set_error("pag_travel: a walk of contig %u left the region of the graph this rank holds (reference band halo too small: raise PAG_SHARD_HALO)", st[i].ci);
+                set_error(g->regional ? "pag_travel: a walk of contig %u left the region of the graph this rank holds (reference band halo too small: raise PAG_SHARD_HALO)"
+                                      : "pag_travel: a walk of contig %u left the view built for this handle's traversals (PAG_VIEW_HALO / PAG_VIEW_MARGIN)",
+                          st[i].ci);
                 return fail(PAG_ERANGE);
             }
             touched.push_back(i);

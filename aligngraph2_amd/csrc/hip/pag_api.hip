@@ -71,6 +71,8 @@ void free_graph_results(pag_graph *g) {  // the memory stays in the pool
     g->eseg = nullptr;
     g->n_t = g->n_e = 0;
     g->tg_ready = false;
+    g->view_pruned = g->view_off = false;
+    g->view_orient.clear();
     g->regional = false;
     g->region_ref_iv.clear();
     g->region_ref_open.clear();

@@ -67,6 +67,13 @@ struct pag_graph {
     bool regional = false;
     std::vector<uint32_t> region_ref_iv;
     std::vector<uint8_t> region_ref_open;
+    // the traversal view (g->tg) was built for these orientations only (trav_view_region, k5_travel_host.hip): it leaves out
+    // what no traversal of them can examine.  view_off: a walk did leave the view (pag_travel then rebuilds the whole graph's
+    // view and walks again); both are reset with the graph.
+    bool view_pruned = false, view_off = false;
+    std::vector<int32_t> view_orient;
+    uint64_t view_counts[3] = {0, 0, 0};  // nodes, vertices, edges of the view
+    uint64_t view_fallbacks = 0;          // (since the handle was created)
     uint64_t n_zero_ctg = 0;  // new ids below it: vertices without a contig coordinate, in reference-coordinate order
     // pinned host staging area of the traversal (packed job results, uploads)
     void *pin_host = nullptr;

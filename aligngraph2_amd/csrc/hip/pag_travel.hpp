@@ -33,12 +33,13 @@ struct TravGraph {
     struct SuccRec *succ; // [n_succ]
     uint64_t n_succ;
     // a graph that holds only a REGION of the block's vertices (pag_shard_select, one rank of a sharded build): bit u set =
-    // the successors of coordinate-free vertex u (new id < n_zero) may lie outside the region.  Such a vertex has ONE
-    // record of grade GRADE_POISON instead of its successors; a walk that examines it reports a fault (TravJobOut::poison).
+    // successors of vertex u may lie outside the region (its reference coordinate is near an open band end, or — a vertex
+    // selected by its contig coordinate — in no band of this rank at all).  Such a vertex has ONE record of grade
+    // GRADE_POISON instead of its successors; a walk that examines it reports a fault (TravJobOut::poison).
     const uint32_t *incomplete;  // null: the whole graph is here
     uint32_t n_zero;
 };
-constexpr uint32_t GRADE_POISON = 7u;
+constexpr uint32_t GRADE_POISON = 7u, GRADE_POISON_IF_LEAP = 6u;  // (marker records, see k_succ / walk_note_record in k5_travel.hip)
 
 // one graded successor of a vertex (searchSuccessors + checkPosition != Oops), in reference order
 struct alignas(16) SuccRec {
@@ -161,9 +162,17 @@ struct TravSeedReq {
     uint64_t left, right, pos;
 };
 
+// what of a finished graph a traversal view takes (device arrays of sorted, disjoint [lo, hi) pairs): vertices with a contig
+// coordinate inside civ, vertices without one whose reference coordinate lies inside riv
+struct TravView {
+    const uint32_t *civ, *riv;
+    uint32_t n_civ, n_riv;
+};
 int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
                  const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
-                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s);
+                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view = nullptr,
+                 uint64_t *counts_out = nullptr);
+int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev, uint32_t n_z, uint32_t *lo_dev, uint32_t *hi_dev, hipStream_t s);
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes);
 void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
                            uint32_t *out, hipStream_t s);

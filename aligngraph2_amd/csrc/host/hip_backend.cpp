@@ -98,13 +98,14 @@ public:
         for (std::size_t i = 0; i < ctx.refs.size(); ++i) refLen.push_back(ctx.refs.length(i));
         const SeqDb &contigs = ctx.contigs;
         pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(), contigs.packed().size()};
-        check(pag_travel_prepare(g_, &cs, refLen.data(), refLen.size(), &params, nullptr), "pag_travel_prepare");
+        const std::vector<std::int32_t> orient = orientations(ctx);
+        check(pag_travel_prepare_for(g_, &cs, orient.data(), refLen.data(), refLen.size(), &params, nullptr), "pag_travel_prepare_for");
     }
 
-    void travelWalks(const TravelContext &ctx, const pag_travel_params &params, TravelViews &out) override {
+    // orientation(s) per contig as PAssembly::testTravel5 walks its ctgSet (PAssembly.cpp:28-36): a contig listed with
+    // both orientations is traversed twice, as two independent entries; in a sharded run only the contigs this rank was dealt
+    std::vector<std::int32_t> orientations(const TravelContext &ctx) const {
         const SeqDb &contigs = ctx.contigs;
-        // orientation(s) per contig as PAssembly::testTravel5 walks its ctgSet (PAssembly.cpp:28-36): a contig listed with
-        // both orientations is traversed twice, as two independent entries
         std::vector<std::int32_t> orient(contigs.size(), PAG_ORIENT_NONE);
         for (auto &c : ctx.ctgSet) {
             if (!contigs.contains(c.first)) continue;
@@ -114,6 +115,12 @@ public:
             const std::int32_t mine = c.second ? PAG_ORIENT_FORWARD : PAG_ORIENT_REVERSE;
             o = (o == PAG_ORIENT_NONE || o == mine) ? mine : PAG_ORIENT_BOTH;
         }
+        return orient;
+    }
+
+    void travelWalks(const TravelContext &ctx, const pag_travel_params &params, TravelViews &out) override {
+        const SeqDb &contigs = ctx.contigs;
+        const std::vector<std::int32_t> orient = orientations(ctx);
         std::vector<std::uint32_t> refLen;
         for (std::size_t i = 0; i < ctx.refs.size(); ++i) refLen.push_back(ctx.refs.length(i));
         pag_seqs cs{contigs.size(), contigs.byteOff().data(), contigs.lens().data(), contigs.packed().data(), contigs.packed().size()};

@@ -150,7 +150,7 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
     // the traversal's view of the new graph (successor records: device work, this thread only waits) still runs beside the
     // previous block's host half ...
     double msPrep = 0;
-    int rc = pag_travel_prepare(g, ctgs, refs->len, refs->n_seqs, &tp, &msPrep);
+    int rc = pag_travel_prepare_for(g, ctgs, ctg_orient, refs->len, refs->n_seqs, &tp, &msPrep);
     if (rc != PAG_OK) {
         setErr("pag_travel_prepare: %s", pag_last_error());
         return rc;

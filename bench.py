@@ -34,7 +34,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -52,8 +51,8 @@ class TraverseStats(C.Structure):
 
 
 def load_libs():
-    import pagctl
-    hip = pagctl.hip_lib()  # raises if the HIP library is missing: there is no CPU fallback
+    import aligngraph2_amd
+    hip = aligngraph2_amd.load_hip()  # raises if the HIP library is missing: there is no CPU fallback
     host_path = os.path.join(ROOT, "aligngraph2_amd", "libpagraph_host.so")
     if not os.path.exists(host_path):
         raise RuntimeError(f"{host_path} missing: run __graft_entry__.build()")
@@ -76,7 +75,7 @@ def load_libs():
 
 def host_seqs(codes_list):
     """2-bit pack a list of uint8 code arrays into a host pag_seqs (keeps the numpy buffers alive)."""
-    import biggen
+    from aligngraph2_amd import workload as biggen
     offs, lens, chunks, cur = [], [], [], 0
     for c in codes_list:
         n = len(c)
@@ -96,9 +95,8 @@ def host_seqs(codes_list):
 
 def cpu_baseline(k, eps, cov, threads_flag):
     """Time the CPU reference on a bounded sample of the same kind of workload (rank 0, N = 1 only)."""
-    import biggen
-    import pagctl
-    import synth
+    import aligngraph2_amd
+    from aligngraph2_amd import workload as biggen
     ncores = os.cpu_count() or 1
     quota = None  # CPUs the container may use (cgroup v2 cpu.max), if limited: the reference's threads share them
     try:
@@ -120,15 +118,20 @@ def cpu_baseline(k, eps, cov, threads_flag):
             t_use = min(ncores, 64)
             out = os.path.join(tmp, "out")
             os.makedirs(out)
-            argv = synth.pagraph_argv(ref_bin, tmp, out, threads=t_use, epsilon=eps, cov=cov)
+            argv = aligngraph2_amd.pagraph_argv(ref_bin, tmp, out, threads=t_use, epsilon=eps, cov=cov)
             t0 = time.time()
             r = subprocess.run(argv, capture_output=True, text=True)
             dt = time.time() - t0
             if r.returncode != 0:
                 raise RuntimeError("reference pagraph failed: " + r.stderr[-500:])
-            return {"value": w.n_bases / dt, "unit": "aligned-read-bases/s", "cores": t_use, "kind": "reference",
+            # cores = what the threads could actually run on: the container's CPU quota when it is below the thread count
+            cores = int(min(t_use, quota)) if quota else t_use
+            return {"value": w.n_bases / dt, "unit": "aligned-read-bases/s", "cores": max(1, cores), "kind": "reference",
                     "sample": sample + f"; compiled reference pagraph -t {t_use} (-O3), wall {dt:.1f} s incl. its file parsing"
-                    + (f"; the host's cgroup CPU quota is {quota:g} CPUs" if quota else "")}
+                    + (f"; the host's cgroup CPU quota is {quota:g} CPUs" if quota else f"; {ncores} host CPUs, no quota")}
+        # (no compiled reference on this box: the C oracle — test infrastructure — stands in, as the checker-side port)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pagctl
         inp = pagctl.LoadedInput(tmp, threads=threads_flag, eps=eps, cov=cov)
         t0 = time.time()
         pagctl.run_oracle(inp)
@@ -148,6 +151,28 @@ KNOWN_PATHS = {(100_000, 10_000, 50_000_000, 14, 10, 2 + r): v for r, v in enume
 # = host restatement of the reference's traversal; logs of those runs: profiles/r02_walk_check_seeds.log)
 
 
+def baseline_config_name(args, shard, world):
+    """names the BASELINE.json config a run measures — only when its arguments ARE that config's"""
+    geo = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon)
+    if geo == (100_000, 10_000, 50_000_000, 14, 10) and not shard:
+        return " (BASELINE configs[1])"
+    if geo == (1_000_000, 10_000, 250_000_000, 14, 10) and shard and world == 4:
+        return " (BASELINE configs[2])"
+    return " (not a BASELINE.json configuration)"
+
+
+def time_share(ms_step, wall, steps, ms_build):
+    """where a step's wall time went, from this run's own laps"""
+    def pct(x):
+        return f"{100.0 * x / ms_step:.0f} %" if ms_step > 0 else "?"
+    succ, walks, prep = wall["succ"] / steps * 1e3, wall["begin"] / steps * 1e3, wall["prepare"] / steps * 1e3
+    wait = wall["collect"] / steps * 1e3
+    return (f"of {ms_step:.0f} ms per step: successor records (traversal view: compaction, coordinate order, records) {pct(succ)}, walks (k_walk_persistent + "
+            f"their control thread) {pct(walks)}, graph build {pct(ms_build)}, pag_prepare {pct(prep)}, waiting for the previous block's host half "
+            f"{pct(wait)}; a block's host half (path graph, chains, output files) runs on host threads beside the next block's device work; the "
+            "roofline object grades the k-mer sort")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,8 +189,17 @@ def main():
     ap.add_argument("--build-only", action="store_true", help="diagnostic: skip traversal (NOT a valid bench line)")
     ap.add_argument("--file-to-file", action="store_true",
                     help="also write the workload as TEXT files (/dev/shm, ~25 s) and time the drop-in executable on them, live: "
-                         "config.file_to_file_* (never part of `value`)")
+                         "config.file_to_file_* (never part of `value`).  On by default for a single-GPU run of the default workload when "
+                         "/dev/shm has room for the 7 GB of text")
+    ap.add_argument("--no-file-to-file", action="store_true")
     args = ap.parse_args()
+    if not args.file_to_file and not args.no_file_to_file and not args.build_only and int(os.environ.get("WORLD_SIZE", "1")) == 1 and \
+            (args.reads, args.read_span, args.ref_len) == (100_000, 10_000, 50_000_000):
+        try:
+            st_shm = os.statvfs("/dev/shm")
+            args.file_to_file = st_shm.f_bavail * st_shm.f_frsize > (16 << 30)
+        except OSError:
+            pass
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,7 +216,7 @@ def main():
     from aligngraph2_amd import parallel
     dist = parallel.init("gloo" if one_device else "nccl")  # RCCL; only the barrier and two 8-byte all-reduces use it
 
-    import biggen
+    from aligngraph2_amd import workload as biggen
     hip, host = load_libs()
     shard = args.mode == "shard" and world > 1
     spec = biggen.BigSpec(seed=2 + (0 if shard else rank), ref_len=args.ref_len, n_reads=args.reads, read_span=args.read_span, k=args.k,
@@ -234,8 +268,7 @@ def main():
     orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
     out_dir = tempfile.mkdtemp(prefix=f"pagbench{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 
-    import pagctl
-    st = pagctl.BuildStats()
+    st = parallel.BuildStats()
     ts = TraverseStats()
 
     wall = {"prepare": 0.0, "process": 0.0, "traverse": 0.0, "collect": 0.0, "succ": 0.0, "begin": 0.0}
@@ -316,9 +349,9 @@ def main():
             # (the successor records of the new graph are device work: built before the previous block's host half is waited for)
             ms_succ = C.c_double()
             ts0 = time.perf_counter()
-            rc = hip.pag_travel_prepare(g, C.byref(ctg_seqs), ref_len_u32.ctypes.data, 1, C.byref(tparams1), C.byref(ms_succ))
+            rc = hip.pag_travel_prepare_for(g, C.byref(ctg_seqs), orient.ctypes.data, ref_len_u32.ctypes.data, 1, C.byref(tparams1), C.byref(ms_succ))
             if rc != 0:
-                raise SystemExit(f"pag_travel_prepare failed ({rc}): {hip.pag_last_error().decode()}")
+                raise SystemExit(f"pag_travel_prepare_for failed ({rc}): {hip.pag_last_error().decode()}")
             succ_ms.append(ms_succ.value)
             wall["succ"] += time.perf_counter() - ts0
             tc0 = time.perf_counter()
@@ -341,8 +374,8 @@ def main():
                     ("start_split", C.c_double), ("min_len", C.c_uint64)]
     tparams1 = TravelParams1(spec.threads, 0, 2 * spec.eps, 0.15, 0.90, 50)
     ref_len_u32 = np.array([len(ref_np)], dtype=np.uint32)
-    hip.pag_travel_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-    hip.pag_travel_prepare.restype = C.c_int
+    hip.pag_travel_prepare_for.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    hip.pag_travel_prepare_for.restype = C.c_int
 
     def collect():
         """statistics (and errors) of the block whose host half is still running, if any"""
@@ -421,13 +454,25 @@ def main():
         n_rec = float(st.n_tuples[0] + st.n_tuples[1] + st.n_edges[0] + st.n_edges[1])
         ws_gbs = SORT_BYTES_PER_RECORD * n_rec / (st.ms_sort * 1e-3) / 1e9 if st.ms_sort > 0 else 0.0
         whole_sort_launches = 2 * ((2 * args.k + 7) // 8)  # scatter launches of both streams (sort_pairs: ceil(key bits / 8) passes)
-        traffic = None
+        traffic = hist_traffic = None
         prof = os.path.join(ROOT, "profiles", "sort_scatter_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                pj = json.load(open(prof))
+                traffic = pj.get("hbm_bytes_per_launch")
+                hist_traffic = pj.get("hist_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the whole sort's traffic: every scatter launch AND every histogram launch (one of each per pass and stream)
+        whole_traffic = (traffic + (hist_traffic or 0.0)) * whole_sort_launches if traffic else None
+        view_info = None
+        if not args.build_only and not shard and g is not None:
+            vn, vp_, ve, vs, fb = (C.c_uint64() for _ in range(5))
+            cut = C.c_int()
+            if hip.pag_travel_view_sizes(g, C.byref(vn), C.byref(vp_), C.byref(ve), C.byref(vs), C.byref(cut), C.byref(fb)) == 0:
+                view_info = {"cut_to_what_the_traversals_can_examine": bool(cut.value), "vertices": int(vp_.value), "of_vertices": int(st.n_pos),
+                             "nodes": int(vn.value), "edges": int(ve.value), "successor_records": int(vs.value),
+                             "walks_redone_on_the_whole_graph": int(fb.value)}
         line = {
             "metric": "aligned-read-bases/sec through PAGraph build+traverse",
             "value": total_bases * args.steps / dt_max,
@@ -442,8 +487,8 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.reads} x {args.read_span // 1000} kb reads vs {args.ref_len / 1e6:g} Mb reference {'in ONE block' if shard else 'per GPU'}, "
-                            f"k={args.k}, epsilon={args.epsilon}, -t 16 semantics (BASELINE configs[1])"
+                "workload": f"{args.reads} x {args.read_span / 1000:g} kb reads vs {args.ref_len / 1e6:g} Mb reference {'in ONE block' if shard else 'per GPU'}, "
+                            f"k={args.k}, epsilon={args.epsilon}, -t 16 semantics" + baseline_config_name(args, shard, world)
                             + (" [BUILD ONLY, diagnostic]" if args.build_only else ""),
                 "read_bases_per_gpu": w.n_bases,
                 "contigs": len(w.ctgs),
@@ -470,9 +515,8 @@ def main():
                 "walk_jobs": int(ts.walk_jobs), "walk_rounds_longest_chain": int(ts.walk_rounds),
                 "walk_path_vertices": int(ts.walk_steps), "walk_classifications": int(ts.walk_classifications),
                 "kmer_counter_on_device": kc,
-                "time_share": "successor records ~35 %, walks (k_walk_persistent + their control thread) ~38 %, build ~17 %, pag_prepare ~2 % of a step; "
-                              "the host half of a block (path graph, chains, 535 MB of output files, ~200 ms on 8 threads) runs beside the next "
-                              "block's device work; the roofline object grades the k-mer sort",
+                "time_share": time_share(dt_max / args.steps * 1e3, wall, args.steps, float(np.mean(build_ms))),
+                "traversal_view": view_info,
             },
             # SURVEY §8d's figure for the graded kernel = the WHOLE k-mer sort (both streams, every radix pass, histograms and
             # scans included): algorithmic bytes = one read + one write of every 12-byte record, independent of the number of
@@ -480,8 +524,9 @@ def main():
             # ONE launch of the scatter kernel (what the sort's inner kernel reaches while it runs).
             "roofline": {"bound": "hbm", "kernel": "k-mer sort (pagdev::sort_hist + scan + pagdev::sort_scatter, all radix passes of both streams)",
                          "achieved": ws_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic * whole_sort_launches if traffic else None,
-                         "traffic_source": "static: rocprofv3 PMC passes kept under profiles/ (bytes per scatter launch x launches; not collected in this run)",
+                         "traffic": whole_traffic,
+                         "traffic_source": "static: rocprofv3 PMC passes kept under profiles/sort_scatter_traffic.json (bytes per scatter launch + bytes per "
+                                           "histogram launch" + ("" if hist_traffic else " [histogram bytes missing from the profile]") + ", x launches; not collected in this run)",
                          "ms_sort": st.ms_sort, "records": int(n_rec), "algorithmic_bytes": SORT_BYTES_PER_RECORD * n_rec,
                          "per_pass": {"kernel": "pagdev::sort_scatter (one radix pass of one stream)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                       "records_per_launch": int(st.sort_records), "ms_per_launch": ms_sort, "traffic": traffic}},
@@ -497,14 +542,20 @@ def main():
             # tests/c2_text_runs.py, the record is kept under profiles/ (a cached measurement, quoted with its provenance)
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", "r03_c2_text_parity.json")))
+                nat = json.load(open(os.path.join(ROOT, "profiles", "r02_c2_text_runs.json")))
                 default_wl = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon) == (100_000, 10_000, 50_000_000, 14, 10)
-                if default_wl and rec.get("reference", {}).get("returncode") == 0:
+                if default_wl and nat.get("reference", {}).get("returncode") == 0:
+                    # the reference as a user runs it (-t 64, its own threads): the honest whole-workload CPU figure.  The
+                    # thread-serialising shim run (-t 16) is the PARITY provenance — the run whose 53 output files the drop-in
+                    # reproduces byte for byte — and is slower by construction.
                     line["cpu_baseline"]["full_workload"] = {
-                        "value": rec["reference"]["bases_per_s"], "unit": "aligned-read-bases/s", "cores": rec["reference"]["threads_flag"],
-                        "kind": "reference", "wall_s": rec["reference"]["wall_s"],
-                        "sample": rec["workload"] + "; compiled reference -t 16 under the thread-serialising shim (the run whose 53 output files the drop-in "
-                                  "reproduces byte for byte); cached: profiles/r03_c2_text_parity.json (tests/c2_text_runs.py --compare, GPU box host); "
-                                  "round 2 measured the same program at -t 64 without the shim: 319 s (profiles/r02_c2_text_runs.json)"}
+                        "value": nat["reference"]["bases_per_s"], "unit": "aligned-read-bases/s", "cores": nat["reference"].get("threads_flag", 64),
+                        "kind": "reference", "wall_s": nat["reference"]["wall_s"],
+                        "sample": nat.get("workload", "BASELINE configs[1] as text files") + "; compiled reference pagraph -t 64, its own threads, GPU box host "
+                                  "(16-CPU cgroup quota); cached: profiles/r02_c2_text_runs.json (tests/c2_text_runs.py)",
+                        "parity_provenance": {"wall_s": rec.get("reference", {}).get("wall_s"), "what": "the same files through the reference at -t 16 under the "
+                                              "thread-serialising shim: the run whose output files the drop-in reproduces byte for byte "
+                                              "(profiles/r03_c2_text_parity.json)"}}
                 if default_wl and rec.get("ours", {}).get("returncode") == 0:
                     line["config"]["file_to_file_bases_per_s"] = rec["ours"]["bases_per_s"]
                     line["config"]["file_to_file_note"] = ("bin/pagraph on the same text files, wall clock incl. parsing and upload; cached: "
@@ -529,7 +580,7 @@ def main():
     if rank == 0 and args.file_to_file and world == 1:
         # live: the same workload as text files through the drop-in executable, a cold process, parsing included (the bench's own
         # device memory is handed back first: the executable sizes its pools by what is free)
-        import synth
+        import aligngraph2_amd
         tdir = tempfile.mkdtemp(prefix="pagf2f_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         try:
             w.write_text(tdir)
@@ -543,9 +594,12 @@ def main():
             os.makedirs(odir)
             exe = os.path.join(ROOT, "aligngraph2_amd", "bin", "pagraph")
             tf = time.time()
-            r = subprocess.run(synth.pagraph_argv(exe, tdir, odir, threads=spec.threads, epsilon=spec.eps, cov=spec.cov), capture_output=True, text=True,
+            r = subprocess.run(aligngraph2_amd.pagraph_argv(exe, tdir, odir, threads=spec.threads, epsilon=spec.eps, cov=spec.cov), capture_output=True, text=True,
                                env=dict(os.environ, PAGRAPH_DEVICE=str(local), PAGRAPH_TIMING="1"))
             dtf = time.time() - tf
+            if r.returncode == 0:  # (the live figure replaces the cached one)
+                line["config"]["file_to_file_bases_per_s"] = n_bases_w / dtf
+                line["config"]["file_to_file_note"] = "bin/pagraph on the same workload as text files, wall clock incl. parsing and upload: measured live in this run (file_to_file_live)"
             line["config"]["file_to_file_live"] = {"returncode": r.returncode, "wall_s": dtf, "bases_per_s": n_bases_w / dtf,
                                                    "input_bytes": sum(os.path.getsize(os.path.join(tdir, f)) for f in os.listdir(tdir) if os.path.isfile(os.path.join(tdir, f))),
                                                    "output_files": len(os.listdir(odir)),

@@ -368,6 +368,19 @@ typedef struct pag_travel_stats {
  * walks.  *ms (may be NULL) receives its wall time. */
 int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm,
                        double *ms);
+/* ... for the traversals pag_travel will then be asked for (orient[i]: PAG_ORIENT_* as pag_travel takes it).  The view is
+ * built from what THOSE traversals can examine — the traversed strand of every contig, the landing zones of all strands
+ * (PAlgorithm.tcc:60-67), the vertices without a contig coordinate along the reference stretch the last tenth of every
+ * traversed strand maps to, where a walk can take a Skip grade (PAlgorithm.tcc:69-86) — and the successor stage runs over
+ * that alone.  Outputs are those of the whole graph: what is left out cannot change a classification, and a walk that comes
+ * within a successor's reach of something left out is detected and pag_travel walks again on the whole graph's view.  A
+ * pag_travel whose orientations the view does not cover rebuilds it.  PAG_TRAVEL_VIEW=whole switches the cut off. */
+int pag_travel_prepare_for(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                           const pag_travel_params *prm, double *ms);
+/* sizes of the prepared view (after pag_travel_prepare* / pag_travel): nodes, vertices, edges, successor records; *cut = 1 if
+ * it was built for given orientations only; *fallbacks = walks-again on the whole graph since the handle was created */
+int pag_travel_view_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges, uint64_t *n_succ, int *cut,
+                          uint64_t *fallbacks);
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *params, pag_travel_stats *stats);
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);

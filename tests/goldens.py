@@ -73,6 +73,36 @@ def compare_out_dir(name, out_dir):
         assert got == data, f"{name}: {f} differs from the reference's golden output"
 
 
+def repeat_config(ind, times):
+    """config.txt written `times` times over: block b reads the files of block b % (blocks of the golden)"""
+    cfg_path = os.path.join(ind, "config.txt")
+    text = open(cfg_path).read().rstrip("\n") + "\n"
+    open(cfg_path, "w").write("\n".join([text] * times))
+
+
+def compare_repeated_blocks(name, out_dir, n_blocks, per_golden=2):
+    """the outputs of a run over repeat_config()'s blocks: block b's files must be the golden's bytes of block b % per_golden
+    under b's own prefix; contig.txt = the golden's set of names"""
+    want = golden_out_files(name)
+    got = {f: open(os.path.join(out_dir, f), "rb").read() for f in sorted(os.listdir(out_dir))}
+    seen = {}
+    for f, data in got.items():
+        if f == "contig.txt":
+            assert sorted(set(data.splitlines())) == sorted(set(want["contig.txt"].splitlines())), "contig.txt"
+            continue
+        no, rest = f.split("_", 1)
+        no = int(no)
+        assert 0 <= no < n_blocks, f
+        seen[no] = seen.get(no, 0) + 1
+        golden = want[f"{no % per_golden}_{rest}"]
+        if rest.endswith((".con", ".fasta")):  # (the sequence names inside start with the block number too)
+            golden = re.sub(rb"(?m)^(>?)%d_" % (no % per_golden), rb"\g<1>%d_" % no, golden)
+        assert data == golden, f"{f} differs from the golden bytes of block {no % per_golden}"
+    assert "contig.txt" in got
+    for b in range(n_blocks):
+        assert seen.get(b, 0) == sum(1 for f in want if f.startswith(f"{b % per_golden}_")), f"block {b}: files missing"
+
+
 def check_blocks_parsed_ahead(exe, blocks, work):
     """The two-block golden's config.txt written twice over (blocks 2 and 3 read the files of blocks 0 and 1), run by `exe`
     (a pagraph_driver.cpp program) with and without parsing the next block ahead (PAGRAPH_PREFETCH) and running a block's host

@@ -19,16 +19,10 @@ WALK_TEST_LIB = os.path.join(ROOT, "tests", "harness", "bin", "libpagh_walk_test
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 
-class BuildStats(C.Structure):
-    _fields_ = [("merge_edge", C.c_uint64 * 2), ("total_pos", C.c_uint64 * 2), ("merge_pos", C.c_uint64 * 2),
-                ("n_tuples", C.c_uint64 * 2), ("n_edges", C.c_uint64 * 2), ("n_nodes", C.c_uint64),
-                ("n_pos", C.c_uint64), ("n_uniq_edges", C.c_uint64), ("ms_extract", C.c_double),
-                ("ms_sort", C.c_double), ("ms_cluster", C.c_double), ("ms_edges", C.c_double),
-                ("ms_total", C.c_double), ("ms_sort_kernel", C.c_double), ("sort_records", C.c_uint64)]
+import sys  # noqa: E402
 
-    def counts(self):
-        return (self.merge_edge[0], self.total_pos[0], self.merge_pos[0], self.merge_edge[1], self.total_pos[1],
-                self.merge_pos[1])
+sys.path.insert(0, ROOT)
+from aligngraph2_amd.parallel import BuildStats  # noqa: E402,F401  (pag_build_stats, include/pagraph_hip.h)
 
 
 class Csr(C.Structure):
@@ -64,19 +58,13 @@ _libs = {}
 
 def hip_lib():
     if "hip" not in _libs:
-        if not os.path.exists(HIP_LIB):
-            raise RuntimeError(f"{HIP_LIB} is missing: run __graft_entry__.build() (no CPU fallback exists)")
-        # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If
-        # our library were loaded first it would pull in the system runtime and a later `import torch` would
-        # mix it with torch's HSA ("no ROCm-capable device").  Loading torch first makes both share torch's.
-        import torch
-        torch.cuda.is_available()
-        lib = C.CDLL(HIP_LIB)
+        import sys
+        sys.path.insert(0, ROOT)
+        import aligngraph2_amd
+        lib = aligngraph2_amd.load_hip()  # (raises if the library is missing: no CPU fallback exists)
         _bind(lib, "pag")
         lib.pag_create.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_int)]
         lib.pag_create.restype = C.c_void_p
-        lib.pag_last_error.restype = C.c_char_p
-        lib.pag_device_available.restype = C.c_int
         _libs["hip"] = lib
     return _libs["hip"]
 

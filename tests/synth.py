@@ -398,8 +398,8 @@ def generate_multi(specs, out_dir: str) -> dict:
 
 def pagraph_argv(binary: str, in_dir: str, out_dir: str, threads: int = 1, epsilon: int = 10, cov: int = 2,
                  min_len: int = 50):
-    """The argv AlignGraph2.py uses (reference AlignGraph2.py:414-427), incl. the doubled -r."""
-    return [binary, "-t", str(threads), "-r", "dummy", "-k", os.path.join(in_dir, "kmer.bin"),
-            "-c", os.path.join(in_dir, "ctg.fasta"), "-R", os.path.join(in_dir, "ref.fasta"),
-            "-p", in_dir, "-a", os.path.join(in_dir, "aln"), "-o", out_dir, "-r", str(min_len),
-            "--epsilon", str(epsilon), "-v", str(cov)]
+    """The argv AlignGraph2.py uses (reference AlignGraph2.py:414-427), incl. the doubled -r (aligngraph2_amd.pagraph_argv)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import aligngraph2_amd
+    return aligngraph2_amd.pagraph_argv(binary, in_dir, out_dir, threads, epsilon, cov, min_len)

@@ -208,6 +208,46 @@ def test_config_blocks_dealt_out_over_processes_equal_the_golden(workdir):
     goldens.compare_out_dir(name, out)
 
 
+def _blocks_worker_gpu(rank, world, port, in_dir, out_dir, argv):
+    import sys
+    sys.path.insert(0, pagctl.ROOT)
+    from aligngraph2_amd import parallel
+    # (the ranks share the box's one device: LOCAL_RANK 0 for all, the walker grids take a share each)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PAG_DEVICE_SHARERS=str(world), PAG_WALK_IDLE_S="60")
+    dist = parallel.init("gloo")
+    codes = parallel.run_config_blocks(in_dir, out_dir, argv, dist, exe=EXE)
+    assert codes == [0] * world, codes
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_24_config_blocks_over_eight_processes_sharing_the_device(workdir):
+    """BASELINE configs[3]'s schedule at its shape (24 reference-sequence blocks over 8 ranks, parallel.run_config_blocks: the
+    blocks weighed by their files, dealt longest-first, ONE bin/pagraph per rank for its three blocks, contig.txt merged by rank
+    0) with the eight processes sharing the box's one MI355X (PAG_DEVICE_SHARERS=8) — against the one-process run of the same
+    24 blocks and the reference's golden bytes of every block."""
+    import torch.multiprocessing as mp
+    name = "two_blocks_both_orient_t16"
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / "b24" / "in"))
+    goldens.repeat_config(ind, 12)
+    outs = {}
+    for mode in ("one", "eight"):
+        out = str(workdir / "b24" / mode)
+        os.makedirs(out, exist_ok=True)
+        argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+        if mode == "one":
+            r = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+        else:
+            port = 29100 + os.getpid() % 300
+            mp.spawn(_blocks_worker_gpu, args=(8, port, ind, out, argv[1:]), nprocs=8, join=True)
+        goldens.compare_repeated_blocks(name, out, 24)
+        outs[mode] = {f: open(os.path.join(out, f), "rb").read() for f in sorted(os.listdir(out)) if f != "contig.txt"}
+    assert outs["one"] == outs["eight"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("blocks", [None, "0,2,3", "1,3"])
 def test_next_block_is_parsed_ahead_without_changing_any_output(blocks, workdir):

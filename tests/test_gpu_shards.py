@@ -245,8 +245,22 @@ def test_ranks_hold_their_region_only_and_walk_the_same_paths(n_shards, workdir)
     g2r = w.g2r.cpu().numpy()
     deal = parallel.deal_contigs(ctg_len, n_shards, ref_begin=[int(g2r[s]) for s, _, _ in w.ctgs])
     alns = [(c, 0, int(g2r[s]), int(g2r[e - 1]) + 1) for c, (s, e, _) in enumerate(w.ctgs)]
-    for halo, must_work in ((60_000, True), (0, False)):
-        regions = parallel.regions_for(deal, ctg_len, orient, alns, [len(w.ref)], halo=halo)
+    for halo, must_work in ((60_000, True), (0, False), ("hole", False)):
+        if halo == "hole":
+            # a band that does NOT cover where the rank's own contigs map (a contig whose reads also map elsewhere, a wrong
+            # alignment list): vertices kept through their contig coordinate have a reference coordinate in the hole, their
+            # coordinate-free successors are on no band of this rank — reported, or no path differs
+            regions = parallel.regions_for(deal, ctg_len, orient, alns, [len(w.ref)], halo=60_000)
+            for d in regions:
+                iv = d["ref_iv"].reshape(-1, 2)
+                lo, hi = int(iv[0][0]), int(iv[0][1])
+                a, b = lo + (hi - lo) // 3, lo + (hi - lo) // 3 + 150_000
+                d["ref_iv"] = np.array([[lo, a], [b, hi]] + [list(x) for x in iv[1:]], dtype=np.uint32).reshape(-1)
+                d["ref_open"] = np.array([int(d["ref_open"][0]), 1, 1] + [int(x) for x in d["ref_open"][1:]], dtype=np.uint8)
+                d["region"] = parallel.Region(len(d["ctg_iv"]) // 2, d["ctg_iv"].ctypes.data, len(d["ref_iv"]) // 2, d["ref_iv"].ctypes.data,
+                                              d["ref_open"].ctypes.data)
+        else:
+            regions = parallel.regions_for(deal, ctg_len, orient, alns, [len(w.ref)], halo=halo)
         gs, tot = _sharded(hip, w, n_shards, regions=regions)
         assert tot.counts() == st1.counts()  # (the count lines stay the block's)
         held = []
@@ -255,6 +269,8 @@ def test_ranks_hold_their_region_only_and_walk_the_same_paths(n_shards, workdir)
             hip.pag_csr_sizes(C.c_void_p(g), C.byref(nn), C.byref(npos), C.byref(ne))
             held.append(npos.value / st1.n_pos)
         out = str(workdir / f"reg{n_shards}_halo{halo}")
+        if halo == "hole":
+            assert max(held) < 1.0  # (something was left out)
         rc, res = _walk_dealt_and_assemble(hip, host, gs, w, deal, orient, seqs, out)
         for g in gs:
             hip.pag_destroy(C.c_void_p(g))
@@ -269,6 +285,7 @@ def test_ranks_hold_their_region_only_and_walk_the_same_paths(n_shards, workdir)
             if rc != 0:
                 assert "left the region" in res
                 continue
+            assert halo != "hole", "a walk over vertices whose reference neighbourhood this rank does not hold went unreported"
         for f in os.listdir(one):
             assert open(os.path.join(out, f), "rb").read() == open(os.path.join(one, f), "rb").read(), f"halo {halo}: {f}"
         assert sorted(os.listdir(out)) == sorted(os.listdir(one))

@@ -161,3 +161,43 @@ def test_config_blocks_over_two_ranks_equal_the_reference_outputs(tmp_path):
     port = 29500 + (os.getpid() + 41) % 1000
     mp.spawn(_blocks_worker, args=(2, port, ind, out, exe, argv), nprocs=2, join=True)
     goldens.compare_out_dir(name, out)
+
+
+def _blocks_worker_n(rank, world, port, in_dir, out_dir, exe, argv, extra_env):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(extra_env)
+    dist = parallel.init("gloo")
+    codes = parallel.run_config_blocks(in_dir, out_dir, argv, dist, exe=exe)
+    assert codes == [0] * world, codes
+    dist.destroy_process_group()
+
+
+def test_24_config_blocks_dealt_over_eight_ranks(tmp_path):
+    """The schedule of BASELINE configs[3] (a genome of 24 reference sequences over the 8 GPUs of a node: level 1, one pagraph
+    process per GPU for the blocks it was dealt, no data-path collective) at its shape: a config.txt of 24 blocks of two
+    sizes, dealt longest-first over 8 ranks (3 blocks each), every rank's driver run once — here the oracle-backed harness
+    build of the driver, no GPU needed — rank 0 merging contig.txt.  Every block's files must be the reference's golden bytes
+    under the block's own number."""
+    import subprocess
+    import goldens
+    import pagctl
+    import synth
+    subprocess.run(["make", "-C", pagctl.ROOT, "harness"], check=True, capture_output=True)
+    name = "two_blocks_both_orient_t16"
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(tmp_path / "in"))
+    goldens.repeat_config(ind, 12)
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    exe = os.path.join(pagctl.ROOT, "tests", "harness", "bin", "pagraph_oracle")
+    argv = synth.pagraph_argv(exe, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])[1:]
+    blocks = parallel.read_config_blocks(ind)
+    assert len(blocks) == 24
+    sizes = [sum(os.path.getsize(os.path.join(ind, f)) for f in b[1:4]) for b in blocks]
+    deal = parallel.assign_blocks(sizes, 8)
+    assert sorted(x for d in deal for x in d) == list(range(24)) and all(len(d) == 3 for d in deal)
+    loads = [sum(sizes[i] for i in d) for d in deal]
+    assert max(loads) - min(loads) <= max(sizes)  # (longest-first: no rank is more than one block behind)
+    port = 29500 + (os.getpid() + 77) % 1000
+    mp.spawn(_blocks_worker_n, args=(8, port, ind, out, exe, argv, {}), nprocs=8, join=True)
+    goldens.compare_repeated_blocks(name, out, 24)
