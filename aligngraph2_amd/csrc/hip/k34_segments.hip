@@ -181,9 +181,13 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
             out.cnt[dst] = (uint16_t)S.cnt[t];
             n_ctg += (v >> 32) != 0;
         }
-        if (t < (uint32_t)SEG_OWN && base + t < n) {
-            uint32_t seglen = 0;
-            if (P.head) {
+        // seg_len: the head of a segment says how many leaders it has; the other LEADER slots say that they are one and how
+        // far behind the head they lie (SEG_LEADER | offset), every other slot 0 — so that later passes can run one thread per
+        // slot (the traversal's compaction, k5_travel.hip).  Every slot has exactly one writer: the tile that owns the head of
+        // its segment (slots of a short segment may lie in that tile's look-ahead halo), cluster_long for a long segment.
+        if (base + t < n) {
+            if (P.head) {  // (t < SEG_OWN)
+                uint32_t seglen;
                 n_seg += 1;
                 if (P.is_long) {
                     uint32_t slot = atomicAdd(long_count, 1u);
@@ -193,8 +197,10 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
                     seglen = (uint32_t)__popc(L);
                     n_all += seglen;
                 }
+                out.seg_len[base + t] = seglen;
+            } else if (P.active) {
+                out.seg_len[base + t] = P.o < (uint32_t)__popc(L) ? (SEG_LEADER | P.o) : 0u;
             }
-            out.seg_len[base + t] = seglen;
         }
     }
     block_flush3(n_ctg, n_all, n_seg, out.counters);
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(64) void cluster_long(const uint32_t *__restrict__ 
         uint32_t n_ctg = 0;
         for (uint32_t l = lane; l < p; l += 64) n_ctg += (val[i + l] >> 32) != 0;
         n_ctg = wave_sum(n_ctg);
+        for (uint64_t l = lane; l < j - i; l += 64) out.seg_len[i + l] = l == 0 ? p : (l < p ? (SEG_LEADER | (uint32_t)l) : 0u);
         if (lane == 0) {
-            out.seg_len[i] = p;
             if (n_ctg) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_ctg);
             atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)p);
         }

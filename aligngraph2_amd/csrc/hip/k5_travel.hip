@@ -33,30 +33,6 @@ namespace pagdev {
 // =================================================================================================
 // graph compaction
 // =================================================================================================
-__global__ void k_head_flags(const uint32_t *__restrict__ key, uint64_t n, uint32_t *__restrict__ flag) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        flag[i] = (i == 0 || key[i - 1] != key[i]) ? 1u : 0u;
-}
-
-__global__ void k_compact_nodes(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval,
-                                const uint32_t *__restrict__ tseg, const uint16_t *__restrict__ tcnt, uint64_t T,
-                                const uint64_t *__restrict__ node_idx, const uint64_t *__restrict__ pos_off, TravGraph G) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t kx = tkey[i];
-        if (i != 0 && tkey[i - 1] == kx) continue;
-        uint64_t n = node_idx[i], p = pos_off[i];
-        G.ncode[n] = kx;
-        G.npos_off[n] = (uint32_t)p;
-        atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
-        uint32_t len = tseg[i];
-        for (uint32_t l = 0; l < len; ++l) {
-            G.vpos[p + l] = tval[i + l];
-            G.vcnt[p + l] = tcnt[i + l];
-            G.vnode[p + l] = (uint32_t)n;
-        }
-    }
-}
-
 // ---- a view that leaves out what no traversal of this handle can examine (trav_view_region, k5_travel_host.hip) --------
 // [lo, hi) pairs, sorted and disjoint
 __device__ __forceinline__ bool iv_contains(const uint32_t *__restrict__ iv, uint32_t n, uint32_t x, uint32_t *which = nullptr) {
@@ -111,56 +87,60 @@ __global__ void k_zone_bands(const uint64_t *__restrict__ tval, uint64_t T, cons
             }
     }
 }
-// per k-mer segment head: which of its leaders the view keeps (keep[] over their slots, zeroed before), head flag of the
-// segments that keep at least one.  A vertex with a contig coordinate is kept by it, one without by its reference coordinate.
-// The interval tables are searched in LDS (a search is ~8 dependent loads per leader: from global memory they were the
-// whole cost of the kernel, 34 ms at BASELINE configs[1]).
+// One thread per tuple slot (the slots say whether they hold a leader and how far behind their segment's head they lie: K3's
+// seg_len layout, pag_device.hpp): keep[i] = the slot holds a vertex the view takes — one with a contig coordinate by that
+// coordinate, one without by its reference coordinate; every vertex when there are no tables —, first[i] = it is the first such
+// slot of its k-mer segment (= the node's flag).  The interval tables are searched in LDS (from global memory the ~8
+// dependent loads per search were the whole cost: 34 ms at BASELINE configs[1] with a thread per segment head).
 constexpr uint32_t PRUNE_LDS = 4096;  // interval ends (u32) the block keeps in LDS
-__global__ void k_prune_flags(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg, uint64_t T,
-                              const uint32_t *__restrict__ civ, uint32_t n_civ, const uint32_t *__restrict__ riv, uint32_t n_riv,
-                              uint32_t *__restrict__ keep, uint32_t *__restrict__ hflag) {
+__global__ void k_view_flags(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg, uint64_t T,
+                             const uint32_t *__restrict__ civ, uint32_t n_civ, const uint32_t *__restrict__ riv, uint32_t n_riv, int whole,
+                             uint32_t *__restrict__ keep, uint32_t *__restrict__ first) {
     __shared__ uint32_t s_iv[PRUNE_LDS];
-    const bool lds = 2u * (n_civ + n_riv) <= PRUNE_LDS;
+    const bool lds = !whole && 2u * (n_civ + n_riv) <= PRUNE_LDS;
     if (lds) {
         for (uint32_t x = threadIdx.x; x < 2u * n_civ; x += blockDim.x) s_iv[x] = civ[x];
         for (uint32_t x = threadIdx.x; x < 2u * n_riv; x += blockDim.x) s_iv[2u * n_civ + x] = riv[x];
         __syncthreads();
     }
     const uint32_t *cv = lds ? s_iv : civ, *rv = lds ? s_iv + 2u * n_civ : riv;
+    auto inside = [&](uint64_t p) {
+        const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
+        return whole || (c != 0u ? iv_contains(cv, n_civ, c) : iv_contains(rv, n_riv, r));
+    };
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t kx = tkey[i];
-        uint32_t kept = 0;
-        if (i == 0 || tkey[i - 1] != kx) {
-            const uint32_t len = tseg[i];
-            for (uint32_t l = 0; l < len; ++l) {
-                const uint64_t p = tval[i + l];
-                const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
-                const bool k = c != 0u ? iv_contains(cv, n_civ, c) : iv_contains(rv, n_riv, r);
-                if (k) keep[i + l] = 1u;
-                kept += k ? 1u : 0u;
+        const uint32_t kx = tkey[i], v = tseg[i];
+        const bool head = i == 0 || tkey[i - 1] != kx;
+        const bool leader = head ? v != 0u : (v & SEG_LEADER) != 0u;
+        bool k = false, f = false;
+        if (leader) {
+            k = inside(tval[i]);
+            if (k) {
+                const uint64_t off = head ? 0u : (v & ~SEG_LEADER);
+                f = true;
+                for (uint64_t j = i - off; j < i && f; ++j) f = !inside(tval[j]);
             }
         }
-        hflag[i] = kept ? 1u : 0u;
+        keep[i] = k ? 1u : 0u;
+        first[i] = f ? 1u : 0u;
     }
 }
-__global__ void k_compact_nodes_kept(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg,
-                                     const uint16_t *__restrict__ tcnt, uint64_t T, const uint32_t *__restrict__ hflag, const uint32_t *__restrict__ keep,
-                                     const uint64_t *__restrict__ node_idx, const uint64_t *__restrict__ pos_off, TravGraph G) {
+// node_idx / pos_off: exclusive prefix sums of first[] / keep[]
+__global__ void k_compact_view(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint16_t *__restrict__ tcnt, uint64_t T,
+                               const uint32_t *__restrict__ first, const uint32_t *__restrict__ keep, const uint64_t *__restrict__ node_idx,
+                               const uint64_t *__restrict__ pos_off, TravGraph G) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (!hflag[i]) continue;
-        const uint32_t kx = tkey[i];
-        const uint64_t n = node_idx[i];
-        uint64_t p = pos_off[i];
-        G.ncode[n] = kx;
-        G.npos_off[n] = (uint32_t)p;
-        atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
-        const uint32_t len = tseg[i];
-        for (uint32_t l = 0; l < len; ++l) {
-            if (!keep[i + l]) continue;
-            G.vpos[p] = tval[i + l];
-            G.vcnt[p] = tcnt[i + l];
-            G.vnode[p] = (uint32_t)n;
-            ++p;
+        if (!keep[i]) continue;
+        const uint32_t f = first[i];
+        const uint64_t n = node_idx[i] + f - 1u, p = pos_off[i];
+        G.vpos[p] = tval[i];
+        G.vcnt[p] = tcnt[i];
+        G.vnode[p] = (uint32_t)n;
+        if (f) {
+            const uint32_t kx = tkey[i];
+            G.ncode[n] = kx;
+            G.npos_off[n] = (uint32_t)p;
+            atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
         }
     }
 }
@@ -2712,14 +2692,16 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     }
     PAG_HIP_TRY(hipMemsetAsync(G.bitmap, 0, n_words * 8, s));
     int rc;
+    if (T) {
+        k_view_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, T, view ? view->civ : nullptr, view ? view->n_civ : 0u, view ? view->riv : nullptr,
+                                                             view ? view->n_riv : 0u, view ? 0 : 1, keep, flags);
+        if ((rc = scan_u32_to_u64(flags, sc1, T, totals, scan_tmp, s))) return rc;
+        if ((rc = scan_u32_to_u64(keep, sc2, T, totals + 1, scan_tmp, s))) return rc;
+        k_compact_view<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tcnt, T, flags, keep, sc1, sc2, G);
+    }
     if (view) {
         uint64_t h[2] = {0, 0};
         if (T) {
-            PAG_HIP_TRY(hipMemsetAsync(keep, 0, T * 4, s));
-            k_prune_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, T, view->civ, view->n_civ, view->riv, view->n_riv, keep, flags);
-            if ((rc = scan_u32_to_u64(flags, sc1, T, totals, scan_tmp, s))) return rc;
-            if ((rc = scan_u32_to_u64(keep, sc2, T, totals + 1, scan_tmp, s))) return rc;
-            k_compact_nodes_kept<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, tcnt, T, flags, keep, sc1, sc2, G);
             PAG_HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
             PAG_HIP_TRY(hipStreamSynchronize(s));
         }
@@ -2731,11 +2713,6 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
         n_pos = h[1];
         G.n_nodes = n_nodes;
         G.n_pos = n_pos;
-    } else if (T) {
-        k_head_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, T, flags);
-        if ((rc = scan_u32_to_u64(flags, sc1, T, nullptr, scan_tmp, s))) return rc;
-        if ((rc = scan_u32_to_u64(tseg, sc2, T, nullptr, scan_tmp, s))) return rc;
-        k_compact_nodes<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, tcnt, T, sc1, sc2, G);
     }
     uint32_t np32 = (uint32_t)n_pos;
     PAG_HIP_TRY(hipMemcpyAsync(G.npos_off + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));

@@ -75,7 +75,7 @@ __global__ void sel_write_vertices(const uint32_t *__restrict__ tkey, const uint
             okey[o] = kx;
             oval[o] = tval[i + l];
             ocnt[o] = tcnt[i + l];
-            oseg[o] = 0;
+            oseg[o] = SEG_LEADER | kept;  // (a leader slot `kept` behind the head of the selected segment: the layout of K3, pag_device.hpp)
             ++kept;
         }
         if (kept) oseg[first] = kept;

@@ -146,8 +146,9 @@ int launch_cov_filter(const pag_aln *aln, uint64_t n_aln, const pag_ref *refs_de
 size_t cov_tmp_bytes(const pag_ref *refs_host, uint64_t n_refs);
 
 // cluster + sort positions inside each k-mer segment of the sorted tuple stream (in place in `val`)
+constexpr uint32_t SEG_LEADER = 0x80000000u;
 struct ClusterOut {
-    uint32_t *seg_len;  // [n] leaders of the segment starting at i (0 when i is not a segment head)
+    uint32_t *seg_len;  // [n] at a segment head: its leaders (slots i .. i + seg_len - 1); at the other leader slots SEG_LEADER | offset behind the head; else 0
     uint16_t *cnt;      // [n] abundance of the leader stored at i
     uint64_t *counters; // device: [0] leaders with ctg != 0, [1] all leaders, [2] segments
 };

@@ -39,11 +39,35 @@ def _used(torch, device):
     return int(total - free)
 
 
+_PINNED = os.environ.get("PAG_RANK_SERIAL_PINNED") == "1"
+
+
 def _to_host(torch, t):
-    """a device tensor into pinned host memory"""
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    h.copy_(t, non_blocking=True)
+    """a device tensor into host memory.  Pageable by default: torch's pinned allocator rounds every block up to a power of two
+    and keeps it cached, which at BASELINE configs[2]'s 265 GB of spills is the difference between fitting the GPU box's
+    300 GiB container and being killed by it (PAG_RANK_SERIAL_PINNED=1: pinned, faster copies)."""
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=_PINNED)
+    h.copy_(t, non_blocking=_PINNED)
     return h
+
+
+def _host_guard(limit_frac=0.8):
+    """raises before the container's memory limit is reached (a run that is killed by it takes the GPU box with it)"""
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read())
+    except (OSError, ValueError):
+        return 0
+    if lim != "max" and cur > limit_frac * int(lim):
+        raise MemoryError(f"rank_serial: {cur / 1e9:.0f} GB of host memory in use, the container's limit is {int(lim) / 1e9:.0f} GB: the block's "
+                          "spills do not fit this host")
+    return cur
+
+
+def _drop_host_cache(torch):
+    fn = getattr(torch._C, "_host_emptyCache", None)
+    if fn is not None:
+        fn()
 
 
 def digest_dir(path):
@@ -127,7 +151,15 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
             raise RuntimeError(f"rank {r}: pag_shard_take failed ({rc}): {hip.pag_last_error().decode()}")
         hip.pag_destroy(C.c_void_p(g))
         t1 = time.perf_counter()
-        spilled.append(tuple(_to_host(torch, t) for t in (tk, tv, ek, ev)))
+        # what goes to owner o waits as its own host arrays (freed when o has taken them): [o] -> (tkey, tval, ekey, eval)
+        per_dst = []
+        for o in range(N):
+            t_off, t_n = int(counts[r, :o, 0:2].sum()), int(counts[r, o, 0:2].sum())
+            e_off, e_n = int(counts[r, :o, 2:4].sum()), int(counts[r, o, 2:4].sum())
+            per_dst.append((_to_host(torch, tk[t_off:t_off + t_n]), _to_host(torch, tv[t_off:t_off + t_n]),
+                            _to_host(torch, ek[e_off:e_off + e_n]), _to_host(torch, ev[e_off:e_off + e_n])))
+        spilled.append(per_dst)
+        res["host_bytes_peak"] = max(res.get("host_bytes_peak", 0), _host_guard())
         sync()
         del tk, tv, ek, ev
         torch.cuda.empty_cache()
@@ -146,13 +178,12 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         val = torch.empty(n, dtype=torch.int64, device=device)
         d1, d2 = 0, n1
         for r in range(N):
-            off = int(counts[r, :o, q0:q0 + 2].sum())
             a, b = int(counts[r, o, q0]), int(counts[r, o, q0 + 1])
-            hk, hv = spilled[r][2 * which], spilled[r][2 * which + 1]
-            key[d1:d1 + a].copy_(hk[off:off + a], non_blocking=True)
-            val[d1:d1 + a].copy_(hv[off:off + a], non_blocking=True)
-            key[d2:d2 + b].copy_(hk[off + a:off + a + b], non_blocking=True)
-            val[d2:d2 + b].copy_(hv[off + a:off + a + b], non_blocking=True)
+            hk, hv = spilled[r][o][2 * which], spilled[r][o][2 * which + 1]
+            key[d1:d1 + a].copy_(hk[:a], non_blocking=True)
+            val[d1:d1 + a].copy_(hv[:a], non_blocking=True)
+            key[d2:d2 + b].copy_(hk[a:a + b], non_blocking=True)
+            val[d2:d2 + b].copy_(hv[a:a + b], non_blocking=True)
             d1 += a
             d2 += b
         return key, val, n1
@@ -166,6 +197,8 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         tk, tv, t1n = received(o, 0)
         ek, ev, e1n = received(o, 1)
         sync()
+        for r in range(N):
+            spilled[r][o] = None  # (taken)
         t1 = time.perf_counter()
         st = sb.build((tk, tv), t1n, (ek, ev), e1n, eps)
         sync()
@@ -183,6 +216,7 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
             sync()
             peak_sel = max(peak_sel, _used(torch, device) - base)
             selected[o][d] = ({nm: _to_host(torch, arrs[nm]) for nm in _NAMES}, sst)
+            res["host_bytes_peak"] = max(res.get("host_bytes_peak", 0), _host_guard())
             sync()
             sel_bytes += sum(arrs[nm].numel() * arrs[nm].element_size() for nm in _NAMES) if d != o else 0
             del arrs
@@ -196,6 +230,7 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         say(f"owner {o}: {info['owner_tuples']} + {info['owner_edges']} records built in {t2 - t1:.1f} s, {info['bytes_owner_build'] / 1e9:.1f} GB; "
             f"{st.n_pos} vertices; selections {time.perf_counter() - t2:.1f} s")
     del spilled
+    _drop_host_cache(torch)
     # the block's count lines = sums over the owners
     tot_counts = [0] * 6
     n_pos_total = 0
@@ -232,6 +267,8 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         info["bytes_region_imported"] = _used(torch, device) - base
         info["wire_in_region_bytes"] = int(sum(sum(selected[o][d][0][nm].numel() * selected[o][d][0][nm].element_size() for nm in _NAMES)
                                                for o in range(N) if o != d))
+        for o in range(N):
+            selected[o][d] = None  # (imported)
         if list(tot.counts()) != tot_counts:
             raise RuntimeError(f"rank {d}: count lines {list(tot.counts())} differ from the owners' sums {tot_counts}")
         nn, npos, ne = C.c_uint64(), C.c_uint64(), C.c_uint64()
@@ -265,6 +302,7 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         say(f"rank {d}: holds {info['held_fraction']:.3f} of the vertices ({info['bytes_region_imported'] / 1e9:.1f} GB imported), traversal peak "
             f"{info['bytes_traversal_peak'] / 1e9:.1f} GB, {len(deal[d])} contigs walked in {info['s_travel']:.1f} s")
     del selected
+    _drop_host_cache(torch)
 
     # ---- rank 0's part: the chains of the whole block from the gathered travel sequences ---------------------------------
     import shutil
@@ -286,6 +324,7 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         raise RuntimeError(f"pagh_assemble_paths failed ({rc}): {host.pagh_last_error().decode()}")
     res["s_assemble"] = time.perf_counter() - t0
     res["outputs_sha256"], res["outputs_bytes"] = digest_dir(out_dir)
+    res["host_bytes_peak"] = max(res.get("host_bytes_peak", 0), _host_guard())
     res.update(path_nodes=int(ts.n_path_nodes), path_bases=int(ts.n_path_bases), path_checksum=f"{ts.path_checksum:016x}",
                chains=int(ts.n_chains_emitted), s_total=time.perf_counter() - t_all)
     return res

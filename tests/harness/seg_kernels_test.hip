@@ -88,6 +88,7 @@ int main(int argc, char **argv) {
         }
         std::sort(lead.begin(), lead.end());
         xlen[i] = (uint32_t)lead.size();
+        for (size_t l = 1; l < lead.size(); ++l) xlen[i + l] = pagdev::SEG_LEADER | (uint32_t)l;  // (the other leader slots are marked)
         for (size_t l = 0; l < lead.size(); ++l) {
             xval[i + l] = lead[l].first;
             xcnt[i + l] = lead[l].second;
@@ -140,7 +141,7 @@ int main(int argc, char **argv) {
                 ++bad;
                 continue;
             }
-            for (uint32_t l = 0; l < xlen[i]; ++l)
+            for (uint32_t l = 0; !(xlen[i] & pagdev::SEG_LEADER) && l < xlen[i]; ++l)
                 if (v[i + l] != xval[i + l] || c[i + l] != xcnt[i + l]) {
                     printf("cluster seg %llu slot %u: (%llx,%u) want (%llx,%u)\n", (unsigned long long)i, l,
                            (unsigned long long)v[i + l], c[i + l], (unsigned long long)xval[i + l], xcnt[i + l]);
