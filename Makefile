@@ -95,7 +95,7 @@ tests/harness/bin/seg_kernels_test: tests/harness/seg_kernels_test.hip $(HIP_DIR
 	@mkdir -p tests/harness/bin
 	$(HIPCC) $(HIPFLAGS) -fno-PIC -o $@ $<
 
-# timing + correctness aid for the radix sort (needs a GPU to run); -DSORT_X=1|2|4 builds the timing experiments
+# timing + correctness aid for the radix sort (needs a GPU to run)
 tests/harness/bin/sort_bench: tests/harness/sort_bench.hip $(HIP_DIR)/k2_sort.hip $(HIP_DIR)/util.hip $(HIP_HDRS)
 	@mkdir -p tests/harness/bin
 	$(HIPCC) $(HIPFLAGS) -fno-PIC -o $@ $<

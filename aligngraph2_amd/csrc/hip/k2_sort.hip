@@ -29,9 +29,6 @@ constexpr int SW = ST / 64;       // waves per block
 constexpr int SROUNDS = SORT_ROUNDS;  // records per thread
 constexpr int STILE = ST * SROUNDS;
 constexpr int SMAXR = 256;        // max radix (8 bits)
-#ifndef SORT_X
-#define SORT_X 0  // timing experiments of tests/harness/sort_bench.hip (results wrong when non-zero)
-#endif
 
 // Digit histogram of every tile: the keys are read once, 16 bytes per lane, by persistent blocks of four waves; every wave
 // counts into its own LDS table (a quarter of the collisions), the tables are summed when the tile's column of
@@ -170,13 +167,12 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
 
     const uint32_t last_count = (uint32_t)(n - (uint64_t)(n_tiles - 1u) * STILE);  // records of the last tile (1 .. STILE)
     auto write_out = [&](const ScatterStage &B, uint32_t count) {
-        if (count == (uint32_t)STILE && !(SORT_X & 8)) {
+        if (count == (uint32_t)STILE) {
 #pragma unroll
             for (int r = 0; r < SROUNDS; ++r) {
                 const uint32_t p = (uint32_t)r * ST + threadIdx.x;
                 const uint32_t kx = B.skey[p];
                 const uint64_t dst = B.goff[(kx >> shift) & rmask] + p;
-                if ((SORT_X & 3) && kx != 0x12345678u) continue;
                 okeys[dst] = kx;
                 ovals[dst] = B.sval[p];
             }
@@ -265,7 +261,6 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
 #pragma unroll
         for (int r = 0; r < SROUNDS; ++r) {
             const uint64_t i = wave_base + (uint64_t)r * 64 + lane;
-            if ((SORT_X & 2) && key[r] != 0x12345678u) continue;
             if (i < n) {
                 const uint32_t d = (key[r] >> shift) & rmask;
                 const uint32_t p = L.dstart[d] + L.wcnt[w][d] + rk[r];

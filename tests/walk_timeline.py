@@ -4,7 +4,7 @@
 import re,sys
 import numpy as np
 txt=open(sys.argv[1]).read().splitlines()
-idx=[i for i,l in enumerate(txt) if 'walker launched' in l][-1]
+idx=[i for i,l in enumerate(txt) if 'walker waves launched' in l][-1]
 lines=txt[idx:]
 W=int(sys.argv[2]) if len(sys.argv)>2 else 256
 jobs=[]
