@@ -2355,7 +2355,14 @@ __global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravP
             const uint32_t slot = (uint32_t)ring * cap + idx % cap;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // buffers of the job were prepared by other kernels / copies
             const uint64_t tb = wall_clock64();
-            walk_job(L, G, jobs[slot].C, jobs[slot].J, &outs[slot], k);
+            if (__hip_atomic_load(&jobs[slot].J.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & TRAV_MODE_CANCELLED) {
+                if (lane == 0) {  // (a job of a round that is over, k5_travel_host.hip: nobody reads its result)
+                    TravJobOut z{};
+                    outs[slot] = z;
+                }
+            } else {
+                walk_job(L, G, jobs[slot].C, jobs[slot].J, &outs[slot], k);
+            }
             if (lane == 0) {
                 outs[slot].t_begin = tb;
                 outs[slot].t_end = wall_clock64();

@@ -891,8 +891,18 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         int idx = 0;   // chain / segment number
         uint64_t init_len = 0;
         bool live = false;
+        uint32_t round = 0;  // the contig's round the job was posted in (see is_orphan)
     };
     std::vector<JobRef> jref(NR * (size_t)QCAP);
+    // A round of a contig is decided when all its chains are final.  Segment jobs of the round that are still waiting or
+    // walking then are ORPHANS: nobody will look at their paths (a chain that dead-ends at a fifth of its contig leaves four
+    // fifths of the round's segments behind — at BASELINE configs[1] the next round of such a contig used to start when the
+    // last of them had been walked, ~85 ms into the walks, and its own walk was the tail everything waited for).  An orphan
+    // that no wave has taken yet is cancelled (the wave that takes it reports it done at once); one that is walking finishes
+    // into its own buffers — a round's buffers come from the walk arena, which is never handed out twice within one
+    // pag_travel; a round that had to fall back on the per-contig slots waits for its jobs as before (RoundState::slot_bufs).
+    uint64_t n_orphans = 0;
+    const bool orphaning = !(std::getenv("PAG_WALK_ORPHANS") && std::atoi(std::getenv("PAG_WALK_ORPHANS")) == 0);  // (0: every round waits for all its jobs)
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
     std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];
     for (auto &x : n_leap_refused) x = 0;
@@ -956,9 +966,16 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         if (!backlog[ring].empty() || !place_job(ring, P, jr2)) backlog[ring].push_back(Backlogged{P, jr2});
         return PAG_OK;
     };
+    auto is_orphan = [&](const JobRef &jr) { return jr.kind == 1 && (jr.round != RS[jr.ctg].round || !RS[jr.ctg].active); };
     auto flush_backlog = [&]() {
         for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
-            while (!backlog[ring].empty() && place_job(ring, backlog[ring].front().P, backlog[ring].front().jr)) {
+            while (!backlog[ring].empty()) {
+                if (is_orphan(backlog[ring].front().jr)) {  // (never entered a ring: gone)
+                    backlog[ring].pop_front();
+                    n_live -= 1;
+                    continue;
+                }
+                if (!place_job(ring, backlog[ring].front().P, backlog[ring].front().jr)) break;
                 backlog[ring].pop_front();
                 need_publish = true;
             }
@@ -1008,6 +1025,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     g->walk_arena_used += (need[q] + 16 + 255) & ~(size_t)255;
                 }
             } else {
+                R.slot_bufs = true;  // (per-contig slots are handed out again by the next batch of the group)
                 for (size_t q = 0; q < 9; ++q)
                     if ((r = bufs[q]->alloc(need[q]))) return r;
             }
@@ -1072,6 +1090,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             jr2.idx = pl.idx;
             jr2.init_len = J.init_len;
             jr2.live = true;
+            jr2.round = R.round;
             if (pl.kind == 0) {
                 if (pl.mode & TRAV_MODE_RESUME) ++n_resume_jobs;
             } else {
@@ -1130,6 +1149,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             R.n_spec = 0;
             R.zone_end = 0;
             R.live_jobs = 0;
+            R.slot_bufs = false;
             R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
             rounds = std::max<uint64_t>(rounds, R.round);
             const uint64_t split = (uint64_t)(cs.len * startSplit);
@@ -1586,7 +1606,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 Got &G2 = got[x];
                 G2.jn = fin[x];
                 G2.from = std::min<uint64_t>(jref[slot].init_len, o.seq_len);
-                G2.len = o.seq_len - G2.from;
+                G2.len = is_orphan(jref[slot]) ? 0 : o.seq_len - G2.from;  // (nobody reads an orphan's path)
                 G2.off = tot;
                 tot += trav_pack_words(G2.len, J.seq_x != nullptr);
                 max_len = std::max(max_len, G2.len);
@@ -1654,6 +1674,11 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             const TravJobOut o = houts[slot];
             const uint32_t i = jr.ctg;
             RoundState &R = RS[i];
+            if (is_orphan(jr)) {  // a segment job of a round that is over: its slot is free again, nothing else
+                jr.live = false;
+                n_live -= 1;
+                continue;
+            }
             jr.live = false;
             n_live -= 1;
             R.live_jobs -= 1;
@@ -1776,8 +1801,21 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             if (!R.active) continue;
             bool all = true;
             for (auto &ch : R.chains) all = all && ch.final;
-            // (segment jobs that are still walking use buffers the next round takes over: the round waits for them)
-            if (all && R.live_jobs == 0) batch.push_back(i);
+            // (segment jobs still waiting or walking become orphans — unless the round's buffers are per-contig slots, which the
+            // next round takes over: such a round waits for them)
+            if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs))) {
+                if (R.live_jobs) {
+                    n_orphans += R.live_jobs;
+                    for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)  // those no wave has taken yet never start
+                        for (uint32_t q = 0; q < QCAP; ++q) {
+                            JobRef &jr = jref[ring * QCAP + q];
+                            if (jr.live && jr.ctg == i && jr.kind == 1 && jr.round == R.round)
+                                __atomic_fetch_or(&hjobs[ring * QCAP + q].J.mode, (uint32_t)TRAV_MODE_CANCELLED, __ATOMIC_RELEASE);
+                        }
+                    R.live_jobs = 0;
+                }
+                batch.push_back(i);
+            }
         }
         flush_backlog();
         if (batch.empty()) {
@@ -1822,6 +1860,14 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     P.off = tot;
                     P.len = R.chains[(size_t)P.chosen].len;
                     tot += P.len;
+                }
+                if (wdebug && P.chosen >= 0) {
+                    const Chain &ch = R.chains[(size_t)P.chosen];
+                    const uint32_t last_ctg = ch.len == 0 ? 0u : ch.parts.back().pc[ch.parts.back().n - 1];
+                    std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %llu over: chain %d of %zu chosen, %llu vertices, size %llu, from offset %lld, ends at offset %lld (strand %u), mx %u%s\n",
+                                 now_ms() - t_begin, i, (unsigned long long)R.round, P.chosen, R.chains.size(), (unsigned long long)ch.len, (unsigned long long)ch.size,
+                                 (long long)cs.seeds[(size_t)P.chosen].ctg - (long long)cs.ctgLeft, last_ctg ? (long long)last_ctg - (long long)cs.ctgLeft : -1ll, cs.len,
+                                 ch.mx_all >= cs.ctgLeft ? ch.mx_all - cs.ctgLeft : 0u, P.leap ? ", leap" : "");
                 }
             }
             // the chosen walks go to the device through the pinned staging area (vertex ids only: the commit kernels need
@@ -2173,6 +2219,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     lap("epilogue");
     if (timing) {
         std::fprintf(stderr, "[timing] walks redone without speculation: %u\n", respeculated);
+        std::fprintf(stderr, "[timing] segment jobs left behind by rounds that were decided without them: %llu\n", (unsigned long long)n_orphans);
         std::fprintf(stderr, "[timing] pag_travel laps:");
         for (auto &l : laps) std::fprintf(stderr, " %s %.1f ms;", l.first, l.second);
         std::fprintf(stderr, "\n");

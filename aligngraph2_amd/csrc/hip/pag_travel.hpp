@@ -106,7 +106,8 @@ struct TravJob {
     // no contig coordinate (all ones: none); records examined by probes of earlier iterations that are still walking count.
     uint64_t *seq_x;
 };
-enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2, TRAV_MODE_LEAP = 4, TRAV_MODE_UNTIL_LEAP = 8 };  // (8: with RESUME, see k_walk's stop rules)
+enum { TRAV_MODE_SPEC = 1, TRAV_MODE_RESUME = 2, TRAV_MODE_LEAP = 4, TRAV_MODE_UNTIL_LEAP = 8,
+       TRAV_MODE_CANCELLED = 16 };  // (16: set by the host on a job nobody waits for any more: the wave that takes it reports it done at once)  // (8: with RESUME, see k_walk's stop rules)
 
 struct TravJobOut {
     uint64_t seq_len, seq_size;

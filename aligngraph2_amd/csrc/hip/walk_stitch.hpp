@@ -113,6 +113,7 @@ struct RoundState {
     uint32_t zone_end = 0;  // coordinate from which the walk is no longer cut (0: no segments this round)
     uint32_t live_jobs = 0;
     uint64_t has_size = 0;
+    bool slot_bufs = false;  // some job of the round has its buffers in per-contig slots (not in the walk arena)
 };
 
 // T grows by a job's new vertices or by an adopted stretch of a segment
