@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,9 +66,18 @@ void AlnDb::sortByScore() {
 // is parsed by the strict fast path (ten whitespace-separated fields, the last six plain decimal numbers) or, when it
 // does not fit that, by the very stream extraction of the sequential loop, and the column classes are written
 // to their final place (offsets = running sum of the word counts in file order).
+namespace {
+ColumnClassifier g_classifier = nullptr;
+double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+void setColumnClassifier(ColumnClassifier f) { g_classifier = f; }
+
 bool AlnDb::loadMecatParallel(const std::string &path) {
+    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    const double t0 = nowS();
     FileLines fl;
     if (!fl.load(path)) return false;
+    const double t1 = nowS();
     const std::size_t nRec = fl.size() / 3;
     recs_.assign(nRec, AlnRecord{});
     std::vector<std::uint64_t> off(nRec + 1, 0);
@@ -77,6 +87,27 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         off[r + 1] = off[r] + (n + 15) / 16;
     }
     diff_.assign(off[nRec], 0);
+    // the bulk half on the device, when a classifier is installed: the rows go up as they lie in the file
+    bool classified = false;
+    std::vector<std::uint32_t> devEmit, devRadv;
+    if (g_classifier && nRec) {
+        std::vector<std::uint64_t> qOff(nRec), rOff(nRec);
+        std::vector<std::uint32_t> qLen(nRec), rLen(nRec);
+        bool fits = true;
+        for (std::size_t r = 0; r < nRec; ++r) {
+            qOff[r] = fl.offset(3 * r + 1);
+            rOff[r] = fl.offset(3 * r + 2);
+            qLen[r] = static_cast<std::uint32_t>(fl.length(3 * r + 1));
+            fits = fits && fl.length(3 * r + 2) <= 0xFFFFFFFFull;
+            rLen[r] = static_cast<std::uint32_t>(fl.length(3 * r + 2));
+        }
+        devEmit.assign(nRec, 0);
+        devRadv.assign(nRec, 0);
+        classified = fits && g_classifier(fl.base(), fl.bytes(), qOff.data(), qLen.data(), rOff.data(), rLen.data(), off.data(), nRec, diff_.data(),
+                                          diff_.size(), devEmit.data(), devRadv.data());
+        if (!classified) std::fill(diff_.begin(), diff_.end(), 0u);
+    }
+    const double t2 = nowS();
     parallelFor(nRec, 64, [&](std::size_t r) {
         AlnRecord &rec = recs_[r];
         {   // header
@@ -136,6 +167,11 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         const std::size_t n = fl.length(3 * r + 1), rn = fl.length(3 * r + 2);
         rec.diffOff = off[r];
         rec.nCols = static_cast<std::uint32_t>(n);
+        if (classified) {  // (done by the device)
+            rec.nEmit = devEmit[r];
+            rec.nRadv = devRadv[r];
+            return;
+        }
         std::uint32_t *w = diff_.data() + off[r];
         std::uint32_t nEmit = 0, nRadv = 0;
         for (std::size_t i = 0; i < n; ++i) {
@@ -153,6 +189,10 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         rec.nEmit = nEmit;
         rec.nRadv = nRadv;
     });
+    if (timing)
+        std::fprintf(stderr, "[timing]   ALN %s: %zu records, lines found %.3f s, %s %.3f s, headers%s %.3f s\n", path.c_str(), nRec, t1 - t0,
+                     g_classifier ? (classified ? "columns on the device" : "device classifier declined") : "offsets", t2 - t1,
+                     classified ? "" : " + columns on the host", nowS() - t2);
     return true;
 }
 

@@ -20,6 +20,14 @@ struct AlnRecord {
     std::uint32_t nRadv = 0;  // columns that advance the target (classes 00, 11, 01)
 };
 
+// The bulk half of an ALN parse — the column classes of every record's two rows (parseDiff) and the two counts per record — as
+// a hook: the HIP backend installs pag_classify_columns_host (k_ingest.hip) when PAGRAPH_DEVICE_INGEST=1; without a hook, or
+// when it returns false, the host loop below does the work.  Arguments as pag_classify_columns_host takes them.
+using ColumnClassifier = bool (*)(const char *text, std::uint64_t textBytes, const std::uint64_t *qOff, const std::uint32_t *qLen,
+                                  const std::uint64_t *rOff, const std::uint32_t *rLen, const std::uint64_t *diffOff, std::uint64_t nRecs,
+                                  std::uint32_t *diff, std::uint64_t nDiffWords, std::uint32_t *nEmit, std::uint32_t *nRadv);
+void setColumnClassifier(ColumnClassifier f);
+
 class AlnDb {
 public:
     enum class Flavor {

@@ -89,6 +89,9 @@ public:
         return true;
     }
     std::size_t size() const { return start_.size(); }
+    const char *base() const { return base_; }       // the whole text
+    std::size_t bytes() const { return n_; }
+    std::size_t offset(std::size_t i) const { return start_[i]; }  // of line i in the text
     const char *data(std::size_t i) const { return base_ + start_[i]; }
     std::size_t length(std::size_t i) const {
         const std::size_t end = i + 1 < start_.size() ? start_[i + 1] - 1 : (endsWithNewline_ ? n_ - 1 : n_);

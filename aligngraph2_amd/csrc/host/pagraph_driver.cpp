@@ -239,13 +239,18 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         // The text files of the NEXT block this process will handle are parsed while the current block is on the device
         // (the parsers' threads are idle then; PAGRAPH_PREFETCH=0 parses every block when its turn comes, as the
         // reference does, and holds one block's inputs in host memory instead of two).
+        // the block's three text files (pagraph.cpp:186-199 reads them one after the other; they are independent): parsed side by
+        // side, each by its own pool of threads
         struct BlockFiles {
             SeqDb reads;
             AlnDb readToCtg, readToRef;
-            BlockFiles(const std::string &pre, const BlockConfig &cfg)
-                : reads(pre + "/" + cfg.readPath),
-                  readToCtg(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat),
-                  readToRef(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat) {}
+            BlockFiles(const std::string &pre, const BlockConfig &cfg) {
+                auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
+                auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat); });
+                reads = SeqDb(pre + "/" + cfg.readPath);
+                readToCtg = ctgAln.get();
+                readToRef = refAln.get();
+            }
         };
         const bool prefetch = !(std::getenv("PAGRAPH_PREFETCH") && std::atoi(std::getenv("PAGRAPH_PREFETCH")) == 0);
         auto mine = [&](std::size_t no) { return !blocksEnv || onlyBlocks.count(no) != 0; };
@@ -285,9 +290,10 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             std::cout << "Done! aln number=" << readToCtg.size() << std::endl;
             std::cout << "Done! aln number=" << readToRef.size() << std::endl;
 
+            lap("load block inputs");
             reserver.join();
             if (reserveError) std::rethrow_exception(reserveError);
-            lap("load block inputs");
+            lap("device memory of the walks reserved (wait)");
             if (prefetch) {
                 std::size_t nextNo = blockNo + 1;
                 while (nextNo < configs.size() && !mine(nextNo)) ++nextNo;

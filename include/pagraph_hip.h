@@ -399,6 +399,29 @@ int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases);
  * reads: pag_seqs in host memory (reads_on_device = 0) or device memory (1; every read 4-byte aligned and followed by
  * at least 8 readable bytes).  bitmap: 4^k / 8 bytes (at least 4), host or device (bitmap_on_device).  k = 1..16
  * (the reference's own table size overflows at k = 16, quirk Q13; here k = 16 means 2^32 codes). */
+/* ---- a block's TEXT to the packed forms the build takes, on the device (first half) --------------------
+ * text: the bytes of a FASTA / FASTQ / ALN file as they lie in the file, in device memory (text_on_device = 1) or in host
+ * memory (0: streamed to the device through pinned staging buffers).  The caller has found the lines (and, for ALN
+ * records, parsed the header fields): these calls do the bulk work.
+ * pag_pack_text_seqs: sequence i = seq_len[i] characters at text + seq_off[i] -> 2-bit packed at packed_dev + byte_off[i]
+ * (byte_off a multiple of 4; ceil(len / 4) bytes rounded up to a multiple of 4 are written, unused bits zero) exactly as
+ * CompressedSeq does (CompressedSeq.cpp:8-38): 4 bases per byte, base i at bits 2 * (i & 3), C/c = 1, G/g = 2, T/t = 3,
+ * every other character 0.
+ * pag_classify_columns: record i = a query row (q_len[i] characters at q_off[i]) over a reference row (r_len / r_off) ->
+ * parseDiff (ParseAlignTools.cpp:8-26) as 2 bits per column of the query row, 16 columns per u32, at diff_dev +
+ * diff_off[i] (ceil(q_len / 16) words): 1 = gap in the query row, 2 = gap in the reference row, 3 = the characters differ
+ * (a reference row that is shorter reads as NUL there), 0 = equal; n_emit_dev[i] / n_radv_dev[i] = columns of class != 1 /
+ * != 2.  The offset arrays are host memory; packed_dev, diff_dev, n_emit_dev, n_radv_dev device memory. */
+int pag_pack_text_seqs(const char *text, int text_on_device, uint64_t text_bytes, const uint64_t *seq_off, const uint32_t *seq_len,
+                       uint64_t n_seqs, const uint64_t *byte_off, uint8_t *packed_dev, uint64_t packed_bytes, int device);
+int pag_classify_columns(const char *text, int text_on_device, uint64_t text_bytes, const uint64_t *q_off, const uint32_t *q_len,
+                         const uint64_t *r_off, const uint32_t *r_len, const uint64_t *diff_off, uint64_t n_recs, uint32_t *diff_dev,
+                         uint64_t n_diff_words, uint32_t *n_emit_dev, uint32_t *n_radv_dev, int device);
+/* ... text and results in HOST memory (device buffers are the call's own) */
+int pag_classify_columns_host(const char *text, uint64_t text_bytes, const uint64_t *q_off, const uint32_t *q_len, const uint64_t *r_off,
+                              const uint32_t *r_len, const uint64_t *diff_off, uint64_t n_recs, uint32_t *diff_host, uint64_t n_diff_words,
+                              uint32_t *n_emit_host, uint32_t *n_radv_host, int device);
+
 typedef struct pag_kmer_count_result {
     uint64_t min_abundance;
     uint64_t n_solid;

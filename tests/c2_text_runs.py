@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--compare", action="store_true", help="reference -t 16 under the serialising shim; byte-compare all output files")
     ap.add_argument("--compare-with", default=None, help="a JSON written by an earlier --compare run of the same workload: the drop-in's output files are "
                     "held against the reference's per-file SHA-256 kept there (no reference run)")
+    ap.add_argument("--keep-text", action="store_true", help="leave the text files in /dev/shm/c2_text (for runs by hand)")
     ap.add_argument("--blocks", type=int, default=1, help="> 1: config.txt written that many times over (every block reads the same files); "
                     "the drop-in alone, block after block / next block parsed ahead / host half beside the next block / packed sidecars")
     args = ap.parse_args()
@@ -158,7 +159,8 @@ def main():
         print("compare:", rec["compare"], flush=True)
         shutil.rmtree(a, ignore_errors=True)
         shutil.rmtree(b, ignore_errors=True)
-    shutil.rmtree(d, ignore_errors=True)
+    if not args.keep_text:
+        shutil.rmtree(d, ignore_errors=True)
     json.dump(rec, open(args.out, "w"), indent=1)
 
 

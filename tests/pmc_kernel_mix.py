@@ -20,7 +20,7 @@ PASSES = [["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"], ["SQ
 def one_pass(counters, tmp):
     shutil.rmtree(tmp, ignore_errors=True)
     r = subprocess.run(["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "c", "--", sys.executable,
-                        os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                        os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-file-to-file"], capture_output=True, text=True,
                        env=dict(os.environ, PAG_WALK_IDLE_S="5"), timeout=900)
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(tmp, "**", "c_counter_collection.csv"), recursive=True):

@@ -21,7 +21,7 @@ def one_pass(counter, tmp):
     shutil.rmtree(tmp, ignore_errors=True)
     env = dict(os.environ, PAG_WALK_IDLE_S="5")
     subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "c", "--",
-                    sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                    sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-file-to-file"],
                    capture_output=True, text=True, env=env, timeout=900)
     acc = collections.defaultdict(lambda: [0.0, 0])
     dur = collections.defaultdict(lambda: [0.0, 0])
