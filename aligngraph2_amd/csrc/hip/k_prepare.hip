@@ -22,6 +22,8 @@
 // which the device does; longer lists go through introsort, whose tie order only the same library reproduces), and the sort
 // of the handful of contig -> reference lists.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstring>
 #include <vector>
 
@@ -423,27 +425,38 @@ int prepare_read_db(pag_graph *g, int pass, const pag_raw_db &db, const uint32_t
     PAG_HIP_TRY(hipMemcpyAsync(&n_listed, b_off.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, s));
     PAG_HIP_TRY(hipStreamSynchronize(s));
     if (n_long) {
-        // lists of more than 16 alignments: std::sort itself (introsort: its order among equal scores is the library's).
-        // The list arrives in database order (the device sort by query is stable), exactly mergeAlignInfHelper's input.
+        // lists of more than 16 alignments: std::sort itself (introsort: its order among equal scores is the library's — the
+        // host's libstdc++ has to be the one the reference was built with).  A list arrives in database order
+        // (the device sort by query is stable), exactly mergeAlignInfHelper's input.  All of them in ONE round trip: the
+        // offset table and the id array come down once, the lists are sorted by a pool of host threads, the id array goes
+        // back once (a repeat-rich read set has tens of thousands of such lists: three blocking copies per list, as until
+        // round 4, would have cost seconds).
         std::vector<uint32_t> qs(n_long);
         PAG_HIP_TRY(hipMemcpy(qs.data(), d_nlong + 1, (size_t)n_long * 4, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> offs((size_t)nq + 1), ids((size_t)n_listed);
+        PAG_HIP_TRY(hipMemcpy(offs.data(), b_off.as<uint64_t>(), ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost));
+        if (n_listed) PAG_HIP_TRY(hipMemcpy(ids.data(), val, (size_t)n_listed * 8, hipMemcpyDeviceToHost));
         struct ListEntry {
             uint64_t score, rec;
         };
-        std::vector<ListEntry> list;
-        std::vector<uint64_t> ids;
-        for (uint32_t q : qs) {
-            uint64_t ab[2];
-            PAG_HIP_TRY(hipMemcpy(ab, b_off.as<uint64_t>() + q, 16, hipMemcpyDeviceToHost));
-            const size_t m = (size_t)(ab[1] - ab[0]);
-            ids.resize(m);
-            PAG_HIP_TRY(hipMemcpy(ids.data(), val + ab[0], m * 8, hipMemcpyDeviceToHost));
-            list.resize(m);
-            for (size_t i = 0; i < m; ++i) list[i] = ListEntry{db.rec[ids[i]].score, ids[i]};
-            std::sort(list.begin(), list.end(), [](const ListEntry &a, const ListEntry &b) { return a.score > b.score; });
-            for (size_t i = 0; i < m; ++i) ids[i] = list[i].rec;
-            PAG_HIP_TRY(hipMemcpy(val + ab[0], ids.data(), m * 8, hipMemcpyHostToDevice));
-        }
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            std::vector<ListEntry> list;
+            for (size_t x; (x = next.fetch_add(1)) < qs.size();) {
+                const uint64_t a0 = offs[qs[x]], a1 = offs[(size_t)qs[x] + 1];
+                const size_t m = (size_t)(a1 - a0);
+                list.resize(m);
+                for (size_t i = 0; i < m; ++i) list[i] = ListEntry{db.rec[ids[a0 + i]].score, ids[a0 + i]};
+                std::sort(list.begin(), list.end(), [](const ListEntry &l, const ListEntry &r) { return l.score > r.score; });
+                for (size_t i = 0; i < m; ++i) ids[a0 + i] = list[i].rec;
+            }
+        };
+        const unsigned nthr = (unsigned)std::min<size_t>(qs.size(), std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+        if (n_listed) PAG_HIP_TRY(hipMemcpy(val, ids.data(), (size_t)n_listed * 8, hipMemcpyHostToDevice));
     }
     // filters, flips, n_valid; compaction of the listed records
     uint64_t n_kept = 0, n_cov = 0;
