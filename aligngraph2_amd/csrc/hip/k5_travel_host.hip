@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "pag_graph_impl.hpp"
+#include "walk_config.hpp"
 #include "walk_stitch.hpp"
 #include "walker_grid.hpp"
 
@@ -126,6 +127,7 @@ struct CtgState {
     bool delivered = false;  // its finished sequence has been filtered, gathered and sent to the host
     bool committed = false;  // a walk has been recorded in the global visited structures (device: gbits / gset)
     uint32_t gwinLo = 0xFFFFFFFFu, gwinHi = 0;
+    uint32_t gFreeHi = 0;  // highest id + 1 of a coordinate-free vertex on the committed paths (walk_stitch.hpp MergeCtx::g_free_hi)
     uint32_t *gset = nullptr;   // device: global visited, vertices outside the strand's id range
     uint32_t gcap = 0;
     uint32_t *gbits = nullptr;  // device: global visited bitmap over [inLo, inHi)
@@ -182,18 +184,13 @@ void merge_intervals(std::vector<std::pair<uint64_t, uint64_t>> &iv) {
     }
     iv.resize(w);
 }
-int trav_view_region(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
-                     double startSplit, DevBuf &scratch, ViewRegion *out) {
+int trav_view_region(pag_graph *g, const WalkConfig &cfg, const uint32_t *ctg_len, uint64_t n_ctgs, const int32_t *orient, const uint32_t *ref_len,
+                     uint64_t n_refs, double startSplit, DevBuf &scratch, ViewRegion *out) {
     hipStream_t s = g->stream;
     const Mapper cm(ctg_len, n_ctgs), rm(ref_len, n_refs);
-    uint64_t halo = 100000;
-    if (const char *e = std::getenv("PAG_VIEW_HALO")) halo = (uint64_t)std::max(0ll, std::atoll(e));
-    double margin_frac = 0.03;
-    uint64_t margin_min = 4000;
-    if (const char *e = std::getenv("PAG_VIEW_MARGIN")) {
-        margin_min = (uint64_t)std::max(0ll, std::atoll(e));
-        margin_frac = 0.0;
-    }
+    const uint64_t halo = cfg.view_halo;
+    const double margin_frac = cfg.view_margin_set ? 0.0 : 0.03;
+    const uint64_t margin_min = cfg.view_margin;
     std::vector<std::pair<uint64_t, uint64_t>> civ, zones;
     const double leap_min = 1.0 - startSplit;
     for (uint64_t c = 0; c < n_ctgs; ++c) {
@@ -317,8 +314,8 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         return PAG_OK;
     }
     // a graph that is one rank's region of a sharded build is cut already (pag_shard_select); PAG_TRAVEL_VIEW=whole: never cut
-    const char *view_env = std::getenv("PAG_TRAVEL_VIEW");
-    const bool prune = orient && !g->regional && !g->view_off && !(view_env && std::strcmp(view_env, "whole") == 0);
+    const WalkConfig cfg = WalkConfig::from_env();
+    const bool prune = orient && !g->regional && !g->view_off && !cfg.view_whole;
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
            b_estep = buf(), b_bitmap = buf(), b_rank = buf(), b_ctmp = buf(), b_uold = buf(), b_newid = buf(), b_upos = buf(), b_ucnt = buf(),
@@ -364,7 +361,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         DevBuf b_view(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 2), b_viewiv(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 3);
         g->view_pruned = false;
         if (prune) {
-            if ((rc = trav_view_region(g, ctg_len, n_ctgs, orient, ref_len, n_refs, startSplit, b_view, &vr))) return rc;
+            if ((rc = trav_view_region(g, cfg, ctg_len, n_ctgs, orient, ref_len, n_refs, startSplit, b_view, &vr))) return rc;
             if ((rc = b_viewiv.alloc((vr.civ.size() + vr.riv.size() + 8) * 4))) return rc;
             uint32_t *d = b_viewiv.as<uint32_t>();
             if (!vr.civ.empty()) PAG_HIP_TRY(hipMemcpyAsync(d, vr.civ.data(), vr.civ.size() * 4, hipMemcpyHostToDevice, s));
@@ -373,7 +370,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             tv.n_civ = (uint32_t)(vr.civ.size() / 2);
             tv.riv = d + vr.civ.size();
             tv.n_riv = (uint32_t)(vr.riv.size() / 2);
-            if (std::getenv("PAGRAPH_TIMING")) {
+            if (cfg.timing) {
                 uint64_t cl = 0, rl = 0;
                 for (size_t i = 0; i + 1 < vr.civ.size(); i += 2) cl += vr.civ[i + 1] - vr.civ[i];
                 for (size_t i = 0; i + 1 < vr.riv.size(); i += 2) rl += vr.riv[i + 1] - vr.riv[i];
@@ -433,8 +430,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
         // records, see DESIGN.md, and computing the bound is not free)
         // PAG_SUCC_MODE=bound|twopass forces one of the two ways (tests compare their records); PAG_SUCC_TWO_PASS=1 is twopass
-        const char *mode_env = std::getenv("PAG_SUCC_MODE");
-        const std::string mode = mode_env ? mode_env : (std::getenv("PAG_SUCC_TWO_PASS") ? "twopass" : "");
+        const std::string &mode = cfg.succ_mode;
         if ((mode.empty() && np <= (64ull << 20)) || mode == "bound") {
             if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
                 return rc;
@@ -472,7 +468,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         g->tg_dev = deviation;
         g->tg_err = errorRate;
         g->tg_ready = true;
-        if (std::getenv("PAGRAPH_TIMING"))
+        if (cfg.timing)
             std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%llu without a contig coordinate) of %llu (%s view: %llu of %llu nodes, %llu of %llu edges; %s, %llu candidate pairs)\n",
                          (unsigned long long)n_succ, (unsigned long long)G.n_pos, (unsigned long long)g->n_zero_ctg, (unsigned long long)np, g->view_pruned ? "cut" : "whole", (unsigned long long)G.n_nodes,
                          (unsigned long long)nn, (unsigned long long)G.n_edges, (unsigned long long)ne,
@@ -571,7 +567,7 @@ int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const 
     if (rc == PAG_ERANGE && g->view_pruned && !g->regional) {
         // a walk examined a vertex whose successors this handle's own view left out (trav_view_region): nothing of that walk is
         // kept — the whole graph's view is built and every contig walked again (the outputs are those of the un-cut graph)
-        if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] a walk left the view: %s; walking again on the whole graph\n", pag_last_error());
+        if (WalkConfig::from_env().timing) std::fprintf(stderr, "[timing] a walk left the view: %s; walking again on the whole graph\n", pag_last_error());
         g->view_off = true;
         g->tg_ready = false;
         g->view_fallbacks += 1;
@@ -584,7 +580,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     PAG_HIP_TRY(hipSetDevice(g->device));
     hipStream_t s = g->stream;
     const double t_begin = now_ms();
-    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    const WalkConfig cfg = WalkConfig::from_env();
+    const bool timing = cfg.timing;
     double lap_t = t_begin;
     std::vector<std::pair<const char *, double>> laps;
     auto lap = [&](const char *what) {
@@ -687,7 +684,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         cs.revRight = (uint32_t)mapper.dualToSingle(-cs.chosenOne, cs.len);
         cs.nodesOff = nodes_total;
         cs.seqCap = (uint64_t)cs.len / 2 + 8192;
-        if (const char *e = std::getenv("PAG_DEBUG_SEQCAP")) cs.seqCap = std::max(16, std::atoi(e));  // tests: force the overflow / regrow path
+        if (cfg.debug_seqcap) cs.seqCap = (uint64_t)cfg.debug_seqcap;  // tests: force the overflow / regrow path
         nodes_total += cs.len >= k ? cs.len - k + 1 : 0;
         st.push_back(std::move(cs));
     }
@@ -845,12 +842,12 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     // of this call can post in one round (segments every few kb of every strand, top-K <= 8 chains each), twice over.
     uint32_t QCAP = 32768;
     {
-        const uint64_t sl = std::max<uint64_t>(128, std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 12000);
-        const uint64_t ll = std::max<uint64_t>(128, std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : sl / 2);
+        const uint64_t sl = std::max<uint64_t>(128, cfg.seg_len ? cfg.seg_len : 12000);
+        const uint64_t ll = std::max<uint64_t>(128, cfg.leap_seg_len ? cfg.leap_seg_len : sl / 2);
         uint64_t est = 0;
         for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / sl + (uint64_t)st[i].len / ll + 32;  // (every strand as if all of it were both zones)
         while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
-        if (const char *e = std::getenv("PAG_DEBUG_RING")) QCAP = (uint32_t)std::max(4, std::atoi(e));  // tests: a ring far smaller than a round
+        if (cfg.debug_ring) QCAP = (uint32_t)cfg.debug_ring;  // tests: a ring far smaller than a round
     }
     const uint32_t NR = TRAV_RINGS;
     const size_t q_need = 256 + NR * (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
@@ -871,12 +868,12 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     PAG_HIP_TRY(hipMemsetAsync(g->wq_next, 0, 256, s));
     PAG_HIP_TRY(hipStreamSynchronize(s));
 
-    const bool wdebug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+    const bool wdebug = cfg.walk_debug;
     double t_walk0 = now_ms();  // (debug time stamps count from the launch of the walker)
-    const bool use_pieces = !(std::getenv("PAG_WALK_PIECES") && std::atoi(std::getenv("PAG_WALK_PIECES")) == 0);
-    const uint64_t seg_len_env = std::getenv("PAG_SEG_LEN") ? std::strtoull(std::getenv("PAG_SEG_LEN"), nullptr, 10) : 0;
-    const uint64_t seg_ov = std::getenv("PAG_SEG_OVERLAP") ? std::strtoull(std::getenv("PAG_SEG_OVERLAP"), nullptr, 10) : 1500;
-    const bool force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
+    const bool use_pieces = cfg.pieces;
+    const uint64_t seg_len_env = cfg.seg_len;
+    const uint64_t seg_ov = cfg.seg_overlap;
+    const bool force_exact = cfg.force_exact;
 
     double t_st[4] = {0, 0, 0, 0};  // stitch: bookkeeping / paths of finished jobs / chains moving on; posting (inside the others)
     // (The stitch below is serial on purpose.  Worker threads — spinning, polling or sleeping on a condition variable, 4 to
@@ -891,7 +888,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         int idx = 0;   // chain / segment number
         uint64_t init_len = 0;
         bool live = false;
-        uint32_t round = 0;  // the contig's round the job was posted in (see is_orphan)
+        uint32_t epoch = 0;  // RoundState::seg_epoch of its contig when the job was posted (see is_orphan)
     };
     std::vector<JobRef> jref(NR * (size_t)QCAP);
     // A round of a contig is decided when all its chains are final.  Segment jobs of the round that are still waiting or
@@ -902,12 +899,13 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     // into its own buffers — a round's buffers come from the walk arena, which is never handed out twice within one
     // pag_travel; a round that had to fall back on the per-contig slots waits for its jobs as before (RoundState::slot_bufs).
     uint64_t n_orphans = 0;
-    const bool orphaning = !(std::getenv("PAG_WALK_ORPHANS") && std::atoi(std::getenv("PAG_WALK_ORPHANS")) == 0);  // (0: every round waits for all its jobs)
+    const bool orphaning = cfg.orphaning;  // (PAG_WALK_ORPHANS=0: every round waits for all its jobs)
+    const bool keep_segments = orphaning && cfg.keep_segments;  // (PAG_WALK_KEEP_SEGMENTS=0: every round plans and walks its own)
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
     std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];
     for (auto &x : n_leap_refused) x = 0;
     uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
-    const bool use_leap_pieces = !(std::getenv("PAG_LEAP_PIECES") && std::atoi(std::getenv("PAG_LEAP_PIECES")) == 0);
+    const bool use_leap_pieces = cfg.leap_pieces;
     WalkerGrid walkers;
     auto shutdown_walker = [&]() {
         if (!walkers.up) return;
@@ -966,7 +964,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         if (!backlog[ring].empty() || !place_job(ring, P, jr2)) backlog[ring].push_back(Backlogged{P, jr2});
         return PAG_OK;
     };
-    auto is_orphan = [&](const JobRef &jr) { return jr.kind == 1 && (jr.round != RS[jr.ctg].round || !RS[jr.ctg].active); };
+    auto is_orphan = [&](const JobRef &jr) { return jr.kind == 1 && jr.epoch != RS[jr.ctg].seg_epoch; };
     auto flush_backlog = [&]() {
         for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
             while (!backlog[ring].empty()) {
@@ -979,6 +977,25 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 backlog[ring].pop_front();
                 need_publish = true;
             }
+    };
+    // The segment list of contig i is given up (the contig is finished, or its next round plans its own): the jobs of the list
+    // that no wave has taken are cancelled, those that are walking finish as orphans.
+    auto give_up_segments = [&](uint32_t i) {
+        RoundState &R = RS[i];
+        for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
+            for (uint32_t q = 0; q < QCAP; ++q) {
+                JobRef &jr = jref[ring * QCAP + q];
+                if (jr.live && jr.ctg == i && jr.kind == 1 && jr.epoch == R.seg_epoch) {
+                    __atomic_fetch_or(&hjobs[ring * QCAP + q].J.mode, (uint32_t)TRAV_MODE_CANCELLED, __ATOMIC_RELEASE);
+                    ++n_orphans;
+                }
+            }
+        R.seg_epoch += 1;
+        R.segs.clear();
+        R.n_spec = 0;
+        R.zone_end = 0;
+        R.live_jobs = 0;
+        R.kept = false;
     };
     // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
     // the walker only by publish())
@@ -1090,7 +1107,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             jr2.idx = pl.idx;
             jr2.init_len = J.init_len;
             jr2.live = true;
-            jr2.round = R.round;
+            jr2.epoch = R.seg_epoch;
             if (pl.kind == 0) {
                 if (pl.mode & TRAV_MODE_RESUME) ++n_resume_jobs;
             } else {
@@ -1129,6 +1146,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         uint32_t x0 = 0xFFFFFFFFu, seed_lo = 0, seed_hi = 0;
         size_t req_off = 0, co_off = 0;
         bool has_co = false;
+        bool kept = false;        // the round adopts the segments of an earlier round (RoundState::kept): none are planned
+        uint32_t kept_stop = 0;   // ... and its seeds walk up to this coordinate (0: to the end)
     };
     auto start_rounds = [&](const std::vector<uint32_t> &which) -> int {
         std::vector<RoundPlan> RP(which.size());
@@ -1142,14 +1161,18 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             uint32_t &x0 = P.x0;
             CtgState &cs = st[i];
             RoundState &R = RS[i];
+            const bool keep = R.kept && !R.segs.empty();
+            P.kept = keep;
             R.round += 1;
             R.active = true;
-            R.segs.clear();
+            if (!keep) {
+                R.segs.clear();
+                R.n_spec = 0;
+                R.zone_end = 0;
+                R.live_jobs = 0;
+                R.slot_bufs = false;
+            }
             R.chains.assign(cs.seeds.size(), Chain{});
-            R.n_spec = 0;
-            R.zone_end = 0;
-            R.live_jobs = 0;
-            R.slot_bufs = false;
             R.has_size = (uint64_t)cs.varLen;  // int64 -> size_t conversion as in the reference call
             rounds = std::max<uint64_t>(rounds, R.round);
             const uint64_t split = (uint64_t)(cs.len * startSplit);
@@ -1157,7 +1180,20 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             // contig coordinate closely but not exactly, so the zone is left with a margin; WHERE the walk is cut only decides how
             // much of it runs in parallel, every adoption is checked against the true sizes (try_merge).
             for (auto &sd : cs.seeds) x0 = std::min(x0, sd.ctg);
-            if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
+            if (keep) {
+                // where the seeds' own walks stop: a little into the first kept segment ahead of them, of the kind a chain
+                // at their coordinate adopts (advance_chain) — or of the other kind when none of that kind lies ahead
+                const bool can = R.has_size + k >= split;
+                const int n_spec = (int)R.n_spec, n_all = (int)R.segs.size();
+                auto first_ahead = [&](int lo, int hi) -> int {
+                    for (int q = lo; q < hi; ++q)
+                        if (R.segs[(size_t)q].x > x0 && (R.segs[(size_t)q].leap || x0 < R.zone_end)) return q;
+                    return -1;
+                };
+                int q = can ? first_ahead(n_spec, n_all) : first_ahead(0, n_spec);
+                if (q < 0) q = can ? first_ahead(0, n_spec) : first_ahead(n_spec, n_all);
+                P.kept_stop = q >= 0 ? stitch::stop_for(R, (size_t)q, seg_ov) : 0u;
+            } else if (use_pieces && cs.varLen >= 0 && x0 >= cs.ctgLeft && x0 < cs.ctgRight) {
                 const uint64_t H = (uint64_t)cs.varLen + k;
                 // (measured at BASELINE configs[1]: segments of 10-20 kb with 1.5 kb of overlap are the optimum, a few thousand
                 // jobs; shorter ones pay more overlap and job start-up, longer ones lengthen the first piece of every chain)
@@ -1169,7 +1205,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 // point.  (Until round 3 the kinds were kept apart by the margins and every contig walked the ~10 kb between them
                 // exactly, 30-48 ms at the end of its round.)  Only decides how much is walked in parallel: every adoption is
                 // checked against the true sizes.
-                const uint64_t margin = std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 400 + 200;
+                const uint64_t margin = cfg.seg_safety_set ? cfg.seg_safety : cs.len / 400 + 200;
                 if (split > H + seg_len) {
                     const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H) + margin, (uint64_t)cs.ctgRight - 1);
                     for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
@@ -1181,17 +1217,16 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     // leap (the steps follow the coordinate closely, not exactly: a margin; every adoption is checked with the true
                     // size) to the end of the strand
                     // (a walk there makes three times the classifications per vertex: shorter pieces for the same job length)
-                    static const uint64_t leap_len_env = std::getenv("PAG_LEAP_SEG_LEN") ? std::strtoull(std::getenv("PAG_LEAP_SEG_LEN"), nullptr, 10) : 0;
+                    const uint64_t leap_len_env = cfg.leap_seg_len;
                     const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
                     // (how far before x0 + split - H the first piece starts: at configs[1] the steps of a path add up to 0.6 % more than
                     // the coordinates it covers — leaping begins ~7 kb earlier than the coordinate says on a 1.2 Mb contig; pieces
                     // started too early cost a few jobs, pieces started too late an exact walk on the contig's critical path)
-                    const uint64_t left = std::getenv("PAG_LEAP_LEFT") ? std::strtoull(std::getenv("PAG_LEAP_LEFT"), nullptr, 10)
-                                          : std::getenv("PAG_SEG_SAFETY") ? std::strtoull(std::getenv("PAG_SEG_SAFETY"), nullptr, 10) : cs.len / 64 + 500;
+                    const uint64_t left = cfg.leap_left_set ? cfg.leap_left : cfg.seg_safety_set ? cfg.seg_safety : cs.len / 64 + 500;
                     const uint64_t first = (uint64_t)x0 + (split > H + left + lseg ? split - H - left : lseg);
                     // (the last stretch of the strand in shorter pieces still: the job that reaches the end of the strand is the
                     // last one of its round, and a contig that needs a second round waits for it twice)
-                    static const uint64_t end_div = std::getenv("PAG_LEAP_END_DIV") ? std::max<uint64_t>(1, std::strtoull(std::getenv("PAG_LEAP_END_DIV"), nullptr, 10)) : 2;
+                    const uint64_t end_div = cfg.leap_end_div;
                     const uint64_t end_zone = (uint64_t)cs.ctgRight > 2 * lseg ? (uint64_t)cs.ctgRight - 2 * lseg : 0;
                     for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 / end_div < (uint64_t)cs.ctgRight - 1; x += (x >= end_zone ? std::max<uint64_t>(lseg / end_div, seg_ov) : lseg))
                         if (ck_x.size() == n_spec_ck || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
@@ -1230,6 +1265,15 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             const std::vector<uint32_t> &ck_x = P.ck_x;
             const size_t n_spec_ck = P.n_spec_ck;
             const uint32_t x0 = P.x0;
+            if (P.kept) {  // (the id range around the seeds' own first piece: [lowest seed - 2000, its stop + 3000])
+                if (P.kept_stop != 0u) {
+                    P.has_co = true;
+                    P.co_off = co.size();
+                    co.push_back((uint32_t)std::max<uint64_t>(cs.ctgLeft, (uint64_t)x0 - std::min<uint64_t>(x0, 2000)));
+                    co.push_back((uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)P.kept_stop + 3000));
+                }
+                continue;
+            }
             if (ck_x.empty()) continue;
             const uint32_t *out_c = out.data() + 3 * P.req_off;
             for (size_t q = 0; q < ck_x.size(); ++q) {
@@ -1239,6 +1283,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 sg.vid = out_c[3 * q];
                 sg.leap = q >= n_spec_ck;
                 sg.win_low = x0;
+                sg.round = R.round;
                 if (!R.segs.empty() && R.segs.back().leap == sg.leap && sg.x <= R.segs.back().x) continue;  // (increasing within a kind)
                 R.segs.push_back(std::move(sg));
             }
@@ -1285,7 +1330,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             RoundState &R = RS[i];
             uint32_t seed_lo = 0, seed_hi = 0;  // id range for the walks of the seeds up to the first checkpoint (0, 0: the strand)
             if (P.has_co) {
-                const size_t nq = R.segs.size();
+                const size_t nq = P.kept ? 0 : R.segs.size();
                 const uint32_t *idc = ids.data() + P.co_off;
                 auto window = [&](size_t q, uint32_t *wlo, uint32_t *whi) {
                     uint32_t lo = std::max(idc[2 * q], cs.inLo), hi = std::min(idc[2 * q + 1], cs.inHi);
@@ -1295,12 +1340,12 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     *whi = hi;
                 };
                 for (size_t q = 0; q < nq; ++q) window(q, &R.segs[q].win_lo, &R.segs[q].win_hi);
-                if (first_stop(R) != 0u) window(nq, &seed_lo, &seed_hi);
+                if (P.kept || first_stop(R) != 0u) window(nq, &seed_lo, &seed_hi);
             }
             std::vector<JobPlan> plans;
             const uint64_t cap_full = cs.seqCap;
             for (size_t sd = 0; sd < cs.seeds.size(); ++sd) {
-                const uint32_t stop = R.segs.empty() ? 0u : first_stop(R);
+                const uint32_t stop = P.kept ? P.kept_stop : (R.segs.empty() ? 0u : first_stop(R));
                 // (a seed's walk that stops at the first checkpoint is a piece like the segments: direct-mapped marks around it,
                 // a sequence buffer for its stretch; the full-strand arrays, 130 MB per job at configs[1], are for resumed walks)
                 JobPlan pl{0, (int)sd, cap_full, cs.seeds[sd].vid, 0u, stop, nullptr, false};
@@ -1312,8 +1357,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 plans.push_back(pl);
             }
             // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
-            static const bool leap_first = !(std::getenv("PAG_LEAP_FIRST") && std::atoi(std::getenv("PAG_LEAP_FIRST")) == 0);
-            for (int pass = 0; pass < 2; ++pass)
+            const bool leap_first = cfg.leap_first;
+            for (int pass = 0; pass < 2 && !P.kept; ++pass)  // (kept segments have their jobs, or their paths, already)
                 for (size_t q = 0; q < R.segs.size(); ++q) {
                     if (R.segs[q].leap != ((pass == 0) == leap_first)) continue;
                     const uint64_t spanc = (R.segs[q].stop ? (uint64_t)R.segs[q].stop : (uint64_t)cs.ctgRight) - R.segs[q].x;
@@ -1323,8 +1368,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     plans.push_back(pl);
                 }
             if (wdebug)
-                std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_walk0, i,
-                             R.round, cs.seeds.size(), R.segs.size(), R.zone_end, cs.ctgLeft, cs.ctgRight);
+                std::fprintf(stderr, "[walk] t=%.1f ms contig %u round %u: %zu seeds, %zu segments%s, cut zone ends at %u (strand %u..%u)\n", now_ms() - t_walk0, i,
+                             R.round, cs.seeds.size(), R.segs.size(), P.kept ? " kept from an earlier round" : "", R.zone_end, cs.ctgLeft, cs.ctgRight);
             if ((r = post_batch(i, GRP_ROUND, plans))) return r;
         }
         return PAG_OK;
@@ -1347,6 +1392,12 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         M.deviation = deviation;
         M.split = (uint64_t)(st[i].len * startSplit);
         M.has_size = RS[i].has_size;
+        M.round = RS[i].round;
+        if (st[i].committed) {
+            M.g_lo = st[i].gwinLo;
+            M.g_hi = st[i].gwinHi;
+            M.g_free_hi = st[i].gFreeHi;
+        }
         return M;
     };
     // what a chain does after its job has ended at a stop coordinate or after a segment it waits for has finished
@@ -1420,7 +1471,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         // segments first).  Posted contig by contig, the last contigs of the list finish their first round when the grid
         // runs empty — and those of them that need a second round (a re-seed after a walk that ended early) start it then:
         // every contig's first round now ends at about the same time, earlier than the last ones did.
-        static const uint32_t interleave = std::getenv("PAG_POST_INTERLEAVE") ? (uint32_t)std::atoi(std::getenv("PAG_POST_INTERLEAVE")) : 8u;
+        const uint32_t interleave = cfg.post_interleave;
         defer_ring2 = interleave != 0;
         {
             std::vector<uint32_t> first_rounds;
@@ -1486,7 +1537,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     // Device buffers from the walk arena; without room there the contig is left to the epilogue.
     auto deliver_contig = [&](uint32_t i) -> int {
         CtgState &cs = st[i];
-        static const bool early = !(std::getenv("PAG_DELIVER_EARLY") && std::atoi(std::getenv("PAG_DELIVER_EARLY")) == 0);
+        const bool early = cfg.deliver_early;
         if (cs.delivered || !cs.done || !early) return PAG_OK;
         const size_t n = cs.travel.size();
         const size_t need = ((n * 8 + 255) & ~(size_t)255) + 512;
@@ -1570,7 +1621,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         if (fin.empty()) {
             // waves that found nothing to do have left (k_walk_persistent): jobs that are outstanding get new ones
             if ((rc = walkers.ensure(n_live))) return fail(rc);
-            static const double idle_limit_ms = (std::getenv("PAG_WALK_IDLE_S") ? std::atof(std::getenv("PAG_WALK_IDLE_S")) : 60.0) * 1000.0;
+            const double idle_limit_ms = cfg.idle_limit_ms;
             if (now_ms() - t_progress > idle_limit_ms) {  // no job finished for a minute: give up instead of hanging
                 uint32_t ticket[TRAV_RINGS] = {0, 0, 0};
                 hipMemcpyAsync(ticket, g->wq_next, sizeof(ticket), hipMemcpyDeviceToHost, s);
@@ -1619,7 +1670,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             // the pack kernel reads its descriptors from, and writes the packed paths to, the pinned host memory directly: one
             // launch + one synchronisation per batch instead of copy + launch + copy + synchronisation (every call of this
             // thread is on the critical path of some chain)
-            static const bool direct = !(std::getenv("PAG_FETCH_DIRECT") && std::atoi(std::getenv("PAG_FETCH_DIRECT")) == 0);
+            const bool direct = cfg.fetch_direct;
             if (direct) {
                 trav_launch_pack_paths(G, hd, (uint32_t)descs.size(), max_len, hp, s);
             } else {
@@ -1632,8 +1683,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 set_error("pag_travel: stream failure while fetching paths");
                 return fail(PAG_EFAULT);
             }
-            static const bool check_aggs = std::getenv("PAG_DEBUG_CHECK_AGGS") != nullptr;
-            static const bool use_aggs = !(std::getenv("PAG_FETCH_TABLES") && std::atoi(std::getenv("PAG_FETCH_TABLES")) == 0);  // (0: every entry is read, for comparisons)
+            const bool check_aggs = cfg.check_aggs;
+            const bool use_aggs = cfg.fetch_tables;  // (PAG_FETCH_TABLES=0: every entry is read, for comparisons)
             for (Got &G2 : got) {
                 G2.v = hp + G2.off;
                 G2.s = G2.v + G2.len;
@@ -1803,19 +1854,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             for (auto &ch : R.chains) all = all && ch.final;
             // (segment jobs still waiting or walking become orphans — unless the round's buffers are per-contig slots, which the
             // next round takes over: such a round waits for them)
-            if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs))) {
-                if (R.live_jobs) {
-                    n_orphans += R.live_jobs;
-                    for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)  // those no wave has taken yet never start
-                        for (uint32_t q = 0; q < QCAP; ++q) {
-                            JobRef &jr = jref[ring * QCAP + q];
-                            if (jr.live && jr.ctg == i && jr.kind == 1 && jr.round == R.round)
-                                __atomic_fetch_or(&hjobs[ring * QCAP + q].J.mode, (uint32_t)TRAV_MODE_CANCELLED, __ATOMIC_RELEASE);
-                        }
-                    R.live_jobs = 0;
-                }
-                batch.push_back(i);
-            }
+            if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs))) batch.push_back(i);
         }
         flush_backlog();
         if (batch.empty()) {
@@ -1919,6 +1958,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     cs.gwinLo = std::min(cs.gwinLo, ch.low_nz);
                     cs.gwinHi = std::max(cs.gwinHi, ch.mx_all);
                 }
+                cs.gFreeHi = std::max(cs.gFreeHi, ch.m0_all);
                 // the first vertex of the round's path: its step is the distance to the path so far (set after the copy)
                 cs.varLen += dLen - ((int64_t)ch.parts.front().s[0] - dist);
                 cs.pendingFirst = at0;
@@ -1941,7 +1981,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 };
                 // (measured at configs[1] on the GPU box, 16-CPU quota, the previous block's host half running beside: 430 ms per block with
                 // one thread, 436 with six — the copy is no longer what the round waits for; PAG_TAKE_THREADS for hosts with CPUs to spare)
-                static const unsigned cap = std::getenv("PAG_TAKE_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAG_TAKE_THREADS"))) : 1u;
+                const unsigned cap = cfg.take_threads;
                 const unsigned nthr = (unsigned)std::min<size_t>(chunks.size(), std::max(1u, std::min(cap, std::thread::hardware_concurrency())));
                 std::vector<std::thread> pool;
                 for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
@@ -1978,10 +2018,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 cs.committed = true;
             }
         }
-        for (uint32_t i : batch) {  // the host copies of the round are spent
-            RS[i].chains.clear();
-            RS[i].segs.clear();
-        }
+        for (uint32_t i : batch) RS[i].chains.clear();  // (the host copies of the round's chains are spent; its segments: below)
         lap("choose+gather");
 
         // splice + stop rules (PAlgorithm.cpp:264-360)
@@ -2058,6 +2095,14 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 reqs.push_back(slot_req[i]);
                 req_cs.push_back(i);
             }
+        // The round's SEGMENTS: a contig that goes on re-seeds behind the path it has just committed and walks the rest of the
+        // strand — through the very checkpoints this round's segments were started from.  They are kept (those still waiting
+        // or walking included): the next round's chains adopt them under the conditions of walk_stitch.hpp, which count the
+        // marks committed since (Seg::round, MergeCtx::g_*).  A finished contig gives them up.
+        for (uint32_t i : batch) {
+            if (st[i].done || !keep_segments) give_up_segments(i);
+            else RS[i].kept = !RS[i].segs.empty();
+        }
         lap("splice");
 
         // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
@@ -2143,7 +2188,10 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 std::sort(keyed.begin(), keyed.end(), [](const Keyed &a, const Keyed &b) { return a.d < b.d; });
                 cs.seeds.clear();
                 for (size_t x = 0; x < keyed.size() && x < topK; ++x) cs.seeds.push_back(keyed[x].n);
-                if (cs.seeds.empty()) cs.done = true;
+                if (cs.seeds.empty()) {
+                    cs.done = true;
+                    give_up_segments(req_cs[q]);
+                }
                 else next_round.push_back(req_cs[q]);
             }
         }

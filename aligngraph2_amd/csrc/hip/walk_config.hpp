@@ -1,0 +1,96 @@
+// The switches of the traversal ("Environment switches"), read from the environment ONCE per call into one
+// struct: none is needed in normal use; tests and measurements set them.  Host code only.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace pagdev {
+
+struct WalkConfig {
+    // ---- the view (trav_view_region)
+    bool view_whole = false;          // PAG_TRAVEL_VIEW=whole: never cut the view to the walked orientations
+    uint64_t view_halo = 100000;      // PAG_VIEW_HALO
+    bool view_margin_set = false;     // PAG_VIEW_MARGIN given: view_margin bases instead of max(4000, 3 % of the contig)
+    uint64_t view_margin = 4000;
+    // ---- successor records
+    std::string succ_mode;            // PAG_SUCC_MODE=bound|twopass ("": by size); PAG_SUCC_TWO_PASS=1 = twopass
+    // ---- diagnostics
+    bool timing = false;              // PAGRAPH_TIMING
+    bool walk_debug = false;          // PAG_WALK_DEBUG
+    double idle_limit_ms = 60000.0;   // PAG_WALK_IDLE_S: watchdog of the event loop
+    bool check_aggs = false;          // PAG_DEBUG_CHECK_AGGS
+    int debug_seqcap = 0;             // PAG_DEBUG_SEQCAP (> 0: tiny initial walk buffers)
+    int debug_ring = 0;               // PAG_DEBUG_RING (> 0: job rings of that many entries)
+    // ---- pieces
+    bool pieces = true;               // PAG_WALK_PIECES
+    bool leap_pieces = true;          // PAG_LEAP_PIECES
+    bool leap_first = true;           // PAG_LEAP_FIRST
+    bool force_exact = false;         // PAG_WALK_EXACT
+    bool orphaning = true;            // PAG_WALK_ORPHANS
+    bool keep_segments = true;        // PAG_WALK_KEEP_SEGMENTS
+    uint64_t seg_len = 0;             // PAG_SEG_LEN (0: 12000)
+    uint64_t seg_overlap = 1500;      // PAG_SEG_OVERLAP
+    bool seg_safety_set = false;      // PAG_SEG_SAFETY
+    uint64_t seg_safety = 0;
+    uint64_t leap_seg_len = 0;        // PAG_LEAP_SEG_LEN (0: derived from the segment length)
+    bool leap_left_set = false;       // PAG_LEAP_LEFT
+    uint64_t leap_left = 0;
+    uint64_t leap_end_div = 2;        // PAG_LEAP_END_DIV
+    uint32_t post_interleave = 8;     // PAG_POST_INTERLEAVE
+    // ---- delivery of results
+    bool deliver_early = true;        // PAG_DELIVER_EARLY
+    bool fetch_direct = true;         // PAG_FETCH_DIRECT
+    bool fetch_tables = true;         // PAG_FETCH_TABLES
+    unsigned take_threads = 1;        // PAG_TAKE_THREADS
+
+    static bool off(const char *name) {  // set and 0
+        const char *e = std::getenv(name);
+        return e && std::atoi(e) == 0;
+    }
+    static bool u64(const char *name, uint64_t *out) {
+        const char *e = std::getenv(name);
+        if (!e) return false;
+        *out = std::strtoull(e, nullptr, 10);
+        return true;
+    }
+    static WalkConfig from_env() {
+        WalkConfig c;
+        if (const char *e = std::getenv("PAG_TRAVEL_VIEW")) c.view_whole = std::strcmp(e, "whole") == 0;
+        if (const char *e = std::getenv("PAG_VIEW_HALO")) c.view_halo = (uint64_t)std::max(0ll, std::atoll(e));
+        if (const char *e = std::getenv("PAG_VIEW_MARGIN")) {
+            c.view_margin_set = true;
+            c.view_margin = (uint64_t)std::max(0ll, std::atoll(e));
+        }
+        if (const char *e = std::getenv("PAG_SUCC_MODE")) c.succ_mode = e;
+        else if (std::getenv("PAG_SUCC_TWO_PASS")) c.succ_mode = "twopass";
+        c.timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+        c.walk_debug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+        if (const char *e = std::getenv("PAG_WALK_IDLE_S")) c.idle_limit_ms = std::atof(e) * 1000.0;
+        c.check_aggs = std::getenv("PAG_DEBUG_CHECK_AGGS") != nullptr;
+        if (const char *e = std::getenv("PAG_DEBUG_SEQCAP")) c.debug_seqcap = std::max(16, std::atoi(e));
+        if (const char *e = std::getenv("PAG_DEBUG_RING")) c.debug_ring = std::max(4, std::atoi(e));
+        c.pieces = !off("PAG_WALK_PIECES");
+        c.leap_pieces = !off("PAG_LEAP_PIECES");
+        c.leap_first = !off("PAG_LEAP_FIRST");
+        c.force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
+        c.orphaning = !off("PAG_WALK_ORPHANS");
+        c.keep_segments = !off("PAG_WALK_KEEP_SEGMENTS");
+        u64("PAG_SEG_LEN", &c.seg_len);
+        u64("PAG_SEG_OVERLAP", &c.seg_overlap);
+        c.seg_safety_set = u64("PAG_SEG_SAFETY", &c.seg_safety);
+        u64("PAG_LEAP_SEG_LEN", &c.leap_seg_len);
+        c.leap_left_set = u64("PAG_LEAP_LEFT", &c.leap_left);
+        if (u64("PAG_LEAP_END_DIV", &c.leap_end_div)) c.leap_end_div = std::max<uint64_t>(1, c.leap_end_div);
+        if (const char *e = std::getenv("PAG_POST_INTERLEAVE")) c.post_interleave = (uint32_t)std::atoi(e);
+        c.deliver_early = !off("PAG_DELIVER_EARLY");
+        c.fetch_direct = !off("PAG_FETCH_DIRECT");
+        c.fetch_tables = !off("PAG_FETCH_TABLES");
+        if (const char *e = std::getenv("PAG_TAKE_THREADS")) c.take_threads = (unsigned)std::max(1, std::atoi(e));
+        return c;
+    }
+};
+
+}  // namespace pagdev

@@ -76,6 +76,10 @@ struct Seg {  // one segment job of a round
     // a segment inside the leaping zone (TRAV_MODE_LEAP), see try_merge_leap:
     bool leap = false;
     uint32_t wd_below_max = 0, wd_forced_min = 0xFFFFFFFFu, win_low = 0;
+    // the round of the contig whose state the job was posted under.  A segment KEPT from an earlier round (the contig's walk
+    // dead-ended, was committed, and the next round re-seeds behind it) was walked without the global marks and the global
+    // coordinate window of the rounds since: the adoption conditions take those into account (MergeCtx::g_*)
+    uint32_t round = 0;
 };
 struct Chain {  // one graphTravel: (contig, seed) of the running round
     // The validated path so far, T, is a list of parts that stay where the fetches put them (pinned memory kept for the
@@ -114,6 +118,8 @@ struct RoundState {
     uint32_t live_jobs = 0;
     uint64_t has_size = 0;
     bool slot_bufs = false;  // some job of the round has its buffers in per-contig slots (not in the walk arena)
+    uint32_t seg_epoch = 0;  // counts the times the segment list was given up: jobs of an earlier list are orphans
+    bool kept = false;       // segs is the list of an earlier round, kept for this one (Seg::round tells which)
 };
 
 // T grows by a job's new vertices or by an adopted stretch of a segment
@@ -283,6 +289,11 @@ struct MergeCtx {
     uint64_t deviation = 0;
     uint64_t split = 0;     // (uint64_t)(contig length * startSplit): from hasSize + nowSize >= split on a walk can leap
     uint64_t has_size = 0;  // the round's hasSize (sum of the steps of the contig's path so far)
+    // what the rounds before this one have committed to the contig's global structures (globalUniqueTable / ctgGlobalPosTable,
+    // PAlgorithm.cpp:146-149, 290-296): the coordinate window [g_lo, g_hi] of their paths (0xFFFFFFFF, 0: nothing yet) and the
+    // highest id + 1 of a coordinate-free vertex on them.  They count for segments kept from an earlier round only.
+    uint32_t round = 0;
+    uint32_t g_lo = 0xFFFFFFFFu, g_hi = 0, g_free_hi = 0;
 };
 
 // Adoption of a finished segment by a chain whose last vertex lies inside it.
@@ -321,7 +332,11 @@ inline int try_merge(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adop
     uint32_t dT = 0, d0 = 0, dP = 0;
     chain_before(ch, a, &dT, &d0);
     for (size_t x = 0; x < b; ++x) dP = std::max(dP, P.pc[x]);
-    const uint64_t dmax = std::max(dT, dP);
+    uint64_t dmax = std::max(dT, dP);
+    // a segment kept from an earlier round: the vertices the rounds since have marked globally are visited for the real walk
+    // and were not for the segment's — they belong to D (all of them have a coordinate <= g_hi, or none: such a vertex is
+    // never a candidate while leaping is impossible)
+    if (sg.round < M.round) dmax = std::max<uint64_t>(dmax, M.g_hi);
     const size_t q = be + 1 > sg.max_chosen ? be + 1 - sg.max_chosen : 0;
     const uint64_t split = M.split;
     const uint64_t base = M.has_size + M.k + ch.size + sg.max_probe + 1;
@@ -420,7 +435,14 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
         }
     }
     if (ch.mx_all != p_top) return refuse(4);
-    const uint32_t lowM = ch.low_nz;
+    uint32_t lowM = ch.low_nz;
+    const bool kept = sg.round < M.round;
+    // A segment kept from an earlier round: the real walk rejects a window-dependent record inside its travel window
+    // [lowest coordinate of T, top] AND inside the global window [g_lo, g_hi] of the rounds since (existCtgPos on
+    // ctgGlobalPosTable, PAlgorithm.cpp:160-168); when the two touch (g_hi >= lowM - 1) their union is one interval from
+    // min(lowM, g_lo) up, and that is what the segment's forced window has to agree with.  A gap between them cannot be
+    // told from the job's extremes: the travel window alone counts then (stricter).
+    if (kept && M.g_hi != 0u && M.g_lo <= M.g_hi && (uint64_t)M.g_hi + 1u >= lowM) lowM = std::min(lowM, M.g_lo);
     if (sg.wd_below_max != 0u && sg.wd_below_max >= lowM) return refuse(5);
     if (sg.wd_forced_min < lowM) return refuse(5);
     if (p_min < lowM) return refuse(5);
@@ -438,9 +460,13 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
     }
     uint32_t t_dmax = 0, t_d0 = 0;
     chain_before(ch, a, &t_dmax, &t_d0);
-    const uint32_t dmax = std::max(t_dmax, p_dmax);
+    uint32_t dmax = std::max(t_dmax, p_dmax);
+    uint32_t d0 = std::max(t_d0, p_d0);  // (id + 1, 0: none)
+    if (kept) {  // (the vertices the rounds since have marked globally belong to D)
+        dmax = std::max(dmax, M.g_hi);
+        d0 = std::max(d0, M.g_free_hi);
+    }
     if (elow <= dmax) return refuse(6);
-    const uint32_t d0 = std::max(t_d0, p_d0);  // (id + 1, 0: none)
     if (d0 != 0u && m0 != 0xFFFFFFFFu && m0 + 1u <= d0) return refuse(7);
     const size_t last = P.n - 1;
     extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1);

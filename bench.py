@@ -541,7 +541,7 @@ def main():
             # through the drop-in executable, both whole programs with their file parsing — measured once on the GPU box by
             # tests/c2_text_runs.py, the record is kept under profiles/ (a cached measurement, quoted with its provenance)
             try:
-                rec = json.load(open(os.path.join(ROOT, "profiles", "r03_c2_text_parity.json")))
+                rec = json.load(open(os.path.join(ROOT, "profiles", "r04_c2_text_parity.json")))
                 nat = json.load(open(os.path.join(ROOT, "profiles", "r02_c2_text_runs.json")))
                 default_wl = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon) == (100_000, 10_000, 50_000_000, 14, 10)
                 if default_wl and nat.get("reference", {}).get("returncode") == 0:
@@ -555,11 +555,11 @@ def main():
                                   "(16-CPU cgroup quota); cached: profiles/r02_c2_text_runs.json (tests/c2_text_runs.py)",
                         "parity_provenance": {"wall_s": rec.get("reference", {}).get("wall_s"), "what": "the same files through the reference at -t 16 under the "
                                               "thread-serialising shim: the run whose output files the drop-in reproduces byte for byte "
-                                              "(profiles/r03_c2_text_parity.json)"}}
+                                              "(profiles/r04_c2_text_parity.json)"}}
                 if default_wl and rec.get("ours", {}).get("returncode") == 0:
                     line["config"]["file_to_file_bases_per_s"] = rec["ours"]["bases_per_s"]
                     line["config"]["file_to_file_note"] = ("bin/pagraph on the same text files, wall clock incl. parsing and upload; cached: "
-                                                           "profiles/r03_c2_text_parity.json (python bench.py --file-to-file measures it live)")
+                                                           "profiles/r04_c2_text_parity.json (python bench.py --file-to-file measures it live)")
                     # what the product's own ingest costs in that run (host code: parsers, then GraphInput = eligibility /
                     # flips / n_valid / contig->reference entries, the inputs this bench takes from its generator)
                     phases = {}

@@ -53,10 +53,22 @@ void pagt_range_xagg(const uint32_t *xl, const uint32_t *xh, uint64_t n, uint64_
 // leap = 0: try_merge, 1: try_merge_leap (xl / xh: the iteration log).  out[0] = decision, out[1] = vertices adopted,
 // out[2] = refusal reason (leap), out[3] = chain length afterwards, out[4] = chain size (sum of steps) afterwards,
 // out[5] = mx_all afterwards.  tail_out (may be null): the adopted vertices.
+// kept: {segment's round, the running round, g_lo, g_hi, g_free_hi} (null: a segment of the running round)
+int pagt_stitch_kept(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, const uint32_t *pv,
+                     const uint32_t *ps, const uint32_t *ppc, const uint32_t *pxl, const uint32_t *pxh, uint64_t pn, uint32_t max_back, uint32_t max_chosen,
+                     uint64_t max_probe, uint32_t wd_below_max, uint32_t wd_forced_min, int usable, uint32_t k, uint64_t deviation, uint64_t split,
+                     uint64_t has_size, int leap, uint64_t *out, uint32_t *tail_out, const uint32_t *kept);
 int pagt_stitch(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, const uint32_t *pv,
                 const uint32_t *ps, const uint32_t *ppc, const uint32_t *pxl, const uint32_t *pxh, uint64_t pn, uint32_t max_back, uint32_t max_chosen,
                 uint64_t max_probe, uint32_t wd_below_max, uint32_t wd_forced_min, int usable, uint32_t k, uint64_t deviation, uint64_t split,
                 uint64_t has_size, int leap, uint64_t *out, uint32_t *tail_out) {
+    return pagt_stitch_kept(tv, ts, tpc, part_off, n_parts, pv, ps, ppc, pxl, pxh, pn, max_back, max_chosen, max_probe, wd_below_max, wd_forced_min, usable, k,
+                            deviation, split, has_size, leap, out, tail_out, nullptr);
+}
+int pagt_stitch_kept(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, const uint64_t *part_off, uint32_t n_parts, const uint32_t *pv,
+                     const uint32_t *ps, const uint32_t *ppc, const uint32_t *pxl, const uint32_t *pxh, uint64_t pn, uint32_t max_back, uint32_t max_chosen,
+                     uint64_t max_probe, uint32_t wd_below_max, uint32_t wd_forced_min, int usable, uint32_t k, uint64_t deviation, uint64_t split,
+                     uint64_t has_size, int leap, uint64_t *out, uint32_t *tail_out, const uint32_t *kept) {
     Chain ch;
     Tables tt, tp, tx;
     build_chain(ch, tt, tv, ts, tpc, part_off, n_parts);
@@ -82,6 +94,13 @@ int pagt_stitch(const uint32_t *tv, const uint32_t *ts, const uint32_t *tpc, con
     M.deviation = deviation;
     M.split = split;
     M.has_size = has_size;
+    if (kept) {
+        sg.round = kept[0];
+        M.round = kept[1];
+        M.g_lo = kept[2];
+        M.g_hi = kept[3];
+        M.g_free_hi = kept[4];
+    }
     const size_t before = ch.len;
     uint64_t adopted = 0;
     int why = -1;

@@ -1,6 +1,6 @@
 """GPU: BASELINE configs[1] at FULL size as text files (100 000 x 10 kb reads vs 50 Mb, 6.9 GB of inputs in /dev/shm) through the
 drop-in executable, every one of its 53 output files held against the SHA-256 of what the compiled reference wrote for the
-same files (profiles/r03_c2_text_parity.json: the reference's `-t 16` run under the thread-serialising shim, 1 639 s — kept as
+same files (profiles/r04_c2_text_parity.json: the reference's `-t 16` run under the thread-serialising shim, 1 639 s — kept as
 digests so that this comparison costs a minute instead of half an hour).  Parsers, pag_prepare, build, walks, writers: the
 whole product at the size the benchmark is quoted on."""
 import json
@@ -13,7 +13,7 @@ import pytest
 
 import pagctl
 
-DIGESTS = os.path.join(pagctl.ROOT, "profiles", "r03_c2_text_parity.json")
+DIGESTS = os.path.join(pagctl.ROOT, "profiles", "r04_c2_text_parity.json")
 
 
 @pytest.mark.gpu

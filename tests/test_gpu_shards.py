@@ -373,3 +373,118 @@ def test_bench_default_mode_two_processes(workdir):
     one_step_bases = d1["value"] * d1["ms_per_step"] / 1e3
     assert 1.8 * one_step_bases < per_step_bases < 2.2 * one_step_bases   # (rank 1 has its own seed: about as many bases)
     assert d2["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_rank_serial_run_equals_the_one_gpu_run(n_ranks, workdir):
+    """aligngraph2_amd/rank_serial.py (the N ranks of the sharded build one after the other on ONE device, their exchanges parked
+    in host memory — how BASELINE configs[2]'s geometry is executed on the one GPU this build has): outputs, count lines and
+    path statistics of the one-GPU run of the same block; every rank holds its share of the vertices."""
+    import torch
+    import bench
+    import biggen
+    from aligngraph2_amd import rank_serial
+    hip, host = bench.load_libs()
+    _bind(hip)
+    sp = biggen.BigSpec(seed=13, ref_len=3_000_000, n_reads=12000, read_span=4000, k=14, eps=10, ctg_len=250_000, gap_lo=300, gap_hi=3000,
+                        rev_ctg_frac=0.3, threads=16, cov=2, solid_min_abundance=2, chunk_reads=512)
+    w = biggen.BigWorkload(sp, device="cuda")
+    torch.cuda.synchronize()
+    inp = w.build_input()
+
+    def make_handle():
+        err = C.c_int()
+        g = hip.pag_create_from_bitmap(w.solid_bits.data_ptr(), w.n_solid, sp.k, 1, 0, C.byref(err))
+        assert g, hip.pag_last_error()
+        return g
+
+    g1 = make_handle()
+    st1 = pagctl.BuildStats()
+    assert hip.pag_process(C.c_void_p(g1), C.byref(inp), C.byref(st1)) == 0, hip.pag_last_error()
+    orient = np.array([0 if r else 1 for _, _, r in w.ctgs], dtype=np.int32)
+    one = str(workdir / f"rs{n_ranks}_one")
+    ts1, seqs = _traverse(host, g1, w, one, orient)
+    host.pagh_release(C.c_void_p(g1))
+    hip.pag_destroy(C.c_void_p(g1))
+    want, _ = rank_serial.digest_dir(one)
+
+    ctg_len = [e - s for s, e, _ in w.ctgs]
+    g2r = w.g2r.cpu().numpy()
+    alns = [(c, 0, int(g2r[s]), int(g2r[e - 1]) + 1) for c, (s, e, _) in enumerate(w.ctgs)]
+    out = str(workdir / f"rs{n_ranks}_serial")
+    res = rank_serial.run(hip, host, make_handle, inp, n_ranks=n_ranks, eps=sp.eps, k=sp.k, threads=sp.threads, ctgs=ctg_len, ctg_alns=alns,
+                          ref_lens=[len(w.ref)], ctg_seqs=seqs[0], ref_seqs=seqs[1], orient=[int(x) for x in orient], out_dir=out, device="cuda:0",
+                          halo=60_000)
+    assert res["outputs_sha256"] == want
+    assert res["count_lines_sum_over_owners"] == list(st1.counts())
+    assert (res["path_nodes"], res["path_bases"]) == (ts1.n_path_nodes, ts1.n_path_bases)
+    assert max(r["held_fraction"] for r in res["ranks"]) < 1.0 / n_ranks + 0.15
+    assert all(r["bytes_extract"] > 0 and r["bytes_traversal_peak"] > 0 for r in res["ranks"])
+
+
+def _comm_worker(rank, world, rdv, q, fail_rank):
+    """a rank of a two-process job on the one device ("host" transport): rank `fail_rank` aborts instead of joining the exchange"""
+    import torch
+    hip = pagctl.hip_lib()
+    hip.pag_comm_create.restype = C.c_void_p
+    hip.pag_comm_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+    hip.pag_comm_all_to_all_v.argtypes = [C.c_void_p] * 5
+    hip.pag_comm_abort.argtypes = [C.c_void_p, C.c_char_p]
+    hip.pag_comm_destroy.argtypes = [C.c_void_p]
+    err = C.c_int()
+    c = hip.pag_comm_create(rank, world, rdv.encode(), 0, b"host", C.byref(err))
+    if not c:
+        q.put((rank, "create", err.value, hip.pag_last_error().decode()))
+        return
+    import time
+    t0 = time.time()
+    if rank == fail_rank:
+        hip.pag_comm_abort(c, b"rank %d ran out of luck" % rank)
+        q.put((rank, "aborted", 0, ""))
+    else:
+        n = 1 << 16
+        src = torch.full((world * n,), rank + 1, dtype=torch.int32, device="cuda")
+        dst = torch.zeros_like(src)
+        sizes = (C.c_uint64 * world)(*([n * 4] * world))
+        rc = hip.pag_comm_all_to_all_v(c, src.data_ptr(), sizes, dst.data_ptr(), sizes)
+        torch.cuda.synchronize()
+        ok = rc == 0 and all(int(dst[r * n]) == r + 1 and int(dst[(r + 1) * n - 1]) == r + 1 for r in range(world))
+        q.put((rank, "exchanged" if ok else "failed", time.time() - t0, hip.pag_last_error().decode() if rc else ""))
+    hip.pag_comm_destroy(c)
+
+
+@pytest.mark.gpu
+def test_library_communicator_between_two_processes_and_a_failing_rank():
+    """pag_comm between TWO processes that share the box's one device (transport "host"): the job nonce agreed by live ranks
+    in a directory that already holds another job's files; an all-to-all(v) of device buffers; and a rank that fails: its peer
+    returns at once with the failing rank's message instead of waiting for PAG_COMM_TIMEOUT_S."""
+    import tempfile
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    rdv = tempfile.mkdtemp(prefix="pagcomm2_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    # what a crashed job left behind: a hello of a dead process, an answer for it, files of its collectives
+    open(os.path.join(rdv, "hello_1"), "wb").write((2 ** 22 + 12345).to_bytes(8, "little") + (77).to_bytes(8, "little") + (99).to_bytes(8, "little"))
+    open(os.path.join(rdv, "job_1"), "wb").write((4242).to_bytes(8, "little") + (99).to_bytes(8, "little"))
+    open(os.path.join(rdv, "j0000000000001092_g0_0"), "wb").write(b"\0")
+    os.environ["PAG_COMM_TIMEOUT_S"] = "60"
+    try:
+        for fail_rank in (-1, 1):
+            q = ctx.Queue()
+            ps = [ctx.Process(target=_comm_worker, args=(r, 2, rdv, q, fail_rank)) for r in range(2)]
+            for p in ps:
+                p.start()
+            got = dict()
+            for _ in ps:
+                r, what, x, msg = q.get(timeout=120)
+                got[r] = (what, x, msg)
+            for p in ps:
+                p.join(timeout=60)
+            if fail_rank < 0:
+                assert got[0][0] == "exchanged" and got[1][0] == "exchanged", got
+            else:
+                assert got[1][0] == "aborted"
+                what, secs, msg = got[0]
+                assert what == "failed" and "ran out of luck" in msg and secs < 20, got  # (not the 60 s timeout)
+    finally:
+        os.environ.pop("PAG_COMM_TIMEOUT_S", None)

@@ -53,6 +53,30 @@ def stitch(lib, T, parts, P, *, leap=False, log=None, max_back=0, max_chosen=1, 
     return results[0][:6]
 
 
+def stitch_kept(lib, T, parts, P, kept, *, leap=False, log=None, max_back=0, max_chosen=1, max_probe=0, wd_below=0, wd_forced=0xFFFFFFFF, k=14, dev=20,
+                split=10 ** 9, has_size=0):
+    """stitch() for a segment KEPT from an earlier round: kept = (segment's round, running round, g_lo, g_hi, g_free_hi)"""
+    tv, ts, tpc = (_u32([x[i] for x in T]) for i in range(3))
+    pv, ps, ppc = (_u32([x[i] for x in P]) for i in range(3))
+    off = np.concatenate([[0], np.cumsum(parts)]).astype(np.uint64)
+    xl = xh = None
+    if log is not None:
+        xl = _u32([m0 for _, _, m0 in log])
+        xh = _u32([((1 << 31) | (elow & 0x7FFFFFFF)) if b else 0 for b, elow, _ in log])
+    out = (C.c_uint64 * 6)()
+    tail = np.zeros(len(P) + 1, dtype=np.uint32)
+    kp = _u32(kept)
+    lib.pagt_stitch_kept.argtypes = [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                                                                          C.c_int, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pagt_use_tables(1)
+    lib.pagt_stitch_kept(tv.ctypes.data, ts.ctypes.data, tpc.ctypes.data, off.ctypes.data, len(parts), pv.ctypes.data, ps.ctypes.data, ppc.ctypes.data,
+                         xl.ctypes.data if xl is not None else None, xh.ctypes.data if xh is not None else None, len(P), max_back, max_chosen, max_probe,
+                         wd_below, wd_forced, 1, k, dev, split, has_size, int(leap), out, tail.ctypes.data, kp.ctypes.data)
+    lib.pagt_use_tables(0)
+    return int(out[0]), int(out[1]), C.c_int64(out[2]).value
+
+
 def line(v0, n, c0, step=3):
     """n consecutive path vertices v0, v0 + 1, .. at coordinates c0, c0 + step, .."""
     return [(v0 + i, step, c0 + i * step) for i in range(n)]
@@ -362,3 +386,46 @@ def test_advance_past_the_zone_of_the_segments_that_cannot_leap(lib):
     r = advance(lib, T, segs[:2] + leap, 2, zone_end)
     # adopted to the end of the zone; leaping is still impossible (true size): across the point, however far that is
     assert (r["what"], r["until_leap"], r["next_seg"]) == (1, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# segments kept from an earlier round of the contig (the walk dead-ended, was committed, the next round re-seeds behind it)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("g_hi,decision", [(0, 1), (5079, 1), (5080, 0), (6000, 0)])
+def test_kept_segment_outside_the_leaping_zone_counts_the_marks_committed_since(lib, g_hi, decision):
+    """the vertices the rounds since have marked globally belong to D: the segment's candidates (lowest coordinate 5100, deviation
+    20) must lie above all of them"""
+    kw = dict(max_back=0, max_chosen=2, max_probe=50, k=14, dev=20, split=10 ** 7, has_size=0)
+    P = line(1000, 40, 5000, step=10)
+    T = line(100, 10, 4000) + P[5:12]
+    same_round = stitch_kept(lib, T, [10, 7], P, (2, 2, 3000, 6000, 0), **kw)
+    assert same_round[0] == 1  # (a segment of the running round: the global marks were there when it was walked)
+    got = stitch_kept(lib, T, [10, 7], P, (1, 2, 3000 if g_hi else 0xFFFFFFFF, g_hi, 0), **kw)
+    assert got[0] == decision, got
+
+
+@pytest.mark.parametrize("case,decision,why", [("adopt", 1, -1), ("global_coordinate_in_reach", 0, 6), ("global_free_vertex_in_reach", 0, 7),
+                                                ("forced_record_inside_the_global_window", 1, -1), ("forced_record_below_the_global_window", 0, 5),
+                                                ("forced_record_in_a_gap_between_the_windows", 0, 5), ("record_below_the_forced_window_inside_the_global_one", 0, 5)])
+def test_kept_segment_of_the_leaping_zone(lib, case, decision, why):
+    P = line(1000, 30, 90000)
+    T = line(100, 10, 80000) + P[3:13]
+    log = [(i % 4 == 0, 90000 + 3 * i - 5, 0xFFFFFFFF) for i in range(30)]
+    kw = dict(k=14, dev=20, split=1000, has_size=5000, wd_below=0, wd_forced=0xFFFFFFFF)
+    g_lo, g_hi, g_free = 60000, 80000, 0          # the rounds since committed a path over [60000, 80000]: it touches T's window (from 80000)
+    if case == "global_coordinate_in_reach":
+        g_hi = 90040                              # ... up to a coordinate an iteration behind the junction examined (elow 90031 at P[12])
+    elif case == "global_free_vertex_in_reach":
+        g_free = 9
+        log[20] = (True, 90050, 5)                # a later iteration examined coordinate-free vertex 5 <= the highest one committed (8)
+    elif case == "forced_record_inside_the_global_window":
+        kw["wd_forced"] = 70000                   # rejected by the segment (inside its forced window), by the real walk through the global window
+    elif case == "forced_record_below_the_global_window":
+        kw["wd_forced"] = 50000                   # rejected by the segment, ACCEPTED by the real walk (below both of its windows)
+    elif case == "forced_record_in_a_gap_between_the_windows":
+        g_hi = 75000                              # the global window ends below T's: a record at 78000 would fall between them
+        kw["wd_forced"] = 78000
+    elif case == "record_below_the_forced_window_inside_the_global_one":
+        kw["wd_below"] = 65000                    # accepted by the segment (below its window), rejected by the real walk (global window)
+    got = stitch_kept(lib, T, [10, 10], P, (1, 2, g_lo, g_hi, g_free), leap=True, log=log, **kw)
+    assert (got[0], got[2]) == (decision, why), (case, got)
