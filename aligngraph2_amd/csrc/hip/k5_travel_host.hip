@@ -1586,7 +1586,13 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             for (int q = 0; q < 32; ++q) __builtin_ia32_pause();
         }
     };
-    while (n_live) {
+    // Contigs whose round is decided and not yet chosen / spliced / re-seeded.  While jobs are in flight they are taken a few at
+    // a time, those that go on to another round first: the copy of a finished contig's walk (hundreds of thousands of vertices
+    // out of pinned memory) keeps this thread — the one every chain waits for — away from the jobs that finish meanwhile; in
+    // the last third of the walks, when the contigs that leapt finish in batches of a dozen, a job of a contig still walking
+    // used to wait 10 - 15 ms for its turn.
+    std::vector<uint32_t> over_queue;
+    while (n_live || !over_queue.empty()) {
         // ---- jobs that have finished since the last look
         std::vector<uint32_t> fin;
         for (uint32_t ring = 0; ring < NR; ++ring) {
@@ -1618,7 +1624,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             }
             t_first_fin = 0;
         }
-        if (fin.empty()) {
+        if (fin.empty() && over_queue.empty()) {
             // waves that found nothing to do have left (k_walk_persistent): jobs that are outstanding get new ones
             if ((rc = walkers.ensure(n_live))) return fail(rc);
             const double idle_limit_ms = cfg.idle_limit_ms;
@@ -1787,7 +1793,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             const TravJobOut o = houts[slot];
             RoundState &R = RS[jr.ctg];
             if (jr.kind != 1) {  // the new part of a chain's path
-                extend_chain(R.chains[(size_t)jr.idx], G2.v, G2.s, G2.pc, (size_t)G2.len, nullptr, G2.agg, 0);
+                extend_chain(R.chains[(size_t)jr.idx], G2.v, G2.s, G2.pc, (size_t)G2.len, nullptr, G2.agg, 0, hjobs[slot].J.seq_v + G2.from, hjobs[slot].J.seq_s + G2.from);
                 continue;
             }
             Seg &sg = R.segs[(size_t)jr.idx];
@@ -1799,6 +1805,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             sg.P.n = (size_t)G2.len;
             sg.P.agg = G2.agg;
             sg.P.xagg = G2.xagg;
+            sg.P.dv = hjobs[slot].J.seq_v + G2.from;
+            sg.P.ds = hjobs[slot].J.seq_s + G2.from;
             // (a coordinate-free vertex cannot happen while leaping is off; never adopt such a path)
             if (!sg.leap && range_agg(sg.P.v, sg.P.s, sg.P.pc, sg.P.agg, 0, sg.P.n).lo_all == 0u) sg.usable = false;
             if (sg.leap) {
@@ -1846,15 +1854,29 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         lap("stitch");
 
         // ---- contigs whose chains are all final: the round is decided
-        std::vector<uint32_t> batch;
         for (uint32_t i : touched) {
             RoundState &R = RS[i];
             if (!R.active) continue;
             bool all = true;
             for (auto &ch : R.chains) all = all && ch.final;
-            // (segment jobs still waiting or walking become orphans — unless the round's buffers are per-contig slots, which the
-            // next round takes over: such a round waits for them)
-            if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs))) batch.push_back(i);
+            // (segment jobs still waiting or walking stay with the contig or become orphans — unless the round's buffers are
+            // per-contig slots, which the next round takes over: such a round waits for them)
+            if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs)) && std::find(over_queue.begin(), over_queue.end(), i) == over_queue.end())
+                over_queue.push_back(i);
+        }
+        std::vector<uint32_t> batch;
+        {
+            auto leaps = [&](uint32_t i) {  // the round ended on another contig: the contig is finished (PAlgorithm.cpp:254-262, 322-328)
+                for (const Chain &ch : RS[i].chains) {
+                    const uint32_t last_ctg = ch.len == 0 ? 0u : ch.parts.back().pc[ch.parts.back().n - 1];
+                    if (last_ctg != 0 && mapper.singleToDual(last_ctg).first != st[i].chosenOne) return true;
+                }
+                return false;
+            };
+            const size_t take = n_live ? std::min<size_t>(over_queue.size(), 2) : over_queue.size();
+            std::stable_partition(over_queue.begin(), over_queue.end(), [&](uint32_t i) { return !leaps(i); });
+            batch.assign(over_queue.begin(), over_queue.begin() + (long)take);
+            over_queue.erase(over_queue.begin(), over_queue.begin() + (long)take);
         }
         flush_backlog();
         if (batch.empty()) {

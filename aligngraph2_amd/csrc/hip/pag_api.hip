@@ -238,7 +238,6 @@ void pag_destroy(pag_graph *g) {
     if (g->wq_next) hipFree(g->wq_next);
     for (hipStream_t ws : g->walk_streams) hipStreamDestroy(ws);
     if (g->solid_bits) hipFree(g->solid_bits);
-    if (g->side_stream) hipStreamDestroy(g->side_stream);
     if (g->stream) hipStreamDestroy(g->stream);
     delete g;
 }
@@ -447,48 +446,20 @@ int build_stage(pag_graph *g, uint32_t eps, const Extracted &x, pag_build_stats 
     if ((rc = b_ev1.alloc((E + 1) * 12))) return rc;
     PAG_HIP_TRY(hipEventRecord(ev[0], s));
 
-    // ---- K2 sorts.  The two streams are independent: the edge stream is sorted on a stream of its own, by a host thread of its
-    // own (sort_pairs times its passes and returns when they are done), so that its histogram / scan launches — small, short,
-    // 8 KB of LDS — run beside the other stream's scatter pass (persistent blocks, 141 KB of LDS each: two scatter kernels
-    // never share a CU, a scatter and a histogram do).  PAG_SORT_OVERLAP=0: one after the other on the handle's stream.
-    DevBuf b_sorttmp(g, 38), b_sorttmp2(g, 39);
-    if ((rc = b_sorttmp.alloc(sort_tmp_bytes(T))) || (rc = b_sorttmp2.alloc(sort_tmp_bytes(E)))) return rc;
+    // ---- K2 sorts.  (Measured in round 4 and not kept: the edge stream's sort on a stream and a host thread of its own, so that
+    // its histogram / scan launches run beside the other stream's scatter pass — the sort stage took the same 24.6 ms, two
+    // persistent scatter kernels never share a CU, and the step was 30 ms slower.)
+    DevBuf b_sorttmp(g, 38);
+    if ((rc = b_sorttmp.alloc(sort_tmp_bytes(std::max(T, E))))) return rc;
     int t_in0 = 1, e_in0 = 1, passes = 0;
     float ms_scatter_t = 0.f, ms_scatter_e = 0.f;
-    static const bool overlap = !(std::getenv("PAG_SORT_OVERLAP") && std::atoi(std::getenv("PAG_SORT_OVERLAP")) == 0);
-    if (overlap && T && E) {
-        if (!g->side_stream) PAG_HIP_TRY(hipStreamCreateWithFlags(&g->side_stream, hipStreamNonBlocking));
-        hipStream_t s2 = g->side_stream;
-        PAG_HIP_TRY(hipStreamWaitEvent(s2, ev[0], 0));  // (the extraction that filled the edge stream)
-        int rc2 = PAG_OK;
-        std::string err2;
-        const int dev = g->device;
-        std::thread edge_sort([&]() {
-            if (hipSetDevice(dev) != hipSuccess) {
-                rc2 = PAG_EFAULT;
-                return;
-            }
-            rc2 = sort_pairs(b_ek0.as<uint32_t>(), b_ev0.as<uint64_t>(), b_ek1.as<uint32_t>(), b_ev1.as<uint64_t>(), E, 2 * (int)g->k, b_sorttmp2.p, &e_in0, s2,
-                             &ms_scatter_e, nullptr);
-            if (rc2) err2 = last_error();  // (the message is thread-local)
-        });
-        rc = sort_pairs(b_tk0.as<uint32_t>(), b_tv0.as<uint64_t>(), b_tk1.as<uint32_t>(), b_tv1.as<uint64_t>(), T, 2 * (int)g->k, b_sorttmp.p, &t_in0, s,
-                        &ms_scatter_t, &passes);
-        edge_sort.join();
-        if (rc) return rc;
-        if (rc2) {
-            set_error("%s", err2.empty() ? "sort of the edge stream failed" : err2.c_str());
-            return rc2;
-        }
-    } else {
-        if ((rc = sort_pairs(b_tk0.as<uint32_t>(), b_tv0.as<uint64_t>(), b_tk1.as<uint32_t>(), b_tv1.as<uint64_t>(), T,
-                             2 * (int)g->k, b_sorttmp.p, &t_in0, s, &ms_scatter_t, &passes)))
-            return rc;
-        if ((rc = sort_pairs(b_ek0.as<uint32_t>(), b_ev0.as<uint64_t>(), b_ek1.as<uint32_t>(), b_ev1.as<uint64_t>(), E,
-                             2 * (int)g->k, b_sorttmp2.p, &e_in0, s, &ms_scatter_e, nullptr)))
-            return rc;
-    }
-    PAG_HIP_TRY(hipEventRecord(ev[1], s));  // (both sorts are done: sort_pairs returns after its stream has drained)
+    if ((rc = sort_pairs(b_tk0.as<uint32_t>(), b_tv0.as<uint64_t>(), b_tk1.as<uint32_t>(), b_tv1.as<uint64_t>(), T,
+                         2 * (int)g->k, b_sorttmp.p, &t_in0, s, &ms_scatter_t, &passes)))
+        return rc;
+    if ((rc = sort_pairs(b_ek0.as<uint32_t>(), b_ev0.as<uint64_t>(), b_ek1.as<uint32_t>(), b_ev1.as<uint64_t>(), E,
+                         2 * (int)g->k, b_sorttmp.p, &e_in0, s, &ms_scatter_e, nullptr)))
+        return rc;
+    PAG_HIP_TRY(hipEventRecord(ev[1], s));
     // make the sorted data live in the (k0, v0)-sized buffers, the spare (v1: 12 B/record) is scratch
     DevBuf *tk = t_in0 ? &b_tk0 : &b_tk1, *tv = t_in0 ? &b_tv0 : &b_tv1;
     DevBuf *ek = e_in0 ? &b_ek0 : &b_ek1, *evb = e_in0 ? &b_ev0 : &b_ev1;

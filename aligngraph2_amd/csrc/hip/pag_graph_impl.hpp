@@ -8,7 +8,6 @@
 struct pag_graph {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;  // the edge stream's sort runs beside the position stream's (build_stage)
     uint32_t k = 0;
     uint64_t n_solid = 0;
     int all_solid = 0;

@@ -63,6 +63,7 @@ struct View {  // a finished job's path where the fetch put it (pinned memory ke
     const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: iteration log, low / high words
     size_t n = 0;
     const uint32_t *agg = nullptr, *xagg = nullptr;  // block tables of the arrays above (null: none, every entry is read)
+    const uint32_t *dv = nullptr, *ds = nullptr;     // where v / s lie on the DEVICE (the job's sequence buffers; null: unknown)
 };
 struct Seg {  // one segment job of a round
     uint32_t x = 0;      // checkpoint coordinate
@@ -92,6 +93,7 @@ struct Chain {  // one graphTravel: (contig, seed) of the running round
         uint32_t mx, m0;
         const uint32_t *agg;  // block table of the fetched path the part is a stretch of (null: none) ...
         size_t org;           // ... in which the part begins at entry `org`
+        const uint32_t *dv = nullptr, *ds = nullptr;  // the part's vertices / steps on the DEVICE (null: unknown)
     };
     std::vector<Part> parts;
     size_t len = 0;  // vertices of T
@@ -205,9 +207,9 @@ inline void range_xagg(const uint32_t *xl, const uint32_t *xh, const uint32_t *x
 
 // (agg, org: the block table of the fetched path the new part is a stretch of, and the entry it begins at)
 inline void extend_chain(Chain &ch, const uint32_t *v, const uint32_t *sv, const uint32_t *pc, size_t n, const PartAgg *known = nullptr,
-                         const uint32_t *agg = nullptr, size_t org = 0) {
+                         const uint32_t *agg = nullptr, size_t org = 0, const uint32_t *dv = nullptr, const uint32_t *ds = nullptr) {
     if (n == 0) return;
-    ch.parts.push_back(Chain::Part{v, sv, pc, n, ch.len, ch.mx_all, ch.m0_all, agg, org});
+    ch.parts.push_back(Chain::Part{v, sv, pc, n, ch.len, ch.mx_all, ch.m0_all, agg, org, dv, ds});
     ch.len += n;
     PartAgg a;
     if (known) {
@@ -374,7 +376,8 @@ inline int try_merge(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t *adop
     }
     if (low <= dmax + sg.max_back + M.deviation) return 0;
     if (last == be && last + 1 < P.n) return 0;
-    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1);
+    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1, P.dv ? P.dv + (be + 1) : nullptr,
+                 P.ds ? P.ds + (be + 1) : nullptr);
     if (adopted) *adopted += last - be;
     return last + 1 == P.n ? 1 : 2;
 }
@@ -469,7 +472,8 @@ inline int try_merge_leap(const MergeCtx &M, Chain &ch, const Seg &sg, uint64_t 
     if (elow <= dmax) return refuse(6);
     if (d0 != 0u && m0 != 0xFFFFFFFFu && m0 + 1u <= d0) return refuse(7);
     const size_t last = P.n - 1;
-    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1);
+    extend_chain(ch, P.v + (be + 1), P.s + (be + 1), P.pc + (be + 1), last - be, &agg, P.agg, be + 1, P.dv ? P.dv + (be + 1) : nullptr,
+                 P.ds ? P.ds + (be + 1) : nullptr);
     if (adopted) *adopted += last - be;
     if (why_out) *why_out = -1;
     return 1;
