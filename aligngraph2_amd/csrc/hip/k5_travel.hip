@@ -2969,6 +2969,22 @@ void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t 
                              hipStream_t s) {
     if (len) k_gather_path<<<dim3(grid_for(len)), dim3(256), 0, s>>>(G, seq_v, seq_s, len, out);
 }
+// blockIdx.y = the part; the blocks of a row stride over its entries
+__global__ void __launch_bounds__(256) k_concat_parts(const TravConcatPart *__restrict__ parts, uint32_t *__restrict__ out_v,
+                                                      uint32_t *__restrict__ out_s, uint32_t first_step) {
+    const TravConcatPart P = parts[blockIdx.y];
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < P.n; x += (uint64_t)gridDim.x * blockDim.x) {
+        out_v[P.start + x] = P.v[x];
+        out_s[P.start + x] = (P.start + x == 0) ? first_step : P.s[x];
+    }
+}
+void trav_launch_concat_parts(const TravConcatPart *parts, uint32_t n_parts, uint32_t *out_v, uint32_t *out_s, uint32_t first_step,
+                              hipStream_t s) {
+    for (uint32_t at = 0; at < n_parts; at += 32768) {
+        const uint32_t n = std::min<uint32_t>(32768, n_parts - at);
+        k_concat_parts<<<dim3(16, n), dim3(256), 0, s>>>(parts + at, out_v, out_s, first_step);
+    }
+}
 void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s) {
     if (n) k_gather_vertices<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(G, vids, n, out);
 }

@@ -137,6 +137,14 @@ struct CtgState {
     uint32_t parentCode = 0;  // k-mer of the last contig-consistent path vertex (seed ordering key)
     uint32_t parentU = 0;     // ... that vertex (new id)
     bool haveParent = false;
+    // The last round of a contig that leaps (the contig is finished by it): its walk never comes to `travel` — the parts are
+    // put one behind the other on the device, behind room for what `travel` holds, and delivered from there.
+    struct DevTail {
+        bool on = false;
+        uint32_t *d_ids = nullptr;  // ids at [0, cap), steps at [cap, 2 cap); the tail from entry m0 on
+        size_t cap = 0, m0 = 0, n = 0;
+        uint32_t last_ctg = 0;      // coordinate of the tail's last vertex (the "Pump it" test)
+    } tail;
 };
 
 uint64_t pow2_at_least(uint64_t x) {
@@ -1508,6 +1516,11 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     lap("round prep");
 
     // filterSequence / "Pump it" of a finished contig (PAlgorithm.cpp:409-423)
+    auto pumped = [&](const CtgState &cs, uint32_t last_ctg) {  // the last vertex of a path that ends in a leap is dropped?
+        auto d = mapper.singleToDual(last_ctg);
+        uint64_t a = (uint64_t)std::llabs(d.first);
+        return a == (uint64_t)cs.ci + 1 || (a >= 1 && a <= mapper.sizes.size() && (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit));
+    };
     auto filter_travel = [&](CtgState &cs) {
         auto &seq = cs.travel;
         if (!cs.finalLeap) {
@@ -1524,11 +1537,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 }
             }
         } else if (!seq.empty()) {
-            auto d = mapper.singleToDual(seq.back().ctg);
-            uint64_t a = (uint64_t)std::llabs(d.first);
-            if (a == (uint64_t)cs.ci + 1 || (a >= 1 && a <= mapper.sizes.size() &&
-                                             (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit)))
-                seq.pop_back();
+            if (pumped(cs, seq.back().ctg)) seq.pop_back();
         }
     };
     // A contig whose traversal is over is DELIVERED while the others still walk: its sequence is filtered, the full records of
@@ -1539,6 +1548,31 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         CtgState &cs = st[i];
         const bool early = cfg.deliver_early;
         if (cs.delivered || !cs.done || !early) return PAG_OK;
+        if (cs.tail.on) {  // (a path that ends in a leap: finalLeap, nothing but the last vertex to filter)
+            const CtgState::DevTail &T = cs.tail;
+            const size_t m0 = T.m0, m = m0 + T.n - (pumped(cs, T.last_ctg) ? 1 : 0);
+            const size_t slot2 = 2 * (size_t)cs.ci + (cs.forward ? 0 : 1);
+            cs.delivered = true;
+            g->path_off[slot2] = 0;
+            g->path_len[slot2] = m;
+            g->path_valid[slot2] = 1;
+            if (m == 0) return PAG_OK;
+            pag_path_node *dst = (pag_path_node *)fetch_alloc(m * sizeof(pag_path_node));
+            if (!dst) return PAG_ENOMEM;
+            if (m0) {
+                uint32_t *hp = (uint32_t *)fetch_alloc(m0 * 8);
+                if (!hp) return PAG_ENOMEM;
+                for (size_t x = 0; x < m0; ++x) {
+                    hp[x] = cs.travel[x].u;
+                    hp[m0 + x] = (uint32_t)cs.travel[x].step;
+                }
+                PAG_HIP_TRY(hipMemcpyAsync(T.d_ids, hp, m0 * 4, hipMemcpyHostToDevice, g->deliver_stream));
+                PAG_HIP_TRY(hipMemcpyAsync(T.d_ids + T.cap, hp + m0, m0 * 4, hipMemcpyHostToDevice, g->deliver_stream));
+            }
+            trav_launch_gather_path(G, T.d_ids, T.d_ids + T.cap, m, dst, g->deliver_stream);
+            g->path_ptr[slot2] = dst;
+            return PAG_OK;
+        }
         const size_t n = cs.travel.size();
         const size_t need = ((n * 8 + 255) & ~(size_t)255) + 512;
         if (!g->walk_arena || g->walk_arena_used + need > g->walk_arena_cap) return PAG_OK;
@@ -1873,7 +1907,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 }
                 return false;
             };
-            const size_t take = n_live ? std::min<size_t>(over_queue.size(), 2) : over_queue.size();
+            const size_t take = n_live && cfg.pace ? std::min<size_t>(over_queue.size(), cfg.pace) : over_queue.size();
             std::stable_partition(over_queue.begin(), over_queue.end(), [&](uint32_t i) { return !leaps(i); });
             batch.assign(over_queue.begin(), over_queue.begin() + (long)take);
             over_queue.erase(over_queue.begin(), over_queue.begin() + (long)take);
@@ -1918,9 +1952,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                     }
                 }
                 if (P.chosen >= 0) {
-                    P.off = tot;
                     P.len = R.chains[(size_t)P.chosen].len;
-                    tot += P.len;
+                    tot += P.len;  // (an upper bound: walks that stay on the device take no room, see below)
                 }
                 if (wdebug && P.chosen >= 0) {
                     const Chain &ch = R.chains[(size_t)P.chosen];
@@ -1954,6 +1987,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             };
             std::vector<CopyChunk> chunks;
             const size_t CHUNK = 1u << 17;
+            uint64_t used = 0;
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
                 if (P.chosen < 0 || P.len == 0) continue;
@@ -1969,8 +2003,31 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 }
                 if (!base.empty()) dist = (int32_t)(head_ctg - base.back().ctg);
                 const size_t at0 = base.size();
+                if (P.leap && cfg.device_tail && cfg.deliver_early && !RS[i].slot_bufs && g->walk_arena) {
+                    // the contig is finished by this walk (splice below): nothing of it is needed on the host
+                    bool on_dev = true;
+                    for (const Chain::Part &pt : ch.parts) on_dev = on_dev && pt.dv && pt.ds;
+                    const size_t cap = at0 + P.len, need = (cap * 8 + 255) & ~(size_t)255;
+                    TravConcatPart *cp = on_dev && g->walk_arena_used + need <= g->walk_arena_cap ? (TravConcatPart *)fetch_alloc(ch.parts.size() * sizeof(TravConcatPart)) : nullptr;
+                    if (cp) {
+                        CtgState::DevTail &T = cs.tail;
+                        T.on = true;
+                        T.d_ids = (uint32_t *)((char *)g->walk_arena + g->walk_arena_used);
+                        g->walk_arena_used += need;
+                        T.cap = cap;
+                        T.m0 = at0;
+                        T.n = P.len;
+                        T.last_ctg = ch.parts.back().pc[ch.parts.back().n - 1];
+                        for (size_t x = 0; x < ch.parts.size(); ++x) cp[x] = TravConcatPart{ch.parts[x].dv, ch.parts[x].ds, ch.parts[x].start, ch.parts[x].n};
+                        if (!g->deliver_stream && hipStreamCreateWithFlags(&g->deliver_stream, hipStreamNonBlocking) != hipSuccess) return fail(PAG_EFAULT);
+                        trav_launch_concat_parts(cp, (uint32_t)ch.parts.size(), T.d_ids + at0, T.d_ids + cap + at0, (uint32_t)dist, g->deliver_stream);
+                        continue;
+                    }
+                }
                 base.resize(at0 + P.len);
                 LNode *dst = base.data() + at0;
+                picks[i].off = used;
+                used += P.len;
                 uint32_t *ids = hp + P.off;
                 for (const Chain::Part &pt : ch.parts)
                     for (size_t x0 = 0; x0 < pt.n; x0 += CHUNK)
@@ -2014,13 +2071,13 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 if (!C.outside.empty()) st[C.i].outsideU.insert(st[C.i].outsideU.end(), C.outside.begin(), C.outside.end());
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
-                if (P.chosen < 0 || P.len == 0) continue;
+                if (P.chosen < 0 || P.len == 0 || st[i].tail.on) continue;
                 st[i].travel[st[i].pendingFirst].step = st[i].pendingFirstStep;
             }
-            if (tot) hipMemcpyAsync(b_gather.p, hp, tot * 4, hipMemcpyHostToDevice, s);
+            if (used) hipMemcpyAsync(b_gather.p, hp, used * 4, hipMemcpyHostToDevice, s);
             for (uint32_t i : batch) {
                 const Pick &P = picks[i];
-                if (P.chosen < 0 || P.len == 0) continue;
+                if (P.chosen < 0 || P.len == 0 || st[i].tail.on) continue;
                 CtgState &cs = st[i];
                 // globalUniqueTable on the device: its hash set (vertices outside the strand's id range) grows as needed
                 if ((uint64_t)cs.outsideU.size() * 2 > cs.gcap) {
@@ -2238,6 +2295,11 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
                      (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted.load(), (unsigned long long)n_leap_refused[0].load(), (unsigned long long)n_leap_refused[1].load(), (unsigned long long)n_leap_refused[2].load(),
                      (unsigned long long)n_leap_refused[3].load(), (unsigned long long)n_leap_refused[4].load(), (unsigned long long)n_leap_refused[5].load(), (unsigned long long)n_leap_refused[6].load(), (unsigned long long)n_leap_refused[7].load());
+        {
+            size_t n_tail = 0, n_tail_behind = 0;
+            for (const CtgState &cs : st) n_tail += cs.tail.on, n_tail_behind += cs.tail.on && cs.tail.m0;
+            std::fprintf(stderr, "[timing] last rounds put together on the device: %zu of %u contigs (%zu behind an earlier round's path)\n", n_tail, n_sel, n_tail_behind);
+        }
         std::fprintf(stderr, "[timing] pieces: %llu segment jobs, %llu resume jobs, %llu vertices adopted, %llu segments not adoptable\n", (unsigned long long)n_seg_jobs,
                      (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted.load(), (unsigned long long)n_merge_fail.load());
     }

@@ -210,5 +210,14 @@ int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const 
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
                              hipStream_t s);
 void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s);
+// the parts of a chosen walk, lying in the sequence buffers of the jobs that walked them, put one behind the other
+// (out_v / out_s + TravConcatPart::start); the step of the very first vertex becomes first_step.  `parts` may be pinned
+// host memory.
+struct TravConcatPart {
+    const uint32_t *v, *s;
+    uint64_t start, n;
+};
+void trav_launch_concat_parts(const TravConcatPart *parts, uint32_t n_parts, uint32_t *out_v, uint32_t *out_s, uint32_t first_step,
+                              hipStream_t s);
 
 }  // namespace pagdev

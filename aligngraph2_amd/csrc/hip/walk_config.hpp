@@ -42,6 +42,8 @@ struct WalkConfig {
     uint32_t post_interleave = 8;     // PAG_POST_INTERLEAVE
     // ---- delivery of results
     bool deliver_early = true;        // PAG_DELIVER_EARLY
+    bool device_tail = true;          // PAG_DEVICE_TAIL: the last round of a contig that leaps is put together on the device
+    unsigned pace = 0;                // PAG_WALK_PACE: decided rounds taken per look at the rings while jobs are live (0: all; measured: no gain)
     bool fetch_direct = true;         // PAG_FETCH_DIRECT
     bool fetch_tables = true;         // PAG_FETCH_TABLES
     unsigned take_threads = 1;        // PAG_TAKE_THREADS
@@ -86,6 +88,8 @@ struct WalkConfig {
         if (u64("PAG_LEAP_END_DIV", &c.leap_end_div)) c.leap_end_div = std::max<uint64_t>(1, c.leap_end_div);
         if (const char *e = std::getenv("PAG_POST_INTERLEAVE")) c.post_interleave = (uint32_t)std::atoi(e);
         c.deliver_early = !off("PAG_DELIVER_EARLY");
+        c.device_tail = !off("PAG_DEVICE_TAIL");
+        if (const char *e = std::getenv("PAG_WALK_PACE")) c.pace = (unsigned)std::max(0, std::atoi(e));
         c.fetch_direct = !off("PAG_FETCH_DIRECT");
         c.fetch_tables = !off("PAG_FETCH_TABLES");
         if (const char *e = std::getenv("PAG_TAKE_THREADS")) c.take_threads = (unsigned)std::max(1, std::atoi(e));

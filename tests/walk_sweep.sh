@@ -7,9 +7,10 @@ print('$name', round(d['ms_per_step'],1), 'walks', round(c['ms_walks_wall'],1), 
 " >> gpurun_out/r04h/sweep2.txt; }
 rm -f gpurun_out/r04h/sweep2.txt
 run base A=1
+run host_tail PAG_DEVICE_TAIL=0
+run pace0 PAG_WALK_PACE=0
+run pace0_host_tail PAG_WALK_PACE=0 PAG_DEVICE_TAIL=0
+run pace4 PAG_WALK_PACE=4
 run take4 PAG_TAKE_THREADS=4
-run take8 PAG_TAKE_THREADS=8
-run take4_host8 PAG_TAKE_THREADS=4 PAGH_OVERLAP_THREADS=8
-run nokeep PAG_WALK_KEEP_SEGMENTS=0
 run base2 A=1
 cat gpurun_out/r04h/sweep2.txt
