@@ -61,6 +61,8 @@ def load_hip():
         lib.pag_destroy.argtypes = [vp]
         lib.pag_destroy.restype = None
         lib.pag_csr_sizes.argtypes = [vp, u64p, u64p, u64p]
+        lib.pag_export_csr.argtypes = [vp, vp]
+        lib.pag_export_csr.restype = C.c_int
         lib.pag_travel.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp]
         lib.pag_travel.restype = C.c_int
         lib.pag_travel_prepare.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]

@@ -238,6 +238,60 @@ __device__ __forceinline__ int d_check_position(uint32_t ac, uint32_t ar, uint32
     return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
 }
 
+// The ratio test as a table: for a given dist the coordinate differences D that pass d_ratio_ok are an interval (a
+// correctly rounded division is monotonic in its dividend, so are 1 - x and fabs on either side of 1), [lo, lo + rng],
+// found by trying d_ratio_ok itself on the few integers around (1 -+ err) dist.  Entry = lo | rng << 16; RATIO_TAB_NONE:
+// no entry (dist 0 — nothing passes — or an interval that was not pinned down): the caller uses d_ratio_ok.  With the
+// table a candidate pair costs integer compares only; the successor kernels, which run this predicate over five billion
+// pairs per block at configs[1] and were bound by their vector instruction issue (SQ counters, profiles/r03_pmc_kernel_mix.json),
+// keep it in LDS.
+#define RATIO_TAB_N 1024u
+#define RATIO_TAB_NONE 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t d_ratio_entry(uint32_t dist, double err) {
+    if (dist == 0u) return RATIO_TAB_NONE;
+    const double ds = (double)dist;
+    const int64_t e0 = (int64_t)((1.0 - err) * ds), e1 = (int64_t)((1.0 + err) * ds);
+    int64_t lo = -1, hi = -1;
+    for (int64_t D = e0 > 3 ? e0 - 3 : 0; D <= e0 + 3; ++D)
+        if (d_ratio_ok((uint32_t)D, (int)dist, err)) {
+            lo = D;
+            break;
+        }
+    for (int64_t D = e1 + 3; D >= (e1 > 3 ? e1 - 3 : 0); --D)
+        if (d_ratio_ok((uint32_t)D, (int)dist, err)) {
+            hi = D;
+            break;
+        }
+    // the interval must have been bracketed on both sides (the first D tried at either end fails) and fit the entry
+    const bool lo_ok = lo >= 0 && (lo == 0 || lo > (e0 > 3 ? e0 - 3 : 0)), hi_ok = hi >= 0 && hi < e1 + 3;
+    if (!lo_ok || !hi_ok || hi < lo || lo > 0xFFFF || hi - lo > 0xFFFE) return RATIO_TAB_NONE;
+    return (uint32_t)lo | ((uint32_t)(hi - lo) << 16);
+}
+__device__ __forceinline__ void d_ratio_table_fill(uint32_t *tab, double err) {  // (all threads of the block; __syncthreads after it)
+    for (uint32_t d = threadIdx.x; d < RATIO_TAB_N; d += blockDim.x) tab[d] = d_ratio_entry(d, err);
+}
+// d_check_position with the two ratio tests given by a table entry (never RATIO_TAB_NONE)
+__device__ __forceinline__ int d_check_position_tab(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev,
+                                                    uint32_t entry, uint32_t *edge_sim) {
+    const uint32_t lo = entry & 0xFFFFu, rng = entry >> 16;
+    const bool q1 = (uint32_t)(bc - ac - lo) <= rng, q2 = (uint32_t)(br - ar - lo) <= rng;
+    const uint32_t tc = ac != 0 ? ac + dist : 0, tr = ar != 0 ? ar + dist : 0;
+    bool s1 = d_coord_sim(tc, bc, dev) || (ac != 0 && bc != 0 && q1);
+    bool s2 = d_coord_sim(tr, br, dev) || (ar != 0 && br != 0 && q2);
+    *edge_sim = (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
+    s1 = s1 || q1;
+    s2 = s2 || q2;
+    if (ac == 0 || bc == 0) return s2 ? (bc != 0 ? G_EXCELLENT : (ac != 0 ? G_SKIP : G_GOOD)) : G_OOPS;
+    if (ar == 0 || br == 0) return s1 ? (br != 0 ? G_EXCELLENT : G_GOOD) : G_OOPS;
+    return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
+}
+// ... for any dist: through the table (LDS) where it has an entry
+__device__ __forceinline__ int d_check_position_any(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev, double err,
+                                                    uint32_t entry, uint32_t *edge_sim) {
+    return entry != RATIO_TAB_NONE ? d_check_position_tab(ac, ar, bc, br, dist, dev, entry, edge_sim)
+                                   : d_check_position(ac, ar, bc, br, dist, dev, err, edge_sim);
+}
+
 // =================================================================================================
 // visited sets
 // =================================================================================================
@@ -333,8 +387,16 @@ __global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uin
 // `mask` which of the first 64 candidates they are.  WHAT = 1: write the accepted ones to out[0 ..] — the first 64
 // candidates through `mask` (nine in ten candidates are rejects: only the accepted ones are touched again), the rest
 // evaluated again.  WHAT = 2: evaluate every candidate once and write the accepted ones as they come.  Returns their number.
+// four / two consecutive entries with one load instruction (4- resp. 8-byte aligned addresses: the hardware takes them; the
+// counting pass issues a load per candidate otherwise, and with some twenty k-mer nodes per wave every load instruction is
+// twenty requests to the L1 — what the pass was bound by, not its arithmetic)
+struct __attribute__((packed, aligned(4))) U32x4 { uint32_t a[4]; };
+struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a[2]; };
+struct __attribute__((packed, aligned(8))) U64x4 { uint64_t a[4]; };
 template <int WHAT>
-__device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out) {
+#define SUCC_HEAVY 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out,
+                                                const uint32_t *__restrict__ ratio_tab, uint32_t heavy_limit = 0xFFFFFFFFu) {
     constexpr int MODE = WHAT;  // (0 counts, 1 fills through the mask, 2 writes while it evaluates)
     const uint64_t rootp = G.vpos[v];
     const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
@@ -354,21 +416,27 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
       // (targets and position ranges of up to four edges requested together: two round trips for the four; k_succ<0>
       // 36 -> 34 ms, k_succ<1> 49 -> 46 ms)
       uint32_t to4[4], st4[4], p04[4], q4[4];
+      const U32x4 toL = *(const U32x4 *)(G.eto + eb), stL = *(const U32x4 *)(G.estep + eb);  // (the arrays are padded by four entries)
 #pragma unroll
       for (uint32_t t = 0; t < 4u; ++t) {
           const bool have = eb + t < e_hi;
-          to4[t] = have ? G.eto[eb + t] : PAG_NONE;
-          st4[t] = have ? G.estep[eb + t] : 0u;
+          to4[t] = have ? toL.a[t] : PAG_NONE;
+          st4[t] = have ? stL.a[t] : 0u;
       }
 #pragma unroll
       for (uint32_t t = 0; t < 4u; ++t) {
-          p04[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t]] : 0u;
-          q4[t] = to4[t] != PAG_NONE ? G.npos_off[to4[t] + 1] - p04[t] : 0u;
+          const U32x2 r = *(const U32x2 *)(G.npos_off + (to4[t] != PAG_NONE ? to4[t] : 0u));
+          p04[t] = to4[t] != PAG_NONE ? r.a[0] : 0u;
+          q4[t] = to4[t] != PAG_NONE ? r.a[1] - r.a[0] : 0u;
       }
 #pragma unroll
       for (uint32_t t4 = 0; t4 < 4u; ++t4) {
         const uint32_t step = st4[t4], p0 = p04[t4], q = q4[t4];
         if (q == 0u) continue;
+        // a vertex with more candidates than the limit is left to a whole wave (k_succ_heavy): the lanes of a wave here run as
+        // long as the one with the longest lists
+        if (q > heavy_limit || base + q > heavy_limit) return SUCC_HEAVY;
+        const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;  // (the ratio tests of this edge, see d_ratio_entry)
         uint32_t j0 = 0;
         if (MODE == 1 && amask) {  // the candidates the mask covers: accepted ones only
             const uint32_t lim = base < 64u ? (q < 64u - base ? q : 64u - base) : 0u;
@@ -378,7 +446,7 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
                 sub &= sub - 1ull;
                 const uint64_t pp = G.vpos[p];
                 uint32_t esim;
-                const int grade = d_check_position(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, &esim);
+                const int grade = d_check_position_any(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, entry, &esim);
                 emit(p, (uint32_t)(pp >> 32), step, grade, esim);
                 ++n;
             }
@@ -391,9 +459,8 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
         // (35.6 ms), four lanes per vertex slower (51 ms), and keeping the first four accepted candidates of every vertex
         // in a side array for the filling pass cost the counting pass more (+14 ms) than it saved the other (-5 ms).
         for (uint32_t jb = j0; jb < q; jb += 4u) {
-            uint64_t pq[4];
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) pq[t] = G.vpos[p0 + (jb + t < q ? jb + t : q - 1u)];
+            const U64x4 pqL = *(const U64x4 *)(G.vpos + p0 + jb);  // (padded by four entries)
+            const uint64_t *pq = pqL.a;
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
                 const uint32_t j = jb + t;
@@ -401,7 +468,7 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
                 const uint32_t p = p0 + j;
                 const uint32_t pc = (uint32_t)(pq[t] >> 32), pr = (uint32_t)pq[t];
                 uint32_t esim;
-                int grade = d_check_position(rc, rr, pc, pr, step, dev, err, &esim);
+                int grade = d_check_position_any(rc, rr, pc, pr, step, dev, err, entry, &esim);
                 if (grade == G_OOPS) continue;
                 if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
                 if (MODE != 0) emit(p, pc, step, grade, esim);
@@ -410,6 +477,47 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
         }
         base += q;
       }
+    }
+    return n;
+}
+
+// ... by a whole wave: 64 candidates of a target node's position list per turn (one coalesced load), the accepted ones counted
+// / placed through the ballot.  WHAT = 0: count + the mask of the first 64 candidates (as succ_vertex<0> leaves it);
+// WHAT = 1: every candidate evaluated again, the accepted ones written in CSR order.  v is the same in all lanes.
+template <int WHAT>
+__device__ __forceinline__ uint32_t succ_vertex_wave(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out,
+                                                     const uint32_t *__restrict__ ratio_tab) {
+    const uint32_t lane = lane_id();
+    const uint64_t rootp = G.vpos[v];
+    const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
+    const uint32_t node = G.vnode[v];
+    uint32_t n = 0, base = 0;
+    const uint32_t e_lo = G.nedge_off[node], e_hi = G.nedge_off[node + 1];
+    for (uint32_t e = e_lo; e < e_hi; ++e) {
+        const uint32_t to = G.eto[e];
+        if (to == PAG_NONE) continue;
+        const uint32_t step = G.estep[e], p0 = G.npos_off[to], q = G.npos_off[to + 1] - p0;
+        const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;
+        for (uint32_t jb = 0; jb < q; jb += 64u) {
+            const uint32_t j = jb + lane;
+            const bool valid = j < q;
+            const uint64_t pp = valid ? G.vpos[p0 + j] : 0ull;
+            const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
+            uint32_t esim = 0;
+            const int grade = valid ? d_check_position_any(rc, rr, pc, pr, step, dev, err, entry, &esim) : (int)G_OOPS;
+            const uint64_t b = __ballot(grade != G_OOPS);
+            if (WHAT == 0 && base + jb < 64u) mask |= b << (base + jb);
+            if (WHAT == 1 && grade != G_OOPS) {
+                SuccRec r;
+                r.tgt = G.newid[p0 + j];
+                r.pc = pc;
+                r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+                r.toff = 0;
+                out[n + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = r;
+            }
+            n += (uint32_t)__popcll(b);
+        }
+        base += q;
     }
     return n;
 }
@@ -426,9 +534,16 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
 // records into coordinate order afterwards (k_succ_place): 82 + 31 ms at configs[1] against 37 + 45 + 6 ms for count, fill
 // and link: the second walk over the candidates is what the fill pass costs, not its scattered writes, and it is no
 // cheaper inside the counting thread.)
+// heavy_list / heavy_n (MODE 0 and 1, may be null): the vertices with more than heavy_limit candidates are left out here — MODE 0
+// appends them to the list — and done by k_succ_heavy, a wave each.
 template <int MODE>
 __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
-                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask) {
+                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask, uint32_t *__restrict__ heavy_list,
+                       unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
+    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    d_ratio_table_fill(ratio_tab, err);
+    __syncthreads();
+    if (!heavy_list || MODE == 2) heavy_limit = 0xFFFFFFFFu;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t n = 0;
         uint64_t mask = 0ull;
@@ -439,7 +554,20 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
         const bool inc = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
         const bool poison = inc && u < G.n_zero, marker = inc && u >= G.n_zero;
         if (poison) n = 1u;
-        else if (MODE == 0) n = succ_vertex<0>(G, v, dev, err, mask, nullptr) + (marker ? 1u : 0u);
+        else if (MODE == 0) {
+            n = succ_vertex<0>(G, v, dev, err, mask, nullptr, ratio_tab, heavy_limit);
+            const bool heavy = n == SUCC_HEAVY;
+            const uint64_t hb = __ballot(heavy);
+            if (hb) {  // (one atomic per wave)
+                const int first = __ffsll((long long)hb) - 1;
+                unsigned long long at = 0;
+                if ((int)lane_id() == first) at = atomicAdd(heavy_n, (unsigned long long)__popcll(hb));
+                at = __shfl(at, first);
+                if (heavy) heavy_list[at + (uint32_t)__popcll(hb & ((1ull << lane_id()) - 1ull))] = (uint32_t)v;
+            }
+            if (heavy) continue;
+            n += marker ? 1u : 0u;
+        }
         SuccRec *out = nullptr;
         if (MODE == 1) out = G.succ + G.succ_off[u];
         if (MODE == 2) out = stage + stage_off[v];
@@ -455,18 +583,53 @@ __global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restri
                 uint32_t m;
                 if (amask) {
                     mask = amask[v];
-                    m = succ_vertex<1>(G, v, dev, err, mask, out);
+                    m = succ_vertex<1>(G, v, dev, err, mask, out, ratio_tab, heavy_limit);
+                    if (m == SUCC_HEAVY) continue;
                 } else {
-                    m = succ_vertex<2>(G, v, dev, err, mask, out);
+                    m = succ_vertex<2>(G, v, dev, err, mask, out, ratio_tab);
                 }
                 if (marker) out[m] = r;
             } else if (MODE == 2) {
-                n = succ_vertex<2>(G, v, dev, err, mask, out);
+                n = succ_vertex<2>(G, v, dev, err, mask, out, ratio_tab);
                 if (marker) out[n++] = r;
             }
         }
         if (MODE != 1) cnt[u] = n;
         if (MODE == 0 && amask) amask[v] = mask;
+    }
+}
+
+// the vertices k_succ left out (more candidates than its limit), a wave each
+template <int MODE>
+__global__ void __launch_bounds__(256) k_succ_heavy(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ amask,
+                                                    const uint32_t *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_n) {
+    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    d_ratio_table_fill(ratio_tab, err);
+    __syncthreads();
+    const uint64_t total = *heavy_n, n_waves = (uint64_t)gridDim.x * (blockDim.x / 64u);
+    for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < total; i += n_waves) {
+        const uint64_t v = heavy_list[i];
+        const uint32_t u = G.newid[v];
+        const bool marker = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);  // (a poisoned vertex never comes here)
+        uint64_t mask = 0ull;
+        if (MODE == 0) {
+            const uint32_t n = succ_vertex_wave<0>(G, v, dev, err, mask, nullptr, ratio_tab) + (marker ? 1u : 0u);
+            if (lane_id() == 0) {
+                cnt[u] = n;
+                amask[v] = mask;
+            }
+        } else {
+            SuccRec *out = G.succ + G.succ_off[u];
+            const uint32_t m = succ_vertex_wave<1>(G, v, dev, err, mask, out, ratio_tab);
+            if (marker && lane_id() == 0) {
+                SuccRec r;
+                r.tgt = u;
+                r.pc = 0u;
+                r.meta = 1u | (GRADE_POISON_IF_LEAP << 24);
+                r.toff = 0;
+                out[m] = r;
+            }
+        }
     }
 }
 
@@ -2931,11 +3094,17 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     return PAG_OK;
 }
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, hipStream_t s) {
+                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
+                    uint32_t heavy_limit, hipStream_t s) {
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
-    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr);
-    else k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask);
+    if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
+    if (heavy_list) PAG_HIP_TRY(hipMemsetAsync(heavy_n, 0, 8, s));
+    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr, nullptr, nullptr, 0u);
+    else {
+        k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
+        if (heavy_list) k_succ_heavy<0><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, cnt, amask, heavy_list, heavy_n);
+    }
     PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
     int rc;
     if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
@@ -2954,12 +3123,14 @@ int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tm
     return PAG_OK;
 }
 int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
-                   uint64_t *amask, hipStream_t s) {
+                   uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s) {
     if (!G.n_pos) return PAG_OK;
+    if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
     if (stage) {
         k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
     } else {
-        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask);
+        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
+        if (heavy_list) k_succ_heavy<1><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, nullptr, amask, heavy_list, heavy_n);
         if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
     }
     PAG_HIP_TRY(hipGetLastError());
@@ -3000,10 +3171,36 @@ __global__ void k_debug_predicates(const uint32_t *__restrict__ rows, uint64_t n
     grade[i] = (uint8_t)d_check_position(r[0], r[1], r[2], r[3], r[4], r[5], err, &es);
     edge_sim[i] = (uint8_t)es;
 }
+// ... the way the successor kernels evaluate them: ratio tests through the LDS table (d_ratio_entry) where the step has an entry
+__global__ void k_debug_predicates_tab(const uint32_t *__restrict__ rows, uint64_t n, double err, uint8_t *__restrict__ grade,
+                                       uint8_t *__restrict__ edge_sim, unsigned long long *__restrict__ n_tab) {
+    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    d_ratio_table_fill(ratio_tab, err);
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *r = rows + 6 * i;
+    uint32_t es = 0;
+    const uint32_t entry = r[4] < RATIO_TAB_N ? ratio_tab[r[4]] : RATIO_TAB_NONE;
+    if (entry != RATIO_TAB_NONE) atomicAdd(n_tab, 1ull);
+    grade[i] = (uint8_t)d_check_position_any(r[0], r[1], r[2], r[3], r[4], r[5], err, entry, &es);
+    edge_sim[i] = (uint8_t)es;
+}
 
 }  // namespace pagdev
 
+static int debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device, uint64_t *n_through_table);
 extern "C" int pag_debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device) {
+    return debug_predicates(rows, n, err, grade, edge_sim, device, nullptr);
+}
+// the same rows through the ratio table of the successor kernels; *n_through_table: how many rows had a table entry
+extern "C" int pag_debug_predicates_tab(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device,
+                                        uint64_t *n_through_table) {
+    if (!n_through_table) return PAG_EINVAL;
+    *n_through_table = 0;
+    return debug_predicates(rows, n, err, grade, edge_sim, device, n_through_table);
+}
+static int debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device, uint64_t *n_through_table) {
     using namespace pagdev;
     if (!rows || !grade || !edge_sim) return PAG_EINVAL;
     if (hipSetDevice(device) != hipSuccess) return PAG_ENODEV;
@@ -3011,15 +3208,19 @@ extern "C" int pag_debug_predicates(const uint32_t *rows, uint64_t n, double err
     uint8_t *d_out = nullptr;
     if (n == 0) return PAG_OK;
     PAG_HIP_TRY(hipMalloc((void **)&d_rows, n * 24));
-    if (hipMalloc((void **)&d_out, 2 * n) != hipSuccess) {
+    if (hipMalloc((void **)&d_out, 2 * n + 16) != hipSuccess) {
         hipFree(d_rows);
         return PAG_ENOMEM;
     }
+    unsigned long long *d_cnt = (unsigned long long *)(d_out + ((2 * n + 7) & ~(uint64_t)7));
     hipError_t e = hipMemcpy(d_rows, rows, n * 24, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, 8);
     if (e == hipSuccess) {
-        k_debug_predicates<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_rows, n, err, d_out, d_out + n);
+        if (n_through_table) k_debug_predicates_tab<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_rows, n, err, d_out, d_out + n, d_cnt);
+        else k_debug_predicates<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_rows, n, err, d_out, d_out + n);
         e = hipDeviceSynchronize();
     }
+    if (e == hipSuccess && n_through_table) e = hipMemcpy(n_through_table, d_cnt, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(grade, d_out, n, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(edge_sim, d_out + n, n, hipMemcpyDeviceToHost);
     hipFree(d_rows);

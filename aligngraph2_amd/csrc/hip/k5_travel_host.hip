@@ -335,8 +335,8 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
     }
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
     if ((rc = b_ncode.alloc((nn + 1) * 4)) || (rc = b_npos.alloc((nn + 2) * 4)) || (rc = b_nedge.alloc((nn + 2) * 4)) ||
-        (rc = b_vpos.alloc((np + 1) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
-        (rc = b_eto.alloc((ne + 1) * 4)) || (rc = b_estep.alloc((ne + 1) * 4)) || (rc = b_bitmap.alloc(n_words * 8)) ||
+        (rc = b_vpos.alloc((np + 4) * 8)) || (rc = b_vcnt.alloc((np + 1) * 2)) || (rc = b_vnode.alloc((np + 1) * 4)) ||
+        (rc = b_eto.alloc((ne + 4) * 4)) || (rc = b_estep.alloc((ne + 4) * 4)) || /* (+ 4: k_succ reads the lists four entries at a time) */ (rc = b_bitmap.alloc(n_words * 8)) ||
         (rc = b_rank.alloc(n_words * 4)) || (rc = b_uold.alloc((np + 1) * 4)) || (rc = b_newid.alloc((np + 1) * 4)) ||
         (rc = b_upos.alloc((np + 1) * 8)) || (rc = b_ucnt.alloc((np + 1) * 4)) || (rc = b_soff.alloc((np + 2) * 4)))
         return rc;
@@ -457,9 +457,12 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         }
         // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
         uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
+        // (the vertices with many candidate pairs, done by a wave each: the list in b_ok1, free since the sort; its length behind the totals)
+        uint32_t *heavy_list = stage ? nullptr : b_ok1.as<uint32_t>();
+        unsigned long long *heavy_n = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 3);
         // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
         if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, s)))
+                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, heavy_list, heavy_n, cfg.succ_heavy, s)))
             return rc;
         PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
         PAG_HIP_TRY(hipStreamSynchronize(s));
@@ -470,12 +473,17 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
         G.succ = b_succ.as<SuccRec>();
         G.n_succ = n_succ;
-        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, s))) return rc;
+        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, heavy_list, heavy_n, cfg.succ_heavy, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         g->tg = G;
         g->tg_dev = deviation;
         g->tg_err = errorRate;
         g->tg_ready = true;
+        if (cfg.timing && heavy_list && cfg.succ_heavy) {
+            unsigned long long nh = 0;
+            hipMemcpy(&nh, heavy_n, 8, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[timing] successor records: %llu of %llu vertices have more than %u candidate pairs (a wave each)\n", nh, (unsigned long long)G.n_pos, cfg.succ_heavy);
+        }
         if (cfg.timing)
             std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%llu without a contig coordinate) of %llu (%s view: %llu of %llu nodes, %llu of %llu edges; %s, %llu candidate pairs)\n",
                          (unsigned long long)n_succ, (unsigned long long)G.n_pos, (unsigned long long)g->n_zero_ctg, (unsigned long long)np, g->view_pruned ? "cut" : "whole", (unsigned long long)G.n_nodes,

@@ -203,10 +203,13 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
 // bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
 int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s);
+// (heavy_list [n_pos] / heavy_n: the two-pass path hands the vertices with more than heavy_limit candidate pairs to a wave each;
+// the counting pass fills the list, the filling pass reads it.  heavy_limit 0 or null pointers: every vertex by its own thread)
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, hipStream_t s);
+                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
+                    uint32_t heavy_limit, hipStream_t s);
 int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
-                   uint64_t *amask, hipStream_t s);
+                   uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s);
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
                              hipStream_t s);
 void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s);

@@ -42,6 +42,7 @@ struct WalkConfig {
     uint32_t post_interleave = 8;     // PAG_POST_INTERLEAVE
     // ---- delivery of results
     bool deliver_early = true;        // PAG_DELIVER_EARLY
+    uint32_t succ_heavy = 64;         // PAG_SUCC_HEAVY: successor records of a vertex with more candidate pairs than this: by a whole wave (0: never)
     bool device_tail = true;          // PAG_DEVICE_TAIL: the last round of a contig that leaps is put together on the device
     unsigned pace = 0;                // PAG_WALK_PACE: decided rounds taken per look at the rings while jobs are live (0: all; measured: no gain)
     bool fetch_direct = true;         // PAG_FETCH_DIRECT
@@ -88,6 +89,7 @@ struct WalkConfig {
         if (u64("PAG_LEAP_END_DIV", &c.leap_end_div)) c.leap_end_div = std::max<uint64_t>(1, c.leap_end_div);
         if (const char *e = std::getenv("PAG_POST_INTERLEAVE")) c.post_interleave = (uint32_t)std::atoi(e);
         c.deliver_early = !off("PAG_DELIVER_EARLY");
+        if (const char *e = std::getenv("PAG_SUCC_HEAVY")) c.succ_heavy = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
         c.device_tail = !off("PAG_DEVICE_TAIL");
         if (const char *e = std::getenv("PAG_WALK_PACE")) c.pace = (unsigned)std::max(0, std::atoi(e));
         c.fetch_direct = !off("PAG_FETCH_DIRECT");

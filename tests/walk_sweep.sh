@@ -7,10 +7,9 @@ print('$name', round(d['ms_per_step'],1), 'walks', round(c['ms_walks_wall'],1), 
 " >> gpurun_out/r04h/sweep2.txt; }
 rm -f gpurun_out/r04h/sweep2.txt
 run base A=1
-run host_tail PAG_DEVICE_TAIL=0
-run pace0 PAG_WALK_PACE=0
-run pace0_host_tail PAG_WALK_PACE=0 PAG_DEVICE_TAIL=0
-run pace4 PAG_WALK_PACE=4
-run take4 PAG_TAKE_THREADS=4
+run heavy0 PAG_SUCC_HEAVY=0
+run heavy16 PAG_SUCC_HEAVY=16
+run heavy32 PAG_SUCC_HEAVY=32
+run heavy48 PAG_SUCC_HEAVY=48
 run base2 A=1
 cat gpurun_out/r04h/sweep2.txt
