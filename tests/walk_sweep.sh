@@ -7,9 +7,11 @@ print('$name', round(d['ms_per_step'],1), 'walks', round(c['ms_walks_wall'],1), 
 " >> gpurun_out/r04h/sweep2.txt; }
 rm -f gpurun_out/r04h/sweep2.txt
 run base A=1
-run heavy0 PAG_SUCC_HEAVY=0
-run heavy16 PAG_SUCC_HEAVY=16
-run heavy32 PAG_SUCC_HEAVY=32
-run heavy48 PAG_SUCC_HEAVY=48
+run wpc4 PAG_WALK_WAVES_PER_CU=4
+run wpc6 PAG_WALK_WAVES_PER_CU=6
+run wpc2 PAG_WALK_WAVES_PER_CU=2
+run seg8k PAG_SEG_LEN=8000
+run seg16k PAG_SEG_LEN=16000
+run wpc4seg8k PAG_WALK_WAVES_PER_CU=4 PAG_SEG_LEN=8000
 run base2 A=1
 cat gpurun_out/r04h/sweep2.txt
