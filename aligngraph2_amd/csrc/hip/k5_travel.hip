@@ -537,7 +537,7 @@ __device__ __forceinline__ uint32_t succ_vertex_wave(const TravGraph &G, uint64_
 // heavy_list / heavy_n (MODE 0 and 1, may be null): the vertices with more than heavy_limit candidates are left out here — MODE 0
 // appends them to the list — and done by k_succ_heavy, a wave each.
 template <int MODE>
-__global__ void k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
+__global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
                        SuccRec *__restrict__ stage, uint64_t *__restrict__ amask, uint32_t *__restrict__ heavy_list,
                        unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
