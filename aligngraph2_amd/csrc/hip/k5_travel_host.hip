@@ -502,105 +502,39 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
     return PAG_OK;
 }
 
-}  // namespace
+using namespace stitch;  // Piece, View, Seg, Chain, RoundState, PartAgg, extend_chain .. try_merge_leap (walk_stitch.hpp)
 
-extern "C" {
+// One call of pag_travel (one graph, the contigs of one block): the state of the traversal and the steps it goes through.
+// run() is the whole of it — the traversal view, the contigs' tables and first seeds, the job rings, the first rounds, then the
+// event loop (finished jobs -> their paths -> the chains move on -> decided rounds are chosen from, spliced, re-seeded or
+// delivered) and the epilogue; the members are what those steps share.
+struct WalkSession {
+    // ---- the call
+    pag_graph *g;
+    const pag_seqs *ctgs;
+    const int32_t *orient;
+    const uint32_t *ref_len;
+    uint64_t n_refs;
+    const pag_travel_params *prm;
+    pag_travel_stats *stats;
+    WalkSession(pag_graph *g_, const pag_seqs *ctgs_, const int32_t *orient_, const uint32_t *ref_len_, uint64_t n_refs_, const pag_travel_params *prm_,
+                pag_travel_stats *stats_)
+        : g(g_), ctgs(ctgs_), orient(orient_), ref_len(ref_len_), n_refs(n_refs_), prm(prm_), stats(stats_), cfg(WalkConfig::from_env()),
+          mapper(ctgs_->len, ctgs_->n_seqs), refMapper(ref_len_, n_refs_) {}
 
-// test hooks (host code only, no device needed): the library's own copies of PositionMapper and editDistance against the
-// reference's function-level golden tables (tests/test_function_goldens.py)
-uint64_t pag_debug_edit_distance(const char *a, const char *b) { return edit_distance(a, b); }
-uint64_t pag_debug_mapper_d2s(const uint32_t *len, uint64_t n, int64_t idx, int64_t pos) { return Mapper(len, n).dualToSingle(idx, pos); }
-void pag_debug_mapper_s2d(const uint32_t *len, uint64_t n, uint64_t single, int64_t *idx, int64_t *pos) {
-    auto d = Mapper(len, n).singleToDual(single);
-    *idx = d.first;
-    *pos = d.second;
-}
-uint64_t pag_debug_mapper_extra(const uint32_t *len, uint64_t n) { return Mapper(len, n).starts.back(); }
-
-// g->paths[2 * contig + (reverse ? 1 : 0)]
-const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len) {
-    const uint64_t slot = 2 * ctg_index + (forward ? 0 : 1);
-    if (!g || slot >= g->path_valid.size() || !g->path_valid[slot]) {
-        if (len) *len = 0;
-        return nullptr;
-    }
-    if (len) *len = g->path_len[slot];
-    if (slot < g->path_ptr.size() && g->path_ptr[slot]) return g->path_ptr[slot];
-    return g->path_store + g->path_off[slot];
-}
-
-const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
-    if (g && 2 * ctg_index + 1 < g->path_valid.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
-    return pag_travel_path_oriented(g, ctg_index, 1, len);
-}
-
-// test hooks: the successor records of the prepared traversal graph (after pag_travel_prepare), copied to the host:
-// succ_off[n_pos + 1], then n_succ records of 16 bytes (target, contig coordinate, step | grade | flags | count, target's offset)
-int pag_debug_succ_sizes(const pag_graph *g, uint64_t *n_pos, uint64_t *n_succ) {
-    if (!g || !g->tg_ready || !n_pos || !n_succ) return PAG_EINVAL;
-    *n_pos = g->tg.n_pos;
-    *n_succ = g->tg.n_succ;
-    return PAG_OK;
-}
-int pag_debug_succ(const pag_graph *g, uint32_t *succ_off, void *recs) {
-    if (!g || !g->tg_ready || !succ_off || !recs) return PAG_EINVAL;
-    PAG_HIP_TRY(hipSetDevice(g->device));
-    PAG_HIP_TRY(hipMemcpy(succ_off, g->tg.succ_off, (g->tg.n_pos + 1) * 4, hipMemcpyDeviceToHost));
-    PAG_HIP_TRY(hipMemcpy(recs, g->tg.succ, g->tg.n_succ * sizeof(SuccRec), hipMemcpyDeviceToHost));
-    return PAG_OK;
-}
-
-// the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
-int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm, double *ms) {
-    return pag_travel_prepare_for(g, ctgs, nullptr, ref_len, n_refs, prm, ms);
-}
-// ... for the traversals pag_travel will be asked for (orient as pag_travel takes it; NULL: any): the view then holds what
-// those traversals can examine and nothing else (trav_view_region above)
-int pag_travel_prepare_for(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
-                           const pag_travel_params *prm, double *ms) {
-    if (!g || !ctgs || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
-    PAG_HIP_TRY(hipSetDevice(g->device));
-    TravGraph G{};
-    return trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, prm->deviation, prm->error_rate, &G, ms, orient, prm->start_split);
-}
-int pag_travel_view_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges, uint64_t *n_succ, int *cut, uint64_t *fallbacks) {
-    if (!g || !g->tg_ready) return PAG_EINVAL;
-    if (n_nodes) *n_nodes = g->view_counts[0];
-    if (n_pos) *n_pos = g->view_counts[1];
-    if (n_edges) *n_edges = g->view_counts[2];
-    if (n_succ) *n_succ = g->tg.n_succ;
-    if (cut) *cut = g->view_pruned ? 1 : 0;
-    if (fallbacks) *fallbacks = g->view_fallbacks;
-    return PAG_OK;
-}
-
-static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
-                       const pag_travel_params *prm, pag_travel_stats *stats);
-int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
-               const pag_travel_params *prm, pag_travel_stats *stats) {
-    if (!g || !ctgs || !orient || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
-    int rc = travel_once(g, ctgs, orient, ref_len, n_refs, prm, stats);
-    if (rc == PAG_ERANGE && g->view_pruned && !g->regional) {
-        // a walk examined a vertex whose successors this handle's own view left out (trav_view_region): nothing of that walk is
-        // kept — the whole graph's view is built and every contig walked again (the outputs are those of the un-cut graph)
-        if (WalkConfig::from_env().timing) std::fprintf(stderr, "[timing] a walk left the view: %s; walking again on the whole graph\n", pag_last_error());
-        g->view_off = true;
-        g->tg_ready = false;
-        g->view_fallbacks += 1;
-        rc = travel_once(g, ctgs, orient, ref_len, n_refs, prm, stats);
-    }
-    return rc;
-}
-static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
-                       const pag_travel_params *prm, pag_travel_stats *stats) {
-    PAG_HIP_TRY(hipSetDevice(g->device));
-    hipStream_t s = g->stream;
-    const double t_begin = now_ms();
-    const WalkConfig cfg = WalkConfig::from_env();
-    const bool timing = cfg.timing;
-    double lap_t = t_begin;
+    // ---- configuration, timing
+    hipStream_t s = nullptr;
+    double t_begin = 0;
+    const WalkConfig cfg;
+    bool timing = false, wdebug = false;
+    double lap_t = 0;
     std::vector<std::pair<const char *, double>> laps;
-    auto lap = [&](const char *what) {
+    uint32_t k = 0;
+    uint64_t deviation = 0;
+    double errorRate = 0, startSplit = 0;
+    size_t topK = 0;
+    int slot = TRAV_SLOT0;  // pool slots of the handle are handed out in the order of the buf() calls
+    void lap(const char *what) {
         if (!timing) return;
         const double t = now_ms();
         for (auto &l : laps)
@@ -611,17 +545,11 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             }
         laps.emplace_back(what, t - lap_t);
         lap_t = t;
-    };
-    const uint32_t k = g->k;
-    const uint64_t deviation = prm->deviation;
-    const double errorRate = prm->error_rate, startSplit = prm->start_split;
-    const size_t topK = std::min<uint32_t>(prm->ref_threads, 8u);
-    int rc;
-    int slot = TRAV_SLOT0;
-    auto buf = [&](void) { return DevBuf(g, slot++); };
+    }
+    DevBuf buf() { return DevBuf(g, slot++); }
     // pinned host staging area (grown, kept in the handle): packed job results on their way in, uploads on their way out
     std::vector<void *> pinned_parked;  // (freeing host memory synchronises the device: never while the walker grid is resident)
-    auto pinned = [&](size_t bytes) -> void * {
+    void *pinned(size_t bytes) {
         if (g->pin_bytes < bytes) {
             if (g->pin_host) {
                 if (g->defer_free) pinned_parked.push_back(g->pin_host);
@@ -637,13 +565,13 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             g->pin_bytes = want;
         }
         return g->pin_host;
-    };
+    }
 
     // Pinned memory that keeps what it is given for the whole call: the fetched paths of finished jobs stay where the copy
     // from the device put them (segments and chains refer to them by pointer).  64 MB chunks kept by the handle.
     size_t fetch_chunk = 0, fetch_used = 0;
-    const size_t FETCH_CHUNK = 64u << 20;
-    auto fetch_alloc = [&](size_t bytes) -> void * {
+    static constexpr size_t FETCH_CHUNK = 64u << 20;
+    void *fetch_alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         for (; fetch_chunk < g->fetch_chunks.size(); ++fetch_chunk, fetch_used = 0)
             if (fetch_used + bytes <= g->fetch_chunk_bytes[fetch_chunk]) {
@@ -661,67 +589,19 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         g->fetch_chunk_bytes.push_back(want);
         fetch_used = bytes;  // (fetch_chunk is the index of the new chunk)
         return q;
-    };
+    }
 
-    // ---- compact CSR, coordinate order, successor records (once per built graph)
+    // ---- the traversal view, the contigs
     TravGraph G{};
     double t_compact = 0;
-    if ((rc = trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, deviation, errorRate, &G, &t_compact, orient, startSplit))) return rc;
-    slot += TRAV_GRAPH_SLOTS + TRAV_EXTRA_SLOTS;
-    const uint64_t np = G.n_pos;
-    (void)np;
-
-    lap("compact");
-    // ---- contigs: packed bases, mapper tables, per-strand node tables
-    Mapper mapper(ctgs->len, ctgs->n_seqs);
-    Mapper refMapper(ref_len, n_refs);
-    const uint32_t n_ctgs = (uint32_t)ctgs->n_seqs;
-    g->path_off.assign(2 * (size_t)n_ctgs, 0);
-    g->path_len.assign(2 * (size_t)n_ctgs, 0);
-    g->path_valid.assign(2 * (size_t)n_ctgs, 0);
-    g->path_ptr.assign(2 * (size_t)n_ctgs, nullptr);
-    std::vector<CtgState> st;
+    Mapper mapper, refMapper;
+    uint32_t n_ctgs = 0, n_sel = 0;
+    std::vector<CtgState> st;  // one entry per (contig, orientation) that is walked
     uint64_t nodes_total = 0;
-    // one entry per (contig, orientation): a contig selected with both orientations is two independent traversals
-    // (PAssembly.cpp:28-36 walks every (name, forward) pair of its set)
-    for (uint32_t c2 = 0; c2 < 2 * n_ctgs; ++c2) {
-        const uint32_t c = c2 >> 1;
-        const bool fwd = (c2 & 1u) == 0;
-        const int32_t o = orient[c];
-        if (!(o == PAG_ORIENT_BOTH || (fwd && o == PAG_ORIENT_FORWARD) || (!fwd && o == PAG_ORIENT_REVERSE))) continue;
-        CtgState cs;
-        cs.ci = c;
-        cs.forward = fwd;
-        cs.chosenOne = cs.forward ? (int64_t)c + 1 : -(int64_t)c - 1;
-        cs.len = ctgs->len[c];
-        cs.ctgLeft = (uint32_t)mapper.dualToSingle(cs.chosenOne, 0);
-        cs.ctgRight = (uint32_t)mapper.dualToSingle(cs.chosenOne, cs.len);
-        cs.revLeft = (uint32_t)mapper.dualToSingle(-cs.chosenOne, 0);
-        cs.revRight = (uint32_t)mapper.dualToSingle(-cs.chosenOne, cs.len);
-        cs.nodesOff = nodes_total;
-        cs.seqCap = (uint64_t)cs.len / 2 + 8192;
-        if (cfg.debug_seqcap) cs.seqCap = (uint64_t)cfg.debug_seqcap;  // tests: force the overflow / regrow path
-        nodes_total += cs.len >= k ? cs.len - k + 1 : 0;
-        st.push_back(std::move(cs));
-    }
-    const uint32_t n_sel = (uint32_t)st.size();
-    if (n_sel == 0) return PAG_OK;
-
-    DevBuf b_packed = buf(), b_nodes = buf(), b_starts = buf(), b_sizes = buf(), b_tc = buf(), b_seedout = buf(), b_req = buf(),
-           b_gset = buf(), b_gather = buf(), b_vids = buf(), b_gbits = buf();
-    if ((rc = b_packed.alloc(ctgs->packed_bytes + 64)) || (rc = b_nodes.alloc((nodes_total + 1) * 4)) ||
-        (rc = b_starts.alloc(mapper.starts.size() * 8 + 8)) || (rc = b_sizes.alloc(mapper.sizes.size() * 8 + 8)) ||
-        (rc = b_tc.alloc(n_sel * sizeof(TravContig))))
-        return rc;
-    PAG_HIP_TRY(hipMemcpyAsync(b_packed.p, ctgs->packed, ctgs->packed_bytes, hipMemcpyHostToDevice, s));
-    PAG_HIP_TRY(hipMemcpyAsync(b_starts.p, mapper.starts.data(), mapper.starts.size() * 8, hipMemcpyHostToDevice, s));
-    PAG_HIP_TRY(hipMemcpyAsync(b_sizes.p, mapper.sizes.data(), mapper.sizes.size() * 8, hipMemcpyHostToDevice, s));
-    for (auto &cs : st)
-        trav_launch_ctg_nodes(b_packed.as<uint8_t>(), ctgs->byte_off[cs.ci], cs.len, cs.forward ? 1 : 0, k, G,
-                              b_nodes.as<uint32_t>() + cs.nodesOff, s);
-
-    std::vector<TravContig> tc(n_sel);
-    auto fill_contigs = [&]() {
+    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout, b_fetch, b_fdesc;
+    std::vector<TravContig> tc;
+    static constexpr uint32_t SEED_STRIDE = 4096;
+    void fill_contigs() {
         for (uint32_t i = 0; i < n_sel; ++i) {
             CtgState &cs = st[i];
             TravContig &t = tc[i];
@@ -746,43 +626,14 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             t.gwin_lo = cs.gwinLo;
             t.gwin_hi = cs.gwinHi;
         }
-    };
-    auto upload_contigs = [&]() -> int {
+    }
+    int upload_contigs() {
         fill_contigs();
         PAG_HIP_TRY(hipMemcpyAsync(b_tc.p, tc.data(), n_sel * sizeof(TravContig), hipMemcpyHostToDevice, s));
         return PAG_OK;
-    };
-    // id ranges of the strands, then the per-contig global visited structures
-    {
-        for (auto &cs : st) cs.gcap = 1024;  // placeholder so that gmask is well formed
-        if ((rc = upload_contigs())) return rc;
-        trav_launch_ranges(G, b_tc.as<TravContig>(), n_sel, s);
-        PAG_HIP_TRY(hipMemcpyAsync(tc.data(), b_tc.p, n_sel * sizeof(TravContig), hipMemcpyDeviceToHost, s));
-        PAG_HIP_TRY(hipStreamSynchronize(s));
-        uint64_t tot_set = 0, tot_bits = 0;
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            CtgState &cs = st[i];
-            cs.inLo = tc[i].in_lo;
-            cs.inHi = tc[i].in_hi;
-            cs.gcap = (uint32_t)pow2_at_least(cs.seqCap / 2 + 8192);
-            tot_set += cs.gcap;
-            tot_bits += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
-        }
-        if ((rc = b_gset.alloc(tot_set * 4)) || (rc = b_gbits.alloc(tot_bits * 4))) return rc;
-        PAG_HIP_TRY(hipMemsetAsync(b_gset.p, 0xFF, tot_set * 4, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_gbits.p, 0, tot_bits * 4, s));
-        uint64_t o1 = 0, o2 = 0;
-        for (auto &cs : st) {
-            cs.gset = b_gset.as<uint32_t>() + o1;
-            o1 += cs.gcap;
-            cs.gbits = b_gbits.as<uint32_t>() + o2;
-            o2 += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
-        }
     }
-
-    lap("contig tables");
     // vertex attributes for a list of vertex ids
-    auto fetch_vertices = [&](const std::vector<uint32_t> &vids, std::vector<pag_path_node> &out) -> int {
+    int fetch_vertices(const std::vector<uint32_t> &vids, std::vector<pag_path_node> &out) {
         out.resize(vids.size());
         if (vids.empty()) return PAG_OK;
         int r;
@@ -792,36 +643,9 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         PAG_HIP_TRY(hipMemcpyAsync(out.data(), b_gather.p, vids.size() * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
         PAG_HIP_TRY(hipStreamSynchronize(s));
         return PAG_OK;
-    };
-
-    // ---- round 0 seeds: searchPANode(onlyFirst) then top-K
-    const uint32_t SEED_STRIDE = 4096;
-    if ((rc = b_seedout.alloc((uint64_t)n_sel * SEED_STRIDE * 4))) return rc;
-    if ((rc = upload_contigs())) return rc;
-    trav_launch_seed_first(G, b_tc.as<TravContig>(), n_sel, deviation, b_seedout.as<uint32_t>(), SEED_STRIDE, s);
-    std::vector<uint32_t> seedbuf((size_t)n_sel * SEED_STRIDE);
-    PAG_HIP_TRY(hipMemcpyAsync(seedbuf.data(), b_seedout.p, seedbuf.size() * 4, hipMemcpyDeviceToHost, s));
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-    {
-        std::vector<uint32_t> vids;
-        std::vector<size_t> cnt(n_sel);
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            const uint32_t *o = &seedbuf[(size_t)i * SEED_STRIDE];
-            size_t n = std::min<size_t>(std::min<size_t>(o[0], (SEED_STRIDE - 2) / 2), topK);
-            cnt[i] = n;
-            for (size_t j = 0; j < n; ++j) vids.push_back(o[1 + 2 * j]);
-        }
-        std::vector<pag_path_node> attrs;
-        if ((rc = fetch_vertices(vids, attrs))) return rc;
-        size_t at = 0;
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            st[i].seeds.assign(attrs.begin() + at, attrs.begin() + at + cnt[i]);
-            at += cnt[i];
-            if (st[i].seeds.empty()) st[i].done = true;
-        }
     }
 
-    lap("first seeds");
+    // ---- statistics of the call
     uint64_t rounds = 0, jobs_total = 0, steps_total = 0, classify_total = 0, probe_total = 0, record_total = 0;
     double t_walk = 0;
 
@@ -849,55 +673,28 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     // plus the leaping zone.
     enum { CB_SEQV = 0, CB_SEQS, CB_ARV, CB_ARS, CB_TSET, CB_PSET, CB_STAMP, CB_TBITS, CB_SEQX, CB_N };
     enum { GRP_ROUND = 0, GRP_CHAIN0 = 1, GRP_FINAL = 9, GROUPS = 10 };  // buffer groups per contig (chains: top-K <= 8)
-    if (g->cpool.size() < (size_t)n_sel * GROUPS * CB_N) g->cpool.resize((size_t)n_sel * GROUPS * CB_N);
-    auto cbuf = [&](uint32_t i, int grp, int b) { return DevBuf(g, &g->cpool[((size_t)i * GROUPS + grp) * CB_N + b]); };
+    DevBuf cbuf(uint32_t i, int grp, int b) { return DevBuf(g, &g->cpool[((size_t)i * GROUPS + grp) * CB_N + b]); }
     // rings of job records, served in order: 0 chain jobs (what a contig's progress waits for), 1 segment jobs of contigs
     // in a later round (they are further along their critical path), 2 segment jobs of first rounds.  slot = ring * QCAP +
     // number mod QCAP
     // A ring holds the jobs of a round that are in flight; a slot is reused QCAP postings later.  Sized by what the contigs
     // of this call can post in one round (segments every few kb of every strand, top-K <= 8 chains each), twice over.
     uint32_t QCAP = 32768;
-    {
-        const uint64_t sl = std::max<uint64_t>(128, cfg.seg_len ? cfg.seg_len : 12000);
-        const uint64_t ll = std::max<uint64_t>(128, cfg.leap_seg_len ? cfg.leap_seg_len : sl / 2);
-        uint64_t est = 0;
-        for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / sl + (uint64_t)st[i].len / ll + 32;  // (every strand as if all of it were both zones)
-        while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
-        if (cfg.debug_ring) QCAP = (uint32_t)cfg.debug_ring;  // tests: a ring far smaller than a round
-    }
-    const uint32_t NR = TRAV_RINGS;
-    const size_t q_need = 256 + NR * (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
-    if (g->wq_bytes < q_need) {
-        if (g->wq_host) hipHostFree(g->wq_host);
-        g->wq_host = nullptr;
-        g->wq_bytes = 0;
-        PAG_HIP_TRY(hipHostMalloc(&g->wq_host, q_need, hipHostMallocCoherent | hipHostMallocMapped));
-        g->wq_bytes = q_need;
-    }
-    if (!g->wq_next) PAG_HIP_TRY(hipMalloc((void **)&g->wq_next, 256));
-    TravQueue *hq = (TravQueue *)g->wq_host;
-    TravPosted *hjobs = (TravPosted *)((char *)g->wq_host + 256);
-    TravJobOut *houts = (TravJobOut *)(hjobs + NR * (size_t)QCAP);
-    uint32_t *hdone = (uint32_t *)(houts + NR * (size_t)QCAP);
-    std::memset(g->wq_host, 0, 256);
-    std::memset(hdone, 0, NR * (size_t)QCAP * sizeof(uint32_t));
-    PAG_HIP_TRY(hipMemsetAsync(g->wq_next, 0, 256, s));
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-
-    const bool wdebug = cfg.walk_debug;
-    double t_walk0 = now_ms();  // (debug time stamps count from the launch of the walker)
-    const bool use_pieces = cfg.pieces;
-    const uint64_t seg_len_env = cfg.seg_len;
-    const uint64_t seg_ov = cfg.seg_overlap;
-    const bool force_exact = cfg.force_exact;
+    static constexpr uint32_t NR = TRAV_RINGS;
+    TravQueue *hq = nullptr;
+    TravPosted *hjobs = nullptr;
+    TravJobOut *houts = nullptr;
+    uint32_t *hdone = nullptr;
+    double t_walk0 = 0, tw0 = 0;  // (debug time stamps count from the launch of the walker)
+    bool use_pieces = true, use_leap_pieces = true, force_exact = false;
+    uint64_t seg_len_env = 0, seg_ov = 0;
 
     double t_st[4] = {0, 0, 0, 0};  // stitch: bookkeeping / paths of finished jobs / chains moving on; posting (inside the others)
     // (The stitch below is serial on purpose.  Worker threads — spinning, polling or sleeping on a condition variable, 4 to
     // 12 of them — cut the path copies from 33 to 10 ms on the GPU box (16-CPU cgroup quota, busy host), but every HIP call
     // of this thread (posting, fetching, re-seeding) got several times slower while they were active and the walks took
     // 180-450 ms instead of 165-180 ms.)
-    using namespace stitch;  // Piece, View, Seg, Chain, RoundState, JobRef, PartAgg, extend_chain .. try_merge_leap (walk_stitch.hpp)
-    std::vector<RoundState> RS(n_sel);
+    std::vector<stitch::RoundState> RS;
     struct JobRef {
         uint32_t ctg = 0;
         int kind = 0;  // 0: chain job (seed or resume), 1: segment
@@ -906,7 +703,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         bool live = false;
         uint32_t epoch = 0;  // RoundState::seg_epoch of its contig when the job was posted (see is_orphan)
     };
-    std::vector<JobRef> jref(NR * (size_t)QCAP);
+    std::vector<JobRef> jref;
     // A round of a contig is decided when all its chains are final.  Segment jobs of the round that are still waiting or
     // walking then are ORPHANS: nobody will look at their paths (a chain that dead-ends at a fifth of its contig leaves four
     // fifths of the round's segments behind — at BASELINE configs[1] the next round of such a contig used to start when the
@@ -915,15 +712,13 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
     // into its own buffers — a round's buffers come from the walk arena, which is never handed out twice within one
     // pag_travel; a round that had to fall back on the per-contig slots waits for its jobs as before (RoundState::slot_bufs).
     uint64_t n_orphans = 0;
-    const bool orphaning = cfg.orphaning;  // (PAG_WALK_ORPHANS=0: every round waits for all its jobs)
-    const bool keep_segments = orphaning && cfg.keep_segments;  // (PAG_WALK_KEEP_SEGMENTS=0: every round plans and walks its own)
+    bool orphaning = true;      // (PAG_WALK_ORPHANS=0: every round waits for all its jobs)
+    bool keep_segments = true;  // (PAG_WALK_KEEP_SEGMENTS=0: every round plans and walks its own)
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
     std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];
-    for (auto &x : n_leap_refused) x = 0;
     uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
-    const bool use_leap_pieces = cfg.leap_pieces;
     WalkerGrid walkers;
-    auto shutdown_walker = [&]() {
+    void shutdown_walker() {
         if (!walkers.up) return;
         walkers.shutdown();
         g->defer_free = false;
@@ -931,7 +726,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         g->deferred.clear();
         for (void *q : pinned_parked) hipHostFree(q);
         pinned_parked.clear();
-    };
+    }
     struct JobPlan {
         int kind, idx;
         uint64_t cap;       // sequence capacity (vertices)
@@ -948,7 +743,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         TravPosted P;
         JobRef jr;
     };
-    std::vector<std::vector<Deferred>> deferred(n_sel);
+    std::vector<std::vector<Deferred>> deferred;
     bool defer_ring2 = false;
     // A job enters its ring when the slot it takes (its number mod QCAP) is free again; until then it waits in the ring's
     // backlog, in posting order (a ring smaller than the jobs of a round is a matter of flow control, not an error).
@@ -957,7 +752,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         JobRef jr;
     };
     std::deque<Backlogged> backlog[TRAV_RINGS];
-    auto place_job = [&](uint32_t ring, const TravPosted &P, const JobRef &jr2) -> bool {
+    bool place_job(uint32_t ring, const TravPosted &P, const JobRef &jr2) {
         const uint32_t jn = n_posted[ring], slot = ring * QCAP + jn % QCAP;
         if (jref[slot].live) return false;
         hjobs[slot] = P;
@@ -966,8 +761,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         if (jr2.kind == 0) RS[jr2.ctg].chains[(size_t)jr2.idx].job = (int)slot;
         n_posted[ring] += 1;
         return true;
-    };
-    auto commit_job = [&](uint32_t ring, const TravPosted &P, const JobRef &jr2, uint32_t mode, uint32_t stop_pc) -> int {
+    }
+    int commit_job(uint32_t ring, const TravPosted &P, const JobRef &jr2, uint32_t mode, uint32_t stop_pc) {
         if (jr2.kind == 0) {
             Chain &ch = RS[jr2.ctg].chains[(size_t)jr2.idx];
             ch.job = 0x7FFFFFFF;  // (outstanding; the slot number follows when the job enters the ring)
@@ -979,9 +774,9 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         jobs_total += 1;
         if (!backlog[ring].empty() || !place_job(ring, P, jr2)) backlog[ring].push_back(Backlogged{P, jr2});
         return PAG_OK;
-    };
-    auto is_orphan = [&](const JobRef &jr) { return jr.kind == 1 && jr.epoch != RS[jr.ctg].seg_epoch; };
-    auto flush_backlog = [&]() {
+    }
+    bool is_orphan(const JobRef &jr) const { return jr.kind == 1 && jr.epoch != RS[jr.ctg].seg_epoch; }
+    void flush_backlog() {
         for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
             while (!backlog[ring].empty()) {
                 if (is_orphan(backlog[ring].front().jr)) {  // (never entered a ring: gone)
@@ -993,10 +788,10 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 backlog[ring].pop_front();
                 need_publish = true;
             }
-    };
+    }
     // The segment list of contig i is given up (the contig is finished, or its next round plans its own): the jobs of the list
     // that no wave has taken are cancelled, those that are walking finish as orphans.
-    auto give_up_segments = [&](uint32_t i) {
+    void give_up_segments(uint32_t i) {
         RoundState &R = RS[i];
         for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
             for (uint32_t q = 0; q < QCAP; ++q) {
@@ -1012,10 +807,10 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         R.zone_end = 0;
         R.live_jobs = 0;
         R.kept = false;
-    };
+    }
     // buffers + job records of a batch of jobs of contig i (memsets and uploads go to stream s; the records become visible to
     // the walker only by publish())
-    auto post_batch = [&](uint32_t i, int grp, const std::vector<JobPlan> &plans) -> int {
+    int post_batch(uint32_t i, int grp, const std::vector<JobPlan> &plans) {
         if (plans.empty()) return PAG_OK;
         const double tp0 = now_ms();
         struct PostTimer {
@@ -1139,20 +934,19 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         }
         need_publish = true;
         return PAG_OK;
-    };
-    auto publish = [&]() -> int {  // after the prepared buffers are ready on the device
+    }
+    int publish() {  // after the prepared buffers are ready on the device
         if (!need_publish) return PAG_OK;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         for (uint32_t r = NR; r-- > 0;) __atomic_store_n(&hq->posted[r], n_posted[r], __ATOMIC_RELEASE);
         need_publish = false;
         return walkers.g ? walkers.ensure(n_live) : PAG_OK;  // (before the first launch: pag_travel starts the waves itself)
-    };
+    }
 
     // ---- start of a round of contig i: its seeds are in cs.seeds.  Decides where the walk can be cut, finds the checkpoint
     //      vertices and posts the seed jobs and the segment jobs.
     // stop coordinate of a job that walks up to segment q of the round (its checkpoint + the overlap)
-    auto first_stop = [&](const RoundState &R) -> uint32_t { return stitch::stop_for(R, 0, seg_ov); };
-    DevBuf b_ckreq = buf(), b_ckout = buf();
+    uint32_t first_stop(const stitch::RoundState &R) const { return stitch::stop_for(R, 0, seg_ov); }
     // The rounds of several contigs are prepared together: their checkpoint vertices come from ONE launch of k_checkpoints and
     // the id ranges around their segments from ONE launch of k_id_bounds (two synchronisations per call; contig by contig
     // the 48 first rounds of configs[1] were ~100 small launches and synchronisations, ~10 ms before the first job).
@@ -1165,7 +959,7 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         bool kept = false;        // the round adopts the segments of an earlier round (RoundState::kept): none are planned
         uint32_t kept_stop = 0;   // ... and its seeds walk up to this coordinate (0: to the end)
     };
-    auto start_rounds = [&](const std::vector<uint32_t> &which) -> int {
+    int start_rounds(const std::vector<uint32_t> &which) {
         std::vector<RoundPlan> RP(which.size());
         std::vector<TravSeedReq> reqs;
         // ---- per contig: the round's state, the checkpoint coordinates of its segments
@@ -1389,20 +1183,20 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             if ((r = post_batch(i, GRP_ROUND, plans))) return r;
         }
         return PAG_OK;
-    };
+    }
 
     // continue chain c of contig i exactly: the path so far goes to the walker as a RESUME job
     // (until_leap: only as far as the first iteration boundary from which the walk can leap, TRAV_MODE_UNTIL_LEAP)
-    auto post_resume = [&](uint32_t i, int c, uint32_t stop, bool until_leap = false) -> int {
+    int post_resume(uint32_t i, int c, uint32_t stop, bool until_leap = false) {
         CtgState &cs = st[i];
         Chain &ch = RS[i].chains[(size_t)c];
         const uint64_t cap = std::max<uint64_t>(cs.seqCap * ch.grow, ch.len + cs.seqCap / 4 + 4096);
         std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)(TRAV_MODE_RESUME | (until_leap ? TRAV_MODE_UNTIL_LEAP : 0)), stop, &ch, ch.exact}};
         return post_batch(i, GRP_CHAIN0 + c, plans);
-    };
+    }
 
     // adoption of a finished segment by a chain (conditions and their justification: walk_stitch.hpp)
-    auto merge_ctx = [&](uint32_t i) {
+    stitch::MergeCtx merge_ctx(uint32_t i) {
         MergeCtx M;
         M.k = k;
         M.deviation = deviation;
@@ -1415,11 +1209,11 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             M.g_free_hi = st[i].gFreeHi;
         }
         return M;
-    };
+    }
     // what a chain does after its job has ended at a stop coordinate or after a segment it waits for has finished
     // (walk_stitch.hpp advance_chain: adoptions, then how the chain goes on)
-    AdvanceStats adv_stats;
-    auto advance = [&](uint32_t i, int c) -> int {
+    stitch::AdvanceStats adv_stats;
+    int advance(uint32_t i, int c) {
         RoundState &R = RS[i];
         Chain &ch = R.chains[(size_t)c];
         const uint64_t fails_before = adv_stats.merge_fail;
@@ -1431,9 +1225,9 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         if (wdebug && adv_stats.merge_fail != fails_before) std::fprintf(stderr, "[walk] contig %u chain %d: a segment was not adoptable, walking on exactly\n", i, c);
         if (nx.what == Next::Resume) return post_resume(i, c, nx.stop, nx.until_leap);
         return PAG_OK;
-    };
+    }
 
-    auto fail = [&](int rc2) {
+    int fail(int rc2) {
         shutdown_walker();
         g->defer_free = false;
         for (void *q : pinned_parked) hipHostFree(q);
@@ -1445,91 +1239,15 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         std::fill(g->path_valid.begin(), g->path_valid.end(), (uint8_t)0);
         std::fill(g->path_ptr.begin(), g->path_ptr.end(), nullptr);
         return rc2;
-    };
-
-    if (!pinned(64u << 20)) return PAG_ENOMEM;  // (grown later if a batch needs more)
-    {   // the walk arena: sized for the first round of every contig (chain buffers over the whole strand + segment buffers)
-        // plus half again for resumed walks and later rounds; at most 40 % of the free device memory; kept by the handle
-        size_t want = 0;
-        for (uint32_t i = 0; i < n_sel; ++i) {
-            const CtgState &cs = st[i];
-            const size_t span = (size_t)(cs.inHi - cs.inLo) + 8, cap = cs.seqCap, oc = pow2_at_least(cap / 4 + 4096);
-            const size_t chain = cap * 8 + cap * 8 * TRAV_PROBE_GROUPS + oc * 8 * (1 + TRAV_PROBE_GROUPS) + span * 4 * (1 + TRAV_PROBE_GROUPS);
-            const size_t n_seg = cs.len / 12000 + 1, scap = 8192 + 8192, soc = pow2_at_least(scap / 4 + 4096), sspan = span / (n_seg ? n_seg : 1) * 2 + 4096;
-            const size_t seg = scap * 8 + scap * 8 * TRAV_PROBE_GROUPS + soc * 8 * (1 + TRAV_PROBE_GROUPS) + sspan * 4 * (1 + TRAV_PROBE_GROUPS);
-            // segments of the leaping zone (the last tenth of the strand + margin, half as long, far larger hash sets, a log)
-            const size_t n_lseg = cs.len / 8 / 6000 + 2, lcap = 3000 + 8192, loc = pow2_at_least(lcap + 8192), lspan = sspan;
-            const size_t lseg = lcap * 8 + lcap * 8 * TRAV_PROBE_GROUPS + lcap * 8 + loc * 8 * (1 + TRAV_PROBE_GROUPS) + lspan * 4 * (1 + TRAV_PROBE_GROUPS);
-            // (full-strand buffers: the resumed walks — the seeds' own first pieces are sized like segments)
-            want += chain * 3 / 2 + (seg * (n_seg + 8) + lseg * n_lseg) * 3 / 2;
-        }
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
-        if (g->walk_arena_cap < want / 10 * 7) {  // (an arena that is there — pag_reserve_walk_arena, an earlier call — is kept
-                                                  // unless it is much too small: what does not fit goes to the slots)
-            if (g->walk_arena) hipFree(g->walk_arena);
-            g->walk_arena = nullptr;
-            g->walk_arena_cap = 0;
-            if (hipMalloc(&g->walk_arena, want) == hipSuccess) g->walk_arena_cap = want;
-            else g->walk_arena = nullptr;  // (the slots do all the work then)
-        }
-        g->walk_arena_used = 0;
     }
-    const double tw0 = now_ms();
-    t_walk0 = tw0;
-    g->defer_free = true;
-    {   // longest contigs first: their exact tails (the leaping zone is a tenth of the contig) are the longest, so their
-        // segments should be through the queue first
-        std::vector<uint32_t> order(n_sel);
-        for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a2, uint32_t b2) { return st[a2].len > st[b2].len; });
-        // First rounds: the contigs' segment jobs enter the ring interleaved, a few per contig and turn (a contig's leap
-        // segments first).  Posted contig by contig, the last contigs of the list finish their first round when the grid
-        // runs empty — and those of them that need a second round (a re-seed after a walk that ended early) start it then:
-        // every contig's first round now ends at about the same time, earlier than the last ones did.
-        const uint32_t interleave = cfg.post_interleave;
-        defer_ring2 = interleave != 0;
-        {
-            std::vector<uint32_t> first_rounds;
-            for (uint32_t i : order)
-                if (!st[i].done) first_rounds.push_back(i);
-            if ((rc = start_rounds(first_rounds))) return fail(rc);
-        }
-        defer_ring2 = false;
-        if (interleave) {
-            std::vector<size_t> at(n_sel, 0);
-            for (bool more = true; more;) {
-                more = false;
-                for (uint32_t i : order) {
-                    auto &dq = deferred[i];
-                    for (uint32_t c = 0; c < interleave && at[i] < dq.size(); ++c, ++at[i])
-                        if ((rc = commit_job(2u, dq[at[i]].P, dq[at[i]].jr, dq[at[i]].P.J.mode, dq[at[i]].P.J.stop_pc))) return fail(rc);
-                    more = more || at[i] < dq.size();
-                }
-            }
-            for (auto &dq : deferred) std::vector<Deferred>().swap(dq);
-        }
-    }
-    if (n_live) {
-        walkers.init(g, G, hjobs, houts, hdone, hq, QCAP, k);
-        if ((rc = publish())) return fail(rc);  // (the jobs' buffers are ready, the rings are visible)
-        if ((rc = walkers.ensure(n_live))) {
-            g->defer_free = false;
-            return rc;
-        }
-        if (wdebug) std::fprintf(stderr, "[walk] %u walker waves launched (at most %u), %u + %u + %u jobs posted\n", walkers.launched, walkers.max_waves, n_posted[0], n_posted[1], n_posted[2]);
-    } else {
-        g->defer_free = false;
-    }
-    lap("round prep");
 
     // filterSequence / "Pump it" of a finished contig (PAlgorithm.cpp:409-423)
-    auto pumped = [&](const CtgState &cs, uint32_t last_ctg) {  // the last vertex of a path that ends in a leap is dropped?
+    bool pumped(const CtgState &cs, uint32_t last_ctg) {  // the last vertex of a path that ends in a leap is dropped?
         auto d = mapper.singleToDual(last_ctg);
         uint64_t a = (uint64_t)std::llabs(d.first);
         return a == (uint64_t)cs.ci + 1 || (a >= 1 && a <= mapper.sizes.size() && (double)d.second >= (double)mapper.sizes[a - 1] * (1 - startSplit));
-    };
-    auto filter_travel = [&](CtgState &cs) {
+    }
+    void filter_travel(CtgState &cs) {
         auto &seq = cs.travel;
         if (!cs.finalLeap) {
             const size_t windowSize = 10;
@@ -1547,12 +1265,12 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         } else if (!seq.empty()) {
             if (pumped(cs, seq.back().ctg)) seq.pop_back();
         }
-    };
+    }
     // A contig whose traversal is over is DELIVERED while the others still walk: its sequence is filtered, the full records of
     // its vertices are gathered on the device and copied (asynchronously, stream s) into pinned memory that lives until the
     // next call — at configs[1] the one gather + 380 MB copy for all contigs used to follow the last walk (15 ms).
     // Device buffers from the walk arena; without room there the contig is left to the epilogue.
-    auto deliver_contig = [&](uint32_t i) -> int {
+    int deliver_contig(uint32_t i) {
         CtgState &cs = st[i];
         const bool early = cfg.deliver_early;
         if (cs.delivered || !cs.done || !early) return PAG_OK;
@@ -1609,16 +1327,16 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         trav_launch_gather_path(G, d_ids, d_ids + m, m, dst, g->deliver_stream);
         g->path_ptr[slot2] = dst;
         return PAG_OK;
-    };
+    }
 
-    DevBuf b_fetch = buf(), b_fdesc = buf();
+    // ---- the event loop
     uint32_t scan_from[TRAV_RINGS] = {0, 0, 0};  // per ring: every job number below it has been handled
-    double t_progress = now_ms(), t_first_fin = 0;
+    double t_progress = 0, t_first_fin = 0;
     // Waiting for the walker: a busy wait (pause instructions), not a sleep — on a loaded host a 20 us sleep comes back after
     // a millisecond or more, and every finished job that waits for this thread holds up the jobs that depend on it.  Only
     // after 5 ms without any news does the thread start yielding its time slice.
-    double t_last_news = now_ms();
-    auto idle_wait = [&](double us) {
+    double t_last_news = 0;
+    void idle_wait(double us) {
         const double t0w = now_ms();
         if (t0w - t_last_news > 5.0) {
             std::this_thread::sleep_for(std::chrono::microseconds((long)us));
@@ -1627,16 +1345,278 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         while ((now_ms() - t0w) * 1000.0 < us) {
             for (int q = 0; q < 32; ++q) __builtin_ia32_pause();
         }
-    };
+    }
     // Contigs whose round is decided and not yet chosen / spliced / re-seeded.  While jobs are in flight they are taken a few at
     // a time, those that go on to another round first: the copy of a finished contig's walk (hundreds of thousands of vertices
     // out of pinned memory) keeps this thread — the one every chain waits for — away from the jobs that finish meanwhile; in
     // the last third of the walks, when the contigs that leapt finish in batches of a dozen, a job of a contig still walking
     // used to wait 10 - 15 ms for its turn.
     std::vector<uint32_t> over_queue;
-    while (n_live || !over_queue.empty()) {
-        // ---- jobs that have finished since the last look
-        std::vector<uint32_t> fin;
+
+    // ---- the steps of a call, in the order run() takes them
+    // the traversal view: compact CSR, coordinate order, successor records (once per built graph)
+    int begin() {
+        PAG_HIP_TRY(hipSetDevice(g->device));
+        s = g->stream;
+        t_begin = now_ms();
+        timing = cfg.timing;
+        wdebug = cfg.walk_debug;
+        lap_t = t_begin;
+        k = g->k;
+        deviation = prm->deviation;
+        errorRate = prm->error_rate;
+        startSplit = prm->start_split;
+        topK = std::min<uint32_t>(prm->ref_threads, 8u);
+        int rc;
+        if ((rc = trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, deviation, errorRate, &G, &t_compact, orient, startSplit))) return rc;
+        slot += TRAV_GRAPH_SLOTS + TRAV_EXTRA_SLOTS;
+        lap("compact");
+        return PAG_OK;
+    }
+    // contigs: packed bases, mapper tables, per-strand node tables, id ranges, global visited structures
+    int setup_contigs() {
+        int rc;
+        n_ctgs = (uint32_t)ctgs->n_seqs;
+        g->path_off.assign(2 * (size_t)n_ctgs, 0);
+        g->path_len.assign(2 * (size_t)n_ctgs, 0);
+        g->path_valid.assign(2 * (size_t)n_ctgs, 0);
+        g->path_ptr.assign(2 * (size_t)n_ctgs, nullptr);
+        // one entry per (contig, orientation): a contig selected with both orientations is two independent traversals
+        // (PAssembly.cpp:28-36 walks every (name, forward) pair of its set)
+        for (uint32_t c2 = 0; c2 < 2 * n_ctgs; ++c2) {
+            const uint32_t c = c2 >> 1;
+            const bool fwd = (c2 & 1u) == 0;
+            const int32_t o = orient[c];
+            if (!(o == PAG_ORIENT_BOTH || (fwd && o == PAG_ORIENT_FORWARD) || (!fwd && o == PAG_ORIENT_REVERSE))) continue;
+            CtgState cs;
+            cs.ci = c;
+            cs.forward = fwd;
+            cs.chosenOne = cs.forward ? (int64_t)c + 1 : -(int64_t)c - 1;
+            cs.len = ctgs->len[c];
+            cs.ctgLeft = (uint32_t)mapper.dualToSingle(cs.chosenOne, 0);
+            cs.ctgRight = (uint32_t)mapper.dualToSingle(cs.chosenOne, cs.len);
+            cs.revLeft = (uint32_t)mapper.dualToSingle(-cs.chosenOne, 0);
+            cs.revRight = (uint32_t)mapper.dualToSingle(-cs.chosenOne, cs.len);
+            cs.nodesOff = nodes_total;
+            cs.seqCap = (uint64_t)cs.len / 2 + 8192;
+            if (cfg.debug_seqcap) cs.seqCap = (uint64_t)cfg.debug_seqcap;  // tests: force the overflow / regrow path
+            nodes_total += cs.len >= k ? cs.len - k + 1 : 0;
+            st.push_back(std::move(cs));
+        }
+        n_sel = (uint32_t)st.size();
+        if (n_sel == 0) return PAG_OK;
+
+        b_packed = buf(), b_nodes = buf(), b_starts = buf(), b_sizes = buf(), b_tc = buf(), b_seedout = buf(), b_req = buf();
+        b_gset = buf(), b_gather = buf(), b_vids = buf(), b_gbits = buf();
+        if ((rc = b_packed.alloc(ctgs->packed_bytes + 64)) || (rc = b_nodes.alloc((nodes_total + 1) * 4)) ||
+            (rc = b_starts.alloc(mapper.starts.size() * 8 + 8)) || (rc = b_sizes.alloc(mapper.sizes.size() * 8 + 8)) ||
+            (rc = b_tc.alloc(n_sel * sizeof(TravContig))))
+            return rc;
+        PAG_HIP_TRY(hipMemcpyAsync(b_packed.p, ctgs->packed, ctgs->packed_bytes, hipMemcpyHostToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(b_starts.p, mapper.starts.data(), mapper.starts.size() * 8, hipMemcpyHostToDevice, s));
+        PAG_HIP_TRY(hipMemcpyAsync(b_sizes.p, mapper.sizes.data(), mapper.sizes.size() * 8, hipMemcpyHostToDevice, s));
+        for (auto &cs : st)
+            trav_launch_ctg_nodes(b_packed.as<uint8_t>(), ctgs->byte_off[cs.ci], cs.len, cs.forward ? 1 : 0, k, G,
+                                  b_nodes.as<uint32_t>() + cs.nodesOff, s);
+
+        tc.assign(n_sel, TravContig{});
+        // id ranges of the strands, then the per-contig global visited structures
+        {
+            for (auto &cs : st) cs.gcap = 1024;  // placeholder so that gmask is well formed
+            if ((rc = upload_contigs())) return rc;
+            trav_launch_ranges(G, b_tc.as<TravContig>(), n_sel, s);
+            PAG_HIP_TRY(hipMemcpyAsync(tc.data(), b_tc.p, n_sel * sizeof(TravContig), hipMemcpyDeviceToHost, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            uint64_t tot_set = 0, tot_bits = 0;
+            for (uint32_t i = 0; i < n_sel; ++i) {
+                CtgState &cs = st[i];
+                cs.inLo = tc[i].in_lo;
+                cs.inHi = tc[i].in_hi;
+                cs.gcap = (uint32_t)pow2_at_least(cs.seqCap / 2 + 8192);
+                tot_set += cs.gcap;
+                tot_bits += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+            }
+            if ((rc = b_gset.alloc(tot_set * 4)) || (rc = b_gbits.alloc(tot_bits * 4))) return rc;
+            PAG_HIP_TRY(hipMemsetAsync(b_gset.p, 0xFF, tot_set * 4, s));
+            PAG_HIP_TRY(hipMemsetAsync(b_gbits.p, 0, tot_bits * 4, s));
+            uint64_t o1 = 0, o2 = 0;
+            for (auto &cs : st) {
+                cs.gset = b_gset.as<uint32_t>() + o1;
+                o1 += cs.gcap;
+                cs.gbits = b_gbits.as<uint32_t>() + o2;
+                o2 += ((uint64_t)(cs.inHi - cs.inLo) + 31) / 32 + 1;
+            }
+        }
+
+        lap("contig tables");
+        return PAG_OK;
+    }
+    // round 0 seeds: searchPANode(onlyFirst) then top-K
+    int first_seeds() {
+        int rc;
+        if ((rc = b_seedout.alloc((uint64_t)n_sel * SEED_STRIDE * 4))) return rc;
+        if ((rc = upload_contigs())) return rc;
+        trav_launch_seed_first(G, b_tc.as<TravContig>(), n_sel, deviation, b_seedout.as<uint32_t>(), SEED_STRIDE, s);
+        std::vector<uint32_t> seedbuf((size_t)n_sel * SEED_STRIDE);
+        PAG_HIP_TRY(hipMemcpyAsync(seedbuf.data(), b_seedout.p, seedbuf.size() * 4, hipMemcpyDeviceToHost, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        {
+            std::vector<uint32_t> vids;
+            std::vector<size_t> cnt(n_sel);
+            for (uint32_t i = 0; i < n_sel; ++i) {
+                const uint32_t *o = &seedbuf[(size_t)i * SEED_STRIDE];
+                size_t n = std::min<size_t>(std::min<size_t>(o[0], (SEED_STRIDE - 2) / 2), topK);
+                cnt[i] = n;
+                for (size_t j = 0; j < n; ++j) vids.push_back(o[1 + 2 * j]);
+            }
+            std::vector<pag_path_node> attrs;
+            if ((rc = fetch_vertices(vids, attrs))) return rc;
+            size_t at = 0;
+            for (uint32_t i = 0; i < n_sel; ++i) {
+                st[i].seeds.assign(attrs.begin() + at, attrs.begin() + at + cnt[i]);
+                at += cnt[i];
+                if (st[i].seeds.empty()) st[i].done = true;
+            }
+        }
+
+        lap("first seeds");
+        return PAG_OK;
+    }
+    // the rings of job records (host memory the walker reads), the switches of the pieces
+    int setup_rings() {
+        if (g->cpool.size() < (size_t)n_sel * GROUPS * CB_N) g->cpool.resize((size_t)n_sel * GROUPS * CB_N);
+        {
+            const uint64_t sl = std::max<uint64_t>(128, cfg.seg_len ? cfg.seg_len : 12000);
+            const uint64_t ll = std::max<uint64_t>(128, cfg.leap_seg_len ? cfg.leap_seg_len : sl / 2);
+            uint64_t est = 0;
+            for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / sl + (uint64_t)st[i].len / ll + 32;  // (every strand as if all of it were both zones)
+            while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
+            if (cfg.debug_ring) QCAP = (uint32_t)cfg.debug_ring;  // tests: a ring far smaller than a round
+        }
+        const size_t q_need = 256 + NR * (size_t)QCAP * (sizeof(TravPosted) + sizeof(TravJobOut) + sizeof(uint32_t)) + 256;
+        if (g->wq_bytes < q_need) {
+            if (g->wq_host) hipHostFree(g->wq_host);
+            g->wq_host = nullptr;
+            g->wq_bytes = 0;
+            PAG_HIP_TRY(hipHostMalloc(&g->wq_host, q_need, hipHostMallocCoherent | hipHostMallocMapped));
+            g->wq_bytes = q_need;
+        }
+        if (!g->wq_next) PAG_HIP_TRY(hipMalloc((void **)&g->wq_next, 256));
+        hq = (TravQueue *)g->wq_host;
+        hjobs = (TravPosted *)((char *)g->wq_host + 256);
+        houts = (TravJobOut *)(hjobs + NR * (size_t)QCAP);
+        hdone = (uint32_t *)(houts + NR * (size_t)QCAP);
+        std::memset(g->wq_host, 0, 256);
+        std::memset(hdone, 0, NR * (size_t)QCAP * sizeof(uint32_t));
+        PAG_HIP_TRY(hipMemsetAsync(g->wq_next, 0, 256, s));
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        t_walk0 = now_ms();
+        use_pieces = cfg.pieces;
+        seg_len_env = cfg.seg_len;
+        seg_ov = cfg.seg_overlap;
+        force_exact = cfg.force_exact;
+        RS.clear();
+        RS.resize(n_sel);
+        jref.assign(NR * (size_t)QCAP, JobRef{});
+        orphaning = cfg.orphaning;
+        keep_segments = orphaning && cfg.keep_segments;
+        for (auto &x : n_leap_refused) x = 0;
+        use_leap_pieces = cfg.leap_pieces;
+        deferred.clear();
+        deferred.resize(n_sel);
+        b_ckreq = buf(), b_ckout = buf();
+        return PAG_OK;
+    }
+    // pinned staging + the walk arena
+    int reserve_arena() {
+        if (!pinned(64u << 20)) return PAG_ENOMEM;  // (grown later if a batch needs more)
+        {   // the walk arena: sized for the first round of every contig (chain buffers over the whole strand + segment buffers)
+            // plus half again for resumed walks and later rounds; at most 40 % of the free device memory; kept by the handle
+            size_t want = 0;
+            for (uint32_t i = 0; i < n_sel; ++i) {
+                const CtgState &cs = st[i];
+                const size_t span = (size_t)(cs.inHi - cs.inLo) + 8, cap = cs.seqCap, oc = pow2_at_least(cap / 4 + 4096);
+                const size_t chain = cap * 8 + cap * 8 * TRAV_PROBE_GROUPS + oc * 8 * (1 + TRAV_PROBE_GROUPS) + span * 4 * (1 + TRAV_PROBE_GROUPS);
+                const size_t n_seg = cs.len / 12000 + 1, scap = 8192 + 8192, soc = pow2_at_least(scap / 4 + 4096), sspan = span / (n_seg ? n_seg : 1) * 2 + 4096;
+                const size_t seg = scap * 8 + scap * 8 * TRAV_PROBE_GROUPS + soc * 8 * (1 + TRAV_PROBE_GROUPS) + sspan * 4 * (1 + TRAV_PROBE_GROUPS);
+                // segments of the leaping zone (the last tenth of the strand + margin, half as long, far larger hash sets, a log)
+                const size_t n_lseg = cs.len / 8 / 6000 + 2, lcap = 3000 + 8192, loc = pow2_at_least(lcap + 8192), lspan = sspan;
+                const size_t lseg = lcap * 8 + lcap * 8 * TRAV_PROBE_GROUPS + lcap * 8 + loc * 8 * (1 + TRAV_PROBE_GROUPS) + lspan * 4 * (1 + TRAV_PROBE_GROUPS);
+                // (full-strand buffers: the resumed walks — the seeds' own first pieces are sized like segments)
+                want += chain * 3 / 2 + (seg * (n_seg + 8) + lseg * n_lseg) * 3 / 2;
+            }
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
+            if (g->walk_arena_cap < want / 10 * 7) {  // (an arena that is there — pag_reserve_walk_arena, an earlier call — is kept
+                                                      // unless it is much too small: what does not fit goes to the slots)
+                if (g->walk_arena) hipFree(g->walk_arena);
+                g->walk_arena = nullptr;
+                g->walk_arena_cap = 0;
+                if (hipMalloc(&g->walk_arena, want) == hipSuccess) g->walk_arena_cap = want;
+                else g->walk_arena = nullptr;  // (the slots do all the work then)
+            }
+            g->walk_arena_used = 0;
+        }
+        return PAG_OK;
+    }
+    // the first round of every contig is posted, the walker grid launched
+    int post_first_rounds() {
+        int rc;
+        tw0 = now_ms();
+        t_walk0 = tw0;
+        g->defer_free = true;
+        {   // longest contigs first: their exact tails (the leaping zone is a tenth of the contig) are the longest, so their
+            // segments should be through the queue first
+            std::vector<uint32_t> order(n_sel);
+            for (uint32_t i = 0; i < n_sel; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a2, uint32_t b2) { return st[a2].len > st[b2].len; });
+            // First rounds: the contigs' segment jobs enter the ring interleaved, a few per contig and turn (a contig's leap
+            // segments first).  Posted contig by contig, the last contigs of the list finish their first round when the grid
+            // runs empty — and those of them that need a second round (a re-seed after a walk that ended early) start it then:
+            // every contig's first round now ends at about the same time, earlier than the last ones did.
+            const uint32_t interleave = cfg.post_interleave;
+            defer_ring2 = interleave != 0;
+            {
+                std::vector<uint32_t> first_rounds;
+                for (uint32_t i : order)
+                    if (!st[i].done) first_rounds.push_back(i);
+                if ((rc = start_rounds(first_rounds))) return fail(rc);
+            }
+            defer_ring2 = false;
+            if (interleave) {
+                std::vector<size_t> at(n_sel, 0);
+                for (bool more = true; more;) {
+                    more = false;
+                    for (uint32_t i : order) {
+                        auto &dq = deferred[i];
+                        for (uint32_t c = 0; c < interleave && at[i] < dq.size(); ++c, ++at[i])
+                            if ((rc = commit_job(2u, dq[at[i]].P, dq[at[i]].jr, dq[at[i]].P.J.mode, dq[at[i]].P.J.stop_pc))) return fail(rc);
+                        more = more || at[i] < dq.size();
+                    }
+                }
+                for (auto &dq : deferred) std::vector<Deferred>().swap(dq);
+            }
+        }
+        if (n_live) {
+            walkers.init(g, G, hjobs, houts, hdone, hq, QCAP, k);
+            if ((rc = publish())) return fail(rc);  // (the jobs' buffers are ready, the rings are visible)
+            if ((rc = walkers.ensure(n_live))) {
+                g->defer_free = false;
+                return rc;
+            }
+            if (wdebug) std::fprintf(stderr, "[walk] %u walker waves launched (at most %u), %u + %u + %u jobs posted\n", walkers.launched, walkers.max_waves, n_posted[0], n_posted[1], n_posted[2]);
+        } else {
+            g->defer_free = false;
+        }
+        lap("round prep");
+        return PAG_OK;
+    }
+
+    // ---- the event loop, step by step
+    // jobs that have finished since the last look (again: nothing to do yet, look again)
+    int poll_finished(std::vector<uint32_t> &fin, bool &again) {
+        int rc;
+        again = false;
         for (uint32_t ring = 0; ring < NR; ++ring) {
             // (at most QCAP jobs of a ring are in flight: a slot is taken again only when the job QCAP numbers earlier has been
             // handled — without this clamp a ring far smaller than a round would be scanned around more than once)
@@ -1662,7 +1642,8 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             if (t_first_fin == 0) t_first_fin = now_ms();
             if (!urgent) {
                 idle_wait(20.0);
-                continue;
+                again = true;
+                return PAG_OK;
             }
             t_first_fin = 0;
         }
@@ -1679,22 +1660,26 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 return fail(PAG_EFAULT);
             }
             idle_wait(30.0);
-            continue;
+            again = true;
+            return PAG_OK;
         }
         t_progress = now_ms();
         t_last_news = t_progress;
         lap("walk");
-
-        // ---- their paths: vertices, steps and contig coordinates to the host (one round trip for the batch)
-        struct Got {
-            uint32_t jn;
-            uint64_t from, len, off;       // the part of the sequence that is new; word offset of its packed words (trav_pack_words)
-            const uint32_t *v, *s, *pc;     // ... in pinned memory that lives as long as this call (fetch_alloc)
-            const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: low / high words of the iteration log
-            const uint32_t *agg = nullptr, *xagg = nullptr;  // block tables of those arrays (walk_stitch.hpp; written by k_pack_paths)
-        };
+        return PAG_OK;
+    }
+    // ---- their paths: vertices, steps and contig coordinates to the host (one round trip for the batch)
+    struct Got {
+        uint32_t jn;
+        uint64_t from, len, off;       // the part of the sequence that is new; word offset of its packed words (trav_pack_words)
+        const uint32_t *v, *s, *pc;     // ... in pinned memory that lives as long as this call (fetch_alloc)
+        const uint32_t *xl = nullptr, *xh = nullptr;  // TRAV_MODE_LEAP: low / high words of the iteration log
+        const uint32_t *agg = nullptr, *xagg = nullptr;  // block tables of those arrays (walk_stitch.hpp; written by k_pack_paths)
+    };
+    int fetch_paths(const std::vector<uint32_t> &fin, std::vector<Got> &got) {
+        int rc;
         static_assert(AGG_BLOCK == 64 && AGG_WORDS == 5 && AGG_XWORDS == 2, "k_pack_paths writes these tables");
-        std::vector<Got> got(fin.size());
+        got.assign(fin.size(), Got{});
         {
             uint64_t tot = 0, max_len = 0;
             std::vector<TravPackDesc> descs(fin.size());
@@ -1761,9 +1746,12 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             }
         }
         lap("fetch");
-
+        return PAG_OK;
+    }
+    // bookkeeping of the finished jobs, their paths into segments and chains, the chains move on; touched: the contigs with news
+    int stitch_finished(std::vector<Got> &got, std::vector<uint32_t> &touched) {
+        int rc;
         const double ts0 = now_ms();
-        std::vector<uint32_t> touched;  // contigs with news
         // serial part: bookkeeping, and the (rare) jobs that have to be posted again
         std::vector<size_t> heavy;  // items of `got` whose path has to be copied / indexed
         for (size_t gx = 0; gx < got.size(); ++gx) {
@@ -1894,8 +1882,10 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         t_st[1] += ts2 - ts1;
         t_st[2] += now_ms() - ts2;
         lap("stitch");
-
-        // ---- contigs whose chains are all final: the round is decided
+        return PAG_OK;
+    }
+    // contigs whose chains are all final: the round is decided; batch: those taken now
+    void decide_rounds(const std::vector<uint32_t> &touched, std::vector<uint32_t> &batch) {
         for (uint32_t i : touched) {
             RoundState &R = RS[i];
             if (!R.active) continue;
@@ -1906,7 +1896,6 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs)) && std::find(over_queue.begin(), over_queue.end(), i) == over_queue.end())
                 over_queue.push_back(i);
         }
-        std::vector<uint32_t> batch;
         {
             auto leaps = [&](uint32_t i) {  // the round ended on another contig: the contig is finished (PAlgorithm.cpp:254-262, 322-328)
                 for (const Chain &ch : RS[i].chains) {
@@ -1920,23 +1909,17 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             batch.assign(over_queue.begin(), over_queue.begin() + (long)take);
             over_queue.erase(over_queue.begin(), over_queue.begin() + (long)take);
         }
-        flush_backlog();
-        if (batch.empty()) {
-            if ((rc = publish())) return fail(rc);
-            lap("round prep");
-            continue;
-        }
-
-        // ---- per contig: choose (PAlgorithm.cpp:238-262); the chosen walks are uploaded, gathered and committed on the
-        //      device back to back, copied out, and spliced by a pool of host threads (contigs are independent)
-        struct Pick {
-            int chosen = -1;
-            bool leap = false;
-            size_t chooseCtgPos = 0, chooseRefPos = 0;
-            uint64_t off = 0, len = 0;
-        };
-        std::vector<Pick> picks(n_sel);
-        std::vector<uint32_t> next_round;
+    }
+    // ---- per contig: choose (PAlgorithm.cpp:238-262); the chosen walks are uploaded, gathered and committed on the
+    //      device back to back, copied out, and spliced by a pool of host threads (contigs are independent)
+    struct Pick {
+        int chosen = -1;
+        bool leap = false;
+        size_t chooseCtgPos = 0, chooseRefPos = 0;
+        uint64_t off = 0, len = 0;
+    };
+    int take_walks(const std::vector<uint32_t> &batch, std::vector<Pick> &picks) {
+        int rc;
         {
             uint64_t tot = 0;
             for (uint32_t i : batch) {
@@ -2107,8 +2090,10 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
         }
         for (uint32_t i : batch) RS[i].chains.clear();  // (the host copies of the round's chains are spent; its segments: below)
         lap("choose+gather");
-
-        // splice + stop rules (PAlgorithm.cpp:264-360)
+        return PAG_OK;
+    }
+    // splice + stop rules (PAlgorithm.cpp:264-360); reqs / req_cs: the seed searches of the contigs that go on
+    void splice_batch(const std::vector<uint32_t> &batch, const std::vector<Pick> &picks, std::vector<TravSeedReq> &reqs, std::vector<uint32_t> &req_cs) {
         std::vector<TravSeedReq> slot_req(n_sel);
         std::vector<uint8_t> slot_has(n_sel, 0);
         auto splice = [&](uint32_t i) {
@@ -2175,8 +2160,6 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             worker();
             for (auto &t : pool) t.join();
         }
-        std::vector<TravSeedReq> reqs;
-        std::vector<uint32_t> req_cs;
         for (uint32_t i : batch)
             if (slot_has[i]) {
                 reqs.push_back(slot_req[i]);
@@ -2191,8 +2174,10 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
             else RS[i].kept = !RS[i].segs.empty();
         }
         lap("splice");
-
-        // ---- next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
+    }
+    // next seeds: searchPANode2 + filterPANodes + sort by edit distance + top-K
+    int reseed(std::vector<TravSeedReq> &reqs, const std::vector<uint32_t> &req_cs, std::vector<uint32_t> &next_round) {
+        int rc;
         if (!reqs.empty()) {
             const uint32_t PARTS = TRAV_SEED_PARTS;
             uint32_t WSTRIDE = 2048;  // words per part of a request
@@ -2282,100 +2267,239 @@ static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient
                 else next_round.push_back(req_cs[q]);
             }
         }
-        for (uint32_t i : batch)
-            if (st[i].done && (rc = deliver_contig(i))) return fail(rc);
-        lap("reseed");
-        // ---- post the follow-up rounds
-        if (!next_round.empty() && (rc = start_rounds(next_round))) return fail(rc);
-        flush_backlog();
-        if ((rc = publish())) return fail(rc);
-        lap("round prep");
+        return PAG_OK;
     }
-    shutdown_walker();
-    g->defer_free = false;
-    for (void *q : pinned_parked) hipHostFree(q);
-    pinned_parked.clear();
-    t_walk = now_ms() - tw0;
-    lap("walk");
-    if (timing || wdebug) {
-        std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms; fetch memory: chunk %zu of %zu; walk arena: %.2f of %.2f GB used\n", t_st[0], t_st[1], t_st[2], t_st[3],
-                     fetch_chunk + 1, g->fetch_chunks.size(), g->walk_arena_used / 1e9, g->walk_arena_cap / 1e9);
-        std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
-                     (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted.load(), (unsigned long long)n_leap_refused[0].load(), (unsigned long long)n_leap_refused[1].load(), (unsigned long long)n_leap_refused[2].load(),
-                     (unsigned long long)n_leap_refused[3].load(), (unsigned long long)n_leap_refused[4].load(), (unsigned long long)n_leap_refused[5].load(), (unsigned long long)n_leap_refused[6].load(), (unsigned long long)n_leap_refused[7].load());
-        {
-            size_t n_tail = 0, n_tail_behind = 0;
-            for (const CtgState &cs : st) n_tail += cs.tail.on, n_tail_behind += cs.tail.on && cs.tail.m0;
-            std::fprintf(stderr, "[timing] last rounds put together on the device: %zu of %u contigs (%zu behind an earlier round's path)\n", n_tail, n_sel, n_tail_behind);
+    int event_loop() {
+        int rc;
+        b_fetch = buf(), b_fdesc = buf();
+        t_progress = now_ms();
+        t_first_fin = 0;
+        t_last_news = now_ms();
+        while (n_live || !over_queue.empty()) {
+            std::vector<uint32_t> fin, touched, batch, req_cs, next_round;
+            bool again = false;
+            if ((rc = poll_finished(fin, again))) return rc;
+            if (again) continue;
+            std::vector<Got> got;
+            if ((rc = fetch_paths(fin, got))) return rc;
+            if ((rc = stitch_finished(got, touched))) return rc;
+            decide_rounds(touched, batch);
+            flush_backlog();
+            if (batch.empty()) {
+                if ((rc = publish())) return fail(rc);
+                lap("round prep");
+                continue;
+            }
+            // per contig: choose (PAlgorithm.cpp:238-262), commit, splice, stop or re-seed
+            std::vector<Pick> picks(n_sel);
+            if ((rc = take_walks(batch, picks))) return rc;
+            std::vector<TravSeedReq> reqs;
+            splice_batch(batch, picks, reqs, req_cs);
+            if ((rc = reseed(reqs, req_cs, next_round))) return rc;
+            for (uint32_t i : batch)
+                if (st[i].done && (rc = deliver_contig(i))) return fail(rc);
+            lap("reseed");
+            // the follow-up rounds
+            if (!next_round.empty() && (rc = start_rounds(next_round))) return fail(rc);
+            flush_backlog();
+            if ((rc = publish())) return fail(rc);
+            lap("round prep");
         }
-        std::fprintf(stderr, "[timing] pieces: %llu segment jobs, %llu resume jobs, %llu vertices adopted, %llu segments not adoptable\n", (unsigned long long)n_seg_jobs,
-                     (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted.load(), (unsigned long long)n_merge_fail.load());
+        return PAG_OK;
     }
+    // the walker is sent home; whatever has not been delivered while the walks ran; statistics
+    int finish() {
+        int rc;
+        shutdown_walker();
+        g->defer_free = false;
+        for (void *q : pinned_parked) hipHostFree(q);
+        pinned_parked.clear();
+        t_walk = now_ms() - tw0;
+        lap("walk");
+        if (timing || wdebug) {
+            std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms; fetch memory: chunk %zu of %zu; walk arena: %.2f of %.2f GB used\n", t_st[0], t_st[1], t_st[2], t_st[3],
+                         fetch_chunk + 1, g->fetch_chunks.size(), g->walk_arena_used / 1e9, g->walk_arena_cap / 1e9);
+            std::fprintf(stderr, "[timing] leaping zone: %llu segment jobs, %llu adopted, refused by reason (unusable, no junction, not a boundary, cannot leap yet, window top, window bottom, contig-following record, coordinate-free record): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                         (unsigned long long)n_leap_jobs, (unsigned long long)n_leap_adopted.load(), (unsigned long long)n_leap_refused[0].load(), (unsigned long long)n_leap_refused[1].load(), (unsigned long long)n_leap_refused[2].load(),
+                         (unsigned long long)n_leap_refused[3].load(), (unsigned long long)n_leap_refused[4].load(), (unsigned long long)n_leap_refused[5].load(), (unsigned long long)n_leap_refused[6].load(), (unsigned long long)n_leap_refused[7].load());
+            {
+                size_t n_tail = 0, n_tail_behind = 0;
+                for (const CtgState &cs : st) n_tail += cs.tail.on, n_tail_behind += cs.tail.on && cs.tail.m0;
+                std::fprintf(stderr, "[timing] last rounds put together on the device: %zu of %u contigs (%zu behind an earlier round's path)\n", n_tail, n_sel, n_tail_behind);
+            }
+            std::fprintf(stderr, "[timing] pieces: %llu segment jobs, %llu resume jobs, %llu vertices adopted, %llu segments not adoptable\n", (unsigned long long)n_seg_jobs,
+                         (unsigned long long)n_resume_jobs, (unsigned long long)n_adopted.load(), (unsigned long long)n_merge_fail.load());
+        }
 
-    // ---- epilogue: whatever has not been delivered while the walks ran (see deliver_contig)
-    for (uint32_t i = 0; i < n_sel; ++i)
-        if (!st[i].delivered) filter_travel(st[i]);
-    {   // the full records of those sequences: one gather, results straight into the pinned array the handle keeps for
-        // pag_travel_path()
-        uint64_t tot = 0;
-        for (auto &cs : st)
-            if (!cs.delivered) tot += cs.travel.size();
-        if (g->path_cap < tot + 1) {
-            if (g->path_store) hipHostFree(g->path_store);
-            g->path_store = nullptr;
-            g->path_cap = 0;
-            const size_t want = tot + tot / 8 + 1024;
-            if (hipHostMalloc((void **)&g->path_store, want * sizeof(pag_path_node), hipHostMallocDefault) != hipSuccess) {
-                set_error("pag_travel: hipHostMalloc for %zu path records failed", want);
-                return fail(PAG_ENOMEM);
+        // ---- epilogue: whatever has not been delivered while the walks ran (see deliver_contig)
+        for (uint32_t i = 0; i < n_sel; ++i)
+            if (!st[i].delivered) filter_travel(st[i]);
+        {   // the full records of those sequences: one gather, results straight into the pinned array the handle keeps for
+            // pag_travel_path()
+            uint64_t tot = 0;
+            for (auto &cs : st)
+                if (!cs.delivered) tot += cs.travel.size();
+            if (g->path_cap < tot + 1) {
+                if (g->path_store) hipHostFree(g->path_store);
+                g->path_store = nullptr;
+                g->path_cap = 0;
+                const size_t want = tot + tot / 8 + 1024;
+                if (hipHostMalloc((void **)&g->path_store, want * sizeof(pag_path_node), hipHostMallocDefault) != hipSuccess) {
+                    set_error("pag_travel: hipHostMalloc for %zu path records failed", want);
+                    return fail(PAG_ENOMEM);
+                }
+                g->path_cap = want;
             }
-            g->path_cap = want;
-        }
-        uint32_t *hp = (uint32_t *)pinned(tot * 8 + 256);
-        if (!hp) return fail(PAG_ENOMEM);
-        uint64_t at = 0;
-        for (auto &cs : st) {
-            if (cs.delivered) continue;
-            const size_t slot2 = 2 * (size_t)cs.ci + (cs.forward ? 0 : 1);
-            g->path_off[slot2] = at;
-            g->path_len[slot2] = cs.travel.size();
-            g->path_valid[slot2] = 1;
-            for (size_t x = 0; x < cs.travel.size(); ++x) {
-                hp[at + x] = cs.travel[x].u;
-                hp[tot + at + x] = (uint32_t)cs.travel[x].step;
+            uint32_t *hp = (uint32_t *)pinned(tot * 8 + 256);
+            if (!hp) return fail(PAG_ENOMEM);
+            uint64_t at = 0;
+            for (auto &cs : st) {
+                if (cs.delivered) continue;
+                const size_t slot2 = 2 * (size_t)cs.ci + (cs.forward ? 0 : 1);
+                g->path_off[slot2] = at;
+                g->path_len[slot2] = cs.travel.size();
+                g->path_valid[slot2] = 1;
+                for (size_t x = 0; x < cs.travel.size(); ++x) {
+                    hp[at + x] = cs.travel[x].u;
+                    hp[tot + at + x] = (uint32_t)cs.travel[x].step;
+                }
+                at += cs.travel.size();
             }
-            at += cs.travel.size();
+            DevBuf b_fin = buf();
+            if ((rc = b_fin.alloc(tot * 8 + 64)) || (rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return fail(rc);
+            if (tot) {
+                PAG_HIP_TRY(hipMemcpyAsync(b_fin.p, hp, tot * 8, hipMemcpyHostToDevice, s));
+                trav_launch_gather_path(G, b_fin.as<uint32_t>(), b_fin.as<uint32_t>() + tot, tot, b_gather.as<pag_path_node>(), s);
+                PAG_HIP_TRY(hipMemcpyAsync(g->path_store, b_gather.p, tot * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
+            }
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            if (g->deliver_stream) PAG_HIP_TRY(hipStreamSynchronize(g->deliver_stream));  // (the deliveries made during the walks)
         }
-        DevBuf b_fin = buf();
-        if ((rc = b_fin.alloc(tot * 8 + 64)) || (rc = b_gather.alloc(tot * sizeof(pag_path_node) + 64))) return fail(rc);
-        if (tot) {
-            PAG_HIP_TRY(hipMemcpyAsync(b_fin.p, hp, tot * 8, hipMemcpyHostToDevice, s));
-            trav_launch_gather_path(G, b_fin.as<uint32_t>(), b_fin.as<uint32_t>() + tot, tot, b_gather.as<pag_path_node>(), s);
-            PAG_HIP_TRY(hipMemcpyAsync(g->path_store, b_gather.p, tot * sizeof(pag_path_node), hipMemcpyDeviceToHost, s));
+        lap("epilogue");
+        if (timing) {
+            std::fprintf(stderr, "[timing] walks redone without speculation: %u\n", respeculated);
+            std::fprintf(stderr, "[timing] segment jobs left behind by rounds that were decided without them: %llu\n", (unsigned long long)n_orphans);
+            std::fprintf(stderr, "[timing] pag_travel laps:");
+            for (auto &l : laps) std::fprintf(stderr, " %s %.1f ms;", l.first, l.second);
+            std::fprintf(stderr, "\n");
         }
-        PAG_HIP_TRY(hipStreamSynchronize(s));
-        if (g->deliver_stream) PAG_HIP_TRY(hipStreamSynchronize(g->deliver_stream));  // (the deliveries made during the walks)
+        if (stats) {
+            stats->ms_compact = t_compact;
+            stats->ms_walk = t_walk;
+            stats->ms_total = now_ms() - t_begin;
+            stats->rounds = rounds;
+            stats->jobs = jobs_total;
+            stats->walk_steps = steps_total;
+            stats->classify_calls = classify_total;
+            stats->probes = probe_total;
+            stats->records = record_total;
+        }
+        return PAG_OK;
     }
-    lap("epilogue");
-    if (timing) {
-        std::fprintf(stderr, "[timing] walks redone without speculation: %u\n", respeculated);
-        std::fprintf(stderr, "[timing] segment jobs left behind by rounds that were decided without them: %llu\n", (unsigned long long)n_orphans);
-        std::fprintf(stderr, "[timing] pag_travel laps:");
-        for (auto &l : laps) std::fprintf(stderr, " %s %.1f ms;", l.first, l.second);
-        std::fprintf(stderr, "\n");
+    int run() {
+        int rc;
+        if ((rc = begin()) || (rc = setup_contigs())) return rc;
+        if (n_sel == 0) return PAG_OK;
+        if ((rc = first_seeds()) || (rc = setup_rings()) || (rc = reserve_arena()) || (rc = post_first_rounds()) || (rc = event_loop())) return rc;
+        return finish();
     }
-    if (stats) {
-        stats->ms_compact = t_compact;
-        stats->ms_walk = t_walk;
-        stats->ms_total = now_ms() - t_begin;
-        stats->rounds = rounds;
-        stats->jobs = jobs_total;
-        stats->walk_steps = steps_total;
-        stats->classify_calls = classify_total;
-        stats->probes = probe_total;
-        stats->records = record_total;
+};
+
+}  // namespace
+
+
+extern "C" {
+
+// test hooks (host code only, no device needed): the library's own copies of PositionMapper and editDistance against the
+// reference's function-level golden tables (tests/test_function_goldens.py)
+uint64_t pag_debug_edit_distance(const char *a, const char *b) { return edit_distance(a, b); }
+uint64_t pag_debug_mapper_d2s(const uint32_t *len, uint64_t n, int64_t idx, int64_t pos) { return Mapper(len, n).dualToSingle(idx, pos); }
+void pag_debug_mapper_s2d(const uint32_t *len, uint64_t n, uint64_t single, int64_t *idx, int64_t *pos) {
+    auto d = Mapper(len, n).singleToDual(single);
+    *idx = d.first;
+    *pos = d.second;
+}
+uint64_t pag_debug_mapper_extra(const uint32_t *len, uint64_t n) { return Mapper(len, n).starts.back(); }
+
+// g->paths[2 * contig + (reverse ? 1 : 0)]
+const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len) {
+    const uint64_t slot = 2 * ctg_index + (forward ? 0 : 1);
+    if (!g || slot >= g->path_valid.size() || !g->path_valid[slot]) {
+        if (len) *len = 0;
+        return nullptr;
     }
+    if (len) *len = g->path_len[slot];
+    if (slot < g->path_ptr.size() && g->path_ptr[slot]) return g->path_ptr[slot];
+    return g->path_store + g->path_off[slot];
+}
+
+const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len) {
+    if (g && 2 * ctg_index + 1 < g->path_valid.size() && !g->path_valid[2 * ctg_index]) return pag_travel_path_oriented(g, ctg_index, 0, len);
+    return pag_travel_path_oriented(g, ctg_index, 1, len);
+}
+
+// test hooks: the successor records of the prepared traversal graph (after pag_travel_prepare), copied to the host:
+// succ_off[n_pos + 1], then n_succ records of 16 bytes (target, contig coordinate, step | grade | flags | count, target's offset)
+int pag_debug_succ_sizes(const pag_graph *g, uint64_t *n_pos, uint64_t *n_succ) {
+    if (!g || !g->tg_ready || !n_pos || !n_succ) return PAG_EINVAL;
+    *n_pos = g->tg.n_pos;
+    *n_succ = g->tg.n_succ;
     return PAG_OK;
 }
+int pag_debug_succ(const pag_graph *g, uint32_t *succ_off, void *recs) {
+    if (!g || !g->tg_ready || !succ_off || !recs) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    PAG_HIP_TRY(hipMemcpy(succ_off, g->tg.succ_off, (g->tg.n_pos + 1) * 4, hipMemcpyDeviceToHost));
+    PAG_HIP_TRY(hipMemcpy(recs, g->tg.succ, g->tg.n_succ * sizeof(SuccRec), hipMemcpyDeviceToHost));
+    return PAG_OK;
+}
+
+// the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
+int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm, double *ms) {
+    return pag_travel_prepare_for(g, ctgs, nullptr, ref_len, n_refs, prm, ms);
+}
+// ... for the traversals pag_travel will be asked for (orient as pag_travel takes it; NULL: any): the view then holds what
+// those traversals can examine and nothing else (trav_view_region above)
+int pag_travel_prepare_for(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                           const pag_travel_params *prm, double *ms) {
+    if (!g || !ctgs || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    TravGraph G{};
+    return trav_prepare_graph(g, ctgs->len, ctgs->n_seqs, ref_len, n_refs, prm->deviation, prm->error_rate, &G, ms, orient, prm->start_split);
+}
+int pag_travel_view_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos, uint64_t *n_edges, uint64_t *n_succ, int *cut, uint64_t *fallbacks) {
+    if (!g || !g->tg_ready) return PAG_EINVAL;
+    if (n_nodes) *n_nodes = g->view_counts[0];
+    if (n_pos) *n_pos = g->view_counts[1];
+    if (n_edges) *n_edges = g->view_counts[2];
+    if (n_succ) *n_succ = g->tg.n_succ;
+    if (cut) *cut = g->view_pruned ? 1 : 0;
+    if (fallbacks) *fallbacks = g->view_fallbacks;
+    return PAG_OK;
+}
+
+static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                       const pag_travel_params *prm, pag_travel_stats *stats);
+int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+               const pag_travel_params *prm, pag_travel_stats *stats) {
+    if (!g || !ctgs || !orient || !prm || (!ref_len && n_refs)) return PAG_EINVAL;
+    int rc = travel_once(g, ctgs, orient, ref_len, n_refs, prm, stats);
+    if (rc == PAG_ERANGE && g->view_pruned && !g->regional) {
+        // a walk examined a vertex whose successors this handle's own view left out (trav_view_region): nothing of that walk is
+        // kept — the whole graph's view is built and every contig walked again (the outputs are those of the un-cut graph)
+        if (WalkConfig::from_env().timing) std::fprintf(stderr, "[timing] a walk left the view: %s; walking again on the whole graph\n", pag_last_error());
+        g->view_off = true;
+        g->tg_ready = false;
+        g->view_fallbacks += 1;
+        rc = travel_once(g, ctgs, orient, ref_len, n_refs, prm, stats);
+    }
+    return rc;
+}
+static int travel_once(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
+                       const pag_travel_params *prm, pag_travel_stats *stats) {
+    WalkSession W(g, ctgs, orient, ref_len, n_refs, prm, stats);
+    return W.run();
+}
+
 
 }  // extern "C"

@@ -90,6 +90,7 @@ struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_dest
     pag_graph *g = nullptr;
     pag_graph::Slot *sl = nullptr;
     void *p = nullptr;
+    DevBuf() = default;
     DevBuf(pag_graph *gg, int s) : g(gg), sl(&gg->pool[s]) {}
     DevBuf(pag_graph *gg, pag_graph::Slot *slot) : g(gg), sl(slot) {}
     int alloc(size_t bytes) {
