@@ -2089,24 +2089,41 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         } else {
             uint64_t add = 0;
             uint32_t lo = 0xFFFFFFFFu, hi = 0, n_outside = 0;
-            for (uint64_t i = lane; i < ch_len; i += 64) {
-                uint32_t v = ch_v[ch_off + i], st = ch_s[ch_off + i];
-                J.seq_v[seq_len + i] = v;  // (a RESUME job's first "chosen path" is the sequence itself: stored onto itself)
-                J.seq_s[seq_len + i] = st;
-                if (in_range(X, v)) {
-                    stamp_store(&X.tbits[v - X.C.in_lo], X.epoch);
-                    const uint32_t e = v - X.C.in_lo - X.w_d0;
-                    if (e < X.w_nid) L.wts[e] = X.epoch;
-                } else {
-                    hs64_insert(X.tset_o, X.tmask_o, v, X.epoch);
-                    filt_set(L.ft, v);
-                    ++n_outside;
+            // Four entries per lane and turn, their loads issued together: the path a RESUME job takes over is the whole walk so
+            // far — a quarter of a million vertices at the end of a 1 Mb contig — and one entry per turn (load, coordinate
+            // gather, mark: three dependent round trips) made such a job spend 5 ms here before its first step, on the
+            // critical path of its contig (every contig ends with one or two of them).
+            for (uint64_t i0 = lane; i0 < ch_len; i0 += 256) {
+                uint32_t v4[4], st4[4], c4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t i = i0 + (uint64_t)q * 64u;
+                    v4[q] = i < ch_len ? ch_v[ch_off + i] : 0u;
+                    st4[q] = i < ch_len ? ch_s[ch_off + i] : 0u;
                 }
-                add += st;
-                uint32_t c = (uint32_t)(G.upos[v] >> 32);
-                if (c != 0) {
-                    lo = c < lo ? c : lo;
-                    hi = c > hi ? c : hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c4[q] = i0 + (uint64_t)q * 64u < ch_len ? (uint32_t)(G.upos[v4[q]] >> 32) : 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t i = i0 + (uint64_t)q * 64u;
+                    if (i >= ch_len) break;
+                    const uint32_t v = v4[q], st = st4[q], c = c4[q];
+                    J.seq_v[seq_len + i] = v;  // (a RESUME job's first "chosen path" is the sequence itself: stored onto itself)
+                    J.seq_s[seq_len + i] = st;
+                    if (in_range(X, v)) {
+                        stamp_store(&X.tbits[v - X.C.in_lo], X.epoch);
+                        const uint32_t e = v - X.C.in_lo - X.w_d0;
+                        if (e < X.w_nid) L.wts[e] = X.epoch;
+                    } else {
+                        hs64_insert(X.tset_o, X.tmask_o, v, X.epoch);
+                        filt_set(L.ft, v);
+                        ++n_outside;
+                    }
+                    add += st;
+                    if (c != 0) {
+                        lo = c < lo ? c : lo;
+                        hi = c > hi ? c : hi;
+                    }
                 }
             }
             {

@@ -2280,29 +2280,42 @@ struct WalkSession {
             bool again = false;
             if ((rc = poll_finished(fin, again))) return rc;
             if (again) continue;
+            auto mark = [&](const char *what) {  // (PAG_WALK_DEBUG: where this thread's time goes, iteration by iteration)
+                if (wdebug) std::fprintf(stderr, "[walk] t=%.1f ms loop: %s (%zu jobs, %zu contigs decided, %u live)\n", now_ms() - tw0, what, fin.size(), batch.size(), n_live);
+            };
+            mark("polled");
             std::vector<Got> got;
             if ((rc = fetch_paths(fin, got))) return rc;
+            mark("fetched");
             if ((rc = stitch_finished(got, touched))) return rc;
+            mark("stitched");
             decide_rounds(touched, batch);
             flush_backlog();
             if (batch.empty()) {
                 if ((rc = publish())) return fail(rc);
+                mark("published");
                 lap("round prep");
                 continue;
             }
             // per contig: choose (PAlgorithm.cpp:238-262), commit, splice, stop or re-seed
             std::vector<Pick> picks(n_sel);
             if ((rc = take_walks(batch, picks))) return rc;
+            mark("walks taken");
             std::vector<TravSeedReq> reqs;
             splice_batch(batch, picks, reqs, req_cs);
+            mark("spliced");
             if ((rc = reseed(reqs, req_cs, next_round))) return rc;
+            mark("re-seeded");
             for (uint32_t i : batch)
                 if (st[i].done && (rc = deliver_contig(i))) return fail(rc);
+            mark("delivered");
             lap("reseed");
             // the follow-up rounds
             if (!next_round.empty() && (rc = start_rounds(next_round))) return fail(rc);
+            mark("next rounds posted");
             flush_backlog();
             if ((rc = publish())) return fail(rc);
+            mark("published");
             lap("round prep");
         }
         return PAG_OK;

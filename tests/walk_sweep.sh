@@ -7,11 +7,10 @@ print('$name', round(d['ms_per_step'],1), 'walks', round(c['ms_walks_wall'],1), 
 " >> gpurun_out/r04h/sweep2.txt; }
 rm -f gpurun_out/r04h/sweep2.txt
 run base A=1
-run wpc4 PAG_WALK_WAVES_PER_CU=4
-run wpc6 PAG_WALK_WAVES_PER_CU=6
-run wpc2 PAG_WALK_WAVES_PER_CU=2
-run seg8k PAG_SEG_LEN=8000
-run seg16k PAG_SEG_LEN=16000
-run wpc4seg8k PAG_WALK_WAVES_PER_CU=4 PAG_SEG_LEN=8000
+run group8 PAG_POST_GROUP=8
+run group12 PAG_POST_GROUP=12
+run group16 PAG_POST_GROUP=16
+run group24 PAG_POST_GROUP=24
+run group32 PAG_POST_GROUP=32
 run base2 A=1
 cat gpurun_out/r04h/sweep2.txt
