@@ -2,6 +2,7 @@
 # Everything lands under gpurun_out/evidence/; copy what is to be judged into profiles/.
 out=gpurun_out/evidence
 mkdir -p $out
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
 python -m pytest tests -q -m gpu -x > $out/gputest_full_suite.log 2>&1
 tail -3 $out/gputest_full_suite.log
 python bench.py > $out/bench_line.json 2> $out/bench_stderr.log
