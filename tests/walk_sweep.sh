@@ -7,10 +7,11 @@ print('$name', round(d['ms_per_step'],1), 'walks', round(c['ms_walks_wall'],1), 
 " >> gpurun_out/r04h/sweep2.txt; }
 rm -f gpurun_out/r04h/sweep2.txt
 run base A=1
-run group8 PAG_POST_GROUP=8
-run group12 PAG_POST_GROUP=12
-run group16 PAG_POST_GROUP=16
-run group24 PAG_POST_GROUP=24
-run group32 PAG_POST_GROUP=32
+run host_tail PAG_DEVICE_TAIL=0
+run no_kept_segments PAG_WALK_KEEP_SEGMENTS=0
+run interleave0 PAG_POST_INTERLEAVE=0
+run waves4 PAG_WALK_WAVES_PER_CU=4
+run seg8k PAG_SEG_LEN=8000
+run succ_heavy0 PAG_SUCC_HEAVY=0
 run base2 A=1
 cat gpurun_out/r04h/sweep2.txt
