@@ -397,7 +397,10 @@ template <int WHAT>
 #define SUCC_HEAVY 0xFFFFFFFFu
 __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out,
                                                 const uint32_t *__restrict__ ratio_tab, uint32_t heavy_limit = 0xFFFFFFFFu) {
-    constexpr int MODE = WHAT;  // (0 counts, 1 fills through the mask, 2 writes while it evaluates)
+    // (0 counts, 1 fills through the mask, 2 writes while it evaluates; 3: 1 for a vertex known to have at most 64 candidates —
+    // everything is under the mask, the loop that evaluates candidates is not even compiled in: registers, k_succ<3>)
+    constexpr int MODE = WHAT == 3 ? 1 : WHAT;
+    constexpr bool MASK_ONLY = WHAT == 3;
     const uint64_t rootp = G.vpos[v];
     const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
     const uint32_t node = G.vnode[v];
@@ -458,7 +461,7 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
         // a node has 2.65 edges on average, the rest is wasted loads and registers), eight candidates per turn no better
         // (35.6 ms), four lanes per vertex slower (51 ms), and keeping the first four accepted candidates of every vertex
         // in a side array for the filling pass cost the counting pass more (+14 ms) than it saved the other (-5 ms).
-        for (uint32_t jb = j0; jb < q; jb += 4u) {
+        for (uint32_t jb = j0; !MASK_ONLY && jb < q; jb += 4u) {
             const U64x4 pqL = *(const U64x4 *)(G.vpos + p0 + jb);  // (padded by four entries)
             const uint64_t *pq = pqL.a;
 #pragma unroll
@@ -543,6 +546,7 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
     d_ratio_table_fill(ratio_tab, err);
     __syncthreads();
+    constexpr bool FILL = MODE == 1 || MODE == 3;  // (3: with the heavy list and a limit of at most 64 — see succ_vertex)
     if (!heavy_list || MODE == 2) heavy_limit = 0xFFFFFFFFu;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t n = 0;
@@ -569,7 +573,7 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
             n += marker ? 1u : 0u;
         }
         SuccRec *out = nullptr;
-        if (MODE == 1) out = G.succ + G.succ_off[u];
+        if (FILL) out = G.succ + G.succ_off[u];
         if (MODE == 2) out = stage + stage_off[v];
         if (MODE != 0 && out) {
             SuccRec r;
@@ -579,11 +583,11 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
             r.toff = 0;
             if (poison) {
                 out[0] = r;
-            } else if (MODE == 1) {
+            } else if (FILL) {
                 uint32_t m;
                 if (amask) {
                     mask = amask[v];
-                    m = succ_vertex<1>(G, v, dev, err, mask, out, ratio_tab, heavy_limit);
+                    m = succ_vertex<MODE == 3 ? 3 : 1>(G, v, dev, err, mask, out, ratio_tab, heavy_limit);
                     if (m == SUCC_HEAVY) continue;
                 } else {
                     m = succ_vertex<2>(G, v, dev, err, mask, out, ratio_tab);
@@ -594,7 +598,7 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
                 if (marker) out[n++] = r;
             }
         }
-        if (MODE != 1) cnt[u] = n;
+        if (!FILL) cnt[u] = n;
         if (MODE == 0 && amask) amask[v] = mask;
     }
 }
@@ -3146,7 +3150,10 @@ int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const 
     if (stage) {
         k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
     } else {
-        k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
+        if (heavy_list && heavy_limit <= 64u && amask)
+            k_succ<3><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
+        else
+            k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
         if (heavy_list) k_succ_heavy<1><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, nullptr, amask, heavy_list, heavy_n);
         if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
     }
