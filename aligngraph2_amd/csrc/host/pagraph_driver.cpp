@@ -165,6 +165,44 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
 
         std::cout << "Loading config.txt" << std::endl;
         auto configs = loadConfig(opt.pre + "/config.txt");
+        // Multi-GPU runs of ONE pagraph invocation (aligngraph2_amd/parallel.py: run_config_blocks): the config blocks are
+        // independent (pagraph.cpp:181-182 resets the graph between them), so every GPU's process gets a list of block
+        // numbers in PAGRAPH_BLOCKS ("0,3,5"), processes only those — under their ORIGINAL numbers, which are the output
+        // file prefixes — and writes its share of contig.txt to contig.txt.part<PAGRAPH_PART>; the launcher merges the parts.
+        std::set<std::size_t> onlyBlocks;
+        const char *blocksEnv = std::getenv("PAGRAPH_BLOCKS");
+        if (blocksEnv) {
+            std::stringstream ss(blocksEnv);
+            std::string tok;
+            while (std::getline(ss, tok, ','))
+                if (!tok.empty()) onlyBlocks.insert(static_cast<std::size_t>(std::stoull(tok)));
+        }
+        // the block's three text files (pagraph.cpp:186-199 reads them one after the other; they are independent): parsed side by
+        // side, each by its own pool of threads
+        struct BlockFiles {
+            SeqDb reads;
+            AlnDb readToCtg, readToRef;
+            BlockFiles(const std::string &pre, const BlockConfig &cfg) {
+                auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
+                auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat); });
+                reads = SeqDb(pre + "/" + cfg.readPath);
+                readToCtg = ctgAln.get();
+                readToRef = refAln.get();
+            }
+        };
+        const bool prefetch = !(std::getenv("PAGRAPH_PREFETCH") && std::atoi(std::getenv("PAGRAPH_PREFETCH")) == 0);
+        auto mine = [&](std::size_t no) { return !blocksEnv || onlyBlocks.count(no) != 0; };
+        auto loadBlock = [&opt, &configs](std::size_t no) { return std::make_unique<BlockFiles>(opt.pre, configs[no]); };
+        std::future<std::unique_ptr<BlockFiles>> ahead;
+        std::size_t aheadNo = static_cast<std::size_t>(-1);
+        // (the text of the first block this process works on is parsed beside the global inputs below: 0.3 s of a 2 s run)
+        if (prefetch)
+            for (std::size_t no = 0; no < configs.size(); ++no)
+                if (mine(no)) {
+                    aheadNo = no;
+                    ahead = std::async(std::launch::async, loadBlock, no);
+                    break;
+                }
         std::cout << "Loading KMer" << std::endl;
         KmerFile kmers(opt.kmer);
         std::cout << "Done! k=" << kmers.k() << std::endl;
@@ -187,18 +225,6 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
 
         std::unordered_set<std::string> okCtg;  // same container as the reference: contig.txt order (quirk Q11)
         std::size_t blockNo = 0;
-        // Multi-GPU runs of ONE pagraph invocation (aligngraph2_amd/parallel.py: run_config_blocks): the config blocks are
-        // independent (pagraph.cpp:181-182 resets the graph between them), so every GPU's process gets a list of block
-        // numbers in PAGRAPH_BLOCKS ("0,3,5"), processes only those — under their ORIGINAL numbers, which are the output
-        // file prefixes — and writes its share of contig.txt to contig.txt.part<PAGRAPH_PART>; the launcher merges the parts.
-        std::set<std::size_t> onlyBlocks;
-        const char *blocksEnv = std::getenv("PAGRAPH_BLOCKS");
-        if (blocksEnv) {
-            std::stringstream ss(blocksEnv);
-            std::string tok;
-            while (std::getline(ss, tok, ','))
-                if (!tok.empty()) onlyBlocks.insert(static_cast<std::size_t>(std::stoull(tok)));
-        }
         HostGraph graphs[2];  // (storage reused from block to block; two sets: a block's host half runs beside the next block)
         std::vector<TravelSequence> precomputed[2];
         GraphBackend::TravelViews tviews[2];
@@ -239,24 +265,6 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         // The text files of the NEXT block this process will handle are parsed while the current block is on the device
         // (the parsers' threads are idle then; PAGRAPH_PREFETCH=0 parses every block when its turn comes, as the
         // reference does, and holds one block's inputs in host memory instead of two).
-        // the block's three text files (pagraph.cpp:186-199 reads them one after the other; they are independent): parsed side by
-        // side, each by its own pool of threads
-        struct BlockFiles {
-            SeqDb reads;
-            AlnDb readToCtg, readToRef;
-            BlockFiles(const std::string &pre, const BlockConfig &cfg) {
-                auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
-                auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat); });
-                reads = SeqDb(pre + "/" + cfg.readPath);
-                readToCtg = ctgAln.get();
-                readToRef = refAln.get();
-            }
-        };
-        const bool prefetch = !(std::getenv("PAGRAPH_PREFETCH") && std::atoi(std::getenv("PAGRAPH_PREFETCH")) == 0);
-        auto mine = [&](std::size_t no) { return !blocksEnv || onlyBlocks.count(no) != 0; };
-        auto loadBlock = [&opt, &configs](std::size_t no) { return std::make_unique<BlockFiles>(opt.pre, configs[no]); };
-        std::future<std::unique_ptr<BlockFiles>> ahead;
-        std::size_t aheadNo = static_cast<std::size_t>(-1);
         for (auto &cfg : configs) {
             if (!mine(blockNo)) {
                 ++blockNo;

@@ -1,12 +1,24 @@
 // pagraph — MI355X-native drop-in for AlignGraph2's PAGraph stage (reference PAGraph/src/main/pagraph.cpp).
 // Same command line, same input files, same output files; the graph build runs on the GPU through
 // libpagraph_hip.so.  There is no CPU build path in this program.
+#include <cstdio>
 #include <cstdlib>
+#include <iostream>
 
 #include "hip_backend.hpp"
 
 int main(int argc, char **argv) {
     const char *dev = std::getenv("PAGRAPH_DEVICE");
     auto backend = pagh::makeHipBackend(dev ? std::atoi(dev) : 0);
-    return pagh::runPagraph(argc, argv, *backend);
+    const int rc = pagh::runPagraph(argc, argv, *backend);
+    // Every output file is written and closed, every host thread joined: the process leaves without returning tens of GB of
+    // device and pinned memory piece by piece (the driver reclaims them in one go: 0.1-0.2 s of a 2 s run).
+    // PAGRAPH_FULL_TEARDOWN=1: the ordinary way out (leak checkers).
+    if (!std::getenv("PAGRAPH_FULL_TEARDOWN")) {
+        std::cout.flush();
+        std::cerr.flush();
+        std::fflush(nullptr);
+        std::_Exit(rc);
+    }
+    return rc;
 }
