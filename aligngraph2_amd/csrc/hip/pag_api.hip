@@ -119,6 +119,27 @@ const char *pag_last_error(void) { return last_error(); }
 
 int pag_device_available(void) { return pick_device(0) == PAG_OK ? 1 : 0; }
 
+namespace {
+__global__ void k_warm(uint32_t *p) {
+    if (p) *p = 1u;
+}
+}  // namespace
+int pag_device_warm(int device_ordinal) {
+    int rc = pick_device(device_ordinal);
+    if (rc != PAG_OK) return rc;
+    // the context, the first allocation, the code object of this library: a third of a second of a cold process
+    uint32_t *p = nullptr;
+    if (hipMalloc((void **)&p, 256) != hipSuccess) return PAG_ENOMEM;
+    k_warm<<<dim3(1), dim3(64)>>>(p);
+    hipError_t e = hipDeviceSynchronize();
+    hipFree(p);
+    if (e != hipSuccess) {
+        set_error("pag_device_warm: %s", hipGetErrorString(e));
+        return PAG_EFAULT;
+    }
+    return PAG_OK;
+}
+
 pag_graph *pag_create(const uint64_t *codes, uint64_t n_codes, uint32_t k, int device_ordinal, int *err) {
     int rc = PAG_OK;
     pag_graph *g = nullptr;

@@ -12,10 +12,64 @@
 #include <sstream>
 #include <stdexcept>
 #include <unordered_map>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "line_index.hpp"
 
 namespace pagh {
+
+namespace {
+// parseDiff (ParseAlignTools.cpp:8-26) over one record: q=='-' -> class 1; r=='-' -> 2; mismatch -> 3; match -> 0, two bits per
+// column, 16 columns per word (words zeroed by the caller); a reference row shorter than the query row reads as NUL.
+void classifyScalar(const char *q, std::size_t n, const char *r, std::size_t rn, std::uint32_t *w, std::size_t from, std::uint32_t &nEmit, std::uint32_t &nRadv) {
+    for (std::size_t i = from; i < n; ++i) {
+        const char qc = q[i];
+        const char rc = i < rn ? r[i] : '\0';
+        unsigned cls;
+        if (qc == '-') cls = 1;
+        else if (rc == '-') cls = 2;
+        else if (qc != rc) cls = 3;
+        else cls = 0;
+        w[i >> 4] |= cls << ((i & 15) * 2);
+        nEmit += cls != 1;
+        nRadv += cls != 2;
+    }
+}
+#if defined(__x86_64__)
+// 32 columns per turn: byte compares, the two class bits as movemasks, interleaved with pdep (the text of BASELINE configs[1]
+// is 2.2 G columns per block: the one-character-at-a-time loop was most of the time a block's files take to load)
+__attribute__((target("avx2,bmi2,popcnt"))) std::size_t classifyAvx2(const char *q, const char *r, std::size_t n32, std::uint32_t *w, std::uint32_t &nEmit,
+                                                                   std::uint32_t &nRadv) {
+    const __m256i dash = _mm256_set1_epi8('-');
+    std::uint32_t e = 0, a = 0;
+    for (std::size_t i = 0; i < n32; i += 32) {
+        const __m256i qv = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q + i));
+        const __m256i rv = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(r + i));
+        const std::uint32_t mq = static_cast<std::uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(qv, dash)));
+        const std::uint32_t mr = static_cast<std::uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(rv, dash))) & ~mq;
+        const std::uint32_t ne = ~static_cast<std::uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(qv, rv))) & ~mq & ~mr;
+        const std::uint32_t b0 = mq | ne, b1 = mr | ne;  // class bits 0 and 1 of the 32 columns
+        w[(i >> 4)] = static_cast<std::uint32_t>(_pdep_u32(b0 & 0xFFFFu, 0x55555555u) | _pdep_u32(b1 & 0xFFFFu, 0xAAAAAAAAu));
+        w[(i >> 4) + 1] = static_cast<std::uint32_t>(_pdep_u32(b0 >> 16, 0x55555555u) | _pdep_u32(b1 >> 16, 0xAAAAAAAAu));
+        e += 32u - static_cast<std::uint32_t>(_mm_popcnt_u32(mq));
+        a += 32u - static_cast<std::uint32_t>(_mm_popcnt_u32(mr));
+    }
+    nEmit += e;
+    nRadv += a;
+    return n32;
+}
+#endif
+void classifyColumns(const char *q, std::size_t n, const char *r, std::size_t rn, std::uint32_t *w, std::uint32_t &nEmit, std::uint32_t &nRadv) {
+    std::size_t done = 0;
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
+    if (wide) done = classifyAvx2(q, r, std::min(n, rn) & ~static_cast<std::size_t>(31), w, nEmit, nRadv);
+#endif
+    classifyScalar(q, n, r, rn, w, done, nEmit, nRadv);
+}
+}  // namespace
 
 void AlnDb::addRecord(AlnRecord rec, const std::string &qline, const std::string &rline) {
     // parseDiff: q=='-' -> (1,0); r=='-' -> (0,1); mismatch -> (1,1); match -> (0,0).  One column
@@ -27,18 +81,7 @@ void AlnDb::addRecord(AlnRecord rec, const std::string &qline, const std::string
     diff_.resize(diff_.size() + (n + 15) / 16, 0);
     std::uint32_t *w = diff_.data() + rec.diffOff;
     std::uint32_t nEmit = 0, nRadv = 0;
-    for (std::size_t i = 0; i < n; ++i) {
-        char q = qline[i];
-        char r = i < rline.size() ? rline[i] : '\0';
-        unsigned cls;
-        if (q == '-') cls = 1;
-        else if (r == '-') cls = 2;
-        else if (q != r) cls = 3;
-        else cls = 0;
-        w[i >> 4] |= cls << ((i & 15) * 2);
-        nEmit += cls != 1;
-        nRadv += cls != 2;
-    }
+    classifyColumns(qline.data(), n, rline.data(), rline.size(), w, nEmit, nRadv);
     rec.nEmit = nEmit;
     rec.nRadv = nRadv;
     recs_.push_back(std::move(rec));
@@ -174,18 +217,7 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         }
         std::uint32_t *w = diff_.data() + off[r];
         std::uint32_t nEmit = 0, nRadv = 0;
-        for (std::size_t i = 0; i < n; ++i) {
-            const char q = ql[i];
-            const char rr = i < rn ? rl[i] : '\0';
-            unsigned cls;
-            if (q == '-') cls = 1;
-            else if (rr == '-') cls = 2;
-            else if (q != rr) cls = 3;
-            else cls = 0;
-            w[i >> 4] |= cls << ((i & 15) * 2);
-            nEmit += cls != 1;
-            nRadv += cls != 2;
-        }
+        classifyColumns(ql, n, rl, rn, w, nEmit, nRadv);
         rec.nEmit = nEmit;
         rec.nRadv = nRadv;
     });

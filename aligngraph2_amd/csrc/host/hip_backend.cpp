@@ -4,6 +4,7 @@
 #include "path_graph.hpp"
 #include "shard_plan.hpp"
 
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -24,6 +25,8 @@ bool classifyOnDevice(const char *text, std::uint64_t textBytes, const std::uint
 class HipBackend final : public GraphBackend {
 public:
     explicit HipBackend(int device) : device_(device) {
+        // (the HIP runtime comes up while the driver parses its first input files)
+        warm_ = std::thread([device] { (void)pag_device_warm(device); });
         if (const char *e = std::getenv("PAGRAPH_DEVICE_INGEST"))
             if (e[0] == '1') {
                 g_ingest_device = device;
@@ -52,6 +55,7 @@ public:
         world_ = static_cast<unsigned>(n);
     }
     ~HipBackend() override {
+        if (warm_.joinable()) warm_.join();
         pag_destroy(g_);
         pag_comm_destroy(comm_);
     }
@@ -59,6 +63,7 @@ public:
     unsigned shardWorld() const override { return world_; }
     const char *name() const override { return "HIP gfx950"; }
     void create(const std::uint64_t *words, std::size_t nWords, unsigned k) override {
+        if (warm_.joinable()) warm_.join();
         int err = 0;
         g_ = pag_create(words, nWords, k, device_, &err);
         if (!g_) throw std::runtime_error(std::string("pag_create failed (") + std::to_string(err) + "): " + pag_last_error());
@@ -206,6 +211,7 @@ private:
         throw std::runtime_error(msg);
     }
     int device_;
+    std::thread warm_;  // pag_device_warm() beside the first file parses
     pag_graph *g_ = nullptr;
     pag_comm *comm_ = nullptr;
     unsigned rank_ = 0, world_ = 1;

@@ -434,6 +434,10 @@ int pag_kmer_count(const pag_seqs *reads, int reads_on_device, uint32_t k, doubl
 const char *pag_last_error(void);
 /* 1 if a gfx950 device is present and the code object loads */
 int pag_device_available(void);
+/* Brings up the HIP runtime on the device (context, first allocation, this library's code object) — the third of a second a
+ * cold process otherwise spends inside its first pag_create().  A caller with input files to parse calls it on a thread of its
+ * own at start-up (bin/pagraph does).  Thread-safe with respect to the other entry points; PAG_OK or an error code. */
+int pag_device_warm(int device_ordinal);
 
 #ifdef __cplusplus
 }
