@@ -207,14 +207,18 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         KmerFile kmers(opt.kmer);
         std::cout << "Done! k=" << kmers.k() << std::endl;
         lap("  solid k-mer file");
+        // (the three files are independent: parsed side by side, reported in the reference's order; a file that fails throws
+        // where the reference would have failed on it)
+        auto refsAhead = std::async(std::launch::async, [&opt] { return SeqDb(opt.ref); });
+        auto alnAhead = std::async(std::launch::async, [&opt] { return AlnDb(opt.aln, AlnDb::Flavor::MummerV2); });
         std::cout << "Loading Contigs" << std::endl;
         SeqDb contigs(opt.contig);
         std::cout << "Done! contigs number=" << contigs.size() << std::endl;
         std::cout << "Loading References" << std::endl;
-        SeqDb refs(opt.ref);
+        SeqDb refs = refsAhead.get();
         std::cout << "Done! reference number=" << refs.size() << std::endl;
         std::cout << "Loading ContigToRef" << std::endl;
-        AlnDb ctgToRef(opt.aln, AlnDb::Flavor::MummerV2);
+        AlnDb ctgToRef = alnAhead.get();
         std::cout << "Done! number=" << ctgToRef.size() << std::endl;
         lap("  contigs, references, contig->reference alignments");
         std::cout << "Building original pa Graph [" << backend.name() << "]" << std::endl;

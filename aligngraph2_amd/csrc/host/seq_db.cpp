@@ -1,5 +1,9 @@
 #include "seq_db.hpp"
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <cstring>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -18,6 +22,39 @@ inline unsigned encodeBase(char c) {
         case 'T': case 't': return 3;
         default: return 0;  // A, a and everything else
     }
+}
+#if defined(__x86_64__)
+// 32 bases -> 8 packed bytes per turn (CompressedSeq's packing: 4 bases per byte, base i at bits 2 * (i & 3); C/c = 1, G/g = 2,
+// T/t = 3, everything else 0).  Returns how many bases it packed (a multiple of 32).
+__attribute__((target("avx2"))) std::size_t packBasesAvx2(const char *sq, std::size_t n, std::uint8_t *out) {
+    const __m256i lower = _mm256_set1_epi8(0x20), cC = _mm256_set1_epi8('c'), cG = _mm256_set1_epi8('g'), cT = _mm256_set1_epi8('t');
+    const __m256i one = _mm256_set1_epi8(1), two = _mm256_set1_epi8(2), three = _mm256_set1_epi8(3);
+    const __m256i w8 = _mm256_set1_epi16(0x0401);       // bytes (c0, c1) -> c0 + 4 c1
+    const __m256i w16 = _mm256_set1_epi32(0x00100001);  // words (x0, x1) -> x0 + 16 x1
+    const __m256i gather = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    std::size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i v = _mm256_or_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(sq + i)), lower);
+        const __m256i code = _mm256_or_si256(_mm256_or_si256(_mm256_and_si256(_mm256_cmpeq_epi8(v, cC), one), _mm256_and_si256(_mm256_cmpeq_epi8(v, cG), two)),
+                                             _mm256_and_si256(_mm256_cmpeq_epi8(v, cT), three));
+        const __m256i b = _mm256_shuffle_epi8(_mm256_madd_epi16(_mm256_maddubs_epi16(code, w8), w16), gather);
+        const std::uint32_t lo = static_cast<std::uint32_t>(_mm256_extract_epi32(b, 0)), hi = static_cast<std::uint32_t>(_mm256_extract_epi32(b, 4));
+        std::memcpy(out + (i >> 2), &lo, 4);
+        std::memcpy(out + (i >> 2) + 4, &hi, 4);
+    }
+    return i;
+}
+#endif
+// a sequence's bases packed to out (zeroed, (n + 3) / 4 bytes)
+void packBases(const char *sq, std::size_t n, std::uint8_t *out) {
+    std::size_t i = 0;
+#if defined(__x86_64__)
+    static const bool wide = __builtin_cpu_supports("avx2");
+    if (wide) i = packBasesAvx2(sq, n, out);
+#endif
+    for (; i + 4 <= n; i += 4)
+        out[i >> 2] = static_cast<std::uint8_t>(encodeBase(sq[i]) | (encodeBase(sq[i + 1]) << 2) | (encodeBase(sq[i + 2]) << 4) | (encodeBase(sq[i + 3]) << 6));
+    for (; i < n; ++i) out[i >> 2] |= static_cast<std::uint8_t>(encodeBase(sq[i]) << ((i & 3) * 2));
 }
 }  // namespace
 
@@ -141,12 +178,7 @@ bool SeqDb::loadFastqParallel(const std::string &path) {
         names_[first + r].assign(fl.data(4 * r) + tok[r].first + 1, tok[r].second - 1);
         const char *sq = fl.data(4 * r + 1);
         const std::size_t n = len_[first + r];
-        std::uint8_t *out = packed_.data() + byteOff_[first + r];
-        std::size_t i = 0;
-        for (; i + 4 <= n; i += 4)
-            out[i >> 2] = static_cast<std::uint8_t>(encodeBase(sq[i]) | (encodeBase(sq[i + 1]) << 2) | (encodeBase(sq[i + 2]) << 4) |
-                                                    (encodeBase(sq[i + 3]) << 6));
-        for (; i < n; ++i) out[i >> 2] |= static_cast<std::uint8_t>(encodeBase(sq[i]) << ((i & 3) * 2));
+        packBases(sq, n, packed_.data() + byteOff_[first + r]);
     });
     for (std::size_t r = 0; r < nRec; ++r) nameToId_[names_[first + r]] = first + r;  // later duplicates win
     lastName_.assign(fl.data(4 * (nRec - 1)) + tok[nRec - 1].first, tok[nRec - 1].second);
