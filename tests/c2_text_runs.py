@@ -53,6 +53,7 @@ def multi_block(args, rec, d, ours, n_bases):
              ("from the packed sidecars", {"PAGRAPH_PREFETCH": "1", "PAGRAPH_OVERLAP": "1"}),
              ("from the packed sidecars, block after block", {"PAGRAPH_PREFETCH": "0", "PAGRAPH_OVERLAP": "0"})]
     for name, env in modes:
+        time.sleep(8)  # (a process started right after another one gave back ~100 GB of device memory waits 3-4 s for its first allocation)
         out = "/dev/shm/c2_out_multi"
         shutil.rmtree(out, ignore_errors=True)
         os.makedirs(out)
