@@ -959,10 +959,9 @@ struct WalkSession {
         bool kept = false;        // the round adopts the segments of an earlier round (RoundState::kept): none are planned
         uint32_t kept_stop = 0;   // ... and its seeds walk up to this coordinate (0: to the end)
     };
-    int start_rounds(const std::vector<uint32_t> &which) {
-        std::vector<RoundPlan> RP(which.size());
-        std::vector<TravSeedReq> reqs;
-        // ---- per contig: the round's state, the checkpoint coordinates of its segments
+    // ---- start of a round of contigs `which` (their seeds are in cs.seeds): four steps
+    // (1) per contig: the round's state, the checkpoint coordinates of its segments (reqs: the checkpoint searches)
+    void plan_rounds(const std::vector<uint32_t> &which, std::vector<RoundPlan> &RP, std::vector<TravSeedReq> &reqs) {
         for (size_t w = 0; w < which.size(); ++w) {
             const uint32_t i = which[w];
             RoundPlan &P = RP[w];
@@ -1054,8 +1053,10 @@ struct WalkSession {
                 reqs.push_back(rq);
             }
         }
-        // ---- the checkpoint vertices of all of them
-        std::vector<uint32_t> out(reqs.size() * 3);
+    }
+    // (2) the checkpoint vertices of all of them: one launch, one round trip
+    int find_checkpoints(const std::vector<TravSeedReq> &reqs, std::vector<uint32_t> &out) {
+        out.assign(reqs.size() * 3, 0u);
         int r;
         if (!reqs.empty()) {
             if ((r = b_ckreq.alloc(reqs.size() * sizeof(TravSeedReq))) || (r = b_ckout.alloc(reqs.size() * 12))) return r;
@@ -1065,8 +1066,10 @@ struct WalkSession {
             PAG_HIP_TRY(hipMemcpyAsync(out.data(), b_ckout.p, out.size() * 4, hipMemcpyDeviceToHost, s));
             PAG_HIP_TRY(hipStreamSynchronize(s));
         }
-        // ---- per contig: its segments, and the contig coordinates their id ranges are asked for
-        std::vector<uint32_t> co;
+        return PAG_OK;
+    }
+    // (3) per contig: its segments, and the contig coordinates their id ranges are asked for (co)
+    void make_segments(const std::vector<uint32_t> &which, std::vector<RoundPlan> &RP, const std::vector<uint32_t> &out, std::vector<uint32_t> &co) {
         for (size_t w = 0; w < which.size(); ++w) {
             const uint32_t i = which[w];
             RoundPlan &P = RP[w];
@@ -1124,7 +1127,10 @@ struct WalkSession {
                 cc[2 * nq + 1] = (uint32_t)std::min<uint64_t>(cs.ctgRight, (uint64_t)first_stop(R) + 3000);
             }
         }
-        std::vector<uint32_t> ids(co.size());
+    }
+    int find_id_bounds(const std::vector<uint32_t> &co, std::vector<uint32_t> &ids) {
+        ids.assign(co.size(), 0u);
+        int r;
         if (!co.empty()) {
             if ((r = b_ckreq.alloc(co.size() * 4)) || (r = b_ckout.alloc(co.size() * 4))) return r;
             PAG_HIP_TRY(hipMemcpyAsync(b_ckreq.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, s));
@@ -1132,7 +1138,11 @@ struct WalkSession {
             PAG_HIP_TRY(hipMemcpyAsync(ids.data(), b_ckout.p, ids.size() * 4, hipMemcpyDeviceToHost, s));
             PAG_HIP_TRY(hipStreamSynchronize(s));
         }
-        // ---- per contig: the id ranges, the jobs
+        return PAG_OK;
+    }
+    // (4) per contig: the id ranges, the jobs
+    int post_round_jobs(const std::vector<uint32_t> &which, std::vector<RoundPlan> &RP, const std::vector<uint32_t> &ids) {
+        int r;
         for (size_t w = 0; w < which.size(); ++w) {
             const uint32_t i = which[w];
             RoundPlan &P = RP[w];
@@ -1183,6 +1193,17 @@ struct WalkSession {
             if ((r = post_batch(i, GRP_ROUND, plans))) return r;
         }
         return PAG_OK;
+    }
+    int start_rounds(const std::vector<uint32_t> &which) {
+        std::vector<RoundPlan> RP(which.size());
+        std::vector<TravSeedReq> reqs;
+        std::vector<uint32_t> out, co, ids;
+        int r;
+        plan_rounds(which, RP, reqs);
+        if ((r = find_checkpoints(reqs, out))) return r;
+        make_segments(which, RP, out, co);
+        if ((r = find_id_bounds(co, ids))) return r;
+        return post_round_jobs(which, RP, ids);
     }
 
     // continue chain c of contig i exactly: the path so far goes to the walker as a RESUME job
