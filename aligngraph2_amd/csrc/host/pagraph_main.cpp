@@ -14,7 +14,9 @@ int main(int argc, char **argv) {
     // Every output file is written and closed, every host thread joined: the process leaves without returning tens of GB of
     // device and pinned memory piece by piece (the driver reclaims them in one go: 0.1-0.2 s of a 2 s run).
     // PAGRAPH_FULL_TEARDOWN=1: the ordinary way out (leak checkers).
-    if (!std::getenv("PAGRAPH_FULL_TEARDOWN")) {
+    // (a rank of a sharded build leaves the ordinary way: its communicator says goodbye to its peers)
+    const char *shard = std::getenv("PAGRAPH_SHARD");
+    if (!std::getenv("PAGRAPH_FULL_TEARDOWN") && !(shard && *shard)) {
         std::cout.flush();
         std::cerr.flush();
         std::fflush(nullptr);
