@@ -71,6 +71,16 @@ void classifyColumns(const char *q, std::size_t n, const char *r, std::size_t rn
 }
 }  // namespace
 
+// test hook (tests/test_host_simd.py): the column classes of one record, by the production path or by the scalar loop alone
+extern "C" void pagh_debug_classify_columns(const char *q, std::uint64_t n, const char *r, std::uint64_t rn, std::uint32_t *words, std::uint32_t *n_emit,
+                                            std::uint32_t *n_radv, int scalar_only) {
+    std::uint32_t e = 0, a = 0;
+    if (scalar_only) classifyScalar(q, n, r, rn, words, 0, e, a);
+    else classifyColumns(q, n, r, rn, words, e, a);
+    *n_emit = e;
+    *n_radv = a;
+}
+
 void AlnDb::addRecord(AlnRecord rec, const std::string &qline, const std::string &rline) {
     // parseDiff: q=='-' -> (1,0); r=='-' -> (0,1); mismatch -> (1,1); match -> (0,0).  One column
     // per character of the query line; a shorter reference line reads as NUL (mismatch).

@@ -58,6 +58,12 @@ void packBases(const char *sq, std::size_t n, std::uint8_t *out) {
 }
 }  // namespace
 
+// test hook (tests/test_host_simd.py): a sequence packed by the production path or by the scalar loop alone (out zeroed, (n + 3) / 4 bytes)
+extern "C" void pagh_debug_pack_bases(const char *sq, std::uint64_t n, std::uint8_t *out, int scalar_only) {
+    if (!scalar_only) return packBases(sq, n, out);
+    for (std::uint64_t i = 0; i < n; ++i) out[i >> 2] |= static_cast<std::uint8_t>(encodeBase(sq[i]) << ((i & 3) * 2));
+}
+
 void SeqDb::add(const std::string &comment, const std::string &seq) {
     // name: first whitespace-separated token of the header line, minus its leading '>' / '@'.
     // An empty/blank header leaves the previous token in place, as the reference's stream does.
