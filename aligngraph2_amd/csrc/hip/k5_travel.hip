@@ -370,15 +370,22 @@ __global__ void k_order_keys(const uint64_t *__restrict__ vpos, uint64_t n, uint
     }
 }
 
-__global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uint64_t *__restrict__ sorted_val, uint64_t n, uint64_t n_zero, TravGraph G) {
+// (slice / slice_shift: the random half of the work — newid[v], vcnt[v] — for the vertices v of one slice of the k-mer-major id
+// range per launch, so that the slice of both arrays stays in the Infinity Cache; the streamed half with slice 0)
+__global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uint64_t *__restrict__ sorted_val, uint64_t n, uint64_t n_zero, TravGraph G,
+                              uint32_t slice, uint32_t slice_shift) {
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t x = sorted_val[u];
         const uint32_t v = (uint32_t)x;
-        G.uold[u] = v;
-        G.newid[v] = (uint32_t)u;
-        // (the first n_zero keys were overwritten by the second sort: their contig coordinate is 0)
-        G.upos[u] = ((uint64_t)(u < n_zero ? 0u : sorted_ctg[u]) << 32) | (x >> 32);
-        G.ucnt[u] = G.vcnt[v];
+        if (slice == 0u) {
+            G.uold[u] = v;
+            // (the first n_zero keys were overwritten by the second sort: their contig coordinate is 0)
+            G.upos[u] = ((uint64_t)(u < n_zero ? 0u : sorted_ctg[u]) << 32) | (x >> 32);
+        }
+        if (slice_shift >= 32u || (v >> slice_shift) == slice) {
+            G.newid[v] = (uint32_t)u;
+            G.ucnt[u] = G.vcnt[v];
+        }
     }
 }
 
@@ -3110,7 +3117,22 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
         if (!in0b) PAG_HIP_TRY(hipMemcpyAsync(vs, vo, n0 * 8, hipMemcpyDeviceToDevice, s));
     }
     if (n_zero) *n_zero = n0;
-    k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, vs, n, n0 > 1 ? n0 : 0, G);
+    {
+        // (eight slices once the two arrays — 6 bytes per vertex — outgrow the Infinity Cache: 16.2 -> 12.5 ms at configs[1],
+        // 13.2 with four or sixteen, tests/order_probe.sh; PAG_ORDER_SLICES=<2^n> overrides)
+        uint32_t lg = n >= (32ull << 20) ? 3u : 0u;
+        if (const char *e = std::getenv("PAG_ORDER_SLICES")) {
+            const uint32_t want = (uint32_t)std::max(1, std::atoi(e));
+            lg = 0;
+            while ((1u << (lg + 1)) <= want) ++lg;
+        }
+        uint32_t bits = 1;
+        while (bits < 32 && (n >> bits) != 0) ++bits;  // v < n < 2^bits
+        if (lg >= bits) lg = 0;
+        const uint32_t shift = lg ? bits - lg : 32u;
+        for (uint32_t sl = 0; sl < (1u << lg); ++sl)
+            k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, vs, n, n0 > 1 ? n0 : 0, G, sl, shift);
+    }
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
