@@ -36,7 +36,10 @@ def hip_count(rs, on_device, k, threshold, bitmap_ptr, bitmap_on_device):
 @pytest.mark.parametrize("seed,k,threshold,n,hi", [(21, 3, 0.2, 50, 80), (22, 8, 0.2, 400, 900), (23, 11, 0.05, 3000, 2500),
                                                   (24, 2, 0.2, 10, 40), (25, 9, 0.0, 500, 700), (26, 10, -1.0, 100, 300),
                                                   (27, 6, 0.2, 5, 4)])
-def test_hip_counter_matches_oracle(seed, k, threshold, n, hi):
+@pytest.mark.parametrize("slices", [None, "4"])  # (None: the library's own choice; "4": the table filled a quarter of the code range per launch)
+def test_hip_counter_matches_oracle(seed, k, threshold, n, hi, slices, monkeypatch):
+    if slices:
+        monkeypatch.setenv("PAG_KC_SLICES", slices)
     case = dict(seed=seed, n=n, lo=1, hi=hi, k=k, threshold=threshold, threads=1, fmt="fastq", alphabet="ACGTNacgt")
     seqs = kmer_cases.sequences(case)
     _, mn, want = oracle_file_words(seqs, k, threshold, 1)

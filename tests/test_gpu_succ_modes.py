@@ -2,7 +2,8 @@
 PABruijnGraph.cpp:143-197) built the two ways trav_prepare_graph knows — staged by the candidate bound (one evaluation of every
 pair, small graphs) and two passes (count, fill through the acceptance mask, link: what runs at BASELINE configs[1]) — must
 be the same arrays, record for record.  The two-pass path hands vertices with many candidate pairs to a whole wave (k_succ_heavy):
-run with its default limit and with a limit of 4, which sends most vertices that way."""
+run with its default limit and with a limit of 4, which sends most vertices that way; the coordinate order applied in one and in
+eight slices of the vertex id range (k_order_apply)."""
 import ctypes as C
 import os
 
@@ -38,11 +39,14 @@ def test_successor_records_do_not_depend_on_how_they_are_built(monkeypatch):
     hip.pag_debug_succ_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     hip.pag_debug_succ.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     got = {}
-    for mode in ("bound", "twopass", "twopass heavy=4", "twopass heavy=0"):
+    for mode in ("bound", "twopass", "twopass heavy=4", "twopass heavy=0", "twopass order=8", "twopass order=1"):
         monkeypatch.setenv("PAG_SUCC_MODE", mode.split()[0])
         monkeypatch.delenv("PAG_SUCC_HEAVY", raising=False)
+        monkeypatch.delenv("PAG_ORDER_SLICES", raising=False)
         if "heavy=" in mode:
             monkeypatch.setenv("PAG_SUCC_HEAVY", mode.split("=")[1])
+        if "order=" in mode:  # (k_order_apply's scatter / gather in that many slices of the vertex id range)
+            monkeypatch.setenv("PAG_ORDER_SLICES", mode.split("=")[1])
         st = pagctl.BuildStats()
         assert hip.pag_process(g, C.byref(inp), C.byref(st)) == 0, hip.pag_last_error()
         assert hip.pag_travel_prepare(g, C.byref(ctg_seqs), ref_len.ctypes.data, 1, C.byref(prm), None) == 0, hip.pag_last_error()
