@@ -793,12 +793,17 @@ struct WalkSession {
     // that no wave has taken are cancelled, those that are walking finish as orphans.
     void give_up_segments(uint32_t i) {
         RoundState &R = RS[i];
-        for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring)
-            for (uint32_t q = 0; q < QCAP; ++q) {
-                JobRef &jr = jref[ring * QCAP + q];
-                if (jr.live && jr.ctg == i && jr.kind == 1 && jr.epoch == R.seg_epoch) {
-                    __atomic_fetch_or(&hjobs[ring * QCAP + q].J.mode, (uint32_t)TRAV_MODE_CANCELLED, __ATOMIC_RELEASE);
-                    ++n_orphans;
+        if (R.live_jobs != 0)  // (nothing of the contig is in a ring otherwise: most contigs finish that way)
+            for (uint32_t ring = 0; ring < TRAV_RINGS; ++ring) {
+                // the live jobs of a ring are among its last QCAP postings, none below scan_from
+                const uint32_t hi = n_posted[ring], lo = std::max(scan_from[ring], hi > QCAP ? hi - QCAP : 0u);
+                for (uint32_t jn = lo; jn < hi; ++jn) {
+                    const uint32_t q = jn % QCAP;
+                    JobRef &jr = jref[ring * QCAP + q];
+                    if (jr.live && jr.ctg == i && jr.kind == 1 && jr.epoch == R.seg_epoch) {
+                        __atomic_fetch_or(&hjobs[ring * QCAP + q].J.mode, (uint32_t)TRAV_MODE_CANCELLED, __ATOMIC_RELEASE);
+                        ++n_orphans;
+                    }
                 }
             }
         R.seg_epoch += 1;
