@@ -162,6 +162,26 @@ __device__ __forceinline__ uint32_t node_of_code(const TravGraph &G, uint32_t co
     return G.rank[code >> 6] + (uint32_t)__popcll(w & ((1ull << b) - 1ull));
 }
 
+// An edge of the traversal graph: eto = first position (k-mer-major vertex id) of the target node (PAG_NONE: the target has no
+// node), estep = step (24 bits) | number of the target's positions << 24, EDGE_Q_MANY = "255 or more: count them".
+constexpr uint32_t EDGE_STEP_MASK = 0xFFFFFFu, EDGE_Q_MANY = 255u;
+struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a[2]; };
+__device__ __forceinline__ void edge_target(const TravGraph &G, uint32_t eto, uint32_t estep, uint32_t *step, uint32_t *p0, uint32_t *q) {
+    *step = estep & EDGE_STEP_MASK;
+    if (eto == PAG_NONE) {
+        *p0 = 0u;
+        *q = 0u;
+        return;
+    }
+    *p0 = eto;
+    uint32_t n = estep >> 24;
+    if (n == EDGE_Q_MANY) {  // (a k-mer with hundreds of positions: its node's range)
+        const uint32_t node = G.vnode[eto];
+        n = G.npos_off[node + 1] - G.npos_off[node];
+    }
+    *q = n;
+}
+
 __global__ void k_edge_counts(const uint32_t *__restrict__ ekey, const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G,
                               uint32_t *__restrict__ necnt) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (uint64_t)gridDim.x * blockDim.x) {
@@ -182,8 +202,19 @@ __global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_
         uint32_t dst = G.nedge_off[n], len = eseg[j];
         for (uint32_t l = 0; l < len; ++l) {
             uint64_t v = eval[j + l];
-            G.eto[dst + l] = node_of_code(G, (uint32_t)(v >> 32));
-            G.estep[dst + l] = ((uint32_t)v) >> 1;
+            // (the edge carries what the successor kernels need of its target: where the target node's positions begin and how
+            // many they are — one random sector less per edge in each of their two passes, see edge_target)
+            const uint32_t to = node_of_code(G, (uint32_t)(v >> 32));
+            const uint32_t step = (((uint32_t)v) >> 1) & EDGE_STEP_MASK;
+            if (to == PAG_NONE) {
+                G.eto[dst + l] = PAG_NONE;
+                G.estep[dst + l] = step;
+            } else {
+                const U32x2 r = *(const U32x2 *)(G.npos_off + to);
+                const uint32_t q = r.a[1] - r.a[0];
+                G.eto[dst + l] = r.a[0];
+                G.estep[dst + l] = step | ((q < EDGE_Q_MANY ? q : EDGE_Q_MANY) << 24);
+            }
         }
     }
 }
@@ -398,7 +429,6 @@ __global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uin
 // counting pass issues a load per candidate otherwise, and with some twenty k-mer nodes per wave every load instruction is
 // twenty requests to the L1 — what the pass was bound by, not its arithmetic)
 struct __attribute__((packed, aligned(4))) U32x4 { uint32_t a[4]; };
-struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a[2]; };
 struct __attribute__((packed, aligned(8))) U64x4 { uint64_t a[4]; };
 template <int WHAT>
 #define SUCC_HEAVY 0xFFFFFFFFu
@@ -431,13 +461,7 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
       for (uint32_t t = 0; t < 4u; ++t) {
           const bool have = eb + t < e_hi;
           to4[t] = have ? toL.a[t] : PAG_NONE;
-          st4[t] = have ? stL.a[t] : 0u;
-      }
-#pragma unroll
-      for (uint32_t t = 0; t < 4u; ++t) {
-          const U32x2 r = *(const U32x2 *)(G.npos_off + (to4[t] != PAG_NONE ? to4[t] : 0u));
-          p04[t] = to4[t] != PAG_NONE ? r.a[0] : 0u;
-          q4[t] = to4[t] != PAG_NONE ? r.a[1] - r.a[0] : 0u;
+          edge_target(G, to4[t], have ? stL.a[t] : 0u, &st4[t], &p04[t], &q4[t]);
       }
 #pragma unroll
       for (uint32_t t4 = 0; t4 < 4u; ++t4) {
@@ -506,7 +530,8 @@ __device__ __forceinline__ uint32_t succ_vertex_wave(const TravGraph &G, uint64_
     for (uint32_t e = e_lo; e < e_hi; ++e) {
         const uint32_t to = G.eto[e];
         if (to == PAG_NONE) continue;
-        const uint32_t step = G.estep[e], p0 = G.npos_off[to], q = G.npos_off[to + 1] - p0;
+        uint32_t step, p0, q;
+        edge_target(G, to, G.estep[e], &step, &p0, &q);
         const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;
         for (uint32_t jb = 0; jb < q; jb += 64u) {
             const uint32_t j = jb + lane;
@@ -650,8 +675,9 @@ __global__ void k_succ_bound(TravGraph G, uint32_t *__restrict__ ub) {
         const uint32_t node = G.vnode[v];
         uint32_t n = 0;
         for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
-            const uint32_t to = G.eto[e];
-            if (to != PAG_NONE) n += G.npos_off[to + 1] - G.npos_off[to];
+            uint32_t step, p0, q;
+            edge_target(G, G.eto[e], G.estep[e], &step, &p0, &q);
+            n += q;
         }
         ub[v] = n + (G.incomplete ? 1u : 0u);  // (room for a poison / marker record, see k_succ)
     }
@@ -3018,7 +3044,7 @@ void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s
 // largest step of any edge (bounds how far a successor's coordinate can lie from its source's)
 __global__ void k_max_step(const uint32_t *__restrict__ estep, uint64_t n, uint32_t *__restrict__ out) {
     uint32_t m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = estep[i] > m ? estep[i] : m;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = (estep[i] & EDGE_STEP_MASK) > m ? (estep[i] & EDGE_STEP_MASK) : m;
     m = wave_max_u32(m);
     if (lane_id() == 0 && m) atomicMax(out, m);
 }

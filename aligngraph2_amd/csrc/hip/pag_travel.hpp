@@ -20,8 +20,8 @@ struct TravGraph {
     uint64_t *vpos;       // [n_pos] ctg << 32 | ref
     uint16_t *vcnt;       // [n_pos]
     uint32_t *vnode;      // [n_pos]
-    uint32_t *eto;        // [n_edges] child node id
-    uint32_t *estep;      // [n_edges]
+    uint32_t *eto;        // [n_edges] first position (k-mer-major vertex id) of the child node; PAG_NONE: the child has no node
+    uint32_t *estep;      // [n_edges] step | min(number of the child's positions, 255) << 24 (k5_travel.hip edge_target)
     uint64_t *bitmap;     // 4^k bits: k-mer code owns a node
     uint32_t *rank;       // per 64-bit bitmap word: nodes before it
     // coordinate order ("new ids" u): [ctg == 0 vertices] ++ [ctg != 0 ascending]
