@@ -260,7 +260,7 @@ __device__ __forceinline__ uint32_t tab_compose(uint32_t first, uint32_t then, u
 template <bool EMIT, int MAXS>
 __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
     __shared__ WaveLds<MAXS> L;
-    const uint32_t job = blockIdx.x;
+    const uint32_t job = A.exec_perm ? A.exec_perm[blockIdx.x] : blockIdx.x;
     const uint32_t lane = lane_id();
     const uint32_t r = A.emit_order[job >> 1];
     const uint32_t strand = job & 1u;
@@ -530,6 +530,44 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
         A.job_samples[A.job_base + job] = job_samples;
         A.job_tuples[A.job_base + job] = (uint32_t)job_tuples;
     }
+}
+
+// Pass 0 looks every kept sample's contig base up in the contig -> reference entry map (queryContig): jobs that run at the same
+// time should work on the same stretch of the contigs, so that those 4-byte gathers share their sectors in the L2s.  Key of a
+// job = single coordinate of the first contig base its read's first alignment on that strand covers (jobs without one: last).
+__global__ void exec_keys(ExtractArgs A, uint32_t n_jobs, uint32_t *__restrict__ key, uint64_t *__restrict__ val) {
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= n_jobs) return;
+    const uint32_t r = A.emit_order[job >> 1], strand = job & 1u;
+    uint32_t k = 0xFFFFFFFFu;
+    int done = 0;
+    for (uint64_t ai = A.query_off[r]; ai < A.query_off[r + 1]; ++ai) {
+        if (A.topk >= 0 && done >= A.topk) break;
+        const pag_aln al = A.aln[ai];
+        if (!(al.flags & PAG_ALN_ELIGIBLE)) continue;
+        ++done;
+        if (((al.flags & PAG_ALN_REV_STRAND) ? 1u : 0u) != strand) continue;
+        if (al.q_start == PAG_NONE || al.n_valid == 0) continue;
+        k = A.ctgs[al.target].single_base + al.t_start;
+        break;
+    }
+    key[job] = k;
+    val[job] = job;
+}
+__global__ void exec_perm_narrow(const uint64_t *__restrict__ val, uint32_t n, uint32_t *__restrict__ perm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = (uint32_t)val[i];
+}
+// perm [2 n_reads]: pass 0's jobs in the order they should run.  key / val / key2 / val2: [2 n_reads] scratch, tmp: sort_tmp_bytes
+int launch_exec_perm(const ExtractArgs &a, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *tmp, uint32_t *perm, hipStream_t s) {
+    const uint32_t n_jobs = 2u * a.n_reads;
+    if (!n_jobs) return PAG_OK;
+    exec_keys<<<dim3((n_jobs + 255) / 256), dim3(256), 0, s>>>(a, n_jobs, key, val);
+    int in0 = 1, rc;
+    if ((rc = sort_pairs(key, val, key2, val2, n_jobs, 32, tmp, &in0, s, nullptr, nullptr))) return rc;
+    exec_perm_narrow<<<dim3((n_jobs + 255) / 256), dim3(256), 0, s>>>(in0 ? val : val2, n_jobs, perm);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
 }
 
 int launch_extract(const ExtractArgs &a, bool emit, hipStream_t s) {

@@ -101,6 +101,8 @@ struct ExtractArgs {
     const uint32_t *read_len;
     const uint8_t *packed;
     const uint32_t *emit_order;
+    const uint32_t *exec_perm;  // job of workgroup b (null: b): the order the jobs RUN in — their outputs go to the places the
+                                // emission order gives them whatever it is (k1_extract.hip exec_keys)
     uint32_t n_reads;
     // alignment database of this pass
     const pag_aln *aln;
@@ -136,6 +138,8 @@ struct ExtractArgs {
 int launch_colidx(const pag_aln *aln, uint64_t n_aln, const uint32_t *diff, const uint64_t *colidx_off, uint2 *colidx,
                   hipStream_t s);
 int launch_extract(const ExtractArgs &a, bool emit, hipStream_t s);
+// pass 0's jobs in the order they should run: sorted by where on the contigs their read aligns (k1_extract.hip exec_keys)
+int launch_exec_perm(const ExtractArgs &a, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *tmp, uint32_t *perm, hipStream_t s);
 int launch_solid_mask(const ExtractArgs &a, const pag_aln *aln2, const uint64_t *qoff2, uint16_t *mask, hipStream_t s);
 uint32_t solid_mask_slices();
 
