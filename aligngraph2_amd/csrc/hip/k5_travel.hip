@@ -200,20 +200,32 @@ __global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_
         uint32_t n = node_of_code(G, kx);
         if (n == PAG_NONE) continue;
         uint32_t dst = G.nedge_off[n], len = eseg[j];
-        for (uint32_t l = 0; l < len; ++l) {
-            uint64_t v = eval[j + l];
-            // (the edge carries what the successor kernels need of its target: where the target node's positions begin and how
-            // many they are — one random sector less per edge in each of their two passes, see edge_target)
-            const uint32_t to = node_of_code(G, (uint32_t)(v >> 32));
-            const uint32_t step = (((uint32_t)v) >> 1) & EDGE_STEP_MASK;
-            if (to == PAG_NONE) {
-                G.eto[dst + l] = PAG_NONE;
-                G.estep[dst + l] = step;
-            } else {
-                const U32x2 r = *(const U32x2 *)(G.npos_off + to);
-                const uint32_t q = r.a[1] - r.a[0];
-                G.eto[dst + l] = r.a[0];
-                G.estep[dst + l] = step | ((q < EDGE_Q_MANY ? q : EDGE_Q_MANY) << 24);
+        // (the edge carries what the successor kernels need of its target: where the target node's positions begin and how
+        // many they are — one random sector less per edge in each of their two passes, see edge_target.  Four edges per
+        // turn, their lookups in flight together: code -> bitmap word + rank -> position range is three dependent gathers)
+        for (uint32_t l0 = 0; l0 < len; l0 += 4u) {
+            uint64_t v4[4];
+            uint32_t to4[4];
+            U32x2 r4[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) v4[t] = l0 + t < len ? eval[j + l0 + t] : 0ull;
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) to4[t] = l0 + t < len ? node_of_code(G, (uint32_t)(v4[t] >> 32)) : PAG_NONE;
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) r4[t] = *(const U32x2 *)(G.npos_off + (to4[t] != PAG_NONE ? to4[t] : 0u));
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+                const uint32_t l = l0 + t;
+                if (l >= len) break;
+                const uint32_t step = (((uint32_t)v4[t]) >> 1) & EDGE_STEP_MASK;
+                if (to4[t] == PAG_NONE) {
+                    G.eto[dst + l] = PAG_NONE;
+                    G.estep[dst + l] = step;
+                } else {
+                    const uint32_t q = r4[t].a[1] - r4[t].a[0];
+                    G.eto[dst + l] = r4[t].a[0];
+                    G.estep[dst + l] = step | ((q < EDGE_Q_MANY ? q : EDGE_Q_MANY) << 24);
+                }
             }
         }
     }
