@@ -455,9 +455,9 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
     const uint32_t node = G.vnode[v];
     uint32_t n = 0, base = 0;
     const bool amask = true;  // (the mask is always there; a caller without one passes 0 and WHAT = 2)
-    auto emit = [&](uint32_t p, uint32_t pc, uint32_t step, int grade, uint32_t esim) {
+    auto emit = [&](uint32_t tgt, uint32_t pc, uint32_t step, int grade, uint32_t esim) {
         SuccRec r;
-        r.tgt = G.newid[p];
+        r.tgt = tgt;
         r.pc = pc;
         r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
         r.toff = 0;  // the target's own record range is linked in afterwards
@@ -491,9 +491,10 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
                 const uint32_t p = p0 + (uint32_t)(__ffsll((long long)sub) - 1);
                 sub &= sub - 1ull;
                 const uint64_t pp = G.vpos[p];
+                const uint32_t tgt = G.newid[p];  // (asked for together with the position: one round trip per record, not two)
                 uint32_t esim;
                 const int grade = d_check_position_any(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, entry, &esim);
-                emit(p, (uint32_t)(pp >> 32), step, grade, esim);
+                emit(tgt, (uint32_t)(pp >> 32), step, grade, esim);
                 ++n;
             }
             j0 = lim;
@@ -517,7 +518,7 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
                 int grade = d_check_position_any(rc, rr, pc, pr, step, dev, err, entry, &esim);
                 if (grade == G_OOPS) continue;
                 if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
-                if (MODE != 0) emit(p, pc, step, grade, esim);
+                if (MODE != 0) emit(G.newid[p], pc, step, grade, esim);
                 ++n;
             }
         }
