@@ -2493,6 +2493,22 @@ int pag_debug_succ(const pag_graph *g, uint32_t *succ_off, void *recs) {
     return PAG_OK;
 }
 
+// ... and which vertex of the finished graph every id of the view is: its k-mer code and its position (ctg << 32 | ref) —
+// (code, position) names a vertex of the reference's graph uniquely (the clustered positions of a k-mer are pairwise
+// distinct), which is how tests/test_gpu_succ_golden.py holds every record against the reference's successors() dump
+int pag_debug_trav_vertices(const pag_graph *g, uint32_t *code, uint64_t *pos) {
+    if (!g || !g->tg_ready || !code || !pos) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    const TravGraph &G = g->tg;
+    std::vector<uint32_t> uold(G.n_pos), vnode(G.n_pos), ncode(G.n_nodes);
+    PAG_HIP_TRY(hipMemcpy(uold.data(), G.uold, G.n_pos * 4, hipMemcpyDeviceToHost));
+    PAG_HIP_TRY(hipMemcpy(vnode.data(), G.vnode, G.n_pos * 4, hipMemcpyDeviceToHost));
+    PAG_HIP_TRY(hipMemcpy(ncode.data(), G.ncode, G.n_nodes * 4, hipMemcpyDeviceToHost));
+    PAG_HIP_TRY(hipMemcpy(pos, G.upos, G.n_pos * 8, hipMemcpyDeviceToHost));
+    for (uint64_t u = 0; u < G.n_pos; ++u) code[u] = ncode[vnode[uold[u]]];
+    return PAG_OK;
+}
+
 // the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
 int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm, double *ms) {
     return pag_travel_prepare_for(g, ctgs, nullptr, ref_len, n_refs, prm, ms);

@@ -14,6 +14,12 @@
 //   K <code> <npos> <nchild>          (only nodes with npos+nchild > 0, ascending code)
 //   P <ctgSingle> <refSingle> <count>
 //   C <toCode> <step>
+// with --succ 1 also outdir/<P>.succ.txt: what PABruijnGraph::successors (the reference's epsilon-join,
+// PABruijnGraph.cpp:167-197, called as the traversal calls it: deviation = 2 * epsilon, error rate 0.15,
+// pagraph.cpp:251, PAlgorithm.tcc:41) returns for EVERY vertex of the finished graph, in its own order:
+//   V <code> <posIndex> <n>           (every vertex, nodes ascending by code, positions ascending)
+//   T <toCode> <toPosIndex> <step> <grade> <ctgSimilar>     n lines; grade = checkPosition (:143-165: 1 Skip,
+//                                     2 Good, 3 Excellent, 4 Amazing), ctgSimilar = isEdgeSimilar(...).first (:385-400)
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -94,6 +100,7 @@ int main(int argc, char **argv) {
     std::string outDir = argOf(argc, argv, "-o", ".");
     std::size_t eps = static_cast<std::size_t>(std::atoll(argOf(argc, argv, "--epsilon", "10")));
     std::size_t cov = static_cast<std::size_t>(std::atoll(argOf(argc, argv, "-v", "1")));
+    bool dumpSucc = std::atoi(argOf(argc, argv, "--succ", "0")) != 0;
 
     auto blocks = readConfig(preDir + "/config.txt");
     auto kmerIt = std::make_shared<FileKmerIterator>(kmerPath);
@@ -159,6 +166,29 @@ int main(int argc, char **argv) {
             for (std::size_t j = 0; j < pos.size(); ++j)
                 out << "P " << pos[j].first << " " << pos[j].second << " " << cnt[j] << "\n";
             for (auto &c : chd) out << "C " << graph->_kmerIndexArr[c.first] << " " << c.second << "\n";
+        }
+        if (dumpSucc) {
+            std::ofstream so(outDir + "/" + std::to_string(blockNo) + ".succ.txt");
+            const PABruijnGraph::PosType deviation = static_cast<PABruijnGraph::PosType>(2 * eps);
+            const double errorRate = 0.15;
+            std::vector<std::pair<PABruijnGraph::PANode, int>> res;
+            for (std::size_t i = 0; i < table.size(); ++i) {
+                auto &node = table[i];
+                PABruijnGraph::ANode aNode(node, i);
+                for (std::size_t j = 0; j < aNode.size(); ++j) {
+                    PABruijnGraph::PANode pa(aNode, j);
+                    res.clear();
+                    graph->successors(res, pa, deviation, errorRate);
+                    so << "V " << graph->_kmerIndexArr[i] << " " << j << " " << res.size() << "\n";
+                    for (auto &r : res) {
+                        auto &t = r.first;
+                        auto grade = PABruijnGraph::checkPosition(pa.getPosition(), t.getPosition(), r.second, deviation, errorRate);
+                        auto es = PABruijnGraph::isEdgeSimilar(pa.getPosition(), t.getPosition(), r.second, deviation, errorRate);
+                        so << "T " << graph->_kmerIndexArr[t.getABruijnNode().getIndex()] << " " << t.getPosIndex() << " " << r.second
+                           << " " << static_cast<int>(grade) << " " << (es.first ? 1 : 0) << "\n";
+                    }
+                }
+            }
         }
         ++blockNo;
     }

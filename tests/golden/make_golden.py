@@ -8,6 +8,9 @@ Per case <name>/:
   inputs.tar.gz        the input files themselves (small cases only)
   out/                 the reference pagraph's complete -o directory (contig.txt sorted)
   graph.txt.gz         the reference's complete graph after PositionProcessor::process (graph_dump)
+  succ.txt.gz          what the reference's PABruijnGraph::successors returns for EVERY vertex of that graph (graph_dump --succ 1:
+                       target, step, checkPosition grade, isEdgeSimilar().first, in the reference's order; "B <block>" lines
+                       separate the config blocks)
 Function-level tables: func_{kmer,mapper,predicate,edit}.txt(.gz) from oracle/_ref/func_golden.
 
 usage: python tests/golden/make_golden.py        (re-creates everything deterministically)
@@ -47,6 +50,11 @@ CASES = {
     "eps20_k11_jitter_t16": (dict(seed=106, ref_len=14000, n_reads=200, read_len=1800, read_len_jitter=0.5, k=11,
                                   solid_min_abundance=2, clip_frac=0.8,
                                   contigs=[(200, 6700, False), (7000, 13800, False)]), 16, 20, 3, False),
+    # corners of the successor records: a homopolymer tract (k-mers with > 255 clustered positions, vertices with > 64 candidate
+    # pairs) and a stretch without solid k-mers (edges with steps >= 1024: the f64 ratio tests instead of the table)
+    "succ_corners_t8": (dict(seed=109, ref_len=20000, n_reads=160, read_len=5000, k=11, solid_min_abundance=2,
+                             contigs=[(200, 8600, False), (9750, 19800, False)], homopolymer=(3000, 2400),
+                             desert=(13000, 1300)), 8, 5, 2, False),
 }
 
 # multi-block cases: name -> (list of Spec kwargs (one per config block), threads, epsilon, cov, keep_inputs).
@@ -110,12 +118,16 @@ def main():
             gd = os.path.join(tmp, "gd")
             os.makedirs(gd)
             run([os.path.join(REF, "graph_dump"), "-t", str(threads), "-k", ind + "/kmer.bin", "-c", ind + "/ctg.fasta",
-                 "-R", ind + "/ref.fasta", "-p", ind, "-a", ind + "/aln", "-o", gd, "--epsilon", str(eps), "-v", str(cov)],
-                threads)
+                 "-R", ind + "/ref.fasta", "-p", ind, "-a", ind + "/aln", "-o", gd, "--epsilon", str(eps), "-v", str(cov),
+                 "--succ", "1"], threads)
             dumps = sorted((f for f in os.listdir(gd) if f.endswith(".graph.txt")), key=lambda f: int(f.split(".")[0]))
             with gzip.GzipFile(os.path.join(case, "graph.txt.gz"), "wb", compresslevel=9, mtime=0) as dst:
                 for f in dumps:  # (one dump per config block, in block order)
                     dst.write(open(os.path.join(gd, f), "rb").read())
+            with gzip.GzipFile(os.path.join(case, "succ.txt.gz"), "wb", compresslevel=9, mtime=0) as dst:
+                for f in dumps:
+                    dst.write(b"B %d\n" % int(f.split(".")[0]))
+                    dst.write(open(os.path.join(gd, f.replace(".graph.txt", ".succ.txt")), "rb").read())
         print(name, sorted(os.listdir(os.path.join(case, "out"))))
     for what in ("kmer", "mapper", "predicate", "edit") if not only else ():
         r = subprocess.run([os.path.join(REF, "func_golden"), what], capture_output=True, check=True)

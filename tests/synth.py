@@ -162,6 +162,12 @@ class Spec:
     ctg_prefix: str = "ctg"
     block: int = 0
     both_orient: tuple = ()
+    # corner-case plants (used by the successor-record golden; no random numbers are drawn for them, so every other case's
+    # inputs are unchanged): a homopolymer tract (start, length) written into the reference — k-mers with hundreds of
+    # clustered positions —, and a "desert" (start, length) in target coordinates: every k-mer a read carries over that
+    # stretch is taken out of the solid set, so that reads crossing it have edges whose step is the whole stretch
+    homopolymer: tuple = ()
+    desert: tuple = ()
 
 
 def _aln_record(qname, rname, strand, score, qb, qe, qsize, rb, re_, rsize, qrow, rrow):
@@ -201,6 +207,8 @@ def generate(spec: Spec, out_dir: str) -> dict:
         a = int(rng.integers(0, G - spec.repeat_len))
         b = int(rng.integers(0, G - spec.repeat_len))
         ref[b:b + spec.repeat_len] = ref[a:a + spec.repeat_len]
+    if spec.homopolymer:
+        ref[spec.homopolymer[0]:spec.homopolymer[0] + spec.homopolymer[1]] = ord("A")
     # target genome and its alignment to the reference (target = query, ref = ref)
     target, b_t, b_r = mutate(rng, ref, spec.target_snp, spec.target_indel / 2, spec.target_indel / 2)
     TL = len(target)
@@ -265,6 +273,7 @@ def generate(spec: Spec, out_dir: str) -> dict:
     f_ctg = open(os.path.join(out_dir, f"{B}.ctg.ref"), "w")
     f_ref = open(os.path.join(out_dir, f"{B}.ref.ref"), "w")
     all_codes = []
+    desert_codes = []
     n_bases = 0
     for rid in range(1, spec.n_reads + 1):
         L0 = spec.read_len
@@ -280,6 +289,11 @@ def generate(spec: Spec, out_dir: str) -> dict:
         fq.write(f"@{rid}\n{read.tobytes().decode()}\n+\n{'~' * n}\n")
         n_bases += n
         all_codes.append(kmer_codes(read, spec.k))
+        if spec.desert and n >= spec.k:
+            ft = (s + np.cumsum(a_t != GAP) - 1)[a_q != GAP]  # target coordinate under every fragment base
+            c = np.concatenate(([0], np.cumsum((ft >= spec.desert[0]) & (ft < spec.desert[0] + spec.desert[1]))))
+            win = (c[spec.k:] - c[:-spec.k]) > 0  # k-mer windows of the fragment that touch the desert
+            desert_codes.append(all_codes[-1][win[::-1] if read_rev else win])
 
         # optional soft clipping: drop some leading/trailing columns (whole columns)
         clo, chi = 0, len(a_q)
@@ -362,6 +376,8 @@ def generate(spec: Spec, out_dir: str) -> dict:
     codes = np.concatenate(all_codes) if all_codes else np.zeros(0, dtype=np.uint64)
     uniq, cnt = np.unique(codes, return_counts=True)
     solid = uniq[cnt >= spec.solid_min_abundance]
+    if desert_codes:
+        solid = np.setdiff1d(solid, np.concatenate(desert_codes))
     write_kmer_file(os.path.join(out_dir, "kmer.bin"), spec.k, solid)
     return {"dir": out_dir, "n_bases": n_bases, "n_solid": int(len(solid)), "k": spec.k,
             "contigs": [c.name for c in contigs]}

@@ -254,3 +254,30 @@ def test_next_block_is_parsed_ahead_without_changing_any_output(blocks, workdir)
     """The driver parses the next block's text files while the current block is on the device (pagraph_driver.cpp):
     goldens.check_blocks_parsed_ahead, here with the HIP backend."""
     goldens.check_blocks_parsed_ahead(EXE, blocks, str(workdir / ("ahead_" + (blocks or "all").replace(",", "_"))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["join_fwd_t1", "join_rev_t16", "two_blocks_both_orient_t16"])
+def test_walk_that_leaves_the_cut_view_is_walked_again_on_the_whole_graph(name, workdir):
+    """The safety net of the traversal's cut view (DESIGN §3 "The view"; pag_travel, k5_travel_host.hip): with no halo around the
+    reference bands and no margin before the leaping zones every walk that can leap examines a marker record (GRADE_POISON /
+    GRADE_POISON_IF_LEAP) -> PAG_ERANGE -> the half-run WalkSession is torn down, the whole graph's view built (view_off) and
+    every contig walked again.  Outputs must be the reference's golden bytes — as they are with the cut switched off
+    (PAG_TRAVEL_VIEW=whole) — and the walk-again path must really have run."""
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / "viewnet" / name / "in"))
+    seen = {}
+    for label, extra in (("nohalo", dict(PAG_VIEW_HALO="0", PAG_VIEW_MARGIN="0")), ("whole", dict(PAG_TRAVEL_VIEW="whole")), ("default", {})):
+        out = str(workdir / "viewnet" / name / label)
+        os.makedirs(out, exist_ok=True)
+        argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+        env = dict(os.environ, PAGRAPH_TIMING="1", **extra)
+        for v in ("PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_TRAVEL_VIEW"):
+            if v not in extra:
+                env.pop(v, None)
+        r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+        goldens.compare_out_dir(name, out)
+        seen[label] = r.stderr.count("a walk left the view")
+    assert seen["nohalo"] > 0, "no walk left the view without halo and margin: the walk-again path did not run"
+    assert seen["whole"] == 0 and seen["default"] == 0
