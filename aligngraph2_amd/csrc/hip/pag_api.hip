@@ -769,6 +769,26 @@ int pag_shard_take(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey,
     return PAG_OK;
 }
 
+int pag_shard_take_part(pag_graph *g, uint64_t t_off, uint64_t t_n, uint32_t *tkey, uint64_t *tval, uint64_t e_off, uint64_t e_n, uint32_t *ekey,
+                        uint64_t *eval) {
+    if (!g) return PAG_EINVAL;
+    const uint64_t T = g->shard_x[0], E = g->shard_x[1];
+    if (t_off > T || t_n > T - t_off || e_off > E || e_n > E - e_off || (t_n && (!tkey || !tval)) || (e_n && (!ekey || !eval))) {
+        set_error("pag_shard_take_part: [%llu, +%llu) of %llu tuples, [%llu, +%llu) of %llu edges", (unsigned long long)t_off, (unsigned long long)t_n,
+                  (unsigned long long)T, (unsigned long long)e_off, (unsigned long long)e_n, (unsigned long long)E);
+        return PAG_EINVAL;
+    }
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    hipStream_t s = g->stream;
+    const int ts = g->shard_in0[0] ? 30 : 32, es = g->shard_in0[1] ? 34 : 36;
+    if (t_n) PAG_HIP_TRY(hipMemcpyAsync(tkey, (const uint32_t *)g->pool[ts].p + t_off, t_n * 4, hipMemcpyDeviceToDevice, s));
+    if (t_n) PAG_HIP_TRY(hipMemcpyAsync(tval, (const uint64_t *)g->pool[ts + 1].p + t_off, t_n * 8, hipMemcpyDeviceToDevice, s));
+    if (e_n) PAG_HIP_TRY(hipMemcpyAsync(ekey, (const uint32_t *)g->pool[es].p + e_off, e_n * 4, hipMemcpyDeviceToDevice, s));
+    if (e_n) PAG_HIP_TRY(hipMemcpyAsync(eval, (const uint64_t *)g->pool[es + 1].p + e_off, e_n * 8, hipMemcpyDeviceToDevice, s));
+    PAG_HIP_TRY(hipStreamSynchronize(s));
+    return PAG_OK;
+}
+
 int pag_shard_build(pag_graph *g, const uint32_t *tkey, const uint64_t *tval, uint64_t n_t, uint64_t t1, const uint32_t *ekey,
                     const uint64_t *eval, uint64_t n_e, uint64_t e1, uint32_t eps, pag_build_stats *stats) {
     if (!g || t1 > n_t || e1 > n_e || (n_t && (!tkey || !tval)) || (n_e && (!ekey || !eval))) return PAG_EINVAL;

@@ -202,6 +202,7 @@ def bind_shard_api(hip):
     vp, u64 = _C.c_void_p, _C.c_uint64
     hip.pag_shard_extract.argtypes = [vp, vp, _C.c_uint32, _C.c_uint32, _C.POINTER(u64)]
     hip.pag_shard_take.argtypes = [vp, vp, vp, vp, vp]
+    hip.pag_shard_take_part.argtypes = [vp, _C.c_uint64, _C.c_uint64, vp, vp, _C.c_uint64, _C.c_uint64, vp, vp]
     hip.pag_shard_build.argtypes = [vp, vp, vp, u64, u64, vp, vp, u64, u64, _C.c_uint32, _C.POINTER(BuildStats)]
     hip.pag_shard_export.argtypes = [vp, _C.POINTER(ShardSlice)]
     hip.pag_shard_take_slice.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
@@ -209,7 +210,7 @@ def bind_shard_api(hip):
     hip.pag_shard_select.argtypes = [vp, _C.POINTER(Region), _C.POINTER(ShardSlice)]
     hip.pag_shard_set_region.argtypes = [vp, _C.POINTER(Region)]
     hip.pag_shard_release_build.argtypes = [vp]
-    for f in ("pag_shard_extract", "pag_shard_take", "pag_shard_build", "pag_shard_export", "pag_shard_take_slice", "pag_shard_import",
+    for f in ("pag_shard_extract", "pag_shard_take", "pag_shard_take_part", "pag_shard_build", "pag_shard_export", "pag_shard_take_slice", "pag_shard_import",
               "pag_shard_select", "pag_shard_set_region"):
         getattr(hip, f).restype = _C.c_int
     hip.pag_last_error.restype = _C.c_char_p

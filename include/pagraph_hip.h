@@ -234,6 +234,9 @@ int pag_prepare(pag_graph *g, const pag_raw_input *raw, pag_build_input *out);
  *   = {tuples pass 1, tuples pass 2, edges pass 1, edges pass 2} destined for owner o; in the partitioned streams the
  *   part of owner o is [its pass-1 records][its pass-2 records], owners ascending.
  * pag_shard_take: copies the partitioned streams into caller (device) buffers of the sizes just reported.
+ * pag_shard_take_part: ... a stretch of them only — records [t_off, t_off + t_n) of the tuple stream, [e_off, e_off + e_n) of
+ *   the edge stream (e.g. ONE owner's pass-1 records: the offsets follow from `counts`) — for a caller that gathers one
+ *   owner's records from several extractions without holding the others' (aligngraph2_amd/rank_serial.py).
  * pag_shard_build: the received records (device pointers, already in the order described above; t1 / e1 = how many
  *   of them are pass-1 records) -> K2 sort, K3, K4; the handle then holds the slice of this owner.
  * pag_shard_export / pag_shard_take_slice / pag_shard_import: the slice as device arrays; a whole graph from the slices of all owners (device
@@ -252,6 +255,8 @@ typedef struct pag_shard_slice {
 } pag_shard_slice;
 int pag_shard_extract(pag_graph *g, const pag_build_input *in, uint32_t shard, uint32_t n_shards, uint64_t *counts);
 int pag_shard_take(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval);
+int pag_shard_take_part(pag_graph *g, uint64_t t_off, uint64_t t_n, uint32_t *tkey, uint64_t *tval, uint64_t e_off, uint64_t e_n, uint32_t *ekey,
+                        uint64_t *eval);
 int pag_shard_build(pag_graph *g, const uint32_t *tkey, const uint64_t *tval, uint64_t n_t, uint64_t t1, const uint32_t *ekey,
                     const uint64_t *eval, uint64_t n_e, uint64_t e1, uint32_t eps, pag_build_stats *stats);
 int pag_shard_export(const pag_graph *g, pag_shard_slice *out);
