@@ -18,6 +18,9 @@ endif
 ifeq ($(WALK_WINDOW),tiny)
 PROF_FLAGS += -DPAG_WALK_TINY_WINDOW
 endif
+ifdef WALK_EU
+PROF_FLAGS += -DPAG_WALK_WAVES_PER_EU=$(WALK_EU)
+endif
 HIPFLAGS := $(PROF_FLAGS) -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Iinclude -Ialigngraph2_amd/csrc/hip -ffp-contract=off -Wall -Wno-unused-value
 
 HOST_DIR := aligngraph2_amd/csrc/host

@@ -781,13 +781,21 @@ __global__ void k_id_bounds(TravGraph G, const uint32_t *__restrict__ coords, ui
 // =================================================================================================
 // the walker
 // =================================================================================================
-constexpr int LIST_CAP = 256;  // successors of one vertex kept per class
-constexpr int BR_CAP = 256;    // branch fan-out kept per graphTravel round
+// What a walker wave keeps in LDS decides how many of them a compute unit holds (160 KB / sizeof(WalkLds)): until round 5 the
+// worst-case caps below were 256 / 256 / 64 and made up half of the 52 KB (three waves per CU).  Now the LDS copies hold the
+// COMMON case and the rare long list lives in global memory with no cap but the job's own buffers, which the host doubles on
+// overflow (k5_travel_host.hip): a classification of more than 64 records writes its chosen class behind the end of the
+// job's sequence (free room until the next append, see classify), a probe that stops with more than PB_CAP accepted records
+// leaves none behind and graphTravel classifies that vertex itself.
+constexpr int LIST_CAP = 64;   // successors of one vertex kept in LDS (the classification of at most 64 records)
+constexpr int BR_CAP = 64;     // alternatives of a graphTravel round kept in LDS (more: read from the global list)
+constexpr int PB_CAP = 16;     // accepted records of the classification a probe stopped at, per slot (more: not kept)
 constexpr int PROBE_GROUPS = TRAV_PROBE_GROUPS;  // probe slots = lane groups of a wave
 constexpr uint32_t GL = 64u / PROBE_GROUPS;       // lanes per slot: successor records of one vertex evaluated side by side
 constexpr uint32_t GL_SHIFT = GL == 8u ? 3u : 4u;
 constexpr uint32_t GL_MASK = (1u << GL) - 1u;
 static_assert(GL == 8u || GL == 16u, "slot geometry");
+static_assert(GL <= (uint32_t)PB_CAP, "a slot's own lanes always fit their accepted records (slots_step)");
 #define STAMP_TRAVEL 0xFFFFFFFFu
 
 // A walk moves through the coordinate-ordered arrays almost monotonically, a few ids per step, and every
@@ -826,8 +834,7 @@ static_assert(WIN_IDS / 32u <= 64u, "one lane per word of the global-visited win
 constexpr uint64_t SPEC_MARGIN = 50000;  // bases: no zombie within this distance of the can-leap threshold  // refill when the anchor gets this close to the upper end
 
 struct WalkLds {
-    uint32_t lst_v[4][LIST_CAP], lst_s[4][LIST_CAP];
-    uint32_t lst_n[4];
+    uint32_t lst_v[1][LIST_CAP], lst_s[1][LIST_CAP];
     uint32_t br_v[BR_CAP], br_s[BR_CAP];
     // per list entry of class 0 / per alternative: contig coordinate, first successor record, record count
     // (15 = look it up) of the vertex, taken from the record that led to it; valid when *_meta is set
@@ -842,7 +849,7 @@ struct WalkLds {
     // After the chosen path is appended, graphTravel's own classification of its last vertex is this list minus
     // the records whose coordinate now falls into the (hull of the) travel window — see k_walk's main loop.
     uint32_t pb_cnt[PROBE_GROUPS];
-    uint32_t pb_v[PROBE_GROUPS][64], pb_meta[PROBE_GROUPS][64], pb_pc[PROBE_GROUPS][64], pb_off[PROBE_GROUPS][64], pb_cls[PROBE_GROUPS][64];
+    uint32_t pb_v[PROBE_GROUPS][PB_CAP], pb_meta[PROBE_GROUPS][PB_CAP], pb_pc[PROBE_GROUPS][PB_CAP], pb_off[PROBE_GROUPS][PB_CAP], pb_cls[PROBE_GROUPS][PB_CAP];
     // blocked Bloom filters (two bits inside one 64-bit word) over the vertices OUTSIDE the strand's id range
     // that are in the travel-visited set (ft, maintained on insert) and in the contig's global visited set
     // (fg, built once per job): a clear bit proves absence, so the random probe into the global hash table
@@ -1165,7 +1172,12 @@ struct Step {
 };
 
 __device__ __forceinline__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0, uint32_t cnt, bool have_pre, const SuccRec &pre, bool can_leap,
-                             int level, const ProbeOut po, Step *one, bool *list_meta = nullptr) {
+                             int level, const ProbeOut po, Step *one, bool *list_meta = nullptr, uint32_t *gl_v = nullptr, uint32_t *gl_s = nullptr,
+                             uint64_t gl_cap = 0) {
+    // list_meta != nullptr: the caller wants the chosen class as a list (graphTravel, level 1); walkStraight (level 2) only asks
+    // how many there are.  The list of a classification of at most 64 records is L.lst_* (*list_meta = true: with every
+    // vertex's own data); of more than 64 records it is gl_v / gl_s[0 .. n) in global memory (*list_meta = false) — n > gl_cap
+    // sets X.overflow.
     const uint32_t lane = lane_id();
     const uint32_t r1 = r0 + cnt;
     X.n_classify += 1;
@@ -1200,6 +1212,7 @@ __device__ __forceinline__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0
             one->next.toff = __shfl(nx.toff, src, 64);
             return 1;
         }
+        if (!list_meta) return n;
         __syncthreads();
         if ((m >> lane) & 1ull) {
             uint32_t at = (uint32_t)__popcll(m & lanemask_lt());
@@ -1209,15 +1222,14 @@ __device__ __forceinline__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0
             L.lst_off[at] = rec.toff;
             L.lst_cnt[at] = rec.meta >> 28;
         }
-        if (list_meta) *list_meta = true;
+        *list_meta = true;
         __syncthreads();
         return n;
     }
     if (list_meta) *list_meta = false;
-    // more than 64 successor records (repeats): chunked, all four class lists kept in LDS
-    __syncthreads();
-    if (lane < 4) L.lst_n[lane] = 0;
-    __syncthreads();
+    // more than 64 successor records (repeats), 64 at a time.  First pass: how many records of every class, and the first of
+    // each (all wave-uniform); the chosen class is written out by a second pass over the records, in reference order.
+    uint32_t cn[4] = {0, 0, 0, 0}, fv[4] = {0, 0, 0, 0}, fs[4] = {0, 0, 0, 0};
     for (uint32_t rb = r0; rb < r1; rb += 64) {
         int cls = -1;
         SuccRec rec{0, 0, 0, 0};
@@ -1225,45 +1237,54 @@ __device__ __forceinline__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0
             rec = rec_load(L, X, rb + lane);
             cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch, X.gen);
         }
-        for (int c = 0; c < 4; ++c) {  // ordered append to the four class lists
-            uint64_t m = __ballot(cls == c);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t m = __ballot(cls == c);
             if (m == 0) continue;
-            uint32_t base = L.lst_n[c];
-            if (cls == c) {
-                uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt());
-                if (at < LIST_CAP) {
-                    L.lst_v[c][at] = rec.tgt;
-                    L.lst_s[c][at] = rec.meta & 0xFFFFFFu;
-                }
+            if (cn[c] == 0) {
+                const int src = __ffsll((long long)m) - 1;
+                fv[c] = __shfl(rec.tgt, src, 64);
+                fs[c] = __shfl(rec.meta, src, 64) & 0xFFFFFFu;
             }
-            __syncthreads();
-            if (lane == 0) L.lst_n[c] = base + (uint32_t)__popcll(m);
-            __syncthreads();
+            cn[c] += (uint32_t)__popcll(m);
         }
     }
-    __syncthreads();
-    int chosen = L.lst_n[0] ? 0 : (L.lst_n[1] ? 1 : (L.lst_n[2] ? 2 : 3));
-    uint32_t n = L.lst_n[chosen];
-    if (n > LIST_CAP) {
-        X.overflow = 1;
-        n = LIST_CAP;
-    }
-    if (chosen != 0) {
-        for (uint32_t i = lane; i < n; i += 64) {
-            L.lst_v[0][i] = L.lst_v[chosen][i];
-            L.lst_s[0][i] = L.lst_s[chosen][i];
-        }
-    }
-    __syncthreads();
+    const int chosen = cn[0] ? 0 : (cn[1] ? 1 : (cn[2] ? 2 : 3));
+    const uint32_t n = cn[chosen];
+    if (n == 0) return 0;
     if (n == 1) {
-        one->v = L.lst_v[0][0];
-        one->s = L.lst_s[0][0];
+        one->v = chosen == 0 ? fv[0] : chosen == 1 ? fv[1] : chosen == 2 ? fv[2] : fv[3];
+        one->s = chosen == 0 ? fs[0] : chosen == 1 ? fs[1] : chosen == 2 ? fs[2] : fs[3];
         one->pc = (uint32_t)(X.G.upos[one->v] >> 32);
         one->off = X.G.succ_off[one->v];
         uint32_t c2 = X.G.succ_off[one->v + 1] - one->off;
         one->cnt = c2 < 15u ? c2 : 15u;
         one->have_next = false;
+        return 1;
     }
+    if (!list_meta) return n;
+    if ((uint64_t)n > gl_cap) {  // (the host doubles the job's buffers and posts it again)
+        X.overflow = 1;
+        return n;
+    }
+    uint32_t base = 0;
+    for (uint32_t rb = r0; rb < r1; rb += 64) {
+        int cls = -1;
+        SuccRec rec{0, 0, 0, 0};
+        if (rb + lane < r1) {
+            rec = rec_load(L, X, rb + lane);
+            cls = eval_record(L, X, rec, can_leap, level, 0u, po, X.epoch, X.gen);
+        }
+        const uint64_t m = __ballot(cls == chosen);
+        if (cls == chosen) {
+            const uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt());
+            gl_v[at] = rec.tgt;
+            gl_s[at] = rec.meta & 0xFFFFFFu;
+        }
+        base += (uint32_t)__popcll(m);
+    }
+    __threadfence_block();
+    __syncthreads();
     return n;
 }
 
@@ -1460,7 +1481,7 @@ __device__ __forceinline__ bool slot_finish_wide(WalkLds &L, WalkCtx &X, Slot &S
             status = n == 0 ? WS_END : WS_BRANCH;
             if (!zombie) {  // the accepted records, for the classification of the chosen path's last vertex
                 const uint64_t ga = __ballot(cls >= 0);
-                if (cls >= 0) {
+                if (cls >= 0 && (uint32_t)__popcll(ga & lanemask_lt()) < (uint32_t)PB_CAP) {  // (more than PB_CAP: the count says so, see walk_job)
                     const uint32_t kk = (uint32_t)__popcll(ga & lanemask_lt());
                     L.pb_v[g][kk] = rec.tgt;
                     L.pb_meta[g][kk] = rec.meta;
@@ -1911,7 +1932,7 @@ __device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp,
         const uint32_t n = (uint32_t)__popcll(m);
         if (n != 1u) {  // the walk stops at this classification: leave the accepted records behind (see WalkLds)
             const uint64_t am = __ballot(cls >= 0);
-            if (cls >= 0) {
+            if (cls >= 0 && (uint32_t)__popcll(am & lanemask_lt()) < (uint32_t)PB_CAP) {
                 const uint32_t kk = (uint32_t)__popcll(am & lanemask_lt());
                 L.pb_v[grp][kk] = rec.tgt;
                 L.pb_meta[grp][kk] = rec.meta;
@@ -2225,12 +2246,20 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         Step one;
         bool list_meta = false;
         uint32_t m;
-        if (fast && f_list) {
+        // the alternatives of this iteration: L.br_*[0 .. m) — or, beyond BR_CAP of them (a classification of more than 64
+        // records: repeats), gl_v / gl_s[0 .. m): the room behind the end of the job's sequence, free until the chosen path
+        // of this iteration is appended at the top of the next one
+        uint32_t *const gl_v = J.seq_v + seq_len, *const gl_s = J.seq_s + seq_len;
+        bool use_list = fast && f_list;
+        if (use_list) {
+            __syncthreads();
+            use_list = L.pb_cnt[f_grp] <= (uint32_t)PB_CAP;  // (a probe that stopped with more accepted records left none behind)
+        }
+        if (use_list) {
             // graphTravel's classification of `last` (level 1) = the classification the chosen probe stopped at
             // (level 2): the probe's marks are exactly the vertices just appended and its coordinate window has just
             // been merged into the travel window.  The one difference: the merged window is the HULL of the two, so
             // an accepted record whose coordinate lies in the gap between them is rejected now.
-            __syncthreads();
             const uint32_t nc = L.pb_cnt[f_grp];
             int c = -1;
             uint32_t cv = 0, cmeta = 0, cpc = 0, coff = 0;
@@ -2265,12 +2294,9 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         const SuccRec none{0, 0, 0, 0};
         win_follow(L, X, last, l_off, l_cnt);
         m = classify(L, X, l_off, l_cnt, false, none, (has_size + now_size) >= X.C.split_size, 1, ProbeOut{0, 0, 0}, &one,
-                              &list_meta);
+                              &list_meta, gl_v, gl_s, J.seq_cap - seq_len);
         if (m == 0) break;
-        if (m > BR_CAP) {
-            X.overflow = 1;
-            m = BR_CAP;
-        }
+        if (X.overflow) break;  // (the list of a wide classification did not fit behind the sequence: the host doubles the buffers)
         __syncthreads();
         if (m == 1) {  // the single-successor fast path of classify bypasses the LDS list
             if (lane == 0) {
@@ -2282,18 +2308,22 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             }
             list_meta = true;
         } else {
-            for (uint32_t i = lane; i < m; i += 64) {
-                L.br_v[i] = L.lst_v[0][i];
-                L.br_s[i] = L.lst_s[0][i];
+            for (uint32_t i = lane; i < m && i < (uint32_t)BR_CAP; i += 64) {
                 if (list_meta) {
+                    L.br_v[i] = L.lst_v[0][i];
+                    L.br_s[i] = L.lst_s[0][i];
                     L.br_pc[i] = L.lst_pc[i];
                     L.br_off[i] = L.lst_off[i];
                     L.br_cnt[i] = L.lst_cnt[i];
+                } else {
+                    L.br_v[i] = gl_v[i];
+                    L.br_s[i] = gl_s[i];
                 }
             }
         }
         __syncthreads();
         }
+        const bool br_global = m > (uint32_t)BR_CAP;  // (then the list is the global one: only a wide classification gets that long)
 
         // probe every alternative (PAlgorithm.tcc:251-266): PROBE_GROUPS at a time side by side, each in
         // its own share of the arena; sequential full-wave probing only when a vertex has more than 64 records
@@ -2421,7 +2451,8 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
             uint64_t used = 0;
             for (uint32_t i = 0; i < m; ++i) {
                 uint64_t l2 = 0;
-                int stt = walk_straight(L, X, L.br_v[i], L.br_s[i], has_size + now_size, J.arena_v + used, J.arena_s + used,
+                const uint32_t alt_v = br_global ? gl_v[i] : L.br_v[i], alt_s = br_global ? gl_s[i] : L.br_s[i];
+                int stt = walk_straight(L, X, alt_v, alt_s, has_size + now_size, J.arena_v + used, J.arena_s + used,
                                         J.arena_cap - used, &l2);
                 it_low = X.win_p0 < it_low ? X.win_p0 : it_low;
                 if (it_low < lc && lc - it_low > max_back) max_back = lc - it_low;
@@ -2438,7 +2469,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
                         tip_off = used;
                     }
                 } else {
-                    uint32_t ab = G.ucnt[L.br_v[i]];
+                    uint32_t ab = G.ucnt[alt_v];
                     if (best_branch < 0 || ab > best_ab) {
                         best_branch = (int)i;
                         best_ab = ab;
@@ -2539,7 +2570,12 @@ __global__ __launch_bounds__(64) void k_walk(TravGraph G, const TravContig *__re
 // units' LDS with walkers of its own — therefore stalls the dispatcher only until running jobs end or idle waves leave,
 // never until a host acts that may itself be queued behind the stalled dispatch.  q->started / q->exited (system scope)
 // tell the host how many waves it has.
-__global__ __launch_bounds__(64) void k_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done,
+// (PAG_WALK_WAVES_PER_EU, make WALK_EU=: the register budget.  Left to itself the compiler takes 256 VGPRs + AGPRs for the walker:
+// one wave per SIMD, four per compute unit whatever the LDS allows; with 2 it keeps to 256 in all and spills ~35 to scratch.)
+#ifndef PAG_WALK_WAVES_PER_EU
+#define PAG_WALK_WAVES_PER_EU 1
+#endif
+__global__ __launch_bounds__(64, PAG_WALK_WAVES_PER_EU) void k_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done,
                                                         TravQueue *q, uint32_t *next, uint32_t cap, uint32_t k,
                                                         uint64_t idle_ticks) {
     __shared__ WalkLds L;
@@ -3039,7 +3075,7 @@ int trav_walk_waves_per_cu() {
         (void)hipGetLastError();
         n = (int)((160 * 1024) / sizeof(WalkLds));
     }
-    return n >= 4 ? 4 : n >= 1 ? n : 1;
+    return n >= 8 ? 8 : n >= 1 ? n : 1;
 }
 void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut *outs, uint32_t *done, TravQueue *q,
                                  uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_ticks, hipStream_t s) {

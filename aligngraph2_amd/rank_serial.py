@@ -1,17 +1,28 @@
 """ONE config block too large for one GPU, built and traversed on ONE GPU: the N ranks of a sharded build (SURVEY.md §8e
-level 2, `parallel.ShardedBuild` / include/pagraph_hip.h `pag_shard_*`) run ONE AFTER THE OTHER on the same device, and what
-the ranks of a real N-GPU run would hand each other over xGMI waits in pinned host memory in between.
+level 2, `parallel.ShardedBuild` / include/pagraph_hip.h `pag_shard_*`) run ONE AFTER THE OTHER on the same device.
 
-Every kernel, every piece of host logic and every byte exchanged is the N-GPU run's; only the transport differs (host memory
-instead of RCCL) and the ranks take turns.  That makes it two things:
+Nothing is parked in host memory (round 4 spilled every exchange — 265 GB at BASELINE configs[2] — and took the GPU box down
+with it).  What a rank would RECEIVE over xGMI is RECOMPUTED when its turn comes; the schedule is destination-major:
 
-* a way to run BASELINE configs[2] (1 M x 10 kb reads vs a 250 Mb reference, sharded over 4 GPUs) on the one GPU this build
-  has, with the per-rank device footprint of every stage MEASURED (hipMemGetInfo around the stages) instead of computed by
-  hand;
-* a product mode: a block whose graph does not fit one MI355X is still processed on it, at the price of the host spills.
+    counts[r][o]                              one extraction per read range r (sizes of what r sends owner o)
+    for rank d:                               (its contigs, its region of the graph)
+        for owner o:
+            for read range r: extract r, keep only o's records         -> o's received streams, canonical order
+            K2-K4 on them (pag_shard_build)                             -> o's slice of the block's graph
+            pag_shard_select for d's region                             -> appended to d's region, on the device
+        import the region, release the build, pag_travel d's contigs    -> their travel sequences (host)
+    chains + output files of the whole block from the gathered sequences (pagh_assemble_paths)
 
-Reference semantics: the block is one `PositionProcessor::process` + one `PAssembly::testTravel5` (pagraph.cpp:181-263);
-the partition argument for bit-identity is the sharded build's (include/pagraph_hip.h, pag_shard_*).
+A build is 0.1-0.3 s per rank at configs[2]'s size, so the N^2 small builds cost seconds; the host holds the travel sequences
+and nothing else.  Every kernel, every piece of host logic and every byte a rank takes in is the N-GPU run's; only the
+transport differs (a device-to-device copy instead of RCCL) and the ranks take turns.  That makes it a MEASURING AID: BASELINE
+configs[2] (1 M x 10 kb reads vs a 250 Mb reference, sharded over 4 GPUs) executes on the one GPU this build has, with the
+per-rank device footprint of every stage measured (hipMemGetInfo around the stages) instead of computed by hand.
+It is not how a multi-GPU node runs the block (that is `pag_shard_run` / `bin/pagraph` under PAGRAPH_SHARD), and no
+multi-GPU timing follows from it.
+
+Reference semantics: the block is one `PositionProcessor::process` + one `PAssembly::testTravel5` (pagraph.cpp:181-263,
+PAssembly.cpp:30-79); the partition argument for bit-identity is the sharded build's (include/pagraph_hip.h, pag_shard_*).
 """
 from __future__ import annotations
 
@@ -39,35 +50,11 @@ def _used(torch, device):
     return int(total - free)
 
 
-_PINNED = os.environ.get("PAG_RANK_SERIAL_PINNED") == "1"
-
-
-def _to_host(torch, t):
-    """a device tensor into host memory.  Pageable by default: torch's pinned allocator rounds every block up to a power of two
-    and keeps it cached, which at BASELINE configs[2]'s 265 GB of spills is the difference between fitting the GPU box's
-    300 GiB container and being killed by it (PAG_RANK_SERIAL_PINNED=1: pinned, faster copies)."""
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=_PINNED)
-    h.copy_(t, non_blocking=_PINNED)
-    return h
-
-
-def _host_guard(limit_frac=0.8):
-    """raises before the container's memory limit is reached (a run that is killed by it takes the GPU box with it)"""
+def _host_bytes():
     try:
-        lim = open("/sys/fs/cgroup/memory.max").read().strip()
-        cur = int(open("/sys/fs/cgroup/memory.current").read())
+        return int(open("/sys/fs/cgroup/memory.current").read())
     except (OSError, ValueError):
         return 0
-    if lim != "max" and cur > limit_frac * int(lim):
-        raise MemoryError(f"rank_serial: {cur / 1e9:.0f} GB of host memory in use, the container's limit is {int(lim) / 1e9:.0f} GB: the block's "
-                          "spills do not fit this host")
-    return cur
-
-
-def _drop_host_cache(torch):
-    fn = getattr(torch._C, "_host_emptyCache", None)
-    if fn is not None:
-        fn()
 
 
 def digest_dir(path):
@@ -89,13 +76,14 @@ def digest_dir(path):
 
 def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns, ref_lens, ctg_seqs, ref_seqs, orient, out_dir, device="cuda",
         halo=200_000, min_len=50, log=None):
-    """The block as N ranks, rank after rank, on one device.
+    """The block as N ranks, rank after rank, on one device (schedule: module docstring).
 
     make_handle() -> a fresh pag_graph* (e.g. pag_create_from_bitmap on the block's solid set); inp: the prepared
     pag_build_input (device resident, owned by the caller); ctgs: [(length)] per contig; ctg_alns / ref_lens: as
     parallel.regions_for takes them, with ref_begin taken from the first alignment of a contig; ctg_seqs / ref_seqs: host
-    pag_seqs of the contigs / references (for pag_travel and the chain selection); orient[c]: PAG_ORIENT_*.
-    Returns a dict: count lines, per-rank per-stage device bytes, wire bytes, held fractions, times, output digest."""
+    pag_seqs of the contigs / references (for pag_travel and the chain selection); orient[c]: PAG_ORIENT_*; out_dir: must not
+    exist or be empty (the block's output files are written there).
+    Returns a dict: count lines, per-rank per-stage device bytes, bytes a rank sends / takes in, held fractions, times, output digest."""
     import torch
     say = log or (lambda *a: None)
     parallel.bind_shard_api(hip)
@@ -109,6 +97,9 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
                                          C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, C.c_uint32, C.c_void_p]
     host.pagh_assemble_paths.restype = C.c_int
     host.pagh_last_error.restype = C.c_char_p
+    if os.path.isdir(out_dir) and os.listdir(out_dir):
+        raise ValueError(f"rank_serial: {out_dir} exists and is not empty (nothing of the caller's is ever removed)")
+    os.makedirs(out_dir, exist_ok=True)
     N = n_ranks
     n_ctg = len(ctgs)
     first_aln = {}
@@ -118,164 +109,160 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
     ref_begin = [rst[first_aln[c][0]] + first_aln[c][1] if c in first_aln else 0 for c in range(n_ctg)]
     deal = parallel.deal_contigs(list(ctgs), N, ref_begin=ref_begin)
     regions = parallel.regions_for(deal, list(ctgs), orient, ctg_alns, list(ref_lens), halo=halo)
-    res = {"n_ranks": N, "halo": halo, "ranks": [dict() for _ in range(N)], "contigs_per_rank": [len(d) for d in deal]}
+    res = {"n_ranks": N, "halo": halo, "schedule": "destination-major, everything a rank takes in recomputed on the device (no host spills)",
+           "ranks": [dict() for _ in range(N)], "contigs_per_rank": [len(d) for d in deal]}
     t_all = time.perf_counter()
+    host0 = _host_bytes()
 
     def sync():
         torch.cuda.synchronize(device)
 
-    torch.cuda.empty_cache()
-    base = _used(torch, device)  # (the block's inputs and whatever else the caller holds)
-    res["device_bytes_inputs_and_caller"] = base
+    def used():
+        return _used(torch, device)
 
-    # ---- phase A: every rank extracts its read range and partitions its two streams by k-mer owner ---------------------
-    counts = np.zeros((N, N, 4), dtype=np.int64)
-    spilled = []  # per rank: (tk, tv, ek, ev) in pinned host memory
-    for r in range(N):
-        t0 = time.perf_counter()
-        g = make_handle()
+    def destroy(g):
+        hip.pag_destroy(C.c_void_p(g))
+        torch.cuda.empty_cache()
+
+    torch.cuda.empty_cache()
+    base = used()  # (the block's inputs and whatever else the caller holds)
+    res["device_bytes_inputs_and_caller"] = base
+    peak = {"device": base}
+
+    def note_peak():
+        peak["device"] = max(peak["device"], used())
+
+    def extract(g, r):
         c = (C.c_uint64 * (4 * N))()
         rc = hip.pag_shard_extract(C.c_void_p(g), C.byref(inp), r, N, c)
         if rc != 0:
-            raise RuntimeError(f"rank {r}: pag_shard_extract failed ({rc}): {hip.pag_last_error().decode()}")
-        sync()
-        counts[r] = np.array(list(c), dtype=np.int64).reshape(N, 4)
-        res["ranks"][r]["bytes_extract"] = _used(torch, device) - base
-        T, E = int(counts[r][:, 0:2].sum()), int(counts[r][:, 2:4].sum())
-        tk = torch.empty(T, dtype=torch.int32, device=device)
-        tv = torch.empty(T, dtype=torch.int64, device=device)
-        ek = torch.empty(E, dtype=torch.int32, device=device)
-        ev = torch.empty(E, dtype=torch.int64, device=device)
-        rc = hip.pag_shard_take(C.c_void_p(g), C.c_void_p(tk.data_ptr()), C.c_void_p(tv.data_ptr()), C.c_void_p(ek.data_ptr()), C.c_void_p(ev.data_ptr()))
-        if rc != 0:
-            raise RuntimeError(f"rank {r}: pag_shard_take failed ({rc}): {hip.pag_last_error().decode()}")
-        hip.pag_destroy(C.c_void_p(g))
-        t1 = time.perf_counter()
-        # what goes to owner o waits as its own host arrays (freed when o has taken them): [o] -> (tkey, tval, ekey, eval)
-        per_dst = []
-        for o in range(N):
-            t_off, t_n = int(counts[r, :o, 0:2].sum()), int(counts[r, o, 0:2].sum())
-            e_off, e_n = int(counts[r, :o, 2:4].sum()), int(counts[r, o, 2:4].sum())
-            per_dst.append((_to_host(torch, tk[t_off:t_off + t_n]), _to_host(torch, tv[t_off:t_off + t_n]),
-                            _to_host(torch, ek[e_off:e_off + e_n]), _to_host(torch, ev[e_off:e_off + e_n])))
-        spilled.append(per_dst)
-        res["host_bytes_peak"] = max(res.get("host_bytes_peak", 0), _host_guard())
-        sync()
-        del tk, tv, ek, ev
-        torch.cuda.empty_cache()
-        res["ranks"][r].update(tuples_extracted=T, edges_extracted=E, s_extract=t1 - t0, s_spill_streams=time.perf_counter() - t1,
-                               wire_out_tuples_bytes=int(12 * (T + E - counts[r][r].sum())))
-        say(f"rank {r}: extracted {T} + {E} records, {res['ranks'][r]['bytes_extract'] / 1e9:.1f} GB on the device, {t1 - t0:.1f} s + spill "
-            f"{time.perf_counter() - t1:.1f} s")
+            raise RuntimeError(f"read range {r}: pag_shard_extract failed ({rc}): {hip.pag_last_error().decode()}")
+        return np.array(list(c), dtype=np.int64).reshape(N, 4)
 
-    # ---- phase B: every owner sorts / clusters what it received and selects every rank's region of its slice ------------
-    def received(o, which):
-        """owner o's records of one stream ([pass 1 from rank 0] .. [pass 1 from rank N-1] [pass 2 from rank 0] ..), uploaded"""
-        q0 = 2 * which
-        n1 = int(counts[:, o, q0].sum())
-        n = n1 + int(counts[:, o, q0 + 1].sum())
-        key = torch.empty(n, dtype=torch.int32, device=device)
-        val = torch.empty(n, dtype=torch.int64, device=device)
-        d1, d2 = 0, n1
-        for r in range(N):
-            a, b = int(counts[r, o, q0]), int(counts[r, o, q0 + 1])
-            hk, hv = spilled[r][o][2 * which], spilled[r][o][2 * which + 1]
-            key[d1:d1 + a].copy_(hk[:a], non_blocking=True)
-            val[d1:d1 + a].copy_(hv[:a], non_blocking=True)
-            key[d2:d2 + b].copy_(hk[a:a + b], non_blocking=True)
-            val[d2:d2 + b].copy_(hv[a:a + b], non_blocking=True)
-            d1 += a
-            d2 += b
-        return key, val, n1
-
-    selected = [[None] * N for _ in range(N)]  # [owner][dest] -> (dict of pinned arrays, stats)
-    owner_stats = []
-    for o in range(N):
+    # ---- what every read range sends every owner: one extraction per range, each on a handle of its own, so that the device
+    # bytes measured around it are the extraction stage of rank r and nothing else
+    counts = np.zeros((N, N, 4), dtype=np.int64)
+    for r in range(N):
         t0 = time.perf_counter()
         g = make_handle()
-        sb = parallel.ShardedBuild(hip, g, inp, o, N, device)
-        tk, tv, t1n = received(o, 0)
-        ek, ev, e1n = received(o, 1)
+        counts[r] = extract(g, r)
         sync()
-        for r in range(N):
-            spilled[r][o] = None  # (taken)
-        t1 = time.perf_counter()
-        st = sb.build((tk, tv), t1n, (ek, ev), e1n, eps)
-        sync()
-        info = res["ranks"][o]
-        info["bytes_owner_build"] = _used(torch, device) - base  # (received records + sort ping-pong + segment results)
-        info["owner_tuples"], info["owner_edges"] = int(tk.numel()), int(ek.numel())
-        del tk, tv, ek, ev
-        torch.cuda.empty_cache()
-        owner_stats.append(st)
-        t2 = time.perf_counter()
-        peak_sel = 0
-        sel_bytes = 0
-        for d in range(N):
-            arrs, sst = sb.select(regions[d])
-            sync()
-            peak_sel = max(peak_sel, _used(torch, device) - base)
-            selected[o][d] = ({nm: _to_host(torch, arrs[nm]) for nm in _NAMES}, sst)
-            res["host_bytes_peak"] = max(res.get("host_bytes_peak", 0), _host_guard())
-            sync()
-            sel_bytes += sum(arrs[nm].numel() * arrs[nm].element_size() for nm in _NAMES) if d != o else 0
-            del arrs
-            torch.cuda.empty_cache()
-        info["bytes_owner_select_peak"] = peak_sel
-        info["wire_out_selection_bytes"] = int(sel_bytes)
-        info.update(s_upload_received=t1 - t0, s_owner_build=t2 - t1, s_select_and_spill=time.perf_counter() - t2,
-                    owner_n_pos=int(st.n_pos), owner_n_nodes=int(st.n_nodes), owner_n_uniq_edges=int(st.n_uniq_edges))
-        hip.pag_destroy(C.c_void_p(g))
-        torch.cuda.empty_cache()
-        say(f"owner {o}: {info['owner_tuples']} + {info['owner_edges']} records built in {t2 - t1:.1f} s, {info['bytes_owner_build'] / 1e9:.1f} GB; "
-            f"{st.n_pos} vertices; selections {time.perf_counter() - t2:.1f} s")
-    del spilled
-    _drop_host_cache(torch)
-    # the block's count lines = sums over the owners
-    tot_counts = [0] * 6
-    n_pos_total = 0
-    for st in owner_stats:
-        for i, x in enumerate(st.counts()):
-            tot_counts[i] += int(x)
-        n_pos_total += int(st.n_pos)
-    res["count_lines_sum_over_owners"] = tot_counts
-    res["vertices_total"] = n_pos_total
+        info = res["ranks"][r]
+        info["bytes_extract"] = used() - base
+        note_peak()
+        destroy(g)
+        T, E = int(counts[r][:, 0:2].sum()), int(counts[r][:, 2:4].sum())
+        info.update(tuples_extracted=T, edges_extracted=E, s_extract=time.perf_counter() - t0,
+                    wire_out_tuples_bytes=int(12 * (T + E - counts[r][r].sum())))
+        say(f"rank {r}: extracts {T} + {E} records, {info['bytes_extract'] / 1e9:.1f} GB on the device, {info['s_extract']:.1f} s")
 
-    # ---- phase C: every rank imports its region from all owners and walks the contigs it was dealt ----------------------
+    def gather_owner(gx, o):
+        """owner o's received records ([pass 1 from range 0] .. [pass 1 from range N-1] [pass 2 from range 0] ..) as device tensors:
+        every read range is extracted again on the handle gx and only o's part is kept"""
+        out = []
+        for which in (0, 1):
+            q0 = 2 * which
+            n1 = int(counts[:, o, q0].sum())
+            n = n1 + int(counts[:, o, q0 + 1].sum())
+            out.append((torch.empty(n, dtype=torch.int32, device=device), torch.empty(n, dtype=torch.int64, device=device), n1))
+        (tk, tv, t1n), (ek, ev, e1n) = out
+        at = [[0, t1n], [0, e1n]]  # next free place of [tuples, edges] x [pass 1, pass 2]
+        for r in range(N):
+            c = extract(gx, r)
+            if not np.array_equal(c, counts[r]):
+                raise RuntimeError(f"read range {r}: the extraction is not reproducible ({c.tolist()} then, {counts[r].tolist()} before)")
+            for ps in (0, 1):
+                t_off = int(counts[r, :o, 0:2].sum()) + (int(counts[r, o, 0]) if ps else 0)
+                e_off = int(counts[r, :o, 2:4].sum()) + (int(counts[r, o, 2]) if ps else 0)
+                t_n, e_n = int(counts[r, o, ps]), int(counts[r, o, 2 + ps])
+                rc = hip.pag_shard_take_part(C.c_void_p(gx), t_off, t_n, C.c_void_p(tk.data_ptr() + 4 * at[0][ps]), C.c_void_p(tv.data_ptr() + 8 * at[0][ps]),
+                                             e_off, e_n, C.c_void_p(ek.data_ptr() + 4 * at[1][ps]), C.c_void_p(ev.data_ptr() + 8 * at[1][ps]))
+                if rc != 0:
+                    raise RuntimeError(f"pag_shard_take_part failed ({rc}): {hip.pag_last_error().decode()}")
+                at[0][ps] += t_n
+                at[1][ps] += e_n
+            note_peak()
+        assert at[0] == [t1n, tk.numel()] and at[1] == [e1n, ek.numel()]
+        return (tk, tv, t1n), (ek, ev, e1n)
+
+    # ---- rank after rank: its region of the graph from all owners (recomputed), then its walks ---------------------------------
     prm = TravelParams(threads, 0, 2 * eps, 0.15, 0.90, min_len)
     ref_len_arr = np.array(list(ref_lens), dtype=np.uint32)
     paths = (C.c_void_p * (2 * n_ctg))()
     lens = (C.c_uint64 * (2 * n_ctg))()
     keep = []
+    owner_counts = None
+    n_pos_total = 0
     for d in range(N):
+        info = res["ranks"][d]
         t0 = time.perf_counter()
+        gx = make_handle()  # (all extractions of this rank's turn: its pools are sized by the first and reused)
+        slices, stats, owner_stats = [], [], []
+        t_extract = t_build = t_select = 0.0
+        sel_bytes_in = 0
+        for o in range(N):
+            ta = time.perf_counter()
+            m0 = used()
+            (tk, tv, t1n), (ek, ev, e1n) = gather_owner(gx, o)
+            sync()
+            tb = time.perf_counter()
+            go = make_handle()
+            sb = parallel.ShardedBuild(hip, go, inp, o, N, device)
+            st = sb.build((tk, tv), t1n, (ek, ev), e1n, eps)
+            sync()
+            if d == o:  # (this owner's own turn: what the stage holds on a rank of the N-GPU run)
+                info["bytes_owner_build"] = used() - m0  # (received records + sort ping-pong + segment results)
+                info["owner_tuples"], info["owner_edges"] = int(tk.numel()), int(ek.numel())
+                info.update(owner_n_pos=int(st.n_pos), owner_n_nodes=int(st.n_nodes), owner_n_uniq_edges=int(st.n_uniq_edges))
+            note_peak()
+            del tk, tv, ek, ev
+            torch.cuda.empty_cache()
+            tc = time.perf_counter()
+            arrs, sst = sb.select(regions[d])
+            sync()
+            note_peak()
+            if d == o:
+                info["bytes_owner_select_peak"] = used() - m0
+            nbytes = sum(arrs[nm].numel() * arrs[nm].element_size() for nm in _NAMES)
+            if o != d:
+                sel_bytes_in += nbytes
+                res["ranks"][o]["wire_out_selection_bytes"] = res["ranks"][o].get("wire_out_selection_bytes", 0) + int(nbytes)
+            slices.append(arrs)
+            stats.append(sst)
+            owner_stats.append(st)
+            destroy(go)
+            t_extract += tb - ta
+            t_build += tc - tb
+            t_select += time.perf_counter() - tc
+        destroy(gx)
+        # the block's count lines = sums over the owners (the same sums in every rank's turn)
+        tot_counts = [0] * 6
+        for st in owner_stats:
+            for i, x in enumerate(st.counts()):
+                tot_counts[i] += int(x)
+        if owner_counts is None:
+            owner_counts = tot_counts
+            n_pos_total = sum(int(st.n_pos) for st in owner_stats)
+        elif owner_counts != tot_counts:
+            raise RuntimeError(f"rank {d}: the owners' count lines {tot_counts} differ from those of rank 0's turn {owner_counts}")
+        t1 = time.perf_counter()
         g = make_handle()
         sb = parallel.ShardedBuild(hip, g, inp, d, N, device)
-        slices, stats = [], []
-        for o in range(N):
-            harr, sst = selected[o][d]
-            slices.append({nm: harr[nm].to(device, non_blocking=True) for nm in _NAMES})
-            stats.append(sst)
-        sync()
         tot = sb.import_all(slices, stats)
         sb.set_region(regions[d])
         del slices
         torch.cuda.empty_cache()
         hip.pag_shard_release_build(C.c_void_p(g))
         sync()
-        info = res["ranks"][d]
-        info["bytes_region_imported"] = _used(torch, device) - base
-        info["wire_in_region_bytes"] = int(sum(sum(selected[o][d][0][nm].numel() * selected[o][d][0][nm].element_size() for nm in _NAMES)
-                                               for o in range(N) if o != d))
-        for o in range(N):
-            selected[o][d] = None  # (imported)
-        if list(tot.counts()) != tot_counts:
-            raise RuntimeError(f"rank {d}: count lines {list(tot.counts())} differ from the owners' sums {tot_counts}")
+        info["bytes_region_imported"] = used() - base
+        info["wire_in_region_bytes"] = int(sel_bytes_in)
+        if list(tot.counts()) != owner_counts:
+            raise RuntimeError(f"rank {d}: count lines {list(tot.counts())} differ from the owners' sums {owner_counts}")
         nn, npos, ne = C.c_uint64(), C.c_uint64(), C.c_uint64()
         hip.pag_csr_sizes(C.c_void_p(g), C.byref(nn), C.byref(npos), C.byref(ne))
         info["held_vertices"], info["held_edges"] = int(npos.value), int(ne.value)
         info["held_fraction"] = npos.value / max(1, n_pos_total)
-        t1 = time.perf_counter()
+        t2 = time.perf_counter()
         mine = np.full(n_ctg, -1, dtype=np.int32)
         for cidx in deal[d]:
             mine[cidx] = orient[cidx]
@@ -283,7 +270,8 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         if rc != 0:
             raise RuntimeError(f"rank {d}: pag_travel failed ({rc}): {hip.pag_last_error().decode()}")
         sync()
-        info["bytes_traversal_peak"] = _used(torch, device) - base  # (region + traversal graph + successor records + walk arena)
+        info["bytes_traversal_peak"] = used() - base  # (region + traversal graph + successor records + walk arena)
+        note_peak()
         n_nodes_path = 0
         for cidx in deal[d]:
             for fwd in ((1, 0) if mine[cidx] == 2 else ((1,) if mine[cidx] == 1 else (0,))):
@@ -296,19 +284,18 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
                 lens[slot] = n.value
                 n_nodes_path += n.value
         host.pagh_release(C.c_void_p(g))
-        hip.pag_destroy(C.c_void_p(g))
-        torch.cuda.empty_cache()
-        info.update(s_import=t1 - t0, s_travel=time.perf_counter() - t1, path_nodes=int(n_nodes_path), contigs=len(deal[d]))
-        say(f"rank {d}: holds {info['held_fraction']:.3f} of the vertices ({info['bytes_region_imported'] / 1e9:.1f} GB imported), traversal peak "
+        destroy(g)
+        info.update(s_recompute_extract=t_extract, s_recompute_build=t_build, s_recompute_select=t_select, s_import=t2 - t1,
+                    s_travel=time.perf_counter() - t2, s_turn=time.perf_counter() - t0, path_nodes=int(n_nodes_path), contigs=len(deal[d]))
+        say(f"rank {d}: its region from {N} owners recomputed in {t1 - t0:.1f} s (extract {t_extract:.1f}, build {t_build:.1f}, select {t_select:.1f}); holds "
+            f"{info['held_fraction']:.3f} of the vertices ({info['bytes_region_imported'] / 1e9:.1f} GB imported), traversal peak "
             f"{info['bytes_traversal_peak'] / 1e9:.1f} GB, {len(deal[d])} contigs walked in {info['s_travel']:.1f} s")
-    del selected
-    _drop_host_cache(torch)
+    res["count_lines_sum_over_owners"] = owner_counts
+    res["vertices_total"] = n_pos_total
+    res["device_bytes_peak_of_the_serial_run"] = peak["device"]  # (this schedule's own peak: several stages' buffers coexist)
+    res["host_bytes_growth"] = max(0, _host_bytes() - host0)     # (the travel sequences)
 
     # ---- rank 0's part: the chains of the whole block from the gathered travel sequences ---------------------------------
-    import shutil
-    if os.path.isdir(out_dir):
-        shutil.rmtree(out_dir)
-    os.makedirs(out_dir)
     t0 = time.perf_counter()
 
     class TraverseStats(C.Structure):
@@ -324,7 +311,6 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         raise RuntimeError(f"pagh_assemble_paths failed ({rc}): {host.pagh_last_error().decode()}")
     res["s_assemble"] = time.perf_counter() - t0
     res["outputs_sha256"], res["outputs_bytes"] = digest_dir(out_dir)
-    res["host_bytes_peak"] = max(res.get("host_bytes_peak", 0), _host_guard())
     res.update(path_nodes=int(ts.n_path_nodes), path_bases=int(ts.n_path_bases), path_checksum=f"{ts.path_checksum:016x}",
                chains=int(ts.n_chains_emitted), s_total=time.perf_counter() - t_all)
     return res

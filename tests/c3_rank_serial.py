@@ -1,10 +1,13 @@
 """BASELINE configs[2] (1 M x 10 kb reads vs a 250 Mb reference, ref-block shard across 4 GPUs) executed on ONE MI355X: the N
-ranks of the sharded build run one after the other (aligngraph2_amd/rank_serial.py), what they would exchange over xGMI waits
-in pinned host memory.  Writes a JSON record: geometry, per-rank per-stage device bytes as measured (next to DESIGN.md §7's
-table), wire bytes, count lines, held fractions, times, one digest over the block's output files per N.
+ranks of the sharded build run one after the other (aligngraph2_amd/rank_serial.py), what a rank would take in over xGMI is
+recomputed on the device when its turn comes (no host spills).  Writes a JSON record: geometry, per-rank per-stage device
+bytes as measured (next to DESIGN.md §7's table), wire bytes, count lines, held fractions, times, one digest over the block's
+output files per N.
 
     python tests/c3_rank_serial.py OUT.json                       # configs[2] geometry, N = 4 and N = 8
     python tests/c3_rank_serial.py OUT.json --reads 100000 --ref-len 50000000 --one-gpu   # a size one GPU holds: also == one GPU
+    ... --reads 100000 --ref-len 50000000 --reference-digests profiles/r04_c2_text_parity.json   # BASELINE configs[1]: every output
+                                            # file against the SHA-256 of what the compiled reference wrote for this workload
 
 Asserted: count lines of every rank = sums over the owners; every rank holds < 1/N + 0.15 of the vertices; no walk leaves its
 region (pag_travel would fail with PAG_ERANGE); the outputs are identical for every N (and equal to the one-GPU run's when
@@ -36,6 +39,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--one-gpu", action="store_true", help="also run the block on one handle (it must fit) and compare the outputs")
     ap.add_argument("--solid-min-abundance", type=int, default=-1)
+    ap.add_argument("--reference-digests", default=None, help="a JSON with compare.reference_sha256 (tests/c2_text_runs.py --compare) for THIS workload: "
+                    "every output file of every run is held against the reference's digest of it")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,6 +122,14 @@ def main():
         res = rank_serial.run(hip, host, make_handle, inp, n_ranks=n, eps=spec.eps, k=spec.k, threads=spec.threads, ctgs=ctg_len, ctg_alns=alns,
                               ref_lens=[len(ref_np)], ctg_seqs=ctg_seqs, ref_seqs=ref_seqs, orient=orient, out_dir=out, device=dev, halo=args.halo,
                               log=lambda *a: print(f"[N={n}]", *a, flush=True))
+        if args.reference_digests:
+            import c2_text_runs
+            want = json.load(open(args.reference_digests))["compare"]["reference_sha256"]
+            got = c2_text_runs._digests(out)
+            want = {f: h for f, h in want.items() if f != "contig.txt"}  # (written by the executable's driver, not by the block's host half)
+            diff = sorted(f for f in set(want) | set(got) if want.get(f) != got.get(f))
+            res["reference_digests"] = {"file": os.path.basename(args.reference_digests), "files": len(want), "differing_files": diff, "identical": not diff}
+            assert not diff, f"N={n}: output files differ from the compiled reference's: {diff[:8]}"
         shutil.rmtree(out, ignore_errors=True)
         held = [r["held_fraction"] for r in res["ranks"]]
         res["properties"] = {"count_lines_equal_sums_over_owners": True, "max_held_fraction": max(held), "held_bound": 1.0 / n + 0.15,

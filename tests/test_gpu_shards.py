@@ -378,8 +378,8 @@ def test_bench_default_mode_two_processes(workdir):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_ranks", [2, 4])
 def test_rank_serial_run_equals_the_one_gpu_run(n_ranks, workdir):
-    """aligngraph2_amd/rank_serial.py (the N ranks of the sharded build one after the other on ONE device, their exchanges parked
-    in host memory — how BASELINE configs[2]'s geometry is executed on the one GPU this build has): outputs, count lines and
+    """aligngraph2_amd/rank_serial.py (the N ranks of the sharded build one after the other on ONE device, what a rank takes in
+    recomputed when its turn comes — how BASELINE configs[2] is executed on the one GPU this build has): outputs, count lines and
     path statistics of the one-GPU run of the same block; every rank holds its share of the vertices."""
     import torch
     import bench
