@@ -197,6 +197,7 @@ def run(hip, host, make_handle, inp, *, n_ranks, eps, k, threads, ctgs, ctg_alns
         info = res["ranks"][d]
         t0 = time.perf_counter()
         gx = make_handle()  # (all extractions of this rank's turn: its pools are sized by the first and reused)
+        extract(gx, 0)      # (... and exist before the owner stages are measured)
         slices, stats, owner_stats = [], [], []
         t_extract = t_build = t_select = 0.0
         sel_bytes_in = 0
