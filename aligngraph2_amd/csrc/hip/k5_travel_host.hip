@@ -1611,11 +1611,34 @@ struct WalkSession {
             defer_ring2 = false;
             if (interleave) {
                 std::vector<size_t> at(n_sel, 0);
+                // a contig's share of a turn (round 5): in proportion to the jobs it has, so that every contig's first round runs
+                // out of the ring in the same turn.  With equal shares the contigs with the most segments — the longest ones, whose
+                // chains also take the longest to stitch — saw their last segments START when the grid was already running empty
+                // (configs[1]: at 58 of 105 ms), and the ones among them that need a second round started it last of all.
+                std::vector<uint32_t> share(n_sel, interleave);
+                if (cfg.post_proportional) {
+                    size_t least = 0;
+                    for (uint32_t i : order)
+                        if (!deferred[i].empty() && (least == 0 || deferred[i].size() < least)) least = deferred[i].size();
+                    const size_t turns = least ? (least + interleave - 1) / interleave : 1;
+                    // (post_spread < 1: the longest contig is through at that fraction of the turns, the others later in the
+                    // order of their length — the control thread stitches the chains of 49 contigs one after the other, and
+                    // the longest chains first)
+                    size_t rank = 0, n_with = 0;
+                    for (uint32_t i : order) n_with += deferred[i].empty() ? 0 : 1;
+                    for (uint32_t i : order) {
+                        if (deferred[i].empty()) continue;
+                        const double frac = cfg.post_spread + (1.0 - cfg.post_spread) * (n_with > 1 ? (double)rank / (double)(n_with - 1) : 1.0);
+                        const double t = std::max(1.0, (double)turns * frac);
+                        share[i] = (uint32_t)std::max<double>(1.0, std::ceil((double)deferred[i].size() / t));
+                        ++rank;
+                    }
+                }
                 for (bool more = true; more;) {
                     more = false;
                     for (uint32_t i : order) {
                         auto &dq = deferred[i];
-                        for (uint32_t c = 0; c < interleave && at[i] < dq.size(); ++c, ++at[i])
+                        for (uint32_t c = 0; c < share[i] && at[i] < dq.size(); ++c, ++at[i])
                             if ((rc = commit_job(2u, dq[at[i]].P, dq[at[i]].jr, dq[at[i]].P.J.mode, dq[at[i]].P.J.stop_pc))) return fail(rc);
                         more = more || at[i] < dq.size();
                     }

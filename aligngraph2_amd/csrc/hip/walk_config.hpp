@@ -39,7 +39,9 @@ struct WalkConfig {
     bool leap_left_set = false;       // PAG_LEAP_LEFT
     uint64_t leap_left = 0;
     uint64_t leap_end_div = 2;        // PAG_LEAP_END_DIV
-    uint32_t post_interleave = 8;     // PAG_POST_INTERLEAVE
+    uint32_t post_interleave = 16;    // PAG_POST_INTERLEAVE (the share of the contig with the fewest jobs; 8 with equal shares until round 5)
+    bool post_proportional = true;    // PAG_POST_PROPORTIONAL=0: equal shares of a turn for every contig (until round 5)
+    double post_spread = 1.0;         // PAG_POST_SPREAD=<0..1>: the longest contig's jobs are through the ring at this fraction of the turns
     // ---- delivery of results
     bool deliver_early = true;        // PAG_DELIVER_EARLY
     uint32_t succ_heavy = 64;         // PAG_SUCC_HEAVY: successor records of a vertex with more candidate pairs than this: by a whole wave (0: never)
@@ -88,6 +90,8 @@ struct WalkConfig {
         c.leap_left_set = u64("PAG_LEAP_LEFT", &c.leap_left);
         if (u64("PAG_LEAP_END_DIV", &c.leap_end_div)) c.leap_end_div = std::max<uint64_t>(1, c.leap_end_div);
         if (const char *e = std::getenv("PAG_POST_INTERLEAVE")) c.post_interleave = (uint32_t)std::atoi(e);
+        c.post_proportional = !off("PAG_POST_PROPORTIONAL");
+        if (const char *e = std::getenv("PAG_POST_SPREAD")) c.post_spread = std::min(1.0, std::max(0.05, std::atof(e)));
         c.deliver_early = !off("PAG_DELIVER_EARLY");
         if (const char *e = std::getenv("PAG_SUCC_HEAVY")) c.succ_heavy = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
         c.device_tail = !off("PAG_DEVICE_TAIL");
