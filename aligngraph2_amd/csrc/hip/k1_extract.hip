@@ -299,6 +299,20 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
         return;
     }
     const uint32_t n_pos = len - k + 1;
+    // EMIT: how many tuples a kept sample gets is, for alignments whose bases all have ONE list entry (pass 2; pass 1 on a contig
+    // without multi-entry bases), the number of active alignments that cover its position — interval arithmetic on the 16-bit
+    // masks, as the counting launch does it, instead of a first walk over the alignments' columns per tile (round 5).  Up to 15
+    // alignments per strand: four bits per position.
+    bool fast_counts = false;
+    if (EMIT) {
+        uint32_t n_act = 0;
+        bool any_multi = false;
+        for_active([&](const pag_aln &al, uint64_t) {
+            ++n_act;
+            any_multi = any_multi || (A.pass == 0 && A.ctgs[al.target].multi != 0);
+        });
+        fast_counts = !any_multi && n_act <= 15u;
+    }
     const uint64_t tuple_base = EMIT ? A.tuple_off[A.job_base + job] : 0;
     const uint64_t edge_base = EMIT ? A.edge_off[A.job_base + job] : 0;
 
@@ -378,6 +392,19 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
         if (tile_samples == 0) continue;
 
         if (EMIT) {
+            uint64_t cnt4 = 0;  // (fast_counts) tuples of my position j at bits 4j
+            if (fast_counts && kept)
+                for_active([&](const pag_aln &al, uint64_t) {
+                    uint32_t lo = al.q_start > p0 ? al.q_start : p0;
+                    uint32_t hi = al.q_start + al.n_valid;
+                    if (hi > p0 + 16) hi = p0 + 16;
+                    if (lo >= hi) return;
+                    uint32_t m = kept & ((1u << (hi - p0)) - 1u) & ~((1u << (lo - p0)) - 1u);
+                    while (m) {
+                        cnt4 += 1ull << (4u * (uint32_t)(__ffs(m) - 1));
+                        m &= m - 1u;
+                    }
+                });
             __syncthreads();  // previous tile's readers are done with L
             L.kept[lane] = kept;
             L.rank[lane] = rank0;
@@ -406,7 +433,7 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
                 if ((kept >> j) & 1u) {
                     uint32_t s_local = rank0 + i;
                     L.scode[s_local] = code[j];
-                    L.scnt[s_local] = 0;
+                    L.scnt[s_local] = (uint32_t)(cnt4 >> (4 * j)) & 15u;  // (0 without fast_counts: counted by the walk below)
                     L.srun[s_local] = 0;
                     if (pvalid) {
                         uint64_t slot = edge_base + (uint64_t)job_samples + s_local - 1;
@@ -452,7 +479,7 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
             job_tuples += wave_sum(tile_tuples);
         } else {
             // F1: tuples per sample
-            for_active([&](const pag_aln &al, uint64_t ai) {
+            if (!fast_counts) for_active([&](const pag_aln &al, uint64_t ai) {
                 const bool ctg_pass = A.pass == 0;
                 pag_ctg cg{};
                 if (ctg_pass) cg = A.ctgs[al.target];

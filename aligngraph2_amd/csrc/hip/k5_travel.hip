@@ -87,16 +87,30 @@ __global__ void k_zone_bands(const uint64_t *__restrict__ tval, uint64_t T, cons
             }
     }
 }
+// The view's vertices out of the tuple slots, in two sweeps over tiles of VC_TILE slots (round 5; until then a flags kernel, two
+// full-length scans of u32 flags into u64 offsets and a compaction kernel that read all of it back: 46 GB and 15.6 ms at BASELINE
+// configs[1] for 12 GB of work):
+//   k_view_mark   per slot: keep = the slot holds a vertex the view takes — one with a contig coordinate by that coordinate,
+//                 one without by its reference coordinate; every vertex when there are no tables —, first = it is the first
+//                 such slot of its k-mer segment (= a node).  Left behind as the ballots of every wave and round (2 bits per
+//                 slot) and as the two counts of every tile.
+//   (exclusive prefix over the tiles: two scans of T / 2048 counters)
+//   k_view_write  the ballots again, their prefix inside the tile, the vertices / nodes written out.
 // One thread per tuple slot (the slots say whether they hold a leader and how far behind their segment's head they lie: K3's
-// seg_len layout, pag_device.hpp): keep[i] = the slot holds a vertex the view takes — one with a contig coordinate by that
-// coordinate, one without by its reference coordinate; every vertex when there are no tables —, first[i] = it is the first such
-// slot of its k-mer segment (= the node's flag).  The interval tables are searched in LDS (from global memory the ~8
-// dependent loads per search were the whole cost: 34 ms at BASELINE configs[1] with a thread per segment head).
+// seg_len layout, pag_device.hpp).  The interval tables are searched in LDS (from global memory the ~8 dependent loads per
+// search were the whole cost: 34 ms at BASELINE configs[1] with a thread per segment head).  "First of its segment" comes from
+// the tile's own prefix of the keep flags — no kept slot between the segment's head and this one —: a vertex without a contig
+// coordinate sorts first in its segment and is what the view mostly leaves out, so a backward scan over the slots from the
+// head (until round 5) ran its full length for every kept vertex behind one: most of the 7.8 ms of the flags kernel.
 constexpr uint32_t PRUNE_LDS = 4096;  // interval ends (u32) the block keeps in LDS
-__global__ void k_view_flags(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg, uint64_t T,
-                             const uint32_t *__restrict__ civ, uint32_t n_civ, const uint32_t *__restrict__ riv, uint32_t n_riv, int whole,
-                             uint32_t *__restrict__ keep, uint32_t *__restrict__ first) {
+constexpr uint32_t VC_T = 256, VC_R = 8, VC_TILE = VC_T * VC_R, VC_W = VC_T / 64;
+__global__ __launch_bounds__(VC_T) void k_view_mark(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg,
+                                                    uint64_t T, const uint32_t *__restrict__ civ, uint32_t n_civ, const uint32_t *__restrict__ riv,
+                                                    uint32_t n_riv, int whole, uint64_t *__restrict__ ballots, uint32_t *__restrict__ tile_first,
+                                                    uint32_t *__restrict__ tile_keep, uint64_t n_tiles) {
     __shared__ uint32_t s_iv[PRUNE_LDS];
+    __shared__ uint32_t s_ck[VC_R][VC_W], s_pk[VC_R][VC_W], s_cf[VC_R][VC_W];
+    __shared__ uint16_t s_pre[VC_TILE];  // kept slots of the tile before this one
     const bool lds = !whole && 2u * (n_civ + n_riv) <= PRUNE_LDS;
     if (lds) {
         for (uint32_t x = threadIdx.x; x < 2u * n_civ; x += blockDim.x) s_iv[x] = civ[x];
@@ -108,40 +122,122 @@ __global__ void k_view_flags(const uint32_t *__restrict__ tkey, const uint64_t *
         const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
         return whole || (c != 0u ? iv_contains(cv, n_civ, c) : iv_contains(rv, n_riv, r));
     };
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t kx = tkey[i], v = tseg[i];
-        const bool head = i == 0 || tkey[i - 1] != kx;
-        const bool leader = head ? v != 0u : (v & SEG_LEADER) != 0u;
-        bool k = false, f = false;
-        if (leader) {
-            k = inside(tval[i]);
-            if (k) {
-                const uint64_t off = head ? 0u : (v & ~SEG_LEADER);
-                f = true;
-                for (uint64_t j = i - off; j < i && f; ++j) f = !inside(tval[j]);
+    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t tile_base = tile * VC_TILE;
+        uint32_t kb = 0;          // bit r: the slot of round r is kept
+        uint32_t off_r[VC_R];     // ... how far behind its segment's head it lies
+        uint64_t bkr[VC_R];
+#pragma unroll
+        for (uint32_t r = 0; r < VC_R; ++r) {
+            const uint64_t i = tile_base + (uint64_t)r * VC_T + threadIdx.x;
+            bool kk = false;
+            off_r[r] = 0;
+            if (i < T) {
+                const uint32_t kx = tkey[i], v = tseg[i];
+                const bool head = i == 0 || tkey[i - 1] != kx;
+                const bool leader = head ? v != 0u : (v & SEG_LEADER) != 0u;
+                if (leader) {
+                    kk = inside(tval[i]);
+                    off_r[r] = head ? 0u : (v & ~SEG_LEADER);
+                }
+            }
+            bkr[r] = __ballot(kk);
+            kb |= kk ? 1u << r : 0u;
+            if (lane == 0) s_ck[r][w] = (uint32_t)__popcll(bkr[r]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {  // exclusive prefix over (round, wave) = slot order, tile total
+            uint32_t ak = 0;
+            for (uint32_t r = 0; r < VC_R; ++r)
+                for (uint32_t ww = 0; ww < VC_W; ++ww) {
+                    s_pk[r][ww] = ak;
+                    ak += s_ck[r][ww];
+                }
+            tile_keep[tile] = ak;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < VC_R; ++r)
+            s_pre[r * VC_T + threadIdx.x] = (uint16_t)(s_pk[r][w] + (uint32_t)__popcll(bkr[r] & lanemask_lt()));
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < VC_R; ++r) {
+            const uint32_t d = r * VC_T + threadIdx.x;  // slot inside the tile
+            bool ff = false;
+            if ((kb >> r) & 1u) {
+                const uint32_t off = off_r[r];
+                if (off <= d) {
+                    ff = s_pre[d] == s_pre[d - off];  // no kept slot in [head, this one)
+                } else {  // the segment began in an earlier tile: the slots before this tile by their own test (one segment per tile)
+                    ff = s_pre[d] == 0u;
+                    const uint64_t i = tile_base + d;
+                    for (uint64_t j = i - off; j < tile_base && ff; ++j) {
+                        const uint32_t kx = tkey[j], v = tseg[j];
+                        const bool head = j == 0 || tkey[j - 1] != kx;
+                        const bool leader = head ? v != 0u : (v & SEG_LEADER) != 0u;
+                        ff = !(leader && inside(tval[j]));
+                    }
+                }
+            }
+            const uint64_t bf = __ballot(ff);
+            if (lane == 0) {
+                s_cf[r][w] = (uint32_t)__popcll(bf);
+                const uint64_t at = ((tile * VC_R + r) * VC_W + w) * 2u;
+                ballots[at] = bkr[r];
+                ballots[at + 1] = bf;
             }
         }
-        keep[i] = k ? 1u : 0u;
-        first[i] = f ? 1u : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t af = 0;
+            for (uint32_t r = 0; r < VC_R; ++r)
+                for (uint32_t ww = 0; ww < VC_W; ++ww) af += s_cf[r][ww];
+            tile_first[tile] = af;
+        }
     }
 }
-// node_idx / pos_off: exclusive prefix sums of first[] / keep[]
-__global__ void k_compact_view(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint16_t *__restrict__ tcnt, uint64_t T,
-                               const uint32_t *__restrict__ first, const uint32_t *__restrict__ keep, const uint64_t *__restrict__ node_idx,
-                               const uint64_t *__restrict__ pos_off, TravGraph G) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (!keep[i]) continue;
-        const uint32_t f = first[i];
-        const uint64_t n = node_idx[i] + f - 1u, p = pos_off[i];
-        G.vpos[p] = tval[i];
-        G.vcnt[p] = tcnt[i];
-        G.vnode[p] = (uint32_t)n;
-        if (f) {
-            const uint32_t kx = tkey[i];
-            G.ncode[n] = kx;
-            G.npos_off[n] = (uint32_t)p;
-            atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
+__global__ __launch_bounds__(VC_T) void k_view_write(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint16_t *__restrict__ tcnt,
+                                                     const uint64_t *__restrict__ ballots, const uint64_t *__restrict__ base_first,
+                                                     const uint64_t *__restrict__ base_keep, uint64_t n_tiles, TravGraph G) {
+    __shared__ uint64_t s_b[VC_R * VC_W * 2];
+    __shared__ uint32_t s_pk[VC_R][VC_W], s_pf[VC_R][VC_W];
+    const uint32_t w = threadIdx.x >> 6;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (threadIdx.x < VC_R * VC_W * 2) s_b[threadIdx.x] = ballots[tile * (VC_R * VC_W * 2) + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t ak = 0, af = 0;
+            for (uint32_t r = 0; r < VC_R; ++r)
+                for (uint32_t ww = 0; ww < VC_W; ++ww) {
+                    s_pk[r][ww] = ak;
+                    s_pf[r][ww] = af;
+                    ak += (uint32_t)__popcll(s_b[(r * VC_W + ww) * 2]);
+                    af += (uint32_t)__popcll(s_b[(r * VC_W + ww) * 2 + 1]);
+                }
         }
+        __syncthreads();
+        const uint64_t bk0 = base_keep[tile], bf0 = base_first[tile];
+#pragma unroll
+        for (uint32_t r = 0; r < VC_R; ++r) {
+            const uint64_t bk = s_b[(r * VC_W + w) * 2], bf = s_b[(r * VC_W + w) * 2 + 1];
+            const uint64_t me = 1ull << lane_id();
+            if (!(bk & me)) continue;
+            const bool ff = (bf & me) != 0ull;
+            const uint64_t i = tile * VC_TILE + (uint64_t)r * VC_T + threadIdx.x;
+            const uint64_t p = bk0 + s_pk[r][w] + (uint32_t)__popcll(bk & lanemask_lt());
+            const uint64_t n = bf0 + s_pf[r][w] + (uint32_t)__popcll(bf & lanemask_lt()) + (ff ? 1u : 0u) - 1u;
+            G.vpos[p] = tval[i];
+            G.vcnt[p] = tcnt[i];
+            G.vnode[p] = (uint32_t)n;
+            if (ff) {
+                const uint32_t kx = tkey[i];
+                G.ncode[n] = kx;
+                G.npos_off[n] = (uint32_t)p;
+                atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -165,6 +261,7 @@ __device__ __forceinline__ uint32_t node_of_code(const TravGraph &G, uint32_t co
 // An edge of the traversal graph: eto = first position (k-mer-major vertex id) of the target node (PAG_NONE: the target has no
 // node), estep = step (24 bits) | number of the target's positions << 24, EDGE_Q_MANY = "255 or more: count them".
 constexpr uint32_t EDGE_STEP_MASK = 0xFFFFFFu, EDGE_Q_MANY = 255u;
+constexpr uint32_t TRAV_CODE_TABLE_MAX_K = 14;  // (the direct code table of k_compact_edges: 8 B x 4^k)
 struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a[2]; };
 __device__ __forceinline__ void edge_target(const TravGraph &G, uint32_t eto, uint32_t estep, uint32_t *step, uint32_t *p0, uint32_t *q) {
     *step = estep & EDGE_STEP_MASK;
@@ -192,8 +289,19 @@ __global__ void k_edge_counts(const uint32_t *__restrict__ ekey, const uint32_t 
     }
 }
 
+// code -> (first position | number of positions << 32) of the k-mer's node, all ones: no node.  A direct table over the 4^k codes
+// (2 GB at k = 14, scratch of the compaction): an edge's target then costs ONE random sector instead of the three dependent
+// gathers of bitmap word, rank and position range (k_compact_edges: 9.9 -> ms at BASELINE configs[1], round 5); built
+// from the node arrays, which are ascending in the code.  Larger k: no table, the three gathers.
+__global__ void k_code_table(TravGraph G, uint64_t *__restrict__ tab) {
+    for (uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; n < G.n_nodes; n += (uint64_t)gridDim.x * blockDim.x) {
+        const U32x2 r = *(const U32x2 *)(G.npos_off + n);
+        tab[G.ncode[n]] = (uint64_t)r.a[0] | ((uint64_t)(r.a[1] - r.a[0]) << 32);
+    }
+}
+
 __global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_t *__restrict__ eval,
-                                const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G) {
+                                const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G, const uint64_t *__restrict__ tab) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t kx = ekey[j];
         if (j != 0 && ekey[j - 1] == kx) continue;
@@ -202,29 +310,45 @@ __global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_
         uint32_t dst = G.nedge_off[n], len = eseg[j];
         // (the edge carries what the successor kernels need of its target: where the target node's positions begin and how
         // many they are — one random sector less per edge in each of their two passes, see edge_target.  Four edges per
-        // turn, their lookups in flight together: code -> bitmap word + rank -> position range is three dependent gathers)
+        // turn, their lookups in flight together)
         for (uint32_t l0 = 0; l0 < len; l0 += 4u) {
             uint64_t v4[4];
-            uint32_t to4[4];
-            U32x2 r4[4];
+            uint32_t p04[4], q4[4];
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) v4[t] = l0 + t < len ? eval[j + l0 + t] : 0ull;
+            if (tab) {
+                uint64_t e4[4];
 #pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) to4[t] = l0 + t < len ? node_of_code(G, (uint32_t)(v4[t] >> 32)) : PAG_NONE;
+                for (uint32_t t = 0; t < 4u; ++t) e4[t] = l0 + t < len ? tab[(uint32_t)(v4[t] >> 32)] : ~0ull;
 #pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) r4[t] = *(const U32x2 *)(G.npos_off + (to4[t] != PAG_NONE ? to4[t] : 0u));
+                for (uint32_t t = 0; t < 4u; ++t) {
+                    p04[t] = (uint32_t)e4[t];
+                    q4[t] = (uint32_t)(e4[t] >> 32);
+                }
+            } else {  // code -> bitmap word + rank -> position range: three dependent gathers
+                uint32_t to4[4];
+                U32x2 r4[4];
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) to4[t] = l0 + t < len ? node_of_code(G, (uint32_t)(v4[t] >> 32)) : PAG_NONE;
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) r4[t] = *(const U32x2 *)(G.npos_off + (to4[t] != PAG_NONE ? to4[t] : 0u));
+#pragma unroll
+                for (uint32_t t = 0; t < 4u; ++t) {
+                    p04[t] = to4[t] != PAG_NONE ? r4[t].a[0] : PAG_NONE;
+                    q4[t] = r4[t].a[1] - r4[t].a[0];
+                }
+            }
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
                 const uint32_t l = l0 + t;
                 if (l >= len) break;
                 const uint32_t step = (((uint32_t)v4[t]) >> 1) & EDGE_STEP_MASK;
-                if (to4[t] == PAG_NONE) {
+                if (p04[t] == PAG_NONE) {
                     G.eto[dst + l] = PAG_NONE;
                     G.estep[dst + l] = step;
                 } else {
-                    const uint32_t q = r4[t].a[1] - r4[t].a[0];
-                    G.eto[dst + l] = r4[t].a[0];
-                    G.estep[dst + l] = step | ((q < EDGE_Q_MANY ? q : EDGE_Q_MANY) << 24);
+                    G.eto[dst + l] = p04[t];
+                    G.estep[dst + l] = step | ((q4[t] < EDGE_Q_MANY ? q4[t] : EDGE_Q_MANY) << 24);
                 }
             }
         }
@@ -913,8 +1037,8 @@ struct WalkCtx {
     int spec_fail;  // a zombie probe ended in a leap (or could not be continued): the job has to be redone without speculation
     uint64_t max_probe;  // per lane: largest probe size (sum of steps) seen, wave maximum taken at the end of the job
 #ifdef PAG_WALK_PROF
-    uint64_t pt[12];
-    uint32_t pc[12];
+    uint64_t pt[14];
+    uint32_t pc[14];
 #endif
 };
 
@@ -2028,13 +2152,14 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
     X.x_poison = 0u;
     X.w_d0 = X.w_nid = X.w_r0 = X.w_nrec = X.w_anchor = X.w_ab = X.n_fill = 0;
 #ifdef PAG_WALK_PROF
-    for (int q = 0; q < 12; ++q) {
+    for (int q = 0; q < 14; ++q) {
         X.pt[q] = 0;
         X.pc[q] = 0;
     }
 #endif
     X.n_classify = X.n_probe = X.n_records = 0;
 
+    PROF_BEGIN(t_setup0);
     for (uint32_t i = lane; i < FILT_WORDS; i += 64) {
         L.ft[i] = 0;
         L.fg[i] = 0;
@@ -2055,6 +2180,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         }
     }
     __syncthreads();
+    PROF_END(X, 12, t_setup0);
     uint64_t seq_len = 0, now_size = k, seq_size = 0;
     const uint64_t has_size = J.has_size;
     const uint32_t start = G.newid[J.start];
@@ -2537,7 +2663,7 @@ __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const T
         o.poison = X.x_poison;
         o.max_probe = mp_all;
 #ifdef PAG_WALK_PROF
-        for (int q = 0; q < 12; ++q) {
+        for (int q = 0; q < 14; ++q) {
             o.prof_t[q] = X.pt[q];
             o.prof_c[q] = X.pc[q];
         }
@@ -2959,6 +3085,7 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     uint32_t *keep = (uint32_t *)take(m * 4);
     uint64_t *totals = (uint64_t *)take(64);
     void *scan_tmp = take(scan_tmp_bytes(m));
+    uint64_t *code_tab = k <= TRAV_CODE_TABLE_MAX_K ? (uint64_t *)take((size_t)8 << (2 * k)) : nullptr;
     if ((size_t)(p - (char *)tmp) > tmp_bytes) {
         set_error("trav_compact: scratch too small");
         return PAG_EINVAL;
@@ -2966,11 +3093,16 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     PAG_HIP_TRY(hipMemsetAsync(G.bitmap, 0, n_words * 8, s));
     int rc;
     if (T) {
-        k_view_flags<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tseg, T, view ? view->civ : nullptr, view ? view->n_civ : 0u, view ? view->riv : nullptr,
-                                                             view ? view->n_riv : 0u, view ? 0 : 1, keep, flags);
-        if ((rc = scan_u32_to_u64(flags, sc1, T, totals, scan_tmp, s))) return rc;
-        if ((rc = scan_u32_to_u64(keep, sc2, T, totals + 1, scan_tmp, s))) return rc;
-        k_compact_view<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tkey, tval, tcnt, T, flags, keep, sc1, sc2, G);
+        const uint64_t n_tiles = (T + VC_TILE - 1) / VC_TILE;
+        uint32_t *tile_first = flags, *tile_keep = keep;  // (n_tiles counters each)
+        const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, 256u * 8u);
+        const uint32_t *civ = view ? view->civ : nullptr, *riv = view ? view->riv : nullptr;
+        const uint32_t n_civ = view ? view->n_civ : 0u, n_riv = view ? view->n_riv : 0u;
+        uint64_t *ballots = sc2 + n_tiles + 16;  // (2 words per 64 slots, behind the tiles' offsets: m * 8 bytes hold both)
+        k_view_mark<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tseg, T, civ, n_civ, riv, n_riv, view ? 0 : 1, ballots, tile_first, tile_keep, n_tiles);
+        if ((rc = scan_u32_to_u64(tile_first, sc1, n_tiles, totals, scan_tmp, s))) return rc;
+        if ((rc = scan_u32_to_u64(tile_keep, sc2, n_tiles, totals + 1, scan_tmp, s))) return rc;
+        k_view_write<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tcnt, ballots, sc1, sc2, n_tiles, G);
     }
     if (view) {
         uint64_t h[2] = {0, 0};
@@ -2998,7 +3130,13 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     if (E) k_edge_counts<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eseg, E, G, flags);
     if ((rc = scan_u32_to_u64(flags, sc1, n_nodes + 1, view ? totals + 2 : nullptr, scan_tmp, s))) return rc;
     k_narrow<<<dim3(grid_for(n_nodes + 1)), dim3(256), 0, s>>>(sc1, n_nodes + 1, G.nedge_off);
-    if (E) k_compact_edges<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eval, eseg, E, G);
+    if (E && code_tab) {
+        PAG_HIP_TRY(hipMemsetAsync(code_tab, 0xFF, (size_t)8 << (2 * k), s));
+        TravGraph Gn = G;
+        Gn.n_nodes = n_nodes;
+        if (n_nodes) k_code_table<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(Gn, code_tab);
+    }
+    if (E) k_compact_edges<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eval, eseg, E, G, code_tab);
     if (view) {
         uint64_t ne = 0;
         PAG_HIP_TRY(hipMemcpyAsync(&ne, totals + 2, 8, hipMemcpyDeviceToHost, s));
@@ -3021,7 +3159,8 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes) {
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
     uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
-    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024 + 256;
+    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024 + 256 +
+           (k <= TRAV_CODE_TABLE_MAX_K ? ((size_t)8 << (2 * k)) + 256 : 0);
 }
 
 // reference bands of the zones (k_zone_bands): lo / hi [n_z] device arrays, preset here

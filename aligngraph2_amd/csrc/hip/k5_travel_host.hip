@@ -1914,6 +1914,15 @@ struct WalkSession {
                     std::fprintf(stderr, "[walk] t=%.1f ms dev %.3f..%.3f contig %u chain %d job done: +%llu vertices (%zu), %s (classify %llu)\n", now_ms() - tw0,
                                  (double)(o.t_begin % 100000000000ull) * 1e-5, (double)(o.t_end % 100000000000ull) * 1e-5, i, jr.idx, (unsigned long long)G2.len,
                                  RS[i].chains[(size_t)jr.idx].len, o.stopped ? "stopped" : "ended", (unsigned long long)o.n_classify);
+#ifdef PAG_WALK_PROF
+                    // (make WALK_PROF=1: 100 MHz ticks and counts per section of the job — 0 append, 1 classification, 2 wait for a
+                    // free slot, 3 slot setup, 4 slot steps, 5 choice, 6 window refills, 7 whole-wave probes, 8-11 inside a slot step:
+                    // window, evaluation, class minimum + shuffles, state update, 12 job setup: filters + the contig's global set)
+                    std::fprintf(stderr, "[walk]    prof mode %u main %llu fills %llu probes %llu:", hjobs[slot].J.mode, (unsigned long long)o.n_main,
+                                 (unsigned long long)(o.n_fill & 0xFFFFFFFFull), (unsigned long long)o.n_probe);
+                    for (int q = 0; q < 14; ++q) std::fprintf(stderr, " [%d] %.2f ms / %u", q, (double)o.prof_t[q] * 1e-5, o.prof_c[q]);
+                    std::fprintf(stderr, "\n");
+#endif
                 }
             }
         std::sort(touched.begin(), touched.end());

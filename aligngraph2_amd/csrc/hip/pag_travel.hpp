@@ -127,8 +127,8 @@ struct TravJobOut {
     uint32_t poison;        // 1: the walk examined the records of a vertex whose successors this rank does not hold (TravGraph::incomplete)
     uint64_t t_begin, t_end;  // 100 MHz device clock when the wave took the job / finished it (PAG_WALK_DEBUG timeline)
 #ifdef PAG_WALK_PROF
-    uint64_t prof_t[12];  // cycles per section of the walk (development aid, make WALK_PROF=1)
-    uint32_t prof_c[12];
+    uint64_t prof_t[14];  // cycles per section of the walk (development aid, make WALK_PROF=1)
+    uint32_t prof_c[14];
 #endif
 };
 
