@@ -332,8 +332,17 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
     int hist_per_cu = 8;
     if (const char *e = getenv("PAG_SORT_HIST_PER_CU")) hist_per_cu = atoi(e) > 0 ? atoi(e) : 8;
     const int hist_blocks = scatter_blocks_cus(dev) * hist_per_cu;
-    hipEvent_t ev[2 * 8];
-    for (int i = 0; i < 2 * passes; ++i) PAG_HIP_TRY(hipEventCreate(&ev[i]));
+    // timing (the k-mer sort of pag_process asks for it): events out of a pool created once per device, and the one
+    // synchronisation their reading takes.  A caller that does not ask gets neither — until round 5 every call created and
+    // destroyed 2 x passes events and synchronised the stream.
+    const bool timed = ms_dominant_kernel != nullptr;
+    static thread_local hipEvent_t ev_pool[64][2 * 8];  // (per host thread: two handles of one device may sort at the same time)
+    static thread_local bool ev_ready[64] = {false};
+    hipEvent_t *ev = ev_pool[dev & 63];
+    if (timed && !ev_ready[dev & 63]) {
+        for (int i = 0; i < 2 * 8; ++i) PAG_HIP_TRY(hipEventCreate(&ev[i]));
+        ev_ready[dev & 63] = true;
+    }
     uint32_t *ka = k0, *kb = k1;
     uint64_t *va = v0, *vb = v1;
     int in0 = 1;
@@ -346,7 +355,7 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
         sort_hist<<<dim3(hist_grid), dim3(HT), 0, s>>>(ka, n, shift, rmask, hist, n_tiles, ((uintptr_t)ka & 15u) == 0 ? 1 : 0);
         int rc = scan_u32_to_u64(hist, hist_scan, used, nullptr, scan_tmp, s);
         if (rc != PAG_OK) return rc;
-        PAG_HIP_TRY(hipEventRecord(ev[2 * pass], s));
+        if (timed) PAG_HIP_TRY(hipEventRecord(ev[2 * pass], s));
         switch (b) {
 #define PAG_SCATTER(B)                                                                                              \
     case B:                                                                                                         \
@@ -355,7 +364,7 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
             PAG_SCATTER(1) PAG_SCATTER(2) PAG_SCATTER(3) PAG_SCATTER(4) PAG_SCATTER(5) PAG_SCATTER(6) PAG_SCATTER(7) PAG_SCATTER(8)
 #undef PAG_SCATTER
         }
-        PAG_HIP_TRY(hipEventRecord(ev[2 * pass + 1], s));
+        if (timed) PAG_HIP_TRY(hipEventRecord(ev[2 * pass + 1], s));
         uint32_t *tk = ka;
         ka = kb;
         kb = tk;
@@ -365,15 +374,16 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
         in0 = !in0;
     }
     PAG_HIP_TRY(hipGetLastError());
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-    float tot = 0.f;
-    for (int pass = 0; pass < passes; ++pass) {
-        float ms = 0.f;
-        PAG_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * pass], ev[2 * pass + 1]));
-        tot += ms;
+    if (timed) {
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+        float tot = 0.f;
+        for (int pass = 0; pass < passes; ++pass) {
+            float ms = 0.f;
+            PAG_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * pass], ev[2 * pass + 1]));
+            tot += ms;
+        }
+        *ms_dominant_kernel = tot / passes;
     }
-    for (int i = 0; i < 2 * passes; ++i) hipEventDestroy(ev[i]);
-    if (ms_dominant_kernel) *ms_dominant_kernel = tot / passes;
     if (n_passes) *n_passes = passes;
     *result_in_0 = in0;
     return PAG_OK;

@@ -93,18 +93,80 @@ def host_seqs(codes_list):
     return s, (packed, off_a, len_a)
 
 
+def cgroup_cpu_quota():
+    """CPUs the container may use (cgroup v2 cpu.max), or None when unlimited"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def parse_phases(stderr_text):
+    """phase seconds out of the [timing] lines `bin/pagraph` prints under PAGRAPH_TIMING=1"""
+    phases = {}
+    for ln in stderr_text.splitlines():
+        for key, tag in (("load_global_inputs_s", "load global inputs + create"), ("load_block_inputs_s", "load block inputs"),
+                         ("prepare_s", "prepare (lists, filters, contig->reference map)"), ("traversal_s", "] traversal "),
+                         ("write_s", "traverse + write"), ("build_s", "graph build (process)"), ("successor_records_s", "] successor records "),
+                         ("walks_s", "] walks "), ("host_half_s", "block's host half ")):
+            if tag in ln and ln.rstrip().endswith(" s"):
+                try:
+                    phases[key] = float(ln.split(tag)[1].split()[0])
+                except (ValueError, IndexError):
+                    pass
+    return phases
+
+
+def live_sort_traffic(args):
+    """HBM bytes per launch of the graded kernels, collected IN THIS RUN when rocprofv3 is on the box: two PMC passes (FETCH_SIZE,
+    WRITE_SIZE; separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled for gfx950) over a
+    build-only child run of this script on the same workload.  Returns (bytes per sort_scatter launch, bytes per sort_hist
+    launch, note) or None.  The launches of the k-mer sort are those within a factor of two of the largest of their kernel."""
+    import collections
+    import csv
+    import glob
+    if not shutil.which("rocprofv3"):
+        return None
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="pagpmc_", dir="/tmp")
+        try:
+            argv = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "c", "--", sys.executable, os.path.abspath(__file__),
+                    "--build-only", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-file-to-file", "--no-live-traffic", "--reads", str(args.reads),
+                    "--read-span", str(args.read_span), "--ref-len", str(args.ref_len), "--k", str(args.k), "--epsilon", str(args.epsilon)]
+            r = subprocess.run(argv, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            acc = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(tmp, "**", "c_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and "pagdev::sort_" in row["Kernel_Name"]:
+                        acc["scatter" if "sort_scatter" in row["Kernel_Name"] else "hist"].append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not acc.get("scatter"):
+                return None
+            for kind, vals in acc.items():
+                big = [v for v in vals if v >= 0.5 * max(vals)]
+                got[(counter, kind)] = (sum(big) / len(big), len(big))
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    def hbm(kind):
+        f, w = got.get(("FETCH_SIZE", kind)), got.get(("WRITE_SIZE", kind))
+        return (2.0 * f[0] + w[0]) * 1024.0 if f and w else None
+    note = (f"live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only, FETCH_SIZE x 2 for gfx950) over a build-only child "
+            f"run of this workload in this bench run; averages over {got[('FETCH_SIZE', 'scatter')][1]} scatter / {got.get(('FETCH_SIZE', 'hist'), (0, 0))[1]} histogram "
+            "launches of the k-mer sort")
+    return hbm("scatter"), hbm("hist"), note
+
+
 def cpu_baseline(k, eps, cov, threads_flag):
     """Time the CPU reference on a bounded sample of the same kind of workload (rank 0, N = 1 only)."""
     import aligngraph2_amd
     from aligngraph2_amd import workload as biggen
     ncores = os.cpu_count() or 1
-    quota = None  # CPUs the container may use (cgroup v2 cpu.max), if limited: the reference's threads share them
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = float(q) / float(per)
-    except (OSError, ValueError):
-        pass
+    quota = cgroup_cpu_quota()  # (the reference's threads share what the container may use)
     sp = biggen.BigSpec(seed=99, ref_len=2_000_000, n_reads=2000, read_span=10_000, k=k, ctg_len=500_000, eps=eps, cov=cov,
                         threads=threads_flag, solid_min_abundance=2, chunk_reads=1000)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
@@ -192,6 +254,7 @@ def main():
                          "config.file_to_file_* (never part of `value`).  On by default for a single-GPU run of the default workload when "
                          "/dev/shm has room for the 7 GB of text")
     ap.add_argument("--no-file-to-file", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the kept profile instead of two rocprofv3 PMC passes in this run")
     args = ap.parse_args()
     if not args.file_to_file and not args.no_file_to_file and not args.build_only and int(os.environ.get("WORLD_SIZE", "1")) == 1 and \
             (args.reads, args.read_span, args.ref_len) == (100_000, 10_000, 50_000_000):
@@ -525,8 +588,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k-mer sort (pagdev::sort_hist + scan + pagdev::sort_scatter, all radix passes of both streams)",
                          "achieved": ws_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws_gbs / HBM_PEAK_GBS,
                          "traffic": whole_traffic,
-                         "traffic_source": "static: rocprofv3 PMC passes kept under profiles/sort_scatter_traffic.json (bytes per scatter launch + bytes per "
-                                           "histogram launch" + ("" if hist_traffic else " [histogram bytes missing from the profile]") + ", x launches; not collected in this run)",
+                         "traffic_source": "static: rocprofv3 PMC passes kept under profiles/sort_scatter_traffic.json (measured in round 4 at commit 1af8d58; bytes per "
+                                           "scatter launch + bytes per histogram launch" + ("" if hist_traffic else " [histogram bytes missing from the profile]")
+                                           + ", x launches; not collected in this run)",
                          "ms_sort": st.ms_sort, "records": int(n_rec), "algorithmic_bytes": SORT_BYTES_PER_RECORD * n_rec,
                          "per_pass": {"kernel": "pagdev::sort_scatter (one radix pass of one stream)", "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                                       "records_per_launch": int(st.sort_records), "ms_per_launch": ms_sort, "traffic": traffic}},
@@ -542,17 +606,20 @@ def main():
             # tests/c2_text_runs.py, the record is kept under profiles/ (a cached measurement, quoted with its provenance)
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", "r04_c2_text_parity.json")))
-                nat = json.load(open(os.path.join(ROOT, "profiles", "r02_c2_text_runs.json")))
+                nat_name = next(n for n in ("r05_c2_text_runs.json", "r02_c2_text_runs.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+                nat = json.load(open(os.path.join(ROOT, "profiles", nat_name)))
                 default_wl = (args.reads, args.read_span, args.ref_len, args.k, args.epsilon) == (100_000, 10_000, 50_000_000, 14, 10)
                 if default_wl and nat.get("reference", {}).get("returncode") == 0:
                     # the reference as a user runs it (-t 64, its own threads): the honest whole-workload CPU figure.  The
                     # thread-serialising shim run (-t 16) is the PARITY provenance — the run whose 53 output files the drop-in
                     # reproduces byte for byte — and is slower by construction.
                     line["cpu_baseline"]["full_workload"] = {
-                        "value": nat["reference"]["bases_per_s"], "unit": "aligned-read-bases/s", "cores": nat["reference"].get("threads_flag", 64),
-                        "kind": "reference", "wall_s": nat["reference"]["wall_s"],
+                        "value": nat["reference"]["bases_per_s"], "unit": "aligned-read-bases/s",
+                        # (what the 64 threads could run on: the GPU box's container has a 16-CPU quota, then as now)
+                        "cores": int(min(nat["reference"].get("threads_flag", 64), nat.get("cgroup_cpu_quota") or cgroup_cpu_quota() or 64)),
+                        "kind": "reference", "wall_s": nat["reference"]["wall_s"], "measured": nat.get("measured", "round 2"),
                         "sample": nat.get("workload", "BASELINE configs[1] as text files") + "; compiled reference pagraph -t 64, its own threads, GPU box host "
-                                  "(16-CPU cgroup quota); cached: profiles/r02_c2_text_runs.json (tests/c2_text_runs.py)",
+                                  f"(16-CPU cgroup quota); NOT measured in this run: cached record profiles/{nat_name} (tests/c2_text_runs.py)",
                         "parity_provenance": {"wall_s": rec.get("reference", {}).get("wall_s"), "what": "the same files through the reference at -t 16 under the "
                                               "thread-serialising shim: the run whose output files the drop-in reproduces byte for byte "
                                               "(profiles/r04_c2_text_parity.json)"}}
@@ -562,19 +629,9 @@ def main():
                                                            "profiles/r04_c2_text_parity.json (python bench.py --file-to-file measures it live)")
                     # what the product's own ingest costs in that run (host code: parsers, then GraphInput = eligibility /
                     # flips / n_valid / contig->reference entries, the inputs this bench takes from its generator)
-                    phases = {}
-                    for ln in rec["ours"].get("stderr_tail", "").splitlines():
-                        for key, tag in (("load_global_inputs_s", "load global inputs + create"), ("load_block_inputs_s", "load block inputs"),
-                                         ("prepare_s", "prepare (lists, filters, contig->reference map)"), ("traversal_s", "] traversal "),
-                                         ("write_s", "traverse + write"), ("build_s", "graph build (process)"), ("successor_records_s", "] successor records "),
-                                         ("walks_s", "] walks "), ("host_half_s", "block's host half ")):
-                            if tag in ln and ln.rstrip().endswith(" s"):
-                                try:
-                                    phases[key] = float(ln.split(tag)[1].split()[0])
-                                except (ValueError, IndexError):
-                                    pass
-                    if phases:
-                        line["config"]["file_to_file_phases"] = phases
+                    phases = parse_phases(rec["ours"].get("stderr_tail", ""))
+                    if phases:  # (of the CACHED run; a live file-to-file leg below replaces them with its own)
+                        line["config"]["file_to_file_phases"] = dict(phases, source="cached run: profiles/r04_c2_text_parity.json")
             except Exception:
                 pass
     if rank == 0 and args.file_to_file and world == 1:
@@ -601,7 +658,12 @@ def main():
             r = subprocess.run(aligngraph2_amd.pagraph_argv(exe, tdir, odir, threads=spec.threads, epsilon=spec.eps, cov=spec.cov), capture_output=True, text=True,
                                env=dict(os.environ, PAGRAPH_DEVICE=str(local), PAGRAPH_TIMING="1"))
             dtf = time.time() - tf
-            if r.returncode == 0:  # (the live figure replaces the cached one)
+            if r.returncode == 0:  # (the live figures replace the cached ones)
+                live_phases = parse_phases(r.stderr)
+                if live_phases:
+                    line["config"]["file_to_file_phases"] = dict(live_phases, source="this run (file_to_file_live)")
+                else:
+                    line["config"].pop("file_to_file_phases", None)
                 line["config"]["file_to_file_bases_per_s"] = n_bases_w / dtf
                 line["config"]["file_to_file_note"] = "bin/pagraph on the same workload as text files, wall clock incl. parsing and upload: measured live in this run (file_to_file_live)"
             line["config"]["file_to_file_live"] = {"returncode": r.returncode, "wall_s": dtf, "bases_per_s": n_bases_w / dtf,
@@ -614,6 +676,24 @@ def main():
                                                    "stderr_tail": r.stderr[-300:] if r.returncode else ""}
         finally:
             shutil.rmtree(tdir, ignore_errors=True)
+    if rank == 0 and world == 1 and not args.no_live_traffic and not args.build_only:
+        # roofline.traffic collected in this run (the bench's own device memory is handed back first: the child builds the same block)
+        try:
+            if g is not None:
+                host.pagh_release(g)
+                hip.pag_destroy(g)
+                g = None
+            w = raw = inp = None
+            torch.cuda.empty_cache()
+            lt = live_sort_traffic(args)
+        except Exception:
+            lt = None
+        if lt and lt[0]:
+            launches = 2 * ((2 * args.k + 7) // 8)
+            rf = line["roofline"]
+            rf["per_pass"]["traffic"] = lt[0]
+            rf["traffic"] = (lt[0] + (lt[1] or 0.0)) * launches
+            rf["traffic_source"] = lt[2]
     if rank == 0:
         print(json.dumps(line), flush=True)
     shutil.rmtree(out_dir, ignore_errors=True)
