@@ -62,10 +62,10 @@ aligngraph2_amd/bin/pre_process: $(HOST_DIR)/pre_process_main.cpp $(HOST_DIR)/li
 	@mkdir -p aligngraph2_amd/bin
 	$(CXX) $(CXXFLAGS) -o $@ $< -pthread
 
-# host-only tool: the reference's consensus step is host code too (tools/cns: a partial-order graph per 5 kb part)
-aligngraph2_amd/bin/pa_cns: $(HOST_DIR)/pa_cns_main.cpp $(B)/host/seq_db.o $(wildcard $(HOST_DIR)/*.hpp)
+# the consensus step after pagraph: parsing / slicing on the host, the per-part graphs on the device (csrc/hip/k_cns.hip)
+aligngraph2_amd/bin/pa_cns: $(HOST_DIR)/pa_cns_main.cpp $(B)/host/seq_db.o $(wildcard $(HOST_DIR)/*.hpp) $(HIP_DIR)/cns_graph.hpp aligngraph2_amd/libpagraph_hip.so
 	@mkdir -p aligngraph2_amd/bin
-	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/host/seq_db.o -pthread
+	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/host/seq_db.o -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/..' -pthread
 
 aligngraph2_amd/bin/paf2aln: $(HOST_DIR)/paf2aln_main.cpp
 	@mkdir -p aligngraph2_amd/bin

@@ -3,7 +3,13 @@
 // -a (3-line ALN) are sliced per part (tools/cns/AlignData.cpp:36-75), gap-normalised (tools/cns/Alignment.cpp:134-215),
 // ordered by score, weighted (AlignData.cpp:77-104), threaded through a partial-order alignment graph per part
 // (tools/cns/AlnGraphBoost.cpp: addAln / mergeNodes / bestPath / consensus) and the parts' consensus strings are written as
-// one FASTA record, 70 columns.  Host code, like the reference's (the parts are independent: a pool of host threads).
+// one FASTA record, 70 columns.
+//
+// Where the graphs are built (PA_CNS_BACKEND): `hip` (default) — on the device, one thread per part (pag_cns_consensus,
+// csrc/hip/k_cns.hip; the program fails without a gfx950 device, there is no silent fallback); `flat` — the device's code
+// (csrc/hip/cns_graph.hpp: flat arrays, linked edge lists) compiled for the host, a verification aid; `host` — the restatement
+// on std::vector / std::map below (AlnGraph), host code like the reference's, what the CPU tests pin on the goldens.  Reading,
+// slicing, gap normalisation, the per-part sort and the weights are host code in every case.
 //
 // What has to be reproduced beyond the arithmetic, because it decides ties:
 //   * the graph is boost::adjacency_list<vecS, vecS, bidirectionalS>: out- and in-edge lists are vectors in insertion order,
@@ -30,7 +36,9 @@
 #include <thread>
 #include <vector>
 
+#include "../hip/cns_graph.hpp"
 #include "host_threads.hpp"
+#include "pagraph_hip.h"
 #include "seq_db.hpp"
 
 namespace {
@@ -617,6 +625,10 @@ int main(int argc, char **argv) {
         std::atomic<std::size_t> consensusLen(0), next(0);
         std::atomic<bool> failed(false);
         std::string failure;
+        std::string backend = std::getenv("PA_CNS_BACKEND") ? std::getenv("PA_CNS_BACKEND") : "hip";
+        if (backend != "hip" && backend != "flat" && backend != "host") throw std::runtime_error("PA_CNS_BACKEND must be hip, flat or host");
+        const bool onHost = backend == "host";
+        std::vector<std::vector<std::size_t>> partWeights(partNum);
         auto work = [&]() {
             for (std::size_t i; (i = next.fetch_add(1)) < partNum;) {
                 try {
@@ -635,7 +647,9 @@ int main(int argc, char **argv) {
                         alns.swap(sorted);
                     }
                     const std::size_t left = i * partLen, right = std::min((i + 1) * partLen, backbone.size());
-                    const auto weights = weightAln(alns, opt.alpha);
+                    partWeights[i] = weightAln(alns, opt.alpha);
+                    if (!onHost) continue;  // (the graphs of all parts are built together below)
+                    const auto &weights = partWeights[i];
                     AlnGraph g(backbone.substr(left, right - left));
                     for (std::size_t x = 0; x < weights.size(); ++x) g.addAln(alns[x].aln, static_cast<int>(weights[x]));
                     g.mergeNodes();
@@ -648,11 +662,110 @@ int main(int argc, char **argv) {
             }
         };
         const unsigned nThreads = std::max(1u, std::min<unsigned>(std::max(1u, pagh::usableCpus()), static_cast<unsigned>(std::max<std::size_t>(1, partNum))));
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(work);
+            work();
+            for (auto &t : pool) t.join();
+        }
         if (failed) throw std::runtime_error(failure);
+        if (!onHost) {
+            // the parts as flat arrays: every alignment's two rows in two pools, the regions of every part's graph sized from its
+            // columns (include/pagraph_hip.h, pag_cns_consensus)
+            std::vector<pag_cns_part> parts(partNum);
+            std::vector<pag_cns_aln> flat;
+            std::string qpool, tpool;
+            std::uint64_t outBytes = 0;
+            for (std::size_t i = 0; i < partNum; ++i) {
+                const std::size_t left = i * partLen, right = std::min((i + 1) * partLen, backbone.size());
+                pag_cns_part &P = parts[i];
+                P.bb_off = left;
+                P.bb_len = static_cast<std::uint32_t>(right - left);
+                P.aln_first = flat.size();
+                std::uint64_t nIns = 0, nEdgeCols = 0;
+                const auto &alns = alignments[i];
+                for (std::size_t x = 0; x < partWeights[i].size(); ++x) {
+                    const Aln &a = alns[x].aln;
+                    pag_cns_aln f{};
+                    f.str_off = qpool.size();
+                    f.len = static_cast<std::uint32_t>(a.qstr.size());
+                    f.start = a.start;
+                    f.weight = static_cast<std::int32_t>(partWeights[i][x]);
+                    flat.push_back(f);
+                    qpool += a.qstr;
+                    tpool += a.tstr;
+                    for (std::size_t c = 0; c < a.qstr.size(); ++c) {
+                        const char qb = a.qstr[c], tb = a.tstr[c];
+                        if (qb != '-' && tb == '-') ++nIns;
+                        if (qb != '-') ++nEdgeCols;
+                    }
+                }
+                P.n_aln = static_cast<std::uint32_t>(flat.size() - P.aln_first);
+                const std::uint64_t nodeCap = P.bb_len + 2ull + nIns, edgeCap = P.bb_len + 1ull + nEdgeCols + P.n_aln + 4096ull;
+                if (nodeCap > 0x7FFFFFFFull || edgeCap > 0x7FFFFFFFull) throw std::runtime_error("pa_cns: a part with more than 2^31 graph slots");
+                P.node_cap = static_cast<std::uint32_t>(nodeCap);
+                P.edge_cap = static_cast<std::uint32_t>(edgeCap);
+                P.aux_cap = static_cast<std::uint32_t>(std::min<std::uint64_t>(4 * nodeCap + 2048, 0x7FFFFFFFull));
+                P.out_cap = P.node_cap;
+                outBytes += P.out_cap;
+            }
+            std::vector<char> outBuf(outBytes + 16);
+            std::vector<std::uint64_t> outOff(partNum + 1, 0);
+            std::vector<std::uint32_t> outLen(partNum, 0);
+            std::vector<std::int32_t> partErr(partNum, 0);
+            if (backend == "hip") {
+                const int device = std::getenv("PAGRAPH_DEVICE") ? std::atoi(std::getenv("PAGRAPH_DEVICE")) : 0;
+                const int rc = pag_cns_consensus(device, backbone.data(), backbone.size(), parts.data(), partNum, flat.data(), flat.size(), qpool.data(), tpool.data(),
+                                                 qpool.size(), 0, outBuf.data(), outBytes, outOff.data(), outLen.data(), partErr.data());
+                if (rc != 0) throw std::runtime_error(std::string("pag_cns_consensus failed (") + std::to_string(rc) + "): " + pag_last_error());
+            } else {  // the device's code on host threads
+                std::uint64_t oo = 0;
+                for (std::size_t i = 0; i < partNum; ++i) {
+                    outOff[i] = oo;
+                    oo += parts[i].out_cap;
+                }
+                outOff[partNum] = oo;
+                std::atomic<std::size_t> nextPart(0);
+                auto flatWork = [&]() {
+                    for (std::size_t i; (i = nextPart.fetch_add(1)) < partNum;) {
+                        const pag_cns_part &S = parts[i];
+                        std::vector<std::uint8_t> nb(S.node_cap), nf(S.node_cap), ev(S.edge_cap);
+                        std::vector<std::int32_t> ncov(S.node_cap), nw(S.node_cap), nbest(S.node_cap), ec(S.edge_cap);
+                        std::vector<std::uint32_t> nu[7], eu[6], aux(S.aux_cap);
+                        for (auto &v : nu) v.resize(S.node_cap);
+                        for (auto &v : eu) v.resize(S.edge_cap);
+                        std::vector<float> nscore(S.node_cap);
+                        pagcns::Arrays A{nb.data(), nf.data(), ncov.data(), nw.data(), nu[0].data(), nu[1].data(), nu[2].data(), nu[3].data(), nu[4].data(), nu[5].data(),
+                                         nu[6].data(), nscore.data(), nbest.data(), eu[0].data(), eu[1].data(), eu[2].data(), eu[3].data(), eu[4].data(), eu[5].data(),
+                                         ec.data(), ev.data(), aux.data()};
+                        pagcns::Part P{};
+                        P.bb_off = S.bb_off;
+                        P.bb_len = S.bb_len;
+                        P.n_aln = S.n_aln;
+                        P.aln_first = S.aln_first;
+                        P.out_off = outOff[i];
+                        P.node_cap = S.node_cap;
+                        P.edge_cap = S.edge_cap;
+                        P.aux_cap = S.aux_cap;
+                        P.out_cap = S.out_cap;
+                        static_assert(sizeof(pag_cns_aln) == sizeof(pagcns::Aln), "pag_cns_aln is pagcns::Aln");
+                        std::uint32_t len = 0;
+                        partErr[i] = pagcns::run_part(A, P, backbone.data(), reinterpret_cast<const pagcns::Aln *>(flat.data()), qpool.data(), tpool.data(), 0, outBuf.data(), &len);
+                        outLen[i] = partErr[i] ? 0 : len;
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < nThreads; ++t) pool.emplace_back(flatWork);
+                flatWork();
+                for (auto &t : pool) t.join();
+            }
+            for (std::size_t i = 0; i < partNum; ++i) {
+                if (partErr[i] == pagcns::CNS_E_OVERRUN) throw std::runtime_error("pa_cns: an alignment runs past the end of its part");
+                if (partErr[i]) throw std::runtime_error("pa_cns: part " + std::to_string(i) + " ran out of its graph regions (code " + std::to_string(partErr[i]) + ")");
+                consensusResults[i].assign(outBuf.data() + outOff[i], outLen[i]);
+                consensusLen += outLen[i];
+            }
+        }
         std::cout << consensusLen << std::endl;
         std::cout << backbone.size() << std::endl;
         std::ofstream of(opt.out);

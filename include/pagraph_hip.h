@@ -427,6 +427,36 @@ int pag_classify_columns_host(const char *text, uint64_t text_bytes, const uint6
                               const uint32_t *r_len, const uint64_t *diff_off, uint64_t n_recs, uint32_t *diff_host, uint64_t n_diff_words,
                               uint32_t *n_emit_host, uint32_t *n_radv_host, int device);
 
+/* ---- pa_cns on the device -----------------------------------------------------------------------------
+ * The consensus step after pagraph (reference PAGraph/src/main/pa_cns.cpp:98-124 + tools/cns/AlnGraphBoost.cpp): the backbone
+ * is cut into parts, every part gets a partial-order alignment graph — AlnGraphBoost(backbone) :16-39, addAln :64-113 for its
+ * alignments in the caller's order (score order, AlignData::weightAln weights), mergeNodes :137-275, bestPath :383-467,
+ * consensus :293-333 — and yields its consensus string.  One device thread per part; a part's graph lives in regions the
+ * caller sizes (slots, not bytes): node_cap >= bb_len + 2 + insertion columns, edge_cap >= bb_len + 1 + columns that are not
+ * query deletions + n_aln (+ slack: a merge creates the surviving node's edges before it clears the merged one), aux_cap =
+ * queue + stack words, out_cap >= node_cap.  The alignments are gap-normalised rows (dagcon normalizeGaps,
+ * cns/Alignment.cpp:134-215) in two pools at the same offsets.  Results: out[out_off[p] .. + out_len[p]) = part p's
+ * consensus (out_off[n_parts] = bytes used), part_err[p] != 0: the part ran out of one of its regions (1 nodes, 2 edges,
+ * 3 queue, 4 stack, 6 output), met an alignment that runs past its part (5) or an empty edge list where the reference reads
+ * .front() (7) — nothing is written for it.  Returns PAG_ENODEV without a device: there is no host fallback behind this call. */
+typedef struct pag_cns_aln {
+    uint64_t str_off; /* offset of its rows in qpool / tpool */
+    uint32_t len;     /* columns */
+    uint32_t start;   /* 1-based backbone position of its first column inside the part */
+    int32_t weight;
+    uint32_t reserved;
+} pag_cns_aln;
+typedef struct pag_cns_part {
+    uint64_t bb_off;    /* the part's slice of `backbone` */
+    uint32_t bb_len;
+    uint32_t n_aln;
+    uint64_t aln_first; /* its alignments: alns[aln_first .. + n_aln) */
+    uint32_t node_cap, edge_cap, aux_cap, out_cap;
+} pag_cns_part;
+int pag_cns_consensus(int device, const char *backbone, uint64_t backbone_len, const pag_cns_part *parts, uint64_t n_parts, const pag_cns_aln *alns,
+                      uint64_t n_alns, const char *qpool, const char *tpool, uint64_t pool_bytes, int32_t min_weight, char *out, uint64_t out_bytes,
+                      uint64_t *out_off, uint32_t *out_len, int32_t *part_err);
+
 typedef struct pag_kmer_count_result {
     uint64_t min_abundance;
     uint64_t n_solid;
