@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--cross-check", type=int, default=1, help="this many one-handle blocks also run as --ranks ranks (same files)")
     ap.add_argument("--blocks", default="", help="only these block numbers (comma separated)")
     ap.add_argument("--seed", type=int, default=40)
+    ap.add_argument("--resume", action="store_true", help="keep the blocks OUT.json already holds, run the others")
     args = ap.parse_args()
 
     import numpy as np
@@ -66,6 +67,11 @@ def main():
            "blocks": []}
     free, total = torch.cuda.mem_get_info(dev)
     rec["device_total_bytes"] = int(total)
+    if args.resume and os.path.exists(args.out):
+        old = json.load(open(args.out))
+        rec["blocks"] = [blk for blk in old.get("blocks", []) if "outputs_sha256" in blk]
+        only = [b for b in only if b not in {blk["block"] for blk in rec["blocks"]}]
+        print("resuming: kept blocks", sorted(blk["block"] for blk in rec["blocks"]), "to run", only, flush=True)
 
     def save():
         with open(args.out, "w") as f:
@@ -107,13 +113,20 @@ def main():
             st = pagctl.BuildStats()
             t1 = time.perf_counter()
             if hip.pag_process(C.c_void_p(g), C.byref(inp), C.byref(st)) != 0:
-                raise SystemExit("pag_process: " + hip.pag_last_error().decode())
+                msg = hip.pag_last_error().decode()
+                hip.pag_destroy(C.c_void_p(g))
+                raise MemoryError("pag_process: " + msg)
             ts = bench.TraverseStats()
             o_arr = np.array(orient, dtype=np.int32)
             rc = host.pagh_traverse(g, spec.k, C.byref(ctg_seqs), None, C.byref(ref_seqs), None, o_arr.ctypes.data, spec.threads, spec.eps, 50, out.encode(), b"0_", 0,
                                     C.byref(ts))
             if rc != 0:
-                raise SystemExit("pagh_traverse: " + host.pagh_last_error().decode())
+                msg = host.pagh_last_error().decode()
+                host.pagh_release(C.c_void_p(g))
+                hip.pag_destroy(C.c_void_p(g))
+                shutil.rmtree(out, ignore_errors=True)
+                torch.cuda.empty_cache()
+                raise MemoryError("pagh_traverse: " + msg)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             peak = int(total - torch.cuda.mem_get_info(dev)[0])
@@ -139,8 +152,14 @@ def main():
                     "per_rank_traversal_peak_bytes": [r["bytes_traversal_peak"] for r in res["ranks"]],
                     "per_rank_owner_build_bytes": [r.get("bytes_owner_build", 0) for r in res["ranks"]], "host_bytes_growth": res["host_bytes_growth"]}
 
-        if w.n_bases <= args.one_gpu_bases:
-            info.update(one_handle())
+        fits = w.n_bases <= args.one_gpu_bases
+        if fits:
+            try:
+                info.update(one_handle())
+            except MemoryError as e:  # (the block does not fit one handle after all: it runs as ranks, the attempt is on record)
+                info["one_handle_attempt"] = str(e)[:300]
+                fits = False
+        if fits:
             if crossed < args.cross_check:
                 x = as_ranks(args.ranks)
                 info["cross_check"] = {"mode": x["mode"], "s_block": x["s_block"], "outputs_sha256": x["outputs_sha256"], "max_held_fraction": x["max_held_fraction"],
@@ -156,6 +175,7 @@ def main():
         del w, inp, ref_np, ctg_seqs, ref_seqs, keep1, keep2
         torch.cuda.empty_cache()
 
+    rec["blocks"].sort(key=lambda blk: blk["block"])
     # level 1 of SURVEY §8e: the blocks dealt over 8 ranks, longest first (parallel.assign_blocks — the deal run_config_blocks makes)
     done = rec["blocks"]
     deal = parallel.assign_blocks([blk["read_bases"] for blk in done], 8)
