@@ -94,7 +94,11 @@ struct ScatterStage {       // one tile staged in digit order, waiting to be wri
                             // goff[d] + staged position (its first half holds the tile's digit totals until the
                             // digit prefix is done)
     uint32_t skey[STILE];
+#ifdef SORT_TWO_PLANE  // (measurement variant, tests/harness/sort_bench: the payload staged as two u32 planes instead of one u64 array)
+    uint32_t sval_lo[STILE], sval_hi[STILE];
+#else
     uint64_t sval[STILE];
+#endif
 };
 struct ScatterLds {
     uint32_t wcnt[SW][SMAXR + 1];  // per-wave running digit counters, then their exclusive prefix over waves (+1: bank spread)
@@ -174,14 +178,22 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
                 const uint32_t kx = B.skey[p];
                 const uint64_t dst = B.goff[(kx >> shift) & rmask] + p;
                 okeys[dst] = kx;
+#ifdef SORT_TWO_PLANE
+                ovals[dst] = (uint64_t)B.sval_lo[p] | ((uint64_t)B.sval_hi[p] << 32);
+#else
                 ovals[dst] = B.sval[p];
+#endif
             }
         } else {
             for (uint32_t p = threadIdx.x; p < count; p += ST) {
                 const uint32_t kx = B.skey[p];
                 const uint64_t dst = B.goff[(kx >> shift) & rmask] + p;
                 okeys[dst] = kx;
+#ifdef SORT_TWO_PLANE
+                ovals[dst] = (uint64_t)B.sval_lo[p] | ((uint64_t)B.sval_hi[p] << 32);
+#else
                 ovals[dst] = B.sval[p];
+#endif
             }
         }
     };
@@ -209,7 +221,11 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
         const uint64_t wave_base = tile_base + (uint64_t)w * (64 * SROUNDS);
         // every wave clears its own counters and match words: LDS operations of one wave execute in program order, no
         // barrier needed
+#ifdef SORT_TWO_PLANE
+        unsigned long long *match = (unsigned long long *)&B.sval_lo[0] + (size_t)w * (rmask + 1u);
+#else
         unsigned long long *match = (unsigned long long *)&B.sval[0] + (size_t)w * (rmask + 1u);  // (this staging buffer is free now)
+#endif
 #pragma unroll
         for (int i = 0; i < SMAXR / 64; ++i) L.wcnt[w][i * 64 + lane] = 0;
 #pragma unroll
@@ -255,6 +271,24 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
             L.dstart[4 * lane + 3] = ex + t0 + t1 + t2;
         }
         __syncthreads();
+#ifdef SORT_LOOKBACK_PROBE
+        // Measurement variant (tests/harness/sort_bench only): what a decoupled look-back would add to a tile AT THE LEAST — the
+        // tile's digit counts published (one word per digit) and the rows of SORT_LOOKBACK_PROBE predecessor tiles read back
+        // with device-scope loads by the digit's thread, here, where the tile's output bases are needed.  No waiting for
+        // flags, no retries: a lower bound of the real thing.  The words live in the (unused, digit-major) tail of the
+        // histogram scan array; their values do not matter.
+        if (threadIdx.x <= rmask) {
+            uint32_t *rows = (uint32_t *)(hist_scan + (uint64_t)(rmask + 1u) * n_tiles);
+            __hip_atomic_store(&rows[tile * (rmask + 1u) + threadIdx.x], dtot[threadIdx.x] | 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t acc = 0;
+            for (uint32_t b = 1; b <= (uint32_t)SORT_LOOKBACK_PROBE; ++b) {
+                const uint64_t t2 = tile >= b ? tile - b : 0;
+                acc += __hip_atomic_load(&rows[t2 * (rmask + 1u) + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (acc == 0xFFFFFFFFu) L.dstart[threadIdx.x] += 1u;  // (never: keeps the loads alive)
+        }
+        __syncthreads();
+#endif
         if (threadIdx.x <= rmask) B.goff[threadIdx.x] = gbase - L.dstart[threadIdx.x];
 
         // stage the tile in digit order
@@ -265,7 +299,12 @@ __global__ SORT_BOUNDS void sort_scatter(const uint32_t *__restrict__ keys, cons
                 const uint32_t d = (key[r] >> shift) & rmask;
                 const uint32_t p = L.dstart[d] + L.wcnt[w][d] + rk[r];
                 B.skey[p] = key[r];
+#ifdef SORT_TWO_PLANE
+                B.sval_lo[p] = (uint32_t)val[r];
+                B.sval_hi[p] = (uint32_t)(val[r] >> 32);
+#else
                 B.sval[p] = val[r];
+#endif
             }
         }
         __syncthreads();  // staged: the tile is written out in the next iteration (or after the loop)
@@ -290,7 +329,11 @@ size_t sort_tmp_bytes(uint64_t n) {
     uint64_t n_tiles = (n + STILE - 1) / STILE;
     if (n_tiles == 0) n_tiles = 1;
     uint64_t cells = (uint64_t)SMAXR * n_tiles;
+#ifdef SORT_LOOKBACK_PROBE
+    return sort_align256(cells * 4) + 2 * sort_align256(cells * 8) + sort_align256(scan_tmp_bytes(cells)) + 256;  // (+ the probe's rows)
+#else
     return sort_align256(cells * 4) + sort_align256(cells * 8) + sort_align256(scan_tmp_bytes(cells)) + 256;
+#endif
 }
 
 int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t n, int key_bits, void *tmp,
