@@ -33,7 +33,7 @@ HOST_OBJS := $(patsubst $(HOST_DIR)/%.cpp,$(B)/host/%.o,$(HOST_LIB_SRCS))
 HIP_SRCS  := $(wildcard $(HIP_DIR)/*.hip)
 HIP_HDRS  := $(wildcard $(HIP_DIR)/*.h) $(wildcard $(HIP_DIR)/*.hpp) include/pagraph_hip.h
 
-.PHONY: all product harness oracle clean
+.PHONY: all product harness oracle clean sort_variants
 all: product harness oracle
 
 product: aligngraph2_amd/libpagraph_hip.so aligngraph2_amd/bin/pagraph aligngraph2_amd/bin/kmer_counter aligngraph2_amd/bin/pre_process aligngraph2_amd/bin/pa_cns aligngraph2_amd/bin/paf2aln aligngraph2_amd/libpagraph_host.so
@@ -102,6 +102,16 @@ tests/harness/bin/seg_kernels_test: tests/harness/seg_kernels_test.hip $(HIP_DIR
 tests/harness/bin/sort_bench: tests/harness/sort_bench.hip $(HIP_DIR)/k2_sort.hip $(HIP_DIR)/util.hip $(HIP_HDRS)
 	@mkdir -p tests/harness/bin
 	$(HIPCC) $(HIPFLAGS) -fno-PIC -o $@ $<
+
+# measurement variants of the scatter kernel (DESIGN §6 "the sort's bound"): the least a decoupled look-back would add to a tile
+# (its digit row published, the rows of N predecessor tiles read back) and the payload staged as two u32 planes
+tests/harness/bin/sort_bench_lb%: tests/harness/sort_bench.hip $(HIP_DIR)/k2_sort.hip $(HIP_DIR)/util.hip $(HIP_HDRS)
+	@mkdir -p tests/harness/bin
+	$(HIPCC) $(HIPFLAGS) -fno-PIC -DSORT_LOOKBACK_PROBE=$* -o $@ $<
+tests/harness/bin/sort_bench_2plane: tests/harness/sort_bench.hip $(HIP_DIR)/k2_sort.hip $(HIP_DIR)/util.hip $(HIP_HDRS)
+	@mkdir -p tests/harness/bin
+	$(HIPCC) $(HIPFLAGS) -fno-PIC -DSORT_TWO_PLANE -o $@ $<
+sort_variants: tests/harness/bin/sort_bench tests/harness/bin/sort_bench_lb4 tests/harness/bin/sort_bench_lb16 tests/harness/bin/sort_bench_lb64 tests/harness/bin/sort_bench_2plane
 
 tests/harness/bin/oracle_graph_dump: tests/harness/oracle_graph_dump.cpp $(HOST_NOHIP_OBJS) $(B)/pag_oracle.o
 	@mkdir -p tests/harness/bin

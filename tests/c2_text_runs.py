@@ -24,6 +24,14 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 
+def _quota():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        return None
+
+
 def _digests(out_dir):
     """SHA-256 per output file (contig.txt as a sorted set: the reference writes it in hash order)"""
     import hashlib
@@ -103,7 +111,8 @@ def main():
     n_bases = w.n_bases
     del w
     rec = {"workload": f"{args.reads} x 10 kb reads vs {args.ref_len / 1e6:g} Mb reference, k=14, epsilon=10 (BASELINE configs[1], seed 2), text inputs in /dev/shm",
-           "read_bases": n_bases, "host_cores": os.cpu_count(), "generate_and_write_s": time.time() - t0,
+           "read_bases": n_bases, "host_cores": os.cpu_count(), "cgroup_cpu_quota": _quota(), "measured": time.strftime("round 5, %Y-%m-%d"),
+           "generate_and_write_s": time.time() - t0,
            "input_bytes": {f: os.path.getsize(os.path.join(d, f)) for f in sorted(os.listdir(d))}}
     print(rec, flush=True)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "pagraph")
