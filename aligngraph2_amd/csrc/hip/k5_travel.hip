@@ -806,6 +806,110 @@ __global__ void __launch_bounds__(256) k_succ_heavy(TravGraph G, uint32_t dev, d
     }
 }
 
+// ONE evaluation of the candidate pairs, records staged DENSELY (round 5, PAG_SUCC_MODE=fused): a vertex's candidates are walked
+// and counted (with the acceptance mask), the waves take room for their vertices' records from a cursor — one atomic per wave —
+// and every thread writes its accepted records there straight away, through the mask, while its node's edge and position lists
+// are still in the caches; k_succ_place moves them to coordinate order and links them.  Against the two passes: the edge /
+// position lists are read once, the records leave as full lines (k-mer-major neighbours write neighbouring records) instead of
+// 16-byte pieces at coordinate-ordered places, and nobody reads succ_off[u] at a random place.  stage_off[v] = where v's records
+// begin; a vertex whose records would not fit the staging array (cap) writes none — the caller sees the cursor beyond the cap
+// and falls back to the two passes.  GENERAL = false: every vertex has at most 64 candidates (the others are on the heavy list).
+template <bool GENERAL>
+__global__ void __launch_bounds__(256, 8) k_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ stage_off,
+                                                       SuccRec *__restrict__ stage, uint64_t cap, unsigned long long *__restrict__ cursor,
+                                                       uint32_t *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
+    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    d_ratio_table_fill(ratio_tab, err);
+    __syncthreads();
+    if (!heavy_list) heavy_limit = 0xFFFFFFFFu;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); v0 < G.n_pos; v0 += stride) {  // (wave-uniform trip count)
+        const uint64_t v = v0 + lane_id();
+        const bool active = v < G.n_pos;
+        uint32_t n = 0, u = 0;
+        uint64_t mask = 0ull;
+        bool poison = false, marker = false, heavy = false;
+        if (active) {
+            u = G.newid[v];
+            const bool inc = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+            poison = inc && u < G.n_zero;
+            marker = inc && u >= G.n_zero;
+            if (poison) n = 1u;
+            else {
+                n = succ_vertex<0>(G, v, dev, err, mask, nullptr, ratio_tab, heavy_limit);
+                heavy = n == SUCC_HEAVY;
+                n = heavy ? 0u : n + (marker ? 1u : 0u);
+            }
+        }
+        const uint64_t hb = __ballot(heavy);
+        if (hb) {  // (one atomic per wave)
+            const int first = __ffsll((long long)hb) - 1;
+            unsigned long long at = 0;
+            if ((int)lane_id() == first) at = atomicAdd(heavy_n, (unsigned long long)__popcll(hb));
+            at = __shfl(at, first);
+            if (heavy) heavy_list[at + (uint32_t)__popcll(hb & ((1ull << lane_id()) - 1ull))] = (uint32_t)v;
+        }
+        uint32_t tot;
+        const uint32_t ex = wave_excl_sum(n, &tot);
+        unsigned long long base = 0;
+        if (tot) {
+            if (lane_id() == 0) base = atomicAdd(cursor, (unsigned long long)tot);
+            base = __shfl(base, 0);
+        }
+        if (!active || heavy) continue;
+        const uint64_t off = base + ex;
+        stage_off[v] = off;
+        cnt[u] = n;
+        if (n == 0u || off + n > cap) continue;
+        SuccRec *out = stage + off;
+        SuccRec r;
+        r.tgt = u;
+        r.pc = 0u;
+        r.meta = 1u | ((poison ? GRADE_POISON : GRADE_POISON_IF_LEAP) << 24);
+        r.toff = 0;
+        if (poison) {
+            out[0] = r;
+        } else {
+            const uint32_t m = succ_vertex<GENERAL ? 1 : 3>(G, v, dev, err, mask, out, ratio_tab, heavy_limit);
+            if (marker) out[m] = r;
+        }
+    }
+}
+// ... the vertices on the heavy list, a wave each: counted, room taken, written
+__global__ void __launch_bounds__(256) k_succ_heavy_fused(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ stage_off,
+                                                          SuccRec *__restrict__ stage, uint64_t cap, unsigned long long *__restrict__ cursor,
+                                                          const uint32_t *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_n) {
+    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    d_ratio_table_fill(ratio_tab, err);
+    __syncthreads();
+    const uint64_t total = *heavy_n, n_waves = (uint64_t)gridDim.x * (blockDim.x / 64u);
+    for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < total; i += n_waves) {
+        const uint64_t v = heavy_list[i];
+        const uint32_t u = G.newid[v];
+        const bool marker = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);  // (a poisoned vertex never comes here)
+        uint64_t mask = 0ull;
+        const uint32_t n = succ_vertex_wave<0>(G, v, dev, err, mask, nullptr, ratio_tab) + (marker ? 1u : 0u);
+        unsigned long long off = 0;
+        if (lane_id() == 0) off = atomicAdd(cursor, (unsigned long long)n);
+        off = __shfl(off, 0);
+        if (lane_id() == 0) {
+            cnt[u] = n;
+            stage_off[v] = off;
+        }
+        if (n == 0u || off + n > cap) continue;
+        SuccRec *out = stage + off;
+        const uint32_t m = succ_vertex_wave<1>(G, v, dev, err, mask, out, ratio_tab);
+        if (marker && lane_id() == 0) {
+            SuccRec r;
+            r.tgt = u;
+            r.pc = 0u;
+            r.meta = 1u | (GRADE_POISON_IF_LEAP << 24);
+            r.toff = 0;
+            out[m] = r;
+        }
+    }
+}
+
 // upper bound of a vertex's records: the positions of all target nodes of its k-mer node (every candidate pair)
 __global__ void k_succ_bound(TravGraph G, uint32_t *__restrict__ ub) {
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
@@ -3362,6 +3466,28 @@ int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
         k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
         if (heavy_list) k_succ_heavy<0><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, cnt, amask, heavy_list, heavy_n);
     }
+    PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
+    int rc;
+    if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
+    k_narrow<<<dim3(grid_for(n + 1)), dim3(256), 0, s>>>(scan_out, n + 1, G.succ_off);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+// the fused way (k_succ_fused): counts, dense staging, offsets; then the scan of the counts into succ_off.  *cursor_dev ends at the
+// number of staged records (beyond `cap`: the staging array was too small, nothing usable was staged)
+int trav_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, uint64_t *stage_off,
+                    SuccRec *stage, uint64_t cap, unsigned long long *cursor_dev, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit,
+                    hipStream_t s) {
+    const uint64_t n = G.n_pos;
+    if (!n) return PAG_OK;
+    if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
+    PAG_HIP_TRY(hipMemsetAsync(cursor_dev, 0, 8, s));
+    if (heavy_n) PAG_HIP_TRY(hipMemsetAsync(heavy_n, 0, 8, s));
+    if (heavy_list && heavy_limit <= 64u)
+        k_succ_fused<false><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, cap, cursor_dev, heavy_list, heavy_n, heavy_limit);
+    else
+        k_succ_fused<true><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, cap, cursor_dev, heavy_list, heavy_n, heavy_limit);
+    if (heavy_list) k_succ_heavy_fused<<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, cap, cursor_dev, heavy_list, heavy_n);
     PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
     int rc;
     if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;

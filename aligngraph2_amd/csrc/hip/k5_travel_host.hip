@@ -401,7 +401,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         g->view_counts[1] = G.n_pos;
         g->view_counts[2] = G.n_edges;
         // coordinate order, then the static half of the epsilon-join for every vertex
-        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 4) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
+        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 8) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
             (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
             return rc;
         // (key widths of the two sorts: the single-coordinate spaces of the contigs and of the references)
@@ -455,12 +455,52 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
                 }
             }
         }
+        // PAG_SUCC_MODE=fused (round 5): one evaluation, the records staged densely by the waves' own allocation, then placed.
+        // The staging array is sized by a guess (6 records per vertex, within a quarter of what is free); a graph that needs
+        // more shows in the cursor and is done again by the two passes.
+        bool fused_done = false;
+        if (!stage && mode == "fused" && np) {
+            size_t free_b = 0, total_b = 0;
+            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t cap = std::min<uint64_t>(6 * np + 1024, ((free_b + b_ctmp.sl->cap) / 4) / sizeof(SuccRec));
+            if (cap >= np && b_ctmp.alloc((cap + 1) * sizeof(SuccRec)) == PAG_OK) {
+                unsigned long long *cursor = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 4);
+                unsigned long long *hn = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 3);
+                if ((rc = trav_succ_fused(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 2,
+                                          b_ov1.as<uint64_t>(), b_ctmp.as<SuccRec>(), cap, cursor, b_ok1.as<uint32_t>(), hn, cfg.succ_heavy, s)))
+                    return rc;
+                uint64_t h2[3] = {0, 0, 0};  // total of the counts, heavy vertices, cursor
+                PAG_HIP_TRY(hipMemcpyAsync(h2, b_ov0.as<uint64_t>() + np + 2, 24, hipMemcpyDeviceToHost, s));
+                PAG_HIP_TRY(hipStreamSynchronize(s));
+                if (h2[2] <= cap) {
+                    if (h2[2] != h2[0]) {
+                        set_error("trav_prepare_graph: %llu records staged, %llu counted", (unsigned long long)h2[2], (unsigned long long)h2[0]);
+                        return PAG_EFAULT;
+                    }
+                    n_succ = h2[0];
+                    if (n_succ >= 0xFFFFFFF0ull) {
+                        set_error("pag_travel: more than 2^32 successor records");
+                        return PAG_EINVAL;
+                    }
+                    if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
+                    G.succ = b_succ.as<SuccRec>();
+                    G.n_succ = n_succ;
+                    if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, b_ov1.as<uint64_t>(), b_ctmp.as<SuccRec>(), nullptr, nullptr, nullptr, 0u, s))) return rc;
+                    PAG_HIP_TRY(hipStreamSynchronize(s));
+                    fused_done = true;
+                    if (cfg.timing) std::fprintf(stderr, "[timing] successor records: fused (one evaluation, dense staging of %llu records, %llu heavy vertices)\n", (unsigned long long)h2[2], (unsigned long long)h2[1]);
+                } else if (cfg.timing) {
+                    std::fprintf(stderr, "[timing] successor records: the staging array of %llu records was too small (%llu needed): two passes\n", (unsigned long long)cap, (unsigned long long)h2[2]);
+                }
+            }
+        }
         // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
         uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
         // (the vertices with many candidate pairs, done by a wave each: the list in b_ok1, free since the sort; its length behind the totals)
         uint32_t *heavy_list = stage ? nullptr : b_ok1.as<uint32_t>();
         unsigned long long *heavy_n = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 3);
         // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
+        if (!fused_done) {
         if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
                                   b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, heavy_list, heavy_n, cfg.succ_heavy, s)))
             return rc;
@@ -475,11 +515,12 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         G.n_succ = n_succ;
         if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, heavy_list, heavy_n, cfg.succ_heavy, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
+        }
         g->tg = G;
         g->tg_dev = deviation;
         g->tg_err = errorRate;
         g->tg_ready = true;
-        if (cfg.timing && heavy_list && cfg.succ_heavy) {
+        if (cfg.timing && heavy_list && cfg.succ_heavy && !fused_done) {
             unsigned long long nh = 0;
             hipMemcpy(&nh, heavy_n, 8, hipMemcpyDeviceToHost);
             std::fprintf(stderr, "[timing] successor records: %llu of %llu vertices have more than %u candidate pairs (a wave each)\n", nh, (unsigned long long)G.n_pos, cfg.succ_heavy);
@@ -488,7 +529,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%llu without a contig coordinate) of %llu (%s view: %llu of %llu nodes, %llu of %llu edges; %s, %llu candidate pairs)\n",
                          (unsigned long long)n_succ, (unsigned long long)G.n_pos, (unsigned long long)g->n_zero_ctg, (unsigned long long)np, g->view_pruned ? "cut" : "whole", (unsigned long long)G.n_nodes,
                          (unsigned long long)nn, (unsigned long long)G.n_edges, (unsigned long long)ne,
-                         stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
+                         fused_done ? "fused" : stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
         t_compact = now_ms() - t0;
     }
 

@@ -208,6 +208,9 @@ int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tm
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
                     const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
                     uint32_t heavy_limit, hipStream_t s);
+int trav_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, uint64_t *stage_off,
+                    SuccRec *stage, uint64_t cap, unsigned long long *cursor_dev, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit,
+                    hipStream_t s);
 int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
                    uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s);
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,

@@ -81,11 +81,21 @@ extern "C" void pagh_debug_classify_columns(const char *q, std::uint64_t n, cons
     *n_radv = a;
 }
 
+namespace {
+AlnRecordFilter g_recordFilter;
+}
+void setAlnRecordFilter(AlnRecordFilter f) { g_recordFilter = std::move(f); }
+
 void AlnDb::addRecord(AlnRecord rec, const std::string &qline, const std::string &rline) {
     // parseDiff: q=='-' -> (1,0); r=='-' -> (0,1); mismatch -> (1,1); match -> (0,0).  One column
     // per character of the query line; a shorter reference line reads as NUL (mismatch).
     std::size_t n = qline.size();
     if (n > 0xFFFFFFFFull) throw std::runtime_error("alignment longer than 2^32 columns");
+    if (filterOn_ && g_recordFilter && !g_recordFilter(rec.queryName.data(), rec.queryName.size())) {  // (header only, see setAlnRecordFilter)
+        rec.diffOff = diff_.size();
+        recs_.push_back(std::move(rec));
+        return;
+    }
     rec.diffOff = diff_.size();
     rec.nCols = static_cast<std::uint32_t>(n);
     diff_.resize(diff_.size() + (n + 15) / 16, 0);
@@ -133,17 +143,79 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
     const double t1 = nowS();
     const std::size_t nRec = fl.size() / 3;
     recs_.assign(nRec, AlnRecord{});
+    // headers first (a filter decides by the query name which records get their columns)
+    parallelFor(nRec, 256, [&](std::size_t r) {
+        AlnRecord &rec = recs_[r];
+        const char *p = fl.data(3 * r);
+        const std::size_t n = fl.length(3 * r);
+        std::pair<std::size_t, std::size_t> tk[10];
+        std::size_t nt = 0, i = 0;
+        while (nt < 10) {
+            while (i < n && isSpaceC(p[i])) ++i;
+            if (i >= n) break;
+            const std::size_t a = i;
+            while (i < n && !isSpaceC(p[i])) ++i;
+            tk[nt++] = {a, i - a};
+        }
+        bool fastOk = nt == 10;
+        std::size_t num[6] = {0, 0, 0, 0, 0, 0};
+        for (int f = 0; f < 6 && fastOk; ++f) {
+            const char *q = p + tk[4 + f].first;
+            const std::size_t len = tk[4 + f].second;
+            if (len == 0 || len > 18) fastOk = false;
+            std::size_t v = 0;
+            for (std::size_t c = 0; c < len && fastOk; ++c) {
+                if (q[c] < '0' || q[c] > '9') fastOk = false;
+                v = v * 10 + static_cast<std::size_t>(q[c] - '0');
+            }
+            num[f] = v;
+        }
+        if (fastOk) {
+            rec.queryName.assign(p + tk[0].first, tk[0].second);
+            rec.refName.assign(p + tk[1].first, tk[1].second);
+            rec.forward = tk[2].second == 1 && p[tk[2].first] == 'F';
+            rec.score = static_cast<std::size_t>(std::atoll(std::string(p + tk[3].first, tk[3].second).c_str()));
+            rec.queryBegin = num[0];
+            rec.queryEnd = num[1];
+            rec.refBegin = num[3];
+            rec.refEnd = num[4];
+        } else {  // anything unusual: the stream extraction itself
+            std::stringstream ss;
+            ss.str(std::string(p, n));
+            std::string queryName, refName, forward, score;
+            std::size_t queryBegin = 0, queryEnd = 0, querySize = 0, refBegin = 0, refEnd = 0, refSize = 0;
+            ss >> queryName >> refName >> forward >> score >> queryBegin >> queryEnd >> querySize >> refBegin >> refEnd >> refSize;
+            if (!ss.fail()) {
+                rec.queryName = queryName;
+                rec.refName = refName;
+                rec.forward = forward == "F";
+                rec.score = static_cast<std::size_t>(std::atoll(score.c_str()));
+                rec.queryBegin = queryBegin;
+                rec.queryEnd = queryEnd;
+                rec.refBegin = refBegin;
+                rec.refEnd = refEnd;
+            }
+        }
+    });
+    const AlnRecordFilter filter = g_recordFilter;  // (a copy: the setter may be called while this load runs)
+    std::vector<std::uint8_t> wanted(nRec, 1);
+    std::size_t nWanted = nRec;
+    if (filter) {
+        parallelFor(nRec, 1024, [&](std::size_t r) { wanted[r] = filter(recs_[r].queryName.data(), recs_[r].queryName.size()) ? 1 : 0; });
+        nWanted = 0;
+        for (std::size_t r = 0; r < nRec; ++r) nWanted += wanted[r];
+    }
     std::vector<std::uint64_t> off(nRec + 1, 0);
     for (std::size_t r = 0; r < nRec; ++r) {
         const std::size_t n = fl.length(3 * r + 1);
         if (n > 0xFFFFFFFFull) throw std::runtime_error("alignment longer than 2^32 columns");
-        off[r + 1] = off[r] + (n + 15) / 16;
+        off[r + 1] = off[r] + (wanted[r] ? (n + 15) / 16 : 0);
     }
     diff_.assign(off[nRec], 0);
     // the bulk half on the device, when a classifier is installed: the rows go up as they lie in the file
     bool classified = false;
     std::vector<std::uint32_t> devEmit, devRadv;
-    if (g_classifier && nRec) {
+    if (g_classifier && nRec && !filter) {
         std::vector<std::uint64_t> qOff(nRec), rOff(nRec);
         std::vector<std::uint32_t> qLen(nRec), rLen(nRec);
         bool fits = true;
@@ -163,62 +235,11 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
     const double t2 = nowS();
     parallelFor(nRec, 64, [&](std::size_t r) {
         AlnRecord &rec = recs_[r];
-        {   // header
-            const char *p = fl.data(3 * r);
-            const std::size_t n = fl.length(3 * r);
-            std::pair<std::size_t, std::size_t> tk[10];
-            std::size_t nt = 0, i = 0;
-            while (nt < 10) {
-                while (i < n && isSpaceC(p[i])) ++i;
-                if (i >= n) break;
-                const std::size_t a = i;
-                while (i < n && !isSpaceC(p[i])) ++i;
-                tk[nt++] = {a, i - a};
-            }
-            bool fastOk = nt == 10;
-            std::size_t num[6] = {0, 0, 0, 0, 0, 0};
-            for (int f = 0; f < 6 && fastOk; ++f) {
-                const char *q = p + tk[4 + f].first;
-                const std::size_t len = tk[4 + f].second;
-                if (len == 0 || len > 18) fastOk = false;
-                std::size_t v = 0;
-                for (std::size_t c = 0; c < len && fastOk; ++c) {
-                    if (q[c] < '0' || q[c] > '9') fastOk = false;
-                    v = v * 10 + static_cast<std::size_t>(q[c] - '0');
-                }
-                num[f] = v;
-            }
-            if (fastOk) {
-                rec.queryName.assign(p + tk[0].first, tk[0].second);
-                rec.refName.assign(p + tk[1].first, tk[1].second);
-                rec.forward = tk[2].second == 1 && p[tk[2].first] == 'F';
-                rec.score = static_cast<std::size_t>(std::atoll(std::string(p + tk[3].first, tk[3].second).c_str()));
-                rec.queryBegin = num[0];
-                rec.queryEnd = num[1];
-                rec.refBegin = num[3];
-                rec.refEnd = num[4];
-            } else {  // anything unusual: the stream extraction itself
-                std::stringstream ss;
-                ss.str(std::string(p, n));
-                std::string queryName, refName, forward, score;
-                std::size_t queryBegin = 0, queryEnd = 0, querySize = 0, refBegin = 0, refEnd = 0, refSize = 0;
-                ss >> queryName >> refName >> forward >> score >> queryBegin >> queryEnd >> querySize >> refBegin >> refEnd >> refSize;
-                if (!ss.fail()) {
-                    rec.queryName = queryName;
-                    rec.refName = refName;
-                    rec.forward = forward == "F";
-                    rec.score = static_cast<std::size_t>(std::atoll(score.c_str()));
-                    rec.queryBegin = queryBegin;
-                    rec.queryEnd = queryEnd;
-                    rec.refBegin = refBegin;
-                    rec.refEnd = refEnd;
-                }
-            }
-        }
         // parseDiff, as in addRecord
         const char *ql = fl.data(3 * r + 1), *rl = fl.data(3 * r + 2);
         const std::size_t n = fl.length(3 * r + 1), rn = fl.length(3 * r + 2);
         rec.diffOff = off[r];
+        if (!wanted[r]) return;  // (header only: nCols = nEmit = nRadv = 0)
         rec.nCols = static_cast<std::uint32_t>(n);
         if (classified) {  // (done by the device)
             rec.nEmit = devEmit[r];
@@ -231,6 +252,7 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         rec.nEmit = nEmit;
         rec.nRadv = nRadv;
     });
+    if (timing && filter) std::fprintf(stderr, "[timing]   ALN %s: columns of %zu of %zu records (this rank's reads)\n", path.c_str(), nWanted, nRec);
     if (timing)
         std::fprintf(stderr, "[timing]   ALN %s: %zu records, lines found %.3f s, %s %.3f s, headers%s %.3f s\n", path.c_str(), nRec, t1 - t0,
                      g_classifier ? (classified ? "columns on the device" : "device classifier declined") : "offsets", t2 - t1,
@@ -364,6 +386,7 @@ AlnDb::AlnDb(const std::string &path, Flavor flavor) {
     if (flavor == Flavor::Mecat && loadMecatParallel(path)) {
         // done by the thread pool
     } else if (flavor == Flavor::Mecat) {
+        filterOn_ = true;
         std::string queryName, refName, forward, score;
         std::size_t queryBegin = 0, queryEnd = 0, querySize = 0, refBegin = 0, refEnd = 0, refSize = 0;
         std::string l1, l2, l3;
@@ -420,7 +443,7 @@ AlnDb::AlnDb(const std::string &path, Flavor flavor) {
     sortByScore();
     diff_.resize(diff_.size() + 4, 0);  // kernels may read one word past an alignment
     if (const char *e = std::getenv("PAGRAPH_ALN_SIDECAR"))
-        if (e[0] == '1') savePacked(path, flavor);
+        if (e[0] == '1' && !(flavor == Flavor::Mecat && g_recordFilter)) savePacked(path, flavor);  // (never a sidecar of a filtered parse)
 }
 
 }  // namespace pagh

@@ -4,6 +4,7 @@
 // MummerAlignDatabaseV2.cpp:7-49, AlignmentHelper.cpp:11-48, ParseAlignTools.cpp:8-26).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,14 @@ using ColumnClassifier = bool (*)(const char *text, std::uint64_t textBytes, con
                                   const std::uint64_t *rOff, const std::uint32_t *rLen, const std::uint64_t *diffOff, std::uint64_t nRecs,
                                   std::uint32_t *diff, std::uint64_t nDiffWords, std::uint32_t *nEmit, std::uint32_t *nRadv);
 void setColumnClassifier(ColumnClassifier f);
+
+// A rank of a sharded build (PAGRAPH_SHARD, SURVEY 8e level 2) extracts the reads of ITS emission range only: of every other
+// read's alignments it needs the header (per-query lists, eligibility, the coverage filter: header fields), never the columns.
+// With a filter set, a read database's records whose query name it rejects keep their header and get no column classes
+// (nCols = nEmit = nRadv = 0): the bulk of the parse — 2.2 B of text per aligned base — and of the staged bytes is then the
+// rank's own share.  Applies to Flavor::Mecat text parses; a packed sidecar is loaded as it is.
+using AlnRecordFilter = std::function<bool(const char *queryName, std::size_t len)>;
+void setAlnRecordFilter(AlnRecordFilter f);  // (empty: none)
 
 class AlnDb {
 public:
@@ -79,6 +88,7 @@ public:
 private:
     bool loadMecatParallel(const std::string &path);
     bool fromSidecar_ = false;
+    bool filterOn_ = false;  // (the sequential text parse of a read database: addRecord asks the record filter)
     std::vector<AlnRecord> recs_;
     std::vector<std::uint32_t> diff_;
 };

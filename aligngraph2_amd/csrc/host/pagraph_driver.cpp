@@ -182,7 +182,31 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         struct BlockFiles {
             SeqDb reads;
             AlnDb readToCtg, readToRef;
-            BlockFiles(const std::string &pre, const BlockConfig &cfg) {
+            BlockFiles(const std::string &pre, const BlockConfig &cfg, unsigned shardRank, unsigned shardWorld, unsigned threads) {
+                if (shardWorld > 1 && !(std::getenv("PAGRAPH_SHARD_PARSE_ALL") && std::atoi(std::getenv("PAGRAPH_SHARD_PARSE_ALL")) != 0)) {
+                    // one of several ranks that build this block together: the columns of an alignment are parsed only for the
+                    // reads of THIS rank's stretch of the emission order (pag_shard_extract: positions [n r / N, n (r + 1) / N) of the
+                    // thread-major strided order, MultiThreadTools.tcc:8-14) — of the others the header is all that is used
+                    reads = SeqDb(pre + "/" + cfg.readPath);
+                    const std::uint64_t n = reads.size(), T = threads ? threads : 1;
+                    const std::uint64_t lo = n * shardRank / shardWorld, hi = n * (shardRank + 1ull) / shardWorld;
+                    const SeqDb *rd = &reads;
+                    setAlnRecordFilter([rd, n, T, lo, hi](const char *name, std::size_t len) {
+                        const std::string nm(name, len);
+                        if (!rd->contains(nm)) return false;
+                        const std::uint64_t i = rd->id(nm), t = i % T;
+                        // reads before i in the order: those of the threads below t (thread t' handles ceil((n - t') / T) reads), then i / T
+                        const std::uint64_t full = n / T, rem = n % T;
+                        const std::uint64_t pos = t * full + (t < rem ? t : rem) + i / T;
+                        return pos >= lo && pos < hi;
+                    });
+                    auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
+                    auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat); });
+                    readToCtg = ctgAln.get();
+                    readToRef = refAln.get();
+                    setAlnRecordFilter(nullptr);
+                    return;
+                }
                 auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
                 auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat); });
                 reads = SeqDb(pre + "/" + cfg.readPath);
@@ -192,7 +216,9 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         };
         const bool prefetch = !(std::getenv("PAGRAPH_PREFETCH") && std::atoi(std::getenv("PAGRAPH_PREFETCH")) == 0);
         auto mine = [&](std::size_t no) { return !blocksEnv || onlyBlocks.count(no) != 0; };
-        auto loadBlock = [&opt, &configs](std::size_t no) { return std::make_unique<BlockFiles>(opt.pre, configs[no]); };
+        auto loadBlock = [&opt, &configs, &backend](std::size_t no) {
+            return std::make_unique<BlockFiles>(opt.pre, configs[no], backend.shardRank(), backend.shardWorld(), static_cast<unsigned>(opt.threads));
+        };
         std::future<std::unique_ptr<BlockFiles>> ahead;
         std::size_t aheadNo = static_cast<std::size_t>(-1);
         // (the text of the first block this process works on is parsed beside the global inputs below: 0.3 s of a 2 s run)

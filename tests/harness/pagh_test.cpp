@@ -110,3 +110,39 @@ void pagt_mapper_s2d(const uint32_t *len, uint64_t n, uint64_t single, int64_t *
 uint64_t pagt_mapper_extra(const uint32_t *len, uint64_t n) { return mapperOf(len, n).extraStart(); }
 
 }  // extern "C"
+
+// test hook for AlnDb's record filter (aln_db.hpp, setAlnRecordFilter): the file parsed without a filter and with "numeric query
+// name % mod == rem".  out[0] = records, out[1] = records that kept their columns, out[2] = 1 if every header field of every
+// record agrees, every kept record has the unfiltered parse's column classes and counts, and every other record has none.
+extern "C" int pagt_aln_filter_check(const char *path, uint64_t mod, uint64_t rem, uint64_t *out) {
+    try {
+        pagh::setAlnRecordFilter(nullptr);
+        pagh::AlnDb full(path, pagh::AlnDb::Flavor::Mecat);
+        pagh::setAlnRecordFilter([mod, rem](const char *name, std::size_t len) { return std::stoull(std::string(name, len)) % mod == rem; });
+        pagh::AlnDb part(path, pagh::AlnDb::Flavor::Mecat);
+        pagh::setAlnRecordFilter(nullptr);
+        out[0] = full.size();
+        out[1] = 0;
+        bool ok = full.size() == part.size();
+        for (std::size_t i = 0; ok && i < full.size(); ++i) {
+            const pagh::AlnRecord &a = full[i], &b = part[i];
+            ok = a.queryName == b.queryName && a.refName == b.refName && a.score == b.score && a.queryBegin == b.queryBegin && a.queryEnd == b.queryEnd &&
+                 a.refBegin == b.refBegin && a.refEnd == b.refEnd && a.forward == b.forward;
+            const bool mine = std::stoull(a.queryName) % mod == rem;
+            if (mine) {
+                out[1] += 1;
+                ok = ok && a.nCols == b.nCols && a.nEmit == b.nEmit && a.nRadv == b.nRadv;
+                for (std::size_t c = 0; ok && c < a.nCols; ++c) ok = full.colClass(a, c) == part.colClass(b, c);
+            } else {
+                ok = ok && b.nCols == 0 && b.nEmit == 0 && b.nRadv == 0;
+            }
+        }
+        out[2] = ok ? 1 : 0;
+        out[3] = part.diff().size();
+        out[4] = full.diff().size();
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "pagt_aln_filter_check: %s\n", e.what());
+        return 1;
+    }
+}

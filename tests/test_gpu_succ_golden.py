@@ -7,7 +7,8 @@ checkPosition grade (:143-165), isEdgeSimilar().first (:385-400), in the referen
 position) through pag_debug_trav_vertices and compared record for record:
 
   * the whole graph's view: every vertex present, every list equal, through every way the records are built (staged by the
-    candidate bound / count + fill; vertices with many candidate pairs by a whole wave with limits 64, 4, never);
+    candidate bound / count + fill / fused: one evaluation with dense staging; vertices with many candidate pairs by a whole wave
+    with limits 64, 4, never);
   * the view cut to what the block's traversals can examine (pag_travel_prepare_for), with the default margins and with tight
     ones: a kept vertex's list is the reference's list restricted to the kept targets, marker records (GRADE_POISON_IF_LEAP
     behind the list, GRADE_POISON in place of it) aside.
@@ -157,11 +158,16 @@ MODES = [  # (label, view, environment)
     ("whole twopass", "whole", {"PAG_SUCC_MODE": "twopass"}),
     ("whole twopass heavy=4", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4"}),
     ("whole twopass heavy=0", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "0"}),
+    ("whole fused", "whole", {"PAG_SUCC_MODE": "fused"}),
+    ("whole fused heavy=4", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4"}),
+    ("whole fused heavy=0", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "0"}),
     ("whole by PAG_TRAVEL_VIEW", "for", {"PAG_TRAVEL_VIEW": "whole"}),
     ("cut default", "for", {}),
     ("cut tight twopass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight twopass heavy=4", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight bound", "for", {"PAG_SUCC_MODE": "bound", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight fused", "for", {"PAG_SUCC_MODE": "fused", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight fused heavy=4", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
 ]
 SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS")
 

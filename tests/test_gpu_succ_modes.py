@@ -39,7 +39,7 @@ def test_successor_records_do_not_depend_on_how_they_are_built(monkeypatch):
     hip.pag_debug_succ_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     hip.pag_debug_succ.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     got = {}
-    for mode in ("bound", "twopass", "twopass heavy=4", "twopass heavy=0", "twopass order=8", "twopass order=1"):
+    for mode in ("bound", "twopass", "twopass heavy=4", "twopass heavy=0", "twopass order=8", "twopass order=1", "fused", "fused heavy=4", "fused heavy=0"):
         monkeypatch.setenv("PAG_SUCC_MODE", mode.split()[0])
         monkeypatch.delenv("PAG_SUCC_HEAVY", raising=False)
         monkeypatch.delenv("PAG_ORDER_SLICES", raising=False)

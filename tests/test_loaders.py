@@ -47,3 +47,19 @@ def test_parallel_loader_equals_sequential(name, tmp_path):
     assert r.returncode == 0, r.stderr
     slow = tuple(int(x) for x in r.stdout.split())
     assert fast == slow
+
+
+def test_aln_record_filter_keeps_headers_and_own_columns(tmp_path):
+    """a rank of a sharded build parses the columns of ITS reads' alignments only (aln_db.hpp, setAlnRecordFilter): every
+    record keeps its header, the wanted ones the column classes of the unfiltered parse, the others none"""
+    import goldens
+    ind = goldens.materialize_inputs("join_rev_t16", str(tmp_path / "in"))
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import pagctl; lib = pagctl.test_lib(); "
+            "lib.pagt_aln_filter_check.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]; out = (C.c_uint64 * 5)(); "
+            "rc = lib.pagt_aln_filter_check(%r.encode(), 4, 1, out); print(rc, *out)") % (os.path.dirname(os.path.abspath(__file__)), os.path.join(ind, "0.ref.ref"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rc, n, kept, ok, words_part, words_full = (int(x) for x in r.stdout.split())
+    assert rc == 0 and ok == 1
+    assert 0 < kept < n and abs(kept - n / 4) < n / 8
+    assert words_part < 0.45 * words_full
