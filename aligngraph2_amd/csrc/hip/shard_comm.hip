@@ -233,7 +233,11 @@ struct pag_comm {
                     Hello h{};
                     if (slurp(dir + name, blob) && blob.size() == sizeof h) {
                         std::memcpy(&h, blob.data(), sizeof h);
-                        if (h.start != 0 && proc_start((long)h.pid) == h.start) {
+                        // (PAG_COMM_ANY_NAMESPACE=1: the ranks run in containers with PID namespaces of their own — one per GPU
+                        // sharing the rendezvous directory — where /proc/<pid> of a peer is not this process's to see: a hello
+                        // is then taken when the directory is the job's own fresh one, which is the launcher's to guarantee)
+                        static const bool any_ns = std::getenv("PAG_COMM_ANY_NAMESPACE") && std::atoi(std::getenv("PAG_COMM_ANY_NAMESPACE")) != 0;
+                        if (h.start != 0 && (any_ns || proc_start((long)h.pid) == h.start)) {
                             seen[r] = h;
                             break;
                         }

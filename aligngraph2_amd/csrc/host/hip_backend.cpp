@@ -27,9 +27,17 @@ public:
     explicit HipBackend(int device) : device_(device) {
         // (the HIP runtime comes up while the driver parses its first input files)
         warm_ = std::thread([device] { (void)pag_device_warm(device); });
+        try {
+            configure();
+        } catch (...) {  // (a joinable std::thread member in a constructor that throws would end the process without the message)
+            if (warm_.joinable()) warm_.join();
+            throw;
+        }
+    }
+    void configure() {
         if (const char *e = std::getenv("PAGRAPH_DEVICE_INGEST"))
             if (e[0] == '1') {
-                g_ingest_device = device;
+                g_ingest_device = device_;
                 setColumnClassifier(&classifyOnDevice);
             }
         // PAGRAPH_SHARD=r/N (or "env": RANK / WORLD_SIZE as torchrun sets them): this process is rank r of N that build every
