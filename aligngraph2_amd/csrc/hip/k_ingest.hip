@@ -123,9 +123,18 @@ int upload_text(const char *text, uint64_t bytes, unsigned char **dev, hipStream
     PAG_HIP_TRY(hipMemsetAsync(*dev + bytes, 0, 64, s));
     const size_t CH = 64u << 20;
     char *pin[2] = {nullptr, nullptr};
-    hipEvent_t done[2];
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto drop = [&]() {
+        for (int b = 0; b < 2; ++b) {
+            if (pin[b]) hipHostFree(pin[b]);
+            if (done[b]) hipEventDestroy(done[b]);
+        }
+    };
     for (int b = 0; b < 2; ++b) {
         if (hipHostMalloc((void **)&pin[b], CH, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) {
+            drop();  // (what the first turn of this loop took, and the device buffer: the caller sees no half-made upload)
+            hipFree(*dev);
+            *dev = nullptr;
             set_error("ingest: pinned staging buffers");
             return PAG_ENOMEM;
         }
@@ -146,10 +155,7 @@ int upload_text(const char *text, uint64_t bytes, unsigned char **dev, hipStream
         if (hipMemcpyAsync(*dev + at, pin[b], n, hipMemcpyHostToDevice, s) != hipSuccess || hipEventRecord(done[b], s) != hipSuccess) rc = PAG_EFAULT;
     }
     if (hipStreamSynchronize(s) != hipSuccess) rc = PAG_EFAULT;
-    for (int b = 0; b < 2; ++b) {
-        hipHostFree(pin[b]);
-        hipEventDestroy(done[b]);
-    }
+    drop();
     if (rc != PAG_OK) set_error("ingest: upload of the text failed");
     return rc;
 }
