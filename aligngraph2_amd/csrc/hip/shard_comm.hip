@@ -499,8 +499,25 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
     using namespace pagdev;
     const int W = c->world, me = c->rank;
     int rc;
+    // PAG_SHARD_TIMING=1: one line per rank and block on stderr — seconds per stage of this call (the device idle at every
+    // boundary) and the payload that left the rank in each of the two bulk exchanges
+    const bool timing = std::getenv("PAG_SHARD_TIMING") != nullptr;
+    double lap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t wire[2] = {0, 0};
+    auto now = [&]() {
+        if (timing) hipDeviceSynchronize();
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    double t_prev = now();
+    auto mark = [&](int i) {
+        if (!timing) return;
+        const double t = now();
+        lap[i] += t - t_prev;
+        t_prev = t;
+    };
     std::vector<uint64_t> counts(4 * (size_t)W), allc(4 * (size_t)W * W);
     if ((rc = pag_shard_extract(g, in, (uint32_t)me, (uint32_t)W, counts.data()))) return rc;
+    mark(0);
     if ((rc = pag_comm_all_gather(c, counts.data(), counts.size() * 8, allc.data()))) return rc;
     auto cnt = [&](int src, int dst, int q) { return allc[((size_t)src * W + dst) * 4 + q]; };
     hipStream_t s = g->stream;
@@ -519,6 +536,8 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
     if ((rc = b_rk.alloc((nmax + 1) * 4)) || (rc = b_rv.alloc((nmax + 1) * 8)) || (rc = b_lk.alloc((nT + 1) * 4)) || (rc = b_lv.alloc((nT + 1) * 8))) return rc;
     DevBuf b_lek(g, 210), b_lev(g, 211);
     if ((rc = b_lek.alloc((nE + 1) * 4)) || (rc = b_lev.alloc((nE + 1) * 8))) return rc;
+    mark(1);
+    const uint64_t sent0 = pag_comm_bytes_sent(c);
     for (int stream_no = 0; stream_no < 2; ++stream_no) {
         const int q0 = stream_no * 2;
         const void *sk = g->pool[stream_no == 0 ? ts : es].p, *sv = g->pool[(stream_no == 0 ? ts : es) + 1].p;
@@ -546,8 +565,11 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
             PAG_HIP_TRY(hipStreamSynchronize(s));
         }
     }
+    mark(2);
+    wire[0] = pag_comm_bytes_sent(c) - sent0;
     pag_build_stats mine{};
     if ((rc = pag_shard_build(g, b_lk.as<uint32_t>(), b_lv.as<uint64_t>(), nT, t1, b_lek.as<uint32_t>(), b_lev.as<uint64_t>(), nE, e1, in->eps, &mine))) return rc;
+    mark(3);
     // ---- every rank's region of this owner's slice
     std::vector<pag_shard_slice> sel(W);
     std::vector<uint64_t> my_sizes(2 * (size_t)W), all_sizes(2 * (size_t)W * W);
@@ -592,6 +614,8 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         }
         PAG_HIP_TRY(hipStreamSynchronize(s));
     }
+    mark(4);
+    const uint64_t sent1 = pag_comm_bytes_sent(c);
     if ((rc = pag_comm_all_gather(c, my_sizes.data(), my_sizes.size() * 8, all_sizes.data()))) return rc;
     std::vector<pag_build_stats> all_stats((size_t)W * W);
     if ((rc = pag_comm_all_gather(c, stats_to.data(), stats_to.size() * sizeof(pag_build_stats), all_stats.data()))) return rc;
@@ -613,6 +637,8 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         }
         if ((rc = pag_comm_all_to_all_v(c, g->pool[arrs[a].slot].p, sb.data(), imp[a].p, rb.data()))) return rc;
     }
+    mark(5);
+    wire[1] = pag_comm_bytes_sent(c) - sent1;
     pag_build_stats st{};
     for (int o = 0; o < W; ++o) {
         const pag_build_stats &P = all_stats[(size_t)o * W + me];
@@ -630,6 +656,12 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
     if ((rc = pag_shard_adopt(g, T, E, &st))) return rc;
     if ((rc = pag_shard_set_region(g, &regions[me]))) return rc;
     if ((rc = pag_shard_release_build(g))) return rc;
+    mark(6);
+    if (timing)
+        std::fprintf(stderr,
+                     "[shard timing] rank %d/%d extract+partition %.4f s, counts+buffers %.4f s, tuple exchange %.4f s (%llu B out), K2-K4 %.4f s, "
+                     "selections for %d ranks %.4f s, region exchange %.4f s (%llu B out), import+region+release %.4f s\n",
+                     me, W, lap[0], lap[1], lap[2], (unsigned long long)wire[0], lap[3], W, lap[4], lap[5], (unsigned long long)wire[1], lap[6]);
     if (total) *total = st;
     return PAG_OK;
 }

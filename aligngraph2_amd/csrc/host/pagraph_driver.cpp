@@ -187,7 +187,9 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                     // one of several ranks that build this block together: the columns of an alignment are parsed only for the
                     // reads of THIS rank's stretch of the emission order (pag_shard_extract: positions [n r / N, n (r + 1) / N) of the
                     // thread-major strided order, MultiThreadTools.tcc:8-14) — of the others the header is all that is used
-                    reads = SeqDb(pre + "/" + cfg.readPath);
+                    // (and its bases are packed, and staged on the device, for that stretch only)
+                    const SeqDb::PackWindow window{shardRank, shardWorld, threads ? threads : 1u};
+                    reads = SeqDb(pre + "/" + cfg.readPath, &window);
                     const std::uint64_t n = reads.size(), T = threads ? threads : 1;
                     const std::uint64_t lo = n * shardRank / shardWorld, hi = n * (shardRank + 1ull) / shardWorld;
                     const SeqDb *rd = &reads;

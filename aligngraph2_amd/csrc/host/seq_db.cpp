@@ -3,7 +3,7 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
-#include <cstring>
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -102,7 +102,7 @@ void SeqDb::addPacked(const std::string &name, const std::uint8_t *packed, std::
 
 void SeqDb::finish() { packed_.resize(packed_.size() + 32, 0); }
 
-SeqDb::SeqDb(const std::string &path) {
+SeqDb::SeqDb(const std::string &path, const PackWindow *window) {
     std::ifstream probe(path);
     if (!probe) {  // the reference's AutoSeqDatabase yields an empty database for a file it cannot open (SeqHelper::
         finish();  // autoLoadFromFile finds no record type, AutoSeqDatabase.cpp:9-22) and pagraph carries on
@@ -134,7 +134,7 @@ SeqDb::SeqDb(const std::string &path) {
             }
         }
         if (!header.empty()) add(header, buffer);
-    } else if (sequential || !loadFastqParallel(path)) {
+    } else if (sequential || !loadFastqParallel(path, window)) {  // (the plain loop packs every record: a window only ever leaves work out)
         // 4-line FASTQ records; a trailing partial record is dropped (SeqHelper.cpp:13-26)
         std::string l1, l2, l3, l4;
         while (std::getline(in, l1) && std::getline(in, l2) && std::getline(in, l3) && std::getline(in, l4)) {
@@ -147,7 +147,7 @@ SeqDb::SeqDb(const std::string &path) {
 // The same records as the sequential loop above, with the lines found and the reads packed by a pool of threads.
 // Returns false (nothing loaded) when a header line has no token: the reference then re-uses the previous
 // record's name (AutoSeqDatabase.cpp:12), a cross-record dependency that is left to the sequential path.
-bool SeqDb::loadFastqParallel(const std::string &path) {
+bool SeqDb::loadFastqParallel(const std::string &path, const PackWindow *window) {
     FileLines fl;
     if (!fl.load(path)) return false;
     const std::size_t nRec = fl.size() / 4;
@@ -172,16 +172,29 @@ bool SeqDb::loadFastqParallel(const std::string &path) {
     len_.resize(first + nRec);
     byteOff_.resize(first + nRec);
     std::size_t cursor = packed_.size();
+    const bool windowed = window && window->world > 1 && first == 0;
+    std::size_t shared = 0;  // (bytes of the zero stretch every record outside the window points at)
+    if (windowed) {
+        for (std::size_t r = 0; r < nRec; ++r)
+            if (!window->wants(r, nRec)) shared = std::max(shared, ((fl.length(4 * r + 1) + 3) / 4 + 3) & ~std::size_t(3));
+        cursor += shared;
+    }
+    const std::size_t sharedAt = cursor - shared;
     for (std::size_t r = 0; r < nRec; ++r) {
         const std::size_t n = fl.length(4 * r + 1);
         len_[first + r] = static_cast<std::uint32_t>(n);
+        totalBases_ += n;
+        if (windowed && !window->wants(r, nRec)) {
+            byteOff_[first + r] = sharedAt;
+            continue;
+        }
         byteOff_[first + r] = cursor;
         cursor += (((n + 3) / 4) + 3) & ~std::size_t(3);
-        totalBases_ += n;
     }
     packed_.resize(cursor, 0);
     parallelFor(nRec, 256, [&](std::size_t r) {
         names_[first + r].assign(fl.data(4 * r) + tok[r].first + 1, tok[r].second - 1);
+        if (windowed && !window->wants(r, nRec)) return;
         const char *sq = fl.data(4 * r + 1);
         const std::size_t n = len_[first + r];
         packBases(sq, n, packed_.data() + byteOff_[first + r]);

@@ -15,8 +15,19 @@ class SeqDb {
 public:
     static constexpr std::size_t kNotFound = static_cast<std::size_t>(-1);
 
+    // One of several ranks that share a block packs the bases of ITS reads only: the records whose position in the emission
+    // order (thread-major strided over `threads` workers, MultiThreadTools.tcc:8-14) lies in [n rank / world, n (rank + 1) / world).
+    // Every other record keeps its name and length and points at one shared stretch of zero bytes (it reads as A's).
+    struct PackWindow {
+        unsigned rank = 0, world = 1, threads = 1;
+        bool wants(std::uint64_t i, std::uint64_t n) const {
+            const std::uint64_t T = threads ? threads : 1, t = i % T, full = n / T, rem = n % T;
+            const std::uint64_t pos = t * full + (t < rem ? t : rem) + i / T;
+            return pos >= n * rank / world && pos < n * (rank + 1ull) / world;
+        }
+    };
     // throws std::runtime_error when the file cannot be opened
-    explicit SeqDb(const std::string &path);
+    explicit SeqDb(const std::string &path, const PackWindow *window = nullptr);
     SeqDb() = default;
 
     std::size_t size() const { return len_.size(); }
@@ -44,7 +55,7 @@ public:
     void finish();  // pads the packed buffer
 
 private:
-    bool loadFastqParallel(const std::string &path);
+    bool loadFastqParallel(const std::string &path, const PackWindow *window);
     bool loadFastaParallel(const std::string &path);
     std::vector<std::string> names_;
     std::vector<std::uint32_t> len_;

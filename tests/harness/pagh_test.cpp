@@ -111,6 +111,39 @@ uint64_t pagt_mapper_extra(const uint32_t *len, uint64_t n) { return mapperOf(le
 
 }  // extern "C"
 
+// test hook for SeqDb's pack window (seq_db.hpp): a FASTQ file loaded whole and as rank `rank` of `world` (emission order over
+// `threads` workers).  out[0] = records, out[1] = records inside the window, out[2] = 1 if names and lengths agree for every
+// record, every record inside the window reads back base for base, every other one points at the shared zero stretch;
+// out[3] / out[4] = packed bytes of the windowed / the whole load.
+extern "C" int pagt_seq_window_check(const char *path, unsigned rank, unsigned world, unsigned threads, uint64_t *out) {
+    try {
+        pagh::SeqDb full(path);
+        const pagh::SeqDb::PackWindow w{rank, world, threads};
+        pagh::SeqDb part(path, &w);
+        out[0] = full.size();
+        out[1] = 0;
+        bool ok = full.size() == part.size() && full.totalBases() == part.totalBases();
+        std::uint64_t sharedAt = ~0ull;
+        for (std::size_t i = 0; ok && i < full.size(); ++i) {
+            ok = full.name(i) == part.name(i) && full.length(i) == part.length(i) && part.id(part.name(i)) == full.id(full.name(i));
+            if (w.wants(i, full.size())) {
+                out[1] += 1;
+                ok = ok && full.toString(i, true) == part.toString(i, true) && full.toString(i, false) == part.toString(i, false);
+            } else {
+                if (sharedAt == ~0ull) sharedAt = part.byteOff()[i];
+                ok = ok && part.byteOff()[i] == sharedAt && part.toString(i, true) == std::string(part.length(i), 'A');
+            }
+        }
+        out[2] = ok ? 1 : 0;
+        out[3] = part.packed().size();
+        out[4] = full.packed().size();
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "pagt_seq_window_check: %s\n", e.what());
+        return 1;
+    }
+}
+
 // test hook for AlnDb's record filter (aln_db.hpp, setAlnRecordFilter): the file parsed without a filter and with "numeric query
 // name % mod == rem".  out[0] = records, out[1] = records that kept their columns, out[2] = 1 if every header field of every
 // record agrees, every kept record has the unfiltered parse's column classes and counts, and every other record has none.

@@ -63,3 +63,28 @@ def test_aln_record_filter_keeps_headers_and_own_columns(tmp_path):
     assert rc == 0 and ok == 1
     assert 0 < kept < n and abs(kept - n / 4) < n / 8
     assert words_part < 0.45 * words_full
+
+
+@pytest.mark.parametrize("world,threads", [(4, 16), (2, 1), (8, 5)])
+def test_reads_outside_a_rank_s_stretch_keep_name_and_length_only(tmp_path, world, threads):
+    """a rank of a sharded build packs the bases of ITS stretch of the emission order only (seq_db.hpp, SeqDb::PackWindow): the
+    other reads keep name and length and share one stretch of zero bytes; the windows of all ranks partition the reads"""
+    import goldens
+    ind = goldens.materialize_inputs("join_rev_t16", str(tmp_path / "in"))
+    fq = [f for f in sorted(os.listdir(ind)) if f.endswith((".fastq", ".fq"))]
+    assert fq, os.listdir(ind)
+    total, n_reads = 0, None
+    for rank in range(world):
+        code = ("import ctypes as C, sys; sys.path.insert(0, %r); import pagctl; lib = pagctl.test_lib(); "
+                "lib.pagt_seq_window_check.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]; out = (C.c_uint64 * 5)(); "
+                "rc = lib.pagt_seq_window_check(%r.encode(), %d, %d, %d, out); print(rc, *out)") % (
+                    os.path.dirname(os.path.abspath(__file__)), os.path.join(ind, fq[0]), rank, world, threads)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rc, n, kept, ok, bytes_part, bytes_full = (int(x) for x in r.stdout.split())
+        assert rc == 0 and ok == 1, (rank, r.stdout, r.stderr)
+        assert abs(kept - n / world) <= 1
+        assert bytes_part < bytes_full * (1.0 / world + 0.2)
+        total += kept
+        n_reads = n
+    assert total == n_reads
