@@ -3454,6 +3454,73 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;
 }
+// pag_successors: one wave looks one vertex up in the coordinate order — the vertices without a contig coordinate come first,
+// by reference coordinate; the others by contig coordinate; equal keys in k-mer-major order (trav_order) — and hands its records
+// back in the caller's terms
+struct SuccOut {
+    uint32_t code, step;
+    uint64_t pos;
+    uint32_t grade, ctg_similar;
+};
+__global__ void k_successors_of(TravGraph G, uint32_t code, uint64_t pos, SuccOut *__restrict__ recs, uint64_t cap, unsigned long long *__restrict__ out) {
+    const uint32_t lane = threadIdx.x;
+    const bool zero = (pos >> 32) == 0;
+    const uint64_t lo0 = zero ? 0 : G.n_zero, hi0 = zero ? G.n_zero : G.n_pos;
+    const uint32_t want = zero ? (uint32_t)pos : (uint32_t)(pos >> 32);
+    uint64_t lo = lo0, hi = hi0;  // first u of the stretch whose key is >= want
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint64_t p = G.upos[mid];
+        const uint32_t key = zero ? (uint32_t)p : (uint32_t)(p >> 32);
+        if (key < want) lo = mid + 1;
+        else hi = mid;
+    }
+    unsigned long long found = ~0ull;
+    for (uint64_t base = lo; base < hi0; base += 64) {
+        const uint64_t u = base + lane;
+        bool same_key = false, hit = false;
+        if (u < hi0) {
+            const uint64_t p = G.upos[u];
+            same_key = (zero ? (uint32_t)p : (uint32_t)(p >> 32)) == want;
+            hit = p == pos && G.ncode[G.vnode[G.uold[u]]] == code;
+        }
+        const unsigned long long hits = __ballot(hit);
+        if (hits) {
+            found = base + (unsigned long long)__builtin_ctzll(hits);
+            break;
+        }
+        if (__ballot(same_key) != ~0ull) break;  // (the run of this key ends inside these 64)
+    }
+    if (found == ~0ull) {
+        if (lane == 0) out[0] = ~0ull;
+        return;
+    }
+    const uint32_t a = G.succ_off[found], b = G.succ_off[found + 1];
+    bool marker = false;
+    for (uint32_t i = a + lane; i < b; i += 64) {
+        const SuccRec r = G.succ[i];
+        const uint32_t grade = (r.meta >> 24) & 7u;
+        if (grade >= GRADE_POISON_IF_LEAP) {
+            marker = true;
+        } else if ((uint64_t)(i - a) < cap) {
+            SuccOut o;
+            o.code = G.ncode[G.vnode[G.uold[r.tgt]]];
+            o.step = r.meta & 0xFFFFFFu;
+            o.pos = G.upos[r.tgt];
+            o.grade = grade;
+            o.ctg_similar = (r.meta >> 27) & 1u;
+            recs[i - a] = o;
+        }
+    }
+    const bool any_marker = __ballot(marker) != 0ull;
+    if (lane == 0) out[0] = any_marker ? ~1ull : (unsigned long long)(b - a);
+}
+int trav_successors_of(TravGraph G, uint32_t code, uint64_t pos, void *recs, uint64_t cap, unsigned long long *out, hipStream_t s) {
+    static_assert(sizeof(SuccOut) == sizeof(pag_succ), "pag_succ layout");
+    k_successors_of<<<dim3(1), dim3(64), 0, s>>>(G, code, pos, (SuccOut *)recs, cap, out);
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
                     const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
                     uint32_t heavy_limit, hipStream_t s) {

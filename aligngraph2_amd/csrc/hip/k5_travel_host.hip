@@ -2582,6 +2582,36 @@ int pag_debug_trav_vertices(const pag_graph *g, uint32_t *code, uint64_t *pos) {
     return PAG_OK;
 }
 
+// PABruijnGraph::successors for one vertex of the prepared view (PABruijnGraph.cpp:167-197), see pagraph_hip.h
+int64_t pag_successors(const pag_graph *g, uint32_t code, uint64_t pos, pag_succ *out, uint64_t cap) {
+    if (!g || !g->tg_ready || (!out && cap)) return PAG_EINVAL;
+    PAG_HIP_TRY(hipSetDevice(g->device));
+    if (g->view_pruned || g->regional) {
+        set_error("pag_successors: the prepared view was cut for given traversals (pag_travel_prepare_for / a regional graph): its lists are restricted to what those traversals can examine");
+        return PAG_ERANGE;
+    }
+    void *d = nullptr;
+    const uint64_t room = std::min<uint64_t>(cap, g->tg.n_succ);
+    PAG_HIP_TRY(hipMalloc(&d, 16 + room * sizeof(pag_succ)));
+    unsigned long long *d_n = (unsigned long long *)d;
+    void *d_recs = (char *)d + 16;
+    int rc = trav_successors_of(g->tg, code, pos, d_recs, room, d_n, g->stream);
+    unsigned long long n = 0;
+    if (rc == PAG_OK && (hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess)) rc = PAG_EFAULT;
+    if (rc == PAG_OK && n == ~0ull) {
+        set_error("pag_successors: the graph holds no vertex with that k-mer and position");
+        rc = PAG_EINVAL;
+    } else if (rc == PAG_OK && n == ~1ull) {
+        set_error("pag_successors: that vertex's list is a marker record");
+        rc = PAG_ERANGE;
+    } else if (rc == PAG_OK && std::min<uint64_t>(n, room) &&
+               hipMemcpy(out, d_recs, std::min<uint64_t>(n, room) * sizeof(pag_succ), hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = PAG_EFAULT;
+    }
+    hipFree(d);
+    return rc == PAG_OK ? (int64_t)n : rc;
+}
+
 // the first part of pag_travel on its own (the caller may have other work for the host between it and the walks)
 int pag_travel_prepare(pag_graph *g, const pag_seqs *ctgs, const uint32_t *ref_len, uint64_t n_refs, const pag_travel_params *prm, double *ms) {
     return pag_travel_prepare_for(g, ctgs, nullptr, ref_len, n_refs, prm, ms);

@@ -202,6 +202,9 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
                int ref_bits, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
 // bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
+// the records of ONE vertex named by (code, position), translated back to (code, position) of their targets (pag_successors):
+// out[0] = number of records or ~0 (no such vertex) / ~1 (its list is a marker), written to recs (32 bytes each) up to cap
+int trav_successors_of(TravGraph G, uint32_t code, uint64_t pos, void *recs, uint64_t cap, unsigned long long *out, hipStream_t s);
 int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s);
 // (heavy_list [n_pos] / heavy_n: the two-pass path hands the vertices with more than heavy_limit candidate pairs to a wave each;
 // the counting pass fills the list, the filling pass reads it.  heavy_limit 0 or null pointers: every vertex by its own thread)

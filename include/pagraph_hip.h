@@ -388,6 +388,20 @@ int pag_travel_view_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos
                           uint64_t *fallbacks);
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *params, pag_travel_stats *stats);
+/* One vertex's graded successors as the reference's graph returns them — PABruijnGraph::successors (PABruijnGraph.cpp:167-197:
+ * searchSuccessors x checkPosition != Oops, with isEdgeSimilar().first) with the deviation / error rate the view was prepared
+ * with (pag_travel_prepare*), in the reference's order.  A vertex is named the way the reference's PANode names it, by value:
+ * its k-mer code and its clustered position (contig coordinate << 32 | reference coordinate).  Returns the number of
+ * successors (the first `cap` are written); PAG_EINVAL when the view is not prepared or holds no such vertex; PAG_ERANGE when
+ * the view was cut for given traversals (pag_travel_prepare_for, a regional graph) and left this vertex's successors out. */
+typedef struct pag_succ {
+    uint32_t code;        /* target k-mer */
+    uint32_t step;        /* edge step (KMerAdjEdge) */
+    uint64_t pos;         /* target position: contig coordinate << 32 | reference coordinate */
+    uint32_t grade;       /* checkPosition's grade as the reference numbers it (PABruijnGraph.hpp PositionGrade) */
+    uint32_t ctg_similar; /* isEdgeSimilar().first */
+} pag_succ;
+int64_t pag_successors(const pag_graph *g, uint32_t code, uint64_t pos, pag_succ *out, uint64_t cap);
 const pag_path_node *pag_travel_path(const pag_graph *g, uint64_t ctg_index, uint64_t *len);
 const pag_path_node *pag_travel_path_oriented(const pag_graph *g, uint64_t ctg_index, int forward, uint64_t *len);
 /* Optional: have the device memory the walks of pag_travel take their job buffers from (one arena per handle, kept between

@@ -230,3 +230,77 @@ def test_every_successor_record_equals_the_reference(name, workdir, monkeypatch)
         assert max(npos) > 255, "no k-mer with more than 255 positions: edge_target's clamp was not exercised"
     if name in ("succ_corners_t8", "two_blocks_both_orient_t16"):
         assert totals["cut"] > 0, "the tight view kept every vertex: the cut was not exercised"
+
+
+class PagSucc(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("step", C.c_uint32), ("pos", C.c_uint64), ("grade", C.c_uint32), ("ctg_similar", C.c_uint32)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["join_fwd_t1", "succ_corners_t8", "two_blocks_both_orient_t16"])
+def test_pag_successors_answers_like_the_reference_s_successors(name, workdir, monkeypatch):
+    """the public call (pagraph_hip.h pag_successors = PABruijnGraph::successors, PABruijnGraph.cpp:167-197): vertices named by
+    (k-mer, position) — the longest lists, the empty ones, a spread of the rest, a vertex that does not exist, a buffer that is
+    too small, a view that was cut"""
+    for s in SWITCHES:
+        monkeypatch.delenv(s, raising=False)
+    spec = goldens.load_spec(name)
+    ind = goldens.materialize_inputs(name, str(workdir / name / "in_q"))
+    ref_blocks = reference_blocks(name)
+    hip = pagctl.hip_lib()
+    hip.pag_travel_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    hip.pag_travel_prepare_for.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    hip.pag_successors.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64]
+    hip.pag_successors.restype = C.c_int64
+    ctg_names = [l[1:].split()[0] for l in open(os.path.join(ind, "ctg.fasta")) if l.startswith(">")]
+    for block, ref in enumerate(ref_blocks):
+        inp = pagctl.LoadedInput(ind, threads=spec["threads"], eps=spec["epsilon"], cov=spec["cov"], block=block)
+        err = C.c_int()
+        g = C.c_void_p(hip.pag_create(inp.kmer_words, inp.n_kmer_words, inp.k, 0, C.byref(err)))
+        assert g, hip.pag_last_error()
+        try:
+            raw = PagRawInput.from_address(inp.raw_view)
+            ctg_len = np.ctypeslib.as_array(C.cast(raw.ctg_len, C.POINTER(C.c_uint32)), shape=(raw.n_ctgs,)).copy()
+            ref_len = np.ctypeslib.as_array(C.cast(raw.ref_len, C.POINTER(C.c_uint32)), shape=(raw.n_refs,)).copy()
+            ctgs = PagSeqs(raw.n_ctgs, None, ctg_len.ctypes.data, None, 0)
+            prm = TravelParams(spec["threads"], 0, 2 * spec["epsilon"], 0.15, 0.90, 50)
+            prepared = pagctl._prepared_view(hip, g, inp)
+            st = pagctl.BuildStats()
+            assert hip.pag_process(g, C.byref(prepared), C.byref(st)) == 0, hip.pag_last_error()
+            assert hip.pag_successors(g, 0, 0, None, 0) == -22  # (nothing prepared yet)
+            assert hip.pag_travel_prepare(g, C.byref(ctgs), ref_len.ctypes.data, len(ref_len), C.byref(prm), None) == 0, hip.pag_last_error()
+            keys, off, rec = ref["keys"], ref["off"], ref["rec"]
+            cnt = off[1:] - off[:-1]
+            order = np.argsort(-cnt, kind="stable")
+            rng = np.random.default_rng(5)
+            pick = list(order[:40]) + list(order[-20:]) + list(rng.choice(len(keys), size=min(400, len(keys)), replace=False))
+            buf = (PagSucc * (int(cnt.max()) + 1))()
+            for r in pick:
+                code, ctg, rf = keys[r]
+                n = hip.pag_successors(g, code, (ctg << 32) | rf, buf, len(buf))
+                assert n == cnt[r], (name, block, keys[r], n, int(cnt[r]), hip.pag_last_error())
+                got = [((b.code, b.pos >> 32, b.pos & 0xFFFFFFFF), b.step, b.grade, b.ctg_similar) for b in buf[:n]]
+                want = [(keys[t], s_, g_, e_) for t, s_, g_, e_ in rec[off[r]:off[r + 1]].tolist()]
+                assert got == want, (name, block, keys[r])
+            # a buffer that is too small: the count is the whole list's, the first `cap` are written
+            r = int(order[0])
+            code, ctg, rf = keys[r]
+            small = (PagSucc * 2)()
+            assert hip.pag_successors(g, code, (ctg << 32) | rf, small, 2) == cnt[r]
+            assert [(b.code, b.pos) for b in small[:min(2, int(cnt[r]))]] == [(keys[t][0], (keys[t][1] << 32) | keys[t][2]) for t in rec[off[r]:off[r + 1], 0].tolist()[:2]]
+            # no such vertex: an existing k-mer at a position it does not have, and a k-mer the graph does not hold
+            have = set(keys)
+            miss = next((code, ctg, rf + d) for d in range(1, 1000) if (code, ctg, rf + d) not in have)
+            assert hip.pag_successors(g, miss[0], (miss[1] << 32) | miss[2], buf, len(buf)) == -22
+            codes = {k_[0] for k_ in keys}
+            absent = next((c for c in range(4 ** inp.k) if c not in codes), None)
+            if absent is not None:
+                assert hip.pag_successors(g, absent, (ctg << 32) | rf, buf, len(buf)) == -22
+            # a view cut for given traversals answers PAG_ERANGE instead of a restricted list
+            orient = block_orient(ind, block, ctg_names)
+            assert hip.pag_process(g, C.byref(prepared), C.byref(st)) == 0, hip.pag_last_error()
+            assert hip.pag_travel_prepare_for(g, C.byref(ctgs), orient.ctypes.data, ref_len.ctypes.data, len(ref_len), C.byref(prm), None) == 0, hip.pag_last_error()
+            assert hip.pag_successors(g, code, (ctg << 32) | rf, buf, len(buf)) == -34
+        finally:
+            hip.pag_destroy(g)
+            inp.close()
