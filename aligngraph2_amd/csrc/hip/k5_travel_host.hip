@@ -2582,7 +2582,7 @@ int pag_debug_trav_vertices(const pag_graph *g, uint32_t *code, uint64_t *pos) {
     return PAG_OK;
 }
 
-// PABruijnGraph::successors for one vertex of the prepared view (PABruijnGraph.cpp:167-197), see pagraph_hip.h
+// PABruijnGraph::successors for one vertex of the prepared view (PABruijnGraph.cpp:370-373 -> searchSuccessors :167-197), see pagraph_hip.h
 int64_t pag_successors(const pag_graph *g, uint32_t code, uint64_t pos, pag_succ *out, uint64_t cap) {
     if (!g || !g->tg_ready || (!out && cap)) return PAG_EINVAL;
     PAG_HIP_TRY(hipSetDevice(g->device));

@@ -388,8 +388,9 @@ int pag_travel_view_sizes(const pag_graph *g, uint64_t *n_nodes, uint64_t *n_pos
                           uint64_t *fallbacks);
 int pag_travel(pag_graph *g, const pag_seqs *ctgs, const int32_t *orient, const uint32_t *ref_len, uint64_t n_refs,
                const pag_travel_params *params, pag_travel_stats *stats);
-/* One vertex's graded successors as the reference's graph returns them — PABruijnGraph::successors (PABruijnGraph.cpp:167-197:
- * searchSuccessors x checkPosition != Oops, with isEdgeSimilar().first) with the deviation / error rate the view was prepared
+/* One vertex's graded successors as the reference's graph returns them — PABruijnGraph::successors (PABruijnGraph.cpp:370-373 ->
+ * searchSuccessors :167-197: every position of every child with checkPosition != Oops; the grade and isEdgeSimilar().first
+ * its caller computes per entry, PAlgorithm.tcc:45-58, come with it) with the deviation / error rate the view was prepared
  * with (pag_travel_prepare*), in the reference's order.  A vertex is named the way the reference's PANode names it, by value:
  * its k-mer code and its clustered position (contig coordinate << 32 | reference coordinate).  Returns the number of
  * successors (the first `cap` are written); PAG_EINVAL when the view is not prepared or holds no such vertex; PAG_ERANGE when
