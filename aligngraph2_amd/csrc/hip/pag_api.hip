@@ -661,7 +661,9 @@ extern "C" int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases) {
     size_t want = (size_t)contig_bases * 1200 + (64u << 20);
     size_t free_b = 0, total_b = 0;
     // (the same cap as pag_travel's own estimate: an arena reserved here must not be thrown away there as too small)
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5);
+    // (processes that share the device — PAG_DEVICE_SHARERS, the one-GPU test box — share that cap)
+    const size_t sharers = std::getenv("PAG_DEVICE_SHARERS") ? (size_t)std::max(1, std::atoi(std::getenv("PAG_DEVICE_SHARERS"))) : 1;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5 / sharers);
     // the pinned memory the fetched paths of the walks' jobs land in (64 MB chunks kept by the handle, pag_travel's
     // fetch_alloc): ~14 bytes per contig base at sequencing coverage; a cold process otherwise pins them one by one between
     // the walks' first fetches (5 ms each)

@@ -78,7 +78,11 @@ public:
     }
     std::uint64_t solidCount() override { return pag_solid_count(g_); }
     void reset() override { check(pag_reset(g_), "pag_reset"); }
-    void reserveForContigs(std::uint64_t bases) override { check(pag_reserve_walk_arena(g_, bases), "pag_reserve_walk_arena"); }
+    void reserveForContigs(std::uint64_t bases) override {
+        // (a rank of a sharded build walks the contigs it is dealt: about 1 / N of the block's, ShardPlan balances them by length)
+        if (comm_ && world_ > 1) bases = bases / world_ + bases / (4 * world_);
+        check(pag_reserve_walk_arena(g_, bases), "pag_reserve_walk_arena");
+    }
     void prepare(const RawInput &raw, pag_build_input &out) override {
         check(pag_prepare(g_, &raw.view(), &out), "pag_prepare");
         if (!comm_) return;
