@@ -255,7 +255,56 @@ __device__ __forceinline__ uint32_t node_of_code(const TravGraph &G, uint32_t co
     uint64_t w = G.bitmap[code >> 6];
     uint32_t b = code & 63u;
     if (!((w >> b) & 1ull)) return PAG_NONE;
-    return G.rank[code >> 6] + (uint32_t)__popcll(w & ((1ull << b) - 1ull));
+    const uint32_t in_code_order = G.rank[code >> 6] + (uint32_t)__popcll(w & ((1ull << b) - 1ull));
+    return G.nperm ? G.nperm[in_code_order] : in_code_order;
+}
+
+// ---- nodes numbered by place (round 5).  The compaction leaves the nodes in code order, the order of the build's sorted tuples:
+// a node's children — the k-mers that follow it in the reads — then lie anywhere in the node-major arrays, and so do the
+// coordinate-ordered slots its vertices' results go to: every candidate list, every count, every record of the successor stage
+// was a random 64-byte sector.  Numbered by WHERE the k-mer lies (the reference coordinate of the node's first vertex that has
+// one; a node known on a contig only: its contig coordinate, behind the others), a node's children are its neighbours, and the
+// coordinate order of its vertices runs alongside the node order.  Inside a node nothing moves (positions ascending, edges in
+// tuple order): the reference's order of a vertex's successors does not depend on how nodes are numbered.
+__global__ void k_node_place_keys(const uint32_t *__restrict__ npos_off, const uint64_t *__restrict__ vpos, uint64_t n_nodes, uint32_t shift,
+                                  uint32_t flag, uint32_t *__restrict__ key, uint64_t *__restrict__ val) {
+    for (uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = npos_off[n], b = npos_off[n + 1];
+        uint32_t kk = flag | ((uint32_t)(vpos[a] >> 32) >> shift);
+        for (uint32_t p = a; p < b; ++p) {
+            const uint32_t r = (uint32_t)vpos[p];
+            if (r != 0u) {
+                kk = r >> shift;
+                break;
+            }
+        }
+        key[n] = kk;
+        val[n] = n;
+    }
+}
+// new id i <- node perm[i] of the code order: its number of vertices, and where the code order's number finds it again
+__global__ void k_node_place_counts(const uint64_t *__restrict__ perm, const uint32_t *__restrict__ npos_off_old, uint64_t n_nodes,
+                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ nperm) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t o = (uint32_t)perm[i];
+        cnt[i] = npos_off_old[o + 1] - npos_off_old[o];
+        nperm[o] = (uint32_t)i;
+    }
+}
+__global__ void k_node_place_move(const uint64_t *__restrict__ perm, const uint64_t *__restrict__ off_new, const uint32_t *__restrict__ ncode_old,
+                                  const uint32_t *__restrict__ npos_off_old, const uint64_t *__restrict__ vpos_old, const uint16_t *__restrict__ vcnt_old,
+                                  uint64_t n_nodes, TravGraph G) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t o = (uint32_t)perm[i];
+        const uint32_t a = npos_off_old[o], b = npos_off_old[o + 1], d = (uint32_t)off_new[i];
+        G.ncode[i] = ncode_old[o];
+        G.npos_off[i] = d;
+        for (uint32_t j = 0; j < b - a; ++j) {
+            G.vpos[d + j] = vpos_old[a + j];
+            G.vcnt[d + j] = vcnt_old[a + j];
+            G.vnode[d + j] = (uint32_t)i;
+        }
+    }
 }
 
 // An edge of the traversal graph: eto = first position (k-mer-major vertex id) of the target node (PAG_NONE: the target has no
@@ -3171,7 +3220,9 @@ static unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 
 int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
                  const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
                  uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view,
-                 uint64_t *counts_out) {
+                 uint64_t *counts_out, int place_bits) {
+    // place_bits != 0 (and G.nperm, G.uold / newid / upos / ucnt / succ_off allocated: they are scratch here): the nodes are
+    // numbered by place — place_bits = width of the wider of the two coordinate spaces
     // tmp: flags u32[max(T, E, words, nodes + 1)] | scan out u64[same] | scan out 2 u64[T] | keep u32[T] | scan tmp
     // view != null: only the vertices inside its intervals (device arrays) are taken; counts_out[3] = nodes, vertices, edges
     // of the view (n_nodes / n_pos / n_edges are then upper bounds: what the arrays of G were sized for)
@@ -3188,7 +3239,7 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     uint64_t *sc2 = (uint64_t *)take(m * 8);
     uint32_t *keep = (uint32_t *)take(m * 4);
     uint64_t *totals = (uint64_t *)take(64);
-    void *scan_tmp = take(scan_tmp_bytes(m));
+    void *scan_tmp = take(std::max(scan_tmp_bytes(m), sort_tmp_bytes(n_nodes + 1)));
     uint64_t *code_tab = k <= TRAV_CODE_TABLE_MAX_K ? (uint64_t *)take((size_t)8 << (2 * k)) : nullptr;
     if ((size_t)(p - (char *)tmp) > tmp_bytes) {
         set_error("trav_compact: scratch too small");
@@ -3196,6 +3247,8 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     }
     PAG_HIP_TRY(hipMemsetAsync(G.bitmap, 0, n_words * 8, s));
     int rc;
+    const bool by_place = place_bits > 0 && G.nperm != nullptr;
+    if (!by_place) G.nperm = nullptr;
     if (T) {
         const uint64_t n_tiles = (T + VC_TILE - 1) / VC_TILE;
         uint32_t *tile_first = flags, *tile_keep = keep;  // (n_tiles counters each)
@@ -3206,7 +3259,15 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
         k_view_mark<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tseg, T, civ, n_civ, riv, n_riv, view ? 0 : 1, ballots, tile_first, tile_keep, n_tiles);
         if ((rc = scan_u32_to_u64(tile_first, sc1, n_tiles, totals, scan_tmp, s))) return rc;
         if ((rc = scan_u32_to_u64(tile_keep, sc2, n_tiles, totals + 1, scan_tmp, s))) return rc;
-        k_view_write<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tcnt, ballots, sc1, sc2, n_tiles, G);
+        // (numbered by place: the code-ordered nodes and vertices go to arrays that are free until the coordinate order is made)
+        TravGraph Gw = G;
+        if (by_place) {
+            Gw.ncode = G.newid;
+            Gw.npos_off = G.uold;
+            Gw.vpos = G.upos;
+            Gw.vcnt = (uint16_t *)G.ucnt;
+        }
+        k_view_write<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tcnt, ballots, sc1, sc2, n_tiles, Gw);
     }
     if (view) {
         uint64_t h[2] = {0, 0};
@@ -3224,7 +3285,25 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
         G.n_pos = n_pos;
     }
     uint32_t np32 = (uint32_t)n_pos;
-    PAG_HIP_TRY(hipMemcpyAsync(G.npos_off + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
+    PAG_HIP_TRY(hipMemcpyAsync((by_place ? G.uold : G.npos_off) + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
+    if (by_place && n_nodes) {
+        const uint32_t *ncode_old = G.newid, *npos_off_old = G.uold;
+        const uint64_t *vpos_old = G.upos;
+        const uint16_t *vcnt_old = (const uint16_t *)G.ucnt;
+        const int kb = std::min(32, place_bits + 1);
+        const uint32_t shift = (uint32_t)(place_bits + 1 - kb), flag = 1u << (kb - 1);
+        uint32_t *key0 = keep, *key1 = G.succ_off;
+        uint64_t *val0 = sc2, *val1 = sc1;
+        k_node_place_keys<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(npos_off_old, vpos_old, n_nodes, shift, flag, key0, val0);
+        int in0 = 1;
+        if ((rc = sort_pairs(key0, val0, key1, val1, n_nodes, kb, scan_tmp, &in0, s, nullptr, nullptr))) return rc;
+        const uint64_t *perm = in0 ? val0 : val1;
+        uint64_t *off_new = in0 ? val1 : val0;  // (the other value array is free)
+        k_node_place_counts<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(perm, npos_off_old, n_nodes, flags, G.nperm);
+        if ((rc = scan_u32_to_u64(flags, off_new, n_nodes, nullptr, scan_tmp, s))) return rc;  // (the sort is done with its scratch)
+        k_node_place_move<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(perm, off_new, ncode_old, npos_off_old, vpos_old, vcnt_old, n_nodes, G);
+        PAG_HIP_TRY(hipMemcpyAsync(G.npos_off + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
+    }
     // rank directory
     k_popc_words<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(G.bitmap, n_words, flags);
     if ((rc = scan_u32_to_u64(flags, sc1, n_words, nullptr, scan_tmp, s))) return rc;
@@ -3263,7 +3342,7 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes) {
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
     uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
-    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024 + 256 +
+    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((std::max(scan_tmp_bytes(m), sort_tmp_bytes(n_nodes + 1)) + 255) & ~(size_t)255) + 1024 + 256 +
            (k <= TRAV_CODE_TABLE_MAX_K ? ((size_t)8 << (2 * k)) + 256 : 0);
 }
 
@@ -3438,7 +3517,8 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     {
         // (eight slices once the two arrays — 6 bytes per vertex — outgrow the Infinity Cache: 16.2 -> 12.5 ms at configs[1],
         // 13.2 with four or sixteen, tests/order_probe.sh; PAG_ORDER_SLICES=<2^n> overrides)
-        uint32_t lg = n >= (32ull << 20) ? 3u : 0u;
+        // (nodes numbered by place: newid[v] / vcnt[v] are touched nearly in order — nothing to slice)
+        uint32_t lg = n >= (32ull << 20) && !G.nperm ? 3u : 0u;
         if (const char *e = std::getenv("PAG_ORDER_SLICES")) {
             const uint32_t want = (uint32_t)std::max(1, std::atoi(e));
             lg = 0;
@@ -3450,6 +3530,28 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
         const uint32_t shift = lg ? bits - lg : 32u;
         for (uint32_t sl = 0; sl < (1u << lg); ++sl)
             k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, vs, n, n0 > 1 ? n0 : 0, G, sl, shift);
+    }
+    PAG_HIP_TRY(hipGetLastError());
+    return PAG_OK;
+}
+// blockIdx.y = range; 16 bytes per lane and turn where the range allows (the job buffers are 256-byte aligned), bytes at its edges
+__global__ void k_clear_ranges(const TravClear *__restrict__ ranges) {
+    const TravClear c = ranges[blockIdx.y];
+    uint8_t *p = (uint8_t *)c.p;
+    const uint64_t head = (16u - ((uintptr_t)p & 15u)) & 15u, h = head < c.bytes ? head : c.bytes;
+    const uint64_t n16 = (c.bytes - h) >> 4, tail = (c.bytes - h) & 15u;
+    uint4 *q = (uint4 *)(p + h);
+    const uint4 w = make_uint4(c.word, c.word, c.word, c.word);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) q[i] = w;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h) p[threadIdx.x] = (uint8_t)c.word;
+        if (threadIdx.x < tail) p[h + (n16 << 4) + threadIdx.x] = (uint8_t)c.word;
+    }
+}
+int trav_clear_ranges(const TravClear *ranges_dev, size_t n, hipStream_t s) {
+    for (size_t at = 0; at < n; at += 32768) {
+        const uint32_t m = (uint32_t)std::min<size_t>(32768, n - at);
+        k_clear_ranges<<<dim3(32, m), dim3(256), 0, s>>>(ranges_dev + at);
     }
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;

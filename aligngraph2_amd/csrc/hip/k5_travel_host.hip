@@ -157,7 +157,7 @@ uint64_t pow2_at_least(uint64_t x) {
 // successor records of every vertex (searchSuccessors + checkPosition for all of them, PABruijnGraph.cpp:143-197) — built
 // once per graph and pair of (deviation, error rate), kept in the handle (g->tg).  Pool slots TRAV_SLOT0 .. + TRAV_GRAPH_SLOTS.
 constexpr int TRAV_GRAPH_SLOTS = 22;  // (+ 2 behind them for a regional graph's incomplete-vertex bitmap, + 2 for the view's scratch)
-constexpr int TRAV_EXTRA_SLOTS = 4;
+constexpr int TRAV_EXTRA_SLOTS = 5;  // (incomplete-vertex bitmap + its scratch, the view's two, the node permutation)
 
 // ---- the view of ONE handle's traversals -----------------------------------------------------------------------------
 // A traversal of contig strand S (PAlgorithm::travelSequence for one (contig, orientation)) only ever examines
@@ -387,8 +387,23 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             }
         }
         uint64_t counts[3] = {nn, np, ne};
+        // (key widths of the coordinate sorts: the single-coordinate spaces of the contigs and of the references)
+        auto bits_of = [](const uint32_t *len, uint64_t n) {
+            const uint64_t space = Mapper(len, n).starts.empty() ? 1 : Mapper(len, n).starts.back();
+            int b = 1;
+            while (b < 32 && (space >> b) != 0) ++b;
+            return b;
+        };
+        const int ctg_bits = bits_of(ctg_len, n_ctgs), ref_bits = bits_of(ref_len, n_refs);
+        // the nodes numbered by place (trav_compact): the permutation stays with the graph (node_of_code)
+        DevBuf b_nperm(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 4);
+        G.nperm = nullptr;
+        if (cfg.nodes_by_place) {
+            if ((rc = b_nperm.alloc((nn + 1) * 4))) return rc;
+            G.nperm = b_nperm.as<uint32_t>();
+        }
         if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
-                               b_ctmp.p, tb, s, prune ? &tv : nullptr, counts)))
+                               b_ctmp.p, tb, s, prune ? &tv : nullptr, counts, cfg.nodes_by_place ? std::max(ctg_bits, ref_bits) : 0)))
             return rc;
         if (prune) {
             G.n_nodes = counts[0];
@@ -404,15 +419,8 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 8) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
             (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
             return rc;
-        // (key widths of the two sorts: the single-coordinate spaces of the contigs and of the references)
-        auto bits_of = [](const uint32_t *len, uint64_t n) {
-            const uint64_t space = Mapper(len, n).starts.empty() ? 1 : Mapper(len, n).starts.back();
-            int b = 1;
-            while (b < 32 && (space >> b) != 0) ++b;
-            return b;
-        };
         if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg,
-                             bits_of(ctg_len, n_ctgs), bits_of(ref_len, n_refs), s)))
+                             ctg_bits, ref_bits, s)))
             return rc;
         // a graph that holds a region of the block only: which coordinate-free vertices may have successors beyond it
         G.incomplete = nullptr;
@@ -639,7 +647,7 @@ struct WalkSession {
     uint32_t n_ctgs = 0, n_sel = 0;
     std::vector<CtgState> st;  // one entry per (contig, orientation) that is walked
     uint64_t nodes_total = 0;
-    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout, b_fetch, b_fdesc;
+    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout, b_clr, b_fetch, b_fdesc;
     std::vector<TravContig> tc;
     static constexpr uint32_t SEED_STRIDE = 4096;
     void fill_contigs() {
@@ -779,6 +787,23 @@ struct WalkSession {
         uint32_t win_low = 0;             // TRAV_MODE_LEAP: forced lower end of the travel coordinate window
     };
     bool need_publish = false;
+    // what the posted batches want cleared before their jobs become visible (hash sets, stamps, travel bits): collected, and
+    // cleared by ONE launch when the batch is published (trav_clear_ranges) — five hipMemsetAsync per batch, 673 fill kernels of
+    // ~14 us per block at configs[1], ran one after the other on the stream in front of the first job
+    std::vector<TravClear> clears;
+    void want_clear(void *p, size_t bytes, uint32_t byte_value) {
+        if (bytes) clears.push_back(TravClear{p, (uint64_t)bytes, byte_value * 0x01010101u, 0u});
+    }
+    int flush_clears() {
+        if (clears.empty()) return PAG_OK;
+        int r;
+        if ((r = b_clr.alloc(clears.size() * sizeof(TravClear)))) return r;
+        PAG_HIP_TRY(hipMemcpyAsync(b_clr.p, clears.data(), clears.size() * sizeof(TravClear), hipMemcpyHostToDevice, s));
+        if ((r = trav_clear_ranges(b_clr.as<TravClear>(), clears.size(), s))) return r;
+        PAG_HIP_TRY(hipStreamSynchronize(s));  // (the list is read by the copy until then)
+        clears.clear();
+        return PAG_OK;
+    }
     // a prepared job enters its ring (in posting order; the walker takes the rings' jobs in that order)
     struct Deferred {
         TravPosted P;
@@ -904,11 +929,11 @@ struct WalkSession {
                     if ((r = bufs[q]->alloc(need[q]))) return r;
             }
         }
-        if (o_x[nj]) PAG_HIP_TRY(hipMemsetAsync(b_sx.p, 0, o_x[nj] * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_ts.p, 0xFF, o_oc[nj] * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_ps.p, 0, o_oc[nj] * PG * 8, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_st.p, 0, o_st[nj] * 4, s));
-        PAG_HIP_TRY(hipMemsetAsync(b_tb.p, 0, o_tb[nj] * 4, s));
+        want_clear(b_sx.p, o_x[nj] * 8, 0u);
+        want_clear(b_ts.p, o_oc[nj] * 8, 0xFFu);
+        want_clear(b_ps.p, o_oc[nj] * PG * 8, 0u);
+        want_clear(b_st.p, o_st[nj] * 4, 0u);
+        want_clear(b_tb.p, o_tb[nj] * 4, 0u);
         fill_contigs();
         for (size_t j = 0; j < nj; ++j) {
             const JobPlan &pl = plans[j];
@@ -983,6 +1008,8 @@ struct WalkSession {
     }
     int publish() {  // after the prepared buffers are ready on the device
         if (!need_publish) return PAG_OK;
+        int rcl;
+        if ((rcl = flush_clears())) return rcl;
         PAG_HIP_TRY(hipStreamSynchronize(s));
         for (uint32_t r = NR; r-- > 0;) __atomic_store_n(&hq->posted[r], n_posted[r], __ATOMIC_RELEASE);
         need_publish = false;
@@ -1591,7 +1618,7 @@ struct WalkSession {
         use_leap_pieces = cfg.leap_pieces;
         deferred.clear();
         deferred.resize(n_sel);
-        b_ckreq = buf(), b_ckout = buf();
+        b_ckreq = buf(), b_ckout = buf(), b_clr = buf();
         return PAG_OK;
     }
     // pinned staging + the walk arena

@@ -10,7 +10,9 @@ namespace pagdev {
 // probe slots of a walker wave (lane groups); sizes the per-job stamp arrays, outside sets and arena shares
 constexpr int TRAV_PROBE_GROUPS = 8;
 
-// compact CSR of the finished graph, dense ids: node = k-mer with >= 1 vertex (ascending code),
+// compact CSR of the finished graph, dense ids: node = k-mer with >= 1 vertex — numbered BY PLACE (round 5, trav_compact: by the
+// reference coordinate of the node's first vertex that has one, so that a k-mer's children, the k-mers that follow it in the
+// reads, are its neighbours in every node-major array), or by ascending code (nperm == null) —,
 // vertex = clustered position (node-major, inside a node ascending (ctg, ref))
 struct TravGraph {
     uint64_t n_nodes, n_pos, n_edges;
@@ -24,6 +26,7 @@ struct TravGraph {
     uint32_t *estep;      // [n_edges] step | min(number of the child's positions, 255) << 24 (k5_travel.hip edge_target)
     uint64_t *bitmap;     // 4^k bits: k-mer code owns a node
     uint32_t *rank;       // per 64-bit bitmap word: nodes before it
+    uint32_t *nperm;      // [n_nodes] number of the node among the nodes in code order -> node id (null: the ids ARE in code order)
     // coordinate order ("new ids" u): [ctg == 0 vertices] ++ [ctg != 0 ascending]
     uint32_t *uold;       // [n_pos] new id -> vertex id
     uint32_t *newid;      // [n_pos] vertex id -> new id
@@ -172,7 +175,7 @@ struct TravView {
 int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
                  const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
                  uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view = nullptr,
-                 uint64_t *counts_out = nullptr);
+                 uint64_t *counts_out = nullptr, int place_bits = 0);
 int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev, uint32_t n_z, uint32_t *lo_dev, uint32_t *hi_dev, hipStream_t s);
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes);
 void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
@@ -202,6 +205,13 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
                int ref_bits, hipStream_t s);
 // successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
 // bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
+// device ranges cleared by one launch (the buffers of the walk jobs of a batch): `bytes` bytes at p set to the bytes of `word`
+struct TravClear {
+    void *p;
+    uint64_t bytes;
+    uint32_t word, pad;
+};
+int trav_clear_ranges(const TravClear *ranges_dev, size_t n, hipStream_t s);
 // the records of ONE vertex named by (code, position), translated back to (code, position) of their targets (pag_successors):
 // out[0] = number of records or ~0 (no such vertex) / ~1 (its list is a marker), written to recs (32 bytes each) up to cap
 int trav_successors_of(TravGraph G, uint32_t code, uint64_t pos, void *recs, uint64_t cap, unsigned long long *out, hipStream_t s);

@@ -12,6 +12,7 @@ namespace pagdev {
 struct WalkConfig {
     // ---- the view (trav_view_region)
     bool view_whole = false;          // PAG_TRAVEL_VIEW=whole: never cut the view to the walked orientations
+    bool nodes_by_place = false;      // PAG_NODE_ORDER=place: the traversal graph's nodes numbered by place instead of by k-mer code (measured slower)
     uint64_t view_halo = 100000;      // PAG_VIEW_HALO
     bool view_margin_set = false;     // PAG_VIEW_MARGIN given: view_margin bases instead of max(4000, 3 % of the contig)
     uint64_t view_margin = 4000;
@@ -64,6 +65,7 @@ struct WalkConfig {
     static WalkConfig from_env() {
         WalkConfig c;
         if (const char *e = std::getenv("PAG_TRAVEL_VIEW")) c.view_whole = std::strcmp(e, "whole") == 0;
+        if (const char *e = std::getenv("PAG_NODE_ORDER")) c.nodes_by_place = std::strcmp(e, "place") == 0;
         if (const char *e = std::getenv("PAG_VIEW_HALO")) c.view_halo = (uint64_t)std::max(0ll, std::atoll(e));
         if (const char *e = std::getenv("PAG_VIEW_MARGIN")) {
             c.view_margin_set = true;

@@ -22,7 +22,7 @@ EXE = os.path.join(pagctl.ROOT, "aligngraph2_amd", "bin", "pagraph")
 # can leap and are spliced under other conditions, k5_travel_host.hip try_merge_leap); "pieces-noleap" leaves the leaping
 # zone to one exact walk, as round 1 of the cut did
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact", "pieces-noleap"])
+@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact", "pieces-noleap", "pieces-by-place"])
 @pytest.mark.parametrize("name", goldens.case_names())
 def test_pagraph_matches_golden(name, mode, workdir):
     spec = goldens.load_spec(name)
@@ -31,7 +31,7 @@ def test_pagraph_matches_golden(name, mode, workdir):
     os.makedirs(out, exist_ok=True)
     argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
     env = dict(os.environ)
-    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES", "PAG_LEAP_PIECES", "PAG_LEAP_FIRST"):
+    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES", "PAG_LEAP_PIECES", "PAG_LEAP_FIRST", "PAG_NODE_ORDER"):
         env.pop(v, None)
     if mode.startswith("pieces"):
         # (PAG_DEBUG_CHECK_AGGS: the block tables the pack kernel attaches to every fetched path are recomputed on the host and compared)
@@ -40,6 +40,8 @@ def test_pagraph_matches_golden(name, mode, workdir):
         env["PAG_WALK_EXACT"] = "1"
     if mode.endswith("noleap"):
         env["PAG_LEAP_PIECES"] = "0"
+    if mode.endswith("by-place"):  # (the traversal graph's nodes numbered by place instead of by code: same files)
+        env["PAG_NODE_ORDER"] = "place"
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     assert "HIP gfx950" in r.stdout

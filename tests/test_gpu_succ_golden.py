@@ -162,6 +162,8 @@ MODES = [  # (label, view, environment)
     ("whole fused heavy=4", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4"}),
     ("whole fused heavy=0", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "0"}),
     ("whole by PAG_TRAVEL_VIEW", "for", {"PAG_TRAVEL_VIEW": "whole"}),
+    ("whole, nodes numbered by place", "whole", {"PAG_NODE_ORDER": "place"}),
+    ("cut tight, nodes numbered by place", "for", {"PAG_NODE_ORDER": "place", "PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut default", "for", {}),
     ("cut tight twopass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight twopass heavy=4", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
@@ -169,7 +171,7 @@ MODES = [  # (label, view, environment)
     ("cut tight fused", "for", {"PAG_SUCC_MODE": "fused", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight fused heavy=4", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
 ]
-SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS")
+SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS", "PAG_NODE_ORDER")
 
 
 @pytest.mark.gpu
