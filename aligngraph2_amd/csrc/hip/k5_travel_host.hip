@@ -575,7 +575,16 @@ struct WalkSession {
     hipStream_t s = nullptr;
     double t_begin = 0;
     const WalkConfig cfg;
-    bool timing = false, wdebug = false;
+    bool timing = false, wdebug = false, wtrace = false;
+    // PAG_WALK_TRACE: what = 0 job done (a, b = device begin / end in 10 ns ticks), 1 job posted (a = ring, b = mode), 2 round over
+    // (a = round, b = leap), 3 round started (a = round, b = seeds)
+    struct TraceEv {
+        double t;
+        uint32_t what, ctg;
+        int32_t kind, idx;
+        uint64_t a, b, len, classify;
+    };
+    std::vector<TraceEv> trace;
     double lap_t = 0;
     std::vector<std::pair<const char *, double>> laps;
     uint32_t k = 0;
@@ -647,7 +656,7 @@ struct WalkSession {
     uint32_t n_ctgs = 0, n_sel = 0;
     std::vector<CtgState> st;  // one entry per (contig, orientation) that is walked
     uint64_t nodes_total = 0;
-    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout, b_clr, b_fetch, b_fdesc;
+    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout, b_fetch, b_fdesc;
     std::vector<TravContig> tc;
     static constexpr uint32_t SEED_STRIDE = 4096;
     void fill_contigs() {
@@ -794,15 +803,14 @@ struct WalkSession {
     void want_clear(void *p, size_t bytes, uint32_t byte_value) {
         if (bytes) clears.push_back(TravClear{p, (uint64_t)bytes, byte_value * 0x01010101u, 0u});
     }
-    int flush_clears() {
+    int flush_clears() {  // (asynchronous: the list is read from pinned memory that lives as long as the walks; publish() waits for the stream)
         if (clears.empty()) return PAG_OK;
-        int r;
-        if ((r = b_clr.alloc(clears.size() * sizeof(TravClear)))) return r;
-        PAG_HIP_TRY(hipMemcpyAsync(b_clr.p, clears.data(), clears.size() * sizeof(TravClear), hipMemcpyHostToDevice, s));
-        if ((r = trav_clear_ranges(b_clr.as<TravClear>(), clears.size(), s))) return r;
-        PAG_HIP_TRY(hipStreamSynchronize(s));  // (the list is read by the copy until then)
+        TravClear *d = (TravClear *)fetch_alloc(clears.size() * sizeof(TravClear));
+        if (!d) return PAG_ENOMEM;
+        std::memcpy(d, clears.data(), clears.size() * sizeof(TravClear));
+        const int r = trav_clear_ranges(d, clears.size(), s);
         clears.clear();
-        return PAG_OK;
+        return r;
     }
     // a prepared job enters its ring (in posting order; the walker takes the rings' jobs in that order)
     struct Deferred {
@@ -838,6 +846,7 @@ struct WalkSession {
         n_live += 1;
         RS[jr2.ctg].live_jobs += 1;
         jobs_total += 1;
+        if (wtrace) trace.push_back(TraceEv{now_ms() - tw0, 1u, jr2.ctg, (int32_t)jr2.kind, (int32_t)jr2.idx, ring, mode, jr2.init_len, 0});
         if (!backlog[ring].empty() || !place_job(ring, P, jr2)) backlog[ring].push_back(Backlogged{P, jr2});
         return PAG_OK;
     }
@@ -1008,12 +1017,20 @@ struct WalkSession {
     }
     int publish() {  // after the prepared buffers are ready on the device
         if (!need_publish) return PAG_OK;
+        auto tmark = [&](const char *what) {
+            if (wtrace) trace.push_back(TraceEv{now_ms() - tw0, 4u, n_live, 0, 0, (uint64_t)(uintptr_t)what, 0, clears.size(), 0});
+        };
+        tmark("publish: begin");
         int rcl;
         if ((rcl = flush_clears())) return rcl;
+        tmark("publish: clears launched");
         PAG_HIP_TRY(hipStreamSynchronize(s));
+        tmark("publish: stream idle");
         for (uint32_t r = NR; r-- > 0;) __atomic_store_n(&hq->posted[r], n_posted[r], __ATOMIC_RELEASE);
         need_publish = false;
-        return walkers.g ? walkers.ensure(n_live) : PAG_OK;  // (before the first launch: pag_travel starts the waves itself)
+        const int rcw = walkers.g ? walkers.ensure(n_live) : PAG_OK;  // (before the first launch: pag_travel starts the waves itself)
+        tmark("publish: waves");
+        return rcw;
     }
 
     // ---- start of a round of contig i: its seeds are in cs.seeds.  Decides where the walk can be cut, finds the checkpoint
@@ -1276,7 +1293,8 @@ struct WalkSession {
         if ((r = find_checkpoints(reqs, out))) return r;
         make_segments(which, RP, out, co);
         if ((r = find_id_bounds(co, ids))) return r;
-        return post_round_jobs(which, RP, ids);
+        if ((r = post_round_jobs(which, RP, ids))) return r;
+        return flush_clears();  // (one launch for the buffers of all these rounds, under way while this thread goes on)
     }
 
     // continue chain c of contig i exactly: the path so far goes to the walker as a RESUME job
@@ -1286,7 +1304,7 @@ struct WalkSession {
         Chain &ch = RS[i].chains[(size_t)c];
         const uint64_t cap = std::max<uint64_t>(cs.seqCap * ch.grow, ch.len + cs.seqCap / 4 + 4096);
         std::vector<JobPlan> plans{JobPlan{0, c, cap, cs.seeds[(size_t)c].vid, (uint32_t)(TRAV_MODE_RESUME | (until_leap ? TRAV_MODE_UNTIL_LEAP : 0)), stop, &ch, ch.exact}};
-        return post_batch(i, GRP_CHAIN0 + c, plans);
+        return post_batch(i, GRP_CHAIN0 + c, plans);  // (its buffers are cleared with those of the other resumed walks of this turn: stitch_finished)
     }
 
     // adoption of a finished segment by a chain (conditions and their justification: walk_stitch.hpp)
@@ -1304,22 +1322,8 @@ struct WalkSession {
         }
         return M;
     }
-    // what a chain does after its job has ended at a stop coordinate or after a segment it waits for has finished
-    // (walk_stitch.hpp advance_chain: adoptions, then how the chain goes on)
+    // totals of what the chains adopted (walk_stitch.hpp advance_chain, called from stitch_finished)
     stitch::AdvanceStats adv_stats;
-    int advance(uint32_t i, int c) {
-        RoundState &R = RS[i];
-        Chain &ch = R.chains[(size_t)c];
-        const uint64_t fails_before = adv_stats.merge_fail;
-        const Next nx = advance_chain(R, ch, merge_ctx(i), seg_ov, adv_stats);
-        n_adopted = adv_stats.adopted;
-        n_leap_adopted = adv_stats.leap_adopted;
-        n_merge_fail = adv_stats.merge_fail;
-        for (int w = 0; w < 8; ++w) n_leap_refused[w] = adv_stats.leap_refused[w];
-        if (wdebug && adv_stats.merge_fail != fails_before) std::fprintf(stderr, "[walk] contig %u chain %d: a segment was not adoptable, walking on exactly\n", i, c);
-        if (nx.what == Next::Resume) return post_resume(i, c, nx.stop, nx.until_leap);
-        return PAG_OK;
-    }
 
     int fail(int rc2) {
         shutdown_walker();
@@ -1455,6 +1459,7 @@ struct WalkSession {
         t_begin = now_ms();
         timing = cfg.timing;
         wdebug = cfg.walk_debug;
+        wtrace = cfg.walk_trace;
         lap_t = t_begin;
         k = g->k;
         deviation = prm->deviation;
@@ -1618,7 +1623,7 @@ struct WalkSession {
         use_leap_pieces = cfg.leap_pieces;
         deferred.clear();
         deferred.resize(n_sel);
-        b_ckreq = buf(), b_ckout = buf(), b_clr = buf();
+        b_ckreq = buf(), b_ckout = buf();
         return PAG_OK;
     }
     // pinned staging + the walk arena
@@ -1968,6 +1973,12 @@ struct WalkSession {
             sg.done = true;
         }
         const double ts2 = now_ms();
+        if (wtrace)
+            for (Got &G2 : got) {
+                const JobRef &jr = jref[G2.jn];
+                const TravJobOut &o = houts[G2.jn];
+                trace.push_back(TraceEv{ts2 - tw0, 0u, jr.ctg, (int32_t)jr.kind, (int32_t)jr.idx, o.t_begin, o.t_end, G2.len, o.n_classify});
+            }
         if (wdebug)
             for (Got &G2 : got) {
                 const uint32_t slot = G2.jn;
@@ -1996,14 +2007,58 @@ struct WalkSession {
             }
         std::sort(touched.begin(), touched.end());
         touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
-        for (uint32_t i : touched) {  // the chains of the touched contigs move on (adoptions, resumed walks)
-            RoundState &R = RS[i];
-            for (size_t c = 0; c < R.chains.size(); ++c) {
-                Chain &ch = R.chains[c];
-                if (ch.final || ch.job >= 0) continue;
-                if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
-                if ((rc = advance(i, (int)c))) return fail(rc);
+        // the chains of the touched contigs move on: adoptions (advance_chain reads the round's segments and writes its chain
+        // only: the chains are independent, those of one contig too), then the resumed walks are posted by this thread.  Host
+        // threads since round 5: when the device runs out of first-round work, ~900 segments finish within 15 ms and their
+        // adoptions — 5 us each, 24 ms per block — were what the control thread was busy with while finished chain jobs waited
+        // (tests/walk_trace.py: laps of 3-4 ms per loop iteration in the last 30 ms of the walks).
+        {
+            struct AdvTask {
+                uint32_t i;
+                int c;
+                Next nx;
+            };
+            std::vector<AdvTask> tasks;
+            for (uint32_t i : touched) {
+                RoundState &R = RS[i];
+                for (size_t c = 0; c < R.chains.size(); ++c) {
+                    const Chain &ch = R.chains[c];
+                    if (ch.final || ch.job >= 0) continue;
+                    if (ch.waiting_seg >= 0 && !R.segs[(size_t)ch.waiting_seg].done) continue;
+                    tasks.push_back(AdvTask{i, (int)c, Next{}});
+                }
             }
+            const unsigned nthr = (unsigned)std::min<size_t>(tasks.size() / 2, cfg.stitch_threads);
+            const uint64_t fails_before = adv_stats.merge_fail;
+            auto run = [&](std::atomic<size_t> &next, stitch::AdvanceStats &S) {
+                for (size_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1))
+                    tasks[t].nx = advance_chain(RS[tasks[t].i], RS[tasks[t].i].chains[(size_t)tasks[t].c], merge_ctx(tasks[t].i), seg_ov, S);
+            };
+            std::atomic<size_t> next{0};
+            if (nthr <= 1) {
+                run(next, adv_stats);
+            } else {
+                std::vector<stitch::AdvanceStats> part(nthr);
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < nthr; ++t) pool.emplace_back([&, t]() { run(next, part[t]); });
+                run(next, part[0]);
+                for (auto &th : pool) th.join();
+                for (const stitch::AdvanceStats &S : part) {
+                    adv_stats.adopted += S.adopted;
+                    adv_stats.leap_adopted += S.leap_adopted;
+                    adv_stats.merge_fail += S.merge_fail;
+                    for (int w = 0; w < 8; ++w) adv_stats.leap_refused[w] += S.leap_refused[w];
+                }
+            }
+            n_adopted = adv_stats.adopted;
+            n_leap_adopted = adv_stats.leap_adopted;
+            n_merge_fail = adv_stats.merge_fail;
+            for (int w = 0; w < 8; ++w) n_leap_refused[w] = adv_stats.leap_refused[w];
+            if (wdebug && adv_stats.merge_fail != fails_before)
+                std::fprintf(stderr, "[walk] %llu segments were not adoptable, walking on exactly\n", (unsigned long long)(adv_stats.merge_fail - fails_before));
+            for (const AdvTask &T : tasks)
+                if (T.nx.what == Next::Resume && (rc = post_resume(T.i, T.c, T.nx.stop, T.nx.until_leap))) return fail(rc);
+            if ((rc = flush_clears())) return fail(rc);
         }
         t_st[0] += ts1 - ts0;
         t_st[1] += ts2 - ts1;
@@ -2073,6 +2128,7 @@ struct WalkSession {
                     P.len = R.chains[(size_t)P.chosen].len;
                     tot += P.len;  // (an upper bound: walks that stay on the device take no room, see below)
                 }
+                if (wtrace) trace.push_back(TraceEv{now_ms() - tw0, 2u, i, 0, P.chosen, R.round, P.leap ? 1u : 0u, P.chosen >= 0 ? R.chains[(size_t)P.chosen].len : 0, 0});
                 if (wdebug && P.chosen >= 0) {
                     const Chain &ch = R.chains[(size_t)P.chosen];
                     const uint32_t last_ctg = ch.len == 0 ? 0u : ch.parts.back().pc[ch.parts.back().n - 1];
@@ -2409,6 +2465,7 @@ struct WalkSession {
             if (again) continue;
             auto mark = [&](const char *what) {  // (PAG_WALK_DEBUG: where this thread's time goes, iteration by iteration)
                 if (wdebug) std::fprintf(stderr, "[walk] t=%.1f ms loop: %s (%zu jobs, %zu contigs decided, %u live)\n", now_ms() - tw0, what, fin.size(), batch.size(), n_live);
+                if (wtrace) trace.push_back(TraceEv{now_ms() - tw0, 4u, n_live, 0, 0, (uint64_t)(uintptr_t)what, 0, fin.size(), batch.size()});
             };
             mark("polled");
             std::vector<Got> got;
@@ -2456,6 +2513,25 @@ struct WalkSession {
         pinned_parked.clear();
         t_walk = now_ms() - tw0;
         lap("walk");
+        if (wtrace) {
+            uint64_t d0 = ~0ull;
+            for (const TraceEv &e : trace)
+                if (e.what == 0u) d0 = std::min(d0, e.a);
+            std::fprintf(stderr, "[trace] walks %.2f ms, %zu events; device times relative to the first job's begin\n", t_walk, trace.size());
+            for (const TraceEv &e : trace) {
+                if (e.what == 0u)
+                    std::fprintf(stderr, "[trace] done t=%.2f ctg %u %s %d dev %.2f..%.2f len %llu classify %llu\n", e.t, e.ctg, e.kind ? "seg" : "chain", e.idx, (double)(e.a - d0) * 1e-5,
+                                 (double)(e.b - d0) * 1e-5, (unsigned long long)e.len, (unsigned long long)e.classify);
+                else if (e.what == 4u)
+                    std::fprintf(stderr, "[trace] loop t=%.2f %s jobs %llu decided %llu live %u\n", e.t, (const char *)(uintptr_t)e.a, (unsigned long long)e.len, (unsigned long long)e.classify, e.ctg);
+                else if (e.what == 1u)
+                    std::fprintf(stderr, "[trace] post t=%.2f ctg %u %s %d ring %llu mode %llu init %llu\n", e.t, e.ctg, e.kind ? "seg" : "chain", e.idx, (unsigned long long)e.a, (unsigned long long)e.b,
+                                 (unsigned long long)e.len);
+                else
+                    std::fprintf(stderr, "[trace] over t=%.2f ctg %u round %llu chain %d len %llu%s\n", e.t, e.ctg, (unsigned long long)e.a, e.idx, (unsigned long long)e.len, e.b ? " leap" : "");
+            }
+            trace.clear();
+        }
         if (timing || wdebug) {
             std::fprintf(stderr, "[timing] stitch: bookkeeping %.1f ms, paths %.1f ms, chains %.1f ms; posting jobs (all callers) %.1f ms; fetch memory: chunk %zu of %zu; walk arena: %.2f of %.2f GB used\n", t_st[0], t_st[1], t_st[2], t_st[3],
                          fetch_chunk + 1, g->fetch_chunks.size(), g->walk_arena_used / 1e9, g->walk_arena_cap / 1e9);

@@ -25,6 +25,7 @@
 using namespace pagdev;
 
 #include "pag_graph_impl.hpp"
+#include "walker_grid.hpp"
 
 namespace {
 
@@ -683,6 +684,8 @@ extern "C" int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases) {
             have += FETCH_CHUNK;
         }
     }
+    // (and the streams the walker waves are launched on: ~6 ms each to create, here beside the caller's other work)
+    pagdev::WalkerGrid::prepare_streams(g, 4);
     if (g->walk_arena_cap >= want) return PAG_OK;
     if (g->walk_arena) hipFree(g->walk_arena);
     g->walk_arena = nullptr;

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 
 namespace pagdev {
 
@@ -21,6 +22,8 @@ struct WalkConfig {
     // ---- diagnostics
     bool timing = false;              // PAGRAPH_TIMING
     bool walk_debug = false;          // PAG_WALK_DEBUG
+    unsigned stitch_threads = 8;      // PAG_STITCH_THREADS: host threads for the adoptions of finished segments (1: the control thread alone)
+    bool walk_trace = false;          // PAG_WALK_TRACE: jobs (device begin / end, when the host saw them), postings and decisions kept in memory, printed when the walks are over
     double idle_limit_ms = 60000.0;   // PAG_WALK_IDLE_S: watchdog of the event loop
     bool check_aggs = false;          // PAG_DEBUG_CHECK_AGGS
     int debug_seqcap = 0;             // PAG_DEBUG_SEQCAP (> 0: tiny initial walk buffers)
@@ -75,6 +78,9 @@ struct WalkConfig {
         else if (std::getenv("PAG_SUCC_TWO_PASS")) c.succ_mode = "twopass";
         c.timing = std::getenv("PAGRAPH_TIMING") != nullptr;
         c.walk_debug = std::getenv("PAG_WALK_DEBUG") != nullptr;
+        c.walk_trace = std::getenv("PAG_WALK_TRACE") != nullptr;
+        if (const char *e = std::getenv("PAG_STITCH_THREADS")) c.stitch_threads = (unsigned)std::max(1, std::atoi(e));
+        c.stitch_threads = std::min(c.stitch_threads, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *e = std::getenv("PAG_WALK_IDLE_S")) c.idle_limit_ms = std::atof(e) * 1000.0;
         c.check_aggs = std::getenv("PAG_DEBUG_CHECK_AGGS") != nullptr;
         if (const char *e = std::getenv("PAG_DEBUG_SEQCAP")) c.debug_seqcap = std::max(16, std::atoi(e));

@@ -11,6 +11,8 @@
 //     PAG_WALK_WAVES=<n> forces a total (tests run the walks with 8 waves), PAG_WALK_WAVES_PER_CU=<n> a per-unit figure.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -54,10 +56,25 @@ struct WalkerGrid {
         cap = qcap;
         k = kk;
         max_waves = default_waves(g->device);
+        // the pool's first streams are made here, once per handle: creating one costs ~6 ms (measured, round 5), and a pool that
+        // grew inside the walks paid that in the tail of a block, on the control thread, with finished jobs waiting
+        prepare_streams(g, 4);
         const double idle_us = std::getenv("PAG_WALK_IDLE_US") ? std::max(1.0, std::atof(std::getenv("PAG_WALK_IDLE_US"))) : 2000.0;
         idle_ticks = (uint64_t)(idle_us * 100.0);
         launched = launches = 0;
         up = false;
+    }
+    static void prepare_streams(pag_graph *gg, size_t n) {
+        int lo = 0, hi = 0;
+        if (gg->walk_streams.size() >= n || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return;
+        while (gg->walk_streams.size() < n) {
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+            gg->walk_streams.push_back(st);
+        }
     }
     uint32_t exited() const { return __atomic_load_n(&q->exited, __ATOMIC_ACQUIRE); }
     uint32_t started() const { return __atomic_load_n(&q->started, __ATOMIC_ACQUIRE); }
@@ -85,6 +102,7 @@ struct WalkerGrid {
         // a stream of the pool whose last launch has drained (launches on one stream would run one after the other);
         // the pool grows to 8 streams, all of the highest priority: the runtime multiplexes streams onto a few hardware
         // queues, and work of the call's own stream must never be queued behind walkers
+        const auto tq0 = std::chrono::steady_clock::now();
         hipStream_t st = nullptr;
         for (hipStream_t c : g->walk_streams)
             if (hipStreamQuery(c) == hipSuccess) {
@@ -102,7 +120,16 @@ struct WalkerGrid {
                 st = g->walk_streams[launches % g->walk_streams.size()];
             }
         }
+        const auto tq1 = std::chrono::steady_clock::now();
+        const bool drained = hipStreamQuery(st) == hipSuccess;
+        (void)hipGetLastError();
         trav_launch_walk_persistent(G, jobs, outs, done, q, g->wq_next, cap, k, n, idle_ticks, st);
+        if (std::getenv("PAG_WALK_TRACE")) {
+            const auto tq2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[trace] walker launch %u: %u waves on stream %p (%s, pool of %zu), have %u, picking the stream %.3f ms, the launch call %.3f ms\n", launches, n, (void *)st,
+                         drained ? "drained" : "NOT drained", g->walk_streams.size(), have(), std::chrono::duration<double, std::milli>(tq1 - tq0).count(),
+                         std::chrono::duration<double, std::milli>(tq2 - tq1).count());
+        }
         if (hipGetLastError() != hipSuccess) {
             set_error("pag_travel: walker launch failed");
             return PAG_EFAULT;
