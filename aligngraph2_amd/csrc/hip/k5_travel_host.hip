@@ -1268,8 +1268,20 @@ struct WalkSession {
             }
             // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
             const bool leap_first = cfg.leap_first;
+            // ... and of those the piece that runs to the end of the strand FIRST: it walks on from there until it leaps (at
+            // configs[1] ~5 000 vertices and 20 000 classifications where the other pieces have 1 700 and 6 000: 55-70 ms, the
+            // longest job of its contig by far and the one its round waits for; tests/walk_trace.py showed a fifth of them
+            // starting 12-14 ms into the walks)
+            std::vector<size_t> seg_order;
+            for (size_t q = R.segs.size(); q-- > 0;)
+                if (R.segs[q].leap && R.segs[q].stop == 0u && cfg.last_piece_first) {
+                    seg_order.push_back(q);
+                    break;
+                }
+            for (size_t q = 0; q < R.segs.size(); ++q)
+                if (seg_order.empty() || q != seg_order[0]) seg_order.push_back(q);
             for (int pass = 0; pass < 2 && !P.kept; ++pass)  // (kept segments have their jobs, or their paths, already)
-                for (size_t q = 0; q < R.segs.size(); ++q) {
+                for (size_t q : seg_order) {
                     if (R.segs[q].leap != ((pass == 0) == leap_first)) continue;
                     const uint64_t spanc = (R.segs[q].stop ? (uint64_t)R.segs[q].stop : (uint64_t)cs.ctgRight) - R.segs[q].x;
                     const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
@@ -1708,6 +1720,16 @@ struct WalkSession {
                         ++rank;
                     }
                 }
+                // (a turn of its own for the contigs' longest jobs — the piece that runs to the end of the strand, first in every
+                // contig's list: they all start with the first wave of the grid)
+                if (cfg.last_piece_first)
+                    for (uint32_t i : order) {
+                        auto &dq = deferred[i];
+                        if (at[i] < dq.size() && (dq[0].P.J.mode & TRAV_MODE_LEAP) && dq[0].P.J.stop_pc == 0u) {
+                            if ((rc = commit_job(2u, dq[0].P, dq[0].jr, dq[0].P.J.mode, dq[0].P.J.stop_pc))) return fail(rc);
+                            at[i] = 1;
+                        }
+                    }
                 for (bool more = true; more;) {
                     more = false;
                     for (uint32_t i : order) {

@@ -32,6 +32,7 @@ struct WalkConfig {
     bool pieces = true;               // PAG_WALK_PIECES
     bool leap_pieces = true;          // PAG_LEAP_PIECES
     bool leap_first = true;           // PAG_LEAP_FIRST
+    bool last_piece_first = true;     // PAG_LAST_PIECE_FIRST=0: the piece that runs to the end of the strand in its place among the others
     bool force_exact = false;         // PAG_WALK_EXACT
     bool orphaning = true;            // PAG_WALK_ORPHANS
     bool keep_segments = true;        // PAG_WALK_KEEP_SEGMENTS
@@ -88,6 +89,7 @@ struct WalkConfig {
         c.pieces = !off("PAG_WALK_PIECES");
         c.leap_pieces = !off("PAG_LEAP_PIECES");
         c.leap_first = !off("PAG_LEAP_FIRST");
+        c.last_piece_first = !off("PAG_LAST_PIECE_FIRST");
         c.force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
         c.orphaning = !off("PAG_WALK_ORPHANS");
         c.keep_segments = !off("PAG_WALK_KEEP_SEGMENTS");
