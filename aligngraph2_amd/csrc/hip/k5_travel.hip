@@ -2868,6 +2868,10 @@ __global__ __launch_bounds__(64, PAG_WALK_WAVES_PER_EU) void k_walk_persistent(T
     bool alive = true;
     uint64_t t0 = wall_clock64();
     uint32_t naps = 1;
+    // (bit 63 of idle_ticks, PAG_WALK_PRIO=0 clears it: the walker waves issue ahead of whatever else is resident on their SIMD —
+    // the deliveries of finished contigs, k_gather_path, run beside the last walks of a block)
+    if (idle_ticks >> 63) __builtin_amdgcn_s_setprio(3);
+    idle_ticks &= ~(1ull << 63);
     while (alive) {
         // One relaxed 8-byte read of host memory per poll (posted[0] | posted[1] << 32), polls of an idle wave spaced out up
         // to ~100 us: hundreds of idle waves hammering the host link would slow the working waves down.  (An acquire here
@@ -3692,8 +3696,9 @@ int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const 
     return PAG_OK;
 }
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
-                             hipStream_t s) {
-    if (len) k_gather_path<<<dim3(grid_for(len)), dim3(256), 0, s>>>(G, seq_v, seq_s, len, out);
+                             hipStream_t s, unsigned max_blocks) {
+    const unsigned grid = max_blocks ? std::min(grid_for(len), max_blocks) : grid_for(len);
+    if (len) k_gather_path<<<dim3(grid), dim3(256), 0, s>>>(G, seq_v, seq_s, len, out);
 }
 // blockIdx.y = the part; the blocks of a row stride over its entries
 __global__ void __launch_bounds__(256) k_concat_parts(const TravConcatPart *__restrict__ parts, uint32_t *__restrict__ out_v,

@@ -1405,7 +1405,7 @@ struct WalkSession {
                 PAG_HIP_TRY(hipMemcpyAsync(T.d_ids, hp, m0 * 4, hipMemcpyHostToDevice, g->deliver_stream));
                 PAG_HIP_TRY(hipMemcpyAsync(T.d_ids + T.cap, hp + m0, m0 * 4, hipMemcpyHostToDevice, g->deliver_stream));
             }
-            trav_launch_gather_path(G, T.d_ids, T.d_ids + T.cap, m, dst, g->deliver_stream);
+            trav_launch_gather_path(G, T.d_ids, T.d_ids + T.cap, m, dst, g->deliver_stream, n_live ? cfg.deliver_blocks : 0u);
             g->path_ptr[slot2] = dst;
             return PAG_OK;
         }
@@ -1434,7 +1434,7 @@ struct WalkSession {
         // occupy the copy engine the fetches need (measured: their lap 9 -> 24 ms per step).
         if (!g->deliver_stream) PAG_HIP_TRY(hipStreamCreateWithFlags(&g->deliver_stream, hipStreamNonBlocking));
         PAG_HIP_TRY(hipMemcpyAsync(d_ids, hp, m * 8, hipMemcpyHostToDevice, g->deliver_stream));
-        trav_launch_gather_path(G, d_ids, d_ids + m, m, dst, g->deliver_stream);
+        trav_launch_gather_path(G, d_ids, d_ids + m, m, dst, g->deliver_stream, n_live ? cfg.deliver_blocks : 0u);
         g->path_ptr[slot2] = dst;
         return PAG_OK;
     }

@@ -226,8 +226,9 @@ int trav_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
                     hipStream_t s);
 int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
                    uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s);
+// (max_blocks: 0 = as many as the path has work for; a delivery that runs beside the walks of other contigs is kept small)
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
-                             hipStream_t s);
+                             hipStream_t s, unsigned max_blocks = 0);
 void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s);
 // the parts of a chosen walk, lying in the sequence buffers of the jobs that walked them, put one behind the other
 // (out_v / out_s + TravConcatPart::start); the step of the very first vertex becomes first_step.  `parts` may be pinned

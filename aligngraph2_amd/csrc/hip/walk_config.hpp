@@ -49,6 +49,9 @@ struct WalkConfig {
     double post_spread = 1.0;         // PAG_POST_SPREAD=<0..1>: the longest contig's jobs are through the ring at this fraction of the turns
     // ---- delivery of results
     bool deliver_early = true;        // PAG_DELIVER_EARLY
+    unsigned deliver_blocks = 24;     // PAG_GATHER_BLOCKS: grid of a delivery that runs while walk jobs are live (0: no bound).  The delivery's
+                                      // thousands of waves, each with stores to host memory in flight, slowed every walker wave beside them:
+                                      // 2.5 -> 3.2-5 us per classification in the last 40 ms of a block (round 5, tests/tail_clock_probe.sh)
     uint32_t succ_heavy = 64;         // PAG_SUCC_HEAVY: successor records of a vertex with more candidate pairs than this: by a whole wave (0: never)
     bool device_tail = true;          // PAG_DEVICE_TAIL: the last round of a contig that leaps is put together on the device
     unsigned pace = 0;                // PAG_WALK_PACE: decided rounds taken per look at the rings while jobs are live (0: all; measured: no gain)
@@ -103,6 +106,7 @@ struct WalkConfig {
         c.post_proportional = !off("PAG_POST_PROPORTIONAL");
         if (const char *e = std::getenv("PAG_POST_SPREAD")) c.post_spread = std::min(1.0, std::max(0.05, std::atof(e)));
         c.deliver_early = !off("PAG_DELIVER_EARLY");
+        if (const char *e = std::getenv("PAG_GATHER_BLOCKS")) c.deliver_blocks = (unsigned)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("PAG_SUCC_HEAVY")) c.succ_heavy = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
         c.device_tail = !off("PAG_DEVICE_TAIL");
         if (const char *e = std::getenv("PAG_WALK_PACE")) c.pace = (unsigned)std::max(0, std::atoi(e));
