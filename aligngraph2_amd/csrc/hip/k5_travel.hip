@@ -618,12 +618,16 @@ struct __attribute__((packed, aligned(8))) U64x4 { uint64_t a[4]; };
 template <int WHAT>
 #define SUCC_HEAVY 0xFFFFFFFFu
 __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out,
-                                                const uint32_t *__restrict__ ratio_tab, uint32_t heavy_limit = 0xFFFFFFFFu) {
+                                                const uint32_t *__restrict__ ratio_tab, uint32_t heavy_limit = 0xFFFFFFFFu, uint32_t src_u = 0u) {
     // (0 counts, 1 fills through the mask, 2 writes while it evaluates; 3: 1 for a vertex known to have at most 64 candidates —
     // everything is under the mask, the loop that evaluates candidates is not even compiled in: registers, k_succ<3>)
-    constexpr int MODE = WHAT == 3 ? 1 : WHAT;
-    constexpr bool MASK_ONLY = WHAT == 3;
-    const uint64_t rootp = G.vpos[v];
+    // 4: 3 with the grading left to k_succ_link — the record gets its target's new id and the step, the source's new id in `toff`
+    // (src_u), grade 0; neither the source's nor the target's position is read here: the linking pass runs in coordinate order,
+    // where both are neighbours of what it reads anyway (one random sector per record less than 3)
+    constexpr int MODE = WHAT == 3 || WHAT == 4 ? 1 : WHAT;
+    constexpr bool MASK_ONLY = WHAT == 3 || WHAT == 4;
+    constexpr bool DEFER = WHAT == 4;
+    const uint64_t rootp = DEFER ? 0ull : G.vpos[v];
     const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
     const uint32_t node = G.vnode[v];
     uint32_t n = 0, base = 0;
@@ -663,6 +667,15 @@ __device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, 
             while (sub) {
                 const uint32_t p = p0 + (uint32_t)(__ffsll((long long)sub) - 1);
                 sub &= sub - 1ull;
+                if (DEFER) {
+                    SuccRec r;
+                    r.tgt = G.newid[p];
+                    r.pc = 0u;
+                    r.meta = step & 0xFFFFFFu;  // (grade 0 = not graded yet)
+                    r.toff = src_u;
+                    out[n++] = r;
+                    continue;
+                }
                 const uint64_t pp = G.vpos[p];
                 const uint32_t tgt = G.newid[p];  // (asked for together with the position: one round trip per record, not two)
                 uint32_t esim;
@@ -764,7 +777,7 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
     d_ratio_table_fill(ratio_tab, err);
     __syncthreads();
-    constexpr bool FILL = MODE == 1 || MODE == 3;  // (3: with the heavy list and a limit of at most 64 — see succ_vertex)
+    constexpr bool FILL = MODE == 1 || MODE == 3 || MODE == 4;  // (3, 4: with the heavy list and a limit of at most 64 — see succ_vertex)
     if (!heavy_list || MODE == 2) heavy_limit = 0xFFFFFFFFu;
     for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t n = 0;
@@ -805,7 +818,7 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
                 uint32_t m;
                 if (amask) {
                     mask = amask[v];
-                    m = succ_vertex<MODE == 3 ? 3 : 1>(G, v, dev, err, mask, out, ratio_tab, heavy_limit);
+                    m = succ_vertex<MODE == 3 || MODE == 4 ? MODE : 1>(G, v, dev, err, mask, out, ratio_tab, heavy_limit, u);
                     if (m == SUCC_HEAVY) continue;
                 } else {
                     m = succ_vertex<2>(G, v, dev, err, mask, out, ratio_tab);
@@ -994,7 +1007,16 @@ __global__ void k_succ_place(TravGraph G, const uint64_t *__restrict__ stage_off
 // that a walk step never waits for succ_off.  A pass of its own over the records IN COORDINATE ORDER: the targets of
 // neighbouring records are neighbours on the strand, so the succ_off reads hit the caches — inside k_succ (k-mer-major
 // threads) the same reads were one random HBM access per record.
-__global__ void k_succ_link(TravGraph G, uint64_t n_rec) {
+// GRADE: a record that k_succ<4> left ungraded (grade 0, the source's new id in `toff`) gets its target's contig coordinate, its
+// grade and its edge-similarity bit here, from the positions of both ends IN COORDINATE ORDER (upos): the source's is the
+// neighbour of the previous record's, the target's lies a step ahead of it on the strand.
+template <bool GRADE>
+__global__ void k_succ_link(TravGraph G, uint64_t n_rec, uint32_t dev, double err) {
+    __shared__ uint32_t ratio_tab[GRADE ? RATIO_TAB_N : 1u];
+    if (GRADE) {
+        d_ratio_table_fill(ratio_tab, err);
+        __syncthreads();
+    }
     // four records per thread and trip, their loads issued together (one dependent gather each: latency-bound otherwise)
     const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += 4 * T) {
@@ -1005,15 +1027,29 @@ __global__ void k_succ_link(TravGraph G, uint64_t n_rec) {
             const uint64_t x = i + (uint64_t)q * T;
             r[q] = G.succ[x < n_rec ? x : i];  // one 16-byte load
         }
+        uint64_t ps[4], pt[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             t0[q] = G.succ_off[r[q].tgt];
             t1[q] = G.succ_off[r[q].tgt + 1];
+            if (GRADE) {
+                const bool todo = ((r[q].meta >> 24) & 7u) == 0u;
+                pt[q] = todo ? G.upos[r[q].tgt] : 0ull;
+                ps[q] = todo ? G.upos[r[q].toff] : 0ull;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint64_t x = i + (uint64_t)q * T;
             if (x >= n_rec) continue;
+            if (GRADE && ((r[q].meta >> 24) & 7u) == 0u) {
+                const uint32_t step = r[q].meta & 0xFFFFFFu;
+                const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;
+                uint32_t esim;
+                const int grade = d_check_position_any((uint32_t)(ps[q] >> 32), (uint32_t)ps[q], (uint32_t)(pt[q] >> 32), (uint32_t)pt[q], step, dev, err, entry, &esim);
+                r[q].pc = (uint32_t)(pt[q] >> 32);
+                r[q].meta = step | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+            }
             const uint32_t tc = t1[q] - t0[q] < 15u ? t1[q] - t0[q] : 15u;
             r[q].meta |= tc << 28;
             r[q].toff = t0[q];
@@ -3685,12 +3721,18 @@ int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const 
     if (stage) {
         k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
     } else {
-        if (heavy_list && heavy_limit <= 64u && amask)
+        // (PAG_SUCC_DEFER=0: the filling pass grades its records itself, as until round 5)
+        const bool defer = !(std::getenv("PAG_SUCC_DEFER") && std::atoi(std::getenv("PAG_SUCC_DEFER")) == 0);
+        const bool mask_only = heavy_list && heavy_limit <= 64u && amask;
+        if (mask_only && defer)
+            k_succ<4><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
+        else if (mask_only)
             k_succ<3><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
         else
             k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
         if (heavy_list) k_succ_heavy<1><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, nullptr, amask, heavy_list, heavy_n);
-        if (n_rec) k_succ_link<<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec);
+        if (n_rec && mask_only && defer) k_succ_link<true><<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec, dev, err);
+        else if (n_rec) k_succ_link<false><<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec, dev, err);
     }
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;

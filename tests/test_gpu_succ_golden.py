@@ -157,6 +157,8 @@ MODES = [  # (label, view, environment)
     ("whole bound", "whole", {"PAG_SUCC_MODE": "bound"}),
     ("whole twopass", "whole", {"PAG_SUCC_MODE": "twopass"}),
     ("whole twopass heavy=4", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4"}),
+    ("whole twopass, graded by the filling pass", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_DEFER": "0"}),
+    ("whole twopass heavy=4, graded by the filling pass", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_SUCC_DEFER": "0"}),
     ("whole twopass heavy=0", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "0"}),
     ("whole fused", "whole", {"PAG_SUCC_MODE": "fused"}),
     ("whole fused heavy=4", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4"}),
@@ -167,11 +169,12 @@ MODES = [  # (label, view, environment)
     ("cut default", "for", {}),
     ("cut tight twopass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight twopass heavy=4", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight twopass, graded by the filling pass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_DEFER": "0", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight bound", "for", {"PAG_SUCC_MODE": "bound", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight fused", "for", {"PAG_SUCC_MODE": "fused", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight fused heavy=4", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
 ]
-SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS", "PAG_NODE_ORDER")
+SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS", "PAG_NODE_ORDER", "PAG_SUCC_DEFER")
 
 
 @pytest.mark.gpu
