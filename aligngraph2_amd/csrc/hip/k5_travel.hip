@@ -2310,9 +2310,35 @@ __device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp,
 }
 
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
+// A job clears its own marks before it begins (TravJob::self_clear, PAG_WALK_SELFCLEAR=1; a measured variant, not the default): the
+// control thread has ONE launch clear the stamps, travel epochs and hash sets of every job of a batch (25 GB at configs[1]) and
+// waits for it before the first job is published, 2.7 ms at the head of every block's walks with the device otherwise idle.  With
+// the jobs clearing their own the walks start at once and take LONGER (88.2 against 85.0 ms): a lone wave needs ~0.6 ms for its
+// 4 MB.
+__device__ __forceinline__ void wave_fill16(void *p, uint64_t bytes, uint32_t word) {  // (p 16-byte aligned, bytes a multiple of 16)
+    uint4 *q = (uint4 *)p;
+    const uint4 w = make_uint4(word, word, word, word);
+    const uint64_t n = bytes / 16u;
+    for (uint64_t i = lane_id(); i < n; i += 64u) q[i] = w;
+}
+__device__ __forceinline__ void job_self_clear(const TravJob &J) {
+    const uint64_t PG = TRAV_PROBE_GROUPS;
+    if ((J.mode & TRAV_MODE_LEAP) && J.seq_x)
+        for (uint64_t i = lane_id(); i < J.seq_cap; i += 64u) J.seq_x[i] = 0ull;
+    wave_fill16(J.tset, ((uint64_t)J.tmask + 1u) * 8u, 0xFFFFFFFFu);
+    wave_fill16(J.pset, ((uint64_t)J.pmask + 1u) * PG * 8u, 0u);
+    wave_fill16(J.stamp, PG * (uint64_t)J.stamp_stride * 4u, 0u);
+    wave_fill16(J.tbits, ((uint64_t)J.stamp_stride + 4u) * 4u, 0u);
+    // the stores are in the L2 before anything of the job reads or updates these arrays (L2 atomics, agent-scope loads, plain
+    // loads through an L1 that holds none of these lines yet: the fence drops what it might)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const TravContig &C, const TravJob &Jsrc, TravJobOut *out, uint32_t k) {
     const uint32_t lane = lane_id();
     const TravJob J = Jsrc;  // by value: the record may live in host memory
+    if (J.self_clear) job_self_clear(J);
     WalkCtx X;
     X.G = G;
     X.C = C;

@@ -938,11 +938,13 @@ struct WalkSession {
                     if ((r = bufs[q]->alloc(need[q]))) return r;
             }
         }
-        want_clear(b_sx.p, o_x[nj] * 8, 0u);
-        want_clear(b_ts.p, o_oc[nj] * 8, 0xFFu);
-        want_clear(b_ps.p, o_oc[nj] * PG * 8, 0u);
-        want_clear(b_st.p, o_st[nj] * 4, 0u);
-        want_clear(b_tb.p, o_tb[nj] * 4, 0u);
+        if (!cfg.self_clear) {  // (PAG_WALK_SELFCLEAR=1: every job clears its own marks instead — measured slower, walk_config.hpp)
+            want_clear(b_sx.p, o_x[nj] * 8, 0u);
+            want_clear(b_ts.p, o_oc[nj] * 8, 0xFFu);
+            want_clear(b_ps.p, o_oc[nj] * PG * 8, 0u);
+            want_clear(b_st.p, o_st[nj] * 4, 0u);
+            want_clear(b_tb.p, o_tb[nj] * 4, 0u);
+        }
         fill_contigs();
         for (size_t j = 0; j < nj; ++j) {
             const JobPlan &pl = plans[j];
@@ -971,7 +973,7 @@ struct WalkSession {
             J.stop_pc = pl.stop_pc;
             J.init_len = 0;
             J.win_low = pl.win_low;
-            J.pad_ = 0;
+            J.self_clear = cfg.self_clear ? 1u : 0u;
             J.seq_x = (pl.mode & TRAV_MODE_LEAP) ? b_sx.as<uint64_t>() + o_x[j] : nullptr;
             if (pl.mode & TRAV_MODE_RESUME) {
                 const uint64_t n0 = pl.init->len;

@@ -101,7 +101,7 @@ struct TravJob {
     uint32_t stop_pc;
     uint64_t init_len;
     uint32_t win_low;   // TRAV_MODE_LEAP: lower end forced on the travel coordinate window
-    uint32_t pad_;
+    uint32_t self_clear;  // 1: the job clears its own stamp / tbits / tset / pset / seq_x arrays before it begins (job_self_clear, k5_travel.hip)
     // TRAV_MODE_LEAP: [seq_cap] zeroed; entry i != 0 <=> seq_v[i] is the last vertex of a chosen path, i.e. graphTravel
     // classified it at the top level (an iteration boundary).  Entry = 1 << 63 | elow << 32 | m0 about the iteration that
     // STARTS there: elow = lowest contig coordinate (31 bits, saturated) of any successor record that follows the contig
