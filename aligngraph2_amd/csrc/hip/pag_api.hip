@@ -705,15 +705,26 @@ static int log2_shards(uint32_t n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2
 int pag_shard_extract(pag_graph *g, const pag_build_input *in, uint32_t shard, uint32_t n_shards, uint64_t *counts) {
     int rc = check_process_args(g, in);
     if (rc != PAG_OK) return rc;
-    const int lg = log2_shards(n_shards);
-    if (lg < 0 || shard >= n_shards || !counts || 2 * (int)g->k < lg) {
+    if (log2_shards(n_shards) < 0 || shard >= n_shards) {
         set_error("pag_shard_extract: n_shards must be 1, 2, 4 or 8 (got %u) and shard below it", n_shards);
+        return PAG_EINVAL;
+    }
+    const uint64_t n = in->reads.n_seqs;
+    return pag_shard_extract_range(g, in, n * shard / n_shards, n * (shard + 1ull) / n_shards, n_shards, counts);
+}
+
+int pag_shard_extract_range(pag_graph *g, const pag_build_input *in, uint64_t lo, uint64_t hi, uint32_t n_shards, uint64_t *counts) {
+    int rc = check_process_args(g, in);
+    if (rc != PAG_OK) return rc;
+    const int lg = log2_shards(n_shards);
+    if (lg < 0 || !counts || 2 * (int)g->k < lg || lo > hi || hi > in->reads.n_seqs) {
+        set_error("pag_shard_extract_range: n_shards must be 1, 2, 4 or 8 (got %u), the reads [%llu, %llu) of %llu", n_shards, (unsigned long long)lo,
+                  (unsigned long long)hi, (unsigned long long)in->reads.n_seqs);
         return PAG_EINVAL;
     }
     PAG_HIP_TRY(hipSetDevice(g->device));
     free_graph_results(g);
     hipStream_t s = g->stream;
-    const uint64_t n = in->reads.n_seqs, lo = n * shard / n_shards, hi = n * (shard + 1ull) / n_shards;
     Extracted x;
     if ((rc = extract_stage(g, in, lo, hi, &x, nullptr, nullptr))) return rc;
     keep_debug_streams(g, x.T, x.E);

@@ -481,6 +481,174 @@ int pag_comm_all_to_all_v(pag_comm *c, const void *send, const uint64_t *send_by
     return PAG_OK;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A bulk exchange that runs IN THE BACKGROUND (round 5): several device arrays, each an all-to-all(v) as above, begun by
+// xchg_begin and waited for by xchg_end, so that the next piece of work of the call's own stream — the next chunk's
+// extraction, the next destination's selection — runs beside it.  RCCL: the grouped sends / receives of all arrays are
+// enqueued on the communicator's stream (a stream of its own, non-blocking) and xchg_end waits for that stream.  Files of the
+// rendezvous directory (ranks that share a device): a helper thread does what pag_comm_all_to_all_v does, with copies on the
+// communicator's stream.  One exchange at a time per communicator.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Xchg {
+    pag_comm *c = nullptr;
+    bool active = false;
+    std::thread th;
+    int rc = PAG_OK;
+    std::string err;
+    double t_begin = 0, t_done = 0;  // (host clock; t_done is set when the transfer is known to be over)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float dev_ms = 0.f;
+};
+struct XchgArr {
+    const void *send;
+    void *recv;
+    std::vector<uint64_t> sb, rb;  // bytes to / from every rank
+};
+
+int xchg_files(pag_comm *c, uint64_t n, const XchgArr &A, std::string &err) {
+    std::vector<uint64_t> so(c->world + 1, 0), ro(c->world + 1, 0);
+    for (int r = 0; r < c->world; ++r) {
+        so[r + 1] = so[r] + A.sb[r];
+        ro[r + 1] = ro[r] + A.rb[r];
+    }
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    };
+    std::vector<char> host;
+    int rc;
+    for (int d = 0; d < c->world; ++d) {
+        if (d == c->rank) continue;
+        host.resize(A.sb[d]);
+        if (A.sb[d] && !(hip_ok(hipMemcpyAsync(host.data(), (const char *)A.send + so[d], A.sb[d], hipMemcpyDeviceToHost, c->stream), "copy to host") &&
+                         hip_ok(hipStreamSynchronize(c->stream), "copy to host")))
+            return PAG_EFAULT;
+        if ((rc = c->put_file(c->path("a", n, c->rank, d), host.data(), A.sb[d]))) {
+            err = pagdev::last_error();
+            return rc;
+        }
+    }
+    if (A.sb[c->rank] && !(hip_ok(hipMemcpyAsync((char *)A.recv + ro[c->rank], (const char *)A.send + so[c->rank], A.sb[c->rank], hipMemcpyDeviceToDevice, c->stream), "own part") &&
+                           hip_ok(hipStreamSynchronize(c->stream), "own part")))
+        return PAG_EFAULT;
+    for (int s2 = 0; s2 < c->world; ++s2) {
+        if (s2 == c->rank) continue;
+        if ((rc = c->get_file(c->path("a", n, s2, c->rank), host, true))) {
+            err = pagdev::last_error();
+            return rc;
+        }
+        if (host.size() != A.rb[s2]) {
+            err = "exchange: " + std::to_string(host.size()) + " bytes from rank " + std::to_string(s2) + ", " + std::to_string(A.rb[s2]) + " expected";
+            return PAG_EFAULT;
+        }
+        if (A.rb[s2] && !(hip_ok(hipMemcpyAsync((char *)A.recv + ro[s2], host.data(), A.rb[s2], hipMemcpyHostToDevice, c->stream), "copy to device") &&
+                          hip_ok(hipStreamSynchronize(c->stream), "copy to device")))
+            return PAG_EFAULT;
+    }
+    return PAG_OK;
+}
+
+// (the caller's data — send arrays written on another stream — must be complete: the caller synchronises its stream first)
+int xchg_begin(pag_comm *c, Xchg &X, std::vector<XchgArr> arrs) {
+    X.c = c;
+    X.rc = PAG_OK;
+    X.err.clear();
+    X.dev_ms = 0.f;
+    PAG_HIP_TRY(hipSetDevice(c->device));
+    for (const XchgArr &A : arrs) {
+        if (A.sb[c->rank] != A.rb[c->rank]) return PAG_EINVAL;
+        for (int r = 0; r < c->world; ++r)
+            if (r != c->rank) c->bytes_sent += A.sb[r];
+    }
+    X.t_begin = now_s();
+    if (c->use_rccl) {
+        if (c->world > 1) {  // (only a complete set of ranks enters RCCL: see pag_comm_all_to_all_v)
+            const int brc = pag_comm_barrier(c);
+            if (brc) return brc;
+        }
+        if (!X.ev0) {
+            PAG_HIP_TRY(hipEventCreate(&X.ev0));
+            PAG_HIP_TRY(hipEventCreate(&X.ev1));
+        }
+        PAG_HIP_TRY(hipEventRecord(X.ev0, c->stream));
+        ncclResult_t rc = c->rccl.GroupStart();
+        for (const XchgArr &A : arrs) {
+            uint64_t so = 0, ro = 0;
+            for (int r = 0; r < c->world && rc == ncclSuccess; ++r) {
+                if (A.sb[r]) rc = c->rccl.Send((const char *)A.send + so, A.sb[r], ncclUint8, r, c->comm, c->stream);
+                if (rc == ncclSuccess && A.rb[r]) rc = c->rccl.Recv((char *)A.recv + ro, A.rb[r], ncclUint8, r, c->comm, c->stream);
+                so += A.sb[r];
+                ro += A.rb[r];
+            }
+        }
+        const ncclResult_t rc2 = c->rccl.GroupEnd();
+        if (rc != ncclSuccess || rc2 != ncclSuccess) {
+            pagdev::set_error("exchange: RCCL error %s", c->rccl.GetErrorString ? c->rccl.GetErrorString(rc != ncclSuccess ? rc : rc2) : "?");
+            return PAG_EFAULT;
+        }
+        PAG_HIP_TRY(hipEventRecord(X.ev1, c->stream));
+        X.active = true;
+        return PAG_OK;
+    }
+    std::vector<uint64_t> seqs;
+    for (size_t a = 0; a < arrs.size(); ++a) seqs.push_back(c->seq++);
+    X.active = true;
+    X.th = std::thread([c, &X, arrs = std::move(arrs), seqs]() {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            X.rc = PAG_EFAULT;
+            X.err = "hipSetDevice in the exchange thread";
+        }
+        for (size_t a = 0; a < arrs.size() && X.rc == PAG_OK; ++a) X.rc = xchg_files(c, seqs[a], arrs[a], X.err);
+        X.t_done = now_s();
+    });
+    return PAG_OK;
+}
+int xchg_end(Xchg &X) {
+    if (!X.active) return PAG_OK;
+    X.active = false;
+    if (X.c->use_rccl) {
+        PAG_HIP_TRY(hipStreamSynchronize(X.c->stream));
+        PAG_HIP_TRY(hipEventElapsedTime(&X.dev_ms, X.ev0, X.ev1));
+        X.t_done = X.t_begin + X.dev_ms * 1e-3;
+        return PAG_OK;
+    }
+    X.th.join();
+    if (X.rc != PAG_OK) pagdev::set_error("%s", X.err.c_str());
+    return X.rc;
+}
+struct XchgGuard {  // (an error return between begin and end must not leave a joinable thread behind)
+    Xchg &X;
+    ~XchgGuard() {
+        if (X.active && !X.c->use_rccl && X.th.joinable()) X.th.join();
+        if (X.ev0) hipEventDestroy(X.ev0);
+        if (X.ev1) hipEventDestroy(X.ev1);
+    }
+};
+struct DevTemp {  // device arrays of one call, freed when it returns
+    std::vector<void *> ptrs;
+    void *get(size_t bytes) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+            pagdev::set_error("hipMalloc(%zu) failed in the sharded build", bytes);
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return p;
+    }
+    void release() {
+        for (void *p : ptrs) hipFree(p);
+        ptrs.clear();
+    }
+    ~DevTemp() { release(); }
+};
+}  // namespace
+
+extern "C" {
+
 // ---------------------------------------------------------------------------------------------------------------------
 // pag_shard_run: the sharded build of one block behind one call (every rank calls it with the same prepared input).
 //   extract own read range -> all-to-all(v) of the tuple / edge streams -> K2-K4 on the owned k-mer range -> every rank's
@@ -515,56 +683,120 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         lap[i] += t - t_prev;
         t_prev = t;
     };
-    std::vector<uint64_t> counts(4 * (size_t)W), allc(4 * (size_t)W * W);
-    if ((rc = pag_shard_extract(g, in, (uint32_t)me, (uint32_t)W, counts.data()))) return rc;
-    mark(0);
-    if ((rc = pag_comm_all_gather(c, counts.data(), counts.size() * 8, allc.data()))) return rc;
-    auto cnt = [&](int src, int dst, int q) { return allc[((size_t)src * W + dst) * 4 + q]; };
+    // ---- extraction in CHUNKS, every chunk's partitioned streams on their way to the owners while the next chunk is extracted
+    //      (SURVEY.md 8e).  PAG_SHARD_CHUNKS (default 4; 1: the whole range at once).  A chunk's streams are copied out of the
+    //      extraction's slots (the next chunk overwrites them) and received into arrays of their own; when the last chunk has
+    //      arrived the owner lays the pieces out as [pass 1: rank 0 chunk 0, chunk 1 .. rank 1 ..][pass 2: ..] — the ranks' read
+    //      ranges and, inside a rank, its chunks are contiguous in emission order, so that is the canonical order again.
     hipStream_t s = g->stream;
-    // ---- the partitioned streams to their owners.  Received: [from rank 0: pass 1, pass 2][from rank 1: ..] per array;
-    //      laid out for the build as [pass 1 from all ranks][pass 2 from all ranks]
-    const int ts = g->shard_in0[0] ? 30 : 32, es = g->shard_in0[1] ? 34 : 36;
-    uint64_t nT = 0, nE = 0, t1 = 0, e1 = 0;
-    for (int r = 0; r < W; ++r) {
-        nT += cnt(r, me, 0) + cnt(r, me, 1);
-        nE += cnt(r, me, 2) + cnt(r, me, 3);
-        t1 += cnt(r, me, 0);
-        e1 += cnt(r, me, 2);
-    }
-    DevBuf b_rk(g, 206), b_rv(g, 207), b_lk(g, 208), b_lv(g, 209);
-    const uint64_t nmax = std::max(nT, nE);
-    if ((rc = b_rk.alloc((nmax + 1) * 4)) || (rc = b_rv.alloc((nmax + 1) * 8)) || (rc = b_lk.alloc((nT + 1) * 4)) || (rc = b_lv.alloc((nT + 1) * 8))) return rc;
-    DevBuf b_lek(g, 210), b_lev(g, 211);
-    if ((rc = b_lek.alloc((nE + 1) * 4)) || (rc = b_lev.alloc((nE + 1) * 8))) return rc;
-    mark(1);
+    const uint64_t n_reads = in->reads.n_seqs, r_lo = n_reads * (uint64_t)me / (uint64_t)W, r_hi = n_reads * ((uint64_t)me + 1) / (uint64_t)W;
+    int C = 4;
+    if (const char *e = std::getenv("PAG_SHARD_CHUNKS")) C = std::max(1, std::min(64, std::atoi(e)));
+    std::vector<std::vector<uint64_t>> allc((size_t)C, std::vector<uint64_t>(4 * (size_t)W * W));
+    auto cnt = [&](int ch, int src, int dst, int q) { return allc[(size_t)ch][((size_t)src * W + dst) * 4 + q]; };
+    struct ChunkBufs {
+        void *send[4] = {nullptr, nullptr, nullptr, nullptr};  // tkey tval ekey eval of this rank's chunk, partitioned by owner
+        void *recv[4] = {nullptr, nullptr, nullptr, nullptr};  // what the ranks sent of theirs
+    };
+    std::vector<ChunkBufs> cb((size_t)C);
+    DevTemp tmp;
+    Xchg X;
+    XchgGuard xguard{X};
+    double t_extract = 0, t_xfer = 0, t_loop0 = 0, t_hidden = 0;
     const uint64_t sent0 = pag_comm_bytes_sent(c);
-    for (int stream_no = 0; stream_no < 2; ++stream_no) {
-        const int q0 = stream_no * 2;
-        const void *sk = g->pool[stream_no == 0 ? ts : es].p, *sv = g->pool[(stream_no == 0 ? ts : es) + 1].p;
-        void *lk = stream_no == 0 ? b_lk.p : b_lek.p, *lv = stream_no == 0 ? b_lv.p : b_lev.p;
-        std::vector<uint64_t> sb(W), rb(W);
-        for (int esz : {4, 8}) {
-            for (int r = 0; r < W; ++r) {
-                sb[r] = (cnt(me, r, q0) + cnt(me, r, q0 + 1)) * esz;
-                rb[r] = (cnt(r, me, q0) + cnt(r, me, q0 + 1)) * esz;
-            }
-            void *recv = esz == 4 ? b_rk.p : b_rv.p;
-            if ((rc = pag_comm_all_to_all_v(c, esz == 4 ? sk : sv, sb.data(), recv, rb.data()))) return rc;
-            // [pass 1 from rank 0] .. [pass 1 from rank W-1] [pass 2 from rank 0] ..
-            uint64_t src = 0, d1 = 0, d2 = 0;
-            for (int r = 0; r < W; ++r) d2 += cnt(r, me, q0);
-            for (int r = 0; r < W; ++r) {
-                const uint64_t a = cnt(r, me, q0), b = cnt(r, me, q0 + 1);
-                char *dst = (char *)(esz == 4 ? lk : lv);
-                if (a) PAG_HIP_TRY(hipMemcpyAsync(dst + d1 * esz, (char *)recv + src * esz, a * esz, hipMemcpyDeviceToDevice, s));
-                if (b) PAG_HIP_TRY(hipMemcpyAsync(dst + d2 * esz, (char *)recv + (src + a) * esz, b * esz, hipMemcpyDeviceToDevice, s));
-                src += a + b;
-                d1 += a;
-                d2 += b;
+    {
+        const double tl0 = now_s();
+        double prev_begin = 0;
+        for (int ch = 0; ch < C; ++ch) {
+            const uint64_t lo = r_lo + (r_hi - r_lo) * (uint64_t)ch / (uint64_t)C, hi = r_lo + (r_hi - r_lo) * ((uint64_t)ch + 1) / (uint64_t)C;
+            std::vector<uint64_t> counts(4 * (size_t)W);
+            const double te0 = now_s();
+            if ((rc = pag_shard_extract_range(g, in, lo, hi, (uint32_t)W, counts.data()))) return rc;
+            const int ts = g->shard_in0[0] ? 30 : 32, es = g->shard_in0[1] ? 34 : 36;
+            const uint64_t Tc = g->shard_x[0], Ec = g->shard_x[1];
+            const size_t esz[4] = {4, 8, 4, 8};
+            const void *src[4] = {g->pool[ts].p, g->pool[ts + 1].p, g->pool[es].p, g->pool[es + 1].p};
+            for (int a = 0; a < 4; ++a) {
+                const uint64_t n = a < 2 ? Tc : Ec;
+                if (!(cb[ch].send[a] = tmp.get((n + 1) * esz[a]))) return PAG_ENOMEM;
+                if (n) PAG_HIP_TRY(hipMemcpyAsync(cb[ch].send[a], src[a], n * esz[a], hipMemcpyDeviceToDevice, s));
             }
             PAG_HIP_TRY(hipStreamSynchronize(s));
+            const double te1 = now_s();
+            t_extract += te1 - te0;
+            if ((rc = pag_comm_all_gather(c, counts.data(), counts.size() * 8, allc[(size_t)ch].data()))) return rc;
+            // the chunk before this one has been travelling beside this extraction
+            const bool was_active = X.active;
+            if ((rc = xchg_end(X))) return rc;
+            if (was_active) {
+                t_xfer += X.t_done - prev_begin;
+                t_hidden += std::max(0.0, std::min(X.t_done, te1) - std::max(prev_begin, te0));
+            }
+            std::vector<XchgArr> arrs(4);
+            for (int a = 0; a < 4; ++a) {
+                const int q0 = a < 2 ? 0 : 2;
+                uint64_t tot = 0;
+                arrs[a].sb.resize(W);
+                arrs[a].rb.resize(W);
+                for (int r = 0; r < W; ++r) {
+                    arrs[a].sb[r] = (cnt(ch, me, r, q0) + cnt(ch, me, r, q0 + 1)) * esz[a];
+                    arrs[a].rb[r] = (cnt(ch, r, me, q0) + cnt(ch, r, me, q0 + 1)) * esz[a];
+                    tot += arrs[a].rb[r];
+                }
+                if (!(cb[ch].recv[a] = tmp.get(tot + esz[a]))) return PAG_ENOMEM;
+                arrs[a].send = cb[ch].send[a];
+                arrs[a].recv = cb[ch].recv[a];
+            }
+            if ((rc = xchg_begin(c, X, std::move(arrs)))) return rc;
+            prev_begin = X.t_begin;
         }
+        if ((rc = xchg_end(X))) return rc;
+        t_xfer += X.t_done - prev_begin;
+        t_loop0 = now_s() - tl0;
     }
+    mark(0);
+    uint64_t nT = 0, nE = 0, t1 = 0, e1 = 0;
+    for (int ch = 0; ch < C; ++ch)
+        for (int r = 0; r < W; ++r) {
+            nT += cnt(ch, r, me, 0) + cnt(ch, r, me, 1);
+            nE += cnt(ch, r, me, 2) + cnt(ch, r, me, 3);
+            t1 += cnt(ch, r, me, 0);
+            e1 += cnt(ch, r, me, 2);
+        }
+    for (int ch = 0; ch < C; ++ch)  // (the chunks' send copies are done with)
+        for (int a = 0; a < 4; ++a) {
+            auto it = std::find(tmp.ptrs.begin(), tmp.ptrs.end(), cb[ch].send[a]);
+            if (it != tmp.ptrs.end()) {
+                hipFree(*it);
+                tmp.ptrs.erase(it);
+            }
+        }
+    DevBuf b_lk(g, 208), b_lv(g, 209), b_lek(g, 210), b_lev(g, 211);
+    if ((rc = b_lk.alloc((nT + 1) * 4)) || (rc = b_lv.alloc((nT + 1) * 8)) || (rc = b_lek.alloc((nE + 1) * 4)) || (rc = b_lev.alloc((nE + 1) * 8))) return rc;
+    mark(1);
+    {
+        // [pass 1 from rank 0: chunk 0, chunk 1 ..] .. [pass 1 from rank W-1 ..] [pass 2 from rank 0 ..] ..; a chunk's received array
+        // is [from rank 0: pass 1, pass 2][from rank 1: ..]
+        void *dst_of[4] = {b_lk.p, b_lv.p, b_lek.p, b_lev.p};
+        const size_t esz[4] = {4, 8, 4, 8};
+        for (int a = 0; a < 4; ++a) {
+            const int q0 = a < 2 ? 0 : 2;
+            std::vector<uint64_t> src_at((size_t)C, 0);  // read position in every chunk's received array
+            uint64_t d1 = 0, d2 = a < 2 ? t1 : e1;
+            for (int r = 0; r < W; ++r)
+                for (int ch = 0; ch < C; ++ch) {
+                    const uint64_t p1 = cnt(ch, r, me, q0), p2 = cnt(ch, r, me, q0 + 1);
+                    const char *from = (const char *)cb[ch].recv[a] + src_at[(size_t)ch] * esz[a];
+                    if (p1) PAG_HIP_TRY(hipMemcpyAsync((char *)dst_of[a] + d1 * esz[a], from, p1 * esz[a], hipMemcpyDeviceToDevice, s));
+                    if (p2) PAG_HIP_TRY(hipMemcpyAsync((char *)dst_of[a] + d2 * esz[a], from + p1 * esz[a], p2 * esz[a], hipMemcpyDeviceToDevice, s));
+                    src_at[(size_t)ch] += p1 + p2;
+                    d1 += p1;
+                    d2 += p2;
+                }
+        }
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+    }
+    tmp.release();
     mark(2);
     wire[0] = pag_comm_bytes_sent(c) - sent0;
     pag_build_stats mine{};
@@ -589,6 +821,106 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         DevBuf b(g, arrs[a].slot);
         if ((rc = b.alloc((n_slice + n_slice / 2 + 1024) * arrs[a].esz))) return rc;
     }
+    // (PAG_SHARD_PIPELINE=0: all selections first, then seven whole all-to-all(v)s, as until round 5)
+    const bool pipeline = !(std::getenv("PAG_SHARD_PIPELINE") && std::atoi(std::getenv("PAG_SHARD_PIPELINE")) == 0);
+    uint64_t T = 0, E = 0;
+    std::vector<pag_build_stats> from_owner(W);  // the statistics of what owner o selected for this rank
+    DevBuf imp[7] = {DevBuf(g, 52), DevBuf(g, 53), DevBuf(g, 54), DevBuf(g, 55), DevBuf(g, 56), DevBuf(g, 57), DevBuf(g, 58)};
+    double t_select = 0, t_rxfer = 0, t_rhidden = 0, t_loop1 = 0;
+    const uint64_t sent1 = pag_comm_bytes_sent(c);
+    if (pipeline) {
+        // Step i: this owner selects the region of rank (me + i) mod W and receives, from rank (me - i) mod W, that owner's
+        // selection for this rank; the selection of step i travels while the one of step i + 1 is made.  What arrives is kept
+        // per owner and put in owner order (ascending k-mer ranges) when the last piece is there.
+        struct StepMsg {
+            uint64_t n_t, n_e;
+            pag_build_stats st;
+        };
+        std::vector<std::vector<void *>> piece((size_t)W, std::vector<void *>(7, nullptr));  // [owner][array]
+        std::vector<uint64_t> piece_t(W, 0), piece_e(W, 0);
+        DevTemp rtmp;
+        Xchg X;
+        XchgGuard xguard{X};
+        const double tl0 = now_s();
+        double prev_begin = 0;
+        for (int i = 0; i < W; ++i) {
+            const int dst = (me + i) % W, src = (me - i + W) % W;
+            const double ts0 = now_s();
+            if ((rc = pag_shard_select(g, &regions[dst], &sel[dst]))) return rc;
+            const void *from[7] = {sel[dst].tkey, sel[dst].tval, sel[dst].tseg, sel[dst].tcnt, sel[dst].ekey, sel[dst].eval, sel[dst].eseg};
+            std::vector<uint64_t> at0 = at;
+            for (int a = 0; a < 7; ++a) {
+                const uint64_t n = a < 4 ? sel[dst].n_t : sel[dst].n_e;
+                DevBuf b(g, arrs[a].slot);
+                const uint64_t need = (at[a] + n + 1) * arrs[a].esz;
+                if (b.sl->cap < need) {
+                    // (grown with the old contents kept; an exchange that still reads the old array is waited for first)
+                    if ((rc = xchg_end(X))) return rc;
+                    void *np = nullptr;
+                    const size_t want = need + need / 2 + 256;
+                    PAG_HIP_TRY(hipMalloc(&np, want));
+                    if (b.sl->p && at[a]) PAG_HIP_TRY(hipMemcpy(np, b.sl->p, at[a] * arrs[a].esz, hipMemcpyDeviceToDevice));
+                    if (b.sl->p) hipFree(b.sl->p);
+                    b.sl->p = np;
+                    b.sl->cap = want;
+                    if (piece[(size_t)me][a]) piece[(size_t)me][a] = b.sl->p;  // (this rank's own piece lies at the front of these arrays)
+                }
+                if (n) PAG_HIP_TRY(hipMemcpyAsync((char *)b.sl->p + at[a] * arrs[a].esz, from[a], n * arrs[a].esz, hipMemcpyDeviceToDevice, s));
+                at[a] += n;
+            }
+            PAG_HIP_TRY(hipStreamSynchronize(s));
+            const double ts1 = now_s();
+            t_select += ts1 - ts0;
+            std::vector<StepMsg> msg(W);
+            StepMsg mine_msg{sel[dst].n_t, sel[dst].n_e, sel[dst].stats};
+            if ((rc = pag_comm_all_gather(c, &mine_msg, sizeof mine_msg, msg.data()))) return rc;
+            const bool was_active = X.active;
+            if ((rc = xchg_end(X))) return rc;
+            if (was_active) {
+                t_rxfer += X.t_done - prev_begin;
+                t_rhidden += std::max(0.0, std::min(X.t_done, ts1) - std::max(prev_begin, ts0));
+            }
+            piece_t[(size_t)src] = msg[(size_t)src].n_t;
+            piece_e[(size_t)src] = msg[(size_t)src].n_e;
+            from_owner[(size_t)src] = msg[(size_t)src].st;
+            if (i == 0) {  // this rank's own selection stays where it is
+                for (int a = 0; a < 7; ++a) piece[(size_t)me][a] = (char *)g->pool[arrs[a].slot].p + at0[a] * arrs[a].esz;
+                continue;
+            }
+            std::vector<XchgArr> xa(7);
+            for (int a = 0; a < 7; ++a) {
+                const uint64_t n_out = a < 4 ? sel[dst].n_t : sel[dst].n_e, n_in = a < 4 ? piece_t[(size_t)src] : piece_e[(size_t)src];
+                if (!(piece[(size_t)src][a] = rtmp.get((n_in + 1) * arrs[a].esz))) return PAG_ENOMEM;
+                xa[a].sb.assign(W, 0);
+                xa[a].rb.assign(W, 0);
+                xa[a].sb[(size_t)dst] = n_out * arrs[a].esz;
+                xa[a].rb[(size_t)src] = n_in * arrs[a].esz;
+                xa[a].send = (const char *)g->pool[arrs[a].slot].p + at0[a] * arrs[a].esz;
+                xa[a].recv = piece[(size_t)src][a];
+            }
+            if ((rc = xchg_begin(c, X, std::move(xa)))) return rc;
+            prev_begin = X.t_begin;
+        }
+        const bool was_active = X.active;
+        if ((rc = xchg_end(X))) return rc;
+        if (was_active) t_rxfer += X.t_done - prev_begin;
+        t_loop1 = now_s() - tl0;
+        mark(4);
+        for (int o = 0; o < W; ++o) {
+            T += piece_t[(size_t)o];
+            E += piece_e[(size_t)o];
+        }
+        for (int a = 0; a < 7; ++a) {
+            if ((rc = imp[a].alloc(((a < 4 ? T : E) + 1) * arrs[a].esz))) return rc;
+            uint64_t off = 0;
+            for (int o = 0; o < W; ++o) {  // owner order = ascending k-mer ranges
+                const uint64_t n = a < 4 ? piece_t[(size_t)o] : piece_e[(size_t)o];
+                if (n) PAG_HIP_TRY(hipMemcpyAsync((char *)imp[a].p + off * arrs[a].esz, piece[(size_t)o][a], n * arrs[a].esz, hipMemcpyDeviceToDevice, s));
+                off += n;
+            }
+        }
+        PAG_HIP_TRY(hipStreamSynchronize(s));
+    } else {
     for (int d = 0; d < W; ++d) {
         if ((rc = pag_shard_select(g, &regions[d], &sel[d]))) return rc;
         my_sizes[2 * d] = sel[d].n_t;
@@ -615,18 +947,15 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         PAG_HIP_TRY(hipStreamSynchronize(s));
     }
     mark(4);
-    const uint64_t sent1 = pag_comm_bytes_sent(c);
     if ((rc = pag_comm_all_gather(c, my_sizes.data(), my_sizes.size() * 8, all_sizes.data()))) return rc;
     std::vector<pag_build_stats> all_stats((size_t)W * W);
     if ((rc = pag_comm_all_gather(c, stats_to.data(), stats_to.size() * sizeof(pag_build_stats), all_stats.data()))) return rc;
     auto size_of = [&](int owner, int dst, int which) { return all_sizes[((size_t)owner * W + dst) * 2 + which]; };
-    uint64_t T = 0, E = 0;
     for (int o = 0; o < W; ++o) {
         T += size_of(o, me, 0);
         E += size_of(o, me, 1);
     }
     // received straight into the buffers pag_shard_import fills (slots 52 .. 58): owner order = ascending k-mer ranges
-    DevBuf imp[7] = {DevBuf(g, 52), DevBuf(g, 53), DevBuf(g, 54), DevBuf(g, 55), DevBuf(g, 56), DevBuf(g, 57), DevBuf(g, 58)};
     for (int a = 0; a < 7; ++a) {
         const uint64_t n = a < 4 ? T : E;
         if ((rc = imp[a].alloc((n + 1) * arrs[a].esz))) return rc;
@@ -637,11 +966,13 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         }
         if ((rc = pag_comm_all_to_all_v(c, g->pool[arrs[a].slot].p, sb.data(), imp[a].p, rb.data()))) return rc;
     }
+        for (int o = 0; o < W; ++o) from_owner[(size_t)o] = all_stats[(size_t)o * W + me];
+    }
     mark(5);
     wire[1] = pag_comm_bytes_sent(c) - sent1;
     pag_build_stats st{};
     for (int o = 0; o < W; ++o) {
-        const pag_build_stats &P = all_stats[(size_t)o * W + me];
+        const pag_build_stats &P = from_owner[(size_t)o];
         for (int q = 0; q < 2; ++q) {
             st.merge_edge[q] += P.merge_edge[q];
             st.total_pos[q] += P.total_pos[q];
@@ -659,9 +990,11 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
     mark(6);
     if (timing)
         std::fprintf(stderr,
-                     "[shard timing] rank %d/%d extract+partition %.4f s, counts+buffers %.4f s, tuple exchange %.4f s (%llu B out), K2-K4 %.4f s, "
-                     "selections for %d ranks %.4f s, region exchange %.4f s (%llu B out), import+region+release %.4f s\n",
-                     me, W, lap[0], lap[1], lap[2], (unsigned long long)wire[0], lap[3], W, lap[4], lap[5], (unsigned long long)wire[1], lap[6]);
+                     "[shard timing] rank %d/%d tuples in %d chunks: extraction + owner partition %.4f s, exchange %.4f s of which %.4f s beside the next chunk's "
+                     "extraction (loop %.4f s, %llu B out), owner layout %.4f s, K2-K4 %.4f s; regions %s: selections for %d ranks %.4f s, exchange %.4f s of which "
+                     "%.4f s beside the next selection (loop %.4f s, %llu B out), owner order %.4f s, import+region+release %.4f s\n",
+                     me, W, C, t_extract, t_xfer, t_hidden, t_loop0, (unsigned long long)wire[0], lap[1] + lap[2], lap[3], pipeline ? "pipelined" : "whole", W,
+                     pipeline ? t_select : lap[4], pipeline ? t_rxfer : lap[5], t_rhidden, t_loop1, (unsigned long long)wire[1], pipeline ? lap[5] : 0.0, lap[6]);
     if (total) *total = st;
     return PAG_OK;
 }

@@ -52,10 +52,10 @@ public:
         } else if (std::sscanf(sh, "%d/%d", &r, &n) != 2) {
             throw std::runtime_error("PAGRAPH_SHARD must be r/N or env");
         }
-        if (n <= 1) return;
+        if (n < 1 || (n == 1 && !std::getenv("PAG_COMM_FORCE_RCCL"))) return;  // (one rank takes the sharded path only as a test of it: RCCL with itself)
         const char *dir = std::getenv("PAGRAPH_SHARD_DIR");
         if (!dir) throw std::runtime_error("PAGRAPH_SHARD needs PAGRAPH_SHARD_DIR (a fresh directory every rank sees)");
-        if (n != 2 && n != 4 && n != 8) throw std::runtime_error("PAGRAPH_SHARD: 2, 4 or 8 ranks");
+        if (n != 1 && n != 2 && n != 4 && n != 8) throw std::runtime_error("PAGRAPH_SHARD: 1, 2, 4 or 8 ranks");  // (1: the sharded path with itself, a test aid)
         int err = 0;
         comm_ = pag_comm_create(r, n, dir, device_, std::getenv("PAGRAPH_SHARD_TRANSPORT"), &err);
         if (!comm_) throw std::runtime_error(std::string("pag_comm_create failed (") + std::to_string(err) + "): " + pag_last_error());

@@ -254,6 +254,10 @@ typedef struct pag_shard_slice {
     pag_build_stats stats;  /* this owner's share of every count */
 } pag_shard_slice;
 int pag_shard_extract(pag_graph *g, const pag_build_input *in, uint32_t shard, uint32_t n_shards, uint64_t *counts);
+/* ... for the reads at emission positions [emit_lo, emit_hi) — a CHUNK of a shard's range: pag_shard_run extracts its reads in
+ * chunks and sends chunk c to the owners while chunk c + 1 is extracted (SURVEY.md 8e "overlap with extraction by chunking"); the
+ * chunks of a shard, one behind the other, are the shard's range, so the owner's layout argument above holds chunk by chunk. */
+int pag_shard_extract_range(pag_graph *g, const pag_build_input *in, uint64_t emit_lo, uint64_t emit_hi, uint32_t n_shards, uint64_t *counts);
 int pag_shard_take(pag_graph *g, uint32_t *tkey, uint64_t *tval, uint32_t *ekey, uint64_t *eval);
 int pag_shard_take_part(pag_graph *g, uint64_t t_off, uint64_t t_n, uint32_t *tkey, uint64_t *tval, uint64_t e_off, uint64_t e_n, uint32_t *ekey,
                         uint64_t *eval);

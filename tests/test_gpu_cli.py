@@ -190,6 +190,39 @@ def test_one_block_built_by_several_pagraph_processes(name, world, workdir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("label,world,extra", [
+    ("whole exchanges", 2, {"PAG_SHARD_CHUNKS": "1", "PAG_SHARD_PIPELINE": "0"}),
+    ("three chunks", 4, {"PAG_SHARD_CHUNKS": "3"}),
+    ("more chunks than a rank has reads", 2, {"PAG_SHARD_CHUNKS": "64"}),
+    ("one rank over RCCL with itself", 1, {"PAG_COMM_FORCE_RCCL": "1", "PAGRAPH_SHARD_TRANSPORT": "rccl"}),
+])
+def test_sharded_build_in_chunks_and_pipelined_equals_the_golden(label, world, extra, workdir):
+    """pag_shard_run sends a rank's tuples in chunks while the next chunk is extracted, and the selection for one rank while the
+    next one is made (round 5): any number of chunks, the whole exchanges of round 4, and — the only way RCCL's grouped sends and
+    receives of that path can run on a one-GPU box — ONE rank exchanging with itself over RCCL: the golden files every time."""
+    import tempfile
+    name = "two_blocks_both_orient_t16"
+    spec = goldens.load_spec(name)
+    tag = label.replace(" ", "_")
+    ind = goldens.materialize_inputs(name, str(workdir / f"shardvar_{tag}" / name / "in"))
+    out = str(workdir / f"shardvar_{tag}" / name / "out")
+    os.makedirs(out, exist_ok=True)
+    argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
+    rdv = tempfile.mkdtemp(prefix="pagshard_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PAGRAPH_SHARD=f"{r}/{world}", PAGRAPH_SHARD_DIR=rdv, PAGRAPH_SHARD_TRANSPORT="host", PAG_COMM_TIMEOUT_S="120",
+                   PAG_DEVICE_SHARERS=str(world), PAG_SHARD_TIMING="1")
+        env.update(extra)
+        procs.append(subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    for r, pr in enumerate(procs):
+        so, se = pr.communicate(timeout=300)
+        assert pr.returncode == 0, f"{label}, rank {r}: " + se[-2000:] + so[-1000:]
+        assert "[shard timing]" in se, se[-500:]
+    goldens.compare_out_dir(name, out)
+
+
+@pytest.mark.gpu
 def test_config_blocks_dealt_out_over_processes_equal_the_golden(workdir):
     """PAGRAPH_BLOCKS: the blocks of one config.txt processed by different bin/pagraph processes (what parallel.
     run_config_blocks does with one process per GPU) — here one after the other on the one GPU — and contig.txt merged."""
