@@ -38,6 +38,7 @@ struct WaveLds {
     uint32_t scode[MAXS]; // per tile-local sample: k-mer code
     uint32_t scnt[MAXS];  // per sample: tuple count, then exclusive offset inside the tile
     uint32_t srun[MAXS];  // per sample: tuples written so far
+    uint32_t st[MAXS];    // per sample: target position under the alignment being written (F2), all ones = not covered by it
 };
 constexpr int MAXS_SPACED = 352;  // >= ceil(1024 / 3), a multiple of 16
 
@@ -514,7 +515,11 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
                 }
                 __syncthreads();
             }
-            // F2: write
+            // F2: write.  Two phases per alignment (round 5): the walk only notes the target position of every kept sample it
+            // covers (LDS), then the lanes take the samples IN ORDER — lane l the samples l, l + 64, .. — with the map lookups
+            // of all its samples in flight together and the tuples of neighbouring samples written by neighbouring lanes.
+            // (Before, the lane that owned a column did the lookups and the stores from inside the walk: up to sixteen
+            // columns per lane one after the other, each kept one a chain of two dependent gathers and two stores.)
             const uint64_t out0 = tuple_base + job_tuples;
             for_active([&](const pag_aln &al, uint64_t ai) {
                 const bool ctg_pass = A.pass == 0;
@@ -522,30 +527,58 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
                 uint32_t ref_base = 0;
                 if (ctg_pass) cg = A.ctgs[al.target];
                 else ref_base = A.refs[al.target].single_base;
+                constexpr int PER = MAXS / 64 + (MAXS % 64 ? 1 : 0);
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    if (lane + 64u * i < tile_samples) L.st[lane + 64u * i] = 0xFFFFFFFFu;
+                __syncthreads();
                 walk_alignment(al, A.diff, A.colidx + A.colidx_off[ai], t0, t_hi, [&](uint32_t q, uint32_t t) {
                     uint32_t d = q - t0;
                     uint32_t km = L.kept[d >> 4];
-                    if ((km >> (d & 15u)) & 1u) {
-                        uint32_t s_local = L.rank[d >> 4] + __popc(km & ((1u << (d & 15u)) - 1u));
-                        uint32_t run = L.srun[s_local];
-                        uint64_t dst = out0 + L.scnt[s_local] + run;
-                        uint32_t kc = L.scode[s_local];
+                    if ((km >> (d & 15u)) & 1u) L.st[L.rank[d >> 4] + __popc(km & ((1u << (d & 15u)) - 1u))] = t;
+                });
+                __syncthreads();
+                constexpr int G = 6;  // samples per lane and turn (MAXS = 352: one turn)
+                for (uint32_t sb = 0; sb < tile_samples; sb += 64u * G) {
+                    uint32_t tt[G], e0[G], e1[G], ent0[G];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        const uint32_t sx = sb + lane + 64u * i;
+                        tt[i] = sx < tile_samples ? L.st[sx] : 0xFFFFFFFFu;
+                    }
+                    if (ctg_pass) {
+#pragma unroll
+                        for (int i = 0; i < G; ++i)
+                            if (tt[i] != 0xFFFFFFFFu) {
+                                e0[i] = A.ctg_ent_off[cg.map_off + tt[i]];
+                                e1[i] = A.ctg_ent_off[cg.map_off + tt[i] + 1];
+                            }
+#pragma unroll
+                        for (int i = 0; i < G; ++i)  // (a base's first entry — nearly always its only one — asked for together as well)
+                            if (tt[i] != 0xFFFFFFFFu && e1[i] > e0[i]) ent0[i] = A.ctg_ent[e0[i]];
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        if (tt[i] == 0xFFFFFFFFu) continue;
+                        const uint32_t sx = sb + lane + 64u * i;
+                        const uint32_t run = L.srun[sx];
+                        uint64_t dst = out0 + L.scnt[sx] + run;
+                        const uint32_t kc = L.scode[sx];
                         if (ctg_pass) {
-                            uint32_t e0 = A.ctg_ent_off[cg.map_off + t], e1 = A.ctg_ent_off[cg.map_off + t + 1];
-                            uint64_t hi = (uint64_t)(cg.single_base + t) << 32;
-                            for (uint32_t e = e0; e < e1; ++e) {
+                            const uint64_t hi = (uint64_t)(cg.single_base + tt[i]) << 32;
+                            for (uint32_t e = e0[i]; e < e1[i]; ++e) {
                                 A.tkey[dst] = kc;
-                                A.tval[dst] = hi | A.ctg_ent[e];
+                                A.tval[dst] = hi | (e == e0[i] ? ent0[i] : A.ctg_ent[e]);
                                 ++dst;
                             }
-                            L.srun[s_local] = run + (e1 - e0);
+                            L.srun[sx] = run + (e1[i] - e0[i]);
                         } else {
                             A.tkey[dst] = kc;
-                            A.tval[dst] = (uint64_t)(uint32_t)(ref_base + t);
-                            L.srun[s_local] = run + 1;
+                            A.tval[dst] = (uint64_t)(uint32_t)(ref_base + tt[i]);
+                            L.srun[sx] = run + 1;
                         }
                     }
-                });
+                }
                 __syncthreads();
             });
             job_tuples += tile_tuples;
