@@ -605,6 +605,47 @@ __global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uin
     }
 }
 
+// may successors of a vertex lie outside the region this graph holds?  r = its reference coordinate, on_contig = it has a contig
+// coordinate (new id >= n_zero).  The ONE statement of the test: k_mark_incomplete leaves it as a bit per new id, the successor
+// kernels — threads in k-mer-major order, to which a bit at the vertex's new id is a random sector — evaluate it again from the
+// vertex's own position with the bands staged in LDS.
+__device__ __forceinline__ bool d_incomplete_by_position(const uint32_t *iv, const uint8_t *open, uint32_t n_iv, uint32_t margin, uint32_t r, bool on_contig) {
+    uint32_t lo = 0, hi = n_iv;  // last interval with lo <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (iv[2 * mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    bool bad = n_iv == 0 || r < iv[2 * lo] || r >= iv[2 * lo + 1];
+    if (!bad) bad = (open[2 * lo] && r - iv[2 * lo] < margin) || (open[2 * lo + 1] && iv[2 * lo + 1] - r <= margin);
+    if (on_contig && r == 0u) bad = false;
+    return bad;
+}
+
+constexpr uint32_t INC_LDS_MAX = 256;  // bands a successor kernel stages in LDS (more: the bit per new id is gathered)
+struct IncLds {
+    uint32_t iv[2 * INC_LDS_MAX];
+    uint8_t open[2 * INC_LDS_MAX];
+};
+__device__ __forceinline__ bool inc_lds_fill(IncLds &I, const TravGraph &G) {  // (all threads of the block; __syncthreads after it)
+    const bool use = G.incomplete && G.inc_iv && G.inc_n <= INC_LDS_MAX;
+    if (use)
+        for (uint32_t i = threadIdx.x; i < 2u * G.inc_n; i += blockDim.x) {
+            I.iv[i] = G.inc_iv[i];
+            I.open[i] = G.inc_open[i];
+        }
+    return use;
+}
+// poison / marker of vertex v (new id u): from its own position when the bands are in LDS, else the bit at its new id
+__device__ __forceinline__ bool vertex_incomplete(const TravGraph &G, const IncLds &I, bool lds, uint64_t v, uint32_t u) {
+    if (!G.incomplete) return false;
+    if (lds) {
+        const uint64_t pv = G.vpos[v];
+        return d_incomplete_by_position(I.iv, I.open, G.inc_n, G.inc_margin, (uint32_t)pv, (pv >> 32) != 0u);
+    }
+    return ((G.incomplete[u >> 5] >> (u & 31u)) & 1u) != 0u;
+}
+
 // The candidate pairs of one vertex v (searchSuccessors + checkPosition + isEdgeSimilar, PABruijnGraph.cpp:143-197,385-400):
 // every position of every target node of its k-mer node, in CSR order.  WHAT = 0: count the accepted ones, and note in
 // `mask` which of the first 64 candidates they are.  WHAT = 1: write the accepted ones to out[0 ..] — the first 64
@@ -775,7 +816,9 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
                        SuccRec *__restrict__ stage, uint64_t *__restrict__ amask, uint32_t *__restrict__ heavy_list,
                        unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    __shared__ IncLds inc_bands;
     d_ratio_table_fill(ratio_tab, err);
+    const bool inc_lds = inc_lds_fill(inc_bands, G);
     __syncthreads();
     constexpr bool FILL = MODE == 1 || MODE == 3 || MODE == 4;  // (3, 4: with the heavy list and a limit of at most 64 — see succ_vertex)
     if (!heavy_list || MODE == 2) heavy_limit = 0xFFFFFFFFu;
@@ -786,7 +829,7 @@ __global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, doub
         // successors of it may lie outside the region this graph holds (k_mark_incomplete).  A coordinate-free vertex gets one
         // poison record IN PLACE of its successors; a vertex on a contig keeps its successors — those that follow the contig
         // are all here — and gets one marker record behind them that only counts where a walk could take a Skip grade
-        const bool inc = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+        const bool inc = vertex_incomplete(G, inc_bands, inc_lds, v, u);
         const bool poison = inc && u < G.n_zero, marker = inc && u >= G.n_zero;
         if (poison) n = 1u;
         else if (MODE == 0) {
@@ -839,13 +882,15 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_succ_heavy(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ amask,
                                                     const uint32_t *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_n) {
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    __shared__ IncLds inc_bands;
     d_ratio_table_fill(ratio_tab, err);
+    const bool inc_lds = inc_lds_fill(inc_bands, G);
     __syncthreads();
     const uint64_t total = *heavy_n, n_waves = (uint64_t)gridDim.x * (blockDim.x / 64u);
     for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < total; i += n_waves) {
         const uint64_t v = heavy_list[i];
         const uint32_t u = G.newid[v];
-        const bool marker = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);  // (a poisoned vertex never comes here)
+        const bool marker = vertex_incomplete(G, inc_bands, inc_lds, v, u);  // (a poisoned vertex never comes here)
         uint64_t mask = 0ull;
         if (MODE == 0) {
             const uint32_t n = succ_vertex_wave<0>(G, v, dev, err, mask, nullptr, ratio_tab) + (marker ? 1u : 0u);
@@ -881,7 +926,9 @@ __global__ void __launch_bounds__(256, 8) k_succ_fused(TravGraph G, uint32_t dev
                                                        SuccRec *__restrict__ stage, uint64_t cap, unsigned long long *__restrict__ cursor,
                                                        uint32_t *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    __shared__ IncLds inc_bands;
     d_ratio_table_fill(ratio_tab, err);
+    const bool inc_lds = inc_lds_fill(inc_bands, G);
     __syncthreads();
     if (!heavy_list) heavy_limit = 0xFFFFFFFFu;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -893,7 +940,7 @@ __global__ void __launch_bounds__(256, 8) k_succ_fused(TravGraph G, uint32_t dev
         bool poison = false, marker = false, heavy = false;
         if (active) {
             u = G.newid[v];
-            const bool inc = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);
+            const bool inc = vertex_incomplete(G, inc_bands, inc_lds, v, u);
             poison = inc && u < G.n_zero;
             marker = inc && u >= G.n_zero;
             if (poison) n = 1u;
@@ -942,13 +989,15 @@ __global__ void __launch_bounds__(256) k_succ_heavy_fused(TravGraph G, uint32_t 
                                                           SuccRec *__restrict__ stage, uint64_t cap, unsigned long long *__restrict__ cursor,
                                                           const uint32_t *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_n) {
     __shared__ uint32_t ratio_tab[RATIO_TAB_N];
+    __shared__ IncLds inc_bands;
     d_ratio_table_fill(ratio_tab, err);
+    const bool inc_lds = inc_lds_fill(inc_bands, G);
     __syncthreads();
     const uint64_t total = *heavy_n, n_waves = (uint64_t)gridDim.x * (blockDim.x / 64u);
     for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < total; i += n_waves) {
         const uint64_t v = heavy_list[i];
         const uint32_t u = G.newid[v];
-        const bool marker = G.incomplete && ((G.incomplete[u >> 5] >> (u & 31u)) & 1u);  // (a poisoned vertex never comes here)
+        const bool marker = vertex_incomplete(G, inc_bands, inc_lds, v, u);  // (a poisoned vertex never comes here)
         uint64_t mask = 0ull;
         const uint32_t n = succ_vertex_wave<0>(G, v, dev, err, mask, nullptr, ratio_tab) + (marker ? 1u : 0u);
         unsigned long long off = 0;
@@ -3496,27 +3545,14 @@ __global__ void k_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *
                                   uint32_t margin, uint32_t *__restrict__ bits) {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
-    if (u < G.n_pos) {
-        const uint32_t r = (uint32_t)G.upos[u];
-        uint32_t lo = 0, hi = n_iv;  // last interval with lo <= r
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (iv[2 * mid] <= r) lo = mid;
-            else hi = mid;
-        }
-        bad = n_iv == 0 || r < iv[2 * lo] || r >= iv[2 * lo + 1];
-        if (!bad) {
-            bad = (open[2 * lo] && r - iv[2 * lo] < margin) || (open[2 * lo + 1] && iv[2 * lo + 1] - r <= margin);
-        }
-        if (u >= n_zero && r == 0u) bad = false;
-    }
+    if (u < G.n_pos) bad = d_incomplete_by_position(iv, open, n_iv, margin, (uint32_t)G.upos[u], u >= n_zero);
     const uint64_t m = __ballot(bad);
     if ((threadIdx.x & 63u) == 0 && u < ((G.n_pos + 63ull) & ~63ull)) {
         bits[u >> 5] = (uint32_t)m;
         bits[(u >> 5) + 1] = (uint32_t)(m >> 32);
     }
 }
-int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
+int trav_mark_incomplete(TravGraph &G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
                          uint32_t *bits, void *tmp, hipStream_t s) {
     // tmp: u32 max step | intervals | open flags
     uint32_t *d_max = (uint32_t *)tmp;
@@ -3533,8 +3569,16 @@ int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, 
     PAG_HIP_TRY(hipStreamSynchronize(s));
     // a successor's coordinate lies within step + deviation, or step x (1 + error rate), of its source's (checkPosition)
     const uint64_t margin = (uint64_t)((double)max_step * (1.0 + err)) + dev + 2;
-    if (G.n_pos) k_mark_incomplete<<<dim3((unsigned)((G.n_pos + 255) / 256)), dim3(256), 0, s>>>(G, n_zero, d_iv, d_open, n_iv, (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu), bits);
+    // the bit per new id is only read when the successor kernels cannot repeat the test themselves (more bands than they stage in
+    // LDS, or PAG_SUCC_INC_BITS=1); `incomplete` stays the flag that the graph holds a region
+    const bool bits_read = n_iv > INC_LDS_MAX || (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0);
+    if (G.n_pos && bits_read) k_mark_incomplete<<<dim3((unsigned)((G.n_pos + 255) / 256)), dim3(256), 0, s>>>(G, n_zero, d_iv, d_open, n_iv, (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu), bits);
     PAG_HIP_TRY(hipGetLastError());
+    G.incomplete = bits;
+    G.inc_iv = d_iv;  // (the scratch slot lives as long as the traversal graph: the successor kernels repeat the test, d_incomplete_by_position)
+    G.inc_open = d_open;
+    G.inc_n = n_iv;
+    G.inc_margin = (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu);
     return PAG_OK;
 }
 size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv) { return 256 + (2 * (size_t)n_iv + 2) * 4 + 2 * (size_t)n_iv + 64; }
@@ -3692,6 +3736,7 @@ int trav_successors_of(TravGraph G, uint32_t code, uint64_t pos, void *recs, uin
 int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
                     const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
                     uint32_t heavy_limit, hipStream_t s) {
+    if (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0) G.inc_iv = nullptr;  // (the bit per new id gathered, as until round 5)
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
     if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
@@ -3713,6 +3758,7 @@ int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64
 int trav_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, uint64_t *stage_off,
                     SuccRec *stage, uint64_t cap, unsigned long long *cursor_dev, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit,
                     hipStream_t s) {
+    if (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0) G.inc_iv = nullptr;  // (the bit per new id gathered, as until round 5)
     const uint64_t n = G.n_pos;
     if (!n) return PAG_OK;
     if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
@@ -3742,6 +3788,7 @@ int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tm
 }
 int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
                    uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s) {
+    if (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0) G.inc_iv = nullptr;  // (the bit per new id gathered, as until round 5)
     if (!G.n_pos) return PAG_OK;
     if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
     if (stage) {

@@ -434,7 +434,6 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             if ((rc = b_inc.alloc(((size_t)G.n_pos / 32 + 4) * 4)) || (rc = b_inct.alloc(trav_mark_incomplete_tmp_bytes(n_iv)))) return rc;
             if ((rc = trav_mark_incomplete(G, G.n_zero, riv.data(), ropen.data(), n_iv, (uint32_t)deviation, errorRate, b_inc.as<uint32_t>(), b_inct.p, s)))
                 return rc;
-            G.incomplete = b_inc.as<uint32_t>();
         }
         uint64_t n_succ = 0, n_cand = 0;
         // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a

@@ -41,6 +41,14 @@ struct TravGraph {
     // GRADE_POISON instead of its successors; a walk that examines it reports a fault (TravJobOut::poison).
     const uint32_t *incomplete;  // null: the whole graph is here
     uint32_t n_zero;
+    // What k_mark_incomplete tested, kept so that a kernel whose threads run over the vertices in ANOTHER order (the successor
+    // kernels: k-mer-major) can repeat the test from the vertex's own position instead of gathering the bit at a random place:
+    // the reference bands [inc_iv[2 i], inc_iv[2 i + 1]) of the region, ascending, whether either end of a band is open
+    // (inc_open[2 i], [2 i + 1]) and the margin a successor's coordinate can lie beyond its source's.  inc_n = 0 with
+    // `incomplete` set: every vertex with a reference coordinate is marked.  (device pointers)
+    const uint32_t *inc_iv;
+    const uint8_t *inc_open;
+    uint32_t inc_n, inc_margin;
 };
 constexpr uint32_t GRADE_POISON = 7u, GRADE_POISON_IF_LEAP = 6u;  // (marker records, see k_succ / walk_note_record in k5_travel.hip)
 
@@ -197,8 +205,8 @@ void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut
 void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
                         uint32_t gmask, hipStream_t s);
 void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s);
-int trav_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
-                         uint32_t *bits, void *tmp, hipStream_t s);
+int trav_mark_incomplete(TravGraph &G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
+                         uint32_t *bits, void *tmp, hipStream_t s);  // (sets G.incomplete and G.inc_*)
 size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv);
 
 int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,

@@ -170,11 +170,13 @@ MODES = [  # (label, view, environment)
     ("cut tight twopass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight twopass heavy=4", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight twopass, graded by the filling pass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_DEFER": "0", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight twopass, the incomplete bit gathered", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_INC_BITS": "1", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight fused, the incomplete bit gathered", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_INC_BITS": "1", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight bound", "for", {"PAG_SUCC_MODE": "bound", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight fused", "for", {"PAG_SUCC_MODE": "fused", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut tight fused heavy=4", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
 ]
-SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS", "PAG_NODE_ORDER", "PAG_SUCC_DEFER")
+SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS", "PAG_NODE_ORDER", "PAG_SUCC_DEFER", "PAG_SUCC_INC_BITS")
 
 
 @pytest.mark.gpu
