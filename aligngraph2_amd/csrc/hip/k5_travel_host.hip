@@ -1108,7 +1108,12 @@ struct WalkSession {
                 const uint64_t margin = cfg.seg_safety_set ? cfg.seg_safety : cs.len / 400 + 200;
                 if (split > H + seg_len) {
                     const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H) + margin, (uint64_t)cs.ctgRight - 1);
-                    for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
+                    // (the last stretch before the zone in shorter segments, cfg.seg_tail_frac of the way: the jobs that enter the
+                    // ring last are the ones that run while the grid empties — a job's length is how ragged the end of the first
+                    // rounds is)
+                    const uint64_t tail_from = cfg.seg_tail_frac > 0 ? zone - (uint64_t)((double)(zone - x0) * cfg.seg_tail_frac) : zone;
+                    const uint64_t short_len = std::max<uint64_t>(seg_len / 2, seg_ov * 2);
+                    for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += (x >= tail_from ? short_len : seg_len)) ck_x.push_back((uint32_t)x);
                     if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
                 }
                 n_spec_ck = ck_x.size();

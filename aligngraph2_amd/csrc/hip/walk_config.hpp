@@ -38,6 +38,7 @@ struct WalkConfig {
     bool keep_segments = true;        // PAG_WALK_KEEP_SEGMENTS
     uint64_t seg_len = 0;             // PAG_SEG_LEN (0: 12000)
     uint64_t seg_overlap = 1500;      // PAG_SEG_OVERLAP
+    double seg_tail_frac = 0.0;       // PAG_SEG_TAIL_FRAC: the last fraction of a strand's segment stretch in segments of half the length
     bool seg_safety_set = false;      // PAG_SEG_SAFETY
     uint64_t seg_safety = 0;
     uint64_t leap_seg_len = 0;        // PAG_LEAP_SEG_LEN (0: derived from the segment length)
@@ -101,6 +102,7 @@ struct WalkConfig {
         c.keep_segments = !off("PAG_WALK_KEEP_SEGMENTS");
         u64("PAG_SEG_LEN", &c.seg_len);
         u64("PAG_SEG_OVERLAP", &c.seg_overlap);
+        if (const char *e = std::getenv("PAG_SEG_TAIL_FRAC")) c.seg_tail_frac = std::min(1.0, std::max(0.0, std::atof(e)));
         c.seg_safety_set = u64("PAG_SEG_SAFETY", &c.seg_safety);
         u64("PAG_LEAP_SEG_LEN", &c.leap_seg_len);
         c.leap_left_set = u64("PAG_LEAP_LEFT", &c.leap_left);
