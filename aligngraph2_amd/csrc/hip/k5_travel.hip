@@ -405,11 +405,15 @@ __global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_
 }
 
 // contig strand k-mers -> node ids (PABruijnGraph::findAll).  One thread per k-mer start.
-__global__ void k_ctg_nodes(const uint8_t *__restrict__ packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k,
-                            TravGraph G, uint32_t *__restrict__ out) {
+__global__ void k_ctg_nodes(const uint8_t *__restrict__ packed, const TravCtgNodesJob *__restrict__ jobs, uint32_t k, TravGraph G,
+                            uint32_t *__restrict__ out_all) {
+    const TravCtgNodesJob J = jobs[blockIdx.y];
+    const uint32_t len = J.len;
+    const bool forward = J.forward != 0;
+    uint32_t *__restrict__ out = out_all + J.out_off;
     const uint32_t n_pos = len >= k ? len - k + 1 : 0;
     const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
-    const uint32_t *words = (const uint32_t *)(packed + byte_off);
+    const uint32_t *words = (const uint32_t *)(packed + J.byte_off);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += gridDim.x * blockDim.x) {
         uint32_t a = forward ? i : len - k - i;  // first contig base (forward numbering) covered by the k-mer
         uint32_t w = a >> 4, sh = (a & 15u) * 2u;
@@ -3471,11 +3475,14 @@ int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev,
     return PAG_OK;
 }
 
-void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
-                           uint32_t *out, hipStream_t s) {
-    uint32_t n = len >= k ? len - k + 1 : 0;
-    if (!n) return;
-    k_ctg_nodes<<<dim3(grid_for(n)), dim3(256), 0, s>>>(packed, byte_off, len, forward, k, G, out);
+void trav_launch_ctg_nodes(const uint8_t *packed, const TravCtgNodesJob *jobs, uint32_t n_jobs, uint32_t max_len, uint32_t k, TravGraph G, uint32_t *out,
+                           hipStream_t s) {
+    const uint32_t n = max_len >= k ? max_len - k + 1 : 0;
+    if (!n || !n_jobs) return;
+    for (uint32_t at = 0; at < n_jobs; at += 65535u) {  // (gridDim.y)
+        const uint32_t m = std::min(n_jobs - at, 65535u);
+        k_ctg_nodes<<<dim3(std::min(grid_for(n), 256u), m), dim3(256), 0, s>>>(packed, jobs + at, k, G, out);
+    }
 }
 void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uint64_t dev, uint32_t *out, uint32_t stride,
                             hipStream_t s) {

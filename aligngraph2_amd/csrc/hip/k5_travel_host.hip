@@ -1532,9 +1532,19 @@ struct WalkSession {
         PAG_HIP_TRY(hipMemcpyAsync(b_packed.p, ctgs->packed, ctgs->packed_bytes, hipMemcpyHostToDevice, s));
         PAG_HIP_TRY(hipMemcpyAsync(b_starts.p, mapper.starts.data(), mapper.starts.size() * 8, hipMemcpyHostToDevice, s));
         PAG_HIP_TRY(hipMemcpyAsync(b_sizes.p, mapper.sizes.data(), mapper.sizes.size() * 8, hipMemcpyHostToDevice, s));
-        for (auto &cs : st)
-            trav_launch_ctg_nodes(b_packed.as<uint8_t>(), ctgs->byte_off[cs.ci], cs.len, cs.forward ? 1 : 0, k, G,
-                                  b_nodes.as<uint32_t>() + cs.nodesOff, s);
+        {   // the strands' node tables: one launch
+            std::vector<TravCtgNodesJob> cj;
+            uint32_t max_len = 0;
+            for (auto &cs : st) {
+                cj.push_back(TravCtgNodesJob{ctgs->byte_off[cs.ci], cs.nodesOff, (uint32_t)cs.len, cs.forward ? 1 : 0});
+                max_len = std::max<uint32_t>(max_len, (uint32_t)cs.len);
+            }
+            DevBuf b_cj = buf();
+            if ((rc = b_cj.alloc(cj.size() * sizeof(TravCtgNodesJob)))) return rc;
+            PAG_HIP_TRY(hipMemcpyAsync(b_cj.p, cj.data(), cj.size() * sizeof(TravCtgNodesJob), hipMemcpyHostToDevice, s));
+            PAG_HIP_TRY(hipStreamSynchronize(s));  // (cj is a local)
+            trav_launch_ctg_nodes(b_packed.as<uint8_t>(), b_cj.as<TravCtgNodesJob>(), (uint32_t)cj.size(), max_len, k, G, b_nodes.as<uint32_t>(), s);
+        }
 
         tc.assign(n_sel, TravContig{});
         // id ranges of the strands, then the per-contig global visited structures
@@ -1642,6 +1652,7 @@ struct WalkSession {
         deferred.clear();
         deferred.resize(n_sel);
         b_ckreq = buf(), b_ckout = buf();
+        lap("rings");
         return PAG_OK;
     }
     // pinned staging + the walk arena
@@ -1675,6 +1686,7 @@ struct WalkSession {
             }
             g->walk_arena_used = 0;
         }
+        lap("arena");
         return PAG_OK;
     }
     // the first round of every contig is posted, the walker grid launched
@@ -1700,6 +1712,7 @@ struct WalkSession {
                     if (!st[i].done) first_rounds.push_back(i);
                 if ((rc = start_rounds(first_rounds))) return fail(rc);
             }
+            lap("first rounds planned");
             defer_ring2 = false;
             if (interleave) {
                 std::vector<size_t> at(n_sel, 0);
@@ -1748,9 +1761,11 @@ struct WalkSession {
                 for (auto &dq : deferred) std::vector<Deferred>().swap(dq);
             }
         }
+        lap("ring order");
         if (n_live) {
             walkers.init(g, G, hjobs, houts, hdone, hq, QCAP, k);
             if ((rc = publish())) return fail(rc);  // (the jobs' buffers are ready, the rings are visible)
+            lap("marks cleared, rings published");
             if ((rc = walkers.ensure(n_live))) {
                 g->defer_free = false;
                 return rc;

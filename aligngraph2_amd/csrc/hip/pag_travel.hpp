@@ -186,8 +186,15 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
                  uint64_t *counts_out = nullptr, int place_bits = 0);
 int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev, uint32_t n_z, uint32_t *lo_dev, uint32_t *hi_dev, hipStream_t s);
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes);
-void trav_launch_ctg_nodes(const uint8_t *packed, uint64_t byte_off, uint32_t len, int forward, uint32_t k, TravGraph G,
-                           uint32_t *out, hipStream_t s);
+struct TravCtgNodesJob {  // one contig strand of a k_ctg_nodes launch
+    uint64_t byte_off;  // of its packed bases
+    uint64_t out_off;   // of its node ids in the output array
+    uint32_t len;
+    int32_t forward;
+};
+// (jobs: device array; one launch for all strands — 49 launches of ~30 us one behind the other until round 5)
+void trav_launch_ctg_nodes(const uint8_t *packed, const TravCtgNodesJob *jobs, uint32_t n_jobs, uint32_t max_len, uint32_t k, TravGraph G, uint32_t *out,
+                           hipStream_t s);
 void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uint64_t dev, uint32_t *out, uint32_t stride,
                             hipStream_t s);
 void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
