@@ -58,7 +58,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 const std::set<std::pair<std::string, bool>> &ctgSet, std::size_t deviation,
                                                 double errorRate, double startSplit, std::size_t minLen, unsigned threadNum,
                                                 unsigned hostThreads, AssembleStats *stats, bool quiet,
-                                                std::vector<TravelSequence> &travelled, std::ostream *logTo) {
+                                                std::vector<TravelSequence> &travelled, std::ostream *logTo, const AssembleShare *share) {
     (void)minLen;     // (both only steer the walk itself, which has already happened: PAlgorithm::travelSequence on the device)
     (void)threadNum;
     const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
@@ -89,6 +89,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     const std::size_t CHUNK = 16384;
     struct DumpFile {
         std::size_t ctgIdx = 0, ctgOffset = 0, nChunks = 0;
+        bool written = true;
         std::FILE *f = nullptr;
         std::atomic<std::size_t> turn{0};
     };
@@ -103,6 +104,8 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
         // handed back at the end: no copy
         if (2 * F.ctgIdx + F.ctgOffset < travelled.size()) res.swap(travelled[2 * F.ctgIdx + F.ctgOffset]);
         F.nChunks = (res.size() + CHUNK - 1) / CHUNK;
+        F.written = !(share && share->writesDump) || share->writesDump(F.ctgIdx);  // (a sharded run: the rank that walked the contig writes its dump)
+        if (!F.written) F.nChunks = 0;
     }
     // chunk c of every file before chunk c + 1 of any: the threads then append to as many different files as there are
     // threads (writing new pages of a file is what the kernel serialises)
@@ -131,6 +134,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     std::atomic<bool> openFailed{false};
     runPool(files.size(), [&](std::size_t li) {
         DumpFile &F = files[li];
+        if (!F.written) return;
         const std::string path = outDir + "/" + prefix + std::to_string(F.ctgIdx) + "_" + std::to_string(F.ctgOffset) + ".txt";
         F.f = std::fopen(path.c_str(), "wb");
         if (!F.f) {
@@ -182,7 +186,14 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
     });
     for (std::size_t li = 0; li < ctgList.size(); ++li) {
         DumpFile &F = files[li];
-        std::fclose(F.f);
+        if (F.f) std::fclose(F.f);
+    }
+    if (share && share->dumpsOnly) {
+        lap("per-contig dumps of this rank's contigs");
+        return {};
+    }
+    for (std::size_t li = 0; li < ctgList.size(); ++li) {
+        DumpFile &F = files[li];
         std::stringstream log;
         log << "[Travel] " << F.ctgIdx << " - " << contigs.name(F.ctgIdx) << " - " << contigs.length(F.ctgIdx) << "\n";
         log << "[Travel] " << (F.ctgOffset == 0 ? "forward" : "reverse") << "\n";

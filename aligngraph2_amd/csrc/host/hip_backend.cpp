@@ -69,6 +69,7 @@ public:
     }
     unsigned shardRank() const override { return rank_; }
     unsigned shardWorld() const override { return world_; }
+    bool walksContig(std::size_t id) const override { return !comm_ || (id < plan_.ownerOf.size() && plan_.ownerOf[id] == static_cast<int>(rank_)); }
     const char *name() const override { return "HIP gfx950"; }
     void create(const std::uint64_t *words, std::size_t nWords, unsigned k) override {
         if (warm_.joinable()) warm_.join();

@@ -393,7 +393,23 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 const std::size_t slot = nHalves++ & 1u;
                 backend.travelWalks(ctx, tp, tviews[slot]);
                 lap("walks");
+                // ONE block by several ranks: every rank writes the path dumps of the contigs it walked (most of a block's
+                // output bytes), rank 0 — which has the travel sequences of all ranks — selects the chains and writes the rest
+                // (PAGRAPH_SHARD_RANK_DUMPS=0: rank 0 writes everything, as until round 5)
+                const bool rankDumps = backend.shardWorld() > 1 && !(std::getenv("PAGRAPH_SHARD_RANK_DUMPS") && std::atoi(std::getenv("PAGRAPH_SHARD_RANK_DUMPS")) == 0);
                 if (backend.shardRank() != 0) {
+                    if (rankDumps) {
+                        std::set<std::pair<std::string, bool>> own;
+                        for (auto &c : usedCtg)
+                            if (contigs.contains(c.first) && backend.walksContig(contigs.id(c.first))) own.emplace(c);
+                        const PositionMapper cm(contigs), rm(refs);
+                        buildPathGraph(tviews[slot].views, static_cast<unsigned>(kmers.k()), graphs[slot], precomputed[slot]);
+                        AssembleShare share;
+                        share.dumpsOnly = true;
+                        assemble(opt.out, prefix, graphs[slot], contigs, refs, cm, rm, own, opt.epsilon * 2, errorRate, startSplit, opt.minLen, opt.threads, 0,
+                                 nullptr, true, precomputed[slot], nullptr, &share);
+                        lap("path dumps of this rank's contigs");
+                    }
                     ++blockNo;
                     continue;
                 }
@@ -404,11 +420,19 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 unsigned poolThreads = 0;
                 if (nextNo < configs.size())
                     poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? static_cast<unsigned>(std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS")))) : 12u;
-                half.start([&, slot, prefix, usedCtg, poolThreads, tp]() {
+                // (which contigs this rank walked: a copy — the backend's plan is the next block's by the time the thread reads it)
+                std::vector<char> walkedHere;
+                if (rankDumps) {
+                    walkedHere.assign(contigs.size(), 0);
+                    for (std::size_t id = 0; id < contigs.size(); ++id) walkedHere[id] = backend.walksContig(id) ? 1 : 0;
+                }
+                half.start([&, slot, prefix, usedCtg, poolThreads, tp, rankDumps, walkedHere]() {
                     const PositionMapper cm(contigs), rm(refs);
                     buildPathGraph(tviews[slot].views, static_cast<unsigned>(kmers.k()), graphs[slot], precomputed[slot]);
+                    AssembleShare share;
+                    if (rankDumps) share.writesDump = [&walkedHere](std::size_t id) { return id < walkedHere.size() && walkedHere[id] != 0; };
                     return assemble(opt.out, prefix, graphs[slot], contigs, refs, cm, rm, usedCtg, opt.epsilon * 2, errorRate, startSplit, opt.minLen,
-                                    opt.threads, poolThreads, nullptr, false, precomputed[slot], &half.log);
+                                    opt.threads, poolThreads, nullptr, false, precomputed[slot], &half.log, rankDumps ? &share : nullptr);
                 });
                 ++blockNo;
             }

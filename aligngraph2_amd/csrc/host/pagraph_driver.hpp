@@ -38,6 +38,8 @@ public:
     // block's outputs.  shardRank() / shardWorld() = 0 / 1 for an ordinary run.
     virtual unsigned shardRank() const { return 0; }
     virtual unsigned shardWorld() const { return 1; }
+    // a sharded run: did THIS rank walk contig `id` of the current block (it then writes that contig's path dump)
+    virtual bool walksContig(std::size_t) const { return true; }
     virtual void exportCsr(HostGraph &out) = 0;
     // PAlgorithm::travelSequence for every (contig, orientation) of ctgSet (PAssembly.cpp:30-36): fills `graph` with (at
     // least) the vertices on the travel sequences and travelled[2 * contig + (reverse ? 1 : 0)].  The product backend

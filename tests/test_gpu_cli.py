@@ -195,10 +195,12 @@ def test_one_block_built_by_several_pagraph_processes(name, world, workdir):
     ("three chunks", 4, {"PAG_SHARD_CHUNKS": "3"}),
     ("more chunks than a rank has reads", 2, {"PAG_SHARD_CHUNKS": "64"}),
     ("one rank over RCCL with itself", 1, {"PAG_COMM_FORCE_RCCL": "1", "PAGRAPH_SHARD_TRANSPORT": "rccl"}),
+    ("rank 0 writes every path dump", 4, {"PAGRAPH_SHARD_RANK_DUMPS": "0"}),
 ])
 def test_sharded_build_in_chunks_and_pipelined_equals_the_golden(label, world, extra, workdir):
     """pag_shard_run sends a rank's tuples in chunks while the next chunk is extracted, and the selection for one rank while the
-    next one is made (round 5): any number of chunks, the whole exchanges of round 4, and — the only way RCCL's grouped sends and
+    next one is made (round 5), and every rank writes the path dumps of its own contigs: any number of chunks, the whole exchanges of
+    round 4, rank 0 writing every dump, and — the only way RCCL's grouped sends and
     receives of that path can run on a one-GPU box — ONE rank exchanging with itself over RCCL: the golden files every time."""
     import tempfile
     name = "two_blocks_both_orient_t16"
@@ -212,13 +214,16 @@ def test_sharded_build_in_chunks_and_pipelined_equals_the_golden(label, world, e
     procs = []
     for r in range(world):
         env = dict(os.environ, PAGRAPH_SHARD=f"{r}/{world}", PAGRAPH_SHARD_DIR=rdv, PAGRAPH_SHARD_TRANSPORT="host", PAG_COMM_TIMEOUT_S="120",
-                   PAG_DEVICE_SHARERS=str(world), PAG_SHARD_TIMING="1")
+                   PAG_DEVICE_SHARERS=str(world), PAG_SHARD_TIMING="1", PAGRAPH_TIMING="1")
         env.update(extra)
         procs.append(subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     for r, pr in enumerate(procs):
         so, se = pr.communicate(timeout=300)
         assert pr.returncode == 0, f"{label}, rank {r}: " + se[-2000:] + so[-1000:]
         assert "[shard timing]" in se, se[-500:]
+        # every rank writes the path dumps of the contigs it walked (rank 0 the rest of the block's files)
+        if r > 0:
+            assert ("path dumps of this rank" in se) == (extra.get("PAGRAPH_SHARD_RANK_DUMPS") != "0"), se[-800:]
     goldens.compare_out_dir(name, out)
 
 
