@@ -596,15 +596,20 @@ int xchg_begin(pag_comm *c, Xchg &X, std::vector<XchgArr> arrs) {
     }
     std::vector<uint64_t> seqs;
     for (size_t a = 0; a < arrs.size(); ++a) seqs.push_back(c->seq++);
+    try {
+        X.th = std::thread([c, &X, arrs = std::move(arrs), seqs]() {
+            if (hipSetDevice(c->device) != hipSuccess) {
+                X.rc = PAG_EFAULT;
+                X.err = "hipSetDevice in the exchange thread";
+            }
+            for (size_t a = 0; a < arrs.size() && X.rc == PAG_OK; ++a) X.rc = xchg_files(c, seqs[a], arrs[a], X.err);
+            X.t_done = now_s();
+        });
+    } catch (const std::exception &e) {  // (no thread to be had: nothing was started)
+        pagdev::set_error("exchange: cannot start the helper thread: %s", e.what());
+        return PAG_EFAULT;
+    }
     X.active = true;
-    X.th = std::thread([c, &X, arrs = std::move(arrs), seqs]() {
-        if (hipSetDevice(c->device) != hipSuccess) {
-            X.rc = PAG_EFAULT;
-            X.err = "hipSetDevice in the exchange thread";
-        }
-        for (size_t a = 0; a < arrs.size() && X.rc == PAG_OK; ++a) X.rc = xchg_files(c, seqs[a], arrs[a], X.err);
-        X.t_done = now_s();
-    });
     return PAG_OK;
 }
 int xchg_end(Xchg &X) {
