@@ -419,7 +419,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 while (nextNo < configs.size() && !mine(nextNo)) ++nextNo;
                 unsigned poolThreads = 0;
                 if (nextNo < configs.size())
-                    poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? static_cast<unsigned>(std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS")))) : 12u;
+                    poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? static_cast<unsigned>(std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS")))) : 20u;  // (traverse_api.cpp: the measurement)
                 // (which contigs this rank walked: a copy — the backend's plan is the next block's by the time the thread reads it)
                 std::vector<char> walkedHere;
                 if (rankDumps) {

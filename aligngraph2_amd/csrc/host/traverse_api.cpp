@@ -206,9 +206,13 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
     // sort stalled, 24 -> 74 ms).  pagh_traverse() itself (begin + end back to back) keeps the full pool.
     unsigned poolThreads = host_threads;
     if (!wait_at_once && poolThreads == 0) {
-        // (measured at configs[1] on the GPU box, 16-CPU quota: ms per block 512 / 453 / 443 / 437 / 430 with 6 / 8 / 12 / 16 / 24 threads;
-        // 12 leaves the caller's thread and the walks' control thread their CPUs)
-        static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 12u;
+        // (measured at configs[1] on the GPU box, 16-CPU quota.  Round 3: ms per block 512 / 453 / 443 / 437 / 430 with 6 / 8 / 12 / 16 / 24
+        // threads, and 12 was chosen to leave the caller's thread and the walks' control thread their CPUs.  Round 5: the device work the
+        // host half runs beside — the next block's prepare, build and successor stage — has shrunk to ~163 ms and the host half on 12
+        // threads takes 157-164 ms beside it: the next walks WAITED for it, 10-21 ms per block.  8 / 10 / 12 / 14 / 16 / 20 / 24 / 32
+        // threads: wait 72 / 39 / 21 / 3 / 0-6 / 1 / 0 / 2 ms, host half 217 / 192 / 157-164 / 145 / 126-143 / 127 / 114 / 102 ms
+        // (profiles/r05_overlap_threads_probe.txt); the walks themselves begin after the join and are not touched by the pool)
+        static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 20u;
         poolThreads = cap;
     }
     hc.worker = std::thread([=]() {
