@@ -213,7 +213,7 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
         // threads: wait 72 / 39 / 21 / 3 / 0-6 / 1 / 0 / 2 ms, host half 217 / 192 / 157-164 / 145 / 126-143 / 127 / 114 / 102 ms
         // (profiles/r05_overlap_threads_probe.txt); the walks themselves begin after the join and are not touched by the pool)
         static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 20u;
-        poolThreads = cap;
+        poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? cap : std::min(cap, std::max(4u, pagh::usableCpus()));  // (ranks of a node share its cores: host_threads.hpp)
     }
     hc.worker = std::thread([=]() {
         h->rc = pagh_assemble_paths(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, h->paths.data(), h->lens.data(), ref_threads, epsilon,
