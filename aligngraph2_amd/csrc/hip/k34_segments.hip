@@ -87,20 +87,41 @@ struct SegPos {
 // Stage one tile: values into LDS, segment-start flags as one ballot word per wave.  A record that continues
 // the segment of the record before the tile gets no flag, so the leading part of a segment headed in the
 // previous tile has no start inside this tile and is left to that tile.
-__device__ __forceinline__ void seg_stage(SegLds &S, const uint32_t *__restrict__ key, const uint64_t *__restrict__ val,
-                                          uint64_t base, uint64_t n) {
+// The tile's words come from registers that were loaded while the tile BEFORE it was worked on (SegRegs, seg_request): staged
+// straight from memory, every tile of a block began with a global load round trip in front of its first barrier.
+struct SegRegs {
+    uint32_t k = 0, kprev = 0, kend0 = 0, kend1 = 0;
+    uint64_t v = 0;
+};
+__device__ __forceinline__ void seg_request(SegRegs &R, const uint32_t *__restrict__ key, const uint64_t *__restrict__ val, uint64_t base, uint64_t n) {
+    const uint32_t t = threadIdx.x;
+    const uint64_t gi = base + t;
+    if (gi < n) {
+        R.k = key[gi];
+        R.kprev = gi ? key[gi - 1] : 0u;
+        R.v = val[gi];
+    }
+    if (t == 0) {
+        const uint64_t ge = base + SEG_TILE;
+        if (ge < n) {
+            R.kend0 = key[ge - 1];
+            R.kend1 = key[ge];
+        }
+    }
+}
+__device__ __forceinline__ void seg_stage(SegLds &S, const SegRegs &R, uint64_t base, uint64_t n) {
     const uint32_t t = threadIdx.x;
     const uint64_t gi = base + t;
     bool f = true;  // records past the end close the last segment
     if (gi < n) {
-        f = gi == 0 || key[gi - 1] != key[gi];
-        S.val[t] = val[gi];
+        f = gi == 0 || R.kprev != R.k;
+        S.val[t] = R.v;
     }
     const uint64_t w = __ballot(f);
     if ((t & 63u) == 0) S.flag[t >> 6] = w;
     if (t == 0) {
         const uint64_t ge = base + SEG_TILE;
-        const bool fe = ge >= n || key[ge - 1] != key[ge];
+        const bool fe = ge >= n || R.kend0 != R.kend1;
         S.flag[SEG_TILE / 64] = ~1ull | (fe ? 1ull : 0ull);
     }
 }
@@ -147,10 +168,13 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
     uint64_t n_ctg = 0, n_all = 0, n_seg = 0;
     const uint32_t t = threadIdx.x;
     const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
+    SegRegs R;
+    if (blockIdx.x < n_tiles) seg_request(R, key, val, (uint64_t)blockIdx.x * SEG_OWN, n);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * SEG_OWN;
         __syncthreads();
-        seg_stage(S, key, val, base, n);
+        seg_stage(S, R, base, n);
+        if (tile + gridDim.x < n_tiles) seg_request(R, key, val, (tile + gridDim.x) * SEG_OWN, n);  // (in flight while this tile is worked on)
         __syncthreads();
         const SegPos P = seg_locate(S, t, base, n);
         const uint64_t v = S.val[t];
@@ -308,10 +332,13 @@ __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restri
     uint64_t n_grp = 0, n_grp1 = 0;
     const uint32_t t = threadIdx.x;
     const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
+    SegRegs R;
+    if (blockIdx.x < n_tiles) seg_request(R, key, val, (uint64_t)blockIdx.x * SEG_OWN, n);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * SEG_OWN;
         __syncthreads();
-        seg_stage(S, key, val, base, n);
+        seg_stage(S, R, base, n);
+        if (tile + gridDim.x < n_tiles) seg_request(R, key, val, (tile + gridDim.x) * SEG_OWN, n);  // (in flight while this tile is worked on)
         __syncthreads();
         const SegPos P = seg_locate(S, t, base, n);
         const uint64_t v = S.val[t];
