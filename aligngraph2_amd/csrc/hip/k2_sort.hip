@@ -368,12 +368,10 @@ int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t 
         int cus = 0, per_cu = 0;
         PAG_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         PAG_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sort_scatter<8>, ST, 0));
-        if (const char *e = getenv("PAG_SORT_BLOCKS_PER_CU")) per_cu = atoi(e);
         scatter_blocks = cus * (per_cu > 0 ? per_cu : 1);
     }
     const uint32_t scatter_grid = n_tiles < (uint32_t)scatter_blocks ? n_tiles : (uint32_t)scatter_blocks;
-    int hist_per_cu = 8;
-    if (const char *e = getenv("PAG_SORT_HIST_PER_CU")) hist_per_cu = atoi(e) > 0 ? atoi(e) : 8;
+    const int hist_per_cu = 8;
     const int hist_blocks = scatter_blocks_cus(dev) * hist_per_cu;
     // timing (the k-mer sort of pag_process asks for it): events out of a pool created once per device, and the one
     // synchronisation their reading takes.  A caller that does not ask gets neither — until round 5 every call created and

@@ -1,1148 +1,32 @@
-// k5_travel.hip — K5: epsilon-join traversal on the device.
+// k5_travel.hip — K5: the walker of the epsilon-join traversal.
 //
 // What runs where (reference PAGraph/src/tools/graph/):
-//   device  PABruijnGraph::searchSuccessors + checkPosition + isEdgeSimilar   PABruijnGraph.cpp:143-197, 385-400
-//           PAlgorithm::classifySuccessors / walkStraight / graphTravel        PAlgorithm.tcc:35-298
-//           PAlgorithm::searchPANode / searchPANode2 (seed scans)             PAlgorithm.tcc:300-365
-//           PABruijnGraph::findAll (contig k-mers -> graph nodes)              PABruijnGraph.cpp:339-353
+//   device  PAlgorithm::classifySuccessors / walkStraight / graphTravel        PAlgorithm.tcc:35-298          (this file)
+//           PABruijnGraph::searchSuccessors + checkPosition + isEdgeSimilar   PABruijnGraph.cpp:143-197, 385-400  (k5_succ.hip)
+//           PAlgorithm::searchPANode / searchPANode2 (seed scans)             PAlgorithm.tcc:300-365          (k5_walk_aux.hip)
+//           PABruijnGraph::findAll (contig k-mers -> graph nodes)              PABruijnGraph.cpp:339-353       (k5_view.hip)
 //   host    the outer loop of PAlgorithm::travelSequence (PAlgorithm.cpp:144-426): per round pick the
 //           longest / leaping seed walk, appendSeq, repeat detection, re-seeding incl. the unstable
-//           std::sort by edit distance (same libstdc++ => same tie order), filterSequence, "Pump it".
+//           std::sort by edit distance (same libstdc++ => same tie order), filterSequence, "Pump it"   (k5_travel_host.hip)
 //
-// One wavefront (= one 64-thread workgroup) owns one (contig, seed) graphTravel.  A walk is a chain of
-// dependent steps, so the kernel is latency-bound by design; the lanes share the work inside a step:
-// expanding children x positions, the f64 match predicates, the three visited-set probes, and ordered
-// compaction by ballot.  Visited sets are open-addressing hash tables in HBM; the per-probe set of
-// walkStraight uses generation tags so it never needs clearing.
-//
-// Before traversal the k-mer-sorted streams are compacted into a CSR with dense node / vertex ids and a
-// 4^k-bit node bitmap + rank directory (code -> node id in two loads).
+// One wavefront (= one 64-thread workgroup) owns one walk job (a graphTravel, or a piece of one).  A walk is a chain of
+// dependent steps, so the kernel is latency-bound by design; the lanes share the work inside a step: eight probe slots of
+// eight lanes walk the alternatives of a branch side by side, the successor records of consecutive strand vertices wait in
+// an LDS window, ordered compaction goes by ballot.  Visited sets are direct-mapped marks over the strand's id range and
+// open-addressing hash tables in HBM outside it (trav_device.hpp); the per-probe set of walkStraight uses generation tags
+// so it never needs clearing.
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <deque>
 #include <string>
-#include <unordered_set>
 #include <vector>
 
 #include "pag_device.hpp"
 #include "pag_travel.hpp"
+#include "trav_device.hpp"
 
 namespace pagdev {
-
-// =================================================================================================
-// graph compaction
-// =================================================================================================
-// ---- a view that leaves out what no traversal of this handle can examine (trav_view_region, k5_travel_host.hip) --------
-// [lo, hi) pairs, sorted and disjoint
-__device__ __forceinline__ bool iv_contains(const uint32_t *__restrict__ iv, uint32_t n, uint32_t x, uint32_t *which = nullptr) {
-    if (!n) return false;
-    uint32_t lo = 0, hi = n;  // last interval with lo <= x
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (iv[2 * mid] <= x) lo = mid;
-        else hi = mid;
-    }
-    if (which) *which = lo;
-    return x >= iv[2 * lo] && x < iv[2 * lo + 1];
-}
-// lowest / highest reference coordinate among the positions whose contig coordinate lies in zone z (lo[z] preset to all
-// ones, hi[z] to 0).  One thread per tuple slot: slots behind a segment's leaders still hold positions of the k-mer's
-// reads (members of the clusters), which lie within epsilon of a leader — they widen nothing.
-constexpr uint32_t ZONE_LDS = 2048;
-__global__ void k_zone_bands(const uint64_t *__restrict__ tval, uint64_t T, const uint32_t *__restrict__ zones, uint32_t n_z,
-                             uint32_t *__restrict__ lo, uint32_t *__restrict__ hi) {
-    __shared__ uint32_t s_lo[ZONE_LDS], s_hi[ZONE_LDS], s_z[2 * ZONE_LDS];
-    const bool lds = n_z <= ZONE_LDS;
-    if (lds) {
-        for (uint32_t z = threadIdx.x; z < n_z; z += blockDim.x) {
-            s_lo[z] = 0xFFFFFFFFu;
-            s_hi[z] = 0u;
-            s_z[2 * z] = zones[2 * z];
-            s_z[2 * z + 1] = zones[2 * z + 1];
-        }
-        __syncthreads();
-    }
-    const uint32_t *zz = lds ? s_z : zones;
-    const uint32_t z_first = n_z ? zones[0] : 0u, z_last = n_z ? zones[2 * n_z - 1] : 0u;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t p = tval[i];
-        const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
-        uint32_t z;
-        if (c < z_first || c >= z_last || r == 0u || !iv_contains(zz, n_z, c, &z)) continue;
-        if (lds) {
-            atomicMin(&s_lo[z], r);
-            atomicMax(&s_hi[z], r);
-        } else {
-            atomicMin(&lo[z], r);
-            atomicMax(&hi[z], r);
-        }
-    }
-    if (lds) {
-        __syncthreads();
-        for (uint32_t z = threadIdx.x; z < n_z; z += blockDim.x)
-            if (s_hi[z] != 0u) {
-                atomicMin(&lo[z], s_lo[z]);
-                atomicMax(&hi[z], s_hi[z]);
-            }
-    }
-}
-// The view's vertices out of the tuple slots, in two sweeps over tiles of VC_TILE slots (round 5; until then a flags kernel, two
-// full-length scans of u32 flags into u64 offsets and a compaction kernel that read all of it back: 46 GB and 15.6 ms at BASELINE
-// configs[1] for 12 GB of work):
-//   k_view_mark   per slot: keep = the slot holds a vertex the view takes — one with a contig coordinate by that coordinate,
-//                 one without by its reference coordinate; every vertex when there are no tables —, first = it is the first
-//                 such slot of its k-mer segment (= a node).  Left behind as the ballots of every wave and round (2 bits per
-//                 slot) and as the two counts of every tile.
-//   (exclusive prefix over the tiles: two scans of T / 2048 counters)
-//   k_view_write  the ballots again, their prefix inside the tile, the vertices / nodes written out.
-// One thread per tuple slot (the slots say whether they hold a leader and how far behind their segment's head they lie: K3's
-// seg_len layout, pag_device.hpp).  The interval tables are searched in LDS (from global memory the ~8 dependent loads per
-// search were the whole cost: 34 ms at BASELINE configs[1] with a thread per segment head).  "First of its segment" comes from
-// the tile's own prefix of the keep flags — no kept slot between the segment's head and this one —: a vertex without a contig
-// coordinate sorts first in its segment and is what the view mostly leaves out, so a backward scan over the slots from the
-// head (until round 5) ran its full length for every kept vertex behind one: most of the 7.8 ms of the flags kernel.
-constexpr uint32_t PRUNE_LDS = 4096;  // interval ends (u32) the block keeps in LDS
-constexpr uint32_t VC_T = 256, VC_R = 8, VC_TILE = VC_T * VC_R, VC_W = VC_T / 64;
-__global__ __launch_bounds__(VC_T) void k_view_mark(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint32_t *__restrict__ tseg,
-                                                    uint64_t T, const uint32_t *__restrict__ civ, uint32_t n_civ, const uint32_t *__restrict__ riv,
-                                                    uint32_t n_riv, int whole, uint64_t *__restrict__ ballots, uint32_t *__restrict__ tile_first,
-                                                    uint32_t *__restrict__ tile_keep, uint64_t n_tiles) {
-    __shared__ uint32_t s_iv[PRUNE_LDS];
-    __shared__ uint32_t s_ck[VC_R][VC_W], s_pk[VC_R][VC_W], s_cf[VC_R][VC_W];
-    __shared__ uint16_t s_pre[VC_TILE];  // kept slots of the tile before this one
-    const bool lds = !whole && 2u * (n_civ + n_riv) <= PRUNE_LDS;
-    if (lds) {
-        for (uint32_t x = threadIdx.x; x < 2u * n_civ; x += blockDim.x) s_iv[x] = civ[x];
-        for (uint32_t x = threadIdx.x; x < 2u * n_riv; x += blockDim.x) s_iv[2u * n_civ + x] = riv[x];
-        __syncthreads();
-    }
-    const uint32_t *cv = lds ? s_iv : civ, *rv = lds ? s_iv + 2u * n_civ : riv;
-    auto inside = [&](uint64_t p) {
-        const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
-        return whole || (c != 0u ? iv_contains(cv, n_civ, c) : iv_contains(rv, n_riv, r));
-    };
-    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t tile_base = tile * VC_TILE;
-        uint32_t kb = 0;          // bit r: the slot of round r is kept
-        uint32_t off_r[VC_R];     // ... how far behind its segment's head it lies
-        uint64_t bkr[VC_R];
-#pragma unroll
-        for (uint32_t r = 0; r < VC_R; ++r) {
-            const uint64_t i = tile_base + (uint64_t)r * VC_T + threadIdx.x;
-            bool kk = false;
-            off_r[r] = 0;
-            if (i < T) {
-                const uint32_t kx = tkey[i], v = tseg[i];
-                const bool head = i == 0 || tkey[i - 1] != kx;
-                const bool leader = head ? v != 0u : (v & SEG_LEADER) != 0u;
-                if (leader) {
-                    kk = inside(tval[i]);
-                    off_r[r] = head ? 0u : (v & ~SEG_LEADER);
-                }
-            }
-            bkr[r] = __ballot(kk);
-            kb |= kk ? 1u << r : 0u;
-            if (lane == 0) s_ck[r][w] = (uint32_t)__popcll(bkr[r]);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {  // exclusive prefix over (round, wave) = slot order, tile total
-            uint32_t ak = 0;
-            for (uint32_t r = 0; r < VC_R; ++r)
-                for (uint32_t ww = 0; ww < VC_W; ++ww) {
-                    s_pk[r][ww] = ak;
-                    ak += s_ck[r][ww];
-                }
-            tile_keep[tile] = ak;
-        }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t r = 0; r < VC_R; ++r)
-            s_pre[r * VC_T + threadIdx.x] = (uint16_t)(s_pk[r][w] + (uint32_t)__popcll(bkr[r] & lanemask_lt()));
-        __syncthreads();
-#pragma unroll
-        for (uint32_t r = 0; r < VC_R; ++r) {
-            const uint32_t d = r * VC_T + threadIdx.x;  // slot inside the tile
-            bool ff = false;
-            if ((kb >> r) & 1u) {
-                const uint32_t off = off_r[r];
-                if (off <= d) {
-                    ff = s_pre[d] == s_pre[d - off];  // no kept slot in [head, this one)
-                } else {  // the segment began in an earlier tile: the slots before this tile by their own test (one segment per tile)
-                    ff = s_pre[d] == 0u;
-                    const uint64_t i = tile_base + d;
-                    for (uint64_t j = i - off; j < tile_base && ff; ++j) {
-                        const uint32_t kx = tkey[j], v = tseg[j];
-                        const bool head = j == 0 || tkey[j - 1] != kx;
-                        const bool leader = head ? v != 0u : (v & SEG_LEADER) != 0u;
-                        ff = !(leader && inside(tval[j]));
-                    }
-                }
-            }
-            const uint64_t bf = __ballot(ff);
-            if (lane == 0) {
-                s_cf[r][w] = (uint32_t)__popcll(bf);
-                const uint64_t at = ((tile * VC_R + r) * VC_W + w) * 2u;
-                ballots[at] = bkr[r];
-                ballots[at + 1] = bf;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t af = 0;
-            for (uint32_t r = 0; r < VC_R; ++r)
-                for (uint32_t ww = 0; ww < VC_W; ++ww) af += s_cf[r][ww];
-            tile_first[tile] = af;
-        }
-    }
-}
-__global__ __launch_bounds__(VC_T) void k_view_write(const uint32_t *__restrict__ tkey, const uint64_t *__restrict__ tval, const uint16_t *__restrict__ tcnt,
-                                                     const uint64_t *__restrict__ ballots, const uint64_t *__restrict__ base_first,
-                                                     const uint64_t *__restrict__ base_keep, uint64_t n_tiles, TravGraph G) {
-    __shared__ uint64_t s_b[VC_R * VC_W * 2];
-    __shared__ uint32_t s_pk[VC_R][VC_W], s_pf[VC_R][VC_W];
-    const uint32_t w = threadIdx.x >> 6;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (threadIdx.x < VC_R * VC_W * 2) s_b[threadIdx.x] = ballots[tile * (VC_R * VC_W * 2) + threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t ak = 0, af = 0;
-            for (uint32_t r = 0; r < VC_R; ++r)
-                for (uint32_t ww = 0; ww < VC_W; ++ww) {
-                    s_pk[r][ww] = ak;
-                    s_pf[r][ww] = af;
-                    ak += (uint32_t)__popcll(s_b[(r * VC_W + ww) * 2]);
-                    af += (uint32_t)__popcll(s_b[(r * VC_W + ww) * 2 + 1]);
-                }
-        }
-        __syncthreads();
-        const uint64_t bk0 = base_keep[tile], bf0 = base_first[tile];
-#pragma unroll
-        for (uint32_t r = 0; r < VC_R; ++r) {
-            const uint64_t bk = s_b[(r * VC_W + w) * 2], bf = s_b[(r * VC_W + w) * 2 + 1];
-            const uint64_t me = 1ull << lane_id();
-            if (!(bk & me)) continue;
-            const bool ff = (bf & me) != 0ull;
-            const uint64_t i = tile * VC_TILE + (uint64_t)r * VC_T + threadIdx.x;
-            const uint64_t p = bk0 + s_pk[r][w] + (uint32_t)__popcll(bk & lanemask_lt());
-            const uint64_t n = bf0 + s_pf[r][w] + (uint32_t)__popcll(bf & lanemask_lt()) + (ff ? 1u : 0u) - 1u;
-            G.vpos[p] = tval[i];
-            G.vcnt[p] = tcnt[i];
-            G.vnode[p] = (uint32_t)n;
-            if (ff) {
-                const uint32_t kx = tkey[i];
-                G.ncode[n] = kx;
-                G.npos_off[n] = (uint32_t)p;
-                atomicOr((unsigned long long *)&G.bitmap[kx >> 6], 1ull << (kx & 63u));
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void k_popc_words(const uint64_t *__restrict__ bitmap, uint64_t n_words, uint32_t *__restrict__ out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = (uint32_t)__popcll(bitmap[i]);
-}
-
-__global__ void k_narrow(const uint64_t *__restrict__ in, uint64_t n, uint32_t *__restrict__ out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = (uint32_t)in[i];
-}
-
-__device__ __forceinline__ uint32_t node_of_code(const TravGraph &G, uint32_t code) {
-    uint64_t w = G.bitmap[code >> 6];
-    uint32_t b = code & 63u;
-    if (!((w >> b) & 1ull)) return PAG_NONE;
-    const uint32_t in_code_order = G.rank[code >> 6] + (uint32_t)__popcll(w & ((1ull << b) - 1ull));
-    return G.nperm ? G.nperm[in_code_order] : in_code_order;
-}
-
-// ---- nodes numbered by place (round 5).  The compaction leaves the nodes in code order, the order of the build's sorted tuples:
-// a node's children — the k-mers that follow it in the reads — then lie anywhere in the node-major arrays, and so do the
-// coordinate-ordered slots its vertices' results go to: every candidate list, every count, every record of the successor stage
-// was a random 64-byte sector.  Numbered by WHERE the k-mer lies (the reference coordinate of the node's first vertex that has
-// one; a node known on a contig only: its contig coordinate, behind the others), a node's children are its neighbours, and the
-// coordinate order of its vertices runs alongside the node order.  Inside a node nothing moves (positions ascending, edges in
-// tuple order): the reference's order of a vertex's successors does not depend on how nodes are numbered.
-__global__ void k_node_place_keys(const uint32_t *__restrict__ npos_off, const uint64_t *__restrict__ vpos, uint64_t n_nodes, uint32_t shift,
-                                  uint32_t flag, uint32_t *__restrict__ key, uint64_t *__restrict__ val) {
-    for (uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t a = npos_off[n], b = npos_off[n + 1];
-        uint32_t kk = flag | ((uint32_t)(vpos[a] >> 32) >> shift);
-        for (uint32_t p = a; p < b; ++p) {
-            const uint32_t r = (uint32_t)vpos[p];
-            if (r != 0u) {
-                kk = r >> shift;
-                break;
-            }
-        }
-        key[n] = kk;
-        val[n] = n;
-    }
-}
-// new id i <- node perm[i] of the code order: its number of vertices, and where the code order's number finds it again
-__global__ void k_node_place_counts(const uint64_t *__restrict__ perm, const uint32_t *__restrict__ npos_off_old, uint64_t n_nodes,
-                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ nperm) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t o = (uint32_t)perm[i];
-        cnt[i] = npos_off_old[o + 1] - npos_off_old[o];
-        nperm[o] = (uint32_t)i;
-    }
-}
-__global__ void k_node_place_move(const uint64_t *__restrict__ perm, const uint64_t *__restrict__ off_new, const uint32_t *__restrict__ ncode_old,
-                                  const uint32_t *__restrict__ npos_off_old, const uint64_t *__restrict__ vpos_old, const uint16_t *__restrict__ vcnt_old,
-                                  uint64_t n_nodes, TravGraph G) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t o = (uint32_t)perm[i];
-        const uint32_t a = npos_off_old[o], b = npos_off_old[o + 1], d = (uint32_t)off_new[i];
-        G.ncode[i] = ncode_old[o];
-        G.npos_off[i] = d;
-        for (uint32_t j = 0; j < b - a; ++j) {
-            G.vpos[d + j] = vpos_old[a + j];
-            G.vcnt[d + j] = vcnt_old[a + j];
-            G.vnode[d + j] = (uint32_t)i;
-        }
-    }
-}
-
-// An edge of the traversal graph: eto = first position (k-mer-major vertex id) of the target node (PAG_NONE: the target has no
-// node), estep = step (24 bits) | number of the target's positions << 24, EDGE_Q_MANY = "255 or more: count them".
-constexpr uint32_t EDGE_STEP_MASK = 0xFFFFFFu, EDGE_Q_MANY = 255u;
-constexpr uint32_t TRAV_CODE_TABLE_MAX_K = 14;  // (the direct code table of k_compact_edges: 8 B x 4^k)
-struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a[2]; };
-__device__ __forceinline__ void edge_target(const TravGraph &G, uint32_t eto, uint32_t estep, uint32_t *step, uint32_t *p0, uint32_t *q) {
-    *step = estep & EDGE_STEP_MASK;
-    if (eto == PAG_NONE) {
-        *p0 = 0u;
-        *q = 0u;
-        return;
-    }
-    *p0 = eto;
-    uint32_t n = estep >> 24;
-    if (n == EDGE_Q_MANY) {  // (a k-mer with hundreds of positions: its node's range)
-        const uint32_t node = G.vnode[eto];
-        n = G.npos_off[node + 1] - G.npos_off[node];
-    }
-    *q = n;
-}
-
-__global__ void k_edge_counts(const uint32_t *__restrict__ ekey, const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G,
-                              uint32_t *__restrict__ necnt) {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t kx = ekey[j];
-        if (j != 0 && ekey[j - 1] == kx) continue;
-        uint32_t n = node_of_code(G, kx);
-        if (n != PAG_NONE) necnt[n] = eseg[j];
-    }
-}
-
-// code -> (first position | number of positions << 32) of the k-mer's node, all ones: no node.  A direct table over the 4^k codes
-// (2 GB at k = 14, scratch of the compaction): an edge's target then costs ONE random sector instead of the three dependent
-// gathers of bitmap word, rank and position range (k_compact_edges: 9.9 -> ms at BASELINE configs[1], round 5); built
-// from the node arrays, which are ascending in the code.  Larger k: no table, the three gathers.
-__global__ void k_code_table(TravGraph G, uint64_t *__restrict__ tab) {
-    for (uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; n < G.n_nodes; n += (uint64_t)gridDim.x * blockDim.x) {
-        const U32x2 r = *(const U32x2 *)(G.npos_off + n);
-        tab[G.ncode[n]] = (uint64_t)r.a[0] | ((uint64_t)(r.a[1] - r.a[0]) << 32);
-    }
-}
-
-__global__ void k_compact_edges(const uint32_t *__restrict__ ekey, const uint64_t *__restrict__ eval,
-                                const uint32_t *__restrict__ eseg, uint64_t E, TravGraph G, const uint64_t *__restrict__ tab) {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t kx = ekey[j];
-        if (j != 0 && ekey[j - 1] == kx) continue;
-        uint32_t n = node_of_code(G, kx);
-        if (n == PAG_NONE) continue;
-        uint32_t dst = G.nedge_off[n], len = eseg[j];
-        // (the edge carries what the successor kernels need of its target: where the target node's positions begin and how
-        // many they are — one random sector less per edge in each of their two passes, see edge_target.  Four edges per
-        // turn, their lookups in flight together)
-        for (uint32_t l0 = 0; l0 < len; l0 += 4u) {
-            uint64_t v4[4];
-            uint32_t p04[4], q4[4];
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) v4[t] = l0 + t < len ? eval[j + l0 + t] : 0ull;
-            if (tab) {
-                uint64_t e4[4];
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) e4[t] = l0 + t < len ? tab[(uint32_t)(v4[t] >> 32)] : ~0ull;
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) {
-                    p04[t] = (uint32_t)e4[t];
-                    q4[t] = (uint32_t)(e4[t] >> 32);
-                }
-            } else {  // code -> bitmap word + rank -> position range: three dependent gathers
-                uint32_t to4[4];
-                U32x2 r4[4];
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) to4[t] = l0 + t < len ? node_of_code(G, (uint32_t)(v4[t] >> 32)) : PAG_NONE;
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) r4[t] = *(const U32x2 *)(G.npos_off + (to4[t] != PAG_NONE ? to4[t] : 0u));
-#pragma unroll
-                for (uint32_t t = 0; t < 4u; ++t) {
-                    p04[t] = to4[t] != PAG_NONE ? r4[t].a[0] : PAG_NONE;
-                    q4[t] = r4[t].a[1] - r4[t].a[0];
-                }
-            }
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) {
-                const uint32_t l = l0 + t;
-                if (l >= len) break;
-                const uint32_t step = (((uint32_t)v4[t]) >> 1) & EDGE_STEP_MASK;
-                if (p04[t] == PAG_NONE) {
-                    G.eto[dst + l] = PAG_NONE;
-                    G.estep[dst + l] = step;
-                } else {
-                    G.eto[dst + l] = p04[t];
-                    G.estep[dst + l] = step | ((q4[t] < EDGE_Q_MANY ? q4[t] : EDGE_Q_MANY) << 24);
-                }
-            }
-        }
-    }
-}
-
-// contig strand k-mers -> node ids (PABruijnGraph::findAll).  One thread per k-mer start.
-__global__ void k_ctg_nodes(const uint8_t *__restrict__ packed, const TravCtgNodesJob *__restrict__ jobs, uint32_t k, TravGraph G,
-                            uint32_t *__restrict__ out_all) {
-    const TravCtgNodesJob J = jobs[blockIdx.y];
-    const uint32_t len = J.len;
-    const bool forward = J.forward != 0;
-    uint32_t *__restrict__ out = out_all + J.out_off;
-    const uint32_t n_pos = len >= k ? len - k + 1 : 0;
-    const uint32_t kmask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
-    const uint32_t *words = (const uint32_t *)(packed + J.byte_off);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += gridDim.x * blockDim.x) {
-        uint32_t a = forward ? i : len - k - i;  // first contig base (forward numbering) covered by the k-mer
-        uint32_t w = a >> 4, sh = (a & 15u) * 2u;
-        uint64_t W = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
-        uint32_t x = (uint32_t)(W >> sh) & kmask;
-        uint32_t code = forward ? (rev2(x) >> (32 - 2 * k)) : ((~x) & kmask);
-        out[i] = node_of_code(G, code);
-    }
-}
-
-// =================================================================================================
-// match predicates (f64 exactly as the reference; compiled with -ffp-contract=off, no fast-math)
-// =================================================================================================
-__device__ __forceinline__ bool d_coord_sim(uint32_t a, uint32_t b, uint64_t dev) {
-    return a != 0 && b != 0 && (uint64_t)((a > b ? a : b) - (a > b ? b : a)) <= dev;
-}
-// the ratio test of both predicates: fabs(1.0 - (double)D * 1.0 / (double)dist) <= err, D = u32 difference of the
-// coordinates.  The f64 division (a ~25-instruction sequence) is only executed when D is within one percent of the
-// accepted band: outside of [(1 - err - 0.01) dist, (1 + err + 0.01) dist] the quotient misses the band by 0.01, fifteen
-// orders of magnitude more than the rounding of the two multiplications, so the answer is "no" without dividing.  Nine
-// in ten candidate pairs (other copies of a repeated k-mer) leave here.
-__device__ __forceinline__ bool d_ratio_ok(uint32_t D, int dist, double err) {
-    const double dd = (double)D, ds = (double)dist;
-    if (dd < (1.0 - err - 0.01) * ds || dd > (1.0 + err + 0.01) * ds) return false;
-    return fabs(1.0 - (dd * 1.0 / ds)) <= err;
-}
-enum { G_OOPS = 0, G_SKIP = 1, G_GOOD = 2, G_EXCELLENT = 3, G_AMAZING = 4 };
-// checkPosition (PABruijnGraph.cpp:143-165) incl. the un-guarded second ratio test (quirk Q6), with isEdgeSimilar
-// (PABruijnGraph.cpp:385-400; *edge_sim: bit0 contig side, bit1 reference side) evaluated on the way: both use the
-// same two ratio tests, each computed once here
-__device__ __forceinline__ int d_check_position(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev,
-                                                double err, uint32_t *edge_sim) {
-    const bool q1 = d_ratio_ok(bc - ac, (int)dist, err), q2 = d_ratio_ok(br - ar, (int)dist, err);
-    const uint32_t tc = ac != 0 ? ac + dist : 0, tr = ar != 0 ? ar + dist : 0;
-    bool s1 = d_coord_sim(tc, bc, dev) || (ac != 0 && bc != 0 && q1);
-    bool s2 = d_coord_sim(tr, br, dev) || (ar != 0 && br != 0 && q2);
-    *edge_sim = (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
-    s1 = s1 || q1;
-    s2 = s2 || q2;
-    if (ac == 0 || bc == 0) return s2 ? (bc != 0 ? G_EXCELLENT : (ac != 0 ? G_SKIP : G_GOOD)) : G_OOPS;
-    if (ar == 0 || br == 0) return s1 ? (br != 0 ? G_EXCELLENT : G_GOOD) : G_OOPS;
-    return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
-}
-
-// The ratio test as a table: for a given dist the coordinate differences D that pass d_ratio_ok are an interval (a
-// correctly rounded division is monotonic in its dividend, so are 1 - x and fabs on either side of 1), [lo, lo + rng],
-// found by trying d_ratio_ok itself on the few integers around (1 -+ err) dist.  Entry = lo | rng << 16; RATIO_TAB_NONE:
-// no entry (dist 0 — nothing passes — or an interval that was not pinned down): the caller uses d_ratio_ok.  With the
-// table a candidate pair costs integer compares only; the successor kernels, which run this predicate over five billion
-// pairs per block at configs[1] and were bound by their vector instruction issue (SQ counters, profiles/r03_pmc_kernel_mix.json),
-// keep it in LDS.
-#define RATIO_TAB_N 1024u
-#define RATIO_TAB_NONE 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t d_ratio_entry(uint32_t dist, double err) {
-    if (dist == 0u) return RATIO_TAB_NONE;
-    const double ds = (double)dist;
-    const int64_t e0 = (int64_t)((1.0 - err) * ds), e1 = (int64_t)((1.0 + err) * ds);
-    int64_t lo = -1, hi = -1;
-    for (int64_t D = e0 > 3 ? e0 - 3 : 0; D <= e0 + 3; ++D)
-        if (d_ratio_ok((uint32_t)D, (int)dist, err)) {
-            lo = D;
-            break;
-        }
-    for (int64_t D = e1 + 3; D >= (e1 > 3 ? e1 - 3 : 0); --D)
-        if (d_ratio_ok((uint32_t)D, (int)dist, err)) {
-            hi = D;
-            break;
-        }
-    // the interval must have been bracketed on both sides (the first D tried at either end fails) and fit the entry
-    const bool lo_ok = lo >= 0 && (lo == 0 || lo > (e0 > 3 ? e0 - 3 : 0)), hi_ok = hi >= 0 && hi < e1 + 3;
-    if (!lo_ok || !hi_ok || hi < lo || lo > 0xFFFF || hi - lo > 0xFFFE) return RATIO_TAB_NONE;
-    return (uint32_t)lo | ((uint32_t)(hi - lo) << 16);
-}
-__device__ __forceinline__ void d_ratio_table_fill(uint32_t *tab, double err) {  // (all threads of the block; __syncthreads after it)
-    for (uint32_t d = threadIdx.x; d < RATIO_TAB_N; d += blockDim.x) tab[d] = d_ratio_entry(d, err);
-}
-// d_check_position with the two ratio tests given by a table entry (never RATIO_TAB_NONE)
-__device__ __forceinline__ int d_check_position_tab(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev,
-                                                    uint32_t entry, uint32_t *edge_sim) {
-    const uint32_t lo = entry & 0xFFFFu, rng = entry >> 16;
-    const bool q1 = (uint32_t)(bc - ac - lo) <= rng, q2 = (uint32_t)(br - ar - lo) <= rng;
-    const uint32_t tc = ac != 0 ? ac + dist : 0, tr = ar != 0 ? ar + dist : 0;
-    bool s1 = d_coord_sim(tc, bc, dev) || (ac != 0 && bc != 0 && q1);
-    bool s2 = d_coord_sim(tr, br, dev) || (ar != 0 && br != 0 && q2);
-    *edge_sim = (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
-    s1 = s1 || q1;
-    s2 = s2 || q2;
-    if (ac == 0 || bc == 0) return s2 ? (bc != 0 ? G_EXCELLENT : (ac != 0 ? G_SKIP : G_GOOD)) : G_OOPS;
-    if (ar == 0 || br == 0) return s1 ? (br != 0 ? G_EXCELLENT : G_GOOD) : G_OOPS;
-    return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
-}
-// ... for any dist: through the table (LDS) where it has an entry
-__device__ __forceinline__ int d_check_position_any(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev, double err,
-                                                    uint32_t entry, uint32_t *edge_sim) {
-    return entry != RATIO_TAB_NONE ? d_check_position_tab(ac, ar, bc, br, dist, dev, entry, edge_sim)
-                                   : d_check_position(ac, ar, bc, br, dist, dev, err, edge_sim);
-}
-
-// =================================================================================================
-// visited sets
-// =================================================================================================
-#define HS_EMPTY 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t hs_hash(uint32_t key, uint32_t mask) { return (key * 2654435761u) & mask; }
-// lookups use agent-scope (sc1) loads: inserts are L2 atomics, which a CU's L1 does not observe
-__device__ __forceinline__ bool hs_has(const uint32_t *tab, uint32_t mask, uint32_t key) {
-    if (!tab) return false;
-    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
-        uint32_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (x == key) return true;
-        if (x == HS_EMPTY) return false;
-    }
-}
-// concurrent insert (distinct or equal keys, any lanes)
-__device__ __forceinline__ void hs_insert(uint32_t *tab, uint32_t mask, uint32_t key) {
-    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
-        uint32_t old = atomicCAS(&tab[s], HS_EMPTY, key);
-        if (old == HS_EMPTY || old == key) return;
-    }
-}
-// epoch-tagged travel set: entry = key | epoch << 32, empty = all ones; lookup returns the epoch (0 = absent)
-#define HS64_EMPTY 0xFFFFFFFFFFFFFFFFull
-__device__ __forceinline__ uint32_t hs64_epoch(const uint64_t *tab, uint32_t mask, uint32_t key) {
-    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
-        const uint64_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (x == HS64_EMPTY) return 0u;
-        if ((uint32_t)x == key) return (uint32_t)(x >> 32);
-    }
-}
-// concurrent insert of distinct keys (a key is inserted once per job: a vertex is appended once)
-__device__ __forceinline__ void hs64_insert(uint64_t *tab, uint32_t mask, uint32_t key, uint32_t epoch) {
-    const unsigned long long want = (unsigned long long)key | ((unsigned long long)epoch << 32);
-    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
-        const unsigned long long old = atomicCAS((unsigned long long *)&tab[s], (unsigned long long)HS64_EMPTY, want);
-        if (old == (unsigned long long)HS64_EMPTY || (uint32_t)old == key) return;
-    }
-}
-// generation-tagged set: entry = key | gen << 32; an entry of another generation counts as free
-__device__ __forceinline__ bool gs_has(const uint64_t *tab, uint32_t mask, uint32_t key, uint32_t gen) {
-    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
-        uint64_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(x >> 32) != gen) return false;
-        if ((uint32_t)x == key) return true;
-    }
-}
-__device__ __forceinline__ void gs_insert_single(uint64_t *tab, uint32_t mask, uint32_t key, uint32_t gen) {  // one lane only
-    for (uint32_t s = hs_hash(key, mask);; s = (s + 1) & mask) {
-        uint64_t x = __hip_atomic_load(&tab[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(x >> 32) != gen) {
-            __hip_atomic_store(&tab[s], (uint64_t)key | ((uint64_t)gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if ((uint32_t)x == key) return;
-    }
-}
-
-// =================================================================================================
-// coordinate order + precomputed successor lists
-// =================================================================================================
-// A walk advances along the contig coordinate, but vertex ids are k-mer major, i.e. random with respect
-// to the coordinate: every step of a walk on the k-mer-major CSR is a chain of ~8 dependent random HBM
-// accesses (TLB misses included, ~3 us each).  So the vertices are renumbered by contig coordinate
-// (stable radix sort on DualPos.first: [ctg == 0 vertices] ++ [ctg != 0 ascending]) and the static part of
-// the epsilon-join — searchSuccessors + checkPosition + isEdgeSimilar for EVERY vertex — is evaluated
-// once, in parallel, into per-vertex successor records stored in that order.  A walk then streams
-// through nearly consecutive memory: records, visit stamps and offsets of consecutive path vertices are
-// neighbours.
-// sort records: key = contig coordinate, payload = reference coordinate << 32 | vertex id (the position travels with the
-// record, so that applying the order does not have to gather it back)
-__global__ void k_order_keys(const uint64_t *__restrict__ vpos, uint64_t n, uint32_t *__restrict__ key, uint64_t *__restrict__ val) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t p = vpos[i];
-        key[i] = (uint32_t)(p >> 32);
-        val[i] = (p << 32) | i;
-    }
-}
-
-// (slice / slice_shift: the random half of the work — newid[v], vcnt[v] — for the vertices v of one slice of the k-mer-major id
-// range per launch, so that the slice of both arrays stays in the Infinity Cache; the streamed half with slice 0)
-__global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uint64_t *__restrict__ sorted_val, uint64_t n, uint64_t n_zero, TravGraph G,
-                              uint32_t slice, uint32_t slice_shift) {
-    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t x = sorted_val[u];
-        const uint32_t v = (uint32_t)x;
-        if (slice == 0u) {
-            G.uold[u] = v;
-            // (the first n_zero keys were overwritten by the second sort: their contig coordinate is 0)
-            G.upos[u] = ((uint64_t)(u < n_zero ? 0u : sorted_ctg[u]) << 32) | (x >> 32);
-        }
-        if (slice_shift >= 32u || (v >> slice_shift) == slice) {
-            G.newid[v] = (uint32_t)u;
-            G.ucnt[u] = G.vcnt[v];
-        }
-    }
-}
-
-// may successors of a vertex lie outside the region this graph holds?  r = its reference coordinate, on_contig = it has a contig
-// coordinate (new id >= n_zero).  The ONE statement of the test: k_mark_incomplete leaves it as a bit per new id, the successor
-// kernels — threads in k-mer-major order, to which a bit at the vertex's new id is a random sector — evaluate it again from the
-// vertex's own position with the bands staged in LDS.
-__device__ __forceinline__ bool d_incomplete_by_position(const uint32_t *iv, const uint8_t *open, uint32_t n_iv, uint32_t margin, uint32_t r, bool on_contig) {
-    uint32_t lo = 0, hi = n_iv;  // last interval with lo <= r
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (iv[2 * mid] <= r) lo = mid;
-        else hi = mid;
-    }
-    bool bad = n_iv == 0 || r < iv[2 * lo] || r >= iv[2 * lo + 1];
-    if (!bad) bad = (open[2 * lo] && r - iv[2 * lo] < margin) || (open[2 * lo + 1] && iv[2 * lo + 1] - r <= margin);
-    if (on_contig && r == 0u) bad = false;
-    return bad;
-}
-
-constexpr uint32_t INC_LDS_MAX = 256;  // bands a successor kernel stages in LDS (more: the bit per new id is gathered)
-struct IncLds {
-    uint32_t iv[2 * INC_LDS_MAX];
-    uint8_t open[2 * INC_LDS_MAX];
-};
-__device__ __forceinline__ bool inc_lds_fill(IncLds &I, const TravGraph &G) {  // (all threads of the block; __syncthreads after it)
-    const bool use = G.incomplete && G.inc_iv && G.inc_n <= INC_LDS_MAX;
-    if (use)
-        for (uint32_t i = threadIdx.x; i < 2u * G.inc_n; i += blockDim.x) {
-            I.iv[i] = G.inc_iv[i];
-            I.open[i] = G.inc_open[i];
-        }
-    return use;
-}
-// poison / marker of vertex v (new id u): from its own position when the bands are in LDS, else the bit at its new id
-__device__ __forceinline__ bool vertex_incomplete(const TravGraph &G, const IncLds &I, bool lds, uint64_t v, uint32_t u) {
-    if (!G.incomplete) return false;
-    if (lds) {
-        const uint64_t pv = G.vpos[v];
-        return d_incomplete_by_position(I.iv, I.open, G.inc_n, G.inc_margin, (uint32_t)pv, (pv >> 32) != 0u);
-    }
-    return ((G.incomplete[u >> 5] >> (u & 31u)) & 1u) != 0u;
-}
-
-// The candidate pairs of one vertex v (searchSuccessors + checkPosition + isEdgeSimilar, PABruijnGraph.cpp:143-197,385-400):
-// every position of every target node of its k-mer node, in CSR order.  WHAT = 0: count the accepted ones, and note in
-// `mask` which of the first 64 candidates they are.  WHAT = 1: write the accepted ones to out[0 ..] — the first 64
-// candidates through `mask` (nine in ten candidates are rejects: only the accepted ones are touched again), the rest
-// evaluated again.  WHAT = 2: evaluate every candidate once and write the accepted ones as they come.  Returns their number.
-// four / two consecutive entries with one load instruction (4- resp. 8-byte aligned addresses: the hardware takes them; the
-// counting pass issues a load per candidate otherwise, and with some twenty k-mer nodes per wave every load instruction is
-// twenty requests to the L1 — what the pass was bound by, not its arithmetic)
-struct __attribute__((packed, aligned(4))) U32x4 { uint32_t a[4]; };
-struct __attribute__((packed, aligned(8))) U64x4 { uint64_t a[4]; };
-template <int WHAT>
-#define SUCC_HEAVY 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t succ_vertex(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out,
-                                                const uint32_t *__restrict__ ratio_tab, uint32_t heavy_limit = 0xFFFFFFFFu, uint32_t src_u = 0u) {
-    // (0 counts, 1 fills through the mask, 2 writes while it evaluates; 3: 1 for a vertex known to have at most 64 candidates —
-    // everything is under the mask, the loop that evaluates candidates is not even compiled in: registers, k_succ<3>)
-    // 4: 3 with the grading left to k_succ_link — the record gets its target's new id and the step, the source's new id in `toff`
-    // (src_u), grade 0; neither the source's nor the target's position is read here: the linking pass runs in coordinate order,
-    // where both are neighbours of what it reads anyway (one random sector per record less than 3)
-    constexpr int MODE = WHAT == 3 || WHAT == 4 ? 1 : WHAT;
-    constexpr bool MASK_ONLY = WHAT == 3 || WHAT == 4;
-    constexpr bool DEFER = WHAT == 4;
-    const uint64_t rootp = DEFER ? 0ull : G.vpos[v];
-    const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
-    const uint32_t node = G.vnode[v];
-    uint32_t n = 0, base = 0;
-    const bool amask = true;  // (the mask is always there; a caller without one passes 0 and WHAT = 2)
-    auto emit = [&](uint32_t tgt, uint32_t pc, uint32_t step, int grade, uint32_t esim) {
-        SuccRec r;
-        r.tgt = tgt;
-        r.pc = pc;
-        r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
-        r.toff = 0;  // the target's own record range is linked in afterwards
-        out[n] = r;
-    };
-    const uint32_t e_lo = G.nedge_off[node], e_hi = G.nedge_off[node + 1];
-    for (uint32_t eb = e_lo; eb < e_hi; eb += 4u) {
-      // (targets and position ranges of up to four edges requested together: two round trips for the four; k_succ<0>
-      // 36 -> 34 ms, k_succ<1> 49 -> 46 ms)
-      uint32_t to4[4], st4[4], p04[4], q4[4];
-      const U32x4 toL = *(const U32x4 *)(G.eto + eb), stL = *(const U32x4 *)(G.estep + eb);  // (the arrays are padded by four entries)
-#pragma unroll
-      for (uint32_t t = 0; t < 4u; ++t) {
-          const bool have = eb + t < e_hi;
-          to4[t] = have ? toL.a[t] : PAG_NONE;
-          edge_target(G, to4[t], have ? stL.a[t] : 0u, &st4[t], &p04[t], &q4[t]);
-      }
-#pragma unroll
-      for (uint32_t t4 = 0; t4 < 4u; ++t4) {
-        const uint32_t step = st4[t4], p0 = p04[t4], q = q4[t4];
-        if (q == 0u) continue;
-        // a vertex with more candidates than the limit is left to a whole wave (k_succ_heavy): the lanes of a wave here run as
-        // long as the one with the longest lists
-        if (q > heavy_limit || base + q > heavy_limit) return SUCC_HEAVY;
-        const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;  // (the ratio tests of this edge, see d_ratio_entry)
-        uint32_t j0 = 0;
-        if (MODE == 1 && amask) {  // the candidates the mask covers: accepted ones only
-            const uint32_t lim = base < 64u ? (q < 64u - base ? q : 64u - base) : 0u;
-            uint64_t sub = lim ? (mask >> base) & (lim == 64u ? ~0ull : ((1ull << lim) - 1ull)) : 0ull;
-            while (sub) {
-                const uint32_t p = p0 + (uint32_t)(__ffsll((long long)sub) - 1);
-                sub &= sub - 1ull;
-                if (DEFER) {
-                    SuccRec r;
-                    r.tgt = G.newid[p];
-                    r.pc = 0u;
-                    r.meta = step & 0xFFFFFFu;  // (grade 0 = not graded yet)
-                    r.toff = src_u;
-                    out[n++] = r;
-                    continue;
-                }
-                const uint64_t pp = G.vpos[p];
-                const uint32_t tgt = G.newid[p];  // (asked for together with the position: one round trip per record, not two)
-                uint32_t esim;
-                const int grade = d_check_position_any(rc, rr, (uint32_t)(pp >> 32), (uint32_t)pp, step, dev, err, entry, &esim);
-                emit(tgt, (uint32_t)(pp >> 32), step, grade, esim);
-                ++n;
-            }
-            j0 = lim;
-        }
-        // four candidates per turn, their positions requested together: one at a time, every candidate cost a full memory
-        // round trip (load -> f64 tests -> next load) and the kernel ran at a third of the miss rate the memory system
-        // sustains (k_succ<0>: 45 -> 36 ms).  Also having the first positions of four edges in flight was slower (48 ms:
-        // a node has 2.65 edges on average, the rest is wasted loads and registers), eight candidates per turn no better
-        // (35.6 ms), four lanes per vertex slower (51 ms), and keeping the first four accepted candidates of every vertex
-        // in a side array for the filling pass cost the counting pass more (+14 ms) than it saved the other (-5 ms).
-        for (uint32_t jb = j0; !MASK_ONLY && jb < q; jb += 4u) {
-            const U64x4 pqL = *(const U64x4 *)(G.vpos + p0 + jb);  // (padded by four entries)
-            const uint64_t *pq = pqL.a;
-#pragma unroll
-            for (uint32_t t = 0; t < 4u; ++t) {
-                const uint32_t j = jb + t;
-                if (j >= q) break;
-                const uint32_t p = p0 + j;
-                const uint32_t pc = (uint32_t)(pq[t] >> 32), pr = (uint32_t)pq[t];
-                uint32_t esim;
-                int grade = d_check_position_any(rc, rr, pc, pr, step, dev, err, entry, &esim);
-                if (grade == G_OOPS) continue;
-                if (MODE == 0 && base + j < 64u) mask |= 1ull << (base + j);
-                if (MODE != 0) emit(G.newid[p], pc, step, grade, esim);
-                ++n;
-            }
-        }
-        base += q;
-      }
-    }
-    return n;
-}
-
-// ... by a whole wave: 64 candidates of a target node's position list per turn (one coalesced load), the accepted ones counted
-// / placed through the ballot.  WHAT = 0: count + the mask of the first 64 candidates (as succ_vertex<0> leaves it);
-// WHAT = 1: every candidate evaluated again, the accepted ones written in CSR order.  v is the same in all lanes.
-template <int WHAT>
-__device__ __forceinline__ uint32_t succ_vertex_wave(const TravGraph &G, uint64_t v, uint32_t dev, double err, uint64_t &mask, SuccRec *__restrict__ out,
-                                                     const uint32_t *__restrict__ ratio_tab) {
-    const uint32_t lane = lane_id();
-    const uint64_t rootp = G.vpos[v];
-    const uint32_t rc = (uint32_t)(rootp >> 32), rr = (uint32_t)rootp;
-    const uint32_t node = G.vnode[v];
-    uint32_t n = 0, base = 0;
-    const uint32_t e_lo = G.nedge_off[node], e_hi = G.nedge_off[node + 1];
-    for (uint32_t e = e_lo; e < e_hi; ++e) {
-        const uint32_t to = G.eto[e];
-        if (to == PAG_NONE) continue;
-        uint32_t step, p0, q;
-        edge_target(G, to, G.estep[e], &step, &p0, &q);
-        const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;
-        for (uint32_t jb = 0; jb < q; jb += 64u) {
-            const uint32_t j = jb + lane;
-            const bool valid = j < q;
-            const uint64_t pp = valid ? G.vpos[p0 + j] : 0ull;
-            const uint32_t pc = (uint32_t)(pp >> 32), pr = (uint32_t)pp;
-            uint32_t esim = 0;
-            const int grade = valid ? d_check_position_any(rc, rr, pc, pr, step, dev, err, entry, &esim) : (int)G_OOPS;
-            const uint64_t b = __ballot(grade != G_OOPS);
-            if (WHAT == 0 && base + jb < 64u) mask |= b << (base + jb);
-            if (WHAT == 1 && grade != G_OOPS) {
-                SuccRec r;
-                r.tgt = G.newid[p0 + j];
-                r.pc = pc;
-                r.meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
-                r.toff = 0;
-                out[n + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = r;
-            }
-            n += (uint32_t)__popcll(b);
-        }
-        base += q;
-    }
-    return n;
-}
-
-// Threads run over the vertices in k-mer-major order (the order of the CSR): neighbouring threads belong to the same k-mer
-// node, so the node's edge list and the position lists of its target nodes are shared through the caches; only the
-// per-vertex results go to coordinate-ordered (random) places.
-// MODE 0: count the records of every vertex (cnt[u]) and leave the acceptance mask of its first 64 candidates (amask[v]).
-// MODE 1: write them to their final place succ[succ_off[u] ..] (after MODE 0 + scan: the two-pass path).
-// MODE 2: write them to a staging array at stage_off[v] — offsets from the cheap upper bound of k_succ_bound — and count;
-//         k_succ_place moves them to coordinate order afterwards.
-// (Measured and not kept, round 3: count, then APPEND to a staging array in the same kernel — a wave adds up its counts, takes
-// that much of the array with one atomic add, every thread goes over its accepted candidates once more — and gather the
-// records into coordinate order afterwards (k_succ_place): 82 + 31 ms at configs[1] against 37 + 45 + 6 ms for count, fill
-// and link: the second walk over the candidates is what the fill pass costs, not its scattered writes, and it is no
-// cheaper inside the counting thread.)
-// heavy_list / heavy_n (MODE 0 and 1, may be null): the vertices with more than heavy_limit candidates are left out here — MODE 0
-// appends them to the list — and done by k_succ_heavy, a wave each.
-template <int MODE>
-__global__ void __launch_bounds__(256, 8) k_succ(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, const uint64_t *__restrict__ stage_off,
-                       SuccRec *__restrict__ stage, uint64_t *__restrict__ amask, uint32_t *__restrict__ heavy_list,
-                       unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
-    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
-    __shared__ IncLds inc_bands;
-    d_ratio_table_fill(ratio_tab, err);
-    const bool inc_lds = inc_lds_fill(inc_bands, G);
-    __syncthreads();
-    constexpr bool FILL = MODE == 1 || MODE == 3 || MODE == 4;  // (3, 4: with the heavy list and a limit of at most 64 — see succ_vertex)
-    if (!heavy_list || MODE == 2) heavy_limit = 0xFFFFFFFFu;
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t n = 0;
-        uint64_t mask = 0ull;
-        const uint32_t u = G.newid[v];
-        // successors of it may lie outside the region this graph holds (k_mark_incomplete).  A coordinate-free vertex gets one
-        // poison record IN PLACE of its successors; a vertex on a contig keeps its successors — those that follow the contig
-        // are all here — and gets one marker record behind them that only counts where a walk could take a Skip grade
-        const bool inc = vertex_incomplete(G, inc_bands, inc_lds, v, u);
-        const bool poison = inc && u < G.n_zero, marker = inc && u >= G.n_zero;
-        if (poison) n = 1u;
-        else if (MODE == 0) {
-            n = succ_vertex<0>(G, v, dev, err, mask, nullptr, ratio_tab, heavy_limit);
-            const bool heavy = n == SUCC_HEAVY;
-            const uint64_t hb = __ballot(heavy);
-            if (hb) {  // (one atomic per wave)
-                const int first = __ffsll((long long)hb) - 1;
-                unsigned long long at = 0;
-                if ((int)lane_id() == first) at = atomicAdd(heavy_n, (unsigned long long)__popcll(hb));
-                at = __shfl(at, first);
-                if (heavy) heavy_list[at + (uint32_t)__popcll(hb & ((1ull << lane_id()) - 1ull))] = (uint32_t)v;
-            }
-            if (heavy) continue;
-            n += marker ? 1u : 0u;
-        }
-        SuccRec *out = nullptr;
-        if (FILL) out = G.succ + G.succ_off[u];
-        if (MODE == 2) out = stage + stage_off[v];
-        if (MODE != 0 && out) {
-            SuccRec r;
-            r.tgt = u;
-            r.pc = 0u;  // (no coordinate: neither a leap nor subject to the coordinate windows; the grade alone rejects it)
-            r.meta = 1u | ((poison ? GRADE_POISON : GRADE_POISON_IF_LEAP) << 24);
-            r.toff = 0;
-            if (poison) {
-                out[0] = r;
-            } else if (FILL) {
-                uint32_t m;
-                if (amask) {
-                    mask = amask[v];
-                    m = succ_vertex<MODE == 3 || MODE == 4 ? MODE : 1>(G, v, dev, err, mask, out, ratio_tab, heavy_limit, u);
-                    if (m == SUCC_HEAVY) continue;
-                } else {
-                    m = succ_vertex<2>(G, v, dev, err, mask, out, ratio_tab);
-                }
-                if (marker) out[m] = r;
-            } else if (MODE == 2) {
-                n = succ_vertex<2>(G, v, dev, err, mask, out, ratio_tab);
-                if (marker) out[n++] = r;
-            }
-        }
-        if (!FILL) cnt[u] = n;
-        if (MODE == 0 && amask) amask[v] = mask;
-    }
-}
-
-// the vertices k_succ left out (more candidates than its limit), a wave each
-template <int MODE>
-__global__ void __launch_bounds__(256) k_succ_heavy(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ amask,
-                                                    const uint32_t *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_n) {
-    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
-    __shared__ IncLds inc_bands;
-    d_ratio_table_fill(ratio_tab, err);
-    const bool inc_lds = inc_lds_fill(inc_bands, G);
-    __syncthreads();
-    const uint64_t total = *heavy_n, n_waves = (uint64_t)gridDim.x * (blockDim.x / 64u);
-    for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < total; i += n_waves) {
-        const uint64_t v = heavy_list[i];
-        const uint32_t u = G.newid[v];
-        const bool marker = vertex_incomplete(G, inc_bands, inc_lds, v, u);  // (a poisoned vertex never comes here)
-        uint64_t mask = 0ull;
-        if (MODE == 0) {
-            const uint32_t n = succ_vertex_wave<0>(G, v, dev, err, mask, nullptr, ratio_tab) + (marker ? 1u : 0u);
-            if (lane_id() == 0) {
-                cnt[u] = n;
-                amask[v] = mask;
-            }
-        } else {
-            SuccRec *out = G.succ + G.succ_off[u];
-            const uint32_t m = succ_vertex_wave<1>(G, v, dev, err, mask, out, ratio_tab);
-            if (marker && lane_id() == 0) {
-                SuccRec r;
-                r.tgt = u;
-                r.pc = 0u;
-                r.meta = 1u | (GRADE_POISON_IF_LEAP << 24);
-                r.toff = 0;
-                out[m] = r;
-            }
-        }
-    }
-}
-
-// ONE evaluation of the candidate pairs, records staged DENSELY (round 5, PAG_SUCC_MODE=fused): a vertex's candidates are walked
-// and counted (with the acceptance mask), the waves take room for their vertices' records from a cursor — one atomic per wave —
-// and every thread writes its accepted records there straight away, through the mask, while its node's edge and position lists
-// are still in the caches; k_succ_place moves them to coordinate order and links them.  Against the two passes: the edge /
-// position lists are read once, the records leave as full lines (k-mer-major neighbours write neighbouring records) instead of
-// 16-byte pieces at coordinate-ordered places, and nobody reads succ_off[u] at a random place.  stage_off[v] = where v's records
-// begin; a vertex whose records would not fit the staging array (cap) writes none — the caller sees the cursor beyond the cap
-// and falls back to the two passes.  GENERAL = false: every vertex has at most 64 candidates (the others are on the heavy list).
-template <bool GENERAL>
-__global__ void __launch_bounds__(256, 8) k_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ stage_off,
-                                                       SuccRec *__restrict__ stage, uint64_t cap, unsigned long long *__restrict__ cursor,
-                                                       uint32_t *__restrict__ heavy_list, unsigned long long *__restrict__ heavy_n, uint32_t heavy_limit) {
-    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
-    __shared__ IncLds inc_bands;
-    d_ratio_table_fill(ratio_tab, err);
-    const bool inc_lds = inc_lds_fill(inc_bands, G);
-    __syncthreads();
-    if (!heavy_list) heavy_limit = 0xFFFFFFFFu;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t v0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); v0 < G.n_pos; v0 += stride) {  // (wave-uniform trip count)
-        const uint64_t v = v0 + lane_id();
-        const bool active = v < G.n_pos;
-        uint32_t n = 0, u = 0;
-        uint64_t mask = 0ull;
-        bool poison = false, marker = false, heavy = false;
-        if (active) {
-            u = G.newid[v];
-            const bool inc = vertex_incomplete(G, inc_bands, inc_lds, v, u);
-            poison = inc && u < G.n_zero;
-            marker = inc && u >= G.n_zero;
-            if (poison) n = 1u;
-            else {
-                n = succ_vertex<0>(G, v, dev, err, mask, nullptr, ratio_tab, heavy_limit);
-                heavy = n == SUCC_HEAVY;
-                n = heavy ? 0u : n + (marker ? 1u : 0u);
-            }
-        }
-        const uint64_t hb = __ballot(heavy);
-        if (hb) {  // (one atomic per wave)
-            const int first = __ffsll((long long)hb) - 1;
-            unsigned long long at = 0;
-            if ((int)lane_id() == first) at = atomicAdd(heavy_n, (unsigned long long)__popcll(hb));
-            at = __shfl(at, first);
-            if (heavy) heavy_list[at + (uint32_t)__popcll(hb & ((1ull << lane_id()) - 1ull))] = (uint32_t)v;
-        }
-        uint32_t tot;
-        const uint32_t ex = wave_excl_sum(n, &tot);
-        unsigned long long base = 0;
-        if (tot) {
-            if (lane_id() == 0) base = atomicAdd(cursor, (unsigned long long)tot);
-            base = __shfl(base, 0);
-        }
-        if (!active || heavy) continue;
-        const uint64_t off = base + ex;
-        stage_off[v] = off;
-        cnt[u] = n;
-        if (n == 0u || off + n > cap) continue;
-        SuccRec *out = stage + off;
-        SuccRec r;
-        r.tgt = u;
-        r.pc = 0u;
-        r.meta = 1u | ((poison ? GRADE_POISON : GRADE_POISON_IF_LEAP) << 24);
-        r.toff = 0;
-        if (poison) {
-            out[0] = r;
-        } else {
-            const uint32_t m = succ_vertex<GENERAL ? 1 : 3>(G, v, dev, err, mask, out, ratio_tab, heavy_limit);
-            if (marker) out[m] = r;
-        }
-    }
-}
-// ... the vertices on the heavy list, a wave each: counted, room taken, written
-__global__ void __launch_bounds__(256) k_succ_heavy_fused(TravGraph G, uint32_t dev, double err, uint32_t *__restrict__ cnt, uint64_t *__restrict__ stage_off,
-                                                          SuccRec *__restrict__ stage, uint64_t cap, unsigned long long *__restrict__ cursor,
-                                                          const uint32_t *__restrict__ heavy_list, const unsigned long long *__restrict__ heavy_n) {
-    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
-    __shared__ IncLds inc_bands;
-    d_ratio_table_fill(ratio_tab, err);
-    const bool inc_lds = inc_lds_fill(inc_bands, G);
-    __syncthreads();
-    const uint64_t total = *heavy_n, n_waves = (uint64_t)gridDim.x * (blockDim.x / 64u);
-    for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; i < total; i += n_waves) {
-        const uint64_t v = heavy_list[i];
-        const uint32_t u = G.newid[v];
-        const bool marker = vertex_incomplete(G, inc_bands, inc_lds, v, u);  // (a poisoned vertex never comes here)
-        uint64_t mask = 0ull;
-        const uint32_t n = succ_vertex_wave<0>(G, v, dev, err, mask, nullptr, ratio_tab) + (marker ? 1u : 0u);
-        unsigned long long off = 0;
-        if (lane_id() == 0) off = atomicAdd(cursor, (unsigned long long)n);
-        off = __shfl(off, 0);
-        if (lane_id() == 0) {
-            cnt[u] = n;
-            stage_off[v] = off;
-        }
-        if (n == 0u || off + n > cap) continue;
-        SuccRec *out = stage + off;
-        const uint32_t m = succ_vertex_wave<1>(G, v, dev, err, mask, out, ratio_tab);
-        if (marker && lane_id() == 0) {
-            SuccRec r;
-            r.tgt = u;
-            r.pc = 0u;
-            r.meta = 1u | (GRADE_POISON_IF_LEAP << 24);
-            r.toff = 0;
-            out[m] = r;
-        }
-    }
-}
-
-// upper bound of a vertex's records: the positions of all target nodes of its k-mer node (every candidate pair)
-__global__ void k_succ_bound(TravGraph G, uint32_t *__restrict__ ub) {
-    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < G.n_pos; v += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t node = G.vnode[v];
-        uint32_t n = 0;
-        for (uint32_t e = G.nedge_off[node]; e < G.nedge_off[node + 1]; ++e) {
-            uint32_t step, p0, q;
-            edge_target(G, G.eto[e], G.estep[e], &step, &p0, &q);
-            n += q;
-        }
-        ub[v] = n + (G.incomplete ? 1u : 0u);  // (room for a poison / marker record, see k_succ)
-    }
-}
-
-// staged records -> coordinate order, target ranges linked in on the way (see k_succ_link)
-__global__ void k_succ_place(TravGraph G, const uint64_t *__restrict__ stage_off, const SuccRec *__restrict__ stage) {
-    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < G.n_pos; u += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t o0 = G.succ_off[u], o1 = G.succ_off[u + 1];
-        if (o0 == o1) continue;
-        const SuccRec *src = stage + stage_off[G.uold[u]];
-        for (uint32_t j = 0; j < o1 - o0; ++j) {
-            SuccRec r = src[j];
-            const uint32_t t0 = G.succ_off[r.tgt], t1 = G.succ_off[r.tgt + 1];
-            const uint32_t tc = t1 - t0 < 15u ? t1 - t0 : 15u;
-            r.meta |= tc << 28;
-            r.toff = t0;
-            G.succ[o0 + j] = r;
-        }
-    }
-}
-
-// Every record learns its target's record range (offset + count clamped to 15 = "15 or more: look the range up"), so
-// that a walk step never waits for succ_off.  A pass of its own over the records IN COORDINATE ORDER: the targets of
-// neighbouring records are neighbours on the strand, so the succ_off reads hit the caches — inside k_succ (k-mer-major
-// threads) the same reads were one random HBM access per record.
-// GRADE: a record that k_succ<4> left ungraded (grade 0, the source's new id in `toff`) gets its target's contig coordinate, its
-// grade and its edge-similarity bit here, from the positions of both ends IN COORDINATE ORDER (upos): the source's is the
-// neighbour of the previous record's, the target's lies a step ahead of it on the strand.
-template <bool GRADE>
-__global__ void k_succ_link(TravGraph G, uint64_t n_rec, uint32_t dev, double err) {
-    __shared__ uint32_t ratio_tab[GRADE ? RATIO_TAB_N : 1u];
-    if (GRADE) {
-        d_ratio_table_fill(ratio_tab, err);
-        __syncthreads();
-    }
-    // four records per thread and trip, their loads issued together (one dependent gather each: latency-bound otherwise)
-    const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rec; i += 4 * T) {
-        SuccRec r[4];
-        uint32_t t0[4], t1[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t x = i + (uint64_t)q * T;
-            r[q] = G.succ[x < n_rec ? x : i];  // one 16-byte load
-        }
-        uint64_t ps[4], pt[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t0[q] = G.succ_off[r[q].tgt];
-            t1[q] = G.succ_off[r[q].tgt + 1];
-            if (GRADE) {
-                const bool todo = ((r[q].meta >> 24) & 7u) == 0u;
-                pt[q] = todo ? G.upos[r[q].tgt] : 0ull;
-                ps[q] = todo ? G.upos[r[q].toff] : 0ull;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint64_t x = i + (uint64_t)q * T;
-            if (x >= n_rec) continue;
-            if (GRADE && ((r[q].meta >> 24) & 7u) == 0u) {
-                const uint32_t step = r[q].meta & 0xFFFFFFu;
-                const uint32_t entry = step < RATIO_TAB_N ? ratio_tab[step] : RATIO_TAB_NONE;
-                uint32_t esim;
-                const int grade = d_check_position_any((uint32_t)(ps[q] >> 32), (uint32_t)ps[q], (uint32_t)(pt[q] >> 32), (uint32_t)pt[q], step, dev, err, entry, &esim);
-                r[q].pc = (uint32_t)(pt[q] >> 32);
-                r[q].meta = step | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
-            }
-            const uint32_t tc = t1[q] - t0[q] < 15u ? t1[q] - t0[q] : 15u;
-            r[q].meta |= tc << 28;
-            r[q].toff = t0[q];
-            G.succ[x] = r[q];  // one 16-byte store
-        }
-    }
-}
-
-// [first, last) new-id range of the vertices whose contig coordinate lies in [lo, hi)
-__global__ void k_ranges(TravGraph G, TravContig *ctgs, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    auto lower = [&](uint32_t x) {
-        uint64_t lo = 0, hi = G.n_pos;
-        while (lo < hi) {
-            uint64_t mid = (lo + hi) >> 1;
-            if ((uint32_t)(G.upos[mid] >> 32) < x) lo = mid + 1;
-            else hi = mid;
-        }
-        return (uint32_t)lo;
-    };
-    ctgs[i].in_lo = lower(ctgs[i].ctg_left);
-    ctgs[i].in_hi = lower(ctgs[i].ctg_right);
-    ctgs[i].g_lo = ctgs[i].in_lo;
-    ctgs[i].g_hi = ctgs[i].in_hi;
-}
-
-// first new id whose contig coordinate is >= coords[i] (the vertices with a coordinate are ordered by it)
-__global__ void k_id_bounds(TravGraph G, const uint32_t *__restrict__ coords, uint32_t n, uint32_t *__restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t x = coords[i];
-    uint64_t lo = 0, hi = G.n_pos;
-    while (lo < hi) {
-        uint64_t mid = (lo + hi) >> 1;
-        if ((uint32_t)(G.upos[mid] >> 32) < x) lo = mid + 1;
-        else hi = mid;
-    }
-    out[i] = (uint32_t)lo;
-}
 
 // =================================================================================================
 // the walker
@@ -2363,35 +1247,9 @@ __device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp,
 }
 
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
-// A job clears its own marks before it begins (TravJob::self_clear, PAG_WALK_SELFCLEAR=1; a measured variant, not the default): the
-// control thread has ONE launch clear the stamps, travel epochs and hash sets of every job of a batch (25 GB at configs[1]) and
-// waits for it before the first job is published, 2.7 ms at the head of every block's walks with the device otherwise idle.  With
-// the jobs clearing their own the walks start at once and take LONGER (88.2 against 85.0 ms): a lone wave needs ~0.6 ms for its
-// 4 MB.
-__device__ __forceinline__ void wave_fill16(void *p, uint64_t bytes, uint32_t word) {  // (p 16-byte aligned, bytes a multiple of 16)
-    uint4 *q = (uint4 *)p;
-    const uint4 w = make_uint4(word, word, word, word);
-    const uint64_t n = bytes / 16u;
-    for (uint64_t i = lane_id(); i < n; i += 64u) q[i] = w;
-}
-__device__ __forceinline__ void job_self_clear(const TravJob &J) {
-    const uint64_t PG = TRAV_PROBE_GROUPS;
-    if ((J.mode & TRAV_MODE_LEAP) && J.seq_x)
-        for (uint64_t i = lane_id(); i < J.seq_cap; i += 64u) J.seq_x[i] = 0ull;
-    wave_fill16(J.tset, ((uint64_t)J.tmask + 1u) * 8u, 0xFFFFFFFFu);
-    wave_fill16(J.pset, ((uint64_t)J.pmask + 1u) * PG * 8u, 0u);
-    wave_fill16(J.stamp, PG * (uint64_t)J.stamp_stride * 4u, 0u);
-    wave_fill16(J.tbits, ((uint64_t)J.stamp_stride + 4u) * 4u, 0u);
-    // the stores are in the L2 before anything of the job reads or updates these arrays (L2 atomics, agent-scope loads, plain
-    // loads through an L1 that holds none of these lines yet: the fence drops what it might)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
 __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const TravContig &C, const TravJob &Jsrc, TravJobOut *out, uint32_t k) {
     const uint32_t lane = lane_id();
     const TravJob J = Jsrc;  // by value: the record may live in host memory
-    if (J.self_clear) job_self_clear(J);
     WalkCtx X;
     X.G = G;
     X.C = C;
@@ -3047,466 +1905,6 @@ __global__ __launch_bounds__(64, PAG_WALK_WAVES_PER_EU) void k_walk_persistent(T
     if (lane == 0) __hip_atomic_fetch_add(&q->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// =================================================================================================
-// seeds
-// =================================================================================================
-// searchPANode(onlyFirst = true) (PAlgorithm.tcc:300-327): the first contig k-mer one of whose positions
-// lies on this contig strand within `dev` of the k-mer's own offset; all such positions of that k-mer.
-// One wave per contig.  out[0] = count, then (vertex, node) pairs.
-__global__ __launch_bounds__(64) void k_seed_first(TravGraph G, const TravContig *__restrict__ ctgs, uint32_t n_ctgs_sel,
-                                                   uint64_t dev, uint32_t *__restrict__ out, uint32_t out_stride) {
-    const uint32_t c = blockIdx.x;
-    if (c >= n_ctgs_sel) return;
-    const TravContig C = ctgs[c];
-    const uint32_t lane = lane_id();
-    uint32_t *o = out + (uint64_t)c * out_stride;
-    uint32_t found = 0;
-    for (uint32_t base = 0; base < C.n_kmers && !found; base += 64) {
-        uint32_t i = base + lane;
-        bool hit = false;
-        uint32_t node = PAG_NONE;
-        if (i < C.n_kmers) {
-            node = C.nodes[i];
-            if (node != PAG_NONE) {
-                for (uint32_t p = G.npos_off[node]; p < G.npos_off[node + 1] && !hit; ++p) {
-                    uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
-                    if (pc >= C.ctg_left && pc < C.ctg_right) {
-                        uint64_t off = pc - C.ctg_left;
-                        uint64_t d = off > i ? off - i : (uint64_t)i - off;
-                        hit = d <= dev;
-                    }
-                }
-            }
-        }
-        uint64_t m = __ballot(hit);
-        if (m) {
-            int src = __ffsll((long long)m) - 1;
-            if ((int)lane == src) {
-                uint32_t n = 0;
-                for (uint32_t p = G.npos_off[node]; p < G.npos_off[node + 1]; ++p) {
-                    uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
-                    if (pc >= C.ctg_left && pc < C.ctg_right) {
-                        uint64_t off = pc - C.ctg_left;
-                        uint64_t d = off > i ? off - i : (uint64_t)i - off;
-                        if (d <= dev && 1 + 2 * n + 1 < out_stride) {
-                            o[1 + 2 * n] = p;
-                            o[2 + 2 * n] = i;
-                            ++n;
-                        }
-                    }
-                }
-                o[0] = n;
-            }
-            found = 1;
-        }
-    }
-    if (!found && lane == 0) o[0] = 0;
-}
-
-// searchPANode2 (PAlgorithm.tcc:329-365): every (contig offset in [left, right], position) pair whose
-// position lies on this strand within `dev` of `pos`, in order.  Duplicates of a vertex are removed on
-// the host (first occurrence wins).  TRAV_SEED_PARTS waves per request, each scanning one part of the offset range
-// (the window spans 1000 x deviation offsets on either side); part p of request r writes out[(r * PARTS + p) * stride]:
-// [0] = count, then vertex ids; the host concatenates the parts in order.
-__global__ __launch_bounds__(64) void k_seed_window(TravGraph G, const TravContig *__restrict__ ctgs,
-                                                    const TravSeedReq *__restrict__ reqs, uint32_t n_req, uint64_t dev,
-                                                    uint32_t *__restrict__ out, uint32_t out_stride) {
-    const uint32_t r = blockIdx.x, part = blockIdx.y;
-    if (r >= n_req) return;
-    const TravSeedReq R = reqs[r];
-    const TravContig C = ctgs[R.ctg];
-    const uint32_t lane = lane_id();
-    uint32_t *o = out + ((uint64_t)r * TRAV_SEED_PARTS + part) * out_stride;
-    uint32_t n_out = 0;
-    const uint64_t right_all = R.right < (uint64_t)C.n_kmers ? R.right + 1 : C.n_kmers;  // exclusive
-    const uint64_t span = right_all > R.left ? right_all - R.left : 0;
-    const uint64_t per = ((span + TRAV_SEED_PARTS - 1) / TRAV_SEED_PARTS + 63) & ~63ull;  // offsets per part (whole wave rows)
-    const uint64_t left = R.left + (uint64_t)part * per;
-    const uint64_t right = left + per < right_all ? left + per : right_all;
-    for (uint64_t base = left; base < right; base += 64) {
-        uint64_t i = base + lane;
-        uint32_t node = i < right ? C.nodes[i] : PAG_NONE;
-        uint32_t p0 = 0, p1 = 0;
-        if (node != PAG_NONE) {
-            p0 = G.npos_off[node];
-            p1 = G.npos_off[node + 1];
-        }
-        // lanes emit in lane order, positions in order: serialise over the lanes that have matches
-        // filterPANodes (PAlgorithm.cpp:97-105): vertices of the contig's globalUniqueTable are dropped here, on the device
-        // (a per-vertex predicate: applying it before the host removes duplicates gives the same list)
-        auto visited = [&](uint32_t p) -> bool {
-            if (!C.gbits) return false;
-            const uint32_t u = G.newid[p];
-            if (u >= C.g_lo && u < C.g_hi) return ((C.gbits[(u - C.g_lo) >> 5] >> ((u - C.g_lo) & 31u)) & 1u) != 0u;
-            return C.gset ? hs_has(C.gset, C.gmask, u) : false;
-        };
-        uint32_t cnt = 0;
-        for (uint32_t p = p0; p < p1; ++p) {
-            uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
-            if (pc >= C.ctg_left && pc < C.ctg_right) {
-                uint64_t off = pc - C.ctg_left;
-                uint64_t d = off > R.pos ? off - R.pos : R.pos - off;
-                cnt += (d <= dev && !visited(p)) ? 1u : 0u;
-            }
-        }
-        uint32_t tot;
-        uint32_t ex = wave_excl_sum(cnt, &tot);
-        uint32_t w = n_out + ex;
-        for (uint32_t p = p0; p < p1 && cnt; ++p) {
-            uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
-            if (pc >= C.ctg_left && pc < C.ctg_right) {
-                uint64_t off = pc - C.ctg_left;
-                uint64_t d = off > R.pos ? off - R.pos : R.pos - off;
-                if (d <= dev && !visited(p)) {
-                    if (1 + w < out_stride) o[1 + w] = p;
-                    ++w;
-                }
-            }
-        }
-        n_out += tot;
-    }
-    if (lane == 0) o[0] = n_out;
-}
-
-// Checkpoints of the segment-parallel walk (k5_travel_host.hip): for every request (contig, contig offset) the most
-// abundant vertex that lies ON the contig strand (its k-mer is the contig's k-mer at offset i and its contig coordinate
-// is within `dev` of i, like a seed of searchPANode) for i in [left, right], and that is not in the contig's global
-// visited set.  Ties: the lowest offset, then position order.  One wave per request; out = (old vertex id, contig
-// coordinate, abundance) or (PAG_NONE, 0, 0).  Which vertex is picked has no influence on the results of the
-// traversal, only on how soon the walk that arrives from behind meets the piece started here.
-__global__ __launch_bounds__(64) void k_checkpoints(TravGraph G, const TravContig *__restrict__ ctgs, const TravSeedReq *__restrict__ reqs,
-                                                    uint32_t n_req, uint64_t dev, uint32_t *__restrict__ out) {
-    const uint32_t r = blockIdx.x;
-    if (r >= n_req) return;
-    const TravSeedReq R = reqs[r];
-    const TravContig C = ctgs[R.ctg];
-    const uint32_t lane = lane_id();
-    const uint64_t right = R.right < (uint64_t)C.n_kmers ? R.right + 1 : C.n_kmers;  // exclusive
-    uint64_t best = 0;  // abundance << 40 | (0xFFFFF - (offset - left)) << 20 | (0xFFFFF - position rank): larger is better
-    uint32_t best_v = PAG_NONE, best_pc = 0;
-    for (uint64_t base = R.left; base < right; base += 64) {
-        const uint64_t i = base + lane;
-        const uint32_t node = i < right ? C.nodes[i] : PAG_NONE;
-        if (node == PAG_NONE) continue;
-        const uint32_t p0 = G.npos_off[node], p1 = G.npos_off[node + 1];
-        for (uint32_t p = p0; p < p1; ++p) {
-            const uint32_t pc = (uint32_t)(G.vpos[p] >> 32);
-            if (pc < C.ctg_left || pc >= C.ctg_right) continue;
-            const uint64_t off = pc - C.ctg_left;
-            const uint64_t d = off > i ? off - i : i - off;
-            if (d > dev) continue;
-            const uint32_t u = G.newid[p];
-            if (C.gbits && u >= C.g_lo && u < C.g_hi && ((C.gbits[(u - C.g_lo) >> 5] >> ((u - C.g_lo) & 31u)) & 1u)) continue;
-            const uint64_t key = ((uint64_t)G.vcnt[p] << 40) | ((uint64_t)(0xFFFFFu - (uint32_t)((i - R.left) & 0xFFFFFu)) << 20) |
-                                 (uint64_t)(0xFFFFFu - ((p - p0) & 0xFFFFFu));
-            if (key > best) {
-                best = key;
-                best_v = p;
-                best_pc = pc;
-            }
-        }
-    }
-    for (int d2 = 32; d2 >= 1; d2 >>= 1) {
-        const uint64_t ob = __shfl_xor(best, d2, 64);
-        const uint32_t ov = (uint32_t)__shfl_xor((int)best_v, d2, 64), op = (uint32_t)__shfl_xor((int)best_pc, d2, 64);
-        if (ob > best) {
-            best = ob;
-            best_v = ov;
-            best_pc = op;
-        }
-    }
-    if (lane == 0) {
-        out[3 * r] = best_v;
-        out[3 * r + 1] = best_pc;
-        out[3 * r + 2] = (uint32_t)(best >> 40);
-    }
-}
-
-// The new parts of the sequences of a batch of finished jobs, packed for ONE copy to the host: per job its vertices (new
-// ids), its steps and the contig coordinates of its vertices (+ the two words of the iteration log of a TRAV_MODE_LEAP
-// job), each `len` words, at out + off — and behind them the job's BLOCK TABLES (walk_stitch.hpp: AGG_WORDS words per 64
-// entries, + AGG_XWORDS for a leap job): a wave copies 64 consecutive entries per turn and reduces them while it holds them.
-__global__ void k_pack_paths(TravGraph G, const TravPackDesc *__restrict__ descs, uint32_t n, uint32_t *__restrict__ out) {
-    const uint32_t j = blockIdx.y;
-    if (j >= n) return;
-    const TravPackDesc D = descs[j];
-    uint32_t *o = out + D.off;
-    const uint32_t lane = lane_id();
-    const uint64_t n_arrays = D.seq_x ? 5 : 3;
-    uint32_t *agg = o + n_arrays * D.len;
-    uint32_t *xagg = agg + ((D.len + 63) / 64) * 5;
-    // (wave-uniform loop: every lane of a wave takes part in the reductions of its block)
-    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < D.len; i0 += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = i0 + lane;
-        const bool valid = i < D.len;
-        uint32_t v = 0, st = 0, c = 0, xl = 0, xh = 0;
-        if (valid) {
-            v = D.seq_v[i];
-            st = D.seq_s[i];
-            c = (uint32_t)(G.upos[v] >> 32);
-            o[i] = v;
-            o[D.len + i] = st;
-            o[2 * D.len + i] = c;
-            if (D.seq_x) {
-                const uint64_t x = D.seq_x[i];
-                xl = (uint32_t)x;
-                xh = (uint32_t)(x >> 32);
-                o[3 * D.len + i] = xl;
-                o[4 * D.len + i] = xh;
-            }
-        }
-        const uint32_t mx = wave_max_u32(valid ? c : 0u);
-        const uint32_t m0 = wave_max_u32(valid && c == 0u ? v + 1u : 0u);
-        const uint32_t lo = wave_min_u32(valid ? c : 0xFFFFFFFFu);
-        const uint32_t lnz = wave_min_u32(valid && c != 0u ? c : 0xFFFFFFFFu);
-        const uint32_t sum = wave_sum(valid ? st : 0u);
-        const uint64_t blk = i0 >> 6;
-        if (lane == 0) {
-            uint32_t *a = agg + blk * 5;
-            a[0] = mx;
-            a[1] = m0;
-            a[2] = lo;
-            a[3] = lnz;
-            a[4] = sum;
-        }
-        if (D.seq_x) {
-            const bool bd = valid && (xh >> 31) != 0u;
-            const uint32_t elow = wave_min_u32(bd ? (xh & 0x7FFFFFFFu) : 0xFFFFFFFFu);
-            const uint32_t xm0 = wave_min_u32(bd ? xl : 0xFFFFFFFFu);
-            if (lane == 0) {
-                xagg[blk * 2] = elow;
-                xagg[blk * 2 + 1] = xm0;
-            }
-        }
-    }
-}
-
-// contig coordinates of a path (new ids) for the host-side stitch
-__global__ void k_gather_pc(TravGraph G, const uint32_t *__restrict__ seq_v, uint64_t len, uint32_t *__restrict__ out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = (uint32_t)(G.upos[seq_v[i]] >> 32);
-}
-
-// record a finished walk (new ids) in the contig's global visited structures
-__global__ void k_commit(const uint32_t *__restrict__ seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits,
-                         uint32_t *gset, uint32_t gmask) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t u = seq_v[i];
-        if (u >= in_lo && u < in_hi) atomicOr(&gbits[(u - in_lo) >> 5], 1u << ((u - in_lo) & 31u));
-        else hs_insert(gset, gmask, u);
-    }
-}
-
-// vertex attributes of a path (new ids) for the host
-__global__ void k_gather_path(TravGraph G, const uint32_t *__restrict__ seq_v, const uint32_t *__restrict__ seq_s, uint64_t len,
-                              pag_path_node *__restrict__ out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t v = G.uold[seq_v[i]];
-        uint64_t p = G.vpos[v];
-        pag_path_node o;
-        o.code = G.ncode[G.vnode[v]];
-        o.ctg = (uint32_t)(p >> 32);
-        o.ref = (uint32_t)p;
-        o.cnt = G.vcnt[v];
-        o.reserved = 0;
-        o.step = (int32_t)seq_s[i];
-        o.vid = v;
-        out[i] = o;
-    }
-}
-
-__global__ void k_gather_vertices(TravGraph G, const uint32_t *__restrict__ vids, uint32_t n, pag_path_node *__restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t v = vids[i];
-    uint64_t p = G.vpos[v];
-    pag_path_node o;
-    o.code = G.ncode[G.vnode[v]];
-    o.ctg = (uint32_t)(p >> 32);
-    o.ref = (uint32_t)p;
-    o.cnt = G.vcnt[v];
-    o.reserved = 0;
-    o.step = 0;
-    o.vid = v;
-    out[i] = o;
-}
-
-// -------------------------------------------------------------------------------------------------
-// launch wrappers used by pag_travel.cpp-side orchestration in pag_api.hip
-// -------------------------------------------------------------------------------------------------
-static unsigned grid_for(uint64_t n) { return (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16) + (n == 0); }
-
-int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
-                 const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
-                 uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view,
-                 uint64_t *counts_out, int place_bits) {
-    // place_bits != 0 (and G.nperm, G.uold / newid / upos / ucnt / succ_off allocated: they are scratch here): the nodes are
-    // numbered by place — place_bits = width of the wider of the two coordinate spaces
-    // tmp: flags u32[max(T, E, words, nodes + 1)] | scan out u64[same] | scan out 2 u64[T] | keep u32[T] | scan tmp
-    // view != null: only the vertices inside its intervals (device arrays) are taken; counts_out[3] = nodes, vertices, edges
-    // of the view (n_nodes / n_pos / n_edges are then upper bounds: what the arrays of G were sized for)
-    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
-    uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
-    char *p = (char *)tmp;
-    auto take = [&](size_t bytes) {
-        char *q = p;
-        p += (bytes + 255) & ~(size_t)255;
-        return (void *)q;
-    };
-    uint32_t *flags = (uint32_t *)take(m * 4);
-    uint64_t *sc1 = (uint64_t *)take(m * 8);
-    uint64_t *sc2 = (uint64_t *)take(m * 8);
-    uint32_t *keep = (uint32_t *)take(m * 4);
-    uint64_t *totals = (uint64_t *)take(64);
-    void *scan_tmp = take(std::max(scan_tmp_bytes(m), sort_tmp_bytes(n_nodes + 1)));
-    uint64_t *code_tab = k <= TRAV_CODE_TABLE_MAX_K ? (uint64_t *)take((size_t)8 << (2 * k)) : nullptr;
-    if ((size_t)(p - (char *)tmp) > tmp_bytes) {
-        set_error("trav_compact: scratch too small");
-        return PAG_EINVAL;
-    }
-    PAG_HIP_TRY(hipMemsetAsync(G.bitmap, 0, n_words * 8, s));
-    int rc;
-    const bool by_place = place_bits > 0 && G.nperm != nullptr;
-    if (!by_place) G.nperm = nullptr;
-    if (T) {
-        const uint64_t n_tiles = (T + VC_TILE - 1) / VC_TILE;
-        uint32_t *tile_first = flags, *tile_keep = keep;  // (n_tiles counters each)
-        const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, 256u * 8u);
-        const uint32_t *civ = view ? view->civ : nullptr, *riv = view ? view->riv : nullptr;
-        const uint32_t n_civ = view ? view->n_civ : 0u, n_riv = view ? view->n_riv : 0u;
-        uint64_t *ballots = sc2 + n_tiles + 16;  // (2 words per 64 slots, behind the tiles' offsets: m * 8 bytes hold both)
-        k_view_mark<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tseg, T, civ, n_civ, riv, n_riv, view ? 0 : 1, ballots, tile_first, tile_keep, n_tiles);
-        if ((rc = scan_u32_to_u64(tile_first, sc1, n_tiles, totals, scan_tmp, s))) return rc;
-        if ((rc = scan_u32_to_u64(tile_keep, sc2, n_tiles, totals + 1, scan_tmp, s))) return rc;
-        // (numbered by place: the code-ordered nodes and vertices go to arrays that are free until the coordinate order is made)
-        TravGraph Gw = G;
-        if (by_place) {
-            Gw.ncode = G.newid;
-            Gw.npos_off = G.uold;
-            Gw.vpos = G.upos;
-            Gw.vcnt = (uint16_t *)G.ucnt;
-        }
-        k_view_write<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tcnt, ballots, sc1, sc2, n_tiles, Gw);
-    }
-    if (view) {
-        uint64_t h[2] = {0, 0};
-        if (T) {
-            PAG_HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
-        }
-        if (h[0] > n_nodes || h[1] > n_pos) {
-            set_error("trav_compact: the view holds more than the graph");
-            return PAG_EFAULT;
-        }
-        n_nodes = h[0];
-        n_pos = h[1];
-        G.n_nodes = n_nodes;
-        G.n_pos = n_pos;
-    }
-    uint32_t np32 = (uint32_t)n_pos;
-    PAG_HIP_TRY(hipMemcpyAsync((by_place ? G.uold : G.npos_off) + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
-    if (by_place && n_nodes) {
-        const uint32_t *ncode_old = G.newid, *npos_off_old = G.uold;
-        const uint64_t *vpos_old = G.upos;
-        const uint16_t *vcnt_old = (const uint16_t *)G.ucnt;
-        const int kb = std::min(32, place_bits + 1);
-        const uint32_t shift = (uint32_t)(place_bits + 1 - kb), flag = 1u << (kb - 1);
-        uint32_t *key0 = keep, *key1 = G.succ_off;
-        uint64_t *val0 = sc2, *val1 = sc1;
-        k_node_place_keys<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(npos_off_old, vpos_old, n_nodes, shift, flag, key0, val0);
-        int in0 = 1;
-        if ((rc = sort_pairs(key0, val0, key1, val1, n_nodes, kb, scan_tmp, &in0, s, nullptr, nullptr))) return rc;
-        const uint64_t *perm = in0 ? val0 : val1;
-        uint64_t *off_new = in0 ? val1 : val0;  // (the other value array is free)
-        k_node_place_counts<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(perm, npos_off_old, n_nodes, flags, G.nperm);
-        if ((rc = scan_u32_to_u64(flags, off_new, n_nodes, nullptr, scan_tmp, s))) return rc;  // (the sort is done with its scratch)
-        k_node_place_move<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(perm, off_new, ncode_old, npos_off_old, vpos_old, vcnt_old, n_nodes, G);
-        PAG_HIP_TRY(hipMemcpyAsync(G.npos_off + n_nodes, &np32, 4, hipMemcpyHostToDevice, s));
-    }
-    // rank directory
-    k_popc_words<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(G.bitmap, n_words, flags);
-    if ((rc = scan_u32_to_u64(flags, sc1, n_words, nullptr, scan_tmp, s))) return rc;
-    k_narrow<<<dim3(grid_for(n_words)), dim3(256), 0, s>>>(sc1, n_words, G.rank);
-    // edges (of the k-mers that own a node: node_of_code finds no node for the others)
-    PAG_HIP_TRY(hipMemsetAsync(flags, 0, (n_nodes + 1) * 4, s));
-    if (E) k_edge_counts<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eseg, E, G, flags);
-    if ((rc = scan_u32_to_u64(flags, sc1, n_nodes + 1, view ? totals + 2 : nullptr, scan_tmp, s))) return rc;
-    k_narrow<<<dim3(grid_for(n_nodes + 1)), dim3(256), 0, s>>>(sc1, n_nodes + 1, G.nedge_off);
-    if (E && code_tab) {
-        PAG_HIP_TRY(hipMemsetAsync(code_tab, 0xFF, (size_t)8 << (2 * k), s));
-        TravGraph Gn = G;
-        Gn.n_nodes = n_nodes;
-        if (n_nodes) k_code_table<<<dim3(grid_for(n_nodes)), dim3(256), 0, s>>>(Gn, code_tab);
-    }
-    if (E) k_compact_edges<<<dim3(grid_for(E)), dim3(256), 0, s>>>(ekey, eval, eseg, E, G, code_tab);
-    if (view) {
-        uint64_t ne = 0;
-        PAG_HIP_TRY(hipMemcpyAsync(&ne, totals + 2, 8, hipMemcpyDeviceToHost, s));
-        PAG_HIP_TRY(hipStreamSynchronize(s));
-        if (ne > n_edges) {
-            set_error("trav_compact: the view holds more edges than the graph");
-            return PAG_EFAULT;
-        }
-        n_edges = ne;
-    }
-    if (counts_out) {
-        counts_out[0] = n_nodes;
-        counts_out[1] = n_pos;
-        counts_out[2] = n_edges;
-    }
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-
-size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes) {
-    const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
-    uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
-    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((std::max(scan_tmp_bytes(m), sort_tmp_bytes(n_nodes + 1)) + 255) & ~(size_t)255) + 1024 + 256 +
-           (k <= TRAV_CODE_TABLE_MAX_K ? ((size_t)8 << (2 * k)) + 256 : 0);
-}
-
-// reference bands of the zones (k_zone_bands): lo / hi [n_z] device arrays, preset here
-int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev, uint32_t n_z, uint32_t *lo_dev, uint32_t *hi_dev, hipStream_t s) {
-    if (!n_z) return PAG_OK;
-    PAG_HIP_TRY(hipMemsetAsync(lo_dev, 0xFF, (size_t)n_z * 4, s));
-    PAG_HIP_TRY(hipMemsetAsync(hi_dev, 0, (size_t)n_z * 4, s));
-    if (T) k_zone_bands<<<dim3(grid_for(T)), dim3(256), 0, s>>>(tval, T, zones_dev, n_z, lo_dev, hi_dev);
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-
-void trav_launch_ctg_nodes(const uint8_t *packed, const TravCtgNodesJob *jobs, uint32_t n_jobs, uint32_t max_len, uint32_t k, TravGraph G, uint32_t *out,
-                           hipStream_t s) {
-    const uint32_t n = max_len >= k ? max_len - k + 1 : 0;
-    if (!n || !n_jobs) return;
-    for (uint32_t at = 0; at < n_jobs; at += 65535u) {  // (gridDim.y)
-        const uint32_t m = std::min(n_jobs - at, 65535u);
-        k_ctg_nodes<<<dim3(std::min(grid_for(n), 256u), m), dim3(256), 0, s>>>(packed, jobs + at, k, G, out);
-    }
-}
-void trav_launch_seed_first(TravGraph G, const TravContig *ctgs, uint32_t n, uint64_t dev, uint32_t *out, uint32_t stride,
-                            hipStream_t s) {
-    if (n) k_seed_first<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, n, dev, out, stride);
-}
-void trav_launch_seed_window(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev,
-                             uint32_t *out, uint32_t stride, hipStream_t s) {
-    if (n) k_seed_window<<<dim3(n, TRAV_SEED_PARTS), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out, stride);
-}
-void trav_launch_checkpoints(TravGraph G, const TravContig *ctgs, const TravSeedReq *reqs, uint32_t n, uint64_t dev, uint32_t *out,
-                             hipStream_t s) {
-    if (n) k_checkpoints<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, reqs, n, dev, out);
-}
-void trav_launch_id_bounds(TravGraph G, const uint32_t *coords, uint32_t n, uint32_t *out, hipStream_t s) {
-    if (n) k_id_bounds<<<dim3((n + 63) / 64), dim3(64), 0, s>>>(G, coords, n, out);
-}
-void trav_launch_pack_paths(TravGraph G, const TravPackDesc *descs, uint32_t n, uint64_t max_len, uint32_t *out, hipStream_t s) {
-    if (!n) return;
-    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((max_len + 255) / 256, 1), 64);
-    k_pack_paths<<<dim3(gx, n), dim3(256), 0, s>>>(G, descs, n, out);
-}
-void trav_launch_gather_pc(TravGraph G, const uint32_t *seq_v, uint64_t len, uint32_t *out, hipStream_t s) {
-    if (len) k_gather_pc<<<dim3(grid_for(len)), dim3(256), 0, s>>>(G, seq_v, len, out);
-}
 void trav_launch_walk(TravGraph G, const TravContig *ctgs, const TravJob *jobs, TravJobOut *outs, uint32_t n, uint32_t k,
                       hipStream_t s) {
     if (n) k_walk<<<dim3(n), dim3(64), 0, s>>>(G, ctgs, jobs, outs, n, k);
@@ -3525,391 +1923,5 @@ void trav_launch_walk_persistent(TravGraph G, const TravPosted *jobs, TravJobOut
                                  uint32_t *next, uint32_t cap, uint32_t k, uint32_t n_waves, uint64_t idle_ticks, hipStream_t s) {
     k_walk_persistent<<<dim3(n_waves), dim3(64), 0, s>>>(G, jobs, outs, done, q, next, cap, k, idle_ticks);
 }
-void trav_launch_commit(const uint32_t *seq_v, uint64_t len, uint32_t in_lo, uint32_t in_hi, uint32_t *gbits, uint32_t *gset,
-                        uint32_t gmask, hipStream_t s) {
-    if (len) k_commit<<<dim3(grid_for(len)), dim3(256), 0, s>>>(seq_v, len, in_lo, in_hi, gbits, gset, gmask);
-}
-void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s) {
-    if (n) k_ranges<<<dim3((n + 63) / 64), dim3(64), 0, s>>>(G, ctgs, n);
-}
-
-// ---- a graph that holds a region of the block only (one rank of a sharded build) ----------------------------------
-// largest step of any edge (bounds how far a successor's coordinate can lie from its source's)
-__global__ void k_max_step(const uint32_t *__restrict__ estep, uint64_t n, uint32_t *__restrict__ out) {
-    uint32_t m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = (estep[i] & EDGE_STEP_MASK) > m ? (estep[i] & EDGE_STEP_MASK) : m;
-    m = wave_max_u32(m);
-    if (lane_id() == 0 && m) atomicMax(out, m);
-}
-// incomplete[u] for every vertex u (new ids; 0 .. n_zero: the coordinate-free ones, ordered by reference coordinate): its
-// REFERENCE coordinate lies within `margin` of an OPEN end of the reference band it is in (iv: sorted disjoint [lo, hi)
-// pairs; open[2 i], open[2 i + 1]: the graph goes on beyond that end, on another rank) — or in no band at all.  For a
-// coordinate-free vertex the latter cannot happen (it was selected by its band); a vertex WITH a contig coordinate was
-// selected by that coordinate whatever its reference coordinate is, and its coordinate-free successors (grade Skip,
-// checkPosition with pos2.first == 0: PABruijnGraph.cpp:143-165) live around its reference coordinate — outside the bands
-// they are on another rank.  A vertex without a reference coordinate has no successor that is found through one.
-__global__ void k_mark_incomplete(TravGraph G, uint32_t n_zero, const uint32_t *__restrict__ iv, const uint8_t *__restrict__ open, uint32_t n_iv,
-                                  uint32_t margin, uint32_t *__restrict__ bits) {
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool bad = false;
-    if (u < G.n_pos) bad = d_incomplete_by_position(iv, open, n_iv, margin, (uint32_t)G.upos[u], u >= n_zero);
-    const uint64_t m = __ballot(bad);
-    if ((threadIdx.x & 63u) == 0 && u < ((G.n_pos + 63ull) & ~63ull)) {
-        bits[u >> 5] = (uint32_t)m;
-        bits[(u >> 5) + 1] = (uint32_t)(m >> 32);
-    }
-}
-int trav_mark_incomplete(TravGraph &G, uint32_t n_zero, const uint32_t *iv_host, const uint8_t *open_host, uint32_t n_iv, uint32_t dev, double err,
-                         uint32_t *bits, void *tmp, hipStream_t s) {
-    // tmp: u32 max step | intervals | open flags
-    uint32_t *d_max = (uint32_t *)tmp;
-    uint32_t *d_iv = d_max + 64;
-    uint8_t *d_open = (uint8_t *)(d_iv + 2 * (size_t)n_iv + 2);
-    PAG_HIP_TRY(hipMemsetAsync(d_max, 0, 4, s));
-    if (G.n_edges) k_max_step<<<dim3(grid_for(G.n_edges)), dim3(256), 0, s>>>(G.estep, G.n_edges, d_max);
-    if (n_iv) {
-        PAG_HIP_TRY(hipMemcpyAsync(d_iv, iv_host, 2 * (size_t)n_iv * 4, hipMemcpyHostToDevice, s));
-        PAG_HIP_TRY(hipMemcpyAsync(d_open, open_host, 2 * (size_t)n_iv, hipMemcpyHostToDevice, s));
-    }
-    uint32_t max_step = 0;
-    PAG_HIP_TRY(hipMemcpyAsync(&max_step, d_max, 4, hipMemcpyDeviceToHost, s));
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-    // a successor's coordinate lies within step + deviation, or step x (1 + error rate), of its source's (checkPosition)
-    const uint64_t margin = (uint64_t)((double)max_step * (1.0 + err)) + dev + 2;
-    // the bit per new id is only read when the successor kernels cannot repeat the test themselves (more bands than they stage in
-    // LDS, or PAG_SUCC_INC_BITS=1); `incomplete` stays the flag that the graph holds a region
-    const bool bits_read = n_iv > INC_LDS_MAX || (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0);
-    if (G.n_pos && bits_read) k_mark_incomplete<<<dim3((unsigned)((G.n_pos + 255) / 256)), dim3(256), 0, s>>>(G, n_zero, d_iv, d_open, n_iv, (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu), bits);
-    PAG_HIP_TRY(hipGetLastError());
-    G.incomplete = bits;
-    G.inc_iv = d_iv;  // (the scratch slot lives as long as the traversal graph: the successor kernels repeat the test, d_incomplete_by_position)
-    G.inc_open = d_open;
-    G.inc_n = n_iv;
-    G.inc_margin = (uint32_t)std::min<uint64_t>(margin, 0x7FFFFFFFu);
-    return PAG_OK;
-}
-size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv) { return 256 + (2 * (size_t)n_iv + 2) * 4 + 2 * (size_t)n_iv + 64; }
-
-// coordinate order + successor records.  key/val/key2/val2: u32/u64 [n_pos] scratch pairs for the sort;
-// cnt: u32 [n_pos + 1]; *n_succ_out receives the number of successor records (call twice: first with
-// G.succ == nullptr to size it, then with the allocation)
-// where the sorted keys stop being zero (keys ascending; *n0 preset to 0, stays 0 when key[0] != 0)
-__global__ void k_zero_prefix(const uint32_t *__restrict__ key, uint64_t n, unsigned long long *__restrict__ n0) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        if (key[i] == 0u && (i + 1 == n || key[i + 1] != 0u)) *n0 = i + 1;
-}
-// sort keys of the vertices without a contig coordinate: their reference coordinate (the payload's upper half)
-__global__ void k_order_refkeys(const uint64_t *__restrict__ val, uint64_t n, uint32_t *__restrict__ key) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        key[i] = (uint32_t)(val[i] >> 32);
-}
-
-// New ids: [vertices without a contig coordinate, by reference coordinate] ++ [the others, by contig coordinate]; equal
-// keys keep the k-mer-major order (stable sorts).  The order inside the first group is not needed by the walks — it makes
-// neighbours on the reference neighbours in memory, and it lets a splice of two walks bound the vertices of that kind a
-// walk has examined by an id (k5_travel_host.hip, try_merge_leap).  *n_zero receives the size of the first group.
-int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,
-               int ref_bits, hipStream_t s) {
-    const uint64_t n = G.n_pos;
-    if (n_zero) *n_zero = 0;
-    if (!n) return PAG_OK;
-    k_order_keys<<<dim3(grid_for(n)), dim3(256), 0, s>>>(G.vpos, n, key, val);
-    int in0 = 1, rc;
-    if ((rc = sort_pairs(key, val, key2, val2, n, ctg_bits, sort_tmp, &in0, s, nullptr, nullptr))) return rc;
-    uint32_t *ks = in0 ? key : key2, *ko = in0 ? key2 : key;
-    uint64_t *vs = in0 ? val : val2, *vo = in0 ? val2 : val;
-    unsigned long long *d_n0 = (unsigned long long *)sort_tmp;  // (the sort is done with its scratch)
-    unsigned long long n0 = 0;
-    PAG_HIP_TRY(hipMemsetAsync(d_n0, 0, 8, s));
-    k_zero_prefix<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, n, d_n0);
-    PAG_HIP_TRY(hipMemcpyAsync(&n0, d_n0, 8, hipMemcpyDeviceToHost, s));
-    PAG_HIP_TRY(hipStreamSynchronize(s));
-    if (n0 > 1) {
-        k_order_refkeys<<<dim3(grid_for(n0)), dim3(256), 0, s>>>(vs, n0, ks);
-        int in0b = 1;
-        if ((rc = sort_pairs(ks, vs, ko, vo, n0, ref_bits, sort_tmp, &in0b, s, nullptr, nullptr))) return rc;
-        if (!in0b) PAG_HIP_TRY(hipMemcpyAsync(vs, vo, n0 * 8, hipMemcpyDeviceToDevice, s));
-    }
-    if (n_zero) *n_zero = n0;
-    {
-        // (eight slices once the two arrays — 6 bytes per vertex — outgrow the Infinity Cache: 16.2 -> 12.5 ms at configs[1],
-        // 13.2 with four or sixteen, tests/order_probe.sh; PAG_ORDER_SLICES=<2^n> overrides)
-        // (nodes numbered by place: newid[v] / vcnt[v] are touched nearly in order — nothing to slice)
-        uint32_t lg = n >= (32ull << 20) && !G.nperm ? 3u : 0u;
-        if (const char *e = std::getenv("PAG_ORDER_SLICES")) {
-            const uint32_t want = (uint32_t)std::max(1, std::atoi(e));
-            lg = 0;
-            while ((1u << (lg + 1)) <= want) ++lg;
-        }
-        uint32_t bits = 1;
-        while (bits < 32 && (n >> bits) != 0) ++bits;  // v < n < 2^bits
-        if (lg >= bits) lg = 0;
-        const uint32_t shift = lg ? bits - lg : 32u;
-        for (uint32_t sl = 0; sl < (1u << lg); ++sl)
-            k_order_apply<<<dim3(grid_for(n)), dim3(256), 0, s>>>(ks, vs, n, n0 > 1 ? n0 : 0, G, sl, shift);
-    }
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-// blockIdx.y = range; 16 bytes per lane and turn where the range allows (the job buffers are 256-byte aligned), bytes at its edges
-__global__ void k_clear_ranges(const TravClear *__restrict__ ranges) {
-    const TravClear c = ranges[blockIdx.y];
-    uint8_t *p = (uint8_t *)c.p;
-    const uint64_t head = (16u - ((uintptr_t)p & 15u)) & 15u, h = head < c.bytes ? head : c.bytes;
-    const uint64_t n16 = (c.bytes - h) >> 4, tail = (c.bytes - h) & 15u;
-    uint4 *q = (uint4 *)(p + h);
-    const uint4 w = make_uint4(c.word, c.word, c.word, c.word);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) q[i] = w;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < h) p[threadIdx.x] = (uint8_t)c.word;
-        if (threadIdx.x < tail) p[h + (n16 << 4) + threadIdx.x] = (uint8_t)c.word;
-    }
-}
-int trav_clear_ranges(const TravClear *ranges_dev, size_t n, hipStream_t s) {
-    for (size_t at = 0; at < n; at += 32768) {
-        const uint32_t m = (uint32_t)std::min<size_t>(32768, n - at);
-        k_clear_ranges<<<dim3(32, m), dim3(256), 0, s>>>(ranges_dev + at);
-    }
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-// pag_successors: one wave looks one vertex up in the coordinate order — the vertices without a contig coordinate come first,
-// by reference coordinate; the others by contig coordinate; equal keys in k-mer-major order (trav_order) — and hands its records
-// back in the caller's terms
-struct SuccOut {
-    uint32_t code, step;
-    uint64_t pos;
-    uint32_t grade, ctg_similar;
-};
-__global__ void k_successors_of(TravGraph G, uint32_t code, uint64_t pos, SuccOut *__restrict__ recs, uint64_t cap, unsigned long long *__restrict__ out) {
-    const uint32_t lane = threadIdx.x;
-    const bool zero = (pos >> 32) == 0;
-    const uint64_t lo0 = zero ? 0 : G.n_zero, hi0 = zero ? G.n_zero : G.n_pos;
-    const uint32_t want = zero ? (uint32_t)pos : (uint32_t)(pos >> 32);
-    uint64_t lo = lo0, hi = hi0;  // first u of the stretch whose key is >= want
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        const uint64_t p = G.upos[mid];
-        const uint32_t key = zero ? (uint32_t)p : (uint32_t)(p >> 32);
-        if (key < want) lo = mid + 1;
-        else hi = mid;
-    }
-    unsigned long long found = ~0ull;
-    for (uint64_t base = lo; base < hi0; base += 64) {
-        const uint64_t u = base + lane;
-        bool same_key = false, hit = false;
-        if (u < hi0) {
-            const uint64_t p = G.upos[u];
-            same_key = (zero ? (uint32_t)p : (uint32_t)(p >> 32)) == want;
-            hit = p == pos && G.ncode[G.vnode[G.uold[u]]] == code;
-        }
-        const unsigned long long hits = __ballot(hit);
-        if (hits) {
-            found = base + (unsigned long long)__builtin_ctzll(hits);
-            break;
-        }
-        if (__ballot(same_key) != ~0ull) break;  // (the run of this key ends inside these 64)
-    }
-    if (found == ~0ull) {
-        if (lane == 0) out[0] = ~0ull;
-        return;
-    }
-    const uint32_t a = G.succ_off[found], b = G.succ_off[found + 1];
-    bool marker = false;
-    for (uint32_t i = a + lane; i < b; i += 64) {
-        const SuccRec r = G.succ[i];
-        const uint32_t grade = (r.meta >> 24) & 7u;
-        if (grade >= GRADE_POISON_IF_LEAP) {
-            marker = true;
-        } else if ((uint64_t)(i - a) < cap) {
-            SuccOut o;
-            o.code = G.ncode[G.vnode[G.uold[r.tgt]]];
-            o.step = r.meta & 0xFFFFFFu;
-            o.pos = G.upos[r.tgt];
-            o.grade = grade;
-            o.ctg_similar = (r.meta >> 27) & 1u;
-            recs[i - a] = o;
-        }
-    }
-    const bool any_marker = __ballot(marker) != 0ull;
-    if (lane == 0) out[0] = any_marker ? ~1ull : (unsigned long long)(b - a);
-}
-int trav_successors_of(TravGraph G, uint32_t code, uint64_t pos, void *recs, uint64_t cap, unsigned long long *out, hipStream_t s) {
-    static_assert(sizeof(SuccOut) == sizeof(pag_succ), "pag_succ layout");
-    k_successors_of<<<dim3(1), dim3(64), 0, s>>>(G, code, pos, (SuccOut *)recs, cap, out);
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
-                    uint32_t heavy_limit, hipStream_t s) {
-    if (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0) G.inc_iv = nullptr;  // (the bit per new id gathered, as until round 5)
-    const uint64_t n = G.n_pos;
-    if (!n) return PAG_OK;
-    if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
-    if (heavy_list) PAG_HIP_TRY(hipMemsetAsync(heavy_n, 0, 8, s));
-    if (stage) k_succ<2><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, nullptr, nullptr, nullptr, 0u);
-    else {
-        k_succ<0><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
-        if (heavy_list) k_succ_heavy<0><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, cnt, amask, heavy_list, heavy_n);
-    }
-    PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
-    int rc;
-    if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
-    k_narrow<<<dim3(grid_for(n + 1)), dim3(256), 0, s>>>(scan_out, n + 1, G.succ_off);
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-// the fused way (k_succ_fused): counts, dense staging, offsets; then the scan of the counts into succ_off.  *cursor_dev ends at the
-// number of staged records (beyond `cap`: the staging array was too small, nothing usable was staged)
-int trav_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, uint64_t *stage_off,
-                    SuccRec *stage, uint64_t cap, unsigned long long *cursor_dev, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit,
-                    hipStream_t s) {
-    if (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0) G.inc_iv = nullptr;  // (the bit per new id gathered, as until round 5)
-    const uint64_t n = G.n_pos;
-    if (!n) return PAG_OK;
-    if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
-    PAG_HIP_TRY(hipMemsetAsync(cursor_dev, 0, 8, s));
-    if (heavy_n) PAG_HIP_TRY(hipMemsetAsync(heavy_n, 0, 8, s));
-    if (heavy_list && heavy_limit <= 64u)
-        k_succ_fused<false><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, cap, cursor_dev, heavy_list, heavy_n, heavy_limit);
-    else
-        k_succ_fused<true><<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, cap, cursor_dev, heavy_list, heavy_n, heavy_limit);
-    if (heavy_list) k_succ_heavy_fused<<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, cnt, stage_off, stage, cap, cursor_dev, heavy_list, heavy_n);
-    PAG_HIP_TRY(hipMemsetAsync(cnt + n, 0, 4, s));
-    int rc;
-    if ((rc = scan_u32_to_u64(cnt, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
-    k_narrow<<<dim3(grid_for(n + 1)), dim3(256), 0, s>>>(scan_out, n + 1, G.succ_off);
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s) {
-    const uint64_t n = G.n_pos;
-    if (!n) return PAG_OK;
-    k_succ_bound<<<dim3(grid_for(n)), dim3(256), 0, s>>>(G, ub);
-    PAG_HIP_TRY(hipMemsetAsync(ub + n, 0, 4, s));
-    int rc;
-    if ((rc = scan_u32_to_u64(ub, scan_out, n + 1, total_dev, scan_tmp, s))) return rc;
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
-                   uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s) {
-    if (std::getenv("PAG_SUCC_INC_BITS") && std::atoi(std::getenv("PAG_SUCC_INC_BITS")) != 0) G.inc_iv = nullptr;  // (the bit per new id gathered, as until round 5)
-    if (!G.n_pos) return PAG_OK;
-    if (heavy_limit == 0 || !heavy_n) heavy_list = nullptr;
-    if (stage) {
-        k_succ_place<<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, stage_off, stage);
-    } else {
-        // (PAG_SUCC_DEFER=0: the filling pass grades its records itself, as until round 5)
-        const bool defer = !(std::getenv("PAG_SUCC_DEFER") && std::atoi(std::getenv("PAG_SUCC_DEFER")) == 0);
-        const bool mask_only = heavy_list && heavy_limit <= 64u && amask;
-        if (mask_only && defer)
-            k_succ<4><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
-        else if (mask_only)
-            k_succ<3><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
-        else
-            k_succ<1><<<dim3(grid_for(G.n_pos)), dim3(256), 0, s>>>(G, dev, err, nullptr, nullptr, nullptr, amask, heavy_list, heavy_n, heavy_limit);
-        if (heavy_list) k_succ_heavy<1><<<dim3(4096), dim3(256), 0, s>>>(G, dev, err, nullptr, amask, heavy_list, heavy_n);
-        if (n_rec && mask_only && defer) k_succ_link<true><<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec, dev, err);
-        else if (n_rec) k_succ_link<false><<<dim3(grid_for(n_rec)), dim3(256), 0, s>>>(G, n_rec, dev, err);
-    }
-    PAG_HIP_TRY(hipGetLastError());
-    return PAG_OK;
-}
-void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
-                             hipStream_t s, unsigned max_blocks) {
-    const unsigned grid = max_blocks ? std::min(grid_for(len), max_blocks) : grid_for(len);
-    if (len) k_gather_path<<<dim3(grid), dim3(256), 0, s>>>(G, seq_v, seq_s, len, out);
-}
-// blockIdx.y = the part; the blocks of a row stride over its entries
-__global__ void __launch_bounds__(256) k_concat_parts(const TravConcatPart *__restrict__ parts, uint32_t *__restrict__ out_v,
-                                                      uint32_t *__restrict__ out_s, uint32_t first_step) {
-    const TravConcatPart P = parts[blockIdx.y];
-    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < P.n; x += (uint64_t)gridDim.x * blockDim.x) {
-        out_v[P.start + x] = P.v[x];
-        out_s[P.start + x] = (P.start + x == 0) ? first_step : P.s[x];
-    }
-}
-void trav_launch_concat_parts(const TravConcatPart *parts, uint32_t n_parts, uint32_t *out_v, uint32_t *out_s, uint32_t first_step,
-                              hipStream_t s) {
-    for (uint32_t at = 0; at < n_parts; at += 32768) {
-        const uint32_t n = std::min<uint32_t>(32768, n_parts - at);
-        k_concat_parts<<<dim3(16, n), dim3(256), 0, s>>>(parts + at, out_v, out_s, first_step);
-    }
-}
-void trav_launch_gather_vertices(TravGraph G, const uint32_t *vids, uint32_t n, pag_path_node *out, hipStream_t s) {
-    if (n) k_gather_vertices<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(G, vids, n, out);
-}
-
-// test hook: the device match predicates on caller-supplied rows (tests/test_gpu_predicates.py feeds the reference's
-// truth table tests/golden/func_predicate.txt.gz and a dense sweep around the 0.15 ratio boundary)
-__global__ void k_debug_predicates(const uint32_t *__restrict__ rows, uint64_t n, double err, uint8_t *__restrict__ grade,
-                                   uint8_t *__restrict__ edge_sim) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t *r = rows + 6 * i;  // a_ctg a_ref b_ctg b_ref dist dev
-    uint32_t es = 0;
-    grade[i] = (uint8_t)d_check_position(r[0], r[1], r[2], r[3], r[4], r[5], err, &es);
-    edge_sim[i] = (uint8_t)es;
-}
-// ... the way the successor kernels evaluate them: ratio tests through the LDS table (d_ratio_entry) where the step has an entry
-__global__ void k_debug_predicates_tab(const uint32_t *__restrict__ rows, uint64_t n, double err, uint8_t *__restrict__ grade,
-                                       uint8_t *__restrict__ edge_sim, unsigned long long *__restrict__ n_tab) {
-    __shared__ uint32_t ratio_tab[RATIO_TAB_N];
-    d_ratio_table_fill(ratio_tab, err);
-    __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t *r = rows + 6 * i;
-    uint32_t es = 0;
-    const uint32_t entry = r[4] < RATIO_TAB_N ? ratio_tab[r[4]] : RATIO_TAB_NONE;
-    if (entry != RATIO_TAB_NONE) atomicAdd(n_tab, 1ull);
-    grade[i] = (uint8_t)d_check_position_any(r[0], r[1], r[2], r[3], r[4], r[5], err, entry, &es);
-    edge_sim[i] = (uint8_t)es;
-}
 
 }  // namespace pagdev
-
-static int debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device, uint64_t *n_through_table);
-extern "C" int pag_debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device) {
-    return debug_predicates(rows, n, err, grade, edge_sim, device, nullptr);
-}
-// the same rows through the ratio table of the successor kernels; *n_through_table: how many rows had a table entry
-extern "C" int pag_debug_predicates_tab(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device,
-                                        uint64_t *n_through_table) {
-    if (!n_through_table) return PAG_EINVAL;
-    *n_through_table = 0;
-    return debug_predicates(rows, n, err, grade, edge_sim, device, n_through_table);
-}
-static int debug_predicates(const uint32_t *rows, uint64_t n, double err, uint8_t *grade, uint8_t *edge_sim, int device, uint64_t *n_through_table) {
-    using namespace pagdev;
-    if (!rows || !grade || !edge_sim) return PAG_EINVAL;
-    if (hipSetDevice(device) != hipSuccess) return PAG_ENODEV;
-    uint32_t *d_rows = nullptr;
-    uint8_t *d_out = nullptr;
-    if (n == 0) return PAG_OK;
-    PAG_HIP_TRY(hipMalloc((void **)&d_rows, n * 24));
-    if (hipMalloc((void **)&d_out, 2 * n + 16) != hipSuccess) {
-        hipFree(d_rows);
-        return PAG_ENOMEM;
-    }
-    unsigned long long *d_cnt = (unsigned long long *)(d_out + ((2 * n + 7) & ~(uint64_t)7));
-    hipError_t e = hipMemcpy(d_rows, rows, n * 24, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_cnt, 0, 8);
-    if (e == hipSuccess) {
-        if (n_through_table) k_debug_predicates_tab<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_rows, n, err, d_out, d_out + n, d_cnt);
-        else k_debug_predicates<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(d_rows, n, err, d_out, d_out + n);
-        e = hipDeviceSynchronize();
-    }
-    if (e == hipSuccess && n_through_table) e = hipMemcpy(n_through_table, d_cnt, 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(grade, d_out, n, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(edge_sim, d_out + n, n, hipMemcpyDeviceToHost);
-    hipFree(d_rows);
-    hipFree(d_out);
-    if (e != hipSuccess) {
-        set_error("pag_debug_predicates: %s", hipGetErrorString(e));
-        return PAG_EFAULT;
-    }
-    return PAG_OK;
-}

@@ -157,7 +157,7 @@ uint64_t pow2_at_least(uint64_t x) {
 // successor records of every vertex (searchSuccessors + checkPosition for all of them, PABruijnGraph.cpp:143-197) — built
 // once per graph and pair of (deviation, error rate), kept in the handle (g->tg).  Pool slots TRAV_SLOT0 .. + TRAV_GRAPH_SLOTS.
 constexpr int TRAV_GRAPH_SLOTS = 22;  // (+ 2 behind them for a regional graph's incomplete-vertex bitmap, + 2 for the view's scratch)
-constexpr int TRAV_EXTRA_SLOTS = 5;  // (incomplete-vertex bitmap + its scratch, the view's two, the node permutation)
+constexpr int TRAV_EXTRA_SLOTS = 4;  // (incomplete-vertex bitmap + its scratch, the two of the view)
 
 // ---- the view of ONE handle's traversals -----------------------------------------------------------------------------
 // A traversal of contig strand S (PAlgorithm::travelSequence for one (contig, orientation)) only ever examines
@@ -395,15 +395,8 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             return b;
         };
         const int ctg_bits = bits_of(ctg_len, n_ctgs), ref_bits = bits_of(ref_len, n_refs);
-        // the nodes numbered by place (trav_compact): the permutation stays with the graph (node_of_code)
-        DevBuf b_nperm(g, TRAV_SLOT0 + TRAV_GRAPH_SLOTS + 4);
-        G.nperm = nullptr;
-        if (cfg.nodes_by_place) {
-            if ((rc = b_nperm.alloc((nn + 1) * 4))) return rc;
-            G.nperm = b_nperm.as<uint32_t>();
-        }
         if ((rc = trav_compact(g->tkey, g->tval, g->tseg, g->tcnt, g->n_t, g->ekey, g->eval, g->eseg, g->n_e, k, nn, np, ne, G,
-                               b_ctmp.p, tb, s, prune ? &tv : nullptr, counts, cfg.nodes_by_place ? std::max(ctg_bits, ref_bits) : 0)))
+                               b_ctmp.p, tb, s, prune ? &tv : nullptr, counts)))
             return rc;
         if (prune) {
             G.n_nodes = counts[0];
@@ -435,84 +428,38 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             if ((rc = trav_mark_incomplete(G, G.n_zero, riv.data(), ropen.data(), n_iv, (uint32_t)deviation, errorRate, b_inc.as<uint32_t>(), b_inct.p, s)))
                 return rc;
         }
-        uint64_t n_succ = 0, n_cand = 0;
-        // One evaluation of the candidate pairs instead of two when memory allows: the records are first written to a
-        // staging array laid out by the candidate-pair bound (b_ok1 = bound per vertex, b_ov1 = its prefix,
-        // b_ov0[np + 1] = total), then moved to coordinate order.  Staging = 16 B per CANDIDATE (about twice the
-        // records); it reuses the compaction scratch slot.
-        const SuccRec *stage = nullptr;
-        const uint64_t *stage_off = nullptr;
-        // (only attempted for graphs small enough that it can fit: at sequencing coverage the candidates are ~10x the
-        // records, see DESIGN.md, and computing the bound is not free)
-        // PAG_SUCC_MODE=bound|twopass forces one of the two ways (tests compare their records); PAG_SUCC_TWO_PASS=1 is twopass
-        const std::string &mode = cfg.succ_mode;
-        if ((mode.empty() && np <= (64ull << 20)) || mode == "bound") {
-            if ((rc = trav_succ_bound(G, b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 1, s)))
-                return rc;
-            PAG_HIP_TRY(hipMemcpyAsync(&n_cand, b_ov0.as<uint64_t>() + np + 1, 8, hipMemcpyDeviceToHost, s));
-            PAG_HIP_TRY(hipStreamSynchronize(s));
-            size_t free_b = 0, total_b = 0;
-            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const size_t want = (n_cand + 1) * sizeof(SuccRec);
-            // the final array (<= the staging size) has to fit as well; keep a margin for the walk buffers
-            if (want <= b_ctmp.sl->cap || want < (free_b + b_ctmp.sl->cap) / 4) {
-                if (b_ctmp.alloc(want) == PAG_OK) {
-                    stage = b_ctmp.as<SuccRec>();
-                    stage_off = b_ov1.as<uint64_t>();
-                }
-            }
-        }
-        // PAG_SUCC_MODE=fused (round 5): one evaluation, the records staged densely by the waves' own allocation, then placed.
-        // The staging array is sized by a guess (6 records per vertex, within a quarter of what is free); a graph that needs
-        // more shows in the cursor and is done again by the two passes.
-        bool fused_done = false;
-        if (!stage && mode == "fused" && np) {
-            size_t free_b = 0, total_b = 0;
-            PAG_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const uint64_t cap = std::min<uint64_t>(6 * np + 1024, ((free_b + b_ctmp.sl->cap) / 4) / sizeof(SuccRec));
-            if (cap >= np && b_ctmp.alloc((cap + 1) * sizeof(SuccRec)) == PAG_OK) {
-                unsigned long long *cursor = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 4);
-                unsigned long long *hn = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 3);
-                if ((rc = trav_succ_fused(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p, b_ov0.as<uint64_t>() + np + 2,
-                                          b_ov1.as<uint64_t>(), b_ctmp.as<SuccRec>(), cap, cursor, b_ok1.as<uint32_t>(), hn, cfg.succ_heavy, s)))
+        // The successor records: one evaluation of the candidate pairs into an emission stream (12 bytes per slot, two arrays
+        // of `cap` slots that the sort ping-pongs between: the sort scratch of the coordinate order), sorted by source, finished
+        // into G.succ (k5_travel.hip, k_succ_emit).  The stream's size is not known before the evaluation: the handle remembers
+        // the records per vertex of its last graph; a stream that turns out too small is made again with what it asked for.
+        uint64_t n_succ = 0, n_slots = 0, n_heavy = 0;
+        const uint32_t *sk = nullptr;
+        const uint64_t *sv = nullptr;
+        {
+            const uint64_t nv = G.n_pos;
+            uint64_t cap = (uint64_t)((double)nv * g->succ_per_vertex * 1.05) + EMIT_SLACK_SLOTS;
+            if (cfg.debug_emit_cap) cap = cfg.debug_emit_cap;
+            DevBuf b_heavy = b_ctmp;  // (the compaction's scratch is free: the list of the vertices done by a wave each)
+            const size_t heavy_bytes = ((nv + 16) * 4 + 15) & ~(size_t)15;
+            if ((rc = b_heavy.alloc(heavy_bytes + 64))) return rc;
+            unsigned long long *counters = (unsigned long long *)((char *)b_heavy.p + heavy_bytes);  // (slots taken, records, heavy vertices)
+            for (int attempt = 0; attempt < 3; ++attempt) {
+                if ((rc = b_ok0.alloc((cap + 8) * 4)) || (rc = b_ov0.alloc((cap + 8) * 8)) || (rc = b_ok1.alloc((cap + 8) * 4)) || (rc = b_ov1.alloc((cap + 8) * 8)) ||
+                    (rc = b_otmp.alloc(sort_tmp_bytes(cap))))
                     return rc;
-                uint64_t h2[3] = {0, 0, 0};  // total of the counts, heavy vertices, cursor
-                PAG_HIP_TRY(hipMemcpyAsync(h2, b_ov0.as<uint64_t>() + np + 2, 24, hipMemcpyDeviceToHost, s));
-                PAG_HIP_TRY(hipStreamSynchronize(s));
-                if (h2[2] <= cap) {
-                    if (h2[2] != h2[0]) {
-                        set_error("trav_prepare_graph: %llu records staged, %llu counted", (unsigned long long)h2[2], (unsigned long long)h2[0]);
-                        return PAG_EFAULT;
-                    }
-                    n_succ = h2[0];
-                    if (n_succ >= 0xFFFFFFF0ull) {
-                        set_error("pag_travel: more than 2^32 successor records");
-                        return PAG_EINVAL;
-                    }
-                    if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
-                    G.succ = b_succ.as<SuccRec>();
-                    G.n_succ = n_succ;
-                    if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, b_ov1.as<uint64_t>(), b_ctmp.as<SuccRec>(), nullptr, nullptr, nullptr, 0u, s))) return rc;
-                    PAG_HIP_TRY(hipStreamSynchronize(s));
-                    fused_done = true;
-                    if (cfg.timing) std::fprintf(stderr, "[timing] successor records: fused (one evaluation, dense staging of %llu records, %llu heavy vertices)\n", (unsigned long long)h2[2], (unsigned long long)h2[1]);
-                } else if (cfg.timing) {
-                    std::fprintf(stderr, "[timing] successor records: the staging array of %llu records was too small (%llu needed): two passes\n", (unsigned long long)cap, (unsigned long long)h2[2]);
-                }
+                if ((rc = trav_succ_emit(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), cap,
+                                         b_otmp.p, counters, b_heavy.as<uint32_t>(), cfg.succ_heavy, &n_slots, &n_succ, &n_heavy, &sk, &sv, s)))
+                    return rc;
+                if (sk) break;
+                if (cfg.timing) std::fprintf(stderr, "[timing] successor records: a stream of %llu slots was too small (%llu taken): again\n", (unsigned long long)cap, (unsigned long long)n_slots);
+                cap = n_slots + n_slots / 64 + EMIT_SLACK_SLOTS;
             }
+            if (!sk) {
+                set_error("trav_prepare_graph: the emission stream of the successor records did not fit in three attempts");
+                return PAG_EFAULT;
+            }
+            if (nv) g->succ_per_vertex = (double)n_slots / (double)nv;
         }
-        // two passes: b_ov1 (free then) keeps, per vertex, which of its first 64 candidates the counting pass accepted
-        uint64_t *amask = stage ? nullptr : b_ov1.as<uint64_t>();
-        // (the vertices with many candidate pairs, done by a wave each: the list in b_ok1, free since the sort; its length behind the totals)
-        uint32_t *heavy_list = stage ? nullptr : b_ok1.as<uint32_t>();
-        unsigned long long *heavy_n = (unsigned long long *)(b_ov0.as<uint64_t>() + np + 3);
-        // b_ok0 doubles as the per-vertex count array, b_ov0 as the scan output, b_ov0[np + 2] as the total
-        if (!fused_done) {
-        if ((rc = trav_succ_count(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_otmp.p,
-                                  b_ov0.as<uint64_t>() + np + 2, stage_off, const_cast<SuccRec *>(stage), amask, heavy_list, heavy_n, cfg.succ_heavy, s)))
-            return rc;
-        PAG_HIP_TRY(hipMemcpyAsync(&n_succ, b_ov0.as<uint64_t>() + np + 2, 8, hipMemcpyDeviceToHost, s));
-        PAG_HIP_TRY(hipStreamSynchronize(s));
         if (n_succ >= 0xFFFFFFF0ull) {
             set_error("pag_travel: more than 2^32 successor records");
             return PAG_EINVAL;
@@ -520,23 +467,17 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         if ((rc = b_succ.alloc((n_succ + 1) * sizeof(SuccRec)))) return rc;
         G.succ = b_succ.as<SuccRec>();
         G.n_succ = n_succ;
-        if ((rc = trav_succ_fill(G, (uint32_t)deviation, errorRate, n_succ, stage_off, stage, amask, heavy_list, heavy_n, cfg.succ_heavy, s))) return rc;
+        if ((rc = trav_succ_finish(G, sk, sv, n_succ, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
-        }
         g->tg = G;
         g->tg_dev = deviation;
         g->tg_err = errorRate;
         g->tg_ready = true;
-        if (cfg.timing && heavy_list && cfg.succ_heavy && !fused_done) {
-            unsigned long long nh = 0;
-            hipMemcpy(&nh, heavy_n, 8, hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "[timing] successor records: %llu of %llu vertices have more than %u candidate pairs (a wave each)\n", nh, (unsigned long long)G.n_pos, cfg.succ_heavy);
-        }
         if (cfg.timing)
-            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%llu without a contig coordinate) of %llu (%s view: %llu of %llu nodes, %llu of %llu edges; %s, %llu candidate pairs)\n",
+            std::fprintf(stderr, "[timing] successor records %llu for %llu vertices (%llu without a contig coordinate) of %llu (%s view: %llu of %llu nodes, %llu of %llu edges); "
+                                 "emission stream %llu slots, %llu vertices with more than %u candidate pairs by a wave each\n",
                          (unsigned long long)n_succ, (unsigned long long)G.n_pos, (unsigned long long)g->n_zero_ctg, (unsigned long long)np, g->view_pruned ? "cut" : "whole", (unsigned long long)G.n_nodes,
-                         (unsigned long long)nn, (unsigned long long)G.n_edges, (unsigned long long)ne,
-                         fused_done ? "fused" : stage ? "staged by the candidate bound, one evaluation" : "two passes", (unsigned long long)n_cand);
+                         (unsigned long long)nn, (unsigned long long)G.n_edges, (unsigned long long)ne, (unsigned long long)n_slots, (unsigned long long)n_heavy, cfg.succ_heavy);
         t_compact = now_ms() - t0;
     }
 
@@ -655,7 +596,7 @@ struct WalkSession {
     uint32_t n_ctgs = 0, n_sel = 0;
     std::vector<CtgState> st;  // one entry per (contig, orientation) that is walked
     uint64_t nodes_total = 0;
-    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout, b_fetch, b_fdesc;
+    DevBuf b_packed, b_nodes, b_starts, b_sizes, b_tc, b_seedout, b_req, b_gset, b_gather, b_vids, b_gbits, b_ckreq, b_ckout;
     std::vector<TravContig> tc;
     static constexpr uint32_t SEED_STRIDE = 4096;
     void fill_contigs() {
@@ -769,8 +710,6 @@ struct WalkSession {
     // into its own buffers — a round's buffers come from the walk arena, which is never handed out twice within one
     // pag_travel; a round that had to fall back on the per-contig slots waits for its jobs as before (RoundState::slot_bufs).
     uint64_t n_orphans = 0;
-    bool orphaning = true;      // (PAG_WALK_ORPHANS=0: every round waits for all its jobs)
-    bool keep_segments = true;  // (PAG_WALK_KEEP_SEGMENTS=0: every round plans and walks its own)
     uint32_t n_posted[TRAV_RINGS] = {0, 0, 0}, n_live = 0, respeculated = 0;
     std::atomic<uint64_t> n_adopted{0}, n_merge_fail{0}, n_leap_adopted{0}, n_leap_refused[8];
     uint64_t n_seg_jobs = 0, n_resume_jobs = 0, n_leap_jobs = 0;
@@ -937,13 +876,11 @@ struct WalkSession {
                     if ((r = bufs[q]->alloc(need[q]))) return r;
             }
         }
-        if (!cfg.self_clear) {  // (PAG_WALK_SELFCLEAR=1: every job clears its own marks instead — measured slower, walk_config.hpp)
-            want_clear(b_sx.p, o_x[nj] * 8, 0u);
-            want_clear(b_ts.p, o_oc[nj] * 8, 0xFFu);
-            want_clear(b_ps.p, o_oc[nj] * PG * 8, 0u);
-            want_clear(b_st.p, o_st[nj] * 4, 0u);
-            want_clear(b_tb.p, o_tb[nj] * 4, 0u);
-        }
+        want_clear(b_sx.p, o_x[nj] * 8, 0u);
+        want_clear(b_ts.p, o_oc[nj] * 8, 0xFFu);
+        want_clear(b_ps.p, o_oc[nj] * PG * 8, 0u);
+        want_clear(b_st.p, o_st[nj] * 4, 0u);
+        want_clear(b_tb.p, o_tb[nj] * 4, 0u);
         fill_contigs();
         for (size_t j = 0; j < nj; ++j) {
             const JobPlan &pl = plans[j];
@@ -972,7 +909,6 @@ struct WalkSession {
             J.stop_pc = pl.stop_pc;
             J.init_len = 0;
             J.win_low = pl.win_low;
-            J.self_clear = cfg.self_clear ? 1u : 0u;
             J.seq_x = (pl.mode & TRAV_MODE_LEAP) ? b_sx.as<uint64_t>() + o_x[j] : nullptr;
             if (pl.mode & TRAV_MODE_RESUME) {
                 const uint64_t n0 = pl.init->len;
@@ -1108,12 +1044,7 @@ struct WalkSession {
                 const uint64_t margin = cfg.seg_safety_set ? cfg.seg_safety : cs.len / 400 + 200;
                 if (split > H + seg_len) {
                     const uint64_t zone = std::min<uint64_t>((uint64_t)x0 + (split - H) + margin, (uint64_t)cs.ctgRight - 1);
-                    // (the last stretch before the zone in shorter segments, cfg.seg_tail_frac of the way: the jobs that enter the
-                    // ring last are the ones that run while the grid empties — a job's length is how ragged the end of the first
-                    // rounds is)
-                    const uint64_t tail_from = cfg.seg_tail_frac > 0 ? zone - (uint64_t)((double)(zone - x0) * cfg.seg_tail_frac) : zone;
-                    const uint64_t short_len = std::max<uint64_t>(seg_len / 2, seg_ov * 2);
-                    for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += (x >= tail_from ? short_len : seg_len)) ck_x.push_back((uint32_t)x);
+                    for (uint64_t x = (uint64_t)x0 + seg_len; x + seg_ov + seg_len / 4 < zone; x += seg_len) ck_x.push_back((uint32_t)x);
                     if (!ck_x.empty()) R.zone_end = (uint32_t)zone;
                 }
                 n_spec_ck = ck_x.size();
@@ -1122,16 +1053,15 @@ struct WalkSession {
                     // leap (the steps follow the coordinate closely, not exactly: a margin; every adoption is checked with the true
                     // size) to the end of the strand
                     // (a walk there makes three times the classifications per vertex: shorter pieces for the same job length)
-                    const uint64_t leap_len_env = cfg.leap_seg_len;
-                    const uint64_t lseg = leap_len_env ? leap_len_env : std::max<uint64_t>(seg_len / 2, seg_ov * 2);
+                    const uint64_t lseg = std::max<uint64_t>(seg_len / 2, seg_ov * 2);
                     // (how far before x0 + split - H the first piece starts: at configs[1] the steps of a path add up to 0.6 % more than
                     // the coordinates it covers — leaping begins ~7 kb earlier than the coordinate says on a 1.2 Mb contig; pieces
                     // started too early cost a few jobs, pieces started too late an exact walk on the contig's critical path)
-                    const uint64_t left = cfg.leap_left_set ? cfg.leap_left : cfg.seg_safety_set ? cfg.seg_safety : cs.len / 64 + 500;
+                    const uint64_t left = cfg.seg_safety_set ? cfg.seg_safety : cs.len / 64 + 500;
                     const uint64_t first = (uint64_t)x0 + (split > H + left + lseg ? split - H - left : lseg);
                     // (the last stretch of the strand in shorter pieces still: the job that reaches the end of the strand is the
                     // last one of its round, and a contig that needs a second round waits for it twice)
-                    const uint64_t end_div = cfg.leap_end_div;
+                    const uint64_t end_div = 2;
                     const uint64_t end_zone = (uint64_t)cs.ctgRight > 2 * lseg ? (uint64_t)cs.ctgRight - 2 * lseg : 0;
                     for (uint64_t x = std::max<uint64_t>(first, (uint64_t)x0 + lseg); x + lseg / 4 / end_div < (uint64_t)cs.ctgRight - 1; x += (x >= end_zone ? std::max<uint64_t>(lseg / end_div, seg_ov) : lseg))
                         if (ck_x.size() == n_spec_ck || x > (uint64_t)ck_x.back() + lseg / 4 / end_div) ck_x.push_back((uint32_t)x);
@@ -1273,14 +1203,13 @@ struct WalkSession {
                 plans.push_back(pl);
             }
             // (the segments of the leaping zone first: they are the slowest, three times the classifications per vertex)
-            const bool leap_first = cfg.leap_first;
             // ... and of those the piece that runs to the end of the strand FIRST: it walks on from there until it leaps (at
             // configs[1] ~5 000 vertices and 20 000 classifications where the other pieces have 1 700 and 6 000: 55-70 ms, the
             // longest job of its contig by far and the one its round waits for; tests/walk_trace.py showed a fifth of them
             // starting 12-14 ms into the walks)
             std::vector<size_t> seg_order;
             for (size_t q = R.segs.size(); q-- > 0;)
-                if (R.segs[q].leap && R.segs[q].stop == 0u && cfg.last_piece_first) {
+                if (R.segs[q].leap && R.segs[q].stop == 0u) {
                     seg_order.push_back(q);
                     break;
                 }
@@ -1288,7 +1217,7 @@ struct WalkSession {
                 if (seg_order.empty() || q != seg_order[0]) seg_order.push_back(q);
             for (int pass = 0; pass < 2 && !P.kept; ++pass)  // (kept segments have their jobs, or their paths, already)
                 for (size_t q : seg_order) {
-                    if (R.segs[q].leap != ((pass == 0) == leap_first)) continue;
+                    if (R.segs[q].leap != (pass == 0)) continue;
                     const uint64_t spanc = (R.segs[q].stop ? (uint64_t)R.segs[q].stop : (uint64_t)cs.ctgRight) - R.segs[q].x;
                     const uint64_t cap = std::min<uint64_t>(cap_full, spanc / 2 + 8192);
                     JobPlan pl{1, (int)q, cap, R.segs[q].vid, (uint32_t)(R.segs[q].leap ? TRAV_MODE_LEAP : TRAV_MODE_SPEC), R.segs[q].stop, nullptr, false, R.segs[q].win_lo, R.segs[q].win_hi};
@@ -1386,10 +1315,12 @@ struct WalkSession {
     // its vertices are gathered on the device and copied (asynchronously, stream s) into pinned memory that lives until the
     // next call — at configs[1] the one gather + 380 MB copy for all contigs used to follow the last walk (15 ms).
     // Device buffers from the walk arena; without room there the contig is left to the epilogue.
+    // (a delivery issued while walk jobs are live runs on 24 blocks: its thousands of waves, each with stores to host memory in
+    // flight, slowed every walker wave beside them — 2.5 -> 3.2-5 us per classification in the last 40 ms of a block, round 5)
+    static constexpr unsigned DELIVER_BLOCKS = 24;
     int deliver_contig(uint32_t i) {
         CtgState &cs = st[i];
-        const bool early = cfg.deliver_early;
-        if (cs.delivered || !cs.done || !early) return PAG_OK;
+        if (cs.delivered || !cs.done) return PAG_OK;
         if (cs.tail.on) {  // (a path that ends in a leap: finalLeap, nothing but the last vertex to filter)
             const CtgState::DevTail &T = cs.tail;
             const size_t m0 = T.m0, m = m0 + T.n - (pumped(cs, T.last_ctg) ? 1 : 0);
@@ -1411,7 +1342,7 @@ struct WalkSession {
                 PAG_HIP_TRY(hipMemcpyAsync(T.d_ids, hp, m0 * 4, hipMemcpyHostToDevice, g->deliver_stream));
                 PAG_HIP_TRY(hipMemcpyAsync(T.d_ids + T.cap, hp + m0, m0 * 4, hipMemcpyHostToDevice, g->deliver_stream));
             }
-            trav_launch_gather_path(G, T.d_ids, T.d_ids + T.cap, m, dst, g->deliver_stream, n_live ? cfg.deliver_blocks : 0u);
+            trav_launch_gather_path(G, T.d_ids, T.d_ids + T.cap, m, dst, g->deliver_stream, n_live ? DELIVER_BLOCKS : 0u);
             g->path_ptr[slot2] = dst;
             return PAG_OK;
         }
@@ -1440,7 +1371,7 @@ struct WalkSession {
         // occupy the copy engine the fetches need (measured: their lap 9 -> 24 ms per step).
         if (!g->deliver_stream) PAG_HIP_TRY(hipStreamCreateWithFlags(&g->deliver_stream, hipStreamNonBlocking));
         PAG_HIP_TRY(hipMemcpyAsync(d_ids, hp, m * 8, hipMemcpyHostToDevice, g->deliver_stream));
-        trav_launch_gather_path(G, d_ids, d_ids + m, m, dst, g->deliver_stream, n_live ? cfg.deliver_blocks : 0u);
+        trav_launch_gather_path(G, d_ids, d_ids + m, m, dst, g->deliver_stream, n_live ? DELIVER_BLOCKS : 0u);
         g->path_ptr[slot2] = dst;
         return PAG_OK;
     }
@@ -1614,7 +1545,7 @@ struct WalkSession {
         if (g->cpool.size() < (size_t)n_sel * GROUPS * CB_N) g->cpool.resize((size_t)n_sel * GROUPS * CB_N);
         {
             const uint64_t sl = std::max<uint64_t>(128, cfg.seg_len ? cfg.seg_len : 12000);
-            const uint64_t ll = std::max<uint64_t>(128, cfg.leap_seg_len ? cfg.leap_seg_len : sl / 2);
+            const uint64_t ll = std::max<uint64_t>(128, sl / 2);
             uint64_t est = 0;
             for (uint32_t i = 0; i < n_sel; ++i) est += (uint64_t)st[i].len / sl + (uint64_t)st[i].len / ll + 32;  // (every strand as if all of it were both zones)
             while (QCAP < 2 * est && QCAP < (1u << 24)) QCAP *= 2;
@@ -1645,8 +1576,6 @@ struct WalkSession {
         RS.clear();
         RS.resize(n_sel);
         jref.assign(NR * (size_t)QCAP, JobRef{});
-        orphaning = cfg.orphaning;
-        keep_segments = orphaning && cfg.keep_segments;
         for (auto &x : n_leap_refused) x = 0;
         use_leap_pieces = cfg.leap_pieces;
         deferred.clear();
@@ -1704,8 +1633,8 @@ struct WalkSession {
             // segments first).  Posted contig by contig, the last contigs of the list finish their first round when the grid
             // runs empty — and those of them that need a second round (a re-seed after a walk that ended early) start it then:
             // every contig's first round now ends at about the same time, earlier than the last ones did.
-            const uint32_t interleave = cfg.post_interleave;
-            defer_ring2 = interleave != 0;
+            const uint32_t interleave = 16;  // (the share of the contig with the fewest jobs)
+            defer_ring2 = true;
             {
                 std::vector<uint32_t> first_rounds;
                 for (uint32_t i : order)
@@ -1714,41 +1643,30 @@ struct WalkSession {
             }
             lap("first rounds planned");
             defer_ring2 = false;
-            if (interleave) {
+            {
                 std::vector<size_t> at(n_sel, 0);
                 // a contig's share of a turn (round 5): in proportion to the jobs it has, so that every contig's first round runs
                 // out of the ring in the same turn.  With equal shares the contigs with the most segments — the longest ones, whose
                 // chains also take the longest to stitch — saw their last segments START when the grid was already running empty
                 // (configs[1]: at 58 of 105 ms), and the ones among them that need a second round started it last of all.
                 std::vector<uint32_t> share(n_sel, interleave);
-                if (cfg.post_proportional) {
+                {
                     size_t least = 0;
                     for (uint32_t i : order)
                         if (!deferred[i].empty() && (least == 0 || deferred[i].size() < least)) least = deferred[i].size();
                     const size_t turns = least ? (least + interleave - 1) / interleave : 1;
-                    // (post_spread < 1: the longest contig is through at that fraction of the turns, the others later in the
-                    // order of their length — the control thread stitches the chains of 49 contigs one after the other, and
-                    // the longest chains first)
-                    size_t rank = 0, n_with = 0;
-                    for (uint32_t i : order) n_with += deferred[i].empty() ? 0 : 1;
-                    for (uint32_t i : order) {
-                        if (deferred[i].empty()) continue;
-                        const double frac = cfg.post_spread + (1.0 - cfg.post_spread) * (n_with > 1 ? (double)rank / (double)(n_with - 1) : 1.0);
-                        const double t = std::max(1.0, (double)turns * frac);
-                        share[i] = (uint32_t)std::max<double>(1.0, std::ceil((double)deferred[i].size() / t));
-                        ++rank;
-                    }
+                    for (uint32_t i : order)
+                        if (!deferred[i].empty()) share[i] = (uint32_t)std::max<double>(1.0, std::ceil((double)deferred[i].size() / (double)turns));
                 }
                 // (a turn of its own for the contigs' longest jobs — the piece that runs to the end of the strand, first in every
                 // contig's list: they all start with the first wave of the grid)
-                if (cfg.last_piece_first)
-                    for (uint32_t i : order) {
-                        auto &dq = deferred[i];
-                        if (at[i] < dq.size() && (dq[0].P.J.mode & TRAV_MODE_LEAP) && dq[0].P.J.stop_pc == 0u) {
-                            if ((rc = commit_job(2u, dq[0].P, dq[0].jr, dq[0].P.J.mode, dq[0].P.J.stop_pc))) return fail(rc);
-                            at[i] = 1;
-                        }
+                for (uint32_t i : order) {
+                    auto &dq = deferred[i];
+                    if (at[i] < dq.size() && (dq[0].P.J.mode & TRAV_MODE_LEAP) && dq[0].P.J.stop_pc == 0u) {
+                        if ((rc = commit_job(2u, dq[0].P, dq[0].jr, dq[0].P.J.mode, dq[0].P.J.stop_pc))) return fail(rc);
+                        at[i] = 1;
                     }
+                }
                 for (bool more = true; more;) {
                     more = false;
                     for (uint32_t i : order) {
@@ -1843,7 +1761,6 @@ struct WalkSession {
         const uint32_t *agg = nullptr, *xagg = nullptr;  // block tables of those arrays (walk_stitch.hpp; written by k_pack_paths)
     };
     int fetch_paths(const std::vector<uint32_t> &fin, std::vector<Got> &got) {
-        int rc;
         static_assert(AGG_BLOCK == 64 && AGG_WORDS == 5 && AGG_XWORDS == 2, "k_pack_paths writes these tables");
         got.assign(fin.size(), Got{});
         {
@@ -1869,21 +1786,12 @@ struct WalkSession {
             // the pack kernel reads its descriptors from, and writes the packed paths to, the pinned host memory directly: one
             // launch + one synchronisation per batch instead of copy + launch + copy + synchronisation (every call of this
             // thread is on the critical path of some chain)
-            const bool direct = cfg.fetch_direct;
-            if (direct) {
-                trav_launch_pack_paths(G, hd, (uint32_t)descs.size(), max_len, hp, s);
-            } else {
-                if ((rc = b_fetch.alloc(tot * 4 + 64)) || (rc = b_fdesc.alloc(descs.size() * sizeof(TravPackDesc)))) return fail(rc);
-                hipMemcpyAsync(b_fdesc.p, hd, descs.size() * sizeof(TravPackDesc), hipMemcpyHostToDevice, s);
-                trav_launch_pack_paths(G, b_fdesc.as<TravPackDesc>(), (uint32_t)descs.size(), max_len, b_fetch.as<uint32_t>(), s);
-                if (tot) hipMemcpyAsync(hp, b_fetch.p, tot * 4, hipMemcpyDeviceToHost, s);
-            }
+            trav_launch_pack_paths(G, hd, (uint32_t)descs.size(), max_len, hp, s);
             if (hipStreamSynchronize(s) != hipSuccess) {
                 set_error("pag_travel: stream failure while fetching paths");
                 return fail(PAG_EFAULT);
             }
             const bool check_aggs = cfg.check_aggs;
-            const bool use_aggs = cfg.fetch_tables;  // (PAG_FETCH_TABLES=0: every entry is read, for comparisons)
             for (Got &G2 : got) {
                 G2.v = hp + G2.off;
                 G2.s = G2.v + G2.len;
@@ -1908,7 +1816,6 @@ struct WalkSession {
                         return fail(PAG_EFAULT);
                     }
                 }
-                if (!use_aggs) G2.agg = G2.xagg = nullptr;
             }
         }
         lap("fetch");
@@ -2118,7 +2025,7 @@ struct WalkSession {
             for (auto &ch : R.chains) all = all && ch.final;
             // (segment jobs still waiting or walking stay with the contig or become orphans — unless the round's buffers are
             // per-contig slots, which the next round takes over: such a round waits for them)
-            if (all && (R.live_jobs == 0 || (orphaning && !R.slot_bufs)) && std::find(over_queue.begin(), over_queue.end(), i) == over_queue.end())
+            if (all && (R.live_jobs == 0 || !R.slot_bufs) && std::find(over_queue.begin(), over_queue.end(), i) == over_queue.end())
                 over_queue.push_back(i);
         }
         {
@@ -2129,7 +2036,7 @@ struct WalkSession {
                 }
                 return false;
             };
-            const size_t take = n_live && cfg.pace ? std::min<size_t>(over_queue.size(), cfg.pace) : over_queue.size();
+            const size_t take = over_queue.size();
             std::stable_partition(over_queue.begin(), over_queue.end(), [&](uint32_t i) { return !leaps(i); });
             batch.assign(over_queue.begin(), over_queue.begin() + (long)take);
             over_queue.erase(over_queue.begin(), over_queue.begin() + (long)take);
@@ -2220,7 +2127,7 @@ struct WalkSession {
                 }
                 if (!base.empty()) dist = (int32_t)(head_ctg - base.back().ctg);
                 const size_t at0 = base.size();
-                if (P.leap && cfg.device_tail && cfg.deliver_early && !RS[i].slot_bufs && g->walk_arena) {
+                if (P.leap && !RS[i].slot_bufs && g->walk_arena) {
                     // the contig is finished by this walk (splice below): nothing of it is needed on the host
                     bool on_dev = true;
                     for (const Chain::Part &pt : ch.parts) on_dev = on_dev && pt.dv && pt.ds;
@@ -2275,14 +2182,9 @@ struct WalkSession {
                         }
                     }
                 };
-                // (measured at configs[1] on the GPU box, 16-CPU quota, the previous block's host half running beside: 430 ms per block with
-                // one thread, 436 with six — the copy is no longer what the round waits for; PAG_TAKE_THREADS for hosts with CPUs to spare)
-                const unsigned cap = cfg.take_threads;
-                const unsigned nthr = (unsigned)std::min<size_t>(chunks.size(), std::max(1u, std::min(cap, std::thread::hardware_concurrency())));
-                std::vector<std::thread> pool;
-                for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+                // (one thread: measured at configs[1] on the GPU box, 16-CPU quota, the previous block's host half running beside — 430 ms
+                // per block with one thread, 436 with six; the copy is not what the round waits for)
                 worker();
-                for (auto &t : pool) t.join();
             }
             for (CopyChunk &C : chunks)  // (in the order of the path)
                 if (!C.outside.empty()) st[C.i].outsideU.insert(st[C.i].outsideU.end(), C.outside.begin(), C.outside.end());
@@ -2396,7 +2298,7 @@ struct WalkSession {
         // or walking included): the next round's chains adopt them under the conditions of walk_stitch.hpp, which count the
         // marks committed since (Seg::round, MergeCtx::g_*).  A finished contig gives them up.
         for (uint32_t i : batch) {
-            if (st[i].done || !keep_segments) give_up_segments(i);
+            if (st[i].done) give_up_segments(i);
             else RS[i].kept = !RS[i].segs.empty();
         }
         lap("splice");
@@ -2497,7 +2399,6 @@ struct WalkSession {
     }
     int event_loop() {
         int rc;
-        b_fetch = buf(), b_fdesc = buf();
         t_progress = now_ms();
         t_first_fin = 0;
         t_last_news = now_ms();

@@ -410,12 +410,11 @@ int extract_stage(pag_graph *g, const pag_build_input *in, uint64_t emit_lo, uin
         a.job_tuples = b_jt.as<uint32_t>();
         a.job_base = (uint32_t)(pass * 2ull * n_reads);
     }
-    // the order pass 0's jobs run in (PAG_EXTRACT_ORDER=0: the emission order)
+    // the order pass 0's jobs run in
     DevBuf b_pk0(g, 39), b_pv0(g, 40), b_pk1(g, 41), b_pv1(g, 42), b_ptmp(g, 23), b_perm(g, 24);
     {
-        const char *e = std::getenv("PAG_EXTRACT_ORDER");
         const uint64_t nj0 = 2ull * n_reads;
-        if (nj0 >= 4096 && !(e && std::atoi(e) == 0)) {
+        if (nj0 >= 4096) {
             if ((rc = b_pk0.alloc(nj0 * 4)) || (rc = b_pv0.alloc(nj0 * 8)) || (rc = b_pk1.alloc(nj0 * 4)) || (rc = b_pv1.alloc(nj0 * 8)) ||
                 (rc = b_ptmp.alloc(sort_tmp_bytes(nj0))) || (rc = b_perm.alloc(nj0 * 4)))
                 return rc;

@@ -74,6 +74,7 @@ struct pag_graph {
     std::vector<int32_t> view_orient;
     uint64_t view_counts[3] = {0, 0, 0};  // nodes, vertices, edges of the view
     uint64_t view_fallbacks = 0;          // (since the handle was created)
+    double succ_per_vertex = 3.0;  // emission-stream slots per vertex of the last traversal graph: sizes the stream of the next (trav_prepare_graph)
     uint64_t n_zero_ctg = 0;  // new ids below it: vertices without a contig coordinate, in reference-coordinate order
     // pinned host staging area of the traversal (packed job results, uploads)
     void *pin_host = nullptr;

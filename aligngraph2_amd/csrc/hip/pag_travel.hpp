@@ -10,10 +10,8 @@ namespace pagdev {
 // probe slots of a walker wave (lane groups); sizes the per-job stamp arrays, outside sets and arena shares
 constexpr int TRAV_PROBE_GROUPS = 8;
 
-// compact CSR of the finished graph, dense ids: node = k-mer with >= 1 vertex — numbered BY PLACE (round 5, trav_compact: by the
-// reference coordinate of the node's first vertex that has one, so that a k-mer's children, the k-mers that follow it in the
-// reads, are its neighbours in every node-major array), or by ascending code (nperm == null) —,
-// vertex = clustered position (node-major, inside a node ascending (ctg, ref))
+// compact CSR of the finished graph, dense ids: node = k-mer with >= 1 vertex, by ascending code; vertex = clustered position
+// (node-major, inside a node ascending (ctg, ref))
 struct TravGraph {
     uint64_t n_nodes, n_pos, n_edges;
     uint32_t *ncode;      // [n_nodes]
@@ -26,7 +24,6 @@ struct TravGraph {
     uint32_t *estep;      // [n_edges] step | min(number of the child's positions, 255) << 24 (k5_travel.hip edge_target)
     uint64_t *bitmap;     // 4^k bits: k-mer code owns a node
     uint32_t *rank;       // per 64-bit bitmap word: nodes before it
-    uint32_t *nperm;      // [n_nodes] number of the node among the nodes in code order -> node id (null: the ids ARE in code order)
     // coordinate order ("new ids" u): [ctg == 0 vertices] ++ [ctg != 0 ascending]
     uint32_t *uold;       // [n_pos] new id -> vertex id
     uint32_t *newid;      // [n_pos] vertex id -> new id
@@ -109,7 +106,7 @@ struct TravJob {
     uint32_t stop_pc;
     uint64_t init_len;
     uint32_t win_low;   // TRAV_MODE_LEAP: lower end forced on the travel coordinate window
-    uint32_t self_clear;  // 1: the job clears its own stamp / tbits / tset / pset / seq_x arrays before it begins (job_self_clear, k5_travel.hip)
+    uint32_t pad0;
     // TRAV_MODE_LEAP: [seq_cap] zeroed; entry i != 0 <=> seq_v[i] is the last vertex of a chosen path, i.e. graphTravel
     // classified it at the top level (an iteration boundary).  Entry = 1 << 63 | elow << 32 | m0 about the iteration that
     // STARTS there: elow = lowest contig coordinate (31 bits, saturated) of any successor record that follows the contig
@@ -183,7 +180,7 @@ struct TravView {
 int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tseg, const uint16_t *tcnt, uint64_t T,
                  const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
                  uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view = nullptr,
-                 uint64_t *counts_out = nullptr, int place_bits = 0);
+                 uint64_t *counts_out = nullptr);
 int trav_zone_bands(const uint64_t *tval, uint64_t T, const uint32_t *zones_dev, uint32_t n_z, uint32_t *lo_dev, uint32_t *hi_dev, hipStream_t s);
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes);
 struct TravCtgNodesJob {  // one contig strand of a k_ctg_nodes launch
@@ -218,8 +215,6 @@ size_t trav_mark_incomplete_tmp_bytes(uint32_t n_iv);
 
 int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64_t *val2, void *sort_tmp, uint64_t *n_zero, int ctg_bits,
                int ref_bits, hipStream_t s);
-// successor records, either two passes (count, scan, fill + link) or, with a staging array sized by the candidate-pair
-// bound (trav_succ_bound), one evaluation pass (stage != nullptr) followed by a placement pass
 // device ranges cleared by one launch (the buffers of the walk jobs of a batch): `bytes` bytes at p set to the bytes of `word`
 struct TravClear {
     void *p;
@@ -230,17 +225,16 @@ int trav_clear_ranges(const TravClear *ranges_dev, size_t n, hipStream_t s);
 // the records of ONE vertex named by (code, position), translated back to (code, position) of their targets (pag_successors):
 // out[0] = number of records or ~0 (no such vertex) / ~1 (its list is a marker), written to recs (32 bytes each) up to cap
 int trav_successors_of(TravGraph G, uint32_t code, uint64_t pos, void *recs, uint64_t cap, unsigned long long *out, hipStream_t s);
-int trav_succ_bound(TravGraph G, uint32_t *ub, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, hipStream_t s);
-// (heavy_list [n_pos] / heavy_n: the two-pass path hands the vertices with more than heavy_limit candidate pairs to a wave each;
-// the counting pass fills the list, the filling pass reads it.  heavy_limit 0 or null pointers: every vertex by its own thread)
-int trav_succ_count(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev,
-                    const uint64_t *stage_off, SuccRec *stage, uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n,
-                    uint32_t heavy_limit, hipStream_t s);
-int trav_succ_fused(TravGraph G, uint32_t dev, double err, uint32_t *cnt, uint64_t *scan_out, void *scan_tmp, uint64_t *total_dev, uint64_t *stage_off,
-                    SuccRec *stage, uint64_t cap, unsigned long long *cursor_dev, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit,
-                    hipStream_t s);
-int trav_succ_fill(TravGraph G, uint32_t dev, double err, uint64_t n_rec, const uint64_t *stage_off, const SuccRec *stage,
-                   uint64_t *amask, uint32_t *heavy_list, unsigned long long *heavy_n, uint32_t heavy_limit, hipStream_t s);
+// geometry of the emission stream (k5_travel.hip, k_succ_emit): slots a wave takes at a time, and how many waves can hold a
+// partly used chunk at the end (both launches) — the slack of the stream
+constexpr uint32_t EMIT_CHUNK_SLOTS = 2048u, EMIT_GRID_THREADS = 2048u, EMIT_GRID_WAVES = 1024u;
+constexpr uint64_t EMIT_SLACK_SLOTS = (uint64_t)(EMIT_GRID_THREADS + EMIT_GRID_WAVES) * 4u * EMIT_CHUNK_SLOTS;
+// the successor records of every vertex (k5_travel.hip, k_succ_emit): one evaluation of the candidate pairs into an emission
+// stream sorted by source, then the records a walk reads
+int trav_succ_emit(TravGraph G, uint32_t dev, double err, uint32_t *key0, uint64_t *val0, uint32_t *key1, uint64_t *val1, uint64_t cap, void *sort_tmp,
+                   unsigned long long *counters, uint32_t *heavy_list, uint32_t heavy_limit, uint64_t *n_slots, uint64_t *n_rec, uint64_t *n_heavy,
+                   const uint32_t **sorted_key, const uint64_t **sorted_val, hipStream_t s);
+int trav_succ_finish(TravGraph G, const uint32_t *key, const uint64_t *val, uint64_t n_rec, hipStream_t s);
 // (max_blocks: 0 = as many as the path has work for; a delivery that runs beside the walks of other contigs is kept small)
 void trav_launch_gather_path(TravGraph G, const uint32_t *seq_v, const uint32_t *seq_s, uint64_t len, pag_path_node *out,
                              hipStream_t s, unsigned max_blocks = 0);

@@ -674,7 +674,7 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
     int rc;
     // PAG_SHARD_TIMING=1: one line per rank and block on stderr — seconds per stage of this call (the device idle at every
     // boundary) and the payload that left the rank in each of the two bulk exchanges
-    const bool timing = std::getenv("PAG_SHARD_TIMING") != nullptr;
+    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
     double lap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t wire[2] = {0, 0};
     auto now = [&]() {

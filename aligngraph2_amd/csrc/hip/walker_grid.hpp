@@ -61,7 +61,7 @@ struct WalkerGrid {
         prepare_streams(g, 4);
         const double idle_us = std::getenv("PAG_WALK_IDLE_US") ? std::max(1.0, std::atof(std::getenv("PAG_WALK_IDLE_US"))) : 2000.0;
         idle_ticks = (uint64_t)(idle_us * 100.0);
-        if (!(std::getenv("PAG_WALK_PRIO") && std::atoi(std::getenv("PAG_WALK_PRIO")) == 0)) idle_ticks |= 1ull << 63;  // (wave priority: see k_walk_persistent)
+        idle_ticks |= 1ull << 63;  // (the walker waves raise their issue priority: see k_walk_persistent)
         launched = launches = 0;
         up = false;
     }

@@ -81,17 +81,12 @@ extern "C" void pagh_debug_classify_columns(const char *q, std::uint64_t n, cons
     *n_radv = a;
 }
 
-namespace {
-AlnRecordFilter g_recordFilter;
-}
-void setAlnRecordFilter(AlnRecordFilter f) { g_recordFilter = std::move(f); }
-
 void AlnDb::addRecord(AlnRecord rec, const std::string &qline, const std::string &rline) {
     // parseDiff: q=='-' -> (1,0); r=='-' -> (0,1); mismatch -> (1,1); match -> (0,0).  One column
     // per character of the query line; a shorter reference line reads as NUL (mismatch).
     std::size_t n = qline.size();
     if (n > 0xFFFFFFFFull) throw std::runtime_error("alignment longer than 2^32 columns");
-    if (filterOn_ && g_recordFilter && !g_recordFilter(rec.queryName.data(), rec.queryName.size())) {  // (header only, see setAlnRecordFilter)
+    if (filter_ && *filter_ && !(*filter_)(rec.queryName.data(), rec.queryName.size())) {  // (header only, see AlnRecordFilter)
         rec.diffOff = diff_.size();
         recs_.push_back(std::move(rec));
         return;
@@ -130,12 +125,9 @@ void AlnDb::sortByScore() {
 // does not fit that, by the very stream extraction of the sequential loop, and the column classes are written
 // to their final place (offsets = running sum of the word counts in file order).
 namespace {
-ColumnClassifier g_classifier = nullptr;
 double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
-void setColumnClassifier(ColumnClassifier f) { g_classifier = f; }
-
-bool AlnDb::loadMecatParallel(const std::string &path) {
+bool AlnDb::loadMecatParallel(const std::string &path, const AlnRecordFilter &filter) {
     const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
     const double t0 = nowS();
     FileLines fl;
@@ -197,7 +189,6 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
             }
         }
     });
-    const AlnRecordFilter filter = g_recordFilter;  // (a copy: the setter may be called while this load runs)
     std::vector<std::uint8_t> wanted(nRec, 1);
     std::size_t nWanted = nRec;
     if (filter) {
@@ -212,26 +203,6 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         off[r + 1] = off[r] + (wanted[r] ? (n + 15) / 16 : 0);
     }
     diff_.assign(off[nRec], 0);
-    // the bulk half on the device, when a classifier is installed: the rows go up as they lie in the file
-    bool classified = false;
-    std::vector<std::uint32_t> devEmit, devRadv;
-    if (g_classifier && nRec && !filter) {
-        std::vector<std::uint64_t> qOff(nRec), rOff(nRec);
-        std::vector<std::uint32_t> qLen(nRec), rLen(nRec);
-        bool fits = true;
-        for (std::size_t r = 0; r < nRec; ++r) {
-            qOff[r] = fl.offset(3 * r + 1);
-            rOff[r] = fl.offset(3 * r + 2);
-            qLen[r] = static_cast<std::uint32_t>(fl.length(3 * r + 1));
-            fits = fits && fl.length(3 * r + 2) <= 0xFFFFFFFFull;
-            rLen[r] = static_cast<std::uint32_t>(fl.length(3 * r + 2));
-        }
-        devEmit.assign(nRec, 0);
-        devRadv.assign(nRec, 0);
-        classified = fits && g_classifier(fl.base(), fl.bytes(), qOff.data(), qLen.data(), rOff.data(), rLen.data(), off.data(), nRec, diff_.data(),
-                                          diff_.size(), devEmit.data(), devRadv.data());
-        if (!classified) std::fill(diff_.begin(), diff_.end(), 0u);
-    }
     const double t2 = nowS();
     parallelFor(nRec, 64, [&](std::size_t r) {
         AlnRecord &rec = recs_[r];
@@ -241,11 +212,6 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
         rec.diffOff = off[r];
         if (!wanted[r]) return;  // (header only: nCols = nEmit = nRadv = 0)
         rec.nCols = static_cast<std::uint32_t>(n);
-        if (classified) {  // (done by the device)
-            rec.nEmit = devEmit[r];
-            rec.nRadv = devRadv[r];
-            return;
-        }
         std::uint32_t *w = diff_.data() + off[r];
         std::uint32_t nEmit = 0, nRadv = 0;
         classifyColumns(ql, n, rl, rn, w, nEmit, nRadv);
@@ -254,9 +220,8 @@ bool AlnDb::loadMecatParallel(const std::string &path) {
     });
     if (timing && filter) std::fprintf(stderr, "[timing]   ALN %s: columns of %zu of %zu records (this rank's reads)\n", path.c_str(), nWanted, nRec);
     if (timing)
-        std::fprintf(stderr, "[timing]   ALN %s: %zu records, lines found %.3f s, %s %.3f s, headers%s %.3f s\n", path.c_str(), nRec, t1 - t0,
-                     g_classifier ? (classified ? "columns on the device" : "device classifier declined") : "offsets", t2 - t1,
-                     classified ? "" : " + columns on the host", nowS() - t2);
+        std::fprintf(stderr, "[timing]   ALN %s: %zu records, lines found %.3f s, offsets %.3f s, headers + columns %.3f s\n", path.c_str(), nRec, t1 - t0, t2 - t1,
+                     nowS() - t2);
     return true;
 }
 
@@ -377,16 +342,16 @@ bool AlnDb::savePacked(const std::string &alnPath, Flavor flavor) const {
     return ok;
 }
 
-AlnDb::AlnDb(const std::string &path, Flavor flavor) {
+AlnDb::AlnDb(const std::string &path, Flavor flavor, AlnRecordFilter filter) {
     std::ifstream in(path);
     if (!in.is_open()) return;  // the reference silently yields an empty database
     if (loadPacked(path, flavor)) return;
 
     std::stringstream ss;
-    if (flavor == Flavor::Mecat && loadMecatParallel(path)) {
+    if (flavor == Flavor::Mecat && loadMecatParallel(path, filter)) {
         // done by the thread pool
     } else if (flavor == Flavor::Mecat) {
-        filterOn_ = true;
+        filter_ = &filter;
         std::string queryName, refName, forward, score;
         std::size_t queryBegin = 0, queryEnd = 0, querySize = 0, refBegin = 0, refEnd = 0, refSize = 0;
         std::string l1, l2, l3;
@@ -440,10 +405,11 @@ AlnDb::AlnDb(const std::string &path, Flavor flavor) {
             }
         }
     }
+    filter_ = nullptr;
     sortByScore();
     diff_.resize(diff_.size() + 4, 0);  // kernels may read one word past an alignment
     if (const char *e = std::getenv("PAGRAPH_ALN_SIDECAR"))
-        if (e[0] == '1' && !(flavor == Flavor::Mecat && g_recordFilter)) savePacked(path, flavor);  // (never a sidecar of a filtered parse)
+        if (e[0] == '1' && !(flavor == Flavor::Mecat && filter)) savePacked(path, flavor);  // (never a sidecar of a filtered parse)
 }
 
 }  // namespace pagh

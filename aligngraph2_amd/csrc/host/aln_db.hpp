@@ -21,21 +21,14 @@ struct AlnRecord {
     std::uint32_t nRadv = 0;  // columns that advance the target (classes 00, 11, 01)
 };
 
-// The bulk half of an ALN parse — the column classes of every record's two rows (parseDiff) and the two counts per record — as
-// a hook: the HIP backend installs pag_classify_columns_host (k_ingest.hip) when PAGRAPH_DEVICE_INGEST=1; without a hook, or
-// when it returns false, the host loop below does the work.  Arguments as pag_classify_columns_host takes them.
-using ColumnClassifier = bool (*)(const char *text, std::uint64_t textBytes, const std::uint64_t *qOff, const std::uint32_t *qLen,
-                                  const std::uint64_t *rOff, const std::uint32_t *rLen, const std::uint64_t *diffOff, std::uint64_t nRecs,
-                                  std::uint32_t *diff, std::uint64_t nDiffWords, std::uint32_t *nEmit, std::uint32_t *nRadv);
-void setColumnClassifier(ColumnClassifier f);
-
 // A rank of a sharded build (PAGRAPH_SHARD, SURVEY 8e level 2) extracts the reads of ITS emission range only: of every other
 // read's alignments it needs the header (per-query lists, eligibility, the coverage filter: header fields), never the columns.
-// With a filter set, a read database's records whose query name it rejects keep their header and get no column classes
+// A database constructed with a filter: the records whose query name it rejects keep their header and get no column classes
 // (nCols = nEmit = nRadv = 0): the bulk of the parse — 2.2 B of text per aligned base — and of the staged bytes is then the
-// rank's own share.  Applies to Flavor::Mecat text parses; a packed sidecar is loaded as it is.
+// rank's own share.  Applies to Flavor::Mecat text parses; a packed sidecar is loaded as it is, and a filtered parse writes none.
+// The filter belongs to the database it was handed to (it is called from the parser's threads while the constructor runs and
+// dropped when it returns): nothing outlives the objects it refers to, whichever way the constructor ends.
 using AlnRecordFilter = std::function<bool(const char *queryName, std::size_t len)>;
-void setAlnRecordFilter(AlnRecordFilter f);  // (empty: none)
 
 class AlnDb {
 public:
@@ -44,7 +37,7 @@ public:
         MummerV2 // contig->ref: score = qEnd - qBegin, 9 header fields read
     };
     AlnDb() = default;
-    AlnDb(const std::string &path, Flavor flavor);
+    AlnDb(const std::string &path, Flavor flavor, AlnRecordFilter filter = nullptr);
 
     std::size_t size() const { return recs_.size(); }
     const AlnRecord &operator[](std::size_t i) const { return recs_[i]; }
@@ -86,9 +79,9 @@ public:
     bool fromSidecar() const { return fromSidecar_; }
 
 private:
-    bool loadMecatParallel(const std::string &path);
+    bool loadMecatParallel(const std::string &path, const AlnRecordFilter &filter);
     bool fromSidecar_ = false;
-    bool filterOn_ = false;  // (the sequential text parse of a read database: addRecord asks the record filter)
+    const AlnRecordFilter *filter_ = nullptr;  // (set while the sequential text parse of a filtered read database runs: addRecord asks it)
     std::vector<AlnRecord> recs_;
     std::vector<std::uint32_t> diff_;
 };

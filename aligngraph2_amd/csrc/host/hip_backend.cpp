@@ -14,14 +14,6 @@ namespace pagh {
 
 namespace {
 
-// PAGRAPH_DEVICE_INGEST=1: the column classes of the ALN files come from the device (pag_classify_columns_host, k_ingest.hip)
-int g_ingest_device = 0;
-bool classifyOnDevice(const char *text, std::uint64_t textBytes, const std::uint64_t *qOff, const std::uint32_t *qLen, const std::uint64_t *rOff,
-                      const std::uint32_t *rLen, const std::uint64_t *diffOff, std::uint64_t nRecs, std::uint32_t *diff, std::uint64_t nDiffWords,
-                      std::uint32_t *nEmit, std::uint32_t *nRadv) {
-    return pag_classify_columns_host(text, textBytes, qOff, qLen, rOff, rLen, diffOff, nRecs, diff, nDiffWords, nEmit, nRadv, g_ingest_device) == PAG_OK;
-}
-
 class HipBackend final : public GraphBackend {
 public:
     explicit HipBackend(int device) : device_(device) {
@@ -35,11 +27,6 @@ public:
         }
     }
     void configure() {
-        if (const char *e = std::getenv("PAGRAPH_DEVICE_INGEST"))
-            if (e[0] == '1') {
-                g_ingest_device = device_;
-                setColumnClassifier(&classifyOnDevice);
-            }
         // PAGRAPH_SHARD=r/N (or "env": RANK / WORLD_SIZE as torchrun sets them): this process is rank r of N that build every
         // config block TOGETHER, one process per GPU of the node; PAGRAPH_SHARD_DIR = a fresh directory all of them see;
         // PAGRAPH_SHARD_TRANSPORT = rccl (default) | host (ranks sharing one device: test boxes)

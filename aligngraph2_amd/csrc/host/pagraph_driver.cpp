@@ -183,7 +183,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
             SeqDb reads;
             AlnDb readToCtg, readToRef;
             BlockFiles(const std::string &pre, const BlockConfig &cfg, unsigned shardRank, unsigned shardWorld, unsigned threads) {
-                if (shardWorld > 1 && !(std::getenv("PAGRAPH_SHARD_PARSE_ALL") && std::atoi(std::getenv("PAGRAPH_SHARD_PARSE_ALL")) != 0)) {
+                if (shardWorld > 1) {
                     // one of several ranks that build this block together: the columns of an alignment are parsed only for the
                     // reads of THIS rank's stretch of the emission order (pag_shard_extract: positions [n r / N, n (r + 1) / N) of the
                     // thread-major strided order, MultiThreadTools.tcc:8-14) — of the others the header is all that is used
@@ -193,7 +193,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                     const std::uint64_t n = reads.size(), T = threads ? threads : 1;
                     const std::uint64_t lo = n * shardRank / shardWorld, hi = n * (shardRank + 1ull) / shardWorld;
                     const SeqDb *rd = &reads;
-                    setAlnRecordFilter([rd, n, T, lo, hi](const char *name, std::size_t len) {
+                    const AlnRecordFilter mine = [rd, n, T, lo, hi](const char *name, std::size_t len) {
                         const std::string nm(name, len);
                         if (!rd->contains(nm)) return false;
                         const std::uint64_t i = rd->id(nm), t = i % T;
@@ -201,12 +201,13 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                         const std::uint64_t full = n / T, rem = n % T;
                         const std::uint64_t pos = t * full + (t < rem ? t : rem) + i / T;
                         return pos >= lo && pos < hi;
-                    });
-                    auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
-                    auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat); });
+                    };
+                    // (each database gets its own copy of the filter; `reads`, which it refers to, is a member and outlives both parses
+                    // whichever way they end)
+                    auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat, mine); });
+                    auto refAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.refAlnPath, AlnDb::Flavor::Mecat, mine); });
                     readToCtg = ctgAln.get();
                     readToRef = refAln.get();
-                    setAlnRecordFilter(nullptr);
                     return;
                 }
                 auto ctgAln = std::async(std::launch::async, [&] { return AlnDb(pre + "/" + cfg.ctgAlnPath, AlnDb::Flavor::Mecat); });
@@ -395,8 +396,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 lap("walks");
                 // ONE block by several ranks: every rank writes the path dumps of the contigs it walked (most of a block's
                 // output bytes), rank 0 — which has the travel sequences of all ranks — selects the chains and writes the rest
-                // (PAGRAPH_SHARD_RANK_DUMPS=0: rank 0 writes everything, as until round 5)
-                const bool rankDumps = backend.shardWorld() > 1 && !(std::getenv("PAGRAPH_SHARD_RANK_DUMPS") && std::atoi(std::getenv("PAGRAPH_SHARD_RANK_DUMPS")) == 0);
+                const bool rankDumps = backend.shardWorld() > 1;
                 if (backend.shardRank() != 0) {
                     if (rankDumps) {
                         std::set<std::pair<std::string, bool>> own;

@@ -21,13 +21,12 @@ int main(int argc, char **argv) {
     const int rc = pagh::runPagraph(argc, argv, *backend);
     // Every output file is written and closed, every host thread joined: the process leaves without returning tens of GB of
     // device and pinned memory piece by piece (the driver reclaims them in one go: 0.1-0.2 s of a 2 s run).
-    // PAGRAPH_FULL_TEARDOWN=1: the ordinary way out (leak checkers).
     // (a rank of a sharded build leaves the ordinary way: its communicator says goodbye to its peers)
     const char *shard = std::getenv("PAGRAPH_SHARD");
     // (tools that flush at exit — rocprofv3, coverage, sanitizers — need the ordinary way out as well)
     const bool tool = std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("LD_PRELOAD") || std::getenv("GCOV_PREFIX") ||
                       std::getenv("ASAN_OPTIONS") || std::getenv("LSAN_OPTIONS");
-    if (!std::getenv("PAGRAPH_FULL_TEARDOWN") && !(shard && *shard) && !tool) {
+    if (!(shard && *shard) && !tool) {
         std::cout.flush();
         std::cerr.flush();
         std::fflush(nullptr);

@@ -144,16 +144,13 @@ extern "C" int pagt_seq_window_check(const char *path, unsigned rank, unsigned w
     }
 }
 
-// test hook for AlnDb's record filter (aln_db.hpp, setAlnRecordFilter): the file parsed without a filter and with "numeric query
+// test hook for AlnDb's record filter (aln_db.hpp, AlnRecordFilter): the file parsed without a filter and with "numeric query
 // name % mod == rem".  out[0] = records, out[1] = records that kept their columns, out[2] = 1 if every header field of every
 // record agrees, every kept record has the unfiltered parse's column classes and counts, and every other record has none.
 extern "C" int pagt_aln_filter_check(const char *path, uint64_t mod, uint64_t rem, uint64_t *out) {
     try {
-        pagh::setAlnRecordFilter(nullptr);
         pagh::AlnDb full(path, pagh::AlnDb::Flavor::Mecat);
-        pagh::setAlnRecordFilter([mod, rem](const char *name, std::size_t len) { return std::stoull(std::string(name, len)) % mod == rem; });
-        pagh::AlnDb part(path, pagh::AlnDb::Flavor::Mecat);
-        pagh::setAlnRecordFilter(nullptr);
+        pagh::AlnDb part(path, pagh::AlnDb::Flavor::Mecat, [mod, rem](const char *name, std::size_t len) { return std::stoull(std::string(name, len)) % mod == rem; });
         out[0] = full.size();
         out[1] = 0;
         bool ok = full.size() == part.size();

@@ -32,7 +32,7 @@ def run_ranks(argv, world, extra):
     procs, t0 = [], time.time()
     for r in range(world):
         env = dict(os.environ, PAGRAPH_SHARD=f"{r}/{world}", PAGRAPH_SHARD_DIR=rdv, PAGRAPH_SHARD_TRANSPORT="host", PAG_COMM_TIMEOUT_S="600",
-                   PAG_DEVICE_SHARERS=str(world), PAGRAPH_TIMING="1", PAG_SHARD_TIMING="1", **extra)
+                   PAG_DEVICE_SHARERS=str(world), PAGRAPH_TIMING="1", **extra)
         procs.append(subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     ranks = []
     for r, pr in enumerate(procs):

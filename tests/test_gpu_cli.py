@@ -22,7 +22,7 @@ EXE = os.path.join(pagctl.ROOT, "aligngraph2_amd", "bin", "pagraph")
 # can leap and are spliced under other conditions, k5_travel_host.hip try_merge_leap); "pieces-noleap" leaves the leaping
 # zone to one exact walk, as round 1 of the cut did
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact", "pieces-noleap", "pieces-by-place"])
+@pytest.mark.parametrize("mode", ["speculative", "exact", "pieces", "pieces-exact", "pieces-noleap"])
 @pytest.mark.parametrize("name", goldens.case_names())
 def test_pagraph_matches_golden(name, mode, workdir):
     spec = goldens.load_spec(name)
@@ -31,7 +31,7 @@ def test_pagraph_matches_golden(name, mode, workdir):
     os.makedirs(out, exist_ok=True)
     argv = synth.pagraph_argv(EXE, ind, out, threads=spec["threads"], epsilon=spec["epsilon"], cov=spec["cov"])
     env = dict(os.environ)
-    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES", "PAG_LEAP_PIECES", "PAG_LEAP_FIRST", "PAG_NODE_ORDER"):
+    for v in ("PAG_WALK_EXACT", "PAG_SEG_LEN", "PAG_SEG_OVERLAP", "PAG_SEG_SAFETY", "PAG_WALK_PIECES", "PAG_LEAP_PIECES"):
         env.pop(v, None)
     if mode.startswith("pieces"):
         # (PAG_DEBUG_CHECK_AGGS: the block tables the pack kernel attaches to every fetched path are recomputed on the host and compared)
@@ -40,8 +40,6 @@ def test_pagraph_matches_golden(name, mode, workdir):
         env["PAG_WALK_EXACT"] = "1"
     if mode.endswith("noleap"):
         env["PAG_LEAP_PIECES"] = "0"
-    if mode.endswith("by-place"):  # (the traversal graph's nodes numbered by place instead of by code: same files)
-        env["PAG_NODE_ORDER"] = "place"
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     assert "HIP gfx950" in r.stdout
@@ -195,12 +193,11 @@ def test_one_block_built_by_several_pagraph_processes(name, world, workdir):
     ("three chunks", 4, {"PAG_SHARD_CHUNKS": "3"}),
     ("more chunks than a rank has reads", 2, {"PAG_SHARD_CHUNKS": "64"}),
     ("one rank over RCCL with itself", 1, {"PAG_COMM_FORCE_RCCL": "1", "PAGRAPH_SHARD_TRANSPORT": "rccl"}),
-    ("rank 0 writes every path dump", 4, {"PAGRAPH_SHARD_RANK_DUMPS": "0"}),
 ])
 def test_sharded_build_in_chunks_and_pipelined_equals_the_golden(label, world, extra, workdir):
     """pag_shard_run sends a rank's tuples in chunks while the next chunk is extracted, and the selection for one rank while the
     next one is made (round 5), and every rank writes the path dumps of its own contigs: any number of chunks, the whole exchanges of
-    round 4, rank 0 writing every dump, and — the only way RCCL's grouped sends and
+    round 4, and — the only way RCCL's grouped sends and
     receives of that path can run on a one-GPU box — ONE rank exchanging with itself over RCCL: the golden files every time."""
     import tempfile
     name = "two_blocks_both_orient_t16"
@@ -214,7 +211,7 @@ def test_sharded_build_in_chunks_and_pipelined_equals_the_golden(label, world, e
     procs = []
     for r in range(world):
         env = dict(os.environ, PAGRAPH_SHARD=f"{r}/{world}", PAGRAPH_SHARD_DIR=rdv, PAGRAPH_SHARD_TRANSPORT="host", PAG_COMM_TIMEOUT_S="120",
-                   PAG_DEVICE_SHARERS=str(world), PAG_SHARD_TIMING="1", PAGRAPH_TIMING="1")
+                   PAG_DEVICE_SHARERS=str(world), PAGRAPH_TIMING="1")
         env.update(extra)
         procs.append(subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     for r, pr in enumerate(procs):
@@ -223,7 +220,7 @@ def test_sharded_build_in_chunks_and_pipelined_equals_the_golden(label, world, e
         assert "[shard timing]" in se, se[-500:]
         # every rank writes the path dumps of the contigs it walked (rank 0 the rest of the block's files)
         if r > 0:
-            assert ("path dumps of this rank" in se) == (extra.get("PAGRAPH_SHARD_RANK_DUMPS") != "0"), se[-800:]
+            assert "path dumps of this rank" in se, se[-800:]
     goldens.compare_out_dir(name, out)
 
 

@@ -153,30 +153,18 @@ def check_against_reference(ref, off, recs, code, pos, whole, label):
             "big_steps": int((step[real] >= 1024).sum()), "dropped_targets": int((~kept).sum())}
 
 
-MODES = [  # (label, view, environment)
-    ("whole bound", "whole", {"PAG_SUCC_MODE": "bound"}),
-    ("whole twopass", "whole", {"PAG_SUCC_MODE": "twopass"}),
-    ("whole twopass heavy=4", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4"}),
-    ("whole twopass, graded by the filling pass", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_DEFER": "0"}),
-    ("whole twopass heavy=4, graded by the filling pass", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_SUCC_DEFER": "0"}),
-    ("whole twopass heavy=0", "whole", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "0"}),
-    ("whole fused", "whole", {"PAG_SUCC_MODE": "fused"}),
-    ("whole fused heavy=4", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4"}),
-    ("whole fused heavy=0", "whole", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "0"}),
+MODES = [  # (label, view, environment): the one way the records are built (k_succ_emit -> sort by source -> k_succ_finish), with
+          # its thread-per-vertex / wave-per-vertex split at the default limit, at 4 candidate pairs (most vertices by a wave) and never
+    ("whole", "whole", {}),
+    ("whole heavy=4", "whole", {"PAG_SUCC_HEAVY": "4"}),
+    ("whole heavy=0", "whole", {"PAG_SUCC_HEAVY": "0"}),
     ("whole by PAG_TRAVEL_VIEW", "for", {"PAG_TRAVEL_VIEW": "whole"}),
-    ("whole, nodes numbered by place", "whole", {"PAG_NODE_ORDER": "place"}),
-    ("cut tight, nodes numbered by place", "for", {"PAG_NODE_ORDER": "place", "PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
     ("cut default", "for", {}),
-    ("cut tight twopass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight twopass heavy=4", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight twopass, graded by the filling pass", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_DEFER": "0", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight twopass, the incomplete bit gathered", "for", {"PAG_SUCC_MODE": "twopass", "PAG_SUCC_INC_BITS": "1", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight fused, the incomplete bit gathered", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_INC_BITS": "1", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight bound", "for", {"PAG_SUCC_MODE": "bound", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight fused", "for", {"PAG_SUCC_MODE": "fused", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
-    ("cut tight fused heavy=4", "for", {"PAG_SUCC_MODE": "fused", "PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight", "for", {"PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight heavy=4", "for", {"PAG_SUCC_HEAVY": "4", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
+    ("cut tight heavy=0", "for", {"PAG_SUCC_HEAVY": "0", "PAG_VIEW_HALO": "300", "PAG_VIEW_MARGIN": "50"}),
 ]
-SWITCHES = ("PAG_SUCC_MODE", "PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN", "PAG_SUCC_TWO_PASS", "PAG_NODE_ORDER", "PAG_SUCC_DEFER", "PAG_SUCC_INC_BITS")
+SWITCHES = ("PAG_SUCC_HEAVY", "PAG_TRAVEL_VIEW", "PAG_VIEW_HALO", "PAG_VIEW_MARGIN")
 
 
 @pytest.mark.gpu

@@ -50,7 +50,7 @@ def test_parallel_loader_equals_sequential(name, tmp_path):
 
 
 def test_aln_record_filter_keeps_headers_and_own_columns(tmp_path):
-    """a rank of a sharded build parses the columns of ITS reads' alignments only (aln_db.hpp, setAlnRecordFilter): every
+    """a rank of a sharded build parses the columns of ITS reads' alignments only (aln_db.hpp, AlnRecordFilter): every
     record keeps its header, the wanted ones the column classes of the unfiltered parse, the others none"""
     import goldens
     ind = goldens.materialize_inputs("join_rev_t16", str(tmp_path / "in"))

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--epsilon", type=int, default=10)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-host", action="store_true")
-    ap.add_argument("--modes", default="exact,speculative,uncut,hosttail", help="device modes to run besides the host walk")
+    ap.add_argument("--modes", default="exact,speculative,uncut", help="device modes to run besides the host walk")
     ap.add_argument("--min-abundance", type=int, default=-1, help=">= 0: abundance cut of the solid set (needed for k > 14)")
     args = ap.parse_args()
     import torch
@@ -55,9 +55,6 @@ def main():
         ts = bench.TraverseStats()
         os.environ.pop("PAG_WALK_EXACT", None)
         os.environ.pop("PAG_WALK_PIECES", None)
-        os.environ.pop("PAG_DEVICE_TAIL", None)
-        if mode == "hosttail":  # the last round of a leaping contig taken through the host like every other round
-            os.environ["PAG_DEVICE_TAIL"] = "0"
         if mode == "exact":
             os.environ["PAG_WALK_EXACT"] = "1"
         if mode == "uncut":  # one job per (contig, seed): the walk without the segment-parallel cut
