@@ -323,6 +323,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
     }
     // a graph that is one rank's region of a sharded build is cut already (pag_shard_select); PAG_TRAVEL_VIEW=whole: never cut
     const WalkConfig cfg = WalkConfig::from_env();
+    const double t_entry = now_ms(), alloc_entry = g->alloc_ms;
     const bool prune = orient && !g->regional && !g->view_off && !cfg.view_whole;
     // ---- compact CSR (once per built graph)
     DevBuf b_ncode = buf(), b_npos = buf(), b_nedge = buf(), b_vpos = buf(), b_vcnt = buf(), b_vnode = buf(), b_eto = buf(),
@@ -361,7 +362,20 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
     G.succ_off = b_soff.as<uint32_t>();
     double t_compact = 0;
     {
-        const double t0 = now_ms();
+        const double t0 = t_entry;
+        // (PAGRAPH_TIMING: the stage's laps — each ends with the stream idle — and what of them was hipMalloc / hipFree)
+        double lap_t = t0, lap_alloc = alloc_entry;
+        std::string lap_line;
+        auto lap = [&](const char *what) {
+            if (!cfg.timing) return;
+            hipStreamSynchronize(s);
+            const double t = now_ms();
+            char b[96];
+            std::snprintf(b, sizeof b, " %s %.1f ms (pool %.1f);", what, t - lap_t, g->alloc_ms - lap_alloc);
+            lap_line += b;
+            lap_t = t;
+            lap_alloc = g->alloc_ms;
+        };
         size_t tb = trav_compact_tmp_bytes(g->n_t, g->n_e, k, nn);
         if ((rc = b_ctmp.alloc(tb))) return rc;
         ViewRegion vr;
@@ -405,16 +419,52 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             g->view_pruned = true;
             g->view_orient.assign(orient, orient + n_ctgs);
         }
+        lap("view + CSR");
         g->view_counts[0] = G.n_nodes;
         g->view_counts[1] = G.n_pos;
         g->view_counts[2] = G.n_edges;
         // coordinate order, then the static half of the epsilon-join for every vertex
-        if ((rc = b_ok0.alloc((np + 1) * 4)) || (rc = b_ov0.alloc((np + 8) * 8)) || (rc = b_ok1.alloc((np + 1) * 4)) ||
-            (rc = b_ov1.alloc((np + 1) * 8)) || (rc = b_otmp.alloc(std::max(sort_tmp_bytes(np), scan_tmp_bytes(np + 2) + 64))))
-            return rc;
+        // The two (key, value) scratch pairs of the sorts that follow — the coordinate order of the view's vertices, then the emission
+        // stream of the successor records, four to six times as long — and their scratch: on LOAN from the build where it has room.
+        // pag_process leaves, beside the finished streams, the other half of each ping-pong pair, the segment kernels' scratch and the
+        // sort's (28 bytes per tuple slot, 47 GB for a 90 Mb block at 30x) untouched until its next call; a loan never grows a slot.
+        struct Lender {
+            pag_graph *g;
+            bool lent[64] = {false};
+            bool take(DevBuf &b, size_t bytes) {  // smallest idle build slot that holds `bytes`; false: none (b keeps its own slot)
+                static const int cand[] = {30, 31, 32, 33, 34, 35, 36, 37, 38, 43, 44};
+                int best = -1;
+                for (int c : cand) {
+                    const pag_graph::Slot &sl = g->pool[c];
+                    if (lent[c] || !sl.p || sl.cap < bytes) continue;
+                    if (sl.p == (void *)g->tkey || sl.p == (void *)g->tval || sl.p == (void *)g->ekey || sl.p == (void *)g->eval) continue;
+                    if (best < 0 || sl.cap < g->pool[best].cap) best = c;
+                }
+                if (best < 0) return false;
+                lent[best] = true;
+                b = DevBuf(g, best);
+                b.p = g->pool[best].p;
+                return true;
+            }
+            void give_back() { std::fill(lent, lent + 64, false); }
+        } lender{g};
+        const DevBuf own_ok0 = b_ok0, own_ov0 = b_ov0, own_ok1 = b_ok1, own_ov1 = b_ov1, own_otmp = b_otmp;
+        auto scratch_pairs = [&](uint64_t n_elems, size_t tmp_bytes) -> int {  // (values first: the larger requests get the larger slots)
+            lender.give_back();
+            b_ok0 = own_ok0, b_ov0 = own_ov0, b_ok1 = own_ok1, b_ov1 = own_ov1, b_otmp = own_otmp;
+            int r2;
+            if (!lender.take(b_ov0, (n_elems + 8) * 8) && (r2 = b_ov0.alloc((n_elems + 8) * 8))) return r2;
+            if (!lender.take(b_ov1, (n_elems + 8) * 8) && (r2 = b_ov1.alloc((n_elems + 8) * 8))) return r2;
+            if (!lender.take(b_ok0, (n_elems + 8) * 4) && (r2 = b_ok0.alloc((n_elems + 8) * 4))) return r2;
+            if (!lender.take(b_ok1, (n_elems + 8) * 4) && (r2 = b_ok1.alloc((n_elems + 8) * 4))) return r2;
+            if (!lender.take(b_otmp, tmp_bytes) && (r2 = b_otmp.alloc(tmp_bytes))) return r2;
+            return PAG_OK;
+        };
+        if ((rc = scratch_pairs(G.n_pos, std::max(sort_tmp_bytes(G.n_pos), scan_tmp_bytes(G.n_pos + 2) + 64)))) return rc;
         if ((rc = trav_order(G, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), b_otmp.p, &g->n_zero_ctg,
                              ctg_bits, ref_bits, s)))
             return rc;
+        lap("coordinate order");
         // a graph that holds a region of the block only: which coordinate-free vertices may have successors beyond it
         G.incomplete = nullptr;
         G.n_zero = (uint32_t)g->n_zero_ctg;
@@ -444,9 +494,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             if ((rc = b_heavy.alloc(heavy_bytes + 64))) return rc;
             unsigned long long *counters = (unsigned long long *)((char *)b_heavy.p + heavy_bytes);  // (slots taken, records, heavy vertices)
             for (int attempt = 0; attempt < 3; ++attempt) {
-                if ((rc = b_ok0.alloc((cap + 8) * 4)) || (rc = b_ov0.alloc((cap + 8) * 8)) || (rc = b_ok1.alloc((cap + 8) * 4)) || (rc = b_ov1.alloc((cap + 8) * 8)) ||
-                    (rc = b_otmp.alloc(sort_tmp_bytes(cap))))
-                    return rc;
+                if ((rc = scratch_pairs(cap, sort_tmp_bytes(cap)))) return rc;
                 if ((rc = trav_succ_emit(G, (uint32_t)deviation, errorRate, b_ok0.as<uint32_t>(), b_ov0.as<uint64_t>(), b_ok1.as<uint32_t>(), b_ov1.as<uint64_t>(), cap,
                                          b_otmp.p, counters, b_heavy.as<uint32_t>(), cfg.succ_heavy, &n_slots, &n_succ, &n_heavy, &sk, &sv, s)))
                     return rc;
@@ -460,6 +508,7 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
             }
             if (nv) g->succ_per_vertex = (double)n_slots / (double)nv;
         }
+        lap("candidate pairs -> sorted stream");
         if (n_succ >= 0xFFFFFFF0ull) {
             set_error("pag_travel: more than 2^32 successor records");
             return PAG_EINVAL;
@@ -469,6 +518,8 @@ int trav_prepare_graph(pag_graph *g, const uint32_t *ctg_len, uint64_t n_ctgs, c
         G.n_succ = n_succ;
         if ((rc = trav_succ_finish(G, sk, sv, n_succ, s))) return rc;
         PAG_HIP_TRY(hipStreamSynchronize(s));
+        lap("records");
+        if (cfg.timing) std::fprintf(stderr, "[timing] traversal graph:%s\n", lap_line.c_str());
         g->tg = G;
         g->tg_dev = deviation;
         g->tg_err = errorRate;

@@ -375,11 +375,15 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
                  const uint32_t *ekey, const uint64_t *eval, const uint32_t *eseg, uint64_t E, uint32_t k, uint64_t n_nodes,
                  uint64_t n_pos, uint64_t n_edges, TravGraph G, void *tmp, size_t tmp_bytes, hipStream_t s, const TravView *view,
                  uint64_t *counts_out) {
-    // tmp: flags u32[max(T, E, words, nodes + 1)] | scan out u64[same] | scan out 2 u64[T] | keep u32[T] | scan tmp
+    // tmp: flags u32[m] | scan out u64[m] | tile offsets + the view's ballots u64[n_tiles x 65 + ..] | tile counters u32[n_tiles] | scan
+    // tmp | code table, m = max(tiles, bitmap words, nodes + 1): nothing here is as long as the tuple streams (until round 6 every
+    // array was: 24 bytes per tuple slot, 37 GB for a 90 Mb block at 30x)
     // view != null: only the vertices inside its intervals (device arrays) are taken; counts_out[3] = nodes, vertices, edges
     // of the view (n_nodes / n_pos / n_edges are then upper bounds: what the arrays of G were sized for)
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
-    uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
+    const uint64_t n_tiles_all = (T + VC_TILE - 1) / VC_TILE;
+    const uint64_t m = std::max(n_tiles_all, std::max(n_words, n_nodes + 1)) + 1;
+    const uint64_t m_ballots = n_tiles_all * (VC_TILE / 64 * 2 + 1) + 64;
     char *p = (char *)tmp;
     auto take = [&](size_t bytes) {
         char *q = p;
@@ -388,8 +392,8 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
     };
     uint32_t *flags = (uint32_t *)take(m * 4);
     uint64_t *sc1 = (uint64_t *)take(m * 8);
-    uint64_t *sc2 = (uint64_t *)take(m * 8);
-    uint32_t *keep = (uint32_t *)take(m * 4);
+    uint64_t *sc2 = (uint64_t *)take(m_ballots * 8);
+    uint32_t *keep = (uint32_t *)take((n_tiles_all + 1) * 4);
     uint64_t *totals = (uint64_t *)take(64);
     void *scan_tmp = take(scan_tmp_bytes(m));
     uint64_t *code_tab = k <= TRAV_CODE_TABLE_MAX_K ? (uint64_t *)take((size_t)8 << (2 * k)) : nullptr;
@@ -405,7 +409,7 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
         const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, 256u * 8u);
         const uint32_t *civ = view ? view->civ : nullptr, *riv = view ? view->riv : nullptr;
         const uint32_t n_civ = view ? view->n_civ : 0u, n_riv = view ? view->n_riv : 0u;
-        uint64_t *ballots = sc2 + n_tiles + 16;  // (2 words per 64 slots, behind the tiles' offsets: m * 8 bytes hold both)
+        uint64_t *ballots = sc2 + n_tiles + 16;  // (2 words per 64 slots, behind the tiles' offsets)
         k_view_mark<<<dim3(grid), dim3(VC_T), 0, s>>>(tkey, tval, tseg, T, civ, n_civ, riv, n_riv, view ? 0 : 1, ballots, tile_first, tile_keep, n_tiles);
         if ((rc = scan_u32_to_u64(tile_first, sc1, n_tiles, totals, scan_tmp, s))) return rc;
         if ((rc = scan_u32_to_u64(tile_keep, sc2, n_tiles, totals + 1, scan_tmp, s))) return rc;
@@ -464,10 +468,12 @@ int trav_compact(const uint32_t *tkey, const uint64_t *tval, const uint32_t *tse
 }
 
 size_t trav_compact_tmp_bytes(uint64_t T, uint64_t E, uint32_t k, uint64_t n_nodes) {
+    (void)E;
     const uint64_t n_words = ((1ull << (2 * k)) + 63) / 64;
-    uint64_t m = std::max(std::max(T, E), std::max(n_words, n_nodes + 1)) + 1;
-    return 2 * ((m * 4 + 255) & ~(size_t)255) + 2 * ((m * 8 + 255) & ~(size_t)255) + ((scan_tmp_bytes(m) + 255) & ~(size_t)255) + 1024 + 256 +
-           (k <= TRAV_CODE_TABLE_MAX_K ? ((size_t)8 << (2 * k)) + 256 : 0);
+    const uint64_t n_tiles = (T + VC_TILE - 1) / VC_TILE;
+    const uint64_t m = std::max(n_tiles, std::max(n_words, n_nodes + 1)) + 1, m_ballots = n_tiles * (VC_TILE / 64 * 2 + 1) + 64;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return al(m * 4) + al(m * 8) + al(m_ballots * 8) + al((n_tiles + 1) * 4) + al(64) + al(scan_tmp_bytes(m)) + (k <= TRAV_CODE_TABLE_MAX_K ? al((size_t)8 << (2 * k)) : 0) + 1024;
 }
 
 // reference bands of the zones (k_zone_bands): lo / hi [n_z] device arrays, preset here

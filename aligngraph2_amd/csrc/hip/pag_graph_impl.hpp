@@ -1,5 +1,6 @@
 // Internal: the handle behind include/pagraph_hip.h and its pooled device buffers.
 #pragma once
+#include <chrono>
 #include <vector>
 
 #include "pag_device.hpp"
@@ -33,6 +34,10 @@ struct pag_graph {
         size_t cap = 0;
     };
     Slot pool[256];
+    // what the pool cost (PAGRAPH_TIMING reports it per stage: at the sizes of BASELINE configs[2] / [3] a fresh handle's tens of
+    // GB are seconds of hipMalloc / hipFree)
+    double alloc_ms = 0;
+    uint64_t alloc_bytes = 0, alloc_calls = 0;
     // per-contig walker buffers (k5_travel_host.hip), grown on demand like the slots above
     std::vector<Slot> cpool;
     // while the persistent walker is resident nothing may be hipFree'd (it synchronises the device): replaced
@@ -97,6 +102,7 @@ struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_dest
     int alloc(size_t bytes) {
         if (bytes == 0) bytes = 16;
         if (sl->cap < bytes) {
+            const auto t0 = std::chrono::steady_clock::now();
             if (sl->p) {
                 if (g->defer_free) g->deferred.push_back(sl->p);
                 else hipFree(sl->p);
@@ -105,6 +111,9 @@ struct DevBuf {  // a view of one pool slot of the handle (never frees; pag_dest
             sl->cap = 0;
             size_t want = bytes + bytes / 8 + 256;
             hipError_t e = hipMalloc(&sl->p, want);
+            g->alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            g->alloc_bytes += want;
+            g->alloc_calls += 1;
             if (e != hipSuccess) {
                 sl->p = nullptr;
                 pagdev::set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));

@@ -158,6 +158,7 @@ def main():
                 info.update(one_handle())
             except MemoryError as e:  # (the block does not fit one handle after all: it runs as ranks, the attempt is on record)
                 info["one_handle_attempt"] = str(e)[:300]
+                print(f"block {b}: one handle failed: {str(e)[:300]}; {(total - torch.cuda.mem_get_info(dev)[0]) / 1e9:.1f} GB in use after releasing it", flush=True)
                 fits = False
         if fits:
             if crossed < args.cross_check:
