@@ -62,10 +62,11 @@ aligngraph2_amd/bin/pre_process: $(HOST_DIR)/pre_process_main.cpp $(HOST_DIR)/li
 	@mkdir -p aligngraph2_amd/bin
 	$(CXX) $(CXXFLAGS) -o $@ $< -pthread
 
-# the consensus step after pagraph: parsing / slicing on the host, the per-part graphs on the device (csrc/hip/k_cns.hip)
-aligngraph2_amd/bin/pa_cns: $(HOST_DIR)/pa_cns_main.cpp $(B)/host/seq_db.o $(wildcard $(HOST_DIR)/*.hpp) $(HIP_DIR)/cns_graph.hpp aligngraph2_amd/libpagraph_hip.so
+# the consensus step after pagraph: parsing / slicing on the host, the per-part graphs on host threads or on the device (csrc/hip/k_cns.hip;
+# libpagraph_hip.so is loaded at run time, by the device backend only)
+aligngraph2_amd/bin/pa_cns: $(HOST_DIR)/pa_cns_main.cpp $(B)/host/seq_db.o $(wildcard $(HOST_DIR)/*.hpp) $(HIP_DIR)/cns_graph.hpp
 	@mkdir -p aligngraph2_amd/bin
-	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/host/seq_db.o -Laligngraph2_amd -lpagraph_hip -Wl,-rpath,'$$ORIGIN/..' -pthread
+	$(CXX) $(CXXFLAGS) -o $@ $< $(B)/host/seq_db.o -ldl -pthread
 
 aligngraph2_amd/bin/paf2aln: $(HOST_DIR)/paf2aln_main.cpp
 	@mkdir -p aligngraph2_amd/bin

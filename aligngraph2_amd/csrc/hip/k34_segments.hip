@@ -16,16 +16,19 @@
 //      Payload = to << 32 | step << 1 | pass, so one numeric sort orders by (to, step, pass) and the
 //      head of every (to, step) group tells whether pass 1 already had that edge.
 //
-// Short segments (<= SHORT_MAX records): one thread per record, bit-mask formulation (see K3 below).  Long
-// segments (repeats, low-complexity k-mers) are queued and handled by one wavefront each: 64 leaders
-// compared per step, ballot -> first hit; rank sort through the idle sort ping-pong buffers.
+// Short segments (<= SHORT_MAX = 64 records): one thread per record, bit-mask formulation (see K3 below).  Longer ones are queued
+// and handled by one wavefront each with the segment's state ON CHIP: up to 512 leaders in registers (a lane holds leaders l,
+// l + 64, ...), the items broadcast from a coalesced load of 64, ballot -> first hit; up to 1 024 edges sorted in LDS.  Beyond
+// that (low-complexity k-mers with thousands of positions) the same wavefront works in place through memory, as every long
+// segment did until round 6 — one global round trip per item then, 106 + 94 ms for K3 + K4 on a 62.5 Mb block at 40x coverage,
+// where most k-mer segments are longer than 32 records (the short path's limit until then).
 #include <algorithm>
 
 #include "pag_device.hpp"
 
 namespace pagdev {
 
-constexpr uint32_t SHORT_MAX = 32;
+constexpr uint32_t SHORT_MAX = 64;
 
 __device__ __forceinline__ bool coord_sim(uint32_t a, uint32_t b, uint32_t eps) {
     if (a == 0 || b == 0) return a == 0 && b == 0;
@@ -62,18 +65,18 @@ __device__ __forceinline__ void block_flush3(uint64_t a, uint64_t b, uint64_t c,
 // halo of SHORT_MAX through LDS with coalesced loads and owns the segments whose head lies in the first
 // SEG_OWN records.  Every record finds its offset `o` in its segment and the segment length by scanning
 // the staged keys, then the greedy scan is evaluated without any serial per-segment thread:
-//   M[x]  = bit j set iff record x is similar to the EARLIER record j of its segment     (o compares)
+//   M[x]  = bit j set iff record x is similar to the EARLIER record j of its segment     (o compares; 64-bit masks)
 //   L     = leader mask: record j is a leader iff M[j] & L == 0, folded for j = 0..len-1   (len steps)
 //   a non-leader adds 1 to leader ctz(M & L) — the first leader it is similar to, exactly the reference's
 //   scan order; a leader's output slot is its rank by (ctg, ref) among the leaders.
 // All lanes of a wave are busy and the trip counts are the segment length, instead of one lane in ~5
 // running length^2/2 dependent compares (the earlier layout was VALU-issue bound at 45 ms for the C2 set).
-constexpr int SEG_OWN = 480;
+constexpr int SEG_OWN = 448;
 constexpr int SEG_TILE = SEG_OWN + (int)SHORT_MAX;  // threads per block = staged records
 struct SegLds {
     uint64_t flag[SEG_TILE / 64 + 1];  // bit x = record x starts a k-mer segment; word 8 covers record SEG_TILE
     uint64_t val[SEG_TILE];
-    uint32_t m[SEG_TILE];
+    uint64_t m[SEG_TILE];
     uint32_t cnt[SEG_TILE];
 };
 
@@ -178,21 +181,21 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
         __syncthreads();
         const SegPos P = seg_locate(S, t, base, n);
         const uint64_t v = S.val[t];
-        uint32_t M = 0;
+        uint64_t M = 0;
         if (P.active) {
-            for (uint32_t j = 0; j < P.o; ++j) M |= (uint32_t)pos_sim(v, S.val[P.s + j], eps) << j;
+            for (uint32_t j = 0; j < P.o; ++j) M |= (uint64_t)pos_sim(v, S.val[P.s + j], eps) << j;
         }
         S.m[t] = M;
         S.cnt[t] = 1;
         __syncthreads();
-        uint32_t L = 0;
+        uint64_t L = 0;
         bool leader = false;
         uint32_t rank = 0;
         if (P.active) {
-            for (uint32_t j = 0; j < P.len; ++j) L |= (uint32_t)((S.m[P.s + j] & L) == 0) << j;
-            leader = (L >> P.o) & 1u;
+            for (uint32_t j = 0; j < P.len; ++j) L |= (uint64_t)((S.m[P.s + j] & L) == 0) << j;
+            leader = (L >> P.o) & 1ull;
             if (!leader) {
-                atomicAdd(&S.cnt[P.s + (uint32_t)__builtin_ctz(M & L)], 1u);
+                atomicAdd(&S.cnt[P.s + (uint32_t)__builtin_ctzll(M & L)], 1u);
             } else {
                 // sortWithCount: slot = rank by (ctg, ref) among the leaders (distinct keys)
                 for (uint32_t j = 0; j < P.len; ++j) rank += ((L >> j) & 1u) && S.val[P.s + j] < v;
@@ -218,12 +221,12 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
                     long_list[slot] = base + t;
                     seglen = 0xFFFFFFFFu;  // filled in by cluster_long
                 } else {
-                    seglen = (uint32_t)__popc(L);
+                    seglen = (uint32_t)__popcll(L);
                     n_all += seglen;
                 }
                 out.seg_len[base + t] = seglen;
             } else if (P.active) {
-                out.seg_len[base + t] = P.o < (uint32_t)__popc(L) ? (SEG_LEADER | P.o) : 0u;
+                out.seg_len[base + t] = P.o < (uint32_t)__popcll(L) ? (SEG_LEADER | P.o) : 0u;
             }
         }
     }
@@ -267,14 +270,89 @@ __device__ __forceinline__ void wave_rank_sort(uint64_t *__restrict__ val, uint1
     __syncthreads();
 }
 
+// A long segment with its leaders in registers: lane l holds leaders l, l + 64, ... (values and counts), at most LONG_REGS * 64
+// of them.  The items come in coalesced loads of 64 and are handed round by shuffles; an item is compared with 64 leaders per
+// step, the ballot's first set bit is the first leader it is similar to — the reference's scan order.  Nothing is written until the
+// segment is through (the leaders' slots are the segment's own first slots, which hold items until then).  Returns false when the
+// segment has more leaders than the registers hold: nothing was written, the caller does it in place.
+constexpr int LONG_REGS = 8;
+__device__ __forceinline__ bool cluster_long_on_chip(uint64_t *__restrict__ val, uint64_t i, uint64_t j, uint32_t eps, ClusterOut out, uint64_t *lds_leaders) {
+    const uint32_t lane = lane_id();
+    uint64_t lv[LONG_REGS];
+    uint32_t lc[LONG_REGS];
+#pragma unroll
+    for (int r = 0; r < LONG_REGS; ++r) lv[r] = 0ull, lc[r] = 0u;
+    uint32_t p = 0;
+    for (uint64_t c0 = i; c0 < j; c0 += 64) {
+        const uint64_t mine = c0 + lane < j ? val[c0 + lane] : 0ull;
+        const uint32_t nk = (uint32_t)(j - c0 < 64 ? j - c0 : 64);
+        for (uint32_t kk = 0; kk < nk; ++kk) {
+            const uint64_t item = __shfl(mine, (int)kk);
+            int hit = -1;
+#pragma unroll
+            for (int r = 0; r < LONG_REGS; ++r) {
+                if (hit < 0 && (uint32_t)r * 64u < p) {  // (wave-uniform)
+                    const bool sim = (uint32_t)r * 64u + lane < p && pos_sim(item, lv[r], eps);
+                    const uint64_t m = __ballot(sim);
+                    if (m) hit = r * 64 + (int)__ffsll((long long)m) - 1;
+                }
+            }
+            if (hit < 0) {
+                if (p >= (uint32_t)LONG_REGS * 64u) return false;
+#pragma unroll
+                for (int r = 0; r < LONG_REGS; ++r)
+                    if ((p >> 6) == (uint32_t)r && (p & 63u) == lane) lv[r] = item, lc[r] = 1u;
+                ++p;
+            } else {
+#pragma unroll
+                for (int r = 0; r < LONG_REGS; ++r)
+                    if (((uint32_t)hit >> 6) == (uint32_t)r && ((uint32_t)hit & 63u) == lane) lc[r] += 1u;
+            }
+        }
+    }
+    // sortWithCount: a leader's slot = its rank by (ctg, ref) among the leaders (distinct keys); the leaders staged in LDS, read back
+    // by every lane at the same address (broadcast)
+#pragma unroll
+    for (int r = 0; r < LONG_REGS; ++r)
+        if ((uint32_t)r * 64u + lane < p) lds_leaders[r * 64 + lane] = lv[r];
+    __syncthreads();
+    uint32_t rank[LONG_REGS];
+#pragma unroll
+    for (int r = 0; r < LONG_REGS; ++r) rank[r] = 0u;
+    for (uint32_t x = 0; x < p; ++x) {
+        const uint64_t u = lds_leaders[x];
+#pragma unroll
+        for (int r = 0; r < LONG_REGS; ++r) rank[r] += u < lv[r];
+    }
+    uint32_t n_ctg = 0;
+#pragma unroll
+    for (int r = 0; r < LONG_REGS; ++r)
+        if ((uint32_t)r * 64u + lane < p) {
+            val[i + rank[r]] = lv[r];
+            out.cnt[i + rank[r]] = (uint16_t)lc[r];
+            n_ctg += (lv[r] >> 32) != 0;
+        }
+    n_ctg = wave_sum(n_ctg);
+    for (uint64_t l = lane; l < j - i; l += 64) out.seg_len[i + l] = l == 0 ? p : (l < p ? (SEG_LEADER | (uint32_t)l) : 0u);
+    if (lane == 0) {
+        if (n_ctg) atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)n_ctg);
+        atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)p);
+    }
+    __syncthreads();  // (the staging array is written again by the next segment)
+    return true;
+}
+
 __global__ __launch_bounds__(64) void cluster_long(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                   uint64_t *__restrict__ s64, uint32_t *__restrict__ s32, uint64_t n,
                                                   uint32_t eps, ClusterOut out, const uint64_t *__restrict__ long_list,
                                                   const uint32_t *__restrict__ long_count) {
+    __shared__ uint64_t lds_leaders[LONG_REGS * 64];
     const uint32_t lane = lane_id();
     for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
         const uint64_t i = long_list[li];
         const uint64_t j = run_end(key, i, n, key[i]);
+        if (cluster_long_on_chip(val, i, j, eps, out, lds_leaders)) continue;
+        // more leaders than the registers hold: in place, through memory
         uint32_t p = 0;
         for (uint64_t it = i; it < j; ++it) {
             uint64_t item = val[it];
@@ -350,7 +428,7 @@ __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restri
                 kept = kept && !((u >> 1) == (v >> 1) && (u < v || (u == v && j < P.o)));
             }
         }
-        S.m[t] = kept;
+        S.m[t] = kept ? 1ull : 0ull;
         __syncthreads();
         uint32_t p = 0;
         if (P.active && (kept || P.head)) {
@@ -383,15 +461,53 @@ __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restri
     block_flush3(n_grp, n_grp1, 0, out.counters);
 }
 
+constexpr uint32_t EDGE_LDS = 1024;  // edges of a long segment sorted in LDS (more: through memory)
 __global__ __launch_bounds__(64) void edges_long(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                 uint64_t *__restrict__ s64, uint64_t n, EdgeOut out,
                                                 const uint64_t *__restrict__ long_list,
                                                 const uint32_t *__restrict__ long_count) {
+    __shared__ uint64_t lds_in[EDGE_LDS], lds_sorted[EDGE_LDS];
     const uint32_t lane = lane_id();
     for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
         const uint64_t i = long_list[li];
         const uint64_t j = run_end(key, i, n, key[i]);
         const uint32_t m = (uint32_t)(j - i);
+        if (m <= EDGE_LDS) {
+            // the segment in LDS: rank sort by (value, index) with broadcast reads, then the heads of the (to, step) groups compacted
+            // in order
+            for (uint32_t x = lane; x < m; x += 64) lds_in[x] = val[i + x];
+            __syncthreads();
+            for (uint32_t t = lane; t < m; t += 64) {
+                const uint64_t v = lds_in[t];
+                uint32_t rank = 0;
+                for (uint32_t x = 0; x < m; ++x) {
+                    const uint64_t u = lds_in[x];
+                    rank += (u < v) || (u == v && x < t);
+                }
+                lds_sorted[rank] = v;
+            }
+            __syncthreads();
+            uint32_t p = 0, g1 = 0;
+            for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+                const uint32_t x = c0 + lane;
+                const uint64_t v = x < m ? lds_sorted[x] : 0;
+                const bool headg = x < m && (x == 0 || (lds_sorted[x - 1] >> 1) != (v >> 1));
+                const uint64_t hm = __ballot(headg);
+                if (headg) {
+                    val[i + p + (uint32_t)__popcll(hm & lanemask_lt())] = v;
+                    g1 += (v & 1ull) == 0;
+                }
+                p += (uint32_t)__popcll(hm);
+            }
+            g1 = wave_sum(g1);
+            if (lane == 0) {
+                out.seg_len[i] = p;
+                atomicAdd((unsigned long long *)&out.counters[0], (unsigned long long)p);
+                if (g1) atomicAdd((unsigned long long *)&out.counters[1], (unsigned long long)g1);
+            }
+            __syncthreads();
+            continue;
+        }
         wave_rank_sort(val + i, nullptr, m, s64 + i, nullptr);
         // unique by (to, step): compact group heads through the scratch buffer
         uint32_t p = 0, g1 = 0;

@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -589,6 +590,36 @@ Options parseCli(int argc, char **argv) {
 
 }  // namespace
 
+// parts from which the default backend is the device (PA_CNS_BACKEND=auto)
+constexpr std::size_t kDevicePartsMin = 4096;
+
+// libpagraph_hip.so, loaded on demand from beside the executable (bin/../libpagraph_hip.so) or the loader's search path
+struct HipLibrary {
+    using ConsensusFn = int (*)(int, const char *, std::uint64_t, const pag_cns_part *, std::uint64_t, const pag_cns_aln *, std::uint64_t, const char *, const char *,
+                                std::uint64_t, std::int32_t, char *, std::uint64_t, std::uint64_t *, std::uint32_t *, std::int32_t *);
+    using ErrorFn = const char *(*)();
+    void *handle = nullptr;
+    ConsensusFn consensus = nullptr;
+    ErrorFn last_error = nullptr;
+    explicit HipLibrary(const char *argv0) {
+        std::string dir = argv0 ? argv0 : "";
+        const std::size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+        const std::string beside = dir + "/../libpagraph_hip.so";
+        handle = dlopen(beside.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!handle) handle = dlopen("libpagraph_hip.so", RTLD_NOW | RTLD_LOCAL);
+        if (!handle) throw std::runtime_error(std::string("the device backend needs libpagraph_hip.so: ") + dlerror());
+        consensus = reinterpret_cast<ConsensusFn>(dlsym(handle, "pag_cns_consensus"));
+        last_error = reinterpret_cast<ErrorFn>(dlsym(handle, "pag_last_error"));
+        if (!consensus || !last_error) throw std::runtime_error("libpagraph_hip.so does not export pag_cns_consensus");
+    }
+    HipLibrary(const HipLibrary &) = delete;
+    HipLibrary &operator=(const HipLibrary &) = delete;
+    ~HipLibrary() {
+        if (handle) dlclose(handle);
+    }
+};
+
 int main(int argc, char **argv) {
     if (argc <= 1) {
         usage(std::cerr);
@@ -625,8 +656,15 @@ int main(int argc, char **argv) {
         std::atomic<std::size_t> consensusLen(0), next(0);
         std::atomic<bool> failed(false);
         std::string failure;
-        std::string backend = std::getenv("PA_CNS_BACKEND") ? std::getenv("PA_CNS_BACKEND") : "hip";
-        if (backend != "hip" && backend != "flat" && backend != "host") throw std::runtime_error("PA_CNS_BACKEND must be hip, flat or host");
+        // Where the per-part graphs are built.  hip: one device thread per part (csrc/hip/k_cns.hip) — the library is loaded when, and
+        // only when, this backend runs: the program starts on a machine without the ROCm runtime; flat: the device's code
+        // (csrc/hip/cns_graph.hpp) on host threads; host: the std::vector / std::map restatement.  Default: by the number of parts —
+        // a part is a serial chain of dependent accesses, the device wins by running thousands side by side, host threads win on
+        // the few hundred parts of one contig of the pipeline (AlignGraph2.py:503 calls pa_cns once per new contig;
+        // profiles/r06_pa_cns_timing.json).
+        std::string backend = std::getenv("PA_CNS_BACKEND") ? std::getenv("PA_CNS_BACKEND") : "auto";
+        if (backend == "auto") backend = partNum >= kDevicePartsMin ? "hip" : "flat";
+        if (backend != "hip" && backend != "flat" && backend != "host") throw std::runtime_error("PA_CNS_BACKEND must be hip, flat, host or auto");
         const bool onHost = backend == "host";
         std::vector<std::vector<std::size_t>> partWeights(partNum);
         auto work = [&]() {
@@ -700,6 +738,7 @@ int main(int argc, char **argv) {
                         if (qb != '-') ++nEdgeCols;
                     }
                 }
+                std::vector<ScoredAln>().swap(alignments[i]);  // (its rows live in the pools now)
                 P.n_aln = static_cast<std::uint32_t>(flat.size() - P.aln_first);
                 const std::uint64_t nodeCap = P.bb_len + 2ull + nIns, edgeCap = P.bb_len + 1ull + nEdgeCols + P.n_aln + 4096ull;
                 if (nodeCap > 0x7FFFFFFFull || edgeCap > 0x7FFFFFFFull) throw std::runtime_error("pa_cns: a part with more than 2^31 graph slots");
@@ -715,9 +754,10 @@ int main(int argc, char **argv) {
             std::vector<std::int32_t> partErr(partNum, 0);
             if (backend == "hip") {
                 const int device = std::getenv("PAGRAPH_DEVICE") ? std::atoi(std::getenv("PAGRAPH_DEVICE")) : 0;
-                const int rc = pag_cns_consensus(device, backbone.data(), backbone.size(), parts.data(), partNum, flat.data(), flat.size(), qpool.data(), tpool.data(),
-                                                 qpool.size(), 0, outBuf.data(), outBytes, outOff.data(), outLen.data(), partErr.data());
-                if (rc != 0) throw std::runtime_error(std::string("pag_cns_consensus failed (") + std::to_string(rc) + "): " + pag_last_error());
+                const HipLibrary hip(argv[0]);  // (throws when the library or a gfx950 device is missing: there is no silent fallback)
+                const int rc = hip.consensus(device, backbone.data(), backbone.size(), parts.data(), partNum, flat.data(), flat.size(), qpool.data(), tpool.data(),
+                                             qpool.size(), 0, outBuf.data(), outBytes, outOff.data(), outLen.data(), partErr.data());
+                if (rc != 0) throw std::runtime_error(std::string("pag_cns_consensus failed (") + std::to_string(rc) + "): " + hip.last_error());
             } else {  // the device's code on host threads
                 std::uint64_t oo = 0;
                 for (std::size_t i = 0; i < partNum; ++i) {

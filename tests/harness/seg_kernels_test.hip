@@ -48,7 +48,11 @@ int main(int argc, char **argv) {
     for (uint64_t sgi = 0; sgi < n_seg_target; ++sgi) {
         code += 1 + (uint32_t)(rng() % 3);
         uint32_t r = (uint32_t)(rng() % 100);
-        uint32_t len = r < 70 ? 1 + (uint32_t)(rng() % 8) : r < 95 ? 1 + (uint32_t)(rng() % 33) : 30 + (uint32_t)(rng() % 200);
+        // (the short path takes segments of up to 64 records, the long path keeps up to 512 leaders / 1 024 edges on chip: lengths on
+        // both sides of each limit; "spread": positions far apart, so that nearly every item becomes a leader)
+        const bool spread = r >= 98;
+        uint32_t len = r < 60 ? 1 + (uint32_t)(rng() % 8) : r < 85 ? 1 + (uint32_t)(rng() % 33) : r < 92 ? 30 + (uint32_t)(rng() % 200) : r < 96 ? 60 + (uint32_t)(rng() % 10)
+                       : r < 98 ? 400 + (uint32_t)(rng() % 900) : 300 + (uint32_t)(rng() % 1200);
         uint32_t centers = 1 + (uint32_t)(rng() % 4);
         uint32_t c0[4], r0[4];
         for (int c = 0; c < 4; ++c) {
@@ -60,9 +64,13 @@ int main(int argc, char **argv) {
             bool pass2 = j >= len / 2;
             uint32_t ctg = pass2 ? 0 : c0[c] + (uint32_t)(rng() % 15);
             uint32_t ref = (rng() % 5 == 0) ? 0 : r0[c] + (uint32_t)(rng() % 15);
+            if (spread) {
+                ctg = pass2 ? 0 : 1000 + (uint32_t)(rng() % 40000);
+                ref = 5000 + (uint32_t)(rng() % 40000);
+            }
             key.push_back(code);
             val.push_back((uint64_t)ctg << 32 | ref);
-            uint32_t to = (uint32_t)(rng() % 6), step = (uint32_t)(rng() % 4);
+            uint32_t to = (uint32_t)(rng() % (spread ? 400 : 6)), step = (uint32_t)(rng() % 4);
             eval.push_back((uint64_t)to << 32 | step << 1 | (pass2 ? 1 : 0));
         }
     }

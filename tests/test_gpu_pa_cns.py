@@ -29,7 +29,7 @@ def run(exe, d, out, case, threads=4, backend=None):
 def test_device_pa_cns_matches_golden_and_reference_binary(name, tmp_path):
     case = cns_cases.CASES[name]
     d = cns_cases.write_case(case, str(tmp_path / "in"))
-    r = run(EXE, d, str(tmp_path / "ours.fasta"), case)
+    r = run(EXE, d, str(tmp_path / "ours.fasta"), case, backend="hip")
     assert r.returncode == 0, r.stderr[-800:]
     ours = open(tmp_path / "ours.fasta", "rb").read()
     assert ours == open(os.path.join(GOLD, name + ".fasta"), "rb").read()
@@ -46,7 +46,7 @@ def test_device_pa_cns_at_pipeline_settings(tmp_path):
     vertices per part, in-lists of dozens of edges)"""
     case = cns_cases.DEEP_CASE
     d = cns_cases.write_case(case, str(tmp_path / "in"))
-    r = run(EXE, d, str(tmp_path / "ours.fasta"), case, threads=16)
+    r = run(EXE, d, str(tmp_path / "ours.fasta"), case, threads=16, backend="hip")
     assert r.returncode == 0, r.stderr[-800:]
     want_exe, want_be = (REF, None) if os.path.exists(REF) else (EXE, "host")
     r2 = run(want_exe, d, str(tmp_path / "want.fasta"), case, threads=16, backend=want_be)
@@ -58,7 +58,7 @@ def test_device_pa_cns_at_pipeline_settings(tmp_path):
 def test_device_pa_cns_many_parts(tmp_path):
     case = dict(seed=11, backbone=30000, n_reads=900, read_len=1200, part=500, top_k=3000, alpha=250, score_classes=3)
     d = cns_cases.write_case(case, str(tmp_path / "in"))
-    r = run(EXE, d, str(tmp_path / "ours.fasta"), case, threads=8)
+    r = run(EXE, d, str(tmp_path / "ours.fasta"), case, threads=8, backend="hip")
     assert r.returncode == 0, r.stderr[-800:]
     assert r.stdout.startswith("PartNum=6")
     r2 = run(EXE, d, str(tmp_path / "host.fasta"), case, threads=8, backend="host")

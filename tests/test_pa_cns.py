@@ -79,9 +79,10 @@ def test_pa_cns_cli_contract(tmp_path):
     assert r.returncode == 2 and "No backbone" in r.stderr
 
 
-def test_pa_cns_fails_loudly_without_a_device(tmp_path):
-    """the default backend builds the graphs on the device: on a box without one the program must say so and fail — no silent
-    host fallback (skipped where a GPU is present)"""
+def test_pa_cns_device_backend_fails_loudly_without_a_device(tmp_path):
+    """PA_CNS_BACKEND=hip builds the graphs on the device: on a box without one the program must say so and fail — no silent
+    host fallback (skipped where a GPU is present).  The default chooses by the number of parts (a contig of the pipeline: host
+    threads running the device's code) and starts without the ROCm runtime: libpagraph_hip.so is loaded by the device backend only."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
@@ -89,8 +90,25 @@ def test_pa_cns_fails_loudly_without_a_device(tmp_path):
         pytest.skip("aligngraph2_amd/bin/pa_cns not built (make product)")
     case = cns_cases.CASES["one_part"]
     d = cns_cases.write_case(case, str(tmp_path / "in"))
+    env = dict(os.environ, PA_CNS_BACKEND="hip")
+    r = subprocess.run(cns_cases.argv(EXE, d, str(tmp_path / "o.fasta"), case), capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and ("pag_cns_consensus" in r.stderr or "libpagraph_hip.so" in r.stderr), r.stderr[-500:]
+    assert not os.path.exists(tmp_path / "o.fasta") or os.path.getsize(tmp_path / "o.fasta") == 0
+
+
+def test_pa_cns_default_backend_needs_no_device_library(tmp_path):
+    """the default (by part count: one part here) runs the flat graph code on host threads; the executable does not link the HIP
+    library (ldd), so the host backends start on a machine without the ROCm runtime"""
+    if not os.path.exists(EXE):
+        pytest.skip("aligngraph2_amd/bin/pa_cns not built (make product)")
+    case = cns_cases.CASES["one_part"]
+    d = cns_cases.write_case(case, str(tmp_path / "in"))
     env = dict(os.environ)
     env.pop("PA_CNS_BACKEND", None)
     r = subprocess.run(cns_cases.argv(EXE, d, str(tmp_path / "o.fasta"), case), capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode != 0 and "pag_cns_consensus" in r.stderr
-    assert not os.path.exists(tmp_path / "o.fasta") or os.path.getsize(tmp_path / "o.fasta") == 0
+    assert r.returncode == 0, r.stderr[-500:]
+    env["PA_CNS_BACKEND"] = "host"
+    r2 = subprocess.run(cns_cases.argv(EXE, d, str(tmp_path / "o2.fasta"), case), capture_output=True, text=True, env=env, timeout=300)
+    assert r2.returncode == 0 and open(tmp_path / "o.fasta", "rb").read() == open(tmp_path / "o2.fasta", "rb").read()
+    ldd = subprocess.run(["ldd", EXE], capture_output=True, text=True).stdout
+    assert "pagraph_hip" not in ldd and "amdhip" not in ldd, ldd
