@@ -1,9 +1,11 @@
-// k_cns.hip — pa_cns on the device: the partial-order alignment graphs of a backbone's parts, ONE THREAD PER
+// k_cns.hip — pa_cns on the device: the partial-order alignment graphs of a backbone's parts, ONE WAVEFRONT PER
 // PART.  The parts are independent (pa_cns.cpp:98-124 hands them to threads the same way); inside a part the algorithm is a
 // chain of order-dependent list operations (AlnGraphBoost.cpp: addAln / mergeNodes / bestPath — the order of a vertex's edge
 // lists decides every tie), so a part is one serial instruction stream: cns_graph.hpp, the same code the host build of
 // bin/pa_cns can run (PA_CNS_BACKEND=flat).  What the device adds is many such streams side by side, each a chain of dependent
-// gathers the memory system overlaps across threads; a wave's 64 parts diverge freely.
+// gathers the memory system overlaps across waves.  One LANE of a wave runs a part: with a part per lane (round 5) the 64
+// parts of a wave diverged at every branch and the wave executed them one after the other — 64 s for the 200 parts of a 1 Mb
+// backbone at 190x against 4 s on 16 host threads (profiles/r06_pa_cns_timing.json).
 //
 // Memory: a part's node / edge / scratch regions come out of arrays allocated per batch; batches are cut so that a batch fits the
 // byte budget (free device memory x 0.8).
@@ -18,8 +20,8 @@ namespace pagdev {
 __global__ __launch_bounds__(64) void cns_parts_kernel(pagcns::Arrays A, const pagcns::Part *__restrict__ parts, uint32_t n_parts, const char *__restrict__ backbone,
                                                         const pagcns::Aln *__restrict__ alns, const char *__restrict__ qpool, const char *__restrict__ tpool,
                                                         int min_weight, char *__restrict__ out, uint32_t *__restrict__ out_len, int32_t *__restrict__ part_err) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_parts) return;
+    const uint32_t p = blockIdx.x;
+    if (p >= n_parts || threadIdx.x != 0) return;
     uint32_t len = 0;
     const int err = pagcns::run_part(A, parts[p], backbone, alns, qpool, tpool, min_weight, out, &len);
     out_len[p] = err ? 0u : len;
@@ -138,7 +140,7 @@ extern "C" int pag_cns_consensus(int device, const char *backbone, uint64_t back
             return rc;
         PAG_HIP_TRY(hipMemcpy(d_parts, hp.data(), hp.size() * sizeof(pagcns::Part), hipMemcpyHostToDevice));
         const uint32_t n = (uint32_t)hp.size();
-        cns_parts_kernel<<<dim3((n + 63) / 64), dim3(64), 0, 0>>>(A, d_parts, n, d_bb, d_alns, d_q, d_t, min_weight, d_out, d_len, d_err);
+        cns_parts_kernel<<<dim3(n), dim3(64), 0, 0>>>(A, d_parts, n, d_bb, d_alns, d_q, d_t, min_weight, d_out, d_len, d_err);
         PAG_HIP_TRY(hipGetLastError());
         PAG_HIP_TRY(hipDeviceSynchronize());
         PAG_HIP_TRY(hipMemcpy(out_len + p0, d_len, (size_t)n * 4, hipMemcpyDeviceToHost));

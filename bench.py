@@ -177,7 +177,9 @@ def cpu_baseline(k, eps, cov, threads_flag):
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "pagraph")
         sample = f"{sp.n_reads} x {sp.read_span // 1000} kb reads vs {sp.ref_len // 1_000_000} Mb reference, k={k}, text inputs from /dev/shm"
         if os.path.exists(ref_bin):
-            t_use = min(ncores, 64)
+            # as many threads as the container may run at once (the GPU box: a 16-CPU cgroup quota on a 256-CPU host), at most the
+            # 64 north_star names: matched width, not 64 threads taking turns on 16 CPUs
+            t_use = int(max(1, min(64, quota if quota else ncores)))
             out = os.path.join(tmp, "out")
             os.makedirs(out)
             argv = aligngraph2_amd.pagraph_argv(ref_bin, tmp, out, threads=t_use, epsilon=eps, cov=cov)
@@ -623,6 +625,18 @@ def main():
                         "parity_provenance": {"wall_s": rec.get("reference", {}).get("wall_s"), "what": "the same files through the reference at -t 16 under the "
                                               "thread-serialising shim: the run whose output files the drop-in reproduces byte for byte "
                                               "(profiles/r04_c2_text_parity.json)"}}
+                    # the same files at MATCHED width: -t 16, its own threads, on the box's 16 CPUs (round 6)
+                    t16_path = os.path.join(ROOT, "profiles", "r06_c2_text_runs_t16.json")
+                    if os.path.exists(t16_path):
+                        t16 = json.load(open(t16_path))
+                        if t16.get("reference", {}).get("returncode") == 0:
+                            line["cpu_baseline"]["full_workload"]["matched_width"] = {
+                                "value": t16["reference"]["bases_per_s"], "unit": "aligned-read-bases/s", "cores": int(t16["reference"].get("threads_flag", 16)),
+                                "kind": "reference", "wall_s": t16["reference"]["wall_s"], "measured": t16.get("measured", "round 6"),
+                                "sample": "the same text files; compiled reference pagraph -t 16, its own threads, one per CPU of the box's quota; cached record "
+                                          "profiles/r06_c2_text_runs_t16.json"}
+                    line["cpu_baseline"]["full_workload"]["not_measured"] = ("north_star's comparison point — a 64-core host at 1 M x 10 kb reads — was never measured: "
+                                                                              "the GPU box's container may use 16 CPUs, and the reference needs ~1 h for 10 Gbases there")
                 if default_wl and rec.get("ours", {}).get("returncode") == 0:
                     line["config"]["file_to_file_bases_per_s"] = rec["ours"]["bases_per_s"]
                     line["config"]["file_to_file_note"] = ("bin/pagraph on the same text files, wall clock incl. parsing and upload; cached: "
