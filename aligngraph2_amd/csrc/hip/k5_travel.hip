@@ -533,6 +533,9 @@ __device__ __forceinline__ uint32_t classify(WalkLds &L, WalkCtx &X, uint32_t r0
         }
         base += (uint32_t)__popcll(m);
     }
+    // (both passes evaluate the records against the same marks, window and epoch — nothing is written between them; a list that
+    // came out another length than it was counted would be read short or stale: the job is reported instead and walked again)
+    if (base != n) X.overflow = 1;
     __threadfence_block();
     __syncthreads();
     return n;

@@ -631,7 +631,7 @@ extern "C" {
 int pag_process(pag_graph *g, const pag_build_input *in, pag_build_stats *stats) {
     int rc = check_process_args(g, in);
     if (rc != PAG_OK) return rc;
-    const bool timing = getenv("PAGRAPH_TIMING") != nullptr;
+    const bool timing = env_timing();
     const auto wall0 = std::chrono::steady_clock::now();
     auto wall_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(); };
     PAG_HIP_TRY(hipSetDevice(g->device));
@@ -662,7 +662,7 @@ extern "C" int pag_reserve_walk_arena(pag_graph *g, uint64_t contig_bases) {
     size_t free_b = 0, total_b = 0;
     // (the same cap as pag_travel's own estimate: an arena reserved here must not be thrown away there as too small)
     // (processes that share the device — PAG_DEVICE_SHARERS, the one-GPU test box — share that cap)
-    const size_t sharers = std::getenv("PAG_DEVICE_SHARERS") ? (size_t)std::max(1, std::atoi(std::getenv("PAG_DEVICE_SHARERS"))) : 1;
+    const size_t sharers = env_device_sharers();
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5 / sharers);
     // the pinned memory the fetched paths of the walks' jobs land in (64 MB chunks kept by the handle, pag_travel's
     // fetch_alloc): ~14 bytes per contig base at sequencing coverage; a cold process otherwise pins them one by one between

@@ -10,6 +10,12 @@
 
 namespace pagdev {
 
+// ---------------------------------------------------------------- environment (host side; read where it is asked for: tests set it between calls)
+// PAGRAPH_TIMING: stage timers on stderr.  PAG_DEVICE_SHARERS=<n>: processes that share the device (the one-GPU test boxes run
+// the ranks of a node that way): grids and memory budgets are a share of it.
+bool env_timing();
+size_t env_device_sharers();
+
 // ---------------------------------------------------------------- error plumbing (host side)
 void set_error(const char *fmt, ...);
 const char *last_error();
@@ -91,6 +97,9 @@ int scan_u32_to_u64(const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *tot
 
 // stable LSD radix sort of (u32 key, u64 value) pairs on key bits [first_bit, first_bit + key_bits).  Ping-pongs
 // between (k0, v0) and (k1, v1); returns in *result_in_0 which pair holds the result.  tmp: sort_tmp_bytes(n).
+// ASYNCHRONOUS on stream s unless ms_dominant_kernel is given (the timing reads events and waits for the stream): the result,
+// both pairs and tmp belong to the stream until the caller has ordered behind it — on the same stream, or after a
+// synchronisation before the host or another stream touches them.  (Every caller continues on s.)
 size_t sort_tmp_bytes(uint64_t n);
 int sort_pairs(uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, uint64_t n, int key_bits, void *tmp,
                int *result_in_0, hipStream_t s, float *ms_dominant_kernel, int *n_passes, int first_bit = 0);

@@ -629,6 +629,10 @@ struct XchgGuard {  // (an error return between begin and end must not leave a j
     Xchg &X;
     ~XchgGuard() {
         if (X.active && !X.c->use_rccl && X.th.joinable()) X.th.join();
+        // (RCCL: the grouped sends / receives of an exchange that was begun and never ended read and write the chunk buffers the
+        // caller is about to free — they are waited for first; a peer that has died makes this wait end with the communicator's
+        // own error, which the caller is returning anyway)
+        if (X.active && X.c->use_rccl) (void)hipStreamSynchronize(X.c->stream);
         if (X.ev0) hipEventDestroy(X.ev0);
         if (X.ev1) hipEventDestroy(X.ev1);
     }
@@ -674,7 +678,7 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
     int rc;
     // PAG_SHARD_TIMING=1: one line per rank and block on stderr — seconds per stage of this call (the device idle at every
     // boundary) and the payload that left the rank in each of the two bulk exchanges
-    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    const bool timing = env_timing();
     double lap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t wire[2] = {0, 0};
     auto now = [&]() {
@@ -865,7 +869,10 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
                     const size_t want = need + need / 2 + 256;
                     PAG_HIP_TRY(hipMalloc(&np, want));
                     if (b.sl->p && at[a]) PAG_HIP_TRY(hipMemcpy(np, b.sl->p, at[a] * arrs[a].esz, hipMemcpyDeviceToDevice));
-                    if (b.sl->p) hipFree(b.sl->p);
+                    if (b.sl->p) {  // (as DevBuf::alloc: nothing is freed under a resident walker grid)
+                        if (g->defer_free) g->deferred.push_back(b.sl->p);
+                        else hipFree(b.sl->p);
+                    }
                     b.sl->p = np;
                     b.sl->cap = want;
                     if (piece[(size_t)me][a]) piece[(size_t)me][a] = b.sl->p;  // (this rank's own piece lies at the front of these arrays)
@@ -942,7 +949,10 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
                 const size_t want = need + need / 2 + 256;
                 PAG_HIP_TRY(hipMalloc(&np, want));
                 if (b.sl->p && at[a]) PAG_HIP_TRY(hipMemcpy(np, b.sl->p, at[a] * arrs[a].esz, hipMemcpyDeviceToDevice));
-                if (b.sl->p) hipFree(b.sl->p);
+                if (b.sl->p) {
+                    if (g->defer_free) g->deferred.push_back(b.sl->p);
+                    else hipFree(b.sl->p);
+                }
                 b.sl->p = np;
                 b.sl->cap = want;
             }

@@ -10,11 +10,20 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "pag_device.hpp"
 
 namespace pagdev {
 
 static thread_local char g_err[512] = "";
+bool env_timing() { return std::getenv("PAGRAPH_TIMING") != nullptr; }
+size_t env_device_sharers() {
+    const char *e = std::getenv("PAG_DEVICE_SHARERS");
+    return e ? (size_t)std::max(1, std::atoi(e)) : 1;
+}
+
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

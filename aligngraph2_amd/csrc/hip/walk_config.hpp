@@ -7,6 +7,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+
+#include "pag_device.hpp"
 namespace pagdev {
 
 struct WalkConfig {
@@ -53,7 +55,7 @@ struct WalkConfig {
             c.view_margin_set = true;
             c.view_margin = (uint64_t)std::max(0ll, std::atoll(e));
         }
-        c.timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+        c.timing = env_timing();
         c.walk_debug = std::getenv("PAG_WALK_DEBUG") != nullptr;
         c.walk_trace = std::getenv("PAG_WALK_TRACE") != nullptr;
         c.stitch_threads = std::min(c.stitch_threads, std::max(1u, std::thread::hardware_concurrency()));

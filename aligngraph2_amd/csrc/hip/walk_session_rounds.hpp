@@ -639,7 +639,7 @@ struct WalkRounds : WalkJobs {
                 want += chain * 3 / 2 + (seg * (n_seg + 8) + lseg * n_lseg) * 3 / 2;
             }
             size_t free_b = 0, total_b = 0;
-            const size_t sharers = std::getenv("PAG_DEVICE_SHARERS") ? (size_t)std::max(1, std::atoi(std::getenv("PAG_DEVICE_SHARERS"))) : 1;
+            const size_t sharers = env_device_sharers();
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, (free_b + g->walk_arena_cap) * 2 / 5 / sharers);
             if (g->walk_arena_cap < want / 10 * 7) {  // (an arena that is there — pag_reserve_walk_arena, an earlier call — is kept
                                                       // unless it is much too small: what does not fit goes to the slots)

@@ -40,7 +40,7 @@ struct WalkerGrid {
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
         const int per_cu = std::getenv("PAG_WALK_WAVES_PER_CU") ? std::max(1, std::atoi(std::getenv("PAG_WALK_WAVES_PER_CU"))) : trav_walk_waves_per_cu();
-        const int sharers = std::getenv("PAG_DEVICE_SHARERS") ? std::max(1, std::atoi(std::getenv("PAG_DEVICE_SHARERS"))) : 1;
+        const int sharers = (int)env_device_sharers();
         const int n_xcd = 8;
         return (uint32_t)std::max(n_xcd, n_cu * per_cu / sharers);
     }

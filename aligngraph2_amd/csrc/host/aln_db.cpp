@@ -1,3 +1,4 @@
+#include "host_threads.hpp"
 #include "aln_db.hpp"
 
 #include <sys/stat.h>
@@ -128,7 +129,7 @@ namespace {
 double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 bool AlnDb::loadMecatParallel(const std::string &path, const AlnRecordFilter &filter) {
-    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    const bool timing = pagh::envTiming();
     const double t0 = nowS();
     FileLines fl;
     if (!fl.load(path)) return false;

@@ -61,7 +61,7 @@ std::set<std::pair<std::string, bool>> assemble(const std::string &outDir, const
                                                 std::vector<TravelSequence> &travelled, std::ostream *logTo, const AssembleShare *share) {
     (void)minLen;     // (both only steer the walk itself, which has already happened: PAlgorithm::travelSequence on the device)
     (void)threadNum;
-    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    const bool timing = pagh::envTiming();
     auto nowMs = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tLap = nowMs();
     auto lap = [&](const char *what) {

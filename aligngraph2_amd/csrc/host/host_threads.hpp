@@ -10,6 +10,15 @@
 
 namespace pagh {
 
+// PAGRAPH_TIMING: lap timers of the host stages on stderr
+inline bool envTiming() { return std::getenv("PAGRAPH_TIMING") != nullptr; }
+// PAGH_OVERLAP_THREADS=<n>: host threads of a block's host half while it runs beside the next block's device work (0: not given)
+inline unsigned envOverlapThreads() {
+    const char *e = std::getenv("PAGH_OVERLAP_THREADS");
+    return e ? static_cast<unsigned>(std::max(1, std::atoi(e))) : 0u;
+}
+
+
 inline unsigned usableCpus() {
     static const unsigned n = [] {
         unsigned hw = std::max(1u, std::thread::hardware_concurrency());

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "host_threads.hpp"
 #include "pagraph_hip.h"
 #include "seq_db.hpp"
 
@@ -174,7 +175,7 @@ int main(int argc, char **argv) {
             }
         }
         of.write(reinterpret_cast<const char *>(buf.data()), static_cast<std::streamsize>(buf.size() * 8));
-        if (std::getenv("PAGRAPH_TIMING"))
+        if (pagh::envTiming())
             std::fprintf(stderr, "[timing] kmer_counter: %llu reads, min abundance %llu, %llu solid k-mers, count %.2f ms, select %.2f ms\n",
                          (unsigned long long)reads.size(), (unsigned long long)res.min_abundance, (unsigned long long)res.n_solid,
                          res.ms_count, res.ms_select);

@@ -1,3 +1,4 @@
+#include "host_threads.hpp"
 #include "pagraph_driver.hpp"
 
 #include <sstream>
@@ -132,7 +133,7 @@ double nowSec() { return std::chrono::duration<double>(std::chrono::steady_clock
 }  // namespace
 
 int runPagraph(int argc, char **argv, GraphBackend &backend) {
-    const bool timing = std::getenv("PAGRAPH_TIMING") != nullptr;
+    const bool timing = pagh::envTiming();
     double tPrev = nowSec();
     const double tStart = tPrev;
     auto lap = [&](const char *what) {
@@ -419,7 +420,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 while (nextNo < configs.size() && !mine(nextNo)) ++nextNo;
                 unsigned poolThreads = 0;
                 if (nextNo < configs.size())
-                    poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? static_cast<unsigned>(std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS")))) : 20u;  // (traverse_api.cpp: the measurement)
+                    poolThreads = pagh::envOverlapThreads() ? pagh::envOverlapThreads() : 20u;  // (traverse_api.cpp: the measurement)
                 // (which contigs this rank walked: a copy — the backend's plan is the next block's by the time the thread reads it)
                 std::vector<char> walkedHere;
                 if (rankDumps) {

@@ -11,6 +11,7 @@
 #include <string>
 #include <thread>
 
+#include "host_threads.hpp"
 #include "assembly.hpp"
 #include "host_graph.hpp"
 #include "pagraph_host.h"
@@ -111,7 +112,7 @@ int pagh_assemble_paths(pag_graph *cache_key, uint32_t k, const pag_seqs *ctgs, 
         const double tg0 = nowMs();
         pagh::buildPathGraph(views, k, hc.graph, hc.travelled, host_threads);
         const double t1 = nowMs();
-        if (std::getenv("PAGRAPH_TIMING")) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
+        if (pagh::envTiming()) std::fprintf(stderr, "[timing] buildPathGraph %.1f ms\n", t1 - tg0);
         pagh::AssembleStats as;
         pagh::assemble(out_dir, prefix ? prefix : "0_", hc.graph, contigDb, refDb, ctgMapper, refMapper, ctgSet, epsilon * 2, 0.15,
                        0.90, min_len, ref_threads, host_threads, &as, true, hc.travelled);
@@ -171,7 +172,7 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
     hc.tst.ms_compact += msPrep;
     hc.tst.ms_total += msPrep;
     const pag_travel_stats &tst = hc.tst;
-    if (std::getenv("PAGRAPH_TIMING"))
+    if (pagh::envTiming())
         std::fprintf(stderr, "[timing] pag_travel total %.1f ms compact %.1f ms walk %.1f ms rounds %llu jobs %llu steps %llu classify %llu probes %llu records %llu\n", tst.ms_total,
                      tst.ms_compact, tst.ms_walk, (unsigned long long)tst.rounds, (unsigned long long)tst.jobs,
                      (unsigned long long)tst.walk_steps, (unsigned long long)tst.classify_calls, (unsigned long long)tst.probes,
@@ -193,7 +194,7 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
         }
     hc.tBegin = t0;
     hc.tHost = nowMs();
-    if (std::getenv("PAGRAPH_TIMING"))
+    if (pagh::envTiming())
         std::fprintf(stderr, "[timing] traverse_begin: successor stage %.1f ms, wait for the previous host half %.1f ms, pag_travel %.1f ms, views %.1f ms\n", tA - t0, tB - tA,
                      tC - tB, hc.tHost - tC);
     hc.pending = true;
@@ -212,8 +213,8 @@ static int traverse_begin(pag_graph *g, uint32_t k, const pag_seqs *ctgs, const 
         // threads takes 157-164 ms beside it: the next walks WAITED for it, 10-21 ms per block.  8 / 10 / 12 / 14 / 16 / 20 / 24 / 32
         // threads: wait 72 / 39 / 21 / 3 / 0-6 / 1 / 0 / 2 ms, host half 217 / 192 / 157-164 / 145 / 126-143 / 127 / 114 / 102 ms
         // (profiles/r05_overlap_threads_probe.txt); the walks themselves begin after the join and are not touched by the pool)
-        static const unsigned cap = std::getenv("PAGH_OVERLAP_THREADS") ? (unsigned)std::max(1, std::atoi(std::getenv("PAGH_OVERLAP_THREADS"))) : 20u;
-        poolThreads = std::getenv("PAGH_OVERLAP_THREADS") ? cap : std::min(cap, std::max(4u, pagh::usableCpus()));  // (ranks of a node share its cores: host_threads.hpp)
+        static const unsigned asked = pagh::envOverlapThreads();
+        poolThreads = asked ? asked : std::min(20u, std::max(4u, pagh::usableCpus()));  // (ranks of a node share its cores: host_threads.hpp)
     }
     hc.worker = std::thread([=]() {
         h->rc = pagh_assemble_paths(g, k, ctgs, ctg_names, refs, ref_names, ctg_orient, h->paths.data(), h->lens.data(), ref_threads, epsilon,

@@ -111,7 +111,7 @@ def main():
     n_bases = w.n_bases
     del w
     rec = {"workload": f"{args.reads} x 10 kb reads vs {args.ref_len / 1e6:g} Mb reference, k=14, epsilon=10 (BASELINE configs[1], seed 2), text inputs in /dev/shm",
-           "read_bases": n_bases, "host_cores": os.cpu_count(), "cgroup_cpu_quota": _quota(), "measured": time.strftime("round 5, %Y-%m-%d"),
+           "read_bases": n_bases, "host_cores": os.cpu_count(), "cgroup_cpu_quota": _quota(), "measured": time.strftime("round 6, %Y-%m-%d"),
            "generate_and_write_s": time.time() - t0,
            "input_bytes": {f: os.path.getsize(os.path.join(d, f)) for f in sorted(os.listdir(d))}}
     print(rec, flush=True)
