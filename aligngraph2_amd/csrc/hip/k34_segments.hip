@@ -23,12 +23,22 @@
 // segment did until round 6 — one global round trip per item then, 106 + 94 ms for K3 + K4 on a 62.5 Mb block at 40x coverage,
 // where most k-mer segments are longer than 32 records (the short path's limit until then).
 #include <algorithm>
+#include <type_traits>
 
 #include "pag_device.hpp"
 
 namespace pagdev {
 
-constexpr uint32_t SHORT_MAX = 64;
+// The short path in two widths, chosen per launch from the stream's average segment length (launch_cluster / launch_edges): 32-bit
+// masks and 480 owned records per 512-thread tile where most segments are short (20x coverage: ~6 records), 64-bit masks and
+// 448 owned records where many are longer than 32 (30x and more).  Same results either way: a segment longer than the width
+// goes to the long path.
+template <int W>
+struct ShortW {
+    using Mask = typename std::conditional<W == 32, uint32_t, uint64_t>::type;
+    static constexpr uint32_t MAX = W;
+    static constexpr int OWN = 512 - W;
+};
 
 __device__ __forceinline__ bool coord_sim(uint32_t a, uint32_t b, uint32_t eps) {
     if (a == 0 || b == 0) return a == 0 && b == 0;
@@ -71,12 +81,12 @@ __device__ __forceinline__ void block_flush3(uint64_t a, uint64_t b, uint64_t c,
 //   scan order; a leader's output slot is its rank by (ctg, ref) among the leaders.
 // All lanes of a wave are busy and the trip counts are the segment length, instead of one lane in ~5
 // running length^2/2 dependent compares (the earlier layout was VALU-issue bound at 45 ms for the C2 set).
-constexpr int SEG_OWN = 448;
-constexpr int SEG_TILE = SEG_OWN + (int)SHORT_MAX;  // threads per block = staged records
+constexpr int SEG_TILE = 512;  // threads per block = staged records = owned records + the look-ahead halo of the short path's width
+template <int W>
 struct SegLds {
     uint64_t flag[SEG_TILE / 64 + 1];  // bit x = record x starts a k-mer segment; word 8 covers record SEG_TILE
     uint64_t val[SEG_TILE];
-    uint64_t m[SEG_TILE];
+    typename ShortW<W>::Mask m[SEG_TILE];
     uint32_t cnt[SEG_TILE];
 };
 
@@ -112,7 +122,8 @@ __device__ __forceinline__ void seg_request(SegRegs &R, const uint32_t *__restri
         }
     }
 }
-__device__ __forceinline__ void seg_stage(SegLds &S, const SegRegs &R, uint64_t base, uint64_t n) {
+template <int W>
+__device__ __forceinline__ void seg_stage(SegLds<W> &S, const SegRegs &R, uint64_t base, uint64_t n) {
     const uint32_t t = threadIdx.x;
     const uint64_t gi = base + t;
     bool f = true;  // records past the end close the last segment
@@ -131,7 +142,10 @@ __device__ __forceinline__ void seg_stage(SegLds &S, const SegRegs &R, uint64_t 
 
 // locate record x of the staged tile inside its k-mer segment: nearest start flag at or before x and the
 // next one after it, each at most two flag words away for a short segment
-__device__ __forceinline__ SegPos seg_locate(const SegLds &S, uint32_t x, uint64_t base, uint64_t n) {
+template <int W>
+__device__ __forceinline__ SegPos seg_locate(const SegLds<W> &S, uint32_t x, uint64_t base, uint64_t n) {
+    constexpr uint32_t SHORT_MAX = ShortW<W>::MAX;
+    constexpr int SEG_OWN = ShortW<W>::OWN;
     SegPos r;
     r.o = 0;
     r.s = x;
@@ -164,10 +178,13 @@ __device__ __forceinline__ SegPos seg_locate(const SegLds &S, uint32_t x, uint64
     return r;
 }
 
+template <int W>
 __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                          uint64_t n, uint32_t eps, ClusterOut out,
                                                          uint64_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
-    __shared__ SegLds S;
+    using Mask = typename ShortW<W>::Mask;
+    constexpr int SEG_OWN = ShortW<W>::OWN;
+    __shared__ SegLds<W> S;
     uint64_t n_ctg = 0, n_all = 0, n_seg = 0;
     const uint32_t t = threadIdx.x;
     const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
@@ -181,21 +198,21 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
         __syncthreads();
         const SegPos P = seg_locate(S, t, base, n);
         const uint64_t v = S.val[t];
-        uint64_t M = 0;
+        Mask M = 0;
         if (P.active) {
-            for (uint32_t j = 0; j < P.o; ++j) M |= (uint64_t)pos_sim(v, S.val[P.s + j], eps) << j;
+            for (uint32_t j = 0; j < P.o; ++j) M |= (Mask)pos_sim(v, S.val[P.s + j], eps) << j;
         }
         S.m[t] = M;
         S.cnt[t] = 1;
         __syncthreads();
-        uint64_t L = 0;
+        Mask L = 0;
         bool leader = false;
         uint32_t rank = 0;
         if (P.active) {
-            for (uint32_t j = 0; j < P.len; ++j) L |= (uint64_t)((S.m[P.s + j] & L) == 0) << j;
-            leader = (L >> P.o) & 1ull;
+            for (uint32_t j = 0; j < P.len; ++j) L |= (Mask)((S.m[P.s + j] & L) == 0) << j;
+            leader = (L >> P.o) & (Mask)1;
             if (!leader) {
-                atomicAdd(&S.cnt[P.s + (uint32_t)__builtin_ctzll(M & L)], 1u);
+                atomicAdd(&S.cnt[P.s + (uint32_t)__builtin_ctzll((uint64_t)(M & L))], 1u);
             } else {
                 // sortWithCount: slot = rank by (ctg, ref) among the leaders (distinct keys)
                 for (uint32_t j = 0; j < P.len; ++j) rank += ((L >> j) & 1u) && S.val[P.s + j] < v;
@@ -221,12 +238,12 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
                     long_list[slot] = base + t;
                     seglen = 0xFFFFFFFFu;  // filled in by cluster_long
                 } else {
-                    seglen = (uint32_t)__popcll(L);
+                    seglen = (uint32_t)__popcll((uint64_t)L);
                     n_all += seglen;
                 }
                 out.seg_len[base + t] = seglen;
             } else if (P.active) {
-                out.seg_len[base + t] = P.o < (uint32_t)__popcll(L) ? (SEG_LEADER | P.o) : 0u;
+                out.seg_len[base + t] = P.o < (uint32_t)__popcll((uint64_t)L) ? (SEG_LEADER | P.o) : 0u;
             }
         }
     }
@@ -387,12 +404,17 @@ __global__ __launch_bounds__(64) void cluster_long(const uint32_t *__restrict__ 
 }
 
 int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, uint32_t eps, ClusterOut out,
-                   uint64_t *long_list, uint32_t *long_count, hipStream_t s) {
+                   uint64_t *long_list, uint32_t *long_count, hipStream_t s, bool wide) {
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_OWN - 1) / SEG_OWN, 256 * 16);
-    cluster_short<<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, eps, out, long_list, long_count);
+    if (wide) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + ShortW<64>::OWN - 1) / ShortW<64>::OWN, 256 * 16);
+        cluster_short<64><<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, eps, out, long_list, long_count);
+    } else {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + ShortW<32>::OWN - 1) / ShortW<32>::OWN, 256 * 16);
+        cluster_short<32><<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, eps, out, long_list, long_count);
+    }
     // scratch: u64[n] followed by u32[n] (the idle sort ping-pong buffers)
     cluster_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, (uint32_t *)(scratch + n), n, eps, out,
                                                  long_list, long_count);
@@ -403,10 +425,13 @@ int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64
 // ------------------------------------------------------------------------------------------------ K4
 // Same record-per-thread layout as cluster_short: a record survives iff it is the smallest (value, index) of its
 // (to, step) group, and its output slot is the number of surviving records with a smaller value.
+template <int W>
 __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restrict__ key, uint64_t *__restrict__ val,
                                                        uint64_t n, EdgeOut out, uint64_t *__restrict__ long_list,
                                                        uint32_t *__restrict__ long_count) {
-    __shared__ SegLds S;
+    using Mask = typename ShortW<W>::Mask;
+    constexpr int SEG_OWN = ShortW<W>::OWN;
+    __shared__ SegLds<W> S;
     uint64_t n_grp = 0, n_grp1 = 0;
     const uint32_t t = threadIdx.x;
     const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
@@ -428,7 +453,7 @@ __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restri
                 kept = kept && !((u >> 1) == (v >> 1) && (u < v || (u == v && j < P.o)));
             }
         }
-        S.m[t] = kept ? 1ull : 0ull;
+        S.m[t] = kept ? (Mask)1 : (Mask)0;
         __syncthreads();
         uint32_t p = 0;
         if (P.active && (kept || P.head)) {
@@ -535,12 +560,17 @@ __global__ __launch_bounds__(64) void edges_long(const uint32_t *__restrict__ ke
 }
 
 int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, EdgeOut out, uint64_t *long_list,
-                 uint32_t *long_count, hipStream_t s) {
+                 uint32_t *long_count, hipStream_t s, bool wide) {
     PAG_HIP_TRY(hipMemsetAsync(long_count, 0, sizeof(uint32_t), s));
     PAG_HIP_TRY(hipMemsetAsync(out.counters, 0, 4 * sizeof(uint64_t), s));
     if (n == 0) return PAG_OK;
-    unsigned grid = (unsigned)std::min<uint64_t>((n + SEG_OWN - 1) / SEG_OWN, 256 * 16);
-    edges_short<<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, out, long_list, long_count);
+    if (wide) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + ShortW<64>::OWN - 1) / ShortW<64>::OWN, 256 * 16);
+        edges_short<64><<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, out, long_list, long_count);
+    } else {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + ShortW<32>::OWN - 1) / ShortW<32>::OWN, 256 * 16);
+        edges_short<32><<<dim3(grid), dim3(SEG_TILE), 0, s>>>(key, val, n, out, long_list, long_count);
+    }
     edges_long<<<dim3(1024), dim3(64), 0, s>>>(key, val, scratch, n, out, long_list, long_count);
     PAG_HIP_TRY(hipGetLastError());
     return PAG_OK;

@@ -524,13 +524,15 @@ int build_stage(pag_graph *g, uint32_t eps, const Extracted &x, pag_build_stats 
     if ((rc = b_ctr.alloc(128))) return rc;
     uint64_t *ctr_dev = b_ctr.as<uint64_t>();  // [0..3] cluster counters, [4..7] edge counters
     ClusterOut co{b_tseg.as<uint32_t>(), b_tcnt.as<uint16_t>(), ctr_dev};
+    // (the short path's width: 64-record masks where the average k-mer segment is long — 30x coverage and more; results do not depend on it)
+    const bool wide = g->n_solid != 0 && T / g->n_solid > 12;
     if ((rc = launch_cluster(tk->as<uint32_t>(), tv->as<uint64_t>(), t_scratch, T, eps, co, b_long.as<uint64_t>(),
-                             b_lcnt.as<uint32_t>(), s)))
+                             b_lcnt.as<uint32_t>(), s, wide)))
         return rc;
     PAG_HIP_TRY(hipEventRecord(ev[2], s));
     EdgeOut eo{b_eseg.as<uint32_t>(), ctr_dev + 4};
     if ((rc = launch_edges(ek->as<uint32_t>(), evb->as<uint64_t>(), e_scratch, E, eo, b_long.as<uint64_t>(),
-                           b_lcnt.as<uint32_t>(), s)))
+                           b_lcnt.as<uint32_t>(), s, wide)))
         return rc;
     uint64_t ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PAG_HIP_TRY(hipMemcpyAsync(ctr, b_ctr.p, 64, hipMemcpyDeviceToHost, s));

@@ -165,8 +165,9 @@ struct ClusterOut {
     uint16_t *cnt;      // [n] abundance of the leader stored at i
     uint64_t *counters; // device: [0] leaders with ctg != 0, [1] all leaders, [2] segments
 };
+// (wide: the short path takes segments of up to 64 records instead of 32 — for streams whose segments are long, k34_segments.hip)
 int launch_cluster(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, uint32_t eps, ClusterOut out,
-                   uint64_t *long_list, uint32_t *long_count, hipStream_t s);
+                   uint64_t *long_list, uint32_t *long_count, hipStream_t s, bool wide);
 
 // sort + unique the (to, step, pass-tag) payloads inside each `from` segment of the sorted edge stream
 struct EdgeOut {
@@ -174,6 +175,6 @@ struct EdgeOut {
     uint64_t *counters; // device: [0] unique (to,step) groups, [1] groups whose first member is pass 1
 };
 int launch_edges(const uint32_t *key, uint64_t *val, uint64_t *scratch, uint64_t n, EdgeOut out, uint64_t *long_list,
-                 uint32_t *long_count, hipStream_t s);
+                 uint32_t *long_count, hipStream_t s, bool wide);
 
 }  // namespace pagdev

@@ -40,6 +40,7 @@ static bool psim(uint64_t x, uint64_t y, uint32_t eps) {
 int main(int argc, char **argv) {
     const uint64_t n_seg_target = argc > 1 ? strtoull(argv[1], nullptr, 10) : 20000;
     const unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1;
+    const bool wide = argc > 3 ? atoi(argv[3]) != 0 : false;  // (the short path with 64-record masks instead of 32)
     const uint32_t eps = 10;
     std::mt19937_64 rng(seed);
     std::vector<uint32_t> key;
@@ -134,7 +135,7 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(d_val, val.data(), n * 8, hipMemcpyHostToDevice));
         CK(hipMemset(d_seg, 0xEE, n * 4));
         pagdev::ClusterOut co{d_seg, d_cnt, d_ctr};
-        if (pagdev::launch_cluster(d_key, d_val, d_scr, n, eps, co, d_ll, d_lc, 0) != 0) return 2;
+        if (pagdev::launch_cluster(d_key, d_val, d_scr, n, eps, co, d_ll, d_lc, 0, wide) != 0) return 2;
         CK(hipDeviceSynchronize());
         std::vector<uint32_t> seg(n);
         std::vector<uint64_t> v(n), ctr(4);
@@ -168,7 +169,7 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(d_val, eval.data(), n * 8, hipMemcpyHostToDevice));
         CK(hipMemset(d_seg, 0xEE, n * 4));
         pagdev::EdgeOut eo{d_seg, d_ctr};
-        if (pagdev::launch_edges(d_key, d_val, d_scr, n, eo, d_ll, d_lc, 0) != 0) return 2;
+        if (pagdev::launch_edges(d_key, d_val, d_scr, n, eo, d_ll, d_lc, 0, wide) != 0) return 2;
         CK(hipDeviceSynchronize());
         std::vector<uint32_t> seg(n);
         std::vector<uint64_t> v(n), ctr(4);

@@ -44,13 +44,15 @@ def test_build_matches_oracle(name, workdir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("segments,seed", [(2000, 1), (20000, 2), (300000, 3)])
-def test_segment_kernels_match_sequential_restatement(segments, seed):
-    """K3/K4 alone (short and long segments, tile halos) against a sequential greedy scan / sort-unique."""
+def test_segment_kernels_match_sequential_restatement(segments, seed, wide):
+    """K3/K4 alone (both widths of the short path, segments on both sides of every limit of the on-chip long paths, tile halos) against
+    a sequential greedy scan / sort-unique."""
     import subprocess
     exe = os.path.join(pagctl.ROOT, "tests", "harness", "bin", "seg_kernels_test")
     assert os.path.exists(exe), "run `make harness`"
-    r = subprocess.run([exe, str(segments), str(seed)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(segments), str(seed), str(wide)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
