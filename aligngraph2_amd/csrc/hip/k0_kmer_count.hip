@@ -152,9 +152,8 @@ extern "C" int pag_kmer_count(const pag_seqs *reads, int reads_on_device, uint32
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
         // The table is filled one slice of the code range per launch once it is larger than the Infinity Cache can hold beside
         // the reads (k >= 13): with a quarter of the counters live at a time the atomics stay on chip — 52 -> 39 ms at
-        // BASELINE configs[1], k = 14, the same with 8 or 16 slices (tests/kc_probe.sh).  PAG_KC_SLICES=<2^n> overrides.
-        uint32_t slices = n_codes * 4 > (128ull << 20) ? 4u : 1u;
-        if (const char *e = std::getenv("PAG_KC_SLICES")) slices = (uint32_t)std::max(1, std::atoi(e));
+        // BASELINE configs[1], k = 14, the same with 8 or 16 slices (tests/kc_probe.sh).  Tests: PAG_KC_SLICES=<2^n> runs the sliced form at small k.
+        const uint32_t slices = (uint32_t)std::max<long long>(1, env_int("PAG_KC_SLICES", n_codes * 4 > (128ull << 20) ? 4 : 1));
         uint32_t lg = 0;
         while ((1u << (lg + 1)) <= slices) ++lg;
         if (2 * k <= lg) lg = 0;

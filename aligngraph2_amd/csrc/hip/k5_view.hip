@@ -596,12 +596,11 @@ int trav_order(TravGraph G, uint32_t *key, uint64_t *val, uint32_t *key2, uint64
     if (n_zero) *n_zero = n0;
     {
         // (eight slices once the two arrays — 6 bytes per vertex — outgrow the Infinity Cache: 16.2 -> 12.5 ms at configs[1],
-        // 13.2 with four or sixteen, tests/order_probe.sh; PAG_ORDER_SLICES=<2^n> overrides)
+        // 13.2 with four or sixteen, tests/order_probe.sh; tests: PAG_ORDER_SLICES=<2^n> runs the sliced form on small graphs)
         uint32_t lg = n >= (32ull << 20) ? 3u : 0u;
-        if (const char *e = std::getenv("PAG_ORDER_SLICES")) {
-            const uint32_t want = (uint32_t)std::max(1, std::atoi(e));
+        if (const long long want = env_int("PAG_ORDER_SLICES", 0)) {
             lg = 0;
-            while ((1u << (lg + 1)) <= want) ++lg;
+            while ((1u << (lg + 1)) <= (uint32_t)std::max<long long>(1, want)) ++lg;
         }
         uint32_t bits = 1;
         while (bits < 32 && (n >> bits) != 0) ++bits;  // v < n < 2^bits

@@ -15,6 +15,7 @@ namespace pagdev {
 // the ranks of a node that way): grids and memory budgets are a share of it.
 bool env_timing();
 size_t env_device_sharers();
+long long env_int(const char *name, long long otherwise);  // the variable as an integer; `otherwise` when it is not set
 
 // ---------------------------------------------------------------- error plumbing (host side)
 void set_error(const char *fmt, ...);

@@ -236,7 +236,7 @@ struct pag_comm {
                         // (PAG_COMM_ANY_NAMESPACE=1: the ranks run in containers with PID namespaces of their own — one per GPU
                         // sharing the rendezvous directory — where /proc/<pid> of a peer is not this process's to see: a hello
                         // is then taken when the directory is the job's own fresh one, which is the launcher's to guarantee)
-                        static const bool any_ns = std::getenv("PAG_COMM_ANY_NAMESPACE") && std::atoi(std::getenv("PAG_COMM_ANY_NAMESPACE")) != 0;
+                        static const bool any_ns = pagdev::env_int("PAG_COMM_ANY_NAMESPACE", 0) != 0;
                         if (h.start != 0 && (any_ns || proc_start((long)h.pid) == h.start)) {
                             seen[r] = h;
                             break;
@@ -831,7 +831,7 @@ static int shard_run(pag_graph *g, pag_comm *c, const pag_build_input *in, const
         if ((rc = b.alloc((n_slice + n_slice / 2 + 1024) * arrs[a].esz))) return rc;
     }
     // (PAG_SHARD_PIPELINE=0: all selections first, then seven whole all-to-all(v)s, as until round 5)
-    const bool pipeline = !(std::getenv("PAG_SHARD_PIPELINE") && std::atoi(std::getenv("PAG_SHARD_PIPELINE")) == 0);
+    const bool pipeline = env_int("PAG_SHARD_PIPELINE", 1) != 0;
     uint64_t T = 0, E = 0;
     std::vector<pag_build_stats> from_owner(W);  // the statistics of what owner o selected for this rank
     DevBuf imp[7] = {DevBuf(g, 52), DevBuf(g, 53), DevBuf(g, 54), DevBuf(g, 55), DevBuf(g, 56), DevBuf(g, 57), DevBuf(g, 58)};

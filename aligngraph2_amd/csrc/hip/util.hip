@@ -19,6 +19,10 @@ namespace pagdev {
 
 static thread_local char g_err[512] = "";
 bool env_timing() { return std::getenv("PAGRAPH_TIMING") != nullptr; }
+long long env_int(const char *name, long long otherwise) {
+    const char *e = std::getenv(name);
+    return e ? std::atoll(e) : otherwise;
+}
 size_t env_device_sharers() {
     const char *e = std::getenv("PAG_DEVICE_SHARERS");
     return e ? (size_t)std::max(1, std::atoi(e)) : 1;

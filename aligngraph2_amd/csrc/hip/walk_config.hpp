@@ -37,40 +37,42 @@ struct WalkConfig {
     uint64_t seg_overlap = 1500;      // PAG_SEG_OVERLAP
     bool seg_safety_set = false;      // PAG_SEG_SAFETY
     uint64_t seg_safety = 0;
-    static bool off(const char *name) {  // set and 0
-        const char *e = std::getenv(name);
-        return e && std::atoi(e) == 0;
-    }
-    static bool u64(const char *name, uint64_t *out) {
+    static bool u64(const char *name, uint64_t *out) {  // the one place the traversal's switches are read from the environment
         const char *e = std::getenv(name);
         if (!e) return false;
         *out = std::strtoull(e, nullptr, 10);
         return true;
     }
+    static bool given(const char *name) {
+        uint64_t x;
+        return u64(name, &x);
+    }
+    static bool off(const char *name) {  // set and 0
+        uint64_t x = 1;
+        return u64(name, &x) && x == 0;
+    }
     static WalkConfig from_env() {
         WalkConfig c;
         if (const char *e = std::getenv("PAG_TRAVEL_VIEW")) c.view_whole = std::strcmp(e, "whole") == 0;
-        if (const char *e = std::getenv("PAG_VIEW_HALO")) c.view_halo = (uint64_t)std::max(0ll, std::atoll(e));
-        if (const char *e = std::getenv("PAG_VIEW_MARGIN")) {
-            c.view_margin_set = true;
-            c.view_margin = (uint64_t)std::max(0ll, std::atoll(e));
-        }
+        u64("PAG_VIEW_HALO", &c.view_halo);
+        c.view_margin_set = u64("PAG_VIEW_MARGIN", &c.view_margin);
         c.timing = env_timing();
-        c.walk_debug = std::getenv("PAG_WALK_DEBUG") != nullptr;
-        c.walk_trace = std::getenv("PAG_WALK_TRACE") != nullptr;
+        c.walk_debug = given("PAG_WALK_DEBUG");
+        c.walk_trace = given("PAG_WALK_TRACE");
         c.stitch_threads = std::min(c.stitch_threads, std::max(1u, std::thread::hardware_concurrency()));
-        if (const char *e = std::getenv("PAG_WALK_IDLE_S")) c.idle_limit_ms = std::atof(e) * 1000.0;
-        c.check_aggs = std::getenv("PAG_DEBUG_CHECK_AGGS") != nullptr;
-        if (const char *e = std::getenv("PAG_DEBUG_SEQCAP")) c.debug_seqcap = std::max(16, std::atoi(e));
-        if (const char *e = std::getenv("PAG_DEBUG_RING")) c.debug_ring = std::max(4, std::atoi(e));
+        uint64_t x = 0;
+        if (u64("PAG_WALK_IDLE_S", &x)) c.idle_limit_ms = (double)x * 1000.0;
+        c.check_aggs = given("PAG_DEBUG_CHECK_AGGS");
+        if (u64("PAG_DEBUG_SEQCAP", &x)) c.debug_seqcap = (int)std::max<uint64_t>(16, std::min<uint64_t>(x, 1u << 30));
+        if (u64("PAG_DEBUG_RING", &x)) c.debug_ring = (int)std::max<uint64_t>(4, std::min<uint64_t>(x, 1u << 30));
         u64("PAG_DEBUG_EMIT_CAP", &c.debug_emit_cap);
         c.pieces = !off("PAG_WALK_PIECES");
         c.leap_pieces = !off("PAG_LEAP_PIECES");
-        c.force_exact = std::getenv("PAG_WALK_EXACT") != nullptr;
+        c.force_exact = given("PAG_WALK_EXACT");
         u64("PAG_SEG_LEN", &c.seg_len);
         u64("PAG_SEG_OVERLAP", &c.seg_overlap);
         c.seg_safety_set = u64("PAG_SEG_SAFETY", &c.seg_safety);
-        if (const char *e = std::getenv("PAG_SUCC_HEAVY")) c.succ_heavy = (uint32_t)std::min(1 << 24, std::max(0, std::atoi(e)));
+        if (u64("PAG_SUCC_HEAVY", &x)) c.succ_heavy = (uint32_t)std::min<uint64_t>(1u << 24, x);
         return c;
     }
 };

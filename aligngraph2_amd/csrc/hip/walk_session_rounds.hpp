@@ -718,6 +718,7 @@ struct WalkRounds : WalkJobs {
         lap("ring order");
         if (n_live) {
             walkers.init(g, G, hjobs, houts, hdone, hq, QCAP, k);
+            walkers.trace = wtrace;
             if ((rc = publish())) return fail(rc);  // (the jobs' buffers are ready, the rings are visible)
             lap("marks cleared, rings published");
             if ((rc = walkers.ensure(n_live))) {

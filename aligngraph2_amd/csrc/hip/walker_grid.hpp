@@ -33,13 +33,14 @@ struct WalkerGrid {
     uint32_t launched = 0;    // waves started by this session
     uint32_t launches = 0;
     bool up = false;
+    bool trace = false;       // (WalkConfig::walk_trace: the launches are reported on stderr)
 
     // how many waves the device should carry for this process
     static uint32_t default_waves(int device) {
         if (const char *e = std::getenv("PAG_WALK_WAVES")) return (uint32_t)std::max(1, std::atoi(e));
         int n_cu = 256;
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
-        const int per_cu = std::getenv("PAG_WALK_WAVES_PER_CU") ? std::max(1, std::atoi(std::getenv("PAG_WALK_WAVES_PER_CU"))) : trav_walk_waves_per_cu();
+        const int per_cu = std::max(1, (int)env_int("PAG_WALK_WAVES_PER_CU", trav_walk_waves_per_cu()));
         const int sharers = (int)env_device_sharers();
         const int n_xcd = 8;
         return (uint32_t)std::max(n_xcd, n_cu * per_cu / sharers);
@@ -59,7 +60,7 @@ struct WalkerGrid {
         // the pool's first streams are made here, once per handle: creating one costs ~6 ms (measured, round 5), and a pool that
         // grew inside the walks paid that in the tail of a block, on the control thread, with finished jobs waiting
         prepare_streams(g, 4);
-        const double idle_us = std::getenv("PAG_WALK_IDLE_US") ? std::max(1.0, std::atof(std::getenv("PAG_WALK_IDLE_US"))) : 2000.0;
+        const double idle_us = (double)std::max<long long>(1, env_int("PAG_WALK_IDLE_US", 2000));
         idle_ticks = (uint64_t)(idle_us * 100.0);
         idle_ticks |= 1ull << 63;  // (the walker waves raise their issue priority: see k_walk_persistent)
         launched = launches = 0;
@@ -125,7 +126,7 @@ struct WalkerGrid {
         const bool drained = hipStreamQuery(st) == hipSuccess;
         (void)hipGetLastError();
         trav_launch_walk_persistent(G, jobs, outs, done, q, g->wq_next, cap, k, n, idle_ticks, st);
-        if (std::getenv("PAG_WALK_TRACE")) {
+        if (trace) {
             const auto tq2 = std::chrono::steady_clock::now();
             std::fprintf(stderr, "[trace] walker launch %u: %u waves on stream %p (%s, pool of %zu), have %u, picking the stream %.3f ms, the launch call %.3f ms\n", launches, n, (void *)st,
                          drained ? "drained" : "NOT drained", g->walk_streams.size(), have(), std::chrono::duration<double, std::milli>(tq1 - tq0).count(),

@@ -1,6 +1,7 @@
 #include "hip_backend.hpp"
 
 #include "aln_db.hpp"
+#include "host_threads.hpp"
 #include "path_graph.hpp"
 #include "shard_plan.hpp"
 
@@ -34,8 +35,8 @@ public:
         if (!sh || !*sh) return;
         int r = 0, n = 1;
         if (std::strcmp(sh, "env") == 0) {
-            r = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0;
-            n = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
+            r = static_cast<int>(envInt("RANK", 0));
+            n = static_cast<int>(envInt("WORLD_SIZE", 1));
         } else if (std::sscanf(sh, "%d/%d", &r, &n) != 2) {
             throw std::runtime_error("PAGRAPH_SHARD must be r/N or env");
         }
@@ -82,7 +83,7 @@ public:
             const std::int32_t mine = c.second ? PAG_ORIENT_FORWARD : PAG_ORIENT_REVERSE;
             o = (o == PAG_ORIENT_NONE || o == mine) ? mine : PAG_ORIENT_BOTH;
         }
-        const std::uint64_t halo = std::getenv("PAG_SHARD_HALO") ? std::strtoull(std::getenv("PAG_SHARD_HALO"), nullptr, 10) : 200000;
+        const std::uint64_t halo = static_cast<std::uint64_t>(envInt("PAG_SHARD_HALO", 200000));
         plan_ = planShards(raw, orient, world_, halo, 0.90);
     }
     void process(const pag_build_input &in, pag_build_stats &stats) override {

@@ -10,6 +10,11 @@
 
 namespace pagh {
 
+// a variable of the environment as an integer; `otherwise` when it is not set
+inline long long envInt(const char *name, long long otherwise) {
+    const char *e = std::getenv(name);
+    return e ? std::atoll(e) : otherwise;
+}
 // PAGRAPH_TIMING: lap timers of the host stages on stderr
 inline bool envTiming() { return std::getenv("PAGRAPH_TIMING") != nullptr; }
 // PAGH_OVERLAP_THREADS=<n>: host threads of a block's host half while it runs beside the next block's device work (0: not given)

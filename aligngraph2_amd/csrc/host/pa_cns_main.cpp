@@ -662,7 +662,8 @@ int main(int argc, char **argv) {
         // a part is a serial chain of dependent accesses, the device wins by running thousands side by side, host threads win on
         // the few hundred parts of one contig of the pipeline (AlignGraph2.py:503 calls pa_cns once per new contig;
         // profiles/r06_pa_cns_timing.json).
-        std::string backend = std::getenv("PA_CNS_BACKEND") ? std::getenv("PA_CNS_BACKEND") : "auto";
+        const char *backendEnv = std::getenv("PA_CNS_BACKEND");
+        std::string backend = backendEnv ? backendEnv : "auto";
         if (backend == "auto") backend = partNum >= kDevicePartsMin ? "hip" : "flat";
         if (backend != "hip" && backend != "flat" && backend != "host") throw std::runtime_error("PA_CNS_BACKEND must be hip, flat, host or auto");
         const bool onHost = backend == "host";
@@ -753,7 +754,7 @@ int main(int argc, char **argv) {
             std::vector<std::uint32_t> outLen(partNum, 0);
             std::vector<std::int32_t> partErr(partNum, 0);
             if (backend == "hip") {
-                const int device = std::getenv("PAGRAPH_DEVICE") ? std::atoi(std::getenv("PAGRAPH_DEVICE")) : 0;
+                const int device = static_cast<int>(pagh::envInt("PAGRAPH_DEVICE", 0));
                 const HipLibrary hip(argv[0]);  // (throws when the library or a gfx950 device is missing: there is no silent fallback)
                 const int rc = hip.consensus(device, backbone.data(), backbone.size(), parts.data(), partNum, flat.data(), flat.size(), qpool.data(), tpool.data(),
                                              qpool.size(), 0, outBuf.data(), outBytes, outOff.data(), outLen.data(), partErr.data());

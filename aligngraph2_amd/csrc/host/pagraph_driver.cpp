@@ -218,7 +218,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
                 readToRef = refAln.get();
             }
         };
-        const bool prefetch = !(std::getenv("PAGRAPH_PREFETCH") && std::atoi(std::getenv("PAGRAPH_PREFETCH")) == 0);
+        const bool prefetch = envInt("PAGRAPH_PREFETCH", 1) != 0;
         auto mine = [&](std::size_t no) { return !blocksEnv || onlyBlocks.count(no) != 0; };
         auto loadBlock = [&opt, &configs, &backend](std::size_t no) {
             return std::make_unique<BlockFiles>(opt.pre, configs[no], backend.shardRank(), backend.shardWorld(), static_cast<unsigned>(opt.threads));
@@ -262,7 +262,7 @@ int runPagraph(int argc, char **argv, GraphBackend &backend) {
         HostGraph graphs[2];  // (storage reused from block to block; two sets: a block's host half runs beside the next block)
         std::vector<TravelSequence> precomputed[2];
         GraphBackend::TravelViews tviews[2];
-        const bool halves = backend.travelsInHalves() && !(std::getenv("PAGRAPH_OVERLAP") && std::atoi(std::getenv("PAGRAPH_OVERLAP")) == 0);
+        const bool halves = backend.travelsInHalves() && envInt("PAGRAPH_OVERLAP", 1) != 0;
         std::size_t nHalves = 0;
         // the host half of the block before: joined before the next walks (and before anything is thrown past it)
         struct HostHalf {

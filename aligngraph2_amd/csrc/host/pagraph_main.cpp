@@ -24,8 +24,9 @@ int main(int argc, char **argv) {
     // (a rank of a sharded build leaves the ordinary way: its communicator says goodbye to its peers)
     const char *shard = std::getenv("PAGRAPH_SHARD");
     // (tools that flush at exit — rocprofv3, coverage, sanitizers — need the ordinary way out as well)
-    const bool tool = std::getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("LD_PRELOAD") || std::getenv("GCOV_PREFIX") ||
-                      std::getenv("ASAN_OPTIONS") || std::getenv("LSAN_OPTIONS");
+    bool tool = false;
+    for (const char *name : {"ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "GCOV_PREFIX", "ASAN_OPTIONS", "LSAN_OPTIONS"})
+        tool = tool || std::getenv(name) != nullptr;
     if (!(shard && *shard) && !tool) {
         std::cout.flush();
         std::cerr.flush();
