@@ -89,6 +89,28 @@ struct SegLds {
     typename ShortW<W>::Mask m[SEG_TILE];
     uint32_t cnt[SEG_TILE];
 };
+// K3 only: a record's two coordinates in the form the similarity masks compare (SimForm below), and whether some coordinate of
+// the tile lies too close to 2^32 for that form
+struct SimLds {
+    uint2 t[SEG_TILE];
+    uint32_t slow;
+};
+// pos_sim in two subtractions and two compares per pair.  A coordinate c becomes c' = c ? c + eps + 1 : 0: "both zero" is
+// distance 0, "one zero" a distance of more than eps, two real coordinates keep their distance — so coord_sim(a, b) is
+// |a' - b'| <= eps, i.e. (a' + eps) - b' <= 2 eps in unsigned arithmetic (a difference below zero wraps to more than 2 eps).
+// Exact as long as no c' + eps wraps: coordinates up to 2^32 - 2 eps - 3; a tile that holds a larger one (SimLds::slow), or an
+// eps of 2^30 and more, takes the plain predicate.  The masks were 240 of cluster_short's 570 vector instructions per 64
+// records, and the kernel is bound by their number (81 % of the issue slots, profiles/r05_pmc_kernel_mix_end.json).
+struct SimForm {
+    uint32_t eps, two, limit;
+    bool usable;
+    __device__ __forceinline__ explicit SimForm(uint32_t e) : eps(e), two(2u * e), limit(0xFFFFFFFFu - 2u * e - 3u), usable(e < (1u << 30)) {}
+    __device__ __forceinline__ uint2 of(uint64_t v) const {
+        const uint32_t c = (uint32_t)(v >> 32), r = (uint32_t)v;
+        return make_uint2(c ? c + eps + 1u : 0u, r ? r + eps + 1u : 0u);
+    }
+    __device__ __forceinline__ bool fits(uint64_t v) const { return (uint32_t)(v >> 32) <= limit && (uint32_t)v <= limit; }
+};
 
 struct SegPos {
     uint32_t o, s, len;
@@ -185,26 +207,44 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
     using Mask = typename ShortW<W>::Mask;
     constexpr int SEG_OWN = ShortW<W>::OWN;
     __shared__ SegLds<W> S;
+    __shared__ SimLds Q;
     uint64_t n_ctg = 0, n_all = 0, n_seg = 0;
     const uint32_t t = threadIdx.x;
     const uint64_t n_tiles = (n + SEG_OWN - 1) / SEG_OWN;
+    const SimForm F(eps);
+    if (t == 0) Q.slow = 0u;
     SegRegs R;
     if (blockIdx.x < n_tiles) seg_request(R, key, val, (uint64_t)blockIdx.x * SEG_OWN, n);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * SEG_OWN;
         __syncthreads();
         seg_stage(S, R, base, n);
+        if (base + t < n) {
+            Q.t[t] = F.of(R.v);
+            if (!F.fits(R.v)) Q.slow = 1u;
+        }
         if (tile + gridDim.x < n_tiles) seg_request(R, key, val, (tile + gridDim.x) * SEG_OWN, n);  // (in flight while this tile is worked on)
         __syncthreads();
         const SegPos P = seg_locate(S, t, base, n);
         const uint64_t v = S.val[t];
+        const bool fast = F.usable && Q.slow == 0u;  // (the same answer for every thread of the tile)
         Mask M = 0;
         if (P.active) {
-            for (uint32_t j = 0; j < P.o; ++j) M |= (Mask)pos_sim(v, S.val[P.s + j], eps) << j;
+            if (fast) {
+                const uint2 a = Q.t[t];
+                const uint32_t ac = a.x + F.eps, ar = a.y + F.eps;
+                for (uint32_t j = 0; j < P.o; ++j) {
+                    const uint2 b = Q.t[P.s + j];
+                    M |= (Mask)((ac - b.x <= F.two) & (ar - b.y <= F.two)) << j;
+                }
+            } else {
+                for (uint32_t j = 0; j < P.o; ++j) M |= (Mask)pos_sim(v, S.val[P.s + j], eps) << j;
+            }
         }
         S.m[t] = M;
         S.cnt[t] = 1;
         __syncthreads();
+        if (t == 0) Q.slow = 0u;  // (every thread has read it; the next tile's writers are behind the barrier at the top of the loop)
         Mask L = 0;
         bool leader = false;
         uint32_t rank = 0;

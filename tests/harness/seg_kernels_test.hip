@@ -60,6 +60,14 @@ int main(int argc, char **argv) {
             c0[c] = 1000 + (uint32_t)(rng() % 300);
             r0[c] = 5000 + (uint32_t)(rng() % 300);
         }
+        // (every 40th segment at the ends of the coordinate space: coordinates of 1 .. eps next to "no coordinate" (0), and coordinates
+        // within 2 eps of 2^32, which cluster_short's two-subtraction form of the similarity test must leave to the plain predicate)
+        if (sgi % 40 == 7)
+            for (int c = 0; c < 4; ++c) {
+                const bool top = rng() % 2 == 0;
+                c0[c] = top ? 0xFFFFFFFFu - 14u - (uint32_t)(rng() % 30) : 1u + (uint32_t)(rng() % 12);
+                r0[c] = rng() % 2 ? 0xFFFFFFFFu - 14u - (uint32_t)(rng() % 30) : 1u + (uint32_t)(rng() % 12);
+            }
         for (uint32_t j = 0; j < len; ++j) {
             uint32_t c = (uint32_t)(rng() % centers);
             bool pass2 = j >= len / 2;
