@@ -252,6 +252,10 @@ uint32_t solid_mask_slices() { return SOLID_SLICES; }
 // A function state -> state is a packed table of 4-bit entries.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t tab_get(uint32_t tab, uint32_t s) { return (tab >> (4 * s)) & 15u; }
+// ... of up to four states as four bytes: "first, then" is out.byte[s] = then.byte[first.byte[s]] — one v_perm_b32 (selector
+// bytes 0..3 pick from the second operand)
+__device__ __forceinline__ uint32_t byte_compose(uint32_t first, uint32_t then) { return __builtin_amdgcn_perm(then, then, first); }
+__device__ __forceinline__ uint32_t byte_get(uint32_t tab, uint32_t s) { return (tab >> (8 * s)) & 255u; }
 __device__ __forceinline__ uint32_t tab_compose(uint32_t first, uint32_t then, uint32_t S) {
     uint32_t out = 0;
     for (uint32_t s = 0; s <= S; ++s) out |= tab_get(then, tab_get(first, s)) << (4 * s);
@@ -318,6 +322,12 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
     const uint64_t edge_base = EMIT ? A.edge_off[A.job_base + job] : 0;
 
     uint32_t state = S;  // free
+    // (S <= 3) the two transition tables of a position — without / with a candidate — as bytes: state s -> byte s
+    uint32_t byte_t0 = 0, byte_t1 = 0;
+    for (uint32_t st = 0; st < 4u; ++st) {
+        byte_t0 |= (st + 1u > S ? S : st + 1u) << (8u * st);
+        byte_t1 |= (st + 1u >= S ? 0u : st + 1u) << (8u * st);
+    }
     bool carry_valid = false;
     uint32_t carry_pos = 0, carry_code = 0;
 
@@ -356,26 +366,46 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
         }
 
         // ---- C. greedy sampling as an associative scan of state-transition tables
-        uint32_t tab = 0;
-        for (uint32_t s = 0; s <= S; ++s) tab |= s << (4 * s);
-        for (uint32_t j = 0; j < n_mine; ++j) {
-            uint32_t c = (cand >> j) & 1u, nt = 0;
-            for (uint32_t s = 0; s <= S; ++s) {
-                uint32_t v = tab_get(tab, s);
-                v = (c && v + 1 >= S) ? 0u : (v + 1 > S ? S : v + 1);
-                nt |= v << (4 * s);
-            }
-            tab = nt;
-        }
-        uint32_t incl = tab;
+        uint32_t v;
+        if (S <= 3u) {
+            // (the pipeline's outer = 3, pagraph.cpp:113) four states: a table is four BYTES and "first, then" is ONE byte permute
+            // (byte_compose) — the nibble tables below cost ~30 vector instructions per composition, 22 compositions per lane and
+            // tile: 700 of the kernel's instructions per tile, and the kernel is bound by their number (SQ counters, round 5)
+            uint32_t tab = 0x03020100u;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t prev = __shfl_up(incl, d, 64);
-            if ((int)lane >= d) incl = tab_compose(prev, incl, S);
+            for (uint32_t j = 0; j < 16u; ++j)
+                if (j < n_mine) tab = byte_compose(tab, ((cand >> j) & 1u) ? byte_t1 : byte_t0);
+            uint32_t incl = tab;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t prev = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl = byte_compose(prev, incl);
+            }
+            const uint32_t excl = __shfl_up(incl, 1, 64);
+            v = lane == 0 ? state : byte_get(excl, state);
+            state = byte_get(__shfl(incl, 63, 64), state);
+        } else {
+            uint32_t tab = 0;
+            for (uint32_t s = 0; s <= S; ++s) tab |= s << (4 * s);
+            for (uint32_t j = 0; j < n_mine; ++j) {
+                uint32_t c = (cand >> j) & 1u, nt = 0;
+                for (uint32_t s = 0; s <= S; ++s) {
+                    uint32_t x = tab_get(tab, s);
+                    x = (c && x + 1 >= S) ? 0u : (x + 1 > S ? S : x + 1);
+                    nt |= x << (4 * s);
+                }
+                tab = nt;
+            }
+            uint32_t incl = tab;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t prev = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl = tab_compose(prev, incl, S);
+            }
+            uint32_t excl = __shfl_up(incl, 1, 64);
+            v = lane == 0 ? state : tab_get(excl, state);
+            state = tab_get(__shfl(incl, 63, 64), state);
         }
-        uint32_t excl = __shfl_up(incl, 1, 64);
-        uint32_t v = lane == 0 ? state : tab_get(excl, state);
-        state = tab_get(__shfl(incl, 63, 64), state);
         uint32_t kept = 0;
         for (uint32_t j = 0; j < n_mine; ++j) {
             uint32_t c = (cand >> j) & 1u;
