@@ -41,11 +41,12 @@ __global__ __launch_bounds__(64) void kc_count(const uint64_t *__restrict__ read
             // k-mer most significant in its code: reverse the 2-bit groups)
             const uint32_t w0 = p0 >> 4;
             const uint64_t W = (uint64_t)words[w0] | ((uint64_t)words[w0 + 1] << 32);
+            uint32_t codes[16];
+            fwd_codes16(W, k, kmask, codes);
 #pragma unroll
             for (uint32_t j = 0; j < 16u; ++j) {
                 if (j < n_mine) {
-                    const uint32_t x = (uint32_t)(W >> (2u * j)) & kmask;
-                    const uint32_t code = rev2(x) >> (32u - 2u * k);
+                    const uint32_t code = codes[j];
                     // (one launch per slice of the code range: the slice's counters stay in the Infinity Cache)
                     if (slice_shift >= 32u || (code >> slice_shift) == slice) atomicAdd(&table[code], 1u);
                 }

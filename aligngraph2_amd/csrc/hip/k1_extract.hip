@@ -170,17 +170,15 @@ __device__ __forceinline__ void lane_codes(const uint32_t *__restrict__ words, u
             sh0 = (uint32_t)((a0 - (int64_t)a1) * 2);  // <= 0 as a signed value; fine for valid j
         }
     }
+    if (strand == 0) {
+        fwd_codes16(W, k, kmask, code);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        uint32_t x;
-        if (strand == 0) {
-            x = (uint32_t)(W >> (2 * j)) & kmask;
-            code[j] = rev2(x) >> (32 - 2 * k);
-        } else {
-            uint32_t shj = (uint32_t)(2 * (15 - j)) + sh0;  // wraps harmlessly for invalid j
-            x = (uint32_t)(W >> (shj & 63u)) & kmask;
-            code[j] = (~x) & kmask;
-        }
+        const uint32_t shj = (uint32_t)(2 * (15 - j)) + sh0;  // wraps harmlessly for invalid j
+        const uint32_t x = (uint32_t)(W >> (shj & 63u)) & kmask;
+        code[j] = (~x) & kmask;
     }
 }
 

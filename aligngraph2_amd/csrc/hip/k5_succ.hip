@@ -45,10 +45,13 @@ struct EmitStream {
 struct EmitWave {  // (LDS, one per wave; read and written by the leader of an appending group only)
     uint32_t base_lo, base_hi, used, n;
 };
+// (a pointer that SAYS it points into LDS: through a plain `volatile EmitWave *` every access became a flat load / store with
+// system-scope cache flags and a full wait behind it — address-space inference leaves volatile accesses alone)
+typedef volatile __attribute__((address_space(3))) EmitWave *EmitWaveLds;
 // The lanes that are HERE together — any subset of the wave: the callers sit in divergent loops — append one record each.  One
 // of them takes the room (from the wave's chunk, or a new chunk from the stream's cursor: one global atomic per 2 048 slots);
 // later appends of a lane get higher slots than its earlier ones, so a vertex's records stay in order.
-__device__ __forceinline__ void emit_append(const EmitStream &S, volatile EmitWave *W, uint32_t key, uint64_t val) {
+__device__ __forceinline__ void emit_append(const EmitStream &S, EmitWaveLds W, uint32_t key, uint64_t val) {
     const uint64_t m = __ballot(1);
     const uint32_t n = (uint32_t)__popcll(m), rank = (uint32_t)__popcll(m & lanemask_lt());
     uint32_t lo = 0, hi = 0;
@@ -77,7 +80,7 @@ __device__ __forceinline__ void emit_append(const EmitStream &S, volatile EmitWa
 }
 // ... ALL lanes of the wave are here: room for n records of every lane, in lane order (n <= EMIT_CHUNK / 64); returns the lane's
 // first slot
-__device__ __forceinline__ uint64_t emit_alloc_wave(const EmitStream &S, volatile EmitWave *W, uint32_t n) {
+__device__ __forceinline__ uint64_t emit_alloc_wave(const EmitStream &S, EmitWaveLds W, uint32_t n) {
     uint32_t tot;
     const uint32_t ex = wave_excl_sum(n, &tot);
     uint32_t lo = 0, hi = 0;
@@ -103,7 +106,7 @@ __device__ __forceinline__ uint64_t emit_alloc_wave(const EmitStream &S, volatil
 __device__ __forceinline__ uint64_t emit_value(uint32_t tgt, uint32_t step, uint32_t grade, uint32_t esim) {
     return (uint64_t)tgt | ((uint64_t)((step & 0xFFFFFFu) | (grade << 24) | ((esim & 1u) << 27)) << 32);
 }
-__device__ __forceinline__ void emit_wave_init(volatile EmitWave *W) {  // (lane 0 of the wave; a barrier or wave-level sync after it)
+__device__ __forceinline__ void emit_wave_init(EmitWaveLds W) {  // (lane 0 of the wave; a barrier or wave-level sync after it)
     W->base_lo = 0u;
     W->base_hi = 0u;
     W->used = EMIT_CHUNK;  // (the first append takes a chunk)
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(256, BLOCKS) k_succ_emit(TravGraph G, uint32_t
     __shared__ EmitWave emit_wave[4];
     d_ratio_table_fill(ratio_tab, err);
     const bool inc_lds = inc_lds_fill(inc_bands, G);
-    volatile EmitWave *W = &emit_wave[threadIdx.x >> 6];
+    EmitWaveLds W = (EmitWaveLds)&emit_wave[threadIdx.x >> 6];
     if (lane_id() == 0u) emit_wave_init(W);
     __syncthreads();
     const uint32_t marker_meta = 1u | (GRADE_POISON_IF_LEAP << 24), poison_meta = 1u | (GRADE_POISON << 24);
@@ -183,15 +186,27 @@ __global__ void __launch_bounds__(256, BLOCKS) k_succ_emit(TravGraph G, uint32_t
                                 // memory round trip (load -> tests -> next load)
                                 for (uint32_t jb = 0; jb < q; jb += 4u) {
                                     const U64x4 pqL = *(const U64x4 *)(G.vpos + p0 + jb);  // (padded by four entries)
+                                    // The four candidates are only GRADED here — a byte each, 0 = rejected — and the accepted ones taken
+                                    // in order by the loop behind: one copy of the bookkeeping, run as often as the wave's busiest lane
+                                    // accepted (one in ten candidates is: once or twice), where it stood behind every one of the sixteen
+                                    // evaluation sites of an edge group and ran at each as soon as ANY lane accepted (a third of the
+                                    // kernel's instructions, 55 KB of code).
+                                    uint32_t am = 0;
 #pragma unroll
                                     for (uint32_t t = 0; t < 4u; ++t) {
-                                        const uint32_t j = jb + t;
-                                        if (j >= q) break;
+                                        if (jb + t >= q) break;
                                         const uint32_t pc = (uint32_t)(pqL.a[t] >> 32), pr = (uint32_t)pqL.a[t];
                                         uint32_t esim;
                                         const int grade = d_check_position_any(rc, rr, pc, pr, step, dev, err, entry, &esim);
-                                        if (grade == G_OOPS) continue;
-                                        const uint32_t meta = (step & 0xFFFFFFu) | ((uint32_t)grade << 24) | ((esim & 1u) << 27);
+                                        am |= ((uint32_t)grade | ((esim & 1u) << 3)) << (8u * t);
+                                    }
+                                    while (am) {
+                                        uint32_t t = ((uint32_t)__ffs((int)am) - 1u) >> 3;
+                                        uint32_t g = (am >> (8u * t)) & 0xFFu;
+                                        am &= ~(0xFFu << (8u * t));
+                                        if ((g & 7u) == (uint32_t)G_OOPS) continue;  // (never: the contig side is only similar in accepted pairs, d_check_position)
+                                        const uint32_t j = jb + t;
+                                        const uint32_t meta = (step & 0xFFFFFFu) | ((g & 7u) << 24) | ((g >> 3) << 27);
                                         if (nb < 4u) {  // (the lane's first four accepted candidates wait in registers for the wave's common append)
                                             bp0 = nb == 0u ? p0 + j : bp0, bm0 = nb == 0u ? meta : bm0;
                                             bp1 = nb == 1u ? p0 + j : bp1, bm1 = nb == 1u ? meta : bm1;

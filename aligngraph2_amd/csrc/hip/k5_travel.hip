@@ -1252,10 +1252,19 @@ __device__ __forceinline__ bool probe_wave(WalkLds &L, WalkCtx &X, uint32_t grp,
 // graphTravel (PAlgorithm.tcc:172-298), one wave per job
 __device__ __forceinline__ void walk_job(WalkLds &L, const TravGraph &G, const TravContig &C, const TravJob &Jsrc, TravJobOut *out, uint32_t k) {
     const uint32_t lane = lane_id();
-    const TravJob J = Jsrc;  // by value: the record may live in host memory
+    TravJob Jg = Jsrc;  // by value: the record may live in host memory
+    TravContig Cg = C;
+    // The job's buffers are device memory; as pointers READ FROM MEMORY they are "generic" to the compiler, which then uses FLAT
+    // instructions for them: those count against the LDS counter as well, so every wait for an LDS read (the window: 600 sites)
+    // also waited for whatever hash-set probe or write-through store of the job was in flight.  Saying what they are (as_global,
+    // pag_device.hpp) makes them global loads / stores (322 flat instructions in the kernel before).
+    Jg.seq_v = as_global(Jg.seq_v), Jg.seq_s = as_global(Jg.seq_s), Jg.arena_v = as_global(Jg.arena_v), Jg.arena_s = as_global(Jg.arena_s);
+    Jg.stamp = as_global(Jg.stamp), Jg.tbits = as_global(Jg.tbits), Jg.tset = as_global(Jg.tset), Jg.pset = as_global(Jg.pset), Jg.seq_x = as_global(Jg.seq_x);
+    Cg.nodes = as_global(Cg.nodes), Cg.starts = as_global(Cg.starts), Cg.sizes = as_global(Cg.sizes), Cg.gbits = as_global(Cg.gbits), Cg.gset = as_global(Cg.gset);
+    const TravJob J = Jg;
     WalkCtx X;
     X.G = G;
-    X.C = C;
+    X.C = Cg;
     X.stamp = J.stamp;
     X.stamp_stride = J.stamp_stride;
     X.tbits = J.tbits;

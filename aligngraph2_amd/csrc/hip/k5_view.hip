@@ -47,13 +47,13 @@ __global__ void k_zone_bands(const uint64_t *__restrict__ tval, uint64_t T, cons
         }
         __syncthreads();
     }
-    const uint32_t *zz = lds ? s_z : zones;
     const uint32_t z_first = n_z ? zones[0] : 0u, z_last = n_z ? zones[2 * n_z - 1] : 0u;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t p = tval[i];
         const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
         uint32_t z;
-        if (c < z_first || c >= z_last || r == 0u || !iv_contains(zz, n_z, c, &z)) continue;
+        if (c < z_first || c >= z_last || r == 0u) continue;
+        if (!(lds ? iv_contains(s_z, n_z, c, &z) : iv_contains(zones, n_z, c, &z))) continue;  // (two searches: a pointer "LDS or global" means flat loads)
         if (lds) {
             atomicMin(&s_lo[z], r);
             atomicMax(&s_hi[z], r);
@@ -101,10 +101,13 @@ __global__ __launch_bounds__(VC_T) void k_view_mark(const uint32_t *__restrict__
         for (uint32_t x = threadIdx.x; x < 2u * n_riv; x += blockDim.x) s_iv[2u * n_civ + x] = riv[x];
         __syncthreads();
     }
-    const uint32_t *cv = lds ? s_iv : civ, *rv = lds ? s_iv + 2u * n_civ : riv;
+    // (two searches, not one through a pointer that is "LDS or global": that pointer is generic to the compiler, and the eight
+    // dependent loads of a search became flat loads — the slow way into LDS — 81 of them in this kernel)
     auto inside = [&](uint64_t p) {
         const uint32_t c = (uint32_t)(p >> 32), r = (uint32_t)p;
-        return whole || (c != 0u ? iv_contains(cv, n_civ, c) : iv_contains(rv, n_riv, r));
+        if (whole) return true;
+        if (lds) return c != 0u ? iv_contains(s_iv, n_civ, c) : iv_contains(s_iv + 2u * n_civ, n_riv, r);
+        return c != 0u ? iv_contains(civ, n_civ, c) : iv_contains(riv, n_riv, r);
     };
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {

@@ -366,7 +366,7 @@ void trav_launch_ranges(TravGraph G, TravContig *ctgs, uint32_t n, hipStream_t s
 // blockIdx.y = range; 16 bytes per lane and turn where the range allows (the job buffers are 256-byte aligned), bytes at its edges
 __global__ void k_clear_ranges(const TravClear *__restrict__ ranges) {
     const TravClear c = ranges[blockIdx.y];
-    uint8_t *p = (uint8_t *)c.p;
+    uint8_t *p = as_global((uint8_t *)c.p);  // (device memory: global stores, not flat ones)
     const uint64_t head = (16u - ((uintptr_t)p & 15u)) & 15u, h = head < c.bytes ? head : c.bytes;
     const uint64_t n16 = (c.bytes - h) >> 4, tail = (c.bytes - h) & 15u;
     uint4 *q = (uint4 *)(p + h);

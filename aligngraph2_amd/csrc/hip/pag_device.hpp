@@ -82,10 +82,34 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// "this pointer points to device memory": a pointer loaded from memory is generic to the compiler (flat instructions, which
+// count against the LDS counter too); after a cast to the global address space and back its uses become global loads / stores —
+// address-space inference starts from such casts, as it does for kernel arguments.  The empty asm keeps the two casts from
+// being folded into nothing; "s": the pointer is the same for the whole wave (a job's buffer) and stays in scalar registers.
+template <typename T>
+__device__ __forceinline__ T *as_global(T *p) {
+    const uint64_t x = (uint64_t)p;
+    const uint64_t u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
+    __attribute__((address_space(1))) T *g = (__attribute__((address_space(1))) T *)u;
+    asm volatile("" : "+s"(g));
+    return (T *)g;
+}
+
 // reverse the order of the sixteen 2-bit groups of a 32-bit word
 __device__ __forceinline__ uint32_t rev2(uint32_t x) {
     x = __brev(x);
     return ((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1);
+}
+// the k-mer codes of the sixteen positions a 64-bit window of a 2-bit packed strand begins with (kmer2Code: base i of the stream in
+// bits 2i..2i+1, the first base of a k-mer most significant in its code): ALL thirty-two groups reversed once, every code then a
+// shift and a mask — instead of a shift, a mask and a reversal of its own per position (nine vector instructions each in
+// kernels that are bound by their number)
+__device__ __forceinline__ void fwd_codes16(uint64_t W, uint32_t k, uint32_t kmask, uint32_t (&code)[16]) {
+    const uint64_t R = ((uint64_t)rev2((uint32_t)W) << 32) | (uint64_t)rev2((uint32_t)(W >> 32));  // group g -> group 31 - g
+    const uint32_t s0 = 2u * (32u - k);  // base j .. j + k - 1 of the stream = groups 32 - j - k .. 31 - j of R
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; ++j) code[j] = (uint32_t)(R >> (s0 - 2u * j)) & kmask;
 }
 #endif
 
