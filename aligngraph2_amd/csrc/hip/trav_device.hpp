@@ -118,9 +118,13 @@ __device__ __forceinline__ int d_check_position_tab(uint32_t ac, uint32_t ar, ui
     *edge_sim = (s1 ? 1u : 0u) | (s2 ? 2u : 0u);
     s1 = s1 || q1;
     s2 = s2 || q2;
-    if (ac == 0 || bc == 0) return s2 ? (bc != 0 ? G_EXCELLENT : (ac != 0 ? G_SKIP : G_GOOD)) : G_OOPS;
-    if (ar == 0 || br == 0) return s1 ? (br != 0 ? G_EXCELLENT : G_GOOD) : G_OOPS;
-    return (s1 && s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
+    // (the three cases of checkPosition as selects: written as early returns they became three exec-mask branches per candidate,
+    // in a kernel that is bound by the instructions it issues)
+    const bool A = ac != 0, B = bc != 0, C = ar != 0, D = br != 0;
+    const int g1 = s2 ? (B ? G_EXCELLENT : (A ? G_SKIP : G_GOOD)) : G_OOPS;
+    const int g2 = s1 ? (D ? G_EXCELLENT : G_GOOD) : G_OOPS;
+    const int g3 = (s1 & s2) ? G_AMAZING : (s1 ? G_EXCELLENT : (s2 ? G_SKIP : G_OOPS));
+    return !(A & B) ? g1 : (!(C & D) ? g2 : g3);
 }
 // ... for any dist: through the table (LDS) where it has an entry
 __device__ __forceinline__ int d_check_position_any(uint32_t ac, uint32_t ar, uint32_t bc, uint32_t br, uint32_t dist, uint32_t dev, double err,
