@@ -149,6 +149,75 @@ __device__ __forceinline__ void walk_alignment(const pag_aln &al, const uint32_t
     }
 }
 
+// ... for the KEPT samples of the tile [lo, lo + TILE) only: g(sample, t) with sample = the kept sample's number inside the tile
+// (from the per-lane masks / ranks `kept`, `rank` of the tile's positions) and t its target position.  walk_alignment visits
+// every emitting column — sixteen turns of ~25 instructions per lane and chunk — although one position in six is kept: here a
+// lane looks its (at most sixteen) positions up in the kept masks first and only finds the columns of those (the n-th set bit
+// of its emit mask).  The emission launch is bound by the instructions it issues.
+__device__ __forceinline__ uint32_t even_bits16(uint32_t x) {  // bits 0, 2, 4, .. 30 -> bits 0 .. 15
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t nth_set_bit16(uint32_t x, uint32_t n) {  // position of the (n + 1)-th set bit (it exists)
+    uint32_t pos = 0, c = __popc(x & 0xFFu);
+    if (n >= c) n -= c, pos = 8u, x >>= 8;
+    c = __popc(x & 0xFu);
+    if (n >= c) n -= c, pos += 4u, x >>= 4;
+    c = __popc(x & 0x3u);
+    if (n >= c) n -= c, pos += 2u, x >>= 2;
+    return pos + (n >= (x & 1u) ? 1u : 0u);
+}
+template <typename G>
+__device__ __forceinline__ void walk_kept(const pag_aln &al, const uint32_t *__restrict__ diff, const uint2 *__restrict__ cidx, uint32_t lo,
+                                          uint32_t hi, const uint32_t (&kept)[64], const uint32_t (&rank)[64], G g) {
+    const uint32_t q_end = al.q_start + al.n_valid;
+    const uint32_t a = lo > al.q_start ? lo : al.q_start;
+    const uint32_t b = hi < q_end ? hi : q_end;
+    if (a >= b) return;
+    const uint32_t e0 = a - al.q_start, e1 = b - al.q_start;  // emit ordinals wanted: [e0, e1)
+    const bool back = (al.flags & PAG_ALN_WALK_BACK) != 0;
+    const uint32_t n_chunks = (al.n_cols + CHUNK - 1) / CHUNK;
+    uint32_t c_lo = 0, c_hi = n_chunks;
+    while (c_hi - c_lo > 1) {
+        const uint32_t mid = (c_lo + c_hi) >> 1;
+        if (cidx[mid].x <= e0) c_lo = mid;
+        else c_hi = mid;
+    }
+    for (uint32_t c = c_lo; c < n_chunks; ++c) {
+        const uint2 pre = cidx[c];
+        if (pre.x >= e1) break;
+        uint32_t n_lane, eb, rb;
+        const uint32_t bits = load_cols16(diff, al.diff_off, al.n_cols, back, c * CHUNK + lane_id() * 16, &n_lane);
+        col_masks(bits, n_lane, &eb, &rb);
+        const uint32_t ne = __popc(eb);
+        uint32_t tot;
+        const uint32_t eex = wave_excl_sum(ne, &tot) + pre.x;
+        const uint32_t rex = wave_excl_sum(__popc(rb), &tot) + pre.y;
+        const uint32_t o_lo = eex > e0 ? eex : e0, o_hi = eex + ne < e1 ? eex + ne : e1;  // my emit ordinals inside [e0, e1)
+        if (o_lo >= o_hi) continue;
+        const uint32_t d_lo = al.q_start + o_lo - lo, n = o_hi - o_lo;  // their positions in the tile: d_lo .. d_lo + n - 1 (n <= 16)
+        const uint32_t w = d_lo >> 4, sh = d_lo & 15u;
+        const bool two = sh + n > 16u;
+        const uint32_t k0 = kept[w] & 0xFFFFu, k1 = two ? kept[w + 1] & 0xFFFFu : 0u;
+        uint32_t km = ((k0 | (k1 << 16)) >> sh) & ((1u << n) - 1u);  // bit i: position d_lo + i is a kept sample
+        if (!km) continue;
+        const uint32_t e16 = even_bits16(eb), r16 = even_bits16(rb);
+        const uint32_t r0 = rank[w], r1 = two ? rank[w + 1] : 0u;
+        while (km) {
+            const uint32_t i = (uint32_t)__ffs((int)km) - 1u;
+            km &= km - 1u;
+            const uint32_t col = nth_set_bit16(e16, o_lo + i - eex);  // my column that emits ordinal o_lo + i
+            const uint32_t t = al.t_start + rex + __popc(r16 & ((1u << col) - 1u));
+            const uint32_t d = d_lo + i;
+            const bool first = (d >> 4) == w;
+            g((first ? r0 : r1) + __popc((first ? k0 : k1) & ((1u << (d & 15u)) - 1u)), t);
+        }
+    }
+}
+
 // k-mer codes of the 16 positions p0 .. p0+15 of one read strand (kmer2Code / reverse strand of
 // CompressedSeq): a 64-bit window of the 2-bit packed read, 2-bit-group reversal for the forward strand
 // (first base most significant), complement for the reverse strand.
@@ -560,11 +629,7 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
                 for (int i = 0; i < PER; ++i)
                     if (lane + 64u * i < tile_samples) L.st[lane + 64u * i] = 0xFFFFFFFFu;
                 __syncthreads();
-                walk_alignment(al, A.diff, A.colidx + A.colidx_off[ai], t0, t_hi, [&](uint32_t q, uint32_t t) {
-                    uint32_t d = q - t0;
-                    uint32_t km = L.kept[d >> 4];
-                    if ((km >> (d & 15u)) & 1u) L.st[L.rank[d >> 4] + __popc(km & ((1u << (d & 15u)) - 1u))] = t;
-                });
+                walk_kept(al, A.diff, A.colidx + A.colidx_off[ai], t0, t_hi, L.kept, L.rank, [&](uint32_t sample, uint32_t t) { L.st[sample] = t; });
                 __syncthreads();
                 constexpr int G = 6;  // samples per lane and turn (MAXS = 352: one turn)
                 for (uint32_t sb = 0; sb < tile_samples; sb += 64u * G) {
