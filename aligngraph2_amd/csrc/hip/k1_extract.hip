@@ -251,6 +251,38 @@ __device__ __forceinline__ void lane_codes(const uint32_t *__restrict__ words, u
     }
 }
 
+// The same window, kept, for a lane that wants the codes of a FEW of its sixteen positions (the emission launch: the kept
+// samples, one position in six): forward strand — all groups reversed once (fwd_codes16's R), a code is a shift and a mask;
+// reverse strand — the window and its offset, a code is a shift, a complement and a mask.
+struct LaneWindow {
+    uint64_t x = 0;   // forward: the window with its 2-bit groups reversed; reverse: the window
+    uint32_t s0 = 0;  // forward: shift of position 0 (2 (32 - k)); reverse: sh0 of lane_codes
+    __device__ __forceinline__ uint32_t code(uint32_t strand, uint32_t kmask, uint32_t j) const {
+        if (strand == 0) return (uint32_t)(x >> (s0 - 2u * j)) & kmask;
+        return ~(uint32_t)(x >> ((2u * (15u - j) + s0) & 63u)) & kmask;
+    }
+};
+__device__ __forceinline__ LaneWindow lane_window(const uint32_t *__restrict__ words, uint32_t strand, uint32_t len, uint32_t k, uint32_t p0,
+                                                  uint32_t n_mine) {
+    LaneWindow L;
+    if (!n_mine) return L;  // lanes past the end of the strand must not touch memory
+    if (strand == 0) {
+        const uint32_t w0 = p0 >> 4;
+        const uint32_t lo = words[w0], hi = words[w0 + 1];
+        L.x = ((uint64_t)rev2(lo) << 32) | (uint64_t)rev2(hi);
+        L.s0 = 2u * (32u - k);
+    } else {
+        const int64_t a0 = (int64_t)len - (int64_t)k - (int64_t)p0 - 15;
+        const uint32_t a1 = a0 > 0 ? (uint32_t)a0 : 0u;
+        const uint32_t w = a1 >> 4, sh = (a1 & 15u) * 2u;
+        const uint64_t lo64 = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
+        L.x = lo64 >> sh;
+        if (sh) L.x |= (uint64_t)words[w + 2] << (64 - sh);
+        L.s0 = (uint32_t)((a0 - (int64_t)a1) * 2);
+    }
+    return L;
+}
+
 // Solid-set membership of every k-mer start of every read strand that some alignment (of either pass)
 // touches: ONE random bitmap gather per read position for the whole build.  The four extraction launches
 // (count / emit x pass 1 / pass 2) then read 16-bit masks per 16 positions instead of gathering again —
@@ -416,11 +448,11 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
             continue;
         }
 
-        // ---- B. k-mer codes of my positions + solid test
-        uint32_t code[16];
+        // ---- B. the window my positions' k-mer codes come from (the codes of the kept ones are taken in E) + solid test
         uint32_t cand = 0;
         const uint32_t n_mine = p0 >= n_pos ? 0u : (n_pos - p0 > 16 ? 16u : n_pos - p0);
-        lane_codes(words, strand, len, k, kmask, p0, n_mine, code);
+        LaneWindow win;
+        if (EMIT) win = lane_window(words, strand, len, k, p0, n_mine);
         if (A.all_solid) {
             cand = ne;
         } else if (ne) {
@@ -508,12 +540,10 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
             L.rank[lane] = rank0;
             // ---- E. edges between consecutive kept samples (prev -> this)
             uint32_t last_pos = 0, last_code = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if ((kept >> j) & 1u) {
-                    last_pos = p0 + j;
-                    last_code = code[j];
-                }
+            if (kept) {
+                const uint32_t jl = 31u - (uint32_t)__clz((int)kept);
+                last_pos = p0 + jl;
+                last_code = win.code(strand, kmask, jl);
             }
             uint64_t has = __ballot(kept != 0);
             uint64_t before = has & lanemask_lt();
@@ -525,24 +555,25 @@ __global__ __launch_bounds__(64) void extract_kernel(ExtractArgs A) {
                 pc = carry_code;
                 pvalid = carry_valid;
             }
+            // (a turn per KEPT sample — at most six of a lane's sixteen positions, they are three apart — with its code taken from
+            // the window: sixteen predicated bodies over a code array were a third of the launch's instructions)
             uint32_t i = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if ((kept >> j) & 1u) {
-                    uint32_t s_local = rank0 + i;
-                    L.scode[s_local] = code[j];
-                    L.scnt[s_local] = (uint32_t)(cnt4 >> (4 * j)) & 15u;  // (0 without fast_counts: counted by the walk below)
-                    L.srun[s_local] = 0;
-                    if (pvalid) {
-                        uint64_t slot = edge_base + (uint64_t)job_samples + s_local - 1;
-                        A.ekey[slot] = pc;
-                        A.eval[slot] = ((uint64_t)code[j] << 32) | ((uint64_t)(p0 + j - pp) << 1) | (uint64_t)A.pass;
-                    }
-                    pp = p0 + j;
-                    pc = code[j];
-                    pvalid = true;
-                    ++i;
+            for (uint32_t m = kept; m; m &= m - 1u) {
+                const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t cj = win.code(strand, kmask, j);
+                const uint32_t s_local = rank0 + i;
+                L.scode[s_local] = cj;
+                L.scnt[s_local] = (uint32_t)(cnt4 >> (4 * j)) & 15u;  // (0 without fast_counts: counted by the walk below)
+                L.srun[s_local] = 0;
+                if (pvalid) {
+                    const uint64_t slot = edge_base + (uint64_t)job_samples + s_local - 1;
+                    A.ekey[slot] = pc;
+                    A.eval[slot] = ((uint64_t)cj << 32) | ((uint64_t)(p0 + j - pp) << 1) | (uint64_t)A.pass;
                 }
+                pp = p0 + j;
+                pc = cj;
+                pvalid = true;
+                ++i;
             }
             int top = 63 - __clzll((long long)has);
             carry_pos = __shfl(last_pos, top, 64);
