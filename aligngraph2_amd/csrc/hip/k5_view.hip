@@ -360,12 +360,15 @@ __global__ void k_order_keys(const uint64_t *__restrict__ vpos, uint64_t n, uint
 __global__ void k_order_apply(const uint32_t *__restrict__ sorted_ctg, const uint64_t *__restrict__ sorted_val, uint64_t n, uint64_t n_zero, TravGraph G,
                               uint32_t slice, uint32_t slice_shift) {
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t x = sorted_val[u];
-        const uint32_t v = (uint32_t)x;
+        uint32_t v;
         if (slice == 0u) {
+            const uint64_t x = sorted_val[u];
+            v = (uint32_t)x;
             G.uold[u] = v;
             // (the first n_zero keys were overwritten by the second sort: their contig coordinate is 0)
             G.upos[u] = ((uint64_t)(u < n_zero ? 0u : sorted_ctg[u]) << 32) | (x >> 32);
+        } else {
+            v = G.uold[u];  // (what the first launch left: four bytes per vertex for the seven other slices instead of the eight of the sort record)
         }
         if (slice_shift >= 32u || (v >> slice_shift) == slice) {
             G.newid[v] = (uint32_t)u;
