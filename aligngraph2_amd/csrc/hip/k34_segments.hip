@@ -255,7 +255,7 @@ __global__ __launch_bounds__(SEG_TILE) void cluster_short(const uint32_t *__rest
                 atomicAdd(&S.cnt[P.s + (uint32_t)__builtin_ctzll((uint64_t)(M & L))], 1u);
             } else {
                 // sortWithCount: slot = rank by (ctg, ref) among the leaders (distinct keys)
-                for (uint32_t j = 0; j < P.len; ++j) rank += ((L >> j) & 1u) && S.val[P.s + j] < v;
+                for (uint32_t j = 0; j < P.len; ++j) rank += (uint32_t)((L >> j) & 1u) & (uint32_t)(S.val[P.s + j] < v);  // (no short circuit: see edges_short)
             }
         }
         __syncthreads();
@@ -487,11 +487,14 @@ __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restri
         const uint64_t v = S.val[t];
         bool kept = false;
         if (P.active) {
-            kept = true;
+            // (no short circuit: written as `kept = kept && ..` every turn waited for its own LDS read before it knew whether the
+            // lane goes on — one exposed round trip and a pair of exec-mask branches per record of the segment)
+            bool dead = false;
             for (uint32_t j = 0; j < P.len; ++j) {
                 const uint64_t u = S.val[P.s + j];
-                kept = kept && !((u >> 1) == (v >> 1) && (u < v || (u == v && j < P.o)));
+                dead |= ((u ^ v) < 2ull) & ((u < v) | ((u == v) & (j < P.o)));
             }
+            kept = !dead;
         }
         S.m[t] = kept ? (Mask)1 : (Mask)0;
         __syncthreads();
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(SEG_TILE) void edges_short(const uint32_t *__restri
             for (uint32_t j = 0; j < P.len; ++j) {
                 const bool kj = S.m[P.s + j] != 0;
                 p += kj;
-                rank += kj && S.val[P.s + j] < v;
+                rank += (uint32_t)kj & (uint32_t)(S.val[P.s + j] < v);
             }
             if (kept) {
                 val[base + P.s + rank] = v;
