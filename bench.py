@@ -241,7 +241,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)  # (two: the first process on a fresh box still settles in its second block — 150 ms once in the
+                                                         # successor stage, profiles/r06_first_process_probe.txt; the driver warms up five)
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--read-span", type=int, default=10_000)
     ap.add_argument("--ref-len", type=int, default=50_000_000)
@@ -577,6 +578,7 @@ def main():
                 # the traversal is a latency-bound serial chain (no HBM roofline): what bounds it is the longest
                 # chain of dependent walk steps and the time per step, reported here instead
                 "ms_successor_records": float(np.mean(succ_ms[-args.steps:])) if succ_ms else ts.ms_successors, "ms_walk": ts.ms_walk,
+                "ms_successor_records_per_step": [round(x, 1) for x in succ_ms[-args.steps:]],
                 "walk_jobs": int(ts.walk_jobs), "walk_rounds_longest_chain": int(ts.walk_rounds),
                 "walk_path_vertices": int(ts.walk_steps), "walk_classifications": int(ts.walk_classifications),
                 "kmer_counter_on_device": kc,
