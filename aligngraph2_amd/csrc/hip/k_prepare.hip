@@ -273,7 +273,7 @@ struct CtgMapJob {  // one listed contig -> reference alignment of a selected co
     uint64_t chunk0;        // first entry of this job in the chunk prefix array
     uint32_t n_cols, len;   // alignment columns, contig length
     uint32_t ref_single_base;
-    uint32_t ctg, rank, pad;  // contig; position in the contig's list
+    uint32_t ctg, rank, alone;  // contig; position in the contig's list; 1: the contig's ONLY listed alignment (no base of it is touched twice)
 };
 constexpr uint32_t MAP_CHUNK = 1024;  // columns per chunk: 64 lanes x 16
 
@@ -339,7 +339,12 @@ __global__ __launch_bounds__(64) void ctgmap_walk(const CtgMapJob *__restrict__ 
         const uint64_t ref_cur = J.ref_begin + rex + __popc(rb & below);
         const uint64_t b = J.cb + k;
         if (k < J.span && b < J.len) {
-            if (!FILL) {
+            if (J.alone) {
+                // (the contig's only alignment: every base gets this one entry — a plain store where the general case pays a global
+                // atomic per column, 55 M of them at BASELINE configs[1], and a cursor per base in the fill)
+                if (!FILL) cnt[J.map_off + b] = 1u;
+                else ent[ent_off[J.map_off + b]] = (uint32_t)((uint64_t)J.ref_single_base + ref_cur);
+            } else if (!FILL) {
                 if (atomicAdd(&cnt[J.map_off + b], 1u) >= 1u) multi[J.ctg] = 1u;
             } else {
                 const uint32_t at = cnt[J.map_off + b];
@@ -587,6 +592,7 @@ extern "C" int pag_prepare(pag_graph *g, const pag_raw_input *raw, pag_build_inp
             std::sort(l.begin(), l.end(), [](const ListEntry &a, const ListEntry &b) { return a.score > b.score; });
             if (!raw->ctg_selected[c]) continue;
             uint32_t rank = 0;
+            const size_t first_job = jobs.size();
             for (const ListEntry &e : l) {
                 const pag_raw_aln &r = raw->ctg_to_ref.rec[e.rec];
                 if (!raw->ref_accepted[r.target]) continue;
@@ -616,6 +622,8 @@ extern "C" int pag_prepare(pag_graph *g, const pag_raw_input *raw, pag_build_inp
                 jobs.push_back(J);
                 max_rank = std::max(max_rank, J.rank + 1);
             }
+            // (rank counts every listed alignment of the contig, also those without columns: alone = it was the only one)
+            if (rank == 1 && jobs.size() == first_job + 1) jobs.back().alone = 1u;
         }
         chunk_first.push_back(n_chunks);
     }
