@@ -156,8 +156,24 @@ __global__ void prep_pass1(const pag_raw_aln *__restrict__ rec, const uint32_t *
         if (ctgBegin + a.n_radv >= ctgLen) {
             uint64_t k = 0, t = ctgBegin, firstBad = nValid;
             bool found = false;
-            for (uint64_t jj = 0; jj < a.n_cols && !found; ++jj) {
-                const uint32_t cls = d_col_class(diff, a.diff_off, walkBack ? a.n_cols - jj - 1 : jj);
+            for (uint64_t jj = 0; jj < a.n_cols && !found;) {
+                // a whole word of sixteen columns at a time while the contig's end stays out of reach (a column at a time these few
+                // records — alignments that overhang a contig's end — were the kernel: one thread walking ten thousand columns,
+                // a dependent global load each; the classes' totals of a word do not depend on the order inside it)
+                const uint64_t sc = walkBack ? a.n_cols - jj - 1 : jj;  // storage column of walk column jj
+                const bool word_start = walkBack ? (sc & 15u) == 15u : (sc & 15u) == 0u;
+                if (word_start && jj + 16 <= a.n_cols) {
+                    const uint32_t w = diff[a.diff_off + (sc >> 4)];
+                    const uint32_t qd = w & 0x55555555u, rd = (w >> 1) & 0x55555555u;
+                    const uint32_t n1 = (uint32_t)__popc(qd & ~rd), n2 = (uint32_t)__popc(rd & ~qd);  // classes 01 (target only) and 10 (query only)
+                    if (t + (16u - n2) < ctgLen) {  // every column of the word sees a target position before the end
+                        k += 16u - n1;
+                        t += 16u - n2;
+                        jj += 16;
+                        continue;
+                    }
+                }
+                const uint32_t cls = d_col_class(diff, a.diff_off, sc);
                 if (cls == 1u) {
                     ++t;
                 } else {
@@ -168,6 +184,7 @@ __global__ void prep_pass1(const pag_raw_aln *__restrict__ rec, const uint32_t *
                     ++k;
                     if (cls != 2u) ++t;
                 }
+                ++jj;
             }
             nValid = nValid < firstBad ? nValid : firstBad;
         }
